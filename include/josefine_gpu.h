@@ -1,0 +1,327 @@
+/*
+ * josefine_gpu.h — C ABI of the MI355X batched Chained-Raft engine.
+ *
+ * This is the drop-in boundary for the hot path of tychedelia/josefine's
+ * `src/raft` state machine.  One engine hosts N independent
+ * Raft node instances ("groups", index g) and applies batches of
+ * `Command`s to them with exactly the per-instance semantics of the reference's
+ *
+ *     trait Apply { fn apply(self, cmd: Command) -> Result<RaftHandle>; }
+ *                                               (src/raft/mod.rs:483-489)
+ *
+ * Plain pointers and sizes only: this header is what a Rust `extern "C"`
+ * block / bindgen would bind (see INTEGRATION.md for the adapter that
+ * implements `Apply` on top of it).  All paths cited below are relative to the
+ * reference checkout.
+ *
+ * Conventions
+ *   - every entry point returns 0 (JG_OK) or a negative JG_E* status;
+ *     `jg_last_error()` returns a thread-local description of the last failure;
+ *   - reference panics / `Err` returns never abort a batch: they are recorded as
+ *     a sticky per-group fault code (`JG_FIELD_FAULT`), after which the group
+ *     ignores commands until `JG_CMD_RESTART` (the process would be dead);
+ *   - BlockId is the reference's 8-byte big-endian id (src/raft/chain.rs:29-36,
+ *     63-67) carried as a native uint64_t (same ordering);
+ *   - one engine is externally synchronised (one caller thread at a time),
+ *     exactly like the by-value `RaftHandle` (src/raft/mod.rs:471-479).
+ */
+#ifndef JOSEFINE_GPU_H
+#define JOSEFINE_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JG_ABI_VERSION 1u
+#define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
+#define JG_CHAIN_WINDOW 8u  /* explicit (id,next) entries per group besides the dense run  */
+#define JG_MAX_INFLIGHT 5u  /* src/raft/progress.rs:117                                    */
+#define JG_NO_ACK UINT64_MAX /* dense ack column: "no AppendResponse from this replica"    */
+
+/* ---- status codes -------------------------------------------------------- */
+enum {
+  JG_OK = 0,
+  JG_EINVAL = -1,   /* bad argument / config (cf. RaftConfig::validate, src/raft/config.rs:60-84) */
+  JG_ENOMEM = -2,
+  JG_EDEVICE = -3,  /* HIP runtime error; no CPU fallback exists                    */
+  JG_ECAPACITY = -4 /* caller's output buffer too small; nothing was consumed       */
+};
+
+/* ---- roles: RaftHandle variants, src/raft/mod.rs:417-425 ------------------ */
+enum { JG_ROLE_FOLLOWER = 0, JG_ROLE_CANDIDATE = 1, JG_ROLE_LEADER = 2 };
+
+/* ---- Command kinds: enum Command, src/raft/mod.rs:160-227 ------------------
+ * Column use per kind (unused columns are ignored):
+ *   kind              from          term   id            aux        flag
+ *   TICK              -             -      -             -          -
+ *   PROPOSE           -             -      -             -          -
+ *   VOTE_REQUEST      candidate_id  term   head          last_term  -
+ *   VOTE_RESPONSE     from          term   -             -          granted
+ *   APPEND_ENTRIES    leader_id     term   first block*  n_blocks   -
+ *   APPEND_RESPONSE   node_id       term   head          -          success
+ *   HEARTBEAT         leader_id     term   commit        -          -
+ *   HEARTBEAT_RESPONSE -            -      commit        -          has_committed
+ *   TIMEOUT           -             -      -             -          -
+ *   NOOP              -             -      -             -          -
+ *   CLIENT_REQUEST    -             -      request token -          -
+ *   CLIENT_RESPONSE   -             -      request token -          -
+ *   RESTART (engine)  -             -      -             -          -
+ * (*) index of the first of `aux` consecutive entries in the batch's
+ *     blk_id/blk_next side arrays (Vec<Block>, payload stays on the host).
+ * RESTART is not a reference Command: it restates process restart, i.e.
+ * `Raft::<Follower>::new` + `Chain::new` on the persisted tree
+ * (src/raft/follower.rs:68-95, src/raft/chain.rs:117-137), and clears the fault.
+ */
+enum {
+  JG_CMD_TICK = 0,
+  JG_CMD_PROPOSE = 1,
+  JG_CMD_VOTE_REQUEST = 2,
+  JG_CMD_VOTE_RESPONSE = 3,
+  JG_CMD_APPEND_ENTRIES = 4,
+  JG_CMD_APPEND_RESPONSE = 5,
+  JG_CMD_HEARTBEAT = 6,
+  JG_CMD_HEARTBEAT_RESPONSE = 7,
+  JG_CMD_TIMEOUT = 8,
+  JG_CMD_NOOP = 9,
+  JG_CMD_CLIENT_REQUEST = 10,
+  JG_CMD_CLIENT_RESPONSE = 11,
+  JG_CMD_RESTART = 12,
+  JG_CMD__COUNT = 13
+};
+
+/* ---- Address, src/raft/rpc.rs:5-14 ---------------------------------------- */
+enum { JG_TO_PEERS = 0, JG_TO_PEER = 1, JG_TO_LOCAL = 2, JG_TO_CLIENT = 3, JG_TO_QUEUE = 4 };
+
+/* ---- client request queue rows ----------------------------------------------
+ * Follower / Candidate queue client requests they cannot forward yet
+ * (src/raft/follower.rs:22,258-270; candidate.rs:20,190-193).  The request
+ * payloads stay with the host adapter; the engine keeps only the queue length
+ * and tells the adapter what to do with its mirror through CLIENT_REQUEST rows:
+ *   to_kind JG_TO_QUEUE, flag 0              : push request `id` onto the group's queue
+ *   to_kind JG_TO_PEER,  flag JG_QUEUE_FLUSH : send the `aux` queued requests, in order, to
+ *                                              to_id, then clear the queue (follower.rs:190-197)
+ *   to_kind JG_TO_QUEUE, flag JG_QUEUE_DROP  : the `aux` queued requests are dropped by a
+ *                                              role change (follower.rs:295, candidate.rs:216-238)
+ *   to_kind JG_TO_PEER,  flag 0              : forward request `id` now (follower.rs:262-265) */
+enum { JG_QUEUE_FLUSH = 1, JG_QUEUE_DROP = 2 };
+
+/* ---- fault codes ------------------------------------------------------------
+ * 1..63: the reference would panic or return Err at the cited line.
+ * 128.. : engine-domain limits (inputs outside what the device layout can
+ *         represent); never silently wrong, always loud. */
+enum {
+  JG_FAULT_NONE = 0,
+  JG_FAULT_LEADER_TERM_UNIMPLEMENTED = 1, /* leader.rs:33-35 via leader.rs:200-208, mod.rs:360-365 */
+  JG_FAULT_APPEND_ID_NOT_ABOVE_HEAD = 2,  /* chain.rs:163 assert!(id > self.head)                  */
+  JG_FAULT_PROGRESS_UNKNOWN_NODE = 3,     /* progress.rs:43 expect("the node does not exist")      */
+  JG_FAULT_COMMIT_MISSING_BLOCK = 4,      /* chain.rs:197-202 panic!("")                           */
+  JG_FAULT_EXTEND_MISSING_PARENT = 5,     /* chain.rs:180-185 Err via follower.rs:159              */
+  JG_FAULT_FOLLOWER_STALE_LEADER = 6,     /* follower.rs:147-154 assert!                           */
+  JG_FAULT_CANDIDATE_TICK_ELECTED = 7,    /* candidate.rs:64 panic!("this should never happen")    */
+  JG_FAULT_RANGE_HIT_COMMIT_KEY = 8,      /* chain.rs:198 + 219-226 via leader.rs:135,152-157 (Q9) */
+  JG_FAULT_ENGINE_WINDOW_OVERFLOW = 128,  /* > JG_CHAIN_WINDOW irregular blocks in one group       */
+  JG_FAULT_ENGINE_FOREIGN_VOTER = 129,    /* VoteResponse.from not in the configured membership    */
+  JG_FAULT_ENGINE_TOO_MANY_BLOCKS = 130,  /* AppendEntries with more than 2*JG_MAX_INFLIGHT blocks */
+  JG_FAULT_ENGINE_DENSE_NONLEADER = 131   /* dense tick asked a non-leader group to append         */
+};
+
+/* ---- engine configuration ---------------------------------------------------
+ * Restates the parts of RaftConfig that feed L1 (src/raft/config.rs:14-41,
+ * defaults 87-111) for N instances at once.  `node_ids[r]` is the NodeId of
+ * replica slot r; an instance's own slot is `self_slot[g]` (default 0) and its
+ * `config.nodes` are the other slots in ascending slot order. */
+typedef struct jg_config {
+  uint32_t abi_version;              /* JG_ABI_VERSION                                        */
+  uint32_t n_groups;                 /* G                                                     */
+  uint32_t n_replicas;               /* R = config.nodes.len()+1, 1..JG_MAX_REPLICAS          */
+  uint32_t node_ids[JG_MAX_REPLICAS];/* nonzero, distinct (config.rs:64-66)                   */
+  int32_t device_id;                 /* HIP device ordinal                                    */
+  uint32_t heartbeat_timeout_ms;     /* config.rs:104 (100)                                   */
+  uint32_t election_timeout_min_ms;  /* mod.rs:318 (500)                                      */
+  uint32_t election_timeout_max_ms;  /* mod.rs:319 (1000)                                     */
+  uint64_t seed;                     /* replaces thread_rng (follower.rs:105); see DESIGN.md  */
+  uint64_t group_base;               /* global id of local group 0 (sharding; keys the RNG)   */
+  uint32_t flags;                    /* JG_CFG_*                                              */
+  uint32_t reserved;
+} jg_config;
+
+enum {
+  /* keep the "commit" key out of the block keyspace, i.e. do NOT reproduce Q9
+   * (SURVEY.md §7.3): unbounded ranges then simply end at the last block. */
+  JG_CFG_SEPARATE_COMMIT_KEY = 1u
+};
+
+/* ---- SoA command batch (host memory), SURVEY.md §8(a) a18 -------------------- */
+typedef struct jg_cmd_batch {
+  size_t n;               /* number of command rows                                       */
+  const uint8_t* kind;    /* [n] JG_CMD_*                                                 */
+  const uint32_t* group;  /* [n] local group index; rows of one group apply in row order  */
+  const uint32_t* from;   /* [n] NodeId                                                   */
+  const uint64_t* term;   /* [n]                                                          */
+  const uint64_t* id;     /* [n] BlockId / token / side-array index                       */
+  const uint64_t* aux;    /* [n]                                                          */
+  const uint8_t* flag;    /* [n]                                                          */
+  size_t n_blocks;        /* entries in the side arrays                                   */
+  const uint64_t* blk_id; /* [n_blocks] Block.id   (chain.rs:86-91)                       */
+  const uint64_t* blk_next;/*[n_blocks] Block.next                                        */
+} jg_cmd_batch;
+
+/* ---- outbound Message rows: what the reference pushes on rpc_tx -----------
+ * (src/raft/mod.rs:337-340,390-400; src/raft/rpc.rs:17-27).  `kind` is the
+ * Command kind; columns as in the table above, with `from` = sender NodeId.
+ * APPEND_ENTRIES rows (leader.rs:124-174) carry id = range start key
+ * (progress.head) and aux = number of blocks: the payload is the next `aux`
+ * stored blocks after skipping the first item of `range(id..)`. */
+typedef struct jg_msg_row {
+  uint32_t group;
+  uint8_t kind;
+  uint8_t to_kind; /* JG_TO_* */
+  uint8_t flag;
+  uint8_t pad;
+  uint32_t to_id;  /* NodeId when to_kind == JG_TO_PEER */
+  uint32_t from;
+  uint64_t term;
+  uint64_t id;
+  uint64_t aux;
+} jg_msg_row;
+
+/* ---- FSM instruction rows: what the reference pushes on fsm_tx -------------
+ * (src/raft/fsm.rs:20-29).  Apply instructions are run-length encoded as key
+ * ranges; the host expands them against its block store in key order:
+ *   JG_FSM_APPLY_LEADER   : range(a..=b).skip(1)   (leader.rs:93)
+ *   JG_FSM_APPLY_FOLLOWER : range(a..b)            (follower.rs:204, half-open)
+ *   JG_FSM_NOTIFY         : Notify{block_id=a, id=b} (leader.rs:184-188) */
+enum { JG_FSM_APPLY_LEADER = 0, JG_FSM_APPLY_FOLLOWER = 1, JG_FSM_NOTIFY = 2 };
+typedef struct jg_fsm_row {
+  uint32_t group;
+  uint8_t kind;
+  uint8_t pad[3];
+  uint64_t a;
+  uint64_t b;
+} jg_fsm_row;
+
+typedef struct jg_fault_row {
+  uint32_t group;
+  uint32_t code; /* JG_FAULT_* */
+} jg_fault_row;
+
+/* ---- state columns readable through jg_read_state ------------------------- */
+enum {
+  JG_FIELD_TERM = 0,        /* u64  State.current_term          mod.rs:277            */
+  JG_FIELD_VOTED_FOR = 1,   /* u32  State.voted_for or 0        mod.rs:279            */
+  JG_FIELD_HAS_VOTED = 2,   /* u8   voted_for.is_some()                                */
+  JG_FIELD_ROLE = 3,        /* u8   JG_ROLE_*                   mod.rs:417-425        */
+  JG_FIELD_COMMIT = 4,      /* u64  Chain.commit                chain.rs:102          */
+  JG_FIELD_HEAD = 5,        /* u64  Chain.head                  chain.rs:103          */
+  JG_FIELD_ID_GEN = 6,      /* u64  Chain.id_gen                chain.rs:101          */
+  JG_FIELD_MATCH = 7,       /* u64  Progress.head of `replica`  progress.rs:124       */
+  JG_FIELD_REPL_STATE = 8,  /* u8   bit r = Replicate (else Probe) progress.rs:62-66  */
+  JG_FIELD_VOTE_SEEN = 9,   /* u8   bit r = votes.contains(r)   election.rs:8         */
+  JG_FIELD_VOTE_GRANTED = 10,/*u8   bit r = votes[r] == true                           */
+  JG_FIELD_FAULT = 11,      /* u8   JG_FAULT_*                                         */
+  JG_FIELD_LEADER_ID = 12,  /* u32  Follower.leader_id or 0     follower.rs:20        */
+  JG_FIELD_HAS_LEADER = 13, /* u8                                                      */
+  JG_FIELD_ELECTION_TIME = 14,   /* u64 ms, State.election_time       mod.rs:281      */
+  JG_FIELD_ELECTION_TIMEOUT = 15,/* u32 ms, State.election_timeout    mod.rs:283      */
+  JG_FIELD_HEARTBEAT_TIME = 16,  /* u64 ms, Leader.heartbeat_time     leader.rs:27    */
+  JG_FIELD_QUEUED_REQS = 17,     /* u32 queued_reqs.len()  follower.rs:22, candidate.rs:20 */
+  JG_FIELD_SELF_SLOT = 18,  /* u8                                                      */
+  JG_FIELD__COUNT = 19
+};
+
+typedef struct jg_engine jg_engine;
+
+/* RaftHandle::new for every group (src/raft/mod.rs:428-435 -> follower.rs:68-95):
+ * Follower, State::default(), fresh Chain (genesis block 0), election timer armed
+ * at now = 0.  Fails with JG_EDEVICE when no gfx950 device / HIP runtime is usable. */
+int jg_engine_create(const jg_config* cfg, jg_engine** out);
+void jg_engine_destroy(jg_engine* e);
+
+/* Per-group own replica slot (default: all 0).  Only legal before the first step. */
+int jg_set_self_slots(jg_engine* e, const uint8_t* slots /* [G] host */);
+
+/* Queue a batch of commands (host memory, borrowed for the call).  Rows may be in
+ * any group order; rows of the same group are applied in row order, after rows
+ * queued by earlier jg_submit calls. */
+int jg_submit(jg_engine* e, const jg_cmd_batch* batch);
+
+/* Apply everything queued since the last step: for each group, `apply(cmd)` in
+ * stream order (src/raft/mod.rs:471-479).  `now_ms` is the logical clock that
+ * replaces Instant::now() (mod.rs:352-357, follower.rs:110-113, leader.rs:78-84).
+ * Outputs are appended to the message / fsm queues.  Asynchronous on the
+ * engine's stream; drains and reads synchronise. */
+int jg_step(jg_engine* e, uint64_t now_ms);
+
+/* Dense steady-state leader tick (the HBM-roofline path).
+ * `acks` is an [R][G] column-major array (replica-major: acks[r*G+g]):
+ *   r != self_slot[g]: head of an AppendResponse{node_id: node_ids[r], head} or JG_NO_ACK;
+ *   r == self_slot[g]: number of ClientRequests to append this tick.
+ * Per group, in this order: the appends (leader.rs:177-197, each with its
+ * self-ack), then the acks in ascending slot order (leader.rs:211-219 ->
+ * progress.rs:42-60 -> leader.rs:87-99).  Equivalent to submitting those
+ * commands through jg_submit/jg_step, except that the FSM instructions are not
+ * queued: they are the per-group head / commit deltas (Notify for ids
+ * (head_before, head_after], Apply for keys (commit_before, commit_after]), which
+ * the caller reads back with jg_read_state.  Non-leader groups ignore acks exactly as the
+ * reference does (follower.rs:62, candidate.rs:194); asking one to append is a
+ * precondition violation of the dense path (client proxying needs the message
+ * queue of jg_step) and raises JG_FAULT_ENGINE_DENSE_NONLEADER. */
+int jg_step_dense_acks(jg_engine* e, const uint64_t* acks_host);
+int jg_step_dense_acks_device(jg_engine* e, const uint64_t* acks_dev);
+
+/* Batched Chain::compact (src/raft/chain.rs:239-253) as a pure function over
+ * explicit (id,next) trees: tree t owns entries [off[t], off[t+1]); ids within a
+ * tree need not be sorted.  removed[i] = 1 iff the walk removes entry i. */
+int jg_chain_compact(jg_engine* e, size_t n_trees, const uint64_t* off /*[n_trees+1]*/,
+                     const uint64_t* ids, const uint64_t* nexts, const uint64_t* commits /*[n_trees]*/,
+                     uint8_t* removed /* [off[n_trees]] out */);
+
+int jg_sync(jg_engine* e);
+
+/* Drains.  Each returns the queued rows (per-group emission order identical to the
+ * reference; groups in ascending order within one step) and clears the queue.
+ * With out == NULL only *n is set. */
+int jg_drain_messages(jg_engine* e, jg_msg_row* out, size_t cap, size_t* n);
+int jg_drain_applies(jg_engine* e, jg_fsm_row* out, size_t cap, size_t* n);
+int jg_drain_faults(jg_engine* e, jg_fault_row* out, size_t cap, size_t* n);
+
+/* Copy one state column for groups [g0, g0+n) to host memory (element type per
+ * JG_FIELD_* above).  `replica` selects the slot for JG_FIELD_MATCH. */
+int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t g0, uint32_t n);
+
+/* Counters since creation: [0] commands applied, [1] quorum decisions
+ * (Leader::commit evaluations + election_status evaluations),
+ * [2] group-steps of the dense path, [3] kernel launches. */
+int jg_get_counters(jg_engine* e, uint64_t out[4]);
+
+/* ---- device-resident helpers for benchmarks ---------------------------------
+ * The engine owns its stream; these let a caller keep inputs in HBM and time
+ * the stream with HIP events without linking the HIP runtime itself. */
+int jg_device_alloc(jg_engine* e, size_t bytes, void** dev_ptr);
+int jg_device_free(jg_engine* e, void* dev_ptr);
+int jg_device_upload(jg_engine* e, void* dev_dst, const void* host_src, size_t bytes);
+int jg_device_download(jg_engine* e, void* host_dst, const void* dev_src, size_t bytes);
+int jg_timer_start(jg_engine* e);            /* hipEventRecord on the engine stream */
+int jg_timer_stop(jg_engine* e, float* ms);  /* record + synchronize + elapsed      */
+
+/* Synthetic AppendEntries-ack stream generator,
+ * counter-based so any shard regenerates its slice: fills one dense [R][G] tick
+ * on the device from (seed, tick, global group, replica) and the generator's own
+ * follower model kept in `sim` ([R][G] u64, zero-initialised by the caller).
+ * mode 0: steady state (#3/#4) — 1 append per tick, every follower acks the
+ *         leader head of the previous tick;
+ * mode 1: ragged (#2) — a in {0,1,2} appends, follower ack = min(leader_head,
+ *         prev_ack + U{0..MAX_INFLIGHT}), 5 % dropped, 5 % stale duplicates. */
+int jg_synth_fill_acks_device(jg_engine* e, uint32_t mode, uint64_t tick, uint64_t* sim_dev,
+                              uint64_t* acks_dev);
+
+const char* jg_last_error(void);
+uint32_t jg_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JOSEFINE_GPU_H */

@@ -1,0 +1,359 @@
+"""Host-side mirror of josefine's Raft driver surface over the C ABI.
+
+The reference drives one Raft group through
+
+    trait Apply { fn apply(self, cmd: Command) -> Result<RaftHandle>; }
+                                        (src/raft/mod.rs:483-489)
+
+with `Command` (src/raft/mod.rs:160-227) as the input vocabulary and two
+output channels, `rpc_tx` / `fsm_tx` (src/raft/mod.rs:337-340).  `BatchedRaft`
+is the same surface for N groups at once: `Command` keeps the reference's
+variant and field names, `RaftHandle` keeps `apply` / `is_leader` / … , and the
+channels become `drain_messages()` / `drain_applies()`.
+
+There is no CPU implementation behind this class: it binds
+`josefine_amd/csrc/libjosefine_gpu.so` (HIP, gfx950) and raises if that
+library is missing or no device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _capi as capi
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libjosefine_gpu.so")
+_device_api: Optional[capi.Api] = None
+
+
+class EngineError(RuntimeError):
+    """A C-ABI call returned a negative status (anyhow::Error in the reference)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"josefine engine error {status}: {message}")
+        self.status = status
+
+
+def device_api() -> capi.Api:
+    """Load the HIP engine library; never falls back to anything else."""
+    global _device_api
+    if _device_api is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _device_api = capi.Api(_LIB_PATH, "jg_")
+    return _device_api
+
+
+@dataclass
+class Command:
+    """enum Command (src/raft/mod.rs:160-227), flattened to the batch columns."""
+
+    kind: int
+    from_: int = 0
+    term: int = 0
+    id: int = 0
+    aux: int = 0
+    flag: int = 0
+    blocks: List[Tuple[int, int]] = field(default_factory=list)  # Vec<Block> as (id, next)
+
+    # constructors named after the reference variants and their fields
+    @staticmethod
+    def Tick() -> "Command":
+        return Command(capi.CMD_TICK)
+
+    @staticmethod
+    def Propose() -> "Command":
+        return Command(capi.CMD_PROPOSE)
+
+    @staticmethod
+    def VoteRequest(term: int, candidate_id: int, last_term: int, head: int) -> "Command":
+        return Command(capi.CMD_VOTE_REQUEST, from_=candidate_id, term=term, id=head, aux=last_term)
+
+    @staticmethod
+    def VoteResponse(term: int, from_: int, granted: bool) -> "Command":
+        return Command(capi.CMD_VOTE_RESPONSE, from_=from_, term=term, flag=int(granted))
+
+    @staticmethod
+    def AppendEntries(term: int, leader_id: int, blocks: Sequence[Tuple[int, int]]) -> "Command":
+        return Command(capi.CMD_APPEND_ENTRIES, from_=leader_id, term=term, blocks=list(blocks))
+
+    @staticmethod
+    def AppendResponse(node_id: int, term: int, head: int, success: bool = True) -> "Command":
+        return Command(capi.CMD_APPEND_RESPONSE, from_=node_id, term=term, id=head, flag=int(success))
+
+    @staticmethod
+    def Heartbeat(term: int, commit: int, leader_id: int) -> "Command":
+        return Command(capi.CMD_HEARTBEAT, from_=leader_id, term=term, id=commit)
+
+    @staticmethod
+    def HeartbeatResponse(commit: int, has_committed: bool) -> "Command":
+        return Command(capi.CMD_HEARTBEAT_RESPONSE, id=commit, flag=int(has_committed))
+
+    @staticmethod
+    def Timeout() -> "Command":
+        return Command(capi.CMD_TIMEOUT)
+
+    @staticmethod
+    def Noop() -> "Command":
+        return Command(capi.CMD_NOOP)
+
+    @staticmethod
+    def ClientRequest(id: int = 0) -> "Command":
+        return Command(capi.CMD_CLIENT_REQUEST, id=id)
+
+    @staticmethod
+    def ClientResponse(id: int = 0) -> "Command":
+        return Command(capi.CMD_CLIENT_RESPONSE, id=id)
+
+    @staticmethod
+    def Restart() -> "Command":
+        """Engine op: process restart (Raft::new + Chain::new on the persisted tree)."""
+        return Command(capi.CMD_RESTART)
+
+
+class BatchedRaft:
+    """N independent Raft node instances behind one engine handle."""
+
+    def __init__(self, n_groups: int, n_replicas: int = 1, node_ids: Optional[Sequence[int]] = None,
+                 self_slots: Optional[Sequence[int]] = None, seed: int = 0, device_id: int = 0,
+                 group_base: int = 0, flags: int = 0, heartbeat_timeout_ms: int = 100,
+                 election_timeout_ms: Tuple[int, int] = (500, 1000), api: Optional[capi.Api] = None):
+        self.api = api if api is not None else device_api()
+        self.G, self.R = int(n_groups), int(n_replicas)
+        if node_ids is None:
+            node_ids = list(range(1, self.R + 1))  # examples/multi-node/node-*.toml: ids 1..R
+        cfg = capi.Config()
+        cfg.abi_version = capi.ABI_VERSION
+        cfg.n_groups = self.G
+        cfg.n_replicas = self.R
+        for r, nid in enumerate(node_ids):
+            cfg.node_ids[r] = int(nid)
+        cfg.device_id = device_id
+        cfg.heartbeat_timeout_ms = heartbeat_timeout_ms
+        cfg.election_timeout_min_ms, cfg.election_timeout_max_ms = election_timeout_ms
+        cfg.seed = seed
+        cfg.group_base = group_base
+        cfg.flags = flags
+        self.node_ids = [int(x) for x in node_ids]
+        self.cfg = cfg
+        h = C.c_void_p()
+        self._check(self.api.engine_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._pending: List[Tuple[int, Command]] = []
+        if self_slots is not None:
+            s = np.ascontiguousarray(self_slots, dtype=np.uint8)
+            assert s.shape == (self.G,)
+            self._check(self.api.set_self_slots(self._h, s.ctypes.data))
+
+    # -- lifecycle -----------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.api.engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, status: int) -> None:
+        if status != capi.OK:
+            raise EngineError(status, self.api.error())
+
+    # -- input ---------------------------------------------------------------
+    def submit(self, group: int, cmd: Command) -> None:
+        """Queue `cmd` for `group`; applied at the next step() in submit order."""
+        self._pending.append((int(group), cmd))
+
+    def submit_columns(self, kind, group, from_=None, term=None, id=None, aux=None, flag=None,
+                       blk_id=None, blk_next=None) -> None:
+        """Queue a whole SoA batch (numpy columns) — jg_submit as is."""
+        self._flush_pending()
+        n = len(kind)
+
+        def col(x, dt):
+            if x is None:
+                return np.zeros(n, dtype=dt)
+            return np.ascontiguousarray(x, dtype=dt)
+
+        cols = [col(kind, np.uint8), col(group, np.uint32), col(from_, np.uint32), col(term, np.uint64),
+                col(id, np.uint64), col(aux, np.uint64), col(flag, np.uint8)]
+        bi = np.ascontiguousarray(blk_id if blk_id is not None else [], dtype=np.uint64)
+        bn = np.ascontiguousarray(blk_next if blk_next is not None else [], dtype=np.uint64)
+        b = capi.CmdBatch()
+        b.n = n
+        (b.kind, b.group, b.from_, b.term, b.id, b.aux, b.flag) = [c.ctypes.data for c in cols]
+        b.n_blocks = len(bi)
+        b.blk_id, b.blk_next = bi.ctypes.data, bn.ctypes.data
+        self._check(self.api.submit(self._h, C.byref(b)))
+
+    def _flush_pending(self) -> None:
+        if not self._pending:
+            return
+        pend, self._pending = self._pending, []
+        n = len(pend)
+        kind = np.zeros(n, np.uint8)
+        group = np.zeros(n, np.uint32)
+        from_ = np.zeros(n, np.uint32)
+        term = np.zeros(n, np.uint64)
+        id_ = np.zeros(n, np.uint64)
+        aux = np.zeros(n, np.uint64)
+        flag = np.zeros(n, np.uint8)
+        bi: List[int] = []
+        bn: List[int] = []
+        for i, (g, c) in enumerate(pend):
+            kind[i], group[i], from_[i], term[i], flag[i] = c.kind, g, c.from_, c.term, c.flag
+            if c.kind == capi.CMD_APPEND_ENTRIES:
+                id_[i], aux[i] = len(bi), len(c.blocks)
+                for (b_id, b_next) in c.blocks:
+                    bi.append(b_id)
+                    bn.append(b_next)
+            else:
+                id_[i], aux[i] = c.id, c.aux
+        self.submit_columns(kind, group, from_, term, id_, aux, flag, bi, bn)
+
+    def step(self, now_ms: int = 0) -> None:
+        """Apply everything submitted, per group in stream order (Apply::apply)."""
+        self._flush_pending()
+        self._check(self.api.step(self._h, int(now_ms)))
+
+    def apply(self, group: int, cmd: Command, now_ms: int = 0) -> "RaftHandle":
+        """RaftHandle::apply for one group: submit + step."""
+        self.submit(group, cmd)
+        self.step(now_ms)
+        return RaftHandle(self, group)
+
+    def apply_all(self, cmd: Command, now_ms: int = 0) -> None:
+        """Apply the same command to every group."""
+        n = self.G
+        self.submit_columns(np.full(n, cmd.kind, np.uint8), np.arange(n, dtype=np.uint32),
+                            np.full(n, cmd.from_, np.uint32), np.full(n, cmd.term, np.uint64),
+                            np.full(n, cmd.id, np.uint64), np.full(n, cmd.aux, np.uint64),
+                            np.full(n, cmd.flag, np.uint8))
+        self.step(now_ms)
+
+    def step_dense_acks(self, acks: np.ndarray) -> None:
+        """Dense leader tick from a host [R, G] uint64 array (jg_step_dense_acks)."""
+        self._flush_pending()
+        a = np.ascontiguousarray(acks, dtype=np.uint64)
+        assert a.shape == (self.R, self.G), a.shape
+        self._check(self.api.step_dense_acks(self._h, a.ctypes.data))
+
+    # -- output --------------------------------------------------------------
+    def _drain(self, fn, dtype) -> np.ndarray:
+        n = C.c_size_t(0)
+        self._check(fn(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=dtype)
+        if n.value:
+            self._check(fn(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def drain_messages(self) -> np.ndarray:
+        """Everything the groups pushed on rpc_tx since the last drain."""
+        return self._drain(self.api.drain_messages, capi.MSG_DTYPE)
+
+    def drain_applies(self) -> np.ndarray:
+        """Everything the groups pushed on fsm_tx since the last drain."""
+        return self._drain(self.api.drain_applies, capi.FSM_DTYPE)
+
+    def drain_faults(self) -> np.ndarray:
+        return self._drain(self.api.drain_faults, capi.FAULT_DTYPE)
+
+    def read(self, field_name: str, replica: int = 0, g0: int = 0, n: Optional[int] = None) -> np.ndarray:
+        fld = capi.FIELD_NAMES[field_name]
+        n = self.G - g0 if n is None else n
+        out = np.zeros(n, dtype=capi.FIELD_DTYPES[fld])
+        if n:
+            self._check(self.api.read_state(self._h, fld, replica, out.ctypes.data, g0, n))
+        return out
+
+    def counters(self) -> dict:
+        arr = (C.c_uint64 * 4)()
+        self._check(self.api.get_counters(self._h, C.byref(arr)))
+        return {"commands": arr[0], "decisions": arr[1], "dense_group_steps": arr[2], "launches": arr[3]}
+
+    def snapshot(self) -> dict:
+        """All readable columns (used by the parity tests)."""
+        snap = {}
+        for name in capi.FIELD_NAMES:
+            if name == "match":
+                snap[name] = np.stack([self.read("match", r) for r in range(self.R)])
+            else:
+                snap[name] = self.read(name)
+        return snap
+
+    def chain_compact(self, trees: Iterable[Tuple[Sequence[Tuple[int, int]], int]]) -> List[np.ndarray]:
+        """Batched Chain::compact: trees = [([(id, next), ...], commit), ...] -> removed masks."""
+        trees = list(trees)
+        off = np.zeros(len(trees) + 1, np.uint64)
+        for i, (blocks, _) in enumerate(trees):
+            off[i + 1] = off[i] + len(blocks)
+        ids = np.array([b[0] for t in trees for b in t[0]], dtype=np.uint64)
+        nexts = np.array([b[1] for t in trees for b in t[0]], dtype=np.uint64)
+        commits = np.array([t[1] for t in trees], dtype=np.uint64)
+        removed = np.zeros(int(off[-1]), np.uint8)
+        ids = np.ascontiguousarray(ids)
+        nexts = np.ascontiguousarray(nexts)
+        self._check(self.api.chain_compact(self._h, len(trees), off.ctypes.data, ids.ctypes.data,
+                                           nexts.ctypes.data, commits.ctypes.data, removed.ctypes.data))
+        return [removed[int(off[i]):int(off[i + 1])].copy() for i in range(len(trees))]
+
+    def handle(self, group: int) -> "RaftHandle":
+        return RaftHandle(self, group)
+
+
+class RaftHandle:
+    """enum RaftHandle (src/raft/mod.rs:417-468) for one group of a BatchedRaft."""
+
+    def __init__(self, engine: BatchedRaft, group: int):
+        self.engine = engine
+        self.group = int(group)
+
+    def apply(self, cmd: Command, now_ms: int = 0) -> "RaftHandle":
+        return self.engine.apply(self.group, cmd, now_ms)
+
+    def _get(self, name: str, replica: int = 0):
+        return self.engine.read(name, replica, self.group, 1)[0]
+
+    def is_follower(self) -> bool:
+        return self._get("role") == capi.ROLE_FOLLOWER
+
+    def is_candidate(self) -> bool:
+        return self._get("role") == capi.ROLE_CANDIDATE
+
+    def is_leader(self) -> bool:
+        return self._get("role") == capi.ROLE_LEADER
+
+    @property
+    def id(self) -> int:
+        return self.engine.node_ids[int(self._get("self_slot"))]
+
+    @property
+    def current_term(self) -> int:
+        return int(self._get("term"))
+
+    @property
+    def voted_for(self) -> Optional[int]:
+        return int(self._get("voted_for")) if self._get("has_voted") else None
+
+    @property
+    def commit(self) -> int:
+        return int(self._get("commit"))
+
+    @property
+    def head(self) -> int:
+        return int(self._get("head"))
+
+    @property
+    def fault(self) -> int:
+        return int(self._get("fault"))
+
+    def match(self, replica: int) -> int:
+        return int(self._get("match", replica))

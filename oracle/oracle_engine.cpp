@@ -1,0 +1,378 @@
+// oracle_engine.cpp — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see raft_oracle.hpp).
+//
+// Batched facade over the single-group restatement: the same entry points as
+// include/josefine_gpu.h with a `jo_` prefix, so tests/ can push one trace
+// through both and compare every state column and every drained row.  It loops
+// the oracle over groups exactly as josefine would run one `event_loop` per
+// process (src/raft/server.rs:103-165); this is also the "port" CPU baseline
+// that bench.py times (per ack: HashMap remove/insert + Vec sort, mirroring
+// src/raft/progress.rs:42-60).
+#include "raft_oracle.hpp"
+
+#include <cstring>
+#include <string>
+#include <thread>
+
+using namespace jo;
+
+struct jo_engine {
+  jg_config cfg;
+  std::vector<Raft> groups;
+  std::vector<uint8_t> self_slot;
+  bool stepped = false;
+  // queued commands, bucketed per group in submit order
+  std::vector<std::vector<Cmd>> pending;
+  std::vector<uint32_t> touched;
+  std::vector<jg_msg_row> msgs;
+  std::vector<jg_fsm_row> fsms;
+  std::vector<jg_fault_row> faults;
+  uint64_t counters[4] = {0, 0, 0, 0};
+  unsigned threads = 1;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const char* msg) {
+  g_err = msg;
+  return code;
+}
+
+static void init_group(jo_engine* e, uint32_t g) {
+  const jg_config& c = e->cfg;
+  Timing t;
+  t.heartbeat_timeout_ms = c.heartbeat_timeout_ms;
+  t.election_min_ms = c.election_timeout_min_ms;
+  t.election_max_ms = c.election_timeout_max_ms;
+  t.seed = c.seed;
+  t.separate_commit_key = (c.flags & JG_CFG_SEPARATE_COMMIT_KEY) != 0;
+  std::vector<NodeId> peers;
+  for (uint32_t r = 0; r < c.n_replicas; r++)
+    if (r != e->self_slot[g]) peers.push_back(c.node_ids[r]);
+  e->groups[g].init(c.node_ids[e->self_slot[g]], peers, c.group_base + g, t, 0);
+}
+
+extern "C" {
+
+const char* jo_last_error(void) { return g_err.c_str(); }
+
+int jo_engine_create(const jg_config* cfg, jo_engine** out) {
+  if (!cfg || !out) return fail(JG_EINVAL, "null argument");
+  if (cfg->abi_version != JG_ABI_VERSION) return fail(JG_EINVAL, "abi version mismatch");
+  if (cfg->n_replicas < 1 || cfg->n_replicas > JG_MAX_REPLICAS) return fail(JG_EINVAL, "n_replicas out of range");
+  for (uint32_t r = 0; r < cfg->n_replicas; r++) {
+    if (cfg->node_ids[r] == 0) return fail(JG_EINVAL, "id cannot be 0");  // config.rs:64-66
+    for (uint32_t q = 0; q < r; q++)
+      if (cfg->node_ids[q] == cfg->node_ids[r]) return fail(JG_EINVAL, "duplicate node id");
+  }
+  if (cfg->heartbeat_timeout_ms < 5) return fail(JG_EINVAL, "heartbeat timeout is too low");  // config.rs:70-72
+  if (cfg->election_timeout_max_ms < cfg->election_timeout_min_ms) return fail(JG_EINVAL, "election timeout range");
+  jo_engine* e = new jo_engine();
+  e->cfg = *cfg;
+  e->groups.resize(cfg->n_groups);
+  e->self_slot.assign(cfg->n_groups, 0);
+  e->pending.resize(cfg->n_groups);
+  for (uint32_t g = 0; g < cfg->n_groups; g++) init_group(e, g);
+  *out = e;
+  return JG_OK;
+}
+
+void jo_engine_destroy(jo_engine* e) { delete e; }
+
+int jo_set_threads(jo_engine* e, unsigned n) {
+  e->threads = n ? n : 1;
+  return JG_OK;
+}
+
+int jo_set_self_slots(jo_engine* e, const uint8_t* slots) {
+  if (e->stepped) return fail(JG_EINVAL, "self slots are fixed after the first step");
+  for (uint32_t g = 0; g < e->cfg.n_groups; g++)
+    if (slots[g] >= e->cfg.n_replicas) return fail(JG_EINVAL, "self slot out of range");
+  for (uint32_t g = 0; g < e->cfg.n_groups; g++) {
+    e->self_slot[g] = slots[g];
+    init_group(e, g);
+  }
+  return JG_OK;
+}
+
+int jo_submit(jo_engine* e, const jg_cmd_batch* b) {
+  for (size_t i = 0; i < b->n; i++) {
+    if (b->group[i] >= e->cfg.n_groups) return fail(JG_EINVAL, "group out of range");
+    if (b->kind[i] >= JG_CMD__COUNT) return fail(JG_EINVAL, "unknown command kind");
+    if (b->kind[i] == JG_CMD_APPEND_ENTRIES && b->id[i] + b->aux[i] > b->n_blocks)
+      return fail(JG_EINVAL, "block side-array range out of bounds");
+  }
+  for (size_t i = 0; i < b->n; i++) {
+    Cmd c;
+    c.kind = b->kind[i];
+    c.from = b->from ? b->from[i] : 0;
+    c.term = b->term ? b->term[i] : 0;
+    c.id = b->id ? b->id[i] : 0;
+    c.aux = b->aux ? b->aux[i] : 0;
+    c.flag = b->flag ? b->flag[i] : 0;
+    if (c.kind == JG_CMD_APPEND_ENTRIES)
+      for (uint64_t k = 0; k < c.aux; k++) c.blocks.push_back(Block{b->blk_id[c.id + k], b->blk_next[c.id + k]});
+    uint32_t g = b->group[i];
+    if (e->pending[g].empty()) e->touched.push_back(g);
+    e->pending[g].push_back(std::move(c));
+  }
+  return JG_OK;
+}
+
+static void collect(jo_engine* e, uint32_t g) {
+  Raft& r = e->groups[g];
+  for (const Msg& m : r.rpc) {
+    jg_msg_row row;
+    std::memset(&row, 0, sizeof row);
+    row.group = g;
+    row.kind = m.kind;
+    row.to_kind = m.to_kind;
+    row.flag = m.flag;
+    row.to_id = m.to_id;
+    row.from = m.from;
+    row.term = m.term;
+    row.id = m.id;
+    row.aux = m.aux;
+    e->msgs.push_back(row);
+  }
+  r.rpc.clear();
+  for (const FsmRow& f : r.fsm) {
+    jg_fsm_row row;
+    std::memset(&row, 0, sizeof row);
+    row.group = g;
+    row.kind = f.kind;
+    row.a = f.a;
+    row.b = f.b;
+    e->fsms.push_back(row);
+  }
+  r.fsm.clear();
+  e->counters[1] += r.decisions;
+  r.decisions = 0;
+}
+
+int jo_step(jo_engine* e, uint64_t now_ms) {
+  e->stepped = true;
+  std::sort(e->touched.begin(), e->touched.end());
+  for (uint32_t g : e->touched) {
+    Raft& r = e->groups[g];
+    for (const Cmd& c : e->pending[g]) {
+      int before = r.fault;
+      r.apply(c, now_ms);
+      if (r.fault && r.fault != before) e->faults.push_back(jg_fault_row{g, (uint32_t)r.fault});
+      e->counters[0]++;
+    }
+    e->pending[g].clear();
+    collect(e, g);
+  }
+  e->touched.clear();
+  return JG_OK;
+}
+
+static void dense_range(jo_engine* e, const uint64_t* acks, uint32_t g0, uint32_t g1, uint64_t* ncmd) {
+  const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  uint64_t n = 0;
+  for (uint32_t g = g0; g < g1; g++) {
+    Raft& r = e->groups[g];
+    uint32_t s = e->self_slot[g];
+    uint64_t n_append = acks[(size_t)s * G + g];
+    if (r.fault) continue;
+    if (r.role != JG_ROLE_LEADER) {
+      if (n_append) r.fault = JG_FAULT_ENGINE_DENSE_NONLEADER;
+      continue;
+    }
+    Cmd c;
+    c.kind = JG_CMD_CLIENT_REQUEST;
+    for (uint64_t i = 0; i < n_append && !r.fault; i++) {
+      r.apply(c, 0);
+      n++;
+    }
+    c.kind = JG_CMD_APPEND_RESPONSE;
+    c.flag = 1;
+    for (uint32_t q = 0; q < R && !r.fault; q++) {
+      if (q == s) continue;
+      uint64_t h = acks[(size_t)q * G + g];
+      if (h == JG_NO_ACK) continue;
+      c.from = e->cfg.node_ids[q];
+      c.id = h;
+      r.apply(c, 0);
+      n++;
+    }
+    r.rpc.clear();
+    r.fsm.clear();  // dense path reports deltas, not rows
+  }
+  *ncmd = n;
+}
+
+int jo_step_dense_acks(jo_engine* e, const uint64_t* acks) {
+  e->stepped = true;
+  const uint32_t G = e->cfg.n_groups;
+  std::vector<int> fault_before(G);
+  for (uint32_t g = 0; g < G; g++) fault_before[g] = e->groups[g].fault;
+  unsigned T = std::min<unsigned>(e->threads, G ? G : 1);
+  std::vector<uint64_t> ncmd(T, 0);
+  if (T <= 1) {
+    dense_range(e, acks, 0, G, &ncmd[0]);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++) {
+      uint32_t g0 = (uint32_t)((uint64_t)G * t / T), g1 = (uint32_t)((uint64_t)G * (t + 1) / T);
+      th.emplace_back(dense_range, e, acks, g0, g1, &ncmd[t]);
+    }
+    for (auto& x : th) x.join();
+  }
+  for (unsigned t = 0; t < T; t++) e->counters[0] += ncmd[t];
+  for (uint32_t g = 0; g < G; g++) {
+    Raft& r = e->groups[g];
+    if (r.fault && r.fault != fault_before[g]) e->faults.push_back(jg_fault_row{g, (uint32_t)r.fault});
+    e->counters[1] += r.decisions;
+    r.decisions = 0;
+  }
+  e->counters[2] += G;
+  return JG_OK;
+}
+
+int jo_chain_compact(jo_engine*, size_t n_trees, const uint64_t* off, const uint64_t* ids, const uint64_t* nexts,
+                     const uint64_t* commits, uint8_t* removed) {
+  for (size_t t = 0; t < n_trees; t++) {
+    Chain c;
+    // later entries overwrite earlier ones with the same id (sled insert = upsert)
+    std::map<BlockId, size_t> last;
+    for (uint64_t i = off[t]; i < off[t + 1]; i++) {
+      c.db[ids[i]] = Block{ids[i], nexts[i]};
+      last[ids[i]] = i;
+      removed[i] = 0;
+    }
+    c.commit = commits[t];
+    for (BlockId id : c.compact()) removed[last[id]] = 1;
+  }
+  return JG_OK;
+}
+
+#define DRAIN(vec, T)                                          \
+  if (!n) return fail(JG_EINVAL, "null count");                \
+  if (!out) {                                                  \
+    *n = e->vec.size();                                        \
+    return JG_OK;                                              \
+  }                                                            \
+  if (cap < e->vec.size()) {                                   \
+    *n = e->vec.size();                                        \
+    return fail(JG_ECAPACITY, "output buffer too small");      \
+  }                                                            \
+  *n = e->vec.size();                                          \
+  if (*n) std::memcpy(out, e->vec.data(), *n * sizeof(T));     \
+  e->vec.clear();                                              \
+  return JG_OK;
+
+int jo_drain_messages(jo_engine* e, jg_msg_row* out, size_t cap, size_t* n) { DRAIN(msgs, jg_msg_row) }
+int jo_drain_applies(jo_engine* e, jg_fsm_row* out, size_t cap, size_t* n) { DRAIN(fsms, jg_fsm_row) }
+int jo_drain_faults(jo_engine* e, jg_fault_row* out, size_t cap, size_t* n) { DRAIN(faults, jg_fault_row) }
+
+int jo_read_state(jo_engine* e, int field, uint32_t replica, void* out, uint32_t g0, uint32_t n) {
+  if ((uint64_t)g0 + n > e->cfg.n_groups) return fail(JG_EINVAL, "group range out of bounds");
+  if (field == JG_FIELD_MATCH && replica >= e->cfg.n_replicas) return fail(JG_EINVAL, "replica out of range");
+  for (uint32_t i = 0; i < n; i++) {
+    const Raft& r = e->groups[g0 + i];
+    auto slot_of = [&](NodeId id) -> int {
+      for (uint32_t q = 0; q < e->cfg.n_replicas; q++)
+        if (e->cfg.node_ids[q] == id) return (int)q;
+      return -1;
+    };
+    switch (field) {
+      case JG_FIELD_TERM: ((uint64_t*)out)[i] = r.current_term; break;
+      case JG_FIELD_VOTED_FOR: ((uint32_t*)out)[i] = r.has_voted ? r.voted_for : 0; break;
+      case JG_FIELD_HAS_VOTED: ((uint8_t*)out)[i] = r.has_voted; break;
+      case JG_FIELD_ROLE: ((uint8_t*)out)[i] = (uint8_t)r.role; break;
+      case JG_FIELD_COMMIT: ((uint64_t*)out)[i] = r.chain.commit; break;
+      case JG_FIELD_HEAD: ((uint64_t*)out)[i] = r.chain.head; break;
+      case JG_FIELD_ID_GEN: ((uint64_t*)out)[i] = r.chain.id_gen; break;
+      case JG_FIELD_MATCH: {
+        uint64_t v = 0;
+        if (r.role == JG_ROLE_LEADER) {
+          auto it = r.progress.progress.find(e->cfg.node_ids[replica]);
+          if (it != r.progress.progress.end()) v = it->second.head;
+        }
+        ((uint64_t*)out)[i] = v;
+        break;
+      }
+      case JG_FIELD_REPL_STATE: {
+        uint8_t m = 0;
+        if (r.role == JG_ROLE_LEADER)
+          for (auto& kv : r.progress.progress) {
+            int s = slot_of(kv.first);
+            if (s >= 0 && kv.second.replicate) m |= (uint8_t)(1u << s);
+          }
+        ((uint8_t*)out)[i] = m;
+        break;
+      }
+      case JG_FIELD_VOTE_SEEN:
+      case JG_FIELD_VOTE_GRANTED: {
+        uint8_t m = 0;
+        if (r.role == JG_ROLE_CANDIDATE)
+          for (auto& kv : r.election.votes) {
+            int s = slot_of(kv.first);
+            if (s >= 0 && (field == JG_FIELD_VOTE_SEEN || kv.second)) m |= (uint8_t)(1u << s);
+          }
+        ((uint8_t*)out)[i] = m;
+        break;
+      }
+      case JG_FIELD_FAULT: ((uint8_t*)out)[i] = (uint8_t)r.fault; break;
+      case JG_FIELD_LEADER_ID: ((uint32_t*)out)[i] = (r.role == JG_ROLE_FOLLOWER && r.has_leader) ? r.leader_id : 0; break;
+      case JG_FIELD_HAS_LEADER: ((uint8_t*)out)[i] = r.role == JG_ROLE_FOLLOWER && r.has_leader; break;
+      case JG_FIELD_ELECTION_TIME: ((uint64_t*)out)[i] = r.election_time; break;
+      case JG_FIELD_ELECTION_TIMEOUT: ((uint32_t*)out)[i] = r.election_timeout; break;
+      case JG_FIELD_HEARTBEAT_TIME: ((uint64_t*)out)[i] = r.role == JG_ROLE_LEADER ? r.heartbeat_time : 0; break;
+      case JG_FIELD_QUEUED_REQS: ((uint32_t*)out)[i] = r.queued_reqs; break;
+      case JG_FIELD_SELF_SLOT: ((uint8_t*)out)[i] = e->self_slot[g0 + i]; break;
+      default: return fail(JG_EINVAL, "unknown field");
+    }
+  }
+  return JG_OK;
+}
+
+int jo_get_counters(jo_engine* e, uint64_t out[4]) {
+  std::memcpy(out, e->counters, sizeof e->counters);
+  return JG_OK;
+}
+
+// Synthetic ack-stream generator — specification in DESIGN.md "Synthetic traces";
+// restated independently on the device (josefine_amd/csrc/synth.hip).
+static inline uint64_t synth_hash(uint64_t seed, uint64_t tick, uint64_t gg, uint32_t r) {
+  return mix64(mix64(seed + tick * 0x9e3779b97f4a7c15ull) ^ (gg * 8 + r));
+}
+
+int jo_synth_fill_acks(jo_engine* e, uint32_t mode, uint64_t tick, uint64_t* sim, uint64_t* acks) {
+  const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  if (mode > 1) return fail(JG_EINVAL, "unknown synth mode");
+  for (uint32_t g = 0; g < G; g++) {
+    uint32_t s = e->self_slot[g];
+    uint64_t gg = e->cfg.group_base + g;
+    uint64_t lead = sim[(size_t)s * G + g];
+    uint64_t n_append = mode == 0 ? 1 : synth_hash(e->cfg.seed, tick, gg, s) % 3;
+    acks[(size_t)s * G + g] = n_append;
+    sim[(size_t)s * G + g] = lead + n_append;
+    for (uint32_t r = 0; r < R; r++) {
+      if (r == s) continue;
+      size_t k = (size_t)r * G + g;
+      if (mode == 0) {
+        acks[k] = lead;
+        sim[k] = lead;
+      } else {
+        uint64_t u = synth_hash(e->cfg.seed, tick, gg, r);
+        uint32_t p = (uint32_t)(u % 100);
+        if (p < 5) {
+          acks[k] = JG_NO_ACK;  // dropped
+        } else if (p < 10) {
+          acks[k] = sim[k];  // stale duplicate of the previous ack
+        } else {
+          uint64_t adv = (u >> 32) % (JG_MAX_INFLIGHT + 1);
+          uint64_t v = std::min(lead, sim[k] + adv);
+          acks[k] = v;
+          sim[k] = v;
+        }
+      }
+    }
+  }
+  return JG_OK;
+}
+
+uint32_t jo_abi_version(void) { return JG_ABI_VERSION; }
+
+}  // extern "C"
