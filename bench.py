@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — Raft quorum decisions/sec on the dense leader-tick hot path.
+
+Workload (N=1): BASELINE.json configs[2] — 1M partitions x 5 replicas,
+steady-state append + commit: every tick each leader appends one block and
+receives the 4 follower acks of the previous tick.  The
+synthetic AppendEntries-ack stream for all warm-up + timed ticks is generated
+on the device BEFORE the timed region, so inputs are resident in HBM.  For
+N>1 (one process per GPU, launched by torch.distributed.run) every rank owns
+its own 1M x 5 shard (weak scaling, contiguous global group ids, no data-path
+collective: Raft groups are independent — SURVEY.md §8(e)).
+
+A "step" = one tick = one launch of k_leader_tick_dense<5> over the rank's
+groups.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+def alg_bytes_per_group_step(R: int) -> int:
+    """read R ack heads + R match heads + commit + head + term (8 B each)
+    + 4 B flags; write R match heads + commit."""
+    return 24 * R + 36
+
+
+def cpu_baseline(R: int, seed: int, budget_s: float):
+    """Time the CPU oracle (the reference-shaped C++ port: per ack HashMap remove/insert +
+    Vec sort, progress.rs:42-60) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from oracle_lib import oracle_engine
+    from parity import elect_all, synth_tick_host
+
+    Gs, ticks = 50_000, 12
+    ora = oracle_engine(Gs, R, seed=seed)
+    elect_all(ora)
+    sim = np.zeros((R, Gs), dtype=np.uint64)
+    acks = [synth_tick_host(ora, 0, t, sim) for t in range(ticks)]
+    d0 = ora.counters()["decisions"]
+    t0 = time.perf_counter()
+    done = 0
+    for t in range(ticks):
+        ora.step_dense_acks(acks[t])
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    dec = ora.counters()["decisions"] - d0
+    # the same sample on all host cores (groups block-partitioned over std::thread)
+    cores = os.cpu_count() or 1
+    mt = None
+    if cores > 1:
+        ora2 = oracle_engine(Gs, R, seed=seed)
+        elect_all(ora2)
+        ora2.api.set_threads(ora2._h, cores)
+        t1 = time.perf_counter()
+        for t in range(done):
+            ora2.step_dense_acks(acks[t])
+        mt = (ora2.counters()["decisions"] - d0) / (time.perf_counter() - t1)
+    return {
+        "value": dec / dt, "unit": "decisions/s", "cores": 1, "kind": "port",
+        "sample": f"{Gs} groups x {R} replicas x {done} ticks of the same steady-state stream, "
+                  f"C++ oracle (Rust reference not buildable here: no cargo)",
+        "all_cores_value": mt, "all_cores": cores,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--groups", type=int, default=1_000_000, help="partitions per GPU")
+    ap.add_argument("--replicas", type=int, default=5)
+    ap.add_argument("--mode", type=int, default=0, help="0 steady-state (#3/#4), 1 ragged (#2)")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x6A6F736566696E65)
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch  # first: the engine library then resolves against the same HIP runtime
+    import torch.distributed as dist
+    import numpy as np
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from josefine_amd import BatchedRaft
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity import elect_all
+
+    G, R, K, W = args.groups, args.replicas, args.steps, args.warmup
+    eng = BatchedRaft(G, R, seed=args.seed, device_id=local_rank, group_base=rank * G)
+    elect_all(eng)  # Timeout -> votes -> leader through the general kernel
+    eng.drain_messages(), eng.drain_applies()
+    api, h = eng.api, eng._h
+
+    # pre-generate the whole ack stream in HBM: (W+K) ticks x [R][G] u64
+    tick_bytes = R * G * 8
+    sim = C.c_void_p()
+    stream_buf = C.c_void_p()
+    eng._check(api.device_alloc(h, tick_bytes, C.byref(sim)))
+    eng._check(api.device_alloc(h, tick_bytes * (W + K), C.byref(stream_buf)))
+    for t in range(W + K):
+        eng._check(api.synth_fill_acks_device(h, args.mode, t, sim, C.c_void_p(stream_buf.value + t * tick_bytes)))
+    eng._check(api.sync(h))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng._check(api.sync(h))
+
+    for t in range(W):
+        eng._check(api.step_dense_acks_device(h, C.c_void_p(stream_buf.value + t * tick_bytes)))
+    barrier()
+    c0 = eng.counters()
+    barrier()
+    t0 = time.perf_counter()
+    eng._check(api.timer_start(h))
+    for t in range(W, W + K):
+        eng._check(api.step_dense_acks_device(h, C.c_void_p(stream_buf.value + t * tick_bytes)))
+    ev_ms = C.c_float(0)
+    eng._check(api.timer_stop(h, C.byref(ev_ms)))  # HIP events on the engine's stream
+    barrier()
+    wall = time.perf_counter() - t0
+    c1 = eng.counters()
+
+    decisions = c1["decisions"] - c0["decisions"]
+    # parity property at full size (closed form of the steady-state stream, mode 0):
+    # after T ticks every leader has head == T and commit == T-1, no faults.
+    if args.mode == 0:
+        T = W + K
+        head, commit, fault = eng.read("head"), eng.read("commit"), eng.read("fault")
+        assert (head == T).all() and (commit == T - 1).all() and not fault.any(), "steady-state closed form violated"
+
+    if world > 1:
+        tw = torch.tensor([wall, ev_ms.value], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        td = torch.tensor([float(decisions)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(td, op=dist.ReduceOp.SUM)
+        wall, ev_max_ms, decisions_all = tw[0].item(), tw[1].item(), td[0].item()
+    else:
+        ev_max_ms, decisions_all = ev_ms.value, float(decisions)
+
+    if rank == 0:
+        launch_s = (ev_ms.value / 1e3) / K  # average k_leader_tick_dense launch on this rank's stream
+        alg = alg_bytes_per_group_step(R) * G
+        achieved = alg / launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(f"G{G}_R{R}_mode{args.mode}")
+        out = {
+            "metric": "Raft quorum decisions/sec over N partitions; achieved HBM GB/s vs roofline",
+            "value": decisions_all / wall,
+            "unit": "decisions/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": wall * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{G} partitions x {R} replicas per GPU, steady-state append+commit "
+                            f"(BASELINE.json configs[2]); device-resident synthetic AppendEntries-ack stream, mode {args.mode}",
+                "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world,
+                "parallelism": f"{world} independent shard(s), no collective",
+            },
+            "group_steps_per_s": G * world * K / wall,
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": f"k_leader_tick_dense<{R}>", "alg_bytes_per_launch": alg,
+                "avg_launch_us": launch_s * 1e6, "peak_basis": "8.0 TB/s spec (6.29 TB/s measured copy)",
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(R, args.seed, args.cpu_budget)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

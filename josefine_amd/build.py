@@ -1,0 +1,30 @@
+"""In-tree build of the HIP engine: one hipcc invocation, gfx950 only."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libjosefine_gpu.so")
+SOURCES = ["josefine_gpu.hip", "jg_kernels.h", "jg_device.h"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    deps = [os.path.join(CSRC, s) for s in SOURCES]
+    deps.append(os.path.join(CSRC, "..", "..", "include", "josefine_gpu.h"))
+    return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> josefine_amd/csrc/libjosefine_gpu.so"""
+    if not force and not needs_build():
+        return LIB
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
+           "-Wno-unused-function", "-o", LIB, os.path.join(CSRC, "josefine_gpu.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB

@@ -1,0 +1,649 @@
+// jg_device.h — device-side state layout and the per-group Raft state machine
+// for gfx950.  Independent implementation (SoA columns, bitmasks, implicit chain
+// run) of the reference functions cited inline; the CPU oracle under oracle/ is
+// never included or linked here.  All citations are relative to /root/reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/josefine_gpu.h"
+
+// ---- per-group flag word ------------------------------------------------------
+//  bits 0-1   role (JG_ROLE_*)                                   mod.rs:417-425
+//  bit  2     voted_for.is_some()                                mod.rs:279
+//  bit  3     Follower.leader_id.is_some()                       follower.rs:20
+//  bit  4     FAST chain: run_hi == head, id_gen == head+1, no explicit window
+//             entries -> the id set is exactly [0, head]; the id_gen / run_hi
+//             columns are then implicit (possibly stale in memory)
+//  bit  5     the "commit" key has been persisted               chain.rs:198
+//  bits 8-15  bit r: progress of slot r is Replicate (else Probe) progress.rs:62-66
+//  bits 16-23 sticky fault code (JG_FAULT_*)
+//  bits 24-26 own replica slot
+//  bits 28-31 number of explicit chain-window entries (0..JG_CHAIN_WINDOW)
+#define JGF_ROLE_MASK 0x3u
+#define JGF_VOTED (1u << 2)
+#define JGF_HAS_LEADER (1u << 3)
+#define JGF_FAST (1u << 4)
+#define JGF_COMMIT_KEY (1u << 5)
+#define JGF_REPL_SHIFT 8
+#define JGF_REPL_MASK (0xffu << JGF_REPL_SHIFT)
+#define JGF_FAULT_SHIFT 16
+#define JGF_FAULT_MASK (0xffu << JGF_FAULT_SHIFT)
+#define JGF_SELF_SHIFT 24
+#define JGF_SELF_MASK (0x7u << JGF_SELF_SHIFT)
+#define JGF_WIN_SHIFT 28
+#define JGF_WIN_MASK (0xfu << JGF_WIN_SHIFT)
+
+struct JgFaultRec {
+  uint32_t group;
+  uint32_t code;
+  uint32_t seq;  // step sequence number (orders rows of different steps at drain)
+  uint32_t pad;
+};
+
+// Structure-of-arrays state in HBM; column c of group g is c[g], replica-major
+// for the [R][G] / [W][G] arrays so that a wave reads contiguous lanes.
+struct JgDev {
+  uint32_t G, R;
+  uint32_t node_ids[JG_MAX_REPLICAS];
+  uint32_t hb_timeout, el_min, el_max, cfg_flags;
+  uint64_t seed, group_base;
+  uint64_t* term;            // State.current_term                     mod.rs:277
+  uint64_t* commit;          // Chain.commit                           chain.rs:102
+  uint64_t* head;            // Chain.head                             chain.rs:103
+  uint64_t* id_gen;          // Chain.id_gen (valid unless FAST)       chain.rs:101
+  uint64_t* run_hi;          // ids [0, run_hi] exist with next = id-1 (valid unless FAST)
+  uint64_t* match;           // [R][G] Progress.head                   progress.rs:124
+  uint64_t* election_time;   // State.election_time (ms)               mod.rs:281
+  uint64_t* heartbeat_time;  // Leader.heartbeat_time (ms)             leader.rs:27
+  uint64_t* win_id;          // [W][G] explicit chain entries: id
+  uint64_t* win_next;        // [W][G]                          ...and parent pointer
+  uint32_t* flags;
+  uint32_t* voted_for;       // State.voted_for                        mod.rs:279
+  uint32_t* leader_id;       // Follower.leader_id                     follower.rs:20
+  uint32_t* election_timeout;// State.election_timeout (ms)            mod.rs:283
+  uint32_t* rng_draws;       // draws taken from the timeout RNG
+  uint32_t* queued;          // queued_reqs.len()                      follower.rs:22
+  uint32_t* votes;           // Election.votes: seen | granted << 8    election.rs:8
+  uint64_t* blk_decisions;   // per-workgroup decision counters (no atomics on the hot path)
+  JgFaultRec* fault_q;
+  uint32_t* fault_q_n;
+  uint32_t fault_q_cap;
+  uint32_t* slow_list;       // groups the dense fast path deferred
+  uint32_t* slow_n;
+};
+
+// splitmix64 finaliser: the counter-based RNG of DESIGN.md "Logical time and randomness"
+__device__ __forceinline__ uint64_t jg_mix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+// Registers of one group while a lane walks its command segment.
+struct JgLane {
+  uint32_t g;
+  uint64_t term, commit, head, id_gen, run_hi, election_time, heartbeat_time;
+  uint32_t flags, voted_for, leader_id, election_timeout, rng_draws, queued, votes;
+  uint64_t now;
+  uint32_t seq;
+  uint32_t decisions;
+  jg_msg_row* mp;
+  jg_msg_row* mend;
+  jg_fsm_row* fp;
+  jg_fsm_row* fend;
+  uint32_t overflow;  // an output row did not fit its bound (engine bug guard)
+};
+
+__device__ __forceinline__ uint32_t jg_role(const JgLane& L) { return L.flags & JGF_ROLE_MASK; }
+__device__ __forceinline__ void jg_set_role(JgLane& L, uint32_t r) { L.flags = (L.flags & ~JGF_ROLE_MASK) | r; }
+__device__ __forceinline__ uint32_t jg_fault(const JgLane& L) { return (L.flags & JGF_FAULT_MASK) >> JGF_FAULT_SHIFT; }
+__device__ __forceinline__ uint32_t jg_self(const JgLane& L) { return (L.flags & JGF_SELF_MASK) >> JGF_SELF_SHIFT; }
+__device__ __forceinline__ uint32_t jg_wcnt(const JgLane& L) { return (L.flags & JGF_WIN_MASK) >> JGF_WIN_SHIFT; }
+__device__ __forceinline__ uint32_t jg_self_id(const JgDev& d, const JgLane& L) { return d.node_ids[jg_self(L)]; }
+
+__device__ inline void jg_push_fault(const JgDev& d, uint32_t g, uint32_t code, uint32_t seq) {
+  uint32_t i = atomicAdd(d.fault_q_n, 1u);
+  if (i < d.fault_q_cap) {
+    JgFaultRec r;
+    r.group = g;
+    r.code = code;
+    r.seq = seq;
+    r.pad = 0;
+    d.fault_q[i] = r;
+  }
+}
+__device__ inline void jg_raise(const JgDev& d, JgLane& L, uint32_t code) {
+  if (jg_fault(L)) return;
+  L.flags |= code << JGF_FAULT_SHIFT;
+  jg_push_fault(d, L.g, code, L.seq);
+}
+
+__device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
+  L.g = g;
+  L.flags = d.flags[g];
+  L.term = d.term[g];
+  L.commit = d.commit[g];
+  L.head = d.head[g];
+  if (L.flags & JGF_FAST) {
+    L.id_gen = L.head + 1;
+    L.run_hi = L.head;
+  } else {
+    L.id_gen = d.id_gen[g];
+    L.run_hi = d.run_hi[g];
+  }
+  L.election_time = d.election_time[g];
+  L.heartbeat_time = d.heartbeat_time[g];
+  L.voted_for = d.voted_for[g];
+  L.leader_id = d.leader_id[g];
+  L.election_timeout = d.election_timeout[g];
+  L.rng_draws = d.rng_draws[g];
+  L.queued = d.queued[g];
+  L.votes = d.votes[g];
+  L.decisions = 0;
+  L.overflow = 0;
+}
+__device__ inline void jg_store(const JgDev& d, JgLane& L) {
+  uint32_t g = L.g;
+  bool fast = (L.run_hi == L.head) && (L.id_gen == L.head + 1) && (jg_wcnt(L) == 0);
+  L.flags = fast ? (L.flags | JGF_FAST) : (L.flags & ~JGF_FAST);
+  d.flags[g] = L.flags;
+  d.term[g] = L.term;
+  d.commit[g] = L.commit;
+  d.head[g] = L.head;
+  d.id_gen[g] = L.id_gen;
+  d.run_hi[g] = L.run_hi;
+  d.election_time[g] = L.election_time;
+  d.heartbeat_time[g] = L.heartbeat_time;
+  d.voted_for[g] = L.voted_for;
+  d.leader_id[g] = L.leader_id;
+  d.election_timeout[g] = L.election_timeout;
+  d.rng_draws[g] = L.rng_draws;
+  d.queued[g] = L.queued;
+  d.votes[g] = L.votes;
+}
+
+// ---- output rows ------------------------------------------------------------------
+__device__ inline void jg_emit_msg(const JgDev& d, JgLane& L, uint8_t kind, uint8_t to_kind, uint32_t to_id,
+                                   uint8_t flag, uint64_t term, uint64_t id, uint64_t aux) {
+  if (L.mp >= L.mend) {
+    L.overflow = 1;
+    return;
+  }
+  jg_msg_row r;
+  r.group = L.g;
+  r.kind = kind;
+  r.to_kind = to_kind;
+  r.flag = flag;
+  r.pad = 0;
+  r.to_id = to_id;
+  r.from = jg_self_id(d, L);  // Message::new(Address::Peer(self.id), ..)  mod.rs:390-400
+  r.term = term;
+  r.id = id;
+  r.aux = aux;
+  *L.mp++ = r;
+}
+__device__ inline void jg_emit_fsm(JgLane& L, uint8_t kind, uint64_t a, uint64_t b) {
+  if (L.fp >= L.fend) {
+    L.overflow = 1;
+    return;
+  }
+  jg_fsm_row r;
+  r.group = L.g;
+  r.kind = kind;
+  r.pad[0] = r.pad[1] = r.pad[2] = 0;
+  r.a = a;
+  r.b = b;
+  *L.fp++ = r;
+}
+
+// ---- Chain (src/raft/chain.rs:99-254) ------------------------------------------------
+// Id set = [0, run_hi] (each id with next = id-1, genesis next = 0) plus up to
+// JG_CHAIN_WINDOW explicit (id,next) entries, which take precedence.
+__device__ inline int jg_win_find(const JgDev& d, const JgLane& L, uint64_t id) {
+  uint32_t n = jg_wcnt(L);
+  for (uint32_t w = 0; w < n; w++)
+    if (d.win_id[(size_t)w * d.G + L.g] == id) return (int)w;
+  return -1;
+}
+__device__ inline bool jg_chain_has(const JgDev& d, const JgLane& L, uint64_t id) {  // chain.rs:155-157
+  if (id <= L.run_hi) return true;
+  return jg_win_find(d, L, id) >= 0;
+}
+// sled insert (upsert) of Block{id,next}; returns an engine fault or 0
+__device__ inline uint32_t jg_chain_insert(const JgDev& d, JgLane& L, uint64_t id, uint64_t next) {
+  int w = jg_win_find(d, L, id);
+  if (w >= 0) {
+    d.win_next[(size_t)w * d.G + L.g] = next;
+    return 0;
+  }
+  if (id <= L.run_hi) {
+    uint64_t implicit = id ? id - 1 : 0;
+    if (next == implicit) return 0;
+  } else if (id == L.run_hi + 1 && next == L.run_hi) {
+    L.run_hi = id;
+    return 0;
+  }
+  uint32_t n = jg_wcnt(L);
+  if (n >= JG_CHAIN_WINDOW) return JG_FAULT_ENGINE_WINDOW_OVERFLOW;
+  d.win_id[(size_t)n * d.G + L.g] = id;
+  d.win_next[(size_t)n * d.G + L.g] = next;
+  L.flags = (L.flags & ~JGF_WIN_MASK) | ((n + 1) << JGF_WIN_SHIFT);
+  return 0;
+}
+// number of block keys >= from, saturated at `cap` (unbounded range(from..), leader.rs:135,152-157)
+__device__ inline uint32_t jg_chain_blocks_from(const JgDev& d, const JgLane& L, uint64_t from, uint32_t cap) {
+  uint64_t k = 0;
+  if (from <= L.run_hi) {
+    k = L.run_hi - from + 1;
+    if (k >= cap) return cap;
+  }
+  uint32_t n = jg_wcnt(L);
+  for (uint32_t w = 0; w < n; w++) {
+    uint64_t id = d.win_id[(size_t)w * d.G + L.g];
+    if (id > L.run_hi && id >= from) k++;
+  }
+  return k >= cap ? cap : (uint32_t)k;
+}
+// Chain::append, chain.rs:160-175
+__device__ inline uint32_t jg_chain_append(const JgDev& d, JgLane& L, uint64_t* out) {
+  uint64_t id = L.id_gen++;                                      // :161
+  if (!(id > L.head)) return JG_FAULT_APPEND_ID_NOT_ABOVE_HEAD;  // :163
+  uint32_t f = jg_chain_insert(d, L, id, L.head);                // :164-172
+  if (f) return f;
+  L.head = id;                                                   // :173
+  *out = id;
+  return 0;
+}
+// Chain::extend, chain.rs:178-192
+__device__ inline uint32_t jg_chain_extend(const JgDev& d, JgLane& L, uint64_t id, uint64_t next) {
+  if (!jg_chain_has(d, L, next)) return JG_FAULT_EXTEND_MISSING_PARENT;  // :180-185
+  uint32_t f = jg_chain_insert(d, L, id, next);                          // :187-189
+  if (f) return f;
+  L.head = id;                                                           // :190
+  return 0;
+}
+// Chain::commit, chain.rs:195-205
+__device__ inline uint32_t jg_chain_commit(const JgDev& d, JgLane& L, uint64_t id) {
+  if (!jg_chain_has(d, L, id)) return JG_FAULT_COMMIT_MISSING_BLOCK;  // :200-202
+  L.flags |= JGF_COMMIT_KEY;                                          // :198
+  L.commit = id;                                                      // :199
+  return 0;
+}
+// Chain::new on the persisted tree, chain.rs:117-137 (+ init 139-153)
+__device__ inline uint32_t jg_chain_reopen(const JgDev& d, JgLane& L) {
+  uint64_t c = (L.flags & JGF_COMMIT_KEY) ? L.commit : 0;
+  L.id_gen = c;
+  L.commit = c;
+  L.head = c;
+  if (c == 0) {
+    L.id_gen = 1;                        // id_gen.next() -> 0
+    return jg_chain_insert(d, L, 0, 0);  // genesis re-inserted
+  }
+  return 0;
+}
+
+// ---- timers ---------------------------------------------------------------------------
+__device__ inline void jg_set_election_timeout(const JgDev& d, JgLane& L) {  // follower.rs:103-113
+  uint32_t span = d.el_max - d.el_min;
+  uint64_t key = d.group_base + L.g;
+  uint64_t r = jg_mix64(d.seed ^ jg_mix64(key * 0xd1342543de82ef95ull + L.rng_draws));
+  L.rng_draws++;
+  L.election_timeout = d.el_min + (span ? (uint32_t)(r % span) : 0u);
+  L.election_time = L.now;
+}
+__device__ inline bool jg_needs_election(const JgLane& L) {  // mod.rs:352-357
+  return (L.now - L.election_time) > (uint64_t)L.election_timeout;
+}
+
+// ---- progress (src/raft/progress.rs) ----------------------------------------------------
+__device__ inline int jg_slot_of(const JgDev& d, uint32_t node_id) {
+  for (uint32_t r = 0; r < d.R; r++)
+    if (d.node_ids[r] == node_id) return (int)r;
+  return -1;
+}
+// ReplicationProgress::committed_index, progress.rs:48-60: element R/2 of the heads
+// sorted descending == the head whose rank (number of strictly-greater heads, ties
+// broken by slot) is R/2.
+__device__ inline uint64_t jg_committed_index(const JgDev& d, const JgLane& L) {
+  uint64_t v[JG_MAX_REPLICAS];
+#pragma unroll
+  for (uint32_t r = 0; r < JG_MAX_REPLICAS; r++) v[r] = r < d.R ? d.match[(size_t)r * d.G + L.g] : 0;
+  uint32_t k = d.R / 2;
+  uint64_t q = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < JG_MAX_REPLICAS; j++) {
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < JG_MAX_REPLICAS; i++)
+      cnt += (i < d.R && (v[i] > v[j] || (v[i] == v[j] && i < j))) ? 1u : 0u;
+    if (j < d.R && cnt == k) q = v[j];
+  }
+  return q;
+}
+
+// ---- role transitions -----------------------------------------------------------------
+__device__ inline void jg_drop_queue(const JgDev& d, JgLane& L) {
+  if (L.queued) jg_emit_msg(d, L, JG_CMD_CLIENT_REQUEST, JG_TO_QUEUE, 0, JG_QUEUE_DROP, 0, 0, L.queued);
+  L.queued = 0;
+}
+__device__ inline void jg_clear_leader(JgLane& L) {
+  L.flags &= ~JGF_HAS_LEADER;
+  L.leader_id = 0;
+}
+// Raft::term (mod.rs:360-365) + Role::term; returns a fault for the Leader role
+__device__ inline uint32_t jg_set_term(JgLane& L, uint64_t t) {
+  L.flags &= ~JGF_VOTED;
+  L.voted_for = 0;
+  L.term = t;
+  switch (jg_role(L)) {
+    case JG_ROLE_FOLLOWER: jg_clear_leader(L); return 0;              // follower.rs:27-29
+    case JG_ROLE_CANDIDATE: L.votes = 0; return 0;                    // candidate.rs:161-163
+    default: return JG_FAULT_LEADER_TERM_UNIMPLEMENTED;               // leader.rs:33-35
+  }
+}
+__device__ inline void jg_vote_for(JgLane& L, uint32_t id) {
+  L.flags |= JGF_VOTED;
+  L.voted_for = id;
+}
+__device__ inline void jg_become_candidate(const JgDev& d, JgLane& L) {  // follower.rs:285-304
+  L.votes = 0;
+  jg_set_role(L, JG_ROLE_CANDIDATE);
+  jg_drop_queue(d, L);  // Candidate{queued_reqs: Vec::new()} (follower.rs:295)
+  jg_clear_leader(L);
+}
+__device__ inline void jg_follower_from_candidate(JgLane& L) {  // candidate.rs:198-214
+  jg_set_role(L, JG_ROLE_FOLLOWER);
+  jg_clear_leader(L);
+  L.votes = 0;
+}
+__device__ inline void jg_follower_from_leader(JgLane& L) {  // leader.rs:268-284
+  jg_set_role(L, JG_ROLE_FOLLOWER);
+  jg_clear_leader(L);
+  L.queued = 0;
+  L.flags &= ~JGF_REPL_MASK;
+}
+__device__ inline void jg_become_leader(const JgDev& d, JgLane& L) {  // candidate.rs:216-238
+  for (uint32_t r = 0; r < d.R; r++) d.match[(size_t)r * d.G + L.g] = 0;  // progress.rs:155-162
+  L.flags &= ~JGF_REPL_MASK;
+  L.heartbeat_time = L.now;
+  jg_set_role(L, JG_ROLE_LEADER);
+  jg_drop_queue(d, L);
+  L.votes = 0;
+}
+__device__ inline void jg_send_heartbeat(const JgDev& d, JgLane& L) {  // leader.rs:44-51
+  jg_emit_msg(d, L, JG_CMD_HEARTBEAT, JG_TO_PEERS, 0, 0, L.term, L.commit, 0);
+}
+
+// ---- Leader (src/raft/leader.rs) -------------------------------------------------------
+__device__ inline uint32_t jg_leader_commit(const JgDev& d, JgLane& L) {  // leader.rs:87-99
+  L.decisions++;
+  uint64_t q = jg_committed_index(d, L);
+  if (q > L.commit) {
+    uint64_t prev = L.commit;
+    uint32_t f = jg_chain_commit(d, L, q);
+    if (f) return f;
+    jg_emit_fsm(L, JG_FSM_APPLY_LEADER, prev, q);  // :93
+  }
+  return 0;
+}
+__device__ inline uint32_t jg_leader_append_response(const JgDev& d, JgLane& L, uint32_t node, uint64_t head) {
+  // leader.rs:211-219 -> progress.rs:42-46,76-94,133-140
+  int s = jg_slot_of(d, node);
+  if (s < 0) return JG_FAULT_PROGRESS_UNKNOWN_NODE;  // progress.rs:43
+  size_t k = (size_t)s * d.G + L.g;
+  uint64_t m = d.match[k];
+  bool inc = m < head;
+  if (inc) d.match[k] = head;
+  uint32_t bit = 1u << (JGF_REPL_SHIFT + s);
+  L.flags = inc ? (L.flags | bit) : (L.flags & ~bit);
+  return jg_leader_commit(d, L);
+}
+__device__ inline uint32_t jg_leader_client_request(const JgDev& d, JgLane& L, uint64_t token) {  // leader.rs:177-197
+  uint64_t bid = 0;
+  uint32_t f = jg_chain_append(d, L, &bid);
+  if (f) return f;
+  jg_emit_fsm(L, JG_FSM_NOTIFY, bid, token);                               // :184-188
+  return jg_leader_append_response(d, L, jg_self_id(d, L), L.head);        // :190-196
+}
+__device__ inline uint32_t jg_leader_replicate(const JgDev& d, JgLane& L) {  // leader.rs:124-174
+  uint32_t self = jg_self(L);
+  bool key_in_range = (L.flags & JGF_COMMIT_KEY) && !(d.cfg_flags & JG_CFG_SEPARATE_COMMIT_KEY);
+  for (uint32_t r = 0; r < d.R; r++) {  // config.nodes: the other slots in ascending order
+    if (r == self) continue;
+    bool repl = (L.flags >> (JGF_REPL_SHIFT + r)) & 1u;
+    uint32_t want = repl ? JG_MAX_INFLIGHT + 1 : 2;  // items consumed by skip(1).take(5) / nth(1)
+    uint64_t from = d.match[(size_t)r * d.G + L.g];
+    uint32_t k = jg_chain_blocks_from(d, L, from, want);
+    if (k < want && key_in_range) return JG_FAULT_RANGE_HIT_COMMIT_KEY;  // chain.rs:219-226 (Q9)
+    uint32_t n_blocks = k ? k - 1 : 0;
+    jg_emit_msg(d, L, JG_CMD_APPEND_ENTRIES, JG_TO_PEER, d.node_ids[r], 0, L.term, from, n_blocks);
+  }
+  return 0;
+}
+__device__ inline uint32_t jg_leader_tick(const JgDev& d, JgLane& L) {  // leader.rs:234-245
+  if ((L.now - L.heartbeat_time) > (uint64_t)d.hb_timeout) {            // :78-80
+    jg_send_heartbeat(d, L);
+    L.heartbeat_time = L.now;                                           // :82-84
+  }
+  return jg_leader_replicate(d, L);
+}
+
+// ---- Candidate (src/raft/candidate.rs) + Election (src/raft/election.rs) -----------------
+// 0 = Voting, 1 = Elected, 2 = Defeated (election.rs:37-57, quorum_size 66-73)
+__device__ inline uint32_t jg_election_status(const JgDev& d, const JgLane& L) {
+  uint32_t seen = L.votes & 0xffu, granted = (L.votes >> 8) & 0xffu;
+  uint32_t yes = __popc(granted & seen), total = __popc(seen);
+  uint32_t quorum = d.R == 1 ? 0u : d.R / 2 + 1;
+  if (yes >= quorum) return 1;
+  if (total - yes == quorum) return 2;
+  return 0;
+}
+__device__ inline uint32_t jg_candidate_vote_response(const JgDev& d, JgLane& L, bool granted, uint32_t from) {
+  // candidate.rs:91-98
+  int s = jg_slot_of(d, from);
+  if (s < 0) return JG_FAULT_ENGINE_FOREIGN_VOTER;
+  uint32_t bit = 1u << s;
+  L.votes |= bit;                                                         // election.rs:33-35
+  L.votes = granted ? (L.votes | (bit << 8)) : (L.votes & ~(bit << 8));
+  L.decisions++;
+  switch (jg_election_status(d, L)) {
+    case 1:  // elect(): candidate.rs:108-113
+      jg_become_leader(d, L);
+      jg_send_heartbeat(d, L);
+      return 0;
+    case 0: return 0;
+    default:  // defeat(): candidate.rs:101-105
+      L.flags &= ~JGF_VOTED;
+      L.voted_for = 0;
+      jg_follower_from_candidate(L);
+      return 0;
+  }
+}
+__device__ inline uint32_t jg_seek_election(const JgDev& d, JgLane& L) {  // candidate.rs:24-45
+  jg_vote_for(L, jg_self_id(d, L));                                       // :25
+  L.term += 1;                                                            // :26
+  for (uint32_t i = 0; i + 1 < d.R; i++)                                  // :30-37, one broadcast per peer
+    jg_emit_msg(d, L, JG_CMD_VOTE_REQUEST, JG_TO_PEERS, 0, 0, L.term, L.head, L.term);
+  return jg_candidate_vote_response(d, L, true, jg_self_id(d, L));        // :40-44
+}
+__device__ inline uint32_t jg_follower_timeout(const JgDev& d, JgLane& L) {  // follower.rs:248-256
+  if (!(L.flags & JGF_VOTED)) {
+    jg_set_election_timeout(d, L);
+    jg_become_candidate(d, L);
+    return jg_seek_election(d, L);
+  }
+  return 0;
+}
+__device__ inline uint32_t jg_candidate_tick(const JgDev& d, JgLane& L) {  // candidate.rs:48-68
+  if (jg_needs_election(L)) {
+    if (jg_election_status(d, L) == 1) return JG_FAULT_CANDIDATE_TICK_ELECTED;  // :64
+    L.flags &= ~JGF_VOTED;  // :53 / :59
+    L.voted_for = 0;
+    jg_follower_from_candidate(L);
+    return jg_follower_timeout(d, L);
+  }
+  return 0;
+}
+
+// ---- Follower (src/raft/follower.rs) -------------------------------------------------
+struct JgCmd {
+  uint32_t kind, from, flag;
+  uint64_t term, id, aux;
+};
+
+__device__ inline uint32_t jg_follower_append_entries(const JgDev& d, JgLane& L, const JgCmd& c,
+                                                      const uint64_t* blk_id, const uint64_t* blk_next) {
+  // follower.rs:130-176
+  if (!(L.flags & JGF_VOTED) && c.term >= L.term) {  // :137
+    jg_set_term(L, c.term);                          // :138
+    L.election_time = L.now;                         // :141
+    L.flags |= JGF_HAS_LEADER;                       // :142
+    L.leader_id = c.from;
+    jg_vote_for(L, c.from);                          // :143
+  }
+  if ((L.flags & JGF_VOTED) && L.voted_for != c.from && c.term < L.term)  // :147-154
+    return JG_FAULT_FOLLOWER_STALE_LEADER;
+  if (c.aux) {  // :157
+    for (uint64_t k = 0; k < c.aux; k++) {
+      uint32_t f = jg_chain_extend(d, L, blk_id[c.id + k], blk_next[c.id + k]);  // :159
+      if (f) return f;
+    }
+    jg_emit_msg(d, L, JG_CMD_APPEND_RESPONSE, JG_TO_PEER, c.from, 1, L.term, L.head, 0);  // :163-172
+  }
+  return 0;
+}
+__device__ inline uint32_t jg_follower_heartbeat(const JgDev& d, JgLane& L, uint32_t leader, uint64_t term,
+                                                 uint64_t commit) {
+  // follower.rs:178-217
+  jg_set_election_timeout(d, L);  // :184
+  jg_set_term(L, term);           // :185 (unconditional)
+  L.flags |= JGF_HAS_LEADER;      // :186
+  L.leader_id = leader;
+  jg_vote_for(L, leader);         // :187
+  if (L.queued) {                 // :190-197
+    jg_emit_msg(d, L, JG_CMD_CLIENT_REQUEST, JG_TO_PEER, leader, JG_QUEUE_FLUSH, 0, 0, L.queued);
+    L.queued = 0;
+  }
+  bool has_committed = jg_chain_has(d, L, commit);  // :200
+  if (has_committed && commit > L.commit) {         // :201
+    uint64_t prev = L.commit;
+    uint32_t f = jg_chain_commit(d, L, commit);     // :203
+    if (f) return f;
+    jg_emit_fsm(L, JG_FSM_APPLY_FOLLOWER, prev, commit);  // :204-206, half-open range(prev..commit)
+  }
+  jg_emit_msg(d, L, JG_CMD_HEARTBEAT_RESPONSE, JG_TO_PEER, leader, has_committed ? 1 : 0, 0, L.commit, 0);
+  return 0;
+}
+__device__ inline uint32_t jg_follower_vote_request(const JgDev& d, JgLane& L, uint32_t cand, uint64_t last_term,
+                                                    uint64_t head) {
+  // follower.rs:219-246 with can_vote 97-101
+  bool can = !((L.flags & JGF_VOTED) || L.term > last_term || L.commit > head);
+  jg_emit_msg(d, L, JG_CMD_VOTE_RESPONSE, JG_TO_PEER, cand, can ? 1 : 0, L.term, 0, 0);
+  if (can) jg_vote_for(L, cand);  // :234
+  return 0;
+}
+__device__ inline void jg_enqueue(const JgDev& d, JgLane& L, uint64_t token) {
+  jg_emit_msg(d, L, JG_CMD_CLIENT_REQUEST, JG_TO_QUEUE, 0, 0, 0, token, 0);
+  L.queued++;
+}
+
+__device__ inline uint32_t jg_follower_apply(const JgDev& d, JgLane& L, const JgCmd& c, const uint64_t* blk_id,
+                                             const uint64_t* blk_next) {  // follower.rs:36-64
+  switch (c.kind) {
+    case JG_CMD_TICK: return jg_needs_election(L) ? jg_follower_timeout(d, L) : 0;  // :121-128
+    case JG_CMD_APPEND_ENTRIES: return jg_follower_append_entries(d, L, c, blk_id, blk_next);
+    case JG_CMD_HEARTBEAT: return jg_follower_heartbeat(d, L, c.from, c.term, c.id);
+    case JG_CMD_VOTE_REQUEST: return jg_follower_vote_request(d, L, c.from, c.aux, c.id);
+    case JG_CMD_TIMEOUT: return jg_follower_timeout(d, L);
+    case JG_CMD_CLIENT_REQUEST:  // :258-270
+      if (L.flags & JGF_HAS_LEADER)
+        jg_emit_msg(d, L, JG_CMD_CLIENT_REQUEST, JG_TO_PEER, L.leader_id, 0, 0, c.id, 0);
+      else
+        jg_enqueue(d, L, c.id);
+      return 0;
+    case JG_CMD_CLIENT_RESPONSE:  // :272-282
+      jg_emit_msg(d, L, JG_CMD_CLIENT_RESPONSE, JG_TO_CLIENT, 0, 0, 0, c.id, 0);
+      return 0;
+    default: return 0;  // apply_self
+  }
+}
+__device__ inline uint32_t jg_candidate_apply(const JgDev& d, JgLane& L, const JgCmd& c) {  // candidate.rs:170-196
+  switch (c.kind) {
+    case JG_CMD_TICK: return jg_candidate_tick(d, L);
+    case JG_CMD_VOTE_REQUEST:  // :71-88
+      if (c.term > L.term) {
+        jg_set_term(L, c.term);
+        jg_follower_from_candidate(L);
+        return 0;
+      }
+      jg_emit_msg(d, L, JG_CMD_VOTE_RESPONSE, JG_TO_PEER, c.from, 0, L.term, 0, 0);
+      return 0;
+    case JG_CMD_VOTE_RESPONSE: return jg_candidate_vote_response(d, L, c.flag != 0, c.from);
+    case JG_CMD_APPEND_ENTRIES:  // :116-134
+      if (c.term >= L.term) jg_follower_from_candidate(L);
+      return 0;
+    case JG_CMD_HEARTBEAT: {  // :137-157
+      bool has_committed = jg_chain_has(d, L, c.id);
+      uint64_t own = L.commit;
+      jg_set_term(L, c.term);
+      jg_vote_for(L, c.from);
+      jg_follower_from_candidate(L);
+      jg_emit_msg(d, L, JG_CMD_HEARTBEAT_RESPONSE, JG_TO_PEER, c.from, has_committed ? 1 : 0, 0, own, 0);
+      return 0;
+    }
+    case JG_CMD_CLIENT_REQUEST:  // :190-193
+      jg_enqueue(d, L, c.id);
+      return 0;
+    default: return 0;
+  }
+}
+__device__ inline uint32_t jg_leader_apply(const JgDev& d, JgLane& L, const JgCmd& c) {  // leader.rs:248-266
+  switch (c.kind) {
+    case JG_CMD_TICK: return jg_leader_tick(d, L);
+    case JG_CMD_HEARTBEAT_RESPONSE:  // :222-231
+      return (!c.flag && c.id > 0) ? jg_leader_replicate(d, L) : 0;
+    case JG_CMD_APPEND_RESPONSE: return jg_leader_append_response(d, L, c.from, c.id);
+    case JG_CMD_APPEND_ENTRIES:  // :200-208
+      if (c.term > L.term) {
+        uint32_t f = jg_set_term(L, c.term);  // unimplemented!() (Q3)
+        if (f) return f;
+        jg_follower_from_leader(L);
+      }
+      return 0;
+    case JG_CMD_CLIENT_REQUEST: return jg_leader_client_request(d, L, c.id);
+    default: return 0;
+  }
+}
+
+// process restart: Raft::<Follower>::new (follower.rs:68-95) on the persisted chain
+__device__ inline void jg_restart(const JgDev& d, JgLane& L) {
+  L.flags &= ~(JGF_FAULT_MASK | JGF_ROLE_MASK | JGF_VOTED | JGF_HAS_LEADER | JGF_REPL_MASK);
+  uint32_t f = jg_chain_reopen(d, L);
+  L.term = 0;
+  L.voted_for = 0;
+  L.leader_id = 0;
+  L.queued = 0;
+  L.votes = 0;
+  L.heartbeat_time = 0;
+  jg_set_election_timeout(d, L);
+  if (f) jg_raise(d, L, f);
+}
+
+// RaftHandle::apply, mod.rs:471-479
+__device__ inline void jg_apply(const JgDev& d, JgLane& L, const JgCmd& c, const uint64_t* blk_id,
+                                const uint64_t* blk_next) {
+  if (c.kind == JG_CMD_RESTART) {
+    jg_restart(d, L);
+    return;
+  }
+  if (jg_fault(L)) return;  // the reference process is gone
+  uint32_t f;
+  switch (jg_role(L)) {
+    case JG_ROLE_FOLLOWER: f = jg_follower_apply(d, L, c, blk_id, blk_next); break;
+    case JG_ROLE_CANDIDATE: f = jg_candidate_apply(d, L, c); break;
+    default: f = jg_leader_apply(d, L, c); break;
+  }
+  if (f) jg_raise(d, L, f);
+}

@@ -1,0 +1,58 @@
+"""Random command traces for parity fuzzing.  Values are drawn near the current
+state of the *oracle* (terms around current_term, ids around head, node ids from
+the membership plus an occasional stranger) so that every branch of every role
+is reached, including the reference's panic / Err paths."""
+import numpy as np
+
+from josefine_amd import capi
+
+KINDS = [capi.CMD_TICK, capi.CMD_PROPOSE, capi.CMD_VOTE_REQUEST, capi.CMD_VOTE_RESPONSE,
+         capi.CMD_APPEND_ENTRIES, capi.CMD_APPEND_RESPONSE, capi.CMD_HEARTBEAT,
+         capi.CMD_HEARTBEAT_RESPONSE, capi.CMD_TIMEOUT, capi.CMD_NOOP, capi.CMD_CLIENT_REQUEST,
+         capi.CMD_CLIENT_RESPONSE, capi.CMD_RESTART]
+# weights: keep RESTART / TIMEOUT rare enough that leaders live for a while
+WEIGHTS = np.array([6, 1, 6, 10, 10, 16, 8, 4, 3, 1, 12, 2, 1], dtype=np.float64)
+WEIGHTS /= WEIGHTS.sum()
+
+
+def random_batch(rng: np.random.Generator, ora, n: int, foreign_voters: bool = False):
+    """n random command rows + block side arrays, as kwargs for submit_columns."""
+    G, R = ora.G, ora.R
+    ids = np.array(ora.node_ids, dtype=np.uint32)
+    term_now = ora.read("term").astype(np.int64)
+    head_now = ora.read("head").astype(np.int64)
+    commit_now = ora.read("commit").astype(np.int64)
+    group = rng.integers(0, G, n).astype(np.uint32)
+    kind = rng.choice(KINDS, size=n, p=WEIGHTS).astype(np.uint8)
+    from_ = ids[rng.integers(0, R, n)]
+    stranger = rng.random(n) < 0.02
+    if not foreign_voters:
+        stranger &= kind != capi.CMD_VOTE_RESPONSE
+    from_ = np.where(stranger, np.uint32(4242), from_).astype(np.uint32)
+    term = np.maximum(term_now[group] + rng.integers(-1, 3, n), 0).astype(np.uint64)
+    idv = np.maximum(head_now[group] + rng.integers(-2, 3, n), 0)
+    use_commit = rng.random(n) < 0.3
+    idv = np.where(use_commit, np.maximum(commit_now[group] + rng.integers(-1, 2, n), 0), idv).astype(np.uint64)
+    aux = np.maximum(term_now[group] + rng.integers(-1, 2, n), 0).astype(np.uint64)  # last_term
+    flag = (rng.random(n) < 0.7).astype(np.uint8)
+    blk_id, blk_next = [], []
+    id_col = idv.copy()
+    for i in np.nonzero(kind == capi.CMD_APPEND_ENTRIES)[0]:
+        nb = int(rng.integers(0, 4))
+        id_col[i] = len(blk_id)
+        aux[i] = nb
+        h = int(head_now[group[i]])
+        for _ in range(nb):
+            r = rng.random()
+            if r < 0.75:       # regular extension of the follower's chain
+                nid, nxt = h + 1, h
+            elif r < 0.9:      # fork / gap with an existing parent
+                nid, nxt = h + int(rng.integers(1, 4)), max(h - int(rng.integers(0, 2)), 0)
+            else:              # missing parent -> Err (chain.rs:180-185)
+                nid, nxt = h + 2, h + 7
+            blk_id.append(nid)
+            blk_next.append(nxt)
+            h = nid
+        head_now[group[i]] = h  # keep later rows of this batch plausible
+    return dict(kind=kind, group=group, from_=from_, term=term, id=id_col, aux=aux, flag=flag,
+                blk_id=np.array(blk_id, dtype=np.uint64), blk_next=np.array(blk_next, dtype=np.uint64))
