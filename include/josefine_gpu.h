@@ -37,7 +37,7 @@ extern "C" {
 
 #define JG_ABI_VERSION 1u
 #define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
-#define JG_CHAIN_WINDOW 8u  /* explicit (id,next) entries per group besides the dense run  */
+#define JG_CHAIN_WINDOW 8u  /* chain segments (gaps / forks) per group besides the main run */
 #define JG_MAX_INFLIGHT 5u  /* src/raft/progress.rs:117                                    */
 #define JG_NO_ACK UINT64_MAX /* dense ack column: "no AppendResponse from this replica"    */
 
@@ -122,9 +122,8 @@ enum {
   JG_FAULT_FOLLOWER_STALE_LEADER = 6,     /* follower.rs:147-154 assert!                           */
   JG_FAULT_CANDIDATE_TICK_ELECTED = 7,    /* candidate.rs:64 panic!("this should never happen")    */
   JG_FAULT_RANGE_HIT_COMMIT_KEY = 8,      /* chain.rs:198 + 219-226 via leader.rs:135,152-157 (Q9) */
-  JG_FAULT_ENGINE_WINDOW_OVERFLOW = 128,  /* > JG_CHAIN_WINDOW irregular blocks in one group       */
+  JG_FAULT_ENGINE_WINDOW_OVERFLOW = 128,  /* chain needs > JG_CHAIN_WINDOW segments (gaps / forks) */
   JG_FAULT_ENGINE_FOREIGN_VOTER = 129,    /* VoteResponse.from not in the configured membership    */
-  JG_FAULT_ENGINE_TOO_MANY_BLOCKS = 130,  /* AppendEntries with more than 2*JG_MAX_INFLIGHT blocks */
   JG_FAULT_ENGINE_DENSE_NONLEADER = 131   /* dense tick asked a non-leader group to append         */
 };
 

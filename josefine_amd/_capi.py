@@ -1,10 +1,9 @@
 """ctypes view of include/josefine_gpu.h.
 
 The same table binds any shared library that exports the ABI under a symbol
-prefix: the shipped HIP engine uses ``jg_``; tests bind the CPU oracle
-(``oracle/libjosefine_oracle.so``, prefix ``jo_``) through the very same table
-so both are driven by identical code.  This module never loads the oracle
-itself.
+prefix: the shipped HIP engine uses ``jg_``; the test-suite binds its CPU
+checker (prefix ``jo_``) through the very same table so both are driven by
+identical code.  Nothing in this package loads that checker.
 """
 from __future__ import annotations
 
@@ -38,7 +37,6 @@ FAULT_CANDIDATE_TICK_ELECTED = 7
 FAULT_RANGE_HIT_COMMIT_KEY = 8
 FAULT_ENGINE_WINDOW_OVERFLOW = 128
 FAULT_ENGINE_FOREIGN_VOTER = 129
-FAULT_ENGINE_TOO_MANY_BLOCKS = 130
 FAULT_ENGINE_DENSE_NONLEADER = 131
 
 CFG_SEPARATE_COMMIT_KEY = 1

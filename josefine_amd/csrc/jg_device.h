@@ -12,14 +12,14 @@
 //  bits 0-1   role (JG_ROLE_*)                                   mod.rs:417-425
 //  bit  2     voted_for.is_some()                                mod.rs:279
 //  bit  3     Follower.leader_id.is_some()                       follower.rs:20
-//  bit  4     FAST chain: run_hi == head, id_gen == head+1, no explicit window
-//             entries -> the id set is exactly [0, head]; the id_gen / run_hi
-//             columns are then implicit (possibly stale in memory)
+//  bit  4     FAST chain: run_hi == head, id_gen == head+1, no extra segments
+//             -> the id set is exactly [0, head]; the id_gen / run_hi columns
+//             are then implicit (possibly stale in memory)
 //  bit  5     the "commit" key has been persisted               chain.rs:198
 //  bits 8-15  bit r: progress of slot r is Replicate (else Probe) progress.rs:62-66
 //  bits 16-23 sticky fault code (JG_FAULT_*)
 //  bits 24-26 own replica slot
-//  bits 28-31 number of explicit chain-window entries (0..JG_CHAIN_WINDOW)
+//  bits 28-31 number of chain segments besides the run (0..JG_CHAIN_WINDOW)
 #define JGF_ROLE_MASK 0x3u
 #define JGF_VOTED (1u << 2)
 #define JGF_HAS_LEADER (1u << 3)
@@ -52,12 +52,13 @@ struct JgDev {
   uint64_t* commit;          // Chain.commit                           chain.rs:102
   uint64_t* head;            // Chain.head                             chain.rs:103
   uint64_t* id_gen;          // Chain.id_gen (valid unless FAST)       chain.rs:101
-  uint64_t* run_hi;          // ids [0, run_hi] exist with next = id-1 (valid unless FAST)
+  uint64_t* run_hi;          // segment 0: ids [0, run_hi], next = id-1 (valid unless FAST)
   uint64_t* match;           // [R][G] Progress.head                   progress.rs:124
   uint64_t* election_time;   // State.election_time (ms)               mod.rs:281
   uint64_t* heartbeat_time;  // Leader.heartbeat_time (ms)             leader.rs:27
-  uint64_t* win_id;          // [W][G] explicit chain entries: id
-  uint64_t* win_next;        // [W][G]                          ...and parent pointer
+  uint64_t* win_lo;          // [W][G] chain segments besides the run: first id,
+  uint64_t* win_hi;          // [W][G]   last id,
+  uint64_t* win_next;        // [W][G]   parent pointer of the first id
   uint32_t* flags;
   uint32_t* voted_for;       // State.voted_for                        mod.rs:279
   uint32_t* leader_id;       // Follower.leader_id                     follower.rs:20
@@ -199,38 +200,79 @@ __device__ inline void jg_emit_fsm(JgLane& L, uint8_t kind, uint64_t a, uint64_t
 }
 
 // ---- Chain (src/raft/chain.rs:99-254) ------------------------------------------------
-// Id set = [0, run_hi] (each id with next = id-1, genesis next = 0) plus up to
-// JG_CHAIN_WINDOW explicit (id,next) entries, which take precedence.
-__device__ inline int jg_win_find(const JgDev& d, const JgLane& L, uint64_t id) {
+// The id set is a union of disjoint *segments* [lo, hi]: every id in a segment
+// exists, next(lo) = lo_next and next(id) = id-1 for lo < id <= hi.  Segment 0 is
+// the implicit run [0, run_hi] (genesis, next(0) = 0); up to JG_CHAIN_WINDOW more
+// live in the win_* columns.  A chain built by in-order appends / extends is one
+// run; each gap or fork costs one segment.
+#define JG_SEG(col, w) d.col[(size_t)(w) * d.G + L.g]
+__device__ inline int jg_seg_find(const JgDev& d, const JgLane& L, uint64_t id) {
   uint32_t n = jg_wcnt(L);
   for (uint32_t w = 0; w < n; w++)
-    if (d.win_id[(size_t)w * d.G + L.g] == id) return (int)w;
+    if (JG_SEG(win_lo, w) <= id && id <= JG_SEG(win_hi, w)) return (int)w;
   return -1;
 }
 __device__ inline bool jg_chain_has(const JgDev& d, const JgLane& L, uint64_t id) {  // chain.rs:155-157
   if (id <= L.run_hi) return true;
-  return jg_win_find(d, L, id) >= 0;
+  return jg_seg_find(d, L, id) >= 0;
+}
+__device__ inline uint32_t jg_seg_add(const JgDev& d, JgLane& L, uint64_t lo, uint64_t hi, uint64_t lo_next) {
+  uint32_t n = jg_wcnt(L);
+  if (n >= JG_CHAIN_WINDOW) return JG_FAULT_ENGINE_WINDOW_OVERFLOW;
+  JG_SEG(win_lo, n) = lo;
+  JG_SEG(win_hi, n) = hi;
+  JG_SEG(win_next, n) = lo_next;
+  L.flags = (L.flags & ~JGF_WIN_MASK) | ((n + 1) << JGF_WIN_SHIFT);
+  return 0;
+}
+// make `id` (which exists) the first id of its segment
+__device__ inline uint32_t jg_seg_split_at(const JgDev& d, JgLane& L, uint64_t id) {
+  if (id <= L.run_hi) {
+    if (id == 0) return 0;
+    uint64_t hi = L.run_hi;
+    L.run_hi = id - 1;
+    return jg_seg_add(d, L, id, hi, id - 1);
+  }
+  int w = jg_seg_find(d, L, id);
+  if (JG_SEG(win_lo, w) == id) return 0;
+  uint64_t hi = JG_SEG(win_hi, w);
+  JG_SEG(win_hi, w) = id - 1;
+  return jg_seg_add(d, L, id, hi, id - 1);
 }
 // sled insert (upsert) of Block{id,next}; returns an engine fault or 0
 __device__ inline uint32_t jg_chain_insert(const JgDev& d, JgLane& L, uint64_t id, uint64_t next) {
-  int w = jg_win_find(d, L, id);
-  if (w >= 0) {
-    d.win_next[(size_t)w * d.G + L.g] = next;
+  if (jg_chain_has(d, L, id)) {
+    uint64_t cur;
+    if (id <= L.run_hi) {
+      cur = id ? id - 1 : 0;
+    } else {
+      int w = jg_seg_find(d, L, id);
+      cur = JG_SEG(win_lo, w) == id ? JG_SEG(win_next, w) : id - 1;
+    }
+    if (cur == next) return 0;  // same block again (e.g. a re-sent AppendEntries)
+    // overwrite of an existing block's parent pointer: isolate [id, id]
+    if (id == 0) return JG_FAULT_ENGINE_WINDOW_OVERFLOW;  // genesis parent is implicit
+    uint32_t f = jg_seg_split_at(d, L, id);
+    if (f) return f;
+    int w = jg_seg_find(d, L, id);
+    if (JG_SEG(win_hi, w) > id) {
+      f = jg_seg_split_at(d, L, id + 1);
+      if (f) return f;
+    }
+    JG_SEG(win_next, w) = next;
     return 0;
   }
-  if (id <= L.run_hi) {
-    uint64_t implicit = id ? id - 1 : 0;
-    if (next == implicit) return 0;
-  } else if (id == L.run_hi + 1 && next == L.run_hi) {
+  if (id == L.run_hi + 1 && next == L.run_hi) {
     L.run_hi = id;
     return 0;
   }
   uint32_t n = jg_wcnt(L);
-  if (n >= JG_CHAIN_WINDOW) return JG_FAULT_ENGINE_WINDOW_OVERFLOW;
-  d.win_id[(size_t)n * d.G + L.g] = id;
-  d.win_next[(size_t)n * d.G + L.g] = next;
-  L.flags = (L.flags & ~JGF_WIN_MASK) | ((n + 1) << JGF_WIN_SHIFT);
-  return 0;
+  for (uint32_t w = 0; w < n; w++)
+    if (JG_SEG(win_hi, w) + 1 == id && next == JG_SEG(win_hi, w)) {
+      JG_SEG(win_hi, w) = id;
+      return 0;
+    }
+  return jg_seg_add(d, L, id, id, next);
 }
 // number of block keys >= from, saturated at `cap` (unbounded range(from..), leader.rs:135,152-157)
 __device__ inline uint32_t jg_chain_blocks_from(const JgDev& d, const JgLane& L, uint64_t from, uint32_t cap) {
@@ -241,8 +283,11 @@ __device__ inline uint32_t jg_chain_blocks_from(const JgDev& d, const JgLane& L,
   }
   uint32_t n = jg_wcnt(L);
   for (uint32_t w = 0; w < n; w++) {
-    uint64_t id = d.win_id[(size_t)w * d.G + L.g];
-    if (id > L.run_hi && id >= from) k++;
+    uint64_t lo = JG_SEG(win_lo, w), hi = JG_SEG(win_hi, w);
+    if (hi >= from) {
+      uint64_t c = hi - (lo > from ? lo : from) + 1;
+      k = (k + c < k) ? UINT64_MAX : k + c;
+    }
   }
   return k >= cap ? cap : (uint32_t)k;
 }

@@ -270,7 +270,8 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.match, G * R);
   A(d.election_time, G);
   A(d.heartbeat_time, G);
-  A(d.win_id, G * JG_CHAIN_WINDOW);
+  A(d.win_lo, G * JG_CHAIN_WINDOW);
+  A(d.win_hi, G * JG_CHAIN_WINDOW);
   A(d.win_next, G * JG_CHAIN_WINDOW);
   A(d.flags, G);
   A(d.voted_for, G);

@@ -132,7 +132,7 @@ class BatchedRaft:
         cfg.abi_version = capi.ABI_VERSION
         cfg.n_groups = self.G
         cfg.n_replicas = self.R
-        for r, nid in enumerate(node_ids):
+        for r, nid in enumerate(list(node_ids)[:capi.MAX_REPLICAS]):
             cfg.node_ids[r] = int(nid)
         cfg.device_id = device_id
         cfg.heartbeat_timeout_ms = heartbeat_timeout_ms

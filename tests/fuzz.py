@@ -15,9 +15,14 @@ WEIGHTS = np.array([6, 1, 6, 10, 10, 16, 8, 4, 3, 1, 12, 2, 1], dtype=np.float64
 WEIGHTS /= WEIGHTS.sum()
 
 
-def random_batch(rng: np.random.Generator, ora, n: int, foreign_voters: bool = False):
-    """n random command rows + block side arrays, as kwargs for submit_columns."""
+def random_batch(rng: np.random.Generator, ora, n: int, foreign_voters: bool = False, budget=None):
+    """n random command rows + block side arrays, as kwargs for submit_columns.
+
+    `budget` ([G] int array, updated in place) bounds the gaps / forks generated per
+    group so that chains stay within the engine's JG_CHAIN_WINDOW segments."""
     G, R = ora.G, ora.R
+    if budget is None:
+        budget = np.full(G, 1 << 30)
     ids = np.array(ora.node_ids, dtype=np.uint32)
     term_now = ora.read("term").astype(np.int64)
     head_now = ora.read("head").astype(np.int64)
@@ -44,6 +49,11 @@ def random_batch(rng: np.random.Generator, ora, n: int, foreign_voters: bool = F
         h = int(head_now[group[i]])
         for _ in range(nb):
             r = rng.random()
+            if r >= 0.75 and r < 0.9:
+                if budget[group[i]] <= 0:
+                    r = 0.0
+                else:
+                    budget[group[i]] -= 1
             if r < 0.75:       # regular extension of the follower's chain
                 nid, nxt = h + 1, h
             elif r < 0.9:      # fork / gap with an existing parent

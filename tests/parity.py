@@ -9,7 +9,10 @@ from josefine_amd import BatchedRaft, Command, capi
 
 
 def compare_snapshots(dev: BatchedRaft, ora: BatchedRaft, what: str = "", fields=None) -> None:
-    names = fields or list(capi.FIELD_NAMES)
+    names = list(fields or capi.FIELD_NAMES)
+    if "fault" in names:  # report a fault mismatch before its consequences
+        names.remove("fault")
+        names.insert(0, "fault")
     for name in names:
         if name == "match":
             for r in range(dev.R):

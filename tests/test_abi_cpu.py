@@ -1,0 +1,127 @@
+"""CPU-side checks of the boundary: the C-ABI library builds, loads and exports every
+symbol include/josefine_gpu.h declares; without a GPU it refuses to run (there is
+no CPU fallback); the host mirror encodes Commands as the header specifies."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from josefine_amd import BatchedRaft, Command, EngineError, capi
+from josefine_amd.build import LIB, build_hip
+from oracle_lib import oracle_engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "josefine_gpu.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build_hip()  # hipcc cross-compiles gfx950 without a GPU
+    return C.CDLL(LIB)
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(jg_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_match_binding_table():
+    assert declared_symbols() == sorted(capi.HEADER_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+    lib.jg_abi_version.restype = C.c_uint32
+    assert lib.jg_abi_version() == capi.ABI_VERSION
+
+
+def test_library_contains_gfx950_code_object():
+    out = os.popen(f"/opt/rocm/lib/llvm/bin/llvm-readelf --notes {LIB} 2>/dev/null; strings {LIB} | grep -m1 gfx950").read()
+    assert "gfx950" in out
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the product path must fail loudly, not compute on the host."""
+    api = capi.Api(LIB, "jg_")
+    cfg = capi.Config()
+    cfg.abi_version, cfg.n_groups, cfg.n_replicas = capi.ABI_VERSION, 4, 1
+    cfg.node_ids[0] = 1
+    cfg.heartbeat_timeout_ms, cfg.election_timeout_min_ms, cfg.election_timeout_max_ms = 100, 500, 1000
+    h = C.c_void_p()
+    rc = api.engine_create(C.byref(cfg), C.byref(h))
+    if rc == capi.OK:  # a GPU is present (GPU box): nothing to check here
+        api.engine_destroy(h)
+        pytest.skip("GPU present")
+    assert rc == capi.EDEVICE
+    assert "no CPU fallback" in api.error() or "HIP" in api.error() or "hip" in api.error()
+
+
+def test_package_never_loads_the_oracle():
+    import josefine_amd
+    pkg = os.path.dirname(josefine_amd.__file__)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "raft_oracle" not in text and "libjosefine_oracle" not in text, f
+                assert "oracle_engine" not in text, f
+
+
+def test_row_struct_layouts_match_header():
+    assert np.dtype(capi.MSG_DTYPE).itemsize == 40
+    assert np.dtype(capi.FSM_DTYPE).itemsize == 24
+    assert np.dtype(capi.FAULT_DTYPE).itemsize == 8
+    assert C.sizeof(capi.Config) == 88  # 60 B of u32 fields, 4 B padding, 2 x u64, 2 x u32
+
+
+def test_command_constructors_use_header_columns():
+    c = Command.VoteRequest(term=7, candidate_id=3, last_term=6, head=9)
+    assert (c.kind, c.from_, c.term, c.id, c.aux) == (capi.CMD_VOTE_REQUEST, 3, 7, 9, 6)
+    c = Command.AppendResponse(node_id=2, term=1, head=5)
+    assert (c.kind, c.from_, c.id, c.flag) == (capi.CMD_APPEND_RESPONSE, 2, 5, 1)
+    c = Command.Heartbeat(term=4, commit=3, leader_id=2)
+    assert (c.kind, c.from_, c.term, c.id) == (capi.CMD_HEARTBEAT, 2, 4, 3)
+    c = Command.AppendEntries(1, 2, [(1, 0), (2, 1)])
+    assert c.blocks == [(1, 0), (2, 1)]
+
+
+def test_stream_order_across_submits_and_groups():
+    """Rows of one group apply in submit order, whatever the interleaving with other groups."""
+    e = oracle_engine(3, 3)
+    e.submit(2, Command.Timeout())
+    e.submit(0, Command.Timeout())
+    e.submit(2, Command.VoteResponse(1, 2, True))   # elected
+    e.submit(2, Command.ClientRequest(5))
+    e.submit(0, Command.VoteResponse(1, 2, False))
+    e.submit(2, Command.AppendResponse(3, 1, 1))    # commit 1
+    e.submit(0, Command.VoteResponse(1, 3, False))  # defeated
+    e.step()
+    assert list(e.read("role")) == [capi.ROLE_FOLLOWER, capi.ROLE_FOLLOWER, capi.ROLE_LEADER]
+    assert list(e.read("commit")) == [0, 0, 1]
+    m = e.drain_messages()
+    assert list(m["group"]) == sorted(m["group"])  # drained group-major, in emission order per group
+    assert [int(k) for k in m["kind"][m["group"] == 2]] == [capi.CMD_VOTE_REQUEST] * 2 + [capi.CMD_HEARTBEAT]
+
+
+def test_drain_capacity_contract():
+    e = oracle_engine(1, 3)
+    e.apply(0, Command.Timeout())
+    n = C.c_size_t(0)
+    assert e.api.drain_messages(e._h, None, 0, C.byref(n)) == capi.OK and n.value == 2
+    buf = np.zeros(1, dtype=capi.MSG_DTYPE)
+    assert e.api.drain_messages(e._h, buf.ctypes.data, 1, C.byref(n)) == capi.ECAPACITY
+    assert len(e.drain_messages()) == 2  # nothing was consumed by the failed call
+
+
+def test_submit_validation():
+    e = oracle_engine(2, 3)
+    with pytest.raises(EngineError):
+        e.submit_columns([capi.CMD_TICK], [5])            # group out of range
+    with pytest.raises(EngineError):
+        e.submit_columns([99], [0])                       # unknown kind
+    with pytest.raises(EngineError):
+        e.submit_columns([capi.CMD_APPEND_ENTRIES], [0], id=[0], aux=[3], blk_id=[1], blk_next=[0])

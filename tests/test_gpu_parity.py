@@ -44,8 +44,9 @@ def test_fuzz_command_stream_parity(R):
     dev, ora = pair(G, R, seed=99, flags=capi.CFG_SEPARATE_COMMIT_KEY if R == 5 else 0)
     rng = np.random.default_rng(1234 + R)
     now = 0
+    budget = np.full(G, capi.CHAIN_WINDOW - 2)  # gaps / forks per group: stay inside the segment window
     for step in range(60):
-        batch = random_batch(rng, ora, 1500)
+        batch = random_batch(rng, ora, 1500, budget=budget)
         now += int(rng.integers(0, 400))
         for e in (dev, ora):
             e.submit_columns(**batch)

@@ -1,0 +1,474 @@
+"""Known-answer tests.
+
+Part 1 ports every test of the reference's own test modules that touches the hot
+path; each test cites the reference test it restates and
+asserts the same facts through the same driver surface (`apply(Command)`,
+drained rpc / fsm output).  Part 2 holds the hand-derived vectors of SURVEY.md
+§8(c) for what the reference leaves untested (every multi-replica result —
+"parity unpinned" by the reference).
+
+Every test runs against the CPU oracle (always) and against the HIP engine
+through the C ABI (`-m gpu`).
+"""
+import numpy as np
+import pytest
+
+from josefine_amd import BatchedRaft, Command, EngineError, capi
+from oracle_lib import oracle_engine
+
+BACKENDS = ["oracle", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def make(request):
+    def _make(G=1, R=1, **kw):
+        return oracle_engine(G, R, **kw) if request.param == "oracle" else BatchedRaft(G, R, **kw)
+
+    return _make
+
+
+def new_follower(make, R=1, **kw):
+    """raft::test::new_follower (src/raft/test/mod.rs:21-29); id pinned to 1."""
+    e = make(1, R, **kw)
+    return e, e.handle(0)
+
+
+def new_leader(make, R):
+    """Leader of an R-replica group at term 1 (slot 0 = id 1; votes from ids 2..)."""
+    e, h = new_follower(make, R)
+    h.apply(Command.Timeout())
+    for nid in range(2, 2 + R // 2):
+        h.apply(Command.VoteResponse(1, nid, True))
+    assert h.is_leader()
+    e.drain_messages(), e.drain_applies()
+    return e, h
+
+
+def msgs(e):
+    return [dict(kind=int(m["kind"]), to_kind=int(m["to_kind"]), to_id=int(m["to_id"]), frm=int(m["from"]),
+                 term=int(m["term"]), id=int(m["id"]), aux=int(m["aux"]), flag=int(m["flag"]))
+            for m in e.drain_messages()]
+
+
+def fsm(e):
+    return [(int(r["kind"]), int(r["a"]), int(r["b"])) for r in e.drain_applies()]
+
+
+# ===================== Part 1: the reference's own tests =====================
+
+def test_chain_new(make):  # src/raft/chain.rs:262-267
+    e, h = new_follower(make)
+    assert h.commit == 0 and h.head == 0
+
+
+def test_chain_append(make):  # src/raft/chain.rs:270-276 (via the only caller, leader.rs:180)
+    e, h = new_leader(make, 3)
+    h.apply(Command.ClientRequest(9))
+    assert h.commit == 0 and h.head == 1
+
+
+def test_chain_commit(make):  # src/raft/chain.rs:279-286 (via leader.rs:87-99)
+    e, h = new_leader(make, 3)
+    h.apply(Command.ClientRequest(9))
+    h.apply(Command.AppendResponse(2, 1, 1))
+    assert h.commit == 1 and h.head == 1
+
+
+def test_chain_extend(make):  # src/raft/chain.rs:289-299 (via follower.rs:158-160)
+    e, h = new_follower(make, 3)
+    h.apply(Command.AppendEntries(0, 2, [(1, 0)]))
+    assert h.commit == 0 and h.head == 1
+
+
+def test_chain_range_and_has(make):  # src/raft/chain.rs:302-325
+    e, h = new_follower(make, 3)
+    h.apply(Command.AppendEntries(0, 2, [(1, 0)]))
+    e.drain_messages()
+    # has(1): a heartbeat naming commit 1 finds the block (follower.rs:200) ...
+    h.apply(Command.Heartbeat(0, 1, 2))
+    (hb,) = msgs(e)
+    assert hb["kind"] == capi.CMD_HEARTBEAT_RESPONSE and hb["flag"] == 1 and hb["id"] == 1
+    # ... and range(prev..commit) covered genesis only (half-open, follower.rs:204)
+    assert fsm(e) == [(capi.FSM_APPLY_FOLLOWER, 0, 1)]
+    # has(7) is false
+    h.apply(Command.Heartbeat(0, 7, 2))
+    assert msgs(e)[0]["flag"] == 0
+
+
+def test_chain_compact_reference_vector(make):  # src/raft/chain.rs:328-343 — the only walk vector
+    e, _ = new_follower(make)
+    tree = [(1, 0), (2, 1), (3, 2), (4, 3), (5, 3), (6, 5)]
+    (removed,) = e.chain_compact([([(0, 0)] + tree, 6)])
+    ids = [0] + [b[0] for b in tree]
+    assert [i for i, r in zip(ids, removed) if r] == [4]
+
+
+def test_block_id_order_is_numeric():  # src/raft/chain.rs:29-36,63-67: 8-byte BE bytes order == u64 order
+    vals = [0, 1, 255, 256, 65535, 65536, 2**32, 2**56, 2**63]
+    be = [v.to_bytes(8, "big") for v in vals]
+    assert sorted(be) == be
+
+
+def test_progress_starts_in_probe_and_increments_to_higher(make):  # src/raft/progress.rs:243-269
+    e, h = new_leader(make, 3)
+    assert e.read("repl_state")[0] == 0  # all Probe
+    h.apply(Command.AppendResponse(2, 1, 666))
+    assert h.match(1) == 666
+    assert e.read("repl_state")[0] == 0b010  # Probe -> Replicate on increment
+    assert h.commit == 0  # [666, 0, 0] sorted desc, index 1 -> 0
+
+
+def test_progress_cannot_construct_empty(make):  # src/raft/progress.rs:271-275
+    with pytest.raises(EngineError):
+        make(1, 0)
+
+
+def test_mod_need_election_and_follower_apply_tick(make):  # src/raft/mod.rs:515-532, follower.rs:405-414
+    e, h = new_follower(make)
+    timeout = int(e.read("election_timeout")[0])
+    assert 500 <= timeout < 1000  # mod.rs:318-319, follower.rs:103-108
+    h.apply(Command.Tick(), now_ms=timeout)  # elapsed == timeout: not yet (mod.rs:354 `>`)
+    assert h.is_follower()
+    h.apply(Command.Tick(), now_ms=timeout + 1)
+    assert h.is_leader()  # single node: straight to leader
+
+
+def test_mod_send_all(make):  # src/raft/mod.rs:534-553: broadcast shape from=Peer(id), to=Peers
+    e, h = new_follower(make, 3)
+    h.apply(Command.Timeout())
+    out = msgs(e)
+    assert len(out) == 2  # one broadcast per configured peer (candidate.rs:30-37)
+    for m in out:
+        assert m["kind"] == capi.CMD_VOTE_REQUEST and m["to_kind"] == capi.TO_PEERS and m["frm"] == 1
+
+
+def test_mod_term(make):  # src/raft/mod.rs:555-569: term() sets current_term, clears voted_for
+    e, h = new_follower(make, 3)
+    h.apply(Command.VoteRequest(1, 2, 1, 0))
+    assert h.voted_for == 2
+    h.apply(Command.Heartbeat(11, 0, 3))
+    assert h.current_term == 11 and h.voted_for == 3
+
+
+def test_follower_to_leader(make):  # src/raft/follower.rs:316-324
+    e, h = new_follower(make)
+    assert h.apply(Command.Timeout()).is_leader()
+    assert h.id == 1
+
+
+def test_follower_noop(make):  # src/raft/follower.rs:327-335
+    e, h = new_follower(make)
+    assert h.apply(Command.Noop()).is_follower()
+
+
+def test_follower_apply_heartbeat(make):  # src/raft/follower.rs:338-358
+    e, h = new_follower(make)
+    h.apply(Command.Heartbeat(term=12, commit=1, leader_id=11))
+    assert h.voted_for == 11 and h.current_term == 12
+    (m,) = msgs(e)
+    # "but we don't have block 1 in our chain"
+    assert m["kind"] == capi.CMD_HEARTBEAT_RESPONSE and m["id"] == 0 and m["flag"] == 0
+    assert m["to_kind"] == capi.TO_PEER and m["to_id"] == 11
+
+
+def test_follower_apply_vote_request(make):  # src/raft/follower.rs:361-395
+    e, h = new_follower(make)
+    h.apply(Command.VoteRequest(term=12, candidate_id=11, last_term=12, head=1))
+    assert h.voted_for == 11
+    (m,) = msgs(e)
+    assert (m["kind"], m["term"], m["frm"], m["flag"]) == (capi.CMD_VOTE_RESPONSE, 0, 1, 1)
+    # "we already voted"
+    h.apply(Command.VoteRequest(term=12, candidate_id=11, last_term=12, head=1))
+    (m,) = msgs(e)
+    assert (m["kind"], m["term"], m["frm"], m["flag"]) == (capi.CMD_VOTE_RESPONSE, 0, 1, 0)
+
+
+def test_follower_apply_timeout(make):  # src/raft/follower.rs:398-403
+    e, h = new_follower(make)
+    assert h.apply(Command.Timeout()).is_leader()
+
+
+def test_candidate_apply_heartbeat(make):  # src/raft/candidate.rs:247-267
+    e, h = new_follower(make, 3)
+    h.apply(Command.Timeout())
+    assert h.is_candidate()
+    e.drain_messages()
+    h.apply(Command.Heartbeat(term=11, commit=1, leader_id=6))
+    assert h.is_follower() and h.voted_for == 6 and h.current_term == 11
+    (m,) = msgs(e)
+    assert m["kind"] == capi.CMD_HEARTBEAT_RESPONSE and m["id"] == 0 and m["flag"] == 0
+
+
+def test_leader_apply_entry_single_node(make):  # src/raft/leader.rs:299-327
+    e, h = new_follower(make)
+    assert h.apply(Command.Timeout()).is_leader()
+    h.apply(Command.ClientRequest(123))
+    h.apply(Command.Tick())
+    assert h.head == 1
+    out = fsm(e)
+    assert out[0] == (capi.FSM_NOTIFY, 1, 123)       # first fsm_rx item: Notify
+    assert out[1] == (capi.FSM_APPLY_LEADER, 0, 1)   # second: Apply{block 1}
+    assert h.commit == 1
+
+
+def test_server_event_loop_single_node_elected(make):  # src/raft/server.rs:179-206: 2 s of 100 ms ticks
+    e, h = new_follower(make)
+    for now in range(100, 2001, 100):
+        h.apply(Command.Tick(), now_ms=now)
+    assert h.is_leader()
+
+
+# ============ Part 2: hand-derived vectors — unpinned by the reference ============
+
+@pytest.mark.parametrize("heads,expect", [
+    ([5, 3, 0], 3), ([0, 0, 0], 0), ([9, 9, 9], 9), ([7, 7, 2, 1, 0], 2), ([8, 6, 6, 1, 0], 6),
+    ([9, 8, 3, 1], 3), ([4, 1], 1), ([4], 4),
+])
+def test_committed_index_vectors(make, heads, expect):  # progress.rs:48-60
+    R = len(heads)
+    e, h = new_leader(make, R)
+    for _ in range(max(heads)):
+        h.apply(Command.ClientRequest())
+    top = max(heads)
+    # the leader's own head is max(heads); the other slots ack their heads
+    order = sorted(heads, reverse=True)
+    assert h.match(0) == top
+    for slot, v in enumerate(order[1:], start=1):
+        if v:
+            h.apply(Command.AppendResponse(slot + 1, 1, v))
+    assert h.commit == expect
+    assert e.read("fault")[0] == 0
+
+
+def test_commit_guard_and_leader_apply_range(make):  # leader.rs:87-99
+    e, h = new_leader(make, 3)
+    for _ in range(5):
+        h.apply(Command.ClientRequest())
+    h.apply(Command.AppendResponse(2, 1, 2))
+    assert h.commit == 2
+    fsm(e)
+    h.apply(Command.AppendResponse(3, 1, 1))  # q = 2 <= commit: unchanged, no Apply
+    assert h.commit == 2 and fsm(e) == []
+    h.apply(Command.AppendResponse(2, 1, 5))  # prev 2 -> new 5: ids 3,4,5
+    assert fsm(e) == [(capi.FSM_APPLY_LEADER, 2, 5)]
+
+
+def test_follower_apply_range_is_half_open(make):  # follower.rs:200-207 (Q6): prev=2, commit=5 -> ids 2,3,4
+    e, h = new_follower(make, 3)
+    h.apply(Command.AppendEntries(1, 2, [(i, i - 1) for i in range(1, 6)]))
+    h.apply(Command.Heartbeat(1, 2, 2))
+    fsm(e)
+    h.apply(Command.Heartbeat(1, 5, 2))
+    assert fsm(e) == [(capi.FSM_APPLY_FOLLOWER, 2, 5)]
+    assert h.commit == 5
+
+
+@pytest.mark.parametrize("R,votes,role", [
+    (3, [], "c"), (3, [(2, True)], "l"), (3, [(2, False)], "c"), (3, [(2, False), (3, False)], "f"),
+    (5, [(2, False), (3, False)], "c"), (5, [(2, True), (3, True)], "l"),
+    (5, [(2, False), (3, False), (4, False)], "f"), (5, [(2, True), (3, False), (4, False)], "c"),
+    (2, [(2, False)], "c"),                  # n=2: quorum 2, 1 rejection != 2
+    (3, [(2, False), (2, True)], "l"),       # duplicate overwrites (election.rs:34)
+    (1, [], "l"),                            # single voter: quorum 0
+])
+def test_election_status_vectors(make, R, votes, role):  # election.rs:37-73, candidate.rs:91-113
+    e, h = new_follower(make, R)
+    h.apply(Command.Timeout())
+    for frm, granted in votes:
+        h.apply(Command.VoteResponse(1, frm, granted))
+    assert {"c": h.is_candidate(), "l": h.is_leader(), "f": h.is_follower()}[role]
+    if role == "f":
+        assert h.voted_for is None  # defeat(): candidate.rs:103
+
+
+def test_can_vote_clauses(make):  # follower.rs:97-101
+    e, h = new_follower(make, 3)
+    h.apply(Command.Heartbeat(3, 0, 2))          # term 3, voted_for 2
+    h.apply(Command.VoteRequest(9, 3, 9, 9))
+    assert msgs(e)[-1]["flag"] == 0              # already voted
+    e2, h2 = new_follower(make, 3)
+    h2.apply(Command.AppendEntries(3, 2, [(i, i - 1) for i in range(1, 5)]))
+    h2.apply(Command.Heartbeat(3, 4, 2))         # commit 4, term 3
+    h2.apply(Command.Restart())                  # voted_for None again, term 0, commit 4 persisted
+    assert h2.commit == 4 and h2.head == 4 and h2.voted_for is None
+    e2.drain_messages()
+    h2.apply(Command.VoteRequest(5, 3, 5, 3))    # commit 4 > head 3
+    assert msgs(e2)[-1]["flag"] == 0
+    h2.apply(Command.VoteRequest(5, 3, 5, 4))    # ok; reply carries the follower's own term (Q5)
+    m = msgs(e2)[-1]
+    assert m["flag"] == 1 and m["term"] == 0 and h2.voted_for == 3 and h2.current_term == 0
+
+
+def test_can_vote_term_clause(make):  # follower.rs:99: current_term > last_term
+    e, h = new_follower(make, 3)
+    h.apply(Command.AppendEntries(3, 2, []))     # term 3, voted_for 2
+    h.apply(Command.Restart())
+    h.apply(Command.Heartbeat(3, 0, 2))
+    # a candidate-turned-follower keeps its term with voted_for cleared by defeat
+    e2, h2 = new_follower(make, 3)
+    h2.apply(Command.Timeout())                  # candidate, term 1
+    h2.apply(Command.VoteResponse(1, 2, False))
+    h2.apply(Command.VoteResponse(1, 3, False))  # defeated -> follower, term 1, voted_for None
+    assert h2.is_follower() and h2.voted_for is None and h2.current_term == 1
+    e2.drain_messages()
+    h2.apply(Command.VoteRequest(0, 3, 0, 0))    # term 1 > last_term 0
+    assert msgs(e2)[-1]["flag"] == 0
+    h2.apply(Command.VoteRequest(1, 3, 1, 0))
+    assert msgs(e2)[-1]["flag"] == 1
+
+
+def test_increment_equal_or_lower_flips_to_probe(make):  # progress.rs:76-94,133-140
+    e, h = new_leader(make, 3)
+    for _ in range(3):
+        h.apply(Command.ClientRequest())
+    h.apply(Command.AppendResponse(2, 1, 2))
+    assert e.read("repl_state")[0] & 0b010
+    h.apply(Command.AppendResponse(2, 1, 2))     # equal -> false -> Replicate -> Probe
+    assert not (e.read("repl_state")[0] & 0b010) and h.match(1) == 2
+    h.apply(Command.AppendResponse(2, 1, 1))     # lower -> stays Probe, head unchanged
+    assert not (e.read("repl_state")[0] & 0b010) and h.match(1) == 2
+
+
+def test_compact_q7_tree(make):  # chain.rs:239-253 quirk Q7: main 0<-1<-2<-5<-6, dead 2<-3<-4, commit 6
+    e, _ = new_follower(make)
+    blocks = [(0, 0), (1, 0), (2, 1), (3, 2), (4, 3), (5, 2), (6, 5)]
+    (removed,) = e.chain_compact([(blocks, 6)])
+    assert [b[0] for b, r in zip(blocks, removed) if r] == [4]  # 4 removed, 3 kept
+
+
+def test_fault_leader_append_entries_higher_term(make):  # Q3: leader.rs:33-35 via 200-208
+    e, h = new_leader(make, 3)
+    h.apply(Command.AppendEntries(2, 2, []))
+    assert h.fault == capi.FAULT_LEADER_TERM_UNIMPLEMENTED
+    assert [tuple(r) for r in e.drain_faults()] == [(0, capi.FAULT_LEADER_TERM_UNIMPLEMENTED)]
+    h.apply(Command.ClientRequest())             # the process is gone: ignored
+    assert h.head == 0
+    h.apply(Command.AppendEntries(1, 2, []))
+    assert h.fault == capi.FAULT_LEADER_TERM_UNIMPLEMENTED
+
+
+def test_fault_follower_turned_leader_append(make):  # Q8: chain.rs:163 — id_gen is not advanced by extend
+    e, h = new_follower(make, 3)
+    h.apply(Command.AppendEntries(0, 2, [(1, 0), (2, 1)]))
+    assert int(e.read("id_gen")[0]) == 1 and h.head == 2
+    h.apply(Command.Restart())                   # voted_for None again (commit 0: head back to 0)
+    assert h.head == 0
+    h.apply(Command.AppendEntries(0, 2, [(1, 0), (2, 1)]))
+    h.apply(Command.Restart())
+    h.apply(Command.AppendEntries(0, 2, [(2, 1)]))  # head 2 via extend, id_gen still 1
+    # become leader with head 2: voted_for is Some(2) -> cannot campaign (Q4); restart clears it but also head.
+    # Drive it the only way the reference allows: commit first so the restart keeps head.
+    h.apply(Command.Heartbeat(0, 2, 2))
+    h.apply(Command.Restart())
+    assert h.head == 2 and h.commit == 2 and int(e.read("id_gen")[0]) == 2
+    h.apply(Command.Timeout())
+    h.apply(Command.VoteResponse(1, 2, True))
+    assert h.is_leader()
+    h.apply(Command.ClientRequest())             # id_gen.next() == 2, assert!(2 > 2) fails
+    assert h.fault == capi.FAULT_APPEND_ID_NOT_ABOVE_HEAD
+
+
+def test_fault_advance_unknown_node(make):  # progress.rs:43
+    e, h = new_leader(make, 3)
+    h.apply(Command.AppendResponse(77, 1, 1))
+    assert h.fault == capi.FAULT_PROGRESS_UNKNOWN_NODE
+
+
+def test_fault_commit_of_absent_id(make):  # chain.rs:197-202 (Q10)
+    e, h = new_leader(make, 3)
+    h.apply(Command.ClientRequest())
+    h.apply(Command.AppendResponse(2, 1, 9))     # q = 1: fine
+    assert h.fault == 0 and h.commit == 1
+    h.apply(Command.AppendResponse(3, 1, 8))     # q = 8, not in the leader's chain
+    assert h.fault == capi.FAULT_COMMIT_MISSING_BLOCK and h.commit == 1 and h.match(2) == 8
+
+
+def test_fault_extend_missing_parent(make):  # chain.rs:180-185: earlier blocks of the message stay
+    e, h = new_follower(make, 3)
+    h.apply(Command.AppendEntries(0, 2, [(1, 0), (3, 2)]))
+    assert h.fault == capi.FAULT_EXTEND_MISSING_PARENT and h.head == 1
+    assert msgs(e) == []                         # no AppendResponse was sent
+
+
+def test_fault_follower_stale_leader_assert(make):  # follower.rs:147-154
+    e, h = new_follower(make, 3)
+    h.apply(Command.Heartbeat(5, 0, 2))
+    h.apply(Command.AppendEntries(4, 3, []))
+    assert h.fault == capi.FAULT_FOLLOWER_STALE_LEADER
+
+
+def test_replicate_and_q9_commit_key(make):  # leader.rs:124-174, chain.rs:198,219-226 (Q9)
+    e, h = new_leader(make, 3)
+    h.apply(Command.ClientRequest())
+    h.apply(Command.Tick(), now_ms=1)
+    out = msgs(e)  # no heartbeat yet (1 ms), two Probe AppendEntries with block 1 each
+    assert [(m["kind"], m["to_id"], m["id"], m["aux"]) for m in out] == \
+        [(capi.CMD_APPEND_ENTRIES, 2, 0, 1), (capi.CMD_APPEND_ENTRIES, 3, 0, 1)]
+    h.apply(Command.AppendResponse(2, 1, 1))
+    assert h.commit == 1
+    h.apply(Command.Tick(), now_ms=2)            # follower 2 is caught up: range(1..) runs into "commit"
+    assert h.fault == capi.FAULT_RANGE_HIT_COMMIT_KEY
+
+
+def test_replicate_with_separate_commit_key(make):  # JG_CFG_SEPARATE_COMMIT_KEY: Q9 not reproduced
+    e, h = new_follower(make, 3, flags=capi.CFG_SEPARATE_COMMIT_KEY)
+    h.apply(Command.Timeout())
+    h.apply(Command.VoteResponse(1, 2, True))
+    e.drain_messages()
+    for _ in range(8):
+        h.apply(Command.ClientRequest())
+    h.apply(Command.AppendResponse(2, 1, 1))     # -> Replicate, commit 1
+    h.apply(Command.Tick(), now_ms=101)          # heartbeat due (leader.rs:78-84)
+    out = msgs(e)
+    assert [(m["kind"], m["to_kind"], m["id"]) for m in out[:1]] == [(capi.CMD_HEARTBEAT, capi.TO_PEERS, 1)]
+    assert [(m["to_id"], m["id"], m["aux"]) for m in out[1:]] == [(2, 1, 5), (3, 0, 1)]  # Replicate: 5, Probe: 1
+    assert h.fault == 0
+
+
+def test_client_request_queue_rows(make):  # follower.rs:190-197,258-270; candidate.rs:190-193
+    e, h = new_follower(make, 3)
+    h.apply(Command.ClientRequest(41))           # no leader yet: queued
+    h.apply(Command.ClientRequest(42))
+    assert int(e.read("queued_reqs")[0]) == 2
+    assert [(m["to_kind"], m["id"]) for m in msgs(e)] == [(capi.TO_QUEUE, 41), (capi.TO_QUEUE, 42)]
+    h.apply(Command.Heartbeat(1, 0, 2))          # flush to the leader, then the response
+    out = msgs(e)
+    assert (out[0]["kind"], out[0]["to_id"], out[0]["flag"], out[0]["aux"]) == \
+        (capi.CMD_CLIENT_REQUEST, 2, capi.QUEUE_FLUSH, 2)
+    assert out[1]["kind"] == capi.CMD_HEARTBEAT_RESPONSE
+    h.apply(Command.ClientRequest(43))           # leader known: forwarded at once
+    (m,) = msgs(e)
+    assert (m["to_kind"], m["to_id"], m["id"], m["flag"]) == (capi.TO_PEER, 2, 43, 0)
+
+
+def test_restart_reopens_chain(make):  # chain.rs:117-137: head = id_gen = commit
+    e, h = new_leader(make, 1)
+    for _ in range(3):
+        h.apply(Command.ClientRequest())
+    assert h.commit == 3
+    h.apply(Command.Restart())
+    assert h.is_follower() and h.current_term == 0 and h.voted_for is None
+    assert h.commit == 3 and h.head == 3 and int(e.read("id_gen")[0]) == 3
+    h.apply(Command.Timeout())
+    h.apply(Command.ClientRequest())             # Q8 again: 3 > 3 fails
+    assert h.fault == capi.FAULT_APPEND_ID_NOT_ABOVE_HEAD
+
+
+def test_dense_tick_nonleader_append_is_loud(make):
+    e, h = new_follower(make, 3)
+    acks = np.full((3, 1), capi.NO_ACK, dtype=np.uint64)
+    acks[0, 0] = 0
+    e.step_dense_acks(acks)                      # acks to a follower are ignored (follower.rs:62)
+    assert h.fault == 0
+    acks[0, 0] = 1
+    e.step_dense_acks(acks)
+    assert h.fault == capi.FAULT_ENGINE_DENSE_NONLEADER
+
+
+def test_config_validation(make):  # src/raft/config.rs:60-84
+    with pytest.raises(EngineError):
+        make(1, 3, node_ids=[0, 1, 2])           # id cannot be 0
+    with pytest.raises(EngineError):
+        make(1, 9)                               # beyond JG_MAX_REPLICAS
+    with pytest.raises(EngineError):
+        make(1, 1, heartbeat_timeout_ms=1)       # heartbeat timeout is too low
