@@ -13,170 +13,7 @@
 #pragma once
 #include "jg_device.h"
 
-#define JG_BLOCK 256
-
-// ---- wave64 / workgroup reduction of the per-lane decision counts --------------------
-// One plain read-modify-write per workgroup into its own slot: kernels on the
-// engine stream are serialised, so no atomics are needed (a single hot atomic
-// would cost ~12 ns x #waves, more than the tick itself).
-__device__ __forceinline__ void jg_block_count(uint64_t* slots, uint32_t v) {
-  __shared__ uint32_t wave_sum[JG_BLOCK / 64];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if (lane == 0) wave_sum[wave] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t s = 0;
-#pragma unroll
-    for (int w = 0; w < JG_BLOCK / 64; w++) s += wave_sum[w];
-    if (s) slots[blockIdx.x] += s;
-  }
-}
-
-// element R/2 of the heads sorted descending (progress.rs:48-60) by rank counting
-template <int R>
-__device__ __forceinline__ uint64_t jg_kth(const uint64_t (&v)[R]) {
-  constexpr int K = R / 2;
-  uint64_t q = 0;
-#pragma unroll
-  for (int j = 0; j < R; j++) {
-    int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < R; i++) cnt += (v[i] > v[j] || (v[i] == v[j] && i < j)) ? 1 : 0;
-    q = (cnt == K) ? v[j] : q;
-  }
-  return q;
-}
-
-// ---- dense steady-state leader tick -----------------------------------------------------
-// One lane per group.  Per group-step it reads R ack heads, R match heads,
-// commit, head (8 B each) and the flag word, and writes back what changed:
-// B(R) = 24R + 36 algorithmic bytes.
-//
-// Exactness: the reference evaluates Leader::commit after every ack.  match[] is
-// monotone, hence so is committed_index(), and the commit guard `q > commit`
-// makes the final commit max(commit, q_final) — provided chain.commit(q) never
-// panics on the way, which in FAST form (id set == [0, head]) means q <= head at
-// the time of each evaluation.  If every old match head and every ack is <= the
-// head before this tick's appends that cannot happen and the tick is fused into
-// one majority evaluation; otherwise the lane replays the acks one by one.
-template <int R>
-__global__ __launch_bounds__(JG_BLOCK) void k_leader_tick_dense(JgDev d, const uint64_t* __restrict__ acks,
-                                                                 uint32_t seq) {
-  const uint32_t G = d.G;
-  uint32_t dec = 0;
-  for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
-    uint32_t f = d.flags[g];
-    uint64_t a[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) a[r] = acks[(size_t)r * G + g];
-    if (f & JGF_FAULT_MASK) continue;
-    const uint32_t s = (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
-    uint64_t n_app = 0;
-#pragma unroll
-    for (int r = 0; r < R; r++) n_app = (r == (int)s) ? a[r] : n_app;
-    if ((f & JGF_ROLE_MASK) != JG_ROLE_LEADER) {
-      // acks are ignored by followers / candidates (follower.rs:62, candidate.rs:194)
-      if (n_app) {
-        d.flags[g] = f | (JG_FAULT_ENGINE_DENSE_NONLEADER << JGF_FAULT_SHIFT);
-        jg_push_fault(d, g, JG_FAULT_ENGINE_DENSE_NONLEADER, seq);
-      }
-      continue;
-    }
-    if (!(f & JGF_FAST)) {  // irregular chain: exact general path in k_dense_slow
-      uint32_t idx = atomicAdd(d.slow_n, 1u);
-      if (idx < G) d.slow_list[idx] = g;
-      continue;
-    }
-    uint64_t m[R], m0[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) m0[r] = m[r] = d.match[(size_t)r * G + g];
-    const uint64_t commit0 = d.commit[g];
-    uint64_t commit = commit0;
-    const uint64_t head0 = d.head[g];
-    uint64_t head = head0;
-    uint32_t nf = f;
-
-    uint64_t hi = 0;  // max over old match heads and follower acks
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      hi = m[r] > hi ? m[r] : hi;
-      bool is_ack = (r != (int)s) && (a[r] != JG_NO_ACK);
-      hi = (is_ack && a[r] > hi) ? a[r] : hi;
-    }
-    uint32_t fault = 0;
-    if (hi <= head0) {
-      // ---- fused path -------------------------------------------------------------
-      head = head0 + n_app;  // n appends: ids head0+1 .. head0+n (chain.rs:160-175, FAST form)
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        uint32_t bit = 1u << (JGF_REPL_SHIFT + r);
-        if (r == (int)s) {
-          if (n_app) {  // n self-acks; the last increment decides Probe/Replicate
-            bool inc = m[r] < head;
-            m[r] = inc ? head : m[r];
-            nf = inc ? (nf | bit) : (nf & ~bit);
-            dec += (uint32_t)n_app;
-          }
-        } else if (a[r] != JG_NO_ACK) {  // progress.rs:76-94,133-140
-          bool inc = m[r] < a[r];
-          m[r] = inc ? a[r] : m[r];
-          nf = inc ? (nf | bit) : (nf & ~bit);
-          dec += 1;
-        }
-      }
-      uint64_t q = jg_kth<R>(m);          // progress.rs:48-60
-      commit = q > commit ? q : commit;   // leader.rs:89-92
-    } else {
-      // ---- exact replay: one Leader::commit per append / ack -------------------------
-      const uint32_t sbit = 1u << (JGF_REPL_SHIFT + s);
-      for (uint64_t i = 0; i < n_app && !fault; i++) {
-        head += 1;
-        bool inc = false;
-#pragma unroll
-        for (int r = 0; r < R; r++)
-          if (r == (int)s) {
-            inc = m[r] < head;
-            m[r] = inc ? head : m[r];
-          }
-        nf = inc ? (nf | sbit) : (nf & ~sbit);
-        dec += 1;
-        uint64_t q = jg_kth<R>(m);
-        if (q > commit) {
-          if (q <= head) commit = q;
-          else fault = JG_FAULT_COMMIT_MISSING_BLOCK;  // chain.rs:197-202
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        if (r == (int)s || a[r] == JG_NO_ACK || fault) continue;
-        uint32_t bit = 1u << (JGF_REPL_SHIFT + r);
-        bool inc = m[r] < a[r];
-        m[r] = inc ? a[r] : m[r];
-        nf = inc ? (nf | bit) : (nf & ~bit);
-        dec += 1;
-        uint64_t q = jg_kth<R>(m);
-        if (q > commit) {
-          if (q <= head) commit = q;
-          else fault = JG_FAULT_COMMIT_MISSING_BLOCK;
-        }
-      }
-      if (fault) {
-        nf |= fault << JGF_FAULT_SHIFT;
-        jg_push_fault(d, g, fault, seq);
-      }
-    }
-    if (commit != commit0) nf |= JGF_COMMIT_KEY;  // chain.rs:198
-#pragma unroll
-    for (int r = 0; r < R; r++)
-      if (m[r] != m0[r]) d.match[(size_t)r * G + g] = m[r];
-    if (commit != commit0) d.commit[g] = commit;
-    if (head != head0) d.head[g] = head;
-    if (nf != f) d.flags[g] = nf;
-  }
-  jg_block_count(d.blk_decisions, dec);
-}
+#include "jg_dense.h"  // k_leader_tick_dense / _x2, jg_block_count, JG_BLOCK
 
 // Same tick through the general state machine, for the groups the fast kernel
 // deferred (chain not in FAST form).

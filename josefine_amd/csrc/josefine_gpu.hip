@@ -48,6 +48,7 @@ struct jg_engine {
   std::vector<void*> allocs;
   uint32_t count_slots = 0;  // workgroup slots of dev.blk_decisions
   uint32_t dense_grid = 0;
+  int dense_variant = 1;
   uint32_t* d_err = nullptr;
   uint64_t* d_acks_staging = nullptr;  // [R][G] for the host-buffer dense entry point
   // commands queued by jg_submit (host SoA)
@@ -102,7 +103,12 @@ inline void row_bounds(uint8_t kind, uint32_t R, uint32_t* m, uint32_t* f) {
 
 template <int R>
 void launch_dense(jg_engine* e, const uint64_t* acks) {
-  hipLaunchKernelGGL(k_leader_tick_dense<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks, e->seq);
+  if (e->dense_variant == 2)  // two groups per lane, 16-B accesses (needs an even G)
+    hipLaunchKernelGGL(k_leader_tick_dense_x2<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
+                       e->seq);
+  else
+    hipLaunchKernelGGL(k_leader_tick_dense<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
+                       e->seq);
 }
 
 int dense_step(jg_engine* e, const uint64_t* acks_dev) {
@@ -258,7 +264,10 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   const char* env_grid = std::getenv("JG_DENSE_GRID");
   uint32_t cap = env_grid ? (uint32_t)std::atoi(env_grid) : 2048u;
   if (cap < 1) cap = 1;
-  e->dense_grid = grid_for(G, cap);
+  const char* env_var = std::getenv("JG_DENSE_VARIANT");
+  e->dense_variant = env_var ? std::atoi(env_var) : 1;
+  if (e->dense_variant != 2 || (G & 1)) e->dense_variant = 1;
+  e->dense_grid = grid_for(e->dense_variant == 2 ? G / 2 : G, cap);
   e->count_slots = std::max<uint32_t>(e->dense_grid, 1024);
 #define A(ptr, n)                                   \
   if ((rc = dev_alloc(e, &ptr, (n))) != JG_OK) return bail(rc)

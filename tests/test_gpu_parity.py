@@ -25,10 +25,17 @@ def test_election_setup_parity(R):
     assert (dev.read("role") == capi.ROLE_LEADER).all()
 
 
+@pytest.fixture(params=["1", "2"])
+def dense_variant(request, monkeypatch):
+    """Both dense kernels: one group per lane (8-B accesses) / two per lane (16-B accesses)."""
+    monkeypatch.setenv("JG_DENSE_VARIANT", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("R,G,mode,ticks", [(3, 10_000, 1, 200), (5, 10_000, 1, 60), (5, 4096, 0, 40),
                                             (1, 1000, 1, 20), (2, 1000, 1, 30), (4, 1000, 1, 30),
-                                            (8, 1000, 1, 30)])
-def test_dense_ack_stream_parity(R, G, mode, ticks):
+                                            (8, 1000, 1, 30), (3, 1001, 1, 20)])
+def test_dense_ack_stream_parity(R, G, mode, ticks, dense_variant):
     """BASELINE config #2 shape (10k x 3 ragged stream) and friends: compare after every tick."""
     dev, ora = pair(G, R, seed=0x6A6F7365 + R)
     for e in (dev, ora):
