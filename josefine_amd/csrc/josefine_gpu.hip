@@ -262,13 +262,13 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   d.seed = cfg->seed;
   d.group_base = cfg->group_base;
   const char* env_grid = std::getenv("JG_DENSE_GRID");
-  uint32_t cap = env_grid ? (uint32_t)std::atoi(env_grid) : 2048u;
+  uint32_t cap = env_grid ? (uint32_t)std::atoi(env_grid) : 8192u;  // measured best (profiles/README.md)
   if (cap < 1) cap = 1;
   const char* env_var = std::getenv("JG_DENSE_VARIANT");
   e->dense_variant = env_var ? std::atoi(env_var) : 1;
   if (e->dense_variant != 2 || (G & 1)) e->dense_variant = 1;
   e->dense_grid = grid_for(e->dense_variant == 2 ? G / 2 : G, cap);
-  e->count_slots = std::max<uint32_t>(e->dense_grid, 1024);
+  e->count_slots = std::max<uint32_t>(e->dense_grid, 4096);
 #define A(ptr, n)                                   \
   if ((rc = dev_alloc(e, &ptr, (n))) != JG_OK) return bail(rc)
   A(d.term, G);

@@ -1,0 +1,354 @@
+// raft_handle.hpp — C++ host mirror of josefine's Raft driver surface over the C ABI
+// (include/josefine_gpu.h).  The reference is Rust and this image has no Rust
+// toolchain, so the host side above the ABI is C++ with the reference's names and
+// argument meaning; the Rust adapter a maintainer would add is in INTEGRATION.md.
+//
+//   reference (src/raft)                              here
+//   enum Command { Tick, VoteRequest{..}, .. }        josefine::Command::{Tick(), VoteRequest(..), ..}   mod.rs:160-227
+//   trait Apply { fn apply(self, Command) }           josefine::RaftHandle::apply / BatchedRaft::apply     mod.rs:471-489
+//   RaftHandle::{is_follower,is_candidate,is_leader}  same                                                mod.rs:437-447
+//   rpc_tx: UnboundedSender<Message>                  BatchedRaft::rpc_tx  (std::function sink)           mod.rs:337-338
+//   fsm_tx: UnboundedSender<Instruction>              BatchedRaft::fsm_tx  (std::function sink)           mod.rs:339-340
+//   Chain's sled tree (block payloads)                josefine::BlockStore (host, key-ordered map)        chain.rs:99-104
+//
+// What stays on the host, exactly as in the reference: block payloads, the queued
+// client requests (follower.rs:22, candidate.rs:20) and the expansion of Apply
+// ranges into blocks in key order (leader.rs:93, follower.rs:204).  No state-machine
+// arithmetic happens here: every decision comes out of the device engine.
+#pragma once
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/josefine_gpu.h"
+
+namespace josefine {
+
+using NodeId = uint32_t;   // mod.rs:136
+using Term = uint64_t;     // mod.rs:139
+using BlockId = uint64_t;  // chain.rs:29-36 (8-byte BE id, numeric order)
+
+struct Block {  // chain.rs:86-91
+  BlockId id = 0, next = 0;
+  std::vector<uint8_t> data;
+};
+
+struct Command {  // mod.rs:160-227
+  uint8_t kind = JG_CMD_NOOP;
+  NodeId from = 0;
+  Term term = 0;
+  uint64_t id = 0, aux = 0;
+  bool flag = false;
+  std::vector<Block> blocks;      // AppendEntries
+  std::vector<uint8_t> proposal;  // ClientRequest payload (rpc.rs:30-40)
+
+  static Command Tick() { return mk(JG_CMD_TICK); }
+  static Command Propose() { return mk(JG_CMD_PROPOSE); }
+  static Command Timeout() { return mk(JG_CMD_TIMEOUT); }
+  static Command Noop() { return mk(JG_CMD_NOOP); }
+  static Command VoteRequest(Term term, NodeId candidate_id, Term last_term, BlockId head) {
+    Command c = mk(JG_CMD_VOTE_REQUEST);
+    c.term = term, c.from = candidate_id, c.aux = last_term, c.id = head;
+    return c;
+  }
+  static Command VoteResponse(Term term, NodeId from, bool granted) {
+    Command c = mk(JG_CMD_VOTE_RESPONSE);
+    c.term = term, c.from = from, c.flag = granted;
+    return c;
+  }
+  static Command AppendEntries(Term term, NodeId leader_id, std::vector<Block> blocks) {
+    Command c = mk(JG_CMD_APPEND_ENTRIES);
+    c.term = term, c.from = leader_id, c.blocks = std::move(blocks);
+    return c;
+  }
+  static Command AppendResponse(NodeId node_id, Term term, BlockId head, bool success) {
+    Command c = mk(JG_CMD_APPEND_RESPONSE);
+    c.from = node_id, c.term = term, c.id = head, c.flag = success;
+    return c;
+  }
+  static Command Heartbeat(Term term, BlockId commit, NodeId leader_id) {
+    Command c = mk(JG_CMD_HEARTBEAT);
+    c.term = term, c.id = commit, c.from = leader_id;
+    return c;
+  }
+  static Command HeartbeatResponse(BlockId commit, bool has_committed) {
+    Command c = mk(JG_CMD_HEARTBEAT_RESPONSE);
+    c.id = commit, c.flag = has_committed;
+    return c;
+  }
+  static Command ClientRequest(uint64_t request_id, std::vector<uint8_t> proposal) {
+    Command c = mk(JG_CMD_CLIENT_REQUEST);
+    c.id = request_id, c.proposal = std::move(proposal);
+    return c;
+  }
+  static Command ClientResponse(uint64_t request_id) {
+    Command c = mk(JG_CMD_CLIENT_RESPONSE);
+    c.id = request_id;
+    return c;
+  }
+
+ private:
+  static Command mk(uint8_t k) {
+    Command c;
+    c.kind = k;
+    return c;
+  }
+};
+
+struct Address {  // rpc.rs:5-14
+  uint8_t kind = JG_TO_PEERS;
+  NodeId peer = 0;
+};
+struct Message {  // rpc.rs:17-27
+  uint32_t group = 0;
+  Address from, to;
+  Command command;
+};
+struct Instruction {  // fsm.rs:20-29
+  enum Kind { Apply, Notify } kind = Apply;
+  uint32_t group = 0;
+  Block block;              // Apply
+  uint64_t request_id = 0;  // Notify
+  BlockId block_id = 0;     // Notify
+};
+
+// Host block store of one group: what sled holds in the reference (chain.rs:99-104).
+using BlockStore = std::map<BlockId, Block>;
+
+class EngineError : public std::runtime_error {  // anyhow::Error
+ public:
+  EngineError(int status, const char* msg) : std::runtime_error(std::string("josefine engine: ") + msg), status(status) {}
+  int status;
+};
+
+class BatchedRaft;
+
+class RaftHandle {  // mod.rs:417-468, a view of one group
+ public:
+  RaftHandle(BatchedRaft* e, uint32_t g) : e_(e), g_(g) {}
+  RaftHandle apply(const Command& cmd, uint64_t now_ms = 0);
+  bool is_follower() const { return role() == JG_ROLE_FOLLOWER; }
+  bool is_candidate() const { return role() == JG_ROLE_CANDIDATE; }
+  bool is_leader() const { return role() == JG_ROLE_LEADER; }
+  Term current_term() const { return read64(JG_FIELD_TERM); }
+  BlockId commit() const { return read64(JG_FIELD_COMMIT); }
+  BlockId head() const { return read64(JG_FIELD_HEAD); }
+  uint32_t fault() const { return read8(JG_FIELD_FAULT); }
+  bool has_voted() const { return read8(JG_FIELD_HAS_VOTED) != 0; }
+  NodeId voted_for() const { return read32(JG_FIELD_VOTED_FOR); }
+
+ private:
+  uint8_t role() const { return read8(JG_FIELD_ROLE); }
+  uint64_t read64(int f) const;
+  uint32_t read32(int f) const;
+  uint8_t read8(int f) const;
+  BatchedRaft* e_;
+  uint32_t g_;
+};
+
+class BatchedRaft {
+ public:
+  // sinks: everything the groups push on the two channels, in per-group order
+  std::function<void(const Message&)> rpc_tx;
+  std::function<void(const Instruction&)> fsm_tx;
+
+  // RaftHandle::new for n_groups groups (mod.rs:428-435)
+  BatchedRaft(uint32_t n_groups, std::vector<NodeId> node_ids, int device = 0, uint64_t seed = 0,
+              uint32_t flags = 0)
+      : stores_(n_groups), queued_(n_groups), ids_(node_ids) {
+    jg_config c{};
+    c.abi_version = JG_ABI_VERSION;
+    c.n_groups = n_groups;
+    c.n_replicas = (uint32_t)node_ids.size();
+    for (size_t r = 0; r < node_ids.size() && r < JG_MAX_REPLICAS; r++) c.node_ids[r] = node_ids[r];
+    c.device_id = device;
+    c.heartbeat_timeout_ms = 100;      // config.rs:104
+    c.election_timeout_min_ms = 500;   // mod.rs:318
+    c.election_timeout_max_ms = 1000;  // mod.rs:319
+    c.seed = seed;
+    c.flags = flags;
+    check(jg_engine_create(&c, &e_));
+    for (auto& s : stores_) s[0] = Block{0, 0, {}};  // genesis (chain.rs:139-153)
+  }
+  ~BatchedRaft() { jg_engine_destroy(e_); }
+  BatchedRaft(const BatchedRaft&) = delete;
+  BatchedRaft& operator=(const BatchedRaft&) = delete;
+
+  RaftHandle handle(uint32_t g) { return RaftHandle(this, g); }
+  const BlockStore& store(uint32_t g) const { return stores_[g]; }
+  jg_engine* raw() { return e_; }
+
+  // Apply::apply for one group: submit, step, forward the outputs to the sinks.
+  RaftHandle apply(uint32_t g, const Command& cmd, uint64_t now_ms = 0) {
+    submit(g, cmd);
+    step(now_ms);
+    return RaftHandle(this, g);
+  }
+
+  void submit(uint32_t g, const Command& cmd) {
+    kind_.push_back(cmd.kind);
+    group_.push_back(g);
+    from_.push_back(cmd.from);
+    term_.push_back(cmd.term);
+    flag_.push_back(cmd.flag ? 1 : 0);
+    if (cmd.kind == JG_CMD_APPEND_ENTRIES) {
+      id_.push_back(blk_id_.size());
+      aux_.push_back(cmd.blocks.size());
+      for (const Block& b : cmd.blocks) {
+        blk_id_.push_back(b.id);
+        blk_next_.push_back(b.next);
+        pending_blocks_.push_back({g, b});  // payload goes to the host store on extend
+      }
+    } else {
+      id_.push_back(cmd.id);
+      aux_.push_back(cmd.aux);
+    }
+    if (cmd.kind == JG_CMD_CLIENT_REQUEST) pending_reqs_[{g, cmd.id}] = cmd.proposal;
+  }
+
+  void step(uint64_t now_ms) {
+    jg_cmd_batch b{};
+    b.n = kind_.size();
+    b.kind = kind_.data(), b.group = group_.data(), b.from = from_.data(), b.term = term_.data();
+    b.id = id_.data(), b.aux = aux_.data(), b.flag = flag_.data();
+    b.n_blocks = blk_id_.size(), b.blk_id = blk_id_.data(), b.blk_next = blk_next_.data();
+    check(jg_submit(e_, &b));
+    kind_.clear(), group_.clear(), from_.clear(), term_.clear(), id_.clear(), aux_.clear(), flag_.clear();
+    blk_id_.clear(), blk_next_.clear();
+    check(jg_step(e_, now_ms));
+    // followers store the payloads of the blocks they were sent (chain.rs:187-189); a
+    // block whose extend failed is harmless here: its id is never reported as applied.
+    for (auto& pb : pending_blocks_) stores_[pb.first][pb.second.id] = pb.second;
+    pending_blocks_.clear();
+    pump();
+  }
+
+ private:
+  friend class RaftHandle;
+  void check(int rc) {
+    if (rc != JG_OK) throw EngineError(rc, jg_last_error());
+  }
+
+  void pump() {
+    size_t n = 0;
+    check(jg_drain_applies(e_, nullptr, 0, &n));
+    std::vector<jg_fsm_row> fr(n);
+    if (n) check(jg_drain_applies(e_, fr.data(), n, &n));
+    for (const jg_fsm_row& r : fr) {
+      BlockStore& st = stores_[r.group];
+      if (r.kind == JG_FSM_NOTIFY) {
+        // leader append (leader.rs:177-188): the block now exists with the request's payload
+        Block b{r.a, r.a ? prev_head(st, r.a) : 0, {}};
+        auto it = pending_reqs_.find({r.group, r.b});
+        if (it != pending_reqs_.end()) {
+          b.data = it->second;
+          pending_reqs_.erase(it);
+        }
+        st[b.id] = b;
+        if (fsm_tx) {
+          Instruction ins;
+          ins.kind = Instruction::Notify, ins.group = r.group, ins.request_id = r.b, ins.block_id = r.a;
+          fsm_tx(ins);
+        }
+      } else {
+        // range(a..=b).skip(1) for the leader (leader.rs:93), range(a..b) for a follower
+        // (follower.rs:204): by key order over what is stored, not by parent pointers.
+        auto lo = st.lower_bound(r.a);
+        auto hi = r.kind == JG_FSM_APPLY_LEADER ? st.upper_bound(r.b) : st.lower_bound(r.b);
+        bool skip = r.kind == JG_FSM_APPLY_LEADER;
+        for (auto it = lo; it != hi; ++it) {
+          if (skip) {
+            skip = false;
+            continue;
+          }
+          if (fsm_tx) {
+            Instruction ins;
+            ins.kind = Instruction::Apply, ins.group = r.group, ins.block = it->second;
+            fsm_tx(ins);
+          }
+        }
+      }
+    }
+    check(jg_drain_messages(e_, nullptr, 0, &n));
+    std::vector<jg_msg_row> mr(n);
+    if (n) check(jg_drain_messages(e_, mr.data(), n, &n));
+    for (const jg_msg_row& r : mr) {
+      std::deque<uint64_t>& q = queued_[r.group];
+      if (r.kind == JG_CMD_CLIENT_REQUEST && r.to_kind == JG_TO_QUEUE) {
+        if (r.flag == JG_QUEUE_DROP) q.clear();  // follower.rs:295 / candidate.rs:216-238
+        else q.push_back(r.id);                  // follower.rs:268, candidate.rs:191
+        continue;
+      }
+      if (r.kind == JG_CMD_CLIENT_REQUEST && r.flag == JG_QUEUE_FLUSH) {  // follower.rs:190-197
+        for (uint64_t tok : q) emit(r, tok);
+        q.clear();
+        continue;
+      }
+      emit(r, r.id);
+    }
+  }
+  void emit(const jg_msg_row& r, uint64_t id) {
+    if (!rpc_tx) return;
+    Message m;
+    m.group = r.group;
+    m.from = Address{JG_TO_PEER, r.from};
+    m.to = Address{r.to_kind, r.to_id};
+    m.command.kind = r.kind;
+    m.command.from = r.from;
+    m.command.term = r.term;
+    m.command.id = id;
+    m.command.aux = r.aux;
+    m.command.flag = r.flag != 0 && r.kind != JG_CMD_CLIENT_REQUEST;
+    if (r.kind == JG_CMD_APPEND_ENTRIES) {  // leader.rs:124-174: range(id..).skip(1).take(aux)
+      const BlockStore& st = stores_[r.group];
+      auto it = st.lower_bound(r.id);
+      if (it != st.end()) ++it;
+      for (uint64_t k = 0; k < r.aux && it != st.end(); ++k, ++it) m.command.blocks.push_back(it->second);
+    }
+    if (r.kind == JG_CMD_CLIENT_REQUEST) {
+      auto it = pending_reqs_.find({r.group, id});
+      if (it != pending_reqs_.end()) m.command.proposal = it->second;
+    }
+    rpc_tx(m);
+  }
+  // Chain::append sets next = the head before the append (chain.rs:164-167): the
+  // largest key below the new id for a leader that only appends.
+  static BlockId prev_head(const BlockStore& st, BlockId id) {
+    auto it = st.lower_bound(id);
+    return it == st.begin() ? 0 : std::prev(it)->first;
+  }
+
+  jg_engine* e_ = nullptr;
+  std::vector<BlockStore> stores_;
+  std::vector<std::deque<uint64_t>> queued_;
+  std::vector<NodeId> ids_;
+  std::vector<uint8_t> kind_, flag_;
+  std::vector<uint32_t> group_, from_;
+  std::vector<uint64_t> term_, id_, aux_, blk_id_, blk_next_;
+  std::vector<std::pair<uint32_t, Block>> pending_blocks_;
+  std::map<std::pair<uint32_t, uint64_t>, std::vector<uint8_t>> pending_reqs_;
+};
+
+inline RaftHandle RaftHandle::apply(const Command& cmd, uint64_t now_ms) { return e_->apply(g_, cmd, now_ms); }
+inline uint64_t RaftHandle::read64(int f) const {
+  uint64_t v = 0;
+  e_->check(jg_read_state(e_->e_, f, 0, &v, g_, 1));
+  return v;
+}
+inline uint32_t RaftHandle::read32(int f) const {
+  uint32_t v = 0;
+  e_->check(jg_read_state(e_->e_, f, 0, &v, g_, 1));
+  return v;
+}
+inline uint8_t RaftHandle::read8(int f) const {
+  uint8_t v = 0;
+  e_->check(jg_read_state(e_->e_, f, 0, &v, g_, 1));
+  return v;
+}
+
+}  // namespace josefine

@@ -6,8 +6,9 @@
 # PMC runs never combine with sys/hip/hsa tracing (pool rule).
 set -u
 TAG=${1:-r01}; shift || true
+SUF=${JG_PROF_SUFFIX:-}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/prof_$TAG
+OUT=$REPO/gpurun_out/prof_$TAG$SUF
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- \

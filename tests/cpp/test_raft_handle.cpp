@@ -1,0 +1,134 @@
+// C++ host-adapter tests: the reference's own L1 tests, restated against
+// josefine_amd/host/raft_handle.hpp (which drives the HIP engine through the C
+// ABI), plus BASELINE.json config #1 — the examples/multi-node topology (ids 1,2,3)
+// as three instances of one partition routed in-process.
+// Built and run by tests/test_cpp_adapter.py (-m gpu).
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+
+#include "../../josefine_amd/host/raft_handle.hpp"
+
+using namespace josefine;
+
+static int g_failed = 0;
+#define CHECK(cond)                                                     \
+  do {                                                                  \
+    if (!(cond)) {                                                      \
+      std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      g_failed++;                                                       \
+    }                                                                   \
+  } while (0)
+
+// src/raft/leader.rs:299-327 apply_entry_single_node
+static void apply_entry_single_node() {
+  BatchedRaft raft(1, {1});
+  std::vector<Instruction> fsm_rx;
+  raft.fsm_tx = [&](const Instruction& i) { fsm_rx.push_back(i); };
+  RaftHandle node = raft.handle(0).apply(Command::Timeout());
+  CHECK(node.is_leader());
+  const uint8_t magic_number = 123;
+  node = node.apply(Command::ClientRequest(77, {magic_number}));
+  node = node.apply(Command::Tick());
+  CHECK(node.is_leader());
+  // let block = leader.chain.range(..).take(2).last().unwrap();
+  auto it = raft.store(0).begin();
+  ++it;
+  CHECK(it->second.data == std::vector<uint8_t>{magic_number});
+  CHECK(fsm_rx.size() == 2);
+  CHECK(fsm_rx[0].kind == Instruction::Notify && fsm_rx[0].block_id == 1 && fsm_rx[0].request_id == 77);
+  CHECK(fsm_rx[1].kind == Instruction::Apply && fsm_rx[1].block.data == std::vector<uint8_t>{magic_number});
+}
+
+// src/raft/follower.rs:338-358 apply_heartbeat
+static void follower_apply_heartbeat() {
+  BatchedRaft raft(1, {1});
+  std::vector<Message> rpc_rx;
+  raft.rpc_tx = [&](const Message& m) { rpc_rx.push_back(m); };
+  RaftHandle follower = raft.handle(0).apply(Command::Heartbeat(12, 1, 11));
+  CHECK(follower.is_follower());
+  CHECK(follower.has_voted() && follower.voted_for() == 11);
+  CHECK(follower.current_term() == 12);
+  CHECK(rpc_rx.size() == 1);
+  // but we don't have block 1 in our chain
+  CHECK(rpc_rx[0].command.kind == JG_CMD_HEARTBEAT_RESPONSE && rpc_rx[0].command.id == 0 && !rpc_rx[0].command.flag);
+  CHECK(rpc_rx[0].to.kind == JG_TO_PEER && rpc_rx[0].to.peer == 11);
+}
+
+// src/raft/candidate.rs:247-267 apply_heartbeat
+static void candidate_apply_heartbeat() {
+  BatchedRaft raft(1, {1, 2, 3});
+  std::vector<Message> rpc_rx;
+  raft.rpc_tx = [&](const Message& m) { rpc_rx.push_back(m); };
+  RaftHandle candidate = raft.handle(0).apply(Command::Timeout());
+  CHECK(candidate.is_candidate());
+  rpc_rx.clear();
+  RaftHandle follower = candidate.apply(Command::Heartbeat(11, 1, 6));
+  CHECK(follower.is_follower() && follower.voted_for() == 6 && follower.current_term() == 11);
+  CHECK(rpc_rx.size() == 1 && rpc_rx[0].command.kind == JG_CMD_HEARTBEAT_RESPONSE && rpc_rx[0].command.id == 0 &&
+        !rpc_rx[0].command.flag);
+}
+
+// BASELINE.json config #1: 3-broker Chained-Raft group (examples/multi-node/node-{1,2,3}.toml),
+// one partition; scripted: Timeout -> votes -> Elected -> 1 proposal -> acks -> commit 1.
+static void multi_node_plumbing() {
+  // three instances (= the three processes of the example) of one partition
+  BatchedRaft raft(3, {1, 2, 3}, 0, 0, JG_CFG_SEPARATE_COMMIT_KEY);
+  uint8_t slots[3] = {0, 1, 2};
+  if (jg_set_self_slots(raft.raw(), slots) != JG_OK) {
+    CHECK(!"jg_set_self_slots");
+    return;
+  }
+  std::deque<Message> wire;
+  std::vector<Instruction> fsm[3];
+  raft.rpc_tx = [&](const Message& m) { wire.push_back(m); };
+  raft.fsm_tx = [&](const Instruction& i) { fsm[i.group].push_back(i); };
+  auto deliver_all = [&](uint64_t now) {
+    int guard = 0;
+    while (!wire.empty() && guard++ < 1000) {
+      Message m = wire.front();
+      wire.pop_front();
+      for (uint32_t dst = 0; dst < 3; dst++) {
+        NodeId dst_id = dst + 1;
+        bool to_me = (m.to.kind == JG_TO_PEERS && dst_id != m.from.peer) || (m.to.kind == JG_TO_PEER && m.to.peer == dst_id);
+        if (to_me) raft.apply(dst, m.command, now);
+      }
+    }
+  };
+  raft.apply(0, Command::Timeout());  // node 1 campaigns
+  deliver_all(0);
+  CHECK(raft.handle(0).is_leader());
+  CHECK(raft.handle(1).is_follower() && raft.handle(2).is_follower());
+  CHECK(raft.handle(1).voted_for() == 1 && raft.handle(1).current_term() == 1);  // via the leader's heartbeat
+  raft.apply(0, Command::ClientRequest(1, {42}));  // propose
+  raft.apply(0, Command::Tick(), 10);              // replicate(): Probe sends block 1
+  deliver_all(10);
+  CHECK(raft.handle(0).commit() == 1 && raft.handle(0).head() == 1);
+  CHECK(raft.handle(1).head() == 1 && raft.handle(2).head() == 1);
+  CHECK(raft.store(1).count(1) && raft.store(1).at(1).data == std::vector<uint8_t>{42});
+  raft.apply(0, Command::Tick(), 150);  // heartbeat due: carries commit 1
+  deliver_all(150);
+  CHECK(raft.handle(1).commit() == 1 && raft.handle(2).commit() == 1);
+  // leader applied (0,1] = block 1; followers applied range(0..1) = genesis only (Q6)
+  CHECK(fsm[0].size() == 2 && fsm[0][1].kind == Instruction::Apply && fsm[0][1].block.id == 1);
+  CHECK(fsm[1].size() == 1 && fsm[1][0].kind == Instruction::Apply && fsm[1][0].block.id == 0);
+  for (uint32_t g = 0; g < 3; g++) CHECK(raft.handle(g).fault() == 0);
+}
+
+int main() {
+  try {
+    apply_entry_single_node();
+    follower_apply_heartbeat();
+    candidate_apply_heartbeat();
+    multi_node_plumbing();
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "exception: %s\n", e.what());
+    return 2;
+  }
+  if (g_failed) {
+    std::fprintf(stderr, "%d check(s) failed\n", g_failed);
+    return 1;
+  }
+  std::puts("cpp adapter ok");
+  return 0;
+}

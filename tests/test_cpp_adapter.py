@@ -1,0 +1,33 @@
+"""Build and run the C++ host-adapter tests (tests/cpp/test_raft_handle.cpp) against
+the HIP engine: the reference's L1 tests through josefine_amd/host/raft_handle.hpp and
+BASELINE config #1 (3-node plumbing)."""
+import os
+import subprocess
+
+import pytest
+
+from josefine_amd.build import CSRC, build_hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "test_raft_handle.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "test_raft_handle")
+
+
+def compile_adapter_test():
+    build_hip()
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-o", EXE, SRC, f"-L{CSRC}", "-ljosefine_gpu",
+                    f"-Wl,-rpath,{CSRC}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+
+
+def test_cpp_adapter_compiles():
+    """CPU: the header-only adapter and its tests compile and link against the C ABI."""
+    compile_adapter_test()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_cpp_adapter_runs_reference_tests():
+    compile_adapter_test()
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cpp adapter ok" in r.stdout
