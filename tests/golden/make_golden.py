@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz from the CPU oracle.
+
+The Rust reference cannot run here (no cargo/rustc), so these fixtures are NOT reference
+outputs: they freeze the oracle's answers on fixed seeded inputs so that (a) the oracle
+cannot drift silently between rounds and (b) the HIP engine is compared against committed
+bytes, not only against an oracle built in the same run.  The reference's own golden vectors
+(chain::compact tree, heartbeat / vote-request expectations …) are transcribed directly in
+tests/test_reference_kats.py.
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from fuzz import random_batch  # noqa: E402
+from oracle_lib import oracle_engine  # noqa: E402
+from parity import elect_all, synth_tick_host  # noqa: E402
+from josefine_amd import capi  # noqa: E402
+
+SEED = 0x6A6F736566696E65
+
+
+def digest(arr) -> str:
+    return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+def dense_fixture(G, R, mode, ticks, every):
+    e = oracle_engine(G, R, seed=SEED + R)
+    elect_all(e)
+    sim = np.zeros((R, G), dtype=np.uint64)
+    out = {"G": G, "R": R, "mode": mode, "ticks": ticks, "every": every, "seed": SEED + R}
+    for t in range(ticks):
+        e.step_dense_acks(synth_tick_host(e, mode, t, sim))
+        if (t + 1) % every == 0:
+            out[f"commit_{t+1}"] = e.read("commit")
+            out[f"head_{t+1}"] = e.read("head")
+            out[f"repl_{t+1}"] = e.read("repl_state")
+            out[f"match_{t+1}"] = np.stack([e.read("match", r) for r in range(R)])
+    out["decisions"] = e.counters()["decisions"]
+    return out
+
+
+def fuzz_fixture(G, R, steps, rows):
+    e = oracle_engine(G, R, seed=99)
+    rng = np.random.default_rng(4321 + R)
+    budget = np.full(G, capi.CHAIN_WINDOW - 2)
+    out = {"G": G, "R": R, "steps": steps}
+    now = 0
+    msg_h, fsm_h, flt_h = hashlib.sha256(), hashlib.sha256(), hashlib.sha256()
+    for s in range(steps):
+        b = random_batch(rng, e, rows, budget=budget)
+        now += int(rng.integers(0, 400))
+        for k, v in b.items():
+            out[f"in{s}_{k}"] = v
+        out[f"in{s}_now"] = now
+        e.submit_columns(**b)
+        e.step(now)
+        msg_h.update(e.drain_messages().tobytes())
+        fsm_h.update(e.drain_applies().tobytes())
+        flt_h.update(e.drain_faults().tobytes())
+    for name in ("term", "voted_for", "role", "commit", "head", "id_gen", "fault", "repl_state", "vote_seen",
+                 "vote_granted", "election_timeout", "queued_reqs"):
+        out[f"final_{name}"] = e.read(name)
+    out["final_match"] = np.stack([e.read("match", r) for r in range(R)])
+    out["digest_messages"] = msg_h.hexdigest()
+    out["digest_applies"] = fsm_h.hexdigest()
+    out["digest_faults"] = flt_h.hexdigest()
+    return out
+
+
+def main():
+    np.savez_compressed(os.path.join(HERE, "dense_r3_ragged.npz"), **dense_fixture(512, 3, 1, 60, 20))
+    np.savez_compressed(os.path.join(HERE, "dense_r5_steady.npz"), **dense_fixture(256, 5, 0, 30, 10))
+    np.savez_compressed(os.path.join(HERE, "fuzz_r3.npz"), **fuzz_fixture(128, 3, 20, 400))
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

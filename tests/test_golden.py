@@ -1,0 +1,62 @@
+"""Committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py):
+the oracle must still reproduce them (CPU), and the HIP engine must match the committed
+bytes (-m gpu)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from josefine_amd import BatchedRaft
+from oracle_lib import oracle_engine
+from parity import elect_all, synth_tick_host
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BACKENDS = ["oracle", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+def make(backend, G, R, **kw):
+    return oracle_engine(G, R, **kw) if backend == "oracle" else BatchedRaft(G, R, **kw)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("name", ["dense_r3_ragged.npz", "dense_r5_steady.npz"])
+def test_dense_golden(backend, name):
+    z = np.load(os.path.join(HERE, name))
+    G, R, mode, ticks, every = (int(z[k]) for k in ("G", "R", "mode", "ticks", "every"))
+    e = make(backend, G, R, seed=int(z["seed"]))
+    elect_all(e)
+    gen = oracle_engine(G, R, seed=int(z["seed"]))  # host restatement of the ack generator only
+    sim = np.zeros((R, G), dtype=np.uint64)
+    for t in range(ticks):
+        e.step_dense_acks(synth_tick_host(gen, mode, t, sim))
+        if (t + 1) % every == 0:
+            assert np.array_equal(e.read("commit"), z[f"commit_{t+1}"]), t
+            assert np.array_equal(e.read("head"), z[f"head_{t+1}"]), t
+            assert np.array_equal(e.read("repl_state"), z[f"repl_{t+1}"]), t
+            for r in range(R):
+                assert np.array_equal(e.read("match", r), z[f"match_{t+1}"][r]), (t, r)
+    assert e.counters()["decisions"] == int(z["decisions"])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_fuzz_golden(backend):
+    z = np.load(os.path.join(HERE, "fuzz_r3.npz"))
+    G, R, steps = int(z["G"]), int(z["R"]), int(z["steps"])
+    e = make(backend, G, R, seed=99)
+    msg_h, fsm_h, flt_h = hashlib.sha256(), hashlib.sha256(), hashlib.sha256()
+    for s in range(steps):
+        cols = {k: z[f"in{s}_{k}"] for k in ("kind", "group", "from_", "term", "id", "aux", "flag", "blk_id", "blk_next")}
+        e.submit_columns(**cols)
+        e.step(int(z[f"in{s}_now"]))
+        msg_h.update(e.drain_messages().tobytes())
+        fsm_h.update(e.drain_applies().tobytes())
+        flt_h.update(e.drain_faults().tobytes())
+    for name in ("term", "voted_for", "role", "commit", "head", "id_gen", "fault", "repl_state", "vote_seen",
+                 "vote_granted", "election_timeout", "queued_reqs"):
+        assert np.array_equal(e.read(name), z[f"final_{name}"]), name
+    for r in range(R):
+        assert np.array_equal(e.read("match", r), z["final_match"][r])
+    assert msg_h.hexdigest() == str(z["digest_messages"])
+    assert fsm_h.hexdigest() == str(z["digest_applies"])
+    assert flt_h.hexdigest() == str(z["digest_faults"])
