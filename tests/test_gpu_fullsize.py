@@ -1,0 +1,85 @@
+"""Parity at BASELINE.json's full sizes.  The oracle cannot run 10^6 groups in seconds, so
+(1) the counter-based trace lets it re-run *windows* of the full problem (any shard
+regenerates its slice from the global group id) which are compared bit for bit, and
+(2) size-independent properties are checked over every group: commit <= head, match <= head,
+commit == element R/2 of the sorted match heads (the majority invariant), monotone commit,
+no faults, and the closed form of the steady-state stream."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from josefine_amd import BatchedRaft, capi
+from oracle_lib import oracle_engine
+from parity import DeviceSynth, elect_all, synth_tick_host
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x6A6F736566696E65
+
+
+def run_device(G, R, mode, ticks, on_tick=None):
+    dev = BatchedRaft(G, R, seed=SEED)
+    elect_all(dev)
+    dev.drain_messages(), dev.drain_applies()
+    synth = DeviceSynth(dev)
+    for t in range(ticks):
+        synth.fill(mode, t)
+        dev._check(dev.api.step_dense_acks_device(dev._h, synth.acks))
+        if on_tick:
+            on_tick(t, dev)
+    synth.close()
+    return dev
+
+
+def window_oracle(base, W, R, mode, ticks):
+    ora = oracle_engine(W, R, seed=SEED, group_base=base)
+    elect_all(ora)
+    sim = np.zeros((R, W), dtype=np.uint64)
+    for t in range(ticks):
+        ora.step_dense_acks(synth_tick_host(ora, mode, t, sim))
+    return ora
+
+
+def check_properties(dev, R):
+    head, commit = dev.read("head"), dev.read("commit")
+    m = np.stack([dev.read("match", r) for r in range(R)])
+    assert not dev.read("fault").any()
+    assert (commit <= head).all()
+    assert (m <= head[None, :]).all()
+    # majority invariant: once a leader has evaluated commit() after its last match change,
+    # commit >= the R/2-th largest match head, and it never exceeds the largest
+    kth = np.sort(m, axis=0)[::-1][R // 2]
+    assert (commit >= kth).all() and (commit <= m.max(axis=0)).all()
+    return head, commit
+
+
+@pytest.mark.parametrize("G,R,mode,ticks", [
+    (1_000_000, 5, 1, 24),   # configs[2] size, ragged stream (drops, stale duplicates)
+    (1_250_000, 3, 1, 24),   # configs[3]: one GPU's shard of 10 M x 3
+    (1_000_000, 5, 0, 30),   # configs[2]: the steady-state stream the bench times
+])
+def test_full_size_windows_and_properties(G, R, mode, ticks):
+    prev = {"commit": None}
+
+    def on_tick(t, dev):
+        if t % 8 == 7:  # monotone commit, sampled
+            c = dev.read("commit")
+            if prev["commit"] is not None:
+                assert (c >= prev["commit"]).all()
+            prev["commit"] = c
+
+    dev = run_device(G, R, mode, ticks, on_tick)
+    head, commit = check_properties(dev, R)
+    if mode == 0:  # closed form: 1 append per tick, acks lag one tick
+        assert (head == ticks).all() and (commit == ticks - 1).all()
+        assert (dev.read("repl_state") == (1 << R) - 1).all()
+    W = 2048
+    for base in (0, 4096 * 7, G // 2 - 1000, G - W):
+        ora = window_oracle(base, W, R, mode, ticks)
+        assert np.array_equal(commit[base:base + W], ora.read("commit")), base
+        assert np.array_equal(head[base:base + W], ora.read("head")), base
+        assert np.array_equal(dev.read("repl_state", 0, base, W), ora.read("repl_state")), base
+        for r in range(R):
+            assert np.array_equal(dev.read("match", r, base, W), ora.read("match", r)), (base, r)
+    assert dev.counters()["dense_group_steps"] == G * ticks
