@@ -270,6 +270,10 @@ int jg_step(jg_engine* e, uint64_t now_ms);
  * queue of jg_step) and raises JG_FAULT_ENGINE_DENSE_NONLEADER. */
 int jg_step_dense_acks(jg_engine* e, const uint64_t* acks_host);
 int jg_step_dense_acks_device(jg_engine* e, const uint64_t* acks_dev);
+/* `n_ticks` consecutive dense ticks in one launch: tick t reads the [R][G] block at
+ * acks_dev + t*R*G.  Identical in effect to n_ticks calls of jg_step_dense_acks_device;
+ * the groups' state is read and written once per launch instead of once per tick. */
+int jg_step_dense_acks_device_n(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks);
 
 /* Batched Chain::compact (src/raft/chain.rs:239-253) as a pure function over
  * explicit (id,next) trees: tree t owns entries [off[t], off[t+1]); ids within a

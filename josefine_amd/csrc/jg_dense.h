@@ -249,3 +249,69 @@ __global__ __launch_bounds__(JG_BLOCK) void k_leader_tick_dense_x2(JgDev d, cons
   }
   jg_block_count(d.blk_decisions, dec);
 }
+
+// ---- variant N: T consecutive ticks per launch (temporal fusion) -----------------------------
+// When the caller already holds the ack blocks of several ticks (a batched event loop, the
+// pre-generated bench stream), the group's state stays in registers across them: it is read
+// once and written once per launch, so a group-step costs 8R (acks) + (16R+36)/T bytes of
+// traffic instead of 24R+36.  Semantically identical to T calls of the single-tick kernel:
+// tick t reads acks + t*tick_stride and carries sequence number seq0 + t.
+template <int R>
+__global__ __launch_bounds__(JG_BLOCK) void k_leader_tick_dense_n(JgDev d, const uint64_t* __restrict__ acks,
+                                                                   uint32_t n_ticks, size_t tick_stride,
+                                                                   uint32_t seq0) {
+  const uint32_t G = d.G;
+  uint32_t dec = 0;
+  for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
+    const uint32_t f = d.flags[g];
+    uint64_t a[R], an[R], m[R], m0[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) a[r] = __builtin_nontemporal_load(&acks[(size_t)r * G + g]);
+#pragma unroll
+    for (int r = 0; r < R; r++) m0[r] = m[r] = d.match[(size_t)r * G + g];
+    const uint64_t commit0 = d.commit[g], head0 = d.head[g];
+    if (f & JGF_FAULT_MASK) continue;  // the reference process is gone
+    const uint32_t s = (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
+    const bool leader = (f & JGF_ROLE_MASK) == JG_ROLE_LEADER;
+    if (leader && !(f & JGF_FAST)) {  // irregular chain: k_dense_slow replays all ticks
+      uint32_t idx = atomicAdd(d.slow_n, 1u);
+      if (idx < G) d.slow_list[idx] = g;
+      continue;
+    }
+    uint64_t commit = commit0, head = head0;
+    uint32_t nf = f;
+    for (uint32_t t = 0; t < n_ticks; t++) {
+      const bool more = t + 1 < n_ticks;
+      if (more) {  // software prefetch of the next tick's acks
+        const uint64_t* nx = acks + (size_t)(t + 1) * tick_stride;
+#pragma unroll
+        for (int r = 0; r < R; r++) an[r] = __builtin_nontemporal_load(&nx[(size_t)r * G + g]);
+      }
+      uint64_t n_app = 0;
+#pragma unroll
+      for (int r = 0; r < R; r++) n_app = (r == (int)s) ? a[r] : n_app;
+      if (!leader) {
+        // acks are ignored by followers / candidates (follower.rs:62, candidate.rs:194)
+        if (n_app) {
+          nf = f | (JG_FAULT_ENGINE_DENSE_NONLEADER << JGF_FAULT_SHIFT);
+          jg_push_fault(d, g, JG_FAULT_ENGINE_DENSE_NONLEADER, seq0 + t);
+          break;
+        }
+      } else {
+        dec += jg_dense_core<R>(d, g, seq0 + t, s, n_app, a, m, commit, head, nf);
+        if (nf & JGF_FAULT_MASK) break;
+      }
+      if (more) {
+#pragma unroll
+        for (int r = 0; r < R; r++) a[r] = an[r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (m[r] != m0[r]) d.match[(size_t)r * G + g] = m[r];
+    if (commit != commit0) d.commit[g] = commit;
+    if (head != head0) d.head[g] = head;
+    if (nf != f) d.flags[g] = nf;
+  }
+  jg_block_count(d.blk_decisions, dec);
+}

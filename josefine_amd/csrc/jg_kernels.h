@@ -15,41 +15,45 @@
 
 #include "jg_dense.h"  // k_leader_tick_dense / _x2, jg_block_count, JG_BLOCK
 
-// Same tick through the general state machine, for the groups the fast kernel
+// Same ticks through the general state machine, for the groups the fast kernel
 // deferred (chain not in FAST form).
-__global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t seq) {
+__global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
+                                                          size_t tick_stride, uint32_t seq0) {
   uint32_t dec = 0;
-  const uint32_t n = *d.slow_n;
+  const uint32_t n = *d.slow_n < d.G ? *d.slow_n : d.G;
   for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < n; i += gridDim.x * JG_BLOCK) {
     JgLane L;
     jg_load(d, L, d.slow_list[i]);
     L.now = 0;
-    L.seq = seq;
     L.mp = L.mend = nullptr;  // a leader's client requests / acks emit no messages
     jg_fsm_row sink[2];
     const uint32_t s = jg_self(L);
-    uint64_t n_app = acks[(size_t)s * d.G + L.g];
-    JgCmd c;
-    c.kind = JG_CMD_CLIENT_REQUEST;
-    c.from = 0;
-    c.flag = 0;
-    c.term = c.id = c.aux = 0;
-    for (uint64_t k = 0; k < n_app && !jg_fault(L); k++) {
-      L.fp = sink;
-      L.fend = sink + 2;
-      jg_apply(d, L, c, nullptr, nullptr);
-    }
-    c.kind = JG_CMD_APPEND_RESPONSE;
-    c.flag = 1;
-    for (uint32_t r = 0; r < d.R && !jg_fault(L); r++) {
-      if (r == s) continue;
-      uint64_t h = acks[(size_t)r * d.G + L.g];
-      if (h == JG_NO_ACK) continue;
-      c.from = d.node_ids[r];
-      c.id = h;
-      L.fp = sink;
-      L.fend = sink + 2;
-      jg_apply(d, L, c, nullptr, nullptr);
+    for (uint32_t t = 0; t < n_ticks && !jg_fault(L); t++) {
+      const uint64_t* A = acks + (size_t)t * tick_stride;
+      L.seq = seq0 + t;
+      uint64_t n_app = A[(size_t)s * d.G + L.g];
+      JgCmd c;
+      c.kind = JG_CMD_CLIENT_REQUEST;
+      c.from = 0;
+      c.flag = 0;
+      c.term = c.id = c.aux = 0;
+      for (uint64_t k = 0; k < n_app && !jg_fault(L); k++) {
+        L.fp = sink;
+        L.fend = sink + 2;
+        jg_apply(d, L, c, nullptr, nullptr);
+      }
+      c.kind = JG_CMD_APPEND_RESPONSE;
+      c.flag = 1;
+      for (uint32_t r = 0; r < d.R && !jg_fault(L); r++) {
+        if (r == s) continue;
+        uint64_t h = A[(size_t)r * d.G + L.g];
+        if (h == JG_NO_ACK) continue;
+        c.from = d.node_ids[r];
+        c.id = h;
+        L.fp = sink;
+        L.fend = sink + 2;
+        jg_apply(d, L, c, nullptr, nullptr);
+      }
     }
     dec += L.decisions;
     jg_store(d, L);

@@ -102,8 +102,12 @@ inline void row_bounds(uint8_t kind, uint32_t R, uint32_t* m, uint32_t* f) {
 }
 
 template <int R>
-void launch_dense(jg_engine* e, const uint64_t* acks) {
-  if (e->dense_variant == 2)  // two groups per lane, 16-B accesses (needs an even G)
+void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks) {
+  const size_t stride = (size_t)e->cfg.n_groups * e->cfg.n_replicas;
+  if (n_ticks > 1)  // temporal fusion: state read once, written once per launch
+    hipLaunchKernelGGL(k_leader_tick_dense_n<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
+                       n_ticks, stride, e->seq);
+  else if (e->dense_variant == 2)  // two groups per lane, 16-B accesses (needs an even G)
     hipLaunchKernelGGL(k_leader_tick_dense_x2<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
                        e->seq);
   else
@@ -111,28 +115,29 @@ void launch_dense(jg_engine* e, const uint64_t* acks) {
                        e->seq);
 }
 
-int dense_step(jg_engine* e, const uint64_t* acks_dev) {
+int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1) {
   e->stepped = true;
-  e->seq++;
+  e->seq++;  // tick t of this launch carries sequence number seq + t
   if (e->maybe_irregular) HIPCHK(hipMemsetAsync(e->dev.slow_n, 0, sizeof(uint32_t), e->stream));
   switch (e->cfg.n_replicas) {
-    case 1: launch_dense<1>(e, acks_dev); break;
-    case 2: launch_dense<2>(e, acks_dev); break;
-    case 3: launch_dense<3>(e, acks_dev); break;
-    case 4: launch_dense<4>(e, acks_dev); break;
-    case 5: launch_dense<5>(e, acks_dev); break;
-    case 6: launch_dense<6>(e, acks_dev); break;
-    case 7: launch_dense<7>(e, acks_dev); break;
-    default: launch_dense<8>(e, acks_dev); break;
+    case 1: launch_dense<1>(e, acks_dev, n_ticks); break;
+    case 2: launch_dense<2>(e, acks_dev, n_ticks); break;
+    case 3: launch_dense<3>(e, acks_dev, n_ticks); break;
+    case 4: launch_dense<4>(e, acks_dev, n_ticks); break;
+    case 5: launch_dense<5>(e, acks_dev, n_ticks); break;
+    case 6: launch_dense<6>(e, acks_dev, n_ticks); break;
+    case 7: launch_dense<7>(e, acks_dev, n_ticks); break;
+    default: launch_dense<8>(e, acks_dev, n_ticks); break;
   }
   e->n_launch++;
   if (e->maybe_irregular) {
     hipLaunchKernelGGL(k_dense_slow, dim3(std::min<uint32_t>(e->count_slots, 64)), dim3(JG_BLOCK), 0, e->stream,
-                       e->dev, acks_dev, e->seq);
+                       e->dev, acks_dev, n_ticks, (size_t)e->cfg.n_groups * e->cfg.n_replicas, e->seq);
     e->n_launch++;
   }
   HIPCHK(hipGetLastError());
-  e->n_dense += e->cfg.n_groups;
+  e->seq += n_ticks - 1;
+  e->n_dense += (uint64_t)e->cfg.n_groups * n_ticks;
   return JG_OK;
 }
 
@@ -492,6 +497,14 @@ int jg_step_dense_acks_device(jg_engine* e, const uint64_t* acks_dev) {
   if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
   HIPCHK(hipSetDevice(e->device));
   return dense_step(e, acks_dev);
+}
+
+int jg_step_dense_acks_device_n(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks) {
+  if (!e || !acks_dev) return fail(JG_EINVAL, "null argument");
+  if (!n_ticks) return JG_OK;
+  if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
+  HIPCHK(hipSetDevice(e->device));
+  return dense_step(e, acks_dev, n_ticks);
 }
 
 int jg_step_dense_acks(jg_engine* e, const uint64_t* acks_host) {

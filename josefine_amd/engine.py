@@ -246,6 +246,26 @@ class BatchedRaft:
         assert a.shape == (self.R, self.G), a.shape
         self._check(self.api.step_dense_acks(self._h, a.ctypes.data))
 
+    def step_dense_acks_n(self, acks: np.ndarray) -> None:
+        """T consecutive dense ticks from a host [T, R, G] array.  On the device engine this is
+        ONE launch (jg_step_dense_acks_device_n: state read and written once); a backend without
+        that entry point gets the T ticks one by one — the two are specified to be identical."""
+        self._flush_pending()
+        a = np.ascontiguousarray(acks, dtype=np.uint64)
+        assert a.ndim == 3 and a.shape[1:] == (self.R, self.G), a.shape
+        if not hasattr(self.api, "step_dense_acks_device_n"):
+            for t in range(a.shape[0]):
+                self._check(self.api.step_dense_acks(self._h, a[t].ctypes.data))
+            return
+        buf = C.c_void_p()
+        self._check(self.api.device_alloc(self._h, a.nbytes, C.byref(buf)))
+        try:
+            self._check(self.api.device_upload(self._h, buf, a.ctypes.data, a.nbytes))
+            self._check(self.api.step_dense_acks_device_n(self._h, buf, a.shape[0]))
+            self._check(self.api.sync(self._h))
+        finally:
+            self.api.device_free(self._h, buf)
+
     # -- output --------------------------------------------------------------
     def _drain(self, fn, dtype) -> np.ndarray:
         n = C.c_size_t(0)

@@ -109,3 +109,128 @@ def test_dense_equals_sparse_path():
         adv = np.nonzero(commit != commit_prev)[0]
         assert set(adv) == set(np.unique(fsm["group"][fsm["kind"] == capi.FSM_APPLY_LEADER]))
         head_prev, commit_prev = head.copy(), commit.copy()
+
+
+@pytest.mark.parametrize("R,T", [(3, 2), (5, 4), (5, 7), (1, 3), (8, 5)])
+def test_dense_fused_ticks_parity(R, T):
+    """jg_step_dense_acks_device_n: T ticks per launch == T single ticks (state after each launch)."""
+    from parity import synth_tick_host
+    G = 5000
+    dev, ora = pair(G, R, seed=31 + R)
+    for e in (dev, ora):
+        elect_all(e)
+        e.drain_messages(), e.drain_applies()
+    sim = np.zeros((R, G), dtype=np.uint64)
+    t = 0
+    for launch in range(6):
+        block = np.stack([synth_tick_host(ora, 1, t + k, sim) for k in range(T)])
+        t += T
+        dev.step_dense_acks_n(block)
+        ora.step_dense_acks_n(block)
+        compare_snapshots(dev, ora, f"fused R={R} T={T} launch {launch}",
+                          ["commit", "head", "match", "repl_state", "fault", "id_gen", "role"])
+    assert dev.counters()["decisions"] == ora.counters()["decisions"]
+    assert dev.counters()["dense_group_steps"] == G * t
+
+
+def _dense_edge_case_engines():
+    """Groups 0: plain leader; 1: follower; 2: leader that will get forged acks; 3: leader whose
+    chain is not in FAST form (restarted with commit 2: id_gen == head, Q8); 4: faulted leader."""
+    G, R = 6, 3
+    dev, ora = pair(G, R, seed=3)
+    for e in (dev, ora):
+        for g in (0, 2, 4, 5):
+            e.submit(g, Command.Timeout())
+            e.submit(g, Command.VoteResponse(1, 2, True))
+        e.submit(4, Command.AppendEntries(9, 2, []))           # leader + higher term -> fault (Q3)
+        e.submit(3, Command.AppendEntries(1, 2, [(1, 0), (2, 1)]))
+        e.submit(3, Command.Heartbeat(1, 2, 2))                 # commit 2
+        e.submit(3, Command.Restart())                          # head = id_gen = commit = 2
+        e.submit(3, Command.Timeout())
+        e.submit(3, Command.VoteResponse(1, 2, True))
+        e.step()
+        e.drain_messages(), e.drain_applies(), e.drain_faults()
+    assert list(ora.read("role")) == [2, 0, 2, 2, 2, 2]
+    return dev, ora, G, R
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_dense_faults_followers_and_irregular_chains(fused, dense_variant):
+    dev, ora, G, R = _dense_edge_case_engines()
+    NO = capi.NO_ACK
+    T = 4
+    acks = np.full((T, R, G), NO, dtype=np.uint64)
+    acks[:, 0, :] = 0
+    # tick 0: everyone healthy appends once, followers ack nothing yet
+    acks[0, 0, [0, 2, 5]] = 1
+    acks[0, 1, 3] = 2                      # an ack to the irregular leader (no append): fine, q = 0.. no commit change
+    # tick 1: acks arrive; group 2 gets a forged head from one follower (no quorum yet: no fault)
+    acks[1, 1, [0, 5]] = 1
+    acks[1, 1, 2] = 10**6
+    acks[1, 0, 5] = 3                      # three appends in one tick
+    # tick 2: the second forged ack makes q = 10^6 > head -> chain.commit panics (chain.rs:197-202);
+    #         the follower group is asked to append -> engine precondition fault; the irregular
+    #         leader appends -> assert!(id > head) fails (chain.rs:163)
+    acks[2, 2, 2] = 10**6
+    acks[2, 0, 1] = 1
+    acks[2, 0, 3] = 1
+    acks[2, 2, [0, 5]] = 1
+    # tick 3: the dead groups ignore everything; the living go on
+    acks[3, 0, :] = 1
+    acks[3, 1, [0, 5]] = 2
+    if fused:
+        dev.step_dense_acks_n(acks)
+        ora.step_dense_acks_n(acks)
+        compare_snapshots(dev, ora, "dense edge cases fused")
+        compare_drains(dev, ora, "dense edge cases fused")
+    else:
+        for t in range(T):
+            dev.step_dense_acks(acks[t])
+            ora.step_dense_acks(acks[t])
+            compare_snapshots(dev, ora, f"dense edge cases tick {t}")
+            compare_drains(dev, ora, f"dense edge cases tick {t}")
+    assert list(ora.read("fault")) == [0, capi.FAULT_ENGINE_DENSE_NONLEADER, capi.FAULT_COMMIT_MISSING_BLOCK,
+                                       capi.FAULT_APPEND_ID_NOT_ABOVE_HEAD, capi.FAULT_LEADER_TERM_UNIMPLEMENTED, 0]
+    assert int(ora.read("head")[5]) == 5 and int(ora.read("commit")[5]) == 2
+
+
+def test_chain_window_overflow_is_loud():
+    """More gaps / forks than JG_CHAIN_WINDOW segments: an engine fault, never a silent miss."""
+    dev = BatchedRaft(2, 3)
+    blocks = [(10 * i, 0) for i in range(1, capi.CHAIN_WINDOW + 2)]  # every block its own segment
+    dev.apply(0, Command.AppendEntries(0, 2, blocks))
+    assert dev.handle(0).fault == capi.FAULT_ENGINE_WINDOW_OVERFLOW
+    assert [tuple(r) for r in dev.drain_faults()] == [(0, capi.FAULT_ENGINE_WINDOW_OVERFLOW)]
+    assert dev.handle(1).fault == 0
+    dev2 = BatchedRaft(1, 3)
+    dev2.apply(0, Command.Timeout())
+    dev2.apply(0, Command.VoteResponse(1, 77, True))  # not a member
+    assert dev2.handle(0).fault == capi.FAULT_ENGINE_FOREIGN_VOTER
+
+
+@pytest.mark.parametrize("n_trees", [1, 300])
+def test_chain_compact_parity(n_trees):
+    """Random forests through Chain::compact: device walk vs oracle walk, bit for bit."""
+    rng = np.random.default_rng(77 + n_trees)
+    dev, ora = pair(1, 1)
+    trees = []
+    for _ in range(n_trees):
+        n = int(rng.integers(0, 40))
+        ids, blocks = [0], [(0, 0)]
+        nxt = 1
+        for _ in range(n):
+            nxt += int(rng.integers(1, 3))                 # gaps in the id space
+            parent = ids[-1] if rng.random() < 0.7 else int(rng.choice(ids))
+            blocks.append((nxt, parent))
+            ids.append(nxt)
+        if n and rng.random() < 0.2:                        # an overwritten block (sled upsert: last wins)
+            blocks.append((ids[len(ids) // 2], ids[0]))
+        order = rng.permutation(len(blocks)) if rng.random() < 0.5 else np.arange(len(blocks))
+        if len(blocks) > len(ids):                          # keep the overwrite after its original
+            order = np.arange(len(blocks))
+        commit = int(rng.choice(ids)) if rng.random() < 0.8 else nxt + 5
+        trees.append(([blocks[i] for i in order], commit))
+    a, b = dev.chain_compact(trees), ora.chain_compact(trees)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), (i, trees[i], x, y)
+    assert sum(int(x.sum()) for x in a) > 0 or n_trees == 1
