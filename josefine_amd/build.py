@@ -24,6 +24,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
            "-Wno-unused-function", "-o", LIB, os.path.join(CSRC, "josefine_gpu.hip")]
+    if os.environ.get("JG_BLOCK"):  # workgroup-size experiments (profiles/README.md); default 256
+        cmd.insert(1, "-DJG_BLOCK=" + os.environ["JG_BLOCK"])
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

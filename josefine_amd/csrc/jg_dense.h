@@ -20,7 +20,9 @@
 #pragma once
 #include "jg_device.h"
 
+#ifndef JG_BLOCK
 #define JG_BLOCK 256
+#endif
 
 typedef unsigned long long jg_u64x2 __attribute__((ext_vector_type(2)));  // one 16-B access
 
@@ -177,21 +179,30 @@ __global__ __launch_bounds__(JG_BLOCK) void k_leader_tick_dense(JgDev d, const u
   uint32_t dec = 0;
   for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
     const uint32_t f = d.flags[g];
-    uint64_t a[R], m[R], m0[R];
+    uint64_t a[R], m[R];
 #pragma unroll
     for (int r = 0; r < R; r++) a[r] = __builtin_nontemporal_load(&acks[(size_t)r * G + g]);
 #pragma unroll
-    for (int r = 0; r < R; r++) m0[r] = m[r] = d.match[(size_t)r * G + g];
+    for (int r = 0; r < R; r++) m[r] = d.match[(size_t)r * G + g];
     const uint64_t commit0 = d.commit[g], head0 = d.head[g];
     uint32_t s;
     uint64_t n_app;
     if (jg_dense_classify<R>(d, g, f, a, seq, &s, &n_app) != JG_DENSE_RUN) continue;
     uint64_t commit = commit0, head = head0;
     uint32_t nf = f;
+    // a match head changes only through an increment, i.e. exactly when its ack (or the
+    // self-ack) is above the old value: remember that instead of keeping the old heads
+    uint32_t chg = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const bool self = r == (int)s;
+      const bool up = self ? (n_app != 0 && m[r] < head0 + n_app) : (a[r] != JG_NO_ACK && m[r] < a[r]);
+      chg |= up ? (1u << r) : 0u;
+    }
     dec += jg_dense_core<R>(d, g, seq, s, n_app, a, m, commit, head, nf);
 #pragma unroll
     for (int r = 0; r < R; r++)
-      if (m[r] != m0[r]) d.match[(size_t)r * G + g] = m[r];
+      if (chg & (1u << r)) d.match[(size_t)r * G + g] = m[r];
     if (commit != commit0) d.commit[g] = commit;
     if (head != head0) d.head[g] = head;
     if (nf != f) d.flags[g] = nf;

@@ -26,7 +26,8 @@ import numpy as np
 
 from . import _capi as capi
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libjosefine_gpu.so")
+_LIB_PATH = os.environ.get("JOSEFINE_GPU_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
+                                                               "libjosefine_gpu.so")
 _device_api: Optional[capi.Api] = None
 
 
