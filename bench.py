@@ -136,7 +136,9 @@ def main():
     if args.failures:
         from failures import failure_rows
         slots = eng.read("self_slot")
-        fail_rows = [failure_rows(args.seed, t, rank * G, G, R, eng.node_ids, slots, args.failures)[0]
+        # the failure trace, like the ack stream, is resident in HBM before the timed region:
+        # one group-sorted device batch per tick (jg_step_device_rows, no host pass per tick)
+        fail_rows = [eng.upload_rows(**failure_rows(args.seed, t, rank * G, G, R, eng.node_ids, slots, args.failures)[0])
                      for t in range(W + K)]
 
     def run_ticks(t0_, t1_):
@@ -150,9 +152,8 @@ def main():
                 eng._check(api.step_dense_acks_device(h, ptr))
             else:
                 eng._check(api.step_dense_acks_device_n(h, ptr, n))
-            if fail_rows is not None and len(fail_rows[t]["kind"]):
-                eng.submit_columns(**fail_rows[t])
-                eng.step(now_ms=100 * (t + 1))
+            if fail_rows is not None and fail_rows[t].n:
+                eng.step_device_rows(fail_rows[t], now_ms=100 * (t + 1))
                 if t % 16 == 15:  # the host consumes the outbound messages as it goes
                     eng.drain_messages(), eng.drain_applies(), eng.drain_faults()
             t += n

@@ -254,6 +254,14 @@ int jg_submit(jg_engine* e, const jg_cmd_batch* batch);
  * engine's stream; drains and reads synchronise. */
 int jg_step(jg_engine* e, uint64_t now_ms);
 
+/* The same step for a batch that already lives in device memory: every pointer of
+ * `dev_batch` is a device pointer (all seven columns required; the block side
+ * arrays only if AppendEntries rows are present) and the rows MUST be sorted by
+ * group, rows of one group in stream order — the form k_apply_rows consumes, so no
+ * host pass is needed.  Unsorted rows or an out-of-range group are reported as
+ * JG_EINVAL by the next synchronising call. */
+int jg_step_device_rows(jg_engine* e, const jg_cmd_batch* dev_batch, uint64_t now_ms);
+
 /* Dense steady-state leader tick (the HBM-roofline path).
  * `acks` is an [R][G] column-major array (replica-major: acks[r*G+g]):
  *   r != self_slot[g]: head of an AppendResponse{node_id: node_ids[r], head} or JG_NO_ACK;

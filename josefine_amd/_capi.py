@@ -132,6 +132,7 @@ class Api:
     }
     # only the device engine has these
     _DEVICE_PROTOS = {
+        "step_device_rows": (C.c_int, [_P, C.POINTER(CmdBatch), C.c_uint64]),
         "step_dense_acks_device": (C.c_int, [_P, _P]),
         "step_dense_acks_device_n": (C.c_int, [_P, _P, C.c_uint32]),
         "sync": (C.c_int, [_P]),
@@ -176,7 +177,7 @@ class Api:
 
 # Every symbol include/josefine_gpu.h declares (checked by the CPU test-suite).
 HEADER_SYMBOLS = [
-    "jg_engine_create", "jg_engine_destroy", "jg_set_self_slots", "jg_submit", "jg_step",
+    "jg_engine_create", "jg_engine_destroy", "jg_set_self_slots", "jg_submit", "jg_step", "jg_step_device_rows",
     "jg_step_dense_acks", "jg_step_dense_acks_device", "jg_step_dense_acks_device_n", "jg_chain_compact", "jg_sync",
     "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_read_state", "jg_get_counters",
     "jg_device_alloc", "jg_device_free", "jg_device_upload", "jg_device_download",

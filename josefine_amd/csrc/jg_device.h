@@ -72,6 +72,7 @@ struct JgDev {
   uint32_t fault_q_cap;
   uint32_t* slow_list;       // groups the dense fast path deferred
   uint32_t* slow_n;
+  uint32_t* irregular_seen;  // set when a group is stored with a chain that is not in FAST form
 };
 
 // splitmix64 finaliser: the counter-based RNG of DESIGN.md "Logical time and randomness"
@@ -149,6 +150,7 @@ __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   uint32_t g = L.g;
   bool fast = (L.run_hi == L.head) && (L.id_gen == L.head + 1) && (jg_wcnt(L) == 0);
   L.flags = fast ? (L.flags | JGF_FAST) : (L.flags & ~JGF_FAST);
+  if (!fast) *d.irregular_seen = 1;  // the host then schedules k_dense_slow behind the dense kernel
   d.flags[g] = L.flags;
   d.term[g] = L.term;
   d.commit[g] = L.commit;

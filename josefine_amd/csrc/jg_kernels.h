@@ -5,7 +5,7 @@
 //                           leaders over SoA columns (progress.rs:42-60,133-140;
 //                           leader.rs:87-99,177-197,211-219)
 //   k_dense_slow            same tick for groups whose chain is not in FAST form
-//   k_apply_cmds            the full state machine over a CSR command batch
+//   k_apply_rows            the full state machine over a group-sorted command batch
 //                           (every role, every Command; mod.rs:471-479)
 //   k_chain_compact         Chain::compact parent-pointer walk (chain.rs:239-253)
 //   k_synth_acks            synthetic ack-stream generator (bench / parity input)
@@ -61,73 +61,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
   jg_block_count(d.blk_decisions, dec);
 }
 
-// ---- general command kernel -----------------------------------------------------------------
-struct JgStepArgs {
-  uint32_t n_active;
-  const uint32_t* seg_group;  // [n_active] group of each segment (ascending)
-  const uint32_t* seg_off;    // [n_active+1] command range of each segment
-  const uint8_t* kind;        // commands in CSR (group-major, stream) order
-  const uint32_t* from;
-  const uint64_t* term;
-  const uint64_t* id;
-  const uint64_t* aux;
-  const uint8_t* flag;
-  const uint64_t* blk_id;
-  const uint64_t* blk_next;
-  const uint32_t* msg_base;   // [n_active+1] output-region bounds (prefix sums)
-  const uint32_t* fsm_base;
-  jg_msg_row* msg_out;
-  jg_fsm_row* fsm_out;
-  uint32_t* msg_cnt;          // [n_active] rows actually produced
-  uint32_t* fsm_cnt;
-  uint32_t* err;              // set when a row did not fit its bound
-  uint64_t now;
-  uint32_t seq;
-};
-
-__global__ __launch_bounds__(JG_BLOCK) void k_apply_cmds(JgDev d, JgStepArgs a) {
-  uint32_t dec = 0;
-  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < a.n_active; i += gridDim.x * JG_BLOCK) {
-    JgLane L;
-    jg_load(d, L, a.seg_group[i]);
-    L.now = a.now;
-    L.seq = a.seq;
-    jg_msg_row* m0 = a.msg_out + a.msg_base[i];
-    jg_fsm_row* f0 = a.fsm_out + a.fsm_base[i];
-    L.mp = m0;
-    L.mend = a.msg_out + a.msg_base[i + 1];
-    L.fp = f0;
-    L.fend = a.fsm_out + a.fsm_base[i + 1];
-    for (uint32_t k = a.seg_off[i]; k < a.seg_off[i + 1]; k++) {
-      JgCmd c;
-      c.kind = a.kind[k];
-      c.from = a.from[k];
-      c.flag = a.flag[k];
-      c.term = a.term[k];
-      c.id = a.id[k];
-      c.aux = a.aux[k];
-      jg_apply(d, L, c, a.blk_id, a.blk_next);
-    }
-    a.msg_cnt[i] = (uint32_t)(L.mp - m0);
-    a.fsm_cnt[i] = (uint32_t)(L.fp - f0);
-    if (L.overflow) *a.err = 1;
-    dec += L.decisions;
-    jg_store(d, L);
-  }
-  jg_block_count(d.blk_decisions, dec);
-}
-
-// drain-time compaction: copy each segment's rows to its final offset
-template <typename Row>
-__global__ void k_gather_rows(uint32_t n_seg, const uint32_t* __restrict__ src_base, const uint32_t* __restrict__ cnt,
-                              const uint32_t* __restrict__ dst_off, const Row* __restrict__ src, Row* __restrict__ dst) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_seg; i += gridDim.x * blockDim.x) {
-    uint32_t n = cnt[i];
-    const Row* s = src + src_base[i];
-    Row* t = dst + dst_off[i];
-    for (uint32_t k = 0; k < n; k++) t[k] = s[k];
-  }
-}
+#include "jg_sparse.h"  // k_apply_rows, k_gather_rows
 
 // ---- Chain::compact (chain.rs:239-253) -------------------------------------------------------
 // One lane per tree: walk the ids below `commit` in descending key order; keep the

@@ -2,7 +2,9 @@
 // Chained-Raft engine: host-side marshalling around the gfx950 kernels in
 // jg_kernels.h.  There is deliberately no CPU implementation in this library:
 // every entry point that computes does so on the device or fails with
-// JG_EDEVICE.
+// JG_EDEVICE.  What the host does do: validate arguments, bucket command rows by
+// group (a stable radix sort of row indices — marshalling, not Raft), move bytes,
+// and launch.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -20,21 +22,58 @@ static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
-#define HIPCHK(expr)                                                                                  \
-  do {                                                                                                \
-    hipError_t _e = (expr);                                                                           \
-    if (_e != hipSuccess)                                                                             \
+#define HIPCHK(expr)                                                                                     \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess)                                                                                \
       return fail(JG_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(_e) + " (no CPU fallback)"); \
   } while (0)
 
 namespace {
 
+// One sparse step whose output rows have not been drained yet.
 struct StepRec {
-  uint32_t n_active = 0;
-  void* blob = nullptr;  // one device allocation per step
-  uint32_t *d_msg_base = nullptr, *d_fsm_base = nullptr, *d_msg_cnt = nullptr, *d_fsm_cnt = nullptr;
+  uint32_t n = 0;  // command rows
+  uint32_t msg_per_row = 0, fsm_per_row = 0;
+  uint32_t *d_msg_cnt = nullptr, *d_fsm_cnt = nullptr;
   jg_msg_row* d_msg = nullptr;
   jg_fsm_row* d_fsm = nullptr;
+};
+
+// Grow-only device arena for the per-step command blobs and output regions:
+// bump allocation, reset when every pending step has been drained.  Keeps
+// hipMalloc/hipFree (hundreds of microseconds each) off the per-step path.
+struct Arena {
+  struct Chunk {
+    char* p;
+    size_t cap, off;
+  };
+  std::vector<Chunk> chunks;
+  hipError_t alloc(size_t bytes, void** out) {
+    bytes = (bytes + 255) & ~size_t(255);
+    if (chunks.empty() || chunks.back().off + bytes > chunks.back().cap) {
+      size_t cap = std::max<size_t>(bytes, chunks.empty() ? (size_t)32 << 20 : chunks.back().cap * 2);
+      void* p = nullptr;
+      hipError_t e = hipMalloc(&p, cap);
+      if (e != hipSuccess) return e;
+      chunks.push_back(Chunk{(char*)p, cap, 0});
+    }
+    Chunk& c = chunks.back();
+    *out = c.p + c.off;
+    c.off += bytes;
+    return hipSuccess;
+  }
+  void reset() {  // keep the largest chunk
+    while (chunks.size() > 1) {
+      (void)hipFree(chunks.front().p);
+      chunks.erase(chunks.begin());
+    }
+    if (!chunks.empty()) chunks.back().off = 0;
+  }
+  void destroy() {
+    for (Chunk& c : chunks) (void)hipFree(c.p);
+    chunks.clear();
+  }
 };
 
 }  // namespace
@@ -44,7 +83,7 @@ struct jg_engine {
   JgDev dev;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_stage = nullptr;
   std::vector<void*> allocs;
   uint32_t count_slots = 0;  // workgroup slots of dev.blk_decisions
   uint32_t dense_grid = 0;
@@ -55,24 +94,33 @@ struct jg_engine {
   std::vector<uint8_t> p_kind, p_flag;
   std::vector<uint32_t> p_group, p_from;
   std::vector<uint64_t> p_term, p_id, p_aux, p_blk_id, p_blk_next;
+  // pinned staging for the upload of one step (reused; guarded by ev_stage)
+  char* stage = nullptr;
+  size_t stage_cap = 0;
+  bool stage_busy = false;
+  Arena arena;
   std::vector<StepRec> recs;
   std::vector<jg_msg_row> q_msgs;
   std::vector<jg_fsm_row> q_fsm;
   std::vector<jg_fault_row> q_faults;
   uint32_t seq = 0;
   bool stepped = false;
-  bool maybe_irregular = false;  // some leader's chain may have left FAST form
+  // Some group's chain may have left FAST form (then k_dense_slow runs behind the
+  // dense kernel).  Set by every sparse step, cleared at the next synchronisation
+  // point if the device-side flag is still 0.
+  bool maybe_irregular = false;
+  bool flag_check_pending = false;
   uint64_t n_cmds = 0, n_dense = 0, n_launch = 0;
 };
 
 namespace {
 
 template <typename T>
-int dev_alloc(jg_engine* e, T** p, size_t n, bool zero = true) {
+int dev_alloc(jg_engine* e, T** p, size_t n) {
   void* q = nullptr;
   size_t bytes = std::max<size_t>(n * sizeof(T), 16);
   HIPCHK(hipMalloc(&q, bytes));
-  if (zero) HIPCHK(hipMemsetAsync(q, 0, bytes, e->stream));
+  HIPCHK(hipMemsetAsync(q, 0, bytes, e->stream));
   e->allocs.push_back(q);
   *p = (T*)q;
   return JG_OK;
@@ -84,22 +132,15 @@ inline uint32_t grid_for(size_t n, uint32_t cap) {
   return (uint32_t)std::min<size_t>(b, cap);
 }
 
-// output-row bounds per command kind (messages, fsm rows) for R replicas
-inline void row_bounds(uint8_t kind, uint32_t R, uint32_t* m, uint32_t* f) {
-  switch (kind) {
-    case JG_CMD_TICK:
-    case JG_CMD_TIMEOUT: *m = R + 1; *f = 0; break;       // DROP + (R-1) VoteRequest + Heartbeat | Heartbeat + (R-1) AppendEntries
-    case JG_CMD_HEARTBEAT_RESPONSE: *m = R; *f = 0; break;  // replicate()
-    case JG_CMD_HEARTBEAT: *m = 2; *f = 1; break;          // FLUSH + HeartbeatResponse; Apply
-    case JG_CMD_VOTE_RESPONSE: *m = 2; *f = 0; break;      // DROP + Heartbeat on elect()
-    case JG_CMD_CLIENT_REQUEST: *m = 1; *f = 2; break;     // proxy/queue; Notify + Apply
-    case JG_CMD_APPEND_RESPONSE: *m = 0; *f = 1; break;
-    case JG_CMD_VOTE_REQUEST:
-    case JG_CMD_APPEND_ENTRIES:
-    case JG_CMD_CLIENT_RESPONSE: *m = 1; *f = 0; break;
-    default: *m = 0; *f = 0; break;
-  }
-}
+// Output-row bounds per command (messages, fsm rows) for R replicas — the maximum
+// over all roles and kinds:
+//   Tick / Timeout      : DROP + (R-1) VoteRequest + Heartbeat (R = 1) | Heartbeat + (R-1) AppendEntries  -> R+1
+//   HeartbeatResponse   : replicate(): R-1 AppendEntries
+//   Heartbeat           : FLUSH + HeartbeatResponse; one Apply range
+//   VoteResponse        : DROP + Heartbeat on elect()
+//   ClientRequest       : forward / queue; Notify + Apply range
+inline uint32_t msg_bound(uint32_t R) { return R + 1 < 2 ? 2 : R + 1; }
+inline uint32_t fsm_bound() { return 2; }
 
 template <int R>
 void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks) {
@@ -141,55 +182,72 @@ int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1) {
   return JG_OK;
 }
 
-// Pull finished steps' output rows and the fault queue to the host queues.
-int collect(jg_engine* e) {
+// Everything that needs the stream idle first calls this: synchronise, surface
+// device-side error flags, and settle the lazily-read irregular-chain flag.
+int sync_and_check(jg_engine* e) {
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
-  uint32_t err = 0, slow_n = 0;
+  e->stage_busy = false;
+  uint32_t err = 0;
   HIPCHK(hipMemcpy(&err, e->d_err, sizeof err, hipMemcpyDeviceToHost));
-  if (err) return fail(JG_EDEVICE, "internal: an output row exceeded its per-command bound");
+  if (err == 1) return fail(JG_EDEVICE, "internal: an output row exceeded its per-command bound");
+  if (err == 2) return fail(JG_EINVAL, "device command rows were not sorted by group");
+  if (err == 3) return fail(JG_EINVAL, "device command rows name a group out of range");
+  if (e->flag_check_pending) {
+    uint32_t seen = 0;
+    HIPCHK(hipMemcpy(&seen, e->dev.irregular_seen, sizeof seen, hipMemcpyDeviceToHost));
+    e->maybe_irregular = seen != 0;  // sticky on the device: once seen, the slow kernel stays scheduled
+    e->flag_check_pending = false;
+  }
   if (!e->maybe_irregular) {
+    uint32_t slow_n = 0;
     HIPCHK(hipMemcpy(&slow_n, e->dev.slow_n, sizeof slow_n, hipMemcpyDeviceToHost));
     if (slow_n) return fail(JG_EDEVICE, "internal: irregular chain reached the fast-only dense path");
   }
+  return JG_OK;
+}
+
+// Pull finished steps' output rows and the fault queue to the host queues.
+int collect(jg_engine* e) {
+  int rc = sync_and_check(e);
+  if (rc) return rc;
   for (StepRec& r : e->recs) {
-    const uint32_t n = r.n_active;
-    std::vector<uint32_t> base(n + 1), cnt(n), off(n);
+    const uint32_t n = r.n;
+    std::vector<uint32_t> cnt(n);
+    std::vector<uint64_t> off(n);
     for (int pass = 0; pass < 2; pass++) {
       const size_t row = pass == 0 ? sizeof(jg_msg_row) : sizeof(jg_fsm_row);
-      HIPCHK(hipMemcpy(cnt.data(), pass == 0 ? r.d_msg_cnt : r.d_fsm_cnt, n * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(cnt.data(), pass == 0 ? r.d_msg_cnt : r.d_fsm_cnt, (size_t)n * 4, hipMemcpyDeviceToHost));
       uint64_t total = 0;
       for (uint32_t i = 0; i < n; i++) {
-        off[i] = (uint32_t)total;
+        off[i] = total;
         total += cnt[i];
       }
       if (!total) continue;
-      uint32_t* d_off = nullptr;
+      uint64_t* d_off = nullptr;
       void* d_dst = nullptr;
-      HIPCHK(hipMalloc((void**)&d_off, n * 4));
-      HIPCHK(hipMalloc(&d_dst, total * row));
-      HIPCHK(hipMemcpyAsync(d_off, off.data(), n * 4, hipMemcpyHostToDevice, e->stream));
-      uint32_t grid = grid_for(n, 1024);
+      HIPCHK(e->arena.alloc((size_t)n * 8, (void**)&d_off));
+      HIPCHK(e->arena.alloc(total * row, &d_dst));
+      HIPCHK(hipMemcpyAsync(d_off, off.data(), (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
+      uint32_t grid = grid_for(n, 2048);
       if (pass == 0) {
-        hipLaunchKernelGGL(k_gather_rows<jg_msg_row>, dim3(grid), dim3(JG_BLOCK), 0, e->stream, n, r.d_msg_base,
+        hipLaunchKernelGGL(k_gather_rows<jg_msg_row>, dim3(grid), dim3(JG_BLOCK), 0, e->stream, n, r.msg_per_row,
                            r.d_msg_cnt, d_off, r.d_msg, (jg_msg_row*)d_dst);
         size_t at = e->q_msgs.size();
         e->q_msgs.resize(at + total);
         HIPCHK(hipMemcpyAsync(e->q_msgs.data() + at, d_dst, total * row, hipMemcpyDeviceToHost, e->stream));
       } else {
-        hipLaunchKernelGGL(k_gather_rows<jg_fsm_row>, dim3(grid), dim3(JG_BLOCK), 0, e->stream, n, r.d_fsm_base,
+        hipLaunchKernelGGL(k_gather_rows<jg_fsm_row>, dim3(grid), dim3(JG_BLOCK), 0, e->stream, n, r.fsm_per_row,
                            r.d_fsm_cnt, d_off, r.d_fsm, (jg_fsm_row*)d_dst);
         size_t at = e->q_fsm.size();
         e->q_fsm.resize(at + total);
         HIPCHK(hipMemcpyAsync(e->q_fsm.data() + at, d_dst, total * row, hipMemcpyDeviceToHost, e->stream));
       }
-      HIPCHK(hipStreamSynchronize(e->stream));
-      HIPCHK(hipFree(d_off));
-      HIPCHK(hipFree(d_dst));
+      HIPCHK(hipStreamSynchronize(e->stream));  // `off` / q_* are reused right away
     }
-    HIPCHK(hipFree(r.blob));
   }
   e->recs.clear();
+  e->arena.reset();
   // faults
   uint32_t nf = 0;
   HIPCHK(hipMemcpy(&nf, e->dev.fault_q_n, sizeof nf, hipMemcpyDeviceToHost));
@@ -216,6 +274,75 @@ int drain(jg_engine* e, std::vector<Row>& q, Row* out, size_t cap, size_t* n) {
   if (cap < q.size()) return fail(JG_ECAPACITY, "output buffer too small");
   if (!q.empty()) std::memcpy(out, q.data(), q.size() * sizeof(Row));
   q.clear();
+  return JG_OK;
+}
+
+// Stable LSD radix sort of row indices by group id: per-group stream order = row order.
+void sort_rows_by_group(const std::vector<uint32_t>& group, uint32_t n_groups, std::vector<uint32_t>& order) {
+  const size_t n = group.size();
+  order.resize(n);
+  std::iota(order.begin(), order.end(), 0u);
+  bool sorted = true;
+  for (size_t i = 1; i < n && sorted; i++) sorted = group[i - 1] <= group[i];
+  if (sorted) return;
+  std::vector<uint32_t> tmp(n);
+  uint32_t bits = 1;
+  while (bits < 32 && (n_groups - 1) >> bits) bits++;
+  const uint32_t RADIX = 11, BUCKETS = 1u << RADIX;
+  std::vector<uint32_t> count(BUCKETS);
+  for (uint32_t shift = 0; shift < bits; shift += RADIX) {
+    std::fill(count.begin(), count.end(), 0u);
+    for (size_t i = 0; i < n; i++) count[(group[order[i]] >> shift) & (BUCKETS - 1)]++;
+    uint32_t sum = 0;
+    for (uint32_t b = 0; b < BUCKETS; b++) {
+      uint32_t c = count[b];
+      count[b] = sum;
+      sum += c;
+    }
+    for (size_t i = 0; i < n; i++) tmp[count[(group[order[i]] >> shift) & (BUCKETS - 1)]++] = order[i];
+    order.swap(tmp);
+  }
+}
+
+// Launch k_apply_rows over device-resident, group-sorted command columns.
+int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* kind, const uint32_t* from,
+                const uint64_t* term, const uint64_t* id, const uint64_t* aux, const uint8_t* flag,
+                const uint64_t* blk_id, const uint64_t* blk_next, uint64_t now_ms) {
+  StepRec rec;
+  rec.n = n;
+  rec.msg_per_row = msg_bound(e->cfg.n_replicas);
+  rec.fsm_per_row = fsm_bound();
+  HIPCHK(e->arena.alloc((size_t)n * 4, (void**)&rec.d_msg_cnt));
+  HIPCHK(e->arena.alloc((size_t)n * 4, (void**)&rec.d_fsm_cnt));
+  HIPCHK(e->arena.alloc((size_t)n * rec.msg_per_row * sizeof(jg_msg_row), (void**)&rec.d_msg));
+  HIPCHK(e->arena.alloc((size_t)n * rec.fsm_per_row * sizeof(jg_fsm_row), (void**)&rec.d_fsm));
+  JgRowsArgs a;
+  a.n = n;
+  a.group = group;
+  a.kind = kind;
+  a.from = from;
+  a.term = term;
+  a.id = id;
+  a.aux = aux;
+  a.flag = flag;
+  a.blk_id = blk_id;
+  a.blk_next = blk_next;
+  a.msg_per_row = rec.msg_per_row;
+  a.fsm_per_row = rec.fsm_per_row;
+  a.msg_out = rec.d_msg;
+  a.fsm_out = rec.d_fsm;
+  a.msg_cnt = rec.d_msg_cnt;
+  a.fsm_cnt = rec.d_fsm_cnt;
+  a.err = e->d_err;
+  a.now = now_ms;
+  a.seq = e->seq;
+  hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(n, e->count_slots)), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
+  HIPCHK(hipGetLastError());
+  e->n_launch++;
+  e->recs.push_back(rec);
+  e->n_cmds += n;
+  e->maybe_irregular = true;  // until the device flag says otherwise (sync_and_check)
+  e->flag_check_pending = true;
   return JG_OK;
 }
 
@@ -250,8 +377,10 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
     jg_engine_destroy(e);
     return code;
   };
-  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(JG_EDEVICE, "hipStreamCreate failed"));
-  if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess)
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(JG_EDEVICE, "hipStreamCreate failed"));
+  if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_stage, hipEventDisableTiming) != hipSuccess)
     return bail(fail(JG_EDEVICE, "hipEventCreate failed"));
 
   const size_t G = cfg->n_groups, R = cfg->n_replicas;
@@ -274,7 +403,7 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   if (e->dense_variant != 2 || (G & 1)) e->dense_variant = 1;
   e->dense_grid = grid_for(e->dense_variant == 2 ? G / 2 : G, cap);
   e->count_slots = std::max<uint32_t>(e->dense_grid, 4096);
-#define A(ptr, n)                                   \
+#define A(ptr, n) \
   if ((rc = dev_alloc(e, &ptr, (n))) != JG_OK) return bail(rc)
   A(d.term, G);
   A(d.commit, G);
@@ -300,6 +429,7 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.fault_q_n, 1);
   A(d.slow_list, G);
   A(d.slow_n, 1);
+  A(d.irregular_seen, 1);
   A(e->d_err, 1);
 #undef A
   hipLaunchKernelGGL(k_init_groups, dim3(grid_for(G, 2048)), dim3(JG_BLOCK), 0, e->stream, e->dev,
@@ -314,11 +444,13 @@ void jg_engine_destroy(jg_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  for (StepRec& r : e->recs) (void)hipFree(r.blob);
+  e->arena.destroy();
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->d_acks_staging) (void)hipFree(e->d_acks_staging);
+  if (e->stage) (void)hipHostFree(e->stage);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->ev_stage) (void)hipEventDestroy(e->ev_stage);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -351,21 +483,25 @@ int jg_submit(jg_engine* e, const jg_cmd_batch* b) {
       if (b->id[i] + b->aux[i] > b->n_blocks) return fail(JG_EINVAL, "block side-array range out of bounds");
     }
   }
+  const size_t at = e->p_kind.size(), n = b->n;
   const uint64_t blk_shift = e->p_blk_id.size();
-  for (size_t i = 0; i < b->n; i++) {
-    e->p_kind.push_back(b->kind[i]);
-    e->p_group.push_back(b->group[i]);
-    e->p_from.push_back(b->from ? b->from[i] : 0);
-    e->p_term.push_back(b->term ? b->term[i] : 0);
-    uint64_t id = b->id ? b->id[i] : 0;
-    if (b->kind[i] == JG_CMD_APPEND_ENTRIES) id += blk_shift;  // side arrays are concatenated
-    e->p_id.push_back(id);
-    e->p_aux.push_back(b->aux ? b->aux[i] : 0);
-    e->p_flag.push_back(b->flag ? b->flag[i] : 0);
-  }
-  for (size_t i = 0; i < b->n_blocks; i++) {
-    e->p_blk_id.push_back(b->blk_id[i]);
-    e->p_blk_next.push_back(b->blk_next[i]);
+  auto put = [&](auto& vec, auto* src) {
+    if (src) vec.insert(vec.end(), src, src + n);
+    else vec.resize(at + n, 0);
+  };
+  put(e->p_kind, b->kind);
+  put(e->p_group, b->group);
+  put(e->p_from, b->from);
+  put(e->p_term, b->term);
+  put(e->p_id, b->id);
+  put(e->p_aux, b->aux);
+  put(e->p_flag, b->flag);
+  if (blk_shift)  // side arrays of successive submits are concatenated
+    for (size_t i = 0; i < n; i++)
+      if (b->kind[i] == JG_CMD_APPEND_ENTRIES) e->p_id[at + i] += blk_shift;
+  if (b->n_blocks) {
+    e->p_blk_id.insert(e->p_blk_id.end(), b->blk_id, b->blk_id + b->n_blocks);
+    e->p_blk_next.insert(e->p_blk_next.end(), b->blk_next, b->blk_next + b->n_blocks);
   }
   return JG_OK;
 }
@@ -375,38 +511,14 @@ int jg_step(jg_engine* e, uint64_t now_ms) {
   e->stepped = true;
   const size_t n = e->p_kind.size();
   if (!n) return JG_OK;
+  if (n > 0x7fffffffull) return fail(JG_EINVAL, "batch too large: split it");
   HIPCHK(hipSetDevice(e->device));
   e->seq++;
-  const uint32_t R = e->cfg.n_replicas;
-  // stable bucket by group: per-group stream order is row order
-  std::vector<uint32_t> order(n);
-  std::iota(order.begin(), order.end(), 0u);
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return e->p_group[a] < e->p_group[b]; });
-  std::vector<uint32_t> seg_group, seg_off, msg_base, fsm_base;
-  uint64_t mb = 0, fb = 0;
-  for (size_t k = 0; k < n; k++) {
-    uint32_t g = e->p_group[order[k]];
-    if (k == 0 || g != seg_group.back()) {
-      seg_group.push_back(g);
-      seg_off.push_back((uint32_t)k);
-      msg_base.push_back((uint32_t)mb);
-      fsm_base.push_back((uint32_t)fb);
-    }
-    uint32_t m, f;
-    uint8_t kind = e->p_kind[order[k]];
-    row_bounds(kind, R, &m, &f);
-    mb += m;
-    fb += f;
-    if (kind == JG_CMD_APPEND_ENTRIES || kind == JG_CMD_RESTART) e->maybe_irregular = true;
-  }
-  if (mb > 0xffffffffull || fb > 0xffffffffull) return fail(JG_EINVAL, "batch too large: split it");
-  const uint32_t na = (uint32_t)seg_group.size();
-  seg_off.push_back((uint32_t)n);
-  msg_base.push_back((uint32_t)mb);
-  fsm_base.push_back((uint32_t)fb);
+  std::vector<uint32_t> order;
+  sort_rows_by_group(e->p_group, e->cfg.n_groups, order);
   const size_t nb = e->p_blk_id.size();
 
-  // blob layout (16-byte aligned sections); the first `up_bytes` are uploaded
+  // one blob: 8-byte columns first, then 4-byte, then 1-byte (16-byte aligned sections)
   size_t off = 0;
   auto sect = [&](size_t bytes) {
     size_t at = off;
@@ -414,72 +526,47 @@ int jg_step(jg_engine* e, uint64_t now_ms) {
     return at;
   };
   const size_t o_term = sect(n * 8), o_id = sect(n * 8), o_aux = sect(n * 8), o_bid = sect(nb * 8),
-               o_bnext = sect(nb * 8), o_from = sect(n * 4), o_sg = sect(na * 4), o_so = sect((na + 1) * 4),
-               o_mb = sect((na + 1) * 4), o_fb = sect((na + 1) * 4), o_kind = sect(n), o_flag = sect(n);
-  const size_t up_bytes = off;
-  const size_t o_mc = sect(na * 4), o_fc = sect(na * 4), o_msg = sect(mb * sizeof(jg_msg_row)),
-               o_fsm = sect(fb * sizeof(jg_fsm_row));
-  std::vector<uint8_t> stage(up_bytes);
-  auto put = [&](size_t at, auto&& get, size_t count, size_t width) {
-    for (size_t k = 0; k < count; k++) {
-      auto v = get(k);
-      std::memcpy(stage.data() + at + k * width, &v, width);
-    }
-  };
-  put(o_term, [&](size_t k) { return e->p_term[order[k]]; }, n, 8);
-  put(o_id, [&](size_t k) { return e->p_id[order[k]]; }, n, 8);
-  put(o_aux, [&](size_t k) { return e->p_aux[order[k]]; }, n, 8);
-  put(o_from, [&](size_t k) { return e->p_from[order[k]]; }, n, 4);
-  put(o_kind, [&](size_t k) { return e->p_kind[order[k]]; }, n, 1);
-  put(o_flag, [&](size_t k) { return e->p_flag[order[k]]; }, n, 1);
-  if (nb) {
-    std::memcpy(stage.data() + o_bid, e->p_blk_id.data(), nb * 8);
-    std::memcpy(stage.data() + o_bnext, e->p_blk_next.data(), nb * 8);
+               o_bnext = sect(nb * 8), o_group = sect(n * 4), o_from = sect(n * 4), o_kind = sect(n),
+               o_flag = sect(n);
+  const size_t bytes = off;
+  if (e->stage_busy) {  // the previous step's upload may still be reading the pinned buffer
+    HIPCHK(hipEventSynchronize(e->ev_stage));
+    e->stage_busy = false;
   }
-  std::memcpy(stage.data() + o_sg, seg_group.data(), na * 4);
-  std::memcpy(stage.data() + o_so, seg_off.data(), (na + 1) * 4);
-  std::memcpy(stage.data() + o_mb, msg_base.data(), (na + 1) * 4);
-  std::memcpy(stage.data() + o_fb, fsm_base.data(), (na + 1) * 4);
-
-  StepRec rec;
-  rec.n_active = na;
-  HIPCHK(hipMalloc(&rec.blob, off));
-  uint8_t* B = (uint8_t*)rec.blob;
-  HIPCHK(hipMemcpyAsync(B, stage.data(), up_bytes, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));  // `stage` is pageable and about to go out of scope
-  rec.d_msg_base = (uint32_t*)(B + o_mb);
-  rec.d_fsm_base = (uint32_t*)(B + o_fb);
-  rec.d_msg_cnt = (uint32_t*)(B + o_mc);
-  rec.d_fsm_cnt = (uint32_t*)(B + o_fc);
-  rec.d_msg = (jg_msg_row*)(B + o_msg);
-  rec.d_fsm = (jg_fsm_row*)(B + o_fsm);
-
-  JgStepArgs a;
-  a.n_active = na;
-  a.seg_group = (const uint32_t*)(B + o_sg);
-  a.seg_off = (const uint32_t*)(B + o_so);
-  a.kind = B + o_kind;
-  a.from = (const uint32_t*)(B + o_from);
-  a.term = (const uint64_t*)(B + o_term);
-  a.id = (const uint64_t*)(B + o_id);
-  a.aux = (const uint64_t*)(B + o_aux);
-  a.flag = B + o_flag;
-  a.blk_id = (const uint64_t*)(B + o_bid);
-  a.blk_next = (const uint64_t*)(B + o_bnext);
-  a.msg_base = rec.d_msg_base;
-  a.fsm_base = rec.d_fsm_base;
-  a.msg_out = rec.d_msg;
-  a.fsm_out = rec.d_fsm;
-  a.msg_cnt = rec.d_msg_cnt;
-  a.fsm_cnt = rec.d_fsm_cnt;
-  a.err = e->d_err;
-  a.now = now_ms;
-  a.seq = e->seq;
-  hipLaunchKernelGGL(k_apply_cmds, dim3(grid_for(na, e->count_slots)), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
-  HIPCHK(hipGetLastError());
-  e->n_launch++;
-  e->recs.push_back(rec);
-  e->n_cmds += n;
+  if (e->stage_cap < bytes) {
+    if (e->stage) HIPCHK(hipHostFree(e->stage));
+    e->stage = nullptr;
+    e->stage_cap = std::max(bytes * 2, (size_t)1 << 20);
+    HIPCHK(hipHostMalloc((void**)&e->stage, e->stage_cap, hipHostMallocDefault));
+  }
+  char* S = e->stage;
+  uint64_t *s_term = (uint64_t*)(S + o_term), *s_id = (uint64_t*)(S + o_id), *s_aux = (uint64_t*)(S + o_aux);
+  uint32_t *s_group = (uint32_t*)(S + o_group), *s_from = (uint32_t*)(S + o_from);
+  uint8_t *s_kind = (uint8_t*)(S + o_kind), *s_flag = (uint8_t*)(S + o_flag);
+  for (size_t k = 0; k < n; k++) {
+    const uint32_t i = order[k];
+    s_term[k] = e->p_term[i];
+    s_id[k] = e->p_id[i];
+    s_aux[k] = e->p_aux[i];
+    s_group[k] = e->p_group[i];
+    s_from[k] = e->p_from[i];
+    s_kind[k] = e->p_kind[i];
+    s_flag[k] = e->p_flag[i];
+  }
+  if (nb) {
+    std::memcpy(S + o_bid, e->p_blk_id.data(), nb * 8);
+    std::memcpy(S + o_bnext, e->p_blk_next.data(), nb * 8);
+  }
+  char* B = nullptr;
+  HIPCHK(e->arena.alloc(bytes, (void**)&B));
+  HIPCHK(hipMemcpyAsync(B, S, bytes, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipEventRecord(e->ev_stage, e->stream));
+  e->stage_busy = true;
+  int rc = launch_rows(e, (uint32_t)n, (const uint32_t*)(B + o_group), (const uint8_t*)(B + o_kind),
+                       (const uint32_t*)(B + o_from), (const uint64_t*)(B + o_term), (const uint64_t*)(B + o_id),
+                       (const uint64_t*)(B + o_aux), (const uint8_t*)(B + o_flag), (const uint64_t*)(B + o_bid),
+                       (const uint64_t*)(B + o_bnext), now_ms);
+  if (rc) return rc;
   e->p_kind.clear();
   e->p_flag.clear();
   e->p_group.clear();
@@ -490,6 +577,20 @@ int jg_step(jg_engine* e, uint64_t now_ms) {
   e->p_blk_id.clear();
   e->p_blk_next.clear();
   return JG_OK;
+}
+
+int jg_step_device_rows(jg_engine* e, const jg_cmd_batch* b, uint64_t now_ms) {
+  if (!e || !b) return fail(JG_EINVAL, "null argument");
+  if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
+  e->stepped = true;
+  if (!b->n) return JG_OK;
+  if (b->n > 0x7fffffffull) return fail(JG_EINVAL, "batch too large: split it");
+  if (!b->kind || !b->group || !b->from || !b->term || !b->id || !b->aux || !b->flag)
+    return fail(JG_EINVAL, "all seven device columns are required");
+  HIPCHK(hipSetDevice(e->device));
+  e->seq++;
+  return launch_rows(e, (uint32_t)b->n, b->group, b->kind, b->from, b->term, b->id, b->aux, b->flag, b->blk_id,
+                     b->blk_next, now_ms);
 }
 
 int jg_step_dense_acks_device(jg_engine* e, const uint64_t* acks_dev) {
@@ -557,9 +658,7 @@ int jg_chain_compact(jg_engine* e, size_t n_trees, const uint64_t* off, const ui
 
 int jg_sync(jg_engine* e) {
   if (!e) return fail(JG_EINVAL, "null argument");
-  HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return JG_OK;
+  return sync_and_check(e);
 }
 
 int jg_drain_messages(jg_engine* e, jg_msg_row* out, size_t cap, size_t* n) { return drain(e, e->q_msgs, out, cap, n); }
@@ -572,37 +671,45 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
   if (field < 0 || field >= JG_FIELD__COUNT) return fail(JG_EINVAL, "unknown field");
   if (field == JG_FIELD_MATCH && replica >= e->cfg.n_replicas) return fail(JG_EINVAL, "replica out of range");
   if (!n) return JG_OK;
-  HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  int rc = sync_and_check(e);
+  if (rc) return rc;
   const JgDev& d = e->dev;
   std::vector<uint32_t> fl(n);
-  HIPCHK(hipMemcpy(fl.data(), d.flags + g0, n * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(fl.data(), d.flags + g0, (size_t)n * 4, hipMemcpyDeviceToHost));
   auto role = [&](uint32_t i) { return fl[i] & JGF_ROLE_MASK; };
   std::vector<uint64_t> t64;
   std::vector<uint32_t> t32;
   auto get64 = [&](const uint64_t* col) -> int {
     t64.resize(n);
-    HIPCHK(hipMemcpy(t64.data(), col + g0, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(t64.data(), col + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
     return JG_OK;
   };
   auto get32 = [&](const uint32_t* col) -> int {
     t32.resize(n);
-    HIPCHK(hipMemcpy(t32.data(), col + g0, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(t32.data(), col + g0, (size_t)n * 4, hipMemcpyDeviceToHost));
     return JG_OK;
   };
-  int rc = JG_OK;
+  auto copy64 = [&](const uint64_t* col) -> int {  // straight column -> caller's buffer
+    HIPCHK(hipMemcpy(out, col + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return JG_OK;
+  };
+  auto copy32 = [&](const uint32_t* col) -> int {
+    HIPCHK(hipMemcpy(out, col + g0, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return JG_OK;
+  };
   uint64_t* o64 = (uint64_t*)out;
   uint32_t* o32 = (uint32_t*)out;
   uint8_t* o8 = (uint8_t*)out;
   switch (field) {
-    case JG_FIELD_TERM: return get64(d.term) ? JG_EDEVICE : (std::memcpy(out, t64.data(), n * 8), JG_OK);
-    case JG_FIELD_COMMIT: return get64(d.commit) ? JG_EDEVICE : (std::memcpy(out, t64.data(), n * 8), JG_OK);
-    case JG_FIELD_HEAD: return get64(d.head) ? JG_EDEVICE : (std::memcpy(out, t64.data(), n * 8), JG_OK);
-    case JG_FIELD_ELECTION_TIME:
-      return get64(d.election_time) ? JG_EDEVICE : (std::memcpy(out, t64.data(), n * 8), JG_OK);
-    case JG_FIELD_ID_GEN: {
+    case JG_FIELD_TERM: return copy64(d.term);
+    case JG_FIELD_COMMIT: return copy64(d.commit);
+    case JG_FIELD_HEAD: return copy64(d.head);
+    case JG_FIELD_ELECTION_TIME: return copy64(d.election_time);
+    case JG_FIELD_ELECTION_TIMEOUT: return copy32(d.election_timeout);
+    case JG_FIELD_QUEUED_REQS: return copy32(d.queued);
+    case JG_FIELD_ID_GEN: {  // implicit (head + 1) while the chain is in FAST form
       std::vector<uint64_t> head(n);
-      HIPCHK(hipMemcpy(head.data(), d.head + g0, n * 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(head.data(), d.head + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
       if ((rc = get64(d.id_gen))) return rc;
       for (uint32_t i = 0; i < n; i++) o64[i] = (fl[i] & JGF_FAST) ? head[i] + 1 : t64[i];
       return JG_OK;
@@ -624,9 +731,6 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
       for (uint32_t i = 0; i < n; i++)
         o32[i] = (role(i) == JG_ROLE_FOLLOWER && (fl[i] & JGF_HAS_LEADER)) ? t32[i] : 0;
       return JG_OK;
-    case JG_FIELD_ELECTION_TIMEOUT:
-      return get32(d.election_timeout) ? JG_EDEVICE : (std::memcpy(out, t32.data(), n * 4), JG_OK);
-    case JG_FIELD_QUEUED_REQS: return get32(d.queued) ? JG_EDEVICE : (std::memcpy(out, t32.data(), n * 4), JG_OK);
     case JG_FIELD_VOTE_SEEN:
     case JG_FIELD_VOTE_GRANTED:
       if ((rc = get32(d.votes))) return rc;
@@ -660,8 +764,8 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
 
 int jg_get_counters(jg_engine* e, uint64_t out[4]) {
   if (!e || !out) return fail(JG_EINVAL, "null argument");
-  HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  int rc = sync_and_check(e);
+  if (rc) return rc;
   std::vector<uint64_t> slots(e->count_slots);
   HIPCHK(hipMemcpy(slots.data(), e->dev.blk_decisions, slots.size() * 8, hipMemcpyDeviceToHost));
   uint64_t dec = 0;

@@ -247,6 +247,27 @@ class BatchedRaft:
         assert a.shape == (self.R, self.G), a.shape
         self._check(self.api.step_dense_acks(self._h, a.ctypes.data))
 
+    def upload_rows(self, kind, group, from_=None, term=None, id=None, aux=None, flag=None,
+                    blk_id=None, blk_next=None) -> "DeviceRows":
+        """Sort a command batch by group (stable) on the host and park it in device memory for
+        step_device_rows — how a caller keeps a pre-built trace resident in HBM."""
+        n = len(kind)
+        order = np.argsort(np.asarray(group, dtype=np.uint32), kind="stable")
+
+        def col(x, dt):
+            a = np.zeros(n, dtype=dt) if x is None else np.asarray(x, dtype=dt)
+            return np.ascontiguousarray(a[order])
+
+        cols = [col(kind, np.uint8), col(group, np.uint32), col(from_, np.uint32), col(term, np.uint64),
+                col(id, np.uint64), col(aux, np.uint64), col(flag, np.uint8)]
+        side = [np.ascontiguousarray(x if x is not None else [], dtype=np.uint64) for x in (blk_id, blk_next)]
+        return DeviceRows(self, cols, side)
+
+    def step_device_rows(self, rows: "DeviceRows", now_ms: int = 0) -> None:
+        """jg_step_device_rows: apply a device-resident, group-sorted batch (no host pass)."""
+        self._flush_pending()
+        self._check(self.api.step_device_rows(self._h, C.byref(rows.batch), int(now_ms)))
+
     def step_dense_acks_n(self, acks: np.ndarray) -> None:
         """T consecutive dense ticks from a host [T, R, G] array.  On the device engine this is
         ONE launch (jg_step_dense_acks_device_n: state read and written once); a backend without
@@ -378,3 +399,33 @@ class RaftHandle:
 
     def match(self, replica: int) -> int:
         return int(self._get("match", replica))
+
+
+class DeviceRows:
+    """A command batch resident in device memory (see BatchedRaft.upload_rows)."""
+
+    def __init__(self, engine: BatchedRaft, cols, side):
+        self.engine = engine
+        self.n = len(cols[0])
+        self._ptrs = []
+        api, h = engine.api, engine._h
+
+        def up(a):
+            p = C.c_void_p()
+            engine._check(api.device_alloc(h, max(a.nbytes, 16), C.byref(p)))
+            if a.nbytes:
+                engine._check(api.device_upload(h, p, a.ctypes.data, a.nbytes))
+            self._ptrs.append(p)
+            return p.value
+
+        b = capi.CmdBatch()
+        b.n = self.n
+        (b.kind, b.group, b.from_, b.term, b.id, b.aux, b.flag) = [up(c) for c in cols]
+        b.n_blocks = len(side[0])
+        b.blk_id, b.blk_next = up(side[0]), up(side[1])
+        self.batch = b
+
+    def free(self) -> None:
+        for p in self._ptrs:
+            self.engine.api.device_free(self.engine._h, p)
+        self._ptrs = []

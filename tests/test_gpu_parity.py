@@ -234,3 +234,32 @@ def test_chain_compact_parity(n_trees):
     for i, (x, y) in enumerate(zip(a, b)):
         assert np.array_equal(x, y), (i, trees[i], x, y)
     assert sum(int(x.sum()) for x in a) > 0 or n_trees == 1
+
+
+def test_device_resident_rows_path():
+    """jg_step_device_rows (group-sorted batch already in HBM) == jg_submit + jg_step."""
+    G, R = 3000, 3
+    dev, ora = pair(G, R, seed=8)
+    rng = np.random.default_rng(3)
+    budget = np.full(G, capi.CHAIN_WINDOW - 2)
+    for step in range(12):
+        batch = random_batch(rng, ora, 4000, budget=budget)
+        rows = dev.upload_rows(**batch)
+        dev.step_device_rows(rows, now_ms=50 * step)
+        ora.submit_columns(**batch)
+        ora.step(50 * step)
+        compare_snapshots(dev, ora, f"device rows step {step}")
+        compare_drains(dev, ora, f"device rows step {step}")
+        rows.free()
+
+
+def test_device_rows_must_be_sorted():
+    from josefine_amd import EngineError
+    dev = BatchedRaft(8, 3)
+    rows = dev.upload_rows([capi.CMD_NOOP] * 3, [1, 2, 3])
+    # corrupt the order on the device: write group column [3, 2, 1]
+    bad = np.array([3, 2, 1], dtype=np.uint32)
+    dev._check(dev.api.device_upload(dev._h, rows.batch.group, bad.ctypes.data, bad.nbytes))
+    dev.step_device_rows(rows)
+    with pytest.raises(EngineError):
+        dev.read("term")
