@@ -82,9 +82,11 @@ __device__ __forceinline__ int jg_dense_classify(const JgDev& d, uint32_t g, uin
     }
     return JG_DENSE_SKIP;
   }
-  if (!(f & JGF_FAST)) {  // irregular chain: exact general path in k_dense_slow
-    uint32_t idx = atomicAdd(d.slow_n, 1u);
-    if (idx < d.G) d.slow_list[idx] = g;
+  if (!(f & JGF_FAST)) {
+    // irregular chain: k_dense_slow, launched right behind this kernel, finds the group by
+    // the same test on its flag word (no list, no atomics on this path) and replays the tick
+    // through the general state machine.  *deferred_seen lets the host verify it was scheduled.
+    *d.deferred_seen = 1;
     return JG_DENSE_SKIP;
   }
   return JG_DENSE_RUN;
@@ -285,8 +287,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_leader_tick_dense_n(JgDev d, const
     const uint32_t s = (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
     const bool leader = (f & JGF_ROLE_MASK) == JG_ROLE_LEADER;
     if (leader && !(f & JGF_FAST)) {  // irregular chain: k_dense_slow replays all ticks
-      uint32_t idx = atomicAdd(d.slow_n, 1u);
-      if (idx < G) d.slow_list[idx] = g;
+      *d.deferred_seen = 1;
       continue;
     }
     uint64_t commit = commit0, head = head0;

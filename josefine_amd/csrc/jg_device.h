@@ -70,8 +70,7 @@ struct JgDev {
   JgFaultRec* fault_q;
   uint32_t* fault_q_n;
   uint32_t fault_q_cap;
-  uint32_t* slow_list;       // groups the dense fast path deferred
-  uint32_t* slow_n;
+  uint32_t* deferred_seen;   // the dense fast path met a leader whose chain is not in FAST form
   uint32_t* irregular_seen;  // set when a group is stored with a chain that is not in FAST form
 };
 

@@ -110,6 +110,7 @@ struct jg_engine {
   // point if the device-side flag is still 0.
   bool maybe_irregular = false;
   bool flag_check_pending = false;
+  bool slow_scheduled_ever = false;  // some dense launch had k_dense_slow behind it
   uint64_t n_cmds = 0, n_dense = 0, n_launch = 0;
 };
 
@@ -159,7 +160,6 @@ void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks) {
 int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1) {
   e->stepped = true;
   e->seq++;  // tick t of this launch carries sequence number seq + t
-  if (e->maybe_irregular) HIPCHK(hipMemsetAsync(e->dev.slow_n, 0, sizeof(uint32_t), e->stream));
   switch (e->cfg.n_replicas) {
     case 1: launch_dense<1>(e, acks_dev, n_ticks); break;
     case 2: launch_dense<2>(e, acks_dev, n_ticks); break;
@@ -172,7 +172,8 @@ int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1) {
   }
   e->n_launch++;
   if (e->maybe_irregular) {
-    hipLaunchKernelGGL(k_dense_slow, dim3(std::min<uint32_t>(e->count_slots, 64)), dim3(JG_BLOCK), 0, e->stream,
+    e->slow_scheduled_ever = true;
+    hipLaunchKernelGGL(k_dense_slow, dim3(grid_for(e->cfg.n_groups, 2048)), dim3(JG_BLOCK), 0, e->stream,
                        e->dev, acks_dev, n_ticks, (size_t)e->cfg.n_groups * e->cfg.n_replicas, e->seq);
     e->n_launch++;
   }
@@ -199,10 +200,13 @@ int sync_and_check(jg_engine* e) {
     e->maybe_irregular = seen != 0;  // sticky on the device: once seen, the slow kernel stays scheduled
     e->flag_check_pending = false;
   }
-  if (!e->maybe_irregular) {
-    uint32_t slow_n = 0;
-    HIPCHK(hipMemcpy(&slow_n, e->dev.slow_n, sizeof slow_n, hipMemcpyDeviceToHost));
-    if (slow_n) return fail(JG_EDEVICE, "internal: irregular chain reached the fast-only dense path");
+  if (!e->slow_scheduled_ever) {
+    // Assertion: irregular chains only come out of sparse steps, and every dense launch after
+    // a sparse step has k_dense_slow behind it until the device flag is read back as 0 — so
+    // while no slow kernel was ever scheduled the dense kernel cannot have deferred a group.
+    uint32_t seen = 0;
+    HIPCHK(hipMemcpy(&seen, e->dev.deferred_seen, sizeof seen, hipMemcpyDeviceToHost));
+    if (seen) return fail(JG_EDEVICE, "internal: irregular chain reached the fast-only dense path");
   }
   return JG_OK;
 }
@@ -427,8 +431,7 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   d.fault_q_cap = (uint32_t)std::max<size_t>(2 * G, 1024);
   A(d.fault_q, d.fault_q_cap);
   A(d.fault_q_n, 1);
-  A(d.slow_list, G);
-  A(d.slow_n, 1);
+  A(d.deferred_seen, 1);
   A(d.irregular_seen, 1);
   A(e->d_err, 1);
 #undef A
