@@ -79,16 +79,88 @@ __global__ __launch_bounds__(JG_BLOCK) void k_apply_rows(JgDev d, JgRowsArgs a) 
   jg_block_count(d.blk_decisions, dec);
 }
 
-// drain-time compaction: copy each run's rows from its region to its final offset
+// ---- drain-time compaction, entirely on the device -------------------------------------------
+// cnt[i] rows sit at src + i*per_row; the drained sequence is their concatenation in row
+// order (= group order, emission order within a group).  Exclusive scan of cnt in three
+// steps: per-workgroup sums (1024 counts each), a single-workgroup scan of those sums, then
+// each workgroup re-scans its 1024 counts (wave64 shuffles + an LDS hop across the four
+// waves), adds its base and copies its rows to their final place.
+#define JG_SCAN_ITEMS 4
+#define JG_SCAN_TILE (JG_BLOCK * JG_SCAN_ITEMS)
+
+// inclusive scan of one value per lane across the workgroup; returns the exclusive prefix of
+// the calling thread and the workgroup total through *total
+__device__ __forceinline__ uint32_t jg_block_exclusive_scan(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t wave_tot[JG_BLOCK / 64];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t up = __shfl_up(inc, off, 64);
+    if (lane >= (uint32_t)off) inc += up;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < JG_BLOCK / 64; w++) {
+    base += w < wave ? wave_tot[w] : 0u;
+    tot += wave_tot[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(JG_BLOCK) void k_count_block_sums(const uint32_t* __restrict__ cnt, uint32_t n,
+                                                               uint64_t* __restrict__ bsum) {
+  const uint32_t base = blockIdx.x * JG_SCAN_TILE + threadIdx.x * JG_SCAN_ITEMS;
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < JG_SCAN_ITEMS; k++) v += (base + k < n) ? cnt[base + k] : 0u;
+  uint32_t tot;
+  (void)jg_block_exclusive_scan(v, &tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// one workgroup: bsum[] -> exclusive prefix in place, grand total to *total
+__global__ __launch_bounds__(JG_BLOCK) void k_scan_block_sums(uint64_t* __restrict__ bsum, uint32_t nb,
+                                                              uint64_t* __restrict__ total) {
+  __shared__ uint64_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += JG_BLOCK) {
+    const uint32_t i = base + threadIdx.x;
+    const uint64_t v = i < nb ? bsum[i] : 0;
+    // tile sums fit 32 bits (<= 1024 counts of at most a few rows each)
+    uint32_t tot;
+    const uint32_t ex = jg_block_exclusive_scan((uint32_t)v, &tot);
+    const uint64_t carry = carry_s;
+    if (i < nb) bsum[i] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry_s;
+}
+
 template <typename Row>
-__global__ void k_gather_rows(uint32_t n, uint32_t per_row, const uint32_t* __restrict__ cnt,
-                              const uint64_t* __restrict__ dst_off, const Row* __restrict__ src,
-                              Row* __restrict__ dst) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t c = cnt[i];
-    if (!c) continue;
-    const Row* s = src + (size_t)i * per_row;
-    Row* t = dst + dst_off[i];
-    for (uint32_t k = 0; k < c; k++) t[k] = s[k];
+__global__ __launch_bounds__(JG_BLOCK) void k_scan_gather(const uint32_t* __restrict__ cnt, uint32_t n,
+                                                          const uint64_t* __restrict__ bsum, uint32_t per_row,
+                                                          const Row* __restrict__ src, Row* __restrict__ dst) {
+  const uint32_t base = blockIdx.x * JG_SCAN_TILE + threadIdx.x * JG_SCAN_ITEMS;
+  uint32_t c[JG_SCAN_ITEMS], v = 0;
+#pragma unroll
+  for (int k = 0; k < JG_SCAN_ITEMS; k++) {
+    c[k] = (base + k < n) ? cnt[base + k] : 0u;
+    v += c[k];
+  }
+  uint32_t tot;
+  uint64_t off = bsum[blockIdx.x] + jg_block_exclusive_scan(v, &tot);
+#pragma unroll
+  for (int k = 0; k < JG_SCAN_ITEMS; k++) {
+    const Row* s = src + (size_t)(base + k) * per_row;
+    for (uint32_t r = 0; r < c[k]; r++) dst[off + r] = s[r];
+    off += c[k];
   }
 }

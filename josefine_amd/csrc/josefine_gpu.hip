@@ -211,47 +211,67 @@ int sync_and_check(jg_engine* e) {
   return JG_OK;
 }
 
-// Pull finished steps' output rows and the fault queue to the host queues.
+// Pull finished steps' output rows and the fault queue to the host queues.  Compaction
+// (exclusive scan of the per-run row counts + gather) runs on the device; the host only
+// learns the totals and receives the compacted rows.
 int collect(jg_engine* e) {
   int rc = sync_and_check(e);
   if (rc) return rc;
-  for (StepRec& r : e->recs) {
-    const uint32_t n = r.n;
-    std::vector<uint32_t> cnt(n);
-    std::vector<uint64_t> off(n);
-    for (int pass = 0; pass < 2; pass++) {
-      const size_t row = pass == 0 ? sizeof(jg_msg_row) : sizeof(jg_fsm_row);
-      HIPCHK(hipMemcpy(cnt.data(), pass == 0 ? r.d_msg_cnt : r.d_fsm_cnt, (size_t)n * 4, hipMemcpyDeviceToHost));
-      uint64_t total = 0;
-      for (uint32_t i = 0; i < n; i++) {
-        off[i] = total;
-        total += cnt[i];
+  const size_t nrec = e->recs.size();
+  if (nrec) {
+    std::vector<uint64_t*> d_bsum(2 * nrec);
+    uint64_t* d_totals = nullptr;
+    HIPCHK(e->arena.alloc(2 * nrec * 8, (void**)&d_totals));
+    for (size_t k = 0; k < nrec; k++) {
+      StepRec& r = e->recs[k];
+      const uint32_t nb = (r.n + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
+      for (int pass = 0; pass < 2; pass++) {
+        HIPCHK(e->arena.alloc((size_t)nb * 8, (void**)&d_bsum[2 * k + pass]));
+        const uint32_t* cnt = pass == 0 ? r.d_msg_cnt : r.d_fsm_cnt;
+        hipLaunchKernelGGL(k_count_block_sums, dim3(nb), dim3(JG_BLOCK), 0, e->stream, cnt, r.n, d_bsum[2 * k + pass]);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(JG_BLOCK), 0, e->stream, d_bsum[2 * k + pass], nb,
+                           d_totals + 2 * k + pass);
       }
-      if (!total) continue;
-      uint64_t* d_off = nullptr;
-      void* d_dst = nullptr;
-      HIPCHK(e->arena.alloc((size_t)n * 8, (void**)&d_off));
-      HIPCHK(e->arena.alloc(total * row, &d_dst));
-      HIPCHK(hipMemcpyAsync(d_off, off.data(), (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
-      uint32_t grid = grid_for(n, 2048);
-      if (pass == 0) {
-        hipLaunchKernelGGL(k_gather_rows<jg_msg_row>, dim3(grid), dim3(JG_BLOCK), 0, e->stream, n, r.msg_per_row,
-                           r.d_msg_cnt, d_off, r.d_msg, (jg_msg_row*)d_dst);
-        size_t at = e->q_msgs.size();
-        e->q_msgs.resize(at + total);
-        HIPCHK(hipMemcpyAsync(e->q_msgs.data() + at, d_dst, total * row, hipMemcpyDeviceToHost, e->stream));
-      } else {
-        hipLaunchKernelGGL(k_gather_rows<jg_fsm_row>, dim3(grid), dim3(JG_BLOCK), 0, e->stream, n, r.fsm_per_row,
-                           r.d_fsm_cnt, d_off, r.d_fsm, (jg_fsm_row*)d_dst);
-        size_t at = e->q_fsm.size();
-        e->q_fsm.resize(at + total);
-        HIPCHK(hipMemcpyAsync(e->q_fsm.data() + at, d_dst, total * row, hipMemcpyDeviceToHost, e->stream));
-      }
-      HIPCHK(hipStreamSynchronize(e->stream));  // `off` / q_* are reused right away
     }
+    HIPCHK(hipGetLastError());
+    std::vector<uint64_t> totals(2 * nrec);
+    HIPCHK(hipMemcpyAsync(totals.data(), d_totals, 2 * nrec * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    uint64_t add_m = 0, add_f = 0;
+    for (size_t k = 0; k < nrec; k++) {
+      add_m += totals[2 * k];
+      add_f += totals[2 * k + 1];
+    }
+    size_t at_m = e->q_msgs.size(), at_f = e->q_fsm.size();
+    e->q_msgs.resize(at_m + add_m);
+    e->q_fsm.resize(at_f + add_f);
+    for (size_t k = 0; k < nrec; k++) {
+      StepRec& r = e->recs[k];
+      const uint32_t nb = (r.n + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
+      if (totals[2 * k]) {
+        jg_msg_row* d_dst = nullptr;
+        HIPCHK(e->arena.alloc(totals[2 * k] * sizeof(jg_msg_row), (void**)&d_dst));
+        hipLaunchKernelGGL(k_scan_gather<jg_msg_row>, dim3(nb), dim3(JG_BLOCK), 0, e->stream, r.d_msg_cnt, r.n,
+                           d_bsum[2 * k], r.msg_per_row, r.d_msg, d_dst);
+        HIPCHK(hipMemcpyAsync(e->q_msgs.data() + at_m, d_dst, totals[2 * k] * sizeof(jg_msg_row),
+                              hipMemcpyDeviceToHost, e->stream));
+        at_m += totals[2 * k];
+      }
+      if (totals[2 * k + 1]) {
+        jg_fsm_row* d_dst = nullptr;
+        HIPCHK(e->arena.alloc(totals[2 * k + 1] * sizeof(jg_fsm_row), (void**)&d_dst));
+        hipLaunchKernelGGL(k_scan_gather<jg_fsm_row>, dim3(nb), dim3(JG_BLOCK), 0, e->stream, r.d_fsm_cnt, r.n,
+                           d_bsum[2 * k + 1], r.fsm_per_row, r.d_fsm, d_dst);
+        HIPCHK(hipMemcpyAsync(e->q_fsm.data() + at_f, d_dst, totals[2 * k + 1] * sizeof(jg_fsm_row),
+                              hipMemcpyDeviceToHost, e->stream));
+        at_f += totals[2 * k + 1];
+      }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->recs.clear();
+    e->arena.reset();
   }
-  e->recs.clear();
-  e->arena.reset();
   // faults
   uint32_t nf = 0;
   HIPCHK(hipMemcpy(&nf, e->dev.fault_q_n, sizeof nf, hipMemcpyDeviceToHost));
@@ -316,6 +336,7 @@ int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* 
   rec.n = n;
   rec.msg_per_row = msg_bound(e->cfg.n_replicas);
   rec.fsm_per_row = fsm_bound();
+  if ((uint64_t)n * rec.msg_per_row > 0xffffffffull) return fail(JG_EINVAL, "batch too large: split it");
   HIPCHK(e->arena.alloc((size_t)n * 4, (void**)&rec.d_msg_cnt));
   HIPCHK(e->arena.alloc((size_t)n * 4, (void**)&rec.d_fsm_cnt));
   HIPCHK(e->arena.alloc((size_t)n * rec.msg_per_row * sizeof(jg_msg_row), (void**)&rec.d_msg));
