@@ -71,6 +71,8 @@ struct JgDev {
   uint32_t* fault_q_n;
   uint32_t fault_q_cap;
   uint32_t* deferred_seen;   // the dense fast path met a leader whose chain is not in FAST form
+  uint32_t* slow_list;       // [JG_SHARDS][ceil(G/JG_SHARDS)] deferred groups per shard
+  uint32_t* slow_cnt;        // [JG_SHARDS]
   uint32_t* irregular_seen;  // set when a group is stored with a chain that is not in FAST form
 };
 

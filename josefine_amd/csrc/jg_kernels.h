@@ -15,17 +15,42 @@
 
 #include "jg_dense.h"  // k_leader_tick_dense / _x2, jg_block_count, JG_BLOCK
 
-// Same ticks through the general state machine, for the groups the fast kernel
-// deferred (chain not in FAST form).  It scans the flag column (4 B per group) instead
-// of consuming a list: appending ~1 % of the groups to a list with returning atomics
-// cost the dense kernel 65 us per tick at 1 M groups (profiles/README.md).
+// ---- groups the dense kernel deferred (healthy leaders whose chain is not in FAST form) ----
+// Two kernels, no contended global atomics: k_collect_deferred compacts the deferred
+// groups of each of JG_SHARDS contiguous group ranges into that shard's list (LDS counter);
+// k_dense_slow then replays the ticks for them with densely packed lanes, so its fault-queue
+// pushes coalesce per wave.  (Appending ~1 % of 1 M groups to one list from the dense kernel
+// cost it +65 us per tick: ~8 ns per contended wave-level atomic request; scanning the flag
+// column with one sparse lane per wave cost the slow kernel the same in fault pushes —
+// profiles/README.md.)
+#define JG_SHARDS 256
+__global__ __launch_bounds__(JG_BLOCK) void k_collect_deferred(JgDev d) {
+  __shared__ uint32_t n_s;
+  if (threadIdx.x == 0) n_s = 0;
+  __syncthreads();
+  const uint32_t cap = (d.G + JG_SHARDS - 1) / JG_SHARDS;
+  const uint32_t g0 = blockIdx.x * cap;
+  const uint32_t g1 = g0 + cap < d.G ? g0 + cap : d.G;
+  uint32_t* list = d.slow_list + (size_t)blockIdx.x * cap;
+  for (uint32_t g = g0 + threadIdx.x; g < g1; g += JG_BLOCK) {
+    const uint32_t f = d.flags[g];
+    if (!(f & JGF_FAULT_MASK) && (f & JGF_ROLE_MASK) == JG_ROLE_LEADER && !(f & JGF_FAST))
+      list[atomicAdd(&n_s, 1u)] = g;  // LDS atomic; order within a shard does not matter
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) d.slow_cnt[blockIdx.x] = n_s;
+}
+
+// Same ticks through the general state machine for the collected groups; workgroup s owns
+// shard s.
 __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
                                                           size_t tick_stride, uint32_t seq0) {
   uint32_t dec = 0;
-  for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < d.G; g += gridDim.x * JG_BLOCK) {
-    // exactly the groups the dense kernel deferred: healthy leaders not in FAST form
-    const uint32_t f = d.flags[g];
-    if ((f & JGF_FAULT_MASK) || (f & JGF_ROLE_MASK) != JG_ROLE_LEADER || (f & JGF_FAST)) continue;
+  const uint32_t cap = (d.G + JG_SHARDS - 1) / JG_SHARDS;
+  const uint32_t n = d.slow_cnt[blockIdx.x];
+  const uint32_t* list = d.slow_list + (size_t)blockIdx.x * cap;
+  for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) {
+    const uint32_t g = list[i];
     JgLane L;
     jg_load(d, L, g);
     L.now = 0;

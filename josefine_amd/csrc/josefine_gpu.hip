@@ -173,7 +173,9 @@ int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1) {
   e->n_launch++;
   if (e->maybe_irregular) {
     e->slow_scheduled_ever = true;
-    hipLaunchKernelGGL(k_dense_slow, dim3(grid_for(e->cfg.n_groups, 2048)), dim3(JG_BLOCK), 0, e->stream,
+    hipLaunchKernelGGL(k_collect_deferred, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream, e->dev);
+    e->n_launch++;
+    hipLaunchKernelGGL(k_dense_slow, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream,
                        e->dev, acks_dev, n_ticks, (size_t)e->cfg.n_groups * e->cfg.n_replicas, e->seq);
     e->n_launch++;
   }
@@ -453,6 +455,8 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.fault_q, d.fault_q_cap);
   A(d.fault_q_n, 1);
   A(d.deferred_seen, 1);
+  A(d.slow_list, G + JG_SHARDS);
+  A(d.slow_cnt, JG_SHARDS);
   A(d.irregular_seen, 1);
   A(e->d_err, 1);
 #undef A
