@@ -38,7 +38,8 @@ def cpu_baseline(R: int, seed: int, budget_s: float):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     from oracle_lib import oracle_engine
-    from parity import elect_all, synth_tick_host
+    from josefine_amd.traces import elect_all
+    from parity import synth_tick_host
 
     Gs, ticks = 50_000, 12
     ora = oracle_engine(Gs, R, seed=seed)
@@ -106,8 +107,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from josefine_amd import BatchedRaft
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from parity import elect_all
+    from josefine_amd.traces import elect_all
 
     G, R, K, W = args.groups, args.replicas, args.steps, args.warmup
     eng = BatchedRaft(G, R, seed=args.seed, device_id=local_rank, group_base=rank * G)
@@ -134,7 +134,7 @@ def main():
     T = max(1, args.ticks_per_launch) if not args.failures else 1
     fail_rows = None
     if args.failures:
-        from failures import failure_rows
+        from josefine_amd.traces import failure_rows
         slots = eng.read("self_slot")
         # the failure trace, like the ack stream, is resident in HBM before the timed region:
         # one group-sorted device batch per tick (jg_step_device_rows, no host pass per tick)

@@ -1,0 +1,72 @@
+"""Host-side builders of the synthetic command traces: pure row
+generation with numpy — no Raft logic, no oracle.  Used by bench.py, the smoke test and
+the parity tests so that all of them drive the engine with the same inputs.
+
+`hash(seed, tick, g, r)` is the counter-based hash of DESIGN.md "Synthetic traces" (the
+same function the device generator k_synth_acks evaluates), keyed by the *global* group id
+so that any shard regenerates its own slice.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _capi as capi
+
+
+def mix64(z):
+    """splitmix64 finaliser, vectorised (uint64 wrap-around arithmetic)."""
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def synth_hash(seed, tick, gg, r):
+    with np.errstate(over="ignore"):
+        a = mix64(np.uint64(seed) + np.uint64(tick) * np.uint64(0x9E3779B97F4A7C15))
+        return mix64(a ^ (np.asarray(gg, dtype=np.uint64) * np.uint64(8) + np.uint64(r)))
+
+
+def elect_all(e, now_ms: int = 0) -> None:
+    """Make the local instance of every group the leader at term 1 by the reference's own
+    path: Timeout -> candidate + self-vote (follower.rs:248-256, candidate.rs:24-45), then
+    granted VoteResponses from the next R/2 slots until quorum (candidate.rs:91-113)."""
+    from .engine import Command
+
+    e.apply_all(Command.Timeout(), now_ms)
+    if e.R == 1:
+        return
+    slots = e.read("self_slot")
+    ids = np.array(e.node_ids, dtype=np.uint32)
+    n = e.G
+    for k in range(1, e.R // 2 + 1):  # quorum = R/2 + 1 including the self-vote
+        voter = ids[(slots.astype(np.int64) + k) % e.R]
+        e.submit_columns(np.full(n, capi.CMD_VOTE_RESPONSE, np.uint8), np.arange(n, dtype=np.uint32),
+                         from_=voter, term=np.ones(n, np.uint64), flag=np.ones(n, np.uint8))
+        e.step(now_ms)
+
+
+def failure_rows(seed, tick, group_base, G, R, node_ids, self_slots, percent=1):
+    """BASELINE.json configs[4]: the command rows of one tick's leader failures.
+
+    Every group fails with probability percent/100 (hash salt 7): the local (leader) instance
+    crashes and restarts (JG_CMD_RESTART = Raft::new + Chain::new on the persisted tree), times
+    out with voted_for == None — the only way a node can campaign in the reference (SURVEY.md
+    §7.3 Q4) — and receives granted VoteResponses from the next R/2 replicas.  Returns (columns
+    for submit_columns / upload_rows, number of failing groups)."""
+    gg = np.arange(G, dtype=np.uint64) + np.uint64(group_base)
+    failing = np.nonzero(synth_hash(seed, tick, gg, 7) % np.uint64(100) < np.uint64(percent))[0].astype(np.uint32)
+    n = len(failing)
+    ids = np.array(node_ids, dtype=np.uint32)
+    kind = [np.full(n, capi.CMD_RESTART, np.uint8), np.full(n, capi.CMD_TIMEOUT, np.uint8)]
+    group = [failing, failing]
+    frm = [np.zeros(n, np.uint32), np.zeros(n, np.uint32)]
+    for k in range(1, R // 2 + 1):
+        kind.append(np.full(n, capi.CMD_VOTE_RESPONSE, np.uint8))
+        group.append(failing)
+        frm.append(ids[(np.asarray(self_slots)[failing].astype(np.int64) + k) % R])
+    kind, group, frm = np.concatenate(kind), np.concatenate(group), np.concatenate(frm)
+    return dict(kind=kind, group=group, from_=frm, term=np.ones(len(kind), np.uint64),
+                flag=np.ones(len(kind), np.uint8)), n

@@ -40,22 +40,7 @@ def compare_drains(dev: BatchedRaft, ora: BatchedRaft, what: str = "") -> None:
                                  f"oracle={b[first] if first < len(b) else None}")
 
 
-def elect_all(e: BatchedRaft, now_ms: int = 0) -> None:
-    """Make the local instance of every group the leader at term 1 by the reference's
-    own path: Timeout -> candidate + self-vote (follower.rs:248-256, candidate.rs:24-45),
-    then granted VoteResponses from the next R/2 slots until quorum (candidate.rs:91-113)."""
-    e.apply_all(Command.Timeout(), now_ms)
-    if e.R == 1:
-        return
-    slots = e.read("self_slot")
-    need = e.R // 2  # quorum = R/2+1 including the self-vote
-    ids = np.array(e.node_ids, dtype=np.uint32)
-    for k in range(1, need + 1):
-        voter = ids[(slots.astype(np.int64) + k) % e.R]
-        n = e.G
-        e.submit_columns(np.full(n, capi.CMD_VOTE_RESPONSE, np.uint8), np.arange(n, dtype=np.uint32),
-                         from_=voter, term=np.ones(n, np.uint64), flag=np.ones(n, np.uint8))
-        e.step(now_ms)
+from josefine_amd.traces import elect_all  # noqa: E402,F401  (shared with bench.py / smoke)
 
 
 def synth_tick_host(ora: BatchedRaft, mode: int, tick: int, sim: np.ndarray) -> np.ndarray:
