@@ -14,11 +14,16 @@ from josefine_amd import capi
 
 
 class Cluster:
-    def __init__(self, engine, P, R):
+    def __init__(self, engine, P, R, chaos_seed=None, drop=0.05, dup=0.05, restart=0.002):
         self.e, self.P, self.R = engine, P, R
         self.now = 0
         self.inbox = None  # dict of columns for the next step
         self.next_token = 1
+        # optional unreliable network + crashing processes (same seed => same perturbation for
+        # every engine driven with the same messages): drops (tcp.rs:90-93 drops when a peer
+        # queue is full), duplicates, and process restarts
+        self.chaos = np.random.default_rng(chaos_seed) if chaos_seed is not None else None
+        self.p_drop, self.p_dup, self.p_restart = drop, dup, restart
 
     @staticmethod
     def self_slots(P, R):
@@ -40,6 +45,12 @@ class Cluster:
             start = np.maximum.accumulate(np.where(first, np.arange(len(msgs)), 0))
             k_in_sender = np.arange(len(msgs)) - start
             msgs = msgs[np.argsort(k_in_sender, kind="stable")]
+            if self.chaos is not None:
+                u = self.chaos.random(len(msgs))
+                keep = u >= self.p_drop
+                dup = keep & (u >= 1.0 - self.p_dup)
+                idx = np.concatenate([np.nonzero(keep)[0], np.nonzero(dup)[0]])
+                msgs = msgs[np.sort(idx, kind="stable")]
         for m in msgs:
             k = int(m["kind"])
             if k == capi.CMD_CLIENT_REQUEST or int(m["to_kind"]) in (capi.TO_QUEUE, capi.TO_CLIENT, capi.TO_LOCAL):
@@ -77,6 +88,10 @@ class Cluster:
         if self.inbox is not None and len(self.inbox["kind"]):
             e.submit_columns(**self.inbox)
         G = self.P * self.R
+        if self.chaos is not None:
+            crash = np.nonzero(self.chaos.random(G) < self.p_restart)[0].astype(np.uint32)
+            if len(crash):
+                e.submit_columns(np.full(len(crash), capi.CMD_RESTART, np.uint8), crash)
         e.submit_columns(np.full(G, capi.CMD_TICK, np.uint8), np.arange(G, dtype=np.uint32))
         roles = e.read("role")
         leaders = np.nonzero((roles == capi.ROLE_LEADER) & (e.read("fault") == 0))[0]

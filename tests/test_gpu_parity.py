@@ -263,3 +263,41 @@ def test_device_rows_must_be_sorted():
     dev.step_device_rows(rows)
     with pytest.raises(EngineError):
         dev.read("term")
+
+
+def test_abi_contract_on_device():
+    """Status codes of the C ABI on the real library: capacity, ranges, validation, ordering."""
+    import ctypes as C
+    from josefine_amd import EngineError
+    dev = BatchedRaft(4, 3)
+    dev.apply(0, Command.Timeout())
+    n = C.c_size_t(0)
+    assert dev.api.drain_messages(dev._h, None, 0, C.byref(n)) == capi.OK and n.value == 2
+    buf = np.zeros(1, dtype=capi.MSG_DTYPE)
+    assert dev.api.drain_messages(dev._h, buf.ctypes.data, 1, C.byref(n)) == capi.ECAPACITY
+    assert len(dev.drain_messages()) == 2
+    out = np.zeros(8, np.uint64)
+    assert dev.api.read_state(dev._h, capi.FIELD_TERM, 0, out.ctypes.data, 2, 3) == capi.EINVAL
+    assert dev.api.read_state(dev._h, capi.FIELD_MATCH, 3, out.ctypes.data, 0, 1) == capi.EINVAL
+    assert dev.api.read_state(dev._h, 99, 0, out.ctypes.data, 0, 1) == capi.EINVAL
+    with pytest.raises(EngineError):
+        dev.submit_columns([capi.CMD_TICK], [4])
+    with pytest.raises(EngineError):
+        dev.submit_columns([capi.CMD_APPEND_ENTRIES], [0], id=[0], aux=[2], blk_id=[1], blk_next=[0])
+    with pytest.raises(EngineError):  # self slots are fixed after the first step
+        dev._check(dev.api.set_self_slots(dev._h, np.zeros(4, np.uint8).ctypes.data))
+    # queued commands must be stepped before a dense tick
+    dev.submit_columns([capi.CMD_NOOP], [1])
+    assert dev.api.step_dense_acks(dev._h, np.zeros((3, 4), np.uint64).ctypes.data) == capi.EINVAL
+    dev.step()
+    assert dev.api.abi_version() == capi.ABI_VERSION
+
+
+def test_two_engines_are_independent():
+    a, b = BatchedRaft(16, 3, seed=1), BatchedRaft(16, 3, seed=2)
+    elect_all(a)
+    assert (a.read("role") == capi.ROLE_LEADER).all() and (b.read("role") == capi.ROLE_FOLLOWER).all()
+    assert not np.array_equal(a.read("election_timeout"), b.read("election_timeout"))
+    a.close()
+    b.apply(3, Command.Timeout())
+    assert b.handle(3).is_candidate()
