@@ -102,15 +102,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # RCCL ("nccl") is the backend of record; JG_BENCH_BACKEND=gloo exists only so that the
+    # N>1 code path can be exercised with several ranks on a single-GPU box.
+    backend = os.environ.get("JG_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    red_dev = "cuda" if backend == "nccl" else "cpu"
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from josefine_amd import BatchedRaft
     from josefine_amd.traces import elect_all
 
     G, R, K, W = args.groups, args.replicas, args.steps, args.warmup
-    eng = BatchedRaft(G, R, seed=args.seed, device_id=local_rank, group_base=rank * G)
+    eng = BatchedRaft(G, R, seed=args.seed, device_id=dev_index, group_base=rank * G)
     elect_all(eng)  # Timeout -> votes -> leader through the general kernel
     eng.drain_messages(), eng.drain_applies()
     api, h = eng.api, eng._h
@@ -204,9 +212,9 @@ def main():
         assert (head == W + 2 * K).all() and (commit == W + 2 * K - 1).all(), "closed form violated (batched ticks)"
         dec_b = float(eng.counters()["decisions"] - c1["decisions"])
         if world > 1:
-            tb = torch.tensor([wall_b], dtype=torch.float64, device="cuda")
+            tb = torch.tensor([wall_b], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tb, op=dist.ReduceOp.MAX)
-            tdb = torch.tensor([dec_b], dtype=torch.float64, device="cuda")
+            tdb = torch.tensor([dec_b], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tdb, op=dist.ReduceOp.SUM)
             wall_b, dec_b = tb[0].item(), tdb[0].item()
         batched = {"ticks_per_launch": TB, "steps": K, "ms_per_step": wall_b * 1e3 / K,
@@ -215,9 +223,9 @@ def main():
                    "note": "same results bit for bit; state read/written once per launch"}
 
     if world > 1:
-        tw = torch.tensor([wall, ev_ms.value], dtype=torch.float64, device="cuda")
+        tw = torch.tensor([wall, ev_ms.value], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        td = torch.tensor([float(decisions)], dtype=torch.float64, device="cuda")
+        td = torch.tensor([float(decisions)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(td, op=dist.ReduceOp.SUM)
         wall, ev_max_ms, decisions_all = tw[0].item(), tw[1].item(), td[0].item()
     else:
