@@ -16,6 +16,10 @@
 //             -> the id set is exactly [0, head]; the id_gen / run_hi columns
 //             are then implicit (possibly stale in memory)
 //  bit  5     the "commit" key has been persisted               chain.rs:198
+//  bit  6     SELF-SYNC (leaders): the leader's own progress head equals the chain
+//             head (true after every self-ack, leader.rs:190-196) -> match[self] is
+//             implicit and its column entry stale; the dense kernel then neither
+//             reads nor writes it (16 B per group-step less HBM traffic)
 //  bits 8-15  bit r: progress of slot r is Replicate (else Probe) progress.rs:62-66
 //  bits 16-23 sticky fault code (JG_FAULT_*)
 //  bits 24-26 own replica slot
@@ -25,6 +29,7 @@
 #define JGF_HAS_LEADER (1u << 3)
 #define JGF_FAST (1u << 4)
 #define JGF_COMMIT_KEY (1u << 5)
+#define JGF_SELF_SYNC (1u << 6)
 #define JGF_REPL_SHIFT 8
 #define JGF_REPL_MASK (0xffu << JGF_REPL_SHIFT)
 #define JGF_FAULT_SHIFT 16
@@ -53,7 +58,7 @@ struct JgDev {
   uint64_t* head;            // Chain.head                             chain.rs:103
   uint64_t* id_gen;          // Chain.id_gen (valid unless FAST)       chain.rs:101
   uint64_t* run_hi;          // segment 0: ids [0, run_hi], next = id-1 (valid unless FAST)
-  uint64_t* match;           // [R][G] Progress.head                   progress.rs:124
+  uint64_t* match;           // [R][G] Progress.head (own slot implicit while SELF-SYNC) progress.rs:124
   uint64_t* election_time;   // State.election_time (ms)               mod.rs:281
   uint64_t* heartbeat_time;  // Leader.heartbeat_time (ms)             leader.rs:27
   uint64_t* win_lo;          // [W][G] chain segments besides the run: first id,
@@ -88,6 +93,7 @@ __device__ __forceinline__ uint64_t jg_mix64(uint64_t z) {
 struct JgLane {
   uint32_t g;
   uint64_t term, commit, head, id_gen, run_hi, election_time, heartbeat_time;
+  uint64_t self_match;  // Progress.head of the own slot (leaders; 0 otherwise)
   uint32_t flags, voted_for, leader_id, election_timeout, rng_draws, queued, votes;
   uint64_t now;
   uint32_t seq;
@@ -144,6 +150,9 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
   L.rng_draws = d.rng_draws[g];
   L.queued = d.queued[g];
   L.votes = d.votes[g];
+  L.self_match = 0;
+  if ((L.flags & JGF_ROLE_MASK) == JG_ROLE_LEADER)
+    L.self_match = (L.flags & JGF_SELF_SYNC) ? L.head : d.match[(size_t)jg_self(L) * d.G + g];
   L.decisions = 0;
   L.overflow = 0;
 }
@@ -152,6 +161,9 @@ __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   bool fast = (L.run_hi == L.head) && (L.id_gen == L.head + 1) && (jg_wcnt(L) == 0);
   L.flags = fast ? (L.flags | JGF_FAST) : (L.flags & ~JGF_FAST);
   if (!fast) *d.irregular_seen = 1;  // the host then schedules k_dense_slow behind the dense kernel
+  const bool sync = jg_role(L) == JG_ROLE_LEADER && L.self_match == L.head;
+  L.flags = sync ? (L.flags | JGF_SELF_SYNC) : (L.flags & ~JGF_SELF_SYNC);
+  if (jg_role(L) == JG_ROLE_LEADER && !sync) d.match[(size_t)jg_self(L) * d.G + g] = L.self_match;
   d.flags[g] = L.flags;
   d.term[g] = L.term;
   d.commit[g] = L.commit;
@@ -357,7 +369,8 @@ __device__ inline int jg_slot_of(const JgDev& d, uint32_t node_id) {
 __device__ inline uint64_t jg_committed_index(const JgDev& d, const JgLane& L) {
   uint64_t v[JG_MAX_REPLICAS];
 #pragma unroll
-  for (uint32_t r = 0; r < JG_MAX_REPLICAS; r++) v[r] = r < d.R ? d.match[(size_t)r * d.G + L.g] : 0;
+  for (uint32_t r = 0; r < JG_MAX_REPLICAS; r++)
+    v[r] = r < d.R ? (r == jg_self(L) ? L.self_match : d.match[(size_t)r * d.G + L.g]) : 0;
   uint32_t k = d.R / 2;
   uint64_t q = 0;
 #pragma unroll
@@ -413,7 +426,9 @@ __device__ inline void jg_follower_from_leader(JgLane& L) {  // leader.rs:268-28
   L.flags &= ~JGF_REPL_MASK;
 }
 __device__ inline void jg_become_leader(const JgDev& d, JgLane& L) {  // candidate.rs:216-238
-  for (uint32_t r = 0; r < d.R; r++) d.match[(size_t)r * d.G + L.g] = 0;  // progress.rs:155-162
+  for (uint32_t r = 0; r < d.R; r++)                                      // progress.rs:155-162
+    if (r != jg_self(L)) d.match[(size_t)r * d.G + L.g] = 0;
+  L.self_match = 0;
   L.flags &= ~JGF_REPL_MASK;
   L.heartbeat_time = L.now;
   jg_set_role(L, JG_ROLE_LEADER);
@@ -440,10 +455,15 @@ __device__ inline uint32_t jg_leader_append_response(const JgDev& d, JgLane& L, 
   // leader.rs:211-219 -> progress.rs:42-46,76-94,133-140
   int s = jg_slot_of(d, node);
   if (s < 0) return JG_FAULT_PROGRESS_UNKNOWN_NODE;  // progress.rs:43
-  size_t k = (size_t)s * d.G + L.g;
-  uint64_t m = d.match[k];
-  bool inc = m < head;
-  if (inc) d.match[k] = head;
+  bool inc;
+  if ((uint32_t)s == jg_self(L)) {  // own slot: kept in the lane (implicit while SELF-SYNC)
+    inc = L.self_match < head;
+    if (inc) L.self_match = head;
+  } else {
+    size_t k = (size_t)s * d.G + L.g;
+    inc = d.match[k] < head;
+    if (inc) d.match[k] = head;
+  }
   uint32_t bit = 1u << (JGF_REPL_SHIFT + s);
   L.flags = inc ? (L.flags | bit) : (L.flags & ~bit);
   return jg_leader_commit(d, L);

@@ -13,7 +13,7 @@
 #pragma once
 #include "jg_device.h"
 
-#include "jg_dense.h"  // k_leader_tick_dense / _x2, jg_block_count, JG_BLOCK
+#include "jg_dense.h"  // k_leader_tick_dense / _n, jg_block_count, JG_BLOCK
 
 // ---- groups the dense kernel deferred (healthy leaders whose chain is not in FAST form) ----
 // Two kernels, no contended global atomics: k_collect_deferred compacts the deferred
@@ -175,6 +175,7 @@ __global__ void k_init_groups(JgDev d, const uint8_t* __restrict__ self_slots) {
     L.overflow = 0;
     L.decisions = 0;
     L.term = 0;
+    L.self_match = 0;
     L.commit = L.head = 0;   // Chain::new on an empty tree: genesis block 0
     L.id_gen = 1;
     L.run_hi = 0;

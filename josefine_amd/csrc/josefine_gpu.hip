@@ -87,7 +87,7 @@ struct jg_engine {
   std::vector<void*> allocs;
   uint32_t count_slots = 0;  // workgroup slots of dev.blk_decisions
   uint32_t dense_grid = 0;
-  int dense_variant = 1;
+  int uniform_self = 0;  // the own replica slot if it is the same for every group, else -1
   uint32_t* d_err = nullptr;
   uint64_t* d_acks_staging = nullptr;  // [R][G] for the host-buffer dense entry point
   // commands queued by jg_submit (host SoA)
@@ -148,13 +148,10 @@ void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks) {
   const size_t stride = (size_t)e->cfg.n_groups * e->cfg.n_replicas;
   if (n_ticks > 1)  // temporal fusion: state read once, written once per launch
     hipLaunchKernelGGL(k_leader_tick_dense_n<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
-                       n_ticks, stride, e->seq);
-  else if (e->dense_variant == 2)  // two groups per lane, 16-B accesses (needs an even G)
-    hipLaunchKernelGGL(k_leader_tick_dense_x2<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
-                       e->seq);
+                       n_ticks, stride, e->seq, e->uniform_self);
   else
     hipLaunchKernelGGL(k_leader_tick_dense<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
-                       e->seq);
+                       e->seq, e->uniform_self);
 }
 
 int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1) {
@@ -425,10 +422,7 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   const char* env_grid = std::getenv("JG_DENSE_GRID");
   uint32_t cap = env_grid ? (uint32_t)std::atoi(env_grid) : 8192u;  // measured best (profiles/README.md)
   if (cap < 1) cap = 1;
-  const char* env_var = std::getenv("JG_DENSE_VARIANT");
-  e->dense_variant = env_var ? std::atoi(env_var) : 1;
-  if (e->dense_variant != 2 || (G & 1)) e->dense_variant = 1;
-  e->dense_grid = grid_for(e->dense_variant == 2 ? G / 2 : G, cap);
+  e->dense_grid = grid_for(G, cap);
   e->count_slots = std::max<uint32_t>(e->dense_grid, 4096);
 #define A(ptr, n) \
   if ((rc = dev_alloc(e, &ptr, (n))) != JG_OK) return bail(rc)
@@ -488,6 +482,9 @@ int jg_set_self_slots(jg_engine* e, const uint8_t* slots) {
   if (e->stepped) return fail(JG_EINVAL, "self slots are fixed after the first step");
   for (uint32_t g = 0; g < e->cfg.n_groups; g++)
     if (slots[g] >= e->cfg.n_replicas) return fail(JG_EINVAL, "self slot out of range");
+  e->uniform_self = slots[0];
+  for (uint32_t g = 1; g < e->cfg.n_groups; g++)
+    if (slots[g] != slots[0]) e->uniform_self = -1;
   HIPCHK(hipSetDevice(e->device));
   uint8_t* d_slots = nullptr;
   HIPCHK(hipMalloc((void**)&d_slots, std::max<size_t>(e->cfg.n_groups, 16)));
@@ -742,10 +739,16 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
       for (uint32_t i = 0; i < n; i++) o64[i] = (fl[i] & JGF_FAST) ? head[i] + 1 : t64[i];
       return JG_OK;
     }
-    case JG_FIELD_MATCH:
+    case JG_FIELD_MATCH: {  // the own slot is implicit (== head) while the group is SELF-SYNC
+      std::vector<uint64_t> head(n);
+      HIPCHK(hipMemcpy(head.data(), d.head + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
       if ((rc = get64(d.match + (size_t)replica * d.G))) return rc;
-      for (uint32_t i = 0; i < n; i++) o64[i] = role(i) == JG_ROLE_LEADER ? t64[i] : 0;
+      for (uint32_t i = 0; i < n; i++) {
+        const bool own = ((fl[i] & JGF_SELF_MASK) >> JGF_SELF_SHIFT) == replica;
+        o64[i] = role(i) != JG_ROLE_LEADER ? 0 : (own && (fl[i] & JGF_SELF_SYNC)) ? head[i] : t64[i];
+      }
       return JG_OK;
+    }
     case JG_FIELD_HEARTBEAT_TIME:
       if ((rc = get64(d.heartbeat_time))) return rc;
       for (uint32_t i = 0; i < n; i++) o64[i] = role(i) == JG_ROLE_LEADER ? t64[i] : 0;

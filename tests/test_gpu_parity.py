@@ -25,19 +25,25 @@ def test_election_setup_parity(R):
     assert (dev.read("role") == capi.ROLE_LEADER).all()
 
 
-@pytest.fixture(params=["1", "2"])
-def dense_variant(request, monkeypatch):
-    """Both dense kernels: one group per lane (8-B accesses) / two per lane (16-B accesses)."""
-    monkeypatch.setenv("JG_DENSE_VARIANT", request.param)
-    return request.param
+@pytest.fixture(params=["slot0", "last", "mixed"])
+def slot_layout(request):
+    """Own-slot layouts: the dense kernel skips the (implicit, SELF-SYNC) own match column by a
+    wave-uniform branch when every group has the same own slot, per lane otherwise."""
+    def make(G, R):
+        if request.param == "slot0":
+            return None
+        if request.param == "last":
+            return np.full(G, R - 1, np.uint8)
+        return (np.arange(G) % R).astype(np.uint8)
+    return make
 
 
 @pytest.mark.parametrize("R,G,mode,ticks", [(3, 10_000, 1, 200), (5, 10_000, 1, 60), (5, 4096, 0, 40),
                                             (1, 1000, 1, 20), (2, 1000, 1, 30), (4, 1000, 1, 30),
                                             (8, 1000, 1, 30), (3, 1001, 1, 20)])
-def test_dense_ack_stream_parity(R, G, mode, ticks, dense_variant):
+def test_dense_ack_stream_parity(R, G, mode, ticks, slot_layout):
     """BASELINE config #2 shape (10k x 3 ragged stream) and friends: compare after every tick."""
-    dev, ora = pair(G, R, seed=0x6A6F7365 + R)
+    dev, ora = pair(G, R, seed=0x6A6F7365 + R, self_slots=slot_layout(G, R))
     for e in (dev, ora):
         elect_all(e)
     run_dense_ticks(dev, ora, mode=mode, ticks=ticks, check_every=1)
@@ -155,7 +161,7 @@ def _dense_edge_case_engines():
 
 
 @pytest.mark.parametrize("fused", [False, True])
-def test_dense_faults_followers_and_irregular_chains(fused, dense_variant):
+def test_dense_faults_followers_and_irregular_chains(fused):
     dev, ora, G, R = _dense_edge_case_engines()
     NO = capi.NO_ACK
     T = 4
@@ -192,6 +198,46 @@ def test_dense_faults_followers_and_irregular_chains(fused, dense_variant):
     assert list(ora.read("fault")) == [0, capi.FAULT_ENGINE_DENSE_NONLEADER, capi.FAULT_COMMIT_MISSING_BLOCK,
                                        capi.FAULT_APPEND_ID_NOT_ABOVE_HEAD, capi.FAULT_LEADER_TERM_UNIMPLEMENTED, 0]
     assert int(ora.read("head")[5]) == 5 and int(ora.read("commit")[5]) == 2
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_dense_own_match_head_not_in_sync(fused):
+    """The leader's own progress head is implicit only while it equals the chain head.  An
+    AppendResponse that names the leader's own NodeId (the reference does not check the sender,
+    leader.rs:211-219) can push it above the head: the dense kernel must then go back to the
+    stored column — and to the exact per-ack replay, since q may exceed the head."""
+    G, R = 512, 3
+    dev, ora = pair(G, R, seed=11)
+    for e in (dev, ora):
+        elect_all(e)
+        e.drain_messages(), e.drain_applies()
+    g = np.arange(0, G, 3, dtype=np.uint32)
+    for e in (dev, ora):  # own NodeId is node_ids[0] == 1
+        e.submit_columns(np.full(len(g), capi.CMD_APPEND_RESPONSE, np.uint8), g, from_=np.ones(len(g), np.uint32),
+                         id=np.full(len(g), 7, np.uint64), flag=np.ones(len(g), np.uint8))
+        e.step()
+    compare_snapshots(dev, ora, "forged own ack")
+    assert (ora.read("match", 0)[g] == 7).all()
+    T = 12
+    acks = np.full((T, R, G), capi.NO_ACK, dtype=np.uint64)
+    acks[:, 0, :] = 1
+    for t in range(1, T):
+        acks[t, 1, :] = t      # follower 1 acks the previous head
+        acks[t, 2, ::2] = t
+    if fused:
+        for t0 in range(0, T, 4):
+            dev.step_dense_acks_n(acks[t0:t0 + 4])
+            ora.step_dense_acks_n(acks[t0:t0 + 4])
+            compare_snapshots(dev, ora, f"own head out of sync, ticks {t0}..")
+            compare_drains(dev, ora, f"own head out of sync, ticks {t0}..")
+    else:
+        for t in range(T):
+            dev.step_dense_acks(acks[t])
+            ora.step_dense_acks(acks[t])
+            compare_snapshots(dev, ora, f"own head out of sync, tick {t}")
+            compare_drains(dev, ora, f"own head out of sync, tick {t}")
+    # the forged head is overtaken at tick 8: from then on the own head tracks the chain head again
+    assert (ora.read("match", 0) == ora.read("head")).all() and int(ora.read("head")[0]) == T
 
 
 def test_chain_window_overflow_is_loud():
