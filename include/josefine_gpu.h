@@ -298,6 +298,12 @@ int jg_sync(jg_engine* e);
 int jg_drain_messages(jg_engine* e, jg_msg_row* out, size_t cap, size_t* n);
 int jg_drain_applies(jg_engine* e, jg_fsm_row* out, size_t cap, size_t* n);
 int jg_drain_faults(jg_engine* e, jg_fault_row* out, size_t cap, size_t* n);
+/* Zero-copy drains: *rows points at the engine's pinned host queue (filled by one
+ * asynchronous device-to-host copy), valid until the engine's next synchronising call
+ * (step results are not affected: the rows count as drained).  What a Rust adapter
+ * iterates to re-emit on rpc_tx / fsm_tx without an intermediate Vec. */
+int jg_drain_messages_view(jg_engine* e, const jg_msg_row** rows, size_t* n);
+int jg_drain_applies_view(jg_engine* e, const jg_fsm_row** rows, size_t* n);
 
 /* Copy one state column for groups [g0, g0+n) to host memory (element type per
  * JG_FIELD_* above).  `replica` selects the slot for JG_FIELD_MATCH. */

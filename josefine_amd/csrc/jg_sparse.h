@@ -82,9 +82,11 @@ __global__ __launch_bounds__(JG_BLOCK) void k_apply_rows(JgDev d, JgRowsArgs a) 
 // ---- drain-time compaction, entirely on the device -------------------------------------------
 // cnt[i] rows sit at src + i*per_row; the drained sequence is their concatenation in row
 // order (= group order, emission order within a group).  Exclusive scan of cnt in three
-// steps: per-workgroup sums (1024 counts each), a single-workgroup scan of those sums, then
-// each workgroup re-scans its 1024 counts (wave64 shuffles + an LDS hop across the four
-// waves), adds its base and copies its rows to their final place.
+// steps: per-workgroup sums (1024 counts each; at step time), a single-workgroup scan of
+// those sums (one launch for all pending steps at drain time), then each workgroup re-scans
+// its 1024 counts (wave64 shuffles + an LDS hop across the four waves), adds its base and
+// copies its rows to their final place in ONE buffer per queue, which travels to the pinned
+// host queue in one copy.
 #define JG_SCAN_ITEMS 4
 #define JG_SCAN_TILE (JG_BLOCK * JG_SCAN_ITEMS)
 
@@ -112,21 +114,39 @@ __device__ __forceinline__ uint32_t jg_block_exclusive_scan(uint32_t v, uint32_t
   return base + inc - v;
 }
 
-__global__ __launch_bounds__(JG_BLOCK) void k_count_block_sums(const uint32_t* __restrict__ cnt, uint32_t n,
-                                                               uint64_t* __restrict__ bsum) {
+// step time, right behind k_apply_rows: tile sums of both count arrays
+__global__ __launch_bounds__(JG_BLOCK) void k_count_block_sums(const uint32_t* __restrict__ cnt_m,
+                                                               const uint32_t* __restrict__ cnt_f, uint32_t n,
+                                                               uint64_t* __restrict__ bsum_m,
+                                                               uint64_t* __restrict__ bsum_f) {
   const uint32_t base = blockIdx.x * JG_SCAN_TILE + threadIdx.x * JG_SCAN_ITEMS;
-  uint32_t v = 0;
+  uint32_t vm = 0, vf = 0;
 #pragma unroll
-  for (int k = 0; k < JG_SCAN_ITEMS; k++) v += (base + k < n) ? cnt[base + k] : 0u;
-  uint32_t tot;
-  (void)jg_block_exclusive_scan(v, &tot);
-  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+  for (int k = 0; k < JG_SCAN_ITEMS; k++) {
+    vm += (base + k < n) ? cnt_m[base + k] : 0u;
+    vf += (base + k < n) ? cnt_f[base + k] : 0u;
+  }
+  uint32_t tot_m, tot_f;
+  (void)jg_block_exclusive_scan(vm, &tot_m);
+  (void)jg_block_exclusive_scan(vf, &tot_f);
+  if (threadIdx.x == 0) {
+    bsum_m[blockIdx.x] = tot_m;
+    bsum_f[blockIdx.x] = tot_f;
+  }
 }
 
-// one workgroup: bsum[] -> exclusive prefix in place, grand total to *total
-__global__ __launch_bounds__(JG_BLOCK) void k_scan_block_sums(uint64_t* __restrict__ bsum, uint32_t nb,
-                                                              uint64_t* __restrict__ total) {
+// drain time, one launch for every pending step: workgroup b turns the tile sums of job b
+// (one count array of one step) into exclusive prefixes in place and writes the job's grand
+// total.  The job table and the totals live in pinned host memory (read / written in place).
+struct JgScanJob {
+  uint64_t* bsum;
+  uint32_t nb, pad;
+};
+__global__ __launch_bounds__(JG_BLOCK) void k_scan_block_sums(const JgScanJob* __restrict__ jobs,
+                                                              uint64_t* __restrict__ totals) {
   __shared__ uint64_t carry_s;
+  uint64_t* bsum = jobs[blockIdx.x].bsum;
+  const uint32_t nb = jobs[blockIdx.x].nb;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   for (uint32_t base = 0; base < nb; base += JG_BLOCK) {
@@ -141,7 +161,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_scan_block_sums(uint64_t* __restri
     if (threadIdx.x == 0) carry_s = carry + tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *total = carry_s;
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 
 template <typename Row>

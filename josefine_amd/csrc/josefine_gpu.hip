@@ -36,6 +36,7 @@ struct StepRec {
   uint32_t n = 0;  // command rows
   uint32_t msg_per_row = 0, fsm_per_row = 0;
   uint32_t *d_msg_cnt = nullptr, *d_fsm_cnt = nullptr;
+  uint64_t *d_bsum_m = nullptr, *d_bsum_f = nullptr;  // tile sums -> exclusive prefixes at drain
   jg_msg_row* d_msg = nullptr;
   jg_fsm_row* d_fsm = nullptr;
 };
@@ -76,6 +77,32 @@ struct Arena {
   }
 };
 
+// Host-side output queue in pinned memory: device rows land here with one async copy at PCIe
+// speed (a pageable destination costs a staged, blocking copy), and jg_drain_*_view hands the
+// rows to the caller without another pass.
+template <typename Row>
+struct PinnedQueue {
+  Row* p = nullptr;
+  size_t cap = 0, n = 0;
+  hipError_t reserve(size_t want) {
+    if (want <= cap) return hipSuccess;
+    size_t ncap = std::max<size_t>(want, std::max<size_t>(cap * 2, 4096));
+    Row* q = nullptr;
+    hipError_t e = hipHostMalloc((void**)&q, ncap * sizeof(Row), hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (n) std::memcpy(q, p, n * sizeof(Row));
+    if (p) (void)hipHostFree(p);
+    p = q;
+    cap = ncap;
+    return hipSuccess;
+  }
+  void destroy() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = n = 0;
+  }
+};
+
 }  // namespace
 
 struct jg_engine {
@@ -88,6 +115,10 @@ struct jg_engine {
   uint32_t count_slots = 0;  // workgroup slots of dev.blk_decisions
   uint32_t dense_grid = 0;
   int uniform_self = 0;  // the own replica slot if it is the same for every group, else -1
+  // device status block {err, irregular_seen, deferred_seen, fault_q_n}: read back with one
+  // copy into its pinned mirror at every synchronisation point
+  uint32_t* d_status = nullptr;
+  uint32_t* h_status = nullptr;
   uint32_t* d_err = nullptr;
   uint64_t* d_acks_staging = nullptr;  // [R][G] for the host-buffer dense entry point
   // commands queued by jg_submit (host SoA)
@@ -100,9 +131,14 @@ struct jg_engine {
   bool stage_busy = false;
   Arena arena;
   std::vector<StepRec> recs;
-  std::vector<jg_msg_row> q_msgs;
-  std::vector<jg_fsm_row> q_fsm;
+  PinnedQueue<jg_msg_row> q_msgs;
+  PinnedQueue<jg_fsm_row> q_fsm;
   std::vector<jg_fault_row> q_faults;
+  std::vector<JgFaultRec> fault_tmp;
+  JgScanJob* h_jobs = nullptr;  // pinned: drain-time scan jobs and their totals
+  uint64_t* h_totals = nullptr;
+  size_t scan_cap = 0;
+  bool view_m = false, view_f = false;  // rows handed out by a *_view call: released on the next collect
   uint32_t seq = 0;
   bool stepped = false;
   // Some group's chain may have left FAST form (then k_dense_slow runs behind the
@@ -186,27 +222,22 @@ int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1) {
 // device-side error flags, and settle the lazily-read irregular-chain flag.
 int sync_and_check(jg_engine* e) {
   HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->stage_busy = false;
-  uint32_t err = 0;
-  HIPCHK(hipMemcpy(&err, e->d_err, sizeof err, hipMemcpyDeviceToHost));
+  const uint32_t err = e->h_status[0], irregular = e->h_status[1], deferred = e->h_status[2];
   if (err == 1) return fail(JG_EDEVICE, "internal: an output row exceeded its per-command bound");
   if (err == 2) return fail(JG_EINVAL, "device command rows were not sorted by group");
   if (err == 3) return fail(JG_EINVAL, "device command rows name a group out of range");
   if (e->flag_check_pending) {
-    uint32_t seen = 0;
-    HIPCHK(hipMemcpy(&seen, e->dev.irregular_seen, sizeof seen, hipMemcpyDeviceToHost));
-    e->maybe_irregular = seen != 0;  // sticky on the device: once seen, the slow kernel stays scheduled
+    e->maybe_irregular = irregular != 0;  // sticky on the device: once seen, the slow kernel stays scheduled
     e->flag_check_pending = false;
   }
-  if (!e->slow_scheduled_ever) {
-    // Assertion: irregular chains only come out of sparse steps, and every dense launch after
-    // a sparse step has k_dense_slow behind it until the device flag is read back as 0 — so
-    // while no slow kernel was ever scheduled the dense kernel cannot have deferred a group.
-    uint32_t seen = 0;
-    HIPCHK(hipMemcpy(&seen, e->dev.deferred_seen, sizeof seen, hipMemcpyDeviceToHost));
-    if (seen) return fail(JG_EDEVICE, "internal: irregular chain reached the fast-only dense path");
-  }
+  // Assertion: irregular chains only come out of sparse steps, and every dense launch after
+  // a sparse step has k_dense_slow behind it until the device flag is read back as 0 — so
+  // while no slow kernel was ever scheduled the dense kernel cannot have deferred a group.
+  if (!e->slow_scheduled_ever && deferred)
+    return fail(JG_EDEVICE, "internal: irregular chain reached the fast-only dense path");
   return JG_OK;
 }
 
@@ -216,69 +247,81 @@ int sync_and_check(jg_engine* e) {
 int collect(jg_engine* e) {
   int rc = sync_and_check(e);
   if (rc) return rc;
+  if (e->view_m) e->q_msgs.n = 0, e->view_m = false;  // the caller is done with the last view
+  if (e->view_f) e->q_fsm.n = 0, e->view_f = false;
   const size_t nrec = e->recs.size();
   if (nrec) {
-    std::vector<uint64_t*> d_bsum(2 * nrec);
-    uint64_t* d_totals = nullptr;
-    HIPCHK(e->arena.alloc(2 * nrec * 8, (void**)&d_totals));
+    // job table + totals in pinned host memory, read / written by the kernel in place
+    if (e->scan_cap < 2 * nrec) {
+      if (e->h_jobs) HIPCHK(hipHostFree(e->h_jobs));
+      if (e->h_totals) HIPCHK(hipHostFree(e->h_totals));
+      e->h_jobs = nullptr, e->h_totals = nullptr;
+      e->scan_cap = std::max<size_t>(4 * nrec, 64);
+      HIPCHK(hipHostMalloc((void**)&e->h_jobs, e->scan_cap * sizeof(JgScanJob), hipHostMallocDefault));
+      HIPCHK(hipHostMalloc((void**)&e->h_totals, e->scan_cap * sizeof(uint64_t), hipHostMallocDefault));
+    }
     for (size_t k = 0; k < nrec; k++) {
       StepRec& r = e->recs[k];
       const uint32_t nb = (r.n + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
-      for (int pass = 0; pass < 2; pass++) {
-        HIPCHK(e->arena.alloc((size_t)nb * 8, (void**)&d_bsum[2 * k + pass]));
-        const uint32_t* cnt = pass == 0 ? r.d_msg_cnt : r.d_fsm_cnt;
-        hipLaunchKernelGGL(k_count_block_sums, dim3(nb), dim3(JG_BLOCK), 0, e->stream, cnt, r.n, d_bsum[2 * k + pass]);
-        hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(JG_BLOCK), 0, e->stream, d_bsum[2 * k + pass], nb,
-                           d_totals + 2 * k + pass);
-      }
+      e->h_jobs[2 * k] = JgScanJob{r.d_bsum_m, nb, 0};
+      e->h_jobs[2 * k + 1] = JgScanJob{r.d_bsum_f, nb, 0};
     }
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(2 * nrec), dim3(JG_BLOCK), 0, e->stream,
+                       (const JgScanJob*)e->h_jobs, e->h_totals);
     HIPCHK(hipGetLastError());
-    std::vector<uint64_t> totals(2 * nrec);
-    HIPCHK(hipMemcpyAsync(totals.data(), d_totals, 2 * nrec * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    const uint64_t* totals = e->h_totals;
     uint64_t add_m = 0, add_f = 0;
     for (size_t k = 0; k < nrec; k++) {
       add_m += totals[2 * k];
       add_f += totals[2 * k + 1];
     }
-    size_t at_m = e->q_msgs.size(), at_f = e->q_fsm.size();
-    e->q_msgs.resize(at_m + add_m);
-    e->q_fsm.resize(at_f + add_f);
+    const size_t at_m = e->q_msgs.n, at_f = e->q_fsm.n;
+    HIPCHK(e->q_msgs.reserve(at_m + add_m));
+    HIPCHK(e->q_fsm.reserve(at_f + add_f));
+    jg_msg_row* d_all_m = nullptr;
+    jg_fsm_row* d_all_f = nullptr;
+    if (add_m) HIPCHK(e->arena.alloc(add_m * sizeof(jg_msg_row), (void**)&d_all_m));
+    if (add_f) HIPCHK(e->arena.alloc(add_f * sizeof(jg_fsm_row), (void**)&d_all_f));
+    uint64_t off_m = 0, off_f = 0;
     for (size_t k = 0; k < nrec; k++) {
       StepRec& r = e->recs[k];
       const uint32_t nb = (r.n + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
       if (totals[2 * k]) {
-        jg_msg_row* d_dst = nullptr;
-        HIPCHK(e->arena.alloc(totals[2 * k] * sizeof(jg_msg_row), (void**)&d_dst));
         hipLaunchKernelGGL(k_scan_gather<jg_msg_row>, dim3(nb), dim3(JG_BLOCK), 0, e->stream, r.d_msg_cnt, r.n,
-                           d_bsum[2 * k], r.msg_per_row, r.d_msg, d_dst);
-        HIPCHK(hipMemcpyAsync(e->q_msgs.data() + at_m, d_dst, totals[2 * k] * sizeof(jg_msg_row),
-                              hipMemcpyDeviceToHost, e->stream));
-        at_m += totals[2 * k];
+                           r.d_bsum_m, r.msg_per_row, r.d_msg, d_all_m + off_m);
+        off_m += totals[2 * k];
       }
       if (totals[2 * k + 1]) {
-        jg_fsm_row* d_dst = nullptr;
-        HIPCHK(e->arena.alloc(totals[2 * k + 1] * sizeof(jg_fsm_row), (void**)&d_dst));
         hipLaunchKernelGGL(k_scan_gather<jg_fsm_row>, dim3(nb), dim3(JG_BLOCK), 0, e->stream, r.d_fsm_cnt, r.n,
-                           d_bsum[2 * k + 1], r.fsm_per_row, r.d_fsm, d_dst);
-        HIPCHK(hipMemcpyAsync(e->q_fsm.data() + at_f, d_dst, totals[2 * k + 1] * sizeof(jg_fsm_row),
-                              hipMemcpyDeviceToHost, e->stream));
-        at_f += totals[2 * k + 1];
+                           r.d_bsum_f, r.fsm_per_row, r.d_fsm, d_all_f + off_f);
+        off_f += totals[2 * k + 1];
       }
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(e->stream));
+    if (add_m)
+      HIPCHK(hipMemcpyAsync(e->q_msgs.p + at_m, d_all_m, add_m * sizeof(jg_msg_row), hipMemcpyDeviceToHost, e->stream));
+    if (add_f)
+      HIPCHK(hipMemcpyAsync(e->q_fsm.p + at_f, d_all_f, add_f * sizeof(jg_fsm_row), hipMemcpyDeviceToHost, e->stream));
+    e->q_msgs.n = at_m + add_m;
+    e->q_fsm.n = at_f + add_f;
+  }
+  // faults (the count came with the status block)
+  const uint32_t nf = e->h_status[3];
+  if (nf) {
+    if (nf > e->dev.fault_q_cap) return fail(JG_EDEVICE, "fault queue overflow");
+    e->fault_tmp.resize(nf);
+    HIPCHK(hipMemcpyAsync(e->fault_tmp.data(), e->dev.fault_q, nf * sizeof(JgFaultRec), hipMemcpyDeviceToHost,
+                          e->stream));
+    HIPCHK(hipMemsetAsync(e->dev.fault_q_n, 0, sizeof(uint32_t), e->stream));
+  }
+  if (nrec || nf) HIPCHK(hipStreamSynchronize(e->stream));
+  if (nrec) {
     e->recs.clear();
     e->arena.reset();
   }
-  // faults
-  uint32_t nf = 0;
-  HIPCHK(hipMemcpy(&nf, e->dev.fault_q_n, sizeof nf, hipMemcpyDeviceToHost));
   if (nf) {
-    if (nf > e->dev.fault_q_cap) return fail(JG_EDEVICE, "fault queue overflow");
-    std::vector<JgFaultRec> fr(nf);
-    HIPCHK(hipMemcpy(fr.data(), e->dev.fault_q, nf * sizeof(JgFaultRec), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(e->dev.fault_q_n, 0, sizeof(uint32_t)));
+    std::vector<JgFaultRec>& fr = e->fault_tmp;
     std::stable_sort(fr.begin(), fr.end(), [](const JgFaultRec& a, const JgFaultRec& b) {
       return a.seq != b.seq ? a.seq < b.seq : a.group < b.group;
     });
@@ -288,15 +331,25 @@ int collect(jg_engine* e) {
 }
 
 template <typename Row>
-int drain(jg_engine* e, std::vector<Row>& q, Row* out, size_t cap, size_t* n) {
+int drain(jg_engine* e, PinnedQueue<Row>& q, Row* out, size_t cap, size_t* n) {
   if (!e || !n) return fail(JG_EINVAL, "null argument");
   int rc = collect(e);
   if (rc) return rc;
-  *n = q.size();
+  *n = q.n;
   if (!out) return JG_OK;
-  if (cap < q.size()) return fail(JG_ECAPACITY, "output buffer too small");
-  if (!q.empty()) std::memcpy(out, q.data(), q.size() * sizeof(Row));
-  q.clear();
+  if (cap < q.n) return fail(JG_ECAPACITY, "output buffer too small");
+  if (q.n) std::memcpy(out, q.p, q.n * sizeof(Row));
+  q.n = 0;
+  return JG_OK;
+}
+template <typename Row>
+int drain_view(jg_engine* e, PinnedQueue<Row>& q, bool& viewed, const Row** rows, size_t* n) {
+  if (!e || !rows || !n) return fail(JG_EINVAL, "null argument");
+  int rc = collect(e);
+  if (rc) return rc;
+  *rows = q.p;
+  *n = q.n;
+  viewed = true;  // consumed: the rows stay readable until the engine's next call that synchronises
   return JG_OK;
 }
 
@@ -340,6 +393,9 @@ int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* 
   HIPCHK(e->arena.alloc((size_t)n * 4, (void**)&rec.d_fsm_cnt));
   HIPCHK(e->arena.alloc((size_t)n * rec.msg_per_row * sizeof(jg_msg_row), (void**)&rec.d_msg));
   HIPCHK(e->arena.alloc((size_t)n * rec.fsm_per_row * sizeof(jg_fsm_row), (void**)&rec.d_fsm));
+  const uint32_t n_tiles = (n + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
+  HIPCHK(e->arena.alloc((size_t)n_tiles * 8, (void**)&rec.d_bsum_m));
+  HIPCHK(e->arena.alloc((size_t)n_tiles * 8, (void**)&rec.d_bsum_f));
   JgRowsArgs a;
   a.n = n;
   a.group = group;
@@ -361,8 +417,10 @@ int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* 
   a.now = now_ms;
   a.seq = e->seq;
   hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(n, e->count_slots)), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
+  hipLaunchKernelGGL(k_count_block_sums, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, rec.d_msg_cnt, rec.d_fsm_cnt, n,
+                     rec.d_bsum_m, rec.d_bsum_f);
   HIPCHK(hipGetLastError());
-  e->n_launch++;
+  e->n_launch += 2;
   e->recs.push_back(rec);
   e->n_cmds += n;
   e->maybe_irregular = true;  // until the device flag says otherwise (sync_and_check)
@@ -447,12 +505,15 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.blk_decisions, e->count_slots);
   d.fault_q_cap = (uint32_t)std::max<size_t>(2 * G, 1024);
   A(d.fault_q, d.fault_q_cap);
-  A(d.fault_q_n, 1);
-  A(d.deferred_seen, 1);
+  A(e->d_status, 4);
+  e->d_err = e->d_status;
+  d.irregular_seen = e->d_status + 1;
+  d.deferred_seen = e->d_status + 2;
+  d.fault_q_n = e->d_status + 3;
+  if (hipHostMalloc((void**)&e->h_status, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+    return bail(fail(JG_EDEVICE, "hipHostMalloc failed"));
   A(d.slow_list, G + JG_SHARDS);
   A(d.slow_cnt, JG_SHARDS);
-  A(d.irregular_seen, 1);
-  A(e->d_err, 1);
 #undef A
   hipLaunchKernelGGL(k_init_groups, dim3(grid_for(G, 2048)), dim3(JG_BLOCK), 0, e->stream, e->dev,
                      (const uint8_t*)nullptr);
@@ -470,6 +531,11 @@ void jg_engine_destroy(jg_engine* e) {
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->d_acks_staging) (void)hipFree(e->d_acks_staging);
   if (e->stage) (void)hipHostFree(e->stage);
+  if (e->h_status) (void)hipHostFree(e->h_status);
+  if (e->h_jobs) (void)hipHostFree(e->h_jobs);
+  if (e->h_totals) (void)hipHostFree(e->h_totals);
+  e->q_msgs.destroy();
+  e->q_fsm.destroy();
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->ev_stage) (void)hipEventDestroy(e->ev_stage);
@@ -686,9 +752,29 @@ int jg_sync(jg_engine* e) {
   return sync_and_check(e);
 }
 
-int jg_drain_messages(jg_engine* e, jg_msg_row* out, size_t cap, size_t* n) { return drain(e, e->q_msgs, out, cap, n); }
-int jg_drain_applies(jg_engine* e, jg_fsm_row* out, size_t cap, size_t* n) { return drain(e, e->q_fsm, out, cap, n); }
-int jg_drain_faults(jg_engine* e, jg_fault_row* out, size_t cap, size_t* n) { return drain(e, e->q_faults, out, cap, n); }
+int jg_drain_messages(jg_engine* e, jg_msg_row* out, size_t cap, size_t* n) {
+  return e ? drain(e, e->q_msgs, out, cap, n) : fail(JG_EINVAL, "null argument");
+}
+int jg_drain_applies(jg_engine* e, jg_fsm_row* out, size_t cap, size_t* n) {
+  return e ? drain(e, e->q_fsm, out, cap, n) : fail(JG_EINVAL, "null argument");
+}
+int jg_drain_messages_view(jg_engine* e, const jg_msg_row** rows, size_t* n) {
+  return e ? drain_view(e, e->q_msgs, e->view_m, rows, n) : fail(JG_EINVAL, "null argument");
+}
+int jg_drain_applies_view(jg_engine* e, const jg_fsm_row** rows, size_t* n) {
+  return e ? drain_view(e, e->q_fsm, e->view_f, rows, n) : fail(JG_EINVAL, "null argument");
+}
+int jg_drain_faults(jg_engine* e, jg_fault_row* out, size_t cap, size_t* n) {
+  if (!e || !n) return fail(JG_EINVAL, "null argument");
+  int rc = collect(e);
+  if (rc) return rc;
+  *n = e->q_faults.size();
+  if (!out) return JG_OK;
+  if (cap < e->q_faults.size()) return fail(JG_ECAPACITY, "output buffer too small");
+  if (!e->q_faults.empty()) std::memcpy(out, e->q_faults.data(), e->q_faults.size() * sizeof(jg_fault_row));
+  e->q_faults.clear();
+  return JG_OK;
+}
 
 int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t g0, uint32_t n) {
   if (!e || (!out && n)) return fail(JG_EINVAL, "null argument");

@@ -297,12 +297,28 @@ class BatchedRaft:
             self._check(fn(self._h, out.ctypes.data, n.value, C.byref(n)))
         return out
 
-    def drain_messages(self) -> np.ndarray:
+    def _drain_view(self, fn, dtype, copy: bool) -> np.ndarray:
+        """One call: the rows sit in the engine's pinned host queue; `copy=False` returns a
+        numpy view of it that is valid until the engine's next synchronising call."""
+        p, n = C.c_void_p(), C.c_size_t(0)
+        self._check(fn(self._h, C.byref(p), C.byref(n)))
+        dt = np.dtype(dtype)
+        if not n.value:
+            return np.zeros(0, dtype=dt)
+        buf = (C.c_char * (n.value * dt.itemsize)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dt)
+        return arr.copy() if copy else arr
+
+    def drain_messages(self, copy: bool = True) -> np.ndarray:
         """Everything the groups pushed on rpc_tx since the last drain."""
+        if hasattr(self.api, "drain_messages_view"):
+            return self._drain_view(self.api.drain_messages_view, capi.MSG_DTYPE, copy)
         return self._drain(self.api.drain_messages, capi.MSG_DTYPE)
 
-    def drain_applies(self) -> np.ndarray:
+    def drain_applies(self, copy: bool = True) -> np.ndarray:
         """Everything the groups pushed on fsm_tx since the last drain."""
+        if hasattr(self.api, "drain_applies_view"):
+            return self._drain_view(self.api.drain_applies_view, capi.FSM_DTYPE, copy)
         return self._drain(self.api.drain_applies, capi.FSM_DTYPE)
 
     def drain_faults(self) -> np.ndarray:
