@@ -283,6 +283,75 @@ int jg_step_dense_acks_device(jg_engine* e, const uint64_t* acks_dev);
  * the groups' state is read and written once per launch instead of once per tick. */
 int jg_step_dense_acks_device_n(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks);
 
+/* ---- dense node tick: the steady-state traffic of a cluster in column form ----------------
+ * What a leader sends its followers on a Tick (leader.rs:234-245: heartbeat() if due, then
+ * replicate()) and what they answer (follower.rs:130-217), as device-resident SoA mailboxes, so
+ * that a whole protocol round of millions of groups never leaves HBM: one engine's outbox
+ * columns are another engine's inbox columns (same device: the same pointers).
+ *
+ * Mailbox vocabulary (everything else a step emits is queued as ordinary jg_msg_row rows,
+ * drained with jg_drain_messages, in per-group emission order):
+ *   Heartbeat{term, commit, leader_id}      -> term[g], hb_commit[g]
+ *   AppendEntries{term, leader_id, blocks}  -> term[g], ae_from[r][g], ae_n[r][g]: the blocks are
+ *       ids ae_from+1 .. ae_from+ae_n, each with next = id-1 — expressible exactly when the
+ *       leader's chain is in run form (id set [0, head] built by append only: every FAST-path
+ *       leader); a leader whose chain is not sends all messages of its Tick as rows instead
+ *   AppendResponse{node_id, head}           -> ack_head[g]   (one row of the leader's ack block)
+ *   HeartbeatResponse{commit, has_committed}-> hb_commit[g], hb_has[g]
+ * FSM instructions are not queued by dense steps: they are the per-group commit / head deltas
+ * (follower: Apply for keys [commit_before, commit_after), follower.rs:204; leader: as
+ * jg_step_dense_acks). */
+#define JG_AE_NONE 0xFFu /* ae_n: no AppendEntries for this slot / group this tick            */
+#define JG_HB_NONE 0xFFu /* hb_has: no HeartbeatResponse                                       */
+
+typedef struct jg_leader_inbox { /* device pointers; any may be NULL = nothing of that kind */
+  const uint64_t* acks;      /* [R][G] as jg_step_dense_acks: AppendResponse heads / own slot = #appends */
+  const uint8_t* hbr_has;    /* [R][G] HeartbeatResponse.has_committed: 0, 1 or JG_HB_NONE            */
+  const uint64_t* hbr_commit;/* [R][G] HeartbeatResponse.commit (read only where hbr_has == 0)        */
+} jg_leader_inbox;
+
+typedef struct jg_leader_outbox { /* device pointers, all required */
+  uint64_t* term;      /* [G]    current_term of this tick's messages                              */
+  uint64_t* hb_commit; /* [G]    Heartbeat.commit, or JG_NO_ACK: no heartbeat (not due / no leader) */
+  uint64_t* ae_from;   /* [R][G] range start key = progress head of slot r (leader.rs:135,152)     */
+  uint8_t* ae_n;       /* [R][G] number of blocks (0..JG_MAX_INFLIGHT) or JG_AE_NONE               */
+} jg_leader_outbox;
+
+typedef struct jg_follower_inbox { /* device pointers */
+  const uint32_t* leader;   /* [G] sender NodeId per group, or NULL: `leader_id` for every group   */
+  uint32_t leader_id;
+  uint32_t reserved;
+  const uint64_t* term;     /* [G]                                                                 */
+  const uint64_t* hb_commit;/* [G] JG_NO_ACK = no Heartbeat                                        */
+  const uint64_t* ae_from;  /* [G]                                                                 */
+  const uint8_t* ae_n;      /* [G] JG_AE_NONE = no AppendEntries                                   */
+} jg_follower_inbox;
+
+typedef struct jg_follower_outbox { /* device pointers, all required */
+  uint64_t* ack_head;  /* [G] AppendResponse.head or JG_NO_ACK                                     */
+  uint64_t* hb_commit; /* [G] HeartbeatResponse.commit (defined where hb_has != JG_HB_NONE)        */
+  uint8_t* hb_has;     /* [G] HeartbeatResponse.has_committed, or JG_HB_NONE                       */
+} jg_follower_outbox;
+
+/* Leader half of a node tick.  Per group that is a healthy leader, in this order:
+ *   1. the HeartbeatResponses of `in`, ascending slot (leader.rs:222-231: replicate() again if
+ *      !has_committed && commit > 0 — those extra AppendEntries are queued as rows);
+ *   2. the appends and AppendResponses of in->acks exactly as jg_step_dense_acks;
+ *   3. if `out` != NULL: Command::Tick (leader.rs:234-245) into the outbox columns.
+ * Groups that are not leaders ignore 1-2 as the reference does and are not ticked here
+ * (jg_step_dense_follower ticks them): their outbox entries are "none". */
+int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* in, const jg_leader_outbox* out);
+
+/* Follower half of a node tick.  Per group that is not a leader, in this order:
+ *   1. Heartbeat{in->term, in->hb_commit, leader}      if hb_commit[g] != JG_NO_ACK (follower.rs:178-217)
+ *   2. AppendEntries{in->term, leader, blocks}         if ae_n[g] != JG_AE_NONE     (follower.rs:130-176)
+ *   3. Command::Tick                                   if tick != 0     (follower.rs:121-128, candidate.rs:48-68)
+ * Leaders apply 1-2 as the reference does (leader.rs:200-208,263) and are not ticked here.
+ * Equivalent to submitting those commands through jg_submit/jg_step, except that
+ * AppendResponse / HeartbeatResponse go to the outbox columns and no FSM rows are queued. */
+int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in,
+                           const jg_follower_outbox* out, int tick);
+
 /* Batched Chain::compact (src/raft/chain.rs:239-253) as a pure function over
  * explicit (id,next) trees: tree t owns entries [off[t], off[t+1]); ids within a
  * tree need not be sorted.  removed[i] = 1 iff the walk removes entry i. */

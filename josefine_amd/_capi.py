@@ -101,6 +101,27 @@ class CmdBatch(C.Structure):
     ]
 
 
+AE_NONE = 0xFF
+HB_NONE = 0xFF
+
+
+class LeaderInbox(C.Structure):
+    _fields_ = [("acks", C.c_void_p), ("hbr_has", C.c_void_p), ("hbr_commit", C.c_void_p)]
+
+
+class LeaderOutbox(C.Structure):
+    _fields_ = [("term", C.c_void_p), ("hb_commit", C.c_void_p), ("ae_from", C.c_void_p), ("ae_n", C.c_void_p)]
+
+
+class FollowerInbox(C.Structure):
+    _fields_ = [("leader", C.c_void_p), ("leader_id", C.c_uint32), ("reserved", C.c_uint32),
+                ("term", C.c_void_p), ("hb_commit", C.c_void_p), ("ae_from", C.c_void_p), ("ae_n", C.c_void_p)]
+
+
+class FollowerOutbox(C.Structure):
+    _fields_ = [("ack_head", C.c_void_p), ("hb_commit", C.c_void_p), ("hb_has", C.c_void_p)]
+
+
 # numpy structured dtypes matching jg_msg_row / jg_fsm_row / jg_fault_row
 MSG_DTYPE = [("group", "<u4"), ("kind", "u1"), ("to_kind", "u1"), ("flag", "u1"), ("pad", "u1"),
              ("to_id", "<u4"), ("from", "<u4"), ("term", "<u8"), ("id", "<u8"), ("aux", "<u8")]
@@ -121,6 +142,8 @@ class Api:
         "submit": (C.c_int, [_P, C.POINTER(CmdBatch)]),
         "step": (C.c_int, [_P, C.c_uint64]),
         "step_dense_acks": (C.c_int, [_P, _P]),
+        "step_dense_leader": (C.c_int, [_P, C.c_uint64, C.POINTER(LeaderInbox), C.POINTER(LeaderOutbox)]),
+        "step_dense_follower": (C.c_int, [_P, C.c_uint64, C.POINTER(FollowerInbox), C.POINTER(FollowerOutbox), C.c_int]),
         "chain_compact": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, _P]),
         "drain_messages": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
         "drain_applies": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -180,7 +203,8 @@ class Api:
 # Every symbol include/josefine_gpu.h declares (checked by the CPU test-suite).
 HEADER_SYMBOLS = [
     "jg_engine_create", "jg_engine_destroy", "jg_set_self_slots", "jg_submit", "jg_step", "jg_step_device_rows",
-    "jg_step_dense_acks", "jg_step_dense_acks_device", "jg_step_dense_acks_device_n", "jg_chain_compact", "jg_sync",
+    "jg_step_dense_acks", "jg_step_dense_acks_device", "jg_step_dense_acks_device_n",
+    "jg_step_dense_leader", "jg_step_dense_follower", "jg_chain_compact", "jg_sync",
     "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_read_state", "jg_get_counters",
     "jg_device_alloc", "jg_device_free", "jg_device_upload", "jg_device_download",
     "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_last_error", "jg_abi_version",

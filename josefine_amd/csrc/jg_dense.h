@@ -196,8 +196,46 @@ __device__ __forceinline__ void jg_dense_store(const JgDev& d, uint32_t g, uint3
   if (nf != f) d.flags[g] = nf;
 }
 
+// ---- deferral to the slow kernel: wave-aggregated append to sharded lists -----------------------
+// Groups a dense kernel cannot serve in registers (irregular chains, exceptional inputs) are
+// handed to a slow kernel launched right behind it.  The lanes of a wave that defer are
+// counted with one __ballot / __popcll, the first of them reserves the wave's slots with ONE
+// atomic on the counter of the workgroup's shard (JG_SHARDS counters: ~16 workgroups each at
+// 1 M groups, so no hot address), and every deferring lane writes its group at base + rank.
+// Costs nothing when nobody defers (the ballot is wave-uniform).  `tag` is or-ed into the entry.
+#define JG_SHARDS 256
+#define JG_DEFER_TICK_ONLY 0x80000000u  // follower half: inputs already applied, Tick pending
+__device__ __forceinline__ void jg_defer_push(const JgDev& d, uint32_t g, bool want, uint32_t tag = 0) {
+  const uint64_t mask = __ballot(want);
+  if (!mask) return;
+  const uint32_t shard = blockIdx.x & (JG_SHARDS - 1);
+  const uint32_t lane = threadIdx.x & 63u;
+  const int first = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if ((int)lane == first) base = atomicAdd(&d.slow_cnt[shard], (uint32_t)__popcll(mask));
+  base = __shfl(base, first, 64);
+  if (want) {
+    const uint32_t i = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (i < d.slow_cap) d.slow_list[(size_t)shard * d.slow_cap + i] = g | tag;
+    else *d.err = 4;
+    *d.deferred_seen = 1;  // lets the host verify that the slow kernel was scheduled
+  }
+}
+
+// Node-tick extras of the leader kernel (jg_step_dense_leader): HeartbeatResponse input and the
+// Tick's outbox (leader.rs:234-245).  All pointers may be null (= plain jg_step_dense_acks).
+struct JgLeaderNode {
+  const uint8_t* hbr_has;      // [R][G] 0 / 1 / JG_HB_NONE
+  const uint64_t* hbr_commit;  // [R][G] (slow kernel only)
+  uint64_t* o_term;            // [G]
+  uint64_t* o_hb;              // [G]
+  uint64_t* o_from;            // [R][G]
+  uint8_t* o_n;                // [R][G]
+  uint64_t now;
+};
+
 // What a lane must do with one group after looking at its flag word.
-enum { JG_DENSE_SKIP = 0, JG_DENSE_RUN = 1 };
+enum { JG_DENSE_SKIP = 0, JG_DENSE_RUN = 1, JG_DENSE_DEFER = 2 };
 
 // Classify the group; handles the rare non-RUN outcomes itself.
 __device__ __forceinline__ int jg_dense_classify(const JgDev& d, uint32_t g, uint32_t f, uint64_t n_app,
@@ -211,13 +249,9 @@ __device__ __forceinline__ int jg_dense_classify(const JgDev& d, uint32_t g, uin
     }
     return JG_DENSE_SKIP;
   }
-  if (!(f & JGF_FAST)) {
-    // irregular chain: k_dense_slow, launched right behind this kernel, finds the group by
-    // the same test on its flag word (no list, no atomics on this path) and replays the tick
-    // through the general state machine.  *deferred_seen lets the host verify it was scheduled.
-    *d.deferred_seen = 1;
-    return JG_DENSE_SKIP;
-  }
+  // irregular chain: k_dense_slow, launched right behind this kernel, replays the tick
+  // through the general state machine
+  if (!(f & JGF_FAST)) return JG_DENSE_DEFER;
   return JG_DENSE_RUN;
 }
 
@@ -226,17 +260,106 @@ __device__ __forceinline__ int jg_dense_classify(const JgDev& d, uint32_t g, uin
 // NodeId).  Otherwise the own slot comes from the flag word and the other loads wait for it.
 // (A two-groups-per-lane variant with 16-B accesses measured no faster — the kernel is
 // bandwidth-, not issue-bound: profiles/README.md round 1 — and was dropped.)
-template <int R, bool UNIFORM>
-__device__ __forceinline__ uint32_t jg_dense_tick_body(const JgDev& d, const uint64_t* __restrict__ acks,
-                                                       uint32_t seq, uint32_t us) {
+// Command::Tick of a FAST leader into the outbox columns (leader.rs:234-245): heartbeat() if due,
+// then replicate() — per other slot the range start key (= its progress head) and the number
+// of blocks after it (Probe: nth(1) -> 1, Replicate: skip(1).take(5), leader.rs:135,152-157).
+template <int R>
+__device__ __forceinline__ void jg_dense_leader_tick(const JgDev& d, const JgLeaderNode& nd, uint32_t g, uint32_t seq,
+                                                     uint32_t s, uint64_t term, uint64_t hbt, JgDenseRegs<R>& x) {
   const uint32_t G = d.G;
+  nd.o_term[g] = term;
+  uint64_t hb = JG_NO_ACK;
+  if ((nd.now - hbt) > (uint64_t)d.hb_timeout) {  // leader.rs:78-84
+    hb = x.commit;                                // leader.rs:44-51
+    d.heartbeat_time[g] = nd.now;
+  }
+  nd.o_hb[g] = hb;
+  const bool key_in_range = (x.nf & JGF_COMMIT_KEY) && !(d.cfg_flags & JG_CFG_SEPARATE_COMMIT_KEY);
+  bool dead = false;
+#pragma unroll
+  for (int k = 0; k + 1 < R; k++) {
+    const uint32_t r = jg_other_slot(k, s);
+    uint32_t n = JG_AE_NONE;
+    uint64_t from = 0;
+    if (!dead) {
+      const bool repl = (x.nf >> (JGF_REPL_SHIFT + r)) & 1u;
+      const uint32_t want = repl ? JG_MAX_INFLIGHT + 1 : 2;  // items consumed by the range iterator
+      from = x.mo[k];
+      const uint64_t avail = from <= x.head ? x.head - from + 1 : 0;  // block keys >= from (FAST form)
+      const uint32_t cnt = avail >= want ? want : (uint32_t)avail;
+      if (cnt < want && key_in_range) {  // the iterator runs into the "commit" key: chain.rs:219-226 (Q9)
+        dead = true;
+        from = 0;
+        x.nf |= JG_FAULT_RANGE_HIT_COMMIT_KEY << JGF_FAULT_SHIFT;
+        jg_push_fault(d, g, JG_FAULT_RANGE_HIT_COMMIT_KEY, seq);
+      } else {
+        n = cnt ? cnt - 1 : 0;
+      }
+    }
+    nd.o_from[(size_t)r * G + g] = from;
+    nd.o_n[(size_t)r * G + g] = (uint8_t)n;
+  }
+  nd.o_from[(size_t)s * G + g] = 0;
+  nd.o_n[(size_t)s * G + g] = JG_AE_NONE;
+}
+template <int R>
+__device__ __forceinline__ void jg_dense_outbox_none(const JgDev& d, const JgLeaderNode& nd, uint32_t g) {
+  nd.o_term[g] = 0;
+  nd.o_hb[g] = JG_NO_ACK;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    nd.o_from[(size_t)r * d.G + g] = 0;
+    nd.o_n[(size_t)r * d.G + g] = JG_AE_NONE;
+  }
+}
+
+// ---- one tick per launch ------------------------------------------------------------------------
+// UNIFORM: every group of the engine has own slot `us` (the normal case: a node has one
+// NodeId).  Otherwise the own slot comes from the flag word and the other loads wait for it.
+// NODE: jg_step_dense_leader — HeartbeatResponse input and / or the Tick's outbox.
+// (A two-groups-per-lane variant with 16-B accesses measured no faster — the kernel is
+// bandwidth-, not issue-bound: profiles/README.md round 1 — and was dropped.)
+template <int R, bool UNIFORM, bool NODE>
+__device__ __forceinline__ uint32_t jg_dense_tick_body(const JgDev& d, const uint64_t* __restrict__ acks,
+                                                       uint32_t seq, uint32_t us, const JgLeaderNode& nd) {
+  const uint32_t G = d.G;
+  const bool emit = NODE && nd.o_term != nullptr;
   uint32_t dec = 0;
   for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
     const uint32_t f = d.flags[g];
     const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
     JgDenseRegs<R> x;
-    jg_dense_load<R>(d, acks, g, s, x);
-    if (jg_dense_classify(d, g, f, x.n_app, seq) != JG_DENSE_RUN) continue;
+    if (!NODE || acks) {
+      jg_dense_load<R>(d, acks, g, s, x);
+    } else {  // a Tick without acks
+      x.n_app = 0;
+#pragma unroll
+      for (int k = 0; k + 1 < R; k++) {
+        x.ao[k] = JG_NO_ACK;
+        x.mo[k] = d.match[(size_t)jg_other_slot(k, s) * G + g];
+      }
+      x.commit = d.commit[g];
+      x.head = d.head[g];
+    }
+    uint64_t term = 0, hbt = 0;
+    bool hbr_trigger = false;
+    if (NODE) {
+      if (emit) {
+        term = d.term[g];
+        hbt = d.heartbeat_time[g];
+      }
+      if (nd.hbr_has) {  // leader.rs:222-231: a response without the commit makes the leader replicate again
+#pragma unroll
+        for (int k = 0; k + 1 < R; k++) hbr_trigger |= nd.hbr_has[(size_t)jg_other_slot(k, s) * G + g] == 0;
+      }
+    }
+    int cls = jg_dense_classify(d, g, f, x.n_app, seq);
+    if (NODE && cls == JG_DENSE_RUN && hbr_trigger) cls = JG_DENSE_DEFER;  // extra AppendEntries: rows
+    jg_defer_push(d, g, cls == JG_DENSE_DEFER);
+    if (cls != JG_DENSE_RUN) {
+      if (emit) jg_dense_outbox_none<R>(d, nd, g);  // (a deferred group's Tick: the slow kernel)
+      continue;
+    }
     const uint64_t commit0 = x.commit, head0 = x.head;
     x.ms = head0;  // SELF-SYNC: implicit
     if (!(f & JGF_SELF_SYNC)) x.ms = d.match[(size_t)s * G + g];
@@ -247,6 +370,10 @@ __device__ __forceinline__ uint32_t jg_dense_tick_body(const JgDev& d, const uin
 #pragma unroll
     for (int k = 0; k + 1 < R; k++) chg |= (x.ao[k] != JG_NO_ACK && x.mo[k] < x.ao[k]) ? (2u << k) : 0u;
     dec += jg_dense_core<R>(d, g, seq, s, x);
+    if (emit) {
+      if (x.nf & JGF_FAULT_MASK) jg_dense_outbox_none<R>(d, nd, g);  // the process died before its Tick
+      else jg_dense_leader_tick<R>(d, nd, g, seq, s, term, hbt, x);
+    }
     jg_dense_store<R>(d, g, s, f, chg, x, commit0, head0);
   }
   return dec;
@@ -256,8 +383,19 @@ template <int R>
 __global__ __launch_bounds__(JG_BLOCK) void k_leader_tick_dense(JgDev d, const uint64_t* __restrict__ acks,
                                                                  uint32_t seq, int us) {
   uint32_t dec;
-  if (us >= 0) dec = jg_dense_tick_body<R, true>(d, acks, seq, (uint32_t)us);
-  else dec = jg_dense_tick_body<R, false>(d, acks, seq, 0);
+  JgLeaderNode nd{};
+  if (us >= 0) dec = jg_dense_tick_body<R, true, false>(d, acks, seq, (uint32_t)us, nd);
+  else dec = jg_dense_tick_body<R, false, false>(d, acks, seq, 0, nd);
+  jg_block_count(d.blk_decisions, dec);
+}
+
+// jg_step_dense_leader: the same tick with HeartbeatResponses in and / or the Tick's outbox out
+template <int R>
+__global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDev d, const uint64_t* __restrict__ acks,
+                                                                uint32_t seq, int us, JgLeaderNode nd) {
+  uint32_t dec;
+  if (us >= 0) dec = jg_dense_tick_body<R, true, true>(d, acks, seq, (uint32_t)us, nd);
+  else dec = jg_dense_tick_body<R, false, true>(d, acks, seq, 0, nd);
   jg_block_count(d.blk_decisions, dec);
 }
 
@@ -278,12 +416,11 @@ __device__ __forceinline__ uint32_t jg_dense_ticks_body(const JgDev& d, const ui
     const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
     JgDenseRegs<R> x;
     jg_dense_load<R>(d, acks, g, s, x);
-    if (f & JGF_FAULT_MASK) continue;  // the reference process is gone
     const bool leader = (f & JGF_ROLE_MASK) == JG_ROLE_LEADER;
-    if (leader && !(f & JGF_FAST)) {  // irregular chain: k_dense_slow replays all ticks
-      *d.deferred_seen = 1;
-      continue;
-    }
+    const bool dead = (f & JGF_FAULT_MASK) != 0;                // the reference process is gone
+    const bool defer = !dead && leader && !(f & JGF_FAST);      // irregular chain: k_dense_slow replays all ticks
+    jg_defer_push(d, g, defer);
+    if (dead || defer) continue;
     const uint64_t commit0 = x.commit, head0 = x.head;
     x.ms = head0;
     if (leader && !(f & JGF_SELF_SYNC)) x.ms = d.match[(size_t)s * G + g];

@@ -12,9 +12,11 @@
 //  bits 0-1   role (JG_ROLE_*)                                   mod.rs:417-425
 //  bit  2     voted_for.is_some()                                mod.rs:279
 //  bit  3     Follower.leader_id.is_some()                       follower.rs:20
-//  bit  4     FAST chain: run_hi == head, id_gen == head+1, no extra segments
-//             -> the id set is exactly [0, head]; the id_gen / run_hi columns
-//             are then implicit (possibly stale in memory)
+//  bit  4     FAST chain: RUN (bit 7) and id_gen == head+1 -> the id_gen column is
+//             implicit too (possibly stale in memory); what leaders built by append have
+//  bit  7     RUN chain: run_hi == head and no extra segments -> the id set is exactly
+//             [0, head] with next(id) = id-1; the run_hi column is implicit.  What
+//             followers have (extend does not advance id_gen: chain.rs:178-192, Q8)
 //  bit  5     the "commit" key has been persisted               chain.rs:198
 //  bit  6     SELF-SYNC (leaders): the leader's own progress head equals the chain
 //             head (true after every self-ack, leader.rs:190-196) -> match[self] is
@@ -30,6 +32,7 @@
 #define JGF_FAST (1u << 4)
 #define JGF_COMMIT_KEY (1u << 5)
 #define JGF_SELF_SYNC (1u << 6)
+#define JGF_RUN (1u << 7)
 #define JGF_REPL_SHIFT 8
 #define JGF_REPL_MASK (0xffu << JGF_REPL_SHIFT)
 #define JGF_FAULT_SHIFT 16
@@ -38,6 +41,14 @@
 #define JGF_SELF_MASK (0x7u << JGF_SELF_SHIFT)
 #define JGF_WIN_SHIFT 28
 #define JGF_WIN_MASK (0xfu << JGF_WIN_SHIFT)
+
+// A message row outside the dense mailbox vocabulary, emitted by a dense node step: queued
+// with its step sequence number and emission index, ordered at drain time.
+struct JgXqRec {
+  jg_msg_row row;
+  uint32_t seq;
+  uint32_t k;
+};
 
 struct JgFaultRec {
   uint32_t group;
@@ -78,7 +89,12 @@ struct JgDev {
   uint32_t* deferred_seen;   // the dense fast path met a leader whose chain is not in FAST form
   uint32_t* slow_list;       // [JG_SHARDS][ceil(G/JG_SHARDS)] deferred groups per shard
   uint32_t* slow_cnt;        // [JG_SHARDS]
-  uint32_t* irregular_seen;  // set when a group is stored with a chain that is not in FAST form
+  uint32_t* irregular_seen;  // set when a leader is stored with a chain that is not in FAST form
+  JgXqRec* xq;               // exceptional message rows of dense node steps (lazily allocated)
+  uint32_t* xq_n;
+  uint32_t xq_cap;
+  uint32_t slow_cap;         // entries per shard of slow_list
+  uint32_t* err;             // device error word (status block)
 };
 
 // splitmix64 finaliser: the counter-based RNG of DESIGN.md "Logical time and randomness"
@@ -103,6 +119,11 @@ struct JgLane {
   jg_fsm_row* fp;
   jg_fsm_row* fend;
   uint32_t overflow;  // an output row did not fit its bound (engine bug guard)
+  uint32_t xq_on;     // 1: message rows go to the exceptional queue d.xq instead of [mp, mend);
+                      // 2: the same, but AppendResponse / HeartbeatResponse are captured below
+  uint32_t xq_k;      // emission index within this step
+  uint64_t cap_ack, cap_hbc;  // follower half of the dense node tick: outbox row of this group
+  uint32_t cap_has;
 };
 
 __device__ __forceinline__ uint32_t jg_role(const JgLane& L) { return L.flags & JGF_ROLE_MASK; }
@@ -135,13 +156,8 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
   L.term = d.term[g];
   L.commit = d.commit[g];
   L.head = d.head[g];
-  if (L.flags & JGF_FAST) {
-    L.id_gen = L.head + 1;
-    L.run_hi = L.head;
-  } else {
-    L.id_gen = d.id_gen[g];
-    L.run_hi = d.run_hi[g];
-  }
+  L.id_gen = (L.flags & JGF_FAST) ? L.head + 1 : d.id_gen[g];
+  L.run_hi = (L.flags & JGF_RUN) ? L.head : d.run_hi[g];
   L.election_time = d.election_time[g];
   L.heartbeat_time = d.heartbeat_time[g];
   L.voted_for = d.voted_for[g];
@@ -155,12 +171,17 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
     L.self_match = (L.flags & JGF_SELF_SYNC) ? L.head : d.match[(size_t)jg_self(L) * d.G + g];
   L.decisions = 0;
   L.overflow = 0;
+  L.xq_on = 0;
+  L.xq_k = 0;
 }
 __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   uint32_t g = L.g;
-  bool fast = (L.run_hi == L.head) && (L.id_gen == L.head + 1) && (jg_wcnt(L) == 0);
+  const bool run = (L.run_hi == L.head) && (jg_wcnt(L) == 0);
+  const bool fast = run && (L.id_gen == L.head + 1);
+  L.flags = run ? (L.flags | JGF_RUN) : (L.flags & ~JGF_RUN);
   L.flags = fast ? (L.flags | JGF_FAST) : (L.flags & ~JGF_FAST);
-  if (!fast) *d.irregular_seen = 1;  // the host then schedules k_dense_slow behind the dense kernel
+  // the host then schedules the slow kernel behind the dense leader kernel
+  if (!fast && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L)) *d.irregular_seen = 1;
   const bool sync = jg_role(L) == JG_ROLE_LEADER && L.self_match == L.head;
   L.flags = sync ? (L.flags | JGF_SELF_SYNC) : (L.flags & ~JGF_SELF_SYNC);
   if (jg_role(L) == JG_ROLE_LEADER && !sync) d.match[(size_t)jg_self(L) * d.G + g] = L.self_match;
@@ -183,9 +204,20 @@ __device__ inline void jg_store(const JgDev& d, JgLane& L) {
 // ---- output rows ------------------------------------------------------------------
 __device__ inline void jg_emit_msg(const JgDev& d, JgLane& L, uint8_t kind, uint8_t to_kind, uint32_t to_id,
                                    uint8_t flag, uint64_t term, uint64_t id, uint64_t aux) {
-  if (L.mp >= L.mend) {
+  if (!L.xq_on && L.mp >= L.mend) {
     L.overflow = 1;
     return;
+  }
+  if (L.xq_on == 2) {  // dense mailbox vocabulary of the follower half
+    if (kind == JG_CMD_APPEND_RESPONSE) {
+      L.cap_ack = id;
+      return;
+    }
+    if (kind == JG_CMD_HEARTBEAT_RESPONSE) {
+      L.cap_hbc = id;
+      L.cap_has = flag;
+      return;
+    }
   }
   jg_msg_row r;
   r.group = L.g;
@@ -198,6 +230,17 @@ __device__ inline void jg_emit_msg(const JgDev& d, JgLane& L, uint8_t kind, uint
   r.term = term;
   r.id = id;
   r.aux = aux;
+  if (L.xq_on) {
+    const uint32_t i = atomicAdd(d.xq_n, 1u);
+    if (i < d.xq_cap) {
+      JgXqRec q;
+      q.row = r;
+      q.seq = L.seq;
+      q.k = L.xq_k++;
+      d.xq[i] = q;
+    }
+    return;
+  }
   *L.mp++ = r;
 }
 __device__ inline void jg_emit_fsm(JgLane& L, uint8_t kind, uint64_t a, uint64_t b) {
@@ -575,7 +618,10 @@ __device__ inline uint32_t jg_follower_append_entries(const JgDev& d, JgLane& L,
     return JG_FAULT_FOLLOWER_STALE_LEADER;
   if (c.aux) {  // :157
     for (uint64_t k = 0; k < c.aux; k++) {
-      uint32_t f = jg_chain_extend(d, L, blk_id[c.id + k], blk_next[c.id + k]);  // :159
+      // no side arrays (dense mailbox): the blocks are ids c.id+1 .. c.id+aux, next = id-1 each
+      const uint64_t bid = blk_id ? blk_id[c.id + k] : c.id + 1 + k;
+      const uint64_t bnext = blk_id ? blk_next[c.id + k] : c.id + k;
+      uint32_t f = jg_chain_extend(d, L, bid, bnext);  // :159
       if (f) return f;
     }
     jg_emit_msg(d, L, JG_CMD_APPEND_RESPONSE, JG_TO_PEER, c.from, 1, L.term, L.head, 0);  // :163-172

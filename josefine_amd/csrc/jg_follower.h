@@ -1,0 +1,219 @@
+// jg_follower.h — follower half of the dense node tick (jg_step_dense_follower).
+//
+// Per group, in this order: Heartbeat (follower.rs:178-217), AppendEntries (follower.rs:130-176),
+// Tick (follower.rs:121-128) from one dense inbox row, answers into one dense outbox row.  The
+// HBM-bound kernel serves the steady-state case — a healthy follower whose chain is the run
+// [0, head] and that has no queued client requests — in registers:
+//
+//   Heartbeat      set_election_timeout (one draw of the counter RNG), term := hb.term, leader /
+//                  vote := sender, has_committed = commit <= head, commit advance, response row
+//   AppendEntries  term / vote adoption (follower.rs:137-144), the stale-leader assert (:147-154),
+//                  Chain::extend of ids from+1 .. from+n (each next = id-1): parent check once,
+//                  head := from + n (extend sets head = block.id unconditionally, chain.rs:190, so a
+//                  re-sent window can move it backwards: the run then splits and the group leaves
+//                  run form), ack row
+//   Tick           election timer; a follower that has voted never campaigns (follower.rs:249, Q4)
+//
+// Everything else (candidates, leaders with input, irregular chains, queued requests, a timer
+// that fires on a follower that has not voted) is deferred (jg_defer_push) to k_follower_slow,
+// which runs the general state machine and maps AppendResponse / HeartbeatResponse rows back to
+// the outbox columns; rows outside the mailbox vocabulary go to the exceptional queue.
+//
+// Bytes per follower-step at steady state: read 4 (flags) + 8+4+4 (term, voted_for, leader_id) +
+// 8+8 (head, commit) + 4 (queued) + 4+8+4 (rng_draws, election timer) + inbox 8+8+8+1 = 81;
+// write head 8 + outbox 8+8+1, on a heartbeat also commit 8 + timer 8+4+4: 25 / 49.
+#pragma once
+#include "jg_dense.h"
+
+struct JgFollowerArgs {
+  const uint32_t* leader;  // [G] or null
+  uint32_t leader_id;
+  const uint64_t* term;
+  const uint64_t* hb_commit;
+  const uint64_t* ae_from;
+  const uint8_t* ae_n;
+  uint64_t* o_ack;
+  uint64_t* o_hbc;
+  uint8_t* o_has;
+  uint64_t now;
+  uint32_t seq;
+  uint32_t tick;
+};
+
+__global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFollowerArgs a) {
+  const uint32_t G = d.G;
+  for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
+    // every load is independent of the others
+    const uint32_t f = d.flags[g];
+    const uint64_t in_term = a.term[g];
+    const uint64_t in_hbc = __builtin_nontemporal_load(&a.hb_commit[g]);
+    const uint64_t in_from = __builtin_nontemporal_load(&a.ae_from[g]);
+    const uint32_t in_n = a.ae_n[g];
+    const uint32_t lead = a.leader ? a.leader[g] : a.leader_id;
+    uint64_t term = d.term[g], head = d.head[g], commit = d.commit[g];
+    uint32_t voted_for = d.voted_for[g], leader_id = d.leader_id[g];
+    const uint32_t queued = d.queued[g];
+    // the election timer: a heartbeat redraws it (needs rng_draws), a Tick without one reads it
+    const uint32_t draws = d.rng_draws[g];
+    uint64_t et = d.election_time[g];
+    uint32_t eto = d.election_timeout[g];
+    const bool has_hb = in_hbc != JG_NO_ACK, has_ae = in_n != JG_AE_NONE;
+
+    const uint32_t role = f & JGF_ROLE_MASK;
+    const bool dead = (f & JGF_FAULT_MASK) != 0;
+    // leaders ignore Heartbeat (leader.rs:263) and are ticked by the leader half
+    const bool idle_leader = role == JG_ROLE_LEADER && !has_ae;
+    const bool nothing = !has_hb && !has_ae && !a.tick;
+    const bool fast = role == JG_ROLE_FOLLOWER && (f & JGF_RUN) && queued == 0;
+    const bool defer = !dead && !idle_leader && !nothing && !fast;
+    jg_defer_push(d, g, defer);
+    a.o_ack[g] = JG_NO_ACK;  // defaults; the slow kernel overwrites the rows of its groups
+    a.o_hbc[g] = 0;
+    a.o_has[g] = JG_HB_NONE;
+    if (dead || idle_leader || nothing || defer) continue;
+
+    uint32_t nf = f;
+    const uint64_t term0 = term, head0 = head, commit0 = commit;
+    const uint32_t vf0 = voted_for, lid0 = leader_id;
+    bool timer_dirty = false;
+    uint32_t fault = 0;
+
+    if (has_hb) {  // ---- follower.rs:178-217
+      // set_election_timeout (follower.rs:103-113): one draw, election_time = now
+      const uint32_t span = d.el_max - d.el_min;
+      const uint64_t r = jg_mix64(d.seed ^ jg_mix64((d.group_base + g) * 0xd1342543de82ef95ull + draws));
+      eto = d.el_min + (span ? (uint32_t)(r % span) : 0u);
+      et = a.now;
+      d.rng_draws[g] = draws + 1;
+      timer_dirty = true;
+      term = in_term;                     // :185, unconditional (Q6)
+      nf |= JGF_HAS_LEADER | JGF_VOTED;   // :186-187
+      leader_id = lead;
+      voted_for = lead;
+      const bool has = in_hbc <= head;    // :200, run form: the id set is [0, head]
+      if (has && in_hbc > commit) {       // :201-207
+        commit = in_hbc;
+        nf |= JGF_COMMIT_KEY;
+      }
+      a.o_hbc[g] = commit;                // :209-215
+      a.o_has[g] = has ? 1 : 0;
+    }
+    if (has_ae) {  // ---- follower.rs:130-176
+      if (!(nf & JGF_VOTED) && in_term >= term) {  // :137-144
+        term = in_term;                            // Raft::term clears voted_for and leader_id first
+        et = a.now;
+        timer_dirty = true;
+        nf |= JGF_HAS_LEADER | JGF_VOTED;
+        leader_id = lead;
+        voted_for = lead;
+      }
+      if ((nf & JGF_VOTED) && voted_for != lead && in_term < term) {  // :147-154
+        fault = JG_FAULT_FOLLOWER_STALE_LEADER;
+      } else if (in_n) {                                              // :157-172
+        if (in_from > head) {
+          fault = JG_FAULT_EXTEND_MISSING_PARENT;                     // chain.rs:180-185 on the first block
+        } else {
+          const uint64_t new_head = in_from + in_n;
+          const uint64_t run_hi = new_head > head ? new_head : head;  // ids <= head exist with the same parent
+          if (nf & JGF_FAST) {             // id_gen was implicit (head+1) and does not follow extend (Q8)
+            d.id_gen[g] = head + 1;
+            nf &= ~JGF_FAST;
+          }
+          head = new_head;                 // chain.rs:190, unconditionally the last block's id
+          if (head != run_hi) {            // moved backwards: [0, run_hi] stays stored, run form is lost
+            d.run_hi[g] = run_hi;
+            nf &= ~JGF_RUN;
+          }
+          a.o_ack[g] = head;               // follower.rs:163-172
+        }
+      }
+    }
+    bool tick_defer = false;
+    if (a.tick && !fault) {  // ---- follower.rs:121-128 -> 248-256
+      // a follower that has voted does nothing on Timeout (Q4); otherwise it becomes a candidate
+      tick_defer = (a.now - et) > (uint64_t)eto && !(nf & JGF_VOTED);
+    }
+    if (fault) {
+      nf |= fault << JGF_FAULT_SHIFT;
+      jg_push_fault(d, g, fault, a.seq);
+    }
+    if (term != term0) d.term[g] = term;
+    if (head != head0) d.head[g] = head;
+    if (commit != commit0) d.commit[g] = commit;
+    if (voted_for != vf0) d.voted_for[g] = voted_for;
+    if (leader_id != lid0) d.leader_id[g] = leader_id;
+    if (timer_dirty) {
+      d.election_time[g] = et;
+      d.election_timeout[g] = eto;
+    }
+    if (nf != f) d.flags[g] = nf;
+    // (divergent use of the wave-aggregated push is fine: the ballot covers the active lanes)
+    jg_defer_push(d, g, tick_defer, JG_DEFER_TICK_ONLY);
+  }
+}
+
+// The deferred groups through the general state machine.  AppendResponse / HeartbeatResponse
+// rows are captured into the outbox columns, everything else goes to the exceptional queue.
+__global__ __launch_bounds__(JG_BLOCK) void k_follower_slow(JgDev d, JgFollowerArgs a) {
+  uint32_t dec = 0;
+  const uint32_t n = d.slow_cnt[blockIdx.x] < d.slow_cap ? d.slow_cnt[blockIdx.x] : d.slow_cap;
+  const uint32_t* list = d.slow_list + (size_t)blockIdx.x * d.slow_cap;
+  for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) {
+    const uint32_t entry = list[i];
+    const uint32_t g = entry & ~JG_DEFER_TICK_ONLY;
+    const bool tick_only = (entry & JG_DEFER_TICK_ONLY) != 0;
+    JgLane L;
+    jg_load(d, L, g);
+    L.now = a.now;
+    L.seq = a.seq;
+    L.mp = L.mend = nullptr;
+    jg_fsm_row sink[2];
+    L.xq_on = 2;  // capture mode: mailbox rows -> L.cap_*, the rest -> exceptional queue
+    L.cap_ack = JG_NO_ACK;
+    L.cap_hbc = 0;
+    L.cap_has = JG_HB_NONE;
+    const uint32_t lead = a.leader ? a.leader[g] : a.leader_id;
+    JgCmd c;
+    c.from = lead;
+    c.flag = 0;
+    c.term = a.term[g];
+    c.aux = 0;
+    if (!tick_only) {
+      const uint64_t hbc = a.hb_commit[g];
+      const uint32_t n_blk = a.ae_n[g];
+      if (hbc != JG_NO_ACK) {
+        c.kind = JG_CMD_HEARTBEAT;
+        c.id = hbc;
+        L.fp = sink;
+        L.fend = sink + 2;
+        jg_apply(d, L, c, nullptr, nullptr);
+      }
+      if (n_blk != JG_AE_NONE) {
+        c.kind = JG_CMD_APPEND_ENTRIES;
+        c.id = a.ae_from[g];  // implicit blocks: ids id+1 .. id+aux, next = id-1 each
+        c.aux = n_blk;
+        L.fp = sink;
+        L.fend = sink + 2;
+        jg_apply(d, L, c, nullptr, nullptr);
+      }
+    }
+    if (a.tick && jg_role(L) != JG_ROLE_LEADER) {
+      c.kind = JG_CMD_TICK;
+      c.from = 0;
+      c.term = c.id = c.aux = 0;
+      L.fp = sink;
+      L.fend = sink + 2;
+      jg_apply(d, L, c, nullptr, nullptr);
+    }
+    if (!tick_only) {
+      a.o_ack[g] = L.cap_ack;
+      a.o_hbc[g] = L.cap_hbc;
+      a.o_has[g] = (uint8_t)L.cap_has;
+    }
+    dec += L.decisions;
+    jg_store(d, L);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) d.slow_cnt[blockIdx.x] = 0;
+  jg_block_count(d.blk_decisions, dec);
+}

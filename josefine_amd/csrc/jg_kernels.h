@@ -4,7 +4,9 @@
 //                           majority test and commit-index advance for steady-state
 //                           leaders over SoA columns (progress.rs:42-60,133-140;
 //                           leader.rs:87-99,177-197,211-219)
-//   k_dense_slow            same tick for groups whose chain is not in FAST form
+//   k_leader_node_tick<R>   the same with HeartbeatResponses in and the Tick's outbox out
+//   k_follower_tick_dense   Heartbeat + AppendEntries + Tick for followers over dense mailboxes
+//   k_dense_slow / k_follower_slow  the same ticks for deferred groups (general state machine)
 //   k_apply_rows            the full state machine over a group-sorted command batch
 //                           (every role, every Command; mod.rs:471-479)
 //   k_chain_compact         Chain::compact parent-pointer walk (chain.rs:239-253)
@@ -15,57 +17,50 @@
 
 #include "jg_dense.h"  // k_leader_tick_dense / _n, jg_block_count, JG_BLOCK
 
-// ---- groups the dense kernel deferred (healthy leaders whose chain is not in FAST form) ----
-// Two kernels, no contended global atomics: k_collect_deferred compacts the deferred
-// groups of each of JG_SHARDS contiguous group ranges into that shard's list (LDS counter);
-// k_dense_slow then replays the ticks for them with densely packed lanes, so its fault-queue
-// pushes coalesce per wave.  (Appending ~1 % of 1 M groups to one list from the dense kernel
-// cost it +65 us per tick: ~8 ns per contended wave-level atomic request; scanning the flag
-// column with one sparse lane per wave cost the slow kernel the same in fault pushes —
-// profiles/README.md.)
-#define JG_SHARDS 256
-__global__ __launch_bounds__(JG_BLOCK) void k_collect_deferred(JgDev d) {
-  __shared__ uint32_t n_s;
-  if (threadIdx.x == 0) n_s = 0;
-  __syncthreads();
-  const uint32_t cap = (d.G + JG_SHARDS - 1) / JG_SHARDS;
-  const uint32_t g0 = blockIdx.x * cap;
-  const uint32_t g1 = g0 + cap < d.G ? g0 + cap : d.G;
-  uint32_t* list = d.slow_list + (size_t)blockIdx.x * cap;
-  for (uint32_t g = g0 + threadIdx.x; g < g1; g += JG_BLOCK) {
-    const uint32_t f = d.flags[g];
-    if (!(f & JGF_FAULT_MASK) && (f & JGF_ROLE_MASK) == JG_ROLE_LEADER && !(f & JGF_FAST))
-      list[atomicAdd(&n_s, 1u)] = g;  // LDS atomic; order within a shard does not matter
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) d.slow_cnt[blockIdx.x] = n_s;
-}
-
-// Same ticks through the general state machine for the collected groups; workgroup s owns
-// shard s.
+// ---- groups the dense leader kernel deferred ----------------------------------------------------
+// Healthy leaders whose chain is not in FAST form, and (node tick) leaders that received a
+// HeartbeatResponse without the commit: the same tick(s) through the general state machine.
+// Workgroup s owns shard s of the deferred lists (jg_defer_push) and resets its counter for the
+// next launch.  Message rows outside the dense mailbox vocabulary go to the exceptional queue.
 __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
-                                                          size_t tick_stride, uint32_t seq0) {
+                                                          size_t tick_stride, uint32_t seq0, JgLeaderNode nd) {
   uint32_t dec = 0;
-  const uint32_t cap = (d.G + JG_SHARDS - 1) / JG_SHARDS;
-  const uint32_t n = d.slow_cnt[blockIdx.x];
-  const uint32_t* list = d.slow_list + (size_t)blockIdx.x * cap;
+  const uint32_t n = d.slow_cnt[blockIdx.x] < d.slow_cap ? d.slow_cnt[blockIdx.x] : d.slow_cap;
+  const uint32_t* list = d.slow_list + (size_t)blockIdx.x * d.slow_cap;
   for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) {
     const uint32_t g = list[i];
     JgLane L;
     jg_load(d, L, g);
-    L.now = 0;
-    L.mp = L.mend = nullptr;  // a leader's client requests / acks emit no messages
+    L.now = nd.now;
+    L.mp = L.mend = nullptr;
+    L.xq_on = d.xq != nullptr;  // plain jg_step_dense_acks: a leader's appends / acks emit no messages
     jg_fsm_row sink[2];
     const uint32_t s = jg_self(L);
-    for (uint32_t t = 0; t < n_ticks && !jg_fault(L); t++) {
+    JgCmd c;
+    c.from = 0;
+    c.flag = 0;
+    c.term = c.id = c.aux = 0;
+    if (nd.hbr_has) {  // 1. HeartbeatResponses, ascending slot (leader.rs:222-231)
+      L.seq = seq0;
+      c.kind = JG_CMD_HEARTBEAT_RESPONSE;
+      for (uint32_t r = 0; r < d.R && !jg_fault(L); r++) {
+        if (r == s) continue;
+        const uint8_t has = nd.hbr_has[(size_t)r * d.G + g];
+        if (has == JG_HB_NONE) continue;
+        c.from = d.node_ids[r];
+        c.flag = has;
+        c.id = has ? 0 : nd.hbr_commit[(size_t)r * d.G + g];
+        jg_apply(d, L, c, nullptr, nullptr);
+      }
+      c.from = 0;
+      c.id = 0;
+    }
+    for (uint32_t t = 0; acks && t < n_ticks && !jg_fault(L); t++) {  // 2. appends, then acks
       const uint64_t* A = acks + (size_t)t * tick_stride;
       L.seq = seq0 + t;
       uint64_t n_app = A[(size_t)s * d.G + L.g];
-      JgCmd c;
       c.kind = JG_CMD_CLIENT_REQUEST;
-      c.from = 0;
       c.flag = 0;
-      c.term = c.id = c.aux = 0;
       for (uint64_t k = 0; k < n_app && !jg_fault(L); k++) {
         L.fp = sink;
         L.fend = sink + 2;
@@ -84,9 +79,38 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
         jg_apply(d, L, c, nullptr, nullptr);
       }
     }
+    if (nd.o_term && !jg_fault(L)) {  // 3. Command::Tick (leader.rs:234-245)
+      L.seq = seq0;
+      c.kind = JG_CMD_TICK;
+      c.from = 0;
+      c.flag = 0;
+      c.id = 0;
+      const bool fast = L.run_hi == L.head && L.id_gen == L.head + 1 && jg_wcnt(L) == 0;
+      if (!fast) {
+        jg_apply(d, L, c, nullptr, nullptr);  // rows: the blocks are not id-consecutive
+      } else {                                // columns, via a local row buffer
+        jg_msg_row loc[JG_MAX_REPLICAS + 1];
+        L.xq_on = 0;
+        L.mp = loc;
+        L.mend = loc + JG_MAX_REPLICAS + 1;
+        jg_apply(d, L, c, nullptr, nullptr);
+        nd.o_term[g] = L.term;
+        for (jg_msg_row* m = loc; m < L.mp; m++) {
+          if (m->kind == JG_CMD_HEARTBEAT) {
+            nd.o_hb[g] = m->id;
+          } else {  // AppendEntries to one peer
+            const int r = jg_slot_of(d, m->to_id);
+            nd.o_from[(size_t)r * d.G + g] = m->id;
+            nd.o_n[(size_t)r * d.G + g] = (uint8_t)m->aux;
+          }
+        }
+      }
+    }
     dec += L.decisions;
     jg_store(d, L);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) d.slow_cnt[blockIdx.x] = 0;
   jg_block_count(d.blk_decisions, dec);
 }
 
@@ -173,6 +197,8 @@ __global__ void k_init_groups(JgDev d, const uint8_t* __restrict__ self_slots) {
     L.mp = L.mend = nullptr;
     L.fp = L.fend = nullptr;
     L.overflow = 0;
+    L.xq_on = 0;
+    L.xq_k = 0;
     L.decisions = 0;
     L.term = 0;
     L.self_match = 0;

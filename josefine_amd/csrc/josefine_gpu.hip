@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "jg_kernels.h"
+#include "jg_follower.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -34,6 +35,7 @@ namespace {
 // One sparse step whose output rows have not been drained yet.
 struct StepRec {
   uint32_t n = 0;  // command rows
+  uint32_t seq = 0;
   uint32_t msg_per_row = 0, fsm_per_row = 0;
   uint32_t *d_msg_cnt = nullptr, *d_fsm_cnt = nullptr;
   uint64_t *d_bsum_m = nullptr, *d_bsum_f = nullptr;  // tile sums -> exclusive prefixes at drain
@@ -115,7 +117,7 @@ struct jg_engine {
   uint32_t count_slots = 0;  // workgroup slots of dev.blk_decisions
   uint32_t dense_grid = 0;
   int uniform_self = 0;  // the own replica slot if it is the same for every group, else -1
-  // device status block {err, irregular_seen, deferred_seen, fault_q_n}: read back with one
+  // device status block {err, irregular_seen, deferred_seen, fault_q_n, xq_n}: read back with one
   // copy into its pinned mirror at every synchronisation point
   uint32_t* d_status = nullptr;
   uint32_t* h_status = nullptr;
@@ -135,6 +137,8 @@ struct jg_engine {
   PinnedQueue<jg_fsm_row> q_fsm;
   std::vector<jg_fault_row> q_faults;
   std::vector<JgFaultRec> fault_tmp;
+  std::vector<JgXqRec> xq_tmp;
+  size_t last_add_m = 0;
   JgScanJob* h_jobs = nullptr;  // pinned: drain-time scan jobs and their totals
   uint64_t* h_totals = nullptr;
   size_t scan_cap = 0;
@@ -180,9 +184,12 @@ inline uint32_t msg_bound(uint32_t R) { return R + 1 < 2 ? 2 : R + 1; }
 inline uint32_t fsm_bound() { return 2; }
 
 template <int R>
-void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks) {
+void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks, const JgLeaderNode* nd) {
   const size_t stride = (size_t)e->cfg.n_groups * e->cfg.n_replicas;
-  if (n_ticks > 1)  // temporal fusion: state read once, written once per launch
+  if (nd)  // node tick: HeartbeatResponses in, the Tick's outbox out
+    hipLaunchKernelGGL(k_leader_node_tick<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
+                       e->seq, e->uniform_self, *nd);
+  else if (n_ticks > 1)  // temporal fusion: state read once, written once per launch
     hipLaunchKernelGGL(k_leader_tick_dense_n<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
                        n_ticks, stride, e->seq, e->uniform_self);
   else
@@ -190,26 +197,27 @@ void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks) {
                        e->seq, e->uniform_self);
 }
 
-int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1) {
+int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1, const JgLeaderNode* nd = nullptr) {
   e->stepped = true;
   e->seq++;  // tick t of this launch carries sequence number seq + t
   switch (e->cfg.n_replicas) {
-    case 1: launch_dense<1>(e, acks_dev, n_ticks); break;
-    case 2: launch_dense<2>(e, acks_dev, n_ticks); break;
-    case 3: launch_dense<3>(e, acks_dev, n_ticks); break;
-    case 4: launch_dense<4>(e, acks_dev, n_ticks); break;
-    case 5: launch_dense<5>(e, acks_dev, n_ticks); break;
-    case 6: launch_dense<6>(e, acks_dev, n_ticks); break;
-    case 7: launch_dense<7>(e, acks_dev, n_ticks); break;
-    default: launch_dense<8>(e, acks_dev, n_ticks); break;
+    case 1: launch_dense<1>(e, acks_dev, n_ticks, nd); break;
+    case 2: launch_dense<2>(e, acks_dev, n_ticks, nd); break;
+    case 3: launch_dense<3>(e, acks_dev, n_ticks, nd); break;
+    case 4: launch_dense<4>(e, acks_dev, n_ticks, nd); break;
+    case 5: launch_dense<5>(e, acks_dev, n_ticks, nd); break;
+    case 6: launch_dense<6>(e, acks_dev, n_ticks, nd); break;
+    case 7: launch_dense<7>(e, acks_dev, n_ticks, nd); break;
+    default: launch_dense<8>(e, acks_dev, n_ticks, nd); break;
   }
   e->n_launch++;
-  if (e->maybe_irregular) {
+  // the slow kernel behind it: when a sparse step may have left a leader with an irregular
+  // chain, and whenever HeartbeatResponses come in (a response without the commit defers)
+  if (e->maybe_irregular || (nd && nd->hbr_has)) {
     e->slow_scheduled_ever = true;
-    hipLaunchKernelGGL(k_collect_deferred, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream, e->dev);
-    e->n_launch++;
-    hipLaunchKernelGGL(k_dense_slow, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream,
-                       e->dev, acks_dev, n_ticks, (size_t)e->cfg.n_groups * e->cfg.n_replicas, e->seq);
+    JgLeaderNode none{};
+    hipLaunchKernelGGL(k_dense_slow, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream, e->dev, acks_dev, n_ticks,
+                       (size_t)e->cfg.n_groups * e->cfg.n_replicas, e->seq, nd ? *nd : none);
     e->n_launch++;
   }
   HIPCHK(hipGetLastError());
@@ -218,17 +226,34 @@ int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1) {
   return JG_OK;
 }
 
+// The exceptional-message queue of the dense node steps, allocated at their first use:
+// (R + 3) rows per group bound what one tick can emit outside the mailbox vocabulary.
+int ensure_xq(jg_engine* e) {
+  if (e->dev.xq) return JG_OK;
+  const size_t cap = std::max<size_t>((size_t)(e->cfg.n_replicas + 3) * e->cfg.n_groups, 65536);
+  if (cap > 0xffffffffull) return fail(JG_EINVAL, "too many groups for the dense node tick");
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, cap * sizeof(JgXqRec)));
+  e->allocs.push_back(p);
+  e->dev.xq = (JgXqRec*)p;
+  e->dev.xq_cap = (uint32_t)cap;
+  return JG_OK;
+}
+
 // Everything that needs the stream idle first calls this: synchronise, surface
 // device-side error flags, and settle the lazily-read irregular-chain flag.
 int sync_and_check(jg_engine* e) {
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->stage_busy = false;
   const uint32_t err = e->h_status[0], irregular = e->h_status[1], deferred = e->h_status[2];
   if (err == 1) return fail(JG_EDEVICE, "internal: an output row exceeded its per-command bound");
   if (err == 2) return fail(JG_EINVAL, "device command rows were not sorted by group");
   if (err == 3) return fail(JG_EINVAL, "device command rows name a group out of range");
+  if (err == 4) return fail(JG_EDEVICE, "internal: deferred-group list overflow");
+  if (e->h_status[4] > e->dev.xq_cap)
+    return fail(JG_ECAPACITY, "exceptional-message queue overflow: drain the messages more often");
   if (e->flag_check_pending) {
     e->maybe_irregular = irregular != 0;  // sticky on the device: once seen, the slow kernel stays scheduled
     e->flag_check_pending = false;
@@ -305,6 +330,14 @@ int collect(jg_engine* e) {
       HIPCHK(hipMemcpyAsync(e->q_fsm.p + at_f, d_all_f, add_f * sizeof(jg_fsm_row), hipMemcpyDeviceToHost, e->stream));
     e->q_msgs.n = at_m + add_m;
     e->q_fsm.n = at_f + add_f;
+    e->last_add_m = add_m;
+  }
+  // exceptional rows of dense node steps (the count came with the status block)
+  const uint32_t nx = e->h_status[4];
+  if (nx) {
+    e->xq_tmp.resize(nx);
+    HIPCHK(hipMemcpyAsync(e->xq_tmp.data(), e->dev.xq, (size_t)nx * sizeof(JgXqRec), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemsetAsync(e->dev.xq_n, 0, sizeof(uint32_t), e->stream));
   }
   // faults (the count came with the status block)
   const uint32_t nf = e->h_status[3];
@@ -315,7 +348,31 @@ int collect(jg_engine* e) {
                           e->stream));
     HIPCHK(hipMemsetAsync(e->dev.fault_q_n, 0, sizeof(uint32_t), e->stream));
   }
-  if (nrec || nf) HIPCHK(hipStreamSynchronize(e->stream));
+  if (nrec || nf || nx) HIPCHK(hipStreamSynchronize(e->stream));
+  if (nx) {
+    // Merge by step sequence number: the rows of sparse step k (already in the queue, step
+    // order) carry rec.seq; exceptional rows carry the seq of their dense step.  Rare path.
+    std::vector<JgXqRec>& xr = e->xq_tmp;
+    std::sort(xr.begin(), xr.end(), [](const JgXqRec& a, const JgXqRec& b) {
+      if (a.seq != b.seq) return a.seq < b.seq;
+      if (a.row.group != b.row.group) return a.row.group < b.row.group;
+      return a.k < b.k;
+    });
+    const size_t old_n = e->q_msgs.n - (nrec ? e->last_add_m : 0);  // rows queued before this collect
+    std::vector<jg_msg_row> merged;
+    merged.reserve(e->q_msgs.n - old_n + nx);
+    size_t xi = 0, off = old_n;
+    for (size_t k = 0; k < nrec; k++) {
+      while (xi < nx && xr[xi].seq < e->recs[k].seq) merged.push_back(xr[xi++].row);
+      const size_t cnt = e->h_totals[2 * k];
+      merged.insert(merged.end(), e->q_msgs.p + off, e->q_msgs.p + off + cnt);
+      off += cnt;
+    }
+    while (xi < nx) merged.push_back(xr[xi++].row);
+    HIPCHK(e->q_msgs.reserve(old_n + merged.size()));
+    if (!merged.empty()) std::memcpy(e->q_msgs.p + old_n, merged.data(), merged.size() * sizeof(jg_msg_row));
+    e->q_msgs.n = old_n + merged.size();
+  }
   if (nrec) {
     e->recs.clear();
     e->arena.reset();
@@ -416,6 +473,7 @@ int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* 
   a.err = e->d_err;
   a.now = now_ms;
   a.seq = e->seq;
+  rec.seq = e->seq;
   hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(n, e->count_slots)), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
   hipLaunchKernelGGL(k_count_block_sums, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, rec.d_msg_cnt, rec.d_fsm_cnt, n,
                      rec.d_bsum_m, rec.d_bsum_f);
@@ -505,14 +563,20 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.blk_decisions, e->count_slots);
   d.fault_q_cap = (uint32_t)std::max<size_t>(2 * G, 1024);
   A(d.fault_q, d.fault_q_cap);
-  A(e->d_status, 4);
+  A(e->d_status, 8);
   e->d_err = e->d_status;
+  d.err = e->d_status;
   d.irregular_seen = e->d_status + 1;
   d.deferred_seen = e->d_status + 2;
   d.fault_q_n = e->d_status + 3;
-  if (hipHostMalloc((void**)&e->h_status, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+  d.xq_n = e->d_status + 4;
+  if (hipHostMalloc((void**)&e->h_status, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
     return bail(fail(JG_EDEVICE, "hipHostMalloc failed"));
-  A(d.slow_list, G + JG_SHARDS);
+  {  // deferred lists: shard = workgroup & (JG_SHARDS-1); generous per-shard capacity, bounds-checked
+    const size_t n_wg = (G + JG_BLOCK - 1) / JG_BLOCK;
+    d.slow_cap = (uint32_t)((3 * ((n_wg + JG_SHARDS - 1) / JG_SHARDS) + 2) * JG_BLOCK);
+  }
+  A(d.slow_list, (size_t)JG_SHARDS * d.slow_cap);
   A(d.slow_cnt, JG_SHARDS);
 #undef A
   hipLaunchKernelGGL(k_init_groups, dim3(grid_for(G, 2048)), dim3(JG_BLOCK), 0, e->stream, e->dev,
@@ -709,6 +773,69 @@ int jg_step_dense_acks(jg_engine* e, const uint64_t* acks_host) {
   int rc = dense_step(e, e->d_acks_staging);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));  // the host buffer is only borrowed for the call
+  return JG_OK;
+}
+
+int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* in, const jg_leader_outbox* out) {
+  if (!e) return fail(JG_EINVAL, "null argument");
+  if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
+  if (out && (!out->term || !out->hb_commit || !out->ae_from || !out->ae_n))
+    return fail(JG_EINVAL, "every outbox column is required");
+  if (in && in->hbr_has && !in->hbr_commit) return fail(JG_EINVAL, "hbr_has needs hbr_commit");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = ensure_xq(e);
+  if (rc) return rc;
+  JgLeaderNode nd{};
+  nd.hbr_has = in ? in->hbr_has : nullptr;
+  nd.hbr_commit = in ? in->hbr_commit : nullptr;
+  if (out) {
+    nd.o_term = out->term;
+    nd.o_hb = out->hb_commit;
+    nd.o_from = out->ae_from;
+    nd.o_n = out->ae_n;
+  }
+  nd.now = now_ms;
+  const uint64_t* acks = in ? in->acks : nullptr;
+  if (!acks && !nd.hbr_has && !out) return JG_OK;  // nothing to apply
+  return dense_step(e, acks, 1, &nd);
+}
+
+int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in, const jg_follower_outbox* out,
+                           int tick) {
+  if (!e || !in || !out) return fail(JG_EINVAL, "null argument");
+  if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
+  if (!in->term || !in->hb_commit || !in->ae_from || !in->ae_n) return fail(JG_EINVAL, "every inbox column is required");
+  if (!out->ack_head || !out->hb_commit || !out->hb_has) return fail(JG_EINVAL, "every outbox column is required");
+  if (!in->leader && !in->leader_id) return fail(JG_EINVAL, "id cannot be 0");  // config.rs:64-66
+  HIPCHK(hipSetDevice(e->device));
+  int rc = ensure_xq(e);
+  if (rc) return rc;
+  e->stepped = true;
+  e->seq++;
+  JgFollowerArgs a{};
+  a.leader = in->leader;
+  a.leader_id = in->leader_id;
+  a.term = in->term;
+  a.hb_commit = in->hb_commit;
+  a.ae_from = in->ae_from;
+  a.ae_n = in->ae_n;
+  a.o_ack = out->ack_head;
+  a.o_hbc = out->hb_commit;
+  a.o_has = out->hb_has;
+  a.now = now_ms;
+  a.seq = e->seq;
+  a.tick = tick ? 1 : 0;
+  hipLaunchKernelGGL(k_follower_tick_dense, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
+  // always scheduled: which groups need the general state machine is only known on the device
+  // (empty lists cost a few microseconds)
+  e->slow_scheduled_ever = true;
+  hipLaunchKernelGGL(k_follower_slow, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
+  HIPCHK(hipGetLastError());
+  e->n_launch += 2;
+  e->n_dense += e->cfg.n_groups;
+  // a deferred follower may have become a candidate / changed its chain: like a sparse step
+  e->maybe_irregular = true;
+  e->flag_check_pending = true;
   return JG_OK;
 }
 

@@ -288,6 +288,98 @@ class BatchedRaft:
         finally:
             self.api.device_free(self._h, buf)
 
+    # -- dense node tick (host-array convenience over the device-pointer ABI) ---------------
+    def _is_device(self) -> bool:
+        return hasattr(self.api, "device_alloc")
+
+    def _to_engine(self, arr: Optional[np.ndarray], keep: list):
+        """Host array -> pointer the engine accepts (device copy for the HIP engine)."""
+        if arr is None:
+            return None
+        a = np.ascontiguousarray(arr)
+        if not self._is_device():
+            keep.append(a)
+            return a.ctypes.data
+        p = C.c_void_p()
+        self._check(self.api.device_alloc(self._h, max(a.nbytes, 16), C.byref(p)))
+        self._check(self.api.device_upload(self._h, p, a.ctypes.data, a.nbytes))
+        keep.append(p)
+        return p.value
+
+    def _out_buffer(self, shape, dtype, keep: list):
+        host = np.zeros(shape, dtype=dtype)
+        if not self._is_device():
+            keep.append(host)
+            return host, host.ctypes.data
+        p = C.c_void_p()
+        self._check(self.api.device_alloc(self._h, max(host.nbytes, 16), C.byref(p)))
+        keep.append(p)
+        return host, p.value
+
+    def _finish(self, outs, keep) -> None:
+        if self._is_device():
+            for host, ptr in outs:
+                self._check(self.api.device_download(self._h, host.ctypes.data, C.c_void_p(ptr), host.nbytes))
+            for k in keep:
+                if isinstance(k, C.c_void_p):
+                    self.api.device_free(self._h, k)
+
+    def step_dense_leader(self, now_ms: int = 0, acks: Optional[np.ndarray] = None,
+                          hbr_has: Optional[np.ndarray] = None, hbr_commit: Optional[np.ndarray] = None,
+                          tick: bool = True) -> Optional[dict]:
+        """Leader half of a node tick (jg_step_dense_leader) over host arrays; returns the Tick's
+        outbox columns {term, hb_commit, ae_from, ae_n} or None when `tick` is false."""
+        assert not self._pending
+        keep: list = []
+        inbox = capi.LeaderInbox()
+        inbox.acks = self._to_engine(None if acks is None else np.asarray(acks, np.uint64).reshape(self.R, self.G), keep)
+        inbox.hbr_has = self._to_engine(None if hbr_has is None else np.asarray(hbr_has, np.uint8).reshape(self.R, self.G), keep)
+        inbox.hbr_commit = self._to_engine(
+            None if hbr_commit is None else np.asarray(hbr_commit, np.uint64).reshape(self.R, self.G), keep)
+        outs, res = [], None
+        outbox_p = None
+        if tick:
+            outbox = capi.LeaderOutbox()
+            res = {}
+            for name, shape, dt in (("term", (self.G,), np.uint64), ("hb_commit", (self.G,), np.uint64),
+                                    ("ae_from", (self.R, self.G), np.uint64), ("ae_n", (self.R, self.G), np.uint8)):
+                host, ptr = self._out_buffer(shape, dt, keep)
+                setattr(outbox, name, ptr)
+                res[name] = host
+                outs.append((host, ptr))
+            outbox_p = C.byref(outbox)
+        try:
+            self._check(self.api.step_dense_leader(self._h, now_ms, C.byref(inbox), outbox_p))
+        finally:
+            self._finish(outs, keep)
+        return res
+
+    def step_dense_follower(self, now_ms: int, term, hb_commit, ae_from, ae_n, leader=None, leader_id: int = 0,
+                            tick: bool = True) -> dict:
+        """Follower half of a node tick (jg_step_dense_follower) over host arrays; returns the
+        outbox columns {ack_head, hb_commit, hb_has}."""
+        assert not self._pending
+        keep: list = []
+        inbox = capi.FollowerInbox()
+        inbox.leader = self._to_engine(None if leader is None else np.asarray(leader, np.uint32), keep)
+        inbox.leader_id = int(leader_id)
+        inbox.term = self._to_engine(np.asarray(term, np.uint64), keep)
+        inbox.hb_commit = self._to_engine(np.asarray(hb_commit, np.uint64), keep)
+        inbox.ae_from = self._to_engine(np.asarray(ae_from, np.uint64), keep)
+        inbox.ae_n = self._to_engine(np.asarray(ae_n, np.uint8), keep)
+        outbox = capi.FollowerOutbox()
+        outs, res = [], {}
+        for name, dt in (("ack_head", np.uint64), ("hb_commit", np.uint64), ("hb_has", np.uint8)):
+            host, ptr = self._out_buffer((self.G,), dt, keep)
+            setattr(outbox, name, ptr)
+            res[name] = host
+            outs.append((host, ptr))
+        try:
+            self._check(self.api.step_dense_follower(self._h, now_ms, C.byref(inbox), C.byref(outbox), 1 if tick else 0))
+        finally:
+            self._finish(outs, keep)
+        return res
+
     # -- output --------------------------------------------------------------
     def _drain(self, fn, dtype) -> np.ndarray:
         n = C.c_size_t(0)

@@ -229,6 +229,182 @@ int jo_step_dense_acks(jo_engine* e, const uint64_t* acks) {
   return JG_OK;
 }
 
+// ---- dense node tick (include/josefine_gpu.h "dense node tick") ---------------------------------
+// The specification restated over host arrays: apply the commands the mailbox rows stand for,
+// one by one, through Raft::apply, and sort what the group emits into mailbox columns or rows.
+static int slot_of_id(const jo_engine* e, NodeId id) {
+  for (uint32_t q = 0; q < e->cfg.n_replicas; q++)
+    if (e->cfg.node_ids[q] == id) return (int)q;
+  return -1;
+}
+static void push_row(jo_engine* e, uint32_t g, const Msg& m) {
+  jg_msg_row row;
+  std::memset(&row, 0, sizeof row);
+  row.group = g;
+  row.kind = m.kind;
+  row.to_kind = m.to_kind;
+  row.flag = m.flag;
+  row.to_id = m.to_id;
+  row.from = m.from;
+  row.term = m.term;
+  row.id = m.id;
+  row.aux = m.aux;
+  e->msgs.push_back(row);
+}
+static void note_fault(jo_engine* e, uint32_t g, int before) {
+  Raft& r = e->groups[g];
+  if (r.fault && r.fault != before) e->faults.push_back(jg_fault_row{g, (uint32_t)r.fault});
+}
+
+int jo_step_dense_leader(jo_engine* e, uint64_t now_ms, const jg_leader_inbox* in, const jg_leader_outbox* out) {
+  e->stepped = true;
+  const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  const uint64_t* acks = in ? in->acks : nullptr;
+  if (!acks && !(in && in->hbr_has) && !out) return JG_OK;
+  for (uint32_t g = 0; g < G; g++) {
+    Raft& r = e->groups[g];
+    const uint32_t s = e->self_slot[g];
+    if (out) {  // defaults: "none"
+      out->term[g] = 0;
+      out->hb_commit[g] = JG_NO_ACK;
+      for (uint32_t q = 0; q < R; q++) {
+        out->ae_from[(size_t)q * G + g] = 0;
+        out->ae_n[(size_t)q * G + g] = JG_AE_NONE;
+      }
+    }
+    if (r.fault) continue;
+    const int fault0 = r.fault;
+    const uint64_t n_append = acks ? acks[(size_t)s * G + g] : 0;
+    if (r.role != JG_ROLE_LEADER) {  // acks / responses are ignored (follower.rs:62, candidate.rs:194)
+      if (n_append) r.fault = JG_FAULT_ENGINE_DENSE_NONLEADER;
+      note_fault(e, g, fault0);
+      continue;
+    }
+    Cmd c;
+    // 1. HeartbeatResponses, ascending slot: extra AppendEntries are rows
+    if (in && in->hbr_has) {
+      c.kind = JG_CMD_HEARTBEAT_RESPONSE;
+      for (uint32_t q = 0; q < R && !r.fault; q++) {
+        if (q == s) continue;
+        const uint8_t has = in->hbr_has[(size_t)q * G + g];
+        if (has == JG_HB_NONE) continue;
+        c.from = e->cfg.node_ids[q];
+        c.flag = has;
+        c.id = has ? 0 : in->hbr_commit[(size_t)q * G + g];
+        r.apply(c, now_ms);
+        e->counters[0]++;
+      }
+      for (const Msg& m : r.rpc) push_row(e, g, m);
+      r.rpc.clear();
+    }
+    // 2. appends, then acks in ascending slot order
+    c = Cmd();
+    c.kind = JG_CMD_CLIENT_REQUEST;
+    for (uint64_t i = 0; i < n_append && !r.fault; i++) {
+      r.apply(c, now_ms);
+      e->counters[0]++;
+    }
+    c.kind = JG_CMD_APPEND_RESPONSE;
+    c.flag = 1;
+    for (uint32_t q = 0; acks && q < R && !r.fault; q++) {
+      if (q == s) continue;
+      const uint64_t h = acks[(size_t)q * G + g];
+      if (h == JG_NO_ACK) continue;
+      c.from = e->cfg.node_ids[q];
+      c.id = h;
+      r.apply(c, now_ms);
+      e->counters[0]++;
+    }
+    r.rpc.clear();
+    r.fsm.clear();  // dense steps report deltas, not rows
+    // 3. Tick: columns if the chain is in run form built by append only, rows otherwise
+    if (out && !r.fault) {
+      const bool columns = r.chain.run_form_by_append();
+      c = Cmd();
+      c.kind = JG_CMD_TICK;
+      r.apply(c, now_ms);
+      e->counters[0]++;
+      if (columns) {
+        out->term[g] = r.current_term;
+        for (const Msg& m : r.rpc) {
+          if (m.kind == JG_CMD_HEARTBEAT) {
+            out->hb_commit[g] = m.id;
+          } else {
+            const int q = slot_of_id(e, m.to_id);
+            out->ae_from[(size_t)q * G + g] = m.id;
+            out->ae_n[(size_t)q * G + g] = (uint8_t)m.aux;
+          }
+        }
+      } else {
+        for (const Msg& m : r.rpc) push_row(e, g, m);
+      }
+      r.rpc.clear();
+    }
+    note_fault(e, g, fault0);
+    e->counters[1] += r.decisions;
+    r.decisions = 0;
+  }
+  e->counters[2] += G;
+  return JG_OK;
+}
+
+int jo_step_dense_follower(jo_engine* e, uint64_t now_ms, const jg_follower_inbox* in, const jg_follower_outbox* out,
+                           int tick) {
+  e->stepped = true;
+  const uint32_t G = e->cfg.n_groups;
+  for (uint32_t g = 0; g < G; g++) {
+    Raft& r = e->groups[g];
+    out->ack_head[g] = JG_NO_ACK;
+    out->hb_commit[g] = 0;
+    out->hb_has[g] = JG_HB_NONE;
+    if (r.fault) continue;
+    const int fault0 = r.fault;
+    const NodeId lead = in->leader ? in->leader[g] : in->leader_id;
+    Cmd c;
+    if (in->hb_commit[g] != JG_NO_ACK) {
+      c.kind = JG_CMD_HEARTBEAT;
+      c.from = lead;
+      c.term = in->term[g];
+      c.id = in->hb_commit[g];
+      r.apply(c, now_ms);
+      e->counters[0]++;
+    }
+    if (in->ae_n[g] != JG_AE_NONE) {
+      c = Cmd();
+      c.kind = JG_CMD_APPEND_ENTRIES;
+      c.from = lead;
+      c.term = in->term[g];
+      for (uint32_t k = 0; k < in->ae_n[g]; k++)
+        c.blocks.push_back(Block{in->ae_from[g] + 1 + k, in->ae_from[g] + k});
+      r.apply(c, now_ms);
+      e->counters[0]++;
+    }
+    if (tick && r.role != JG_ROLE_LEADER) {
+      c = Cmd();
+      c.kind = JG_CMD_TICK;
+      r.apply(c, now_ms);
+      e->counters[0]++;
+    }
+    for (const Msg& m : r.rpc) {
+      if (m.kind == JG_CMD_APPEND_RESPONSE) {
+        out->ack_head[g] = m.id;
+      } else if (m.kind == JG_CMD_HEARTBEAT_RESPONSE) {
+        out->hb_commit[g] = m.id;
+        out->hb_has[g] = m.flag;
+      } else {
+        push_row(e, g, m);
+      }
+    }
+    r.rpc.clear();
+    r.fsm.clear();
+    note_fault(e, g, fault0);
+    e->counters[1] += r.decisions;
+    r.decisions = 0;
+  }
+  e->counters[2] += G;
+  return JG_OK;
+}
+
 int jo_chain_compact(jo_engine*, size_t n_trees, const uint64_t* off, const uint64_t* ids, const uint64_t* nexts,
                      const uint64_t* commits, uint8_t* removed) {
   for (size_t t = 0; t < n_trees; t++) {

@@ -161,6 +161,16 @@ struct Chain {
   size_t blocks_from(BlockId from) const {
     return (size_t)std::distance(db.lower_bound(from), db.end());
   }
+  // "Run form built by append only" (include/josefine_gpu.h, dense mailbox vocabulary): the id
+  // set is exactly [0, head], every block's parent is id-1 and id_gen == head+1 — then the
+  // blocks after any key are id-consecutive and an AppendEntries fits the (from, n) columns.
+  // O(#blocks): test infrastructure.
+  bool run_form_by_append() const {
+    if (id_gen != head + 1 || db.size() != head + 1) return false;
+    for (auto& kv : db)
+      if (kv.second.next != (kv.first ? kv.first - 1 : 0)) return false;
+    return !db.empty() && db.rbegin()->first == head;
+  }
 };
 
 // ---------------------------------------------------------------------------

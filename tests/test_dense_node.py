@@ -1,0 +1,245 @@
+"""Dense node tick (jg_step_dense_leader / jg_step_dense_follower): the HIP engine against the
+CPU oracle — outbox columns, every state column and every drained row, bit for bit — plus
+the closed-loop cluster in which engines exchange nothing but mailbox columns."""
+import numpy as np
+import pytest
+
+from josefine_amd import BatchedRaft, Command, capi
+from oracle_lib import oracle_engine
+from parity import compare_drains, compare_snapshots, elect_all
+from dense_node import DenseCluster, random_follower_inbox, random_leader_inbox
+
+NO = capi.NO_ACK
+
+
+def _cmp_cols(a: dict, b: dict, what: str):
+    for k in a:
+        if not np.array_equal(a[k], b[k]):
+            bad = np.argwhere(a[k] != b[k])[:6]
+            raise AssertionError(f"{what}: outbox column {k} differs at {bad.tolist()}: "
+                                 f"hip={[a[k][tuple(i)] for i in bad]} oracle={[b[k][tuple(i)] for i in bad]}")
+
+
+# ---- oracle-only sanity (runs without a GPU): pins the mailbox specification itself ------------
+def test_oracle_closed_loop_commits():
+    """Steady state through real protocol rounds: 1 append per tick, every follower acks what
+    the leader replicated — the commit index follows the head."""
+    G, R, T = 64, 3, 40
+    cl = DenseCluster(oracle_engine, G, R)
+    for t in range(T):
+        cl.round(np.ones(G, np.uint64))
+    lead = cl.nodes[0]
+    assert (lead.read("head") == T).all()
+    commit = lead.read("commit")
+    assert (commit >= T - 4).all() and (commit <= T).all()
+    for r in (1, 2):
+        f = cl.nodes[r]
+        assert (f.read("role") == capi.ROLE_FOLLOWER).all() and (f.read("fault") == 0).all()
+        assert (f.read("head") >= T - 2).all()
+        assert (f.read("commit") >= T - 8).all()
+        assert (f.read("voted_for") == 1).all() and (f.read("term") == 1).all()
+    # nothing left the mailbox vocabulary
+    assert all(len(rows) == 0 for per_round in cl.rows for rows in per_round)
+
+
+def test_oracle_dense_follower_equals_commands():
+    """The follower half is sugar for Heartbeat / AppendEntries / Tick commands."""
+    G, R = 256, 3
+    a, b = oracle_engine(G, R, seed=4), oracle_engine(G, R, seed=4)
+    rng = np.random.default_rng(5)
+    now = 0
+    for t in range(25):
+        now += 150
+        inbox = random_follower_inbox(rng, G, a.node_ids, np.full(G, 1, np.uint32), a.read("head"), a.read("commit"),
+                                      a.read("term"))
+        out = a.step_dense_follower(now, **inbox, tick=True)
+        for g in range(G):
+            if inbox["hb_commit"][g] != NO:
+                b.submit(g, Command.Heartbeat(int(inbox["term"][g]), int(inbox["hb_commit"][g]), int(inbox["leader"][g])))
+            if inbox["ae_n"][g] != capi.AE_NONE:
+                f = int(inbox["ae_from"][g])
+                b.submit(g, Command.AppendEntries(int(inbox["term"][g]), int(inbox["leader"][g]),
+                                                  [(f + 1 + k, f + k) for k in range(int(inbox["ae_n"][g]))]))
+            if b.read("role", g0=g, n=1)[0] != capi.ROLE_LEADER:
+                b.submit(g, Command.Tick())
+        b.step(now)
+        compare_snapshots(a, b, f"tick {t}")
+        rows = b.drain_messages()
+        b.drain_applies()
+        ack = np.full(G, NO, np.uint64)
+        for m in rows[rows["kind"] == capi.CMD_APPEND_RESPONSE]:
+            ack[m["group"]] = m["id"]
+        assert np.array_equal(ack, out["ack_head"])
+        other = rows[(rows["kind"] != capi.CMD_APPEND_RESPONSE) & (rows["kind"] != capi.CMD_HEARTBEAT_RESPONSE)]
+        mine = a.drain_messages()
+        assert other.tobytes() == mine.tobytes()
+
+
+# ---- parity proper ---------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,flags,layout", [(3, capi.CFG_SEPARATE_COMMIT_KEY, "slot0"), (5, capi.CFG_SEPARATE_COMMIT_KEY, "last"),
+                                            (5, 0, "slot0"), (3, capi.CFG_SEPARATE_COMMIT_KEY, "mixed"),
+                                            (1, 0, "slot0"), (2, capi.CFG_SEPARATE_COMMIT_KEY, "slot0")])
+def test_dense_leader_tick_parity(R, flags, layout):
+    G = 3000
+    slots = {"slot0": None, "last": np.full(G, R - 1, np.uint8), "mixed": (np.arange(G) % R).astype(np.uint8)}[layout]
+    dev = BatchedRaft(G, R, seed=21, flags=flags, self_slots=slots)
+    ora = oracle_engine(G, R, seed=21, flags=flags, self_slots=slots)
+    for e in (dev, ora):
+        elect_all(e)
+        e.drain_messages(), e.drain_applies()
+    rng = np.random.default_rng(R * 7 + flags)
+    sl = ora.read("self_slot")
+    now = 0
+    for t in range(40):
+        now += 70
+        acks, hbr_has, hbr_commit = random_leader_inbox(rng, G, R, sl, ora.read("head"))
+        tick = t % 5 != 4
+        oa = dev.step_dense_leader(now, acks, hbr_has, hbr_commit, tick=tick)
+        ob = ora.step_dense_leader(now, acks, hbr_has, hbr_commit, tick=tick)
+        if tick:
+            _cmp_cols(oa, ob, f"R={R} tick {t}")
+        compare_snapshots(dev, ora, f"R={R} leader tick {t}")
+        compare_drains(dev, ora, f"R={R} leader tick {t}")
+    assert dev.counters()["decisions"] == ora.counters()["decisions"]
+    if R > 1 and flags:
+        assert int(ora.read("commit").max()) > 0
+    if R > 1 and not flags:  # Q9: the reference leader runs into the "commit" key
+        assert (ora.read("fault") == capi.FAULT_RANGE_HIT_COMMIT_KEY).any()
+
+
+@pytest.mark.gpu
+def test_dense_leader_tick_irregular_leaders_send_rows():
+    """A leader whose chain is not in run form (restarted with a commit, then re-elected) cannot
+    use the (from, n) columns: its Tick goes out as rows, exactly as the oracle says."""
+    G, R = 600, 3
+    dev = BatchedRaft(G, R, seed=2, flags=capi.CFG_SEPARATE_COMMIT_KEY)
+    ora = oracle_engine(G, R, seed=2, flags=capi.CFG_SEPARATE_COMMIT_KEY)
+    for e in (dev, ora):
+        elect_all(e)
+        acks = np.full((R, G), NO, np.uint64)
+        acks[0] = 2
+        e.step_dense_leader(100, acks, tick=False)
+        acks[0], acks[1] = 0, 2
+        e.step_dense_leader(200, acks, tick=False)  # commit 2
+        g = np.arange(0, G, 2, dtype=np.uint32)
+        e.submit_columns(np.full(len(g), capi.CMD_RESTART, np.uint8), g)
+        e.step(300)
+        e.submit_columns(np.full(len(g), capi.CMD_TIMEOUT, np.uint8), g)
+        e.submit_columns(np.full(len(g), capi.CMD_VOTE_RESPONSE, np.uint8), g, from_=np.full(len(g), 2, np.uint32),
+                         term=np.ones(len(g), np.uint64), flag=np.ones(len(g), np.uint8))
+        e.step(300)
+        e.drain_messages(), e.drain_applies(), e.drain_faults()
+    assert (ora.read("role") == capi.ROLE_LEADER).all() and int(ora.read("id_gen")[0]) == 2
+    acks[:] = NO
+    acks[0] = 0
+    for t in range(3):
+        oa = dev.step_dense_leader(500 + 150 * t, acks, tick=True)
+        ob = ora.step_dense_leader(500 + 150 * t, acks, tick=True)
+        _cmp_cols(oa, ob, f"tick {t}")
+        assert (ob["ae_n"][1][0::2] == capi.AE_NONE).all() and (ob["ae_n"][1][1::2] != capi.AE_NONE).all()
+        compare_snapshots(dev, ora, f"irregular leaders tick {t}")
+        a, b = dev.drain_messages(), ora.drain_messages()
+        assert a.tobytes() == b.tobytes() and len(b) >= G // 2 * (R - 1)
+
+
+def _mixed_role_engines(G, R, seed):
+    dev = BatchedRaft(G, R, seed=seed, election_timeout_ms=(300, 600))
+    ora = oracle_engine(G, R, seed=seed, election_timeout_ms=(300, 600))
+    for e in (dev, ora):
+        g = np.arange(0, G, 7, dtype=np.uint32)  # every 7th group: a candidate
+        e.submit_columns(np.full(len(g), capi.CMD_TIMEOUT, np.uint8), g)
+        g = np.arange(3, G, 11, dtype=np.uint32)  # some leaders
+        e.submit_columns(np.full(len(g), capi.CMD_TIMEOUT, np.uint8), g)
+        e.submit_columns(np.full(len(g), capi.CMD_VOTE_RESPONSE, np.uint8), g, from_=np.full(len(g), 2, np.uint32),
+                         term=np.ones(len(g), np.uint64), flag=np.ones(len(g), np.uint8))
+        g = np.arange(5, G, 13, dtype=np.uint32)  # followers with queued client requests
+        e.submit_columns(np.full(len(g), capi.CMD_CLIENT_REQUEST, np.uint8), g, id=np.arange(len(g), dtype=np.uint64))
+        e.step(0)
+        e.drain_messages(), e.drain_applies(), e.drain_faults()
+    return dev, ora
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [3, 5])
+def test_dense_follower_tick_parity(R):
+    """Random leader traffic into followers, candidates, leaders and queued-request holders:
+    in-order windows, re-sent windows (the head moves backwards), gaps (extend Err), stale
+    leaders (assert), heartbeats ahead of the chain, election timers firing."""
+    G = 4000
+    dev, ora = _mixed_role_engines(G, R, seed=31)
+    rng = np.random.default_rng(R)
+    self_ids = np.full(G, 1, np.uint32)
+    now = 0
+    saw_candidate, n_rows = False, 0
+    for t in range(50):
+        now += int(rng.integers(50, 260))
+        inbox = random_follower_inbox(rng, G, ora.node_ids, self_ids, ora.read("head"), ora.read("commit"),
+                                      ora.read("term"))
+        tick = t % 4 != 3
+        oa = dev.step_dense_follower(now, **inbox, tick=tick)
+        ob = ora.step_dense_follower(now, **inbox, tick=tick)
+        _cmp_cols(oa, ob, f"R={R} follower tick {t}")
+        compare_snapshots(dev, ora, f"R={R} follower tick {t}")
+        saw_candidate |= bool((ora.read("role") == capi.ROLE_CANDIDATE).any())
+        a, b = dev.drain_messages(), ora.drain_messages()
+        assert a.tobytes() == b.tobytes(), f"R={R} follower tick {t}: exceptional rows differ"
+        n_rows += len(b)
+        compare_drains(dev, ora, f"R={R} follower tick {t}")
+    assert dev.counters()["decisions"] == ora.counters()["decisions"]
+    f = ora.read("fault")
+    assert (f == capi.FAULT_EXTEND_MISSING_PARENT).any() and (f == capi.FAULT_FOLLOWER_STALE_LEADER).any()
+    # the run exercised the slow path too: candidates, queue flushes / vote requests as rows
+    assert saw_candidate and n_rows > 0
+
+
+@pytest.mark.gpu
+def test_dense_follower_uniform_leader_and_sparse_mix():
+    """leader_id for every group instead of a column; sparse steps between dense ones."""
+    G, R = 1500, 3
+    dev, ora = BatchedRaft(G, R, seed=8), oracle_engine(G, R, seed=8)
+    rng = np.random.default_rng(9)
+    now = 0
+    for t in range(30):
+        now += 120
+        inbox = random_follower_inbox(rng, G, ora.node_ids, np.full(G, 1, np.uint32), ora.read("head"),
+                                      ora.read("commit"), ora.read("term"))
+        inbox.pop("leader")
+        oa = dev.step_dense_follower(now, **inbox, leader_id=2, tick=True)
+        ob = ora.step_dense_follower(now, **inbox, leader_id=2, tick=True)
+        _cmp_cols(oa, ob, f"tick {t}")
+        if t % 6 == 5:  # a sparse step in between: vote requests and client requests
+            g = rng.integers(0, G, 200).astype(np.uint32)
+            for e in (dev, ora):
+                e.submit_columns(np.full(200, capi.CMD_CLIENT_REQUEST, np.uint8), g, id=np.arange(200, dtype=np.uint64))
+                e.submit_columns(np.full(200, capi.CMD_VOTE_REQUEST, np.uint8), g, from_=np.full(200, 3, np.uint32),
+                                 term=np.full(200, 9, np.uint64), id=np.full(200, 10**6, np.uint64),
+                                 aux=np.full(200, 9, np.uint64))
+                e.step(now)
+        compare_snapshots(dev, ora, f"tick {t}")
+        compare_drains(dev, ora, f"tick {t}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,lead", [(3, 0), (5, 2)])
+def test_closed_loop_cluster_dense(R, lead):
+    """R engines per side exchanging only mailbox columns: device cluster == oracle cluster,
+    every column of every node after every round; commit follows the head."""
+    G, T = 2000, 60
+    dc = DenseCluster(BatchedRaft, G, R, lead=lead)
+    oc = DenseCluster(oracle_engine, G, R, lead=lead)
+    rng = np.random.default_rng(R)
+    for t in range(T):
+        appends = rng.integers(0, 3, G).astype(np.uint64)
+        da, oa = dc.round(appends), oc.round(appends)
+        for r in range(R):
+            _cmp_cols(da[r], oa[r], f"round {t} node {r}")
+            compare_snapshots(dc.nodes[r], oc.nodes[r], f"round {t} node {r}")
+            assert dc.rows[-1][r].tobytes() == oc.rows[-1][r].tobytes()
+    L = oc.nodes[lead]
+    assert (L.read("fault") == 0).all()
+    assert (L.read("commit") + 12 >= L.read("head")).all() and int(L.read("commit").min()) > T // 2
+    for r in range(R):
+        if r != lead:
+            assert (oc.nodes[r].read("commit") > T // 2).all()
+    assert dc.nodes[lead].counters()["decisions"] == L.counters()["decisions"]
