@@ -81,6 +81,141 @@ def cpu_baseline(R: int, seed: int, budget_s: float):
     }
 
 
+def node_alg_bytes(R: int):
+    """Algorithmic bytes per group of one closed-loop protocol round (DESIGN.md "Dense node tick").
+    Leader half: B(R) of the ack tick + term / heartbeat_time (already in B(R): term) 8, HeartbeatResponse
+    flags R-1, outbox term 8 + hb_commit 8 + (R-1) x (ae_from 8 + ae_n 1).  Follower half, per
+    follower: state read 56 + inbox 25, written head 8 + outbox 17, and every other tick (heartbeat)
+    commit 8 + election timer 16."""
+    leader = (24 * R + 36) + 8 + (R - 1) + 16 + 9 * (R - 1)
+    follower = 56 + 25 + 8 + 17 + 12
+    return leader, follower
+
+
+def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
+    """--cluster: all R replicas of every partition on this GPU as R engines (one per node) that
+    exchange nothing but dense mailbox columns, chained with jg_stream_wait.  A step = one full
+    protocol round: leader half (acks + appends + Tick) on the leader node, follower half
+    (Heartbeat + AppendEntries + Tick) on the R-1 others; no synthetic acks anywhere."""
+    import numpy as np
+    from josefine_amd import BatchedRaft, capi
+    from josefine_amd.traces import elect_all
+
+    G, R, K, W = args.groups, args.replicas, args.steps, args.warmup
+    nodes = [BatchedRaft(G, R, seed=args.seed + r, device_id=dev_index, group_base=rank * G,
+                         self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
+    L = nodes[0]
+    elect_all(L)
+    L.drain_messages(), L.drain_applies()
+    api = L.api
+
+    def dalloc(e, nbytes):
+        p = C.c_void_p()
+        e._check(api.device_alloc(e._h, nbytes, C.byref(p)))
+        return p
+
+    acks = dalloc(L, 8 * R * G)          # row r: ack_head of node r; row 0: appends per round
+    hbr_has = dalloc(L, R * G)
+    hbr_commit = dalloc(L, 8 * R * G)
+    init = np.full((R, G), capi.NO_ACK, np.uint64)
+    init[0] = 1                            # one ClientRequest per group per round
+    L._check(api.device_upload(L._h, acks, init.ctypes.data, init.nbytes))
+    none = np.full((R, G), capi.HB_NONE, np.uint8)
+    L._check(api.device_upload(L._h, hbr_has, none.ctypes.data, none.nbytes))
+    o_term, o_hb = dalloc(L, 8 * G), dalloc(L, 8 * G)
+    o_from, o_n = dalloc(L, 8 * R * G), dalloc(L, R * G)
+    inbox = capi.LeaderInbox(acks.value, hbr_has.value, hbr_commit.value)
+    outbox = capi.LeaderOutbox(o_term.value, o_hb.value, o_from.value, o_n.value)
+    f_in, f_out = {}, {}
+    for r in range(1, R):
+        fi = capi.FollowerInbox()
+        fi.leader, fi.leader_id = None, L.node_ids[0]
+        fi.term, fi.hb_commit = o_term.value, o_hb.value
+        fi.ae_from, fi.ae_n = o_from.value + 8 * r * G, o_n.value + r * G
+        f_in[r] = fi
+        f_out[r] = capi.FollowerOutbox(acks.value + 8 * r * G, hbr_commit.value + 8 * r * G, hbr_has.value + r * G)
+    for e in nodes:
+        e._check(api.sync(e._h))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        for e in nodes:
+            e._check(api.sync(e._h))
+
+    now = [0]
+
+    def rounds(n):
+        for _ in range(n):
+            now[0] += 100
+            for r in range(1, R):
+                L._check(api.stream_wait(L._h, nodes[r]._h))
+            L._check(api.step_dense_leader(L._h, now[0], C.byref(inbox), C.byref(outbox)))
+            for r in range(1, R):
+                e = nodes[r]
+                e._check(api.stream_wait(e._h, L._h))
+                e._check(api.step_dense_follower(e._h, now[0], C.byref(f_in[r]), C.byref(f_out[r]), 1))
+        for r in range(1, R):
+            L._check(api.stream_wait(L._h, nodes[r]._h))
+
+    rounds(W)
+    barrier()
+    c0 = L.counters()
+    barrier()
+    t0 = time.perf_counter()
+    L._check(api.timer_start(L._h))
+    rounds(K)
+    ev_ms = C.c_float(0)
+    L._check(api.timer_stop(L._h, C.byref(ev_ms)))
+    barrier()
+    wall = time.perf_counter() - t0
+    decisions = float(L.counters()["decisions"] - c0["decisions"])
+
+    # full-size property check: real protocol rounds, so the commit index trails the head by the
+    # round trip (append -> replicate -> ack -> majority) and every follower tracks the leader
+    T = W + K
+    head, commit = L.read("head"), L.read("commit")
+    assert (head == T).all() and (commit >= T - 3).all() and not L.read("fault").any(), "closed loop: leader state"
+    for r in range(1, R):
+        e = nodes[r]
+        assert (e.read("head") >= T - 1).all() and (e.read("commit") >= T - 5).all() and not e.read("fault").any(), \
+            f"closed loop: follower {r} state"
+        assert (e.read("voted_for") == L.node_ids[0]).all()
+    assert sum(len(e.drain_messages()) for e in nodes) == 0, "rows left the mailbox vocabulary"
+
+    if world > 1:
+        tw = torch.tensor([wall, ev_ms.value], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        td = torch.tensor([decisions], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(td, op=dist.ReduceOp.SUM)
+        wall, decisions = tw[0].item(), td[0].item()
+    if rank == 0:
+        lb, fb = node_alg_bytes(R)
+        alg = (lb + (R - 1) * fb) * G
+        round_s = ev_ms.value / 1e3 / K
+        out = {
+            "metric": "Raft quorum decisions/sec over N partitions; achieved HBM GB/s vs roofline",
+            "value": decisions / wall, "unit": "decisions/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"closed loop: {R} nodes x {G} partitions on one GPU, 1 append per partition per round, "
+                                   "leader half + follower halves over dense mailboxes (no synthetic acks)",
+                       "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world,
+                       "parallelism": f"{world} independent shard(s), no collective"},
+            "group_rounds_per_s": G * world * K / wall,
+            "roofline": {"bound": "hbm", "achieved": alg / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": f"one round: k_leader_node_tick<{R}> + {R - 1} x k_follower_tick_dense (+ empty slow kernels)",
+                         "alg_bytes_per_launch": alg, "avg_launch_us": round_s * 1e6,
+                         "alg_bytes_per_group": {"leader_half": lb, "follower_half": fb}},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +229,9 @@ def main():
     ap.add_argument("--failures", type=int, default=0,
                     help="percent of groups per tick whose leader crashes and is re-elected (BASELINE configs[4]; "
                          "RESTART/Timeout/VoteResponse rows through jg_submit + jg_step)")
+    ap.add_argument("--cluster", action="store_true",
+                    help="closed loop: all R replicas of every partition on this GPU as R engines exchanging dense "
+                         "mailbox columns (jg_step_dense_leader / jg_step_dense_follower); secondary measurement")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x6A6F736566696E65)
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,6 +257,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+
+    if args.cluster:
+        return cluster_main(args, torch, dist, rank, world, dev_index, red_dev)
 
     from josefine_amd import BatchedRaft
     from josefine_amd.traces import elect_all

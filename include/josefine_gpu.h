@@ -361,6 +361,12 @@ int jg_chain_compact(jg_engine* e, size_t n_trees, const uint64_t* off /*[n_tree
 
 int jg_sync(jg_engine* e);
 
+/* Device-side ordering between two engines of one process: everything `waiter` enqueues after
+ * this call runs after everything `signal` has enqueued so far (hipEventRecord on signal's
+ * stream + hipStreamWaitEvent on waiter's; no host synchronisation).  What chains the dense
+ * mailboxes of several engines — one engine's outbox columns are another's inbox. */
+int jg_stream_wait(jg_engine* waiter, jg_engine* signal);
+
 /* Drains.  Each returns the queued rows (per-group emission order identical to the
  * reference; groups in ascending order within one step) and clears the queue.
  * With out == NULL only *n is set. */

@@ -112,7 +112,7 @@ struct jg_engine {
   JgDev dev;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_stage = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_stage = nullptr, ev_order = nullptr;
   std::vector<void*> allocs;
   uint32_t count_slots = 0;  // workgroup slots of dev.blk_decisions
   uint32_t dense_grid = 0;
@@ -520,7 +520,8 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(JG_EDEVICE, "hipStreamCreate failed"));
   if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_stage, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&e->ev_stage, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming) != hipSuccess)
     return bail(fail(JG_EDEVICE, "hipEventCreate failed"));
 
   const size_t G = cfg->n_groups, R = cfg->n_replicas;
@@ -603,6 +604,7 @@ void jg_engine_destroy(jg_engine* e) {
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->ev_stage) (void)hipEventDestroy(e->ev_stage);
+  if (e->ev_order) (void)hipEventDestroy(e->ev_order);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -877,6 +879,16 @@ int jg_chain_compact(jg_engine* e, size_t n_trees, const uint64_t* off, const ui
 int jg_sync(jg_engine* e) {
   if (!e) return fail(JG_EINVAL, "null argument");
   return sync_and_check(e);
+}
+
+int jg_stream_wait(jg_engine* waiter, jg_engine* signal) {
+  if (!waiter || !signal) return fail(JG_EINVAL, "null argument");
+  if (waiter == signal) return JG_OK;
+  HIPCHK(hipSetDevice(signal->device));
+  HIPCHK(hipEventRecord(signal->ev_order, signal->stream));
+  HIPCHK(hipSetDevice(waiter->device));
+  HIPCHK(hipStreamWaitEvent(waiter->stream, signal->ev_order, 0));
+  return JG_OK;
 }
 
 int jg_drain_messages(jg_engine* e, jg_msg_row* out, size_t cap, size_t* n) {
