@@ -334,6 +334,79 @@ class BatchedRaft {
   std::map<std::pair<uint32_t, uint64_t>, std::vector<uint8_t>> pending_reqs_;
 };
 
+// ---- dense node tick over device-resident mailboxes -------------------------------------------
+// The steady-state loop of a batched event loop (server.rs:103-165 for many partitions): per
+// TICK one leader half on the node that leads and one follower half on every other node, the
+// messages being columns in HBM (include/josefine_gpu.h "dense node tick").  `DenseCluster`
+// owns the mailbox columns of one leader node and its followers when all of them live in this
+// process (one engine per node; e.g. the 3 brokers of examples/multi-node in one runtime) and
+// chains the engines' streams with jg_stream_wait — no host synchronisation per round.
+class DenseCluster {
+ public:
+  // nodes[r] hosts replica slot r of every group; nodes[lead] leads them
+  DenseCluster(std::vector<jg_engine*> nodes, uint32_t n_groups, uint32_t lead, NodeId lead_id)
+      : nodes_(std::move(nodes)), G_(n_groups), R_((uint32_t)nodes_.size()), lead_(lead), lead_id_(lead_id) {
+    jg_engine* L = nodes_[lead_];
+    acks_ = (uint64_t*)alloc(L, 8ull * R_ * G_);
+    hbr_commit_ = (uint64_t*)alloc(L, 8ull * R_ * G_);
+    hbr_has_ = (uint8_t*)alloc(L, (size_t)R_ * G_);
+    o_term_ = (uint64_t*)alloc(L, 8ull * G_);
+    o_hb_ = (uint64_t*)alloc(L, 8ull * G_);
+    o_from_ = (uint64_t*)alloc(L, 8ull * R_ * G_);
+    o_n_ = (uint8_t*)alloc(L, (size_t)R_ * G_);
+    std::vector<uint64_t> a((size_t)R_ * G_, JG_NO_ACK);
+    std::vector<uint8_t> h((size_t)R_ * G_, JG_HB_NONE);
+    check(jg_device_upload(L, acks_, a.data(), a.size() * 8));
+    check(jg_device_upload(L, hbr_has_, h.data(), h.size()));
+  }
+  ~DenseCluster() {
+    for (void* p : bufs_) (void)jg_device_free(nodes_[lead_], p);
+  }
+  // number of ClientRequests every group appends in the next round (leader.rs:177-197)
+  void set_appends(const std::vector<uint64_t>& n) {
+    check(jg_device_upload(nodes_[lead_], acks_ + (size_t)lead_ * G_, n.data(), (size_t)G_ * 8));
+  }
+  // one protocol round at logical time now_ms
+  void round(uint64_t now_ms) {
+    jg_engine* L = nodes_[lead_];
+    for (uint32_t r = 0; r < R_; r++)
+      if (r != lead_) check(jg_stream_wait(L, nodes_[r]));  // last round's answers are in
+    jg_leader_inbox in{acks_, hbr_has_, hbr_commit_};
+    jg_leader_outbox out{o_term_, o_hb_, o_from_, o_n_};
+    check(jg_step_dense_leader(L, now_ms, &in, &out));
+    for (uint32_t r = 0; r < R_; r++) {
+      if (r == lead_) continue;
+      check(jg_stream_wait(nodes_[r], L));
+      jg_follower_inbox fi{};
+      fi.leader = nullptr, fi.leader_id = lead_id_;
+      fi.term = o_term_, fi.hb_commit = o_hb_;
+      fi.ae_from = o_from_ + (size_t)r * G_, fi.ae_n = o_n_ + (size_t)r * G_;
+      jg_follower_outbox fo{acks_ + (size_t)r * G_, hbr_commit_ + (size_t)r * G_, hbr_has_ + (size_t)r * G_};
+      check(jg_step_dense_follower(nodes_[r], now_ms, &fi, &fo, 1));
+    }
+  }
+  void sync() {
+    for (jg_engine* e : nodes_) check(jg_sync(e));
+  }
+
+ private:
+  static void check(int rc) {
+    if (rc != JG_OK) throw EngineError(rc, jg_last_error());
+  }
+  void* alloc(jg_engine* e, size_t bytes) {
+    void* p = nullptr;
+    check(jg_device_alloc(e, bytes, &p));
+    bufs_.push_back(p);
+    return p;
+  }
+  std::vector<jg_engine*> nodes_;
+  uint32_t G_, R_, lead_;
+  NodeId lead_id_;
+  uint64_t *acks_, *hbr_commit_, *o_term_, *o_hb_, *o_from_;
+  uint8_t *hbr_has_, *o_n_;
+  std::vector<void*> bufs_;
+};
+
 inline RaftHandle RaftHandle::apply(const Command& cmd, uint64_t now_ms) { return e_->apply(g_, cmd, now_ms); }
 inline uint64_t RaftHandle::read64(int f) const {
   uint64_t v = 0;

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
+#include <memory>
 
 #include "../../josefine_amd/host/raft_handle.hpp"
 
@@ -115,12 +116,47 @@ static void multi_node_plumbing() {
   for (uint32_t g = 0; g < 3; g++) CHECK(raft.handle(g).fault() == 0);
 }
 
+// The same 3-broker topology as three engines (one per broker process) hosting 64 partitions
+// each, driven through the dense node tick: node 1 leads every partition, one ClientRequest per
+// partition per round; the mailboxes never leave the device.
+static void multi_node_dense_rounds() {
+  const uint32_t G = 64;
+  std::vector<std::unique_ptr<BatchedRaft>> nodes;
+  std::vector<jg_engine*> raw;
+  for (uint32_t r = 0; r < 3; r++) {
+    nodes.emplace_back(new BatchedRaft(G, {1, 2, 3}, 0, 7 + r, JG_CFG_SEPARATE_COMMIT_KEY));
+    std::vector<uint8_t> slots(G, (uint8_t)r);
+    CHECK(jg_set_self_slots(nodes[r]->raw(), slots.data()) == JG_OK);
+    raw.push_back(nodes[r]->raw());
+  }
+  // node 1 wins every election the reference's way: Timeout, then a granted vote from node 2
+  for (uint32_t g = 0; g < G; g++) nodes[0]->submit(g, Command::Timeout());
+  nodes[0]->step(0);
+  for (uint32_t g = 0; g < G; g++) nodes[0]->submit(g, Command::VoteResponse(1, 2, true));
+  nodes[0]->step(0);
+  CHECK(nodes[0]->handle(5).is_leader());
+  DenseCluster cl(raw, G, 0, 1);
+  cl.set_appends(std::vector<uint64_t>(G, 1));
+  const uint32_t T = 30;
+  for (uint32_t t = 1; t <= T; t++) cl.round(100ull * t);
+  cl.sync();
+  for (uint32_t g : {0u, 17u, 63u}) {
+    CHECK(nodes[0]->handle(g).head() == T && nodes[0]->handle(g).commit() + 3 >= T);
+    for (uint32_t r = 1; r < 3; r++) {
+      RaftHandle h = nodes[r]->handle(g);
+      CHECK(h.is_follower() && h.fault() == 0 && h.voted_for() == 1 && h.current_term() == 1);
+      CHECK(h.head() + 1 >= T && h.commit() + 5 >= T);
+    }
+  }
+}
+
 int main() {
   try {
     apply_entry_single_node();
     follower_apply_heartbeat();
     candidate_apply_heartbeat();
     multi_node_plumbing();
+    multi_node_dense_rounds();
   } catch (const std::exception& e) {
     std::fprintf(stderr, "exception: %s\n", e.what());
     return 2;
