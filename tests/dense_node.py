@@ -58,9 +58,9 @@ class DenseCluster:
     made leader of all groups.  One round = leader half on the leader node, follower half on
     every other node, the outboxes of one being the inboxes of the others."""
 
-    def __init__(self, factory, G, R, seed=3, lead=0):
+    def __init__(self, factory, G, R, seed=3, lead=0, group_base=0):
         self.G, self.R, self.lead = G, R, lead
-        self.nodes = [factory(G, R, seed=seed + r, self_slots=np.full(G, r, np.uint8),
+        self.nodes = [factory(G, R, seed=seed + r, self_slots=np.full(G, r, np.uint8), group_base=group_base,
                               flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
         self.now = 0
         self.acks = np.full((R, G), NO, dtype=np.uint64)

@@ -76,7 +76,49 @@ def fuzz_fixture(G, R, steps, rows):
     return out
 
 
+def node_fixture(G, R, rounds, ticks):
+    """Dense node tick: a closed-loop cluster (digests of every mailbox column of every round +
+    final state) and random leader traffic into one follower node (inputs stored, outputs digested)."""
+    from dense_node import DenseCluster, random_follower_inbox
+
+    out = {"G": G, "R": R, "rounds": rounds, "ticks": ticks}
+    cl = DenseCluster(oracle_engine, G, R, seed=5)
+    rng = np.random.default_rng(77)
+    h = hashlib.sha256()
+    for t in range(rounds):
+        appends = rng.integers(0, 3, G).astype(np.uint64)
+        out[f"appends_{t}"] = appends
+        outs = cl.round(appends)
+        for r in range(R):
+            for k in sorted(outs[r]):
+                h.update(np.ascontiguousarray(outs[r][k]).tobytes())
+    out["cluster_digest"] = h.hexdigest()
+    for r in range(R):
+        for name in ("commit", "head", "term", "voted_for", "role", "fault"):
+            out[f"cluster_{name}_{r}"] = cl.nodes[r].read(name)
+    e = oracle_engine(G, R, seed=6, election_timeout_ms=(300, 600))
+    rng = np.random.default_rng(78)
+    h, now = hashlib.sha256(), 0
+    for t in range(ticks):
+        now += int(rng.integers(50, 260))
+        inbox = random_follower_inbox(rng, G, e.node_ids, np.full(G, 1, np.uint32), e.read("head"), e.read("commit"),
+                                      e.read("term"))
+        for k, v in inbox.items():
+            out[f"f{t}_{k}"] = v
+        out[f"f{t}_now"] = now
+        o = e.step_dense_follower(now, **inbox, tick=True)
+        for k in sorted(o):
+            h.update(np.ascontiguousarray(o[k]).tobytes())
+        h.update(e.drain_messages().tobytes())
+        h.update(e.drain_faults().tobytes())
+    out["follower_digest"] = h.hexdigest()
+    for name in ("commit", "head", "term", "voted_for", "leader_id", "role", "fault", "election_timeout", "id_gen"):
+        out[f"follower_{name}"] = e.read(name)
+    return out
+
+
 def main():
+    np.savez_compressed(os.path.join(HERE, "node_r3.npz"), **node_fixture(96, 3, 25, 25))
     np.savez_compressed(os.path.join(HERE, "dense_r3_ragged.npz"), **dense_fixture(512, 3, 1, 60, 20))
     np.savez_compressed(os.path.join(HERE, "dense_r5_steady.npz"), **dense_fixture(256, 5, 0, 30, 10))
     np.savez_compressed(os.path.join(HERE, "fuzz_r3.npz"), **fuzz_fixture(128, 3, 20, 400))

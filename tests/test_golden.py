@@ -60,3 +60,37 @@ def test_fuzz_golden(backend):
     assert msg_h.hexdigest() == str(z["digest_messages"])
     assert fsm_h.hexdigest() == str(z["digest_applies"])
     assert flt_h.hexdigest() == str(z["digest_faults"])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_node_tick_golden(backend):
+    """Dense node tick (jg_step_dense_leader / jg_step_dense_follower): closed-loop cluster and
+    random follower traffic against the committed digests."""
+    from dense_node import DenseCluster
+
+    z = np.load(os.path.join(HERE, "node_r3.npz"))
+    G, R, rounds, ticks = int(z["G"]), int(z["R"]), int(z["rounds"]), int(z["ticks"])
+    factory = oracle_engine if backend == "oracle" else BatchedRaft
+    cl = DenseCluster(factory, G, R, seed=5)
+    h = hashlib.sha256()
+    for t in range(rounds):
+        outs = cl.round(z[f"appends_{t}"])
+        for r in range(R):
+            for k in sorted(outs[r]):
+                h.update(np.ascontiguousarray(outs[r][k]).tobytes())
+    assert h.hexdigest() == str(z["cluster_digest"])
+    for r in range(R):
+        for name in ("commit", "head", "term", "voted_for", "role", "fault"):
+            assert np.array_equal(cl.nodes[r].read(name), z[f"cluster_{name}_{r}"]), (r, name)
+    e = make(backend, G, R, seed=6, election_timeout_ms=(300, 600))
+    h = hashlib.sha256()
+    for t in range(ticks):
+        inbox = {k: z[f"f{t}_{k}"] for k in ("leader", "term", "hb_commit", "ae_from", "ae_n")}
+        o = e.step_dense_follower(int(z[f"f{t}_now"]), **inbox, tick=True)
+        for k in sorted(o):
+            h.update(np.ascontiguousarray(o[k]).tobytes())
+        h.update(e.drain_messages().tobytes())
+        h.update(e.drain_faults().tobytes())
+    assert h.hexdigest() == str(z["follower_digest"])
+    for name in ("commit", "head", "term", "voted_for", "leader_id", "role", "fault", "election_timeout", "id_gen"):
+        assert np.array_equal(e.read(name), z[f"follower_{name}"]), name

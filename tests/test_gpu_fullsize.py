@@ -83,3 +83,37 @@ def test_full_size_windows_and_properties(G, R, mode, ticks):
         for r in range(R):
             assert np.array_equal(dev.read("match", r, base, W), ora.read("match", r)), (base, r)
     assert dev.counters()["dense_group_steps"] == G * ticks
+
+
+def test_full_size_closed_loop_cluster():
+    """BASELINE configs[2]-sized closed loop: 3 nodes x 1 M partitions as three engines exchanging
+    dense mailbox columns; oracle clusters re-run windows of the partitions (appends are a
+    function of the global partition id) and must agree on every column of every node."""
+    from dense_node import DenseCluster
+    from josefine_amd.traces import synth_hash
+
+    G, R, T, W = 1_000_000, 3, 16, 1024
+
+    def appends(base, n, t):
+        return (synth_hash(SEED, t, np.arange(base, base + n, dtype=np.uint64), 5) % np.uint64(3)).astype(np.uint64)
+
+    dc = DenseCluster(BatchedRaft, G, R, seed=9)
+    for t in range(T):
+        dc.round(appends(0, G, t))
+    lead = dc.nodes[0]
+    head, commit = lead.read("head"), lead.read("commit")
+    assert not lead.read("fault").any() and (commit <= head).all() and int(commit.min()) > 0
+    for r in (1, 2):
+        f = dc.nodes[r]
+        assert not f.read("fault").any() and (f.read("role") == capi.ROLE_FOLLOWER).all()
+        assert (f.read("head") <= head).all() and (f.read("commit") <= commit).all()
+    assert all(len(rows) == 0 for per_round in dc.rows for rows in per_round)
+    for base in (0, 777_000, G - W):
+        oc = DenseCluster(oracle_engine, W, R, seed=9, group_base=base)
+        for t in range(T):
+            oc.round(appends(base, W, t))
+        for r in range(R):
+            for name in ("commit", "head", "term", "voted_for", "election_timeout", "repl_state"):
+                assert np.array_equal(dc.nodes[r].read(name, 0, base, W), oc.nodes[r].read(name)), (base, r, name)
+            for q in range(R):
+                assert np.array_equal(dc.nodes[r].read("match", q, base, W), oc.nodes[r].read("match", q)), (base, r, q)
