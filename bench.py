@@ -27,8 +27,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 
 
 def alg_bytes_per_group_step(R: int) -> int:
-    """read R ack heads + R match heads + commit + head + term (8 B each)
-    + 4 B flags; write R match heads + commit."""
+    """Bytes the dense leader tick has to move per group-step with the engine's state layout
+    (DESIGN.md "k_leader_tick_dense"): read R ack heads (8 B each) + the packed progress word 8 +
+    commit 8 + head 8 + flags 4; write commit 8 + head 8  =>  8R + 44 (84 B at R = 5)."""
+    return 8 * R + 44
+
+
+def survey_bytes_per_group_step(R: int) -> int:
+    """SURVEY.md §8(d)'s B(R): every progress head an 8-byte absolute value, read and written each
+    tick: read R ack heads + R match heads + commit + head + term (8 B each) + 4 B flags; write R
+    match heads + commit = 24R + 36 (156 B at R = 5).  Reported beside the roofline for continuity."""
     return 24 * R + 36
 
 
@@ -83,11 +91,11 @@ def cpu_baseline(R: int, seed: int, budget_s: float):
 
 def node_alg_bytes(R: int):
     """Algorithmic bytes per group of one closed-loop protocol round (DESIGN.md "Dense node tick").
-    Leader half: B(R) of the ack tick + term / heartbeat_time (already in B(R): term) 8, HeartbeatResponse
-    flags R-1, outbox term 8 + hb_commit 8 + (R-1) x (ae_from 8 + ae_n 1).  Follower half, per
+    Leader half: the 8R + 44 of the ack tick + term 8 + heartbeat_time 8, HeartbeatResponse flags R-1,
+    outbox term 8 + hb_commit 8 + (R-1) x (ae_from 8 + ae_n 1).  Follower half, per
     follower: state read 56 + inbox 25, written head 8 + outbox 17, and every other tick (heartbeat)
     commit 8 + election timer 16."""
-    leader = (24 * R + 36) + 8 + (R - 1) + 16 + 9 * (R - 1)
+    leader = (8 * R + 44) + 16 + (R - 1) + 16 + 9 * (R - 1)
     follower = 56 + 25 + 8 + 17 + 12
     return leader, follower
 
@@ -366,7 +374,7 @@ def main():
             wall_b, dec_b = tb[0].item(), tdb[0].item()
         batched = {"ticks_per_launch": TB, "steps": K, "ms_per_step": wall_b * 1e3 / K,
                    "decisions_per_s": dec_b / wall_b,
-                   "bytes_moved_per_group_step": 8 * R + (16 * R + 36) / TB,
+                   "bytes_moved_per_group_step": 8 * R + 44 / TB,
                    "note": "same results bit for bit; state read/written once per launch"}
 
     if world > 1:
@@ -415,6 +423,12 @@ def main():
                 "kernel": f"k_leader_tick_dense<{R}>" if T == 1 else f"k_leader_tick_dense_n<{R}> (T={T} ticks/launch)",
                 "alg_bytes_per_launch": alg, "ticks_per_launch": ticks_per_launch,
                 "avg_launch_us": launch_s * 1e6, "peak_basis": "8.0 TB/s spec (6.29 TB/s measured copy)",
+                "alg_bytes_per_group_step": alg_bytes_per_group_step(R),
+                # the same launch priced with SURVEY.md's B(R) = 24R + 36 (8-byte absolute progress heads
+                # read and written every tick); > 1 possible: the engine stores them delta-packed
+                "survey_priced": {"bytes_per_group_step": survey_bytes_per_group_step(R),
+                                  "achieved": survey_bytes_per_group_step(R) * G * ticks_per_launch / launch_s / 1e9,
+                                  "frac": survey_bytes_per_group_step(R) * G * ticks_per_launch / launch_s / 1e9 / HBM_PEAK_GBS},
             },
         }
         if args.failures:

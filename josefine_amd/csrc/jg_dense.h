@@ -7,9 +7,9 @@
 //
 // Algorithmic bytes per group-step: B(R) = 24R + 36 — R ack heads,
 // R match heads, commit, head, term read (8 B each) + the 4-B flag word, R match heads
-// + commit written.  The kernel moves less: the leader's own match head equals the
-// chain head after every self-ack (SELF-SYNC, jg_device.h) and is then implicit, so at
-// steady state it reads 16R + 12 and writes 8R + 8 bytes = 24R + 20 (140 B at R = 5).
+// + commit written.  The kernel moves less: the R match heads are delta-packed into one
+// 64-bit word of lags below the chain head (jg_device.h), which in steady state does not
+// even change from tick to tick; it reads 8R + 28 and writes 16 bytes (84 B at R = 5).
 //
 // Exactness of the fusion: the reference evaluates Leader::commit after every
 // ack.  match[] is monotone, hence so is committed_index(), and the guard
@@ -22,8 +22,8 @@
 //
 // Register form: the group's own slot s and the R-1 other slots are kept apart
 // ("self + others": other k is slot k + (k >= s), ascending), so that with an
-// engine-uniform own slot every load except the rarely needed own match head has an
-// address that does not depend on the flag word: one round trip to HBM per group.
+// engine-uniform own slot every load has an address that does not depend on the flag
+// word: one round trip to HBM per group (escaped lag fields cost a second one, rarely).
 #pragma once
 #include "jg_device.h"
 
@@ -170,30 +170,55 @@ __device__ __forceinline__ void jg_dense_load_acks(const uint64_t* __restrict__ 
 }
 template <int R>
 __device__ __forceinline__ void jg_dense_load(const JgDev& d, const uint64_t* __restrict__ acks, uint32_t g,
-                                              uint32_t s, JgDenseRegs<R>& x) {
+                                              uint32_t s, JgDenseRegs<R>& x, uint64_t& mword) {
   const uint32_t G = d.G;
-  jg_dense_load_acks<R>(acks, G, g, s, x.n_app, x.ao);
+  if (acks) {
+    jg_dense_load_acks<R>(acks, G, g, s, x.n_app, x.ao);
+  } else {  // node tick without acks
+    x.n_app = 0;
 #pragma unroll
-  for (int k = 0; k + 1 < R; k++) x.mo[k] = d.match[(size_t)jg_other_slot(k, s) * G + g];
+    for (int k = 0; k + 1 < R; k++) x.ao[k] = JG_NO_ACK;
+  }
+  mword = d.mlag[g];
   x.commit = d.commit[g];
   x.head = d.head[g];
 }
-
-// Store what changed.  `chg`: bit k+1 set = match head of other k may differ from what was
-// loaded, bit 0 = the own one.  The own slot stays implicit while it equals the chain head.
+// packed lags -> absolute progress heads (escaped fields: one more load, rare)
 template <int R>
-__device__ __forceinline__ void jg_dense_store(const JgDev& d, uint32_t g, uint32_t s, uint32_t f, uint32_t chg,
+__device__ __forceinline__ void jg_dense_unpack(const JgDev& d, uint32_t g, uint32_t s, uint64_t mword,
+                                                JgDenseRegs<R>& x) {
+  const uint64_t esc = jg_lag_esc(R);
+  uint64_t f = jg_lag_field(mword, s, R);
+  x.ms = f == esc ? d.match_wide[(size_t)s * d.G + g] : x.head - f;
+#pragma unroll
+  for (int k = 0; k + 1 < R; k++) {
+    const uint32_t r = jg_other_slot(k, s);
+    f = jg_lag_field(mword, r, R);
+    x.mo[k] = f == esc ? d.match_wide[(size_t)r * d.G + g] : x.head - f;
+  }
+}
+
+// Store what changed: the lags re-packed against the new head (in steady state the same
+// word as before: no store), commit, head, flag word.
+template <int R>
+__device__ __forceinline__ void jg_dense_store(const JgDev& d, uint32_t g, uint32_t s, uint32_t f, uint64_t mword0,
                                                const JgDenseRegs<R>& x, uint64_t commit0, uint64_t head0) {
   const uint32_t G = d.G;
+  const uint64_t esc = jg_lag_esc(R);
+  uint64_t fl = jg_lag_encode(x.ms, x.head, R);
+  if (fl == esc) d.match_wide[(size_t)s * G + g] = x.ms;
+  uint64_t w = jg_lag_with(0, s, R, fl);
 #pragma unroll
-  for (int k = 0; k + 1 < R; k++)
-    if ((chg >> (k + 1)) & 1u) d.match[(size_t)jg_other_slot(k, s) * G + g] = x.mo[k];
-  const bool sync1 = x.ms == x.head;
-  if (!sync1 && ((chg & 1u) || (f & JGF_SELF_SYNC))) d.match[(size_t)s * G + g] = x.ms;
-  const uint32_t nf = sync1 ? (x.nf | JGF_SELF_SYNC) : (x.nf & ~JGF_SELF_SYNC);
+  for (int k = 0; k + 1 < R; k++) {
+    const uint32_t r = jg_other_slot(k, s);
+    fl = jg_lag_encode(x.mo[k], x.head, R);
+    if (fl == esc) d.match_wide[(size_t)r * G + g] = x.mo[k];
+    w = jg_lag_with(w, r, R, fl);
+  }
+  if (w != mword0) d.mlag[g] = w;
   if (x.commit != commit0) d.commit[g] = x.commit;
   if (x.head != head0) d.head[g] = x.head;
-  if (nf != f) d.flags[g] = nf;
+  if (x.nf != f) d.flags[g] = x.nf;
 }
 
 // ---- deferral to the slow kernel: wave-aggregated append to sharded lists -----------------------
@@ -329,18 +354,8 @@ __device__ __forceinline__ uint32_t jg_dense_tick_body(const JgDev& d, const uin
     const uint32_t f = d.flags[g];
     const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
     JgDenseRegs<R> x;
-    if (!NODE || acks) {
-      jg_dense_load<R>(d, acks, g, s, x);
-    } else {  // a Tick without acks
-      x.n_app = 0;
-#pragma unroll
-      for (int k = 0; k + 1 < R; k++) {
-        x.ao[k] = JG_NO_ACK;
-        x.mo[k] = d.match[(size_t)jg_other_slot(k, s) * G + g];
-      }
-      x.commit = d.commit[g];
-      x.head = d.head[g];
-    }
+    uint64_t mword0;
+    jg_dense_load<R>(d, acks, g, s, x, mword0);
     uint64_t term = 0, hbt = 0;
     bool hbr_trigger = false;
     if (NODE) {
@@ -361,20 +376,14 @@ __device__ __forceinline__ uint32_t jg_dense_tick_body(const JgDev& d, const uin
       continue;
     }
     const uint64_t commit0 = x.commit, head0 = x.head;
-    x.ms = head0;  // SELF-SYNC: implicit
-    if (!(f & JGF_SELF_SYNC)) x.ms = d.match[(size_t)s * G + g];
+    jg_dense_unpack<R>(d, g, s, mword0, x);
     x.nf = f;
-    // a match head changes only through an increment, i.e. exactly when its ack (or the
-    // self-ack) is above the old value: remember that instead of keeping the old heads
-    uint32_t chg = (x.n_app != 0 && x.ms < head0 + x.n_app) ? 1u : 0u;
-#pragma unroll
-    for (int k = 0; k + 1 < R; k++) chg |= (x.ao[k] != JG_NO_ACK && x.mo[k] < x.ao[k]) ? (2u << k) : 0u;
     dec += jg_dense_core<R>(d, g, seq, s, x);
     if (emit) {
       if (x.nf & JGF_FAULT_MASK) jg_dense_outbox_none<R>(d, nd, g);  // the process died before its Tick
       else jg_dense_leader_tick<R>(d, nd, g, seq, s, term, hbt, x);
     }
-    jg_dense_store<R>(d, g, s, f, chg, x, commit0, head0);
+    jg_dense_store<R>(d, g, s, f, mword0, x, commit0, head0);
   }
   return dec;
 }
@@ -402,8 +411,8 @@ __global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDev d, const ui
 // ---- T consecutive ticks per launch (temporal fusion) ----------------------------------------
 // When the caller already holds the ack blocks of several ticks (a batched event loop, the
 // pre-generated bench stream), the group's state stays in registers across them: it is read
-// once and written once per launch, so a group-step costs 8R (acks) + (16R+20)/T bytes of
-// traffic instead of 24R+36.  Semantically identical to T calls of the single-tick kernel:
+// once and written once per launch, so a group-step costs 8R (acks) + 44/T bytes of
+// traffic instead of 8R+44.  Semantically identical to T calls of the single-tick kernel:
 // tick t reads acks + t*tick_stride and carries sequence number seq0 + t.
 template <int R, bool UNIFORM>
 __device__ __forceinline__ uint32_t jg_dense_ticks_body(const JgDev& d, const uint64_t* __restrict__ acks,
@@ -415,19 +424,15 @@ __device__ __forceinline__ uint32_t jg_dense_ticks_body(const JgDev& d, const ui
     const uint32_t f = d.flags[g];
     const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
     JgDenseRegs<R> x;
-    jg_dense_load<R>(d, acks, g, s, x);
+    uint64_t mword0;
+    jg_dense_load<R>(d, acks, g, s, x, mword0);
     const bool leader = (f & JGF_ROLE_MASK) == JG_ROLE_LEADER;
     const bool dead = (f & JGF_FAULT_MASK) != 0;                // the reference process is gone
     const bool defer = !dead && leader && !(f & JGF_FAST);      // irregular chain: k_dense_slow replays all ticks
     jg_defer_push(d, g, defer);
     if (dead || defer) continue;
     const uint64_t commit0 = x.commit, head0 = x.head;
-    x.ms = head0;
-    if (leader && !(f & JGF_SELF_SYNC)) x.ms = d.match[(size_t)s * G + g];
-    const uint64_t ms0 = x.ms;
-    uint64_t mo0[JgDenseRegs<R>::O];
-#pragma unroll
-    for (int k = 0; k + 1 < R; k++) mo0[k] = x.mo[k];
+    if (leader) jg_dense_unpack<R>(d, g, s, mword0, x);
     x.nf = f;
     for (uint32_t t = 0; t < n_ticks; t++) {
       const bool more = t + 1 < n_ticks;
@@ -452,10 +457,7 @@ __device__ __forceinline__ uint32_t jg_dense_ticks_body(const JgDev& d, const ui
       }
     }
     if (leader) {
-      uint32_t chg = x.ms != ms0 ? 1u : 0u;
-#pragma unroll
-      for (int k = 0; k + 1 < R; k++) chg |= (x.mo[k] != mo0[k]) ? (2u << k) : 0u;
-      jg_dense_store<R>(d, g, s, f, chg, x, commit0, head0);
+      jg_dense_store<R>(d, g, s, f, mword0, x, commit0, head0);
     } else if (x.nf != f) {
       d.flags[g] = x.nf;
     }

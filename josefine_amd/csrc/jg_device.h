@@ -18,10 +18,7 @@
 //             [0, head] with next(id) = id-1; the run_hi column is implicit.  What
 //             followers have (extend does not advance id_gen: chain.rs:178-192, Q8)
 //  bit  5     the "commit" key has been persisted               chain.rs:198
-//  bit  6     SELF-SYNC (leaders): the leader's own progress head equals the chain
-//             head (true after every self-ack, leader.rs:190-196) -> match[self] is
-//             implicit and its column entry stale; the dense kernel then neither
-//             reads nor writes it (16 B per group-step less HBM traffic)
+//  bit  6     (free)
 //  bits 8-15  bit r: progress of slot r is Replicate (else Probe) progress.rs:62-66
 //  bits 16-23 sticky fault code (JG_FAULT_*)
 //  bits 24-26 own replica slot
@@ -31,7 +28,6 @@
 #define JGF_HAS_LEADER (1u << 3)
 #define JGF_FAST (1u << 4)
 #define JGF_COMMIT_KEY (1u << 5)
-#define JGF_SELF_SYNC (1u << 6)
 #define JGF_RUN (1u << 7)
 #define JGF_REPL_SHIFT 8
 #define JGF_REPL_MASK (0xffu << JGF_REPL_SHIFT)
@@ -69,7 +65,8 @@ struct JgDev {
   uint64_t* head;            // Chain.head                             chain.rs:103
   uint64_t* id_gen;          // Chain.id_gen (valid unless FAST)       chain.rs:101
   uint64_t* run_hi;          // segment 0: ids [0, run_hi], next = id-1 (valid unless FAST)
-  uint64_t* match;           // [R][G] Progress.head (own slot implicit while SELF-SYNC) progress.rs:124
+  uint64_t* mlag;            // [G] Progress.head of all R slots, packed as lags below the chain head
+  uint64_t* match_wide;      // [R][G] Progress.head of the slots whose lag field holds the escape value
   uint64_t* election_time;   // State.election_time (ms)               mod.rs:281
   uint64_t* heartbeat_time;  // Leader.heartbeat_time (ms)             leader.rs:27
   uint64_t* win_lo;          // [W][G] chain segments besides the run: first id,
@@ -105,11 +102,35 @@ __device__ __forceinline__ uint64_t jg_mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
+// ---- progress heads, delta-packed (progress.rs:124 `Progress.head`, one per replica) -----------
+// A follower's acknowledged head trails the leader's chain head by a few blocks (at most
+// MAX_INFLIGHT are in flight, progress.rs:117), so the R heads of a group are stored as R
+// lags `head - match[r]` of B = 64 / R bits in ONE 64-bit word (R = 5: 12 bits, R = 3: 21).  The
+// all-ones field is an escape: the absolute value then lives in match_wide[r][g] (a replica
+// that is far behind, or a forged ack above the head).  In steady state the lags do not change
+// from tick to tick, so the dense kernel reads 8 bytes of progress state per group and writes none
+// — instead of reading and writing R x 8.
+__host__ __device__ __forceinline__ uint32_t jg_lag_bits(uint32_t R) { return 64u / R; }
+__host__ __device__ __forceinline__ uint64_t jg_lag_esc(uint32_t R) {
+  return R == 1 ? ~0ull : (1ull << jg_lag_bits(R)) - 1ull;
+}
+__host__ __device__ __forceinline__ uint64_t jg_lag_field(uint64_t w, uint32_t r, uint32_t R) {
+  return (w >> (r * jg_lag_bits(R))) & jg_lag_esc(R);
+}
+__host__ __device__ __forceinline__ uint64_t jg_lag_with(uint64_t w, uint32_t r, uint32_t R, uint64_t field) {
+  const uint32_t sh = r * jg_lag_bits(R);
+  return (w & ~(jg_lag_esc(R) << sh)) | (field << sh);
+}
+// lag field for absolute value v under chain head `base`; the escape when it does not fit
+__host__ __device__ __forceinline__ uint64_t jg_lag_encode(uint64_t v, uint64_t base, uint32_t R) {
+  return (v <= base && base - v < jg_lag_esc(R)) ? base - v : jg_lag_esc(R);
+}
+
 // Registers of one group while a lane walks its command segment.
 struct JgLane {
   uint32_t g;
   uint64_t term, commit, head, id_gen, run_hi, election_time, heartbeat_time;
-  uint64_t self_match;  // Progress.head of the own slot (leaders; 0 otherwise)
+  uint64_t mword, mbase;  // leaders: packed progress heads (d.mlag) and the head they are relative to
   uint32_t flags, voted_for, leader_id, election_timeout, rng_draws, queued, votes;
   uint64_t now;
   uint32_t seq;
@@ -150,6 +171,28 @@ __device__ inline void jg_raise(const JgDev& d, JgLane& L, uint32_t code) {
   jg_push_fault(d, L.g, code, L.seq);
 }
 
+// Progress.head of slot r of the lane's group (leaders)
+__device__ inline uint64_t jg_match_get(const JgDev& d, const JgLane& L, uint32_t r) {
+  const uint64_t f = jg_lag_field(L.mword, r, d.R);
+  return f == jg_lag_esc(d.R) ? d.match_wide[(size_t)r * d.G + L.g] : L.mbase - f;
+}
+__device__ inline void jg_match_set(const JgDev& d, JgLane& L, uint32_t r, uint64_t v) {
+  const uint64_t f = jg_lag_encode(v, L.mbase, d.R);
+  if (f == jg_lag_esc(d.R)) d.match_wide[(size_t)r * d.G + L.g] = v;
+  L.mword = jg_lag_with(L.mword, r, d.R, f);
+}
+__device__ inline void jg_match_rebase(const JgDev& d, JgLane& L) {
+  uint64_t w = 0;
+  for (uint32_t r = 0; r < d.R; r++) {
+    const uint64_t v = jg_match_get(d, L, r);
+    const uint64_t f = jg_lag_encode(v, L.head, d.R);
+    if (f == jg_lag_esc(d.R)) d.match_wide[(size_t)r * d.G + L.g] = v;
+    w = jg_lag_with(w, r, d.R, f);
+  }
+  L.mword = w;
+  L.mbase = L.head;
+}
+
 __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
   L.g = g;
   L.flags = d.flags[g];
@@ -166,9 +209,9 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
   L.rng_draws = d.rng_draws[g];
   L.queued = d.queued[g];
   L.votes = d.votes[g];
-  L.self_match = 0;
-  if ((L.flags & JGF_ROLE_MASK) == JG_ROLE_LEADER)
-    L.self_match = (L.flags & JGF_SELF_SYNC) ? L.head : d.match[(size_t)jg_self(L) * d.G + g];
+  L.mword = 0;
+  L.mbase = L.head;
+  if ((L.flags & JGF_ROLE_MASK) == JG_ROLE_LEADER) L.mword = d.mlag[g];
   L.decisions = 0;
   L.overflow = 0;
   L.xq_on = 0;
@@ -182,9 +225,10 @@ __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   L.flags = fast ? (L.flags | JGF_FAST) : (L.flags & ~JGF_FAST);
   // the host then schedules the slow kernel behind the dense leader kernel
   if (!fast && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L)) *d.irregular_seen = 1;
-  const bool sync = jg_role(L) == JG_ROLE_LEADER && L.self_match == L.head;
-  L.flags = sync ? (L.flags | JGF_SELF_SYNC) : (L.flags & ~JGF_SELF_SYNC);
-  if (jg_role(L) == JG_ROLE_LEADER && !sync) d.match[(size_t)jg_self(L) * d.G + g] = L.self_match;
+  if (jg_role(L) == JG_ROLE_LEADER) {
+    if (L.mbase != L.head) jg_match_rebase(d, L);  // the head moved: the lags are relative to it
+    d.mlag[g] = L.mword;
+  }
   d.flags[g] = L.flags;
   d.term[g] = L.term;
   d.commit[g] = L.commit;
@@ -413,7 +457,7 @@ __device__ inline uint64_t jg_committed_index(const JgDev& d, const JgLane& L) {
   uint64_t v[JG_MAX_REPLICAS];
 #pragma unroll
   for (uint32_t r = 0; r < JG_MAX_REPLICAS; r++)
-    v[r] = r < d.R ? (r == jg_self(L) ? L.self_match : d.match[(size_t)r * d.G + L.g]) : 0;
+    v[r] = r < d.R ? jg_match_get(d, L, r) : 0;
   uint32_t k = d.R / 2;
   uint64_t q = 0;
 #pragma unroll
@@ -469,9 +513,9 @@ __device__ inline void jg_follower_from_leader(JgLane& L) {  // leader.rs:268-28
   L.flags &= ~JGF_REPL_MASK;
 }
 __device__ inline void jg_become_leader(const JgDev& d, JgLane& L) {  // candidate.rs:216-238
-  for (uint32_t r = 0; r < d.R; r++)                                      // progress.rs:155-162
-    if (r != jg_self(L)) d.match[(size_t)r * d.G + L.g] = 0;
-  L.self_match = 0;
+  L.mword = 0;
+  L.mbase = L.head;
+  for (uint32_t r = 0; r < d.R; r++) jg_match_set(d, L, r, 0);            // progress.rs:155-162
   L.flags &= ~JGF_REPL_MASK;
   L.heartbeat_time = L.now;
   jg_set_role(L, JG_ROLE_LEADER);
@@ -498,15 +542,8 @@ __device__ inline uint32_t jg_leader_append_response(const JgDev& d, JgLane& L, 
   // leader.rs:211-219 -> progress.rs:42-46,76-94,133-140
   int s = jg_slot_of(d, node);
   if (s < 0) return JG_FAULT_PROGRESS_UNKNOWN_NODE;  // progress.rs:43
-  bool inc;
-  if ((uint32_t)s == jg_self(L)) {  // own slot: kept in the lane (implicit while SELF-SYNC)
-    inc = L.self_match < head;
-    if (inc) L.self_match = head;
-  } else {
-    size_t k = (size_t)s * d.G + L.g;
-    inc = d.match[k] < head;
-    if (inc) d.match[k] = head;
-  }
+  const bool inc = jg_match_get(d, L, (uint32_t)s) < head;
+  if (inc) jg_match_set(d, L, (uint32_t)s, head);
   uint32_t bit = 1u << (JGF_REPL_SHIFT + s);
   L.flags = inc ? (L.flags | bit) : (L.flags & ~bit);
   return jg_leader_commit(d, L);
@@ -525,7 +562,7 @@ __device__ inline uint32_t jg_leader_replicate(const JgDev& d, JgLane& L) {  // 
     if (r == self) continue;
     bool repl = (L.flags >> (JGF_REPL_SHIFT + r)) & 1u;
     uint32_t want = repl ? JG_MAX_INFLIGHT + 1 : 2;  // items consumed by skip(1).take(5) / nth(1)
-    uint64_t from = d.match[(size_t)r * d.G + L.g];
+    uint64_t from = jg_match_get(d, L, r);
     uint32_t k = jg_chain_blocks_from(d, L, from, want);
     if (k < want && key_in_range) return JG_FAULT_RANGE_HIT_COMMIT_KEY;  // chain.rs:219-226 (Q9)
     uint32_t n_blocks = k ? k - 1 : 0;

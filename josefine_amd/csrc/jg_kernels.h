@@ -201,7 +201,8 @@ __global__ void k_init_groups(JgDev d, const uint8_t* __restrict__ self_slots) {
     L.xq_k = 0;
     L.decisions = 0;
     L.term = 0;
-    L.self_match = 0;
+    L.mword = 0;
+    L.mbase = 0;
     L.commit = L.head = 0;   // Chain::new on an empty tree: genesis block 0
     L.id_gen = 1;
     L.run_hi = 0;
@@ -211,7 +212,7 @@ __global__ void k_init_groups(JgDev d, const uint8_t* __restrict__ self_slots) {
     uint32_t s = self_slots ? self_slots[g] : 0;
     L.flags = JG_ROLE_FOLLOWER | (s << JGF_SELF_SHIFT);
     jg_set_election_timeout(d, L);  // follower.rs:93-95 at now = 0
-    for (uint32_t r = 0; r < d.R; r++) d.match[(size_t)r * d.G + g] = 0;
+    d.mlag[g] = 0;  // every progress head 0 = lag 0 below head 0
     jg_store(d, L);
   }
 }

@@ -548,7 +548,8 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.head, G);
   A(d.id_gen, G);
   A(d.run_hi, G);
-  A(d.match, G * R);
+  A(d.mlag, G);
+  A(d.match_wide, G * R);
   A(d.election_time, G);
   A(d.heartbeat_time, G);
   A(d.win_lo, G * JG_CHAIN_WINDOW);
@@ -964,13 +965,14 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
       for (uint32_t i = 0; i < n; i++) o64[i] = (fl[i] & JGF_FAST) ? head[i] + 1 : t64[i];
       return JG_OK;
     }
-    case JG_FIELD_MATCH: {  // the own slot is implicit (== head) while the group is SELF-SYNC
-      std::vector<uint64_t> head(n);
+    case JG_FIELD_MATCH: {  // delta-packed: head - lag, or the wide column where the lag field is the escape
+      std::vector<uint64_t> head(n), wide(n);
       HIPCHK(hipMemcpy(head.data(), d.head + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
-      if ((rc = get64(d.match + (size_t)replica * d.G))) return rc;
+      HIPCHK(hipMemcpy(wide.data(), d.match_wide + (size_t)replica * d.G + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
+      if ((rc = get64(d.mlag))) return rc;
       for (uint32_t i = 0; i < n; i++) {
-        const bool own = ((fl[i] & JGF_SELF_MASK) >> JGF_SELF_SHIFT) == replica;
-        o64[i] = role(i) != JG_ROLE_LEADER ? 0 : (own && (fl[i] & JGF_SELF_SYNC)) ? head[i] : t64[i];
+        const uint64_t f = jg_lag_field(t64[i], replica, d.R);
+        o64[i] = role(i) != JG_ROLE_LEADER ? 0 : f == jg_lag_esc(d.R) ? wide[i] : head[i] - f;
       }
       return JG_OK;
     }

@@ -240,6 +240,43 @@ def test_dense_own_match_head_not_in_sync(fused):
     assert (ora.read("match", 0) == ora.read("head")).all() and int(ora.read("head")[0]) == T
 
 
+@pytest.mark.parametrize("R,per_tick", [(8, 10), (5, 150), (7, 20)])
+def test_progress_lag_escape(R, per_tick):
+    """Progress heads are stored as lags below the chain head, 64/R bits each; a replica that
+    falls further behind than the field holds (254 blocks at R = 8, 510 at R = 7, 4094 at R = 5)
+    switches to the wide column and comes back when it catches up — invisible in every result."""
+    G = 256
+    dev, ora = pair(G, R, seed=17)
+    for e in (dev, ora):
+        elect_all(e)
+        e.drain_messages(), e.drain_applies()
+    T = 30
+    for t in range(T):
+        acks = np.full((R, G), capi.NO_ACK, dtype=np.uint64)
+        acks[0, :] = per_tick
+        head_before = int(ora.read("head")[0])
+        if R > 1:
+            acks[1, ::2] = head_before            # slot 1 of the even groups keeps up ...
+            if t == 20:
+                acks[1, 1::2] = head_before       # ... of the odd groups only acks once, late
+        if R > 2 and t % 7 == 3:
+            acks[2, :] = max(head_before - 2 * per_tick, 0)   # slot 2 hovers around the field limit
+        dev.step_dense_acks(acks)
+        ora.step_dense_acks(acks)
+        compare_snapshots(dev, ora, f"lag escape R={R} tick {t}")
+    # through the general state machine as well (reads and rewrites the packed word)
+    for e in (dev, ora):
+        g = np.arange(G, dtype=np.uint32)
+        e.submit_columns(np.full(G, capi.CMD_APPEND_RESPONSE, np.uint8), g, from_=np.full(G, e.node_ids[R - 1], np.uint32),
+                         id=np.full(G, 5, np.uint64), flag=np.ones(G, np.uint8))
+        e.submit_columns(np.full(G, capi.CMD_CLIENT_REQUEST, np.uint8), g)
+        e.submit_columns(np.full(G, capi.CMD_TICK, np.uint8), g)
+        e.step(10_000)
+    compare_snapshots(dev, ora, f"lag escape R={R} sparse")
+    compare_drains(dev, ora, f"lag escape R={R} sparse")
+    assert int(ora.read("head")[0]) == T * per_tick + 1
+
+
 def test_chain_window_overflow_is_loud():
     """More gaps / forks than JG_CHAIN_WINDOW segments: an engine fault, never a silent miss."""
     dev = BatchedRaft(2, 3)
