@@ -28,9 +28,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 
 def alg_bytes_per_group_step(R: int) -> int:
     """Bytes the dense leader tick has to move per group-step with the engine's state layout
-    (DESIGN.md "k_leader_tick_dense"): read R ack heads (8 B each) + the packed progress word 8 +
-    commit 8 + head 8 + flags 4; write commit 8 + head 8  =>  8R + 44 (84 B at R = 5)."""
-    return 8 * R + 44
+    (DESIGN.md "k_leader_tick_dense"): read R ack heads (8 B each) + the packed progress / commit
+    word 8 + head 8 + flags 4; write head 8  =>  8R + 28 (68 B at R = 5)."""
+    return 8 * R + 28
 
 
 def survey_bytes_per_group_step(R: int) -> int:
@@ -91,11 +91,11 @@ def cpu_baseline(R: int, seed: int, budget_s: float):
 
 def node_alg_bytes(R: int):
     """Algorithmic bytes per group of one closed-loop protocol round (DESIGN.md "Dense node tick").
-    Leader half: the 8R + 44 of the ack tick + term 8 + heartbeat_time 8, HeartbeatResponse flags R-1,
+    Leader half: the 8R + 28 of the ack tick + term 8 + heartbeat_time 8, HeartbeatResponse flags R-1,
     outbox term 8 + hb_commit 8 + (R-1) x (ae_from 8 + ae_n 1).  Follower half, per
     follower: state read 56 + inbox 25, written head 8 + outbox 17, and every other tick (heartbeat)
     commit 8 + election timer 16."""
-    leader = (8 * R + 44) + 16 + (R - 1) + 16 + 9 * (R - 1)
+    leader = (8 * R + 28) + 16 + (R - 1) + 16 + 9 * (R - 1)
     follower = 56 + 25 + 8 + 17 + 12
     return leader, follower
 
@@ -374,7 +374,7 @@ def main():
             wall_b, dec_b = tb[0].item(), tdb[0].item()
         batched = {"ticks_per_launch": TB, "steps": K, "ms_per_step": wall_b * 1e3 / K,
                    "decisions_per_s": dec_b / wall_b,
-                   "bytes_moved_per_group_step": 8 * R + 44 / TB,
+                   "bytes_moved_per_group_step": 8 * R + 28 / TB,
                    "note": "same results bit for bit; state read/written once per launch"}
 
     if world > 1:

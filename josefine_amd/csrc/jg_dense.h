@@ -7,9 +7,10 @@
 //
 // Algorithmic bytes per group-step: B(R) = 24R + 36 — R ack heads,
 // R match heads, commit, head, term read (8 B each) + the 4-B flag word, R match heads
-// + commit written.  The kernel moves less: the R match heads are delta-packed into one
-// 64-bit word of lags below the chain head (jg_device.h), which in steady state does not
-// even change from tick to tick; it reads 8R + 28 and writes 16 bytes (84 B at R = 5).
+// + commit written.  The kernel moves less: the R match heads and the commit index are
+// delta-packed into one 64-bit word of lags below the chain head (jg_device.h), which in
+// steady state does not even change from tick to tick; it reads 8R + 20 and writes 8 bytes
+// (68 B at R = 5).
 //
 // Exactness of the fusion: the reference evaluates Leader::commit after every
 // ack.  match[] is monotone, hence so is committed_index(), and the guard
@@ -180,7 +181,6 @@ __device__ __forceinline__ void jg_dense_load(const JgDev& d, const uint64_t* __
     for (int k = 0; k + 1 < R; k++) x.ao[k] = JG_NO_ACK;
   }
   mword = d.mlag[g];
-  x.commit = d.commit[g];
   x.head = d.head[g];
 }
 // packed lags -> absolute progress heads (escaped fields: one more load, rare)
@@ -188,7 +188,9 @@ template <int R>
 __device__ __forceinline__ void jg_dense_unpack(const JgDev& d, uint32_t g, uint32_t s, uint64_t mword,
                                                 JgDenseRegs<R>& x) {
   const uint64_t esc = jg_lag_esc(R);
-  uint64_t f = jg_lag_field(mword, s, R);
+  uint64_t f = jg_lag_field(mword, R, R);  // field R: the commit index
+  x.commit = f == esc ? d.commit[g] : x.head - f;
+  f = jg_lag_field(mword, s, R);
   x.ms = f == esc ? d.match_wide[(size_t)s * d.G + g] : x.head - f;
 #pragma unroll
   for (int k = 0; k + 1 < R; k++) {
@@ -215,8 +217,10 @@ __device__ __forceinline__ void jg_dense_store(const JgDev& d, uint32_t g, uint3
     if (fl == esc) d.match_wide[(size_t)r * G + g] = x.mo[k];
     w = jg_lag_with(w, r, R, fl);
   }
+  fl = jg_lag_encode(x.commit, x.head, R);
+  if (fl == esc && (x.commit != commit0 || jg_lag_field(mword0, R, R) != esc)) d.commit[g] = x.commit;
+  w = jg_lag_with(w, R, R, fl);
   if (w != mword0) d.mlag[g] = w;
-  if (x.commit != commit0) d.commit[g] = x.commit;
   if (x.head != head0) d.head[g] = x.head;
   if (x.nf != f) d.flags[g] = x.nf;
 }
@@ -375,8 +379,8 @@ __device__ __forceinline__ uint32_t jg_dense_tick_body(const JgDev& d, const uin
       if (emit) jg_dense_outbox_none<R>(d, nd, g);  // (a deferred group's Tick: the slow kernel)
       continue;
     }
-    const uint64_t commit0 = x.commit, head0 = x.head;
     jg_dense_unpack<R>(d, g, s, mword0, x);
+    const uint64_t commit0 = x.commit, head0 = x.head;
     x.nf = f;
     dec += jg_dense_core<R>(d, g, seq, s, x);
     if (emit) {
@@ -431,8 +435,9 @@ __device__ __forceinline__ uint32_t jg_dense_ticks_body(const JgDev& d, const ui
     const bool defer = !dead && leader && !(f & JGF_FAST);      // irregular chain: k_dense_slow replays all ticks
     jg_defer_push(d, g, defer);
     if (dead || defer) continue;
-    const uint64_t commit0 = x.commit, head0 = x.head;
+    x.commit = 0;
     if (leader) jg_dense_unpack<R>(d, g, s, mword0, x);
+    const uint64_t commit0 = x.commit, head0 = x.head;
     x.nf = f;
     for (uint32_t t = 0; t < n_ticks; t++) {
       const bool more = t + 1 < n_ticks;

@@ -61,11 +61,11 @@ struct JgDev {
   uint32_t hb_timeout, el_min, el_max, cfg_flags;
   uint64_t seed, group_base;
   uint64_t* term;            // State.current_term                     mod.rs:277
-  uint64_t* commit;          // Chain.commit                           chain.rs:102
+  uint64_t* commit;          // Chain.commit (leaders: only where the packed lag escapes) chain.rs:102
   uint64_t* head;            // Chain.head                             chain.rs:103
   uint64_t* id_gen;          // Chain.id_gen (valid unless FAST)       chain.rs:101
   uint64_t* run_hi;          // segment 0: ids [0, run_hi], next = id-1 (valid unless FAST)
-  uint64_t* mlag;            // [G] Progress.head of all R slots, packed as lags below the chain head
+  uint64_t* mlag;            // [G] leaders: Progress.head of all R slots + Chain.commit, packed as lags below the chain head
   uint64_t* match_wide;      // [R][G] Progress.head of the slots whose lag field holds the escape value
   uint64_t* election_time;   // State.election_time (ms)               mod.rs:281
   uint64_t* heartbeat_time;  // Leader.heartbeat_time (ms)             leader.rs:27
@@ -104,16 +104,16 @@ __device__ __forceinline__ uint64_t jg_mix64(uint64_t z) {
 
 // ---- progress heads, delta-packed (progress.rs:124 `Progress.head`, one per replica) -----------
 // A follower's acknowledged head trails the leader's chain head by a few blocks (at most
-// MAX_INFLIGHT are in flight, progress.rs:117), so the R heads of a group are stored as R
-// lags `head - match[r]` of B = 64 / R bits in ONE 64-bit word (R = 5: 12 bits, R = 3: 21).  The
-// all-ones field is an escape: the absolute value then lives in match_wide[r][g] (a replica
-// that is far behind, or a forged ack above the head).  In steady state the lags do not change
-// from tick to tick, so the dense kernel reads 8 bytes of progress state per group and writes none
-// — instead of reading and writing R x 8.
-__host__ __device__ __forceinline__ uint32_t jg_lag_bits(uint32_t R) { return 64u / R; }
-__host__ __device__ __forceinline__ uint64_t jg_lag_esc(uint32_t R) {
-  return R == 1 ? ~0ull : (1ull << jg_lag_bits(R)) - 1ull;
-}
+// MAX_INFLIGHT are in flight, progress.rs:117), and the leader's commit index trails it by the
+// round trip, so a leader's R progress heads and its commit index are stored as R + 1 lags
+// `head - value` of B = 64 / (R + 1) bits in ONE 64-bit word (R = 5: 10 bits, R = 3: 16):
+// field r < R is slot r's progress head, field R the commit index.  The all-ones field is an
+// escape: the absolute value then lives in match_wide[r][g] / commit[g] (a replica that is far
+// behind, a forged ack above the head).  In steady state the lags do not change from tick to
+// tick, so the dense kernel reads 8 bytes of progress + commit state per group and writes none —
+// instead of reading and writing (R + 1) x 8.  Non-leaders keep the absolute commit column.
+__host__ __device__ __forceinline__ uint32_t jg_lag_bits(uint32_t R) { return 64u / (R + 1u); }
+__host__ __device__ __forceinline__ uint64_t jg_lag_esc(uint32_t R) { return (1ull << jg_lag_bits(R)) - 1ull; }
 __host__ __device__ __forceinline__ uint64_t jg_lag_field(uint64_t w, uint32_t r, uint32_t R) {
   return (w >> (r * jg_lag_bits(R))) & jg_lag_esc(R);
 }
@@ -197,7 +197,6 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
   L.g = g;
   L.flags = d.flags[g];
   L.term = d.term[g];
-  L.commit = d.commit[g];
   L.head = d.head[g];
   L.id_gen = (L.flags & JGF_FAST) ? L.head + 1 : d.id_gen[g];
   L.run_hi = (L.flags & JGF_RUN) ? L.head : d.run_hi[g];
@@ -211,7 +210,13 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
   L.votes = d.votes[g];
   L.mword = 0;
   L.mbase = L.head;
-  if ((L.flags & JGF_ROLE_MASK) == JG_ROLE_LEADER) L.mword = d.mlag[g];
+  if ((L.flags & JGF_ROLE_MASK) == JG_ROLE_LEADER) {
+    L.mword = d.mlag[g];
+    const uint64_t fc = jg_lag_field(L.mword, d.R, d.R);
+    L.commit = fc == jg_lag_esc(d.R) ? d.commit[g] : L.head - fc;
+  } else {
+    L.commit = d.commit[g];
+  }
   L.decisions = 0;
   L.overflow = 0;
   L.xq_on = 0;
@@ -227,11 +232,14 @@ __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   if (!fast && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L)) *d.irregular_seen = 1;
   if (jg_role(L) == JG_ROLE_LEADER) {
     if (L.mbase != L.head) jg_match_rebase(d, L);  // the head moved: the lags are relative to it
-    d.mlag[g] = L.mword;
+    const uint64_t fc = jg_lag_encode(L.commit, L.head, d.R);
+    if (fc == jg_lag_esc(d.R)) d.commit[g] = L.commit;
+    d.mlag[g] = jg_lag_with(L.mword, d.R, d.R, fc);
+  } else {
+    d.commit[g] = L.commit;
   }
   d.flags[g] = L.flags;
   d.term[g] = L.term;
-  d.commit[g] = L.commit;
   d.head[g] = L.head;
   d.id_gen[g] = L.id_gen;
   d.run_hi[g] = L.run_hi;

@@ -953,7 +953,17 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
   uint8_t* o8 = (uint8_t*)out;
   switch (field) {
     case JG_FIELD_TERM: return copy64(d.term);
-    case JG_FIELD_COMMIT: return copy64(d.commit);
+    case JG_FIELD_COMMIT: {  // leaders: packed as a lag below the head (field R of mlag), escape -> column
+      std::vector<uint64_t> head(n), col(n);
+      HIPCHK(hipMemcpy(head.data(), d.head + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(col.data(), d.commit + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
+      if ((rc = get64(d.mlag))) return rc;
+      for (uint32_t i = 0; i < n; i++) {
+        const uint64_t f = jg_lag_field(t64[i], d.R, d.R);
+        o64[i] = (role(i) != JG_ROLE_LEADER || f == jg_lag_esc(d.R)) ? col[i] : head[i] - f;
+      }
+      return JG_OK;
+    }
     case JG_FIELD_HEAD: return copy64(d.head);
     case JG_FIELD_ELECTION_TIME: return copy64(d.election_time);
     case JG_FIELD_ELECTION_TIMEOUT: return copy32(d.election_timeout);

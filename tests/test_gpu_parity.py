@@ -242,9 +242,10 @@ def test_dense_own_match_head_not_in_sync(fused):
 
 @pytest.mark.parametrize("R,per_tick", [(8, 10), (5, 150), (7, 20)])
 def test_progress_lag_escape(R, per_tick):
-    """Progress heads are stored as lags below the chain head, 64/R bits each; a replica that
-    falls further behind than the field holds (254 blocks at R = 8, 510 at R = 7, 4094 at R = 5)
-    switches to the wide column and comes back when it catches up — invisible in every result."""
+    """A leader's progress heads and commit index are stored as lags below the chain head,
+    64/(R+1) bits each; a value further behind than the field holds (126 blocks at R = 8, 254 at
+    R = 7, 1022 at R = 5) switches to its wide column and comes back when it catches up —
+    invisible in every result."""
     G = 256
     dev, ora = pair(G, R, seed=17)
     for e in (dev, ora):
