@@ -171,6 +171,8 @@ __device__ inline void jg_raise(const JgDev& d, JgLane& L, uint32_t code) {
   jg_push_fault(d, L.g, code, L.seq);
 }
 
+__device__ inline void jg_chain_normalize(const JgDev& d, JgLane& L);
+
 // Progress.head of slot r of the lane's group (leaders)
 __device__ inline uint64_t jg_match_get(const JgDev& d, const JgLane& L, uint32_t r) {
   const uint64_t f = jg_lag_field(L.mword, r, d.R);
@@ -224,6 +226,7 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
 }
 __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   uint32_t g = L.g;
+  if (jg_wcnt(L)) jg_chain_normalize(d, L);
   const bool run = (L.run_hi == L.head) && (jg_wcnt(L) == 0);
   const bool fast = run && (L.id_gen == L.head + 1);
   L.flags = run ? (L.flags | JGF_RUN) : (L.flags & ~JGF_RUN);
@@ -383,6 +386,31 @@ __device__ inline uint32_t jg_chain_insert(const JgDev& d, JgLane& L, uint64_t i
       return 0;
     }
   return jg_seg_add(d, L, id, id, next);
+}
+// Canonical form: a segment that continues the run (first id run_hi+1 with parent run_hi — e.g. a
+// gap that was filled later) is absorbed into it, repeatedly.  Then "the id set is [0, head] with
+// every parent id-1" holds exactly when run_hi == head and no segment is left, which is what the
+// RUN / FAST flags and the dense mailbox vocabulary are defined on.
+__device__ inline void jg_chain_normalize(const JgDev& d, JgLane& L) {
+  uint32_t n = jg_wcnt(L);
+  bool merged = n != 0;
+  while (merged) {
+    merged = false;
+    for (uint32_t w = 0; w < n; w++) {
+      if (JG_SEG(win_lo, w) == L.run_hi + 1 && JG_SEG(win_next, w) == L.run_hi) {
+        L.run_hi = JG_SEG(win_hi, w);
+        n--;
+        if (w != n) {
+          JG_SEG(win_lo, w) = JG_SEG(win_lo, n);
+          JG_SEG(win_hi, w) = JG_SEG(win_hi, n);
+          JG_SEG(win_next, w) = JG_SEG(win_next, n);
+        }
+        merged = n != 0;
+        break;
+      }
+    }
+  }
+  L.flags = (L.flags & ~JGF_WIN_MASK) | (n << JGF_WIN_SHIFT);
 }
 // number of block keys >= from, saturated at `cap` (unbounded range(from..), leader.rs:135,152-157)
 __device__ inline uint32_t jg_chain_blocks_from(const JgDev& d, const JgLane& L, uint64_t from, uint32_t cap) {

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
       c.from = 0;
       c.flag = 0;
       c.id = 0;
+      if (jg_wcnt(L)) jg_chain_normalize(d, L);
       const bool fast = L.run_hi == L.head && L.id_gen == L.head + 1 && jg_wcnt(L) == 0;
       if (!fast) {
         jg_apply(d, L, c, nullptr, nullptr);  // rows: the blocks are not id-consecutive
