@@ -1,0 +1,61 @@
+"""bench.py's contract with the driver: one JSON line on rank 0 with the agreed keys, the
+`roofline` and `cpu_baseline` objects, whole-job aggregation for N > 1 (two ranks on the one
+GPU of the box, gloo for the barrier / reductions), and the secondary modes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config"}
+
+
+def run(args, env=None, launcher=None):
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env={**os.environ, **(env or {})})
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_default_shape_small():
+    d = run(["--groups", "50000", "--steps", "40", "--warmup", "5", "--cpu-budget", "1"])
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 5 and d["higher_is_better"] is True
+    assert d["unit"] == "decisions/s" and d["dtype"] == "u64" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0
+    assert r["alg_bytes_per_group_step"] == 8 * 5 + 28 and r["survey_priced"]["bytes_per_group_step"] == 156
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    # value = decisions of all ranks / wall time: 5 decisions per group-step in the steady-state stream
+    assert abs(d["value"] / d["group_steps_per_s"] - 5.0) < 1e-6
+    assert d["batched_ticks"]["ticks_per_launch"] == 16
+
+
+def test_two_ranks_aggregate():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    d = run(["--gpus", "2", "--groups", "50000", "--steps", "30", "--warmup", "5"], env={"JG_BENCH_BACKEND": "gloo"},
+            launcher=launcher)
+    assert d["n_gpus"] == 2 and d["config"]["partitions_total"] == 100000
+    assert abs(d["value"] / d["group_steps_per_s"] - 5.0) < 1e-6
+    assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
+
+
+def test_cluster_and_failure_modes():
+    d = run(["--cluster", "--groups", "30000", "--steps", "20", "--warmup", "5"])
+    assert KEYS <= set(d) and "closed loop" in d["config"]["workload"] and d["value"] > 0
+    d = run(["--failures", "1", "--groups", "100000", "--steps", "24", "--warmup", "8", "--no-cpu-baseline"])
+    assert KEYS <= set(d) and d["roofline"] is None and d["value"] > 0
