@@ -431,6 +431,15 @@ def main():
                                   "frac": survey_bytes_per_group_step(R) * G * ticks_per_launch / launch_s / 1e9 / HBM_PEAK_GBS},
             },
         }
+        if hasattr(api, "calibrate_stream") and T == 1 and not args.failures:
+            # what a launch of this shape costs on this machine with no Raft logic in it: a plain
+            # streaming kernel with the same bytes per group, grid, workgroup size and stream
+            cal_us = C.c_float(0)
+            eng._check(api.calibrate_stream(h, max(K, 50), C.byref(cal_us)))
+            out["roofline"]["stream_ceiling"] = {
+                "kernel": f"k_stream_calib<{R}> (same bytes per group, no logic)",
+                "avg_launch_us": cal_us.value, "achieved": alg / (cal_us.value * 1e-6) / 1e9,
+                "unit": "GB/s", "kernel_vs_ceiling": cal_us.value / (launch_s * 1e6)}
         if args.failures:
             # several kernels per tick (dense + deferred-group replay + k_apply_rows) and host
             # drains inside the timed region: the event time is the whole tick, not one kernel

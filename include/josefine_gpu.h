@@ -410,6 +410,15 @@ int jg_timer_stop(jg_engine* e, float* ms);  /* record + synchronize + elapsed  
 int jg_synth_fill_acks_device(jg_engine* e, uint32_t mode, uint64_t tick, uint64_t* sim_dev,
                               uint64_t* acks_dev);
 
+/* Measurement aid (bench.py "roofline.stream_ceiling"): time a plain streaming kernel with the
+ * byte profile of the dense leader tick for this engine's (G, R) — per group R 8-byte reads from
+ * a rotating ack-sized buffer set larger than the Infinity Cache (non-temporal, like the ack
+ * stream), two resident 8-byte columns and one 4-byte column read, one 8-byte column written —
+ * and no Raft logic at all.  Same grid, workgroup size and stream as jg_step_dense_acks_device.
+ * *avg_us = average launch duration over `iters` launches (HIP events).  What a launch of this
+ * shape costs on the machine at hand: the practical ceiling next to the 8 TB/s spec peak. */
+int jg_calibrate_stream(jg_engine* e, uint32_t iters, float* avg_us);
+
 const char* jg_last_error(void);
 uint32_t jg_abi_version(void);
 

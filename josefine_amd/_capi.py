@@ -169,6 +169,7 @@ class Api:
         "timer_start": (C.c_int, [_P]),
         "timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
         "synth_fill_acks_device": (C.c_int, [_P, C.c_uint32, C.c_uint64, _P, _P]),
+        "calibrate_stream": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_float)]),
     }
     # only the oracle has these
     _ORACLE_PROTOS = {
@@ -208,5 +209,5 @@ HEADER_SYMBOLS = [
     "jg_step_dense_leader", "jg_step_dense_follower", "jg_chain_compact", "jg_sync", "jg_stream_wait",
     "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_read_state", "jg_get_counters",
     "jg_device_alloc", "jg_device_free", "jg_device_upload", "jg_device_download",
-    "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_last_error", "jg_abi_version",
+    "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_last_error", "jg_abi_version",
 ]

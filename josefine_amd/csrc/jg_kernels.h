@@ -188,6 +188,25 @@ __global__ void k_synth_acks(JgDev d, uint32_t mode, uint64_t tick, uint64_t* __
   }
 }
 
+// ---- stream calibration (jg_calibrate_stream) ----------------------------------------------------
+// The byte profile of k_leader_tick_dense<R> without any of its logic: R non-temporal 8-byte reads
+// per group from a streamed block, two resident 8-byte columns and a 4-byte column read, one
+// 8-byte column written in place.  What a launch of this shape costs on the machine at hand.
+template <int R>
+__global__ __launch_bounds__(JG_BLOCK) void k_stream_calib(const uint64_t* __restrict__ rot,
+                                                            const uint64_t* __restrict__ a8, uint64_t* b8,
+                                                            const uint32_t* __restrict__ c4, uint32_t G) {
+  for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
+    uint64_t v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = __builtin_nontemporal_load(&rot[(size_t)r * G + g]);
+    uint64_t s = a8[g] ^ b8[g] ^ c4[g];
+#pragma unroll
+    for (int r = 0; r < R; r++) s += v[r];
+    b8[g] = s;
+  }
+}
+
 // ---- engine init: RaftHandle::new for every group (mod.rs:428-435, follower.rs:68-95) ----------
 __global__ void k_init_groups(JgDev d, const uint8_t* __restrict__ self_slots) {
   for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < d.G; g += gridDim.x * blockDim.x) {

@@ -486,6 +486,12 @@ int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* 
   return JG_OK;
 }
 
+template <int R>
+void launch_calib(jg_engine* e, const uint64_t* rot, const uint64_t* a8, uint64_t* b8, const uint32_t* c4) {
+  hipLaunchKernelGGL(k_stream_calib<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, rot, a8, b8, c4,
+                     e->cfg.n_groups);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1085,6 +1091,52 @@ int jg_timer_stop(jg_engine* e, float* ms) {
   HIPCHK(hipEventRecord(e->ev1, e->stream));
   HIPCHK(hipEventSynchronize(e->ev1));
   HIPCHK(hipEventElapsedTime(ms, e->ev0, e->ev1));
+  return JG_OK;
+}
+
+int jg_calibrate_stream(jg_engine* e, uint32_t iters, float* avg_us) {
+  if (!e || !avg_us || !iters) return fail(JG_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  const size_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  const size_t blk = std::max<size_t>(G * R * 8, 16);
+  // enough ack-sized blocks to overflow the 256 MiB Infinity Cache, like the real ack stream
+  const size_t nbuf = std::min<size_t>(std::max<size_t>(((size_t)640 << 20) / blk + 1, 2), 64);
+  char* rot = nullptr;
+  uint64_t *a8 = nullptr, *b8 = nullptr;
+  uint32_t* c4 = nullptr;
+  HIPCHK(hipMalloc((void**)&rot, blk * nbuf));
+  HIPCHK(hipMalloc((void**)&a8, std::max<size_t>(G * 8, 16)));
+  HIPCHK(hipMalloc((void**)&b8, std::max<size_t>(G * 8, 16)));
+  HIPCHK(hipMalloc((void**)&c4, std::max<size_t>(G * 4, 16)));
+  HIPCHK(hipMemsetAsync(rot, 0, blk * nbuf, e->stream));
+  HIPCHK(hipMemsetAsync(a8, 0, std::max<size_t>(G * 8, 16), e->stream));
+  HIPCHK(hipMemsetAsync(b8, 0, std::max<size_t>(G * 8, 16), e->stream));
+  HIPCHK(hipMemsetAsync(c4, 0, std::max<size_t>(G * 4, 16), e->stream));
+  const uint32_t warm = 5;
+  for (uint32_t i = 0; i < warm + iters; i++) {
+    if (i == warm) HIPCHK(hipEventRecord(e->ev0, e->stream));
+    const uint64_t* r = (const uint64_t*)(rot + (i % nbuf) * blk);
+    switch (R) {
+      case 1: launch_calib<1>(e, r, a8, b8, c4); break;
+      case 2: launch_calib<2>(e, r, a8, b8, c4); break;
+      case 3: launch_calib<3>(e, r, a8, b8, c4); break;
+      case 4: launch_calib<4>(e, r, a8, b8, c4); break;
+      case 5: launch_calib<5>(e, r, a8, b8, c4); break;
+      case 6: launch_calib<6>(e, r, a8, b8, c4); break;
+      case 7: launch_calib<7>(e, r, a8, b8, c4); break;
+      default: launch_calib<8>(e, r, a8, b8, c4); break;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev1, e->stream));
+  HIPCHK(hipEventSynchronize(e->ev1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  *avg_us = ms * 1000.0f / (float)iters;
+  HIPCHK(hipFree(rot));
+  HIPCHK(hipFree(a8));
+  HIPCHK(hipFree(b8));
+  HIPCHK(hipFree(c4));
   return JG_OK;
 }
 

@@ -34,6 +34,8 @@ def test_default_shape_small():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0
     assert r["alg_bytes_per_group_step"] == 8 * 5 + 28 and r["survey_priced"]["bytes_per_group_step"] == 156
+    sc = r["stream_ceiling"]  # the same bytes through a kernel with no logic, measured in the same run
+    assert sc["avg_launch_us"] > 0 and abs(sc["kernel_vs_ceiling"] - sc["avg_launch_us"] / r["avg_launch_us"]) < 1e-6
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     # value = decisions of all ranks / wall time: 5 decisions per group-step in the steady-state stream
