@@ -32,6 +32,22 @@
 #define JG_BLOCK 256
 #endif
 
+// The columns the hot path of the ack-only kernel touches, as kernel arguments of their own; the
+// rest of JgDev reaches that kernel as a pointer to a device-resident copy and is dereferenced on
+// the general path only (kernel arguments are loop-invariant loads the compiler hoists into the
+// prologue of every wave: ~40 pointers cost SGPR spills and an occupancy step).
+struct JgDenseHot {
+  uint32_t* flags;
+  uint64_t* mlag;
+  uint64_t* head;
+  uint64_t* blk_decisions;
+  uint32_t G;
+};
+__device__ __forceinline__ JgDenseHot jg_dense_hot_of(const JgDev& d) {
+  return JgDenseHot{d.flags, d.mlag, d.head, d.blk_decisions, d.G};
+}
+
+
 // ---- wave64 / workgroup reduction of the per-lane decision counts --------------------
 // One fire-and-forget atomic per workgroup into the workgroup's own slot (no contention,
 // no return value: the wave does not wait for it; a load/add/store would keep the
@@ -161,27 +177,37 @@ __device__ __forceinline__ uint32_t jg_dense_core(const JgDev& d, uint32_t g, ui
   return dec;
 }
 
-// Issue every load of one group whose address is known without the flag word.
+// Issue every load of one group whose address is known without the flag word: the R slots of
+// the ack block by constant index (the own slot carries the number of appends), the packed
+// progress / commit word and the chain head.
 template <int R>
 __device__ __forceinline__ void jg_dense_load_acks(const uint64_t* __restrict__ acks, uint32_t G, uint32_t g,
-                                                   uint32_t s, uint64_t& n_app, uint64_t (&ao)[JgDenseRegs<R>::O]) {
-  n_app = __builtin_nontemporal_load(&acks[(size_t)s * G + g]);
+                                                   uint64_t (&a)[R]) {
 #pragma unroll
-  for (int k = 0; k + 1 < R; k++) ao[k] = __builtin_nontemporal_load(&acks[(size_t)jg_other_slot(k, s) * G + g]);
+  for (int r = 0; r < R; r++) a[r] = __builtin_nontemporal_load(&acks[(size_t)r * G + g]);
 }
+// the ack block in "self + others" form for own slot s (selects, no loads)
 template <int R>
-__device__ __forceinline__ void jg_dense_load(const JgDev& d, const uint64_t* __restrict__ acks, uint32_t g,
-                                              uint32_t s, JgDenseRegs<R>& x, uint64_t& mword) {
-  const uint32_t G = d.G;
-  if (acks) {
-    jg_dense_load_acks<R>(acks, G, g, s, x.n_app, x.ao);
-  } else {  // node tick without acks
-    x.n_app = 0;
+__device__ __forceinline__ void jg_dense_split_acks(const uint64_t (&a)[R], uint32_t s, uint64_t& n_app,
+                                                    uint64_t (&ao)[JgDenseRegs<R>::O]) {
+  n_app = a[0];
 #pragma unroll
-    for (int k = 0; k + 1 < R; k++) x.ao[k] = JG_NO_ACK;
+  for (int r = 1; r < R; r++) n_app = (uint32_t)r == s ? a[r] : n_app;
+#pragma unroll
+  for (int k = 0; k + 1 < R; k++) ao[k] = (uint32_t)k >= s ? a[k + 1] : a[k];
+  if (R == 1) ao[0] = JG_NO_ACK;
+}
+template <int R, bool MAYBE_NO_ACKS = true>
+__device__ __forceinline__ void jg_dense_load(const JgDenseHot& d, const uint64_t* __restrict__ acks, uint32_t g,
+                                              uint64_t (&a)[R], uint64_t& mword, uint64_t& head) {
+  if (!MAYBE_NO_ACKS || acks) {  // (the ack-only kernel always has an ack block: no branch in its loop)
+    jg_dense_load_acks<R>(acks, d.G, g, a);
+  } else {  // node tick without acks: nothing to append, no AppendResponse
+#pragma unroll
+    for (int r = 0; r < R; r++) a[r] = JG_NO_ACK;
   }
   mword = d.mlag[g];
-  x.head = d.head[g];
+  head = d.head[g];
 }
 // packed lags -> absolute progress heads (escaped fields: one more load, rare)
 template <int R>
@@ -198,6 +224,98 @@ __device__ __forceinline__ void jg_dense_unpack(const JgDev& d, uint32_t g, uint
     f = jg_lag_field(mword, r, R);
     x.mo[k] = f == esc ? d.match_wide[(size_t)r * d.G + g] : x.head - f;
   }
+}
+
+// ---- the tick in lag space -----------------------------------------------------------------------
+// The common case never leaves the packed representation.  With every field of the progress
+// word un-escaped, every ack at or below the chain head and within 2^32 of it, and fewer than
+// 2^20 appends, the whole tick is 32-bit arithmetic on lags below the head:
+//   match[r] = max(match[r], ack[r])          <=>  lag[r] = min(lag[r], head0 - ack[r])
+//   increment() returned true (-> Replicate)  <=>  head0 - ack[r] < lag[r]         progress.rs:133-140
+//   n appends + self-acks                     <=>  every lag += n, own lag = 0     leader.rs:177-197
+//   element R/2 of the heads sorted desc.     <=>  element R/2 of the lags sorted ascending
+//   commit = max(commit, q)                   <=>  clag = min(clag + n, qlag)      leader.rs:89-92
+// Old heads and acks <= head0 is exactly the precondition of the fused path of jg_dense_core
+// (no chain.commit panic possible), so the two agree bit for bit; anything else (escaped field,
+// forged ack above the head, a lag that no longer fits its field) returns false with nothing
+// modified and the caller takes the general register path.
+template <int R>
+struct JgLagTick {
+  uint64_t w1, head1;  // new packed word, new chain head
+  uint32_t nf;         // new flag word
+  uint32_t l[R + 1];   // new lags below head1 (field R: commit)
+};
+
+// element K of v[0..R) sorted ascending
+template <int R>
+__device__ __forceinline__ uint32_t jg_kth_lag(const uint32_t (&v)[R + 1]) {
+  constexpr int K = R / 2;
+  if (R == 3) {  // median of 3
+    const uint32_t lo = min(v[0], v[1]), hi = max(v[0], v[1]);
+    return max(lo, min(hi, v[2]));
+  } else if (R == 5) {  // median of 5: med3(e, max(min(a,b), min(c,d)), min(max(a,b), max(c,d)))
+    const uint32_t x = max(min(v[0], v[1]), min(v[2], v[3]));
+    const uint32_t y = min(max(v[0], v[1]), max(v[2], v[3]));
+    const uint32_t lo = min(x, y), hi = max(x, y);
+    return max(lo, min(hi, v[4]));
+  } else {
+    uint32_t q = 0;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < R; i++) cnt += (v[i] < v[j] || (v[i] == v[j] && i < j)) ? 1 : 0;
+      q = (cnt == K) ? v[j] : q;
+    }
+    return q;
+  }
+}
+
+template <int R>
+__device__ __forceinline__ bool jg_lag_tick(uint32_t s, uint32_t f, uint64_t w0, uint64_t head0, uint64_t n_app,
+                                            const uint64_t (&a)[R], JgLagTick<R>& o, uint32_t& dec) {
+  constexpr uint32_t B = 64u / (R + 1u);
+  if (B > 21) return false;  // R = 1: 32-bit fields, take the register path
+  constexpr uint32_t ESC = (uint32_t)((1ull << (B > 21 ? 21 : B)) - 1ull);
+  bool bad = (n_app >> 20) != 0;
+  const uint32_t n = (uint32_t)n_app;
+  uint32_t nf = f, dc = n;
+  // branch-free per slot (the own slot is engine-uniform in the normal case: scalar selects)
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const uint32_t fr = (uint32_t)(w0 >> (r * B)) & ESC;
+    const uint32_t bit = 1u << (JGF_REPL_SHIFT + r);
+    const bool self = (uint32_t)r == s;
+    const uint64_t ar = a[r];
+    unsigned long long dk;
+    const bool above = __builtin_usubll_overflow((unsigned long long)head0, (unsigned long long)ar, &dk);  // ack > head
+    const bool some = !self && ar != JG_NO_ACK;
+    const uint32_t dl = (uint32_t)dk;
+    const bool inc = some && dl < fr;  // progress.rs:133-140: increment() returned true
+    // own slot: n self-acks, the last one decides (-> Replicate); others: per ack
+    const bool set = self ? n != 0 : inc, clr = some && !inc;
+    nf = (nf | (set ? bit : 0u)) & ~(clr ? bit : 0u);
+    dc += some ? 1u : 0u;
+    const uint32_t lo = self ? (n ? 0u : fr) : (inc ? dl : fr) + n;
+    o.l[r] = lo;
+    bad |= fr == ESC || lo >= ESC || (some && (above || (uint32_t)(dk >> 32) != 0u));
+  }
+  const uint32_t fc = (uint32_t)(w0 >> (R * B)) & ESC;
+  bad |= fc == ESC;
+  const uint32_t lc = fc + n;
+  const uint32_t ql = jg_kth_lag<R>(o.l);  // progress.rs:48-60
+  nf = ql < lc ? (nf | JGF_COMMIT_KEY) : nf;  // leader.rs:89-92, chain.rs:198
+  o.l[R] = min(lc, ql);
+  bad |= o.l[R] >= ESC;
+  if (bad) return false;
+  uint64_t w = 0;
+#pragma unroll
+  for (int r = 0; r <= R; r++) w |= (uint64_t)o.l[r] << (r * B);
+  o.w1 = w;
+  o.head1 = head0 + n;
+  o.nf = nf;
+  dec += dc;
+  return true;
 }
 
 // Store what changed: the lags re-packed against the new head (in steady state the same
@@ -348,58 +466,279 @@ __device__ __forceinline__ void jg_dense_outbox_none(const JgDev& d, const JgLea
 // NODE: jg_step_dense_leader — HeartbeatResponse input and / or the Tick's outbox.
 // (A two-groups-per-lane variant with 16-B accesses measured no faster — the kernel is
 // bandwidth-, not issue-bound: profiles/README.md round 1 — and was dropped.)
+// Everything one group-step reads, as issued loads (no use of the values: the loads of the next
+// group can be in flight while this one is evaluated).
+template <int R>
+struct JgDenseIn {
+  uint32_t f;
+  uint64_t a[R], w, head;
+  uint64_t term, hbt;  // NODE
+  uint8_t hbr[R];      // NODE
+};
 template <int R, bool UNIFORM, bool NODE>
-__device__ __forceinline__ uint32_t jg_dense_tick_body(const JgDev& d, const uint64_t* __restrict__ acks,
-                                                       uint32_t seq, uint32_t us, const JgLeaderNode& nd) {
-  const uint32_t G = d.G;
+__device__ __forceinline__ void jg_dense_issue(const JgDenseHot& h, const JgDev* dp,
+                                               const uint64_t* __restrict__ acks, uint32_t us,
+                                               const JgLeaderNode& nd, bool emit, uint32_t g, JgDenseIn<R>& in) {
+  in.f = h.flags[g];
+  jg_dense_load<R, NODE>(h, acks, g, in.a, in.w, in.head);
+  // keep the flag load up here, in the same round trip as the others: without a use the
+  // compiler sinks it behind the hot-path test (a second, dependent trip to HBM per group)
+  asm volatile("" ::"v"(in.f));
+  __builtin_amdgcn_sched_barrier(0);
+  in.term = in.hbt = 0;
+  if (NODE) {
+    const JgDev& d = *dp;
+    if (emit) {
+      in.term = d.term[g];
+      in.hbt = d.heartbeat_time[g];
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)  // (the own slot's entry is never looked at)
+      in.hbr[r] = nd.hbr_has && !(UNIFORM && (uint32_t)r == us) ? nd.hbr_has[(size_t)r * h.G + g] : (uint8_t)JG_HB_NONE;
+  }
+}
+
+// ---- the general path of the ack-only kernel, in memory form ------------------------------------
+// Same results as jg_dense_unpack + jg_dense_core + jg_dense_store (the register form the node tick
+// and the T-tick kernel use), written as rolled loops over a per-lane LDS column of the R progress
+// heads: a handful of registers instead of ~90, because the register allocation of a kernel is the
+// maximum over all its paths and this one is taken by almost no group (escaped lag fields, acks
+// above the head, non-leaders, irregular chains).  Inputs are read again from memory.
+template <int R>
+__device__ __forceinline__ uint64_t jg_lds_kth(const uint64_t (*sm)[JG_BLOCK]) {
+  // element R/2 of the heads sorted descending (progress.rs:48-60) by rank counting
+  const uint32_t t = threadIdx.x;
+  uint64_t q = 0;
+#pragma clang loop unroll(disable)
+  for (int j = 0; j < R; j++) {
+    const uint64_t vj = sm[j][t];
+    int cnt = 0;
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < R; i++) {
+      const uint64_t vi = sm[i][t];
+      cnt += (vi > vj || (vi == vj && i < j)) ? 1 : 0;
+    }
+    q = (cnt == R / 2) ? vj : q;
+  }
+  return q;
+}
+
+template <int R, bool UNIFORM>
+__device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t* __restrict__ acks, uint32_t seq,
+                                               uint32_t us, uint32_t g, uint32_t& dec, uint64_t (*sm)[JG_BLOCK]) {
+  const uint32_t G = d.G, t = threadIdx.x;
+  const uint32_t f = d.flags[g];
+  const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
+  const uint64_t n_app = acks ? acks[(size_t)s * G + g] : 0;
+  const int cls = jg_dense_classify(d, g, f, n_app, seq);
+  jg_defer_push(d, g, cls == JG_DENSE_DEFER);
+  if (cls != JG_DENSE_RUN) return;
+  const uint32_t B = jg_lag_bits(R);
+  const uint64_t esc = jg_lag_esc(R);
+  const uint64_t w0 = d.mlag[g], head0 = d.head[g];
+  // packed lags -> absolute progress heads (escaped fields: the wide column)
+  uint64_t hi = 0;
+#pragma clang loop unroll(disable)
+  for (int r = 0; r < R; r++) {
+    const uint64_t fl = (w0 >> (r * B)) & esc;
+    const uint64_t v = fl == esc ? d.match_wide[(size_t)r * G + g] : head0 - fl;
+    sm[r][t] = v;
+    hi = v > hi ? v : hi;
+    if ((uint32_t)r != s && acks) {
+      const uint64_t a = acks[(size_t)r * G + g];
+      hi = (a != JG_NO_ACK && a > hi) ? a : hi;
+    }
+  }
+  const uint64_t fc = (w0 >> (R * B)) & esc;
+  const uint64_t commit0 = fc == esc ? d.commit[g] : head0 - fc;
+  uint64_t commit = commit0, head = head0;
+  uint32_t nf = f, fault = 0, dc = 0;
+  const bool fused = hi <= head0;  // no chain.commit panic possible: one majority evaluation
+  // appends with their self-acks (leader.rs:177-197); replayed one at a time unless fused
+  if (fused) {
+    head = head0 + n_app;
+    if (n_app) {
+      const bool inc = sm[s][t] < head;
+      if (inc) sm[s][t] = head;
+      nf = inc ? (nf | (1u << (JGF_REPL_SHIFT + s))) : (nf & ~(1u << (JGF_REPL_SHIFT + s)));
+      dc += (uint32_t)n_app;
+    }
+  } else {
+    for (uint64_t i = 0; i < n_app && !fault; i++) {
+      head += 1;
+      const bool inc = sm[s][t] < head;
+      if (inc) sm[s][t] = head;
+      nf = inc ? (nf | (1u << (JGF_REPL_SHIFT + s))) : (nf & ~(1u << (JGF_REPL_SHIFT + s)));
+      dc += 1;
+      const uint64_t q = jg_lds_kth<R>(sm);
+      if (q > commit) {
+        if (q <= head) commit = q;
+        else fault = JG_FAULT_COMMIT_MISSING_BLOCK;  // chain.rs:197-202
+      }
+    }
+  }
+  // the other slots' acks, ascending (progress.rs:76-94,133-140); one Leader::commit each unless fused
+#pragma clang loop unroll(disable)
+  for (int r = 0; r < R; r++) {
+    if ((uint32_t)r == s || !acks || fault) continue;
+    const uint64_t a = acks[(size_t)r * G + g];
+    if (a == JG_NO_ACK) continue;
+    const bool inc = sm[r][t] < a;
+    if (inc) sm[r][t] = a;
+    nf = inc ? (nf | (1u << (JGF_REPL_SHIFT + r))) : (nf & ~(1u << (JGF_REPL_SHIFT + r)));
+    dc += 1;
+    if (!fused) {
+      const uint64_t q = jg_lds_kth<R>(sm);
+      if (q > commit) {
+        if (q <= head) commit = q;
+        else fault = JG_FAULT_COMMIT_MISSING_BLOCK;
+      }
+    }
+  }
+  if (fused) {
+    const uint64_t q = jg_lds_kth<R>(sm);  // progress.rs:48-60
+    commit = q > commit ? q : commit;      // leader.rs:89-92
+  }
+  if (fault) {
+    nf |= fault << JGF_FAULT_SHIFT;
+    jg_push_fault(d, g, fault, seq);
+  }
+  if (commit != commit0) nf |= JGF_COMMIT_KEY;  // chain.rs:198
+  dec += dc;
+  // store what changed: the lags re-packed against the new head
+  uint64_t w = 0;
+#pragma clang loop unroll(disable)
+  for (int r = 0; r < R; r++) {
+    const uint64_t v = sm[r][t];
+    const uint64_t fl = jg_lag_encode(v, head, R);
+    if (fl == esc) d.match_wide[(size_t)r * G + g] = v;
+    w |= fl << (r * B);
+  }
+  const uint64_t fl = jg_lag_encode(commit, head, R);
+  if (fl == esc && (commit != commit0 || fc != esc)) d.commit[g] = commit;
+  w |= fl << (R * B);
+  if (w != w0) d.mlag[g] = w;
+  if (head != head0) d.head[g] = head;
+  if (nf != f) d.flags[g] = nf;
+}
+
+template <int R, bool UNIFORM, bool NODE>
+__device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev* dp,
+                                               const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us, const JgLeaderNode& nd, bool emit, uint32_t g,
+                                               const JgDenseIn<R>& in, uint32_t& dec, uint64_t (*sm)[JG_BLOCK]) {
+  const uint32_t f = in.f;
+  const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
+  const uint64_t mword0 = in.w, head0 = in.head, term = in.term, hbt = in.hbt;
+  bool hbr_trigger = false;
+  if (NODE) {  // leader.rs:222-231: a response without the commit makes the leader replicate again
+#pragma unroll
+    for (int r = 0; r < R; r++) hbr_trigger |= (uint32_t)r != s && in.hbr[r] == 0;
+  }
+  uint64_t n_app = in.a[0];
+#pragma unroll
+  for (int r = 1; r < R; r++) n_app = (uint32_t)r == s ? in.a[r] : n_app;
+  if (NODE && !acks) n_app = 0;
+  JgDenseRegs<R> x;
+  x.head = head0;
+  // ---- hot path: a healthy leader in FAST form whose tick stays in lag space --------------------
+  // straight-line 32-bit arithmetic, evaluated for every lane; everything else is behind one
+  // (normally wave-uniform, not taken) branch
+  JgLagTick<R> lt;
+  uint32_t dl = 0;
+  bool hot = (f & (JGF_FAULT_MASK | JGF_ROLE_MASK | JGF_FAST)) == (JG_ROLE_LEADER | JGF_FAST);
+  if (NODE) hot = hot && !hbr_trigger;
+  hot = jg_lag_tick<R>(s, f, mword0, head0, n_app, in.a, lt, dl) && hot;
+  if (__builtin_expect(hot, 1)) {
+    dec += dl;
+    if (emit) {  // the Tick reads absolute progress heads
+      x.head = lt.head1, x.nf = lt.nf, x.commit = lt.head1 - lt.l[R];
+#pragma unroll
+      for (int k = 0; k + 1 < R; k++) x.mo[k] = lt.head1 - ((uint32_t)k >= s ? lt.l[k + 1] : lt.l[k]);
+      jg_dense_leader_tick<R>(*dp, nd, g, seq, s, term, hbt, x);  // may raise the Q9 fault in x.nf
+      lt.nf = x.nf;
+    }
+    if (lt.w1 != mword0) h.mlag[g] = lt.w1;
+    if (lt.head1 != head0) h.head[g] = lt.head1;
+    if (lt.nf != f) h.flags[g] = lt.nf;
+    return;
+  }
+  const JgDev& d = *dp;  // (the ack-only kernel: loads from the device copy, general path only)
+  // ---- everything else ---------------------------------------------------------------------------
+  if (!NODE) {  // the ack-only kernel: rolled loops over LDS, so that the kernel's register
+                // allocation (= its occupancy) is the hot path's
+    jg_dense_cold_lds<R, UNIFORM>(d, acks, seq, us, g, dec, sm);
+    return;
+  }
+  int cls = jg_dense_classify(d, g, f, n_app, seq);
+  if (NODE && cls == JG_DENSE_RUN && hbr_trigger) cls = JG_DENSE_DEFER;  // extra AppendEntries: rows
+  jg_defer_push(d, g, cls == JG_DENSE_DEFER);
+  if (cls != JG_DENSE_RUN) {
+    if (emit) jg_dense_outbox_none<R>(d, nd, g);  // (a deferred group's Tick: the slow kernel)
+    return;
+  }
+  // ---- general register path (escaped fields, acks above the head, ...) ------------------------
+  jg_dense_split_acks<R>(in.a, s, x.n_app, x.ao);
+  x.n_app = n_app;
+  jg_dense_unpack<R>(d, g, s, mword0, x);
+  const uint64_t commit0 = x.commit;
+  x.nf = f;
+  dec += jg_dense_core<R>(d, g, seq, s, x);
+  if (emit) {
+    if (x.nf & JGF_FAULT_MASK) jg_dense_outbox_none<R>(d, nd, g);  // the process died before its Tick
+    else jg_dense_leader_tick<R>(d, nd, g, seq, s, term, hbt, x);
+  }
+  jg_dense_store<R>(d, g, s, f, mword0, x, commit0, head0);
+}
+
+// Grid-stride loop with the next group's loads issued before the current group is evaluated
+// (JG_DENSE_PREFETCH): a lane that serves several groups keeps HBM requests in flight during
+// its arithmetic.
+#ifndef JG_DENSE_PREFETCH
+#define JG_DENSE_PREFETCH 0
+#endif
+template <int R, bool UNIFORM, bool NODE>
+__device__ __forceinline__ uint32_t jg_dense_tick_body(const JgDenseHot& h, const JgDev* dp,
+                                                       const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us,
+                                                       const JgLeaderNode& nd, uint64_t (*sm)[JG_BLOCK]) {
+  const uint32_t G = h.G, stride = gridDim.x * JG_BLOCK;
   const bool emit = NODE && nd.o_term != nullptr;
   uint32_t dec = 0;
-  for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
-    const uint32_t f = d.flags[g];
-    const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
-    JgDenseRegs<R> x;
-    uint64_t mword0;
-    jg_dense_load<R>(d, acks, g, s, x, mword0);
-    uint64_t term = 0, hbt = 0;
-    bool hbr_trigger = false;
-    if (NODE) {
-      if (emit) {
-        term = d.term[g];
-        hbt = d.heartbeat_time[g];
-      }
-      if (nd.hbr_has) {  // leader.rs:222-231: a response without the commit makes the leader replicate again
-#pragma unroll
-        for (int k = 0; k + 1 < R; k++) hbr_trigger |= nd.hbr_has[(size_t)jg_other_slot(k, s) * G + g] == 0;
-      }
+  uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x;
+  if (JG_DENSE_PREFETCH && !NODE) {
+    JgDenseIn<R> cur, nxt;
+    if (g < G) jg_dense_issue<R, UNIFORM, NODE>(h, dp, acks, us, nd, emit, g, cur);
+    while (g < G) {
+      const uint32_t gn = g + stride;
+      if (gn < G) jg_dense_issue<R, UNIFORM, NODE>(h, dp, acks, us, nd, emit, gn, nxt);
+      jg_dense_group<R, UNIFORM, NODE>(h, dp, acks, seq, us, nd, emit, g, cur, dec, sm);
+      cur = nxt;
+      g = gn;
     }
-    int cls = jg_dense_classify(d, g, f, x.n_app, seq);
-    if (NODE && cls == JG_DENSE_RUN && hbr_trigger) cls = JG_DENSE_DEFER;  // extra AppendEntries: rows
-    jg_defer_push(d, g, cls == JG_DENSE_DEFER);
-    if (cls != JG_DENSE_RUN) {
-      if (emit) jg_dense_outbox_none<R>(d, nd, g);  // (a deferred group's Tick: the slow kernel)
-      continue;
+  } else {
+    for (; g < G; g += stride) {
+      JgDenseIn<R> in;
+      jg_dense_issue<R, UNIFORM, NODE>(h, dp, acks, us, nd, emit, g, in);
+      jg_dense_group<R, UNIFORM, NODE>(h, dp, acks, seq, us, nd, emit, g, in, dec, sm);
     }
-    jg_dense_unpack<R>(d, g, s, mword0, x);
-    const uint64_t commit0 = x.commit, head0 = x.head;
-    x.nf = f;
-    dec += jg_dense_core<R>(d, g, seq, s, x);
-    if (emit) {
-      if (x.nf & JGF_FAULT_MASK) jg_dense_outbox_none<R>(d, nd, g);  // the process died before its Tick
-      else jg_dense_leader_tick<R>(d, nd, g, seq, s, term, hbt, x);
-    }
-    jg_dense_store<R>(d, g, s, f, mword0, x, commit0, head0);
   }
   return dec;
 }
 
+#ifdef JG_DENSE_WPE
+#define JG_DENSE_ATTR __attribute__((amdgpu_waves_per_eu(JG_DENSE_WPE, JG_DENSE_WPE)))
+#else
+#define JG_DENSE_ATTR
+#endif
 template <int R>
-__global__ __launch_bounds__(JG_BLOCK) void k_leader_tick_dense(JgDev d, const uint64_t* __restrict__ acks,
-                                                                 uint32_t seq, int us) {
+__global__ __launch_bounds__(JG_BLOCK) JG_DENSE_ATTR void k_leader_tick_dense(JgDenseHot h, const JgDev* __restrict__ dp,
+                                                                               const uint64_t* __restrict__ acks,
+                                                                               uint32_t seq, int us) {
+  __shared__ uint64_t sm[R][JG_BLOCK];  // progress heads of the (rare) groups on the general path
   uint32_t dec;
   JgLeaderNode nd{};
-  if (us >= 0) dec = jg_dense_tick_body<R, true, false>(d, acks, seq, (uint32_t)us, nd);
-  else dec = jg_dense_tick_body<R, false, false>(d, acks, seq, 0, nd);
-  jg_block_count(d.blk_decisions, dec);
+  if (us >= 0) dec = jg_dense_tick_body<R, true, false>(h, dp, acks, seq, (uint32_t)us, nd, sm);
+  else dec = jg_dense_tick_body<R, false, false>(h, dp, acks, seq, 0, nd, sm);
+  jg_block_count(h.blk_decisions, dec);
 }
 
 // jg_step_dense_leader: the same tick with HeartbeatResponses in and / or the Tick's outbox out
@@ -407,8 +746,9 @@ template <int R>
 __global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDev d, const uint64_t* __restrict__ acks,
                                                                 uint32_t seq, int us, JgLeaderNode nd) {
   uint32_t dec;
-  if (us >= 0) dec = jg_dense_tick_body<R, true, true>(d, acks, seq, (uint32_t)us, nd);
-  else dec = jg_dense_tick_body<R, false, true>(d, acks, seq, 0, nd);
+  const JgDenseHot h = jg_dense_hot_of(d);
+  if (us >= 0) dec = jg_dense_tick_body<R, true, true>(h, &d, acks, seq, (uint32_t)us, nd, nullptr);
+  else dec = jg_dense_tick_body<R, false, true>(h, &d, acks, seq, 0, nd, nullptr);
   jg_block_count(d.blk_decisions, dec);
 }
 
@@ -428,8 +768,9 @@ __device__ __forceinline__ uint32_t jg_dense_ticks_body(const JgDev& d, const ui
     const uint32_t f = d.flags[g];
     const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
     JgDenseRegs<R> x;
-    uint64_t mword0;
-    jg_dense_load<R>(d, acks, g, s, x, mword0);
+    uint64_t a[R], mword0;
+    jg_dense_load<R>(jg_dense_hot_of(d), acks, g, a, mword0, x.head);
+    jg_dense_split_acks<R>(a, s, x.n_app, x.ao);
     const bool leader = (f & JGF_ROLE_MASK) == JG_ROLE_LEADER;
     const bool dead = (f & JGF_FAULT_MASK) != 0;                // the reference process is gone
     const bool defer = !dead && leader && !(f & JGF_FAST);      // irregular chain: k_dense_slow replays all ticks
@@ -441,9 +782,9 @@ __device__ __forceinline__ uint32_t jg_dense_ticks_body(const JgDev& d, const ui
     x.nf = f;
     for (uint32_t t = 0; t < n_ticks; t++) {
       const bool more = t + 1 < n_ticks;
-      uint64_t n_app_n = 0, an[JgDenseRegs<R>::O];
+      uint64_t an[R];
       if (more)  // software prefetch of the next tick's acks
-        jg_dense_load_acks<R>(acks + (size_t)(t + 1) * tick_stride, G, g, s, n_app_n, an);
+        jg_dense_load_acks<R>(acks + (size_t)(t + 1) * tick_stride, G, g, an);
       if (!leader) {
         // acks are ignored by followers / candidates (follower.rs:62, candidate.rs:194)
         if (x.n_app) {
@@ -455,11 +796,7 @@ __device__ __forceinline__ uint32_t jg_dense_ticks_body(const JgDev& d, const ui
         dec += jg_dense_core<R>(d, g, seq0 + t, s, x);
         if (x.nf & JGF_FAULT_MASK) break;
       }
-      if (more) {
-        x.n_app = n_app_n;
-#pragma unroll
-        for (int k = 0; k + 1 < R; k++) x.ao[k] = an[k];
-      }
+      if (more) jg_dense_split_acks<R>(an, s, x.n_app, x.ao);
     }
     if (leader) {
       jg_dense_store<R>(d, g, s, f, mword0, x, commit0, head0);

@@ -116,6 +116,7 @@ struct jg_engine {
   std::vector<void*> allocs;
   uint32_t count_slots = 0;  // workgroup slots of dev.blk_decisions
   uint32_t dense_grid = 0;
+  JgDev* d_dev = nullptr;  // device copy of `dev` (k_leader_tick_dense's general path)
   int uniform_self = 0;  // the own replica slot if it is the same for every group, else -1
   // device status block {err, irregular_seen, deferred_seen, fault_q_n, xq_n}: read back with one
   // copy into its pinned mirror at every synchronisation point
@@ -193,8 +194,9 @@ void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks, const Jg
     hipLaunchKernelGGL(k_leader_tick_dense_n<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
                        n_ticks, stride, e->seq, e->uniform_self);
   else
-    hipLaunchKernelGGL(k_leader_tick_dense<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
-                       e->seq, e->uniform_self);
+    hipLaunchKernelGGL(k_leader_tick_dense<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
+                       JgDenseHot{e->dev.flags, e->dev.mlag, e->dev.head, e->dev.blk_decisions, e->dev.G},
+                       (const JgDev*)e->d_dev, acks, e->seq, e->uniform_self);
 }
 
 int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1, const JgLeaderNode* nd = nullptr) {
@@ -228,6 +230,13 @@ int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1, con
 
 // The exceptional-message queue of the dense node steps, allocated at their first use:
 // (R + 3) rows per group bound what one tick can emit outside the mailbox vocabulary.
+// The device-resident copy of `dev` the ack-only dense kernel reads on its general path.
+int push_dev_copy(jg_engine* e) {
+  HIPCHK(hipMemcpyAsync(e->d_dev, &e->dev, sizeof(JgDev), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return JG_OK;
+}
+
 int ensure_xq(jg_engine* e) {
   if (e->dev.xq) return JG_OK;
   const size_t cap = std::max<size_t>((size_t)(e->cfg.n_replicas + 3) * e->cfg.n_groups, 65536);
@@ -237,7 +246,7 @@ int ensure_xq(jg_engine* e) {
   e->allocs.push_back(p);
   e->dev.xq = (JgXqRec*)p;
   e->dev.xq_cap = (uint32_t)cap;
-  return JG_OK;
+  return push_dev_copy(e);
 }
 
 // Everything that needs the stream idle first calls this: synchronise, surface
@@ -586,7 +595,9 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   }
   A(d.slow_list, (size_t)JG_SHARDS * d.slow_cap);
   A(d.slow_cnt, JG_SHARDS);
+  A(e->d_dev, 1);
 #undef A
+  if ((rc = push_dev_copy(e)) != JG_OK) return bail(rc);
   hipLaunchKernelGGL(k_init_groups, dim3(grid_for(G, 2048)), dim3(JG_BLOCK), 0, e->stream, e->dev,
                      (const uint8_t*)nullptr);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
