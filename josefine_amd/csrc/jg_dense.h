@@ -275,46 +275,52 @@ template <int R>
 __device__ __forceinline__ bool jg_lag_tick(uint32_t s, uint32_t f, uint64_t w0, uint64_t head0, uint64_t n_app,
                                             const uint64_t (&a)[R], JgLagTick<R>& o, uint32_t& dec) {
   constexpr uint32_t B = 64u / (R + 1u);
-  if (B > 21) return false;  // R = 1: 32-bit fields, take the register path
+  if (B > 21) return false;  // R = 1: 32-bit fields, take the general path
   constexpr uint32_t ESC = (uint32_t)((1ull << (B > 21 ? 21 : B)) - 1ull);
-  bool bad = (n_app >> 20) != 0;
   const uint32_t n = (uint32_t)n_app;
-  uint32_t nf = f, dc = n;
-  // branch-free per slot (the own slot is engine-uniform in the normal case: scalar selects)
+  bool bad = (n_app >> 20) != 0;
+  // any escaped field?  (one test on the whole word: a field is all ones <=> adding 1 to it carries out)
+  uint32_t incm = 0, somem = 0;  // per slot: increment() returned true / an ack arrived
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const uint32_t fr = (uint32_t)(w0 >> (r * B)) & ESC;
-    const uint32_t bit = 1u << (JGF_REPL_SHIFT + r);
-    const bool self = (uint32_t)r == s;
     const uint64_t ar = a[r];
-    unsigned long long dk;
-    const bool above = __builtin_usubll_overflow((unsigned long long)head0, (unsigned long long)ar, &dk);  // ack > head
+    const uint64_t dk = head0 - ar;
+    const bool self = (uint32_t)r == s;  // engine-uniform in the normal case: scalar
     const bool some = !self && ar != JG_NO_ACK;
-    const uint32_t dl = (uint32_t)dk;
-    const bool inc = some && dl < fr;  // progress.rs:133-140: increment() returned true
-    // own slot: n self-acks, the last one decides (-> Replicate); others: per ack
-    const bool set = self ? n != 0 : inc, clr = some && !inc;
-    nf = (nf | (set ? bit : 0u)) & ~(clr ? bit : 0u);
-    dc += some ? 1u : 0u;
-    const uint32_t lo = self ? (n ? 0u : fr) : (inc ? dl : fr) + n;
+    // lag of the ack below the old head; acks further than 2^32 behind are just "stale"
+    uint32_t dl = (uint32_t)(dk >> 32) ? 0xffffffffu : (uint32_t)dk;
+    dl = some ? dl : 0xffffffffu;
+    const bool inc = dl < fr;  // progress.rs:133-140: increment() returned true
+    incm |= inc ? (1u << r) : 0u;
+    somem |= some ? (1u << r) : 0u;
+    // own slot: n self-acks leave its head at the new chain head
+    const uint32_t lo = (self && n) ? 0u : min(fr, dl) + n;
     o.l[r] = lo;
-    bad |= fr == ESC || lo >= ESC || (some && (above || (uint32_t)(dk >> 32) != 0u));
+    bad |= fr == ESC;
+    bad |= lo >= ESC;
+    bad |= some && ar > head0;  // an ack above the head: replay, the reference may panic
   }
   const uint32_t fc = (uint32_t)(w0 >> (R * B)) & ESC;
-  bad |= fc == ESC;
   const uint32_t lc = fc + n;
   const uint32_t ql = jg_kth_lag<R>(o.l);  // progress.rs:48-60
-  nf = ql < lc ? (nf | JGF_COMMIT_KEY) : nf;  // leader.rs:89-92, chain.rs:198
-  o.l[R] = min(lc, ql);
-  bad |= o.l[R] >= ESC;
+  const uint32_t nl = min(lc, ql);         // leader.rs:89-92
+  o.l[R] = nl;
+  bad |= fc == ESC;
+  bad |= nl >= ESC;
   if (bad) return false;
+  // Probe / Replicate bits: cleared where an ack did not advance, set where one did; the own
+  // slot's last self-ack always advances (-> Replicate)
+  uint32_t nf = (f & ~(somem << JGF_REPL_SHIFT)) | (incm << JGF_REPL_SHIFT);
+  nf |= n ? (1u << (JGF_REPL_SHIFT + s)) : 0u;
+  nf |= ql < lc ? JGF_COMMIT_KEY : 0u;  // chain.rs:198
   uint64_t w = 0;
 #pragma unroll
   for (int r = 0; r <= R; r++) w |= (uint64_t)o.l[r] << (r * B);
   o.w1 = w;
   o.head1 = head0 + n;
   o.nf = nf;
-  dec += dc;
+  dec += n + (uint32_t)__popc(somem);
   return true;
 }
 
