@@ -69,6 +69,39 @@ __device__ __forceinline__ void jg_block_count(uint64_t* slots, uint32_t v) {
   }
 }
 
+// The dense leader kernels count without a barrier and without a reduction in the common case: a
+// wave whose lanes all took the same number of decisions in a group-step (the steady state: one
+// append + R-1 acks each) adds count x popcount(lanes) to the workgroup's slot with ONE
+// fire-and-forget atomic, issued before the step's stores so that its latency overlaps theirs (as
+// the last instruction of the wave it held the wave's slot for a full trip to L2: 0.8 us per
+// 1 M-group launch).  Uneven steps go through a per-lane counter that is reduced across the wave
+// at the end - if any lane used it at all.
+struct JgDecCount {
+  uint32_t lane = 0;  // per-lane decisions of uneven steps
+};
+__device__ __forceinline__ void jg_count_add(uint64_t* slots, uint32_t total) {
+  (void)__hip_atomic_fetch_add(&slots[blockIdx.x], (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// `on` marks the lanes that took n decisions in this step
+__device__ __forceinline__ void jg_count_step(uint64_t* slots, JgDecCount& c, bool on, uint32_t n) {
+  const uint64_t m = __ballot(on);
+  if (!m) return;
+  const int first = __ffsll((long long)m) - 1;
+  const uint32_t n0 = __builtin_amdgcn_readlane(n, first);
+  if (__ballot(on && n != n0) == 0) {
+    if ((int)(threadIdx.x & 63u) == first && n0) jg_count_add(slots, n0 * (uint32_t)__popcll(m));
+  } else {
+    c.lane += on ? n : 0u;
+  }
+}
+__device__ __forceinline__ void jg_wave_count(uint64_t* slots, const JgDecCount& c) {
+  uint32_t v = c.lane;
+  if (__ballot(v != 0) == 0) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63u) == 0 && v) jg_count_add(slots, v);
+}
+
 // One group's tick in registers.  O = max(R-1, 1) other slots.
 template <int R>
 struct JgDenseRegs {
@@ -531,7 +564,7 @@ __device__ __forceinline__ uint64_t jg_lds_kth(const uint64_t (*sm)[JG_BLOCK]) {
 
 template <int R, bool UNIFORM>
 __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t* __restrict__ acks, uint32_t seq,
-                                               uint32_t us, uint32_t g, uint32_t& dec, uint64_t (*sm)[JG_BLOCK]) {
+                                               uint32_t us, uint32_t g, JgDecCount& dec, uint64_t (*sm)[JG_BLOCK]) {
   const uint32_t G = d.G, t = threadIdx.x;
   const uint32_t f = d.flags[g];
   const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
@@ -610,7 +643,7 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
     jg_push_fault(d, g, fault, seq);
   }
   if (commit != commit0) nf |= JGF_COMMIT_KEY;  // chain.rs:198
-  dec += dc;
+  dec.lane += dc;
   // store what changed: the lags re-packed against the new head
   uint64_t w = 0;
 #pragma clang loop unroll(disable)
@@ -631,7 +664,7 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
 template <int R, bool UNIFORM, bool NODE>
 __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev* dp,
                                                const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us, const JgLeaderNode& nd, bool emit, uint32_t g,
-                                               const JgDenseIn<R>& in, uint32_t& dec, uint64_t (*sm)[JG_BLOCK]) {
+                                               const JgDenseIn<R>& in, JgDecCount& dec, uint64_t (*sm)[JG_BLOCK]) {
   const uint32_t f = in.f;
   const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
   const uint64_t mword0 = in.w, head0 = in.head, term = in.term, hbt = in.hbt;
@@ -654,8 +687,8 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   bool hot = (f & (JGF_FAULT_MASK | JGF_ROLE_MASK | JGF_FAST)) == (JG_ROLE_LEADER | JGF_FAST);
   if (NODE) hot = hot && !hbr_trigger;
   hot = jg_lag_tick<R>(s, f, mword0, head0, n_app, in.a, lt, dl) && hot;
+  jg_count_step(h.blk_decisions, dec, hot, dl);
   if (__builtin_expect(hot, 1)) {
-    dec += dl;
     if (emit) {  // the Tick reads absolute progress heads
       x.head = lt.head1, x.nf = lt.nf, x.commit = lt.head1 - lt.l[R];
 #pragma unroll
@@ -688,7 +721,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   jg_dense_unpack<R>(d, g, s, mword0, x);
   const uint64_t commit0 = x.commit;
   x.nf = f;
-  dec += jg_dense_core<R>(d, g, seq, s, x);
+  dec.lane += jg_dense_core<R>(d, g, seq, s, x);
   if (emit) {
     if (x.nf & JGF_FAULT_MASK) jg_dense_outbox_none<R>(d, nd, g);  // the process died before its Tick
     else jg_dense_leader_tick<R>(d, nd, g, seq, s, term, hbt, x);
@@ -703,12 +736,12 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
 #define JG_DENSE_PREFETCH 0
 #endif
 template <int R, bool UNIFORM, bool NODE>
-__device__ __forceinline__ uint32_t jg_dense_tick_body(const JgDenseHot& h, const JgDev* dp,
+__device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, const JgDev* dp,
                                                        const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us,
                                                        const JgLeaderNode& nd, uint64_t (*sm)[JG_BLOCK]) {
   const uint32_t G = h.G, stride = gridDim.x * JG_BLOCK;
   const bool emit = NODE && nd.o_term != nullptr;
-  uint32_t dec = 0;
+  JgDecCount dec;
   uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x;
   if (JG_DENSE_PREFETCH && !NODE) {
     JgDenseIn<R> cur, nxt;
@@ -740,22 +773,22 @@ __global__ __launch_bounds__(JG_BLOCK) JG_DENSE_ATTR void k_leader_tick_dense(Jg
                                                                                const uint64_t* __restrict__ acks,
                                                                                uint32_t seq, int us) {
   __shared__ uint64_t sm[R][JG_BLOCK];  // progress heads of the (rare) groups on the general path
-  uint32_t dec;
+  JgDecCount dec;
   JgLeaderNode nd{};
   if (us >= 0) dec = jg_dense_tick_body<R, true, false>(h, dp, acks, seq, (uint32_t)us, nd, sm);
   else dec = jg_dense_tick_body<R, false, false>(h, dp, acks, seq, 0, nd, sm);
-  jg_block_count(h.blk_decisions, dec);
+  jg_wave_count(h.blk_decisions, dec);
 }
 
 // jg_step_dense_leader: the same tick with HeartbeatResponses in and / or the Tick's outbox out
 template <int R>
 __global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDev d, const uint64_t* __restrict__ acks,
                                                                 uint32_t seq, int us, JgLeaderNode nd) {
-  uint32_t dec;
+  JgDecCount dec;
   const JgDenseHot h = jg_dense_hot_of(d);
   if (us >= 0) dec = jg_dense_tick_body<R, true, true>(h, &d, acks, seq, (uint32_t)us, nd, nullptr);
   else dec = jg_dense_tick_body<R, false, true>(h, &d, acks, seq, 0, nd, nullptr);
-  jg_block_count(d.blk_decisions, dec);
+  jg_wave_count(d.blk_decisions, dec);
 }
 
 // ---- T consecutive ticks per launch (temporal fusion) ----------------------------------------

@@ -385,3 +385,60 @@ def test_two_engines_are_independent():
     a.close()
     b.apply(3, Command.Timeout())
     assert b.handle(3).is_candidate()
+
+
+@pytest.mark.parametrize("R", [2, 3, 4, 5, 6, 8])
+def test_dense_lag_space_boundaries(R, slot_layout):
+    """The dense tick is evaluated in lag space (32-bit lags below the chain head in the packed
+    progress word) wherever that is exact, and on the general path otherwise.  Random ack blocks
+    aimed at the border between the two: acks exactly at / one above the head, forged acks far
+    above it (-> replay, chain.commit panic), lags at ESC-1 / ESC / ESC+1 of the field, bursts
+    of appends that push every lag out of its field, dropped and duplicated acks — every
+    state column, decision counter and fault row against the oracle after every tick, in both
+    the one-tick and the T-tick kernel."""
+    G = 2048
+    dev, ora = pair(G, R, seed=23 + R, self_slots=slot_layout(G, R))
+    for e in (dev, ora):
+        elect_all(e)
+        e.drain_messages(), e.drain_applies()
+    rng = np.random.default_rng(100 + R)
+    esc = (1 << (64 // (R + 1))) - 1
+    slots = ora.read("self_slot").astype(np.int64)
+    gi = np.arange(G)
+    NO = np.uint64(capi.NO_ACK)
+    T = 24
+    for t in range(T):
+        head = ora.read("head").astype(np.uint64)
+        acks = np.full((R, G), NO, dtype=np.uint64)
+        for r in range(R):
+            kind = rng.integers(0, 12, G)
+            lag = np.zeros(G, dtype=np.uint64)
+            lag = np.where(kind == 1, 1, lag)
+            lag = np.where(kind == 2, rng.integers(0, 7, G), lag)
+            lag = np.where(kind == 3, esc - 1, lag)
+            lag = np.where(kind == 4, esc, lag)
+            lag = np.where(kind == 5, esc + 1, lag)
+            lag = np.where(kind == 6, 2 * esc, lag)
+            lag = np.where(kind == 7, head, lag).astype(np.uint64)                # an ack of block 0
+            a = np.where(lag <= head, head - np.minimum(lag, head), 0).astype(np.uint64)
+            a = np.where(kind == 8, head + np.uint64(1), a)                      # one above the head
+            a = np.where((kind == 9) & (rng.random(G) < 0.05), head + np.uint64(10**9), a)  # forged
+            a = np.where(kind >= 10, NO, a)                                      # dropped
+            acks[r] = a
+        n_app = rng.integers(0, 3, G).astype(np.uint64)
+        n_app = np.where(rng.random(G) < 0.02, esc + 3 if esc < 70_000 else 5000, n_app)  # burst: every lag leaves its field
+        if t == 9:
+            n_app = np.where(gi % 256 == 1, (1 << 20) + 1, n_app)                # above the lag-space append limit
+        acks[slots, gi] = n_app
+        if t % 6 == 5:  # the same three ticks through the T-tick kernel
+            blk = np.stack([acks, acks, acks])
+            dev.step_dense_acks_n(blk)
+            ora.step_dense_acks_n(blk)
+        else:
+            dev.step_dense_acks(acks)
+            ora.step_dense_acks(acks)
+        compare_snapshots(dev, ora, f"lag-space boundaries R={R} tick {t}")
+        compare_drains(dev, ora, f"lag-space boundaries R={R} tick {t}")
+        assert dev.counters()["decisions"] == ora.counters()["decisions"]
+    faults = np.bincount(ora.read("fault"), minlength=256)
+    assert (R < 3 or faults[capi.FAULT_COMMIT_MISSING_BLOCK] > 0) and faults[0] > G // 2, faults[:8]
