@@ -42,9 +42,13 @@ struct JgDenseHot {
   uint64_t* head;
   uint64_t* blk_decisions;
   uint32_t G;
+  // node tick only (leader.rs:234-245): term and heartbeat timer columns, config
+  uint32_t hb_timeout, cfg_flags;
+  uint64_t* term;
+  uint64_t* heartbeat_time;
 };
-__device__ __forceinline__ JgDenseHot jg_dense_hot_of(const JgDev& d) {
-  return JgDenseHot{d.flags, d.mlag, d.head, d.blk_decisions, d.G};
+__host__ __device__ __forceinline__ JgDenseHot jg_dense_hot_of(const JgDev& d) {
+  return JgDenseHot{d.flags, d.mlag, d.head, d.blk_decisions, d.G, d.hb_timeout, d.cfg_flags, d.term, d.heartbeat_time};
 }
 
 
@@ -449,35 +453,37 @@ __device__ __forceinline__ int jg_dense_classify(const JgDev& d, uint32_t g, uin
 // Command::Tick of a FAST leader into the outbox columns (leader.rs:234-245): heartbeat() if due,
 // then replicate() — per other slot the range start key (= its progress head) and the number
 // of blocks after it (Probe: nth(1) -> 1, Replicate: skip(1).take(5), leader.rs:135,152-157).
-template <int R>
-__device__ __forceinline__ void jg_dense_leader_tick(const JgDev& d, const JgLeaderNode& nd, uint32_t g, uint32_t seq,
-                                                     uint32_t s, uint64_t term, uint64_t hbt, JgDenseRegs<R>& x) {
-  const uint32_t G = d.G;
+// `mo_of(r)` = progress head of slot r; returns the flag word (with the Q9 fault if it was raised).
+template <int R, class MoOf>
+__device__ __forceinline__ uint32_t jg_dense_leader_tick(const JgDenseHot& h, const JgDev* dp, const JgLeaderNode& nd,
+                                                         uint32_t g, uint32_t seq, uint32_t s, uint64_t term,
+                                                         uint64_t hbt, uint64_t head, uint64_t commit, uint32_t nf,
+                                                         MoOf mo_of) {
+  const uint32_t G = h.G;
   nd.o_term[g] = term;
   uint64_t hb = JG_NO_ACK;
-  if ((nd.now - hbt) > (uint64_t)d.hb_timeout) {  // leader.rs:78-84
-    hb = x.commit;                                // leader.rs:44-51
-    d.heartbeat_time[g] = nd.now;
+  if ((nd.now - hbt) > (uint64_t)h.hb_timeout) {  // leader.rs:78-84
+    hb = commit;                                  // leader.rs:44-51
+    h.heartbeat_time[g] = nd.now;
   }
   nd.o_hb[g] = hb;
-  const bool key_in_range = (x.nf & JGF_COMMIT_KEY) && !(d.cfg_flags & JG_CFG_SEPARATE_COMMIT_KEY);
+  const bool key_in_range = (nf & JGF_COMMIT_KEY) && !(h.cfg_flags & JG_CFG_SEPARATE_COMMIT_KEY);
   bool dead = false;
 #pragma unroll
-  for (int k = 0; k + 1 < R; k++) {
-    const uint32_t r = jg_other_slot(k, s);
+  for (int r = 0; r < R; r++) {  // ascending slot = the order of replicate()'s loop
     uint32_t n = JG_AE_NONE;
     uint64_t from = 0;
-    if (!dead) {
-      const bool repl = (x.nf >> (JGF_REPL_SHIFT + r)) & 1u;
+    if ((uint32_t)r != s && !dead) {
+      const bool repl = (nf >> (JGF_REPL_SHIFT + r)) & 1u;
       const uint32_t want = repl ? JG_MAX_INFLIGHT + 1 : 2;  // items consumed by the range iterator
-      from = x.mo[k];
-      const uint64_t avail = from <= x.head ? x.head - from + 1 : 0;  // block keys >= from (FAST form)
+      from = mo_of(r);
+      const uint64_t avail = from <= head ? head - from + 1 : 0;  // block keys >= from (FAST form)
       const uint32_t cnt = avail >= want ? want : (uint32_t)avail;
       if (cnt < want && key_in_range) {  // the iterator runs into the "commit" key: chain.rs:219-226 (Q9)
         dead = true;
         from = 0;
-        x.nf |= JG_FAULT_RANGE_HIT_COMMIT_KEY << JGF_FAULT_SHIFT;
-        jg_push_fault(d, g, JG_FAULT_RANGE_HIT_COMMIT_KEY, seq);
+        nf |= JG_FAULT_RANGE_HIT_COMMIT_KEY << JGF_FAULT_SHIFT;
+        jg_push_fault(*dp, g, JG_FAULT_RANGE_HIT_COMMIT_KEY, seq);
       } else {
         n = cnt ? cnt - 1 : 0;
       }
@@ -485,17 +491,16 @@ __device__ __forceinline__ void jg_dense_leader_tick(const JgDev& d, const JgLea
     nd.o_from[(size_t)r * G + g] = from;
     nd.o_n[(size_t)r * G + g] = (uint8_t)n;
   }
-  nd.o_from[(size_t)s * G + g] = 0;
-  nd.o_n[(size_t)s * G + g] = JG_AE_NONE;
+  return nf;
 }
 template <int R>
-__device__ __forceinline__ void jg_dense_outbox_none(const JgDev& d, const JgLeaderNode& nd, uint32_t g) {
+__device__ __forceinline__ void jg_dense_outbox_none(uint32_t G, const JgLeaderNode& nd, uint32_t g) {
   nd.o_term[g] = 0;
   nd.o_hb[g] = JG_NO_ACK;
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    nd.o_from[(size_t)r * d.G + g] = 0;
-    nd.o_n[(size_t)r * d.G + g] = JG_AE_NONE;
+    nd.o_from[(size_t)r * G + g] = 0;
+    nd.o_n[(size_t)r * G + g] = JG_AE_NONE;
   }
 }
 
@@ -526,10 +531,9 @@ __device__ __forceinline__ void jg_dense_issue(const JgDenseHot& h, const JgDev*
   __builtin_amdgcn_sched_barrier(0);
   in.term = in.hbt = 0;
   if (NODE) {
-    const JgDev& d = *dp;
     if (emit) {
-      in.term = d.term[g];
-      in.hbt = d.heartbeat_time[g];
+      in.term = h.term[g];
+      in.hbt = h.heartbeat_time[g];
     }
 #pragma unroll
     for (int r = 0; r < R; r++)  // (the own slot's entry is never looked at)
@@ -542,7 +546,7 @@ __device__ __forceinline__ void jg_dense_issue(const JgDenseHot& h, const JgDev*
 // and the T-tick kernel use), written as rolled loops over a per-lane LDS column of the R progress
 // heads: a handful of registers instead of ~90, because the register allocation of a kernel is the
 // maximum over all its paths and this one is taken by almost no group (escaped lag fields, acks
-// above the head, non-leaders, irregular chains).  Inputs are read again from memory.
+// above the head).  Apart from the flag word and the append count its inputs are read again from memory.
 template <int R>
 __device__ __forceinline__ uint64_t jg_lds_kth(const uint64_t (*sm)[JG_BLOCK]) {
   // element R/2 of the heads sorted descending (progress.rs:48-60) by rank counting
@@ -564,14 +568,9 @@ __device__ __forceinline__ uint64_t jg_lds_kth(const uint64_t (*sm)[JG_BLOCK]) {
 
 template <int R, bool UNIFORM>
 __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t* __restrict__ acks, uint32_t seq,
-                                               uint32_t us, uint32_t g, JgDecCount& dec, uint64_t (*sm)[JG_BLOCK]) {
+                                               uint32_t s, uint32_t f, uint64_t n_app, uint32_t g, JgDecCount& dec,
+                                               uint64_t (*sm)[JG_BLOCK]) {
   const uint32_t G = d.G, t = threadIdx.x;
-  const uint32_t f = d.flags[g];
-  const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
-  const uint64_t n_app = acks ? acks[(size_t)s * G + g] : 0;
-  const int cls = jg_dense_classify(d, g, f, n_app, seq);
-  jg_defer_push(d, g, cls == JG_DENSE_DEFER);
-  if (cls != JG_DENSE_RUN) return;
   const uint32_t B = jg_lag_bits(R);
   const uint64_t esc = jg_lag_esc(R);
   const uint64_t w0 = d.mlag[g], head0 = d.head[g];
@@ -677,8 +676,6 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
 #pragma unroll
   for (int r = 1; r < R; r++) n_app = (uint32_t)r == s ? in.a[r] : n_app;
   if (NODE && !acks) n_app = 0;
-  JgDenseRegs<R> x;
-  x.head = head0;
   // ---- hot path: a healthy leader in FAST form whose tick stays in lag space --------------------
   // straight-line 32-bit arithmetic, evaluated for every lane; everything else is behind one
   // (normally wave-uniform, not taken) branch
@@ -689,13 +686,9 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   hot = jg_lag_tick<R>(s, f, mword0, head0, n_app, in.a, lt, dl) && hot;
   jg_count_step(h.blk_decisions, dec, hot, dl);
   if (__builtin_expect(hot, 1)) {
-    if (emit) {  // the Tick reads absolute progress heads
-      x.head = lt.head1, x.nf = lt.nf, x.commit = lt.head1 - lt.l[R];
-#pragma unroll
-      for (int k = 0; k + 1 < R; k++) x.mo[k] = lt.head1 - ((uint32_t)k >= s ? lt.l[k + 1] : lt.l[k]);
-      jg_dense_leader_tick<R>(*dp, nd, g, seq, s, term, hbt, x);  // may raise the Q9 fault in x.nf
-      lt.nf = x.nf;
-    }
+    if (emit)  // Command::Tick into the outbox; may raise the Q9 fault
+      lt.nf = jg_dense_leader_tick<R>(h, dp, nd, g, seq, s, term, hbt, lt.head1, lt.head1 - lt.l[R], lt.nf,
+                                      [&](int r) { return lt.head1 - lt.l[r]; });
     if (lt.w1 != mword0) h.mlag[g] = lt.w1;
     if (lt.head1 != head0) h.head[g] = lt.head1;
     if (lt.nf != f) h.flags[g] = lt.nf;
@@ -703,30 +696,22 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   }
   const JgDev& d = *dp;  // (the ack-only kernel: loads from the device copy, general path only)
   // ---- everything else ---------------------------------------------------------------------------
-  if (!NODE) {  // the ack-only kernel: rolled loops over LDS, so that the kernel's register
-                // allocation (= its occupancy) is the hot path's
-    jg_dense_cold_lds<R, UNIFORM>(d, acks, seq, us, g, dec, sm);
-    return;
-  }
+  // dead groups, non-leaders and irregular chains are decided from the flag word in registers
   int cls = jg_dense_classify(d, g, f, n_app, seq);
-  if (NODE && cls == JG_DENSE_RUN && hbr_trigger) cls = JG_DENSE_DEFER;  // extra AppendEntries: rows
+  // node tick: whatever is not served in lag space (a HeartbeatResponse without the commit, an
+  // escaped lag field, an ack above the head) goes to k_dense_slow, which is always launched
+  // behind a node tick and runs HeartbeatResponses, appends, acks and the Tick of these groups
+  // through the general state machine (columns for a FAST chain, rows otherwise)
+  if (NODE && cls == JG_DENSE_RUN) cls = JG_DENSE_DEFER;
   jg_defer_push(d, g, cls == JG_DENSE_DEFER);
-  if (cls != JG_DENSE_RUN) {
-    if (emit) jg_dense_outbox_none<R>(d, nd, g);  // (a deferred group's Tick: the slow kernel)
+  if (NODE) {
+    if (emit) jg_dense_outbox_none<R>(h.G, nd, g);
     return;
   }
-  // ---- general register path (escaped fields, acks above the head, ...) ------------------------
-  jg_dense_split_acks<R>(in.a, s, x.n_app, x.ao);
-  x.n_app = n_app;
-  jg_dense_unpack<R>(d, g, s, mword0, x);
-  const uint64_t commit0 = x.commit;
-  x.nf = f;
-  dec.lane += jg_dense_core<R>(d, g, seq, s, x);
-  if (emit) {
-    if (x.nf & JGF_FAULT_MASK) jg_dense_outbox_none<R>(d, nd, g);  // the process died before its Tick
-    else jg_dense_leader_tick<R>(d, nd, g, seq, s, term, hbt, x);
-  }
-  jg_dense_store<R>(d, g, s, f, mword0, x, commit0, head0);
+  if (cls != JG_DENSE_RUN) return;
+  // the ack-only kernel: rolled loops over LDS, so that the kernel's register allocation
+  // (= its occupancy) is the hot path's
+  jg_dense_cold_lds<R, UNIFORM>(d, acks, seq, s, f, n_app, g, dec, sm);
 }
 
 // Grid-stride loop with the next group's loads issued before the current group is evaluated
@@ -782,13 +767,13 @@ __global__ __launch_bounds__(JG_BLOCK) JG_DENSE_ATTR void k_leader_tick_dense(Jg
 
 // jg_step_dense_leader: the same tick with HeartbeatResponses in and / or the Tick's outbox out
 template <int R>
-__global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDev d, const uint64_t* __restrict__ acks,
-                                                                uint32_t seq, int us, JgLeaderNode nd) {
+__global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDenseHot h, const JgDev* __restrict__ dp,
+                                                                const uint64_t* __restrict__ acks, uint32_t seq, int us,
+                                                                JgLeaderNode nd) {
   JgDecCount dec;
-  const JgDenseHot h = jg_dense_hot_of(d);
-  if (us >= 0) dec = jg_dense_tick_body<R, true, true>(h, &d, acks, seq, (uint32_t)us, nd, nullptr);
-  else dec = jg_dense_tick_body<R, false, true>(h, &d, acks, seq, 0, nd, nullptr);
-  jg_wave_count(d.blk_decisions, dec);
+  if (us >= 0) dec = jg_dense_tick_body<R, true, true>(h, dp, acks, seq, (uint32_t)us, nd, nullptr);
+  else dec = jg_dense_tick_body<R, false, true>(h, dp, acks, seq, 0, nd, nullptr);
+  jg_wave_count(h.blk_decisions, dec);
 }
 
 // ---- T consecutive ticks per launch (temporal fusion) ----------------------------------------

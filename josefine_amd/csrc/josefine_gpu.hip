@@ -189,15 +189,14 @@ template <int R>
 void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks, const JgLeaderNode* nd) {
   const size_t stride = (size_t)e->cfg.n_groups * e->cfg.n_replicas;
   if (nd)  // node tick: HeartbeatResponses in, the Tick's outbox out
-    hipLaunchKernelGGL(k_leader_node_tick<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
-                       e->seq, e->uniform_self, *nd);
+    hipLaunchKernelGGL(k_leader_node_tick<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
+                       jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks, e->seq, e->uniform_self, *nd);
   else if (n_ticks > 1)  // temporal fusion: state read once, written once per launch
     hipLaunchKernelGGL(k_leader_tick_dense_n<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
                        n_ticks, stride, e->seq, e->uniform_self);
   else
     hipLaunchKernelGGL(k_leader_tick_dense<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
-                       JgDenseHot{e->dev.flags, e->dev.mlag, e->dev.head, e->dev.blk_decisions, e->dev.G},
-                       (const JgDev*)e->d_dev, acks, e->seq, e->uniform_self);
+                       jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks, e->seq, e->uniform_self);
 }
 
 int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1, const JgLeaderNode* nd = nullptr) {
@@ -215,8 +214,9 @@ int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1, con
   }
   e->n_launch++;
   // the slow kernel behind it: when a sparse step may have left a leader with an irregular
-  // chain, and whenever HeartbeatResponses come in (a response without the commit defers)
-  if (e->maybe_irregular || (nd && nd->hbr_has)) {
+  // chain, and behind every node tick (its general path: a HeartbeatResponse without the commit,
+  // an escaped lag field, an ack above the head)
+  if (e->maybe_irregular || nd) {
     e->slow_scheduled_ever = true;
     JgLeaderNode none{};
     hipLaunchKernelGGL(k_dense_slow, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream, e->dev, acks_dev, n_ticks,
