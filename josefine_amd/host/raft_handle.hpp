@@ -407,6 +407,127 @@ class DenseCluster {
   std::vector<void*> bufs_;
 };
 
+// ---- fsm::Driver and server::event_loop for many partitions ---------------------------------------
+// The two tasks on either side of Raft<T> in a josefine process, batched over every partition the
+// process hosts.  Logical time: `run_until(now_ms)` plays the
+// interval timer of server.rs:25,113 (one Command::Tick per partition every 100 ms).
+//
+//   reference                                              here
+//   fsm::Driver::run  (fsm.rs:51-88)                       BatchedEventLoop::on_instruction
+//     Notify -> notifications[block_id] = (addr, req id)     notifications_[{group, block_id}]
+//     Apply  -> skip block 0; fsm.transition(data); if a     fsm(group, data); a pending notification
+//               notification is pending, ClientResponse        completes the client's request
+//               {id, res} to that address via rpc_tx           (the hop rpc_tx -> event_loop ->
+//                                                              oneshot of server.rs:144-152 is direct)
+//   server::event_loop (server.rs:103-165)                 BatchedEventLoop::run_until
+//     step_interval.tick() => apply(Tick)                    one Tick per partition per TICK_MS
+//     tcp_rx.recv()        => apply(msg.command)             tcp_rx(msg): queued, applied at the next step
+//     rpc_rx.recv(): Peer / Peers => tcp_tx.send(msg)        tcp_tx sink
+//                    Local        => apply(msg.command)      re-submitted in the same step
+//                    Client       => requests.remove(id)     completes the client's request
+//     client_rx.recv()     => apply(ClientRequest{new id})   propose(group, proposal, on_response)
+class BatchedEventLoop {
+ public:
+  static constexpr uint64_t TICK_MS = 100;  // server.rs:25
+  using Response = std::function<void(bool ok, const std::vector<uint8_t>& res)>;
+  // Fsm::transition (fsm.rs:16): state machine of one partition; an exception is a ResponseError
+  std::function<std::vector<uint8_t>(uint32_t group, const std::vector<uint8_t>& data)> fsm;
+  std::function<void(const Message&)> tcp_tx;  // to the peer transport (tcp.rs), by partition
+
+  explicit BatchedEventLoop(BatchedRaft& raft, uint32_t n_groups) : raft_(raft), G_(n_groups) {
+    raft_.rpc_tx = [this](const Message& m) { on_message(m); };
+    raft_.fsm_tx = [this](const Instruction& i) { on_instruction(i); };
+  }
+  // a message from a peer's event loop (tcp_rx, server.rs:126-137)
+  void tcp_rx(const Message& m) { inbound_.push_back(m); }
+  // RaftClient::propose (client.rs:35): returns the request id (Uuid::new_v4 -> a counter)
+  uint64_t propose(uint32_t group, std::vector<uint8_t> proposal, Response on_response) {
+    const uint64_t id = ++next_request_;
+    requests_[id] = std::move(on_response);
+    client_.push_back({group, Command::ClientRequest(id, std::move(proposal))});
+    return id;
+  }
+  // Advance logical time to now_ms: everything that arrived is applied, a Tick per partition
+  // whenever the interval fires (the first one immediately, like tokio::time::interval).
+  void run_until(uint64_t now_ms) {
+    for (;;) {
+      const bool tick = next_tick_ <= now_ms;
+      const uint64_t at = tick ? next_tick_ : now_ms;
+      if (!tick && inbound_.empty() && client_.empty()) break;
+      step(at, tick);
+      if (tick) next_tick_ += TICK_MS;
+    }
+  }
+  size_t pending_requests() const { return requests_.size(); }
+
+ private:
+  void step(uint64_t at, bool tick) {
+    std::deque<Message> in;
+    in.swap(inbound_);
+    for (const Message& m : in) raft_.submit(m.group, m.command);
+    std::deque<std::pair<uint32_t, Command>> cl;
+    cl.swap(client_);
+    for (auto& c : cl) raft_.submit(c.first, c.second);
+    if (tick)
+      for (uint32_t g = 0; g < G_; g++) raft_.submit(g, Command::Tick());
+    raft_.step(at);
+    // Address::Local messages (server.rs:143) are applied before anything new is accepted
+    int guard = 0;
+    while (!local_.empty() && guard++ < 64) {
+      std::deque<Message> lo;
+      lo.swap(local_);
+      for (const Message& m : lo) raft_.submit(m.group, m.command);
+      raft_.step(at);
+    }
+  }
+  void on_message(const Message& m) {  // rpc_rx (server.rs:139-155)
+    switch (m.to.kind) {
+      case JG_TO_PEER:
+      case JG_TO_PEERS:
+        if (tcp_tx) tcp_tx(m);
+        break;
+      case JG_TO_LOCAL: local_.push_back(m); break;
+      case JG_TO_CLIENT: complete(m.command.id, true, {}); break;
+      default: throw EngineError(JG_EINVAL, "unexpected message");  // server.rs:154
+    }
+  }
+  void on_instruction(const Instruction& i) {  // fsm.rs:56-84
+    const std::pair<uint32_t, BlockId> key{i.group, i.kind == Instruction::Notify ? i.block_id : i.block.id};
+    if (i.kind == Instruction::Notify) {
+      notifications_[key] = i.request_id;
+      return;
+    }
+    if (i.block.id == 0) return;  // fsm.rs:59-61
+    bool ok = true;
+    std::vector<uint8_t> res;
+    try {
+      if (fsm) res = fsm(i.group, i.block.data);
+    } catch (...) {
+      ok = false;
+    }
+    auto it = notifications_.find(key);
+    if (it != notifications_.end()) {
+      complete(it->second, ok, res);
+      notifications_.erase(it);
+    }
+  }
+  void complete(uint64_t id, bool ok, const std::vector<uint8_t>& res) {
+    auto it = requests_.find(id);
+    if (it == requests_.end()) return;  // a proxied request: its oneshot lives on another node (server.rs:129-133)
+    Response cb = std::move(it->second);
+    requests_.erase(it);
+    if (cb) cb(ok, res);
+  }
+
+  BatchedRaft& raft_;
+  uint32_t G_;
+  uint64_t next_tick_ = 0, next_request_ = 0;
+  std::deque<Message> inbound_, local_;
+  std::deque<std::pair<uint32_t, Command>> client_;
+  std::map<uint64_t, Response> requests_;
+  std::map<std::pair<uint32_t, BlockId>, uint64_t> notifications_;
+};
+
 inline RaftHandle RaftHandle::apply(const Command& cmd, uint64_t now_ms) { return e_->apply(g_, cmd, now_ms); }
 inline uint64_t RaftHandle::read64(int f) const {
   uint64_t v = 0;

@@ -8,6 +8,21 @@
 #include <deque>
 #include <memory>
 
+// CPU run of the host logic (tests/test_cpp_adapter.py, -m "not gpu"): the same C ABI as served by
+// the oracle library (test infrastructure) stands in for the HIP engine; the dense mailbox test needs
+// device memory and is left out.
+#ifdef JG_TEST_AGAINST_ORACLE
+#define jg_engine_create jo_engine_create
+#define jg_engine_destroy jo_engine_destroy
+#define jg_set_self_slots jo_set_self_slots
+#define jg_submit jo_submit
+#define jg_step jo_step
+#define jg_drain_messages jo_drain_messages
+#define jg_drain_applies jo_drain_applies
+#define jg_drain_faults jo_drain_faults
+#define jg_read_state jo_read_state
+#define jg_last_error jo_last_error
+#endif
 #include "../../josefine_amd/host/raft_handle.hpp"
 
 using namespace josefine;
@@ -119,6 +134,7 @@ static void multi_node_plumbing() {
 // The same 3-broker topology as three engines (one per broker process) hosting 64 partitions
 // each, driven through the dense node tick: node 1 leads every partition, one ClientRequest per
 // partition per round; the mailboxes never leave the device.
+#ifndef JG_TEST_AGAINST_ORACLE
 static void multi_node_dense_rounds() {
   const uint32_t G = 64;
   std::vector<std::unique_ptr<BatchedRaft>> nodes;
@@ -149,6 +165,81 @@ static void multi_node_dense_rounds() {
     }
   }
 }
+#endif
+
+
+// src/raft/server.rs:185-216 event_loop: a single default-config node left alone for 2 s is leader
+static void server_event_loop_single_node() {
+  BatchedRaft raft(1, {1});
+  BatchedEventLoop loop(raft, 1);
+  loop.run_until(2000);
+  CHECK(raft.handle(0).is_leader());
+}
+
+// Three processes (node-1..3 of examples/multi-node), each with its own engine hosting the same 8
+// partitions, their event loops wired tcp_tx -> tcp_rx; timers are the only source of elections.
+// A proposal through whoever leads a partition comes back to the client once it is committed and
+// applied, and every node's state machine sees the same payload.
+static void server_event_loops_three_nodes() {
+  const uint32_t G = 8, N = 3;
+  std::vector<std::unique_ptr<BatchedRaft>> rafts;
+  std::vector<std::unique_ptr<BatchedEventLoop>> loops;
+  std::vector<std::vector<std::vector<uint8_t>>> applied(N, std::vector<std::vector<uint8_t>>(G));
+  for (uint32_t n = 0; n < N; n++) {
+    rafts.emplace_back(new BatchedRaft(G, {1, 2, 3}, 0, 100 + n, JG_CFG_SEPARATE_COMMIT_KEY));
+    std::vector<uint8_t> slots(G, (uint8_t)n);
+    CHECK(jg_set_self_slots(rafts[n]->raw(), slots.data()) == JG_OK);
+    loops.emplace_back(new BatchedEventLoop(*rafts[n], G));
+    loops[n]->fsm = [&applied, n](uint32_t g, const std::vector<uint8_t>& data) {
+      applied[n][g].insert(applied[n][g].end(), data.begin(), data.end());
+      return data;
+    };
+  }
+  for (uint32_t n = 0; n < N; n++)
+    loops[n]->tcp_tx = [&loops, n](const Message& m) {  // tcp.rs: Peer -> that peer, Peers -> everyone else
+      for (uint32_t dst = 0; dst < 3; dst++) {
+        if (dst == n) continue;
+        if (m.to.kind == JG_TO_PEERS || m.to.peer == dst + 1) loops[dst]->tcp_rx(m);
+      }
+    };
+  auto run_all = [&](uint64_t from, uint64_t to) {
+    for (uint64_t t = from; t <= to; t += 10)
+      for (uint32_t n = 0; n < N; n++) loops[n]->run_until(t);
+  };
+  run_all(0, 3000);
+  uint32_t leaders = 0;
+  for (uint32_t g = 0; g < G; g++) {
+    int lead = -1;
+    for (uint32_t n = 0; n < N; n++)
+      if (rafts[n]->handle(g).is_leader()) lead = (int)n, leaders++;
+    CHECK(lead >= 0);
+    for (uint32_t n = 0; n < N; n++) CHECK(rafts[n]->handle(g).fault() == 0);
+  }
+  CHECK(leaders == G);  // exactly one leader per partition
+  // one proposal per partition through its leader's event loop
+  uint32_t answered = 0;
+  for (uint32_t g = 0; g < G; g++)
+    for (uint32_t n = 0; n < N; n++)
+      if (rafts[n]->handle(g).is_leader())
+        loops[n]->propose(g, {(uint8_t)(40 + g)}, [&answered, g](bool ok, const std::vector<uint8_t>& res) {
+          answered += ok && res == std::vector<uint8_t>{(uint8_t)(40 + g)};
+        });
+  run_all(3010, 4000);
+  CHECK(answered == G);
+  for (uint32_t g = 0; g < G; g++)
+    for (uint32_t n = 0; n < N; n++) {
+      CHECK(rafts[n]->handle(g).head() == 1 && rafts[n]->handle(g).fault() == 0);
+      if (rafts[n]->handle(g).is_leader()) {
+        CHECK(rafts[n]->handle(g).commit() == 1);
+        CHECK(applied[n][g] == std::vector<uint8_t>{(uint8_t)(40 + g)});
+        CHECK(loops[n]->pending_requests() == 0);
+      } else {
+        // a follower commits 1 with the next heartbeat and applies range(0..1) = genesis only (Q6)
+        CHECK(rafts[n]->handle(g).commit() == 1 && applied[n][g].empty());
+        CHECK(rafts[n]->store(g).count(1) && rafts[n]->store(g).at(1).data == std::vector<uint8_t>{(uint8_t)(40 + g)});
+      }
+    }
+}
 
 int main() {
   try {
@@ -156,7 +247,11 @@ int main() {
     follower_apply_heartbeat();
     candidate_apply_heartbeat();
     multi_node_plumbing();
+#ifndef JG_TEST_AGAINST_ORACLE
     multi_node_dense_rounds();
+#endif
+    server_event_loop_single_node();
+    server_event_loops_three_nodes();
   } catch (const std::exception& e) {
     std::fprintf(stderr, "exception: %s\n", e.what());
     return 2;

@@ -25,6 +25,20 @@ def test_cpp_adapter_compiles():
     assert os.path.exists(EXE)
 
 
+def test_cpp_host_logic_on_oracle():
+    """CPU: the host logic above the ABI (BatchedRaft pump, BlockStore, fsm::Driver and
+    server::event_loop for many partitions) with the oracle library standing in for the engine:
+    the reference's L1 tests, its event_loop test and the 3-node plumbing of BASELINE config #1."""
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.run(["make", "-C", odir], check=True, capture_output=True)
+    exe = EXE + "_oracle"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-DJG_TEST_AGAINST_ORACLE", "-o", exe, SRC, f"-L{odir}",
+                    "-ljosefine_oracle", f"-Wl,-rpath,{odir}"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cpp adapter ok" in r.stdout
+
+
 @pytest.mark.gpu
 def test_cpp_adapter_runs_reference_tests():
     compile_adapter_test()
