@@ -21,10 +21,15 @@
 // majority evaluation; otherwise the lane replays appends and acks one by one and
 // faults exactly where the reference would panic (chain.rs:197-202).
 //
-// Register form: the group's own slot s and the R-1 other slots are kept apart
-// ("self + others": other k is slot k + (k >= s), ascending), so that with an
-// engine-uniform own slot every load has an address that does not depend on the flag
-// word: one round trip to HBM per group (escaped lag fields cost a second one, rarely).
+// Three paths, the same results (tests/test_gpu_parity.py, tests/test_dense_node.py vs the oracle):
+//   hot      jg_lag_tick: the whole tick as 32-bit arithmetic on the lags of the packed word, for
+//            a healthy FAST leader whose fields are un-escaped and whose acks are at or below the
+//            head — all loads of the group (flag word, R acks, packed word, head) in one round trip;
+//   general  k_leader_tick_dense: jg_dense_cold_lds, rolled loops over a per-lane LDS column of
+//            absolute heads (few registers: the kernel's occupancy is the hot path's);
+//            k_leader_node_tick / k_leader_tick_dense_n: the group is handed to k_dense_slow (the
+//            general state machine), which is always launched behind them;
+//   skip     dead groups, non-leaders, irregular chains: decided from the flag word.
 #pragma once
 #include "jg_device.h"
 
@@ -106,114 +111,6 @@ __device__ __forceinline__ void jg_wave_count(uint64_t* slots, const JgDecCount&
   if ((threadIdx.x & 63u) == 0 && v) jg_count_add(slots, v);
 }
 
-// One group's tick in registers.  O = max(R-1, 1) other slots.
-template <int R>
-struct JgDenseRegs {
-  static constexpr int O = R > 1 ? R - 1 : 1;
-  uint64_t ao[O];  // acks of the other slots (JG_NO_ACK = none)
-  uint64_t mo[O];  // their match heads
-  uint64_t ms;     // own match head
-  uint64_t n_app;  // ClientRequests to append this tick (the own slot of the ack block)
-  uint64_t commit, head;
-  uint32_t nf;     // flag word being rebuilt
-};
-
-// element R/2 of the heads sorted descending (progress.rs:48-60) by rank counting.  Ties are
-// broken by position only to make the ranks distinct; the selected value does not depend on it.
-template <int R>
-__device__ __forceinline__ uint64_t jg_kth(const JgDenseRegs<R>& x) {
-  constexpr int K = R / 2;
-  uint64_t v[R];
-  v[0] = x.ms;
-#pragma unroll
-  for (int k = 0; k + 1 < R; k++) v[k + 1] = x.mo[k];
-  uint64_t q = 0;
-#pragma unroll
-  for (int j = 0; j < R; j++) {
-    int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < R; i++) cnt += (v[i] > v[j] || (v[i] == v[j] && i < j)) ? 1 : 0;
-    q = (cnt == K) ? v[j] : q;
-  }
-  return q;
-}
-
-// slot of other k for own slot s
-__device__ __forceinline__ uint32_t jg_other_slot(uint32_t k, uint32_t s) { return k + (k >= s ? 1u : 0u); }
-
-// The tick of one FAST leader group, entirely in registers.  Updates the match heads, commit,
-// head and flag word in `x`; returns the number of quorum decisions taken.
-template <int R>
-__device__ __forceinline__ uint32_t jg_dense_core(const JgDev& d, uint32_t g, uint32_t seq, uint32_t s,
-                                                  JgDenseRegs<R>& x) {
-  const uint64_t head0 = x.head, commit0 = x.commit;
-  const uint32_t sbit = 1u << (JGF_REPL_SHIFT + s);
-  uint32_t dec = 0;
-  uint64_t hi = x.ms;  // max over old match heads and follower acks
-#pragma unroll
-  for (int k = 0; k + 1 < R; k++) {
-    hi = x.mo[k] > hi ? x.mo[k] : hi;
-    hi = (x.ao[k] != JG_NO_ACK && x.ao[k] > hi) ? x.ao[k] : hi;
-  }
-  if (hi <= head0) {
-    // ---- fused path ---------------------------------------------------------------
-    x.head = head0 + x.n_app;  // n appends: ids head0+1 .. head0+n (chain.rs:160-175, FAST form)
-    if (x.n_app) {             // n self-acks; the last increment decides Probe/Replicate
-      bool inc = x.ms < x.head;
-      x.ms = inc ? x.head : x.ms;
-      x.nf = inc ? (x.nf | sbit) : (x.nf & ~sbit);
-      dec += (uint32_t)x.n_app;
-    }
-#pragma unroll
-    for (int k = 0; k + 1 < R; k++) {
-      if (x.ao[k] != JG_NO_ACK) {  // progress.rs:76-94,133-140
-        const uint32_t bit = 1u << (JGF_REPL_SHIFT + jg_other_slot(k, s));
-        bool inc = x.mo[k] < x.ao[k];
-        x.mo[k] = inc ? x.ao[k] : x.mo[k];
-        x.nf = inc ? (x.nf | bit) : (x.nf & ~bit);
-        dec += 1;
-      }
-    }
-    uint64_t q = jg_kth<R>(x);               // progress.rs:48-60
-    x.commit = q > x.commit ? q : x.commit;  // leader.rs:89-92
-  } else {
-    // ---- exact replay: one Leader::commit per append / ack ---------------------------
-    uint32_t fault = 0;
-    for (uint64_t i = 0; i < x.n_app && !fault; i++) {
-      x.head += 1;
-      bool inc = x.ms < x.head;
-      x.ms = inc ? x.head : x.ms;
-      x.nf = inc ? (x.nf | sbit) : (x.nf & ~sbit);
-      dec += 1;
-      uint64_t q = jg_kth<R>(x);
-      if (q > x.commit) {
-        if (q <= x.head) x.commit = q;
-        else fault = JG_FAULT_COMMIT_MISSING_BLOCK;  // chain.rs:197-202
-      }
-    }
-#pragma unroll
-    for (int k = 0; k + 1 < R; k++) {  // ascending k = ascending slot
-      if (x.ao[k] == JG_NO_ACK || fault) continue;
-      const uint32_t bit = 1u << (JGF_REPL_SHIFT + jg_other_slot(k, s));
-      bool inc = x.mo[k] < x.ao[k];
-      x.mo[k] = inc ? x.ao[k] : x.mo[k];
-      x.nf = inc ? (x.nf | bit) : (x.nf & ~bit);
-      dec += 1;
-      uint64_t q = jg_kth<R>(x);
-      if (q > x.commit) {
-        if (q <= x.head) x.commit = q;
-        else fault = JG_FAULT_COMMIT_MISSING_BLOCK;
-      }
-    }
-    if (fault) {
-      x.nf |= fault << JGF_FAULT_SHIFT;
-      jg_push_fault(d, g, fault, seq);
-    }
-  }
-  if (x.commit != commit0) x.nf |= JGF_COMMIT_KEY;  // chain.rs:198
-  return dec;
-}
-
 // Issue every load of one group whose address is known without the flag word: the R slots of
 // the ack block by constant index (the own slot carries the number of appends), the packed
 // progress / commit word and the chain head.
@@ -222,17 +119,6 @@ __device__ __forceinline__ void jg_dense_load_acks(const uint64_t* __restrict__ 
                                                    uint64_t (&a)[R]) {
 #pragma unroll
   for (int r = 0; r < R; r++) a[r] = __builtin_nontemporal_load(&acks[(size_t)r * G + g]);
-}
-// the ack block in "self + others" form for own slot s (selects, no loads)
-template <int R>
-__device__ __forceinline__ void jg_dense_split_acks(const uint64_t (&a)[R], uint32_t s, uint64_t& n_app,
-                                                    uint64_t (&ao)[JgDenseRegs<R>::O]) {
-  n_app = a[0];
-#pragma unroll
-  for (int r = 1; r < R; r++) n_app = (uint32_t)r == s ? a[r] : n_app;
-#pragma unroll
-  for (int k = 0; k + 1 < R; k++) ao[k] = (uint32_t)k >= s ? a[k + 1] : a[k];
-  if (R == 1) ao[0] = JG_NO_ACK;
 }
 template <int R, bool MAYBE_NO_ACKS = true>
 __device__ __forceinline__ void jg_dense_load(const JgDenseHot& d, const uint64_t* __restrict__ acks, uint32_t g,
@@ -246,23 +132,6 @@ __device__ __forceinline__ void jg_dense_load(const JgDenseHot& d, const uint64_
   mword = d.mlag[g];
   head = d.head[g];
 }
-// packed lags -> absolute progress heads (escaped fields: one more load, rare)
-template <int R>
-__device__ __forceinline__ void jg_dense_unpack(const JgDev& d, uint32_t g, uint32_t s, uint64_t mword,
-                                                JgDenseRegs<R>& x) {
-  const uint64_t esc = jg_lag_esc(R);
-  uint64_t f = jg_lag_field(mword, R, R);  // field R: the commit index
-  x.commit = f == esc ? d.commit[g] : x.head - f;
-  f = jg_lag_field(mword, s, R);
-  x.ms = f == esc ? d.match_wide[(size_t)s * d.G + g] : x.head - f;
-#pragma unroll
-  for (int k = 0; k + 1 < R; k++) {
-    const uint32_t r = jg_other_slot(k, s);
-    f = jg_lag_field(mword, r, R);
-    x.mo[k] = f == esc ? d.match_wide[(size_t)r * d.G + g] : x.head - f;
-  }
-}
-
 // ---- the tick in lag space -----------------------------------------------------------------------
 // The common case never leaves the packed representation.  With every field of the progress
 // word un-escaped, every ack at or below the chain head and within 2^32 of it, and fewer than
@@ -272,10 +141,10 @@ __device__ __forceinline__ void jg_dense_unpack(const JgDev& d, uint32_t g, uint
 //   n appends + self-acks                     <=>  every lag += n, own lag = 0     leader.rs:177-197
 //   element R/2 of the heads sorted desc.     <=>  element R/2 of the lags sorted ascending
 //   commit = max(commit, q)                   <=>  clag = min(clag + n, qlag)      leader.rs:89-92
-// Old heads and acks <= head0 is exactly the precondition of the fused path of jg_dense_core
-// (no chain.commit panic possible), so the two agree bit for bit; anything else (escaped field,
+// Old heads and acks <= head0 is exactly the precondition of the fused evaluation above (no
+// chain.commit panic possible), so it is exact; anything else (escaped field,
 // forged ack above the head, a lag that no longer fits its field) returns false with nothing
-// modified and the caller takes the general register path.
+// modified and the caller takes the general path.
 template <int R>
 struct JgLagTick {
   uint64_t w1, head1;  // new packed word, new chain head
@@ -361,29 +230,48 @@ __device__ __forceinline__ bool jg_lag_tick(uint32_t s, uint32_t f, uint64_t w0,
   return true;
 }
 
-// Store what changed: the lags re-packed against the new head (in steady state the same
-// word as before: no store), commit, head, flag word.
+// The same tick on lags that are already unpacked (the T-tick kernel carries them in registers from
+// tick to tick and packs once per launch): l[r] may exceed its field between ticks, only 2^30 is a
+// hard bound here; the caller checks the field width when it packs.
 template <int R>
-__device__ __forceinline__ void jg_dense_store(const JgDev& d, uint32_t g, uint32_t s, uint32_t f, uint64_t mword0,
-                                               const JgDenseRegs<R>& x, uint64_t commit0, uint64_t head0) {
-  const uint32_t G = d.G;
-  const uint64_t esc = jg_lag_esc(R);
-  uint64_t fl = jg_lag_encode(x.ms, x.head, R);
-  if (fl == esc) d.match_wide[(size_t)s * G + g] = x.ms;
-  uint64_t w = jg_lag_with(0, s, R, fl);
+__device__ __forceinline__ bool jg_lag_tick_regs(uint32_t s, uint32_t& nf_io, uint32_t (&l)[R + 1], uint64_t& head_io,
+                                                 uint64_t n_app, const uint64_t (&a)[R], uint32_t& dec) {
+  const uint64_t head0 = head_io;
+  const uint32_t n = (uint32_t)n_app;
+  bool bad = (n_app >> 20) != 0;
+  uint32_t incm = 0, somem = 0;
+  uint32_t nl[R + 1];
 #pragma unroll
-  for (int k = 0; k + 1 < R; k++) {
-    const uint32_t r = jg_other_slot(k, s);
-    fl = jg_lag_encode(x.mo[k], x.head, R);
-    if (fl == esc) d.match_wide[(size_t)r * G + g] = x.mo[k];
-    w = jg_lag_with(w, r, R, fl);
+  for (int r = 0; r < R; r++) {
+    const uint32_t fr = l[r];
+    const uint64_t ar = a[r];
+    const uint64_t dk = head0 - ar;
+    const bool self = (uint32_t)r == s;
+    const bool some = !self && ar != JG_NO_ACK;
+    uint32_t dl = (uint32_t)(dk >> 32) ? 0xffffffffu : (uint32_t)dk;
+    dl = some ? dl : 0xffffffffu;
+    const bool inc = dl < fr;  // progress.rs:133-140
+    incm |= inc ? (1u << r) : 0u;
+    somem |= some ? (1u << r) : 0u;
+    const uint32_t lo = (self && n) ? 0u : min(fr, dl) + n;
+    nl[r] = lo;
+    bad |= lo >= (1u << 30);
+    bad |= some && ar > head0;  // an ack above the head: replay, the reference may panic
   }
-  fl = jg_lag_encode(x.commit, x.head, R);
-  if (fl == esc && (x.commit != commit0 || jg_lag_field(mword0, R, R) != esc)) d.commit[g] = x.commit;
-  w = jg_lag_with(w, R, R, fl);
-  if (w != mword0) d.mlag[g] = w;
-  if (x.head != head0) d.head[g] = x.head;
-  if (x.nf != f) d.flags[g] = x.nf;
+  const uint32_t lc = l[R] + n;
+  const uint32_t ql = jg_kth_lag<R>(nl);  // progress.rs:48-60
+  nl[R] = min(lc, ql);                    // leader.rs:89-92
+  bad |= lc >= (1u << 30);
+  if (bad) return false;
+  uint32_t nf = (nf_io & ~(somem << JGF_REPL_SHIFT)) | (incm << JGF_REPL_SHIFT);
+  nf |= n ? (1u << (JGF_REPL_SHIFT + s)) : 0u;
+  nf |= ql < lc ? JGF_COMMIT_KEY : 0u;  // chain.rs:198
+  nf_io = nf;
+#pragma unroll
+  for (int r = 0; r <= R; r++) l[r] = nl[r];
+  head_io = head0 + n;
+  dec += n + (uint32_t)__popc(somem);
+  return true;
 }
 
 // ---- deferral to the slow kernel: wave-aggregated append to sharded lists -----------------------
@@ -542,8 +430,9 @@ __device__ __forceinline__ void jg_dense_issue(const JgDenseHot& h, const JgDev*
 }
 
 // ---- the general path of the ack-only kernel, in memory form ------------------------------------
-// Same results as jg_dense_unpack + jg_dense_core + jg_dense_store (the register form the node tick
-// and the T-tick kernel use), written as rolled loops over a per-lane LDS column of the R progress
+// The tick on absolute 64-bit progress heads (fused when no chain.commit panic is possible, else
+// one Leader::commit per append / ack with a fault exactly where the reference would panic),
+// written as rolled loops over a per-lane LDS column of the R progress
 // heads: a handful of registers instead of ~90, because the register allocation of a kernel is the
 // maximum over all its paths and this one is taken by almost no group (escaped lag fields, acks
 // above the head).  Apart from the flag word and the append count its inputs are read again from memory.
@@ -791,42 +680,78 @@ __device__ __forceinline__ uint32_t jg_dense_ticks_body(const JgDev& d, const ui
   for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
     const uint32_t f = d.flags[g];
     const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
-    JgDenseRegs<R> x;
-    uint64_t a[R], mword0;
-    jg_dense_load<R>(jg_dense_hot_of(d), acks, g, a, mword0, x.head);
-    jg_dense_split_acks<R>(a, s, x.n_app, x.ao);
+    uint64_t a[R], mword0, head0;
+    jg_dense_load<R, false>(jg_dense_hot_of(d), acks, g, a, mword0, head0);
+    asm volatile("" ::"v"(f));  // (one round trip: see jg_dense_issue)
+    __builtin_amdgcn_sched_barrier(0);
     const bool leader = (f & JGF_ROLE_MASK) == JG_ROLE_LEADER;
     const bool dead = (f & JGF_FAULT_MASK) != 0;                // the reference process is gone
     const bool defer = !dead && leader && !(f & JGF_FAST);      // irregular chain: k_dense_slow replays all ticks
     jg_defer_push(d, g, defer);
     if (dead || defer) continue;
-    x.commit = 0;
-    if (leader) jg_dense_unpack<R>(d, g, s, mword0, x);
-    const uint64_t commit0 = x.commit, head0 = x.head;
-    x.nf = f;
-    for (uint32_t t = 0; t < n_ticks; t++) {
-      const bool more = t + 1 < n_ticks;
-      uint64_t an[R];
-      if (more)  // software prefetch of the next tick's acks
-        jg_dense_load_acks<R>(acks + (size_t)(t + 1) * tick_stride, G, g, an);
+    // Leaders stay in lag space: jg_lag_tick on the packed word, carried from tick to tick in
+    // registers.  Nothing is stored before the last tick, so a group with a tick that does not
+    // fit (escaped field, ack above the head) is handed to k_dense_slow as it was, for all T ticks.
+    constexpr uint32_t B = 64u / (R + 1u);
+    constexpr uint32_t ESC = (uint32_t)((1ull << (B > 31 ? 31 : B)) - 1ull);
+    uint64_t head = head0;
+    uint32_t nf = f, gdec = 0;
+    uint32_t l[R + 1];
+    bool fits = B <= 21;  // (R = 1: 32-bit fields, general path)
+#pragma unroll
+    for (int r = 0; r <= R; r++) {
+      l[r] = (uint32_t)(mword0 >> (r * B)) & ESC;
+      fits = fits && l[r] != ESC;
+    }
+    fits = fits || !leader;
+    // software prefetch, two ticks deep: the acks of tick t + 2 are requested before tick t is
+    // evaluated (one tick ahead left the memory system short of requests in flight)
+    uint64_t a1[R];
+    if (n_ticks > 1) {
+      jg_dense_load_acks<R>(acks + tick_stride, G, g, a1);
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) a1[r] = JG_NO_ACK;
+    }
+    for (uint32_t t = 0; fits && t < n_ticks; t++) {
+      uint64_t a2[R];
+      if (t + 2 < n_ticks) {
+        jg_dense_load_acks<R>(acks + (size_t)(t + 2) * tick_stride, G, g, a2);
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) a2[r] = JG_NO_ACK;  // (never looked at)
+      }
+      uint64_t n_app = a[0];
+#pragma unroll
+      for (int r = 1; r < R; r++) n_app = (uint32_t)r == s ? a[r] : n_app;
       if (!leader) {
         // acks are ignored by followers / candidates (follower.rs:62, candidate.rs:194)
-        if (x.n_app) {
-          x.nf = f | (JG_FAULT_ENGINE_DENSE_NONLEADER << JGF_FAULT_SHIFT);
+        if (n_app) {
+          nf = f | (JG_FAULT_ENGINE_DENSE_NONLEADER << JGF_FAULT_SHIFT);
           jg_push_fault(d, g, JG_FAULT_ENGINE_DENSE_NONLEADER, seq0 + t);
           break;
         }
-      } else {
-        dec += jg_dense_core<R>(d, g, seq0 + t, s, x);
-        if (x.nf & JGF_FAULT_MASK) break;
+      } else if (!jg_lag_tick_regs<R>(s, nf, l, head, n_app, a, gdec)) {
+        fits = false;
       }
-      if (more) jg_dense_split_acks<R>(an, s, x.n_app, x.ao);
+#pragma unroll
+      for (int r = 0; r < R; r++) a[r] = a1[r], a1[r] = a2[r];
     }
-    if (leader) {
-      jg_dense_store<R>(d, g, s, f, mword0, x, commit0, head0);
-    } else if (x.nf != f) {
-      d.flags[g] = x.nf;
+    uint64_t w = mword0;
+    if (leader && fits) {  // pack once per launch; a lag that left its field: general path
+      w = 0;
+#pragma unroll
+      for (int r = 0; r <= R; r++) {
+        fits = fits && l[r] < ESC;
+        w |= (uint64_t)l[r] << (r * B);
+      }
     }
+    jg_defer_push(d, g, !fits);
+    if (!fits) continue;
+    dec += gdec;
+    if (w != mword0) d.mlag[g] = w;
+    if (head != head0) d.head[g] = head;
+    if (nf != f) d.flags[g] = nf;
   }
   return dec;
 }

@@ -214,9 +214,9 @@ int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1, con
   }
   e->n_launch++;
   // the slow kernel behind it: when a sparse step may have left a leader with an irregular
-  // chain, and behind every node tick (its general path: a HeartbeatResponse without the commit,
-  // an escaped lag field, an ack above the head)
-  if (e->maybe_irregular || nd) {
+  // chain, and behind every node tick and every T-tick launch (their general path: a
+  // HeartbeatResponse without the commit, an escaped lag field, an ack above the head)
+  if (e->maybe_irregular || nd || n_ticks > 1) {
     e->slow_scheduled_ever = true;
     JgLeaderNode none{};
     hipLaunchKernelGGL(k_dense_slow, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream, e->dev, acks_dev, n_ticks,

@@ -442,3 +442,22 @@ def test_dense_lag_space_boundaries(R, slot_layout):
         assert dev.counters()["decisions"] == ora.counters()["decisions"]
     faults = np.bincount(ora.read("fault"), minlength=256)
     assert (R < 3 or faults[capi.FAULT_COMMIT_MISSING_BLOCK] > 0) and faults[0] > G // 2, faults[:8]
+
+
+@pytest.mark.parametrize("R", [3, 5])
+def test_fused_ticks_nonleader_append_at_every_tick(R):
+    """A follower asked to append (an engine precondition fault, JG_FAULT_ENGINE_DENSE_NONLEADER) in
+    tick t of a T-tick launch, for every (T, t): the ack blocks of the later ticks reach the lane
+    through the two-deep prefetch ring of k_leader_tick_dense_n."""
+    G = 64
+    for T in (1, 2, 3, 4, 7):
+        for tick in range(T):
+            dev, ora = pair(G, R, seed=31)
+            acks = np.full((T, R, G), capi.NO_ACK, dtype=np.uint64)
+            acks[:, 0, :] = 0
+            acks[tick, 0, 3::5] = 1
+            for e in (dev, ora):
+                e.step_dense_acks_n(acks) if T > 1 else e.step_dense_acks(acks[0])
+            compare_snapshots(dev, ora, f"non-leader append T={T} tick={tick}")
+            compare_drains(dev, ora, f"non-leader append T={T} tick={tick}")
+            assert (ora.read("fault")[3::5] == capi.FAULT_ENGINE_DENSE_NONLEADER).all()
