@@ -603,12 +603,8 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   jg_dense_cold_lds<R, UNIFORM>(d, acks, seq, s, f, n_app, g, dec, sm);
 }
 
-// Grid-stride loop with the next group's loads issued before the current group is evaluated
-// (JG_DENSE_PREFETCH): a lane that serves several groups keeps HBM requests in flight during
-// its arithmetic.
-#ifndef JG_DENSE_PREFETCH
-#define JG_DENSE_PREFETCH 0
-#endif
+// Grid-stride loop over the groups (a software prefetch of the next group's loads measured no gain
+// and cost 13 VGPRs: profiles/README.md).
 template <int R, bool UNIFORM, bool NODE>
 __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, const JgDev* dp,
                                                        const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us,
@@ -617,22 +613,10 @@ __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, co
   const bool emit = NODE && nd.o_term != nullptr;
   JgDecCount dec;
   uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x;
-  if (JG_DENSE_PREFETCH && !NODE) {
-    JgDenseIn<R> cur, nxt;
-    if (g < G) jg_dense_issue<R, UNIFORM, NODE>(h, dp, acks, us, nd, emit, g, cur);
-    while (g < G) {
-      const uint32_t gn = g + stride;
-      if (gn < G) jg_dense_issue<R, UNIFORM, NODE>(h, dp, acks, us, nd, emit, gn, nxt);
-      jg_dense_group<R, UNIFORM, NODE>(h, dp, acks, seq, us, nd, emit, g, cur, dec, sm);
-      cur = nxt;
-      g = gn;
-    }
-  } else {
-    for (; g < G; g += stride) {
-      JgDenseIn<R> in;
-      jg_dense_issue<R, UNIFORM, NODE>(h, dp, acks, us, nd, emit, g, in);
-      jg_dense_group<R, UNIFORM, NODE>(h, dp, acks, seq, us, nd, emit, g, in, dec, sm);
-    }
+  for (; g < G; g += stride) {
+    JgDenseIn<R> in;
+    jg_dense_issue<R, UNIFORM, NODE>(h, dp, acks, us, nd, emit, g, in);
+    jg_dense_group<R, UNIFORM, NODE>(h, dp, acks, seq, us, nd, emit, g, in, dec, sm);
   }
   return dec;
 }
