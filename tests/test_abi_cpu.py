@@ -125,3 +125,16 @@ def test_submit_validation():
         e.submit_columns([99], [0])                       # unknown kind
     with pytest.raises(EngineError):
         e.submit_columns([capi.CMD_APPEND_ENTRIES], [0], id=[0], aux=[3], blk_id=[1], blk_next=[0])
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: include/josefine_gpu.h must compile as C99 (what cgo / bindgen /
+    a Rust `extern "C"` block would be generated from), with no C++ or HIP types in it."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "josefine_gpu.h")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    src = open(hdr).read()
+    assert "hip" not in src.lower().replace("hipcc", "") or "hip_runtime" not in src
+    assert "torch" not in src.lower()
