@@ -11,7 +11,10 @@ its own 1M x 5 shard (weak scaling, contiguous global group ids, no data-path
 collective: Raft groups are independent — SURVEY.md §8(e)).
 
 A "step" = one tick = one launch of k_leader_tick_dense<5> over the rank's
-groups.  Prints ONE JSON line on rank 0.
+groups.  Timing: barrier + synchronize, then exactly K steps; a rank's clock stops
+when its own K steps are complete (HIP event + synchronize), the closing barrier
+follows, and the MAX over ranks is what is reported (the latency of the barrier
+collective itself is not part of anybody's K steps).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
@@ -176,8 +179,11 @@ def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
     rounds(K)
     ev_ms = C.c_float(0)
     L._check(api.timer_stop(L._h, C.byref(ev_ms)))
+    for e in nodes:
+        e._check(api.sync(e._h))
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0  # this rank's K rounds are done; MAX over ranks below
     barrier()
-    wall = time.perf_counter() - t0
     decisions = float(L.counters()["decisions"] - c0["decisions"])
 
     # full-size property check: real protocol rounds, so the commit index trails the head by the
@@ -331,9 +337,10 @@ def main():
     eng._check(api.timer_start(h))
     n_launches = run_ticks(W, W + K)
     ev_ms = C.c_float(0)
-    eng._check(api.timer_stop(h, C.byref(ev_ms)))  # HIP events on the engine's stream
+    eng._check(api.timer_stop(h, C.byref(ev_ms)))  # HIP events on the engine's stream (synchronises it)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0  # this rank's K steps are done; MAX over ranks below
     barrier()
-    wall = time.perf_counter() - t0
     c1 = eng.counters()
 
     decisions = c1["decisions"] - c0["decisions"]
