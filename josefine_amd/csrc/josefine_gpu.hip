@@ -645,6 +645,13 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   if ((rc = push_dev_copy(e)) != JG_OK) return bail(rc);
   hipLaunchKernelGGL(k_init_groups, dim3(grid_for(G, 2048)), dim3(JG_BLOCK), 0, e->stream, e->dev,
                      (const uint8_t*)nullptr);
+  {  // one launch of the general-path kernel over its (empty) lists: it is the only kernel with
+     // scratch memory, which the runtime sets up at a kernel's first launch (~150 us) — here, not
+     // inside somebody's first node tick
+    JgLeaderNode none{};
+    hipLaunchKernelGGL(k_dense_slow, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream, e->dev, (const uint64_t*)nullptr,
+                       0u, (size_t)0, 0u, none);
+  }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
     return bail(fail(JG_EDEVICE, "k_init_groups failed: is this a gfx950 device? (no CPU fallback)"));
   *out = e;
