@@ -183,9 +183,9 @@ __device__ __forceinline__ bool jg_lag_tick(uint32_t s, uint32_t f, uint64_t w0,
   constexpr uint32_t B = 64u / (R + 1u);
   if (B > 21) return false;  // R = 1: 32-bit fields, take the general path
   constexpr uint32_t ESC = (uint32_t)((1ull << (B > 21 ? 21 : B)) - 1ull);
+  constexpr uint32_t BEHIND = ESC - 1u, INF = 0xffffffffu;  // jg_lag_behind(); how a BEHIND slot sorts
   const uint32_t n = (uint32_t)n_app;
   bool bad = (n_app >> 20) != 0;
-  // any escaped field?  (one test on the whole word: a field is all ones <=> adding 1 to it carries out)
   uint32_t incm = 0, somem = 0;  // per slot: increment() returned true / an ack arrived
 #pragma unroll
   for (int r = 0; r < R; r++) {
@@ -194,6 +194,10 @@ __device__ __forceinline__ bool jg_lag_tick(uint32_t s, uint32_t f, uint64_t w0,
     const uint64_t dk = head0 - ar;
     const bool self = (uint32_t)r == s;  // engine-uniform in the normal case: scalar
     const bool some = !self && ar != JG_NO_ACK;
+    // A replica that is too far behind for its field (a follower that is down) stays where it
+    // is until an ack arrives for it: its lag is larger than every in-range lag, which is all the
+    // majority needs to know.  An ack for it, or the own slot in that state: exact compare, general path.
+    const bool behind = fr == BEHIND;
     // lag of the ack below the old head; acks further than 2^32 behind are just "stale"
     uint32_t dl = (uint32_t)(dk >> 32) ? 0xffffffffu : (uint32_t)dk;
     dl = some ? dl : 0xffffffffu;
@@ -201,19 +205,20 @@ __device__ __forceinline__ bool jg_lag_tick(uint32_t s, uint32_t f, uint64_t w0,
     incm |= inc ? (1u << r) : 0u;
     somem |= some ? (1u << r) : 0u;
     // own slot: n self-acks leave its head at the new chain head
-    const uint32_t lo = (self && n) ? 0u : min(fr, dl) + n;
+    uint32_t lo = (self && n) ? 0u : min(fr, dl) + n;
+    bad |= fr == ESC;                      // a head above the chain head (forged ack)
+    bad |= behind ? some : lo >= BEHIND;   // an ack for a BEHIND slot / a lag leaving its field (wide column)
+    bad |= some && ar > head0;             // an ack above the head: replay, the reference may panic
+    lo = (behind && !(self && n)) ? INF : lo;  // (an own BEHIND slot: its self-ack lands on the head all the same)
     o.l[r] = lo;
-    bad |= fr == ESC;
-    bad |= lo >= ESC;
-    bad |= some && ar > head0;  // an ack above the head: replay, the reference may panic
   }
   const uint32_t fc = (uint32_t)(w0 >> (R * B)) & ESC;
-  const uint32_t lc = fc + n;
-  const uint32_t ql = jg_kth_lag<R>(o.l);  // progress.rs:48-60
+  const uint32_t lc = fc == BEHIND ? INF : fc + n;  // the commit index, possibly far behind (quorum was lost)
+  const uint32_t ql = jg_kth_lag<R>(o.l);  // progress.rs:48-60; INF: the majority slot is a BEHIND one, q < commit
   const uint32_t nl = min(lc, ql);         // leader.rs:89-92
   o.l[R] = nl;
   bad |= fc == ESC;
-  bad |= nl >= ESC;
+  bad |= nl >= BEHIND;  // (both unknown, or the commit lag leaving its field)
   if (bad) return false;
   // Probe / Replicate bits: cleared where an ack did not advance, set where one did; the own
   // slot's last self-ack always advances (-> Replicate)
@@ -222,7 +227,7 @@ __device__ __forceinline__ bool jg_lag_tick(uint32_t s, uint32_t f, uint64_t w0,
   nf |= ql < lc ? JGF_COMMIT_KEY : 0u;  // chain.rs:198
   uint64_t w = 0;
 #pragma unroll
-  for (int r = 0; r <= R; r++) w |= (uint64_t)o.l[r] << (r * B);
+  for (int r = 0; r <= R; r++) w |= (uint64_t)min(o.l[r], BEHIND) << (r * B);
   o.w1 = w;
   o.head1 = head0 + n;
   o.nf = nf;
@@ -237,6 +242,7 @@ template <int R>
 __device__ __forceinline__ bool jg_lag_tick_regs(uint32_t s, uint32_t& nf_io, uint32_t (&l)[R + 1], uint64_t& head_io,
                                                  uint64_t n_app, const uint64_t (&a)[R], uint32_t& dec) {
   const uint64_t head0 = head_io;
+  constexpr uint32_t INF = 0xffffffffu;  // a BEHIND slot (see jg_lag_tick)
   const uint32_t n = (uint32_t)n_app;
   bool bad = (n_app >> 20) != 0;
   uint32_t incm = 0, somem = 0;
@@ -248,20 +254,21 @@ __device__ __forceinline__ bool jg_lag_tick_regs(uint32_t s, uint32_t& nf_io, ui
     const uint64_t dk = head0 - ar;
     const bool self = (uint32_t)r == s;
     const bool some = !self && ar != JG_NO_ACK;
+    const bool behind = fr == INF;
     uint32_t dl = (uint32_t)(dk >> 32) ? 0xffffffffu : (uint32_t)dk;
     dl = some ? dl : 0xffffffffu;
     const bool inc = dl < fr;  // progress.rs:133-140
     incm |= inc ? (1u << r) : 0u;
     somem |= some ? (1u << r) : 0u;
-    const uint32_t lo = (self && n) ? 0u : min(fr, dl) + n;
-    nl[r] = lo;
-    bad |= lo >= (1u << 30);
+    uint32_t lo = (self && n) ? 0u : min(fr, dl) + n;
+    bad |= behind ? some : lo >= (1u << 30);
     bad |= some && ar > head0;  // an ack above the head: replay, the reference may panic
+    nl[r] = (behind && !(self && n)) ? INF : lo;
   }
-  const uint32_t lc = l[R] + n;
+  const uint32_t lc = l[R] == INF ? INF : l[R] + n;
   const uint32_t ql = jg_kth_lag<R>(nl);  // progress.rs:48-60
   nl[R] = min(lc, ql);                    // leader.rs:89-92
-  bad |= lc >= (1u << 30);
+  bad |= nl[R] >= (1u << 30);
   if (bad) return false;
   uint32_t nf = (nf_io & ~(somem << JGF_REPL_SHIFT)) | (incm << JGF_REPL_SHIFT);
   nf |= n ? (1u << (JGF_REPL_SHIFT + s)) : 0u;
@@ -296,6 +303,22 @@ __device__ __forceinline__ void jg_defer_push(const JgDev& d, uint32_t g, bool w
     const uint32_t i = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     if (i < d.slow_cap) d.slow_list[(size_t)shard * d.slow_cap + i] = g | tag;
     else *d.err = 4;
+    *d.deferred_seen = 1;  // lets the host verify that the slow kernel was scheduled
+  }
+}
+
+// The dense LEADER kernels mark deferred groups in a bitmap instead: a wave serves 64 consecutive
+// groups, so its __ballot is the word of the bitmap, or-ed in by one lane with a fire-and-forget
+// atomic - nothing comes back, the wave does not wait.  (The list append above returns the slot
+// base to the wave: at 1 % deferred groups per tick half the waves of a launch sat out a trip to
+// L2 for it and the configs[4] tick of this kernel took 39 us instead of 11.)  k_dense_slow turns
+// its shard of the bitmap into its list.
+__device__ __forceinline__ void jg_defer_mark(const JgDev& d, uint32_t g, bool want) {
+  const uint64_t mask = __ballot(want);
+  if (!mask) return;
+  const int first = __ffsll((long long)mask) - 1;
+  if ((int)(threadIdx.x & 63u) == first) {
+    (void)__hip_atomic_fetch_or(&d.defer_bits[g >> 6], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *d.deferred_seen = 1;  // lets the host verify that the slow kernel was scheduled
   }
 }
@@ -468,7 +491,7 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
 #pragma clang loop unroll(disable)
   for (int r = 0; r < R; r++) {
     const uint64_t fl = (w0 >> (r * B)) & esc;
-    const uint64_t v = fl == esc ? d.match_wide[(size_t)r * G + g] : head0 - fl;
+    const uint64_t v = jg_lag_wide(fl, R) ? d.match_wide[(size_t)r * G + g] : head0 - fl;
     sm[r][t] = v;
     hi = v > hi ? v : hi;
     if ((uint32_t)r != s && acks) {
@@ -477,7 +500,7 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
     }
   }
   const uint64_t fc = (w0 >> (R * B)) & esc;
-  const uint64_t commit0 = fc == esc ? d.commit[g] : head0 - fc;
+  const uint64_t commit0 = jg_lag_wide(fc, R) ? d.commit[g] : head0 - fc;
   uint64_t commit = commit0, head = head0;
   uint32_t nf = f, fault = 0, dc = 0;
   const bool fused = hi <= head0;  // no chain.commit panic possible: one majority evaluation
@@ -538,11 +561,11 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
   for (int r = 0; r < R; r++) {
     const uint64_t v = sm[r][t];
     const uint64_t fl = jg_lag_encode(v, head, R);
-    if (fl == esc) d.match_wide[(size_t)r * G + g] = v;
+    if (jg_lag_wide(fl, R)) d.match_wide[(size_t)r * G + g] = v;
     w |= fl << (r * B);
   }
   const uint64_t fl = jg_lag_encode(commit, head, R);
-  if (fl == esc && (commit != commit0 || fc != esc)) d.commit[g] = commit;
+  if (jg_lag_wide(fl, R) && (commit != commit0 || !jg_lag_wide(fc, R))) d.commit[g] = commit;
   w |= fl << (R * B);
   if (w != w0) d.mlag[g] = w;
   if (head != head0) d.head[g] = head;
@@ -576,8 +599,9 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   jg_count_step(h.blk_decisions, dec, hot, dl);
   if (__builtin_expect(hot, 1)) {
     if (emit)  // Command::Tick into the outbox; may raise the Q9 fault
-      lt.nf = jg_dense_leader_tick<R>(h, dp, nd, g, seq, s, term, hbt, lt.head1, lt.head1 - lt.l[R], lt.nf,
-                                      [&](int r) { return lt.head1 - lt.l[r]; });
+      lt.nf = jg_dense_leader_tick<R>(h, dp, nd, g, seq, s, term, hbt, lt.head1, lt.head1 - lt.l[R], lt.nf, [&](int r) {
+        return lt.l[r] == 0xffffffffu ? dp->match_wide[(size_t)r * h.G + g] : lt.head1 - lt.l[r];  // BEHIND: wide column
+      });
     if (lt.w1 != mword0) h.mlag[g] = lt.w1;
     if (lt.head1 != head0) h.head[g] = lt.head1;
     if (lt.nf != f) h.flags[g] = lt.nf;
@@ -592,7 +616,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   // behind a node tick and runs HeartbeatResponses, appends, acks and the Tick of these groups
   // through the general state machine (columns for a FAST chain, rows otherwise)
   if (NODE && cls == JG_DENSE_RUN) cls = JG_DENSE_DEFER;
-  jg_defer_push(d, g, cls == JG_DENSE_DEFER);
+  jg_defer_mark(d, g, cls == JG_DENSE_DEFER);
   if (NODE) {
     if (emit) jg_dense_outbox_none<R>(h.G, nd, g);
     return;
@@ -671,7 +695,7 @@ __device__ __forceinline__ uint32_t jg_dense_ticks_body(const JgDev& d, const ui
     const bool leader = (f & JGF_ROLE_MASK) == JG_ROLE_LEADER;
     const bool dead = (f & JGF_FAULT_MASK) != 0;                // the reference process is gone
     const bool defer = !dead && leader && !(f & JGF_FAST);      // irregular chain: k_dense_slow replays all ticks
-    jg_defer_push(d, g, defer);
+    jg_defer_mark(d, g, defer);
     if (dead || defer) continue;
     // Leaders stay in lag space: jg_lag_tick on the packed word, carried from tick to tick in
     // registers.  Nothing is stored before the last tick, so a group with a tick that does not
@@ -685,7 +709,8 @@ __device__ __forceinline__ uint32_t jg_dense_ticks_body(const JgDev& d, const ui
 #pragma unroll
     for (int r = 0; r <= R; r++) {
       l[r] = (uint32_t)(mword0 >> (r * B)) & ESC;
-      fits = fits && l[r] != ESC;
+      fits = fits && l[r] != ESC;                  // a head above the chain head: general path
+      l[r] = l[r] == ESC - 1u ? 0xffffffffu : l[r];  // BEHIND: stays as it is while no ack arrives
     }
     fits = fits || !leader;
     // software prefetch, two ticks deep: the acks of tick t + 2 are requested before tick t is
@@ -726,11 +751,11 @@ __device__ __forceinline__ uint32_t jg_dense_ticks_body(const JgDev& d, const ui
       w = 0;
 #pragma unroll
       for (int r = 0; r <= R; r++) {
-        fits = fits && l[r] < ESC;
-        w |= (uint64_t)l[r] << (r * B);
+        fits = fits && (l[r] < ESC - 1u || l[r] == 0xffffffffu);
+        w |= (uint64_t)min(l[r], ESC - 1u) << (r * B);
       }
     }
-    jg_defer_push(d, g, !fits);
+    jg_defer_mark(d, g, !fits);
     if (!fits) continue;
     dec += gdec;
     if (w != mword0) d.mlag[g] = w;

@@ -86,6 +86,7 @@ struct JgDev {
   uint32_t* deferred_seen;   // the dense fast path met a leader whose chain is not in FAST form
   uint32_t* slow_list;       // [JG_SHARDS][ceil(G/JG_SHARDS)] deferred groups per shard
   uint32_t* slow_cnt;        // [JG_SHARDS]
+  uint64_t* defer_bits;      // [ceil(G/64)] groups a dense leader kernel handed to k_dense_slow (bit g & 63 of word g >> 6)
   uint32_t* irregular_seen;  // set when a leader is stored with a chain that is not in FAST form
   JgXqRec* xq;               // exceptional message rows of dense node steps (lazily allocated)
   uint32_t* xq_n;
@@ -121,9 +122,17 @@ __host__ __device__ __forceinline__ uint64_t jg_lag_with(uint64_t w, uint32_t r,
   const uint32_t sh = r * jg_lag_bits(R);
   return (w & ~(jg_lag_esc(R) << sh)) | (field << sh);
 }
-// lag field for absolute value v under chain head `base`; the escape when it does not fit
+// Two escape codes, both meaning "the absolute value is in the wide column": the all-ones field
+// for a value ABOVE the base (a forged ack above the head), all-ones minus one for a value too far
+// BEHIND it (a replica that is down: its lag grows by one block per append).  The dense kernels
+// keep serving a group with BEHIND fields in lag space (such a slot sorts after every in-range
+// lag; nothing about it changes until an ack arrives for it); an ABOVE field takes the general path.
+__host__ __device__ __forceinline__ uint64_t jg_lag_behind(uint32_t R) { return jg_lag_esc(R) - 1ull; }
+__host__ __device__ __forceinline__ bool jg_lag_wide(uint64_t field, uint32_t R) { return field >= jg_lag_behind(R); }
+// lag field for absolute value v under chain head `base`; an escape code when it does not fit
 __host__ __device__ __forceinline__ uint64_t jg_lag_encode(uint64_t v, uint64_t base, uint32_t R) {
-  return (v <= base && base - v < jg_lag_esc(R)) ? base - v : jg_lag_esc(R);
+  if (v > base) return jg_lag_esc(R);
+  return base - v < jg_lag_behind(R) ? base - v : jg_lag_behind(R);
 }
 
 // Registers of one group while a lane walks its command segment.
@@ -176,11 +185,11 @@ __device__ inline void jg_chain_normalize(const JgDev& d, JgLane& L);
 // Progress.head of slot r of the lane's group (leaders)
 __device__ inline uint64_t jg_match_get(const JgDev& d, const JgLane& L, uint32_t r) {
   const uint64_t f = jg_lag_field(L.mword, r, d.R);
-  return f == jg_lag_esc(d.R) ? d.match_wide[(size_t)r * d.G + L.g] : L.mbase - f;
+  return jg_lag_wide(f, d.R) ? d.match_wide[(size_t)r * d.G + L.g] : L.mbase - f;
 }
 __device__ inline void jg_match_set(const JgDev& d, JgLane& L, uint32_t r, uint64_t v) {
   const uint64_t f = jg_lag_encode(v, L.mbase, d.R);
-  if (f == jg_lag_esc(d.R)) d.match_wide[(size_t)r * d.G + L.g] = v;
+  if (jg_lag_wide(f, d.R)) d.match_wide[(size_t)r * d.G + L.g] = v;
   L.mword = jg_lag_with(L.mword, r, d.R, f);
 }
 __device__ inline void jg_match_rebase(const JgDev& d, JgLane& L) {
@@ -188,7 +197,7 @@ __device__ inline void jg_match_rebase(const JgDev& d, JgLane& L) {
   for (uint32_t r = 0; r < d.R; r++) {
     const uint64_t v = jg_match_get(d, L, r);
     const uint64_t f = jg_lag_encode(v, L.head, d.R);
-    if (f == jg_lag_esc(d.R)) d.match_wide[(size_t)r * d.G + L.g] = v;
+    if (jg_lag_wide(f, d.R)) d.match_wide[(size_t)r * d.G + L.g] = v;
     w = jg_lag_with(w, r, d.R, f);
   }
   L.mword = w;
@@ -215,7 +224,7 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
   if ((L.flags & JGF_ROLE_MASK) == JG_ROLE_LEADER) {
     L.mword = d.mlag[g];
     const uint64_t fc = jg_lag_field(L.mword, d.R, d.R);
-    L.commit = fc == jg_lag_esc(d.R) ? d.commit[g] : L.head - fc;
+    L.commit = jg_lag_wide(fc, d.R) ? d.commit[g] : L.head - fc;
   } else {
     L.commit = d.commit[g];
   }
@@ -236,7 +245,7 @@ __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   if (jg_role(L) == JG_ROLE_LEADER) {
     if (L.mbase != L.head) jg_match_rebase(d, L);  // the head moved: the lags are relative to it
     const uint64_t fc = jg_lag_encode(L.commit, L.head, d.R);
-    if (fc == jg_lag_esc(d.R)) d.commit[g] = L.commit;
+    if (jg_lag_wide(fc, d.R)) d.commit[g] = L.commit;
     d.mlag[g] = jg_lag_with(L.mword, d.R, d.R, fc);
   } else {
     d.commit[g] = L.commit;

@@ -25,8 +25,33 @@
 __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
                                                           size_t tick_stride, uint32_t seq0, JgLeaderNode nd) {
   uint32_t dec = 0;
-  const uint32_t n = d.slow_cnt[blockIdx.x] < d.slow_cap ? d.slow_cnt[blockIdx.x] : d.slow_cap;
-  const uint32_t* list = d.slow_list + (size_t)blockIdx.x * d.slow_cap;
+  // this workgroup's shard of the deferral bitmap (jg_defer_mark) -> its list; the words are
+  // cleared for the next launch.  (Order within the list is immaterial: groups are independent,
+  // fault and exceptional rows are ordered at drain time.)
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  uint32_t* list = d.slow_list + (size_t)blockIdx.x * d.slow_cap;
+  {
+    const uint32_t n_words = (d.G + 63u) / 64u;
+    const uint32_t wpb = (n_words + gridDim.x - 1) / gridDim.x;
+    const uint32_t w0 = blockIdx.x * wpb, w1 = w0 + wpb < n_words ? w0 + wpb : n_words;
+    for (uint32_t w = w0 + threadIdx.x; w < w1; w += JG_BLOCK) {
+      uint64_t m = d.defer_bits[w];
+      if (!m) continue;
+      d.defer_bits[w] = 0;
+      uint32_t at = atomicAdd(&s_n, (uint32_t)__popcll(m));
+      while (m) {
+        const uint32_t b = (uint32_t)__ffsll((long long)m) - 1u;
+        if (at < d.slow_cap) list[at] = w * 64u + b;
+        else *d.err = 4;
+        at++;
+        m &= m - 1;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t n = s_n < d.slow_cap ? s_n : d.slow_cap;
   for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) {
     const uint32_t g = list[i];
     JgLane L;

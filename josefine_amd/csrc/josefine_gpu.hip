@@ -637,9 +637,13 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   {  // deferred lists: shard = workgroup & (JG_SHARDS-1); generous per-shard capacity, bounds-checked
     const size_t n_wg = (G + JG_BLOCK - 1) / JG_BLOCK;
     d.slow_cap = (uint32_t)((3 * ((n_wg + JG_SHARDS - 1) / JG_SHARDS) + 2) * JG_BLOCK);
+    // (>= the groups of one shard of the deferral bitmap: ceil(ceil(G/64)/JG_SHARDS) * 64)
+    const size_t shard_groups = ((((G + 63) / 64) + JG_SHARDS - 1) / JG_SHARDS) * 64;
+    if (d.slow_cap < shard_groups) d.slow_cap = (uint32_t)shard_groups;
   }
   A(d.slow_list, (size_t)JG_SHARDS * d.slow_cap);
   A(d.slow_cnt, JG_SHARDS);
+  A(d.defer_bits, (G + 63) / 64);
   A(e->d_dev, 1);
 #undef A
   if ((rc = push_dev_copy(e)) != JG_OK) return bail(rc);
@@ -1029,7 +1033,7 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
       if ((rc = get64(d.mlag))) return rc;
       for (uint32_t i = 0; i < n; i++) {
         const uint64_t f = jg_lag_field(t64[i], d.R, d.R);
-        o64[i] = (role(i) != JG_ROLE_LEADER || f == jg_lag_esc(d.R)) ? col[i] : head[i] - f;
+        o64[i] = (role(i) != JG_ROLE_LEADER || jg_lag_wide(f, d.R)) ? col[i] : head[i] - f;
       }
       return JG_OK;
     }
@@ -1051,7 +1055,7 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
       if ((rc = get64(d.mlag))) return rc;
       for (uint32_t i = 0; i < n; i++) {
         const uint64_t f = jg_lag_field(t64[i], replica, d.R);
-        o64[i] = role(i) != JG_ROLE_LEADER ? 0 : f == jg_lag_esc(d.R) ? wide[i] : head[i] - f;
+        o64[i] = role(i) != JG_ROLE_LEADER ? 0 : jg_lag_wide(f, d.R) ? wide[i] : head[i] - f;
       }
       return JG_OK;
     }

@@ -461,3 +461,60 @@ def test_fused_ticks_nonleader_append_at_every_tick(R):
             compare_snapshots(dev, ora, f"non-leader append T={T} tick={tick}")
             compare_drains(dev, ora, f"non-leader append T={T} tick={tick}")
             assert (ora.read("fault")[3::5] == capi.FAULT_ENGINE_DENSE_NONLEADER).all()
+
+
+@pytest.mark.parametrize("R,entry", [(5, "acks"), (5, "acks_n"), (5, "leader"), (8, "acks"), (8, "leader"), (4, "acks_n")])
+def test_follower_down_stays_on_the_fast_path_and_exact(R, entry):
+    """The common failure: one follower is down.  Its progress head falls behind the chain head by
+    more than a lag field holds (BEHIND escape: the absolute head moves to the wide column once) and
+    stays there; the dense kernels keep serving such groups in lag space.  Later a second and third
+    follower go quiet too (quorum lost: the commit index falls BEHIND as well), then everybody comes
+    back (acks for BEHIND slots: exact compare on the general path, fields return into range).
+    State, decisions and (leader entry point) the Tick's outbox against the oracle all the way."""
+    G = 256
+    kw = dict(seed=41, flags=capi.CFG_SEPARATE_COMMIT_KEY)
+    dev, ora = pair(G, R, **kw)
+    for e in (dev, ora):
+        elect_all(e)
+        e.drain_messages(), e.drain_applies()
+    esc = (1 << (64 // (R + 1))) - 1
+    per = max(1, esc // 60)                       # appends per tick: ~70 ticks to leave a field
+    T_down, T_quorum, T_back = 80, 160, 240
+    rng = np.random.default_rng(7)
+    now = 0
+    t = 0
+    while t < T_back + 6:
+        n_t = 3 if entry == "acks_n" else 1
+        blk = np.full((n_t, R, G), capi.NO_ACK, dtype=np.uint64)
+        head = ora.read("head").astype(np.uint64)
+        for k in range(n_t):
+            blk[k, 0, :] = per + (rng.integers(0, 2, G) if t % 5 == 0 else 0)
+            up = [r for r in range(1, R)]
+            if t < T_back:
+                up = [r for r in up if r != 1]                        # slot 1 is down from the start
+            if T_quorum <= t < T_back:
+                up = [r for r in up if r > R // 2 + 1]                # ... then more than a minority
+            for r in up:
+                blk[k, r, :] = head + np.uint64(per * k)              # acks the head it was sent
+            if t >= T_back:
+                blk[k, 1, ::2] = head[::2] // 2                       # the returning follower catches up in steps
+        if entry == "leader":
+            now += 100
+            hbr_has = np.full((R, G), capi.HB_NONE, np.uint8)
+            oa = dev.step_dense_leader(now, blk[0], hbr_has, np.zeros((R, G), np.uint64), tick=True)
+            ob = ora.step_dense_leader(now, blk[0], hbr_has, np.zeros((R, G), np.uint64), tick=True)
+            for kk in oa:
+                assert np.array_equal(oa[kk], ob[kk]), f"tick {t}: outbox {kk}"
+        elif entry == "acks_n":
+            dev.step_dense_acks_n(blk)
+            ora.step_dense_acks_n(blk)
+        else:
+            dev.step_dense_acks(blk[0])
+            ora.step_dense_acks(blk[0])
+        t += n_t
+        if t % 16 < n_t or t in (T_down, T_quorum, T_back) or t > T_back - 4:
+            compare_snapshots(dev, ora, f"follower down R={R} {entry} tick {t}")
+            compare_drains(dev, ora, f"follower down R={R} {entry} tick {t}")
+    assert dev.counters()["decisions"] == ora.counters()["decisions"]
+    h, m1 = ora.read("head"), ora.read("match", 1)
+    assert (h > 2 * esc).all() and not ora.read("fault").any() and (m1 > 0).all()
