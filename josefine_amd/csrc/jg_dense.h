@@ -458,7 +458,7 @@ __device__ __forceinline__ void jg_dense_issue(const JgDenseHot& h, const JgDev*
 // written as rolled loops over a per-lane LDS column of the R progress
 // heads: a handful of registers instead of ~90, because the register allocation of a kernel is the
 // maximum over all its paths and this one is taken by almost no group (escaped lag fields, acks
-// above the head).  Apart from the flag word and the append count its inputs are read again from memory.
+// above the head).  Its inputs come from the registers the hot path loaded; the ack block is staged in LDS too.
 template <int R>
 __device__ __forceinline__ uint64_t jg_lds_kth(const uint64_t (*sm)[JG_BLOCK]) {
   // element R/2 of the heads sorted descending (progress.rs:48-60) by rank counting
@@ -480,12 +480,15 @@ __device__ __forceinline__ uint64_t jg_lds_kth(const uint64_t (*sm)[JG_BLOCK]) {
 
 template <int R, bool UNIFORM>
 __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t* __restrict__ acks, uint32_t seq,
-                                               uint32_t s, uint32_t f, uint64_t n_app, uint32_t g, JgDecCount& dec,
+                                               uint32_t s, uint32_t f, uint64_t n_app, uint32_t g,
+                                               const uint64_t (&a_in)[R], uint64_t w0, uint64_t head0, JgDecCount& dec,
                                                uint64_t (*sm)[JG_BLOCK]) {
   const uint32_t G = d.G, t = threadIdx.x;
   const uint32_t B = jg_lag_bits(R);
   const uint64_t esc = jg_lag_esc(R);
-  const uint64_t w0 = d.mlag[g], head0 = d.head[g];
+  uint64_t(*sa)[JG_BLOCK] = sm + R;  // the ack block of this lane, staged from the registers the hot
+#pragma unroll                        // path loaded it into (no second trip to HBM per rolled iteration)
+  for (int r = 0; r < R; r++) sa[r][t] = ((uint32_t)r == s || !acks) ? JG_NO_ACK : a_in[r];
   // packed lags -> absolute progress heads (escaped fields: the wide column)
   uint64_t hi = 0;
 #pragma clang loop unroll(disable)
@@ -494,10 +497,8 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
     const uint64_t v = jg_lag_wide(fl, R) ? d.match_wide[(size_t)r * G + g] : head0 - fl;
     sm[r][t] = v;
     hi = v > hi ? v : hi;
-    if ((uint32_t)r != s && acks) {
-      const uint64_t a = acks[(size_t)r * G + g];
-      hi = (a != JG_NO_ACK && a > hi) ? a : hi;
-    }
+    const uint64_t a = sa[r][t];
+    hi = (a != JG_NO_ACK && a > hi) ? a : hi;
   }
   const uint64_t fc = (w0 >> (R * B)) & esc;
   const uint64_t commit0 = jg_lag_wide(fc, R) ? d.commit[g] : head0 - fc;
@@ -530,8 +531,8 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
   // the other slots' acks, ascending (progress.rs:76-94,133-140); one Leader::commit each unless fused
 #pragma clang loop unroll(disable)
   for (int r = 0; r < R; r++) {
-    if ((uint32_t)r == s || !acks || fault) continue;
-    const uint64_t a = acks[(size_t)r * G + g];
+    if (fault) continue;
+    const uint64_t a = sa[r][t];  // (JG_NO_ACK in the own slot)
     if (a == JG_NO_ACK) continue;
     const bool inc = sm[r][t] < a;
     if (inc) sm[r][t] = a;
@@ -624,7 +625,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   if (cls != JG_DENSE_RUN) return;
   // the ack-only kernel: rolled loops over LDS, so that the kernel's register allocation
   // (= its occupancy) is the hot path's
-  jg_dense_cold_lds<R, UNIFORM>(d, acks, seq, s, f, n_app, g, dec, sm);
+  jg_dense_cold_lds<R, UNIFORM>(d, acks, seq, s, f, n_app, g, in.a, mword0, head0, dec, sm);
 }
 
 // Grid-stride loop over the groups (a software prefetch of the next group's loads measured no gain
@@ -654,7 +655,7 @@ template <int R>
 __global__ __launch_bounds__(JG_BLOCK) JG_DENSE_ATTR void k_leader_tick_dense(JgDenseHot h, const JgDev* __restrict__ dp,
                                                                                const uint64_t* __restrict__ acks,
                                                                                uint32_t seq, int us) {
-  __shared__ uint64_t sm[R][JG_BLOCK];  // progress heads of the (rare) groups on the general path
+  __shared__ uint64_t sm[2 * R][JG_BLOCK];  // progress heads + acks of the (rare) groups on the general path
   JgDecCount dec;
   JgLeaderNode nd{};
   if (us >= 0) dec = jg_dense_tick_body<R, true, false>(h, dp, acks, seq, (uint32_t)us, nd, sm);

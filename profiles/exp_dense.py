@@ -52,6 +52,7 @@ if DEAD > 0:  # kill a fraction of the groups first (two forged acks above the h
     dead = np.random.default_rng(5).random(G) < DEAD
     kill[1][dead] = 10**9
     kill[2][dead] = 10**9
+    kill[3 % R][dead] = 10**9
     e.step_dense_acks(kill)
     e.drain_faults()
     print("dead groups:", int((e.read("fault") != 0).sum()), flush=True)
