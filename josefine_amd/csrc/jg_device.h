@@ -108,9 +108,9 @@ __device__ __forceinline__ uint64_t jg_mix64(uint64_t z) {
 // MAX_INFLIGHT are in flight, progress.rs:117), and the leader's commit index trails it by the
 // round trip, so a leader's R progress heads and its commit index are stored as R + 1 lags
 // `head - value` of B = 64 / (R + 1) bits in ONE 64-bit word (R = 5: 10 bits, R = 3: 16):
-// field r < R is slot r's progress head, field R the commit index.  The all-ones field is an
-// escape: the absolute value then lives in match_wide[r][g] / commit[g] (a replica that is far
-// behind, a forged ack above the head).  In steady state the lags do not change from tick to
+// field r < R is slot r's progress head, field R the commit index.  The two largest field values
+// are escapes (below): the absolute value then lives in match_wide[r][g] / commit[g] (a replica
+// that is far behind, a forged ack above the head).  In steady state the lags do not change from tick to
 // tick, so the dense kernel reads 8 bytes of progress + commit state per group and writes none —
 // instead of reading and writing (R + 1) x 8.  Non-leaders keep the absolute commit column.
 __host__ __device__ __forceinline__ uint32_t jg_lag_bits(uint32_t R) { return 64u / (R + 1u); }

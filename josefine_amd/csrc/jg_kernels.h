@@ -18,10 +18,11 @@
 #include "jg_dense.h"  // k_leader_tick_dense / _n, jg_block_count, JG_BLOCK
 
 // ---- groups the dense leader kernel deferred ----------------------------------------------------
-// Healthy leaders whose chain is not in FAST form, and (node tick) leaders that received a
-// HeartbeatResponse without the commit: the same tick(s) through the general state machine.
-// Workgroup s owns shard s of the deferred lists (jg_defer_push) and resets its counter for the
-// next launch.  Message rows outside the dense mailbox vocabulary go to the exceptional queue.
+// Healthy leaders whose chain is not in FAST form, and (node tick, T-tick kernel) leaders whose
+// tick does not stay in lag space or that received a HeartbeatResponse without the commit: the
+// same tick(s) through the general state machine.  Workgroup s owns shard s of the deferral
+// bitmap (jg_defer_mark), turns it into its list and clears it for the next launch.  Message rows
+// outside the dense mailbox vocabulary go to the exceptional queue.
 __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
                                                           size_t tick_stride, uint32_t seq0, JgLeaderNode nd) {
   uint32_t dec = 0;
