@@ -646,13 +646,8 @@ __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, co
   return dec;
 }
 
-#ifdef JG_DENSE_WPE
-#define JG_DENSE_ATTR __attribute__((amdgpu_waves_per_eu(JG_DENSE_WPE, JG_DENSE_WPE)))
-#else
-#define JG_DENSE_ATTR
-#endif
 template <int R>
-__global__ __launch_bounds__(JG_BLOCK) JG_DENSE_ATTR void k_leader_tick_dense(JgDenseHot h, const JgDev* __restrict__ dp,
+__global__ __launch_bounds__(JG_BLOCK) void k_leader_tick_dense(JgDenseHot h, const JgDev* __restrict__ dp,
                                                                                const uint64_t* __restrict__ acks,
                                                                                uint32_t seq, int us) {
   __shared__ uint64_t sm[2 * R][JG_BLOCK];  // progress heads + acks of the (rare) groups on the general path
