@@ -224,63 +224,70 @@ int jo_step(jo_engine* e, uint64_t now_ms) {
   return JG_OK;
 }
 
-static void dense_range(jo_engine* e, const uint64_t* acks, uint32_t g0, uint32_t g1, uint64_t* ncmd) {
+// one worker's share of a dense tick: commands applied, decisions taken, new faults (group order)
+struct DenseShare {
+  uint64_t ncmd = 0, decisions = 0;
+  std::vector<jg_fault_row> faults;
+};
+static void dense_range(jo_engine* e, const uint64_t* acks, uint32_t g0, uint32_t g1, DenseShare* out) {
   const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
-  uint64_t n = 0;
+  uint64_t n = 0, dec = 0;
   for (uint32_t g = g0; g < g1; g++) {
     Raft& r = e->groups[g];
+    const int fault_before = r.fault;
     uint32_t s = e->self_slot[g];
     uint64_t n_append = acks[(size_t)s * G + g];
-    if (r.fault) continue;
-    if (r.role != JG_ROLE_LEADER) {
-      if (n_append) r.fault = JG_FAULT_ENGINE_DENSE_NONLEADER;
-      continue;
+    if (!r.fault) {
+      if (r.role != JG_ROLE_LEADER) {
+        if (n_append) r.fault = JG_FAULT_ENGINE_DENSE_NONLEADER;
+      } else {
+        Cmd c;
+        c.kind = JG_CMD_CLIENT_REQUEST;
+        for (uint64_t i = 0; i < n_append && !r.fault; i++) {
+          r.apply(c, 0);
+          n++;
+        }
+        c.kind = JG_CMD_APPEND_RESPONSE;
+        c.flag = 1;
+        for (uint32_t q = 0; q < R && !r.fault; q++) {
+          if (q == s) continue;
+          uint64_t h = acks[(size_t)q * G + g];
+          if (h == JG_NO_ACK) continue;
+          c.from = e->cfg.node_ids[q];
+          c.id = h;
+          r.apply(c, 0);
+          n++;
+        }
+        r.rpc.clear();
+        r.fsm.clear();  // dense path reports deltas, not rows
+      }
     }
-    Cmd c;
-    c.kind = JG_CMD_CLIENT_REQUEST;
-    for (uint64_t i = 0; i < n_append && !r.fault; i++) {
-      r.apply(c, 0);
-      n++;
-    }
-    c.kind = JG_CMD_APPEND_RESPONSE;
-    c.flag = 1;
-    for (uint32_t q = 0; q < R && !r.fault; q++) {
-      if (q == s) continue;
-      uint64_t h = acks[(size_t)q * G + g];
-      if (h == JG_NO_ACK) continue;
-      c.from = e->cfg.node_ids[q];
-      c.id = h;
-      r.apply(c, 0);
-      n++;
-    }
-    r.rpc.clear();
-    r.fsm.clear();  // dense path reports deltas, not rows
+    if (r.fault && r.fault != fault_before) out->faults.push_back(jg_fault_row{g, (uint32_t)r.fault});
+    dec += r.decisions;
+    r.decisions = 0;
   }
-  *ncmd = n;
+  out->ncmd = n;
+  out->decisions = dec;
 }
 
 int jo_step_dense_acks(jo_engine* e, const uint64_t* acks) {
   e->stepped = true;
   const uint32_t G = e->cfg.n_groups;
-  std::vector<int> fault_before(G);
-  for (uint32_t g = 0; g < G; g++) fault_before[g] = e->groups[g].fault;
   unsigned T = std::min<unsigned>(e->threads, G ? G : 1);
-  std::vector<uint64_t> ncmd(T, 0);
+  std::vector<DenseShare> share(T);
   if (T <= 1) {
-    dense_range(e, acks, 0, G, &ncmd[0]);
+    dense_range(e, acks, 0, G, &share[0]);
   } else {
     if (!e->pool || e->pool->size() != T) e->pool.reset(new Pool(T));
     e->pool->parallel([&](unsigned t) {
       uint32_t g0 = (uint32_t)((uint64_t)G * t / T), g1 = (uint32_t)((uint64_t)G * (t + 1) / T);
-      dense_range(e, acks, g0, g1, &ncmd[t]);
+      dense_range(e, acks, g0, g1, &share[t]);
     });
   }
-  for (unsigned t = 0; t < T; t++) e->counters[0] += ncmd[t];
-  for (uint32_t g = 0; g < G; g++) {
-    Raft& r = e->groups[g];
-    if (r.fault && r.fault != fault_before[g]) e->faults.push_back(jg_fault_row{g, (uint32_t)r.fault});
-    e->counters[1] += r.decisions;
-    r.decisions = 0;
+  for (unsigned t = 0; t < T; t++) {  // block partition: concatenation keeps the group order
+    e->counters[0] += share[t].ncmd;
+    e->counters[1] += share[t].decisions;
+    e->faults.insert(e->faults.end(), share[t].faults.begin(), share[t].faults.end());
   }
   e->counters[2] += G;
   return JG_OK;
