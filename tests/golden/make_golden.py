@@ -117,7 +117,47 @@ def node_fixture(G, R, rounds, ticks):
     return out
 
 
+def down_acks(R, G, t, head, per, T_quorum=120, T_back=200):
+    """The ack block of tick t of the degraded-cluster trace (shared by the generator and the test):
+    slot 1 is down from the start, more than a minority from T_quorum on, everybody returns at
+    T_back (slot 1 of the even groups far behind, catching up in steps)."""
+    acks = np.full((R, G), capi.NO_ACK, dtype=np.uint64)
+    acks[0] = per
+    up = [r for r in range(1, R)]
+    if t < T_back:
+        up = [r for r in up if r != 1]
+    if T_quorum <= t < T_back:
+        up = [r for r in up if r > R // 2 + 1]
+    for r in up:
+        acks[r] = head
+    if t >= T_back:
+        acks[1, ::2] = head[::2] // 2
+    return acks
+
+
+def down_fixture(G, R, ticks, every):
+    """One follower down, then quorum lost, then recovery: the packed progress word's BEHIND escape
+    and its way back, frozen from the oracle."""
+    e = oracle_engine(G, R, seed=SEED + 100 + R)
+    elect_all(e)
+    e.drain_messages(), e.drain_applies()
+    esc = (1 << (64 // (R + 1))) - 1
+    per = max(1, esc // 50)
+    out = {"G": G, "R": R, "ticks": ticks, "every": every, "seed": SEED + 100 + R, "per": per}
+    for t in range(ticks):
+        e.step_dense_acks(down_acks(R, G, t, e.read("head").astype(np.uint64), per))
+        if (t + 1) % every == 0:
+            out[f"commit_{t+1}"] = e.read("commit")
+            out[f"head_{t+1}"] = e.read("head")
+            out[f"repl_{t+1}"] = e.read("repl_state")
+            out[f"match_{t+1}"] = np.stack([e.read("match", r) for r in range(R)])
+    out["decisions"] = e.counters()["decisions"]
+    out["fault"] = e.read("fault")
+    return out
+
+
 def main():
+    np.savez_compressed(os.path.join(HERE, "down_r5.npz"), **down_fixture(192, 5, 210, 30))
     np.savez_compressed(os.path.join(HERE, "node_r3.npz"), **node_fixture(96, 3, 25, 25))
     np.savez_compressed(os.path.join(HERE, "dense_r3_ragged.npz"), **dense_fixture(512, 3, 1, 60, 20))
     np.savez_compressed(os.path.join(HERE, "dense_r5_steady.npz"), **dense_fixture(256, 5, 0, 30, 10))

@@ -40,6 +40,36 @@ def test_dense_golden(backend, name):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_degraded_cluster_golden(backend):
+    """One follower down -> quorum lost -> everybody back (golden/down_r5.npz): progress heads and
+    the commit index leave their lag fields (BEHIND escape) and return."""
+    import sys
+    sys.path.insert(0, HERE)
+    from make_golden import down_acks
+
+    z = np.load(os.path.join(HERE, "down_r5.npz"))
+    G, R, ticks, every, per = (int(z[k]) for k in ("G", "R", "ticks", "every", "per"))
+    e = make(backend, G, R, seed=int(z["seed"]))
+    elect_all(e)
+    e.drain_messages(), e.drain_applies()
+    for t in range(ticks):
+        e.step_dense_acks(down_acks(R, G, t, e.read("head").astype(np.uint64), per))
+        if (t + 1) % every == 0:
+            assert np.array_equal(e.read("commit"), z[f"commit_{t+1}"]), t
+            assert np.array_equal(e.read("head"), z[f"head_{t+1}"]), t
+            assert np.array_equal(e.read("repl_state"), z[f"repl_{t+1}"]), t
+            for r in range(R):
+                assert np.array_equal(e.read("match", r), z[f"match_{t+1}"][r]), (t, r)
+    assert e.counters()["decisions"] == int(z["decisions"])
+    assert np.array_equal(e.read("fault"), z["fault"]) and not z["fault"].any()
+    esc = (1 << (64 // (R + 1))) - 1
+    lag1 = z["head_180"].astype(np.int64) - z["match_180"][1].astype(np.int64)
+    clag = z["head_180"].astype(np.int64) - z["commit_180"].astype(np.int64)
+    assert (lag1 > esc).all() and (clag > esc).all()        # both left their fields on the way ...
+    assert (z["head_210"] - z["commit_210"] < 4 * per).all()  # ... and the commit index came back
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_fuzz_golden(backend):
     z = np.load(os.path.join(HERE, "fuzz_r3.npz"))
     G, R, steps = int(z["G"]), int(z["R"]), int(z["steps"])
