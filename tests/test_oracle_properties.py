@@ -72,7 +72,7 @@ def test_oracle_dense_facade_equals_rows(R, mode):
 
 
 def test_oracle_threaded_leg_equals_single_thread():
-    """jo_set_threads (the all-cores leg of bench.py's cpu_baseline: a worker pool over block
+    """jo_set_threads (the all-cores leg of bench.py's cpu_baseline: threads over block
     partitions of the groups) changes nothing but the wall clock."""
     G, R = 5000, 5
     a, b = oracle_engine(G, R, seed=9), oracle_engine(G, R, seed=9)
