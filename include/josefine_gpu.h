@@ -35,11 +35,13 @@
 extern "C" {
 #endif
 
-#define JG_ABI_VERSION 1u
+#define JG_ABI_VERSION 2u
 #define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
 #define JG_CHAIN_WINDOW 8u  /* chain segments (gaps / forks) per group besides the main run */
 #define JG_MAX_INFLIGHT 5u  /* src/raft/progress.rs:117                                    */
 #define JG_NO_ACK UINT64_MAX /* dense ack column: "no AppendResponse from this replica"    */
+#define JG_MAX_DEVICES 16u  /* shards (devices) behind one engine handle                      */
+#define JG_MAX_DENSE_APPENDS (1u << 20) /* own slot of a dense ack block: appends per group per tick */
 
 /* ---- status codes -------------------------------------------------------- */
 enum {
@@ -124,7 +126,8 @@ enum {
   JG_FAULT_RANGE_HIT_COMMIT_KEY = 8,      /* chain.rs:198 + 219-226 via leader.rs:135,152-157 (Q9) */
   JG_FAULT_ENGINE_WINDOW_OVERFLOW = 128,  /* chain needs > JG_CHAIN_WINDOW segments (gaps / forks) */
   JG_FAULT_ENGINE_FOREIGN_VOTER = 129,    /* VoteResponse.from not in the configured membership    */
-  JG_FAULT_ENGINE_DENSE_NONLEADER = 131   /* dense tick asked a non-leader group to append         */
+  JG_FAULT_ENGINE_DENSE_NONLEADER = 131,  /* dense tick asked a non-leader group to append         */
+  JG_FAULT_ENGINE_DENSE_APPENDS = 132     /* own slot of a dense ack block >= JG_MAX_DENSE_APPENDS */
 };
 
 /* ---- engine configuration ---------------------------------------------------
@@ -145,6 +148,14 @@ typedef struct jg_config {
   uint64_t group_base;               /* global id of local group 0 (sharding; keys the RNG)   */
   uint32_t flags;                    /* JG_CFG_*                                              */
   uint32_t reserved;
+  /* Multi-device engine (SURVEY.md §8(b),(e)): n_devices >= 1 shards the G groups over
+   * device_ids[0..n_devices) by contiguous ownership — shard d owns local groups
+   * [d*S, min((d+1)*S, G)) with S = ceil(G / n_devices) (trailing shards that would be empty are
+   * not created) — behind this ONE handle: the reference has one caller that owns the handle
+   * (event_loop, src/raft/server.rs:103-165).  A device may be listed more than once (several
+   * shards on one GPU).  n_devices == 0: one shard on `device_id`. */
+  uint32_t n_devices;
+  int32_t device_ids[JG_MAX_DEVICES];
 } jg_config;
 
 enum {
@@ -239,6 +250,30 @@ typedef struct jg_engine jg_engine;
 int jg_engine_create(const jg_config* cfg, jg_engine** out);
 void jg_engine_destroy(jg_engine* e);
 
+/* ---- shards of a multi-device engine ------------------------------------------------------------
+ * Everything that takes HOST memory works on the parent handle exactly as on a single-device
+ * engine: jg_submit buckets the rows by owner (stable: a group's rows keep their order), jg_step
+ * steps every shard (one host thread and one HIP stream per shard), the drains merge the shards'
+ * rows back into the single-engine order (per step: groups ascending; steps in order),
+ * jg_read_state / jg_get_counters / jg_drain_faults / jg_sync / jg_set_self_slots /
+ * jg_step_dense_acks (host [R][G] block) split or concatenate per shard.  Results are
+ * bit-identical to one engine over the same G groups (tests/test_multi_device.py).
+ * Everything that takes DEVICE pointers is per device by nature: the caller addresses a shard's
+ * own engine handle (jg_get_shard; an ordinary single-device engine over groups
+ * [group_lo, group_lo + n_groups), local group index = global - group_lo) for
+ * jg_step_dense_leader / _follower, jg_step_device_rows, jg_device_*, jg_synth_fill_acks_device,
+ * jg_calibrate_stream; jg_step_dense_acks_shards launches the ack tick on every shard at once.
+ * Shard handles are owned by the parent: never destroy them, and do not drain them directly. */
+typedef struct jg_shard_info {
+  jg_engine* engine;  /* the shard's own single-device engine                                  */
+  int32_t device_id;
+  uint32_t group_lo;  /* first group (index within the parent) this shard owns                 */
+  uint32_t n_groups;
+  uint32_t reserved;
+} jg_shard_info;
+uint32_t jg_shard_count(const jg_engine* e); /* 1 for a single-device engine (which is its own shard) */
+int jg_get_shard(jg_engine* e, uint32_t shard, jg_shard_info* out);
+
 /* Per-group own replica slot (default: all 0).  Only legal before the first step. */
 int jg_set_self_slots(jg_engine* e, const uint8_t* slots /* [G] host */);
 
@@ -265,7 +300,9 @@ int jg_step_device_rows(jg_engine* e, const jg_cmd_batch* dev_batch, uint64_t no
 /* Dense steady-state leader tick (the HBM-roofline path).
  * `acks` is an [R][G] column-major array (replica-major: acks[r*G+g]):
  *   r != self_slot[g]: head of an AppendResponse{node_id: node_ids[r], head} or JG_NO_ACK;
- *   r == self_slot[g]: number of ClientRequests to append this tick.
+ *   r == self_slot[g]: number of ClientRequests to append this tick, < JG_MAX_DENSE_APPENDS
+                        (a larger value, JG_NO_ACK included, raises JG_FAULT_ENGINE_DENSE_APPENDS
+                        on that group and applies nothing of its tick).
  * Per group, in this order: the appends (leader.rs:177-197, each with its
  * self-ack), then the acks in ascending slot order (leader.rs:211-219 ->
  * progress.rs:42-60 -> leader.rs:87-99).  Equivalent to submitting those
@@ -282,6 +319,10 @@ int jg_step_dense_acks_device(jg_engine* e, const uint64_t* acks_dev);
  * acks_dev + t*R*G.  Identical in effect to n_ticks calls of jg_step_dense_acks_device;
  * the groups' state is read and written once per launch instead of once per tick. */
 int jg_step_dense_acks_device_n(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks);
+/* The same for every shard of a multi-device engine: acks_dev[d] is shard d's own [n_ticks][R][G_d]
+ * block in the memory of its device (G_d = its n_groups).  One launch per shard, issued by the
+ * shard's host thread on the shard's stream; returns when all are enqueued. */
+int jg_step_dense_acks_shards(jg_engine* e, const uint64_t* const* acks_dev, uint32_t n_ticks);
 
 /* ---- dense node tick: the steady-state traffic of a cluster in column form ----------------
  * What a leader sends its followers on a Tick (leader.rs:234-245: heartbeat() if due, then

@@ -9,10 +9,12 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_REPLICAS = 8
 CHAIN_WINDOW = 8
 MAX_INFLIGHT = 5
+MAX_DEVICES = 16
+MAX_DENSE_APPENDS = 1 << 20
 NO_ACK = 0xFFFFFFFFFFFFFFFF
 
 OK, EINVAL, ENOMEM, EDEVICE, ECAPACITY = 0, -1, -2, -3, -4
@@ -38,6 +40,7 @@ FAULT_RANGE_HIT_COMMIT_KEY = 8
 FAULT_ENGINE_WINDOW_OVERFLOW = 128
 FAULT_ENGINE_FOREIGN_VOTER = 129
 FAULT_ENGINE_DENSE_NONLEADER = 131
+FAULT_ENGINE_DENSE_APPENDS = 132
 
 CFG_SEPARATE_COMMIT_KEY = 1
 
@@ -82,7 +85,14 @@ class Config(C.Structure):
         ("group_base", C.c_uint64),
         ("flags", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("n_devices", C.c_uint32),
+        ("device_ids", C.c_int32 * MAX_DEVICES),
     ]
+
+
+class ShardInfo(C.Structure):
+    _fields_ = [("engine", C.c_void_p), ("device_id", C.c_int32), ("group_lo", C.c_uint32),
+                ("n_groups", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class CmdBatch(C.Structure):
@@ -155,6 +165,9 @@ class Api:
     }
     # only the device engine has these
     _DEVICE_PROTOS = {
+        "shard_count": (C.c_uint32, [_P]),
+        "get_shard": (C.c_int, [_P, C.c_uint32, C.POINTER(ShardInfo)]),
+        "step_dense_acks_shards": (C.c_int, [_P, C.POINTER(_P), C.c_uint32]),
         "step_device_rows": (C.c_int, [_P, C.POINTER(CmdBatch), C.c_uint64]),
         "step_dense_acks_device": (C.c_int, [_P, _P]),
         "step_dense_acks_device_n": (C.c_int, [_P, _P, C.c_uint32]),
@@ -204,7 +217,7 @@ class Api:
 
 # Every symbol include/josefine_gpu.h declares (checked by the CPU test-suite).
 HEADER_SYMBOLS = [
-    "jg_engine_create", "jg_engine_destroy", "jg_set_self_slots", "jg_submit", "jg_step", "jg_step_device_rows",
+    "jg_engine_create", "jg_engine_destroy", "jg_shard_count", "jg_get_shard", "jg_step_dense_acks_shards", "jg_set_self_slots", "jg_submit", "jg_step", "jg_step_device_rows",
     "jg_step_dense_acks", "jg_step_dense_acks_device", "jg_step_dense_acks_device_n",
     "jg_step_dense_leader", "jg_step_dense_follower", "jg_chain_compact", "jg_sync", "jg_stream_wait",
     "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_read_state", "jg_get_counters",

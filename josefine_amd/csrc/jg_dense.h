@@ -136,13 +136,14 @@ __device__ __forceinline__ void jg_dense_load(const JgDenseHot& d, const uint64_
 // The common case never leaves the packed representation.  With every field of the progress
 // word un-escaped, every ack at or below the chain head and within 2^32 of it, and fewer than
 // 2^20 appends, the whole tick is 32-bit arithmetic on lags below the head:
-//   match[r] = max(match[r], ack[r])          <=>  lag[r] = min(lag[r], head0 - ack[r])
-//   increment() returned true (-> Replicate)  <=>  head0 - ack[r] < lag[r]         progress.rs:133-140
 //   n appends + self-acks                     <=>  every lag += n, own lag = 0     leader.rs:177-197
+//   match[r] = max(match[r], ack[r])          <=>  lag[r] = min(lag[r], head1 - ack[r])   (head1 = head0 + n)
+//   increment() returned true (-> Replicate)  <=>  head1 - ack[r] < lag[r]         progress.rs:133-140
 //   element R/2 of the heads sorted desc.     <=>  element R/2 of the lags sorted ascending
 //   commit = max(commit, q)                   <=>  clag = min(clag + n, qlag)      leader.rs:89-92
-// Old heads and acks <= head0 is exactly the precondition of the fused evaluation above (no
-// chain.commit panic possible), so it is exact; anything else (escaped field,
+// Old heads <= head0 and acks <= head0 + n (the appends are applied first, so that is the head an
+// ack meets) is exactly the precondition of the fused evaluation above (no chain.commit panic
+// possible), so it is exact; anything else (escaped field,
 // forged ack above the head, a lag that no longer fits its field) returns false with nothing
 // modified and the caller takes the general path.
 template <int R>
@@ -185,30 +186,32 @@ __device__ __forceinline__ bool jg_lag_tick(uint32_t s, uint32_t f, uint64_t w0,
   constexpr uint32_t ESC = (uint32_t)((1ull << (B > 21 ? 21 : B)) - 1ull);
   constexpr uint32_t BEHIND = ESC - 1u, INF = 0xffffffffu;  // jg_lag_behind(); how a BEHIND slot sorts
   const uint32_t n = (uint32_t)n_app;
-  bool bad = (n_app >> 20) != 0;
+  bool bad = n_app >= JG_MAX_DENSE_APPENDS;
+  const uint64_t head1 = head0 + n;  // the appends come first (leader.rs:177-197): acks meet the new head
   uint32_t incm = 0, somem = 0;  // per slot: increment() returned true / an ack arrived
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const uint32_t fr = (uint32_t)(w0 >> (r * B)) & ESC;
     const uint64_t ar = a[r];
-    const uint64_t dk = head0 - ar;
+    const uint64_t dk = head1 - ar;
     const bool self = (uint32_t)r == s;  // engine-uniform in the normal case: scalar
     const bool some = !self && ar != JG_NO_ACK;
     // A replica that is too far behind for its field (a follower that is down) stays where it
     // is until an ack arrives for it: its lag is larger than every in-range lag, which is all the
     // majority needs to know.  An ack for it, or the own slot in that state: exact compare, general path.
     const bool behind = fr == BEHIND;
-    // lag of the ack below the old head; acks further than 2^32 behind are just "stale"
+    // lag of the ack below the NEW head; acks further than 2^32 behind are just "stale"
     uint32_t dl = (uint32_t)(dk >> 32) ? 0xffffffffu : (uint32_t)dk;
     dl = some ? dl : 0xffffffffu;
-    const bool inc = dl < fr;  // progress.rs:133-140: increment() returned true
+    const uint32_t frn = fr + n;  // the old progress head seen from the new chain head
+    const bool inc = dl < frn;    // progress.rs:133-140: increment() returned true
     incm |= inc ? (1u << r) : 0u;
     somem |= some ? (1u << r) : 0u;
     // own slot: n self-acks leave its head at the new chain head
-    uint32_t lo = (self && n) ? 0u : min(fr, dl) + n;
+    uint32_t lo = (self && n) ? 0u : min(frn, dl);
     bad |= fr == ESC;                      // a head above the chain head (forged ack)
     bad |= behind ? some : lo >= BEHIND;   // an ack for a BEHIND slot / a lag leaving its field (wide column)
-    bad |= some && ar > head0;             // an ack above the head: replay, the reference may panic
+    bad |= some && ar > head1;             // an ack above the head it meets: replay, the reference may panic
     lo = (behind && !(self && n)) ? INF : lo;  // (an own BEHIND slot: its self-ack lands on the head all the same)
     o.l[r] = lo;
   }
@@ -229,7 +232,7 @@ __device__ __forceinline__ bool jg_lag_tick(uint32_t s, uint32_t f, uint64_t w0,
 #pragma unroll
   for (int r = 0; r <= R; r++) w |= (uint64_t)min(o.l[r], BEHIND) << (r * B);
   o.w1 = w;
-  o.head1 = head0 + n;
+  o.head1 = head1;
   o.nf = nf;
   dec += n + (uint32_t)__popc(somem);
   return true;
@@ -244,25 +247,27 @@ __device__ __forceinline__ bool jg_lag_tick_regs(uint32_t s, uint32_t& nf_io, ui
   const uint64_t head0 = head_io;
   constexpr uint32_t INF = 0xffffffffu;  // a BEHIND slot (see jg_lag_tick)
   const uint32_t n = (uint32_t)n_app;
-  bool bad = (n_app >> 20) != 0;
+  bool bad = n_app >= JG_MAX_DENSE_APPENDS;
+  const uint64_t head1 = head0 + n;
   uint32_t incm = 0, somem = 0;
   uint32_t nl[R + 1];
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const uint32_t fr = l[r];
     const uint64_t ar = a[r];
-    const uint64_t dk = head0 - ar;
+    const uint64_t dk = head1 - ar;
     const bool self = (uint32_t)r == s;
     const bool some = !self && ar != JG_NO_ACK;
     const bool behind = fr == INF;
     uint32_t dl = (uint32_t)(dk >> 32) ? 0xffffffffu : (uint32_t)dk;
     dl = some ? dl : 0xffffffffu;
-    const bool inc = dl < fr;  // progress.rs:133-140
+    const uint32_t frn = behind ? INF : fr + n;
+    const bool inc = dl < frn;  // progress.rs:133-140
     incm |= inc ? (1u << r) : 0u;
     somem |= some ? (1u << r) : 0u;
-    uint32_t lo = (self && n) ? 0u : min(fr, dl) + n;
+    uint32_t lo = (self && n) ? 0u : min(frn, dl);
     bad |= behind ? some : lo >= (1u << 30);
-    bad |= some && ar > head0;  // an ack above the head: replay, the reference may panic
+    bad |= some && ar > head1;  // an ack above the head it meets: replay, the reference may panic
     nl[r] = (behind && !(self && n)) ? INF : lo;
   }
   const uint32_t lc = l[R] == INF ? INF : l[R] + n;
@@ -276,7 +281,7 @@ __device__ __forceinline__ bool jg_lag_tick_regs(uint32_t s, uint32_t& nf_io, ui
   nf_io = nf;
 #pragma unroll
   for (int r = 0; r <= R; r++) l[r] = nl[r];
-  head_io = head0 + n;
+  head_io = head1;
   dec += n + (uint32_t)__popc(somem);
   return true;
 }
@@ -348,6 +353,11 @@ __device__ __forceinline__ int jg_dense_classify(const JgDev& d, uint32_t g, uin
       d.flags[g] = f | (JG_FAULT_ENGINE_DENSE_NONLEADER << JGF_FAULT_SHIFT);
       jg_push_fault(d, g, JG_FAULT_ENGINE_DENSE_NONLEADER, seq);
     }
+    return JG_DENSE_SKIP;
+  }
+  if (n_app >= JG_MAX_DENSE_APPENDS) {  // own slot outside its domain (JG_NO_ACK included): nothing is applied
+    d.flags[g] = f | (JG_FAULT_ENGINE_DENSE_APPENDS << JGF_FAULT_SHIFT);
+    jg_push_fault(d, g, JG_FAULT_ENGINE_DENSE_APPENDS, seq);
     return JG_DENSE_SKIP;
   }
   // irregular chain: k_dense_slow, launched right behind this kernel, replays the tick
@@ -490,21 +500,23 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
 #pragma unroll                        // path loaded it into (no second trip to HBM per rolled iteration)
   for (int r = 0; r < R; r++) sa[r][t] = ((uint32_t)r == s || !acks) ? JG_NO_ACK : a_in[r];
   // packed lags -> absolute progress heads (escaped fields: the wide column)
-  uint64_t hi = 0;
+  uint64_t hi_old = 0, hi_ack = 0;
 #pragma clang loop unroll(disable)
   for (int r = 0; r < R; r++) {
     const uint64_t fl = (w0 >> (r * B)) & esc;
     const uint64_t v = jg_lag_wide(fl, R) ? d.match_wide[(size_t)r * G + g] : head0 - fl;
     sm[r][t] = v;
-    hi = v > hi ? v : hi;
+    hi_old = v > hi_old ? v : hi_old;
     const uint64_t a = sa[r][t];
-    hi = (a != JG_NO_ACK && a > hi) ? a : hi;
+    hi_ack = (a != JG_NO_ACK && a > hi_ack) ? a : hi_ack;
   }
   const uint64_t fc = (w0 >> (R * B)) & esc;
   const uint64_t commit0 = jg_lag_wide(fc, R) ? d.commit[g] : head0 - fc;
   uint64_t commit = commit0, head = head0;
   uint32_t nf = f, fault = 0, dc = 0;
-  const bool fused = hi <= head0;  // no chain.commit panic possible: one majority evaluation
+  // no chain.commit panic possible: one majority evaluation.  (Old heads at or below the head, acks
+  // at or below the head they meet - the appends are applied first.)
+  const bool fused = hi_old <= head0 && hi_ack <= head0 + n_app;
   // appends with their self-acks (leader.rs:177-197); replayed one at a time unless fused
   if (fused) {
     head = head0 + n_app;
@@ -576,7 +588,8 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
 template <int R, bool UNIFORM, bool NODE>
 __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev* dp,
                                                const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us, const JgLeaderNode& nd, bool emit, uint32_t g,
-                                               const JgDenseIn<R>& in, JgDecCount& dec, uint64_t (*sm)[JG_BLOCK]) {
+                                               const JgDenseIn<R>& in, JgDecCount& dec, uint64_t (*sm)[JG_BLOCK],
+                                               bool defer_cold) {
   const uint32_t f = in.f;
   const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
   const uint64_t mword0 = in.w, head0 = in.head, term = in.term, hbt = in.hbt;
@@ -597,14 +610,25 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   bool hot = (f & (JGF_FAULT_MASK | JGF_ROLE_MASK | JGF_FAST)) == (JG_ROLE_LEADER | JGF_FAST);
   if (NODE) hot = hot && !hbr_trigger;
   hot = jg_lag_tick<R>(s, f, mword0, head0, n_app, in.a, lt, dl) && hot;
+#ifndef JG_EXP_NOCOUNT
   jg_count_step(h.blk_decisions, dec, hot, dl);
+#endif
+#ifdef JG_EXP_FULLWAVE
+  // the head column is stored by every lane of a wave that has a hot lane with a new head: the
+  // lanes that are not hot write back the value they read (dead groups, non-leaders, deferred
+  // groups; a lane that goes on to the general path stores again behind this, in program order)
+  const bool wave_head = __ballot(hot && lt.head1 != head0) != 0;
+  if (wave_head) h.head[g] = hot ? lt.head1 : head0;
+#endif
   if (__builtin_expect(hot, 1)) {
     if (emit)  // Command::Tick into the outbox; may raise the Q9 fault
       lt.nf = jg_dense_leader_tick<R>(h, dp, nd, g, seq, s, term, hbt, lt.head1, lt.head1 - lt.l[R], lt.nf, [&](int r) {
         return lt.l[r] == 0xffffffffu ? dp->match_wide[(size_t)r * h.G + g] : lt.head1 - lt.l[r];  // BEHIND: wide column
       });
     if (lt.w1 != mword0) h.mlag[g] = lt.w1;
+#if !defined(JG_EXP_FULLWAVE) && !defined(JG_EXP_NOSTORE)
     if (lt.head1 != head0) h.head[g] = lt.head1;
+#endif
     if (lt.nf != f) h.flags[g] = lt.nf;
     return;
   }
@@ -616,7 +640,10 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   // escaped lag field, an ack above the head) goes to k_dense_slow, which is always launched
   // behind a node tick and runs HeartbeatResponses, appends, acks and the Tick of these groups
   // through the general state machine (columns for a FAST chain, rows otherwise)
-  if (NODE && cls == JG_DENSE_RUN) cls = JG_DENSE_DEFER;
+  // the ack-only kernel does the same whenever the host has k_dense_slow scheduled behind it anyway
+  // (`defer_cold`): ONE lane of a wave on the rolled LDS path below keeps the whole wave for several
+  // microseconds (1 % of the groups there tripled the launch: profiles/README.md round 2)
+  if ((NODE || defer_cold) && cls == JG_DENSE_RUN) cls = JG_DENSE_DEFER;
   jg_defer_mark(d, g, cls == JG_DENSE_DEFER);
   if (NODE) {
     if (emit) jg_dense_outbox_none<R>(h.G, nd, g);
@@ -625,6 +652,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   if (cls != JG_DENSE_RUN) return;
   // the ack-only kernel: rolled loops over LDS, so that the kernel's register allocation
   // (= its occupancy) is the hot path's
+  *d.cold_seen = 1;  // read back at the next synchronisation point: the host then schedules k_dense_slow
   jg_dense_cold_lds<R, UNIFORM>(d, acks, seq, s, f, n_app, g, in.a, mword0, head0, dec, sm);
 }
 
@@ -633,7 +661,8 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
 template <int R, bool UNIFORM, bool NODE>
 __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, const JgDev* dp,
                                                        const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us,
-                                                       const JgLeaderNode& nd, uint64_t (*sm)[JG_BLOCK]) {
+                                                       const JgLeaderNode& nd, uint64_t (*sm)[JG_BLOCK],
+                                                       bool defer_cold) {
   const uint32_t G = h.G, stride = gridDim.x * JG_BLOCK;
   const bool emit = NODE && nd.o_term != nullptr;
   JgDecCount dec;
@@ -641,7 +670,7 @@ __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, co
   for (; g < G; g += stride) {
     JgDenseIn<R> in;
     jg_dense_issue<R, UNIFORM, NODE>(h, dp, acks, us, nd, emit, g, in);
-    jg_dense_group<R, UNIFORM, NODE>(h, dp, acks, seq, us, nd, emit, g, in, dec, sm);
+    jg_dense_group<R, UNIFORM, NODE>(h, dp, acks, seq, us, nd, emit, g, in, dec, sm, defer_cold);
   }
   return dec;
 }
@@ -649,12 +678,12 @@ __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, co
 template <int R>
 __global__ __launch_bounds__(JG_BLOCK) void k_leader_tick_dense(JgDenseHot h, const JgDev* __restrict__ dp,
                                                                                const uint64_t* __restrict__ acks,
-                                                                               uint32_t seq, int us) {
+                                                                               uint32_t seq, int us, int defer_cold) {
   __shared__ uint64_t sm[2 * R][JG_BLOCK];  // progress heads + acks of the (rare) groups on the general path
   JgDecCount dec;
   JgLeaderNode nd{};
-  if (us >= 0) dec = jg_dense_tick_body<R, true, false>(h, dp, acks, seq, (uint32_t)us, nd, sm);
-  else dec = jg_dense_tick_body<R, false, false>(h, dp, acks, seq, 0, nd, sm);
+  if (us >= 0) dec = jg_dense_tick_body<R, true, false>(h, dp, acks, seq, (uint32_t)us, nd, sm, defer_cold != 0);
+  else dec = jg_dense_tick_body<R, false, false>(h, dp, acks, seq, 0, nd, sm, defer_cold != 0);
   jg_wave_count(h.blk_decisions, dec);
 }
 
@@ -664,8 +693,8 @@ __global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDenseHot h, con
                                                                 const uint64_t* __restrict__ acks, uint32_t seq, int us,
                                                                 JgLeaderNode nd) {
   JgDecCount dec;
-  if (us >= 0) dec = jg_dense_tick_body<R, true, true>(h, dp, acks, seq, (uint32_t)us, nd, nullptr);
-  else dec = jg_dense_tick_body<R, false, true>(h, dp, acks, seq, 0, nd, nullptr);
+  if (us >= 0) dec = jg_dense_tick_body<R, true, true>(h, dp, acks, seq, (uint32_t)us, nd, nullptr, true);
+  else dec = jg_dense_tick_body<R, false, true>(h, dp, acks, seq, 0, nd, nullptr, true);
   jg_wave_count(h.blk_decisions, dec);
 }
 

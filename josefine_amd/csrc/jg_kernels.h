@@ -66,7 +66,14 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
     c.from = 0;
     c.flag = 0;
     c.term = c.id = c.aux = 0;
-    if (nd.hbr_has) {  // 1. HeartbeatResponses, ascending slot (leader.rs:222-231)
+    // own slot outside its domain (JG_MAX_DENSE_APPENDS; a leader only: non-leaders never get here):
+    // nothing of the tick is applied.  Checked again per tick below (T-tick launches).
+    if (acks && n_ticks && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L) &&
+        acks[(size_t)s * d.G + g] >= JG_MAX_DENSE_APPENDS) {
+      L.seq = seq0;
+      jg_raise(d, L, JG_FAULT_ENGINE_DENSE_APPENDS);
+    }
+    if (nd.hbr_has && !jg_fault(L)) {  // 1. HeartbeatResponses, ascending slot (leader.rs:222-231)
       L.seq = seq0;
       c.kind = JG_CMD_HEARTBEAT_RESPONSE;
       for (uint32_t r = 0; r < d.R && !jg_fault(L); r++) {
@@ -85,6 +92,10 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
       const uint64_t* A = acks + (size_t)t * tick_stride;
       L.seq = seq0 + t;
       uint64_t n_app = A[(size_t)s * d.G + L.g];
+      if (n_app >= JG_MAX_DENSE_APPENDS) {
+        jg_raise(d, L, JG_FAULT_ENGINE_DENSE_APPENDS);
+        break;
+      }
       c.kind = JG_CMD_CLIENT_REQUEST;
       c.flag = 0;
       for (uint64_t k = 0; k < n_app && !jg_fault(L); k++) {

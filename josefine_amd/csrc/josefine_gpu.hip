@@ -87,6 +87,10 @@ template <typename Row>
 struct PinnedQueue {
   Row* p = nullptr;
   size_t cap = 0, n = 0;
+  // rows [0, viewed) were handed out by a *_view call: they stay where the caller was pointed
+  // until the next drain of THIS queue (any other call may only append behind them)
+  size_t viewed = 0;
+  std::vector<Row*> retired;  // buffers a view may still point into
   hipError_t reserve(size_t want) {
     if (want <= cap) return hipSuccess;
     size_t ncap = std::max<size_t>(want, std::max<size_t>(cap * 2, 4096));
@@ -94,16 +98,35 @@ struct PinnedQueue {
     hipError_t e = hipHostMalloc((void**)&q, ncap * sizeof(Row), hipHostMallocDefault);
     if (e != hipSuccess) return e;
     if (n) std::memcpy(q, p, n * sizeof(Row));
-    if (p) (void)hipHostFree(p);
+    if (p) {
+      if (viewed) retired.push_back(p);
+      else (void)hipHostFree(p);
+    }
     p = q;
     cap = ncap;
     return hipSuccess;
   }
+  void release_view() {
+    if (!viewed) return;
+    if (n > viewed) std::memmove(p, p + viewed, (n - viewed) * sizeof(Row));
+    n -= viewed;
+    viewed = 0;
+    for (Row* r : retired) (void)hipHostFree(r);
+    retired.clear();
+  }
   void destroy() {
+    for (Row* r : retired) (void)hipHostFree(r);
+    retired.clear();
     if (p) (void)hipHostFree(p);
     p = nullptr;
-    cap = n = 0;
+    cap = n = viewed = 0;
   }
+};
+
+// A run of queued output rows that came out of one step (multi-device merge: jg_multi.h).
+struct JgSeg {
+  uint32_t seq;
+  size_t n;
 };
 
 }  // namespace
@@ -144,8 +167,14 @@ struct jg_engine {
   JgScanJob* h_jobs = nullptr;  // pinned: drain-time scan jobs and their totals
   uint64_t* h_totals = nullptr;
   size_t scan_cap = 0;
-  bool view_m = false, view_f = false;  // rows handed out by a *_view call: released on the next collect
   uint32_t seq = 0;
+  // multi-device (jg_multi.h): a parent owns a router and no device state; its shards record which
+  // step every queued output row belongs to
+  struct JgRouter* router = nullptr;
+  jg_engine* parent = nullptr;
+  bool track_segs = false;
+  std::vector<JgSeg> seg_m, seg_f;
+  std::vector<uint32_t> q_fault_seq;
   bool stepped = false;
   // Some group's chain may have left FAST form (then k_dense_slow runs behind the
   // dense kernel).  Set by every sparse step, cleared at the next synchronisation
@@ -194,9 +223,10 @@ void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks, const Jg
   else if (n_ticks > 1)  // temporal fusion: state read once, written once per launch
     hipLaunchKernelGGL(k_leader_tick_dense_n<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
                        n_ticks, stride, e->seq, e->uniform_self);
-  else
+  else  // (with k_dense_slow scheduled behind it, the kernel hands its general path to that one too)
     hipLaunchKernelGGL(k_leader_tick_dense<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
-                       jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks, e->seq, e->uniform_self);
+                       jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks, e->seq, e->uniform_self,
+                       e->maybe_irregular ? 1 : 0);
 }
 
 int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1, const JgLeaderNode* nd = nullptr) {
@@ -268,6 +298,9 @@ int sync_and_check(jg_engine* e) {
     e->maybe_irregular = irregular != 0;  // sticky on the device: once seen, the slow kernel stays scheduled
     e->flag_check_pending = false;
   }
+  // the ack-only kernel ran its in-kernel general path (escaped lag fields, acks above the head):
+  // from here on k_dense_slow is scheduled behind it and takes those groups with dense lanes
+  if (e->h_status[5]) e->maybe_irregular = true;
   // Assertion: irregular chains only come out of sparse steps, and every dense launch after
   // a sparse step has k_dense_slow behind it until the device flag is read back as 0 — so
   // while no slow kernel was ever scheduled the dense kernel cannot have deferred a group.
@@ -309,7 +342,9 @@ void sort_faults(std::vector<JgFaultRec>& v, std::vector<JgFaultRec>& tmp) {
 // Pull finished steps' output rows and the fault queue to the host queues.  Compaction
 // (exclusive scan of the per-run row counts + gather) runs on the device; the host only
 // learns the totals and receives the compacted rows.
-int collect(jg_engine* e) {
+// `release_mask`: bit 0 / bit 1 = the caller is a drain of the message / fsm queue, which ends the
+// life of that queue's outstanding view.
+int collect(jg_engine* e, int release_mask) {
   static const bool trace = std::getenv("JG_TRACE_DRAIN") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
@@ -317,8 +352,13 @@ int collect(jg_engine* e) {
   int rc = sync_and_check(e);
   if (rc) return rc;
   t1 = now();
-  if (e->view_m) e->q_msgs.n = 0, e->view_m = false;  // the caller is done with the last view
-  if (e->view_f) e->q_fsm.n = 0, e->view_f = false;
+  if (release_mask & 1) e->q_msgs.release_view();  // the caller is done with that queue's last view
+  if (release_mask & 2) e->q_fsm.release_view();
+  auto seg_add = [](std::vector<JgSeg>& v, uint32_t seq, size_t n) {
+    if (!n) return;
+    if (!v.empty() && v.back().seq == seq) v.back().n += n;
+    else v.push_back(JgSeg{seq, n});
+  };
   const size_t nrec = e->recs.size();
   if (nrec) {
     // job table + totals in pinned host memory, read / written by the kernel in place
@@ -383,6 +423,11 @@ int collect(jg_engine* e) {
     e->q_msgs.n = at_m + add_m;
     e->q_fsm.n = at_f + add_f;
     e->last_add_m = add_m;
+    if (e->track_segs)
+      for (size_t k = 0; k < nrec; k++) {
+        if (!e->h_status[4]) seg_add(e->seg_m, e->recs[k].seq, totals[2 * k]);  // (else: in the merge below)
+        seg_add(e->seg_f, e->recs[k].seq, totals[2 * k + 1]);
+      }
   }
   // exceptional rows of dense node steps (the count came with the status block)
   const uint32_t nx = e->h_status[4];
@@ -416,12 +461,19 @@ int collect(jg_engine* e) {
     merged.reserve(e->q_msgs.n - old_n + nx);
     size_t xi = 0, off = old_n;
     for (size_t k = 0; k < nrec; k++) {
-      while (xi < nx && xr[xi].seq < e->recs[k].seq) merged.push_back(xr[xi++].row);
+      while (xi < nx && xr[xi].seq < e->recs[k].seq) {
+        if (e->track_segs) seg_add(e->seg_m, xr[xi].seq, 1);
+        merged.push_back(xr[xi++].row);
+      }
       const size_t cnt = e->h_totals[2 * k];
       merged.insert(merged.end(), e->q_msgs.p + off, e->q_msgs.p + off + cnt);
+      if (e->track_segs) seg_add(e->seg_m, e->recs[k].seq, cnt);
       off += cnt;
     }
-    while (xi < nx) merged.push_back(xr[xi++].row);
+    while (xi < nx) {
+      if (e->track_segs) seg_add(e->seg_m, xr[xi].seq, 1);
+      merged.push_back(xr[xi++].row);
+    }
     HIPCHK(e->q_msgs.reserve(old_n + merged.size()));
     if (!merged.empty()) std::memcpy(e->q_msgs.p + old_n, merged.data(), merged.size() * sizeof(jg_msg_row));
     e->q_msgs.n = old_n + merged.size();
@@ -434,6 +486,8 @@ int collect(jg_engine* e) {
     sort_faults(e->fault_tmp, e->fault_tmp2);
     e->q_faults.reserve(e->q_faults.size() + e->fault_tmp.size());
     for (const JgFaultRec& f : e->fault_tmp) e->q_faults.push_back(jg_fault_row{f.group, f.code});
+    if (e->track_segs)
+      for (const JgFaultRec& f : e->fault_tmp) e->q_fault_seq.push_back(f.seq);
   }
   if (trace && nrec)
     std::fprintf(stderr, "[jg drain] %zu steps: sync %.3f ms, scan %.3f ms, gather+copy %.3f ms, host tail %.3f ms (%zu msg rows, %u faults)\n",
@@ -442,9 +496,9 @@ int collect(jg_engine* e) {
 }
 
 template <typename Row>
-int drain(jg_engine* e, PinnedQueue<Row>& q, Row* out, size_t cap, size_t* n) {
+int drain(jg_engine* e, PinnedQueue<Row>& q, int mask, Row* out, size_t cap, size_t* n) {
   if (!e || !n) return fail(JG_EINVAL, "null argument");
-  int rc = collect(e);
+  int rc = collect(e, mask);
   if (rc) return rc;
   *n = q.n;
   if (!out) return JG_OK;
@@ -454,14 +508,40 @@ int drain(jg_engine* e, PinnedQueue<Row>& q, Row* out, size_t cap, size_t* n) {
   return JG_OK;
 }
 template <typename Row>
-int drain_view(jg_engine* e, PinnedQueue<Row>& q, bool& viewed, const Row** rows, size_t* n) {
+int drain_view(jg_engine* e, PinnedQueue<Row>& q, int mask, const Row** rows, size_t* n) {
   if (!e || !rows || !n) return fail(JG_EINVAL, "null argument");
-  int rc = collect(e);
+  int rc = collect(e, mask);
   if (rc) return rc;
   *rows = q.p;
   *n = q.n;
-  viewed = true;  // consumed: the rows stay readable until the engine's next call that synchronises
+  q.viewed = q.n;  // consumed: the rows stay where they are until the next drain of this queue
   return JG_OK;
+}
+
+// jg_submit's argument checks (shared with the multi-device router)
+int validate_batch(uint32_t n_groups, const jg_cmd_batch* b) {
+  if (b->n && (!b->kind || !b->group)) return fail(JG_EINVAL, "kind/group columns are required");
+  if (b->n_blocks && (!b->blk_id || !b->blk_next)) return fail(JG_EINVAL, "block side arrays are required");
+  for (size_t i = 0; i < b->n; i++) {
+    if (b->group[i] >= n_groups) return fail(JG_EINVAL, "group out of range");
+    if (b->kind[i] >= JG_CMD__COUNT) return fail(JG_EINVAL, "unknown command kind");
+    if (b->kind[i] == JG_CMD_APPEND_ENTRIES) {
+      if (!b->id || !b->aux) return fail(JG_EINVAL, "AppendEntries needs id/aux columns");
+      if (b->aux[i] > b->n_blocks || b->id[i] > b->n_blocks - b->aux[i])  // (overflow-safe)
+        return fail(JG_EINVAL, "block side-array range out of bounds");
+    }
+  }
+  return JG_OK;
+}
+
+// element width of a jg_read_state column
+size_t field_width(int field) {
+  switch (field) {
+    case JG_FIELD_TERM: case JG_FIELD_COMMIT: case JG_FIELD_HEAD: case JG_FIELD_ID_GEN: case JG_FIELD_MATCH:
+    case JG_FIELD_ELECTION_TIME: case JG_FIELD_HEARTBEAT_TIME: return 8;
+    case JG_FIELD_VOTED_FOR: case JG_FIELD_LEADER_ID: case JG_FIELD_ELECTION_TIMEOUT: case JG_FIELD_QUEUED_REQS: return 4;
+    default: return 1;
+  }
 }
 
 // Stable LSD radix sort of row indices by group id: per-group stream order = row order.
@@ -548,6 +628,8 @@ void launch_calib(jg_engine* e, const uint64_t* rot, const uint64_t* a8, uint64_
 
 }  // namespace
 
+#include "jg_multi.h"
+
 extern "C" {
 
 const char* jg_last_error(void) { return g_err.c_str(); }
@@ -563,15 +645,22 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
       if (cfg->node_ids[q] == cfg->node_ids[r]) return fail(JG_EINVAL, "duplicate node id");
   }
   if (cfg->heartbeat_timeout_ms < 5) return fail(JG_EINVAL, "heartbeat timeout is too low");  // config.rs:70-72
-  if (cfg->election_timeout_max_ms < cfg->election_timeout_min_ms) return fail(JG_EINVAL, "election timeout range");
+  // thread_rng().gen_range(min..max) panics on an empty range (follower.rs:105)
+  if (cfg->election_timeout_max_ms <= cfg->election_timeout_min_ms) return fail(JG_EINVAL, "election timeout range is empty");
+  if (cfg->n_groups == 0) return fail(JG_EINVAL, "n_groups cannot be 0");
+  if (cfg->n_devices > JG_MAX_DEVICES) return fail(JG_EINVAL, "n_devices out of range");
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
-  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(JG_EDEVICE, "no such HIP device (no CPU fallback)");
-  HIPCHK(hipSetDevice(cfg->device_id));
+  for (uint32_t d = 0; d < cfg->n_devices; d++)
+    if (cfg->device_ids[d] < 0 || cfg->device_ids[d] >= ndev) return fail(JG_EDEVICE, "no such HIP device (no CPU fallback)");
+  if (cfg->n_devices > 1) return router_create(cfg, out);  // one shard per listed device, one handle
+  const int device_id = cfg->n_devices == 1 ? cfg->device_ids[0] : cfg->device_id;
+  if (device_id < 0 || device_id >= ndev) return fail(JG_EDEVICE, "no such HIP device (no CPU fallback)");
+  HIPCHK(hipSetDevice(device_id));
 
   jg_engine* e = new jg_engine();
   e->cfg = *cfg;
-  e->device = cfg->device_id;
+  e->device = device_id;
   int rc = JG_OK;
   auto bail = [&](int code) {
     jg_engine_destroy(e);
@@ -632,6 +721,7 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   d.deferred_seen = e->d_status + 2;
   d.fault_q_n = e->d_status + 3;
   d.xq_n = e->d_status + 4;
+  d.cold_seen = e->d_status + 5;
   if (hipHostMalloc((void**)&e->h_status, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
     return bail(fail(JG_EDEVICE, "hipHostMalloc failed"));
   {  // deferred lists: shard = workgroup & (JG_SHARDS-1); generous per-shard capacity, bounds-checked
@@ -664,6 +754,12 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
 
 void jg_engine_destroy(jg_engine* e) {
   if (!e) return;
+  if (e->parent) return;  // a shard handle: owned by its parent
+  if (e->router) {
+    router_destroy(e);
+    delete e;
+    return;
+  }
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   e->arena.destroy();
@@ -683,8 +779,23 @@ void jg_engine_destroy(jg_engine* e) {
   delete e;
 }
 
+uint32_t jg_shard_count(const jg_engine* e) { return !e ? 0u : e->router ? (uint32_t)e->router->D() : 1u; }
+
+int jg_get_shard(jg_engine* e, uint32_t shard, jg_shard_info* out) {
+  if (!e || !out) return fail(JG_EINVAL, "null argument");
+  if (shard >= jg_shard_count(e)) return fail(JG_EINVAL, "shard out of range");
+  jg_engine* s = e->router ? e->router->sh[shard] : e;
+  out->engine = s;
+  out->device_id = s->device;
+  out->group_lo = e->router ? e->router->lo[shard] : 0;
+  out->n_groups = s->cfg.n_groups;
+  out->reserved = 0;
+  return JG_OK;
+}
+
 int jg_set_self_slots(jg_engine* e, const uint8_t* slots) {
   if (!e || !slots) return fail(JG_EINVAL, "null argument");
+  if (e->router) return router_set_self_slots(e, slots);
   if (e->stepped) return fail(JG_EINVAL, "self slots are fixed after the first step");
   for (uint32_t g = 0; g < e->cfg.n_groups; g++)
     if (slots[g] >= e->cfg.n_replicas) return fail(JG_EINVAL, "self slot out of range");
@@ -705,14 +816,10 @@ int jg_set_self_slots(jg_engine* e, const uint8_t* slots) {
 
 int jg_submit(jg_engine* e, const jg_cmd_batch* b) {
   if (!e || !b) return fail(JG_EINVAL, "null argument");
-  if (b->n && (!b->kind || !b->group)) return fail(JG_EINVAL, "kind/group columns are required");
-  for (size_t i = 0; i < b->n; i++) {
-    if (b->group[i] >= e->cfg.n_groups) return fail(JG_EINVAL, "group out of range");
-    if (b->kind[i] >= JG_CMD__COUNT) return fail(JG_EINVAL, "unknown command kind");
-    if (b->kind[i] == JG_CMD_APPEND_ENTRIES) {
-      if (!b->id || !b->aux) return fail(JG_EINVAL, "AppendEntries needs id/aux columns");
-      if (b->id[i] + b->aux[i] > b->n_blocks) return fail(JG_EINVAL, "block side-array range out of bounds");
-    }
+  if (e->router) return router_submit(e, b);
+  {
+    const int rc = validate_batch(e->cfg.n_groups, b);
+    if (rc) return rc;
   }
   const size_t at = e->p_kind.size(), n = b->n;
   const uint64_t blk_shift = e->p_blk_id.size();
@@ -739,6 +846,7 @@ int jg_submit(jg_engine* e, const jg_cmd_batch* b) {
 
 int jg_step(jg_engine* e, uint64_t now_ms) {
   if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) return router_step(e, now_ms);
   e->stepped = true;
   const size_t n = e->p_kind.size();
   if (!n) return JG_OK;
@@ -812,6 +920,7 @@ int jg_step(jg_engine* e, uint64_t now_ms) {
 
 int jg_step_device_rows(jg_engine* e, const jg_cmd_batch* b, uint64_t now_ms) {
   if (!e || !b) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
   if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
   e->stepped = true;
   if (!b->n) return JG_OK;
@@ -826,14 +935,23 @@ int jg_step_device_rows(jg_engine* e, const jg_cmd_batch* b, uint64_t now_ms) {
 
 int jg_step_dense_acks_device(jg_engine* e, const uint64_t* acks_dev) {
   if (!e || !acks_dev) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "one block per shard: jg_step_dense_acks_shards");
   if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
   HIPCHK(hipSetDevice(e->device));
   return dense_step(e, acks_dev);
 }
 
+int jg_step_dense_acks_shards(jg_engine* e, const uint64_t* const* acks_dev, uint32_t n_ticks) {
+  if (!e || !acks_dev) return fail(JG_EINVAL, "null argument");
+  if (!n_ticks) return JG_OK;
+  if (e->router) return router_step_dense_acks_shards(e, acks_dev, n_ticks);
+  return jg_step_dense_acks_device_n(e, acks_dev[0], n_ticks);
+}
+
 int jg_step_dense_acks_device_n(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks) {
   if (!e || !acks_dev) return fail(JG_EINVAL, "null argument");
   if (!n_ticks) return JG_OK;
+  if (e->router) return fail(JG_EINVAL, "one block per shard: jg_step_dense_acks_shards");
   if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
   HIPCHK(hipSetDevice(e->device));
   return dense_step(e, acks_dev, n_ticks);
@@ -841,6 +959,7 @@ int jg_step_dense_acks_device_n(jg_engine* e, const uint64_t* acks_dev, uint32_t
 
 int jg_step_dense_acks(jg_engine* e, const uint64_t* acks_host) {
   if (!e || !acks_host) return fail(JG_EINVAL, "null argument");
+  if (e->router) return router_step_dense_acks(e, acks_host);
   if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
   HIPCHK(hipSetDevice(e->device));
   const size_t bytes = (size_t)e->cfg.n_groups * e->cfg.n_replicas * 8;
@@ -854,6 +973,7 @@ int jg_step_dense_acks(jg_engine* e, const uint64_t* acks_host) {
 
 int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* in, const jg_leader_outbox* out) {
   if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
   if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
   if (out && (!out->term || !out->hb_commit || !out->ae_from || !out->ae_n))
     return fail(JG_EINVAL, "every outbox column is required");
@@ -879,6 +999,7 @@ int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* i
 int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in, const jg_follower_outbox* out,
                            int tick) {
   if (!e || !in || !out) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
   if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
   if (!in->term || !in->hb_commit || !in->ae_from || !in->ae_n) return fail(JG_EINVAL, "every inbox column is required");
   if (!out->ack_head || !out->hb_commit || !out->hb_has) return fail(JG_EINVAL, "every outbox column is required");
@@ -919,6 +1040,7 @@ int jg_chain_compact(jg_engine* e, size_t n_trees, const uint64_t* off, const ui
                      const uint64_t* commits, uint8_t* removed) {
   if (!e || !off || !commits) return fail(JG_EINVAL, "null argument");
   if (!n_trees) return JG_OK;
+  if (e->router) e = e->router->sh[0];  // a pure function: any shard's device will do
   HIPCHK(hipSetDevice(e->device));
   const size_t n = off[n_trees];
   if (n && (!ids || !nexts || !removed)) return fail(JG_EINVAL, "null argument");
@@ -952,12 +1074,22 @@ int jg_chain_compact(jg_engine* e, size_t n_trees, const uint64_t* off, const ui
 
 int jg_sync(jg_engine* e) {
   if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) return e->router->run([&](size_t d) { return sync_and_check(e->router->sh[d]); });
   return sync_and_check(e);
 }
 
 int jg_stream_wait(jg_engine* waiter, jg_engine* signal) {
   if (!waiter || !signal) return fail(JG_EINVAL, "null argument");
   if (waiter == signal) return JG_OK;
+  if (waiter->router || signal->router) {  // shard by shard (same ownership on both sides)
+    if (!waiter->router || !signal->router || waiter->router->lo != signal->router->lo)
+      return fail(JG_EINVAL, "jg_stream_wait: the two engines are sharded differently");
+    for (size_t d = 0; d < waiter->router->D(); d++) {
+      const int rc = jg_stream_wait(waiter->router->sh[d], signal->router->sh[d]);
+      if (rc) return rc;
+    }
+    return JG_OK;
+  }
   HIPCHK(hipSetDevice(signal->device));
   HIPCHK(hipEventRecord(signal->ev_order, signal->stream));
   HIPCHK(hipSetDevice(waiter->device));
@@ -966,31 +1098,42 @@ int jg_stream_wait(jg_engine* waiter, jg_engine* signal) {
 }
 
 int jg_drain_messages(jg_engine* e, jg_msg_row* out, size_t cap, size_t* n) {
-  return e ? drain(e, e->q_msgs, out, cap, n) : fail(JG_EINVAL, "null argument");
+  if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) return router_drain(e, e->router->msgs, 1, out, cap, n);
+  return drain(e, e->q_msgs, 1, out, cap, n);
 }
 int jg_drain_applies(jg_engine* e, jg_fsm_row* out, size_t cap, size_t* n) {
-  return e ? drain(e, e->q_fsm, out, cap, n) : fail(JG_EINVAL, "null argument");
+  if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) return router_drain(e, e->router->fsm, 2, out, cap, n);
+  return drain(e, e->q_fsm, 2, out, cap, n);
 }
 int jg_drain_messages_view(jg_engine* e, const jg_msg_row** rows, size_t* n) {
-  return e ? drain_view(e, e->q_msgs, e->view_m, rows, n) : fail(JG_EINVAL, "null argument");
+  if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) return router_drain_view(e, e->router->msgs, e->router->msgs_view, 1, rows, n);
+  return drain_view(e, e->q_msgs, 1, rows, n);
 }
 int jg_drain_applies_view(jg_engine* e, const jg_fsm_row** rows, size_t* n) {
-  return e ? drain_view(e, e->q_fsm, e->view_f, rows, n) : fail(JG_EINVAL, "null argument");
+  if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) return router_drain_view(e, e->router->fsm, e->router->fsm_view, 2, rows, n);
+  return drain_view(e, e->q_fsm, 2, rows, n);
 }
 int jg_drain_faults(jg_engine* e, jg_fault_row* out, size_t cap, size_t* n) {
   if (!e || !n) return fail(JG_EINVAL, "null argument");
-  int rc = collect(e);
+  int rc = e->router ? router_collect(e, 0) : collect(e, 0);
   if (rc) return rc;
-  *n = e->q_faults.size();
+  std::vector<jg_fault_row>& q = e->router ? e->router->faults : e->q_faults;
+  *n = q.size();
   if (!out) return JG_OK;
-  if (cap < e->q_faults.size()) return fail(JG_ECAPACITY, "output buffer too small");
-  if (!e->q_faults.empty()) std::memcpy(out, e->q_faults.data(), e->q_faults.size() * sizeof(jg_fault_row));
-  e->q_faults.clear();
+  if (cap < q.size()) return fail(JG_ECAPACITY, "output buffer too small");
+  if (!q.empty()) std::memcpy(out, q.data(), q.size() * sizeof(jg_fault_row));
+  q.clear();
+  e->q_fault_seq.clear();
   return JG_OK;
 }
 
 int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t g0, uint32_t n) {
   if (!e || (!out && n)) return fail(JG_EINVAL, "null argument");
+  if (e->router) return router_read_state(e, field, replica, out, g0, n);
   if ((uint64_t)g0 + n > e->cfg.n_groups) return fail(JG_EINVAL, "group range out of bounds");
   if (field < 0 || field >= JG_FIELD__COUNT) return fail(JG_EINVAL, "unknown field");
   if (field == JG_FIELD_MATCH && replica >= e->cfg.n_replicas) return fail(JG_EINVAL, "replica out of range");
@@ -1105,6 +1248,7 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
 
 int jg_get_counters(jg_engine* e, uint64_t out[4]) {
   if (!e || !out) return fail(JG_EINVAL, "null argument");
+  if (e->router) return router_get_counters(e, out);
   int rc = sync_and_check(e);
   if (rc) return rc;
   std::vector<uint64_t> slots(e->count_slots);
@@ -1120,6 +1264,7 @@ int jg_get_counters(jg_engine* e, uint64_t out[4]) {
 
 int jg_device_alloc(jg_engine* e, size_t bytes, void** dev_ptr) {
   if (!e || !dev_ptr) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipMalloc(dev_ptr, std::max<size_t>(bytes, 16)));
   HIPCHK(hipMemsetAsync(*dev_ptr, 0, std::max<size_t>(bytes, 16), e->stream));
@@ -1127,6 +1272,7 @@ int jg_device_alloc(jg_engine* e, size_t bytes, void** dev_ptr) {
 }
 int jg_device_free(jg_engine* e, void* dev_ptr) {
   if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipFree(dev_ptr));
@@ -1134,6 +1280,7 @@ int jg_device_free(jg_engine* e, void* dev_ptr) {
 }
 int jg_device_upload(jg_engine* e, void* dev_dst, const void* host_src, size_t bytes) {
   if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1141,6 +1288,7 @@ int jg_device_upload(jg_engine* e, void* dev_dst, const void* host_src, size_t b
 }
 int jg_device_download(jg_engine* e, void* host_dst, const void* dev_src, size_t bytes) {
   if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1148,12 +1296,29 @@ int jg_device_download(jg_engine* e, void* host_dst, const void* dev_src, size_t
 }
 int jg_timer_start(jg_engine* e) {
   if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) {  // every shard's stream
+    for (jg_engine* s : e->router->sh) {
+      const int rc = jg_timer_start(s);
+      if (rc) return rc;
+    }
+    return JG_OK;
+  }
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipEventRecord(e->ev0, e->stream));
   return JG_OK;
 }
 int jg_timer_stop(jg_engine* e, float* ms) {
   if (!e || !ms) return fail(JG_EINVAL, "null argument");
+  if (e->router) {  // the slowest shard
+    *ms = 0;
+    for (jg_engine* s : e->router->sh) {
+      float v = 0;
+      const int rc = jg_timer_stop(s, &v);
+      if (rc) return rc;
+      *ms = std::max(*ms, v);
+    }
+    return JG_OK;
+  }
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipEventRecord(e->ev1, e->stream));
   HIPCHK(hipEventSynchronize(e->ev1));
@@ -1163,6 +1328,7 @@ int jg_timer_stop(jg_engine* e, float* ms) {
 
 int jg_calibrate_stream(jg_engine* e, uint32_t iters, float* avg_us) {
   if (!e || !avg_us || !iters) return fail(JG_EINVAL, "null argument");
+  if (e->router) e = e->router->sh[0];
   HIPCHK(hipSetDevice(e->device));
   const size_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
   const size_t blk = std::max<size_t>(G * R * 8, 16);
@@ -1209,6 +1375,7 @@ int jg_calibrate_stream(jg_engine* e, uint32_t iters, float* avg_us) {
 
 int jg_synth_fill_acks_device(jg_engine* e, uint32_t mode, uint64_t tick, uint64_t* sim_dev, uint64_t* acks_dev) {
   if (!e || !sim_dev || !acks_dev) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
   if (mode > 1) return fail(JG_EINVAL, "unknown synth mode");
   HIPCHK(hipSetDevice(e->device));
   hipLaunchKernelGGL(k_synth_acks, dim3(grid_for(e->cfg.n_groups, 4096)), dim3(JG_BLOCK), 0, e->stream, e->dev, mode,

@@ -124,7 +124,10 @@ class BatchedRaft:
     def __init__(self, n_groups: int, n_replicas: int = 1, node_ids: Optional[Sequence[int]] = None,
                  self_slots: Optional[Sequence[int]] = None, seed: int = 0, device_id: int = 0,
                  group_base: int = 0, flags: int = 0, heartbeat_timeout_ms: int = 100,
-                 election_timeout_ms: Tuple[int, int] = (500, 1000), api: Optional[capi.Api] = None):
+                 election_timeout_ms: Tuple[int, int] = (500, 1000), api: Optional[capi.Api] = None,
+                 device_ids: Optional[Sequence[int]] = None):
+        """`device_ids` (HIP engine only): shard the groups over these devices behind this one
+        handle (contiguous ownership; a device may be listed several times) — jg_config.n_devices."""
         self.api = api if api is not None else device_api()
         self.G, self.R = int(n_groups), int(n_replicas)
         if node_ids is None:
@@ -136,6 +139,11 @@ class BatchedRaft:
         for r, nid in enumerate(list(node_ids)[:capi.MAX_REPLICAS]):
             cfg.node_ids[r] = int(nid)
         cfg.device_id = device_id
+        if device_ids is not None:
+            assert 1 <= len(device_ids) <= capi.MAX_DEVICES
+            cfg.n_devices = len(device_ids)
+            for d, dev in enumerate(device_ids):
+                cfg.device_ids[d] = int(dev)
         cfg.heartbeat_timeout_ms = heartbeat_timeout_ms
         cfg.election_timeout_min_ms, cfg.election_timeout_max_ms = election_timeout_ms
         cfg.seed = seed
@@ -167,6 +175,23 @@ class BatchedRaft:
     def _check(self, status: int) -> None:
         if status != capi.OK:
             raise EngineError(status, self.api.error())
+
+    # -- shards of a multi-device engine -------------------------------------
+    @property
+    def n_shards(self) -> int:
+        return int(self.api.shard_count(self._h)) if hasattr(self.api, "shard_count") else 1
+
+    def shard(self, d: int) -> "Shard":
+        """Shard d's own single-device engine (jg_get_shard): what the device-pointer entry
+        points are called on."""
+        info = capi.ShardInfo()
+        self._check(self.api.get_shard(self._h, d, C.byref(info)))
+        return Shard(self, info)
+
+    def step_dense_acks_shards(self, ptrs: Sequence[int], n_ticks: int = 1) -> None:
+        """jg_step_dense_acks_shards: ptrs[d] = shard d's device-resident [n_ticks][R][G_d] block."""
+        arr = (C.c_void_p * len(ptrs))(*[C.c_void_p(int(p)) for p in ptrs])
+        self._check(self.api.step_dense_acks_shards(self._h, arr, int(n_ticks)))
 
     # -- input ---------------------------------------------------------------
     def submit(self, group: int, cmd: Command) -> None:
@@ -457,6 +482,27 @@ class BatchedRaft:
 
     def handle(self, group: int) -> "RaftHandle":
         return RaftHandle(self, group)
+
+
+class Shard:
+    """One shard of a multi-device BatchedRaft: a borrowed engine handle (owned by the parent)
+    plus the group range it owns.  Quacks enough like a BatchedRaft for the device-pointer calls."""
+
+    def __init__(self, parent: BatchedRaft, info: "capi.ShardInfo"):
+        self.parent, self.api = parent, parent.api
+        self._h = C.c_void_p(info.engine)
+        self.device_id, self.group_lo, self.G, self.R = info.device_id, info.group_lo, info.n_groups, parent.R
+        self.node_ids = parent.node_ids
+        self._check = parent._check
+
+    def alloc(self, nbytes: int) -> C.c_void_p:
+        p = C.c_void_p()
+        self._check(self.api.device_alloc(self._h, nbytes, C.byref(p)))
+        return p
+
+    def upload(self, dev_ptr, host: np.ndarray) -> None:
+        host = np.ascontiguousarray(host)
+        self._check(self.api.device_upload(self._h, dev_ptr, host.ctypes.data, host.nbytes))
 
 
 class RaftHandle:

@@ -182,6 +182,8 @@ static void dense_range(jo_engine* e, const uint64_t* acks, uint32_t g0, uint32_
     if (!r.fault) {
       if (r.role != JG_ROLE_LEADER) {
         if (n_append) r.fault = JG_FAULT_ENGINE_DENSE_NONLEADER;
+      } else if (n_append >= JG_MAX_DENSE_APPENDS) {
+        r.fault = JG_FAULT_ENGINE_DENSE_APPENDS;  // own slot outside its domain: nothing of the tick is applied
       } else {
         Cmd c;
         c.kind = JG_CMD_CLIENT_REQUEST;
@@ -288,6 +290,11 @@ int jo_step_dense_leader(jo_engine* e, uint64_t now_ms, const jg_leader_inbox* i
     const uint64_t n_append = acks ? acks[(size_t)s * G + g] : 0;
     if (r.role != JG_ROLE_LEADER) {  // acks / responses are ignored (follower.rs:62, candidate.rs:194)
       if (n_append) r.fault = JG_FAULT_ENGINE_DENSE_NONLEADER;
+      note_fault(e, g, fault0);
+      continue;
+    }
+    if (n_append >= JG_MAX_DENSE_APPENDS) {  // own slot outside its domain: nothing of the tick is applied
+      r.fault = JG_FAULT_ENGINE_DENSE_APPENDS;
       note_fault(e, g, fault0);
       continue;
     }

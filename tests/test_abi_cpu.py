@@ -75,7 +75,36 @@ def test_row_struct_layouts_match_header():
     assert np.dtype(capi.MSG_DTYPE).itemsize == 40
     assert np.dtype(capi.FSM_DTYPE).itemsize == 24
     assert np.dtype(capi.FAULT_DTYPE).itemsize == 8
-    assert C.sizeof(capi.Config) == 88  # 60 B of u32 fields, 4 B padding, 2 x u64, 2 x u32
+    assert C.sizeof(capi.Config) == 160  # ABI v2: the v1 88 bytes + n_devices + device_ids[16] (+ 4 B tail padding)
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """sizeof / offsetof of every struct of include/josefine_gpu.h as gcc lays them out, against
+    the ctypes mirrors in josefine_amd/_capi.py."""
+    import subprocess
+    structs = {"jg_config": capi.Config, "jg_cmd_batch": capi.CmdBatch, "jg_shard_info": capi.ShardInfo,
+               "jg_leader_inbox": capi.LeaderInbox, "jg_leader_outbox": capi.LeaderOutbox,
+               "jg_follower_inbox": capi.FollowerInbox, "jg_follower_outbox": capi.FollowerOutbox}
+    rename = {"from_": "from"}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "josefine_gpu.h")}"',
+             'int main(void) {']
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, *_ in ct._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {rename.get(fname, fname)}));')
+    lines += ['  printf("jg_msg_row %zu\\n", sizeof(jg_msg_row));', '  printf("jg_fsm_row %zu\\n", sizeof(jg_fsm_row));',
+              '  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, ct in structs.items():
+        assert int(got[cname]) == C.sizeof(ct), cname
+        for fname, *_ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
+    assert int(got["jg_msg_row"]) == np.dtype(capi.MSG_DTYPE).itemsize
+    assert int(got["jg_fsm_row"]) == np.dtype(capi.FSM_DTYPE).itemsize
 
 
 def test_command_constructors_use_header_columns():

@@ -410,8 +410,16 @@ def test_dense_lag_space_boundaries(R, slot_layout):
     for t in range(T):
         head = ora.read("head").astype(np.uint64)
         acks = np.full((R, G), NO, dtype=np.uint64)
+        n_app = rng.integers(0, 3, G).astype(np.uint64)
+        n_app = np.where(rng.random(G) < 0.02, esc + 3 if esc < 70_000 else 5000, n_app)  # burst: every lag leaves its field
+        if t == 9:   # outside the own slot's domain (JG_MAX_DENSE_APPENDS): an engine fault, nothing applied
+            n_app = np.where(gi % 256 == 1, (1 << 20) + 1, n_app)
+            n_app = np.where(gi % 256 == 2, 1 << 20, n_app)
+            n_app = np.where(gi % 256 == 3, NO, n_app)
+        if t == 10:  # the largest legal value (a million appends in one tick: once, on few groups)
+            n_app = np.where(gi % 1024 == 5, (1 << 20) - 1, n_app)
         for r in range(R):
-            kind = rng.integers(0, 12, G)
+            kind = rng.integers(0, 14, G)
             lag = np.zeros(G, dtype=np.uint64)
             lag = np.where(kind == 1, 1, lag)
             lag = np.where(kind == 2, rng.integers(0, 7, G), lag)
@@ -423,12 +431,11 @@ def test_dense_lag_space_boundaries(R, slot_layout):
             a = np.where(lag <= head, head - np.minimum(lag, head), 0).astype(np.uint64)
             a = np.where(kind == 8, head + np.uint64(1), a)                      # one above the head
             a = np.where((kind == 9) & (rng.random(G) < 0.05), head + np.uint64(10**9), a)  # forged
-            a = np.where(kind >= 10, NO, a)                                      # dropped
+            a = np.where((kind == 10) | (kind == 11), NO, a)                     # dropped
+            small = n_app < np.uint64(1 << 21)
+            a = np.where((kind == 12) & small, head + n_app, a)                  # exactly the head the ack meets (appends first)
+            a = np.where((kind == 13) & small, head + n_app + np.uint64(1), a)   # one above it -> replay
             acks[r] = a
-        n_app = rng.integers(0, 3, G).astype(np.uint64)
-        n_app = np.where(rng.random(G) < 0.02, esc + 3 if esc < 70_000 else 5000, n_app)  # burst: every lag leaves its field
-        if t == 9:
-            n_app = np.where(gi % 256 == 1, (1 << 20) + 1, n_app)                # above the lag-space append limit
         acks[slots, gi] = n_app
         if t % 6 == 5:  # the same three ticks through the T-tick kernel
             blk = np.stack([acks, acks, acks])
@@ -441,7 +448,8 @@ def test_dense_lag_space_boundaries(R, slot_layout):
         compare_drains(dev, ora, f"lag-space boundaries R={R} tick {t}")
         assert dev.counters()["decisions"] == ora.counters()["decisions"]
     faults = np.bincount(ora.read("fault"), minlength=256)
-    assert (R < 3 or faults[capi.FAULT_COMMIT_MISSING_BLOCK] > 0) and faults[0] > G // 2, faults[:8]
+    assert (R < 3 or faults[capi.FAULT_COMMIT_MISSING_BLOCK] > 0) and faults[0] > G // 4, faults[:8]
+    assert faults[capi.FAULT_ENGINE_DENSE_APPENDS] > 0
 
 
 @pytest.mark.parametrize("R", [3, 5])
