@@ -6,7 +6,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libjosefine_gpu.so")
-SOURCES = ["josefine_gpu.hip", "jg_kernels.h", "jg_dense.h", "jg_sparse.h", "jg_device.h"]
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))  # every header the one translation unit includes
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

@@ -29,6 +29,40 @@ def synth_hash(seed, tick, gg, r):
         return mix64(a ^ (np.asarray(gg, dtype=np.uint64) * np.uint64(8) + np.uint64(r)))
 
 
+def synth_fill_acks_host(seed, mode, tick, group_base, slots, sim, n_replicas):
+    """One dense [R][G] tick of the synthetic AppendEntries-ack stream (DESIGN.md "Synthetic
+    traces") in numpy — the same stream k_synth_acks generates on the device, for any shard:
+    `sim` ([R][G] uint64, zero-initialised by the caller) is the generator's follower model and is
+    updated in place.  mode 0: one append, every follower acks the previous leader head; mode 1:
+    hash % 3 appends, 5 % dropped, 5 % stale duplicates, else min(lead, prev + U{0..5})."""
+    R, G = n_replicas, sim.shape[1]
+    slots = np.asarray(slots, dtype=np.int64)
+    gi = np.arange(G)
+    gg = gi.astype(np.uint64) + np.uint64(group_base)
+    acks = np.zeros((R, G), dtype=np.uint64)
+    lead = sim[slots, gi].copy()
+    with np.errstate(over="ignore"):
+        # the own slot's hash: r differs per group
+        n_app = np.ones(G, np.uint64) if mode == 0 else \
+            mix64(mix64(np.uint64(seed) + np.uint64(tick) * np.uint64(0x9E3779B97F4A7C15)) ^ (gg * np.uint64(8) + slots.astype(np.uint64))) % np.uint64(3)
+        for r in range(R):
+            other = slots != r
+            if mode == 0:
+                a, new = lead, lead
+            else:
+                u = synth_hash(seed, tick, gg, r)
+                p = u % np.uint64(100)
+                adv = (u >> np.uint64(32)) % np.uint64(capi.MAX_INFLIGHT + 1)
+                v = np.minimum(lead, sim[r] + adv)
+                a = np.where(p < 5, np.uint64(capi.NO_ACK), np.where(p < 10, sim[r], v))
+                new = np.where(p < 10, sim[r], v)
+            acks[r] = np.where(other, a, acks[r])
+            sim[r] = np.where(other, new, sim[r])
+        acks[slots, gi] = n_app
+        sim[slots, gi] = lead + n_app
+    return acks
+
+
 def elect_all(e, now_ms: int = 0) -> None:
     """Make the local instance of every group the leader at term 1 by the reference's own
     path: Timeout -> candidate + self-vote (follower.rs:248-256, candidate.rs:24-45), then

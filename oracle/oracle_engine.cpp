@@ -64,7 +64,9 @@ int jo_engine_create(const jg_config* cfg, jo_engine** out) {
       if (cfg->node_ids[q] == cfg->node_ids[r]) return fail(JG_EINVAL, "duplicate node id");
   }
   if (cfg->heartbeat_timeout_ms < 5) return fail(JG_EINVAL, "heartbeat timeout is too low");  // config.rs:70-72
-  if (cfg->election_timeout_max_ms < cfg->election_timeout_min_ms) return fail(JG_EINVAL, "election timeout range");
+  // thread_rng().gen_range(min..max) panics on an empty range (follower.rs:105)
+  if (cfg->election_timeout_max_ms <= cfg->election_timeout_min_ms) return fail(JG_EINVAL, "election timeout range is empty");
+  if (cfg->n_groups == 0) return fail(JG_EINVAL, "n_groups cannot be 0");
   jo_engine* e = new jo_engine();
   e->cfg = *cfg;
   e->groups.resize(cfg->n_groups);

@@ -10,7 +10,7 @@
 // (no cargo/rustc, crates not vendored — SURVEY.md §8(c)), so there is no
 // oracle/_ref.  This restatement is pinned against every known-answer test the
 // reference's own test modules hold for this path (single-node cases, the
-// chain tests incl. the only `compact` vector) in tests/test_oracle_reference_kats.py;
+// chain tests incl. the only `compact` vector) in tests/test_reference_kats.py;
 // every multi-replica result (majority, election, can_vote clauses …) is
 // "parity unpinned" by the reference itself — those rest on fidelity to the
 // cited lines plus the hand-derived vectors of SURVEY.md §8(c).

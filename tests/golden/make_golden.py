@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""Regenerates tests/golden/*.npz from the CPU oracle.
+"""Regenerates tests/golden/*.npz from tests/ref_py — the line-by-line Python transliteration
+of the Rust reference, NOT from the C++ oracle the HIP engine is normally checked against.
 
-The Rust reference cannot run here (no cargo/rustc), so these fixtures are NOT reference
-outputs: they freeze the oracle's answers on fixed seeded inputs so that (a) the oracle
-cannot drift silently between rounds and (b) the HIP engine is compared against committed
-bytes, not only against an oracle built in the same run.  The reference's own golden vectors
-(chain::compact tree, heartbeat / vote-request expectations …) are transcribed directly in
-tests/test_reference_kats.py.
+The Rust reference cannot run here (no cargo/rustc), so these fixtures are not reference
+outputs; they are the answers of a second, independent reading of the reference on fixed seeded
+inputs.  tests/test_golden.py then holds the oracle, ref_py itself and the HIP engine to the
+committed bytes: the oracle cannot drift silently between rounds, the device is compared against
+something other than an oracle built in the same run, and the fixtures are no longer the
+oracle's self-portrait.  The reference's own golden vectors (chain::compact tree, heartbeat /
+vote-request expectations …) are transcribed directly in tests/test_reference_kats.py.
+Inputs that are drawn "near the current state" (fuzz rows, follower mailboxes) are drawn from
+the generating engine's state and stored in the fixture.
 
     python tests/golden/make_golden.py
 """
@@ -21,9 +25,9 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from fuzz import random_batch  # noqa: E402
-from oracle_lib import oracle_engine  # noqa: E402
-from parity import elect_all, synth_tick_host  # noqa: E402
 from josefine_amd import capi  # noqa: E402
+from josefine_amd.traces import elect_all, synth_fill_acks_host  # noqa: E402
+from ref_py.engine import RefEngine as make_engine  # noqa: E402
 
 SEED = 0x6A6F736566696E65
 
@@ -33,12 +37,12 @@ def digest(arr) -> str:
 
 
 def dense_fixture(G, R, mode, ticks, every):
-    e = oracle_engine(G, R, seed=SEED + R)
+    e = make_engine(G, R, seed=SEED + R)
     elect_all(e)
     sim = np.zeros((R, G), dtype=np.uint64)
     out = {"G": G, "R": R, "mode": mode, "ticks": ticks, "every": every, "seed": SEED + R}
     for t in range(ticks):
-        e.step_dense_acks(synth_tick_host(e, mode, t, sim))
+        e.step_dense_acks(synth_fill_acks_host(SEED + R, mode, t, 0, np.zeros(G, np.uint8), sim, R))
         if (t + 1) % every == 0:
             out[f"commit_{t+1}"] = e.read("commit")
             out[f"head_{t+1}"] = e.read("head")
@@ -49,7 +53,7 @@ def dense_fixture(G, R, mode, ticks, every):
 
 
 def fuzz_fixture(G, R, steps, rows):
-    e = oracle_engine(G, R, seed=99)
+    e = make_engine(G, R, seed=99)
     rng = np.random.default_rng(4321 + R)
     budget = np.full(G, capi.CHAIN_WINDOW - 2)
     out = {"G": G, "R": R, "steps": steps}
@@ -82,7 +86,7 @@ def node_fixture(G, R, rounds, ticks):
     from dense_node import DenseCluster, random_follower_inbox
 
     out = {"G": G, "R": R, "rounds": rounds, "ticks": ticks}
-    cl = DenseCluster(oracle_engine, G, R, seed=5)
+    cl = DenseCluster(make_engine, G, R, seed=5)
     rng = np.random.default_rng(77)
     h = hashlib.sha256()
     for t in range(rounds):
@@ -96,7 +100,7 @@ def node_fixture(G, R, rounds, ticks):
     for r in range(R):
         for name in ("commit", "head", "term", "voted_for", "role", "fault"):
             out[f"cluster_{name}_{r}"] = cl.nodes[r].read(name)
-    e = oracle_engine(G, R, seed=6, election_timeout_ms=(300, 600))
+    e = make_engine(G, R, seed=6, election_timeout_ms=(300, 600))
     rng = np.random.default_rng(78)
     h, now = hashlib.sha256(), 0
     for t in range(ticks):
@@ -137,8 +141,8 @@ def down_acks(R, G, t, head, per, T_quorum=120, T_back=200):
 
 def down_fixture(G, R, ticks, every):
     """One follower down, then quorum lost, then recovery: the packed progress word's BEHIND escape
-    and its way back, frozen from the oracle."""
-    e = oracle_engine(G, R, seed=SEED + 100 + R)
+    and its way back."""
+    e = make_engine(G, R, seed=SEED + 100 + R)
     elect_all(e)
     e.drain_messages(), e.drain_applies()
     esc = (1 << (64 // (R + 1))) - 1

@@ -17,6 +17,7 @@ All citations are /root/reference/src/raft/<file>:<lines>.
 """
 from __future__ import annotations
 
+import bisect
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -47,11 +48,50 @@ class Block:  # chain.rs:86-91 (data stays with the host)
     next: int
 
 
-class Chain:
-    """chain.rs:99-254 over an in-memory ordered map standing in for sled."""
+class Sled:
+    """What the reference uses of `sled::Db`: an ordered byte-key map (insert = upsert,
+    contains_key, get, remove, range in key order)."""
 
-    def __init__(self, db: Optional[Dict[bytes, object]] = None):  # Chain::new, chain.rs:117-137
-        self.db: Dict[bytes, object] = {} if db is None else db
+    def __init__(self):
+        self.map: Dict[bytes, object] = {}
+        self.keys: List[bytes] = []  # sorted
+
+    def contains_key(self, k: bytes) -> bool:
+        return k in self.map
+
+    def get(self, k: bytes):
+        return self.map.get(k)
+
+    def insert(self, k: bytes, v) -> None:
+        if k not in self.map:
+            bisect.insort(self.keys, k)
+        self.map[k] = v
+
+    def remove(self, k: bytes) -> None:
+        if k in self.map:
+            del self.map[k]
+            del self.keys[bisect.bisect_left(self.keys, k)]
+
+    def range(self, lo: Optional[bytes], hi: Optional[bytes], hi_inclusive: bool):
+        """Lazy, in key order; lo inclusive.  (Snapshot of the key list: callers here never
+        mutate while iterating forward.)"""
+        i = 0 if lo is None else bisect.bisect_left(self.keys, lo)
+        while i < len(self.keys):
+            k = self.keys[i]
+            if hi is not None and (k > hi or (k == hi and not hi_inclusive)):
+                return
+            yield k, self.map[k]
+            i += 1
+
+
+class Chain:
+    """chain.rs:99-254 over `Sled`."""
+
+    def __init__(self, db: Optional[Sled] = None, separate_commit_key: bool = False):
+        # Chain::new, chain.rs:117-137.  `separate_commit_key` = JG_CFG_SEPARATE_COMMIT_KEY: the
+        # engine option that keeps the "commit" key out of the block keyspace (no Q9)
+        self.separate_commit_key = separate_commit_key
+        self.db: Sled = Sled() if db is None else db           # sled::open(path)
         raw = self.db.get(COMMIT_KEY)                          # :119-123
         commit = int.from_bytes(raw, "big") if raw is not None else 0
         self.id_gen = commit                                   # :127
@@ -69,29 +109,29 @@ class Chain:
         id_ = self._next_id()
         if id_ != 0:
             raise Panic("chain.rs:141 assert_eq!(id, 0)")
-        self.db[block_key(id_)] = Block(id_, id_)
+        self.db.insert(block_key(id_), Block(id_, id_))
 
     def has(self, block_id: int) -> bool:                      # chain.rs:155-157
-        return block_key(block_id) in self.db
+        return self.db.contains_key(block_key(block_id))
 
     def append(self) -> int:                                   # chain.rs:160-175
         id_ = self._next_id()
         if not id_ > self.head:
             raise Panic("chain.rs:163 assert!(id > self.head)")
         block = Block(id_, self.head)
-        self.db[block_key(block.id)] = block
+        self.db.insert(block_key(block.id), block)
         self.head = block.id
         return block.id
 
     def extend(self, block: Block) -> None:                    # chain.rs:178-192
         if not self.has(block.next):
             raise Panic("chain.rs:180-185 Err(block not found in chain)")
-        self.db[block_key(block.id)] = Block(block.id, block.next)
+        self.db.insert(block_key(block.id), Block(block.id, block.next))
         self.head = block.id
 
     def commit_to(self, block_id: int) -> int:                 # Chain::commit, chain.rs:195-205
-        if block_key(block_id) in self.db:
-            self.db[COMMIT_KEY] = block_key(block_id)
+        if self.db.contains_key(block_key(block_id)):
+            self.db.insert(COMMIT_KEY, block_key(block_id))
             self.commit = block_id
         else:
             raise Panic('chain.rs:201 panic!("")')
@@ -103,13 +143,10 @@ class Chain:
         8-byte value) panics when it is reached (chain.rs:219-226), not before."""
         lo_k = block_key(lo) if lo is not None else None
         hi_k = block_key(hi) if hi is not None else None
-        for k in sorted(self.db):
-            if lo_k is not None and k < lo_k:
-                continue
-            if hi_k is not None and (k > hi_k or (k == hi_k and not hi_inclusive)):
-                continue
-            v = self.db[k]
+        for _k, v in self.db.range(lo_k, hi_k, hi_inclusive):
             if not isinstance(v, Block):
+                if self.separate_commit_key:
+                    continue
                 raise Panic("chain.rs:219-226 couldn't deserialize (range ran into the commit key)")
             yield v
 
@@ -117,7 +154,7 @@ class Chain:
         next_id = None
         for b in reversed(list(self.range(0, self.commit))):   # range(0..commit).rev()
             if next_id is not None and b.id != next_id:
-                del self.db[block_key(b.id)]
+                self.db.remove(block_key(b.id))
             next_id = b.next
 
 
@@ -276,12 +313,13 @@ class Leader:  # leader.rs:23-30
 
 class Raft:
     """Raft<T> (mod.rs:326-341) with the role object swapped in place where the Rust moves `self`
-    through a `From` impl.  `rpc` / `fsm` are the two channels (mod.rs:337-340); `trace` receives
-    harness annotations (queue bookkeeping and range bounds) that the Rust does not put on a
-    channel but that the engine's row vocabulary spells out."""
+    through a `From` impl.  `rpc` / `fsm` are the two channels (mod.rs:337-340).  They also carry
+    harness markers (queue bookkeeping, range bounds) for things the Rust does not put on a
+    channel but the engine's row vocabulary spells out; the markers change nothing."""
 
     def __init__(self, id_: int, nodes: List[int], heartbeat_timeout: int, min_to: int, max_to: int,
-                 rand_range: Callable[[int, int], int], db: Optional[Dict[bytes, object]] = None, now: int = 0):
+                 rand_range: Callable[[int, int], int], db: Optional[Sled] = None, now: int = 0,
+                 separate_commit_key: bool = False):
         # Raft::<Follower>::new, follower.rs:68-95
         self.id = id_
         self.nodes = list(nodes)          # config.nodes: the OTHER nodes, in configuration order
@@ -290,10 +328,9 @@ class Raft:
         self.now = now
         self.state = State(min_election_timeout=min_to, max_election_timeout=max_to)
         self.role = Follower()
-        self.chain = Chain(db)
-        self.rpc: List[Message] = []
-        self.fsm: List[tuple] = []
-        self.trace: List[tuple] = []
+        self.chain = Chain(db, separate_commit_key)
+        self.rpc: list = []               # Message objects, in emission order (+ harness queue markers)
+        self.fsm: List[tuple] = []        # ("Apply", block_id) / ("Notify", req_id, block_id) (+ "Range" markers)
         self.decisions = 0                # Leader::commit + election_status-on-vote evaluations (bench metric)
         self.set_election_timeout()       # init(), follower.rs:93-95
 
@@ -388,7 +425,7 @@ class Raft:
         if has_committed and commit > self.chain.commit:                         # :201
             prev = self.chain.commit
             self.chain.commit_to(commit)                                         # :203
-            self.trace.append(("apply_follower", prev, commit))
+            self.fsm.append(("Range", "follower", prev, commit))             # (harness marker: range(prev..commit))
             for block in self.chain.range(prev, commit):                         # :204 range(prev..commit)
                 self.fsm.append(("Apply", block.id))
         self.send(("Peer", leader_id),                                           # :209-215
@@ -414,7 +451,7 @@ class Raft:
             self.send(("Peer", self.role.leader_id), Command("ClientRequest", req_id=req_id))
         else:
             self.role.queued_reqs.append(req_id)
-            self.trace.append(("queue_push", req_id))
+            self.rpc.append(("queue_push", req_id))                               # (harness marker)
 
     def follower_apply_client_response(self, req_id: int) -> None:               # follower.rs:272-282
         self.send(("Client", 0), Command("ClientResponse", req_id=req_id))
@@ -423,7 +460,7 @@ class Raft:
         node_ids = list(self.nodes)
         node_ids.append(self.id)
         if self.role.queued_reqs:
-            self.trace.append(("queue_drop", len(self.role.queued_reqs)))        # queued_reqs: Vec::new() (:295)
+            self.rpc.append(("queue_drop", len(self.role.queued_reqs)))          # queued_reqs: Vec::new() (:295)
         self.role = Candidate(election=Election(node_ids), queued_reqs=[])
 
     # -- candidate.rs ---------------------------------------------------------------------
@@ -451,7 +488,7 @@ class Raft:
             self.candidate_apply_heartbeat(cmd.term, cmd.leader_id, cmd.commit)
         elif k == "ClientRequest":
             self.role.queued_reqs.append(cmd.req_id)                             # :190-193
-            self.trace.append(("queue_push", cmd.req_id))
+            self.rpc.append(("queue_push", cmd.req_id))                          # (harness marker)
 
     def candidate_apply_tick(self) -> None:                                      # candidate.rs:48-68
         if self.needs_election():
@@ -507,7 +544,7 @@ class Raft:
         nodes = list(self.nodes)
         nodes.append(self.id)
         if self.role.queued_reqs:
-            self.trace.append(("queue_drop", len(self.role.queued_reqs)))        # Leader has no queue
+            self.rpc.append(("queue_drop", len(self.role.queued_reqs)))          # Leader has no queue
         self.role = Leader(progress=ReplicationProgress(nodes), heartbeat_time=self.now,
                            heartbeat_timeout=self.heartbeat_timeout)
 
@@ -525,7 +562,7 @@ class Raft:
         if quorum_idx > self.chain.commit:
             prev = self.chain.commit
             new = self.chain.commit_to(quorum_idx)
-            self.trace.append(("apply_leader", prev, new))
+            self.fsm.append(("Range", "leader", prev, new))                  # (harness marker: range(prev..=new).skip(1))
             first = True
             for block in self.chain.range(prev, new, hi_inclusive=True):         # range(prev..=new).skip(1)
                 if first:

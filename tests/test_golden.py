@@ -1,6 +1,6 @@
-"""Committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py):
-the oracle must still reproduce them (CPU), and the HIP engine must match the committed
-bytes (-m gpu)."""
+"""Committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from
+tests/ref_py, the second restatement of the reference): the C++ oracle and ref_py must reproduce
+them (CPU), and the HIP engine must match the committed bytes (-m gpu)."""
 import hashlib
 import os
 
@@ -9,14 +9,22 @@ import pytest
 
 from josefine_amd import BatchedRaft
 from oracle_lib import oracle_engine
-from parity import elect_all, synth_tick_host
+from josefine_amd.traces import synth_fill_acks_host
+from parity import elect_all
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-BACKENDS = ["oracle", pytest.param("hip", marks=pytest.mark.gpu)]
+BACKENDS = ["oracle", "ref_py", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+def factory(backend):
+    if backend == "ref_py":
+        from ref_py.engine import RefEngine
+        return RefEngine
+    return oracle_engine if backend == "oracle" else BatchedRaft
 
 
 def make(backend, G, R, **kw):
-    return oracle_engine(G, R, **kw) if backend == "oracle" else BatchedRaft(G, R, **kw)
+    return factory(backend)(G, R, **kw)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -26,10 +34,9 @@ def test_dense_golden(backend, name):
     G, R, mode, ticks, every = (int(z[k]) for k in ("G", "R", "mode", "ticks", "every"))
     e = make(backend, G, R, seed=int(z["seed"]))
     elect_all(e)
-    gen = oracle_engine(G, R, seed=int(z["seed"]))  # host restatement of the ack generator only
     sim = np.zeros((R, G), dtype=np.uint64)
     for t in range(ticks):
-        e.step_dense_acks(synth_tick_host(gen, mode, t, sim))
+        e.step_dense_acks(synth_fill_acks_host(int(z["seed"]), mode, t, 0, np.zeros(G, np.uint8), sim, R))
         if (t + 1) % every == 0:
             assert np.array_equal(e.read("commit"), z[f"commit_{t+1}"]), t
             assert np.array_equal(e.read("head"), z[f"head_{t+1}"]), t
@@ -100,8 +107,7 @@ def test_node_tick_golden(backend):
 
     z = np.load(os.path.join(HERE, "node_r3.npz"))
     G, R, rounds, ticks = int(z["G"]), int(z["R"]), int(z["rounds"]), int(z["ticks"])
-    factory = oracle_engine if backend == "oracle" else BatchedRaft
-    cl = DenseCluster(factory, G, R, seed=5)
+    cl = DenseCluster(factory(backend), G, R, seed=5)
     h = hashlib.sha256()
     for t in range(rounds):
         outs = cl.round(z[f"appends_{t}"])

@@ -7,8 +7,8 @@ drained rpc / fsm output).  Part 2 holds the hand-derived vectors of SURVEY.md
 §8(c) for what the reference leaves untested (every multi-replica result —
 "parity unpinned" by the reference).
 
-Every test runs against the CPU oracle (always) and against the HIP engine
-through the C ABI (`-m gpu`).
+Every test runs against the CPU oracle and against the second, independent restatement
+tests/ref_py (always), and against the HIP engine through the C ABI (`-m gpu`).
 """
 import numpy as np
 import pytest
@@ -16,12 +16,15 @@ import pytest
 from josefine_amd import BatchedRaft, Command, EngineError, capi
 from oracle_lib import oracle_engine
 
-BACKENDS = ["oracle", pytest.param("hip", marks=pytest.mark.gpu)]
+BACKENDS = ["oracle", "ref_py", pytest.param("hip", marks=pytest.mark.gpu)]
 
 
 @pytest.fixture(params=BACKENDS)
 def make(request):
     def _make(G=1, R=1, **kw):
+        if request.param == "ref_py":
+            from ref_py.engine import RefEngine
+            return RefEngine(G, R, **kw)
         return oracle_engine(G, R, **kw) if request.param == "oracle" else BatchedRaft(G, R, **kw)
 
     return _make
