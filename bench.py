@@ -67,29 +67,67 @@ def cpu_baseline(R: int, seed: int, budget_s: float):
         dt += time.perf_counter() - t0
         done += 1
     dec = ora.counters()["decisions"] - d0
-    # the same stream on all host cores (groups block-partitioned over std::thread), a third
-    # of the ticks
+    # The same stream on all host cores: one persistent Python thread per core (ctypes releases the
+    # GIL for the whole tick), each with a PRIVATE engine over its own 10 k groups - Raft groups are
+    # independent, so the threads never meet: no per-tick barrier, no thread creation in the timed
+    # region.  Every thread applies the same number of ticks; the clock is the slowest thread's.
     cores = os.cpu_count() or 1
     mt = None
     if cores > 1:
-        ora2 = oracle_engine(Gs, R, seed=seed)
-        elect_all(ora2)
-        ora2.api.set_threads(ora2._h, cores)
-        sim2 = np.zeros((R, Gs), dtype=np.uint64)
-        dt2 = 0.0
-        n2 = max(1, done // 3)
-        for t in range(n2):
-            acks = synth_tick_host(ora2, 0, t, sim2)
-            t1 = time.perf_counter()
-            ora2.step_dense_acks(acks)
-            dt2 += time.perf_counter() - t1
-        mt = (ora2.counters()["decisions"] - d0) / dt2
-    return {
+        import threading
+        Gt = 10_000
+        Tt = max(4, min(40, int(4.0 * (dec / dt) / (Gt * R))))  # ~4 s per thread at single-core speed
+        start = threading.Barrier(cores + 1)
+        res = [None] * cores
+
+        def worker(i):
+            e = oracle_engine(Gt, R, seed=seed, group_base=i * Gt)
+            elect_all(e)
+            acks = np.zeros((R, Gt), dtype=np.uint64)
+            acks[0] = 1
+            d_0 = e.counters()["decisions"]
+            start.wait()
+            t_0 = time.perf_counter()
+            for t in range(Tt):  # mode 0 closed form: one append, every follower acks the previous head
+                acks[1:] = t
+                e.step_dense_acks(acks)
+            res[i] = (time.perf_counter() - t_0, e.counters()["decisions"] - d_0)
+
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
+        for t in th:
+            t.start()
+        start.wait()
+        for t in th:
+            t.join()
+        slowest = max(r[0] for r in res)
+        mt = sum(r[1] for r in res) / slowest
+    out = {
         "value": dec / dt, "unit": "decisions/s", "cores": 1, "kind": "port",
         "sample": f"{Gs} groups x {R} replicas x {done} ticks of the same steady-state stream, "
                   f"C++ oracle (Rust reference not buildable here: no cargo)",
         "all_cores_value": mt, "all_cores": cores,
     }
+    if mt:
+        out["all_cores_sample"] = f"{cores} threads x private engine of {Gt} groups x {R} replicas x {Tt} ticks"
+        out["all_cores_scaling_efficiency"] = mt / (cores * dec / dt)
+    return out
+
+
+def workload_name(G: int, R: int, mode: int, failures: int) -> str:
+    """Which BASELINE.json config this run is (or which one it is a GPU's share of)."""
+    if failures:
+        tag = f"BASELINE.json configs[4]: {failures} %/tick leader failures + re-elections" + \
+              ("" if (G, R) == (1_000_000, 5) else " at another size")
+    elif mode == 1:
+        tag = "BASELINE.json configs[1]: ragged AppendEntries-ack stream (drops, duplicates, 0-2 appends)" + \
+              ("" if (G, R) == (10_000, 3) else " at another size")
+    elif (G, R) == (1_000_000, 5):
+        tag = "BASELINE.json configs[2]: steady-state append+commit"
+    elif (G, R) == (1_250_000, 3):
+        tag = "one GPU's share of BASELINE.json configs[3] (10 M x 3 over 8 GPUs): steady-state append+commit"
+    else:
+        tag = "steady-state append+commit at a non-BASELINE size"
+    return f"{G} partitions x {R} replicas per GPU, {tag}; device-resident synthetic ack stream, mode {mode}"
 
 
 def node_alg_bytes(R: int):
@@ -230,6 +268,70 @@ def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
         dist.destroy_process_group()
 
 
+def single_process_main(args):
+    """--single-process: ONE process, ONE engine handle, N shards (jg_config.n_devices /
+    device_ids) - the shape a josefine process driving N GPUs has (one event loop owns the handle,
+    src/raft/server.rs:103-165).  Same workload per GPU as the process-per-GPU mode, same JSON line;
+    every shard's ack stream lives in its own device's memory and a step is one
+    jg_step_dense_acks_shards call (one launch per shard, each from the shard's host thread)."""
+    import numpy as np
+    import torch  # noqa: F401  (first: the engine library then resolves against the same HIP runtime)
+    from josefine_amd import BatchedRaft
+    from josefine_amd.traces import elect_all
+
+    N, G, R, K, W = args.gpus, args.groups, args.replicas, args.steps, args.warmup
+    devs = [0] * N if args.alias_devices else list(range(N))
+    eng = BatchedRaft(G * N, R, seed=args.seed, device_ids=devs)
+    assert eng.n_shards == N
+    elect_all(eng)
+    eng.drain_messages(), eng.drain_applies()
+    api = eng.api
+    shards = [eng.shard(d) for d in range(N)]
+    tick_bytes = R * G * 8
+    bufs = []
+    for sh in shards:  # the whole stream resident in each device's HBM before the timed region
+        sim, buf = sh.alloc(tick_bytes), sh.alloc(tick_bytes * (W + K))
+        for t in range(W + K):
+            sh._check(api.synth_fill_acks_device(sh._h, args.mode, t, sim, C.c_void_p(buf.value + t * tick_bytes)))
+        bufs.append(buf)
+    eng._check(api.sync(eng._h))
+    ptrs = [(C.c_void_p * N)(*[C.c_void_p(b.value + t * tick_bytes) for b in bufs]) for t in range(W + K)]
+    for t in range(W):
+        eng._check(api.step_dense_acks_shards(eng._h, ptrs[t], 1))
+    eng._check(api.sync(eng._h))
+    c0 = eng.counters()
+    t0 = time.perf_counter()
+    eng._check(api.timer_start(eng._h))
+    for t in range(W, W + K):
+        eng._check(api.step_dense_acks_shards(eng._h, ptrs[t], 1))
+    ev_ms = C.c_float(0)
+    eng._check(api.timer_stop(eng._h, C.byref(ev_ms)))  # the slowest shard's stream
+    wall = time.perf_counter() - t0
+    decisions = eng.counters()["decisions"] - c0["decisions"]
+    if args.mode == 0:
+        head, commit, fault = eng.read("head"), eng.read("commit"), eng.read("fault")
+        assert (head == W + K).all() and (commit == W + K - 1).all() and not fault.any(), "steady-state closed form violated"
+    launch_s = ev_ms.value / 1e3 / K
+    alg = alg_bytes_per_group_step(R) * G
+    achieved = alg / launch_s / 1e9
+    out = {
+        "metric": "Raft quorum decisions/sec over N partitions; achieved HBM GB/s vs roofline",
+        "value": decisions / wall, "unit": "decisions/s", "n_gpus": N, "steps": K, "warmup": W,
+        "ms_per_step": wall * 1e3 / K, "ms_per_step_events": ev_ms.value / K, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": workload_name(G, R, args.mode, 0), "partitions_per_gpu": G, "replicas": R,
+                   "partitions_total": G * N,
+                   "parallelism": f"1 process, 1 engine handle, {N} shard(s) on devices {devs} (jg_config.n_devices), no collective"},
+        "group_steps_per_s": G * N * K / wall,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": f"k_leader_tick_dense<{R}> (per shard; the slowest shard's stream)",
+                     "alg_bytes_per_launch": alg, "avg_launch_us": launch_s * 1e6, "frac_of_measured_copy": achieved / 6290.0},
+    }
+    if not args.no_cpu_baseline and N == 1:
+        out["cpu_baseline"] = cpu_baseline(R, args.seed, args.cpu_budget)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,10 +348,17 @@ def main():
     ap.add_argument("--cluster", action="store_true",
                     help="closed loop: all R replicas of every partition on this GPU as R engines exchanging dense "
                          "mailbox columns (jg_step_dense_leader / jg_step_dense_follower); secondary measurement")
+    ap.add_argument("--single-process", action="store_true",
+                    help="one process, one engine handle over --gpus shards (jg_config.n_devices) instead of one "
+                         "process per GPU; run it directly, not under torch.distributed.run")
+    ap.add_argument("--alias-devices", action="store_true",
+                    help="with --single-process: put every shard on device 0 (exercises the multi-device path on a 1-GPU box)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x6A6F736566696E65)
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.single_process:
+        return single_process_main(args)
 
     import torch  # first: the engine library then resolves against the same HIP runtime
     import torch.distributed as dist
@@ -323,13 +432,32 @@ def main():
                 eng._check(api.step_dense_acks_device_n(h, ptr, n))
             if fail_rows is not None and fail_rows[t].n:
                 eng.step_device_rows(fail_rows[t], now_ms=100 * (t + 1))
-                if t % 16 == 15:  # the host consumes the outbound messages as it goes (pinned views)
-                    eng.drain_messages(copy=False), eng.drain_applies(copy=False), eng.drain_faults()
+                if t % 16 == 15:
+                    # the host consumes the outbound messages as it goes (pinned views): the batch
+                    # whose transfer was started 16 ticks ago, then the next transfer is started
+                    # (jg_drain_prefetch) - PCIe and host time overlap the device time of the next ticks
+                    eng.drain_wait()   # back-pressure: never more than one batch ahead of our own output
+                    consume()
+                    eng.drain_prefetch()
             t += n
             n_launch += 1
+        if fail_rows is not None:  # everything stepped is delivered before the clock stops
+            eng.drain_flush()
+            consume()
         return n_launch
 
+    drained = {"messages": 0, "applies": 0, "faults": 0}
+
+    def consume():
+        drained["messages"] += len(eng.drain_messages(copy=False))
+        drained["applies"] += len(eng.drain_applies(copy=False))
+        drained["faults"] += len(eng.drain_faults())
+
     run_ticks(0, W)
+    if fail_rows is not None:  # one more full drain cycle outside the timed region (pinned queues at their working size)
+        eng.drain_flush()
+        consume()
+        eng._check(api.kernel_timing(h, 1))
     barrier()
     c0 = eng.counters()
     barrier()
@@ -402,7 +530,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(f"G{G}_R{R}_mode{args.mode}" + ("" if T == 1 else f"_T{T}"))
+                traffic = json.load(f).get(f"G{G}_R{R}_mode{args.mode}" + ("" if T == 1 else f"_T{T}")
+                                           + (f"_failures{args.failures}" if args.failures else ""))
         out = {
             "metric": "Raft quorum decisions/sec over N partitions; achieved HBM GB/s vs roofline",
             "value": decisions_all / wall,
@@ -411,15 +540,14 @@ def main():
             "steps": K,
             "warmup": W,
             "ms_per_step": wall * 1e3 / K,
+            "ms_per_step_events": ev_max_ms / K,  # the same K steps by HIP events on the engine's stream (max over ranks)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": f"{G} partitions x {R} replicas per GPU, steady-state append+commit "
-                            f"(BASELINE.json configs[2]); device-resident synthetic AppendEntries-ack stream, mode {args.mode}"
-                            + (f"; {args.failures} %/tick leader failures + re-elections (configs[4])" if args.failures else ""),
+                "workload": workload_name(G, R, args.mode, args.failures),
                 "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world,
                 "parallelism": f"{world} independent shard(s), no collective",
             },
@@ -430,6 +558,7 @@ def main():
                 "kernel": f"k_leader_tick_dense<{R}>" if T == 1 else f"k_leader_tick_dense_n<{R}> (T={T} ticks/launch)",
                 "alg_bytes_per_launch": alg, "ticks_per_launch": ticks_per_launch,
                 "avg_launch_us": launch_s * 1e6, "peak_basis": "8.0 TB/s spec (6.29 TB/s measured copy)",
+                "frac_of_measured_copy": achieved / 6290.0,
                 "alg_bytes_per_group_step": alg_bytes_per_group_step(R),
                 # the same launch priced with SURVEY.md's B(R) = 24R + 36 (8-byte absolute progress heads
                 # read and written every tick); > 1 possible: the engine stores them delta-packed
@@ -449,9 +578,23 @@ def main():
                 "unit": "GB/s", "kernel_vs_ceiling": cal_us.value / (launch_s * 1e6)}
         if args.failures:
             # several kernels per tick (dense + deferred-group replay + k_apply_rows) and host
-            # drains inside the timed region: the event time is the whole tick, not one kernel
-            out["roofline"] = None
+            # drains inside the timed region: the stream's event time is the whole tick; the
+            # dominant kernel is priced with its own event pairs (jg_kernel_timing: the last 256
+            # launches of k_leader_tick_dense, ~half of the groups dead by then)
+            k_us, k_n = C.c_float(0), C.c_uint32(0)
+            eng._check(api.kernel_timing_read(h, C.byref(k_us), C.byref(k_n)))
+            alg1 = alg_bytes_per_group_step(R) * G
+            ach = alg1 / (k_us.value * 1e-6) / 1e9 if k_us.value else 0.0
+            out["roofline"] = {
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel": f"k_leader_tick_dense<{R}> under failures (dead / deferred groups in every wave)",
+                "alg_bytes_per_launch": alg1, "avg_launch_us": k_us.value, "launches_timed": k_n.value,
+                "frac_of_measured_copy": ach / 6290.0,
+                "note": "every group's bytes are priced, dead or not: the kernel loads them before it can know; launches "
+                        "that overlap the pipelined drain's PCIe gathers run ~4x slower than the 13.8 us the same kernel "
+                        "takes alone (profiles/r02/kernel_stats_failures_1pct.csv)"}
             out["tick_us"] = launch_s * 1e6
+            out["rows_delivered_to_host"] = drained
         if batched is not None:
             out["batched_ticks"] = batched
         if not args.no_cpu_baseline and world == 1:

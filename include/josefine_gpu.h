@@ -415,11 +415,32 @@ int jg_drain_messages(jg_engine* e, jg_msg_row* out, size_t cap, size_t* n);
 int jg_drain_applies(jg_engine* e, jg_fsm_row* out, size_t cap, size_t* n);
 int jg_drain_faults(jg_engine* e, jg_fault_row* out, size_t cap, size_t* n);
 /* Zero-copy drains: *rows points at the engine's pinned host queue (filled by one
- * asynchronous device-to-host copy), valid until the engine's next synchronising call
- * (step results are not affected: the rows count as drained).  What a Rust adapter
- * iterates to re-emit on rpc_tx / fsm_tx without an intermediate Vec. */
+ * asynchronous device-to-host copy), valid until the next drain call on the SAME queue
+ * (drains of the other queues, faults, steps and reads in between leave them alone; step
+ * results are not affected: the rows count as drained).  What a Rust adapter iterates to
+ * re-emit on rpc_tx / fsm_tx without an intermediate Vec. */
 int jg_drain_messages_view(jg_engine* e, const jg_msg_row** rows, size_t* n);
 int jg_drain_applies_view(jg_engine* e, const jg_fsm_row** rows, size_t* n);
+
+/* Pipelined drains.  jg_drain_prefetch marks a point in the step stream and starts, without
+ * blocking, the compaction and the transfer to the host queues of every row that steps before
+ * the point have produced — on a second HIP stream behind an event, driven by the engine's own
+ * drain thread, while the caller keeps stepping.  From the first call on the engine is PIPELINED:
+ *   - jg_drain_prefetch never blocks: while a batch is still in transfer it starts nothing (the
+ *     next call covers more steps);
+ *   - the jg_drain_* calls never block and never synchronise with the step stream: they deliver the
+ *     rows of the batches that have landed (same order as ever: steps in order, groups ascending
+ *     within a step), possibly none;
+ *   - jg_drain_wait blocks until the batch in transfer (if any) has landed - the back-pressure of a
+ *     caller that does not want to run more than one batch ahead of its own output;
+ *   - jg_drain_flush blocks until everything stepped so far has landed (then drain).
+ * The pattern for a caller that forwards messages every N ticks (what server::event_loop does with
+ * rpc_tx for one group, src/raft/server.rs:125-159):
+ *     every N ticks: jg_drain_*_view (whatever has landed) ... jg_drain_prefetch (next batch)
+ * so that PCIe time and host time of one batch overlap the device time of the following ticks. */
+int jg_drain_prefetch(jg_engine* e);
+int jg_drain_wait(jg_engine* e);
+int jg_drain_flush(jg_engine* e);
 
 /* Copy one state column for groups [g0, g0+n) to host memory (element type per
  * JG_FIELD_* above).  `replica` selects the slot for JG_FIELD_MATCH. */
@@ -450,6 +471,14 @@ int jg_timer_stop(jg_engine* e, float* ms);  /* record + synchronize + elapsed  
  *         prev_ack + U{0..MAX_INFLIGHT}), 5 % dropped, 5 % stale duplicates. */
 int jg_synth_fill_acks_device(jg_engine* e, uint32_t mode, uint64_t tick, uint64_t* sim_dev,
                               uint64_t* acks_dev);
+
+/* Measurement aid: HIP event pairs around the dense tick kernel itself (k_leader_tick_dense /
+ * _n / k_leader_node_tick — not the k_dense_slow launch that may follow it), recorded on the
+ * engine's stream for every dense step while enabled; jg_kernel_timing_read synchronises and
+ * returns the average over the most recent launches (a ring of 256).  What bench.py prices the
+ * roofline with when a step is more than one kernel (configs[4], the closed loop). */
+int jg_kernel_timing(jg_engine* e, int enable);
+int jg_kernel_timing_read(jg_engine* e, float* avg_us, uint32_t* n_launches);
 
 /* Measurement aid (bench.py "roofline.stream_ceiling"): time a plain streaming kernel with the
  * byte profile of the dense leader tick for this engine's (G, R) — per group R 8-byte reads from

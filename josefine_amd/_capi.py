@@ -173,6 +173,9 @@ class Api:
         "step_dense_acks_device_n": (C.c_int, [_P, _P, C.c_uint32]),
         "sync": (C.c_int, [_P]),
         "stream_wait": (C.c_int, [_P, _P]),
+        "drain_prefetch": (C.c_int, [_P]),
+        "drain_flush": (C.c_int, [_P]),
+        "drain_wait": (C.c_int, [_P]),
         "drain_messages_view": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
         "drain_applies_view": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
         "device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
@@ -183,6 +186,8 @@ class Api:
         "timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
         "synth_fill_acks_device": (C.c_int, [_P, C.c_uint32, C.c_uint64, _P, _P]),
         "calibrate_stream": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_float)]),
+        "kernel_timing": (C.c_int, [_P, C.c_int]),
+        "kernel_timing_read": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     }
     # only the oracle has these
     _ORACLE_PROTOS = {
@@ -220,7 +225,7 @@ HEADER_SYMBOLS = [
     "jg_engine_create", "jg_engine_destroy", "jg_shard_count", "jg_get_shard", "jg_step_dense_acks_shards", "jg_set_self_slots", "jg_submit", "jg_step", "jg_step_device_rows",
     "jg_step_dense_acks", "jg_step_dense_acks_device", "jg_step_dense_acks_device_n",
     "jg_step_dense_leader", "jg_step_dense_follower", "jg_chain_compact", "jg_sync", "jg_stream_wait",
-    "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_read_state", "jg_get_counters",
+    "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_drain_prefetch", "jg_drain_flush", "jg_drain_wait", "jg_read_state", "jg_get_counters",
     "jg_device_alloc", "jg_device_free", "jg_device_upload", "jg_device_download",
-    "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_last_error", "jg_abi_version",
+    "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",
 ]

@@ -22,7 +22,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -> josefine_amd/csrc/libjosefine_gpu.so"""
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wall",
            "-Wno-unused-function", "-o", LIB, os.path.join(CSRC, "josefine_gpu.hip")]
     if os.environ.get("JG_BLOCK"):  # workgroup-size experiments (profiles/README.md); default 256
         cmd.insert(1, "-DJG_BLOCK=" + os.environ["JG_BLOCK"])

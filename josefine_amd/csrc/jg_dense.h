@@ -500,23 +500,21 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
 #pragma unroll                        // path loaded it into (no second trip to HBM per rolled iteration)
   for (int r = 0; r < R; r++) sa[r][t] = ((uint32_t)r == s || !acks) ? JG_NO_ACK : a_in[r];
   // packed lags -> absolute progress heads (escaped fields: the wide column)
-  uint64_t hi_old = 0, hi_ack = 0;
+  uint64_t hi = 0;
 #pragma clang loop unroll(disable)
   for (int r = 0; r < R; r++) {
     const uint64_t fl = (w0 >> (r * B)) & esc;
     const uint64_t v = jg_lag_wide(fl, R) ? d.match_wide[(size_t)r * G + g] : head0 - fl;
     sm[r][t] = v;
-    hi_old = v > hi_old ? v : hi_old;
+    hi = v > hi ? v : hi;
     const uint64_t a = sa[r][t];
-    hi_ack = (a != JG_NO_ACK && a > hi_ack) ? a : hi_ack;
+    hi = (a != JG_NO_ACK && a > hi) ? a : hi;
   }
   const uint64_t fc = (w0 >> (R * B)) & esc;
   const uint64_t commit0 = jg_lag_wide(fc, R) ? d.commit[g] : head0 - fc;
   uint64_t commit = commit0, head = head0;
   uint32_t nf = f, fault = 0, dc = 0;
-  // no chain.commit panic possible: one majority evaluation.  (Old heads at or below the head, acks
-  // at or below the head they meet - the appends are applied first.)
-  const bool fused = hi_old <= head0 && hi_ack <= head0 + n_app;
+  const bool fused = hi <= head0;  // no chain.commit panic possible: one majority evaluation
   // appends with their self-acks (leader.rs:177-197); replayed one at a time unless fused
   if (fused) {
     head = head0 + n_app;
@@ -585,11 +583,13 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
   if (nf != f) d.flags[g] = nf;
 }
 
-template <int R, bool UNIFORM, bool NODE>
+// DEFER: the host has k_dense_slow scheduled behind this launch: everything that is not served in
+// lag space goes there.  A compile-time switch on purpose: as a run-time flag it cost the hot path
+// of the 1 M x 5 launch 0.5 us (the compiler prepared general-path operands ahead of the branch).
+template <int R, bool UNIFORM, bool NODE, bool DEFER>
 __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev* dp,
                                                const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us, const JgLeaderNode& nd, bool emit, uint32_t g,
-                                               const JgDenseIn<R>& in, JgDecCount& dec, uint64_t (*sm)[JG_BLOCK],
-                                               bool defer_cold) {
+                                               const JgDenseIn<R>& in, JgDecCount& dec, uint64_t (*sm)[JG_BLOCK]) {
   const uint32_t f = in.f;
   const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
   const uint64_t mword0 = in.w, head0 = in.head, term = in.term, hbt = in.hbt;
@@ -610,25 +610,14 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   bool hot = (f & (JGF_FAULT_MASK | JGF_ROLE_MASK | JGF_FAST)) == (JG_ROLE_LEADER | JGF_FAST);
   if (NODE) hot = hot && !hbr_trigger;
   hot = jg_lag_tick<R>(s, f, mword0, head0, n_app, in.a, lt, dl) && hot;
-#ifndef JG_EXP_NOCOUNT
   jg_count_step(h.blk_decisions, dec, hot, dl);
-#endif
-#ifdef JG_EXP_FULLWAVE
-  // the head column is stored by every lane of a wave that has a hot lane with a new head: the
-  // lanes that are not hot write back the value they read (dead groups, non-leaders, deferred
-  // groups; a lane that goes on to the general path stores again behind this, in program order)
-  const bool wave_head = __ballot(hot && lt.head1 != head0) != 0;
-  if (wave_head) h.head[g] = hot ? lt.head1 : head0;
-#endif
   if (__builtin_expect(hot, 1)) {
     if (emit)  // Command::Tick into the outbox; may raise the Q9 fault
       lt.nf = jg_dense_leader_tick<R>(h, dp, nd, g, seq, s, term, hbt, lt.head1, lt.head1 - lt.l[R], lt.nf, [&](int r) {
         return lt.l[r] == 0xffffffffu ? dp->match_wide[(size_t)r * h.G + g] : lt.head1 - lt.l[r];  // BEHIND: wide column
       });
     if (lt.w1 != mword0) h.mlag[g] = lt.w1;
-#if !defined(JG_EXP_FULLWAVE) && !defined(JG_EXP_NOSTORE)
     if (lt.head1 != head0) h.head[g] = lt.head1;
-#endif
     if (lt.nf != f) h.flags[g] = lt.nf;
     return;
   }
@@ -641,15 +630,15 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   // behind a node tick and runs HeartbeatResponses, appends, acks and the Tick of these groups
   // through the general state machine (columns for a FAST chain, rows otherwise)
   // the ack-only kernel does the same whenever the host has k_dense_slow scheduled behind it anyway
-  // (`defer_cold`): ONE lane of a wave on the rolled LDS path below keeps the whole wave for several
+  // (DEFER): ONE lane of a wave on the rolled LDS path below keeps the whole wave for several
   // microseconds (1 % of the groups there tripled the launch: profiles/README.md round 2)
-  if ((NODE || defer_cold) && cls == JG_DENSE_RUN) cls = JG_DENSE_DEFER;
+  if ((NODE || DEFER) && cls == JG_DENSE_RUN) cls = JG_DENSE_DEFER;
   jg_defer_mark(d, g, cls == JG_DENSE_DEFER);
   if (NODE) {
     if (emit) jg_dense_outbox_none<R>(h.G, nd, g);
     return;
   }
-  if (cls != JG_DENSE_RUN) return;
+  if (DEFER || cls != JG_DENSE_RUN) return;
   // the ack-only kernel: rolled loops over LDS, so that the kernel's register allocation
   // (= its occupancy) is the hot path's
   *d.cold_seen = 1;  // read back at the next synchronisation point: the host then schedules k_dense_slow
@@ -658,11 +647,10 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
 
 // Grid-stride loop over the groups (a software prefetch of the next group's loads measured no gain
 // and cost 13 VGPRs: profiles/README.md).
-template <int R, bool UNIFORM, bool NODE>
+template <int R, bool UNIFORM, bool NODE, bool DEFER>
 __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, const JgDev* dp,
                                                        const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us,
-                                                       const JgLeaderNode& nd, uint64_t (*sm)[JG_BLOCK],
-                                                       bool defer_cold) {
+                                                       const JgLeaderNode& nd, uint64_t (*sm)[JG_BLOCK]) {
   const uint32_t G = h.G, stride = gridDim.x * JG_BLOCK;
   const bool emit = NODE && nd.o_term != nullptr;
   JgDecCount dec;
@@ -670,20 +658,21 @@ __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, co
   for (; g < G; g += stride) {
     JgDenseIn<R> in;
     jg_dense_issue<R, UNIFORM, NODE>(h, dp, acks, us, nd, emit, g, in);
-    jg_dense_group<R, UNIFORM, NODE>(h, dp, acks, seq, us, nd, emit, g, in, dec, sm, defer_cold);
+    jg_dense_group<R, UNIFORM, NODE, DEFER>(h, dp, acks, seq, us, nd, emit, g, in, dec, sm);
   }
   return dec;
 }
 
-template <int R>
+template <int R, bool DEFER>
 __global__ __launch_bounds__(JG_BLOCK) void k_leader_tick_dense(JgDenseHot h, const JgDev* __restrict__ dp,
                                                                                const uint64_t* __restrict__ acks,
-                                                                               uint32_t seq, int us, int defer_cold) {
-  __shared__ uint64_t sm[2 * R][JG_BLOCK];  // progress heads + acks of the (rare) groups on the general path
+                                                                               uint32_t seq, int us) {
+  // progress heads + acks of the (rare) groups on the general path (none of it in the DEFER build)
+  __shared__ uint64_t sm[DEFER ? 1 : 2 * R][JG_BLOCK];
   JgDecCount dec;
   JgLeaderNode nd{};
-  if (us >= 0) dec = jg_dense_tick_body<R, true, false>(h, dp, acks, seq, (uint32_t)us, nd, sm, defer_cold != 0);
-  else dec = jg_dense_tick_body<R, false, false>(h, dp, acks, seq, 0, nd, sm, defer_cold != 0);
+  if (us >= 0) dec = jg_dense_tick_body<R, true, false, DEFER>(h, dp, acks, seq, (uint32_t)us, nd, sm);
+  else dec = jg_dense_tick_body<R, false, false, DEFER>(h, dp, acks, seq, 0, nd, sm);
   jg_wave_count(h.blk_decisions, dec);
 }
 
@@ -693,8 +682,8 @@ __global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDenseHot h, con
                                                                 const uint64_t* __restrict__ acks, uint32_t seq, int us,
                                                                 JgLeaderNode nd) {
   JgDecCount dec;
-  if (us >= 0) dec = jg_dense_tick_body<R, true, true>(h, dp, acks, seq, (uint32_t)us, nd, nullptr, true);
-  else dec = jg_dense_tick_body<R, false, true>(h, dp, acks, seq, 0, nd, nullptr, true);
+  if (us >= 0) dec = jg_dense_tick_body<R, true, true, true>(h, dp, acks, seq, (uint32_t)us, nd, nullptr);
+  else dec = jg_dense_tick_body<R, false, true, true>(h, dp, acks, seq, 0, nd, nullptr);
   jg_wave_count(h.blk_decisions, dec);
 }
 

@@ -313,8 +313,17 @@ void router_merge(JgRouter& r, std::vector<Row>& out, QOf q_of, SegOf seg_of) {
   }
 }
 
+// pipelined drains (jg_drain_prefetch): the shards' batches cover the same steps, and the merge
+// needs all of them: nothing is delivered until every shard's batch has landed
+inline bool router_all_landed(jg_engine* p) {
+  for (jg_engine* e : p->router->sh)
+    if (!inflight_landed(e)) return false;
+  return true;
+}
+
 int router_collect(jg_engine* p, int release_mask) {
   JgRouter& r = *p->router;
+  if (p->pipelined && !router_all_landed(p)) return JG_OK;
   const int rc = r.run([&](size_t d) { return collect(r.sh[d], 3); });
   if (rc) return rc;
   if (release_mask & 1) r.msgs_view.clear();

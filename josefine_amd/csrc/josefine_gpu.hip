@@ -5,10 +5,16 @@
 // JG_EDEVICE.  What the host does do: validate arguments, bucket command rows by
 // group (a stable radix sort of row indices — marshalling, not Raft), move bytes,
 // and launch.
+#include <cstring>
+
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>  // plain library sort of the drained fault records
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -140,9 +146,11 @@ struct jg_engine {
   std::vector<void*> allocs;
   uint32_t count_slots = 0;  // workgroup slots of dev.blk_decisions
   uint32_t dense_grid = 0;
-  JgDev* d_dev = nullptr;  // device copy of `dev` (k_leader_tick_dense's general path)
+  JgDev* d_dev = nullptr;  // device copy of `dev` (k_leader_tick_dense's general path): d_dev2[cur_set]
+  JgDev* d_dev2[2] = {nullptr, nullptr};  // one per set of the fault / exceptional-row queues
   int uniform_self = 0;  // the own replica slot if it is the same for every group, else -1
-  // device status block {err, irregular_seen, deferred_seen, fault_q_n, xq_n}: read back with one
+  // device status block {err, irregular_seen, deferred_seen, fault_q_n, xq_n, cold_seen, fault_q_n', xq_n'}
+  // (the primed words: the second set of the fault / exceptional-row queues): read back with one
   // copy into its pinned mirror at every synchronisation point
   uint32_t* d_status = nullptr;
   uint32_t* h_status = nullptr;
@@ -156,14 +164,57 @@ struct jg_engine {
   char* stage = nullptr;
   size_t stage_cap = 0;
   bool stage_busy = false;
-  Arena arena;
+  Arena arenas[2];   // [cur_arena]: steps since the last prefetch point; the other: the batch in transfer
+  int cur_arena = 0;
   std::vector<StepRec> recs;
+  // jg_drain_prefetch: one batch of steps whose compaction + transfer to the host queues runs on
+  // `copy_stream` while the engine keeps stepping (phase 1: scan enqueued, 2: gathers enqueued)
+  struct DrainBatch {
+    std::vector<StepRec> recs;
+    int arena = 0, set = 0, phase = 0;
+    bool to_landing = false;  // rows go to l_msgs / l_fsm (from offset 0) instead of behind q_msgs / q_fsm
+    size_t at_m = 0, at_f = 0, add_m = 0, add_f = 0;
+    uint32_t nf = 0, nx = 0;
+  } inflight;
+  bool pipelined = false;  // drains deliver up to the latest prefetch point and never synchronise later steps
+  // The engine's own drain thread (created at the first jg_drain_prefetch): it waits for the scan
+  // of the batch in transfer, issues phase B the moment the totals are known - whatever the
+  // caller's thread is doing - and waits for the batch to land.
+  struct DrainThread {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    int state = 0;  // 0 idle, 1 batch posted, 2 batch landed (or failed)
+    bool quit = false;
+    int rc = 0;
+    std::string err;
+  }* drain_thread = nullptr;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_steps = nullptr, ev_scan = nullptr, ev_done = nullptr;
+  // two sets of the device-side fault / exceptional-row queues: kernels append to [cur_set] while
+  // the other one is being copied out
+  JgFaultRec* fq[2] = {nullptr, nullptr};
+  JgXqRec* xqb[2] = {nullptr, nullptr};
+  int cur_set = 0;
+  uint32_t* h_cnt = nullptr;  // pinned: {fault_q_n, xq_n} of the batch in transfer
   PinnedQueue<jg_msg_row> q_msgs;
   PinnedQueue<jg_fsm_row> q_fsm;
+  // pipelined drains: the batch in transfer lands in queues of its own (nothing is ever moved
+  // behind rows a view still covers); each is handed over - a pointer swap when the consumer has
+  // taken everything before it - at the next drain call of its kind
+  PinnedQueue<jg_msg_row> l_msgs;
+  PinnedQueue<jg_fsm_row> l_fsm;
+  bool landed_m = false, landed_f = false;
   std::vector<jg_fault_row> q_faults;
-  std::vector<JgFaultRec> fault_tmp, fault_tmp2;
+  PinnedQueue<jg_fault_row> h_faults;  // pinned landing buffers of the device queues (faults: sorted rows + steps)
+  PinnedQueue<uint32_t> h_fault_seq;
+  uint64_t *fs_k0 = nullptr, *fs_k1 = nullptr;  // device scratch of the fault sort (grow-only)
+  uint32_t *fs_v0 = nullptr, *fs_v1 = nullptr, *fs_seq = nullptr;
+  jg_fault_row* fs_rows = nullptr;
+  void* fs_tmp = nullptr;
+  size_t fs_cap = 0, fs_tmp_bytes = 0;
+  PinnedQueue<JgXqRec> h_xq;
   std::vector<JgXqRec> xq_tmp;
-  size_t last_add_m = 0;
   JgScanJob* h_jobs = nullptr;  // pinned: drain-time scan jobs and their totals
   uint64_t* h_totals = nullptr;
   size_t scan_cap = 0;
@@ -183,6 +234,12 @@ struct jg_engine {
   bool flag_check_pending = false;
   bool slow_scheduled_ever = false;  // some dense launch had k_dense_slow behind it
   uint64_t n_cmds = 0, n_dense = 0, n_launch = 0;
+  // jg_kernel_timing: HIP event pairs around the dense tick kernel itself (not the slow kernel
+  // behind it), a ring of the most recent launches, read after the fact
+  static constexpr int KT_RING = 256;
+  std::vector<hipEvent_t> kt_ev;  // 2 * KT_RING once enabled
+  bool kt_on = false;
+  uint64_t kt_n = 0;
 };
 
 namespace {
@@ -217,16 +274,27 @@ inline uint32_t fsm_bound() { return 2; }
 template <int R>
 void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks, const JgLeaderNode* nd) {
   const size_t stride = (size_t)e->cfg.n_groups * e->cfg.n_replicas;
+  struct Lap {  // (event pair around the one launch below, when jg_kernel_timing is on)
+    jg_engine* e;
+    explicit Lap(jg_engine* e_) : e(e_) {
+      if (e->kt_on) (void)hipEventRecord(e->kt_ev[2 * (e->kt_n % jg_engine::KT_RING)], e->stream);
+    }
+    ~Lap() {
+      if (e->kt_on) (void)hipEventRecord(e->kt_ev[2 * (e->kt_n++ % jg_engine::KT_RING) + 1], e->stream);
+    }
+  } lap(e);
   if (nd)  // node tick: HeartbeatResponses in, the Tick's outbox out
     hipLaunchKernelGGL(k_leader_node_tick<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
                        jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks, e->seq, e->uniform_self, *nd);
   else if (n_ticks > 1)  // temporal fusion: state read once, written once per launch
     hipLaunchKernelGGL(k_leader_tick_dense_n<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
                        n_ticks, stride, e->seq, e->uniform_self);
-  else  // (with k_dense_slow scheduled behind it, the kernel hands its general path to that one too)
-    hipLaunchKernelGGL(k_leader_tick_dense<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
-                       jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks, e->seq, e->uniform_self,
-                       e->maybe_irregular ? 1 : 0);
+  else if (e->maybe_irregular)  // k_dense_slow is scheduled behind it: the kernel hands its general path to that one too
+    hipLaunchKernelGGL((k_leader_tick_dense<R, true>), dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
+                       jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks, e->seq, e->uniform_self);
+  else
+    hipLaunchKernelGGL((k_leader_tick_dense<R, false>), dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
+                       jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks, e->seq, e->uniform_self);
 }
 
 int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1, const JgLeaderNode* nd = nullptr) {
@@ -262,9 +330,22 @@ int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1, con
 // The exceptional-message queue of the dense node steps, allocated at their first use:
 // (R + 3) rows per group bound what one tick can emit outside the mailbox vocabulary.
 // The device-resident copy of `dev` the ack-only dense kernel reads on its general path.
+// `dev` as the kernels of buffer set k see it
+JgDev dev_for_set(const jg_engine* e, int k) {
+  JgDev d = e->dev;
+  d.fault_q = e->fq[k];
+  d.fault_q_n = e->d_status + (k ? 6 : 3);
+  d.xq = e->dev.xq ? e->xqb[k] : nullptr;
+  d.xq_n = e->d_status + (k ? 7 : 4);
+  return d;
+}
 int push_dev_copy(jg_engine* e) {
-  HIPCHK(hipMemcpyAsync(e->d_dev, &e->dev, sizeof(JgDev), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < 2; k++) {
+    const JgDev d = dev_for_set(e, k);
+    HIPCHK(hipMemcpyAsync(e->d_dev2[k], &d, sizeof(JgDev), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // (`d` is a local)
+  }
+  e->d_dev = e->d_dev2[e->cur_set];
   return JG_OK;
 }
 
@@ -272,10 +353,13 @@ int ensure_xq(jg_engine* e) {
   if (e->dev.xq) return JG_OK;
   const size_t cap = std::max<size_t>((size_t)(e->cfg.n_replicas + 3) * e->cfg.n_groups, 65536);
   if (cap > 0xffffffffull) return fail(JG_EINVAL, "too many groups for the dense node tick");
-  void* p = nullptr;
-  HIPCHK(hipMalloc(&p, cap * sizeof(JgXqRec)));
-  e->allocs.push_back(p);
-  e->dev.xq = (JgXqRec*)p;
+  for (int k = 0; k < 2; k++) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, cap * sizeof(JgXqRec)));
+    e->allocs.push_back(p);
+    e->xqb[k] = (JgXqRec*)p;
+  }
+  e->dev.xq = e->xqb[e->cur_set];
   e->dev.xq_cap = (uint32_t)cap;
   return push_dev_copy(e);
 }
@@ -292,7 +376,7 @@ int sync_and_check(jg_engine* e) {
   if (err == 2) return fail(JG_EINVAL, "device command rows were not sorted by group");
   if (err == 3) return fail(JG_EINVAL, "device command rows name a group out of range");
   if (err == 4) return fail(JG_EDEVICE, "internal: deferred-group list overflow");
-  if (e->h_status[4] > e->dev.xq_cap)
+  if (e->h_status[4] > e->dev.xq_cap || e->h_status[7] > e->dev.xq_cap)
     return fail(JG_ECAPACITY, "exceptional-message queue overflow: drain the messages more often");
   if (e->flag_check_pending) {
     e->maybe_irregular = irregular != 0;  // sticky on the device: once seen, the slow kernel stays scheduled
@@ -309,195 +393,379 @@ int sync_and_check(jg_engine* e) {
   return JG_OK;
 }
 
-// Fault records leave the device in atomic-append order; the drained order is (step, group).
-// Stable LSD radix sort, 11 bits per pass, over the bits that actually vary (a drain window
-// spans few steps, group ids need log2(G) bits): 3 passes at 1 M groups instead of a
-// comparison sort (3.7 ms per 160 k records: the largest single cost of a configs[4] tick).
-void sort_faults(std::vector<JgFaultRec>& v, std::vector<JgFaultRec>& tmp) {
-  const size_t n = v.size();
-  if (n < 2) return;
-  uint32_t seq_lo = v[0].seq, seq_hi = v[0].seq, g_hi = 0;
-  bool sorted = true;
-  for (size_t i = 0; i < n; i++) {
-    seq_lo = std::min(seq_lo, v[i].seq), seq_hi = std::max(seq_hi, v[i].seq);
-    g_hi = std::max(g_hi, v[i].group);
-    if (i && (v[i - 1].seq > v[i].seq || (v[i - 1].seq == v[i].seq && v[i - 1].group > v[i].group))) sorted = false;
+// Fault records leave the device in atomic-append order; the drained order is (step, group), ties
+// in queue order (= emission order: one lane owns a group for a step).  They are sorted on the
+// device, on the stream that drains them: a stable LSD radix sort (rocPRIM) of (step << 32 | group)
+// keys.  (On the host this was the largest single cost of a configs[4] drain: 0.9 ms per 160 k records.)
+__global__ void k_fault_split(const JgFaultRec* __restrict__ q, uint32_t n, uint64_t* __restrict__ keys,
+                              uint32_t* __restrict__ vals) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    keys[i] = ((uint64_t)q[i].seq << 32) | q[i].group;
+    vals[i] = q[i].code;
   }
-  if (sorted) return;
-  auto bits = [](uint64_t x) { int b = 0; while (x) b++, x >>= 1; return b; };
-  const int gb = bits(g_hi), total = gb + bits((uint64_t)seq_hi - seq_lo);
-  auto key = [&](const JgFaultRec& r) { return ((uint64_t)(r.seq - seq_lo) << gb) | r.group; };
-  tmp.resize(n);
-  JgFaultRec *a = v.data(), *b = tmp.data();
-  for (int sh = 0; sh < total; sh += 11) {
-    size_t hist[2049] = {0};
-    for (size_t i = 0; i < n; i++) hist[((key(a[i]) >> sh) & 2047) + 1]++;
-    for (int d = 0; d < 2048; d++) hist[d + 1] += hist[d];
-    for (size_t i = 0; i < n; i++) b[hist[(key(a[i]) >> sh) & 2047]++] = a[i];
-    std::swap(a, b);
+}
+__global__ void k_fault_join(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
+                             jg_fault_row* __restrict__ rows, uint32_t* __restrict__ seqs) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    rows[i] = jg_fault_row{(uint32_t)keys[i], vals[i]};
+    seqs[i] = (uint32_t)(keys[i] >> 32);
   }
-  if (a != v.data()) std::memcpy(v.data(), a, n * sizeof(JgFaultRec));
 }
 
-// Pull finished steps' output rows and the fault queue to the host queues.  Compaction
-// (exclusive scan of the per-run row counts + gather) runs on the device; the host only
-// learns the totals and receives the compacted rows.
-// `release_mask`: bit 0 / bit 1 = the caller is a drain of the message / fsm queue, which ends the
-// life of that queue's outstanding view.
-int collect(jg_engine* e, int release_mask) {
+// ---- drains ------------------------------------------------------------------------------------
+// Finished steps' output rows and the device-side queues travel to the host queues in two
+// phases, both entirely on the device: A. one scan launch over the per-step tile sums (the host
+// learns the totals), B. one gather per step straight into the pinned host queue + the copies of
+// the fault / exceptional-row queues.  A synchronous drain runs them back to back on the engine's
+// stream; jg_drain_prefetch runs them on `copy_stream` behind an event while the engine keeps
+// stepping (phase B is issued by whichever API call first notices that the scan has finished).
+inline void seg_add(std::vector<JgSeg>& v, uint32_t seq, size_t n) {
+  if (!n) return;
+  if (!v.empty() && v.back().seq == seq) v.back().n += n;
+  else v.push_back(JgSeg{seq, n});
+}
+
+// phase A: job table + one scan launch (totals land in pinned host memory)
+int drain_scan(jg_engine* e, const std::vector<StepRec>& recs, hipStream_t st) {
+  const size_t nrec = recs.size();
+  if (!nrec) return JG_OK;
+  if (e->scan_cap < 2 * nrec) {
+    if (e->h_jobs) HIPCHK(hipHostFree(e->h_jobs));
+    if (e->h_totals) HIPCHK(hipHostFree(e->h_totals));
+    e->h_jobs = nullptr, e->h_totals = nullptr;
+    e->scan_cap = std::max<size_t>(4 * nrec, 64);
+    HIPCHK(hipHostMalloc((void**)&e->h_jobs, e->scan_cap * sizeof(JgScanJob), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&e->h_totals, e->scan_cap * sizeof(uint64_t), hipHostMallocDefault));
+  }
+  for (size_t k = 0; k < nrec; k++) {
+    const StepRec& r = recs[k];
+    const uint32_t nb = (r.n + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
+    e->h_jobs[2 * k] = JgScanJob{r.d_bsum_m, nb, 0};
+    e->h_jobs[2 * k + 1] = JgScanJob{r.d_bsum_f, nb, 0};
+  }
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(2 * nrec), dim3(JG_BLOCK), 0, st, (const JgScanJob*)e->h_jobs, e->h_totals);
+  HIPCHK(hipGetLastError());
+  return JG_OK;
+}
+
+// phase B: the gathers write straight into the pinned host queues (mapped, device-visible: no
+// staging buffer, no device-to-host blit), then the two device queues of buffer set `set`
+int drain_gather(jg_engine* e, jg_engine::DrainBatch& b, const std::vector<StepRec>& recs, hipStream_t st) {
   static const bool trace = std::getenv("JG_TRACE_DRAIN") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t0 = now();
-  double t1 = t0, t2 = t0, t3 = t0;
-  int rc = sync_and_check(e);
-  if (rc) return rc;
-  t1 = now();
-  if (release_mask & 1) e->q_msgs.release_view();  // the caller is done with that queue's last view
-  if (release_mask & 2) e->q_fsm.release_view();
-  auto seg_add = [](std::vector<JgSeg>& v, uint32_t seq, size_t n) {
-    if (!n) return;
-    if (!v.empty() && v.back().seq == seq) v.back().n += n;
-    else v.push_back(JgSeg{seq, n});
-  };
-  const size_t nrec = e->recs.size();
-  if (nrec) {
-    // job table + totals in pinned host memory, read / written by the kernel in place
-    if (e->scan_cap < 2 * nrec) {
-      if (e->h_jobs) HIPCHK(hipHostFree(e->h_jobs));
-      if (e->h_totals) HIPCHK(hipHostFree(e->h_totals));
-      e->h_jobs = nullptr, e->h_totals = nullptr;
-      e->scan_cap = std::max<size_t>(4 * nrec, 64);
-      HIPCHK(hipHostMalloc((void**)&e->h_jobs, e->scan_cap * sizeof(JgScanJob), hipHostMallocDefault));
-      HIPCHK(hipHostMalloc((void**)&e->h_totals, e->scan_cap * sizeof(uint64_t), hipHostMallocDefault));
+  const double g0 = now();
+  double g1 = g0, g2 = g0, g3 = g0, g4 = g0;
+  const uint64_t* totals = e->h_totals;
+  b.add_m = b.add_f = 0;
+  for (size_t k = 0; k < recs.size(); k++) b.add_m += totals[2 * k], b.add_f += totals[2 * k + 1];
+  PinnedQueue<jg_msg_row>& qm = b.to_landing ? e->l_msgs : e->q_msgs;
+  PinnedQueue<jg_fsm_row>& qf = b.to_landing ? e->l_fsm : e->q_fsm;
+  b.at_m = qm.n, b.at_f = qf.n;
+  // (a quarter of headroom when the queue has to grow: the row count wobbles from batch to batch and
+  // re-pinning a 30 MB buffer costs milliseconds)
+  if (qm.cap < b.at_m + b.add_m) HIPCHK(qm.reserve(b.at_m + b.add_m + b.add_m / 4));
+  if (qf.cap < b.at_f + b.add_f) HIPCHK(qf.reserve(b.at_f + b.add_f + b.add_f / 4));
+  uint64_t off_m = 0, off_f = 0;
+  for (size_t k = 0; k < recs.size(); k++) {
+    const StepRec& r = recs[k];
+    const uint32_t nb = (r.n + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
+    if (totals[2 * k]) {
+      hipLaunchKernelGGL(k_scan_gather<jg_msg_row>, dim3(nb), dim3(JG_BLOCK), 0, st, r.d_msg_cnt, r.n, r.d_bsum_m,
+                         r.msg_per_row, r.d_msg, qm.p + b.at_m + off_m);
+      off_m += totals[2 * k];
     }
-    for (size_t k = 0; k < nrec; k++) {
-      StepRec& r = e->recs[k];
-      const uint32_t nb = (r.n + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
-      e->h_jobs[2 * k] = JgScanJob{r.d_bsum_m, nb, 0};
-      e->h_jobs[2 * k + 1] = JgScanJob{r.d_bsum_f, nb, 0};
+    if (totals[2 * k + 1]) {
+      hipLaunchKernelGGL(k_scan_gather<jg_fsm_row>, dim3(nb), dim3(JG_BLOCK), 0, st, r.d_fsm_cnt, r.n, r.d_bsum_f,
+                         r.fsm_per_row, r.d_fsm, qf.p + b.at_f + off_f);
+      off_f += totals[2 * k + 1];
     }
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(2 * nrec), dim3(JG_BLOCK), 0, e->stream,
-                       (const JgScanJob*)e->h_jobs, e->h_totals);
+  }
+  HIPCHK(hipGetLastError());
+  g1 = now();
+  uint32_t* d_cnt = e->d_status + (b.set ? 6 : 3);  // {fault_q_n, xq_n} of this buffer set
+  if (b.nx) {
+    HIPCHK(e->h_xq.reserve(b.nx));
+    HIPCHK(hipMemcpyAsync(e->h_xq.p, e->xqb[b.set], (size_t)b.nx * sizeof(JgXqRec), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(d_cnt + 1, 0, sizeof(uint32_t), st));
+  }
+  if (b.nf) {
+    if (b.nf > e->dev.fault_q_cap) return fail(JG_EDEVICE, "fault queue overflow");
+    const size_t n = b.nf;
+    if (e->fs_cap < n) {  // (grow-only; hipFree synchronises, so this happens a handful of times per engine)
+      for (void* p : {(void*)e->fs_k0, (void*)e->fs_k1, (void*)e->fs_v0, (void*)e->fs_v1, (void*)e->fs_seq, (void*)e->fs_rows})
+        if (p) HIPCHK(hipFree(p));
+      e->fs_cap = std::max<size_t>(2 * n, 4096);
+      HIPCHK(hipMalloc((void**)&e->fs_k0, e->fs_cap * 8));
+      HIPCHK(hipMalloc((void**)&e->fs_k1, e->fs_cap * 8));
+      HIPCHK(hipMalloc((void**)&e->fs_v0, e->fs_cap * 4));
+      HIPCHK(hipMalloc((void**)&e->fs_v1, e->fs_cap * 4));
+      HIPCHK(hipMalloc((void**)&e->fs_seq, e->fs_cap * 4));
+      HIPCHK(hipMalloc((void**)&e->fs_rows, e->fs_cap * sizeof(jg_fault_row)));
+    }
+    size_t need = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, need, e->fs_k0, e->fs_k1, e->fs_v0, e->fs_v1, n, 0, 64, st));
+    if (e->fs_tmp_bytes < need) {
+      if (e->fs_tmp) HIPCHK(hipFree(e->fs_tmp));
+      e->fs_tmp_bytes = 2 * need;
+      HIPCHK(hipMalloc(&e->fs_tmp, e->fs_tmp_bytes));
+    }
+    g2 = now();
+    const uint32_t grid = grid_for(n, 1024);
+    hipLaunchKernelGGL(k_fault_split, dim3(grid), dim3(JG_BLOCK), 0, st, (const JgFaultRec*)e->fq[b.set], (uint32_t)n,
+                       e->fs_k0, e->fs_v0);
+    size_t tmp_bytes = e->fs_tmp_bytes;
+    HIPCHK(rocprim::radix_sort_pairs(e->fs_tmp, tmp_bytes, e->fs_k0, e->fs_k1, e->fs_v0, e->fs_v1, n, 0, 64, st));
+    hipLaunchKernelGGL(k_fault_join, dim3(grid), dim3(JG_BLOCK), 0, st, (const uint64_t*)e->fs_k1,
+                       (const uint32_t*)e->fs_v1, (uint32_t)n, e->fs_rows, e->fs_seq);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(e->stream));
-    t2 = now();
-    const uint64_t* totals = e->h_totals;
-    uint64_t add_m = 0, add_f = 0;
+    g3 = now();
+    HIPCHK(e->h_faults.reserve(2 * n));  // (headroom: the count wobbles from batch to batch, pinned reallocation is slow)
+    HIPCHK(e->h_fault_seq.reserve(2 * n));
+    HIPCHK(hipMemcpyAsync(e->h_faults.p, e->fs_rows, n * sizeof(jg_fault_row), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(e->h_fault_seq.p, e->fs_seq, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), st));
+    g4 = now();
+  }
+  if (trace)
+    std::fprintf(stderr, "[jg drain phase B] reserve + %zu gather launches %.3f ms, sort scratch %.3f ms, sort launches %.3f ms, copies %.3f ms\n",
+                 recs.size(), g1 - g0, g2 - g1, g3 - g2, g4 - g3);
+  return JG_OK;
+}
+
+// host tail, once everything of the batch has landed: the rows count as queued, exceptional rows
+// are merged in by step sequence number, fault records are put in (step, group) order
+int drain_finish(jg_engine* e, jg_engine::DrainBatch& b, std::vector<StepRec>& recs, Arena& arena) {
+  const size_t nrec = recs.size();
+  const uint64_t* totals = e->h_totals;
+  PinnedQueue<jg_msg_row>& qm = b.to_landing ? e->l_msgs : e->q_msgs;
+  PinnedQueue<jg_fsm_row>& qf = b.to_landing ? e->l_fsm : e->q_fsm;
+  qm.n = b.at_m + b.add_m;
+  qf.n = b.at_f + b.add_f;
+  if (b.to_landing) e->landed_m = e->landed_f = true;
+  if (e->track_segs)
     for (size_t k = 0; k < nrec; k++) {
-      add_m += totals[2 * k];
-      add_f += totals[2 * k + 1];
+      if (!b.nx) seg_add(e->seg_m, recs[k].seq, totals[2 * k]);  // (else: in the merge below)
+      seg_add(e->seg_f, recs[k].seq, totals[2 * k + 1]);
     }
-    const size_t at_m = e->q_msgs.n, at_f = e->q_fsm.n;
-    HIPCHK(e->q_msgs.reserve(at_m + add_m));
-    HIPCHK(e->q_fsm.reserve(at_f + add_f));
-    // the gather kernels write straight into the pinned host queues (mapped, device-visible):
-    // no staging buffer and no device-to-host copy (a blit kernel at ~9 GB/s on this platform)
-    jg_msg_row* d_all_m = e->q_msgs.p + at_m;
-    jg_fsm_row* d_all_f = e->q_fsm.p + at_f;
-    if (std::getenv("JG_DRAIN_STAGED")) {  // A/B: staged copy through the arena
-      if (add_m) HIPCHK(e->arena.alloc(add_m * sizeof(jg_msg_row), (void**)&d_all_m));
-      if (add_f) HIPCHK(e->arena.alloc(add_f * sizeof(jg_fsm_row), (void**)&d_all_f));
-    }
-    uint64_t off_m = 0, off_f = 0;
-    for (size_t k = 0; k < nrec; k++) {
-      StepRec& r = e->recs[k];
-      const uint32_t nb = (r.n + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
-      if (totals[2 * k]) {
-        hipLaunchKernelGGL(k_scan_gather<jg_msg_row>, dim3(nb), dim3(JG_BLOCK), 0, e->stream, r.d_msg_cnt, r.n,
-                           r.d_bsum_m, r.msg_per_row, r.d_msg, d_all_m + off_m);
-        off_m += totals[2 * k];
-      }
-      if (totals[2 * k + 1]) {
-        hipLaunchKernelGGL(k_scan_gather<jg_fsm_row>, dim3(nb), dim3(JG_BLOCK), 0, e->stream, r.d_fsm_cnt, r.n,
-                           r.d_bsum_f, r.fsm_per_row, r.d_fsm, d_all_f + off_f);
-        off_f += totals[2 * k + 1];
-      }
-    }
-    HIPCHK(hipGetLastError());
-    if (std::getenv("JG_DRAIN_STAGED")) {
-      if (add_m)
-        HIPCHK(hipMemcpyAsync(e->q_msgs.p + at_m, d_all_m, add_m * sizeof(jg_msg_row), hipMemcpyDeviceToHost, e->stream));
-      if (add_f)
-        HIPCHK(hipMemcpyAsync(e->q_fsm.p + at_f, d_all_f, add_f * sizeof(jg_fsm_row), hipMemcpyDeviceToHost, e->stream));
-    }
-    e->q_msgs.n = at_m + add_m;
-    e->q_fsm.n = at_f + add_f;
-    e->last_add_m = add_m;
-    if (e->track_segs)
-      for (size_t k = 0; k < nrec; k++) {
-        if (!e->h_status[4]) seg_add(e->seg_m, e->recs[k].seq, totals[2 * k]);  // (else: in the merge below)
-        seg_add(e->seg_f, e->recs[k].seq, totals[2 * k + 1]);
-      }
-  }
-  // exceptional rows of dense node steps (the count came with the status block)
-  const uint32_t nx = e->h_status[4];
-  if (nx) {
-    e->xq_tmp.resize(nx);
-    HIPCHK(hipMemcpyAsync(e->xq_tmp.data(), e->dev.xq, (size_t)nx * sizeof(JgXqRec), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemsetAsync(e->dev.xq_n, 0, sizeof(uint32_t), e->stream));
-  }
-  // faults (the count came with the status block)
-  const uint32_t nf = e->h_status[3];
-  if (nf) {
-    if (nf > e->dev.fault_q_cap) return fail(JG_EDEVICE, "fault queue overflow");
-    e->fault_tmp.resize(nf);
-    HIPCHK(hipMemcpyAsync(e->fault_tmp.data(), e->dev.fault_q, nf * sizeof(JgFaultRec), hipMemcpyDeviceToHost,
-                          e->stream));
-    HIPCHK(hipMemsetAsync(e->dev.fault_q_n, 0, sizeof(uint32_t), e->stream));
-  }
-  if (nrec || nf || nx) HIPCHK(hipStreamSynchronize(e->stream));
-  t3 = now();
-  if (nx) {
+  if (b.nx) {
     // Merge by step sequence number: the rows of sparse step k (already in the queue, step
     // order) carry rec.seq; exceptional rows carry the seq of their dense step.  Rare path.
+    e->xq_tmp.assign(e->h_xq.p, e->h_xq.p + b.nx);
     std::vector<JgXqRec>& xr = e->xq_tmp;
-    std::sort(xr.begin(), xr.end(), [](const JgXqRec& a, const JgXqRec& b) {
-      if (a.seq != b.seq) return a.seq < b.seq;
-      if (a.row.group != b.row.group) return a.row.group < b.row.group;
-      return a.k < b.k;
+    std::sort(xr.begin(), xr.end(), [](const JgXqRec& x, const JgXqRec& y) {
+      if (x.seq != y.seq) return x.seq < y.seq;
+      if (x.row.group != y.row.group) return x.row.group < y.row.group;
+      return x.k < y.k;
     });
-    const size_t old_n = e->q_msgs.n - (nrec ? e->last_add_m : 0);  // rows queued before this collect
+    const size_t old_n = b.at_m, nx = b.nx;  // rows queued before this batch
     std::vector<jg_msg_row> merged;
-    merged.reserve(e->q_msgs.n - old_n + nx);
+    merged.reserve(b.add_m + nx);
     size_t xi = 0, off = old_n;
     for (size_t k = 0; k < nrec; k++) {
-      while (xi < nx && xr[xi].seq < e->recs[k].seq) {
+      while (xi < nx && xr[xi].seq < recs[k].seq) {
         if (e->track_segs) seg_add(e->seg_m, xr[xi].seq, 1);
         merged.push_back(xr[xi++].row);
       }
-      const size_t cnt = e->h_totals[2 * k];
-      merged.insert(merged.end(), e->q_msgs.p + off, e->q_msgs.p + off + cnt);
-      if (e->track_segs) seg_add(e->seg_m, e->recs[k].seq, cnt);
+      const size_t cnt = totals[2 * k];
+      merged.insert(merged.end(), qm.p + off, qm.p + off + cnt);
+      if (e->track_segs) seg_add(e->seg_m, recs[k].seq, cnt);
       off += cnt;
     }
     while (xi < nx) {
       if (e->track_segs) seg_add(e->seg_m, xr[xi].seq, 1);
       merged.push_back(xr[xi++].row);
     }
-    HIPCHK(e->q_msgs.reserve(old_n + merged.size()));
-    if (!merged.empty()) std::memcpy(e->q_msgs.p + old_n, merged.data(), merged.size() * sizeof(jg_msg_row));
-    e->q_msgs.n = old_n + merged.size();
+    HIPCHK(qm.reserve(old_n + merged.size()));
+    if (!merged.empty()) std::memcpy(qm.p + old_n, merged.data(), merged.size() * sizeof(jg_msg_row));
+    qm.n = old_n + merged.size();
   }
   if (nrec) {
-    e->recs.clear();
-    e->arena.reset();
+    recs.clear();
+    arena.reset();
   }
-  if (nf) {
-    sort_faults(e->fault_tmp, e->fault_tmp2);
-    e->q_faults.reserve(e->q_faults.size() + e->fault_tmp.size());
-    for (const JgFaultRec& f : e->fault_tmp) e->q_faults.push_back(jg_fault_row{f.group, f.code});
-    if (e->track_segs)
-      for (const JgFaultRec& f : e->fault_tmp) e->q_fault_seq.push_back(f.seq);
+  if (b.nf) {  // (sorted on the device)
+    e->q_faults.insert(e->q_faults.end(), e->h_faults.p, e->h_faults.p + b.nf);
+    if (e->track_segs) e->q_fault_seq.insert(e->q_fault_seq.end(), e->h_fault_seq.p, e->h_fault_seq.p + b.nf);
   }
+  return JG_OK;
+}
+
+// ---- the batch in transfer (jg_drain_prefetch) ---------------------------------------------------
+int inflight_phase_b(jg_engine* e) {
+  static const bool trace = std::getenv("JG_TRACE_DRAIN") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
+  jg_engine::DrainBatch& b = e->inflight;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipEventSynchronize(e->ev_scan));
+  const double t1 = now();
+  b.nf = e->h_cnt[0], b.nx = e->h_cnt[1];
+  if (b.nx > e->dev.xq_cap) return fail(JG_ECAPACITY, "exceptional-message queue overflow: drain the messages more often");
+  int rc = drain_gather(e, b, b.recs, e->copy_stream);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(e->ev_done, e->copy_stream));
+  const double t2 = now();
+  HIPCHK(hipEventSynchronize(e->ev_done));
+  if (trace)
+    std::fprintf(stderr, "[jg drain thread] %zu steps: waited %.3f ms for the scan, issued phase B in %.3f ms, landed after %.3f ms\n",
+                 b.recs.size(), t1 - t0, t2 - t1, now() - t2);
+  return JG_OK;
+}
+void drain_thread_main(jg_engine* e) {
+  jg_engine::DrainThread& t = *e->drain_thread;
+  std::unique_lock<std::mutex> lk(t.m);
+  for (;;) {
+    t.cv.wait(lk, [&] { return t.state == 1 || t.quit; });
+    if (t.quit) return;
+    lk.unlock();
+    g_err.clear();
+    const int rc = inflight_phase_b(e);
+    lk.lock();
+    t.rc = rc;
+    t.err = rc ? g_err : std::string();
+    t.state = 2;
+    t.cv.notify_all();
+  }
+}
+// a landed batch joins the queue the consumer drains: a pointer swap if the consumer has taken
+// everything before it, an append behind what it has not taken yet otherwise
+template <typename Row>
+int handover(PinnedQueue<Row>& q, PinnedQueue<Row>& l, bool& flag) {
+  if (!flag) return JG_OK;
+  flag = false;
+  if (q.n == 0 && !q.viewed) {
+    std::swap(q.p, l.p);
+    std::swap(q.cap, l.cap);
+    q.n = l.n;
+    l.n = 0;
+    return JG_OK;
+  }
+  HIPCHK(q.reserve(q.n + l.n));
+  if (l.n) std::memcpy(q.p + q.n, l.p, l.n * sizeof(Row));
+  q.n += l.n;
+  l.n = 0;
+  return JG_OK;
+}
+
+bool inflight_landed(jg_engine* e) {
+  if (!e->inflight.phase) return true;
+  std::lock_guard<std::mutex> lk(e->drain_thread->m);
+  return e->drain_thread->state == 2;
+}
+// wait for the batch in transfer (never for the engine's own stream) and queue its rows
+int inflight_finish(jg_engine* e) {
+  jg_engine::DrainBatch& b = e->inflight;
+  if (!b.phase) return JG_OK;
+  jg_engine::DrainThread& t = *e->drain_thread;
+  {
+    std::unique_lock<std::mutex> lk(t.m);
+    t.cv.wait(lk, [&] { return t.state == 2; });
+    t.state = 0;
+  }
+  b.phase = 0;
+  if (t.rc) return fail(t.rc, "drain thread: " + t.err);
+  return drain_finish(e, b, b.recs, e->arenas[b.arena]);
+}
+
+// `wait`: jg_drain_flush (block until the previous batch has landed); jg_drain_prefetch never
+// blocks: while a batch is still in transfer it starts nothing (the next call takes more steps)
+int drain_prefetch(jg_engine* e, bool wait) {
+  HIPCHK(hipSetDevice(e->device));
+  e->pipelined = true;
+  if (!wait && !inflight_landed(e)) return JG_OK;
+  int rc = inflight_finish(e);
+  if (rc) return rc;
+  if ((rc = handover(e->q_msgs, e->l_msgs, e->landed_m))) return rc;  // the landing queues must be free
+  if ((rc = handover(e->q_fsm, e->l_fsm, e->landed_f))) return rc;
+  if (!e->stepped) return JG_OK;
+  if (!e->drain_thread) {  // first use: the second stream (a second hardware queue: not before it is needed), its events, the thread
+    HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_steps, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_scan, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+    e->drain_thread = new jg_engine::DrainThread();
+    e->drain_thread->th = std::thread(drain_thread_main, e);
+  }
+  jg_engine::DrainBatch& b = e->inflight;
+  b.to_landing = true;
+  b.recs.swap(e->recs);
+  b.arena = e->cur_arena;
+  e->cur_arena ^= 1;
+  // kernels launched from here on append to the other fault / exceptional-row queues
+  b.set = e->cur_set;
+  e->cur_set ^= 1;
+  e->dev = dev_for_set(e, e->cur_set);
+  e->d_dev = e->d_dev2[e->cur_set];  // (both device copies were written up front: nothing to upload here)
+  HIPCHK(hipEventRecord(e->ev_steps, e->stream));
+  HIPCHK(hipStreamWaitEvent(e->copy_stream, e->ev_steps, 0));
+  rc = drain_scan(e, b.recs, e->copy_stream);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(e->h_cnt, e->d_status + (b.set ? 6 : 3), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                        e->copy_stream));
+  HIPCHK(hipEventRecord(e->ev_scan, e->copy_stream));
+  b.phase = 1;
+  {
+    std::lock_guard<std::mutex> lk(e->drain_thread->m);
+    e->drain_thread->state = 1;
+  }
+  e->drain_thread->cv.notify_all();
+  return JG_OK;
+}
+
+// Synchronous drain: everything stepped so far (unless the engine is pipelined: then exactly the
+// batches up to the latest prefetch point, without synchronising later steps).  `release_mask`:
+// bit 0 / bit 1 = the caller is a drain of the message / fsm queue, which ends the life of that
+// queue's outstanding view.
+int collect(jg_engine* e, int release_mask) {
+  static const bool trace = std::getenv("JG_TRACE_DRAIN") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
+  // (first: the batch in transfer lands BEHIND the rows a view may still cover; only then may
+  // the queue be compacted)
+  if (e->pipelined && !inflight_landed(e)) return JG_OK;  // nothing new yet; the queues are the drain thread's
+  int rc = inflight_finish(e);
+  if (rc) return rc;
+  if (release_mask & 1) {
+    e->q_msgs.release_view();  // the caller is done with that queue's last view
+    if ((rc = handover(e->q_msgs, e->l_msgs, e->landed_m))) return rc;
+  }
+  if (release_mask & 2) {
+    e->q_fsm.release_view();
+    if ((rc = handover(e->q_fsm, e->l_fsm, e->landed_f))) return rc;
+  }
+  if (e->pipelined) {
+    if (trace) std::fprintf(stderr, "[jg drain] pipelined: %.3f ms on the host (%zu msg rows queued)\n", now() - t0, e->q_msgs.n);
+    return JG_OK;
+  }
+  rc = sync_and_check(e);
+  if (rc) return rc;
+  const double t1 = now();
+  jg_engine::DrainBatch b;
+  b.set = e->cur_set;
+  b.nf = e->h_status[b.set ? 6 : 3], b.nx = e->h_status[b.set ? 7 : 4];
+  const size_t nrec = e->recs.size();
+  rc = drain_scan(e, e->recs, e->stream);
+  if (rc) return rc;
+  if (nrec) HIPCHK(hipStreamSynchronize(e->stream));
+  const double t2 = now();
+  rc = drain_gather(e, b, e->recs, e->stream);
+  if (rc) return rc;
+  if (nrec || b.nf || b.nx) HIPCHK(hipStreamSynchronize(e->stream));
+  const double t3 = now();
+  rc = drain_finish(e, b, e->recs, e->arenas[e->cur_arena]);
   if (trace && nrec)
     std::fprintf(stderr, "[jg drain] %zu steps: sync %.3f ms, scan %.3f ms, gather+copy %.3f ms, host tail %.3f ms (%zu msg rows, %u faults)\n",
-                 nrec, t1 - t0, t2 - t1, t3 - t2, now() - t3, e->q_msgs.n, nf);
-  return JG_OK;
+                 nrec, t1 - t0, t2 - t1, t3 - t2, now() - t3, e->q_msgs.n, b.nf);
+  return rc;
 }
 
 template <typename Row>
 int drain(jg_engine* e, PinnedQueue<Row>& q, int mask, Row* out, size_t cap, size_t* n) {
   if (!e || !n) return fail(JG_EINVAL, "null argument");
+  if (e->pipelined && !inflight_landed(e)) {  // a batch is in transfer: nothing new to deliver yet
+    *n = 0;
+    return JG_OK;
+  }
   int rc = collect(e, mask);
   if (rc) return rc;
   *n = q.n;
@@ -510,6 +778,11 @@ int drain(jg_engine* e, PinnedQueue<Row>& q, int mask, Row* out, size_t cap, siz
 template <typename Row>
 int drain_view(jg_engine* e, PinnedQueue<Row>& q, int mask, const Row** rows, size_t* n) {
   if (!e || !rows || !n) return fail(JG_EINVAL, "null argument");
+  if (e->pipelined && !inflight_landed(e)) {  // a batch is in transfer: nothing new (an earlier view stays valid)
+    *rows = q.p;
+    *n = 0;
+    return JG_OK;
+  }
   int rc = collect(e, mask);
   if (rc) return rc;
   *rows = q.p;
@@ -580,13 +853,13 @@ int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* 
   rec.msg_per_row = msg_bound(e->cfg.n_replicas);
   rec.fsm_per_row = fsm_bound();
   if ((uint64_t)n * rec.msg_per_row > 0xffffffffull) return fail(JG_EINVAL, "batch too large: split it");
-  HIPCHK(e->arena.alloc((size_t)n * 4, (void**)&rec.d_msg_cnt));
-  HIPCHK(e->arena.alloc((size_t)n * 4, (void**)&rec.d_fsm_cnt));
-  HIPCHK(e->arena.alloc((size_t)n * rec.msg_per_row * sizeof(jg_msg_row), (void**)&rec.d_msg));
-  HIPCHK(e->arena.alloc((size_t)n * rec.fsm_per_row * sizeof(jg_fsm_row), (void**)&rec.d_fsm));
+  HIPCHK(e->arenas[e->cur_arena].alloc((size_t)n * 4, (void**)&rec.d_msg_cnt));
+  HIPCHK(e->arenas[e->cur_arena].alloc((size_t)n * 4, (void**)&rec.d_fsm_cnt));
+  HIPCHK(e->arenas[e->cur_arena].alloc((size_t)n * rec.msg_per_row * sizeof(jg_msg_row), (void**)&rec.d_msg));
+  HIPCHK(e->arenas[e->cur_arena].alloc((size_t)n * rec.fsm_per_row * sizeof(jg_fsm_row), (void**)&rec.d_fsm));
   const uint32_t n_tiles = (n + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
-  HIPCHK(e->arena.alloc((size_t)n_tiles * 8, (void**)&rec.d_bsum_m));
-  HIPCHK(e->arena.alloc((size_t)n_tiles * 8, (void**)&rec.d_bsum_f));
+  HIPCHK(e->arenas[e->cur_arena].alloc((size_t)n_tiles * 8, (void**)&rec.d_bsum_m));
+  HIPCHK(e->arenas[e->cur_arena].alloc((size_t)n_tiles * 8, (void**)&rec.d_bsum_f));
   JgRowsArgs a;
   a.n = n;
   a.group = group;
@@ -713,7 +986,9 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.votes, G);
   A(d.blk_decisions, e->count_slots);
   d.fault_q_cap = (uint32_t)std::max<size_t>(2 * G, 1024);
-  A(d.fault_q, d.fault_q_cap);
+  A(e->fq[0], d.fault_q_cap);
+  A(e->fq[1], d.fault_q_cap);
+  d.fault_q = e->fq[0];
   A(e->d_status, 8);
   e->d_err = e->d_status;
   d.err = e->d_status;
@@ -722,7 +997,8 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   d.fault_q_n = e->d_status + 3;
   d.xq_n = e->d_status + 4;
   d.cold_seen = e->d_status + 5;
-  if (hipHostMalloc((void**)&e->h_status, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+  if (hipHostMalloc((void**)&e->h_status, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_cnt, 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
     return bail(fail(JG_EDEVICE, "hipHostMalloc failed"));
   {  // deferred lists: shard = workgroup & (JG_SHARDS-1); generous per-shard capacity, bounds-checked
     const size_t n_wg = (G + JG_BLOCK - 1) / JG_BLOCK;
@@ -734,7 +1010,8 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.slow_list, (size_t)JG_SHARDS * d.slow_cap);
   A(d.slow_cnt, JG_SHARDS);
   A(d.defer_bits, (G + 63) / 64);
-  A(e->d_dev, 1);
+  A(e->d_dev2[0], 1);
+  A(e->d_dev2[1], 1);
 #undef A
   if ((rc = push_dev_copy(e)) != JG_OK) return bail(rc);
   hipLaunchKernelGGL(k_init_groups, dim3(grid_for(G, 2048)), dim3(JG_BLOCK), 0, e->stream, e->dev,
@@ -761,16 +1038,43 @@ void jg_engine_destroy(jg_engine* e) {
     return;
   }
   (void)hipSetDevice(e->device);
+  if (e->drain_thread) {
+    jg_engine::DrainThread& t = *e->drain_thread;
+    {
+      std::unique_lock<std::mutex> lk(t.m);
+      t.cv.wait(lk, [&] { return t.state != 1; });  // a batch in transfer lands first
+      t.quit = true;
+    }
+    t.cv.notify_all();
+    if (t.th.joinable()) t.th.join();
+    delete e->drain_thread;
+    e->drain_thread = nullptr;
+  }
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  e->arena.destroy();
+  if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+  e->arenas[0].destroy();
+  e->arenas[1].destroy();
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->d_acks_staging) (void)hipFree(e->d_acks_staging);
   if (e->stage) (void)hipHostFree(e->stage);
   if (e->h_status) (void)hipHostFree(e->h_status);
+  if (e->h_cnt) (void)hipHostFree(e->h_cnt);
+  e->h_faults.destroy();
+  e->h_fault_seq.destroy();
+  e->h_xq.destroy();
+  for (void* p : {(void*)e->fs_k0, (void*)e->fs_k1, (void*)e->fs_v0, (void*)e->fs_v1, (void*)e->fs_seq, (void*)e->fs_rows, e->fs_tmp})
+    if (p) (void)hipFree(p);
+  for (hipEvent_t ev : e->kt_ev) (void)hipEventDestroy(ev);
+  if (e->ev_steps) (void)hipEventDestroy(e->ev_steps);
+  if (e->ev_scan) (void)hipEventDestroy(e->ev_scan);
+  if (e->ev_done) (void)hipEventDestroy(e->ev_done);
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->h_jobs) (void)hipHostFree(e->h_jobs);
   if (e->h_totals) (void)hipHostFree(e->h_totals);
   e->q_msgs.destroy();
   e->q_fsm.destroy();
+  e->l_msgs.destroy();
+  e->l_fsm.destroy();
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->ev_stage) (void)hipEventDestroy(e->ev_stage);
@@ -897,7 +1201,7 @@ int jg_step(jg_engine* e, uint64_t now_ms) {
     std::memcpy(S + o_bnext, e->p_blk_next.data(), nb * 8);
   }
   char* B = nullptr;
-  HIPCHK(e->arena.alloc(bytes, (void**)&B));
+  HIPCHK(e->arenas[e->cur_arena].alloc(bytes, (void**)&B));
   HIPCHK(hipMemcpyAsync(B, S, bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipEventRecord(e->ev_stage, e->stream));
   e->stage_busy = true;
@@ -1117,8 +1421,54 @@ int jg_drain_applies_view(jg_engine* e, const jg_fsm_row** rows, size_t* n) {
   if (e->router) return router_drain_view(e, e->router->fsm, e->router->fsm_view, 2, rows, n);
   return drain_view(e, e->q_fsm, 2, rows, n);
 }
+int jg_drain_prefetch(jg_engine* e) {
+  if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) {  // all shards or none: their batches must cover the same steps
+    e->pipelined = true;
+    for (jg_engine* s : e->router->sh) s->pipelined = true;
+    if (!router_all_landed(e)) return JG_OK;
+    return e->router->run([&](size_t d) { return drain_prefetch(e->router->sh[d], true); });
+  }
+  return drain_prefetch(e, false);
+}
+
+int jg_drain_wait(jg_engine* e) {
+  if (!e) return fail(JG_EINVAL, "null argument");
+  auto wait = [](jg_engine* s) {
+    if (!s->inflight.phase) return (int)JG_OK;
+    jg_engine::DrainThread& t = *s->drain_thread;
+    std::unique_lock<std::mutex> lk(t.m);
+    t.cv.wait(lk, [&] { return t.state == 2; });
+    return (int)JG_OK;
+  };
+  if (e->router) {
+    for (jg_engine* s : e->router->sh) wait(s);
+    return JG_OK;
+  }
+  return wait(e);
+}
+
+int jg_drain_flush(jg_engine* e) {
+  if (!e) return fail(JG_EINVAL, "null argument");
+  auto flush = [](jg_engine* s) {
+    int rc = drain_prefetch(s, true);   // the batch in transfer lands; whatever was stepped since starts
+    if (rc) return rc;
+    return inflight_finish(s);          // ... and lands too
+  };
+  if (e->router) {
+    e->pipelined = true;
+    for (jg_engine* s : e->router->sh) s->pipelined = true;
+    return e->router->run([&](size_t d) { return flush(e->router->sh[d]); });
+  }
+  return flush(e);
+}
+
 int jg_drain_faults(jg_engine* e, jg_fault_row* out, size_t cap, size_t* n) {
   if (!e || !n) return fail(JG_EINVAL, "null argument");
+  if (!e->router && e->pipelined && !inflight_landed(e)) {
+    *n = 0;
+    return JG_OK;
+  }
   int rc = e->router ? router_collect(e, 0) : collect(e, 0);
   if (rc) return rc;
   std::vector<jg_fault_row>& q = e->router ? e->router->faults : e->q_faults;
@@ -1321,8 +1671,63 @@ int jg_timer_stop(jg_engine* e, float* ms) {
   }
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipEventRecord(e->ev1, e->stream));
+  {  // poll for a while before sleeping on the event: an interrupt-driven wake-up costs tens of
+     // microseconds, which is a visible fraction of a 20-launch timed region
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t q;
+    while ((q = hipEventQuery(e->ev1)) == hipErrorNotReady &&
+           std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(20)) {
+    }
+    if (q != hipSuccess && q != hipErrorNotReady) return fail(JG_EDEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
+  }
   HIPCHK(hipEventSynchronize(e->ev1));
   HIPCHK(hipEventElapsedTime(ms, e->ev0, e->ev1));
+  return JG_OK;
+}
+
+int jg_kernel_timing(jg_engine* e, int enable) {
+  if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) {
+    for (jg_engine* s : e->router->sh) {
+      const int rc = jg_kernel_timing(s, enable);
+      if (rc) return rc;
+    }
+    return JG_OK;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  if (enable && e->kt_ev.empty()) {
+    e->kt_ev.resize(2 * jg_engine::KT_RING);
+    for (hipEvent_t& ev : e->kt_ev) HIPCHK(hipEventCreate(&ev));
+  }
+  e->kt_on = enable != 0;
+  e->kt_n = 0;
+  return JG_OK;
+}
+
+int jg_kernel_timing_read(jg_engine* e, float* avg_us, uint32_t* n_launches) {
+  if (!e || !avg_us || !n_launches) return fail(JG_EINVAL, "null argument");
+  if (e->router) {  // the slowest shard's average
+    *avg_us = 0, *n_launches = 0;
+    for (jg_engine* s : e->router->sh) {
+      float v = 0;
+      uint32_t k = 0;
+      const int rc = jg_kernel_timing_read(s, &v, &k);
+      if (rc) return rc;
+      if (v > *avg_us) *avg_us = v, *n_launches = k;
+    }
+    return JG_OK;
+  }
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const uint64_t n = std::min<uint64_t>(e->kt_n, jg_engine::KT_RING);
+  double sum = 0;
+  for (uint64_t k = 0; k < n; k++) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e->kt_ev[2 * k], e->kt_ev[2 * k + 1]));
+    sum += ms;
+  }
+  *avg_us = n ? (float)(sum * 1e3 / (double)n) : 0.0f;
+  *n_launches = (uint32_t)n;
   return JG_OK;
 }
 

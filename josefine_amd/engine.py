@@ -438,6 +438,22 @@ class BatchedRaft:
             return self._drain_view(self.api.drain_applies_view, capi.FSM_DTYPE, copy)
         return self._drain(self.api.drain_applies, capi.FSM_DTYPE)
 
+    def drain_prefetch(self) -> None:
+        """jg_drain_prefetch: start moving everything stepped so far to the host queues without
+        blocking (a no-op while the previous batch is still in transfer); from now on the drains
+        deliver what has landed and never block."""
+        self._flush_pending()
+        self._check(self.api.drain_prefetch(self._h))
+
+    def drain_wait(self) -> None:
+        """jg_drain_wait: block until the batch in transfer (if any) has landed."""
+        self._check(self.api.drain_wait(self._h))
+
+    def drain_flush(self) -> None:
+        """jg_drain_flush: block until everything stepped so far has landed in the host queues."""
+        self._flush_pending()
+        self._check(self.api.drain_flush(self._h))
+
     def drain_faults(self) -> np.ndarray:
         return self._drain(self.api.drain_faults, capi.FAULT_DTYPE)
 
