@@ -43,6 +43,23 @@ def survey_bytes_per_group_step(R: int) -> int:
     return 24 * R + 36
 
 
+def effective_cores() -> int:
+    """Host cores this process may actually use: the scheduler affinity mask and the cgroup CPU
+    quota (the GPU box advertises 256 hardware threads and grants 16 CPUs' worth of time)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(R: int, seed: int, budget_s: float):
     """Time the CPU oracle (the reference-shaped C++ port: per ack HashMap remove/insert +
     Vec sort, progress.rs:42-60) on a bounded sample of the same workload."""
@@ -71,7 +88,7 @@ def cpu_baseline(R: int, seed: int, budget_s: float):
     # GIL for the whole tick), each with a PRIVATE engine over its own 10 k groups - Raft groups are
     # independent, so the threads never meet: no per-tick barrier, no thread creation in the timed
     # region.  Every thread applies the same number of ticks; the clock is the slowest thread's.
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     mt = None
     if cores > 1:
         import threading
@@ -105,7 +122,7 @@ def cpu_baseline(R: int, seed: int, budget_s: float):
         "value": dec / dt, "unit": "decisions/s", "cores": 1, "kind": "port",
         "sample": f"{Gs} groups x {R} replicas x {done} ticks of the same steady-state stream, "
                   f"C++ oracle (Rust reference not buildable here: no cargo)",
-        "all_cores_value": mt, "all_cores": cores,
+        "all_cores_value": mt, "all_cores": cores, "hardware_threads": os.cpu_count(),
     }
     if mt:
         out["all_cores_sample"] = f"{cores} threads x private engine of {Gt} groups x {R} replicas x {Tt} ticks"

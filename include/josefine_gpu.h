@@ -39,6 +39,7 @@ extern "C" {
 #define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
 #define JG_CHAIN_WINDOW 8u  /* chain segments (gaps / forks) per group besides the main run */
 #define JG_MAX_INFLIGHT 5u  /* src/raft/progress.rs:117                                    */
+#define JG_FOREIGN_VOTERS 8u /* distinct voters outside the membership an election remembers */
 #define JG_NO_ACK UINT64_MAX /* dense ack column: "no AppendResponse from this replica"    */
 #define JG_MAX_DEVICES 16u  /* shards (devices) behind one engine handle                      */
 #define JG_MAX_DENSE_APPENDS (1u << 20) /* own slot of a dense ack block: appends per group per tick */
@@ -125,7 +126,8 @@ enum {
   JG_FAULT_CANDIDATE_TICK_ELECTED = 7,    /* candidate.rs:64 panic!("this should never happen")    */
   JG_FAULT_RANGE_HIT_COMMIT_KEY = 8,      /* chain.rs:198 + 219-226 via leader.rs:135,152-157 (Q9) */
   JG_FAULT_ENGINE_WINDOW_OVERFLOW = 128,  /* chain needs > JG_CHAIN_WINDOW segments (gaps / forks) */
-  JG_FAULT_ENGINE_FOREIGN_VOTER = 129,    /* VoteResponse.from not in the configured membership    */
+  JG_FAULT_ENGINE_FOREIGN_VOTER = 129,    /* a 9th distinct voter outside the membership in one election
+                                             (the first JG_FOREIGN_VOTERS are counted, election.rs:33-35) */
   JG_FAULT_ENGINE_DENSE_NONLEADER = 131,  /* dense tick asked a non-leader group to append         */
   JG_FAULT_ENGINE_DENSE_APPENDS = 132     /* own slot of a dense ack block >= JG_MAX_DENSE_APPENDS */
 };
@@ -399,6 +401,20 @@ int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbo
 int jg_chain_compact(jg_engine* e, size_t n_trees, const uint64_t* off /*[n_trees+1]*/,
                      const uint64_t* ids, const uint64_t* nexts, const uint64_t* commits /*[n_trees]*/,
                      uint8_t* removed /* [off[n_trees]] out */);
+
+/* Chain::compact (src/raft/chain.rs:239-253, incl. its quirk Q7: the parent pointer of a REMOVED
+ * block is followed too) on the resident chain of every healthy group: the blocks below the
+ * commit index that the walk removes leave the engine's id set, and are queued as rows for the
+ * host to delete from its block store (jg_drain_compacted: group ascending, ids descending = the
+ * order of the walk).  *n_removed (optional) = rows this call queued.  The reference never calls
+ * compact() outside its test; a host that wants its dead branches gone calls this between steps. */
+typedef struct jg_compact_row {
+  uint32_t group;
+  uint32_t pad;
+  uint64_t id; /* BlockId removed from the chain of `group` */
+} jg_compact_row;
+int jg_chain_compact_resident(jg_engine* e, size_t* n_removed);
+int jg_drain_compacted(jg_engine* e, jg_compact_row* out, size_t cap, size_t* n);
 
 int jg_sync(jg_engine* e);
 

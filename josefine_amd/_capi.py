@@ -14,6 +14,7 @@ MAX_REPLICAS = 8
 CHAIN_WINDOW = 8
 MAX_INFLIGHT = 5
 MAX_DEVICES = 16
+FOREIGN_VOTERS = 8
 MAX_DENSE_APPENDS = 1 << 20
 NO_ACK = 0xFFFFFFFFFFFFFFFF
 
@@ -137,6 +138,7 @@ MSG_DTYPE = [("group", "<u4"), ("kind", "u1"), ("to_kind", "u1"), ("flag", "u1")
              ("to_id", "<u4"), ("from", "<u4"), ("term", "<u8"), ("id", "<u8"), ("aux", "<u8")]
 FSM_DTYPE = [("group", "<u4"), ("kind", "u1"), ("pad", "u1", (3,)), ("a", "<u8"), ("b", "<u8")]
 FAULT_DTYPE = [("group", "<u4"), ("code", "<u4")]
+COMPACT_DTYPE = [("group", "<u4"), ("pad", "<u4"), ("id", "<u8")]
 
 _P = C.c_void_p
 
@@ -155,6 +157,8 @@ class Api:
         "step_dense_leader": (C.c_int, [_P, C.c_uint64, C.POINTER(LeaderInbox), C.POINTER(LeaderOutbox)]),
         "step_dense_follower": (C.c_int, [_P, C.c_uint64, C.POINTER(FollowerInbox), C.POINTER(FollowerOutbox), C.c_int]),
         "chain_compact": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, _P]),
+        "chain_compact_resident": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+        "drain_compacted": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
         "drain_messages": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
         "drain_applies": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
         "drain_faults": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -224,7 +228,7 @@ class Api:
 HEADER_SYMBOLS = [
     "jg_engine_create", "jg_engine_destroy", "jg_shard_count", "jg_get_shard", "jg_step_dense_acks_shards", "jg_set_self_slots", "jg_submit", "jg_step", "jg_step_device_rows",
     "jg_step_dense_acks", "jg_step_dense_acks_device", "jg_step_dense_acks_device_n",
-    "jg_step_dense_leader", "jg_step_dense_follower", "jg_chain_compact", "jg_sync", "jg_stream_wait",
+    "jg_step_dense_leader", "jg_step_dense_follower", "jg_chain_compact", "jg_chain_compact_resident", "jg_drain_compacted", "jg_sync", "jg_stream_wait",
     "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_drain_prefetch", "jg_drain_flush", "jg_drain_wait", "jg_read_state", "jg_get_counters",
     "jg_device_alloc", "jg_device_free", "jg_device_upload", "jg_device_download",
     "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",

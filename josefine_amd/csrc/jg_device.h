@@ -18,7 +18,8 @@
 //             [0, head] with next(id) = id-1; the run_hi column is implicit.  What
 //             followers have (extend does not advance id_gen: chain.rs:178-192, Q8)
 //  bit  5     the "commit" key has been persisted               chain.rs:198
-//  bit  6     (free)
+//  bit  6     the run is EMPTY: Chain::compact removed block 0 (chain.rs:246); the id set is the
+//             window segments only and run_hi means nothing
 //  bits 8-15  bit r: progress of slot r is Replicate (else Probe) progress.rs:62-66
 //  bits 16-23 sticky fault code (JG_FAULT_*)
 //  bits 24-26 own replica slot
@@ -28,6 +29,7 @@
 #define JGF_HAS_LEADER (1u << 3)
 #define JGF_FAST (1u << 4)
 #define JGF_COMMIT_KEY (1u << 5)
+#define JGF_NO_GENESIS (1u << 6)
 #define JGF_RUN (1u << 7)
 #define JGF_REPL_SHIFT 8
 #define JGF_REPL_MASK (0xffu << JGF_REPL_SHIFT)
@@ -79,6 +81,8 @@ struct JgDev {
   uint32_t* rng_draws;       // draws taken from the timeout RNG
   uint32_t* queued;          // queued_reqs.len()                      follower.rs:22
   uint32_t* votes;           // Election.votes: seen | granted << 8    election.rs:8
+                             //   bits 16-23 / 24-31: the same two masks for voters OUTSIDE the membership
+  uint32_t* fvote_id;        // [JG_FOREIGN_VOTERS][G] their NodeIds (election.rs:33-35 counts whoever answers)
   uint64_t* blk_decisions;   // per-workgroup decision counters (no atomics on the hot path)
   JgFaultRec* fault_q;
   uint32_t* fault_q_n;
@@ -237,7 +241,7 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
 __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   uint32_t g = L.g;
   if (jg_wcnt(L)) jg_chain_normalize(d, L);
-  const bool run = (L.run_hi == L.head) && (jg_wcnt(L) == 0);
+  const bool run = (L.run_hi == L.head) && (jg_wcnt(L) == 0) && !(L.flags & JGF_NO_GENESIS);
   const bool fast = run && (L.id_gen == L.head + 1);
   L.flags = run ? (L.flags | JGF_RUN) : (L.flags & ~JGF_RUN);
   L.flags = fast ? (L.flags | JGF_FAST) : (L.flags & ~JGF_FAST);
@@ -335,8 +339,11 @@ __device__ inline int jg_seg_find(const JgDev& d, const JgLane& L, uint64_t id) 
     if (JG_SEG(win_lo, w) <= id && id <= JG_SEG(win_hi, w)) return (int)w;
   return -1;
 }
+__device__ __forceinline__ bool jg_in_run(const JgLane& L, uint64_t id) {
+  return !(L.flags & JGF_NO_GENESIS) && id <= L.run_hi;
+}
 __device__ inline bool jg_chain_has(const JgDev& d, const JgLane& L, uint64_t id) {  // chain.rs:155-157
-  if (id <= L.run_hi) return true;
+  if (jg_in_run(L, id)) return true;
   return jg_seg_find(d, L, id) >= 0;
 }
 __device__ inline uint32_t jg_seg_add(const JgDev& d, JgLane& L, uint64_t lo, uint64_t hi, uint64_t lo_next) {
@@ -350,7 +357,7 @@ __device__ inline uint32_t jg_seg_add(const JgDev& d, JgLane& L, uint64_t lo, ui
 }
 // make `id` (which exists) the first id of its segment
 __device__ inline uint32_t jg_seg_split_at(const JgDev& d, JgLane& L, uint64_t id) {
-  if (id <= L.run_hi) {
+  if (jg_in_run(L, id)) {
     if (id == 0) return 0;
     uint64_t hi = L.run_hi;
     L.run_hi = id - 1;
@@ -366,7 +373,7 @@ __device__ inline uint32_t jg_seg_split_at(const JgDev& d, JgLane& L, uint64_t i
 __device__ inline uint32_t jg_chain_insert(const JgDev& d, JgLane& L, uint64_t id, uint64_t next) {
   if (jg_chain_has(d, L, id)) {
     uint64_t cur;
-    if (id <= L.run_hi) {
+    if (jg_in_run(L, id)) {
       cur = id ? id - 1 : 0;
     } else {
       int w = jg_seg_find(d, L, id);
@@ -385,7 +392,13 @@ __device__ inline uint32_t jg_chain_insert(const JgDev& d, JgLane& L, uint64_t i
     JG_SEG(win_next, w) = next;
     return 0;
   }
-  if (id == L.run_hi + 1 && next == L.run_hi) {
+  if (L.flags & JGF_NO_GENESIS) {
+    if (id == 0 && next == 0) {  // genesis again (Chain::new on a tree without a commit key, chain.rs:132-153)
+      L.flags &= ~JGF_NO_GENESIS;
+      L.run_hi = 0;
+      return 0;
+    }
+  } else if (id == L.run_hi + 1 && next == L.run_hi) {
     L.run_hi = id;
     return 0;
   }
@@ -403,7 +416,7 @@ __device__ inline uint32_t jg_chain_insert(const JgDev& d, JgLane& L, uint64_t i
 // RUN / FAST flags and the dense mailbox vocabulary are defined on.
 __device__ inline void jg_chain_normalize(const JgDev& d, JgLane& L) {
   uint32_t n = jg_wcnt(L);
-  bool merged = n != 0;
+  bool merged = n != 0 && !(L.flags & JGF_NO_GENESIS);
   while (merged) {
     merged = false;
     for (uint32_t w = 0; w < n; w++) {
@@ -425,7 +438,7 @@ __device__ inline void jg_chain_normalize(const JgDev& d, JgLane& L) {
 // number of block keys >= from, saturated at `cap` (unbounded range(from..), leader.rs:135,152-157)
 __device__ inline uint32_t jg_chain_blocks_from(const JgDev& d, const JgLane& L, uint64_t from, uint32_t cap) {
   uint64_t k = 0;
-  if (from <= L.run_hi) {
+  if (jg_in_run(L, from)) {
     k = L.run_hi - from + 1;
     if (k >= cap) return cap;
   }
@@ -625,9 +638,10 @@ __device__ inline uint32_t jg_leader_tick(const JgDev& d, JgLane& L) {  // leade
 }
 
 // ---- Candidate (src/raft/candidate.rs) + Election (src/raft/election.rs) -----------------
-// 0 = Voting, 1 = Elected, 2 = Defeated (election.rs:37-57, quorum_size 66-73)
+// 0 = Voting, 1 = Elected, 2 = Defeated (election.rs:37-57, quorum_size 66-73).  The fold runs over
+// every entry of the votes map: members (bits 0-7 / 8-15) and foreign voters (bits 16-23 / 24-31).
 __device__ inline uint32_t jg_election_status(const JgDev& d, const JgLane& L) {
-  uint32_t seen = L.votes & 0xffu, granted = (L.votes >> 8) & 0xffu;
+  uint32_t seen = (L.votes & 0xffu) | ((L.votes >> 8) & 0xff00u), granted = ((L.votes >> 8) & 0xffu) | ((L.votes >> 16) & 0xff00u);
   uint32_t yes = __popc(granted & seen), total = __popc(seen);
   uint32_t quorum = d.R == 1 ? 0u : d.R / 2 + 1;
   if (yes >= quorum) return 1;
@@ -637,8 +651,22 @@ __device__ inline uint32_t jg_election_status(const JgDev& d, const JgLane& L) {
 __device__ inline uint32_t jg_candidate_vote_response(const JgDev& d, JgLane& L, bool granted, uint32_t from) {
   // candidate.rs:91-98
   int s = jg_slot_of(d, from);
-  if (s < 0) return JG_FAULT_ENGINE_FOREIGN_VOTER;
-  uint32_t bit = 1u << s;
+  if (s < 0) {
+    // votes.insert(id, vote) does not ask who `id` is (election.rs:33-35): a voter outside the
+    // membership takes (or re-uses: a later vote overwrites) one of JG_FOREIGN_VOTERS table entries
+    const uint32_t fseen = (L.votes >> 16) & 0xffu;
+    int k = -1;
+    for (uint32_t i = 0; i < JG_FOREIGN_VOTERS; i++)
+      if (((fseen >> i) & 1u) && d.fvote_id[(size_t)i * d.G + L.g] == from) k = (int)i;
+    if (k < 0) {
+      const uint32_t free_mask = ~fseen & ((1u << JG_FOREIGN_VOTERS) - 1u);
+      if (!free_mask) return JG_FAULT_ENGINE_FOREIGN_VOTER;  // a 9th distinct stranger: the table is full
+      k = __ffs(free_mask) - 1;
+      d.fvote_id[(size_t)k * d.G + L.g] = from;
+    }
+    s = 16 + k;
+  }
+  const uint32_t bit = 1u << s;
   L.votes |= bit;                                                         // election.rs:33-35
   L.votes = granted ? (L.votes | (bit << 8)) : (L.votes & ~(bit << 8));
   L.decisions++;

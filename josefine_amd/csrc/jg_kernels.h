@@ -123,7 +123,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
       c.flag = 0;
       c.id = 0;
       if (jg_wcnt(L)) jg_chain_normalize(d, L);
-      const bool fast = L.run_hi == L.head && L.id_gen == L.head + 1 && jg_wcnt(L) == 0;
+      const bool fast = L.run_hi == L.head && L.id_gen == L.head + 1 && jg_wcnt(L) == 0 && !(L.flags & JGF_NO_GENESIS);
       if (!fast) {
         jg_apply(d, L, c, nullptr, nullptr);  // rows: the blocks are not id-consecutive
       } else {                                // columns, via a local row buffer
@@ -183,6 +183,116 @@ __global__ void k_chain_compact(size_t n_trees, const uint64_t* __restrict__ off
       next_id = nexts[best_i];                                // :249
       bound = best;
     }
+  }
+}
+
+// ---- Chain::compact on the engine's own chains (chain.rs:239-253) ------------------------------
+// The walk visits the block keys below `commit` in descending order; the first is kept, every
+// later block b is removed when b.id != next_id, and next_id = b.next either way (Q7: also for a
+// removed block).  On the segment representation (jg_device.h "Chain") that is a walk over the
+// segments in descending order: inside a segment every id is the parent pointer of the id above
+// it, so only the TOP id of a segment can ever be removed (when it is not the parent the segment
+// above ended on) - and then its own parent pointer (top-1) keeps the rest of the dead branch
+// alive, exactly as the reference's walk does.  One lane per group; the (at most 9) segments of a
+// lane are staged and sorted in LDS (dynamic indexing without scratch memory).
+struct JgCompactRow {
+  uint32_t group, pad;
+  uint64_t id;
+};
+#define JG_COMPACT_SEGS (JG_CHAIN_WINDOW + 1)
+__global__ __launch_bounds__(JG_BLOCK) void k_compact_resident(JgDev d, JgCompactRow* __restrict__ out,
+                                                                uint32_t* __restrict__ out_n, uint32_t out_cap,
+                                                                uint32_t seq) {
+  __shared__ uint64_t s_lo[JG_COMPACT_SEGS][JG_BLOCK], s_hi[JG_COMPACT_SEGS][JG_BLOCK], s_nx[JG_COMPACT_SEGS][JG_BLOCK];
+  __shared__ uint8_t s_ix[JG_COMPACT_SEGS][JG_BLOCK];  // which stored segment (0 = the run, w+1 = window w)
+  const uint32_t t = threadIdx.x;
+  const uint32_t g_end = ((d.G + JG_BLOCK - 1) / JG_BLOCK) * JG_BLOCK;  // whole waves take every iteration together
+  for (uint32_t g0 = blockIdx.x * JG_BLOCK + t; g0 < g_end; g0 += gridDim.x * JG_BLOCK) {
+    const bool in_range = g0 < d.G;
+    const uint32_t g = in_range ? g0 : 0;
+    JgLane L;
+    jg_load(d, L, g);
+    L.now = 0;
+    L.seq = seq;
+    L.mp = L.mend = nullptr;
+    L.fp = L.fend = nullptr;
+    const bool live = in_range && !jg_fault(L);  // (the reference process of a faulted group is gone)
+    const uint64_t commit = L.commit;
+    const uint32_t nw = live ? jg_wcnt(L) : 0;
+    // stage: segment 0 = the run [0, run_hi] (genesis: next(0) = 0), then the window segments
+    uint32_t n = 0;
+    if (live && !(L.flags & JGF_NO_GENESIS)) {
+      s_lo[0][t] = 0, s_hi[0][t] = L.run_hi, s_nx[0][t] = 0, s_ix[0][t] = 0;
+      n = 1;
+    }
+    for (uint32_t w = 0; w < nw; w++) {
+      s_lo[n][t] = JG_SEG(win_lo, w), s_hi[n][t] = JG_SEG(win_hi, w), s_nx[n][t] = JG_SEG(win_next, w);
+      s_ix[n][t] = (uint8_t)(w + 1);
+      n++;
+    }
+    // insertion sort, descending by first id (segments are disjoint intervals)
+    for (uint32_t i = 1; i < n; i++) {
+      const uint64_t lo = s_lo[i][t], hi = s_hi[i][t], nx = s_nx[i][t];
+      const uint8_t ix = s_ix[i][t];
+      uint32_t j = i;
+      while (j > 0 && s_lo[j - 1][t] < lo) {
+        s_lo[j][t] = s_lo[j - 1][t], s_hi[j][t] = s_hi[j - 1][t], s_nx[j][t] = s_nx[j - 1][t], s_ix[j][t] = s_ix[j - 1][t];
+        j--;
+      }
+      s_lo[j][t] = lo, s_hi[j][t] = hi, s_nx[j][t] = nx, s_ix[j][t] = ix;
+    }
+    // the walk (the same number of iterations for every lane of the wave: the removed-block rows
+    // are appended wave by wave, one atomic per wave and iteration instead of one per block)
+    bool have_next = false, changed = false;
+    uint64_t next_id = 0;
+    uint32_t drop_mask = 0;  // window segments that disappear (their only id was removed)
+    for (uint32_t i = 0; i < JG_COMPACT_SEGS; i++) {
+      const bool visit = live && i < n && s_lo[i < n ? i : 0][t] < commit;  // range(0..commit)
+      const uint64_t lo = visit ? s_lo[i][t] : 0, hi = visit ? s_hi[i][t] : 0;
+      const uint64_t top = hi < commit ? hi : commit - 1;  // (a segment that straddles commit starts the walk inside)
+      const bool remove = visit && have_next && top != next_id;  // chain.rs:244-247 — top == hi here
+      const uint64_t m = __ballot(remove);
+      if (m) {
+        const uint32_t lane = t & 63u;
+        const int first = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)lane == first) base = atomicAdd(out_n, (uint32_t)__popcll(m));
+        base = __shfl(base, first, 64);
+        if (remove) {
+          const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (at < out_cap) out[at] = JgCompactRow{g, i, top};  // pad = position in the walk (orders the rows of a group)
+          changed = true;
+          const uint32_t ix = s_ix[i][t];
+          if (ix == 0) {
+            if (top == 0) L.flags |= JGF_NO_GENESIS;  // block 0 itself: the run is empty from now on
+            else L.run_hi = top - 1;
+          } else if (hi == lo) {
+            drop_mask |= 1u << (ix - 1);
+          } else {
+            d.win_hi[(size_t)(ix - 1) * d.G + g] = hi - 1;
+          }
+        }
+      }
+      if (visit) {
+        have_next = true;
+        next_id = s_nx[i][t];  // = next(lo): everything between top and lo is the parent of the id above it
+      }
+    }
+    if (!changed) continue;
+    if (drop_mask) {  // close the gaps in the window columns
+      uint32_t k = 0;
+      for (uint32_t w = 0; w < nw; w++) {
+        if ((drop_mask >> w) & 1u) continue;
+        if (k != w) {
+          JG_SEG(win_lo, k) = JG_SEG(win_lo, w);
+          JG_SEG(win_hi, k) = JG_SEG(win_hi, w);
+          JG_SEG(win_next, k) = JG_SEG(win_next, w);
+        }
+        k++;
+      }
+      L.flags = (L.flags & ~JGF_WIN_MASK) | (k << JGF_WIN_SHIFT);
+    }
+    jg_store(d, L);
   }
 }
 

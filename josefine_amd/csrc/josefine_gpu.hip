@@ -206,6 +206,10 @@ struct jg_engine {
   PinnedQueue<jg_fsm_row> l_fsm;
   bool landed_m = false, landed_f = false;
   std::vector<jg_fault_row> q_faults;
+  std::vector<jg_compact_row> q_compacted;  // jg_chain_compact_resident -> jg_drain_compacted
+  JgCompactRow* d_compact = nullptr;        // device list of one compact pass (lazily allocated)
+  uint32_t* d_compact_n = nullptr;
+  uint32_t compact_cap = 0;
   PinnedQueue<jg_fault_row> h_faults;  // pinned landing buffers of the device queues (faults: sorted rows + steps)
   PinnedQueue<uint32_t> h_fault_seq;
   uint64_t *fs_k0 = nullptr, *fs_k1 = nullptr;  // device scratch of the fault sort (grow-only)
@@ -404,6 +408,20 @@ __global__ void k_fault_split(const JgFaultRec* __restrict__ q, uint32_t n, uint
     vals[i] = q[i].code;
   }
 }
+// the same for the rows of jg_chain_compact_resident: key = (group, position in the walk), value = id
+__global__ void k_compact_split(const JgCompactRow* __restrict__ q, uint32_t n, uint64_t* __restrict__ keys,
+                                uint64_t* __restrict__ vals) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    keys[i] = ((uint64_t)q[i].group << 8) | q[i].pad;
+    vals[i] = q[i].id;
+  }
+}
+__global__ void k_compact_join(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ vals, uint32_t n,
+                               jg_compact_row* __restrict__ rows) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    rows[i] = jg_compact_row{(uint32_t)(keys[i] >> 8), 0, vals[i]};
+}
+
 __global__ void k_fault_join(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
                              jg_fault_row* __restrict__ rows, uint32_t* __restrict__ seqs) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -984,6 +1002,7 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.rng_draws, G);
   A(d.queued, G);
   A(d.votes, G);
+  A(d.fvote_id, G * JG_FOREIGN_VOTERS);
   A(d.blk_decisions, e->count_slots);
   d.fault_q_cap = (uint32_t)std::max<size_t>(2 * G, 1024);
   A(e->fq[0], d.fault_q_cap);
@@ -1373,6 +1392,85 @@ int jg_chain_compact(jg_engine* e, size_t n_trees, const uint64_t* off, const ui
   HIPCHK(hipFree(d_next));
   HIPCHK(hipFree(d_commit));
   HIPCHK(hipFree(d_rem));
+  return JG_OK;
+}
+
+int jg_chain_compact_resident(jg_engine* e, size_t* n_removed) {
+  if (!e) return fail(JG_EINVAL, "null argument");
+  if (n_removed) *n_removed = 0;
+  if (e->router) {  // shard by shard; rows rebased to the parent's group numbers
+    for (size_t d = 0; d < e->router->D(); d++) {
+      jg_engine* s = e->router->sh[d];
+      size_t n = 0;
+      const int rc = jg_chain_compact_resident(s, &n);
+      if (rc) return rc;
+      for (jg_compact_row r : s->q_compacted) {
+        r.group += e->router->lo[d];
+        e->q_compacted.push_back(r);
+      }
+      s->q_compacted.clear();
+      if (n_removed) *n_removed += n;
+    }
+    return JG_OK;
+  }
+  if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->d_compact) {
+    // one pass removes at most one block per segment: (JG_CHAIN_WINDOW + 1) rows per group
+    e->compact_cap = (uint32_t)std::min<size_t>((size_t)(JG_CHAIN_WINDOW + 1) * e->cfg.n_groups, 0x7fffffffu);
+    HIPCHK(hipMalloc((void**)&e->d_compact, (size_t)e->compact_cap * sizeof(JgCompactRow)));
+    HIPCHK(hipMalloc((void**)&e->d_compact_n, 16));
+    e->allocs.push_back(e->d_compact);
+    e->allocs.push_back(e->d_compact_n);
+  }
+  e->stepped = true;
+  e->seq++;
+  HIPCHK(hipMemsetAsync(e->d_compact_n, 0, sizeof(uint32_t), e->stream));
+  hipLaunchKernelGGL(k_compact_resident, dim3(grid_for(e->cfg.n_groups, 4096)), dim3(JG_BLOCK), 0, e->stream, e->dev,
+                     e->d_compact, e->d_compact_n, e->compact_cap, e->seq);
+  HIPCHK(hipGetLastError());
+  e->n_launch++;
+  e->maybe_irregular = true;  // a leader's run may have lost its top: like a sparse step
+  e->flag_check_pending = true;
+  uint32_t n = 0;
+  HIPCHK(hipMemcpyAsync(&n, e->d_compact_n, sizeof n, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (n > e->compact_cap) return fail(JG_ECAPACITY, "more blocks removed than the compaction list holds (the chains ARE compacted)");
+  if (n) {  // order the rows on the device: group ascending, then the order of the walk (ids descending)
+    uint64_t *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr;
+    jg_compact_row *d_rows = nullptr, *h_rows = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    HIPCHK(hipMalloc((void**)&k0, (size_t)n * 8));
+    HIPCHK(hipMalloc((void**)&k1, (size_t)n * 8));
+    HIPCHK(hipMalloc((void**)&v0, (size_t)n * 8));
+    HIPCHK(hipMalloc((void**)&v1, (size_t)n * 8));
+    HIPCHK(hipMalloc((void**)&d_rows, (size_t)n * sizeof(jg_compact_row)));
+    HIPCHK(hipHostMalloc((void**)&h_rows, (size_t)n * sizeof(jg_compact_row), hipHostMallocDefault));
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, v0, v1, (size_t)n, 0, 40, e->stream));
+    HIPCHK(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    const uint32_t grid = grid_for(n, 4096);
+    hipLaunchKernelGGL(k_compact_split, dim3(grid), dim3(JG_BLOCK), 0, e->stream, (const JgCompactRow*)e->d_compact, n, k0, v0);
+    HIPCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, (size_t)n, 0, 40, e->stream));
+    hipLaunchKernelGGL(k_compact_join, dim3(grid), dim3(JG_BLOCK), 0, e->stream, (const uint64_t*)k1, (const uint64_t*)v1, n, d_rows);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_rows, d_rows, (size_t)n * sizeof(jg_compact_row), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->q_compacted.insert(e->q_compacted.end(), h_rows, h_rows + n);
+    for (void* p : {(void*)k0, (void*)k1, (void*)v0, (void*)v1, (void*)d_rows, tmp}) HIPCHK(hipFree(p));
+    HIPCHK(hipHostFree(h_rows));
+  }
+  if (n_removed) *n_removed = n;
+  return JG_OK;
+}
+
+int jg_drain_compacted(jg_engine* e, jg_compact_row* out, size_t cap, size_t* n) {
+  if (!e || !n) return fail(JG_EINVAL, "null argument");
+  *n = e->q_compacted.size();
+  if (!out) return JG_OK;
+  if (cap < *n) return fail(JG_ECAPACITY, "output buffer too small");
+  if (*n) std::memcpy(out, e->q_compacted.data(), *n * sizeof(jg_compact_row));
+  e->q_compacted.clear();
   return JG_OK;
 }
 

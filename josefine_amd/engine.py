@@ -496,6 +496,14 @@ class BatchedRaft:
                                            nexts.ctypes.data, commits.ctypes.data, removed.ctypes.data))
         return [removed[int(off[i]):int(off[i + 1])].copy() for i in range(len(trees))]
 
+    def chain_compact_resident(self) -> np.ndarray:
+        """jg_chain_compact_resident + jg_drain_compacted: Chain::compact on every healthy group's own
+        chain; returns the removed blocks as (group, id) rows, group ascending, ids in walk order."""
+        self._flush_pending()
+        n = C.c_size_t(0)
+        self._check(self.api.chain_compact_resident(self._h, C.byref(n)))
+        return self._drain(self.api.drain_compacted, capi.COMPACT_DTYPE)
+
     def handle(self, group: int) -> "RaftHandle":
         return RaftHandle(self, group)
 

@@ -158,10 +158,15 @@ class BatchedRaft {
   std::function<void(const Instruction&)> fsm_tx;
 
   // RaftHandle::new for n_groups groups (mod.rs:428-435)
+  // `devices`: shard the groups over these HIP devices behind this one handle (jg_config.n_devices:
+  // contiguous ownership, a device may repeat) — one event loop still owns the handle, as in the
+  // reference (server.rs:103-165); empty = one shard on `device`.
   BatchedRaft(uint32_t n_groups, std::vector<NodeId> node_ids, int device = 0, uint64_t seed = 0,
-              uint32_t flags = 0)
+              uint32_t flags = 0, std::vector<int> devices = {})
       : stores_(n_groups), queued_(n_groups), ids_(node_ids) {
     jg_config c{};
+    c.n_devices = (uint32_t)devices.size();
+    for (size_t d = 0; d < devices.size() && d < JG_MAX_DEVICES; d++) c.device_ids[d] = devices[d];
     c.abi_version = JG_ABI_VERSION;
     c.n_groups = n_groups;
     c.n_replicas = (uint32_t)node_ids.size();

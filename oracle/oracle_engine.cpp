@@ -9,6 +9,7 @@
 // src/raft/progress.rs:42-60).
 #include "raft_oracle.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -26,6 +27,7 @@ struct jo_engine {
   std::vector<jg_msg_row> msgs;
   std::vector<jg_fsm_row> fsms;
   std::vector<jg_fault_row> faults;
+  std::vector<jg_compact_row> compacted;
   uint64_t counters[4] = {0, 0, 0, 0};
   unsigned threads = 1;
 };
@@ -439,6 +441,30 @@ int jo_chain_compact(jo_engine*, size_t n_trees, const uint64_t* off, const uint
     c.commit = commits[t];
     for (BlockId id : c.compact()) removed[last[id]] = 1;
   }
+  return JG_OK;
+}
+
+// Chain::compact on every healthy group's own chain; removed blocks queued as (group, id) rows,
+// group ascending, ids descending (the order of the walk).
+int jo_chain_compact_resident(jo_engine* e, size_t* n_removed) {
+  size_t n = 0;
+  for (uint32_t g = 0; g < e->cfg.n_groups; g++) {
+    Raft& r = e->groups[g];
+    if (r.fault) continue;
+    std::vector<BlockId> gone = r.chain.compact();
+    std::sort(gone.begin(), gone.end(), [](BlockId a, BlockId b) { return a > b; });
+    for (BlockId id : gone) e->compacted.push_back(jg_compact_row{g, 0, id});
+    n += gone.size();
+  }
+  if (n_removed) *n_removed = n;
+  return JG_OK;
+}
+int jo_drain_compacted(jo_engine* e, jg_compact_row* out, size_t cap, size_t* n) {
+  *n = e->compacted.size();
+  if (!out) return JG_OK;
+  if (cap < *n) return fail(JG_ECAPACITY, "output buffer too small");
+  if (*n) std::memcpy(out, e->compacted.data(), *n * sizeof(jg_compact_row));
+  e->compacted.clear();
   return JG_OK;
 }
 

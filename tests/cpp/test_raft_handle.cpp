@@ -241,6 +241,64 @@ static void server_event_loops_three_nodes() {
     }
 }
 
+// The same event loop over a MULTI-DEVICE engine (jg_config.n_devices: 3 shards, aliased onto device
+// 0 here): one handle, one loop (server.rs:103-165), 10 single-node partitions; every partition elects
+// itself from its own timer, a proposal per partition is committed, applied and answered, and the
+// per-partition outcome is what the single-device engine gives.
+static void server_event_loop_multi_device() {
+  const uint32_t G = 10;
+  std::vector<std::vector<uint8_t>> applied_one(G), applied_multi(G);
+  for (int multi = 0; multi < 2; multi++) {
+    BatchedRaft raft(G, {1}, 0, 7, 0, multi ? std::vector<int>{0, 0, 0} : std::vector<int>{});
+    CHECK(jg_shard_count(raft.raw()) == (multi ? 3u : 1u));
+    BatchedEventLoop loop(raft, G);
+    auto& applied = multi ? applied_multi : applied_one;
+    loop.fsm = [&applied](uint32_t g, const std::vector<uint8_t>& data) {
+      applied[g].insert(applied[g].end(), data.begin(), data.end());
+      return data;
+    };
+    loop.run_until(2000);
+    uint32_t answered = 0;
+    for (uint32_t g = 0; g < G; g++) {
+      CHECK(raft.handle(g).is_leader());
+      loop.propose(g, {(uint8_t)(g + 1), 9}, [&answered](bool ok, const std::vector<uint8_t>&) { answered += ok; });
+    }
+    loop.run_until(2300);
+    CHECK(answered == G && loop.pending_requests() == 0);
+    for (uint32_t g = 0; g < G; g++) CHECK(raft.handle(g).commit() == 1 && raft.handle(g).head() == 1);
+  }
+  CHECK(applied_one == applied_multi);
+  for (uint32_t g = 0; g < G; g++) CHECK((applied_multi[g] == std::vector<uint8_t>{(uint8_t)(g + 1), 9}));
+}
+
+// fsm fan-out where KEY order is not PARENT order: a follower whose chain
+// holds a dead branch.  range(prev..commit) (follower.rs:204) walks the keys, so the dead block is
+// applied too, exactly as the reference's sled iterator would deliver it: ids 1 <- 2 <- 3 (dead) and
+// 2 <- 4 <- 5; commit 5 applies keys [0, 5) = 0, 1, 2, 3, 4 (genesis is skipped by the driver, fsm.rs:59-61).
+static void fsm_apply_walks_keys_not_parents() {
+  BatchedRaft raft(1, {1, 2, 3});
+  std::vector<uint8_t> seen;
+  BatchedEventLoop loop(raft, 1);
+  loop.fsm = [&seen](uint32_t, const std::vector<uint8_t>& data) {
+    seen.insert(seen.end(), data.begin(), data.end());
+    return data;
+  };
+  auto blk = [](BlockId id, BlockId next) {
+    Block b;
+    b.id = id, b.next = next, b.data = {(uint8_t)(10 * id)};
+    return b;
+  };
+  Message m;
+  m.group = 0;
+  m.command = Command::AppendEntries(1, 2, {blk(1, 0), blk(2, 1), blk(3, 2), blk(4, 2), blk(5, 4)});
+  loop.tcp_rx(m);
+  m.command = Command::Heartbeat(1, 5, 2);
+  loop.tcp_rx(m);
+  loop.run_until(0);
+  CHECK(raft.handle(0).head() == 5 && raft.handle(0).commit() == 5 && raft.handle(0).fault() == 0);
+  CHECK((seen == std::vector<uint8_t>{10, 20, 30, 40}));  // keys 1..4 in key order, the dead block 3 included
+}
+
 int main() {
   try {
     apply_entry_single_node();
@@ -252,6 +310,10 @@ int main() {
 #endif
     server_event_loop_single_node();
     server_event_loops_three_nodes();
+    fsm_apply_walks_keys_not_parents();
+#ifndef JG_TEST_AGAINST_ORACLE
+    server_event_loop_multi_device();
+#endif
   } catch (const std::exception& e) {
     std::fprintf(stderr, "exception: %s\n", e.what());
     return 2;

@@ -33,7 +33,10 @@ def random_batch(rng: np.random.Generator, ora, n: int, foreign_voters: bool = F
     stranger = rng.random(n) < 0.02
     if not foreign_voters:
         stranger &= kind != capi.CMD_VOTE_RESPONSE
-    from_ = np.where(stranger, np.uint32(4242), from_).astype(np.uint32)
+    # strangers: one foreign id, or (foreign_voters) six of them - Election::vote counts whoever
+    # answers (election.rs:33-35); the engine remembers up to JG_FOREIGN_VOTERS distinct ones
+    sid = np.uint32(4242) if not foreign_voters else (4242 + rng.integers(0, 6, n)).astype(np.uint32)
+    from_ = np.where(stranger, sid, from_).astype(np.uint32)
     term = np.maximum(term_now[group] + rng.integers(-1, 3, n), 0).astype(np.uint64)
     idv = np.maximum(head_now[group] + rng.integers(-2, 3, n), 0)
     use_commit = rng.random(n) < 0.3

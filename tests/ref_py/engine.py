@@ -169,6 +169,23 @@ class RefEngine:
             out.append(np.array([0 if ch.db.contains_key(rr.block_key(b_id)) else 1 for b_id, _ in blocks], np.uint8))
         return out
 
+    def chain_compact_resident(self):
+        """Chain::compact (chain.rs:239-253) on every healthy group's own chain -> removed (group, id)
+        rows, group ascending, ids in the order of the walk (descending)."""
+        rows = []
+        for g in range(self.G):
+            if self.fault[g]:
+                continue
+            ch = self.groups[g].chain
+            before = [k for k in ch.db.keys if len(k) == 8]
+            ch.compact()
+            gone = sorted((int.from_bytes(k, "big") for k in before if not ch.db.contains_key(k)), reverse=True)
+            rows += [(g, 0, i) for i in gone]
+        a = np.zeros(len(rows), dtype=capi.COMPACT_DTYPE)
+        for i, r in enumerate(rows):
+            a[i] = r
+        return a
+
     def apply_all(self, cmd, now_ms=0):
         n = self.G
         self.submit_columns(np.full(n, cmd.kind, np.uint8), np.arange(n, dtype=np.uint32),

@@ -39,6 +39,17 @@ def test_cpp_host_logic_on_oracle():
     assert "cpp adapter ok" in r.stdout
 
 
+def test_host_formats_kats():
+    """CPU: josefine_amd/host/formats.hpp — the sled key / bincode value encoding of the chain store
+    and the length-delimited serde_json peer protocol, against the
+    reference's own vectors (chain.rs:345-350, tcp.rs:172-232) and one vector per Command."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_formats.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "test_formats")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-o", exe, src], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "formats ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_adapter_runs_reference_tests():
     compile_adapter_test()

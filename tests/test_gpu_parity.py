@@ -59,7 +59,7 @@ def test_fuzz_command_stream_parity(R):
     now = 0
     budget = np.full(G, capi.CHAIN_WINDOW - 2)  # gaps / forks per group: stay inside the segment window
     for step in range(60):
-        batch = random_batch(rng, ora, 1500, budget=budget)
+        batch = random_batch(rng, ora, 1500, budget=budget, foreign_voters=True)
         now += int(rng.integers(0, 400))
         for e in (dev, ora):
             e.submit_columns(**batch)

@@ -61,7 +61,7 @@ def test_interleaved_entry_points(R, flags, seed):
                 e.submit_columns(kind, grp, from_=frm, term=np.ones(len(kind), np.uint64), flag=np.ones(len(kind), np.uint8))
                 e.step(now)
         elif op == "sparse":
-            batch = random_batch(rng, ora, 900, budget=budget)
+            batch = random_batch(rng, ora, 900, budget=budget, foreign_voters=True)
             for e in (dev, ora):
                 e.submit_columns(**batch)
                 e.step(now)

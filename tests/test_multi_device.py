@@ -49,7 +49,7 @@ def test_sharded_engine_equals_single_engine_and_oracle(D, G, R):
             for e in engines:
                 e.step_dense_acks(acks)
         elif what == 2:      # random commands: every role, every kind, forks, faults
-            batch = random_batch(rng, ora, max(8, G // 2), budget=budget)
+            batch = random_batch(rng, ora, max(8, G // 2), budget=budget, foreign_voters=True)
             for e in engines:
                 e.submit_columns(**batch)
                 e.step(now)

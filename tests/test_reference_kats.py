@@ -475,3 +475,50 @@ def test_config_validation(make):  # src/raft/config.rs:60-84
         make(1, 9)                               # beyond JG_MAX_REPLICAS
     with pytest.raises(EngineError):
         make(1, 1, heartbeat_timeout_ms=1)       # heartbeat timeout is too low
+
+
+def test_votes_from_outside_the_membership_are_counted(make):  # election.rs:33-35: votes.insert(id, vote) asks no questions
+    """`Election::vote` counts whoever answers.  R = 5, quorum 3: the self-vote plus two strangers elect; a
+    stranger's later rejection overwrites its grant (election.rs:34); three strangers' rejections defeat."""
+    e, h = new_follower(make, 5)
+    h.apply(Command.Timeout())
+    h.apply(Command.VoteResponse(1, 77, True))
+    assert h.is_candidate()
+    h.apply(Command.VoteResponse(1, 77, False))   # overwrites: still one grant (self), one rejection
+    h.apply(Command.VoteResponse(1, 78, True))
+    assert h.is_candidate()
+    h.apply(Command.VoteResponse(1, 79, True))    # self + 78 + 79 = 3 = quorum
+    assert h.is_leader() and h.fault == 0
+    e2, h2 = new_follower(make, 5)
+    h2.apply(Command.Timeout())
+    for nid in (90, 91):
+        h2.apply(Command.VoteResponse(1, nid, False))
+    assert h2.is_candidate()
+    h2.apply(Command.VoteResponse(1, 92, False))  # total - yes == quorum -> Defeated
+    assert h2.is_follower() and h2.voted_for is None
+
+
+def test_strangers_never_outnumber_the_table(make):
+    """An undecided election has fewer than `quorum` grants and fewer than `quorum` rejections, so its votes
+    map holds at most 2 * (quorum - 1) <= 8 entries, the self-vote among them: at most 7 voters outside the
+    membership can ever be on record (R = 8, quorum 5).  The device engine's table of JG_FOREIGN_VOTERS = 8
+    entries per election therefore never fills; this walks the extreme case."""
+    e, h = new_follower(make, 8)
+    h.apply(Command.Timeout())
+    for k in range(4):
+        h.apply(Command.VoteResponse(1, 100 + k, False))
+    for k in range(3):
+        h.apply(Command.VoteResponse(1, 200 + k, True))
+    assert h.is_candidate() and h.fault == 0      # 7 strangers + self on record: yes = 4, no = 4
+    h.apply(Command.VoteResponse(1, 101, False))  # a known stranger repeats itself: nothing changes
+    assert h.is_candidate()
+    h.apply(Command.VoteResponse(1, 300, False))  # the 8th stranger decides it: no = 5 = quorum -> Defeated
+    assert h.is_follower() and h.fault == 0 and h.voted_for is None
+    e2, h2 = new_follower(make, 8)
+    h2.apply(Command.Timeout())
+    for k in range(4):
+        h2.apply(Command.VoteResponse(1, 100 + k, False))
+    for k in range(3):
+        h2.apply(Command.VoteResponse(1, 200 + k, True))
+    h2.apply(Command.VoteResponse(1, 103, True))  # a rejection turns into a grant (election.rs:34): yes = 5 -> Elected
+    assert h2.is_leader() and h2.fault == 0
