@@ -29,11 +29,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
 
-def alg_bytes_per_group_step(R: int) -> int:
+def alg_bytes_per_group_step(R: int, mode: int = 0) -> int:
     """Bytes the dense leader tick has to move per group-step with the engine's state layout
     (DESIGN.md "k_leader_tick_dense"): read R ack heads (8 B each) + the packed progress / commit
-    word 8 + head 8 + flags 4; write head 8  =>  8R + 28 (68 B at R = 5)."""
-    return 8 * R + 28
+    word 8 + head 8 + flags 4; write head 8  =>  B*(R) = 8R + 28 (68 B at R = 5).
+    The ragged stream (mode 1: drops, duplicates, 0-2 appends) changes the lags and the
+    Probe / Replicate bits of nearly every group every tick, so the packed word (8 B) and the flag
+    word (4 B) have to be written back as well: B*_ragged(R) = 8R + 40 (80 B at R = 5; PMC: 80.5 MB
+    per 1 M x 5 launch, profiles/traffic.json)."""
+    return 8 * R + 28 + (12 if mode == 1 else 0)
 
 
 def survey_bytes_per_group_step(R: int) -> int:
@@ -175,31 +179,12 @@ def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
     L.drain_messages(), L.drain_applies()
     api = L.api
 
-    def dalloc(e, nbytes):
-        p = C.c_void_p()
-        e._check(api.device_alloc(e._h, nbytes, C.byref(p)))
-        return p
-
-    acks = dalloc(L, 8 * R * G)          # row r: ack_head of node r; row 0: appends per round
-    hbr_has = dalloc(L, R * G)
-    hbr_commit = dalloc(L, 8 * R * G)
-    init = np.full((R, G), capi.NO_ACK, np.uint64)
-    init[0] = 1                            # one ClientRequest per group per round
-    L._check(api.device_upload(L._h, acks, init.ctypes.data, init.nbytes))
-    none = np.full((R, G), capi.HB_NONE, np.uint8)
-    L._check(api.device_upload(L._h, hbr_has, none.ctypes.data, none.nbytes))
-    o_term, o_hb = dalloc(L, 8 * G), dalloc(L, 8 * G)
-    o_from, o_n = dalloc(L, 8 * R * G), dalloc(L, R * G)
-    inbox = capi.LeaderInbox(acks.value, hbr_has.value, hbr_commit.value)
-    outbox = capi.LeaderOutbox(o_term.value, o_hb.value, o_from.value, o_n.value)
-    f_in, f_out = {}, {}
-    for r in range(1, R):
-        fi = capi.FollowerInbox()
-        fi.leader, fi.leader_id = None, L.node_ids[0]
-        fi.term, fi.hb_commit = o_term.value, o_hb.value
-        fi.ae_from, fi.ae_n = o_from.value + 8 * r * G, o_n.value + r * G
-        f_in[r] = fi
-        f_out[r] = capi.FollowerOutbox(acks.value + 8 * r * G, hbr_commit.value + 8 * r * G, hbr_has.value + r * G)
+    # the round is driven from inside the library (jg_dense_cluster_*: leader half, then the follower
+    # halves, streams chained with events): a round costs its launches, not a dozen ctypes calls
+    arr = (C.c_void_p * R)(*[n._h for n in nodes])
+    cl = C.c_void_p()
+    L._check(api.dense_cluster_create(arr, R, 0, C.byref(cl)))
+    L._check(api.dense_cluster_set_appends(cl, 1, None))  # one ClientRequest per group per round
     for e in nodes:
         e._check(api.sync(e._h))
 
@@ -213,17 +198,8 @@ def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
     now = [0]
 
     def rounds(n):
-        for _ in range(n):
-            now[0] += 100
-            for r in range(1, R):
-                L._check(api.stream_wait(L._h, nodes[r]._h))
-            L._check(api.step_dense_leader(L._h, now[0], C.byref(inbox), C.byref(outbox)))
-            for r in range(1, R):
-                e = nodes[r]
-                e._check(api.stream_wait(e._h, L._h))
-                e._check(api.step_dense_follower(e._h, now[0], C.byref(f_in[r]), C.byref(f_out[r]), 1))
-        for r in range(1, R):
-            L._check(api.stream_wait(L._h, nodes[r]._h))
+        L._check(api.dense_cluster_rounds(cl, now[0] + 100, 100, n))
+        now[0] += 100 * n
 
     rounds(W)
     barrier()
@@ -240,10 +216,19 @@ def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
     wall = time.perf_counter() - t0  # this rank's K rounds are done; MAX over ranks below
     barrier()
     decisions = float(L.counters()["decisions"] - c0["decisions"])
+    T_timed = W + K
+    # the leader half alone: a few more rounds, one call each (eager launches), with event pairs
+    # around k_leader_node_tick
+    L._check(api.kernel_timing(L._h, 1))
+    for _ in range(20):
+        rounds(1)
+    k_us, k_n = C.c_float(0), C.c_uint32(0)
+    L._check(api.kernel_timing_read(L._h, C.byref(k_us), C.byref(k_n)))
+    L._check(api.kernel_timing(L._h, 0))
 
     # full-size property check: real protocol rounds, so the commit index trails the head by the
     # round trip (append -> replicate -> ack -> majority) and every follower tracks the leader
-    T = W + K
+    T = T_timed + 20
     head, commit = L.read("head"), L.read("commit")
     assert (head == T).all() and (commit >= T - 3).all() and not L.read("fault").any(), "closed loop: leader state"
     for r in range(1, R):
@@ -277,7 +262,13 @@ def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
                          "frac": alg / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel": f"one round: k_leader_node_tick<{R}> + {R - 1} x k_follower_tick_dense (+ empty slow kernels)",
                          "alg_bytes_per_launch": alg, "avg_launch_us": round_s * 1e6,
-                         "alg_bytes_per_group": {"leader_half": lb, "follower_half": fb}},
+                         "alg_bytes_per_group": {"leader_half": lb, "follower_half": fb},
+                         "frac_of_measured_copy": alg / round_s / 1e9 / 6290.0,
+                         # the leader half alone, by its own HIP event pairs (jg_kernel_timing)
+                         "leader_kernel": {"kernel": f"k_leader_node_tick<{R}>", "avg_launch_us": k_us.value,
+                                           "launches_timed": k_n.value, "alg_bytes_per_launch": lb * G,
+                                           "achieved": lb * G / (k_us.value * 1e-6) / 1e9 if k_us.value else None,
+                                           "frac": lb * G / (k_us.value * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us.value else None}},
         }
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -329,7 +320,7 @@ def single_process_main(args):
         head, commit, fault = eng.read("head"), eng.read("commit"), eng.read("fault")
         assert (head == W + K).all() and (commit == W + K - 1).all() and not fault.any(), "steady-state closed form violated"
     launch_s = ev_ms.value / 1e3 / K
-    alg = alg_bytes_per_group_step(R) * G
+    alg = alg_bytes_per_group_step(R, args.mode) * G
     achieved = alg / launch_s / 1e9
     out = {
         "metric": "Raft quorum decisions/sec over N partitions; achieved HBM GB/s vs roofline",
@@ -541,7 +532,7 @@ def main():
     if rank == 0:
         launch_s = (ev_ms.value / 1e3) / n_launches  # average dense-kernel launch on this rank's stream
         ticks_per_launch = K / n_launches
-        alg = alg_bytes_per_group_step(R) * G * ticks_per_launch
+        alg = alg_bytes_per_group_step(R, args.mode) * G * ticks_per_launch
         achieved = alg / launch_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -576,7 +567,7 @@ def main():
                 "alg_bytes_per_launch": alg, "ticks_per_launch": ticks_per_launch,
                 "avg_launch_us": launch_s * 1e6, "peak_basis": "8.0 TB/s spec (6.29 TB/s measured copy)",
                 "frac_of_measured_copy": achieved / 6290.0,
-                "alg_bytes_per_group_step": alg_bytes_per_group_step(R),
+                "alg_bytes_per_group_step": alg_bytes_per_group_step(R, args.mode),
                 # the same launch priced with SURVEY.md's B(R) = 24R + 36 (8-byte absolute progress heads
                 # read and written every tick); > 1 possible: the engine stores them delta-packed
                 "survey_priced": {"bytes_per_group_step": survey_bytes_per_group_step(R),

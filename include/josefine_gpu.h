@@ -395,6 +395,27 @@ int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* i
 int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in,
                            const jg_follower_outbox* out, int tick);
 
+/* ---- a closed loop of dense node ticks ------------------------------------------------------------
+ * All R nodes of every partition in ONE process (one engine per node, e.g. the three brokers of
+ * examples/multi-node in one runtime): the protocol round — leader half on nodes[lead], follower half
+ * on every other node, each one's outbox columns being the others' inbox columns — driven from
+ * inside the library, so that a round costs its launches and no per-call host overhead of the
+ * caller's language.  The cluster owns the mailbox columns (in the memory of nodes[lead]'s device) and
+ * chains the engines' streams with events; nothing synchronises with the host inside a round.
+ * Equivalent, call for call, to jg_step_dense_leader on nodes[lead] followed by jg_step_dense_follower
+ * (tick = 1) on the others (josefine::DenseCluster::round in josefine_amd/host/raft_handle.hpp).
+ * Engines are borrowed: destroy the cluster before them. */
+typedef struct jg_dense_cluster jg_dense_cluster;
+int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t lead, jg_dense_cluster** out);
+void jg_dense_cluster_destroy(jg_dense_cluster* c);
+/* ClientRequests every group appends per round (leader.rs:177-197): the same number for all groups,
+ * or (per_group != NULL) one value per group from host memory. */
+int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const uint64_t* per_group);
+/* n_rounds protocol rounds at logical times now_ms, now_ms + dt_ms, ...; asynchronous (jg_sync the nodes). */
+int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms, uint32_t n_rounds);
+/* The mailbox columns, for inspection: the leader's inbox / outbox as the structs above. */
+int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_leader_outbox* out);
+
 /* Batched Chain::compact (src/raft/chain.rs:239-253) as a pure function over
  * explicit (id,next) trees: tree t owns entries [off[t], off[t+1]); ids within a
  * tree need not be sorted.  removed[i] = 1 iff the walk removes entry i. */

@@ -330,7 +330,18 @@ __device__ __forceinline__ void jg_defer_mark(const JgDev& d, uint32_t g, bool w
 
 // Node-tick extras of the leader kernel (jg_step_dense_leader): HeartbeatResponse input and the
 // Tick's outbox (leader.rs:234-245).  All pointers may be null (= plain jg_step_dense_acks).
+// Logical time and step numbers of a closed loop that is replayed as a hipGraph
+// (jg_dense_cluster_rounds): kernel arguments are frozen in a graph, so the clock lives in device
+// memory and the graph's first node advances it.
+struct JgClock {
+  uint64_t now;
+  uint32_t seq[JG_MAX_REPLICAS];  // per node of the cluster
+};
 struct JgLeaderNode {
+  const JgClock* clock;        // non-null: `now` and the step number come from here (slot clock_slot)
+  uint32_t clock_slot, pad_;
+  uint32_t ack_stride;         // 1, or 0: no ack block (the `acks` argument points at an all-ones word)
+  uint32_t hbr_stride;         // 1, or 0: no HeartbeatResponses (hbr_has points at an all-ones word)
   const uint8_t* hbr_has;      // [R][G] 0 / 1 / JG_HB_NONE
   const uint64_t* hbr_commit;  // [R][G] (slow kernel only)
   uint64_t* o_term;            // [G]
@@ -438,28 +449,40 @@ struct JgDenseIn {
   uint32_t f;
   uint64_t a[R], w, head;
   uint64_t term, hbt;  // NODE
-  uint8_t hbr[R];      // NODE
+  uint32_t hbr[R];     // NODE (HeartbeatResponse.has_committed bytes, widened)
 };
 template <int R, bool UNIFORM, bool NODE>
 __device__ __forceinline__ void jg_dense_issue(const JgDenseHot& h, const JgDev* dp,
                                                const uint64_t* __restrict__ acks, uint32_t us,
                                                const JgLeaderNode& nd, bool emit, uint32_t g, JgDenseIn<R>& in) {
   in.f = h.flags[g];
-  jg_dense_load<R, NODE>(h, acks, g, in.a, in.w, in.head);
+  in.term = in.hbt = 0;
+  if (!NODE) {
+    jg_dense_load<R, false>(h, acks, g, in.a, in.w, in.head);
+  } else {
+    // Every load of the group unconditionally and back to back - ONE round trip.  An absent input
+    // (no ack block, no HeartbeatResponses) is not a branch around its loads (the compiler waits for
+    // the loads issued so far at every branch: the node tick took eight dependent trips per group,
+    // 38 us per 1 M groups) but a stride of 0 into an all-ones word: JG_NO_ACK / JG_HB_NONE for everybody.
+#pragma unroll
+    for (int r = 0; r < R; r++) in.a[r] = __builtin_nontemporal_load(&acks[((size_t)r * h.G + g) * nd.ack_stride]);
+    in.w = h.mlag[g];
+    in.head = h.head[g];
+    in.term = h.term[g];
+    in.hbt = h.heartbeat_time[g];
+#pragma unroll
+    for (int r = 0; r < R; r++)  // (the own slot's entry is loaded too and never looked at)
+      in.hbr[r] = nd.hbr_has[((size_t)r * h.G + g) * nd.hbr_stride];
+  }
   // keep the flag load up here, in the same round trip as the others: without a use the
   // compiler sinks it behind the hot-path test (a second, dependent trip to HBM per group)
   asm volatile("" ::"v"(in.f));
-  __builtin_amdgcn_sched_barrier(0);
-  in.term = in.hbt = 0;
   if (NODE) {
-    if (emit) {
-      in.term = h.term[g];
-      in.hbt = h.heartbeat_time[g];
-    }
 #pragma unroll
-    for (int r = 0; r < R; r++)  // (the own slot's entry is never looked at)
-      in.hbr[r] = nd.hbr_has && !(UNIFORM && (uint32_t)r == us) ? nd.hbr_has[(size_t)r * h.G + g] : (uint8_t)JG_HB_NONE;
+    for (int r = 0; r < R; r++) asm volatile("" ::"v"(in.hbr[r]));
+    asm volatile("" ::"v"(in.term), "v"(in.hbt));
   }
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---- the general path of the ack-only kernel, in memory form ------------------------------------
@@ -601,7 +624,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   uint64_t n_app = in.a[0];
 #pragma unroll
   for (int r = 1; r < R; r++) n_app = (uint32_t)r == s ? in.a[r] : n_app;
-  if (NODE && !acks) n_app = 0;
+  if (NODE && !nd.ack_stride) n_app = 0;
   // ---- hot path: a healthy leader in FAST form whose tick stays in lag space --------------------
   // straight-line 32-bit arithmetic, evaluated for every lane; everything else is behind one
   // (normally wave-uniform, not taken) branch
@@ -681,6 +704,7 @@ template <int R>
 __global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDenseHot h, const JgDev* __restrict__ dp,
                                                                 const uint64_t* __restrict__ acks, uint32_t seq, int us,
                                                                 JgLeaderNode nd) {
+  if (nd.clock) nd.now = nd.clock->now, seq = nd.clock->seq[nd.clock_slot];
   JgDecCount dec;
   if (us >= 0) dec = jg_dense_tick_body<R, true, true, true>(h, dp, acks, seq, (uint32_t)us, nd, nullptr);
   else dec = jg_dense_tick_body<R, false, true, true>(h, dp, acks, seq, 0, nd, nullptr);

@@ -38,9 +38,12 @@ struct JgFollowerArgs {
   uint64_t now;
   uint32_t seq;
   uint32_t tick;
+  const JgClock* clock;  // non-null: `now` and `seq` come from here (slot clock_slot): a replayed round
+  uint32_t clock_slot, pad_;
 };
 
 __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFollowerArgs a) {
+  if (a.clock) a.now = a.clock->now, a.seq = a.clock->seq[a.clock_slot];
   const uint32_t G = d.G;
   for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
     // every load is independent of the others
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFol
 // The deferred groups through the general state machine.  AppendResponse / HeartbeatResponse
 // rows are captured into the outbox columns, everything else goes to the exceptional queue.
 __global__ __launch_bounds__(JG_BLOCK) void k_follower_slow(JgDev d, JgFollowerArgs a) {
+  if (a.clock) a.now = a.clock->now, a.seq = a.clock->seq[a.clock_slot];
   uint32_t dec = 0;
   const uint32_t n = d.slow_cnt[blockIdx.x] < d.slow_cap ? d.slow_cnt[blockIdx.x] : d.slow_cap;
   const uint32_t* list = d.slow_list + (size_t)blockIdx.x * d.slow_cap;

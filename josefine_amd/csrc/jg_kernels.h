@@ -25,6 +25,7 @@
 // outside the dense mailbox vocabulary go to the exceptional queue.
 __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
                                                           size_t tick_stride, uint32_t seq0, JgLeaderNode nd) {
+  if (nd.clock) nd.now = nd.clock->now, seq0 = nd.clock->seq[nd.clock_slot];
   uint32_t dec = 0;
   // this workgroup's shard of the deferral bitmap (jg_defer_mark) -> its list; the words are
   // cleared for the next launch.  (Order within the list is immaterial: groups are independent,
@@ -183,6 +184,20 @@ __global__ void k_chain_compact(size_t n_trees, const uint64_t* __restrict__ off
       next_id = nexts[best_i];                                // :249
       bound = best;
     }
+  }
+}
+
+// ---- the clock of a replayed closed loop (JgClock) ----------------------------------------------
+__global__ void k_clock_set(JgClock* c, uint64_t now, JgClock init) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *c = init;
+    c->now = now;
+  }
+}
+__global__ void k_clock_advance(JgClock* c, uint64_t dt, uint32_t n_nodes) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    c->now += dt;
+    for (uint32_t r = 0; r < n_nodes; r++) c->seq[r] += 1;  // every node takes one step per round
   }
 }
 

@@ -156,6 +156,7 @@ struct jg_engine {
   uint32_t* h_status = nullptr;
   uint32_t* d_err = nullptr;
   uint64_t* d_acks_staging = nullptr;  // [R][G] for the host-buffer dense entry point
+  uint64_t* d_ones = nullptr;  // one all-ones word: the stride-0 stand-in for an absent ack block / HeartbeatResponse column
   // commands queued by jg_submit (host SoA)
   std::vector<uint8_t> p_kind, p_flag;
   std::vector<uint32_t> p_group, p_from;
@@ -238,6 +239,10 @@ struct jg_engine {
   bool flag_check_pending = false;
   bool slow_scheduled_ever = false;  // some dense launch had k_dense_slow behind it
   uint64_t n_cmds = 0, n_dense = 0, n_launch = 0;
+  // set while a jg_dense_cluster round is being captured into a hipGraph: the node kernels then
+  // take logical time and step number from this device-resident clock instead of their arguments
+  const JgClock* replay_clock = nullptr;
+  uint32_t replay_slot = 0;
   // jg_kernel_timing: HIP event pairs around the dense tick kernel itself (not the slow kernel
   // behind it), a ring of the most recent launches, read after the fact
   static constexpr int KT_RING = 256;
@@ -287,9 +292,14 @@ void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks, const Jg
       if (e->kt_on) (void)hipEventRecord(e->kt_ev[2 * (e->kt_n++ % jg_engine::KT_RING) + 1], e->stream);
     }
   } lap(e);
-  if (nd)  // node tick: HeartbeatResponses in, the Tick's outbox out
+  if (nd) {  // node tick: HeartbeatResponses in, the Tick's outbox out
+    // (an absent input column is a stride-0 view of one all-ones word for this kernel: no branch around loads)
+    JgLeaderNode k = *nd;
+    if (!k.hbr_has) k.hbr_has = (const uint8_t*)e->d_ones;
     hipLaunchKernelGGL(k_leader_node_tick<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
-                       jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks, e->seq, e->uniform_self, *nd);
+                       jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks ? acks : (const uint64_t*)e->d_ones, e->seq,
+                       e->uniform_self, k);
+  }
   else if (n_ticks > 1)  // temporal fusion: state read once, written once per launch
     hipLaunchKernelGGL(k_leader_tick_dense_n<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
                        n_ticks, stride, e->seq, e->uniform_self);
@@ -1029,9 +1039,11 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.slow_list, (size_t)JG_SHARDS * d.slow_cap);
   A(d.slow_cnt, JG_SHARDS);
   A(d.defer_bits, (G + 63) / 64);
+  A(e->d_ones, 2);
   A(e->d_dev2[0], 1);
   A(e->d_dev2[1], 1);
 #undef A
+  if (hipMemsetAsync(e->d_ones, 0xff, 16, e->stream) != hipSuccess) return bail(fail(JG_EDEVICE, "hipMemsetAsync failed"));
   if ((rc = push_dev_copy(e)) != JG_OK) return bail(rc);
   hipLaunchKernelGGL(k_init_groups, dim3(grid_for(G, 2048)), dim3(JG_BLOCK), 0, e->stream, e->dev,
                      (const uint8_t*)nullptr);
@@ -1305,8 +1317,10 @@ int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* i
   int rc = ensure_xq(e);
   if (rc) return rc;
   JgLeaderNode nd{};
+  nd.clock = e->replay_clock, nd.clock_slot = e->replay_slot;
   nd.hbr_has = in ? in->hbr_has : nullptr;
   nd.hbr_commit = in ? in->hbr_commit : nullptr;
+  nd.hbr_stride = nd.hbr_has ? 1 : 0;
   if (out) {
     nd.o_term = out->term;
     nd.o_hb = out->hb_commit;
@@ -1316,6 +1330,7 @@ int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* i
   nd.now = now_ms;
   const uint64_t* acks = in ? in->acks : nullptr;
   if (!acks && !nd.hbr_has && !out) return JG_OK;  // nothing to apply
+  nd.ack_stride = acks ? 1 : 0;
   return dense_step(e, acks, 1, &nd);
 }
 
@@ -1333,6 +1348,7 @@ int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbo
   e->stepped = true;
   e->seq++;
   JgFollowerArgs a{};
+  a.clock = e->replay_clock, a.clock_slot = e->replay_slot;
   a.leader = in->leader;
   a.leader_id = in->leader_id;
   a.term = in->term;
@@ -1356,6 +1372,200 @@ int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbo
   // a deferred follower may have become a candidate / changed its chain: like a sparse step
   e->maybe_irregular = true;
   e->flag_check_pending = true;
+  return JG_OK;
+}
+
+struct jg_dense_cluster {
+  std::vector<jg_engine*> nodes;
+  uint32_t G = 0, R = 0, lead = 0;
+  uint32_t lead_id = 0;
+  uint64_t *acks = nullptr, *hbr_commit = nullptr, *o_term = nullptr, *o_hb = nullptr, *o_from = nullptr;
+  uint8_t *hbr_has = nullptr, *o_n = nullptr;
+  std::vector<void*> bufs;
+  // one protocol round captured as a hipGraph (ten launches and nine cross-stream dependencies per
+  // round cost more host time than the round's kernels take on the device)
+  JgClock* clock = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  uint64_t sig = 0, graph_dt = 0;
+};
+
+int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t lead, jg_dense_cluster** out) {
+  if (!nodes || !out || !n_nodes || lead >= n_nodes) return fail(JG_EINVAL, "bad argument");
+  for (uint32_t r = 0; r < n_nodes; r++) {
+    if (!nodes[r] || nodes[r]->router) return fail(JG_EINVAL, "a dense cluster takes single-device engines (or shard handles)");
+    if (nodes[r]->cfg.n_groups != nodes[0]->cfg.n_groups || nodes[r]->cfg.n_replicas != n_nodes)
+      return fail(JG_EINVAL, "every node hosts the same groups, one replica slot each");
+  }
+  jg_dense_cluster* c = new jg_dense_cluster();
+  c->nodes.assign(nodes, nodes + n_nodes);
+  c->G = nodes[0]->cfg.n_groups, c->R = n_nodes, c->lead = lead;
+  c->lead_id = nodes[lead]->cfg.node_ids[lead];
+  jg_engine* L = nodes[lead];
+  const size_t G = c->G, R = c->R;
+  auto alloc = [&](size_t bytes, void** p) {
+    int rc = jg_device_alloc(L, bytes, p);
+    if (!rc) c->bufs.push_back(*p);
+    return rc;
+  };
+  int rc = JG_OK;
+  if ((rc = alloc(8 * R * G, (void**)&c->acks)) || (rc = alloc(8 * R * G, (void**)&c->hbr_commit)) ||
+      (rc = alloc(R * G, (void**)&c->hbr_has)) || (rc = alloc(8 * G, (void**)&c->o_term)) ||
+      (rc = alloc(8 * G, (void**)&c->o_hb)) || (rc = alloc(8 * R * G, (void**)&c->o_from)) ||
+      (rc = alloc(R * G, (void**)&c->o_n))) {
+    jg_dense_cluster_destroy(c);
+    return rc;
+  }
+  std::vector<uint64_t> a(R * G, JG_NO_ACK);
+  std::vector<uint8_t> h(R * G, (uint8_t)JG_HB_NONE);
+  if ((rc = jg_device_upload(L, c->acks, a.data(), a.size() * 8)) || (rc = jg_device_upload(L, c->hbr_has, h.data(), h.size()))) {
+    jg_dense_cluster_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return JG_OK;
+}
+
+void jg_dense_cluster_destroy(jg_dense_cluster* c) {
+  if (!c) return;
+  if (c->exec) (void)hipGraphExecDestroy(c->exec);
+  if (c->graph) (void)hipGraphDestroy(c->graph);
+  for (void* p : c->bufs) (void)jg_device_free(c->nodes[c->lead], p);
+  delete c;
+}
+
+int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const uint64_t* per_group) {
+  if (!c) return fail(JG_EINVAL, "null argument");
+  std::vector<uint64_t> v;
+  if (!per_group) v.assign(c->G, uniform);
+  return jg_device_upload(c->nodes[c->lead], c->acks + (size_t)c->lead * c->G, per_group ? per_group : v.data(), (size_t)c->G * 8);
+}
+
+int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_leader_outbox* out) {
+  if (!c) return fail(JG_EINVAL, "null argument");
+  if (in) *in = jg_leader_inbox{c->acks, c->hbr_has, c->hbr_commit};
+  if (out) *out = jg_leader_outbox{c->o_term, c->o_hb, c->o_from, c->o_n};
+  return JG_OK;
+}
+
+namespace {
+// the body of one round; `leading_waits`: the leader's stream first waits for the followers' last answers
+int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits) {
+  jg_engine* L = c->nodes[c->lead];
+  const size_t G = c->G;
+  const jg_leader_inbox in{c->acks, c->hbr_has, c->hbr_commit};
+  const jg_leader_outbox out{c->o_term, c->o_hb, c->o_from, c->o_n};
+  int rc = JG_OK;
+  if (leading_waits)
+    for (uint32_t r = 0; r < c->R; r++)
+      if (r != c->lead && (rc = jg_stream_wait(L, c->nodes[r]))) return rc;
+  if ((rc = jg_step_dense_leader(L, now_ms, &in, &out))) return rc;
+  for (uint32_t r = 0; r < c->R; r++) {
+    if (r == c->lead) continue;
+    if ((rc = jg_stream_wait(c->nodes[r], L))) return rc;
+    jg_follower_inbox fi{};
+    fi.leader = nullptr, fi.leader_id = c->lead_id;
+    fi.term = c->o_term, fi.hb_commit = c->o_hb;
+    fi.ae_from = c->o_from + (size_t)r * G, fi.ae_n = c->o_n + (size_t)r * G;
+    const jg_follower_outbox fo{c->acks + (size_t)r * G, c->hbr_commit + (size_t)r * G, c->hbr_has + (size_t)r * G};
+    if ((rc = jg_step_dense_follower(c->nodes[r], now_ms, &fi, &fo, 1))) return rc;
+  }
+  return JG_OK;
+}
+
+// what a captured round depends on besides the mailboxes: recapture when any of it changes
+uint64_t cluster_signature(const jg_dense_cluster* c, uint64_t dt) {
+  uint64_t h = 0x9e3779b97f4a7c15ull ^ dt;
+  for (const jg_engine* e : c->nodes) {
+    h = h * 0x100000001b3ull ^ (uint64_t)e->cur_set;
+    h = h * 0x100000001b3ull ^ (uint64_t)(uintptr_t)e->dev.xq;
+    h = h * 0x100000001b3ull ^ (uint64_t)e->kt_on;
+  }
+  return h;
+}
+
+int cluster_capture(jg_dense_cluster* c, uint64_t dt_ms) {
+  jg_engine* L = c->nodes[c->lead];
+  if (c->exec) (void)hipGraphExecDestroy(c->exec), c->exec = nullptr;
+  if (c->graph) (void)hipGraphDestroy(c->graph), c->graph = nullptr;
+  struct Saved {
+    uint32_t seq;
+    uint64_t n_dense, n_launch;
+  };
+  std::vector<Saved> saved;
+  for (uint32_t r = 0; r < c->R; r++) {
+    jg_engine* e = c->nodes[r];
+    saved.push_back(Saved{e->seq, e->n_dense, e->n_launch});
+    e->replay_clock = c->clock, e->replay_slot = r;
+  }
+  int rc = JG_OK;
+  hipError_t he = hipStreamBeginCapture(L->stream, hipStreamCaptureModeRelaxed);
+  if (he == hipSuccess) {
+    hipLaunchKernelGGL(k_clock_advance, dim3(1), dim3(1), 0, L->stream, c->clock, dt_ms, c->R);
+    rc = cluster_round_body(c, 0, false);
+    for (uint32_t r = 0; r < c->R && !rc; r++)  // every forked stream joins the leader's again
+      if (r != c->lead) rc = jg_stream_wait(L, c->nodes[r]);
+    he = hipStreamEndCapture(L->stream, &c->graph);
+  }
+  for (uint32_t r = 0; r < c->R; r++) {  // nothing has run: the host-side bookkeeping of the captured calls is undone
+    jg_engine* e = c->nodes[r];
+    e->replay_clock = nullptr;
+    e->seq = saved[r].seq, e->n_dense = saved[r].n_dense, e->n_launch = saved[r].n_launch;
+  }
+  if (rc) return rc;
+  if (he != hipSuccess) return fail(JG_EDEVICE, std::string("hipGraph capture: ") + hipGetErrorString(he));
+  HIPCHK(hipGraphInstantiate(&c->exec, c->graph, nullptr, nullptr, 0));
+  c->sig = cluster_signature(c, dt_ms);
+  return JG_OK;
+}
+}  // namespace
+
+int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms, uint32_t n_rounds) {
+  if (!c) return fail(JG_EINVAL, "null argument");
+  if (!n_rounds) return JG_OK;
+  jg_engine* L = c->nodes[c->lead];
+  int rc = JG_OK;
+  static const bool no_graph = std::getenv("JG_NO_GRAPH") != nullptr;
+  bool same_device = true;
+  for (jg_engine* e : c->nodes) same_device = same_device && e->device == L->device;
+  if (no_graph || !same_device || n_rounds < 2) {  // eager: one round at a time
+    for (uint32_t k = 0; k < n_rounds; k++, now_ms += dt_ms)
+      if ((rc = cluster_round_body(c, now_ms, true))) return rc;
+    for (uint32_t r = 0; r < c->R; r++)  // the leader's stream ends behind the last answers
+      if (r != c->lead && (rc = jg_stream_wait(L, c->nodes[r]))) return rc;
+    return JG_OK;
+  }
+  HIPCHK(hipSetDevice(L->device));
+  for (jg_engine* e : c->nodes) {  // nothing may allocate or synchronise inside a capture
+    if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
+    if ((rc = ensure_xq(e))) return rc;
+  }
+  if (!c->clock) {
+    HIPCHK(hipMalloc((void**)&c->clock, sizeof(JgClock)));
+    c->bufs.push_back(c->clock);
+  }
+  if (!c->exec || c->sig != cluster_signature(c, dt_ms))
+    if ((rc = cluster_capture(c, dt_ms))) return rc;
+  for (uint32_t r = 0; r < c->R; r++)  // the followers' earlier work first
+    if (r != c->lead && (rc = jg_stream_wait(L, c->nodes[r]))) return rc;
+  JgClock init{};
+  for (uint32_t r = 0; r < c->R; r++) init.seq[r] = c->nodes[r]->seq;
+  hipLaunchKernelGGL(k_clock_set, dim3(1), dim3(1), 0, L->stream, c->clock, now_ms - dt_ms, init);
+  for (uint32_t k = 0; k < n_rounds; k++) {
+    HIPCHK(hipGraphLaunch(c->exec, L->stream));
+    for (uint32_t r = 0; r < c->R; r++) {  // what the eager calls would have recorded on the host
+      jg_engine* e = c->nodes[r];
+      e->seq += 1;
+      e->stepped = true;
+      e->n_dense += c->G;
+      e->n_launch += 2;
+      e->slow_scheduled_ever = true;
+      if (r != c->lead) e->maybe_irregular = true, e->flag_check_pending = true;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  for (uint32_t r = 0; r < c->R; r++)  // later work on the followers' own streams comes behind the replayed rounds
+    if (r != c->lead && (rc = jg_stream_wait(c->nodes[r], L))) return rc;
   return JG_OK;
 }
 

@@ -243,3 +243,41 @@ def test_closed_loop_cluster_dense(R, lead):
         if r != lead:
             assert (oc.nodes[r].read("commit") > T // 2).all()
     assert dc.nodes[lead].counters()["decisions"] == L.counters()["decisions"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,lead", [(3, 0), (5, 2)])
+def test_library_driven_rounds_equal_eager_rounds(R, lead):
+    """jg_dense_cluster_rounds drives the protocol round from inside the library and replays it as a
+    hipGraph (logical time and step numbers from a device-resident clock).  Same mailboxes, same state,
+    same exceptional rows as the call-by-call loop (dense_node.DenseCluster) and as the oracle."""
+    import ctypes as C
+    G, rounds = 4000, 24
+    rng = np.random.default_rng(R)
+    appends = rng.integers(0, 3, G).astype(np.uint64)
+    eager = DenseCluster(BatchedRaft, G, R, seed=5, lead=lead)
+    ora = DenseCluster(oracle_engine, G, R, seed=5, lead=lead)
+    nodes = [BatchedRaft(G, R, seed=5 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY)
+             for r in range(R)]
+    elect_all(nodes[lead])
+    nodes[lead].drain_messages(), nodes[lead].drain_applies()
+    api = nodes[0].api
+    arr = (C.c_void_p * R)(*[n._h for n in nodes])
+    cl = C.c_void_p()
+    nodes[0]._check(api.dense_cluster_create(arr, R, lead, C.byref(cl)))
+    nodes[0]._check(api.dense_cluster_set_appends(cl, 0, appends.ctypes.data))
+    # 10 rounds in one call (captured + replayed), 1 round (eager), 13 more (replayed again)
+    for first, n in ((100, 10), (1100, 1), (1200, 13)):
+        nodes[0]._check(api.dense_cluster_rounds(cl, first, 100, n))
+    for _ in range(rounds):
+        eager.round(appends)
+        ora.round(appends)
+    for r in range(R):
+        compare_snapshots(nodes[r], eager.nodes[r], f"library-driven vs eager, node {r}")
+        compare_snapshots(nodes[r], ora.nodes[r], f"library-driven vs oracle, node {r}")
+        for fn in ("drain_messages", "drain_faults"):
+            got = getattr(nodes[r], fn)()
+            want = np.concatenate([rows[r] for rows in ora.rows]) if fn == "drain_messages" else getattr(ora.nodes[r], fn)()
+            assert got.tobytes() == want.tobytes(), (r, fn, len(got), len(want))
+    assert int(nodes[lead].read("commit").min()) >= 0 and int(nodes[lead].read("head").max()) == int(appends.max()) * rounds
+    api.dense_cluster_destroy(cl)
