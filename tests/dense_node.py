@@ -90,3 +90,98 @@ class DenseCluster:
             outs[r] = fo
         self.rows.append([n.drain_messages() for n in self.nodes])
         return outs
+
+
+ROUTE_SRC_INJECT = 7  # injected rows sort after every peer's rows of the same group
+
+
+def routable(rows, member_ids):
+    """Which drained message rows the cluster transport delivers: everything addressed to peers
+    that is a plain message.  AppendEntries rows (the payload lives in the sender's block store)
+    and ClientRequest rows (instructions to the host adapter about its request mirror) stay in
+    the queue for the host."""
+    k = rows["kind"]
+    plain = (k != capi.CMD_APPEND_ENTRIES) & (k != capi.CMD_CLIENT_REQUEST)
+    to_all = rows["to_kind"] == capi.TO_PEERS
+    to_one = (rows["to_kind"] == capi.TO_PEER) & np.isin(rows["to_id"], member_ids)
+    return plain & (to_all | to_one)
+
+
+class RoutedCluster(DenseCluster):
+    """DenseCluster + a transport for the rows outside the mailbox vocabulary (votes, …): what a
+    node emits in round t is applied by its addressees at the start of round t+1, per group in
+    the order (sender slot, emission order), followed by the rows injected for that round.  The
+    host-side statement of jg_dense_cluster_round_routed, for any backend."""
+
+    def __init__(self, factory, G, R, **kw):
+        super().__init__(factory, G, R, **kw)
+        self.member_ids = np.array([self.nodes[r].node_ids[r] for r in range(R)], dtype=np.uint32)
+        self.inbound = [[] for _ in range(R)]  # per node: list of (src, structured rows)
+        self.kept = [np.zeros(0, dtype=capi.MSG_DTYPE) for _ in range(R)]
+        self.delivered = np.zeros(R, dtype=np.int64)
+
+    def _inbound_columns(self, n, inject):
+        parts, srcs = [], []
+        for src, rows in self.inbound[n]:
+            parts.append(dict(kind=rows["kind"], group=rows["group"], from_=rows["from"], term=rows["term"],
+                              id=rows["id"], aux=rows["aux"], flag=rows["flag"]))
+            srcs.append(np.full(len(rows), src, np.int64))
+        if inject is not None and len(inject["kind"]):
+            m = len(inject["kind"])
+            z8, z4 = np.zeros(m, np.uint64), np.zeros(m, np.uint32)
+            parts.append(dict(kind=inject["kind"], group=inject["group"], from_=inject.get("from_", z4),
+                              term=inject.get("term", z8), id=inject.get("id", z8), aux=inject.get("aux", z8),
+                              flag=inject.get("flag", np.zeros(m, np.uint8))))
+            srcs.append(np.full(m, ROUTE_SRC_INJECT, np.int64))
+        self.inbound[n] = []
+        if not parts:
+            return None
+        cols = {k: np.concatenate([np.asarray(p[k]) for p in parts]) for k in parts[0]}
+        src = np.concatenate(srcs)
+        order = np.lexsort((np.arange(len(src)), src, cols["group"]))  # group, then sender, then emission order
+        return {k: v[order] for k, v in cols.items()}
+
+    def round(self, appends, inject=None, dt_ms=100):
+        now = self.now + dt_ms
+        for n in range(self.R):
+            cols = self._inbound_columns(n, inject[n] if inject else None)
+            if cols is not None:
+                self.delivered[n] += len(cols["kind"])
+                self.nodes[n].submit_columns(**cols)
+                self.nodes[n].step(now)
+        # client requests are offered only where the lead node leads: at a leaderless replica the
+        # reference queues them (follower.rs:258-270), which the dense append column cannot express
+        leads = self.nodes[self.lead].read("role") == capi.ROLE_LEADER
+        outs = super().round(np.where(leads, np.asarray(appends, dtype=np.uint64), np.uint64(0)), dt_ms)
+        drained = self.rows.pop()
+        for s in range(self.R):
+            rows = drained[s]
+            ok = routable(rows, self.member_ids)
+            self.kept[s] = np.concatenate([self.kept[s], rows[~ok]])
+            rows = rows[ok]
+            for n in range(self.R):
+                if n == s:
+                    continue
+                to_n = (rows["to_kind"] == capi.TO_PEERS) | (rows["to_id"] == self.member_ids[n])
+                if to_n.any():
+                    self.inbound[n].append((s, rows[to_n]))
+        return outs
+
+
+def cluster_failure_rows(seed, tick, G, R, percent=1, lead=0, candidate=1):
+    """BASELINE.json configs[4] on a cluster: every group fails with
+    probability percent/100 per tick; in a failing group the leader's replica crashes and
+    restarts (State::default(), Chain::new on the persisted tree) and a designated follower,
+    restarted as well so that voted_for == None (nobody else may campaign),
+    receives Timeout.  The other replicas answer its VoteRequests through can_vote next round.
+    Returns one column dict per node (or None) for RoutedCluster.round(inject=…)."""
+    from josefine_amd.traces import synth_hash
+    gg = np.arange(G, dtype=np.uint64)
+    failing = np.nonzero(synth_hash(seed, tick, gg, 7) % np.uint64(100) < np.uint64(percent))[0].astype(np.uint32)
+    n = len(failing)
+    out = [None] * R
+    if n:
+        out[lead] = dict(kind=np.full(n, capi.CMD_RESTART, np.uint8), group=failing)
+        out[candidate] = dict(kind=np.concatenate([np.full(n, capi.CMD_RESTART, np.uint8), np.full(n, capi.CMD_TIMEOUT, np.uint8)]),
+                              group=np.concatenate([failing, failing]))
+    return out

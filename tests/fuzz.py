@@ -15,14 +15,22 @@ WEIGHTS = np.array([6, 1, 6, 10, 10, 16, 8, 4, 3, 1, 12, 2, 1], dtype=np.float64
 WEIGHTS /= WEIGHTS.sum()
 
 
+_TRACK = {}  # id(budget array) -> what random_batch remembers about the chains it has built (see below)
+
+
 def random_batch(rng: np.random.Generator, ora, n: int, foreign_voters: bool = False, budget=None):
     """n random command rows + block side arrays, as kwargs for submit_columns.
 
     `budget` ([G] int array, updated in place) bounds the gaps / forks generated per
     group so that chains stay within the engine's JG_CHAIN_WINDOW segments."""
     G, R = ora.G, ora.R
+    track = None
     if budget is None:
         budget = np.full(G, 1 << 30)
+    else:
+        # per budget array: the blocks sent with a parent other than id-1, and the highest id the group
+        # can hold (a Restart puts the head back at the commit index but keeps the stored blocks)
+        track = _TRACK.setdefault(id(budget), {"forks": {}, "hi": np.zeros(G, np.int64)})
     ids = np.array(ora.node_ids, dtype=np.uint32)
     term_now = ora.read("term").astype(np.int64)
     head_now = ora.read("head").astype(np.int64)
@@ -50,22 +58,40 @@ def random_batch(rng: np.random.Generator, ora, n: int, foreign_voters: bool = F
         id_col[i] = len(blk_id)
         aux[i] = nb
         h = int(head_now[group[i]])
+        forks = track["forks"].setdefault(int(group[i]), {}) if track else {}
+        hi = max(int(track["hi"][group[i]]), h) if track else h
         for _ in range(nb):
             r = rng.random()
-            if r >= 0.75 and r < 0.9:
-                if budget[group[i]] <= 0:
+            if r >= 0.75 and r < 0.9:  # a fork costs the engine at most two segments (it may land inside a run)
+                if budget[group[i]] < 2:
                     r = 0.0
                 else:
-                    budget[group[i]] -= 1
+                    budget[group[i]] -= 2
             if r < 0.75:       # regular extension of the follower's chain
                 nid, nxt = h + 1, h
+                # ... which, after a Restart put the head back at the commit index, can re-send an id
+                # that an earlier fork stored with another parent: an overwrite, up to two segments
+                if forks.get(nid, nxt) != nxt:
+                    if budget[group[i]] < 2:
+                        blk_id.append(h + 2), blk_next.append(hi + 7)  # no budget: the Err case instead
+                        h = h + 2
+                        continue
+                    budget[group[i]] -= 2
             elif r < 0.9:      # fork / gap with an existing parent
                 nid, nxt = h + int(rng.integers(1, 4)), max(h - int(rng.integers(0, 2)), 0)
             else:              # missing parent -> Err (chain.rs:180-185)
-                nid, nxt = h + 2, h + 7
+                nid, nxt = h + 2, hi + 7
+            hi = max(hi, nid)
+            if r < 0.9:
+                if nxt != nid - 1:
+                    forks[nid] = nxt
+                else:
+                    forks.pop(nid, None)
             blk_id.append(nid)
             blk_next.append(nxt)
             h = nid
         head_now[group[i]] = h  # keep later rows of this batch plausible
+        if track:
+            track["hi"][group[i]] = hi
     return dict(kind=kind, group=group, from_=from_, term=term, id=id_col, aux=aux, flag=flag,
                 blk_id=np.array(blk_id, dtype=np.uint64), blk_next=np.array(blk_next, dtype=np.uint64))

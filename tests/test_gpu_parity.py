@@ -286,10 +286,13 @@ def test_chain_window_overflow_is_loud():
     assert dev.handle(0).fault == capi.FAULT_ENGINE_WINDOW_OVERFLOW
     assert [tuple(r) for r in dev.drain_faults()] == [(0, capi.FAULT_ENGINE_WINDOW_OVERFLOW)]
     assert dev.handle(1).fault == 0
-    dev2 = BatchedRaft(1, 3)
-    dev2.apply(0, Command.Timeout())
-    dev2.apply(0, Command.VoteResponse(1, 77, True))  # not a member
-    assert dev2.handle(0).fault == capi.FAULT_ENGINE_FOREIGN_VOTER
+    # a voter outside the membership is no fault: Election::vote counts whoever answers (election.rs:33-35)
+    dev2, ora2 = pair(1, 3)
+    for e in (dev2, ora2):
+        e.apply(0, Command.Timeout())
+        e.apply(0, Command.VoteResponse(1, 77, True))  # not a member
+    assert dev2.handle(0).fault == 0
+    compare_snapshots(dev2, ora2, "foreign voter")
 
 
 @pytest.mark.parametrize("n_trees", [1, 300])
