@@ -171,6 +171,8 @@ def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
     from josefine_amd import BatchedRaft, capi
     from josefine_amd.traces import elect_all
 
+    if args.failures:
+        return cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev)
     G, R, K, W = args.groups, args.replicas, args.steps, args.warmup
     nodes = [BatchedRaft(G, R, seed=args.seed + r, device_id=dev_index, group_base=rank * G,
                          self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
@@ -271,6 +273,137 @@ def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
                                            "frac": lb * G / (k_us.value * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us.value else None}},
         }
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
+    """--cluster --failures p: BASELINE.json configs[4] as SURVEY.md §8(d) #5 specifies it.  The closed
+    loop of --cluster, and per round p % of the partitions lose their leader: its replica crashes and
+    restarts, a restarted follower (voted_for == None, §7.3 Q4) times out and campaigns, the other
+    replicas answer its VoteRequests through can_vote on the device; every vote travels between the
+    engines through the library's device-side transport (jg_dense_cluster_round_routed) and is applied
+    the round after.  Nothing here is synthetic except the failures and the client requests."""
+    import numpy as np
+    from josefine_amd import BatchedRaft, DenseCluster, capi
+    from josefine_amd.traces import cluster_failure_rows, elect_all
+
+    G, R, K, W = args.groups, args.replicas, args.steps, args.warmup
+    nodes = [BatchedRaft(G, R, seed=args.seed + r, device_id=dev_index, group_base=rank * G,
+                         self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
+    L = nodes[0]
+    elect_all(L)
+    L.drain_messages(), L.drain_applies()
+    api = L.api
+    lib = DenseCluster(nodes)
+    lib.set_appends(1)
+    # the failure trace is resident in HBM before the timed region: per round and node one group-sorted batch
+    failed = np.zeros(G, bool)
+    trace = []
+    for t in range(W + K):
+        cols = cluster_failure_rows(args.seed, t, G, R, args.failures, group_base=rank * G)
+        if cols[0] is not None:
+            failed[cols[0]["group"]] = True
+        trace.append([None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(cols)])
+    for e in nodes:
+        e._check(api.sync(e._h))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        for e in nodes:
+            e._check(api.sync(e._h))
+
+    delivered = [0, 0]  # [warm-up, timed] rows the transport moved
+    kept = [0]
+
+    def rounds(t0_, t1_, which):
+        for t in range(t0_, t1_):
+            st = lib.round_routed((t + 1) * 100, trace[t])
+            delivered[which] += sum(st["delivered"])
+            kept[0] += st["kept"] + st["fsm_rows"]
+
+    rounds(0, W, 0)
+    barrier()
+    c0 = sum(e.counters()["decisions"] for e in nodes)
+    L._check(api.kernel_timing(L._h, 1))
+    barrier()
+    t0 = time.perf_counter()
+    L._check(api.timer_start(L._h))
+    rounds(W, W + K, 1)
+    ev_ms = C.c_float(0)
+    L._check(api.timer_stop(L._h, C.byref(ev_ms)))
+    for e in nodes:
+        e._check(api.sync(e._h))
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    barrier()
+    decisions = float(sum(e.counters()["decisions"] for e in nodes) - c0)
+    k_us, k_n = C.c_float(0), C.c_uint32(0)
+    L._check(api.kernel_timing_read(L._h, C.byref(k_us), C.byref(k_n)))
+    L._check(api.kernel_timing(L._h, 0))
+
+    # full-size properties (window parity against oracle clusters: tests/test_gpu_fullsize.py): what the
+    # reference's rules make of this trace (SURVEY.md §7.3 Q4/Q5) - a failing partition stays leaderless
+    # (every replica that was not restarted still remembers its vote and refuses), the others keep committing
+    T = W + K
+    role = L.read("role")
+    assert (role[failed] == capi.ROLE_FOLLOWER).all() and (role[~failed] == capi.ROLE_LEADER).all(), "leadership"
+    assert (L.read("head")[~failed] == T).all() and (L.read("commit")[~failed] >= T - 3).all(), "healthy partitions commit"
+    for e in nodes:
+        assert not e.read("fault").any() and (e.read("role")[failed] != capi.ROLE_LEADER).all()
+    assert kept[0] == 0 and sum(len(e.drain_messages()) for e in nodes) == 0, "rows left the transport's vocabulary"
+
+    if world > 1:
+        tw = torch.tensor([wall, ev_ms.value], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        td = torch.tensor([decisions, float(delivered[1])], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(td, op=dist.ReduceOp.SUM)
+        wall, decisions, delivered[1] = tw[0].item(), td[0].item(), td[1].item()
+    if rank == 0:
+        lb, fb = node_alg_bytes(R)
+        alg = (lb + (R - 1) * fb) * G
+        round_s = wall / K
+        out = {
+            "metric": "Raft quorum decisions/sec over N partitions; achieved HBM GB/s vs roofline",
+            "value": decisions / wall, "unit": "decisions/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall * 1e3 / K, "ms_per_step_events": ev_ms.value / K, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[4] as specified: closed loop of {R} nodes x {G} partitions on one GPU, "
+                                   f"{args.failures} %/round of the partitions lose their leader (crash + restart), a restarted "
+                                   "follower times out and campaigns, votes answered through can_vote and routed between "
+                                   "the nodes on the device, applied the round after; 1 client request per led partition per round",
+                       "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world,
+                       "parallelism": f"{world} independent shard(s), no collective"},
+            "group_rounds_per_s": G * world * K / wall,
+            "leaderless_fraction": {"at_start_of_timed_region": None, "at_end": float(failed.mean())},
+            "rows_routed_per_round": delivered[1] / K / world,
+            "roofline": {"bound": "hbm", "achieved": alg / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": f"one round: k_leader_node_tick<{R}> + {R - 1} x k_follower_tick_dense + slow kernels "
+                                   f"+ {R} x k_apply_rows over the routed rows + the transport (k_route_*, radix sort)",
+                         "alg_bytes_per_launch": alg, "avg_launch_us": round_s * 1e6,
+                         "alg_bytes_per_group": {"leader_half": lb, "follower_half": fb},
+                         "frac_of_measured_copy": alg / round_s / 1e9 / 6290.0,
+                         "note": "priced with the dense halves only (every partition's tick); the routed rows and the "
+                                 "general state machine they run through are the overhead this line shows; one host "
+                                 "synchronisation per round (the transport's row counts)",
+                         "leader_kernel": {"kernel": f"k_leader_node_tick<{R}> (leaderless partitions deferred to k_dense_slow)",
+                                           "avg_launch_us": k_us.value, "launches_timed": k_n.value,
+                                           "alg_bytes_per_launch": lb * G,
+                                           "achieved": lb * G / (k_us.value * 1e-6) / 1e9 if k_us.value else None,
+                                           "frac": lb * G / (k_us.value * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us.value else None}},
+        }
+        W_failed = np.zeros(G, bool)
+        for t in range(W):
+            c = cluster_failure_rows(args.seed, t, G, R, args.failures, group_base=rank * G)[0]
+            if c is not None:
+                W_failed[c["group"]] = True
+        out["leaderless_fraction"]["at_start_of_timed_region"] = float(W_failed.mean())
+        print(json.dumps(out), flush=True)
+    lib.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

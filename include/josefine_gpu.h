@@ -416,6 +416,31 @@ int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms
 /* The mailbox columns, for inspection: the leader's inbox / outbox as the structs above. */
 int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_leader_outbox* out);
 
+/* One protocol round WITH a transport for everything outside the mailbox vocabulary — elections above
+ * all: in the reference a VoteRequest leaves on rpc_tx, crosses tcp.rs and comes back out of the peer's
+ * event loop as a Command (server.rs:127-137); here the rows the nodes queued during the round are
+ * taken out of their undrained output ON THE DEVICE and become the addressees' first step of the next
+ * routed round.  Per node and call:
+ *   1. jg_step over the rows delivered by the previous call, then over inject[node] (a device batch as
+ *      for jg_step_device_rows, or n == 0; NULL = nothing for anybody) — per group: the peers' rows in
+ *      the order (sender slot, emission order), then the injected ones;
+ *   2. the dense round of jg_dense_cluster_rounds at now_ms, except that the ClientRequests of
+ *      jg_dense_cluster_set_appends are offered only to groups nodes[lead] leads at that moment (a
+ *      replica without a leader queues them, follower.rs:258-270: not a dense append);
+ *   3. the transport: rows addressed to members (JG_TO_PEERS: all other members; JG_TO_PEER: to_id)
+ *      are delivered, EXCEPT AppendEntries rows (the payload is the sender's block store) and
+ *      ClientRequest rows (instructions to the host adapter about its request mirror): those, and
+ *      everything addressed elsewhere, stay queued for jg_drain_messages, as do FSM rows.
+ * A sender whose round left nothing for the host needs no drain (its output regions are recycled).
+ * The nodes must share a device.  Synchronises with the host once per call (row counts). */
+typedef struct jg_route_stats {
+  uint64_t delivered[JG_MAX_REPLICAS]; /* rows queued for node n's next routed round                   */
+  uint64_t kept;                       /* message rows of this round left for jg_drain_messages        */
+  uint64_t fsm_rows;                   /* FSM rows this round's steps queued (jg_drain_applies)        */
+} jg_route_stats;
+int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_batch* inject /* [n_nodes] or NULL */,
+                                  jg_route_stats* stats /* may be NULL */);
+
 /* Batched Chain::compact (src/raft/chain.rs:239-253) as a pure function over
  * explicit (id,next) trees: tree t owns entries [off[t], off[t+1]); ids within a
  * tree need not be sorted.  removed[i] = 1 iff the walk removes entry i. */

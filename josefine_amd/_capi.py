@@ -96,6 +96,11 @@ class ShardInfo(C.Structure):
                 ("n_groups", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class RouteStats(C.Structure):
+    """jg_route_stats."""
+    _fields_ = [("delivered", C.c_uint64 * 8), ("kept", C.c_uint64), ("fsm_rows", C.c_uint64)]
+
+
 class CmdBatch(C.Structure):
     _fields_ = [
         ("n", C.c_size_t),
@@ -195,6 +200,7 @@ class Api:
         "dense_cluster_set_appends": (C.c_int, [_P, C.c_uint64, _P]),
         "dense_cluster_rounds": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32]),
         "dense_cluster_mailboxes": (C.c_int, [_P, C.POINTER(LeaderInbox), C.POINTER(LeaderOutbox)]),
+        "dense_cluster_round_routed": (C.c_int, [_P, C.c_uint64, C.POINTER(CmdBatch), C.POINTER(RouteStats)]),
         "kernel_timing": (C.c_int, [_P, C.c_int]),
         "kernel_timing_read": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     }
@@ -236,5 +242,5 @@ HEADER_SYMBOLS = [
     "jg_step_dense_leader", "jg_step_dense_follower", "jg_chain_compact", "jg_chain_compact_resident", "jg_drain_compacted", "jg_sync", "jg_stream_wait",
     "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_drain_prefetch", "jg_drain_flush", "jg_drain_wait", "jg_read_state", "jg_get_counters",
     "jg_device_alloc", "jg_device_free", "jg_device_upload", "jg_device_download",
-    "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_dense_cluster_create", "jg_dense_cluster_destroy", "jg_dense_cluster_set_appends", "jg_dense_cluster_rounds", "jg_dense_cluster_mailboxes", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",
+    "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_dense_cluster_create", "jg_dense_cluster_destroy", "jg_dense_cluster_set_appends", "jg_dense_cluster_rounds", "jg_dense_cluster_mailboxes", "jg_dense_cluster_round_routed", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",
 ]

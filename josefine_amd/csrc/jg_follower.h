@@ -14,8 +14,8 @@
 //                  run form), ack row
 //   Tick           election timer; a follower that has voted never campaigns (follower.rs:249, Q4)
 //
-// Everything else (candidates, leaders with input, irregular chains, queued requests, a timer
-// that fires on a follower that has not voted) is deferred (jg_defer_push) to k_follower_slow,
+// Everything else (candidates whose timer fires, leaders with input, input for irregular chains or
+// with queued requests, a timer that fires on a follower that has not voted) is deferred (jg_defer_push) to k_follower_slow,
 // which runs the general state machine and maps AppendResponse / HeartbeatResponse rows back to
 // the outbox columns; rows outside the mailbox vocabulary go to the exceptional queue.
 //
@@ -66,7 +66,13 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFol
     const bool dead = (f & JGF_FAULT_MASK) != 0;
     // leaders ignore Heartbeat (leader.rs:263) and are ticked by the leader half
     const bool idle_leader = role == JG_ROLE_LEADER && !has_ae;
-    const bool nothing = !has_hb && !has_ae && !a.tick;
+    // a Tick alone changes nothing unless the election timer has fired - and then only for a candidate
+    // or a follower that has not voted (follower.rs:121-128,248-256; candidate.rs:46-66): whatever the
+    // chain looks like (a restarted replica's is not in run form), such a group needs no general path
+    const bool fired = (a.now - et) > (uint64_t)eto;
+    const bool quiet = !has_hb && !has_ae &&
+                       ((role == JG_ROLE_FOLLOWER && (!fired || (f & JGF_VOTED))) || (role == JG_ROLE_CANDIDATE && !fired));
+    const bool nothing = (!has_hb && !has_ae && !a.tick) || quiet;
     const bool fast = role == JG_ROLE_FOLLOWER && (f & JGF_RUN) && queued == 0;
     const bool defer = !dead && !idle_leader && !nothing && !fast;
     jg_defer_push(d, g, defer);

@@ -15,20 +15,23 @@
 // about its request mirror (josefine_gpu.h, "client request queue rows").
 #pragma once
 #include "jg_device.h"
+#include "jg_sparse.h"
 
-#define JG_ROUTE_ORD_BITS 27u  // key: group << 32 | sender slot << 29 | step of the round << 27 | emission index
-#define JG_ROUTE_INJECT_SRC 7u
-
+#define JG_ROUTE_ORD_BITS 27u
+// ordering key of a delivered row, most significant first: destination member (3 bits, right above
+// the group's bits), group, sender slot (3), step of the round (2), emission index (27)
 struct JgRouteTable {
-  uint32_t R, src;                        // members, the sending member's index
-  uint32_t member_id[JG_MAX_REPLICAS];    // NodeId of member n
-  uint64_t* key[JG_MAX_REPLICAS];         // staging of destination n (scatter pass)
-  jg_msg_row* row[JG_MAX_REPLICAS];
-  uint32_t cap[JG_MAX_REPLICAS];
-  uint32_t* cursor;                       // [R]   scatter positions
-  uint32_t* count;                        // [R+3] count pass: rows per destination, kept rows, fsm rows, overflow
+  uint32_t R, src;                      // members, the sending member's index
+  uint32_t member_id[JG_MAX_REPLICAS];  // NodeId of member n
+  uint32_t group_bits;                  // bits of a group index
+  uint32_t cap;                         // entries of the staging below
+  uint64_t* key;                        // staging shared by all destinations (the sort separates them)
+  uint32_t* idx;
+  jg_msg_row* row;
+  uint32_t* cursor;                     // staging entries reserved so far
+  uint32_t* count;                      // [R+4] of this sender: rows per destination, then JG_ROUTE_*
 };
-enum { JG_ROUTE_KEPT = 0, JG_ROUTE_FSM = 1, JG_ROUTE_OVERFLOW = 2 };  // count[R + …]
+enum { JG_ROUTE_KEPT = 0, JG_ROUTE_FSM = 1, JG_ROUTE_OVERFLOW = 2, JG_ROUTE_KEPT_XQ = 3 };  // count[R + …]
 
 // the members a row is delivered to, as a bit mask
 __device__ __forceinline__ uint32_t jg_route_dests(const jg_msg_row& r, const JgRouteTable& t) {
@@ -42,101 +45,164 @@ __device__ __forceinline__ uint32_t jg_route_dests(const jg_msg_row& r, const Jg
     if (n < t.R && t.member_id[n] == r.to_id) m |= 1u << n;
   return m & all;
 }
-
-// one wave-aggregated reservation per destination and iteration
-__device__ __forceinline__ void jg_route_emit(const JgRouteTable& t, uint32_t mask, const jg_msg_row& r, uint64_t key,
-                                              bool scatter) {
-  const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t n = 0; n < t.R; n++) {
-    const uint64_t b = __ballot((mask >> n) & 1u);
-    if (!b) continue;
-    const uint32_t first = (uint32_t)__ffsll((long long)b) - 1u;
-    uint32_t base = 0;
-    if (lane == first) base = atomicAdd(scatter ? &t.cursor[n] : &t.count[n], (uint32_t)__popcll(b));
-    base = __shfl(base, (int)first, 64);
-    if (scatter && ((mask >> n) & 1u)) {
-      const uint32_t pos = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-      if (pos < t.cap[n]) {
-        t.key[n][pos] = key;
-        t.row[n][pos] = r;
-      } else {
-        t.count[t.R + JG_ROUTE_OVERFLOW] = 1;
-      }
-    }
+__device__ __forceinline__ uint64_t jg_route_key(const JgRouteTable& t, uint32_t dest, uint32_t group, uint32_t step,
+                                                 uint32_t ord) {
+  return ((uint64_t)dest << t.group_bits | group) << 32 | (uint64_t)t.src << 29 | (uint64_t)step << JG_ROUTE_ORD_BITS | ord;
+}
+// One staging reservation per workgroup and tile (every wave of a launch reserving for itself made the
+// one cursor the bottleneck: a returning atomic on a single address retires every ~18 ns, 85 us for the
+// 4.7 k waves of a 300 k-slot step).  Returns the calling thread's first position.
+__device__ __forceinline__ uint32_t jg_route_reserve(const JgRouteTable& t, uint32_t c) {
+  __shared__ uint32_t base_s;
+  uint32_t tot;
+  const uint32_t excl = jg_block_exclusive_scan(c, &tot);
+  if (threadIdx.x == 0) base_s = tot ? atomicAdd(t.cursor, tot) : 0u;
+  __syncthreads();
+  const uint32_t pos = base_s + excl;
+  __syncthreads();  // (base_s is reused by the next tile)
+  return pos;
+}
+// The launch's tallies -> the sender's count words, one global atomic per workgroup and word (per wave
+// they queued up behind each other on a handful of addresses).  `pd_*`: rows per destination, 16 bits
+// each (destinations 0-3 in lo, 4-7 in hi); call once, at the end of the kernel, from every thread.
+__device__ __forceinline__ void jg_route_tally(const JgRouteTable& t, uint64_t pd_lo, uint64_t pd_hi, uint32_t kept,
+                                               uint32_t kept_word, uint32_t fsm) {
+  __shared__ uint32_t tally_s[JG_MAX_REPLICAS + 2];
+  if (threadIdx.x < JG_MAX_REPLICAS + 2) tally_s[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int off = 32; off; off >>= 1) {
+    pd_lo += __shfl_down(pd_lo, off, 64);
+    pd_hi += __shfl_down(pd_hi, off, 64);
+    kept += __shfl_down(kept, off, 64);
+    fsm += __shfl_down(fsm, off, 64);
   }
+  if ((threadIdx.x & 63u) == 0) {
+    for (uint32_t n = 0; n < t.R; n++) {
+      const uint32_t v = (uint32_t)((n < 4 ? pd_lo : pd_hi) >> (16 * (n & 3u))) & 0xffffu;
+      if (v) atomicAdd(&tally_s[n], v);
+    }
+    if (kept) atomicAdd(&tally_s[JG_MAX_REPLICAS], kept);
+    if (fsm) atomicAdd(&tally_s[JG_MAX_REPLICAS + 1], fsm);
+  }
+  __syncthreads();
+  if (threadIdx.x < t.R && tally_s[threadIdx.x]) atomicAdd(&t.count[threadIdx.x], tally_s[threadIdx.x]);
+  if (threadIdx.x == JG_MAX_REPLICAS && tally_s[JG_MAX_REPLICAS]) atomicAdd(&t.count[t.R + kept_word], tally_s[JG_MAX_REPLICAS]);
+  if (threadIdx.x == JG_MAX_REPLICAS + 1 && tally_s[JG_MAX_REPLICAS + 1])
+    atomicAdd(&t.count[t.R + JG_ROUTE_FSM], tally_s[JG_MAX_REPLICAS + 1]);
+}
+__device__ __forceinline__ void jg_route_note(uint64_t& pd_lo, uint64_t& pd_hi, uint32_t dest) {
+  if (dest < 4) pd_lo += 1ull << (16 * dest);
+  else pd_hi += 1ull << (16 * (dest - 4));
 }
 
-// The slots of one sparse step.  SCATTER = false: count only.  SCATTER = true: deliver, and
-// compact the rows that stay to the front of their slot (msg_cnt rewritten).
-template <bool SCATTER>
+// The slots of one sparse step: every deliverable row goes to the staging (nothing is modified: the
+// pass can be repeated with a larger staging); rows that stay and FSM rows are counted.
+#define JG_ROUTE_ITEMS 2  // slots per thread: a workgroup serves a tile of JG_BLOCK * JG_ROUTE_ITEMS
 __global__ __launch_bounds__(JG_BLOCK) void k_route_rec(JgRouteTable t, uint32_t n, uint32_t per_row, uint32_t step,
-                                                        uint32_t* __restrict__ msg_cnt, jg_msg_row* __restrict__ msg,
+                                                        const uint32_t* __restrict__ msg_cnt,
+                                                        const jg_msg_row* __restrict__ msg,
                                                         const uint32_t* __restrict__ fsm_cnt) {
-  const uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x;
-  const uint32_t cnt = i < n ? msg_cnt[i] : 0u;
-  uint32_t kept = 0;
-  for (uint32_t j = 0; __any(j < cnt); j++) {
-    uint32_t mask = 0;
-    jg_msg_row r{};
-    if (j < cnt) {
-      r = msg[(size_t)i * per_row + j];
-      mask = jg_route_dests(r, t);
-      if (!mask) {
-        if (SCATTER && kept != j) msg[(size_t)i * per_row + kept] = r;
-        kept++;
+  const uint32_t tile0 = blockIdx.x * (JG_BLOCK * JG_ROUTE_ITEMS) + threadIdx.x;
+  uint32_t cnt[JG_ROUTE_ITEMS];
+  uint32_t c = 0, kept = 0, f = 0;
+  uint64_t pd_lo = 0, pd_hi = 0;
+#pragma unroll
+  for (int k = 0; k < JG_ROUTE_ITEMS; k++) {
+    const uint32_t i = tile0 + k * JG_BLOCK;
+    cnt[k] = i < n ? msg_cnt[i] : 0u;
+    f += i < n ? fsm_cnt[i] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < JG_ROUTE_ITEMS; k++) {
+    const jg_msg_row* mine = msg + (size_t)(tile0 + k * JG_BLOCK) * per_row;
+    for (uint32_t j = 0; j < cnt[k]; j++) {
+      const uint32_t m = jg_route_dests(mine[j], t);
+      c += __popc(m);
+      kept += !m;
+      for (uint32_t b = m; b; b &= b - 1) jg_route_note(pd_lo, pd_hi, (uint32_t)__ffs(b) - 1u);
+    }
+  }
+  uint32_t pos = jg_route_reserve(t, c);
+  if (c) {
+#pragma unroll
+    for (int k = 0; k < JG_ROUTE_ITEMS; k++) {
+      const uint32_t i = tile0 + k * JG_BLOCK;
+      const jg_msg_row* mine = msg + (size_t)i * per_row;
+      for (uint32_t j = 0; j < cnt[k]; j++) {
+        const jg_msg_row r = mine[j];
+        for (uint32_t b = jg_route_dests(r, t); b; b &= b - 1, pos++) {
+          if (pos >= t.cap) continue;  // (the host sees cursor > cap, grows the staging and repeats the pass)
+          t.key[pos] = jg_route_key(t, (uint32_t)__ffs(b) - 1u, r.group, step, i * per_row + j);
+          t.idx[pos] = pos;
+          t.row[pos] = r;
+        }
       }
     }
-    const uint64_t ord = (uint64_t)i * per_row + j;
-    const uint64_t key = (uint64_t)r.group << 32 | (uint64_t)t.src << 29 | (uint64_t)step << JG_ROUTE_ORD_BITS | ord;
-    jg_route_emit(t, mask, r, key, SCATTER);
   }
-  if (SCATTER) {
-    if (i < n && kept != cnt) msg_cnt[i] = kept;
-  } else {
-    uint32_t f = i < n ? fsm_cnt[i] : 0u;
-    for (int off = 32; off; off >>= 1) {
-      kept += __shfl_down(kept, off, 64);
-      f += __shfl_down(f, off, 64);
-    }
-    if ((threadIdx.x & 63u) == 0) {
-      if (kept) atomicAdd(&t.count[t.R + JG_ROUTE_KEPT], kept);
-      if (f) atomicAdd(&t.count[t.R + JG_ROUTE_FSM], f);
-    }
+  jg_route_tally(t, pd_lo, pd_hi, kept, JG_ROUTE_KEPT, f);
+}
+// second pass, only for a step that keeps rows for the host: the delivered rows leave their slots
+__global__ __launch_bounds__(JG_BLOCK) void k_route_rec_compact(JgRouteTable t, uint32_t n, uint32_t per_row,
+                                                                uint32_t* __restrict__ msg_cnt, jg_msg_row* __restrict__ msg) {
+  const uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t cnt = msg_cnt[i];
+  jg_msg_row* mine = msg + (size_t)i * per_row;
+  uint32_t kept = 0;
+  for (uint32_t j = 0; j < cnt; j++) {
+    const jg_msg_row r = mine[j];
+    if (jg_route_dests(r, t)) continue;
+    if (kept != j) mine[kept] = r;
+    kept++;
   }
+  if (kept != cnt) msg_cnt[i] = kept;
 }
 
-// The exceptional-row queue of the dense steps.  SCATTER: the rows that stay are appended to
-// `keep` (the queue is unordered; its rows carry their own step and emission index).
-template <bool SCATTER>
+// The exceptional-row queue of the dense steps.  COMPACT = false: deliver + count (nothing modified);
+// COMPACT = true: the rows that stay are appended to `keep` (the queue is unordered; its rows carry
+// their own step and emission index).
+template <bool COMPACT>
 __global__ __launch_bounds__(JG_BLOCK) void k_route_xq(JgRouteTable t, const JgXqRec* __restrict__ xq,
                                                        const uint32_t* __restrict__ xq_n, uint32_t xq_cap,
                                                        uint32_t seq_base, JgXqRec* __restrict__ keep,
                                                        uint32_t* __restrict__ keep_n) {
   const uint32_t n = min(*xq_n, xq_cap);
   const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t i0 = (blockIdx.x * JG_BLOCK + threadIdx.x) & ~63u; i0 < n; i0 += gridDim.x * JG_BLOCK) {
-    const uint32_t i = i0 + lane;
+  uint64_t pd_lo = 0, pd_hi = 0;
+  uint32_t stays = 0;
+  for (uint32_t i0 = blockIdx.x * JG_BLOCK; i0 < n; i0 += gridDim.x * JG_BLOCK) {  // (block-uniform trip count)
+    const uint32_t i = i0 + threadIdx.x;
     uint32_t mask = 0;
     JgXqRec q{};
-    bool stay = false;
     if (i < n) {
       q = xq[i];
       mask = jg_route_dests(q.row, t);
-      stay = !mask;
+    }
+    const bool stay = i < n && !mask;
+    if (COMPACT) {
+      const uint64_t b = __ballot(stay);
+      if (b) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(keep_n, (uint32_t)__popcll(b));
+        base = __shfl(base, 0, 64);
+        if (stay) keep[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = q;
+      }
+      continue;
     }
     const uint32_t step = q.seq - seq_base;
     if (mask && (step > 3u || q.k >> JG_ROUTE_ORD_BITS)) t.count[t.R + JG_ROUTE_OVERFLOW] = 1;
-    const uint64_t key = (uint64_t)q.row.group << 32 | (uint64_t)t.src << 29 | (uint64_t)(step & 3u) << JG_ROUTE_ORD_BITS | q.k;
-    jg_route_emit(t, mask, q.row, key, SCATTER);
-    const uint64_t b = __ballot(stay);
-    if (b) {
-      const uint32_t first = (uint32_t)__ffsll((long long)b) - 1u;
-      uint32_t base = 0;
-      if (lane == first) base = atomicAdd(SCATTER ? keep_n : &t.count[t.R + JG_ROUTE_KEPT], (uint32_t)__popcll(b));
-      base = __shfl(base, (int)first, 64);
-      if (SCATTER && stay) keep[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = q;
+    uint32_t pos = jg_route_reserve(t, __popc(mask));
+    stays += stay;
+    for (uint32_t b = mask; b; b &= b - 1, pos++) {
+      jg_route_note(pd_lo, pd_hi, (uint32_t)__ffs(b) - 1u);
+      if (pos >= t.cap) continue;
+      t.key[pos] = jg_route_key(t, (uint32_t)__ffs(b) - 1u, q.row.group, step & 3u, q.k);
+      t.idx[pos] = pos;
+      t.row[pos] = q.row;
     }
   }
+  if (!COMPACT) jg_route_tally(t, pd_lo, pd_hi, stays, JG_ROUTE_KEPT_XQ, 0);
 }
 
 // sorted staging -> the command columns k_apply_rows consumes
@@ -157,10 +223,6 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_build(uint32_t n, const uint
   c.term[p] = r.term;
   c.id[p] = r.id;
   c.aux[p] = r.aux;
-}
-__global__ void k_route_iota(uint32_t n, uint32_t* __restrict__ v) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) v[p] = p;
 }
 
 // ClientRequests are offered only where the lead node leads (at a leaderless replica the reference

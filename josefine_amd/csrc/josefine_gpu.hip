@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "jg_kernels.h"
+#include "jg_route.h"
 #include "jg_follower.h"
 
 static thread_local std::string g_err;
@@ -1388,6 +1389,27 @@ struct jg_dense_cluster {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   uint64_t sig = 0, graph_dt = 0;
+  uint64_t* offered = nullptr;  // [G] the ClientRequests per round as set by jg_dense_cluster_set_appends
+  // jg_dense_cluster_round_routed: per destination node, the staging the senders' rows are scattered
+  // into, its sort scratch, and the command columns of the node's next round (all grow-only)
+  struct Route {
+    uint32_t* d_count = nullptr;  // [R][R+4] per sender: rows per destination + JG_ROUTE_*; then the staging cursor; then [R] kept exceptional rows
+    uint32_t* h_count = nullptr;  // pinned mirror
+    // staging shared by all destinations, its sort scratch, the sorted command columns (node n's rows
+    // are the slice [in_off[n], in_off[n] + n_in[n]) of every column); all grow-only
+    uint64_t *key = nullptr, *key_alt = nullptr;
+    uint32_t *idx = nullptr, *idx_alt = nullptr;
+    jg_msg_row* row = nullptr;
+    uint32_t cap = 0;
+    JgRouteCols cols{};
+    char* cols_mem = nullptr;
+    std::vector<uint32_t> n_in, in_off;
+    std::vector<JgXqRec*> xq_keep;  // per node, lazily: where the exceptional rows that stay are compacted
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    uint32_t group_bits = 1;
+    bool ready = false;
+  } rt;
 };
 
 int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t lead, jg_dense_cluster** out) {
@@ -1412,7 +1434,7 @@ int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t 
   if ((rc = alloc(8 * R * G, (void**)&c->acks)) || (rc = alloc(8 * R * G, (void**)&c->hbr_commit)) ||
       (rc = alloc(R * G, (void**)&c->hbr_has)) || (rc = alloc(8 * G, (void**)&c->o_term)) ||
       (rc = alloc(8 * G, (void**)&c->o_hb)) || (rc = alloc(8 * R * G, (void**)&c->o_from)) ||
-      (rc = alloc(R * G, (void**)&c->o_n))) {
+      (rc = alloc(R * G, (void**)&c->o_n)) || (rc = alloc(8 * G, (void**)&c->offered))) {
     jg_dense_cluster_destroy(c);
     return rc;
   }
@@ -1431,6 +1453,13 @@ void jg_dense_cluster_destroy(jg_dense_cluster* c) {
   if (c->exec) (void)hipGraphExecDestroy(c->exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
   for (void* p : c->bufs) (void)jg_device_free(c->nodes[c->lead], p);
+  for (void* p : {(void*)c->rt.key, (void*)c->rt.key_alt, (void*)c->rt.idx, (void*)c->rt.idx_alt, (void*)c->rt.row, (void*)c->rt.cols_mem})
+    if (p) (void)hipFree(p);
+  for (JgXqRec* p : c->rt.xq_keep)
+    if (p) (void)hipFree(p);
+  if (c->rt.sort_tmp) (void)hipFree(c->rt.sort_tmp);
+  if (c->rt.d_count) (void)hipFree(c->rt.d_count);
+  if (c->rt.h_count) (void)hipHostFree(c->rt.h_count);
   delete c;
 }
 
@@ -1438,7 +1467,10 @@ int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const ui
   if (!c) return fail(JG_EINVAL, "null argument");
   std::vector<uint64_t> v;
   if (!per_group) v.assign(c->G, uniform);
-  return jg_device_upload(c->nodes[c->lead], c->acks + (size_t)c->lead * c->G, per_group ? per_group : v.data(), (size_t)c->G * 8);
+  const uint64_t* src = per_group ? per_group : v.data();
+  int rc = jg_device_upload(c->nodes[c->lead], c->offered, src, (size_t)c->G * 8);
+  if (rc) return rc;
+  return jg_device_upload(c->nodes[c->lead], c->acks + (size_t)c->lead * c->G, src, (size_t)c->G * 8);
 }
 
 int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_leader_outbox* out) {
@@ -1566,6 +1598,212 @@ int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms
   HIPCHK(hipGetLastError());
   for (uint32_t r = 0; r < c->R; r++)  // later work on the followers' own streams comes behind the replayed rounds
     if (r != c->lead && (rc = jg_stream_wait(c->nodes[r], L))) return rc;
+  return JG_OK;
+}
+
+namespace {
+constexpr uint32_t ROUTE_WORDS = JG_MAX_REPLICAS + 4;  // per sender: rows per destination, kept, fsm rows, overflow, kept exceptional rows
+
+int route_grow(jg_dense_cluster::Route& d, size_t need) {
+  if (need <= d.cap) return JG_OK;
+  for (void* p : {(void*)d.key, (void*)d.key_alt, (void*)d.idx, (void*)d.idx_alt, (void*)d.row, (void*)d.cols_mem})
+    if (p) HIPCHK(hipFree(p));
+  const size_t cap = std::max<size_t>(need + need / 2, 65536);
+  if (cap > 0x7fffffffull) return fail(JG_ECAPACITY, "routed round: too many rows");
+  HIPCHK(hipMalloc((void**)&d.key, cap * 8));
+  HIPCHK(hipMalloc((void**)&d.key_alt, cap * 8));
+  HIPCHK(hipMalloc((void**)&d.idx, cap * 4));
+  HIPCHK(hipMalloc((void**)&d.idx_alt, cap * 4));
+  HIPCHK(hipMalloc((void**)&d.row, cap * sizeof(jg_msg_row)));
+  HIPCHK(hipMalloc((void**)&d.cols_mem, cap * 34));  // 3 x 8 + 2 x 4 + 2 x 1 bytes per row, widest columns first
+  char* m = d.cols_mem;
+  d.cols.term = (uint64_t*)m, m += cap * 8;
+  d.cols.id = (uint64_t*)m, m += cap * 8;
+  d.cols.aux = (uint64_t*)m, m += cap * 8;
+  d.cols.group = (uint32_t*)m, m += cap * 4;
+  d.cols.from = (uint32_t*)m, m += cap * 4;
+  d.cols.kind = (uint8_t*)m, m += cap;
+  d.cols.flag = (uint8_t*)m;
+  d.cap = (uint32_t)cap;
+  return JG_OK;
+}
+}  // namespace
+
+int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_batch* inject, jg_route_stats* stats) {
+  if (!c) return fail(JG_EINVAL, "null argument");
+  jg_engine* L = c->nodes[c->lead];
+  const uint32_t R = c->R;
+  int rc = JG_OK;
+  for (jg_engine* e : c->nodes) {
+    if (e->device != L->device) return fail(JG_EINVAL, "routed rounds take nodes that share a device");
+    if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
+    if (e->inflight.phase || e->pipelined) return fail(JG_EINVAL, "a drain is in transfer: jg_drain_flush first");
+    if ((rc = ensure_xq(e))) return rc;
+  }
+  HIPCHK(hipSetDevice(L->device));
+  static const bool trace = std::getenv("JG_TRACE_ROUTE") != nullptr;
+  auto clk = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double T0 = clk();
+  double T1 = T0, T2 = T0, T3 = T0, T4 = T0;
+  jg_dense_cluster::Route& rt = c->rt;
+  const size_t words = (size_t)R * ROUTE_WORDS + 1 + R;
+  if (!rt.ready) {
+    HIPCHK(hipMalloc((void**)&rt.d_count, words * 4));
+    HIPCHK(hipHostMalloc((void**)&rt.h_count, words * 4, hipHostMallocDefault));
+    rt.n_in.assign(R, 0), rt.in_off.assign(R, 0);
+    rt.xq_keep.assign(R, nullptr);
+    while (rt.group_bits < 32 && (c->G - 1) >> rt.group_bits) rt.group_bits++;
+    if (rt.group_bits > 29) return fail(JG_EINVAL, "routed rounds: too many groups for the transport's ordering key");
+    if ((rc = route_grow(rt, 1))) return rc;
+    rt.ready = true;
+  }
+  // -- 1. what the transport delivered last round, then this round's injected rows (per group: in that order)
+  std::vector<uint32_t> seq_base(R);
+  for (uint32_t n = 0; n < R; n++) {
+    jg_engine* e = c->nodes[n];
+    seq_base[n] = e->seq;
+    if (rt.n_in[n]) {
+      const size_t o = rt.in_off[n];
+      e->stepped = true;
+      e->seq++;
+      if ((rc = launch_rows(e, rt.n_in[n], rt.cols.group + o, rt.cols.kind + o, rt.cols.from + o, rt.cols.term + o, rt.cols.id + o,
+                            rt.cols.aux + o, rt.cols.flag + o, nullptr, nullptr, now_ms)))
+        return rc;
+      rt.n_in[n] = 0;
+    }
+    if (inject && inject[n].n) {
+      if (inject[n].n_blocks) return fail(JG_EINVAL, "injected rows cannot carry blocks");
+      if ((rc = jg_step_device_rows(e, &inject[n], now_ms))) return rc;
+    }
+  }
+  // -- 2. the dense round; ClientRequests only where the lead node (still) leads
+  hipLaunchKernelGGL(k_route_mask_appends, dim3((c->G + 255) / 256), dim3(256), 0, L->stream, c->G, (const uint32_t*)L->dev.flags,
+                     (const uint64_t*)c->offered, c->acks + (size_t)c->lead * c->G);
+  if ((rc = cluster_round_body(c, now_ms, true))) return rc;
+  T1 = clk();
+  // -- 3. the transport, on the lead node's stream behind everybody's round
+  for (uint32_t r = 0; r < R; r++)
+    if (r != c->lead && (rc = jg_stream_wait(L, c->nodes[r]))) return rc;
+  hipStream_t st = L->stream;
+  uint32_t* d_cursor = rt.d_count + (size_t)R * ROUTE_WORDS;
+  uint32_t* d_keep_n = d_cursor + 1;
+  auto table = [&](uint32_t s) {
+    JgRouteTable t{};
+    t.R = R, t.src = s;
+    for (uint32_t n = 0; n < R; n++) t.member_id[n] = c->nodes[n]->cfg.node_ids[n];
+    t.group_bits = rt.group_bits, t.cap = rt.cap;
+    t.key = rt.key, t.idx = rt.idx, t.row = rt.row;
+    t.cursor = d_cursor;
+    t.count = rt.d_count + (size_t)s * ROUTE_WORDS;
+    return t;
+  };
+  for (uint32_t s = 0; s < R; s++)
+    for (const StepRec& r : c->nodes[s]->recs)
+      if (r.seq > seq_base[s] && (r.seq - seq_base[s] > 3 || (uint64_t)r.n * r.msg_per_row >> JG_ROUTE_ORD_BITS))
+        return fail(JG_ECAPACITY, "routed round: a step is too large for the transport's ordering key");
+  const uint32_t* h_cursor = rt.h_count + (size_t)R * ROUTE_WORDS;
+  for (int attempt = 0;; attempt++) {  // (repeated once when the staging turns out too small: the pass modifies nothing)
+    HIPCHK(hipMemsetAsync(rt.d_count, 0, words * 4, st));
+    for (uint32_t s = 0; s < R; s++) {
+      jg_engine* e = c->nodes[s];
+      const JgRouteTable t = table(s);
+      for (const StepRec& r : e->recs)
+        if (r.seq > seq_base[s])
+          hipLaunchKernelGGL(k_route_rec, dim3((r.n + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS)), dim3(JG_BLOCK), 0, st, t, r.n, r.msg_per_row,
+                             r.seq - seq_base[s], (const uint32_t*)r.d_msg_cnt, (const jg_msg_row*)r.d_msg, (const uint32_t*)r.d_fsm_cnt);
+      hipLaunchKernelGGL(k_route_xq<false>, dim3(1024), dim3(JG_BLOCK), 0, st, t, (const JgXqRec*)e->dev.xq, (const uint32_t*)e->dev.xq_n,
+                         e->dev.xq_cap, seq_base[s], (JgXqRec*)nullptr, (uint32_t*)nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(rt.h_count, rt.d_count, words * 4, hipMemcpyDeviceToHost, st));
+    T2 = clk();
+    HIPCHK(hipStreamSynchronize(st));
+    T3 = clk();
+    if (*h_cursor <= rt.cap) break;
+    if (attempt) return fail(JG_EDEVICE, "internal: routed round: staging still too small");
+    if ((rc = route_grow(rt, *h_cursor))) return rc;
+  }
+  const uint32_t total = *h_cursor;
+  std::vector<uint64_t> to(R, 0), from(R, 0);
+  uint64_t kept = 0, fsm = 0;
+  for (uint32_t s = 0; s < R; s++) {
+    const uint32_t* h = rt.h_count + (size_t)s * ROUTE_WORDS;
+    if (h[R + JG_ROUTE_OVERFLOW]) return fail(JG_ECAPACITY, "routed round: an exceptional row outside the transport's ordering key");
+    for (uint32_t n = 0; n < R; n++) to[n] += h[n], from[s] += h[n];
+    kept += h[R + JG_ROUTE_KEPT] + h[R + JG_ROUTE_KEPT_XQ];
+    fsm += h[R + JG_ROUTE_FSM];
+  }
+  // senders that keep rows for the host: the delivered ones leave their slots / the exceptional queue
+  for (uint32_t s = 0; s < R; s++) {
+    jg_engine* e = c->nodes[s];
+    const uint32_t* h = rt.h_count + (size_t)s * ROUTE_WORDS;
+    if (!from[s]) continue;
+    const JgRouteTable t = table(s);
+    if (h[R + JG_ROUTE_KEPT])
+      for (const StepRec& r : e->recs) {
+        if (r.seq <= seq_base[s]) continue;
+        hipLaunchKernelGGL(k_route_rec_compact, dim3((r.n + JG_BLOCK - 1) / JG_BLOCK), dim3(JG_BLOCK), 0, st, t, r.n, r.msg_per_row,
+                           r.d_msg_cnt, r.d_msg);
+        hipLaunchKernelGGL(k_count_block_sums, dim3((r.n + JG_SCAN_TILE - 1) / JG_SCAN_TILE), dim3(JG_BLOCK), 0, st, r.d_msg_cnt,
+                           r.d_fsm_cnt, r.n, r.d_bsum_m, r.d_bsum_f);
+      }
+    const uint32_t kx = h[R + JG_ROUTE_KEPT_XQ];
+    if (kx) {
+      if (!rt.xq_keep[s]) HIPCHK(hipMalloc((void**)&rt.xq_keep[s], (size_t)e->dev.xq_cap * sizeof(JgXqRec)));
+      hipLaunchKernelGGL(k_route_xq<true>, dim3(256), dim3(JG_BLOCK), 0, st, t, (const JgXqRec*)e->dev.xq, (const uint32_t*)e->dev.xq_n,
+                         e->dev.xq_cap, seq_base[s], rt.xq_keep[s], d_keep_n + s);
+      HIPCHK(hipMemcpyAsync(e->dev.xq, rt.xq_keep[s], (size_t)kx * sizeof(JgXqRec), hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(e->dev.xq_n, d_keep_n + s, 4, hipMemcpyDeviceToDevice, st));
+    } else {
+      HIPCHK(hipMemsetAsync(e->dev.xq_n, 0, 4, st));
+    }
+  }
+  // one sort for all destinations, then the command columns of every node's next round
+  if (total) {
+    const uint32_t end_bit = 32 + rt.group_bits + 3;
+    size_t need = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, need, rt.key, rt.key_alt, rt.idx, rt.idx_alt, (size_t)total, 0, end_bit, st));
+    if (rt.sort_tmp_bytes < need) {
+      if (rt.sort_tmp) HIPCHK(hipFree(rt.sort_tmp));
+      rt.sort_tmp_bytes = 2 * need;
+      HIPCHK(hipMalloc(&rt.sort_tmp, rt.sort_tmp_bytes));
+    }
+    size_t bytes = rt.sort_tmp_bytes;
+    HIPCHK(rocprim::radix_sort_pairs(rt.sort_tmp, bytes, rt.key, rt.key_alt, rt.idx, rt.idx_alt, (size_t)total, 0, end_bit, st));
+    hipLaunchKernelGGL(k_route_build, dim3((total + JG_BLOCK - 1) / JG_BLOCK), dim3(JG_BLOCK), 0, st, total,
+                       (const uint32_t*)rt.idx_alt, (const jg_msg_row*)rt.row, rt.cols);
+  }
+  uint32_t off = 0;
+  for (uint32_t n = 0; n < R; n++) {
+    rt.in_off[n] = off, rt.n_in[n] = (uint32_t)to[n];
+    off += (uint32_t)to[n];
+  }
+  if (off != total) return fail(JG_EDEVICE, "internal: routed round: row counts disagree");
+  HIPCHK(hipGetLastError());
+  for (uint32_t r = 0; r < R; r++)  // the nodes' next steps come behind the transport
+    if (r != c->lead && (rc = jg_stream_wait(c->nodes[r], L))) return rc;
+  // a round whose sparse steps left nothing for the host needs no drain: its output regions are released here
+  for (uint32_t s = 0; s < R; s++) {
+    jg_engine* e = c->nodes[s];
+    const uint32_t* h = rt.h_count + (size_t)s * ROUTE_WORDS;
+    if (h[R + JG_ROUTE_KEPT] || h[R + JG_ROUTE_FSM]) continue;
+    while (!e->recs.empty() && e->recs.back().seq > seq_base[s]) e->recs.pop_back();
+    if (e->recs.empty()) {
+      // (nothing of this round reads those regions any more: the delivering pass has completed, and
+      // no compaction pass was launched for this sender)
+      e->arenas[e->cur_arena].reset();
+    }
+  }
+  T4 = clk();
+  if (trace)
+    std::fprintf(stderr, "[jg route] steps+round issued %.0f us, delivering pass issued %.0f us, wait %.0f us, sort+build issued %.0f us (%u rows)\n",
+                 T1 - T0, T2 - T1, T3 - T2, T4 - T3, total);
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    for (uint32_t n = 0; n < R; n++) stats->delivered[n] = to[n];
+    stats->kept = kept;
+    stats->fsm_rows = fsm;
+  }
   return JG_OK;
 }
 

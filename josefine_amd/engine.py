@@ -607,3 +607,41 @@ class DeviceRows:
         for p in self._ptrs:
             self.engine.api.device_free(self.engine._h, p)
         self._ptrs = []
+
+
+class DenseCluster:
+    """jg_dense_cluster: the R nodes of every partition as R engines of one process, their
+    protocol rounds driven from inside the library (josefine_gpu.h, "a closed loop of dense node
+    ticks").  `nodes[r]` hosts replica slot r of every group; nodes[lead] is made leader by the
+    caller (traces.elect_all)."""
+
+    def __init__(self, nodes, lead: int = 0):
+        self.nodes, self.lead, self.R = list(nodes), lead, len(nodes)
+        self.api = nodes[0].api
+        arr = (C.c_void_p * self.R)(*[n._h for n in nodes])
+        self._h = C.c_void_p()
+        nodes[0]._check(self.api.dense_cluster_create(arr, self.R, lead, C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            self.api.dense_cluster_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def set_appends(self, uniform: int = 1, per_group=None) -> None:
+        p = None if per_group is None else np.ascontiguousarray(per_group, dtype=np.uint64).ctypes.data
+        self.nodes[0]._check(self.api.dense_cluster_set_appends(self._h, int(uniform), p))
+
+    def rounds(self, now_ms: int, dt_ms: int, n: int) -> None:
+        self.nodes[0]._check(self.api.dense_cluster_rounds(self._h, int(now_ms), int(dt_ms), int(n)))
+
+    def round_routed(self, now_ms: int, inject=None) -> dict:
+        """jg_dense_cluster_round_routed; `inject`: per node a DeviceRows (upload_rows) or None."""
+        arr = None
+        if inject is not None:
+            arr = (capi.CmdBatch * self.R)()
+            for r, rows in enumerate(inject):
+                if rows is not None:
+                    arr[r] = rows.batch
+        st = capi.RouteStats()
+        self.nodes[0]._check(self.api.dense_cluster_round_routed(self._h, int(now_ms), arr, C.byref(st)))
+        return {"delivered": [int(st.delivered[r]) for r in range(self.R)], "kept": int(st.kept), "fsm_rows": int(st.fsm_rows)}

@@ -104,3 +104,28 @@ def failure_rows(seed, tick, group_base, G, R, node_ids, self_slots, percent=1):
     kind, group, frm = np.concatenate(kind), np.concatenate(group), np.concatenate(frm)
     return dict(kind=kind, group=group, from_=frm, term=np.ones(len(kind), np.uint64),
                 flag=np.ones(len(kind), np.uint8)), n
+
+
+def cluster_failure_rows(seed, tick, G, R, percent=1, lead=0, candidate=1, also=(), group_base=0):
+    """BASELINE.json configs[4] on a cluster of R nodes: every group fails with
+    probability percent/100 per tick (the hash of failure_rows: same failing groups).  In a failing
+    group the leader's replica crashes and restarts (State::default(), Chain::new on the persisted
+    tree) and a designated follower — restarted as well, so that voted_for == None: nobody else may
+    campaign — receives Timeout.  The other replicas answer its VoteRequests
+    through can_vote when the transport delivers them, next round.
+    `also`: more replicas that crash and restart with the leader (a rack going down).
+    Returns one column dict (kind, group; group-sorted) or None per node, for
+    jg_dense_cluster_round_routed's `inject`."""
+    gg = np.arange(G, dtype=np.uint64) + np.uint64(group_base)
+    failing = np.nonzero(synth_hash(seed, tick, gg, 7) % np.uint64(100) < np.uint64(percent))[0].astype(np.uint32)
+    n = len(failing)
+    out = [None] * R
+    if n:
+        restart = np.full(n, capi.CMD_RESTART, np.uint8)
+        out[lead] = dict(kind=restart, group=failing)
+        for r in also:
+            out[r] = dict(kind=restart, group=failing)
+        # group-sorted: Restart then Timeout of each failing group
+        out[candidate] = dict(kind=np.stack([restart, np.full(n, capi.CMD_TIMEOUT, np.uint8)], axis=1).reshape(-1),
+                              group=np.repeat(failing, 2))
+    return out

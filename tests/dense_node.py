@@ -168,20 +168,4 @@ class RoutedCluster(DenseCluster):
         return outs
 
 
-def cluster_failure_rows(seed, tick, G, R, percent=1, lead=0, candidate=1):
-    """BASELINE.json configs[4] on a cluster: every group fails with
-    probability percent/100 per tick; in a failing group the leader's replica crashes and
-    restarts (State::default(), Chain::new on the persisted tree) and a designated follower,
-    restarted as well so that voted_for == None (nobody else may campaign),
-    receives Timeout.  The other replicas answer its VoteRequests through can_vote next round.
-    Returns one column dict per node (or None) for RoutedCluster.round(inject=…)."""
-    from josefine_amd.traces import synth_hash
-    gg = np.arange(G, dtype=np.uint64)
-    failing = np.nonzero(synth_hash(seed, tick, gg, 7) % np.uint64(100) < np.uint64(percent))[0].astype(np.uint32)
-    n = len(failing)
-    out = [None] * R
-    if n:
-        out[lead] = dict(kind=np.full(n, capi.CMD_RESTART, np.uint8), group=failing)
-        out[candidate] = dict(kind=np.concatenate([np.full(n, capi.CMD_RESTART, np.uint8), np.full(n, capi.CMD_TIMEOUT, np.uint8)]),
-                              group=np.concatenate([failing, failing]))
-    return out
+from josefine_amd.traces import cluster_failure_rows  # noqa: E402,F401  (shared with bench.py)

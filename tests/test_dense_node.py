@@ -281,3 +281,70 @@ def test_library_driven_rounds_equal_eager_rounds(R, lead):
             assert got.tobytes() == want.tobytes(), (r, fn, len(got), len(want))
     assert int(nodes[lead].read("commit").min()) >= 0 and int(nodes[lead].read("head").max()) == int(appends.max()) * rounds
     api.dense_cluster_destroy(cl)
+
+
+def test_routed_cluster_elections_on_the_oracle():
+    """CPU: the configs[4] cluster trace through the Python statement of the transport.  What the
+    reference's rules make of it: the restarted leader is a follower, the
+    designated candidate is refused by every replica that still remembers a vote — the failing
+    groups stay leaderless, nothing faults, nothing leaves the transport's vocabulary."""
+    from dense_node import RoutedCluster, cluster_failure_rows
+    G, R, T = 600, 5, 40
+    cl = RoutedCluster(oracle_engine, G, R, seed=5)
+    failed = np.zeros(G, bool)
+    for t in range(T):
+        inj = cluster_failure_rows(77, t, G, R, 2) if t >= 3 else None
+        if inj and inj[0] is not None:
+            failed[inj[0]["group"]] = True
+        cl.round(np.ones(G, np.uint64), inject=inj)
+    L = cl.nodes[0]
+    assert failed.sum() > G // 3
+    assert (L.read("role")[failed] == capi.ROLE_FOLLOWER).all() and (L.read("role")[~failed] == capi.ROLE_LEADER).all()
+    assert (L.read("commit")[~failed] >= T - 3).all()
+    for n in cl.nodes:
+        assert (n.read("fault") == 0).all()
+        assert (n.read("role")[failed] != capi.ROLE_LEADER).all()
+    assert sum(len(k) for k in cl.kept) == 0 and cl.delivered.sum() > 0
+    # the voters that were not restarted still hold their vote for the old leader: that is what refuses the candidate
+    assert (cl.nodes[2].read("voted_for")[failed] == L.node_ids[0]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,percent,also", [(3, 3, ()), (5, 2, ()), (5, 2, (2,)), (3, 3, (2,))])
+def test_routed_cluster_device_transport_parity(R, percent, also):
+    """jg_dense_cluster_round_routed (rows routed between the nodes on the device) == the Python-routed
+    oracle cluster: every state column of every node after every round, the number of rows delivered
+    per node and round, and the rows left for the host.  `also`: replicas that restart with the leader, so
+    that the candidate wins and a node other than the lead one leads those groups (its Heartbeats travel
+    as rows through the transport, its AppendEntries stay queued for the host)."""
+    from josefine_amd import DenseCluster as LibCluster
+    from dense_node import RoutedCluster, cluster_failure_rows
+    G, T = 3000, 50
+    ora = RoutedCluster(oracle_engine, G, R, seed=5)
+    nodes = [BatchedRaft(G, R, seed=5 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY)
+             for r in range(R)]
+    elect_all(nodes[0])
+    nodes[0].drain_messages(), nodes[0].drain_applies()
+    lib = LibCluster(nodes)
+    lib.set_appends(1)
+    for t in range(T):
+        inj = cluster_failure_rows(99, t, G, R, percent, also=also) if t >= 3 else [None] * R
+        if t == 20:  # something the transport must leave alone: a client request at every replica of node 2
+            inj[2] = dict(kind=np.full(G, capi.CMD_CLIENT_REQUEST, np.uint8), group=np.arange(G, dtype=np.uint32),
+                          id=np.arange(G, dtype=np.uint64) + 1000)
+        up = [None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(inj)]
+        st = lib.round_routed((t + 1) * 100, up)
+        ora.round(np.ones(G, np.uint64), inject=inj)
+        for n in range(R):
+            compare_snapshots(nodes[n], ora.nodes[n], f"routed round {t} node {n}")
+        assert st["delivered"] == [sum(len(r) for _, r in ora.inbound[n]) for n in range(R)], t
+        for rows in up:
+            if rows is not None:
+                rows.free()
+    assert sum(ora.delivered) > 0 and sum(len(k) for k in ora.kept) >= G
+    for n in range(R):
+        got, want = nodes[n].drain_messages(), ora.kept[n]
+        assert got.tobytes() == want.tobytes(), (n, len(got), len(want))
+        assert nodes[n].drain_faults().tobytes() == ora.nodes[n].drain_faults().tobytes()
+        assert nodes[n].drain_applies().tobytes() == ora.nodes[n].drain_applies().tobytes()
+    lib.close()

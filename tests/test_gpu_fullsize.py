@@ -117,3 +117,54 @@ def test_full_size_closed_loop_cluster():
                 assert np.array_equal(dc.nodes[r].read(name, 0, base, W), oc.nodes[r].read(name)), (base, r, name)
             for q in range(R):
                 assert np.array_equal(dc.nodes[r].read("match", q, base, W), oc.nodes[r].read("match", q)), (base, r, q)
+
+
+def test_full_size_routed_cluster_failures():
+    """BASELINE configs[4] as specified at full size: 5 nodes x 1 M partitions, per
+    round 1 % of the partitions lose their leader (crash + restart), a restarted follower times out and
+    campaigns, the other replicas answer through can_vote — every VoteRequest / VoteResponse routed
+    between the nodes on the device (jg_dense_cluster_round_routed).  Oracle clusters with the Python
+    statement of the transport re-run windows of the partitions and must agree on every state column
+    of every node; the whole population is checked through what the reference's rules imply (§7.3 Q4/Q5:
+    the failing partitions stay leaderless, the others keep committing)."""
+    from josefine_amd import DenseCluster as LibCluster
+    from josefine_amd.traces import cluster_failure_rows, elect_all
+    from dense_node import RoutedCluster
+
+    G, R, T, W, P = 1_000_000, 5, 30, 1024, 1
+    nodes = [BatchedRaft(G, R, seed=9 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY)
+             for r in range(R)]
+    elect_all(nodes[0])
+    nodes[0].drain_messages(), nodes[0].drain_applies()
+    lib = LibCluster(nodes)
+    lib.set_appends(1)
+    failed = np.zeros(G, bool)
+    delivered = 0
+    for t in range(T):
+        inj = cluster_failure_rows(SEED, t, G, R, P) if t >= 2 else [None] * R
+        if inj[0] is not None:
+            failed[inj[0]["group"]] = True
+        up = [None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(inj)]
+        st = lib.round_routed((t + 1) * 100, up)
+        delivered += sum(st["delivered"])
+        assert st["kept"] == 0 and st["fsm_rows"] == 0
+        for rows in up:
+            if rows is not None:
+                rows.free()
+    L = nodes[0]
+    assert 0.2 * G < failed.sum() < 0.3 * G and delivered > failed.sum() * 2 * (R - 1)
+    role = L.read("role")
+    assert (role[failed] == capi.ROLE_FOLLOWER).all() and (role[~failed] == capi.ROLE_LEADER).all()
+    assert (L.read("head")[~failed] == T).all() and (L.read("commit")[~failed] >= T - 3).all()
+    for n in nodes:
+        assert not n.read("fault").any() and (n.read("role")[failed] != capi.ROLE_LEADER).all()
+        assert len(n.drain_messages()) == 0
+    for base in (0, 555_000, G - W):
+        oc = RoutedCluster(oracle_engine, W, R, seed=9, group_base=base)
+        for t in range(T):
+            oc.round(np.ones(W, np.uint64), inject=cluster_failure_rows(SEED, t, W, R, P, group_base=base) if t >= 2 else None)
+        for r in range(R):
+            for name in ("commit", "head", "term", "voted_for", "role", "leader_id", "election_timeout", "vote_seen",
+                         "vote_granted", "repl_state", "fault"):
+                assert np.array_equal(nodes[r].read(name, 0, base, W), oc.nodes[r].read(name)), (base, r, name)
+    lib.close()
