@@ -153,12 +153,13 @@ def workload_name(G: int, R: int, mode: int, failures: int) -> str:
 
 def node_alg_bytes(R: int):
     """Algorithmic bytes per group of one closed-loop protocol round (DESIGN.md "Dense node tick").
-    Leader half: the 8R + 28 of the ack tick + term 8 + heartbeat_time 8, HeartbeatResponse flags R-1,
-    outbox term 8 + hb_commit 8 + (R-1) x (ae_from 8 + ae_n 1).  Follower half, per
-    follower: state read 56 + inbox 25, written head 8 + outbox 17, and every other tick (heartbeat)
-    commit 8 + election timer 16."""
-    leader = (8 * R + 28) + 16 + (R - 1) + 16 + 9 * (R - 1)
-    follower = 56 + 25 + 8 + 17 + 12
+    Leader half: the 8R + 28 of the ack tick (the inbox's answer words are its ack block: the
+    HeartbeatResponse code rides in their low byte) + term 8 + heartbeat_time 8, outbox beat 16 +
+    (R-1) x ae word 8.  Follower half, per follower: state read 56 + inbox 24 (beat 16 + ae 8), written
+    head 8 + answer 8, and every other tick (heartbeat) HeartbeatResponse.commit 8 + commit 8 + election
+    timer 16."""
+    leader = (8 * R + 28) + 16 + 16 + 8 * (R - 1)
+    follower = 56 + 24 + 8 + 8 + 16
     return leader, follower
 
 

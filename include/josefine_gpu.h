@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JG_ABI_VERSION 2u
+#define JG_ABI_VERSION 3u
 #define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
 #define JG_CHAIN_WINDOW 8u  /* chain segments (gaps / forks) per group besides the main run */
 #define JG_MAX_INFLIGHT 5u  /* src/raft/progress.rs:117                                    */
@@ -129,7 +129,8 @@ enum {
   JG_FAULT_ENGINE_FOREIGN_VOTER = 129,    /* a 9th distinct voter outside the membership in one election
                                              (the first JG_FOREIGN_VOTERS are counted, election.rs:33-35) */
   JG_FAULT_ENGINE_DENSE_NONLEADER = 131,  /* dense tick asked a non-leader group to append         */
-  JG_FAULT_ENGINE_DENSE_APPENDS = 132     /* own slot of a dense ack block >= JG_MAX_DENSE_APPENDS */
+  JG_FAULT_ENGINE_DENSE_APPENDS = 132,    /* own slot of a dense ack block >= JG_MAX_DENSE_APPENDS */
+  JG_FAULT_ENGINE_MAILBOX_RANGE = 133     /* a block id >= 2^56 - 1 would have to go into a mailbox word */
 };
 
 /* ---- engine configuration ---------------------------------------------------
@@ -333,61 +334,73 @@ int jg_step_dense_acks_shards(jg_engine* e, const uint64_t* const* acks_dev, uin
  * columns are another engine's inbox columns (same device: the same pointers).
  *
  * Mailbox vocabulary (everything else a step emits is queued as ordinary jg_msg_row rows,
- * drained with jg_drain_messages, in per-group emission order):
- *   Heartbeat{term, commit, leader_id}      -> term[g], hb_commit[g]
- *   AppendEntries{term, leader_id, blocks}  -> term[g], ae_from[r][g], ae_n[r][g]: the blocks are
- *       ids ae_from+1 .. ae_from+ae_n, each with next = id-1 — expressible exactly when the
- *       leader's chain is in run form (id set [0, head] built by append only: every FAST-path
- *       leader); a leader whose chain is not sends all messages of its Tick as rows instead
- *   AppendResponse{node_id, head}           -> ack_head[g]   (one row of the leader's ack block)
- *   HeartbeatResponse{commit, has_committed}-> hb_commit[g], hb_has[g]
+ * drained with jg_drain_messages, in per-group emission order).  One 8-byte word per message where
+ * the message has one addressee, so that a tick touches as few address streams as possible (the node
+ * tick is bound by the number of its memory instructions, not by their bytes: profiles/README.md):
+ *   Heartbeat{term, commit, leader_id}      -> beat[g] = {term, commit}
+ *   AppendEntries{term, leader_id, blocks}  -> beat[g].term, ae[r][g] = JG_AE(from, n): the blocks are
+ *       ids from+1 .. from+n, each with next = id-1 — expressible exactly when the leader's chain is
+ *       in run form (id set [0, head] built by append only: every FAST-path leader); a leader whose
+ *       chain is not sends all messages of its Tick as rows instead
+ *   AppendResponse{node_id, head}           -> answer[g], bits 63..8 (one word of the leader's inbox block)
+ *   HeartbeatResponse{commit, has_committed}-> answer[g], bits 7..0 = has_committed; commit -> hb_commit[g]
+ * Block ids in mailbox words are 56 bits wide: a group whose head reaches JG_MAILBOX_NONE raises
+ * JG_FAULT_ENGINE_MAILBOX_RANGE instead of emitting (never silently wrong; sequential ids get there
+ * after 7 x 10^16 appends).
  * FSM instructions are not queued by dense steps: they are the per-group commit / head deltas
  * (follower: Apply for keys [commit_before, commit_after), follower.rs:204; leader: as
  * jg_step_dense_acks). */
-#define JG_AE_NONE 0xFFu /* ae_n: no AppendEntries for this slot / group this tick            */
-#define JG_HB_NONE 0xFFu /* hb_has: no HeartbeatResponse                                       */
+#define JG_AE_NONE 0xFFu /* low byte of an ae word: no AppendEntries for this slot / group this tick */
+#define JG_HB_NONE 0xFFu /* low byte of an answer word: no HeartbeatResponse                        */
+#define JG_MAILBOX_NONE 0x00FFFFFFFFFFFFFFull /* bits 63..8 of an answer word: no AppendResponse    */
+/* (the all-ones word JG_NO_ACK is therefore "nothing at all" in both kinds of word) */
+#define JG_ANSWER(ack_head, hb_code) (((uint64_t)(ack_head) << 8) | (uint64_t)(hb_code))
+#define JG_AE(from, n) (((uint64_t)(from) << 8) | (uint64_t)(n))
 
-typedef struct jg_leader_inbox { /* device pointers; any may be NULL = nothing of that kind */
-  const uint64_t* acks;      /* [R][G] as jg_step_dense_acks: AppendResponse heads / own slot = #appends */
-  const uint8_t* hbr_has;    /* [R][G] HeartbeatResponse.has_committed: 0, 1 or JG_HB_NONE            */
-  const uint64_t* hbr_commit;/* [R][G] HeartbeatResponse.commit (read only where hbr_has == 0)        */
+typedef struct jg_leader_beat { /* what every follower of the group reads of the leader's Tick */
+  uint64_t term;      /* current_term of this tick's messages                              */
+  uint64_t hb_commit; /* Heartbeat.commit, or JG_NO_ACK: no heartbeat (not due / no leader) */
+} jg_leader_beat;
+
+typedef struct jg_leader_inbox { /* device pointers; answers == NULL: nothing came in */
+  const uint64_t* answers;   /* [R][G] JG_ANSWER(AppendResponse.head or JG_MAILBOX_NONE, has_committed or
+                                JG_HB_NONE) of slot r; own slot: JG_ANSWER(#ClientRequests to append, JG_HB_NONE),
+                                the count as in jg_step_dense_acks                                          */
+  const uint64_t* hbr_commit;/* [R][G] HeartbeatResponse.commit (read only where has_committed == 0)     */
 } jg_leader_inbox;
 
 typedef struct jg_leader_outbox { /* device pointers, all required */
-  uint64_t* term;      /* [G]    current_term of this tick's messages                              */
-  uint64_t* hb_commit; /* [G]    Heartbeat.commit, or JG_NO_ACK: no heartbeat (not due / no leader) */
-  uint64_t* ae_from;   /* [R][G] range start key = progress head of slot r (leader.rs:135,152)     */
-  uint8_t* ae_n;       /* [R][G] number of blocks (0..JG_MAX_INFLIGHT) or JG_AE_NONE               */
+  jg_leader_beat* beat; /* [G]                                                                        */
+  uint64_t* ae;         /* [R][G] JG_AE(range start key = progress head of slot r, number of blocks
+                           0..JG_MAX_INFLIGHT) (leader.rs:135,152), or JG_NO_ACK: nothing for slot r  */
 } jg_leader_outbox;
 
 typedef struct jg_follower_inbox { /* device pointers */
   const uint32_t* leader;   /* [G] sender NodeId per group, or NULL: `leader_id` for every group   */
   uint32_t leader_id;
   uint32_t reserved;
-  const uint64_t* term;     /* [G]                                                                 */
-  const uint64_t* hb_commit;/* [G] JG_NO_ACK = no Heartbeat                                        */
-  const uint64_t* ae_from;  /* [G]                                                                 */
-  const uint8_t* ae_n;      /* [G] JG_AE_NONE = no AppendEntries                                   */
+  const jg_leader_beat* beat;/* [G] the leader's outbox beat                                        */
+  const uint64_t* ae;       /* [G] this node's row of the leader's outbox ae                       */
 } jg_follower_inbox;
 
 typedef struct jg_follower_outbox { /* device pointers, all required */
-  uint64_t* ack_head;  /* [G] AppendResponse.head or JG_NO_ACK                                     */
-  uint64_t* hb_commit; /* [G] HeartbeatResponse.commit (defined where hb_has != JG_HB_NONE)        */
-  uint8_t* hb_has;     /* [G] HeartbeatResponse.has_committed, or JG_HB_NONE                       */
+  uint64_t* answer;    /* [G] JG_ANSWER(AppendResponse.head or JG_MAILBOX_NONE, has_committed or JG_HB_NONE):
+                          this node's row of the leader's inbox answers                                 */
+  uint64_t* hb_commit; /* [G] HeartbeatResponse.commit (written where a HeartbeatResponse is)          */
 } jg_follower_outbox;
 
 /* Leader half of a node tick.  Per group that is a healthy leader, in this order:
  *   1. the HeartbeatResponses of `in`, ascending slot (leader.rs:222-231: replicate() again if
  *      !has_committed && commit > 0 — those extra AppendEntries are queued as rows);
- *   2. the appends and AppendResponses of in->acks exactly as jg_step_dense_acks;
+ *   2. the appends and AppendResponses of in->answers exactly as jg_step_dense_acks;
  *   3. if `out` != NULL: Command::Tick (leader.rs:234-245) into the outbox columns.
  * Groups that are not leaders ignore 1-2 as the reference does and are not ticked here
  * (jg_step_dense_follower ticks them): their outbox entries are "none". */
 int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* in, const jg_leader_outbox* out);
 
 /* Follower half of a node tick.  Per group that is not a leader, in this order:
- *   1. Heartbeat{in->term, in->hb_commit, leader}      if hb_commit[g] != JG_NO_ACK (follower.rs:178-217)
- *   2. AppendEntries{in->term, leader, blocks}         if ae_n[g] != JG_AE_NONE     (follower.rs:130-176)
+ *   1. Heartbeat{beat.term, beat.hb_commit, leader}    if beat[g].hb_commit != JG_NO_ACK (follower.rs:178-217)
+ *   2. AppendEntries{beat.term, leader, blocks}        if ae[g] != JG_NO_ACK             (follower.rs:130-176)
  *   3. Command::Tick                                   if tick != 0     (follower.rs:121-128, candidate.rs:48-68)
  * Leaders apply 1-2 as the reference does (leader.rs:200-208,263) and are not ticked here.
  * Equivalent to submitting those commands through jg_submit/jg_step, except that

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_REPLICAS = 8
 CHAIN_WINDOW = 8
 MAX_INFLIGHT = 5
@@ -42,6 +42,7 @@ FAULT_ENGINE_WINDOW_OVERFLOW = 128
 FAULT_ENGINE_FOREIGN_VOTER = 129
 FAULT_ENGINE_DENSE_NONLEADER = 131
 FAULT_ENGINE_DENSE_APPENDS = 132
+FAULT_ENGINE_MAILBOX_RANGE = 133
 
 CFG_SEPARATE_COMMIT_KEY = 1
 
@@ -122,20 +123,53 @@ HB_NONE = 0xFF
 
 
 class LeaderInbox(C.Structure):
-    _fields_ = [("acks", C.c_void_p), ("hbr_has", C.c_void_p), ("hbr_commit", C.c_void_p)]
+    _fields_ = [("answers", C.c_void_p), ("hbr_commit", C.c_void_p)]
 
 
 class LeaderOutbox(C.Structure):
-    _fields_ = [("term", C.c_void_p), ("hb_commit", C.c_void_p), ("ae_from", C.c_void_p), ("ae_n", C.c_void_p)]
+    _fields_ = [("beat", C.c_void_p), ("ae", C.c_void_p)]
 
 
 class FollowerInbox(C.Structure):
     _fields_ = [("leader", C.c_void_p), ("leader_id", C.c_uint32), ("reserved", C.c_uint32),
-                ("term", C.c_void_p), ("hb_commit", C.c_void_p), ("ae_from", C.c_void_p), ("ae_n", C.c_void_p)]
+                ("beat", C.c_void_p), ("ae", C.c_void_p)]
 
 
 class FollowerOutbox(C.Structure):
-    _fields_ = [("ack_head", C.c_void_p), ("hb_commit", C.c_void_p), ("hb_has", C.c_void_p)]
+    _fields_ = [("answer", C.c_void_p), ("hb_commit", C.c_void_p)]
+
+
+# mailbox words (josefine_gpu.h: JG_ANSWER / JG_AE)
+MAILBOX_NONE = (1 << 56) - 1
+
+
+def pack_answers(ack_head, hb_has):
+    """JG_ANSWER: AppendResponse.head (NO_ACK: none) and the HeartbeatResponse code per entry."""
+    import numpy as np
+    a = np.asarray(ack_head, dtype=np.uint64)
+    field = np.where(a == np.uint64(NO_ACK), np.uint64(MAILBOX_NONE), a)
+    # (a head that does not fit 56 bits cannot be put on the wire: the engines fault where they produce one)
+    return (field << np.uint64(8)) | np.asarray(hb_has, dtype=np.uint64)
+
+
+def unpack_answers(words):
+    import numpy as np
+    w = np.asarray(words, dtype=np.uint64)
+    field = w >> np.uint64(8)
+    return np.where(field == np.uint64(MAILBOX_NONE), np.uint64(NO_ACK), field), (w & np.uint64(0xFF)).astype(np.uint8)
+
+
+def pack_ae(ae_from, ae_n):
+    import numpy as np
+    n = np.asarray(ae_n, dtype=np.uint64)
+    return np.where(n == np.uint64(AE_NONE), np.uint64(NO_ACK), (np.asarray(ae_from, dtype=np.uint64) << np.uint64(8)) | n)
+
+
+def unpack_ae(words):
+    import numpy as np
+    w = np.asarray(words, dtype=np.uint64)
+    n = (w & np.uint64(0xFF)).astype(np.uint8)
+    return np.where(n == AE_NONE, np.uint64(0), w >> np.uint64(8)), n
 
 
 # numpy structured dtypes matching jg_msg_row / jg_fsm_row / jg_fault_row

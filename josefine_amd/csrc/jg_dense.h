@@ -340,16 +340,20 @@ struct JgClock {
 struct JgLeaderNode {
   const JgClock* clock;        // non-null: `now` and the step number come from here (slot clock_slot)
   uint32_t clock_slot, pad_;
-  uint32_t ack_stride;         // 1, or 0: no ack block (the `acks` argument points at an all-ones word)
-  uint32_t hbr_stride;         // 1, or 0: no HeartbeatResponses (hbr_has points at an all-ones word)
-  const uint8_t* hbr_has;      // [R][G] 0 / 1 / JG_HB_NONE
+  uint32_t ack_stride;         // 1, or 0: nothing came in (the `acks` argument points at an all-ones word)
+  uint32_t packed;             // 1: `acks` holds jg_leader_inbox answer words (JG_ANSWER), not bare heads
   const uint64_t* hbr_commit;  // [R][G] (slow kernel only)
-  uint64_t* o_term;            // [G]
-  uint64_t* o_hb;              // [G]
-  uint64_t* o_from;            // [R][G]
-  uint8_t* o_n;                // [R][G]
+  jg_leader_beat* o_beat;      // [G]     null: no Tick
+  uint64_t* o_ae;              // [R][G]
   uint64_t now;
 };
+
+// jg_leader_inbox answer word -> AppendResponse head (JG_NO_ACK: none) / HeartbeatResponse code
+__device__ __forceinline__ uint64_t jg_answer_ack(uint64_t w) {
+  const uint64_t v = w >> 8;
+  return v == JG_MAILBOX_NONE ? JG_NO_ACK : v;
+}
+__device__ __forceinline__ uint32_t jg_answer_hb(uint64_t w) { return (uint32_t)w & 0xffu; }
 
 // What a lane must do with one group after looking at its flag word.
 enum { JG_DENSE_SKIP = 0, JG_DENSE_RUN = 1, JG_DENSE_DEFER = 2 };
@@ -382,6 +386,12 @@ __device__ __forceinline__ int jg_dense_classify(const JgDev& d, uint32_t g, uin
 // NodeId).  Otherwise the own slot comes from the flag word and the other loads wait for it.
 // (A two-groups-per-lane variant with 16-B accesses measured no faster — the kernel is
 // bandwidth-, not issue-bound: profiles/README.md round 1 — and was dropped.)
+template <int R>
+__device__ __forceinline__ void jg_dense_outbox_none(uint32_t G, const JgLeaderNode& nd, uint32_t g) {
+  nd.o_beat[g] = jg_leader_beat{0, JG_NO_ACK};
+#pragma unroll
+  for (int r = 0; r < R; r++) nd.o_ae[(size_t)r * G + g] = JG_NO_ACK;
+}
 // Command::Tick of a FAST leader into the outbox columns (leader.rs:234-245): heartbeat() if due,
 // then replicate() — per other slot the range start key (= its progress head) and the number
 // of blocks after it (Probe: nth(1) -> 1, Replicate: skip(1).take(5), leader.rs:135,152-157).
@@ -392,13 +402,17 @@ __device__ __forceinline__ uint32_t jg_dense_leader_tick(const JgDenseHot& h, co
                                                          uint64_t hbt, uint64_t head, uint64_t commit, uint32_t nf,
                                                          MoOf mo_of) {
   const uint32_t G = h.G;
-  nd.o_term[g] = term;
+  if (head >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words: loud, never wrong
+    jg_dense_outbox_none<R>(G, nd, g);
+    jg_push_fault(*dp, g, JG_FAULT_ENGINE_MAILBOX_RANGE, seq);
+    return nf | (JG_FAULT_ENGINE_MAILBOX_RANGE << JGF_FAULT_SHIFT);
+  }
   uint64_t hb = JG_NO_ACK;
   if ((nd.now - hbt) > (uint64_t)h.hb_timeout) {  // leader.rs:78-84
     hb = commit;                                  // leader.rs:44-51
     h.heartbeat_time[g] = nd.now;
   }
-  nd.o_hb[g] = hb;
+  nd.o_beat[g] = jg_leader_beat{term, hb};  // one 16-byte store
   const bool key_in_range = (nf & JGF_COMMIT_KEY) && !(h.cfg_flags & JG_CFG_SEPARATE_COMMIT_KEY);
   bool dead = false;
 #pragma unroll
@@ -420,20 +434,9 @@ __device__ __forceinline__ uint32_t jg_dense_leader_tick(const JgDenseHot& h, co
         n = cnt ? cnt - 1 : 0;
       }
     }
-    nd.o_from[(size_t)r * G + g] = from;
-    nd.o_n[(size_t)r * G + g] = (uint8_t)n;
+    nd.o_ae[(size_t)r * G + g] = n == JG_AE_NONE ? JG_NO_ACK : JG_AE(from, n);
   }
   return nf;
-}
-template <int R>
-__device__ __forceinline__ void jg_dense_outbox_none(uint32_t G, const JgLeaderNode& nd, uint32_t g) {
-  nd.o_term[g] = 0;
-  nd.o_hb[g] = JG_NO_ACK;
-#pragma unroll
-  for (int r = 0; r < R; r++) {
-    nd.o_from[(size_t)r * G + g] = 0;
-    nd.o_n[(size_t)r * G + g] = JG_AE_NONE;
-  }
 }
 
 // ---- one tick per launch ------------------------------------------------------------------------
@@ -449,7 +452,6 @@ struct JgDenseIn {
   uint32_t f;
   uint64_t a[R], w, head;
   uint64_t term, hbt;  // NODE
-  uint32_t hbr[R];     // NODE (HeartbeatResponse.has_committed bytes, widened)
 };
 template <int R, bool UNIFORM, bool NODE>
 __device__ __forceinline__ void jg_dense_issue(const JgDenseHot& h, const JgDev* dp,
@@ -463,25 +465,20 @@ __device__ __forceinline__ void jg_dense_issue(const JgDenseHot& h, const JgDev*
     // Every load of the group unconditionally and back to back - ONE round trip.  An absent input
     // (no ack block, no HeartbeatResponses) is not a branch around its loads (the compiler waits for
     // the loads issued so far at every branch: the node tick took eight dependent trips per group,
-    // 38 us per 1 M groups) but a stride of 0 into an all-ones word: JG_NO_ACK / JG_HB_NONE for everybody.
+    // 38 us per 1 M groups) but a stride of 0 into an all-ones word: "nothing" for everybody.  One word
+    // per slot carries both answers of that follower (JG_ANSWER): R loads, not 2R + R byte loads - the
+    // kernel's time follows the number of its memory instructions (profiles/README.md).
 #pragma unroll
     for (int r = 0; r < R; r++) in.a[r] = __builtin_nontemporal_load(&acks[((size_t)r * h.G + g) * nd.ack_stride]);
     in.w = h.mlag[g];
     in.head = h.head[g];
     in.term = h.term[g];
     in.hbt = h.heartbeat_time[g];
-#pragma unroll
-    for (int r = 0; r < R; r++)  // (the own slot's entry is loaded too and never looked at)
-      in.hbr[r] = nd.hbr_has[((size_t)r * h.G + g) * nd.hbr_stride];
   }
   // keep the flag load up here, in the same round trip as the others: without a use the
   // compiler sinks it behind the hot-path test (a second, dependent trip to HBM per group)
   asm volatile("" ::"v"(in.f));
-  if (NODE) {
-#pragma unroll
-    for (int r = 0; r < R; r++) asm volatile("" ::"v"(in.hbr[r]));
-    asm volatile("" ::"v"(in.term), "v"(in.hbt));
-  }
+  if (NODE) asm volatile("" ::"v"(in.term), "v"(in.hbt));
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -617,13 +614,16 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   const uint32_t s = UNIFORM ? us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
   const uint64_t mword0 = in.w, head0 = in.head, term = in.term, hbt = in.hbt;
   bool hbr_trigger = false;
-  if (NODE) {  // leader.rs:222-231: a response without the commit makes the leader replicate again
+  uint64_t a[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) hbr_trigger |= (uint32_t)r != s && in.hbr[r] == 0;
+  for (int r = 0; r < R; r++) {
+    a[r] = NODE ? jg_answer_ack(in.a[r]) : in.a[r];
+    // leader.rs:222-231: a response without the commit makes the leader replicate again
+    if (NODE) hbr_trigger |= (uint32_t)r != s && jg_answer_hb(in.a[r]) == 0;
   }
-  uint64_t n_app = in.a[0];
+  uint64_t n_app = a[0];
 #pragma unroll
-  for (int r = 1; r < R; r++) n_app = (uint32_t)r == s ? in.a[r] : n_app;
+  for (int r = 1; r < R; r++) n_app = (uint32_t)r == s ? a[r] : n_app;
   if (NODE && !nd.ack_stride) n_app = 0;
   // ---- hot path: a healthy leader in FAST form whose tick stays in lag space --------------------
   // straight-line 32-bit arithmetic, evaluated for every lane; everything else is behind one
@@ -632,7 +632,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   uint32_t dl = 0;
   bool hot = (f & (JGF_FAULT_MASK | JGF_ROLE_MASK | JGF_FAST)) == (JG_ROLE_LEADER | JGF_FAST);
   if (NODE) hot = hot && !hbr_trigger;
-  hot = jg_lag_tick<R>(s, f, mword0, head0, n_app, in.a, lt, dl) && hot;
+  hot = jg_lag_tick<R>(s, f, mword0, head0, n_app, a, lt, dl) && hot;
   jg_count_step(h.blk_decisions, dec, hot, dl);
   if (__builtin_expect(hot, 1)) {
     if (emit)  // Command::Tick into the outbox; may raise the Q9 fault
@@ -665,7 +665,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   // the ack-only kernel: rolled loops over LDS, so that the kernel's register allocation
   // (= its occupancy) is the hot path's
   *d.cold_seen = 1;  // read back at the next synchronisation point: the host then schedules k_dense_slow
-  jg_dense_cold_lds<R, UNIFORM>(d, acks, seq, s, f, n_app, g, in.a, mword0, head0, dec, sm);
+  jg_dense_cold_lds<R, UNIFORM>(d, acks, seq, s, f, n_app, g, a, mword0, head0, dec, sm);
 }
 
 // Grid-stride loop over the groups (a software prefetch of the next group's loads measured no gain
@@ -675,7 +675,7 @@ __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, co
                                                        const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us,
                                                        const JgLeaderNode& nd, uint64_t (*sm)[JG_BLOCK]) {
   const uint32_t G = h.G, stride = gridDim.x * JG_BLOCK;
-  const bool emit = NODE && nd.o_term != nullptr;
+  const bool emit = NODE && nd.o_beat != nullptr;
   JgDecCount dec;
   uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x;
   for (; g < G; g += stride) {

@@ -20,21 +20,18 @@
 // the outbox columns; rows outside the mailbox vocabulary go to the exceptional queue.
 //
 // Bytes per follower-step at steady state: read 4 (flags) + 8+4+4 (term, voted_for, leader_id) +
-// 8+8 (head, commit) + 4 (queued) + 4+8+4 (rng_draws, election timer) + inbox 8+8+8+1 = 81;
-// write head 8 + outbox 8+8+1, on a heartbeat also commit 8 + timer 8+4+4: 25 / 49.
+// 8+8 (head, commit) + 4 (queued) + 4+8+4 (rng_draws, election timer) + inbox 16+8 = 80;
+// write head 8 + outbox 8, on a heartbeat also outbox 8 + commit 8 + timer 8+4+4: 16 / 48.
 #pragma once
 #include "jg_dense.h"
 
 struct JgFollowerArgs {
   const uint32_t* leader;  // [G] or null
   uint32_t leader_id;
-  const uint64_t* term;
-  const uint64_t* hb_commit;
-  const uint64_t* ae_from;
-  const uint8_t* ae_n;
-  uint64_t* o_ack;
-  uint64_t* o_hbc;
-  uint8_t* o_has;
+  const jg_leader_beat* beat;  // [G] {term, Heartbeat.commit or JG_NO_ACK}
+  const uint64_t* ae;          // [G] JG_AE(from, n) or JG_NO_ACK
+  uint64_t* o_answer;          // [G] JG_ANSWER(AppendResponse.head, HeartbeatResponse code)
+  uint64_t* o_hbc;             // [G] HeartbeatResponse.commit, where there is one
   uint64_t now;
   uint32_t seq;
   uint32_t tick;
@@ -48,10 +45,11 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFol
   for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
     // every load is independent of the others
     const uint32_t f = d.flags[g];
-    const uint64_t in_term = a.term[g];
-    const uint64_t in_hbc = __builtin_nontemporal_load(&a.hb_commit[g]);
-    const uint64_t in_from = __builtin_nontemporal_load(&a.ae_from[g]);
-    const uint32_t in_n = a.ae_n[g];
+    const jg_leader_beat beat = a.beat[g];  // one 16-byte load
+    const uint64_t in_term = beat.term, in_hbc = beat.hb_commit;
+    const uint64_t in_ae = __builtin_nontemporal_load(&a.ae[g]);
+    const uint64_t in_from = in_ae >> 8;
+    const uint32_t in_n = (uint32_t)in_ae & 0xffu;
     const uint32_t lead = a.leader ? a.leader[g] : a.leader_id;
     uint64_t term = d.term[g], head = d.head[g], commit = d.commit[g];
     uint32_t voted_for = d.voted_for[g], leader_id = d.leader_id[g];
@@ -76,10 +74,12 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFol
     const bool fast = role == JG_ROLE_FOLLOWER && (f & JGF_RUN) && queued == 0;
     const bool defer = !dead && !idle_leader && !nothing && !fast;
     jg_defer_push(d, g, defer);
-    a.o_ack[g] = JG_NO_ACK;  // defaults; the slow kernel overwrites the rows of its groups
-    a.o_hbc[g] = 0;
-    a.o_has[g] = JG_HB_NONE;
-    if (dead || idle_leader || nothing || defer) continue;
+    if (dead || idle_leader || nothing || defer) {
+      a.o_answer[g] = JG_NO_ACK;  // nothing; the slow kernel overwrites the words of its groups
+      continue;
+    }
+    uint64_t o_ack = JG_MAILBOX_NONE;
+    uint32_t o_has = JG_HB_NONE;
 
     uint32_t nf = f;
     const uint64_t term0 = term, head0 = head, commit0 = commit;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFol
         nf |= JGF_COMMIT_KEY;
       }
       a.o_hbc[g] = commit;                // :209-215
-      a.o_has[g] = has ? 1 : 0;
+      o_has = has ? 1 : 0;
     }
     if (has_ae) {  // ---- follower.rs:130-176
       if (!(nf & JGF_VOTED) && in_term >= term) {  // :137-144
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFol
             d.run_hi[g] = run_hi;
             nf &= ~JGF_RUN;
           }
-          a.o_ack[g] = head;               // follower.rs:163-172
+          if (head >= JG_MAILBOX_NONE) fault = JG_FAULT_ENGINE_MAILBOX_RANGE;  // 56-bit ids in mailbox words
+          else o_ack = head;               // follower.rs:163-172
         }
       }
     }
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFol
       nf |= fault << JGF_FAULT_SHIFT;
       jg_push_fault(d, g, fault, a.seq);
     }
+    a.o_answer[g] = JG_ANSWER(o_ack, o_has);
     if (term != term0) d.term[g] = term;
     if (head != head0) d.head[g] = head;
     if (commit != commit0) d.commit[g] = commit;
@@ -186,11 +188,12 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_slow(JgDev d, JgFollowerA
     JgCmd c;
     c.from = lead;
     c.flag = 0;
-    c.term = a.term[g];
+    c.term = a.beat[g].term;
     c.aux = 0;
     if (!tick_only) {
-      const uint64_t hbc = a.hb_commit[g];
-      const uint32_t n_blk = a.ae_n[g];
+      const uint64_t hbc = a.beat[g].hb_commit;
+      const uint64_t ae = a.ae[g];
+      const uint32_t n_blk = (uint32_t)ae & 0xffu;
       if (hbc != JG_NO_ACK) {
         c.kind = JG_CMD_HEARTBEAT;
         c.id = hbc;
@@ -200,11 +203,15 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_slow(JgDev d, JgFollowerA
       }
       if (n_blk != JG_AE_NONE) {
         c.kind = JG_CMD_APPEND_ENTRIES;
-        c.id = a.ae_from[g];  // implicit blocks: ids id+1 .. id+aux, next = id-1 each
+        c.id = ae >> 8;  // implicit blocks: ids id+1 .. id+aux, next = id-1 each
         c.aux = n_blk;
         L.fp = sink;
         L.fend = sink + 2;
         jg_apply(d, L, c, nullptr, nullptr);
+        if (L.cap_ack != JG_NO_ACK && L.cap_ack >= JG_MAILBOX_NONE && !jg_fault(L)) {  // 56-bit ids in mailbox words:
+          jg_raise(d, L, JG_FAULT_ENGINE_MAILBOX_RANGE);                                // raised where the answer is produced
+          L.cap_ack = JG_NO_ACK;
+        }
       }
     }
     if (a.tick && jg_role(L) != JG_ROLE_LEADER) {
@@ -216,9 +223,8 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_slow(JgDev d, JgFollowerA
       jg_apply(d, L, c, nullptr, nullptr);
     }
     if (!tick_only) {
-      a.o_ack[g] = L.cap_ack;
-      a.o_hbc[g] = L.cap_hbc;
-      a.o_has[g] = (uint8_t)L.cap_has;
+      a.o_answer[g] = JG_ANSWER(L.cap_ack == JG_NO_ACK ? JG_MAILBOX_NONE : L.cap_ack, L.cap_has);
+      if (L.cap_has != JG_HB_NONE) a.o_hbc[g] = L.cap_hbc;
     }
     dec += L.decisions;
     jg_store(d, L);

@@ -69,17 +69,20 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
     c.term = c.id = c.aux = 0;
     // own slot outside its domain (JG_MAX_DENSE_APPENDS; a leader only: non-leaders never get here):
     // nothing of the tick is applied.  Checked again per tick below (T-tick launches).
+    // (node tick: the block holds answer words, JG_ANSWER(head, HeartbeatResponse code))
+    const bool packed = nd.packed != 0;
+    auto ack_of = [packed](uint64_t w) { return packed ? jg_answer_ack(w) : w; };
     if (acks && n_ticks && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L) &&
-        acks[(size_t)s * d.G + g] >= JG_MAX_DENSE_APPENDS) {
+        ack_of(acks[(size_t)s * d.G + g]) >= JG_MAX_DENSE_APPENDS) {
       L.seq = seq0;
       jg_raise(d, L, JG_FAULT_ENGINE_DENSE_APPENDS);
     }
-    if (nd.hbr_has && !jg_fault(L)) {  // 1. HeartbeatResponses, ascending slot (leader.rs:222-231)
+    if (packed && acks && !jg_fault(L)) {  // 1. HeartbeatResponses, ascending slot (leader.rs:222-231)
       L.seq = seq0;
       c.kind = JG_CMD_HEARTBEAT_RESPONSE;
       for (uint32_t r = 0; r < d.R && !jg_fault(L); r++) {
         if (r == s) continue;
-        const uint8_t has = nd.hbr_has[(size_t)r * d.G + g];
+        const uint32_t has = jg_answer_hb(acks[(size_t)r * d.G + g]);
         if (has == JG_HB_NONE) continue;
         c.from = d.node_ids[r];
         c.flag = has;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
     for (uint32_t t = 0; acks && t < n_ticks && !jg_fault(L); t++) {  // 2. appends, then acks
       const uint64_t* A = acks + (size_t)t * tick_stride;
       L.seq = seq0 + t;
-      uint64_t n_app = A[(size_t)s * d.G + L.g];
+      uint64_t n_app = ack_of(A[(size_t)s * d.G + L.g]);
       if (n_app >= JG_MAX_DENSE_APPENDS) {
         jg_raise(d, L, JG_FAULT_ENGINE_DENSE_APPENDS);
         break;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
       c.flag = 1;
       for (uint32_t r = 0; r < d.R && !jg_fault(L); r++) {
         if (r == s) continue;
-        uint64_t h = A[(size_t)r * d.G + L.g];
+        uint64_t h = ack_of(A[(size_t)r * d.G + L.g]);
         if (h == JG_NO_ACK) continue;
         c.from = d.node_ids[r];
         c.id = h;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
         jg_apply(d, L, c, nullptr, nullptr);
       }
     }
-    if (nd.o_term && !jg_fault(L)) {  // 3. Command::Tick (leader.rs:234-245)
+    if (nd.o_beat && !jg_fault(L)) {  // 3. Command::Tick (leader.rs:234-245)
       L.seq = seq0;
       c.kind = JG_CMD_TICK;
       c.from = 0;
@@ -127,22 +130,24 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
       const bool fast = L.run_hi == L.head && L.id_gen == L.head + 1 && jg_wcnt(L) == 0 && !(L.flags & JGF_NO_GENESIS);
       if (!fast) {
         jg_apply(d, L, c, nullptr, nullptr);  // rows: the blocks are not id-consecutive
+      } else if (L.head >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words
+        jg_raise(d, L, JG_FAULT_ENGINE_MAILBOX_RANGE);
       } else {                                // columns, via a local row buffer
         jg_msg_row loc[JG_MAX_REPLICAS + 1];
         L.xq_on = 0;
         L.mp = loc;
         L.mend = loc + JG_MAX_REPLICAS + 1;
         jg_apply(d, L, c, nullptr, nullptr);
-        nd.o_term[g] = L.term;
+        uint64_t hb = JG_NO_ACK;
         for (jg_msg_row* m = loc; m < L.mp; m++) {
           if (m->kind == JG_CMD_HEARTBEAT) {
-            nd.o_hb[g] = m->id;
+            hb = m->id;
           } else {  // AppendEntries to one peer
             const int r = jg_slot_of(d, m->to_id);
-            nd.o_from[(size_t)r * d.G + g] = m->id;
-            nd.o_n[(size_t)r * d.G + g] = (uint8_t)m->aux;
+            nd.o_ae[(size_t)r * d.G + g] = JG_AE(m->id, m->aux);
           }
         }
+        nd.o_beat[g] = jg_leader_beat{L.term, hb};
       }
     }
     dec += L.decisions;

@@ -230,5 +230,5 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_build(uint32_t n, const uint
 __global__ void k_route_mask_appends(uint32_t G, const uint32_t* __restrict__ flags, const uint64_t* __restrict__ offered,
                                      uint64_t* __restrict__ own_col) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < G) own_col[g] = (flags[g] & JGF_ROLE_MASK) == JG_ROLE_LEADER ? offered[g] : 0ull;
+  if (g < G) own_col[g] = (flags[g] & JGF_ROLE_MASK) == JG_ROLE_LEADER ? offered[g] : JG_ANSWER(0, JG_HB_NONE);  // (answer words)
 }

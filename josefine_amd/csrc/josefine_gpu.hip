@@ -295,11 +295,9 @@ void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks, const Jg
   } lap(e);
   if (nd) {  // node tick: HeartbeatResponses in, the Tick's outbox out
     // (an absent input column is a stride-0 view of one all-ones word for this kernel: no branch around loads)
-    JgLeaderNode k = *nd;
-    if (!k.hbr_has) k.hbr_has = (const uint8_t*)e->d_ones;
     hipLaunchKernelGGL(k_leader_node_tick<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
                        jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks ? acks : (const uint64_t*)e->d_ones, e->seq,
-                       e->uniform_self, k);
+                       e->uniform_self, *nd);
   }
   else if (n_ticks > 1)  // temporal fusion: state read once, written once per launch
     hipLaunchKernelGGL(k_leader_tick_dense_n<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
@@ -1311,26 +1309,22 @@ int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* i
   if (!e) return fail(JG_EINVAL, "null argument");
   if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
   if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
-  if (out && (!out->term || !out->hb_commit || !out->ae_from || !out->ae_n))
-    return fail(JG_EINVAL, "every outbox column is required");
-  if (in && in->hbr_has && !in->hbr_commit) return fail(JG_EINVAL, "hbr_has needs hbr_commit");
+  if (out && (!out->beat || !out->ae)) return fail(JG_EINVAL, "every outbox column is required");
+  if (in && in->answers && !in->hbr_commit) return fail(JG_EINVAL, "answers need hbr_commit");
   HIPCHK(hipSetDevice(e->device));
   int rc = ensure_xq(e);
   if (rc) return rc;
   JgLeaderNode nd{};
   nd.clock = e->replay_clock, nd.clock_slot = e->replay_slot;
-  nd.hbr_has = in ? in->hbr_has : nullptr;
   nd.hbr_commit = in ? in->hbr_commit : nullptr;
-  nd.hbr_stride = nd.hbr_has ? 1 : 0;
+  nd.packed = 1;
   if (out) {
-    nd.o_term = out->term;
-    nd.o_hb = out->hb_commit;
-    nd.o_from = out->ae_from;
-    nd.o_n = out->ae_n;
+    nd.o_beat = out->beat;
+    nd.o_ae = out->ae;
   }
   nd.now = now_ms;
-  const uint64_t* acks = in ? in->acks : nullptr;
-  if (!acks && !nd.hbr_has && !out) return JG_OK;  // nothing to apply
+  const uint64_t* acks = in ? in->answers : nullptr;
+  if (!acks && !out) return JG_OK;  // nothing to apply
   nd.ack_stride = acks ? 1 : 0;
   return dense_step(e, acks, 1, &nd);
 }
@@ -1340,8 +1334,8 @@ int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbo
   if (!e || !in || !out) return fail(JG_EINVAL, "null argument");
   if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
   if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
-  if (!in->term || !in->hb_commit || !in->ae_from || !in->ae_n) return fail(JG_EINVAL, "every inbox column is required");
-  if (!out->ack_head || !out->hb_commit || !out->hb_has) return fail(JG_EINVAL, "every outbox column is required");
+  if (!in->beat || !in->ae) return fail(JG_EINVAL, "every inbox column is required");
+  if (!out->answer || !out->hb_commit) return fail(JG_EINVAL, "every outbox column is required");
   if (!in->leader && !in->leader_id) return fail(JG_EINVAL, "id cannot be 0");  // config.rs:64-66
   HIPCHK(hipSetDevice(e->device));
   int rc = ensure_xq(e);
@@ -1352,13 +1346,10 @@ int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbo
   a.clock = e->replay_clock, a.clock_slot = e->replay_slot;
   a.leader = in->leader;
   a.leader_id = in->leader_id;
-  a.term = in->term;
-  a.hb_commit = in->hb_commit;
-  a.ae_from = in->ae_from;
-  a.ae_n = in->ae_n;
-  a.o_ack = out->ack_head;
+  a.beat = in->beat;
+  a.ae = in->ae;
+  a.o_answer = out->answer;
   a.o_hbc = out->hb_commit;
-  a.o_has = out->hb_has;
   a.now = now_ms;
   a.seq = e->seq;
   a.tick = tick ? 1 : 0;
@@ -1380,8 +1371,8 @@ struct jg_dense_cluster {
   std::vector<jg_engine*> nodes;
   uint32_t G = 0, R = 0, lead = 0;
   uint32_t lead_id = 0;
-  uint64_t *acks = nullptr, *hbr_commit = nullptr, *o_term = nullptr, *o_hb = nullptr, *o_from = nullptr;
-  uint8_t *hbr_has = nullptr, *o_n = nullptr;
+  uint64_t *acks = nullptr, *hbr_commit = nullptr, *o_ae = nullptr;  // acks: the lead node's inbox answer words
+  jg_leader_beat* o_beat = nullptr;
   std::vector<void*> bufs;
   // one protocol round captured as a hipGraph (ten launches and nine cross-stream dependencies per
   // round cost more host time than the round's kernels take on the device)
@@ -1432,15 +1423,13 @@ int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t 
   };
   int rc = JG_OK;
   if ((rc = alloc(8 * R * G, (void**)&c->acks)) || (rc = alloc(8 * R * G, (void**)&c->hbr_commit)) ||
-      (rc = alloc(R * G, (void**)&c->hbr_has)) || (rc = alloc(8 * G, (void**)&c->o_term)) ||
-      (rc = alloc(8 * G, (void**)&c->o_hb)) || (rc = alloc(8 * R * G, (void**)&c->o_from)) ||
-      (rc = alloc(R * G, (void**)&c->o_n)) || (rc = alloc(8 * G, (void**)&c->offered))) {
+      (rc = alloc(16 * G, (void**)&c->o_beat)) || (rc = alloc(8 * R * G, (void**)&c->o_ae)) ||
+      (rc = alloc(8 * G, (void**)&c->offered))) {
     jg_dense_cluster_destroy(c);
     return rc;
   }
-  std::vector<uint64_t> a(R * G, JG_NO_ACK);
-  std::vector<uint8_t> h(R * G, (uint8_t)JG_HB_NONE);
-  if ((rc = jg_device_upload(L, c->acks, a.data(), a.size() * 8)) || (rc = jg_device_upload(L, c->hbr_has, h.data(), h.size()))) {
+  std::vector<uint64_t> a(R * G, JG_NO_ACK);  // nothing from anybody
+  if ((rc = jg_device_upload(L, c->acks, a.data(), a.size() * 8))) {
     jg_dense_cluster_destroy(c);
     return rc;
   }
@@ -1465,9 +1454,12 @@ void jg_dense_cluster_destroy(jg_dense_cluster* c) {
 
 int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const uint64_t* per_group) {
   if (!c) return fail(JG_EINVAL, "null argument");
-  std::vector<uint64_t> v;
-  if (!per_group) v.assign(c->G, uniform);
-  const uint64_t* src = per_group ? per_group : v.data();
+  std::vector<uint64_t> v(c->G);  // the own slot's answer words: JG_ANSWER(#appends, no HeartbeatResponse)
+  for (uint32_t g = 0; g < c->G; g++) {
+    const uint64_t n = per_group ? per_group[g] : uniform;
+    v[g] = n < JG_MAILBOX_NONE ? JG_ANSWER(n, JG_HB_NONE) : JG_NO_ACK;  // (out of range stays out of range: JG_FAULT_ENGINE_DENSE_APPENDS)
+  }
+  const uint64_t* src = v.data();
   int rc = jg_device_upload(c->nodes[c->lead], c->offered, src, (size_t)c->G * 8);
   if (rc) return rc;
   return jg_device_upload(c->nodes[c->lead], c->acks + (size_t)c->lead * c->G, src, (size_t)c->G * 8);
@@ -1475,8 +1467,8 @@ int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const ui
 
 int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_leader_outbox* out) {
   if (!c) return fail(JG_EINVAL, "null argument");
-  if (in) *in = jg_leader_inbox{c->acks, c->hbr_has, c->hbr_commit};
-  if (out) *out = jg_leader_outbox{c->o_term, c->o_hb, c->o_from, c->o_n};
+  if (in) *in = jg_leader_inbox{c->acks, c->hbr_commit};
+  if (out) *out = jg_leader_outbox{c->o_beat, c->o_ae};
   return JG_OK;
 }
 
@@ -1485,8 +1477,8 @@ namespace {
 int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits) {
   jg_engine* L = c->nodes[c->lead];
   const size_t G = c->G;
-  const jg_leader_inbox in{c->acks, c->hbr_has, c->hbr_commit};
-  const jg_leader_outbox out{c->o_term, c->o_hb, c->o_from, c->o_n};
+  const jg_leader_inbox in{c->acks, c->hbr_commit};
+  const jg_leader_outbox out{c->o_beat, c->o_ae};
   int rc = JG_OK;
   if (leading_waits)
     for (uint32_t r = 0; r < c->R; r++)
@@ -1497,9 +1489,8 @@ int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits)
     if ((rc = jg_stream_wait(c->nodes[r], L))) return rc;
     jg_follower_inbox fi{};
     fi.leader = nullptr, fi.leader_id = c->lead_id;
-    fi.term = c->o_term, fi.hb_commit = c->o_hb;
-    fi.ae_from = c->o_from + (size_t)r * G, fi.ae_n = c->o_n + (size_t)r * G;
-    const jg_follower_outbox fo{c->acks + (size_t)r * G, c->hbr_commit + (size_t)r * G, c->hbr_has + (size_t)r * G};
+    fi.beat = c->o_beat, fi.ae = c->o_ae + (size_t)r * G;
+    const jg_follower_outbox fo{c->acks + (size_t)r * G, c->hbr_commit + (size_t)r * G};
     if ((rc = jg_step_dense_follower(c->nodes[r], now_ms, &fi, &fo, 1))) return rc;
   }
   return JG_OK;

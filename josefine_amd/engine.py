@@ -352,58 +352,64 @@ class BatchedRaft:
     def step_dense_leader(self, now_ms: int = 0, acks: Optional[np.ndarray] = None,
                           hbr_has: Optional[np.ndarray] = None, hbr_commit: Optional[np.ndarray] = None,
                           tick: bool = True) -> Optional[dict]:
-        """Leader half of a node tick (jg_step_dense_leader) over host arrays; returns the Tick's
-        outbox columns {term, hb_commit, ae_from, ae_n} or None when `tick` is false."""
+        """Leader half of a node tick (jg_step_dense_leader) over host arrays in column form: the
+        AppendResponse heads (own slot: #appends) and HeartbeatResponse codes are packed into the
+        inbox's answer words here, the outbox words are unpacked into {term, hb_commit, ae_from,
+        ae_n}; returns None when `tick` is false."""
         assert not self._pending
         keep: list = []
         inbox = capi.LeaderInbox()
-        inbox.acks = self._to_engine(None if acks is None else np.asarray(acks, np.uint64).reshape(self.R, self.G), keep)
-        inbox.hbr_has = self._to_engine(None if hbr_has is None else np.asarray(hbr_has, np.uint8).reshape(self.R, self.G), keep)
-        inbox.hbr_commit = self._to_engine(
-            None if hbr_commit is None else np.asarray(hbr_commit, np.uint64).reshape(self.R, self.G), keep)
+        if acks is not None or hbr_has is not None:
+            a = np.full((self.R, self.G), capi.NO_ACK, np.uint64) if acks is None else \
+                np.asarray(acks, np.uint64).reshape(self.R, self.G)
+            if acks is None:  # only HeartbeatResponses: nobody appends
+                a[self.read("self_slot"), np.arange(self.G)] = 0
+            h = np.full((self.R, self.G), capi.HB_NONE, np.uint8) if hbr_has is None else \
+                np.asarray(hbr_has, np.uint8).reshape(self.R, self.G)
+            c = np.zeros((self.R, self.G), np.uint64) if hbr_commit is None else \
+                np.asarray(hbr_commit, np.uint64).reshape(self.R, self.G)
+            inbox.answers = self._to_engine(np.ascontiguousarray(capi.pack_answers(a, h)), keep)
+            inbox.hbr_commit = self._to_engine(c, keep)
         outs, res = [], None
         outbox_p = None
         if tick:
             outbox = capi.LeaderOutbox()
-            res = {}
-            for name, shape, dt in (("term", (self.G,), np.uint64), ("hb_commit", (self.G,), np.uint64),
-                                    ("ae_from", (self.R, self.G), np.uint64), ("ae_n", (self.R, self.G), np.uint8)):
-                host, ptr = self._out_buffer(shape, dt, keep)
-                setattr(outbox, name, ptr)
-                res[name] = host
-                outs.append((host, ptr))
+            beat, outbox.beat = self._out_buffer((self.G, 2), np.uint64, keep)
+            ae, outbox.ae = self._out_buffer((self.R, self.G), np.uint64, keep)
+            outs = [(beat, outbox.beat), (ae, outbox.ae)]
             outbox_p = C.byref(outbox)
         try:
             self._check(self.api.step_dense_leader(self._h, now_ms, C.byref(inbox), outbox_p))
         finally:
             self._finish(outs, keep)
+        if tick:
+            ae_from, ae_n = capi.unpack_ae(ae)
+            res = {"term": np.ascontiguousarray(beat[:, 0]), "hb_commit": np.ascontiguousarray(beat[:, 1]),
+                   "ae_from": ae_from, "ae_n": ae_n}
         return res
 
     def step_dense_follower(self, now_ms: int, term, hb_commit, ae_from, ae_n, leader=None, leader_id: int = 0,
                             tick: bool = True) -> dict:
-        """Follower half of a node tick (jg_step_dense_follower) over host arrays; returns the
-        outbox columns {ack_head, hb_commit, hb_has}."""
+        """Follower half of a node tick (jg_step_dense_follower) over host arrays in column form
+        (packed into the inbox words here); returns the answers unpacked: {ack_head, hb_commit, hb_has}."""
         assert not self._pending
         keep: list = []
         inbox = capi.FollowerInbox()
         inbox.leader = self._to_engine(None if leader is None else np.asarray(leader, np.uint32), keep)
         inbox.leader_id = int(leader_id)
-        inbox.term = self._to_engine(np.asarray(term, np.uint64), keep)
-        inbox.hb_commit = self._to_engine(np.asarray(hb_commit, np.uint64), keep)
-        inbox.ae_from = self._to_engine(np.asarray(ae_from, np.uint64), keep)
-        inbox.ae_n = self._to_engine(np.asarray(ae_n, np.uint8), keep)
+        beat = np.stack([np.asarray(term, np.uint64), np.asarray(hb_commit, np.uint64)], axis=1)
+        inbox.beat = self._to_engine(np.ascontiguousarray(beat), keep)
+        inbox.ae = self._to_engine(np.ascontiguousarray(capi.pack_ae(ae_from, ae_n)), keep)
         outbox = capi.FollowerOutbox()
-        outs, res = [], {}
-        for name, dt in (("ack_head", np.uint64), ("hb_commit", np.uint64), ("hb_has", np.uint8)):
-            host, ptr = self._out_buffer((self.G,), dt, keep)
-            setattr(outbox, name, ptr)
-            res[name] = host
-            outs.append((host, ptr))
+        answer, outbox.answer = self._out_buffer((self.G,), np.uint64, keep)
+        hbc, outbox.hb_commit = self._out_buffer((self.G,), np.uint64, keep)
+        outs = [(answer, outbox.answer), (hbc, outbox.hb_commit)]
         try:
             self._check(self.api.step_dense_follower(self._h, now_ms, C.byref(inbox), C.byref(outbox), 1 if tick else 0))
         finally:
             self._finish(outs, keep)
-        return res
+        ack_head, hb_has = capi.unpack_answers(answer)
+        return {"ack_head": ack_head, "hb_commit": np.where(hb_has != capi.HB_NONE, hbc, np.uint64(0)), "hb_has": hb_has}
 
     # -- output --------------------------------------------------------------
     def _drain(self, fn, dtype) -> np.ndarray:

@@ -352,41 +352,37 @@ class DenseCluster {
   DenseCluster(std::vector<jg_engine*> nodes, uint32_t n_groups, uint32_t lead, NodeId lead_id)
       : nodes_(std::move(nodes)), G_(n_groups), R_((uint32_t)nodes_.size()), lead_(lead), lead_id_(lead_id) {
     jg_engine* L = nodes_[lead_];
-    acks_ = (uint64_t*)alloc(L, 8ull * R_ * G_);
+    answers_ = (uint64_t*)alloc(L, 8ull * R_ * G_);  // the leader's inbox: one answer word per slot and group
     hbr_commit_ = (uint64_t*)alloc(L, 8ull * R_ * G_);
-    hbr_has_ = (uint8_t*)alloc(L, (size_t)R_ * G_);
-    o_term_ = (uint64_t*)alloc(L, 8ull * G_);
-    o_hb_ = (uint64_t*)alloc(L, 8ull * G_);
-    o_from_ = (uint64_t*)alloc(L, 8ull * R_ * G_);
-    o_n_ = (uint8_t*)alloc(L, (size_t)R_ * G_);
-    std::vector<uint64_t> a((size_t)R_ * G_, JG_NO_ACK);
-    std::vector<uint8_t> h((size_t)R_ * G_, JG_HB_NONE);
-    check(jg_device_upload(L, acks_, a.data(), a.size() * 8));
-    check(jg_device_upload(L, hbr_has_, h.data(), h.size()));
+    o_beat_ = (jg_leader_beat*)alloc(L, sizeof(jg_leader_beat) * (size_t)G_);
+    o_ae_ = (uint64_t*)alloc(L, 8ull * R_ * G_);
+    std::vector<uint64_t> a((size_t)R_ * G_, JG_NO_ACK);  // nothing from anybody
+    check(jg_device_upload(L, answers_, a.data(), a.size() * 8));
   }
   ~DenseCluster() {
     for (void* p : bufs_) (void)jg_device_free(nodes_[lead_], p);
   }
   // number of ClientRequests every group appends in the next round (leader.rs:177-197)
   void set_appends(const std::vector<uint64_t>& n) {
-    check(jg_device_upload(nodes_[lead_], acks_ + (size_t)lead_ * G_, n.data(), (size_t)G_ * 8));
+    std::vector<uint64_t> w(G_);  // the own slot's answer words
+    for (uint32_t g = 0; g < G_; g++) w[g] = JG_ANSWER(n[g], JG_HB_NONE);
+    check(jg_device_upload(nodes_[lead_], answers_ + (size_t)lead_ * G_, w.data(), (size_t)G_ * 8));
   }
   // one protocol round at logical time now_ms
   void round(uint64_t now_ms) {
     jg_engine* L = nodes_[lead_];
     for (uint32_t r = 0; r < R_; r++)
       if (r != lead_) check(jg_stream_wait(L, nodes_[r]));  // last round's answers are in
-    jg_leader_inbox in{acks_, hbr_has_, hbr_commit_};
-    jg_leader_outbox out{o_term_, o_hb_, o_from_, o_n_};
+    jg_leader_inbox in{answers_, hbr_commit_};
+    jg_leader_outbox out{o_beat_, o_ae_};
     check(jg_step_dense_leader(L, now_ms, &in, &out));
     for (uint32_t r = 0; r < R_; r++) {
       if (r == lead_) continue;
       check(jg_stream_wait(nodes_[r], L));
       jg_follower_inbox fi{};
       fi.leader = nullptr, fi.leader_id = lead_id_;
-      fi.term = o_term_, fi.hb_commit = o_hb_;
-      fi.ae_from = o_from_ + (size_t)r * G_, fi.ae_n = o_n_ + (size_t)r * G_;
-      jg_follower_outbox fo{acks_ + (size_t)r * G_, hbr_commit_ + (size_t)r * G_, hbr_has_ + (size_t)r * G_};
+      fi.beat = o_beat_, fi.ae = o_ae_ + (size_t)r * G_;
+      jg_follower_outbox fo{answers_ + (size_t)r * G_, hbr_commit_ + (size_t)r * G_};
       check(jg_step_dense_follower(nodes_[r], now_ms, &fi, &fo, 1));
     }
   }
@@ -407,8 +403,8 @@ class DenseCluster {
   std::vector<jg_engine*> nodes_;
   uint32_t G_, R_, lead_;
   NodeId lead_id_;
-  uint64_t *acks_, *hbr_commit_, *o_term_, *o_hb_, *o_from_;
-  uint8_t *hbr_has_, *o_n_;
+  uint64_t *answers_, *hbr_commit_, *o_ae_;
+  jg_leader_beat* o_beat_;
   std::vector<void*> bufs_;
 };
 

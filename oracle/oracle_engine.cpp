@@ -276,22 +276,20 @@ static void note_fault(jo_engine* e, uint32_t g, int before) {
 int jo_step_dense_leader(jo_engine* e, uint64_t now_ms, const jg_leader_inbox* in, const jg_leader_outbox* out) {
   e->stepped = true;
   const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
-  const uint64_t* acks = in ? in->acks : nullptr;
-  if (!acks && !(in && in->hbr_has) && !out) return JG_OK;
+  // (the inbox block holds answer words: JG_ANSWER(AppendResponse.head, HeartbeatResponse code))
+  const uint64_t* acks = in ? in->answers : nullptr;
+  auto ack_of = [](uint64_t w) { return (w >> 8) == JG_MAILBOX_NONE ? JG_NO_ACK : w >> 8; };
+  if (!acks && !out) return JG_OK;
   for (uint32_t g = 0; g < G; g++) {
     Raft& r = e->groups[g];
     const uint32_t s = e->self_slot[g];
     if (out) {  // defaults: "none"
-      out->term[g] = 0;
-      out->hb_commit[g] = JG_NO_ACK;
-      for (uint32_t q = 0; q < R; q++) {
-        out->ae_from[(size_t)q * G + g] = 0;
-        out->ae_n[(size_t)q * G + g] = JG_AE_NONE;
-      }
+      out->beat[g] = jg_leader_beat{0, JG_NO_ACK};
+      for (uint32_t q = 0; q < R; q++) out->ae[(size_t)q * G + g] = JG_NO_ACK;
     }
     if (r.fault) continue;
     const int fault0 = r.fault;
-    const uint64_t n_append = acks ? acks[(size_t)s * G + g] : 0;
+    const uint64_t n_append = acks ? ack_of(acks[(size_t)s * G + g]) : 0;
     if (r.role != JG_ROLE_LEADER) {  // acks / responses are ignored (follower.rs:62, candidate.rs:194)
       if (n_append) r.fault = JG_FAULT_ENGINE_DENSE_NONLEADER;
       note_fault(e, g, fault0);
@@ -304,11 +302,11 @@ int jo_step_dense_leader(jo_engine* e, uint64_t now_ms, const jg_leader_inbox* i
     }
     Cmd c;
     // 1. HeartbeatResponses, ascending slot: extra AppendEntries are rows
-    if (in && in->hbr_has) {
+    if (acks) {
       c.kind = JG_CMD_HEARTBEAT_RESPONSE;
       for (uint32_t q = 0; q < R && !r.fault; q++) {
         if (q == s) continue;
-        const uint8_t has = in->hbr_has[(size_t)q * G + g];
+        const uint8_t has = (uint8_t)(acks[(size_t)q * G + g] & 0xffu);
         if (has == JG_HB_NONE) continue;
         c.from = e->cfg.node_ids[q];
         c.flag = has;
@@ -330,7 +328,7 @@ int jo_step_dense_leader(jo_engine* e, uint64_t now_ms, const jg_leader_inbox* i
     c.flag = 1;
     for (uint32_t q = 0; acks && q < R && !r.fault; q++) {
       if (q == s) continue;
-      const uint64_t h = acks[(size_t)q * G + g];
+      const uint64_t h = ack_of(acks[(size_t)q * G + g]);
       if (h == JG_NO_ACK) continue;
       c.from = e->cfg.node_ids[q];
       c.id = h;
@@ -342,19 +340,23 @@ int jo_step_dense_leader(jo_engine* e, uint64_t now_ms, const jg_leader_inbox* i
     // 3. Tick: columns if the chain is in run form built by append only, rows otherwise
     if (out && !r.fault) {
       const bool columns = r.chain.run_form_by_append();
+      if (columns && r.chain.head >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words: loud, never wrong
+        r.fault = JG_FAULT_ENGINE_MAILBOX_RANGE;
+        note_fault(e, g, fault0);
+        continue;
+      }
       c = Cmd();
       c.kind = JG_CMD_TICK;
       r.apply(c, now_ms);
       e->counters[0]++;
       if (columns) {
-        out->term[g] = r.current_term;
+        out->beat[g].term = r.current_term;
         for (const Msg& m : r.rpc) {
           if (m.kind == JG_CMD_HEARTBEAT) {
-            out->hb_commit[g] = m.id;
+            out->beat[g].hb_commit = m.id;
           } else {
             const int q = slot_of_id(e, m.to_id);
-            out->ae_from[(size_t)q * G + g] = m.id;
-            out->ae_n[(size_t)q * G + g] = (uint8_t)m.aux;
+            out->ae[(size_t)q * G + g] = JG_AE(m.id, m.aux);
           }
         }
       } else {
@@ -376,32 +378,37 @@ int jo_step_dense_follower(jo_engine* e, uint64_t now_ms, const jg_follower_inbo
   const uint32_t G = e->cfg.n_groups;
   for (uint32_t g = 0; g < G; g++) {
     Raft& r = e->groups[g];
-    out->ack_head[g] = JG_NO_ACK;
-    out->hb_commit[g] = 0;
-    out->hb_has[g] = JG_HB_NONE;
+    out->answer[g] = JG_NO_ACK;
     if (r.fault) continue;
+    uint64_t o_ack = JG_MAILBOX_NONE;
+    uint8_t o_has = JG_HB_NONE;
+    const uint64_t in_term = in->beat[g].term, in_hbc = in->beat[g].hb_commit;
+    const uint64_t in_from = in->ae[g] >> 8;
+    const uint32_t in_n = (uint32_t)(in->ae[g] & 0xffu);
     const int fault0 = r.fault;
     const NodeId lead = in->leader ? in->leader[g] : in->leader_id;
     Cmd c;
-    if (in->hb_commit[g] != JG_NO_ACK) {
+    if (in_hbc != JG_NO_ACK) {
       c.kind = JG_CMD_HEARTBEAT;
       c.from = lead;
-      c.term = in->term[g];
-      c.id = in->hb_commit[g];
+      c.term = in_term;
+      c.id = in_hbc;
       r.apply(c, now_ms);
       e->counters[0]++;
     }
-    if (in->ae_n[g] != JG_AE_NONE) {
+    if (in_n != JG_AE_NONE) {
       c = Cmd();
       c.kind = JG_CMD_APPEND_ENTRIES;
       c.from = lead;
-      c.term = in->term[g];
-      for (uint32_t k = 0; k < in->ae_n[g]; k++)
-        c.blocks.push_back(Block{in->ae_from[g] + 1 + k, in->ae_from[g] + k});
+      c.term = in_term;
+      for (uint32_t k = 0; k < in_n; k++) c.blocks.push_back(Block{in_from + 1 + k, in_from + k});
       r.apply(c, now_ms);
       e->counters[0]++;
+      // 56-bit block ids in mailbox words: raised where the answer is produced
+      for (const Msg& m : r.rpc)
+        if (m.kind == JG_CMD_APPEND_RESPONSE && m.id >= JG_MAILBOX_NONE && !r.fault) r.fault = JG_FAULT_ENGINE_MAILBOX_RANGE;
     }
-    if (tick && r.role != JG_ROLE_LEADER) {
+    if (tick && r.role != JG_ROLE_LEADER && !r.fault) {
       c = Cmd();
       c.kind = JG_CMD_TICK;
       r.apply(c, now_ms);
@@ -409,14 +416,15 @@ int jo_step_dense_follower(jo_engine* e, uint64_t now_ms, const jg_follower_inbo
     }
     for (const Msg& m : r.rpc) {
       if (m.kind == JG_CMD_APPEND_RESPONSE) {
-        out->ack_head[g] = m.id;
+        if (m.id < JG_MAILBOX_NONE) o_ack = m.id;
       } else if (m.kind == JG_CMD_HEARTBEAT_RESPONSE) {
         out->hb_commit[g] = m.id;
-        out->hb_has[g] = m.flag;
+        o_has = m.flag;
       } else {
         push_row(e, g, m);
       }
     }
+    out->answer[g] = JG_ANSWER(o_ack, o_has);
     r.rpc.clear();
     r.fsm.clear();
     note_fault(e, g, fault0);

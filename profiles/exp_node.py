@@ -27,25 +27,24 @@ def dalloc(n):
     return p
 
 
-NT = 8  # rotating ack blocks (tick t acks head t-1)
+NT = 8  # rotating inbox blocks (tick t acks head t-1)
 acks = [dalloc(8 * R * G) for _ in range(NT)]
-hbr_has, hbr_commit = dalloc(R * G), dalloc(8 * R * G)
-one = np.ones((R, G), np.uint8)
-e._check(api.device_upload(h, hbr_has, one.ctypes.data, one.nbytes))
-o_term, o_hb, o_from, o_n = dalloc(8 * G), dalloc(8 * G), dalloc(8 * R * G), dalloc(R * G)
-outbox = capi.LeaderOutbox(o_term.value, o_hb.value, o_from.value, o_n.value)
+hbr_commit = dalloc(8 * R * G)
+o_beat, o_ae = dalloc(16 * G), dalloc(8 * R * G)
+outbox = capi.LeaderOutbox(o_beat.value, o_ae.value)
 e._check(api.kernel_timing(h, 1))
 now = 0
 blk = np.zeros((R, G), np.uint64)
+has = np.ones((R, G), np.uint8)  # HeartbeatResponse{has_committed: true} from everybody
 for t in range(K + 10):
-    if t < NT or True:
-        blk[:] = max(t - 1, 0) if t else capi.NO_ACK
-        blk[0] = 1
-        if t == 0:
-            blk[1:] = capi.NO_ACK
-        e._check(api.device_upload(h, acks[t % NT], blk.ctypes.data, blk.nbytes))
+    blk[:] = max(t - 1, 0) if t else capi.NO_ACK
+    blk[0] = 1
+    if t == 0:
+        blk[1:] = capi.NO_ACK
+    words = np.ascontiguousarray(capi.pack_answers(blk, has))
+    e._check(api.device_upload(h, acks[t % NT], words.ctypes.data, words.nbytes))
     now += 100
-    inbox = capi.LeaderInbox(acks[t % NT].value, hbr_has.value, hbr_commit.value)
+    inbox = capi.LeaderInbox(acks[t % NT].value, hbr_commit.value)
     e._check(api.step_dense_leader(h, now, C.byref(inbox), C.byref(outbox)))
 us, n = C.c_float(0), C.c_uint32(0)
 e._check(api.kernel_timing_read(h, C.byref(us), C.byref(n)))

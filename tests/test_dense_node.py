@@ -348,3 +348,34 @@ def test_routed_cluster_device_transport_parity(R, percent, also):
         assert nodes[n].drain_faults().tobytes() == ora.nodes[n].drain_faults().tobytes()
         assert nodes[n].drain_applies().tobytes() == ora.nodes[n].drain_applies().tobytes()
     lib.close()
+
+
+def _mailbox_range_case(make):
+    """A follower whose head reaches 2^56 - 1 cannot put it into an answer word: engine fault, no answer."""
+    G, R = 4, 3
+    e = make(G, R, seed=3, flags=capi.CFG_SEPARATE_COMMIT_KEY)
+    top = capi.MAILBOX_NONE - 1
+    e.apply(1, Command.AppendEntries(1, 2, [(top, 0)]))  # a block far up the id space, parent = genesis
+    assert e.handle(1).head == top and e.handle(1).fault == 0
+    e.drain_messages()
+    z = np.zeros(G, np.uint64)
+    ae_n = np.full(G, capi.AE_NONE, np.uint8)
+    ae_n[1] = 1
+    out = e.step_dense_follower(100, term=z + 1, hb_commit=np.full(G, capi.NO_ACK, np.uint64), ae_from=z + top, ae_n=ae_n,
+                                leader_id=2, tick=False)
+    return e, out
+
+
+def test_mailbox_word_range_is_loud_on_the_oracle():
+    e, out = _mailbox_range_case(oracle_engine)
+    assert e.handle(1).fault == capi.FAULT_ENGINE_MAILBOX_RANGE and e.handle(0).fault == 0
+    assert (out["ack_head"] == capi.NO_ACK).all()
+
+
+@pytest.mark.gpu
+def test_mailbox_word_range_parity():
+    (dev, od), (ora, oo) = _mailbox_range_case(BatchedRaft), _mailbox_range_case(oracle_engine)
+    compare_snapshots(dev, ora, "mailbox range")
+    _cmp_cols(od, oo, "mailbox range")
+    assert dev.handle(1).fault == capi.FAULT_ENGINE_MAILBOX_RANGE
+    assert dev.drain_faults().tobytes() == ora.drain_faults().tobytes()
