@@ -35,46 +35,93 @@ struct JgRowsArgs {
   uint32_t seq;
 };
 
+// Every lane loads the columns of ITS row (coalesced); the lane that owns a run then reads row i+t of
+// its run out of lane+t's registers.  The first version had the owner load the six columns of each of
+// its rows itself: one dependent trip to memory per row — a candidate's sixteen VoteResponses took the
+// batch's owner lanes sixteen round trips (profiles/README.md, the routed round).  Rows of a run that
+// continue in the next wave are still loaded by the owner.
 __global__ __launch_bounds__(JG_BLOCK) void k_apply_rows(JgDev d, JgRowsArgs a) {
   uint32_t dec = 0;
-  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < a.n; i += gridDim.x * JG_BLOCK) {
-    const uint32_t g = a.group[i];
-    const uint32_t gp = i ? a.group[i - 1] : 0xffffffffu;
-    a.msg_cnt[i] = 0;
-    a.fsm_cnt[i] = 0;
-    if (i && gp == g) continue;  // not the head of a run
-    if (i && gp > g) *a.err = 2;
-    if (g >= d.G) {
-      *a.err = 3;
-      continue;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t base = blockIdx.x * JG_BLOCK; base < a.n; base += gridDim.x * JG_BLOCK) {  // (workgroup-uniform trips)
+    const uint32_t i = base + threadIdx.x;
+    const bool in = i < a.n;
+    const uint32_t g = in ? a.group[i] : 0xffffffffu;
+    const uint32_t gp = (in && i) ? a.group[i - 1] : 0xffffffffu;
+    JgCmd mine{};
+    if (in) {
+      mine.kind = a.kind[i];
+      mine.from = a.from[i];
+      mine.flag = a.flag[i];
+      mine.term = a.term[i];
+      mine.id = a.id[i];
+      mine.aux = a.aux[i];
+      a.msg_cnt[i] = 0;
+      a.fsm_cnt[i] = 0;
     }
-    uint32_t j = i + 1;
-    while (j < a.n && a.group[j] == g) j++;
+    const bool start = in && !(i && gp == g);  // first row of a run
+    if (start && i && gp > g) *a.err = 2;
+    if (start && g >= d.G) *a.err = 3;
+    const bool owner = start && g < d.G;
+    // the run ends at the next run start (or the end of the batch); beyond this wave: look it up
+    const uint64_t bounds = __ballot(start || !in);
+    const uint64_t above = lane == 63 ? 0ull : bounds >> (lane + 1);
+    uint32_t run = 0;
+    if (owner) {
+      if (above) {
+        run = (uint32_t)__ffsll((long long)above);
+      } else {
+        uint32_t j = i + (64 - lane);
+        while (j < a.n && a.group[j] == g) j++;
+        run = j - i;
+      }
+    }
+    uint32_t longest = run;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off, 64));
     JgLane L;
-    jg_load(d, L, g);
-    L.now = a.now;
-    L.seq = a.seq;
-    jg_msg_row* m0 = a.msg_out + (size_t)i * a.msg_per_row;
-    jg_fsm_row* f0 = a.fsm_out + (size_t)i * a.fsm_per_row;
-    L.mp = m0;
-    L.mend = m0 + (size_t)(j - i) * a.msg_per_row;
-    L.fp = f0;
-    L.fend = f0 + (size_t)(j - i) * a.fsm_per_row;
-    for (uint32_t k = i; k < j; k++) {
-      JgCmd c;
-      c.kind = a.kind[k];
-      c.from = a.from[k];
-      c.flag = a.flag[k];
-      c.term = a.term[k];
-      c.id = a.id[k];
-      c.aux = a.aux[k];
-      jg_apply(d, L, c, a.blk_id, a.blk_next);
+    jg_msg_row* m0 = nullptr;
+    jg_fsm_row* f0 = nullptr;
+    if (owner) {
+      jg_load(d, L, g);
+      L.now = a.now;
+      L.seq = a.seq;
+      m0 = a.msg_out + (size_t)i * a.msg_per_row;
+      f0 = a.fsm_out + (size_t)i * a.fsm_per_row;
+      L.mp = m0;
+      L.mend = m0 + (size_t)run * a.msg_per_row;
+      L.fp = f0;
+      L.fend = f0 + (size_t)run * a.fsm_per_row;
     }
-    a.msg_cnt[i] = (uint32_t)(L.mp - m0);
-    a.fsm_cnt[i] = (uint32_t)(L.fp - f0);
-    if (L.overflow) *a.err = 1;
-    dec += L.decisions;
-    jg_store(d, L);
+    for (uint32_t t = 0; t < longest; t++) {  // (wave-uniform)
+      const int src = (int)((lane + t) & 63u);
+      JgCmd c;
+      c.kind = (uint8_t)__shfl((int)mine.kind, src, 64);
+      c.from = (uint32_t)__shfl((int)mine.from, src, 64);
+      c.flag = (uint8_t)__shfl((int)mine.flag, src, 64);
+      c.term = __shfl(mine.term, src, 64);
+      c.id = __shfl(mine.id, src, 64);
+      c.aux = __shfl(mine.aux, src, 64);
+      if (owner && t < run) {
+        if (lane + t >= 64) {  // the run continues in the next wave's rows
+          const uint32_t k = i + t;
+          c.kind = a.kind[k];
+          c.from = a.from[k];
+          c.flag = a.flag[k];
+          c.term = a.term[k];
+          c.id = a.id[k];
+          c.aux = a.aux[k];
+        }
+        jg_apply(d, L, c, a.blk_id, a.blk_next);
+      }
+    }
+    if (owner) {
+      a.msg_cnt[i] = (uint32_t)(L.mp - m0);
+      a.fsm_cnt[i] = (uint32_t)(L.fp - f0);
+      if (L.overflow) *a.err = 1;
+      dec += L.decisions;
+      jg_store(d, L);
+    }
   }
   jg_block_count(d.blk_decisions, dec);
 }
