@@ -413,11 +413,14 @@ int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbo
  * examples/multi-node in one runtime): the protocol round — leader half on nodes[lead], follower half
  * on every other node, each one's outbox columns being the others' inbox columns — driven from
  * inside the library, so that a round costs its launches and no per-call host overhead of the
- * caller's language.  The cluster owns the mailbox columns (in the memory of nodes[lead]'s device) and
- * chains the engines' streams with events; nothing synchronises with the host inside a round.
+ * caller's language.  The cluster owns the mailbox columns (in the memory of nodes[lead]'s device);
+ * nothing synchronises with the host inside a round.  While the cluster exists, the nodes that share
+ * nodes[lead]'s device issue ALL their work on its stream (the halves of a round are bandwidth-bound:
+ * side by side they only slow each other down); nodes on other devices keep their streams and are
+ * chained with events.
  * Equivalent, call for call, to jg_step_dense_leader on nodes[lead] followed by jg_step_dense_follower
  * (tick = 1) on the others (josefine::DenseCluster::round in josefine_amd/host/raft_handle.hpp).
- * Engines are borrowed: destroy the cluster before them. */
+ * Engines are borrowed: destroy the cluster BEFORE them (it gives them their streams back). */
 typedef struct jg_dense_cluster jg_dense_cluster;
 int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t lead, jg_dense_cluster** out);
 void jg_dense_cluster_destroy(jg_dense_cluster* c);

@@ -1381,6 +1381,12 @@ struct jg_dense_cluster {
   hipGraphExec_t exec = nullptr;
   uint64_t sig = 0, graph_dt = 0;
   uint64_t* offered = nullptr;  // [G] the ClientRequests per round as set by jg_dense_cluster_set_appends
+  // While clustered, nodes that share the lead node's device run on ITS stream: the halves of a round
+  // are bandwidth-bound, so running them side by side buys nothing (each then takes 50-60 us instead
+  // of 20), five streams do not fit four hardware queues (two follower halves ended up behind each
+  // other anyway), and every cross-stream dependency is a host call.  The nodes' own streams are
+  // restored when the cluster is destroyed.
+  std::vector<hipStream_t> own_stream;
   // jg_dense_cluster_round_routed: per destination node, the staging the senders' rows are scattered
   // into, its sort scratch, and the command columns of the node's next round (all grow-only)
   struct Route {
@@ -1433,12 +1439,29 @@ int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t 
     jg_dense_cluster_destroy(c);
     return rc;
   }
+  static const bool own_streams = std::getenv("JG_CLUSTER_OWN_STREAMS") != nullptr;
+  c->own_stream.assign(n_nodes, nullptr);
+  for (uint32_t r = 0; r < n_nodes && !own_streams; r++) {
+    jg_engine* e = nodes[r];
+    if (e == L || e->device != L->device) continue;
+    if ((rc = sync_and_check(e))) {  // nothing of its own is in flight when the stream changes hands
+      jg_dense_cluster_destroy(c);
+      return rc;
+    }
+    c->own_stream[r] = e->stream;
+    e->stream = L->stream;
+  }
   *out = c;
   return JG_OK;
 }
 
 void jg_dense_cluster_destroy(jg_dense_cluster* c) {
   if (!c) return;
+  for (size_t r = 0; r < c->own_stream.size(); r++)
+    if (c->own_stream[r]) {
+      (void)hipStreamSynchronize(c->nodes[r]->stream);
+      c->nodes[r]->stream = c->own_stream[r];
+    }
   if (c->exec) (void)hipGraphExecDestroy(c->exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
   for (void* p : c->bufs) (void)jg_device_free(c->nodes[c->lead], p);
@@ -1931,6 +1954,7 @@ int jg_stream_wait(jg_engine* waiter, jg_engine* signal) {
     }
     return JG_OK;
   }
+  if (waiter->stream == signal->stream) return JG_OK;  // (nodes of a jg_dense_cluster share a stream: already in order)
   HIPCHK(hipSetDevice(signal->device));
   HIPCHK(hipEventRecord(signal->ev_order, signal->stream));
   HIPCHK(hipSetDevice(waiter->device));
