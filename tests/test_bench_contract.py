@@ -65,6 +65,12 @@ def test_cluster_and_failure_modes():
     assert r["bound"] == "hbm" and r["avg_launch_us"] > 0 and r["launches_timed"] == 24
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["rows_delivered_to_host"]["messages"] > 0 and d["rows_delivered_to_host"]["faults"] > 0
+    # configs[4] as specified: real votes, routed between the nodes on the device
+    d = run(["--cluster", "--failures", "2", "--groups", "40000", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    assert KEYS <= set(d) and "configs[4] as specified" in d["config"]["workload"] and d["value"] > 0
+    assert d["rows_routed_per_round"] > 0 and 0 < d["leaderless_fraction"]["at_start_of_timed_region"] < d["leaderless_fraction"]["at_end"] < 1
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["leader_kernel"]["avg_launch_us"] > 0
 
 
 def test_single_process_multi_device_agrees_with_process_per_gpu():
