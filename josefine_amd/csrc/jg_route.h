@@ -177,7 +177,8 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_xq(JgRouteTable t, const JgX
     JgXqRec q{};
     if (i < n) {
       q = xq[i];
-      mask = jg_route_dests(q.row, t);
+      // (rows of steps before this round - left undrained by the caller - are not this round's mail: they stay)
+      mask = (q.seq - seq_base - 1u < 3u) ? jg_route_dests(q.row, t) : 0u;
     }
     const bool stay = i < n && !mask;
     if (COMPACT) {
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_xq(JgRouteTable t, const JgX
       continue;
     }
     const uint32_t step = q.seq - seq_base;
-    if (mask && (step > 3u || q.k >> JG_ROUTE_ORD_BITS)) t.count[t.R + JG_ROUTE_OVERFLOW] = 1;
+    if (mask && q.k >> JG_ROUTE_ORD_BITS) t.count[t.R + JG_ROUTE_OVERFLOW] = 1;
     uint32_t pos = jg_route_reserve(t, __popc(mask));
     stays += stay;
     for (uint32_t b = mask; b; b &= b - 1, pos++) {

@@ -3,6 +3,7 @@
 // ABI), plus BASELINE.json config #1 — the examples/multi-node topology (ids 1,2,3)
 // as three instances of one partition routed in-process.
 // Built and run by tests/test_cpp_adapter.py (-m gpu).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
@@ -299,6 +300,30 @@ static void fsm_apply_walks_keys_not_parents() {
   CHECK((seen == std::vector<uint8_t>{10, 20, 30, 40}));  // keys 1..4 in key order, the dead block 3 included
 }
 
+// SURVEY.md §8(f) rank 3, FSM apply fan-out: what the host side of one step costs when every one of
+// many partitions commits something - Notify + Apply rows drained, expanded against the block stores by
+// key order and handed to fsm_tx.  Prints the rate; the check is only that everything arrives.
+static void fsm_fanout_throughput() {
+  const uint32_t G = 20000, rounds = 8;
+  BatchedRaft raft(G, {1});  // single-node partitions: every ClientRequest commits at once
+  uint64_t notifies = 0, applies = 0, bytes = 0;
+  raft.fsm_tx = [&](const Instruction& i) {
+    if (i.kind == Instruction::Notify) notifies++;
+    else applies++, bytes += i.block.data.size();
+  };
+  for (uint32_t g = 0; g < G; g++) raft.submit(g, Command::Timeout());
+  raft.step(0);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t r = 0; r < rounds; r++) {
+    for (uint32_t g = 0; g < G; g++) raft.submit(g, Command::ClientRequest(r * G + g, {1, 2, 3, 4, 5, 6, 7, 8}));
+    raft.step(100 * (r + 1));
+  }
+  const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  CHECK(notifies == (uint64_t)G * rounds && applies == (uint64_t)G * rounds && bytes == 8ull * G * rounds);
+  std::printf("fsm fan-out: %u partitions x %u rounds, %.2f M instructions/s through fsm_tx (submit + step + drain + expansion, one host thread)\n",
+              G, rounds, (double)(notifies + applies) / s / 1e6);
+}
+
 int main() {
   try {
     apply_entry_single_node();
@@ -311,6 +336,7 @@ int main() {
     server_event_loop_single_node();
     server_event_loops_three_nodes();
     fsm_apply_walks_keys_not_parents();
+    fsm_fanout_throughput();
 #ifndef JG_TEST_AGAINST_ORACLE
     server_event_loop_multi_device();
 #endif

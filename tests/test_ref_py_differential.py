@@ -155,3 +155,36 @@ def test_closed_loop_clusters_agree():
 
 def test_zz_more_than_a_million_commands_were_compared():
     assert TOTAL["n"] >= 1_000_000, TOTAL
+
+
+@pytest.mark.parametrize("R,also", [(3, ()), (3, (2,)), (5, ()), (5, (2, 3))])
+def test_routed_cluster_ref_py_vs_oracle(R, also):
+    """The configs[4] cluster trace (leader restarts, a restarted follower campaigns, the others answer
+    through can_vote, every vote delivered a round later by the Python statement of the transport) on
+    clusters of ref_py engines and of oracle engines: every state column of every node after every
+    round, the rows delivered, the rows kept.  Restart, can_vote, Defeated and the re-campaign timers of
+    R >= 2 elections are thereby held to the independent reading of the Rust, not only to the oracle."""
+    from dense_node import RoutedCluster
+    from josefine_amd.traces import cluster_failure_rows
+    G, T = 48, 45
+    ref = RoutedCluster(RefEngine, G, R, seed=11)
+    ora = RoutedCluster(oracle_engine, G, R, seed=11)
+    for t in range(T):
+        inj = cluster_failure_rows(5, t, G, R, 6, also=also) if t >= 2 else None
+        for cl in (ref, ora):
+            cl.round(np.ones(G, np.uint64), inject=inj)
+        for n in range(R):
+            for name in capi.FIELD_NAMES:
+                if name == "match":
+                    for q in range(R):
+                        assert np.array_equal(ref.nodes[n].read("match", q), ora.nodes[n].read("match", q)), (t, n, q)
+                else:
+                    assert np.array_equal(ref.nodes[n].read(name), ora.nodes[n].read(name)), (t, n, name)
+            a = [r for _, r in ref.inbound[n]]
+            b = [r for _, r in ora.inbound[n]]
+            assert len(a) == len(b) and all(x.tobytes() == y.tobytes() for x, y in zip(a, b)), (t, n)
+    assert sum(ref.delivered) == sum(ora.delivered) > 0
+    for n in range(R):
+        assert ref.kept[n].tobytes() == ora.kept[n].tobytes()
+    if R == 3 and also:  # with a majority of fresh replicas the candidate wins: leadership really moved
+        assert (ora.nodes[1].read("role") == capi.ROLE_LEADER).any()
