@@ -17,13 +17,16 @@
 #include "jg_device.h"
 #include "jg_sparse.h"
 
-#define JG_ROUTE_ORD_BITS 27u
+#define JG_ROUTE_ORD_BITS 27u       // widest emission-index field: the key then has 35 + bits(G) <= 64 bits (G <= 2^29)
+#define JG_ROUTE_ORD_BITS_FAST 12u  // what a round's keys are built with first: 5 sort passes instead of 7 at 1 M groups
 // ordering key of a delivered row, most significant first: destination member (3 bits, right above
-// the group's bits), group, sender slot (3), step of the round (2), emission index (27)
+// the group's bits), group, sender slot (3), step of the round (2), emission index within the group's
+// step (ord_bits: the pass reports an index that does not fit and is repeated with the wide field)
 struct JgRouteTable {
   uint32_t R, src;                      // members, the sending member's index
   uint32_t member_id[JG_MAX_REPLICAS];  // NodeId of member n
   uint32_t group_bits;                  // bits of a group index
+  uint32_t ord_bits;                    // bits of the emission-index field
   uint32_t cap;                         // entries of the staging below
   uint64_t* key;                        // staging shared by all destinations (the sort separates them)
   uint32_t* idx;
@@ -47,7 +50,8 @@ __device__ __forceinline__ uint32_t jg_route_dests(const jg_msg_row& r, const Jg
 }
 __device__ __forceinline__ uint64_t jg_route_key(const JgRouteTable& t, uint32_t dest, uint32_t group, uint32_t step,
                                                  uint32_t ord) {
-  return ((uint64_t)dest << t.group_bits | group) << 32 | (uint64_t)t.src << 29 | (uint64_t)step << JG_ROUTE_ORD_BITS | ord;
+  if (ord >> t.ord_bits) t.count[t.R + JG_ROUTE_OVERFLOW] = 1;
+  return ((((uint64_t)dest << t.group_bits | group) << 3 | t.src) << 2 | step) << t.ord_bits | ord;
 }
 // One staging reservation per workgroup and tile (every wave of a launch reserving for itself made the
 // one cursor the bottleneck: a returning atomic on a single address retires every ~18 ns, 85 us for the
@@ -133,7 +137,8 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_rec(JgRouteTable t, uint32_t
         const jg_msg_row r = mine[j];
         for (uint32_t b = jg_route_dests(r, t); b; b &= b - 1, pos++) {
           if (pos >= t.cap) continue;  // (the host sees cursor > cap, grows the staging and repeats the pass)
-          t.key[pos] = jg_route_key(t, (uint32_t)__ffs(b) - 1u, r.group, step, i * per_row + j);
+          // (a run's rows lie back to back from its first slot: j is the emission index within the group's step)
+          t.key[pos] = jg_route_key(t, (uint32_t)__ffs(b) - 1u, r.group, step, j);
           t.idx[pos] = pos;
           t.row[pos] = r;
         }
@@ -192,7 +197,6 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_xq(JgRouteTable t, const JgX
       continue;
     }
     const uint32_t step = q.seq - seq_base;
-    if (mask && q.k >> JG_ROUTE_ORD_BITS) t.count[t.R + JG_ROUTE_OVERFLOW] = 1;
     uint32_t pos = jg_route_reserve(t, __popc(mask));
     stays += stay;
     for (uint32_t b = mask; b; b &= b - 1, pos++) {

@@ -1701,11 +1701,14 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
   hipStream_t st = L->stream;
   uint32_t* d_cursor = rt.d_count + (size_t)R * ROUTE_WORDS;
   uint32_t* d_keep_n = d_cursor + 1;
+  // (JG_ROUTE_NARROW_BITS: test hook - a field too narrow for the trace exercises the repeat with the wide one)
+  static const uint32_t narrow = std::getenv("JG_ROUTE_NARROW_BITS") ? (uint32_t)std::atoi(std::getenv("JG_ROUTE_NARROW_BITS")) : JG_ROUTE_ORD_BITS_FAST;
+  uint32_t ord_bits = std::min<uint32_t>(std::max<uint32_t>(narrow, 1u), JG_ROUTE_ORD_BITS);
   auto table = [&](uint32_t s) {
     JgRouteTable t{};
     t.R = R, t.src = s;
     for (uint32_t n = 0; n < R; n++) t.member_id[n] = c->nodes[n]->cfg.node_ids[n];
-    t.group_bits = rt.group_bits, t.cap = rt.cap;
+    t.group_bits = rt.group_bits, t.ord_bits = ord_bits, t.cap = rt.cap;
     t.key = rt.key, t.idx = rt.idx, t.row = rt.row;
     t.cursor = d_cursor;
     t.count = rt.d_count + (size_t)s * ROUTE_WORDS;
@@ -1713,8 +1716,8 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
   };
   for (uint32_t s = 0; s < R; s++)
     for (const StepRec& r : c->nodes[s]->recs)
-      if (r.seq > seq_base[s] && (r.seq - seq_base[s] > 3 || (uint64_t)r.n * r.msg_per_row >> JG_ROUTE_ORD_BITS))
-        return fail(JG_ECAPACITY, "routed round: a step is too large for the transport's ordering key");
+      if (r.seq > seq_base[s] && r.seq - seq_base[s] > 3)
+        return fail(JG_ECAPACITY, "routed round: more steps than the transport's ordering key numbers");
   const uint32_t* h_cursor = rt.h_count + (size_t)R * ROUTE_WORDS;
   for (int attempt = 0;; attempt++) {  // (repeated once when the staging turns out too small: the pass modifies nothing)
     HIPCHK(hipMemsetAsync(rt.d_count, 0, words * 4, st));
@@ -1733,16 +1736,21 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
     T2 = clk();
     HIPCHK(hipStreamSynchronize(st));
     T3 = clk();
-    if (*h_cursor <= rt.cap) break;
-    if (attempt) return fail(JG_EDEVICE, "internal: routed round: staging still too small");
-    if ((rc = route_grow(rt, *h_cursor))) return rc;
+    bool wide = false;  // some group emitted more rows in one step than the narrow index field numbers
+    for (uint32_t s = 0; s < R; s++) wide = wide || rt.h_count[(size_t)s * ROUTE_WORDS + R + JG_ROUTE_OVERFLOW];
+    if (*h_cursor <= rt.cap && !wide) break;
+    if (attempt >= 2) return fail(JG_EDEVICE, "internal: routed round: the delivering pass does not settle");
+    if (wide) {
+      if (ord_bits == JG_ROUTE_ORD_BITS) return fail(JG_ECAPACITY, "routed round: a group emitted too many rows in one step");
+      ord_bits = JG_ROUTE_ORD_BITS;
+    }
+    if (*h_cursor > rt.cap && (rc = route_grow(rt, *h_cursor))) return rc;
   }
   const uint32_t total = *h_cursor;
   std::vector<uint64_t> to(R, 0), from(R, 0);
   uint64_t kept = 0, fsm = 0;
   for (uint32_t s = 0; s < R; s++) {
     const uint32_t* h = rt.h_count + (size_t)s * ROUTE_WORDS;
-    if (h[R + JG_ROUTE_OVERFLOW]) return fail(JG_ECAPACITY, "routed round: an exceptional row outside the transport's ordering key");
     for (uint32_t n = 0; n < R; n++) to[n] += h[n], from[s] += h[n];
     kept += h[R + JG_ROUTE_KEPT] + h[R + JG_ROUTE_KEPT_XQ];
     fsm += h[R + JG_ROUTE_FSM];
@@ -1774,7 +1782,7 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
   }
   // one sort for all destinations, then the command columns of every node's next round
   if (total) {
-    const uint32_t end_bit = 32 + rt.group_bits + 3;
+    const uint32_t end_bit = ord_bits + 5 + rt.group_bits + 3;
     size_t need = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, need, rt.key, rt.key_alt, rt.idx, rt.idx_alt, (size_t)total, 0, end_bit, st));
     if (rt.sort_tmp_bytes < need) {

@@ -379,3 +379,18 @@ def test_mailbox_word_range_parity():
     _cmp_cols(od, oo, "mailbox range")
     assert dev.handle(1).fault == capi.FAULT_ENGINE_MAILBOX_RANGE
     assert dev.drain_faults().tobytes() == ora.drain_faults().tobytes()
+
+
+@pytest.mark.gpu
+def test_routed_transport_repeats_with_wide_keys():
+    """The transport first builds its sort keys with a 12-bit emission index and repeats the (non-mutating)
+    delivering pass with the wide field when a group emitted more rows than that in one step.  With the field
+    narrowed to one bit (test hook, read once per process: hence the subprocess) every election triggers the repeat."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_dense_node.py"), "-q", "-m", "gpu", "-k",
+                        "test_routed_cluster_device_transport_parity"], capture_output=True, text=True, timeout=600,
+                       cwd=root, env={**os.environ, "JG_ROUTE_NARROW_BITS": "1"})
+    assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
