@@ -23,6 +23,9 @@
 // same tick(s) through the general state machine.  Workgroup s owns shard s of the deferral
 // bitmap (jg_defer_mark), turns it into its list and clears it for the next launch.  Message rows
 // outside the dense mailbox vocabulary go to the exceptional queue.
+// NODE: behind a node tick (HeartbeatResponses in, the Tick's outbox out).  A template parameter so that the
+// instance behind the ack-only kernels carries neither the Tick's local row buffer (scratch) nor its code.
+template <bool NODE>
 __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
                                                           size_t tick_stride, uint32_t seq0, JgLeaderNode nd) {
   if (nd.clock) nd.now = nd.clock->now, seq0 = nd.clock->seq[nd.clock_slot];
@@ -70,14 +73,14 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
     // own slot outside its domain (JG_MAX_DENSE_APPENDS; a leader only: non-leaders never get here):
     // nothing of the tick is applied.  Checked again per tick below (T-tick launches).
     // (node tick: the block holds answer words, JG_ANSWER(head, HeartbeatResponse code))
-    const bool packed = nd.packed != 0;
-    auto ack_of = [packed](uint64_t w) { return packed ? jg_answer_ack(w) : w; };
+    const bool packed = NODE && nd.packed != 0;
+    auto ack_of = [=](uint64_t w) { return packed ? jg_answer_ack(w) : w; };
     if (acks && n_ticks && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L) &&
         ack_of(acks[(size_t)s * d.G + g]) >= JG_MAX_DENSE_APPENDS) {
       L.seq = seq0;
       jg_raise(d, L, JG_FAULT_ENGINE_DENSE_APPENDS);
     }
-    if (packed && acks && !jg_fault(L)) {  // 1. HeartbeatResponses, ascending slot (leader.rs:222-231)
+    if (NODE && packed && acks && !jg_fault(L)) {  // 1. HeartbeatResponses, ascending slot (leader.rs:222-231)
       L.seq = seq0;
       c.kind = JG_CMD_HEARTBEAT_RESPONSE;
       for (uint32_t r = 0; r < d.R && !jg_fault(L); r++) {
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
         jg_apply(d, L, c, nullptr, nullptr);
       }
     }
-    if (nd.o_beat && !jg_fault(L)) {  // 3. Command::Tick (leader.rs:234-245)
+    if (NODE && nd.o_beat && !jg_fault(L)) {  // 3. Command::Tick (leader.rs:234-245)
       L.seq = seq0;
       c.kind = JG_CMD_TICK;
       c.from = 0;

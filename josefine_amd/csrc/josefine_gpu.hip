@@ -330,8 +330,12 @@ int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1, con
   if (e->maybe_irregular || nd || n_ticks > 1) {
     e->slow_scheduled_ever = true;
     JgLeaderNode none{};
-    hipLaunchKernelGGL(k_dense_slow, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream, e->dev, acks_dev, n_ticks,
-                       (size_t)e->cfg.n_groups * e->cfg.n_replicas, e->seq, nd ? *nd : none);
+    if (nd)
+      hipLaunchKernelGGL(k_dense_slow<true>, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream, e->dev, acks_dev, n_ticks,
+                         (size_t)e->cfg.n_groups * e->cfg.n_replicas, e->seq, *nd);
+    else
+      hipLaunchKernelGGL(k_dense_slow<false>, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream, e->dev, acks_dev, n_ticks,
+                         (size_t)e->cfg.n_groups * e->cfg.n_replicas, e->seq, none);
     e->n_launch++;
   }
   HIPCHK(hipGetLastError());
@@ -1050,7 +1054,7 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
      // scratch memory, which the runtime sets up at a kernel's first launch (~150 us) — here, not
      // inside somebody's first node tick
     JgLeaderNode none{};
-    hipLaunchKernelGGL(k_dense_slow, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream, e->dev, (const uint64_t*)nullptr,
+    hipLaunchKernelGGL(k_dense_slow<true>, dim3(JG_SHARDS), dim3(JG_BLOCK), 0, e->stream, e->dev, (const uint64_t*)nullptr,
                        0u, (size_t)0, 0u, none);
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
