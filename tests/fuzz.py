@@ -2,6 +2,8 @@
 state of the *oracle* (terms around current_term, ids around head, node ids from
 the membership plus an occasional stranger) so that every branch of every role
 is reached, including the reference's panic / Err paths."""
+import weakref
+
 import numpy as np
 
 from josefine_amd import capi
@@ -30,7 +32,9 @@ def random_batch(rng: np.random.Generator, ora, n: int, foreign_voters: bool = F
     else:
         # per budget array: the blocks sent with a parent other than id-1, and the highest id the group
         # can hold (a Restart puts the head back at the commit index but keeps the stored blocks)
-        track = _TRACK.setdefault(id(budget), {"forks": {}, "hi": np.zeros(G, np.int64)})
+        track = _TRACK.get(id(budget))
+        if track is None or track["of"]() is not budget:  # (ids are reused once an array is gone)
+            track = _TRACK[id(budget)] = {"of": weakref.ref(budget), "forks": {}, "hi": np.zeros(G, np.int64)}
     ids = np.array(ora.node_ids, dtype=np.uint32)
     term_now = ora.read("term").astype(np.int64)
     head_now = ora.read("head").astype(np.int64)
