@@ -220,6 +220,10 @@ struct jg_engine {
   void* fs_tmp = nullptr;
   size_t fs_cap = 0, fs_tmp_bytes = 0;
   PinnedQueue<JgXqRec> h_xq;
+  // the gathers compact into device memory and ONE copy per queue takes the rows to the pinned host
+  // queue (a DMA engine's work, not the gather kernels' across PCIe)
+  void *d_stage_m = nullptr, *d_stage_f = nullptr;
+  size_t stage_m_cap = 0, stage_f_cap = 0;
   std::vector<JgXqRec> xq_tmp;
   JgScanJob* h_jobs = nullptr;  // pinned: drain-time scan jobs and their totals
   uint64_t* h_totals = nullptr;
@@ -479,8 +483,8 @@ int drain_scan(jg_engine* e, const std::vector<StepRec>& recs, hipStream_t st) {
   return JG_OK;
 }
 
-// phase B: the gathers write straight into the pinned host queues (mapped, device-visible: no
-// staging buffer, no device-to-host blit), then the two device queues of buffer set `set`
+// phase B: the gathers compact into a device staging buffer, one copy per queue moves the rows into the
+// pinned host queues, then the two device queues of buffer set `set`
 int drain_gather(jg_engine* e, jg_engine::DrainBatch& b, const std::vector<StepRec>& recs, hipStream_t st) {
   static const bool trace = std::getenv("JG_TRACE_DRAIN") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -496,22 +500,43 @@ int drain_gather(jg_engine* e, jg_engine::DrainBatch& b, const std::vector<StepR
   // re-pinning a 30 MB buffer costs milliseconds)
   if (qm.cap < b.at_m + b.add_m) HIPCHK(qm.reserve(b.at_m + b.add_m + b.add_m / 4));
   if (qf.cap < b.at_f + b.add_f) HIPCHK(qf.reserve(b.at_f + b.add_f + b.add_f / 4));
+  // (the gather kernels used to write into the pinned host queue themselves: PCIe-bound for 90 us per
+  // 16-tick batch of configs[4], during which the tick kernels beside them ran 2-4 x slower; now they
+  // compact in HBM and a copy engine moves the rows.  JG_DRAIN_DIRECT=1: the old way, for an A/B)
+  static const bool staged = std::getenv("JG_DRAIN_DIRECT") == nullptr;
+  jg_msg_row* dst_m = qm.p + b.at_m;
+  jg_fsm_row* dst_f = qf.p + b.at_f;
+  if (staged) {
+    auto grow = [](void*& p, size_t& cap, size_t bytes) -> hipError_t {
+      if (bytes <= cap) return hipSuccess;
+      if (p) (void)hipFree(p);
+      cap = bytes + bytes / 4;
+      return hipMalloc(&p, cap);
+    };
+    HIPCHK(grow(e->d_stage_m, e->stage_m_cap, b.add_m * sizeof(jg_msg_row)));
+    HIPCHK(grow(e->d_stage_f, e->stage_f_cap, b.add_f * sizeof(jg_fsm_row)));
+    dst_m = (jg_msg_row*)e->d_stage_m, dst_f = (jg_fsm_row*)e->d_stage_f;
+  }
   uint64_t off_m = 0, off_f = 0;
   for (size_t k = 0; k < recs.size(); k++) {
     const StepRec& r = recs[k];
     const uint32_t nb = (r.n + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
     if (totals[2 * k]) {
       hipLaunchKernelGGL(k_scan_gather<jg_msg_row>, dim3(nb), dim3(JG_BLOCK), 0, st, r.d_msg_cnt, r.n, r.d_bsum_m,
-                         r.msg_per_row, r.d_msg, qm.p + b.at_m + off_m);
+                         r.msg_per_row, r.d_msg, dst_m + off_m);
       off_m += totals[2 * k];
     }
     if (totals[2 * k + 1]) {
       hipLaunchKernelGGL(k_scan_gather<jg_fsm_row>, dim3(nb), dim3(JG_BLOCK), 0, st, r.d_fsm_cnt, r.n, r.d_bsum_f,
-                         r.fsm_per_row, r.d_fsm, qf.p + b.at_f + off_f);
+                         r.fsm_per_row, r.d_fsm, dst_f + off_f);
       off_f += totals[2 * k + 1];
     }
   }
   HIPCHK(hipGetLastError());
+  if (staged) {
+    if (b.add_m) HIPCHK(hipMemcpyAsync(qm.p + b.at_m, e->d_stage_m, b.add_m * sizeof(jg_msg_row), hipMemcpyDeviceToHost, st));
+    if (b.add_f) HIPCHK(hipMemcpyAsync(qf.p + b.at_f, e->d_stage_f, b.add_f * sizeof(jg_fsm_row), hipMemcpyDeviceToHost, st));
+  }
   g1 = now();
   uint32_t* d_cnt = e->d_status + (b.set ? 6 : 3);  // {fault_q_n, xq_n} of this buffer set
   if (b.nx) {
@@ -1096,7 +1121,7 @@ void jg_engine_destroy(jg_engine* e) {
   e->h_faults.destroy();
   e->h_fault_seq.destroy();
   e->h_xq.destroy();
-  for (void* p : {(void*)e->fs_k0, (void*)e->fs_k1, (void*)e->fs_v0, (void*)e->fs_v1, (void*)e->fs_seq, (void*)e->fs_rows, e->fs_tmp})
+  for (void* p : {(void*)e->fs_k0, (void*)e->fs_k1, (void*)e->fs_v0, (void*)e->fs_v1, (void*)e->fs_seq, (void*)e->fs_rows, e->fs_tmp, e->d_stage_m, e->d_stage_f})
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->kt_ev) (void)hipEventDestroy(ev);
   if (e->ev_steps) (void)hipEventDestroy(e->ev_steps);
