@@ -1790,7 +1790,7 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
     const uint32_t* h = rt.h_count + (size_t)s * ROUTE_WORDS;
     if (!from[s]) continue;
     const JgRouteTable t = table(s);
-    if (h[R + JG_ROUTE_KEPT])
+    if (h[R + JG_ROUTE_KEPT] || h[R + JG_ROUTE_FSM])  // (its steps stay queued for a drain: without the delivered rows)
       for (const StepRec& r : e->recs) {
         if (r.seq <= seq_base[s]) continue;
         hipLaunchKernelGGL(k_route_rec_compact, dim3((r.n + JG_BLOCK - 1) / JG_BLOCK), dim3(JG_BLOCK), 0, st, t, r.n, r.msg_per_row,

@@ -332,12 +332,19 @@ def test_routed_cluster_device_transport_parity(R, percent, also):
         if t == 20:  # something the transport must leave alone: a client request at every replica of node 2
             inj[2] = dict(kind=np.full(G, capi.CMD_CLIENT_REQUEST, np.uint8), group=np.arange(G, dtype=np.uint32),
                           id=np.arange(G, dtype=np.uint64) + 1000)
+        if t == 25:  # ... and a step that queues FSM rows but keeps no message: a Heartbeat as a row at node 2 (its
+            # HeartbeatResponse is delivered, the Apply range stays for jg_drain_applies - without the response)
+            g = np.arange(G, dtype=np.uint32)
+            inj[2] = dict(kind=np.full(G, capi.CMD_HEARTBEAT, np.uint8), group=g, from_=np.full(G, nodes[0].node_ids[0], np.uint32),
+                          term=ora.nodes[0].read("term").astype(np.uint64), id=ora.nodes[0].read("commit").astype(np.uint64))
         up = [None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(inj)]
         st = lib.round_routed((t + 1) * 100, up)
         ora.round(np.ones(G, np.uint64), inject=inj)
         for n in range(R):
             compare_snapshots(nodes[n], ora.nodes[n], f"routed round {t} node {n}")
         assert st["delivered"] == [sum(len(r) for _, r in ora.inbound[n]) for n in range(R)], t
+        if t == 25:
+            assert st["fsm_rows"] > 0
         for rows in up:
             if rows is not None:
                 rows.free()
