@@ -30,6 +30,8 @@ struct JgRowsArgs {
   jg_fsm_row* fsm_out;  // [n * fsm_per_row]
   uint32_t* msg_cnt;    // [n] rows produced by the run starting here (0 elsewhere)
   uint32_t* fsm_cnt;
+  uint64_t* bsum_m;     // [ceil(n / JG_BLOCK)] sums of msg_cnt / fsm_cnt over each workgroup-sized tile of rows:
+  uint64_t* bsum_f;     //   what the drain's scan starts from (written here: no separate counting launch)
   uint32_t* err;        // 1: output bound exceeded, 2: rows not sorted by group, 3: group out of range
   uint64_t now;
   uint32_t seq;
@@ -115,13 +117,32 @@ __global__ __launch_bounds__(JG_BLOCK) void k_apply_rows(JgDev d, JgRowsArgs a) 
         jg_apply(d, L, c, a.blk_id, a.blk_next);
       }
     }
+    uint32_t cm = 0, cf = 0;
     if (owner) {
-      a.msg_cnt[i] = (uint32_t)(L.mp - m0);
-      a.fsm_cnt[i] = (uint32_t)(L.fp - f0);
+      cm = (uint32_t)(L.mp - m0), cf = (uint32_t)(L.fp - f0);
+      a.msg_cnt[i] = cm;
+      a.fsm_cnt[i] = cf;
       if (L.overflow) *a.err = 1;
       dec += L.decisions;
       jg_store(d, L);
     }
+    // the tile's sums (tile = the JG_BLOCK rows this workgroup just served)
+    __shared__ uint32_t red_m[JG_BLOCK / 64], red_f[JG_BLOCK / 64];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+      cm += __shfl_down(cm, off, 64);
+      cf += __shfl_down(cf, off, 64);
+    }
+    if (lane == 0) red_m[threadIdx.x >> 6] = cm, red_f[threadIdx.x >> 6] = cf;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tm = 0, tf = 0;
+#pragma unroll
+      for (int w = 0; w < JG_BLOCK / 64; w++) tm += red_m[w], tf += red_f[w];
+      a.bsum_m[base / JG_BLOCK] = tm;
+      a.bsum_f[base / JG_BLOCK] = tf;
+    }
+    __syncthreads();
   }
   jg_block_count(d.blk_decisions, dec);
 }
@@ -129,12 +150,12 @@ __global__ __launch_bounds__(JG_BLOCK) void k_apply_rows(JgDev d, JgRowsArgs a) 
 // ---- drain-time compaction, entirely on the device -------------------------------------------
 // cnt[i] rows sit at src + i*per_row; the drained sequence is their concatenation in row
 // order (= group order, emission order within a group).  Exclusive scan of cnt in three
-// steps: per-workgroup sums (1024 counts each; at step time), a single-workgroup scan of
+// steps: per-workgroup sums (JG_SCAN_TILE counts each; at step time, by k_apply_rows itself), a single-workgroup scan of
 // those sums (one launch for all pending steps at drain time), then each workgroup re-scans
-// its 1024 counts (wave64 shuffles + an LDS hop across the four waves), adds its base and
+// its counts (wave64 shuffles + an LDS hop across the four waves), adds its base and
 // copies its rows to their final place in ONE buffer per queue, which travels to the pinned
 // host queue in one copy.
-#define JG_SCAN_ITEMS 4
+#define JG_SCAN_ITEMS 1  // (a tile = the rows one workgroup of k_apply_rows serves: it writes the tile sums itself)
 #define JG_SCAN_TILE (JG_BLOCK * JG_SCAN_ITEMS)
 
 // inclusive scan of one value per lane across the workgroup; returns the exclusive prefix of
@@ -161,7 +182,7 @@ __device__ __forceinline__ uint32_t jg_block_exclusive_scan(uint32_t v, uint32_t
   return base + inc - v;
 }
 
-// step time, right behind k_apply_rows: tile sums of both count arrays
+// tile sums of both count arrays again (after the cluster transport took rows out of a step's slots)
 __global__ __launch_bounds__(JG_BLOCK) void k_count_block_sums(const uint32_t* __restrict__ cnt_m,
                                                                const uint32_t* __restrict__ cnt_f, uint32_t n,
                                                                uint64_t* __restrict__ bsum_m,

@@ -933,15 +933,15 @@ int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* 
   a.fsm_out = rec.d_fsm;
   a.msg_cnt = rec.d_msg_cnt;
   a.fsm_cnt = rec.d_fsm_cnt;
+  a.bsum_m = rec.d_bsum_m;
+  a.bsum_f = rec.d_bsum_f;
   a.err = e->d_err;
   a.now = now_ms;
   a.seq = e->seq;
   rec.seq = e->seq;
   hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(n, e->count_slots)), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
-  hipLaunchKernelGGL(k_count_block_sums, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, rec.d_msg_cnt, rec.d_fsm_cnt, n,
-                     rec.d_bsum_m, rec.d_bsum_f);
   HIPCHK(hipGetLastError());
-  e->n_launch += 2;
+  e->n_launch += 1;
   e->recs.push_back(rec);
   e->n_cmds += n;
   e->maybe_irregular = true;  // until the device flag says otherwise (sync_and_check)
