@@ -1680,7 +1680,7 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
   for (jg_engine* e : c->nodes) {
     if (e->device != L->device) return fail(JG_EINVAL, "routed rounds take nodes that share a device");
     if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
-    if (e->inflight.phase || e->pipelined) return fail(JG_EINVAL, "a drain is in transfer: jg_drain_flush first");
+    if (e->inflight.phase) return fail(JG_EINVAL, "a drain is in transfer: jg_drain_flush first");
     if ((rc = ensure_xq(e))) return rc;
   }
   HIPCHK(hipSetDevice(L->device));

@@ -401,3 +401,31 @@ def test_routed_transport_repeats_with_wide_keys():
                         "test_routed_cluster_device_transport_parity"], capture_output=True, text=True, timeout=600,
                        cwd=root, env={**os.environ, "JG_ROUTE_NARROW_BITS": "1"})
     assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_routed_round_argument_checks():
+    """Misuse is refused with JG_EINVAL, not executed: injected rows that carry blocks, a node with a
+    drain in transfer."""
+    from josefine_amd import DenseCluster as LibCluster, EngineError
+    G, R = 64, 3
+    nodes = [BatchedRaft(G, R, seed=5 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY)
+             for r in range(R)]
+    elect_all(nodes[0])
+    nodes[0].drain_messages(), nodes[0].drain_applies()
+    lib = LibCluster(nodes)
+    lib.set_appends(1)
+    lib.round_routed(100, None)
+    rows = nodes[1].upload_rows(kind=np.array([capi.CMD_APPEND_ENTRIES], np.uint8), group=np.array([3], np.uint32),
+                                aux=np.array([1], np.uint64), blk_id=np.array([7], np.uint64), blk_next=np.array([6], np.uint64))
+    with pytest.raises(EngineError, match="cannot carry blocks"):
+        lib.round_routed(200, [None, rows, None])
+    rows.free()
+    nodes[2].apply(0, Command.Tick())
+    nodes[2].drain_prefetch()
+    with pytest.raises(EngineError, match="drain is in transfer"):
+        lib.round_routed(300, None)
+    nodes[2].drain_flush()
+    lib.round_routed(300, None)  # and the cluster carries on
+    assert (nodes[0].read("fault") == 0).all()
+    lib.close()
