@@ -1683,6 +1683,13 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
     if (e->inflight.phase) return fail(JG_EINVAL, "a drain is in transfer: jg_drain_flush first");
     if ((rc = ensure_xq(e))) return rc;
   }
+  for (uint32_t n = 0; inject && n < R; n++) {  // (checked before anything is launched)
+    if (!inject[n].n) continue;
+    if (inject[n].n_blocks) return fail(JG_EINVAL, "injected rows cannot carry blocks");
+    if (inject[n].n > 0x7fffffffull) return fail(JG_EINVAL, "batch too large: split it");
+    if (!inject[n].kind || !inject[n].group || !inject[n].from || !inject[n].term || !inject[n].id || !inject[n].aux || !inject[n].flag)
+      return fail(JG_EINVAL, "all seven device columns are required");
+  }
   HIPCHK(hipSetDevice(L->device));
   static const bool trace = std::getenv("JG_TRACE_ROUTE") != nullptr;
   auto clk = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1714,10 +1721,7 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
         return rc;
       rt.n_in[n] = 0;
     }
-    if (inject && inject[n].n) {
-      if (inject[n].n_blocks) return fail(JG_EINVAL, "injected rows cannot carry blocks");
-      if ((rc = jg_step_device_rows(e, &inject[n], now_ms))) return rc;
-    }
+    if (inject && inject[n].n && (rc = jg_step_device_rows(e, &inject[n], now_ms))) return rc;
   }
   // -- 2. the dense round; ClientRequests only where the lead node (still) leads
   hipLaunchKernelGGL(k_route_mask_appends, dim3((c->G + 255) / 256), dim3(256), 0, L->stream, c->G, (const uint32_t*)L->dev.flags,
