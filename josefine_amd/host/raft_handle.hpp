@@ -408,6 +408,37 @@ class DenseCluster {
   std::vector<void*> bufs_;
 };
 
+// The same closed loop driven from inside the library (jg_dense_cluster_*: the round replayed as a
+// hipGraph), and - round_routed - with the library's device-side transport for everything outside the
+// mailbox vocabulary: the votes of an election travel between the nodes' engines without a host in
+// between (the in-process stand-in for rpc_tx -> tcp.rs -> the peer's event_loop, server.rs:127-137).
+#ifndef JG_TEST_AGAINST_ORACLE
+class LibraryCluster {
+ public:
+  LibraryCluster(const std::vector<jg_engine*>& nodes, uint32_t lead) : R_((uint32_t)nodes.size()) {
+    check(jg_dense_cluster_create(nodes.data(), R_, lead, &c_));
+  }
+  ~LibraryCluster() { jg_dense_cluster_destroy(c_); }
+  LibraryCluster(const LibraryCluster&) = delete;
+  LibraryCluster& operator=(const LibraryCluster&) = delete;
+  void set_appends(uint64_t per_group_and_round) { check(jg_dense_cluster_set_appends(c_, per_group_and_round, nullptr)); }
+  void rounds(uint64_t now_ms, uint64_t dt_ms, uint32_t n) { check(jg_dense_cluster_rounds(c_, now_ms, dt_ms, n)); }
+  // `inject`: per node a device batch (jg_step_device_rows' form) or n == 0; empty = nothing for anybody
+  jg_route_stats round_routed(uint64_t now_ms, const std::vector<jg_cmd_batch>& inject = {}) {
+    jg_route_stats st{};
+    check(jg_dense_cluster_round_routed(c_, now_ms, inject.empty() ? nullptr : inject.data(), &st));
+    return st;
+  }
+
+ private:
+  static void check(int rc) {
+    if (rc != JG_OK) throw EngineError(rc, jg_last_error());
+  }
+  uint32_t R_;
+  jg_dense_cluster* c_ = nullptr;
+};
+#endif
+
 // ---- fsm::Driver and server::event_loop for many partitions ---------------------------------------
 // The two tasks on either side of Raft<T> in a josefine process, batched over every partition the
 // process hosts.  Logical time: `run_until(now_ms)` plays the

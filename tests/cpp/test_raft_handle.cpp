@@ -169,6 +169,68 @@ static void multi_node_dense_rounds() {
 #endif
 
 
+#ifndef JG_TEST_AGAINST_ORACLE
+// Three nodes in one process, the library driving the rounds; then node 1's and node 3's replicas of every
+// partition crash and restart, node 2 (restarted too: voted_for == None) times out
+// and campaigns: its VoteRequests reach the others through the device-side transport, node 3 grants
+// (can_vote, follower.rs:97-101), node 2 is elected (quorum 2 of 3 with its own vote) - no row of the
+// election ever passes through the host.
+static void library_cluster_routed_election() {
+  const uint32_t G = 32;
+  std::vector<std::unique_ptr<BatchedRaft>> nodes;
+  std::vector<jg_engine*> raw;
+  for (uint32_t r = 0; r < 3; r++) {
+    nodes.emplace_back(new BatchedRaft(G, {1, 2, 3}, 0, 7 + r, JG_CFG_SEPARATE_COMMIT_KEY));
+    std::vector<uint8_t> slots(G, (uint8_t)r);
+    CHECK(jg_set_self_slots(nodes[r]->raw(), slots.data()) == JG_OK);
+    raw.push_back(nodes[r]->raw());
+  }
+  for (uint32_t g = 0; g < G; g++) nodes[0]->submit(g, Command::Timeout());
+  nodes[0]->step(0);
+  for (uint32_t g = 0; g < G; g++) nodes[0]->submit(g, Command::VoteResponse(1, 2, true));
+  nodes[0]->step(0);
+  LibraryCluster cl(raw, 0);
+  cl.set_appends(1);
+  cl.rounds(100, 100, 10);  // steady state, replayed graph
+  CHECK(nodes[0]->handle(3).head() == 10 && nodes[1]->handle(3).voted_for() == 1);
+  // the crash: per node one device-resident, group-sorted batch
+  auto upload = [&](jg_engine* e, const std::vector<uint8_t>& kinds) {  // the same rows for every group
+    const size_t n = kinds.size() * G;
+    std::vector<uint8_t> kind(n), flag(n, 0);
+    std::vector<uint32_t> group(n), from(n, 0);
+    std::vector<uint64_t> zero(n, 0);
+    for (uint32_t g = 0; g < G; g++)
+      for (size_t k = 0; k < kinds.size(); k++) kind[g * kinds.size() + k] = kinds[k], group[g * kinds.size() + k] = g;
+    jg_cmd_batch b{};
+    b.n = n;
+    auto dev = [&](const void* src, size_t bytes) {
+      void* p = nullptr;
+      CHECK(jg_device_alloc(e, bytes, &p) == JG_OK && jg_device_upload(e, p, src, bytes) == JG_OK);
+      return p;
+    };
+    b.kind = (const uint8_t*)dev(kind.data(), n), b.flag = (const uint8_t*)dev(flag.data(), n);
+    b.group = (const uint32_t*)dev(group.data(), 4 * n), b.from = (const uint32_t*)dev(from.data(), 4 * n);
+    b.term = (const uint64_t*)dev(zero.data(), 8 * n), b.id = (const uint64_t*)dev(zero.data(), 8 * n);
+    b.aux = (const uint64_t*)dev(zero.data(), 8 * n);
+    return b;
+  };
+  std::vector<jg_cmd_batch> inject(3);
+  inject[0] = upload(raw[0], {JG_CMD_RESTART});
+  inject[1] = upload(raw[1], {JG_CMD_RESTART, JG_CMD_TIMEOUT});
+  inject[2] = upload(raw[2], {JG_CMD_RESTART});
+  jg_route_stats st = cl.round_routed(1100, inject);
+  CHECK(st.delivered[0] == 2ull * G && st.delivered[2] == 2ull * G && st.kept == 0);  // 2 copies of the VoteRequest each (candidate.rs:30-37)
+  CHECK(nodes[1]->handle(3).is_candidate());
+  st = cl.round_routed(1200);  // the others answer through can_vote
+  CHECK(st.delivered[1] == 4ull * G);
+  st = cl.round_routed(1300);  // the candidate counts: its own vote + the first grant = quorum
+  for (uint32_t g : {0u, 3u, 31u}) {
+    CHECK(nodes[1]->handle(g).is_leader() && nodes[1]->handle(g).fault() == 0);
+    CHECK(nodes[0]->handle(g).is_follower() && nodes[2]->handle(g).is_follower());
+  }
+}
+#endif
+
 // src/raft/server.rs:185-216 event_loop: a single default-config node left alone for 2 s is leader
 static void server_event_loop_single_node() {
   BatchedRaft raft(1, {1});
@@ -332,6 +394,7 @@ int main() {
     multi_node_plumbing();
 #ifndef JG_TEST_AGAINST_ORACLE
     multi_node_dense_rounds();
+    library_cluster_routed_election();
 #endif
     server_event_loop_single_node();
     server_event_loops_three_nodes();
