@@ -84,7 +84,8 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     import subprocess
     structs = {"jg_config": capi.Config, "jg_cmd_batch": capi.CmdBatch, "jg_shard_info": capi.ShardInfo,
                "jg_leader_inbox": capi.LeaderInbox, "jg_leader_outbox": capi.LeaderOutbox,
-               "jg_follower_inbox": capi.FollowerInbox, "jg_follower_outbox": capi.FollowerOutbox}
+               "jg_follower_inbox": capi.FollowerInbox, "jg_follower_outbox": capi.FollowerOutbox,
+               "jg_route_stats": capi.RouteStats}
     rename = {"from_": "from"}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "josefine_gpu.h")}"',
              'int main(void) {']
@@ -93,6 +94,9 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
         for fname, *_ in ct._fields_:
             lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {rename.get(fname, fname)}));')
     lines += ['  printf("jg_msg_row %zu\\n", sizeof(jg_msg_row));', '  printf("jg_fsm_row %zu\\n", sizeof(jg_fsm_row));',
+              '  printf("jg_leader_beat %zu\\n", sizeof(jg_leader_beat));',
+              '  printf("answer %llx\\n", (unsigned long long)JG_ANSWER(5, JG_HB_NONE));',
+              '  printf("ae %llx\\n", (unsigned long long)JG_AE(7, 2));',
               '  return 0;', '}']
     src = tmp_path / "layout.c"
     src.write_text("\n".join(lines))
@@ -105,6 +109,11 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
             assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
     assert int(got["jg_msg_row"]) == np.dtype(capi.MSG_DTYPE).itemsize
     assert int(got["jg_fsm_row"]) == np.dtype(capi.FSM_DTYPE).itemsize
+    # the mailbox words: a 16-byte beat, and the header's packing macros against the Python helpers
+    assert int(got["jg_leader_beat"]) == 16
+    assert int(got["answer"], 16) == int(capi.pack_answers(np.array([5], np.uint64), np.array([capi.HB_NONE], np.uint8))[0])
+    assert int(got["ae"], 16) == int(capi.pack_ae(np.array([7], np.uint64), np.array([2], np.uint8))[0])
+    assert capi.unpack_answers(capi.pack_answers(np.array([capi.NO_ACK, 9], np.uint64), np.array([1, capi.HB_NONE], np.uint8)))[0].tolist() == [capi.NO_ACK, 9]
 
 
 def test_command_constructors_use_header_columns():
