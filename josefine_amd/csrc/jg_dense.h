@@ -407,14 +407,15 @@ __device__ __forceinline__ uint32_t jg_dense_leader_tick(const JgDenseHot& h, co
     jg_push_fault(*dp, g, JG_FAULT_ENGINE_MAILBOX_RANGE, seq);
     return nf | (JG_FAULT_ENGINE_MAILBOX_RANGE << JGF_FAULT_SHIFT);
   }
-  uint64_t hb = JG_NO_ACK;
-  if ((nd.now - hbt) > (uint64_t)h.hb_timeout) {  // leader.rs:78-84
-    hb = commit;                                  // leader.rs:44-51
-    h.heartbeat_time[g] = nd.now;
-  }
-  nd.o_beat[g] = jg_leader_beat{term, hb};  // one 16-byte store
+  // First every word, then every store.  A progress head in the wide column (BEHIND) is a load under a
+  // branch, and the wait the compiler puts behind that branch counts the stores issued so far as well
+  // (one counter for loads and stores here): with the stores interleaved, every follower's word waited
+  // for the previous follower's store to be acknowledged - five store round trips in a row per wave.
+  const bool due = (nd.now - hbt) > (uint64_t)h.hb_timeout;  // leader.rs:78-84
+  const uint64_t hb = due ? commit : JG_NO_ACK;              // leader.rs:44-51
   const bool key_in_range = (nf & JGF_COMMIT_KEY) && !(h.cfg_flags & JG_CFG_SEPARATE_COMMIT_KEY);
   bool dead = false;
+  uint64_t word[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {  // ascending slot = the order of replicate()'s loop
     uint32_t n = JG_AE_NONE;
@@ -429,13 +430,17 @@ __device__ __forceinline__ uint32_t jg_dense_leader_tick(const JgDenseHot& h, co
         dead = true;
         from = 0;
         nf |= JG_FAULT_RANGE_HIT_COMMIT_KEY << JGF_FAULT_SHIFT;
-        jg_push_fault(*dp, g, JG_FAULT_RANGE_HIT_COMMIT_KEY, seq);
       } else {
         n = cnt ? cnt - 1 : 0;
       }
     }
-    nd.o_ae[(size_t)r * G + g] = n == JG_AE_NONE ? JG_NO_ACK : JG_AE(from, n);
+    word[r] = n == JG_AE_NONE ? JG_NO_ACK : JG_AE(from, n);
   }
+  if (dead) jg_push_fault(*dp, g, JG_FAULT_RANGE_HIT_COMMIT_KEY, seq);
+  if (due) h.heartbeat_time[g] = nd.now;
+  nd.o_beat[g] = jg_leader_beat{term, hb};  // one 16-byte store
+#pragma unroll
+  for (int r = 0; r < R; r++) nd.o_ae[(size_t)r * G + g] = word[r];
   return nf;
 }
 
@@ -633,7 +638,9 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   bool hot = (f & (JGF_FAULT_MASK | JGF_ROLE_MASK | JGF_FAST)) == (JG_ROLE_LEADER | JGF_FAST);
   if (NODE) hot = hot && !hbr_trigger;
   hot = jg_lag_tick<R>(s, f, mword0, head0, n_app, a, lt, dl) && hot;
-  jg_count_step(h.blk_decisions, dec, hot, dl);
+  // (the node tick counts behind its stores: the counter's atomic would otherwise be one more thing the
+  // waits inside the Tick's emission wait for)
+  if (!NODE) jg_count_step(h.blk_decisions, dec, hot, dl);
   if (__builtin_expect(hot, 1)) {
     if (emit)  // Command::Tick into the outbox; may raise the Q9 fault
       lt.nf = jg_dense_leader_tick<R>(h, dp, nd, g, seq, s, term, hbt, lt.head1, lt.head1 - lt.l[R], lt.nf, [&](int r) {
@@ -642,6 +649,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
     if (lt.w1 != mword0) h.mlag[g] = lt.w1;
     if (lt.head1 != head0) h.head[g] = lt.head1;
     if (lt.nf != f) h.flags[g] = lt.nf;
+    if (NODE) jg_count_step(h.blk_decisions, dec, true, dl);  // (the ballots see the lanes of this branch: the hot ones)
     return;
   }
   const JgDev& d = *dp;  // (the ack-only kernel: loads from the device copy, general path only)
