@@ -143,6 +143,7 @@ struct jg_engine {
   JgDev dev;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;  // non-null while a jg_dense_cluster has this node on its lead node's stream: the stream to destroy
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_stage = nullptr, ev_order = nullptr;
   std::vector<void*> allocs;
   uint32_t count_slots = 0;  // workgroup slots of dev.blk_decisions
@@ -1138,7 +1139,10 @@ void jg_engine_destroy(jg_engine* e) {
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->ev_stage) (void)hipEventDestroy(e->ev_stage);
   if (e->ev_order) (void)hipEventDestroy(e->ev_order);
-  if (e->stream) (void)hipStreamDestroy(e->stream);
+  // (an engine destroyed while still in a jg_dense_cluster - against the documented order - must not
+  // destroy the lead node's stream it was lent: its own one is the one to release)
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  else if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
 
@@ -1478,6 +1482,7 @@ int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t 
       return rc;
     }
     c->own_stream[r] = e->stream;
+    e->own_stream = e->stream;
     e->stream = L->stream;
   }
   *out = c;
@@ -1490,6 +1495,7 @@ void jg_dense_cluster_destroy(jg_dense_cluster* c) {
     if (c->own_stream[r]) {
       (void)hipStreamSynchronize(c->nodes[r]->stream);
       c->nodes[r]->stream = c->own_stream[r];
+      c->nodes[r]->own_stream = nullptr;
     }
   if (c->exec) (void)hipGraphExecDestroy(c->exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);

@@ -633,6 +633,12 @@ class DenseCluster:
             self.api.dense_cluster_destroy(self._h)
             self._h = C.c_void_p()
 
+    def __del__(self):  # (this object keeps its nodes alive: the cluster always goes before them)
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def set_appends(self, uniform: int = 1, per_group=None) -> None:
         p = None if per_group is None else np.ascontiguousarray(per_group, dtype=np.uint64).ctypes.data
         self.nodes[0]._check(self.api.dense_cluster_set_appends(self._h, int(uniform), p))
