@@ -284,6 +284,27 @@ def test_election_status_vectors(make, R, votes, role):  # election.rs:37-73, ca
         assert h.voted_for is None  # defeat(): candidate.rs:103
 
 
+@pytest.mark.parametrize("order,role", [("by_sender", "f"), ("interleaved", "l")])
+def test_five_node_election_depends_on_the_delivery_order(make, order, role):
+    """A consequence of three lines read together, and the reason the cluster transport's
+    schedule matters: a candidate sends nodes.len() copies of its VoteRequest to every peer (candidate.rs:30-37),
+    a voter grants the first copy and refuses the others (voted_for is set by then, follower.rs:97-101,219-246),
+    and a later answer overwrites an earlier one (election.rs:34).  Two fresh voters of five that would both
+    grant: with each voter's four answers delivered back to back every grant is overwritten by the refusals
+    behind it and the third refuser makes it Defeated (election.rs:52); with the first answers of all voters
+    first, self + two grants are the quorum before any refusal arrives."""
+    e, h = new_follower(make, 5)
+    h.apply(Command.Timeout())
+    answers = {2: [True, False, False, False], 3: [True, False, False, False], 4: [False] * 4, 5: [False] * 4}
+    seq = [(v, g) for v, gs in answers.items() for g in gs] if order == "by_sender" else \
+          [(v, answers[v][k]) for k in range(4) for v in answers]
+    for frm, granted in seq:
+        if not h.is_candidate():
+            break
+        h.apply(Command.VoteResponse(1, frm, granted))
+    assert {"l": h.is_leader(), "f": h.is_follower()}[role]
+
+
 def test_can_vote_clauses(make):  # follower.rs:97-101
     e, h = new_follower(make, 3)
     h.apply(Command.Heartbeat(3, 0, 2))          # term 3, voted_for 2
