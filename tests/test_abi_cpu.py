@@ -176,3 +176,14 @@ def test_header_is_plain_c():
     src = open(hdr).read()
     assert "hip" not in src.lower().replace("hipcc", "") or "hip_runtime" not in src
     assert "torch" not in src.lower()
+
+
+def test_integration_md_binds_every_entry_point():
+    """INTEGRATION.md's `extern "C"` block (the binding a josefine maintainer would paste into
+    src/raft/gpu/ffi.rs) names exactly the functions include/josefine_gpu.h declares."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "josefine_gpu.h")).read()
+    declared = set(re.findall(r"^(?:int|void|uint32_t|const char\*) (jg_[a-z_0-9]+)\(", hdr, re.M))
+    bound = set(re.findall(r"pub fn (jg_[a-z_0-9]+)\(", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
+    assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
+    assert declared == set(capi.HEADER_SYMBOLS)
