@@ -6,8 +6,10 @@ steady-state append + commit: every tick each leader appends one block and
 receives the 4 follower acks of the previous tick.  The
 synthetic AppendEntries-ack stream for all warm-up + timed ticks is generated
 on the device BEFORE the timed region, so inputs are resident in HBM.  For
-N>1 (one process per GPU, launched by torch.distributed.run) every rank owns
-its own 1M x 5 shard (weak scaling, contiguous global group ids, no data-path
+N>1 (one process per GPU: launched by torch.distributed.run, or - when plain
+`python bench.py --gpus N` is run without a launcher - by bench.py re-executing
+itself under torch.distributed.run; WORLD_SIZE must equal --gpus either way)
+every rank owns its own 1M x 5 shard (weak scaling, contiguous global group ids, no data-path
 collective: Raft groups are independent — SURVEY.md §8(e)).
 
 A "step" = one tick = one launch of k_leader_tick_dense<5> over the rank's
@@ -259,7 +261,7 @@ def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
             "config": {"workload": f"closed loop: {R} nodes x {G} partitions on one GPU, 1 append per partition per round, "
                                    "leader half + follower halves over dense mailboxes (no synthetic acks)",
                        "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world,
-                       "parallelism": f"{world} independent shard(s), no collective"},
+                       "parallelism": f"{world} independent shard(s), no collective", **devices_config(args, world)},
             "group_rounds_per_s": G * world * K / wall,
             "roofline": {"bound": "hbm", "achieved": alg / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -377,7 +379,7 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
                                    "follower times out and campaigns, votes answered through can_vote and routed between "
                                    "the nodes on the device, applied the round after; 1 client request per led partition per round",
                        "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world,
-                       "parallelism": f"{world} independent shard(s), no collective"},
+                       "parallelism": f"{world} independent shard(s), no collective", **devices_config(args, world)},
             "group_rounds_per_s": G * world * K / wall,
             "leaderless_fraction": {"at_start_of_timed_region": None, "at_end": float(failed.mean())},
             "rows_routed_per_round": delivered[1] / K / world,
@@ -474,6 +476,37 @@ def single_process_main(args):
     print(json.dumps(out), flush=True)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1, no launcher around it): re-exec this script under
+    torch.distributed.run with N ranks on this node, one per GPU - the command the driver uses.  On a
+    box with fewer than N devices the ranks share devices (rank r -> device r mod #devices) and the
+    barrier / reductions go over gloo (RCCL refuses two ranks on one device); the JSON line then says
+    `"devices_aliased": true`: an exercise of the N-rank path, not a scaling number."""
+    import socket
+    import subprocess
+
+    import torch
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    env = dict(os.environ)
+    if ndev < args.gpus:
+        env.setdefault("JG_BENCH_BACKEND", "gloo")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a launcher: {' '.join(cmd)} ({ndev} device(s) visible)", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def devices_config(args, world):
+    """config entries that say where the ranks ran"""
+    devs = getattr(args, "devices_bound", [0])
+    return {"devices": devs, "devices_aliased": len(set(devs)) < world}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -499,8 +532,13 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
     if args.single_process:
         return single_process_main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU)
+        return self_launch(args)
 
     import torch  # first: the engine library then resolves against the same HIP runtime
     import torch.distributed as dist
@@ -509,6 +547,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: every rank is one GPU's share, "
+                         "launch exactly --gpus ranks (or run `python bench.py --gpus N` and let it launch them)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     # RCCL ("nccl") is the backend of record; JG_BENCH_BACKEND=gloo exists only so that the
@@ -522,6 +563,14 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+    # which device ordinal every rank bound (in rank order): part of the JSON line, so that an N-GPU
+    # number that was really measured on fewer devices says so
+    args.devices_bound = [dev_index]
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, dev_index)
+        args.devices_bound = [int(x) for x in got]
+    print(f"[bench rank {rank}/{world}] bound to HIP device {dev_index} of {torch.cuda.device_count()}", file=sys.stderr, flush=True)
 
     if args.cluster:
         return cluster_main(args, torch, dist, rank, world, dev_index, red_dev)
@@ -691,7 +740,7 @@ def main():
             "config": {
                 "workload": workload_name(G, R, args.mode, args.failures),
                 "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world,
-                "parallelism": f"{world} independent shard(s), no collective",
+                "parallelism": f"{world} independent shard(s), no collective", **devices_config(args, world),
             },
             "group_steps_per_s": G * world * K / wall,
             "roofline": {

@@ -56,6 +56,38 @@ def test_two_ranks_aggregate():
     assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
 
 
+def test_plain_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's scaling command
+    when it does not wrap it): bench.py re-executes itself under torch.distributed.run; the line says
+    n_gpus 2, twice the partitions, and which devices the ranks bound (aliased on this 1-GPU box)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--groups", "50000", "--steps", "30", "--warmup", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["partitions_total"] == 100000 and d["config"]["partitions_per_gpu"] == 50000
+    assert len(d["config"]["devices"]) == 2
+    import torch
+    assert d["config"]["devices_aliased"] == (torch.cuda.device_count() < 2)
+    assert abs(d["value"] / d["group_steps_per_s"] - 5.0) < 1e-6
+    one = run(["--groups", "50000", "--steps", "30", "--warmup", "5", "--no-cpu-baseline"])
+    assert one["n_gpus"] == 1 and one["config"]["devices"] == [0] and one["config"]["devices_aliased"] is False
+    if not d["config"]["devices_aliased"]:  # distinct devices: the job is two GPUs' worth of decisions per second
+        assert 1.5 < d["value"] / one["value"] < 2.5
+
+
+def test_world_size_must_equal_gpus():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--groups", "1000", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env={**os.environ, "JG_BENCH_BACKEND": "gloo"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stdout + r.stderr
+
+
 def test_cluster_and_failure_modes():
     d = run(["--cluster", "--groups", "30000", "--steps", "20", "--warmup", "5"])
     assert KEYS <= set(d) and "closed loop" in d["config"]["workload"] and d["value"] > 0
