@@ -375,6 +375,15 @@ int router_drain(jg_engine* p, std::vector<Row>& q, int mask, Row* out, size_t c
 template <typename Row>
 int router_drain_view(jg_engine* p, std::vector<Row>& q, std::vector<Row>& view, int mask, const Row** rows, size_t* n) {
   if (!rows || !n) return fail(JG_EINVAL, "null argument");
+  if (p->pipelined && !router_all_landed(p)) {
+    // a batch is still in transfer: router_collect would not collect (and would not release the
+    // outstanding view either), so the swap below would hand the view's rows back to `q` and they
+    // would be delivered a second time behind the next batch.  Nothing new: the earlier view stays
+    // valid and untouched, exactly like drain_view() of a single-device engine.
+    *rows = view.data();
+    *n = 0;
+    return JG_OK;
+  }
   const int rc = router_collect(p, mask);  // (releases this queue's previous view)
   if (rc) return rc;
   view.swap(q);

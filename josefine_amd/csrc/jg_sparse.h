@@ -25,6 +25,7 @@ struct JgRowsArgs {
   const uint8_t* flag;
   const uint64_t* blk_id;   // Vec<Block> side arrays (chain.rs:86-91)
   const uint64_t* blk_next;
+  uint64_t n_blocks;        // entries in the side arrays (an AppendEntries row must stay inside them)
   uint32_t msg_per_row, fsm_per_row;
   jg_msg_row* msg_out;  // [n * msg_per_row]
   jg_fsm_row* fsm_out;  // [n * fsm_per_row]
@@ -32,7 +33,8 @@ struct JgRowsArgs {
   uint32_t* fsm_cnt;
   uint64_t* bsum_m;     // [ceil(n / JG_BLOCK)] sums of msg_cnt / fsm_cnt over each workgroup-sized tile of rows:
   uint64_t* bsum_f;     //   what the drain's scan starts from (written here: no separate counting launch)
-  uint32_t* err;        // 1: output bound exceeded, 2: rows not sorted by group, 3: group out of range
+  uint32_t* err;        // 1: output bound exceeded, 2: rows not sorted by group, 3: group out of range,
+                        // 5: an AppendEntries row's block range leaves the side arrays (the row is not applied)
   uint64_t now;
   uint32_t seq;
 };
@@ -60,6 +62,12 @@ __global__ __launch_bounds__(JG_BLOCK) void k_apply_rows(JgDev d, JgRowsArgs a) 
       mine.aux = a.aux[i];
       a.msg_cnt[i] = 0;
       a.fsm_cnt[i] = 0;
+      // a device-resident batch is not validated by the host (jg_submit's rows are): a forged
+      // AppendEntries row must not read past the block side arrays
+      if (mine.kind == JG_CMD_APPEND_ENTRIES && a.blk_id && (mine.aux > a.n_blocks || mine.id > a.n_blocks - mine.aux)) {
+        *a.err = 5;
+        mine.kind = JG_CMD_NOOP;
+      }
     }
     const bool start = in && !(i && gp == g);  // first row of a run
     if (start && i && gp > g) *a.err = 2;
@@ -113,6 +121,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_apply_rows(JgDev d, JgRowsArgs a) 
           c.term = a.term[k];
           c.id = a.id[k];
           c.aux = a.aux[k];
+          if (c.kind == JG_CMD_APPEND_ENTRIES && a.blk_id && (c.aux > a.n_blocks || c.id > a.n_blocks - c.aux)) c.kind = JG_CMD_NOOP;
         }
         jg_apply(d, L, c, a.blk_id, a.blk_next);
       }

@@ -178,6 +178,7 @@ struct jg_engine {
     bool to_landing = false;  // rows go to l_msgs / l_fsm (from offset 0) instead of behind q_msgs / q_fsm
     size_t at_m = 0, at_f = 0, add_m = 0, add_f = 0;
     uint32_t nf = 0, nx = 0;
+    uint64_t irr_gen = 0;  // e->irr_gen at the prefetch point
   } inflight;
   bool pipelined = false;  // drains deliver up to the latest prefetch point and never synchronise later steps
   // The engine's own drain thread (created at the first jg_drain_prefetch): it waits for the scan
@@ -199,7 +200,7 @@ struct jg_engine {
   JgFaultRec* fq[2] = {nullptr, nullptr};
   JgXqRec* xqb[2] = {nullptr, nullptr};
   int cur_set = 0;
-  uint32_t* h_cnt = nullptr;  // pinned: {fault_q_n, xq_n} of the batch in transfer
+  uint32_t* h_cnt = nullptr;  // pinned: {fault_q_n, xq_n} of the batch in transfer, then the 8 status words at its prefetch point
   PinnedQueue<jg_msg_row> q_msgs;
   PinnedQueue<jg_fsm_row> q_fsm;
   // pipelined drains: the batch in transfer lands in queues of its own (nothing is ever moved
@@ -243,6 +244,7 @@ struct jg_engine {
   // point if the device-side flag is still 0.
   bool maybe_irregular = false;
   bool flag_check_pending = false;
+  uint64_t irr_gen = 0;  // bumped by every step that sets flag_check_pending (a pipelined status snapshot settles the flag only if nothing did since)
   bool slow_scheduled_ever = false;  // some dense launch had k_dense_slow behind it
   uint64_t n_cmds = 0, n_dense = 0, n_launch = 0;
   // set while a jg_dense_cluster round is being captured into a hipGraph: the node kernels then
@@ -386,6 +388,19 @@ int ensure_xq(jg_engine* e) {
   return push_dev_copy(e);
 }
 
+// device-side error flags of a status block {err, irregular_seen, deferred_seen, fault_q_n, xq_n, cold_seen, fault_q_n', xq_n'}
+int status_check(const jg_engine* e, const uint32_t* st) {
+  const uint32_t err = st[0];
+  if (err == 1) return fail(JG_EDEVICE, "internal: an output row exceeded its per-command bound");
+  if (err == 2) return fail(JG_EINVAL, "device command rows were not sorted by group");
+  if (err == 3) return fail(JG_EINVAL, "device command rows name a group out of range");
+  if (err == 4) return fail(JG_EDEVICE, "internal: deferred-group list overflow");
+  if (err == 5) return fail(JG_EINVAL, "device command rows: an AppendEntries row's block range is outside the side arrays");
+  if (st[4] > e->dev.xq_cap || st[7] > e->dev.xq_cap)
+    return fail(JG_ECAPACITY, "exceptional-message queue overflow: drain the messages more often");
+  return JG_OK;
+}
+
 // Everything that needs the stream idle first calls this: synchronise, surface
 // device-side error flags, and settle the lazily-read irregular-chain flag.
 int sync_and_check(jg_engine* e) {
@@ -393,13 +408,11 @@ int sync_and_check(jg_engine* e) {
   HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->stage_busy = false;
-  const uint32_t err = e->h_status[0], irregular = e->h_status[1], deferred = e->h_status[2];
-  if (err == 1) return fail(JG_EDEVICE, "internal: an output row exceeded its per-command bound");
-  if (err == 2) return fail(JG_EINVAL, "device command rows were not sorted by group");
-  if (err == 3) return fail(JG_EINVAL, "device command rows name a group out of range");
-  if (err == 4) return fail(JG_EDEVICE, "internal: deferred-group list overflow");
-  if (e->h_status[4] > e->dev.xq_cap || e->h_status[7] > e->dev.xq_cap)
-    return fail(JG_ECAPACITY, "exceptional-message queue overflow: drain the messages more often");
+  const uint32_t irregular = e->h_status[1], deferred = e->h_status[2];
+  {
+    const int rc = status_check(e, e->h_status);
+    if (rc) return rc;
+  }
   if (e->flag_check_pending) {
     e->maybe_irregular = irregular != 0;  // sticky on the device: once seen, the slow kernel stays scheduled
     e->flag_check_pending = false;
@@ -721,6 +734,16 @@ int inflight_finish(jg_engine* e) {
   }
   b.phase = 0;
   if (t.rc) return fail(t.rc, "drain thread: " + t.err);
+  {  // what sync_and_check does with the status block, on the snapshot taken at the prefetch point
+    const uint32_t* st = e->h_cnt + 2;
+    const int rc = status_check(e, st);
+    if (rc) return rc;
+    if (e->flag_check_pending && b.irr_gen == e->irr_gen) {  // no step since could have left an irregular chain
+      e->maybe_irregular = st[1] != 0;
+      e->flag_check_pending = false;
+    }
+    if (st[5]) e->maybe_irregular = true;
+  }
   return drain_finish(e, b, b.recs, e->arenas[b.arena]);
 }
 
@@ -759,6 +782,10 @@ int drain_prefetch(jg_engine* e, bool wait) {
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(e->h_cnt, e->d_status + (b.set ? 6 : 3), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost,
                         e->copy_stream));
+  // the status block as of the prefetch point: a pipelined engine never reaches sync_and_check through its
+  // drains, so this copy is where device-side error flags surface and the irregular-chain flag settles
+  HIPCHK(hipMemcpyAsync(e->h_cnt + 2, e->d_status, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->copy_stream));
+  b.irr_gen = e->irr_gen;
   HIPCHK(hipEventRecord(e->ev_scan, e->copy_stream));
   b.phase = 1;
   {
@@ -904,7 +931,7 @@ void sort_rows_by_group(const std::vector<uint32_t>& group, uint32_t n_groups, s
 // Launch k_apply_rows over device-resident, group-sorted command columns.
 int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* kind, const uint32_t* from,
                 const uint64_t* term, const uint64_t* id, const uint64_t* aux, const uint8_t* flag,
-                const uint64_t* blk_id, const uint64_t* blk_next, uint64_t now_ms) {
+                const uint64_t* blk_id, const uint64_t* blk_next, uint64_t n_blocks, uint64_t now_ms) {
   StepRec rec;
   rec.n = n;
   rec.msg_per_row = msg_bound(e->cfg.n_replicas);
@@ -928,6 +955,7 @@ int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* 
   a.flag = flag;
   a.blk_id = blk_id;
   a.blk_next = blk_next;
+  a.n_blocks = n_blocks;
   a.msg_per_row = rec.msg_per_row;
   a.fsm_per_row = rec.fsm_per_row;
   a.msg_out = rec.d_msg;
@@ -947,6 +975,7 @@ int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* 
   e->n_cmds += n;
   e->maybe_irregular = true;  // until the device flag says otherwise (sync_and_check)
   e->flag_check_pending = true;
+  e->irr_gen++;
   return JG_OK;
 }
 
@@ -1056,7 +1085,7 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   d.xq_n = e->d_status + 4;
   d.cold_seen = e->d_status + 5;
   if (hipHostMalloc((void**)&e->h_status, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-      hipHostMalloc((void**)&e->h_cnt, 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+      hipHostMalloc((void**)&e->h_cnt, 10 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
     return bail(fail(JG_EDEVICE, "hipHostMalloc failed"));
   {  // deferred lists: shard = workgroup & (JG_SHARDS-1); generous per-shard capacity, bounds-checked
     const size_t n_wg = (G + JG_BLOCK - 1) / JG_BLOCK;
@@ -1271,7 +1300,7 @@ int jg_step(jg_engine* e, uint64_t now_ms) {
   int rc = launch_rows(e, (uint32_t)n, (const uint32_t*)(B + o_group), (const uint8_t*)(B + o_kind),
                        (const uint32_t*)(B + o_from), (const uint64_t*)(B + o_term), (const uint64_t*)(B + o_id),
                        (const uint64_t*)(B + o_aux), (const uint8_t*)(B + o_flag), (const uint64_t*)(B + o_bid),
-                       (const uint64_t*)(B + o_bnext), now_ms);
+                       (const uint64_t*)(B + o_bnext), nb, now_ms);
   if (rc) return rc;
   e->p_kind.clear();
   e->p_flag.clear();
@@ -1296,8 +1325,12 @@ int jg_step_device_rows(jg_engine* e, const jg_cmd_batch* b, uint64_t now_ms) {
     return fail(JG_EINVAL, "all seven device columns are required");
   HIPCHK(hipSetDevice(e->device));
   e->seq++;
-  return launch_rows(e, (uint32_t)b->n, b->group, b->kind, b->from, b->term, b->id, b->aux, b->flag, b->blk_id,
-                     b->blk_next, now_ms);
+  if (b->n_blocks && (!b->blk_id || !b->blk_next)) return fail(JG_EINVAL, "block side arrays are required");
+  // every AppendEntries row's block range is checked against n_blocks on the device (error word 5 -> JG_EINVAL at the
+  // next synchronising call; the row is not applied): a batch without side arrays can only carry empty AppendEntries
+  const uint64_t* none = (const uint64_t*)e->d_ones;
+  return launch_rows(e, (uint32_t)b->n, b->group, b->kind, b->from, b->term, b->id, b->aux, b->flag,
+                     b->n_blocks ? b->blk_id : none, b->n_blocks ? b->blk_next : none, b->n_blocks, now_ms);
 }
 
 int jg_step_dense_acks_device(jg_engine* e, const uint64_t* acks_dev) {
@@ -1397,6 +1430,7 @@ int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbo
   // a deferred follower may have become a candidate / changed its chain: like a sparse step
   e->maybe_irregular = true;
   e->flag_check_pending = true;
+  e->irr_gen++;
   return JG_OK;
 }
 
@@ -1467,8 +1501,12 @@ int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t 
     jg_dense_cluster_destroy(c);
     return rc;
   }
-  std::vector<uint64_t> a(R * G, JG_NO_ACK);  // nothing from anybody
-  if ((rc = jg_device_upload(L, c->acks, a.data(), a.size() * 8))) {
+  std::vector<uint64_t> a(R * G, JG_NO_ACK);  // nothing from anybody ...
+  // ... and the lead node's own slot carries the number of appends: zero, with no HeartbeatResponse
+  // (JG_NO_ACK there is outside the own slot's domain: JG_FAULT_ENGINE_DENSE_APPENDS)
+  for (size_t g = 0; g < G; g++) a[(size_t)lead * G + g] = JG_ANSWER(0, JG_HB_NONE);
+  if ((rc = jg_device_upload(L, c->acks, a.data(), a.size() * 8)) ||
+      (rc = jg_device_upload(L, c->offered, a.data() + (size_t)lead * G, G * 8))) {
     jg_dense_cluster_destroy(c);
     return rc;
   }
@@ -1641,7 +1679,7 @@ int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms
       e->n_dense += c->G;
       e->n_launch += 2;
       e->slow_scheduled_ever = true;
-      if (r != c->lead) e->maybe_irregular = true, e->flag_check_pending = true;
+      if (r != c->lead) e->maybe_irregular = true, e->flag_check_pending = true, e->irr_gen++;
     }
   }
   HIPCHK(hipGetLastError());
@@ -1723,7 +1761,7 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
       e->stepped = true;
       e->seq++;
       if ((rc = launch_rows(e, rt.n_in[n], rt.cols.group + o, rt.cols.kind + o, rt.cols.from + o, rt.cols.term + o, rt.cols.id + o,
-                            rt.cols.aux + o, rt.cols.flag + o, nullptr, nullptr, now_ms)))
+                            rt.cols.aux + o, rt.cols.flag + o, nullptr, nullptr, 0, now_ms)))
         return rc;
       rt.n_in[n] = 0;
     }
@@ -1941,6 +1979,7 @@ int jg_chain_compact_resident(jg_engine* e, size_t* n_removed) {
   e->n_launch++;
   e->maybe_irregular = true;  // a leader's run may have lost its top: like a sparse step
   e->flag_check_pending = true;
+  e->irr_gen++;
   uint32_t n = 0;
   HIPCHK(hipMemcpyAsync(&n, e->d_compact_n, sizeof n, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));

@@ -356,7 +356,8 @@ class DenseCluster {
     hbr_commit_ = (uint64_t*)alloc(L, 8ull * R_ * G_);
     o_beat_ = (jg_leader_beat*)alloc(L, sizeof(jg_leader_beat) * (size_t)G_);
     o_ae_ = (uint64_t*)alloc(L, 8ull * R_ * G_);
-    std::vector<uint64_t> a((size_t)R_ * G_, JG_NO_ACK);  // nothing from anybody
+    std::vector<uint64_t> a((size_t)R_ * G_, JG_NO_ACK);  // nothing from anybody; own slot: zero appends
+    for (uint32_t g = 0; g < G_; g++) a[(size_t)lead_ * G_ + g] = JG_ANSWER(0, JG_HB_NONE);
     check(jg_device_upload(L, answers_, a.data(), a.size() * 8));
   }
   ~DenseCluster() {

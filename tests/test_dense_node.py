@@ -429,3 +429,26 @@ def test_routed_round_argument_checks():
     lib.round_routed(300, None)  # and the cluster carries on
     assert (nodes[0].read("fault") == 0).all()
     lib.close()
+
+
+@pytest.mark.gpu
+def test_cluster_rounds_before_set_appends_append_nothing():
+    """A cluster that is run before jg_dense_cluster_set_appends was ever called appends nothing: the lead
+    node's own-slot column starts as JG_ANSWER(0, JG_HB_NONE) (zero appends), not as JG_NO_ACK - which is
+    outside the own slot's domain and would put JG_FAULT_ENGINE_DENSE_APPENDS on every group it leads."""
+    from josefine_amd import DenseCluster as LibCluster
+    G, R = 2000, 3
+    nodes = [BatchedRaft(G, R, seed=3 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY)
+             for r in range(R)]
+    elect_all(nodes[0])
+    nodes[0].drain_messages(), nodes[0].drain_applies()
+    lib = LibCluster(nodes)
+    lib.rounds(100, 100, 4)
+    lib.round_routed(500)
+    for n in nodes:
+        assert (n.read("fault") == 0).all()
+    assert (nodes[0].read("head") == 0).all() and (nodes[0].read("role") == capi.ROLE_LEADER).all()
+    lib.set_appends(1)
+    lib.rounds(600, 100, 4)
+    assert (nodes[0].read("head") == 4).all() and (nodes[0].read("fault") == 0).all()
+    lib.close()

@@ -97,3 +97,51 @@ def test_prefetch_then_drain_is_the_synchronous_drain():
     b.drain_applies(), b.drain_faults()
     assert view.tobytes() == snap.tobytes()
     assert len(b.drain_messages()) == G * R
+
+
+@pytest.mark.parametrize("D", [1, 3])
+def test_view_while_a_batch_is_in_transfer_repeats_nothing(D):
+    """Take a non-empty view, start a large batch, drain the SAME queue's view again at once (the
+    batch has most likely not landed: nothing new, the first view stays valid), flush, drain: every
+    row is delivered exactly once, in order - on one engine and on a sharded one (the router used to
+    hand the outstanding view's rows back to its queue and deliver them a second time)."""
+    G, R = 60_000, 3
+    kw = dict(seed=9)
+    e = BatchedRaft(G, R, **kw) if D == 1 else BatchedRaft(G, R, device_ids=[0] * D, **kw)
+    ora = oracle_engine(G, R, **kw)
+    for x in (e, ora):
+        elect_all(x)
+        x.drain_messages(), x.drain_applies(), x.drain_faults()
+    want_m, want_f = [], []
+    got_m, got_f = [], []
+
+    def step(now):
+        for x in (e, ora):
+            x.apply_all(Command.ClientRequest(7))
+            x.apply_all(Command.Tick(), now_ms=now)
+        want_m.append(ora.drain_messages())
+        want_f.append(ora.drain_applies())
+
+    step(400)
+    e.drain_flush()                            # pipelined from here on; batch A has landed
+    view_m = e.drain_messages(copy=False)
+    view_f = e.drain_applies(copy=False)
+    snap_m, snap_f = view_m.copy(), view_f.copy()
+    assert len(snap_m) == G * R and len(snap_f) >= G
+    got_m.append(snap_m), got_f.append(snap_f)
+    for k in range(3):                         # a large batch B ...
+        step(900 + 500 * k)
+    e.drain_prefetch()                         # ... in transfer
+    again_m = e.drain_messages(copy=False)     # the same queue, immediately
+    again_f = e.drain_applies(copy=False)
+    got_m.append(again_m.copy()), got_f.append(again_f.copy())
+    if len(again_m) == 0:                      # (not landed yet: the first view must not have moved)
+        assert view_m.tobytes() == snap_m.tobytes()
+    if len(again_f) == 0:
+        assert view_f.tobytes() == snap_f.tobytes()
+    e.drain_flush()
+    got_m.append(e.drain_messages()), got_f.append(e.drain_applies())
+    got_m.append(e.drain_messages()), got_f.append(e.drain_applies())  # and nothing after that
+    for got, want in ((got_m, want_m), (got_f, want_f)):
+        a, b = np.concatenate(got), np.concatenate(want)
+        assert a.shape == b.shape and a.tobytes() == b.tobytes(), (len(a), len(b))

@@ -352,6 +352,36 @@ def test_device_rows_must_be_sorted():
         dev.read("term")
 
 
+def test_device_rows_block_range_is_checked_on_the_device():
+    """A device-resident batch is not validated by the host.  An AppendEntries row whose (id, aux)
+    leaves the block side arrays must not read past them: the row is not applied, and the next
+    synchronising call reports JG_EINVAL - where the reference would have returned Err for a block it
+    cannot read (chain.rs:180-185); host rows are rejected by jg_submit up front."""
+    from josefine_amd import EngineError
+    dev = BatchedRaft(8, 3)
+    blocks = [(1, 0), (2, 1)]
+    ok = dev.upload_rows([capi.CMD_APPEND_ENTRIES], [2], from_=[2], term=[1], id=[0], aux=[2],
+                         blk_id=[b[0] for b in blocks], blk_next=[b[1] for b in blocks])
+    dev.step_device_rows(ok)
+    assert int(dev.read("head")[2]) == 2
+    for forged_id, forged_aux in ((1, 2), (0, 3), (2**63, 2), (0, 2**64 - 1)):
+        dev2 = BatchedRaft(8, 3)
+        rows = dev2.upload_rows([capi.CMD_APPEND_ENTRIES, capi.CMD_TIMEOUT], [2, 5], from_=[2, 0], term=[1, 0], id=[forged_id, 0],
+                                aux=[forged_aux, 0], blk_id=[1, 2], blk_next=[0, 1])
+        dev2.step_device_rows(rows)
+        with pytest.raises(EngineError, match="block range"):
+            dev2.read("head")
+    # no side arrays at all: only an empty AppendEntries is legal
+    dev3 = BatchedRaft(8, 3)
+    rows = dev3.upload_rows([capi.CMD_APPEND_ENTRIES], [1], from_=[2], term=[4], id=[0], aux=[0])
+    dev3.step_device_rows(rows)
+    assert int(dev3.read("term")[1]) == 4
+    rows = dev3.upload_rows([capi.CMD_APPEND_ENTRIES], [1], from_=[2], term=[4], id=[0], aux=[1])
+    dev3.step_device_rows(rows)
+    with pytest.raises(EngineError, match="block range"):
+        dev3._check(dev3.api.sync(dev3._h))
+
+
 def test_abi_contract_on_device():
     """Status codes of the C ABI on the real library: capacity, ranges, validation, ordering."""
     import ctypes as C
