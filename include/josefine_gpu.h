@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JG_ABI_VERSION 3u
+#define JG_ABI_VERSION 4u
 #define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
 #define JG_CHAIN_WINDOW 8u  /* chain segments (gaps / forks) per group besides the main run */
 #define JG_MAX_INFLIGHT 5u  /* src/raft/progress.rs:117                                    */
@@ -66,7 +66,7 @@ enum { JG_ROLE_FOLLOWER = 0, JG_ROLE_CANDIDATE = 1, JG_ROLE_LEADER = 2 };
  *   APPEND_ENTRIES    leader_id     term   first block*  n_blocks   -
  *   APPEND_RESPONSE   node_id       term   head          -          success
  *   HEARTBEAT         leader_id     term   commit        -          -
- *   HEARTBEAT_RESPONSE -            -      commit        -          has_committed
+ *   HEARTBEAT_RESPONSE (sender**)   -      commit        -          has_committed
  *   TIMEOUT           -             -      -             -          -
  *   NOOP              -             -      -             -          -
  *   CLIENT_REQUEST    -             -      request token -          -
@@ -74,6 +74,9 @@ enum { JG_ROLE_FOLLOWER = 0, JG_ROLE_CANDIDATE = 1, JG_ROLE_LEADER = 2 };
  *   RESTART (engine)  -             -      -             -          -
  * (*) index of the first of `aux` consecutive entries in the batch's
  *     blk_id/blk_next side arrays (Vec<Block>, payload stays on the host).
+ * (**) the reference's handler does not look at the sender (leader.rs:222-231) and neither does
+ *     jg_step; jg_step_node needs Message.from (rpc.rs:17-27) to put the response into the
+ *     sender's mailbox slot (0 or a non-member: the row takes the general path).
  * RESTART is not a reference Command: it restates process restart, i.e.
  * `Raft::<Follower>::new` + `Chain::new` on the persisted tree
  * (src/raft/follower.rs:68-95, src/raft/chain.rs:117-137), and clears the fault.
@@ -407,6 +410,55 @@ int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* i
  * AppendResponse / HeartbeatResponse go to the outbox columns and no FSM rows are queued. */
 int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in,
                            const jg_follower_outbox* out, int tick);
+
+/* ---- a node's whole tick from host rows: the dense kernels behind the Apply surface ---------------
+ * What server::event_loop (src/raft/server.rs:103-165) does between two ticks of its interval, for
+ * every partition this node hosts at once: apply whatever tcp_rx / client_rx delivered (jg_submit:
+ * rows in ANY order, no sorting on the host), then Command::Tick.  The rows are uploaded as they are
+ * and classified on the device.  A partition whose rows all fit the mailbox vocabulary -
+ *     at most one AppendResponse and one HeartbeatResponse per member slot (heads < JG_MAILBOX_NONE),
+ *     at most one ClientRequest, and only if this node leads the partition,
+ *     at most one Heartbeat and one AppendEntries, from the same sender with the same term, the
+ *     AppendEntries' blocks a run (ids consecutive, each block's parent its predecessor, <= 254 blocks)
+ * - is served in column form by the dense node tick (jg_step_dense_leader / _follower: the HBM-bound
+ * kernels), in the order those define: HeartbeatResponses (ascending slot), the ClientRequest,
+ * AppendResponses (ascending slot), the leader's Tick; then Heartbeat, AppendEntries, the follower's
+ * Tick.  That is one legal schedule of the reference's event loop: messages of one peer keep their
+ * order (a follower answers the Heartbeat before the AppendEntries of the same Tick, leader.rs:234-245),
+ * and the interleaving of different peers' messages and client requests is the network's.  Every row
+ * of any OTHER partition (votes, Timeout, Restart, explicit Tick rows, duplicates, a ClientRequest at a
+ * non-leader, ...) is applied first, in stream order, by the general state machine exactly as
+ * jg_submit + jg_step would; that partition then takes part in the Tick like everybody else.
+ *
+ * Outputs: rpc_tx - the Tick's Heartbeat / AppendEntries and the followers' answers as the mailbox
+ * columns of jg_node_outbox (pinned host memory, one copy per column), everything else as rows through
+ * jg_drain_messages; fsm_tx - unlike the plain dense entry points, jg_step_node QUEUES the FSM rows of
+ * its dense halves for jg_drain_applies, run-length encoded per partition and step: at most one
+ * JG_FSM_NOTIFY {a = block id, b = the ClientRequest's token} followed by at most one Apply range
+ * (JG_FSM_APPLY_LEADER range(a..=b).skip(1) resp. JG_FSM_APPLY_FOLLOWER range(a..b)) - consecutive
+ * ranges of one tick concatenate exactly (the progress heads only grow).  Faults: jg_drain_faults. */
+enum {
+  JG_NODE_LEADER_HALF = 1u,   /* serve the partitions this node leads (jg_step_dense_leader)            */
+  JG_NODE_FOLLOWER_HALF = 2u, /* serve the partitions it follows (jg_step_dense_follower)              */
+  JG_NODE_TICK = 4u           /* Command::Tick for every partition after its rows (server.rs:125)      */
+};
+typedef struct jg_node_outbox { /* host pointers into the engine's pinned buffers; NULL: that half did not run */
+  const jg_leader_beat* beat;  /* [G]    what a leader's followers read of its Tick (jg_leader_outbox.beat)   */
+  const uint64_t* ae;          /* [R][G] JG_AE(from, n) per addressee slot, JG_NO_ACK: none                    */
+  const uint64_t* answer;      /* [G]    JG_ANSWER(AppendResponse.head, has_committed) to the partition's leader */
+  const uint64_t* hb_commit;   /* [G]    HeartbeatResponse.commit (valid where the answer carries a response)  */
+  uint64_t rows;               /* command rows the step took                                                   */
+  uint64_t rows_general;       /* ... of which went through the general state machine                          */
+  uint64_t bytes_h2d;          /* PCIe: uploaded for this step                                                 */
+  uint64_t bytes_d2h;          /* PCIe: outbox columns downloaded for this step (drains not included)          */
+} jg_node_outbox;
+/* Apply everything queued by jg_submit since the last step as described above (`flags`: JG_NODE_*; at
+ * least one half).  Asynchronous like jg_step except for one synchronisation after the classification
+ * (the number of general-path rows sizes that step's launch). */
+int jg_step_node(jg_engine* e, uint64_t now_ms, uint32_t flags);
+/* The mailbox columns the last jg_step_node produced: waits for them to land; the pointers stay valid
+ * until the next jg_step_node.  On a multi-device engine the columns are the shards' concatenated. */
+int jg_node_outbox_view(jg_engine* e, jg_node_outbox* out);
 
 /* ---- a closed loop of dense node ticks ------------------------------------------------------------
  * All R nodes of every partition in ONE process (one engine per node, e.g. the three brokers of

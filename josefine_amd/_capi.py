@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_REPLICAS = 8
 CHAIN_WINDOW = 8
 MAX_INFLIGHT = 5
@@ -45,6 +45,7 @@ FAULT_ENGINE_DENSE_APPENDS = 132
 FAULT_ENGINE_MAILBOX_RANGE = 133
 
 CFG_SEPARATE_COMMIT_KEY = 1
+NODE_LEADER_HALF, NODE_FOLLOWER_HALF, NODE_TICK = 1, 2, 4
 
 FSM_APPLY_LEADER, FSM_APPLY_FOLLOWER, FSM_NOTIFY = 0, 1, 2
 
@@ -100,6 +101,12 @@ class ShardInfo(C.Structure):
 class RouteStats(C.Structure):
     """jg_route_stats."""
     _fields_ = [("delivered", C.c_uint64 * 8), ("kept", C.c_uint64), ("fsm_rows", C.c_uint64)]
+
+
+class NodeOutbox(C.Structure):
+    """jg_node_outbox."""
+    _fields_ = [("beat", C.c_void_p), ("ae", C.c_void_p), ("answer", C.c_void_p), ("hb_commit", C.c_void_p),
+                ("rows", C.c_uint64), ("rows_general", C.c_uint64), ("bytes_h2d", C.c_uint64), ("bytes_d2h", C.c_uint64)]
 
 
 class CmdBatch(C.Structure):
@@ -205,6 +212,8 @@ class Api:
         "get_counters": (C.c_int, [_P, C.POINTER(C.c_uint64 * 4)]),
         "last_error": (C.c_char_p, []),
         "abi_version": (C.c_uint32, []),
+        "step_node": (C.c_int, [_P, C.c_uint64, C.c_uint32]),
+        "node_outbox_view": (C.c_int, [_P, C.POINTER(NodeOutbox)]),
     }
     # only the device engine has these
     _DEVICE_PROTOS = {
@@ -277,4 +286,5 @@ HEADER_SYMBOLS = [
     "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_drain_prefetch", "jg_drain_flush", "jg_drain_wait", "jg_read_state", "jg_get_counters",
     "jg_device_alloc", "jg_device_free", "jg_device_upload", "jg_device_download",
     "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_dense_cluster_create", "jg_dense_cluster_destroy", "jg_dense_cluster_set_appends", "jg_dense_cluster_rounds", "jg_dense_cluster_mailboxes", "jg_dense_cluster_round_routed", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",
+    "jg_step_node", "jg_node_outbox_view",
 ]

@@ -151,6 +151,8 @@ struct JgLagTick {
   uint64_t w1, head1;  // new packed word, new chain head
   uint32_t nf;         // new flag word
   uint32_t l[R + 1];   // new lags below head1 (field R: commit)
+  uint32_t adv;        // how far the commit index moved (leader.rs:89-92); meaningless when cwide
+  bool cwide;          // the commit index BEFORE the tick was in the wide column (far behind: quorum had been lost)
 };
 
 // element K of v[0..R) sorted ascending
@@ -234,6 +236,8 @@ __device__ __forceinline__ bool jg_lag_tick(uint32_t s, uint32_t f, uint64_t w0,
   o.w1 = w;
   o.head1 = head1;
   o.nf = nf;
+  o.cwide = fc == BEHIND;
+  o.adv = lc - nl;  // (commit_after - commit_before = (head1 - nl) - (head1 - lc))
   dec += n + (uint32_t)__popc(somem);
   return true;
 }
@@ -346,7 +350,13 @@ struct JgLeaderNode {
   jg_leader_beat* o_beat;      // [G]     null: no Tick
   uint64_t* o_ae;              // [R][G]
   uint64_t now;
+  // jg_step_node: what the step pushed on fsm_tx, as one word per group (jg_node.h JGN_FSM_*); null otherwise
+  uint32_t* fsm_delta;         // [G]
+  uint64_t* fsm_prev;          // [G] the commit index before the step where the word says JGN_FSM_WIDE
 };
+#define JG_FSM_APPENDED_BIT (1u << 31)
+#define JG_FSM_WIDE_BIT (1u << 30)
+#define JG_FSM_FOLLOWER_BIT (1u << 29)
 
 // jg_leader_inbox answer word -> AppendResponse head (JG_NO_ACK: none) / HeartbeatResponse code
 __device__ __forceinline__ uint64_t jg_answer_ack(uint64_t w) {
@@ -611,7 +621,7 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
 // DEFER: the host has k_dense_slow scheduled behind this launch: everything that is not served in
 // lag space goes there.  A compile-time switch on purpose: as a run-time flag it cost the hot path
 // of the 1 M x 5 launch 0.5 us (the compiler prepared general-path operands ahead of the branch).
-template <int R, bool UNIFORM, bool NODE, bool DEFER>
+template <int R, bool UNIFORM, bool NODE, bool DEFER, bool FSM = false>
 __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev* dp,
                                                const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us, const JgLeaderNode& nd, bool emit, uint32_t g,
                                                const JgDenseIn<R>& in, JgDecCount& dec, uint64_t (*sm)[JG_BLOCK]) {
@@ -634,10 +644,14 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   // straight-line 32-bit arithmetic, evaluated for every lane; everything else is behind one
   // (normally wave-uniform, not taken) branch
   JgLagTick<R> lt;
+  lt.cwide = false, lt.adv = 0;
   uint32_t dl = 0;
   bool hot = (f & (JGF_FAULT_MASK | JGF_ROLE_MASK | JGF_FAST)) == (JG_ROLE_LEADER | JGF_FAST);
   if (NODE) hot = hot && !hbr_trigger;
   hot = jg_lag_tick<R>(s, f, mword0, head0, n_app, a, lt, dl) && hot;
+  // fsm rows come from the (appended?, commit advance) word: one Notify at most, and a commit index whose old
+  // value is in the packed word - anything else is the general state machine's (k_dense_slow)
+  if (FSM) hot = hot && n_app <= 1 && !lt.cwide;
   // (the node tick counts behind its stores: the counter's atomic would otherwise be one more thing the
   // waits inside the Tick's emission wait for)
   if (!NODE) jg_count_step(h.blk_decisions, dec, hot, dl);
@@ -649,6 +663,10 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
     if (lt.w1 != mword0) h.mlag[g] = lt.w1;
     if (lt.head1 != head0) h.head[g] = lt.head1;
     if (lt.nf != f) h.flags[g] = lt.nf;
+    if (FSM) {  // (a Q9 fault raised by the Tick comes after the appends and acks: their rows stand)
+      const uint32_t w = (n_app ? JG_FSM_APPENDED_BIT : 0u) | lt.adv;
+      if (w) nd.fsm_delta[g] = w;  // (the column was zeroed by the step's prefill)
+    }
     if (NODE) jg_count_step(h.blk_decisions, dec, true, dl);  // (the ballots see the lanes of this branch: the hot ones)
     return;
   }
@@ -678,7 +696,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
 
 // Grid-stride loop over the groups (a software prefetch of the next group's loads measured no gain
 // and cost 13 VGPRs: profiles/README.md).
-template <int R, bool UNIFORM, bool NODE, bool DEFER>
+template <int R, bool UNIFORM, bool NODE, bool DEFER, bool FSM = false>
 __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, const JgDev* dp,
                                                        const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us,
                                                        const JgLeaderNode& nd, uint64_t (*sm)[JG_BLOCK]) {
@@ -689,7 +707,7 @@ __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, co
   for (; g < G; g += stride) {
     JgDenseIn<R> in;
     jg_dense_issue<R, UNIFORM, NODE>(h, dp, acks, us, nd, emit, g, in);
-    jg_dense_group<R, UNIFORM, NODE, DEFER>(h, dp, acks, seq, us, nd, emit, g, in, dec, sm);
+    jg_dense_group<R, UNIFORM, NODE, DEFER, FSM>(h, dp, acks, seq, us, nd, emit, g, in, dec, sm);
   }
   return dec;
 }
@@ -708,14 +726,15 @@ __global__ __launch_bounds__(JG_BLOCK) void k_leader_tick_dense(JgDenseHot h, co
 }
 
 // jg_step_dense_leader: the same tick with HeartbeatResponses in and / or the Tick's outbox out
-template <int R>
+// FSM (jg_step_node): the step's fsm_tx output is left behind as one word per group (nd.fsm_delta)
+template <int R, bool FSM>
 __global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDenseHot h, const JgDev* __restrict__ dp,
                                                                 const uint64_t* __restrict__ acks, uint32_t seq, int us,
                                                                 JgLeaderNode nd) {
   if (nd.clock) nd.now = nd.clock->now, seq = nd.clock->seq[nd.clock_slot];
   JgDecCount dec;
-  if (us >= 0) dec = jg_dense_tick_body<R, true, true, true>(h, dp, acks, seq, (uint32_t)us, nd, nullptr);
-  else dec = jg_dense_tick_body<R, false, true, true>(h, dp, acks, seq, 0, nd, nullptr);
+  if (us >= 0) dec = jg_dense_tick_body<R, true, true, true, FSM>(h, dp, acks, seq, (uint32_t)us, nd, nullptr);
+  else dec = jg_dense_tick_body<R, false, true, true, FSM>(h, dp, acks, seq, 0, nd, nullptr);
   jg_wave_count(h.blk_decisions, dec);
 }
 

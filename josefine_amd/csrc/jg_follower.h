@@ -37,7 +37,20 @@ struct JgFollowerArgs {
   uint32_t tick;
   const JgClock* clock;  // non-null: `now` and `seq` come from here (slot clock_slot): a replayed round
   uint32_t clock_slot, pad_;
+  // jg_step_node: what the step pushed on fsm_tx, one word per group (jg_dense.h JG_FSM_*_BIT); null otherwise
+  uint32_t* fsm_delta;
+  uint64_t* fsm_prev;
 };
+__device__ __forceinline__ void jg_follower_fsm_note(const JgFollowerArgs& a, uint32_t g, uint64_t commit0, uint64_t commit1) {
+  if (!a.fsm_delta || commit1 == commit0) return;  // follower.rs:201-207: one Apply range per Heartbeat that advances
+  const uint64_t adv = commit1 - commit0;
+  if (adv < JG_FSM_FOLLOWER_BIT) {
+    a.fsm_delta[g] = JG_FSM_FOLLOWER_BIT | (uint32_t)adv;
+  } else {
+    a.fsm_prev[g] = commit0;
+    a.fsm_delta[g] = JG_FSM_FOLLOWER_BIT | JG_FSM_WIDE_BIT;
+  }
+}
 
 __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFollowerArgs a) {
   if (a.clock) a.now = a.clock->now, a.seq = a.clock->seq[a.clock_slot];
@@ -151,6 +164,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFol
     if (term != term0) d.term[g] = term;
     if (head != head0) d.head[g] = head;
     if (commit != commit0) d.commit[g] = commit;
+    jg_follower_fsm_note(a, g, commit0, commit);
     if (voted_for != vf0) d.voted_for[g] = voted_for;
     if (leader_id != lid0) d.leader_id[g] = leader_id;
     if (timer_dirty) {
@@ -176,6 +190,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_slow(JgDev d, JgFollowerA
     const bool tick_only = (entry & JG_DEFER_TICK_ONLY) != 0;
     JgLane L;
     jg_load(d, L, g);
+    const uint64_t fsm_commit0 = L.commit;
     L.now = a.now;
     L.seq = a.seq;
     L.mp = L.mend = nullptr;
@@ -226,6 +241,9 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_slow(JgDev d, JgFollowerA
       a.o_answer[g] = JG_ANSWER(L.cap_ack == JG_NO_ACK ? JG_MAILBOX_NONE : L.cap_ack, L.cap_has);
       if (L.cap_has != JG_HB_NONE) a.o_hbc[g] = L.cap_hbc;
     }
+    // (the only fsm_tx output of this half is a follower's Apply range: a candidate or a leader that takes a
+    // Heartbeat does not move its commit index, candidate.rs:137-157, leader.rs:263)
+    jg_follower_fsm_note(a, g, fsm_commit0, L.commit);
     dec += L.decisions;
     jg_store(d, L);
   }

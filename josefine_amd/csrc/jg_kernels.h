@@ -61,6 +61,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
     const uint32_t g = list[i];
     JgLane L;
     jg_load(d, L, g);
+    const uint64_t fsm_head0 = L.head, fsm_commit0 = L.commit;  // (jg_step_node: what this tick pushes on fsm_tx)
     L.now = nd.now;
     L.mp = L.mend = nullptr;
     L.xq_on = d.xq != nullptr;  // plain jg_step_dense_acks: a leader's appends / acks emit no messages
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
         jg_raise(d, L, JG_FAULT_ENGINE_DENSE_APPENDS);
         break;
       }
+      if (NODE && nd.fsm_delta && n_app > 1) *d.err = 1;  // (jg_step_node offers at most one: the word below holds one Notify)
       c.kind = JG_CMD_CLIENT_REQUEST;
       c.flag = 0;
       for (uint64_t k = 0; k < n_app && !jg_fault(L); k++) {
@@ -130,7 +132,10 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
       c.flag = 0;
       c.id = 0;
       if (jg_wcnt(L)) jg_chain_normalize(d, L);
-      const bool fast = L.run_hi == L.head && L.id_gen == L.head + 1 && jg_wcnt(L) == 0 && !(L.flags & JGF_NO_GENESIS);
+      bool fast = L.run_hi == L.head && L.id_gen == L.head + 1 && jg_wcnt(L) == 0 && !(L.flags & JGF_NO_GENESIS);
+      // ... and every AppendEntries word must be able to hold its range start key (a progress head forged
+      // up to 2^56 - 1 or beyond does not fit the 56-bit field): otherwise the Tick travels as rows
+      for (uint32_t r = 0; r < d.R; r++) fast = fast && (r == s || jg_match_get(d, L, r) < JG_MAILBOX_NONE);
       if (!fast) {
         jg_apply(d, L, c, nullptr, nullptr);  // rows: the blocks are not id-consecutive
       } else if (L.head >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words
@@ -152,6 +157,16 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
         }
         nd.o_beat[g] = jg_leader_beat{L.term, hb};
       }
+    }
+    if (NODE && nd.fsm_delta) {
+      // the rows the general state machine pushed on fsm_tx for this tick are Notify (if it appended) and
+      // the Apply ranges of its commit advances, which concatenate: (commit before, commit after]
+      uint32_t w = L.head != fsm_head0 ? JG_FSM_APPENDED_BIT : 0u;
+      if (L.commit != fsm_commit0) {
+        w |= JG_FSM_WIDE_BIT;
+        nd.fsm_prev[g] = fsm_commit0;
+      }
+      nd.fsm_delta[g] = w;
     }
     dec += L.decisions;
     jg_store(d, L);

@@ -254,6 +254,49 @@ int router_step(jg_engine* p, uint64_t now_ms) {
   return rc;
 }
 
+int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags);
+
+// jg_step_node on every shard (each one's rows were bucketed by jg_submit)
+int router_step_node(jg_engine* p, uint64_t now_ms, uint32_t flags) {
+  JgRouter& r = *p->router;
+  for (jg_engine* s : r.sh)
+    if (s->inflight.phase) return fail(JG_EINVAL, "a drain is in transfer: jg_drain_wait first");
+  router_align_seq(p);
+  const int rc = r.run([&](size_t d) { return node_step(r.sh[d], now_ms, flags); });
+  router_after_step(p);
+  p->node.last_flags = flags;
+  return rc;
+}
+// the shards' outbox columns, concatenated into the parent's group numbering
+int router_node_outbox(jg_engine* p, jg_node_outbox* out) {
+  JgRouter& r = *p->router;
+  jg_engine::NodeStep& nd = p->node;
+  if (!nd.last_flags) return fail(JG_EINVAL, "no jg_step_node yet");
+  const size_t G = p->cfg.n_groups, R = p->cfg.n_replicas;
+  *out = jg_node_outbox{};
+  const bool lead = (nd.last_flags & JG_NODE_LEADER_HALF) && (nd.last_flags & JG_NODE_TICK), fol = (nd.last_flags & JG_NODE_FOLLOWER_HALF) != 0;
+  if (lead) nd.cat_beat.resize(G), nd.cat_ae.resize(R * G);
+  if (fol) nd.cat_answer.resize(G), nd.cat_hbc.resize(G);
+  for (size_t d = 0; d < r.D(); d++) {
+    jg_node_outbox o{};
+    const int rc = jg_node_outbox_view(r.sh[d], &o);
+    if (rc) return rc;
+    const size_t lo = r.lo[d], n = r.lo[d + 1] - r.lo[d];
+    if (lead) {
+      std::memcpy(nd.cat_beat.data() + lo, o.beat, n * sizeof(jg_leader_beat));
+      for (size_t q = 0; q < R; q++) std::memcpy(nd.cat_ae.data() + q * G + lo, o.ae + q * n, n * 8);
+    }
+    if (fol) {
+      std::memcpy(nd.cat_answer.data() + lo, o.answer, n * 8);
+      std::memcpy(nd.cat_hbc.data() + lo, o.hb_commit, n * 8);
+    }
+    out->rows += o.rows, out->rows_general += o.rows_general, out->bytes_h2d += o.bytes_h2d, out->bytes_d2h += o.bytes_d2h;
+  }
+  if (lead) out->beat = nd.cat_beat.data(), out->ae = nd.cat_ae.data();
+  if (fol) out->answer = nd.cat_answer.data(), out->hb_commit = nd.cat_hbc.data();
+  return JG_OK;
+}
+
 int router_step_dense_acks_shards(jg_engine* p, const uint64_t* const* acks_dev, uint32_t n_ticks) {
   JgRouter& r = *p->router;
   for (size_t d = 0; d < r.D(); d++)

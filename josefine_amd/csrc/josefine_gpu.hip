@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>  // plain library sort of the drained fault records
+#include <rocprim/device/device_select.hpp>      // jg_step_node's rare path: order-preserving compaction of the general-path rows
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -25,6 +27,7 @@
 #include "jg_kernels.h"
 #include "jg_route.h"
 #include "jg_follower.h"
+#include "jg_node.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -251,6 +254,26 @@ struct jg_engine {
   // take logical time and step number from this device-resident clock instead of their arguments
   const JgClock* replay_clock = nullptr;
   uint32_t replay_slot = 0;
+  // jg_step_node: the inbox / outbox columns of the node step, their pinned host mirrors, rocPRIM scratch
+  struct NodeStep {
+    bool ready = false;
+    JgNodeCols cols{};
+    jg_leader_beat* o_beat = nullptr;  // device outbox
+    uint64_t *o_ae = nullptr, *o_answer = nullptr, *o_hbc = nullptr;
+    jg_leader_beat* h_beat = nullptr;  // pinned mirrors
+    uint64_t *h_ae = nullptr, *h_answer = nullptr, *h_hbc = nullptr;
+    uint32_t* d_nsparse = nullptr;     // {general-path rows, rocprim::select's count}
+    uint32_t* h_nsparse = nullptr;     // pinned
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    uint32_t group_bits = 1;
+    hipEvent_t ev_out = nullptr;
+    jg_node_outbox last{};
+    uint32_t last_flags = 0;
+    // multi-device parent: the shards' columns concatenated
+    std::vector<jg_leader_beat> cat_beat;
+    std::vector<uint64_t> cat_ae, cat_answer, cat_hbc;
+  } node;
   // jg_kernel_timing: HIP event pairs around the dense tick kernel itself (not the slow kernel
   // behind it), a ring of the most recent launches, read after the fact
   static constexpr int KT_RING = 256;
@@ -302,9 +325,14 @@ void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks, const Jg
   } lap(e);
   if (nd) {  // node tick: HeartbeatResponses in, the Tick's outbox out
     // (an absent input column is a stride-0 view of one all-ones word for this kernel: no branch around loads)
-    hipLaunchKernelGGL(k_leader_node_tick<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
-                       jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks ? acks : (const uint64_t*)e->d_ones, e->seq,
-                       e->uniform_self, *nd);
+    if (nd->fsm_delta)  // jg_step_node: the tick leaves its fsm_tx output behind as one word per group
+      hipLaunchKernelGGL((k_leader_node_tick<R, true>), dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
+                         jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks ? acks : (const uint64_t*)e->d_ones, e->seq,
+                         e->uniform_self, *nd);
+    else
+      hipLaunchKernelGGL((k_leader_node_tick<R, false>), dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream,
+                         jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks ? acks : (const uint64_t*)e->d_ones, e->seq,
+                         e->uniform_self, *nd);
   }
   else if (n_ticks > 1)  // temporal fusion: state read once, written once per launch
     hipLaunchKernelGGL(k_leader_tick_dense_n<R>, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, acks,
@@ -489,7 +517,7 @@ int drain_scan(jg_engine* e, const std::vector<StepRec>& recs, hipStream_t st) {
   for (size_t k = 0; k < nrec; k++) {
     const StepRec& r = recs[k];
     const uint32_t nb = (r.n + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
-    e->h_jobs[2 * k] = JgScanJob{r.d_bsum_m, nb, 0};
+    e->h_jobs[2 * k] = JgScanJob{r.d_bsum_m, r.d_bsum_m ? nb : 0u, 0};  // (a node step's record has fsm rows only)
     e->h_jobs[2 * k + 1] = JgScanJob{r.d_bsum_f, nb, 0};
   }
   hipLaunchKernelGGL(k_scan_block_sums, dim3(2 * nrec), dim3(JG_BLOCK), 0, st, (const JgScanJob*)e->h_jobs, e->h_totals);
@@ -1160,6 +1188,10 @@ void jg_engine_destroy(jg_engine* e) {
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->h_jobs) (void)hipHostFree(e->h_jobs);
   if (e->h_totals) (void)hipHostFree(e->h_totals);
+  for (void* p : {(void*)e->node.h_beat, (void*)e->node.h_ae, (void*)e->node.h_answer, (void*)e->node.h_hbc, (void*)e->node.h_nsparse})
+    if (p) (void)hipHostFree(p);
+  if (e->node.tmp) (void)hipFree(e->node.tmp);
+  if (e->node.ev_out) (void)hipEventDestroy(e->node.ev_out);
   e->q_msgs.destroy();
   e->q_fsm.destroy();
   e->l_msgs.destroy();
@@ -1395,17 +1427,10 @@ int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* i
   return dense_step(e, acks, 1, &nd);
 }
 
-int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in, const jg_follower_outbox* out,
-                           int tick) {
-  if (!e || !in || !out) return fail(JG_EINVAL, "null argument");
-  if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
-  if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
-  if (!in->beat || !in->ae) return fail(JG_EINVAL, "every inbox column is required");
-  if (!out->answer || !out->hb_commit) return fail(JG_EINVAL, "every outbox column is required");
-  if (!in->leader && !in->leader_id) return fail(JG_EINVAL, "id cannot be 0");  // config.rs:64-66
-  HIPCHK(hipSetDevice(e->device));
-  int rc = ensure_xq(e);
-  if (rc) return rc;
+namespace {
+// the two launches of a follower half; `fsm_*`: jg_step_node's fsm delta columns (or null)
+int follower_half(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in, const jg_follower_outbox* out, int tick,
+                  uint32_t* fsm_delta, uint64_t* fsm_prev) {
   e->stepped = true;
   e->seq++;
   JgFollowerArgs a{};
@@ -1419,6 +1444,8 @@ int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbo
   a.now = now_ms;
   a.seq = e->seq;
   a.tick = tick ? 1 : 0;
+  a.fsm_delta = fsm_delta;
+  a.fsm_prev = fsm_prev;
   hipLaunchKernelGGL(k_follower_tick_dense, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
   // always scheduled: which groups need the general state machine is only known on the device
   // (empty lists cost a few microseconds)
@@ -1431,6 +1458,260 @@ int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbo
   e->maybe_irregular = true;
   e->flag_check_pending = true;
   e->irr_gen++;
+  return JG_OK;
+}
+}  // namespace
+
+int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in, const jg_follower_outbox* out,
+                           int tick) {
+  if (!e || !in || !out) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
+  if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
+  if (!in->beat || !in->ae) return fail(JG_EINVAL, "every inbox column is required");
+  if (!out->answer || !out->hb_commit) return fail(JG_EINVAL, "every outbox column is required");
+  if (!in->leader && !in->leader_id) return fail(JG_EINVAL, "id cannot be 0");  // config.rs:64-66
+  HIPCHK(hipSetDevice(e->device));
+  int rc = ensure_xq(e);
+  if (rc) return rc;
+  return follower_half(e, now_ms, in, out, tick, nullptr, nullptr);
+}
+
+
+// ---- jg_step_node: a node's whole tick from host rows (jg_node.h) -----------------------------------
+namespace {
+int node_ensure(jg_engine* e) {
+  jg_engine::NodeStep& n = e->node;
+  if (n.ready) return JG_OK;
+  const size_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  int rc = JG_OK;
+#define A(ptr, cnt) \
+  if ((rc = dev_alloc(e, &ptr, (cnt))) != JG_OK) return rc
+  A(n.cols.answers, R * G);
+  A(n.cols.hbr_commit, R * G);
+  A(n.cols.token, G);
+  A(n.cols.f_beat, G);
+  A(n.cols.f_ae, G);
+  A(n.cols.f_leader, G);
+  A(n.cols.cls, G);
+  A(n.cols.lt_max, G);
+  A(n.cols.lt_min, G);
+  A(n.cols.lf_max, G);
+  A(n.cols.lf_min, G);
+  A(n.cols.fsm_delta, G);
+  A(n.cols.fsm_prev, G);
+  A(n.o_beat, G);
+  A(n.o_ae, R * G);
+  A(n.o_answer, G);
+  A(n.o_hbc, G);
+  A(n.d_nsparse, 4);
+#undef A
+  HIPCHK(hipHostMalloc((void**)&n.h_beat, std::max<size_t>(G * sizeof(jg_leader_beat), 16), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&n.h_ae, std::max<size_t>(R * G * 8, 16), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&n.h_answer, std::max<size_t>(G * 8, 16), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&n.h_hbc, std::max<size_t>(G * 8, 16), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&n.h_nsparse, 16, hipHostMallocDefault));
+  HIPCHK(hipEventCreateWithFlags(&n.ev_out, hipEventDisableTiming));
+  while (n.group_bits < 32 && (G - 1) >> n.group_bits) n.group_bits++;
+  n.ready = true;
+  return JG_OK;
+}
+
+int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
+  jg_engine::NodeStep& nd = e->node;
+  const uint32_t halves = flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF);
+  const bool tick = (flags & JG_NODE_TICK) != 0;
+  HIPCHK(hipSetDevice(e->device));
+  int rc = node_ensure(e);
+  if (rc) return rc;
+  if ((rc = ensure_xq(e))) return rc;
+  e->stepped = true;
+  const size_t n = e->p_kind.size(), nb = e->p_blk_id.size();
+  if (n > 0x7fffffffull) return fail(JG_EINVAL, "batch too large: split it");
+  const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  size_t n_hb = 0, n_ae = 0;
+  for (size_t i = 0; i < n; i++) n_hb += e->p_kind[i] == JG_CMD_HEARTBEAT, n_ae += e->p_kind[i] == JG_CMD_APPEND_ENTRIES;
+  const uint32_t both_beats = n_hb && n_ae;
+  const uint32_t ggrid = grid_for(G, 4096);
+  hipLaunchKernelGGL(k_node_prefill, dim3(ggrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, e->uniform_self,
+                     halves & JG_NODE_LEADER_HALF, halves & JG_NODE_FOLLOWER_HALF, both_beats);
+  uint64_t bytes_up = 0;
+  uint32_t n_sparse = 0;
+  if (n) {
+    // one blob, the rows in stream order: 8-byte columns first (16-byte aligned sections)
+    size_t off = 0;
+    auto sect = [&](size_t bytes) {
+      size_t at = off;
+      off = (off + bytes + 15) & ~size_t(15);
+      return at;
+    };
+    const size_t o_term = sect(n * 8), o_id = sect(n * 8), o_aux = sect(n * 8), o_bid = sect(nb * 8), o_bnext = sect(nb * 8),
+                 o_group = sect(n * 4), o_from = sect(n * 4), o_kind = sect(n), o_flag = sect(n);
+    const size_t bytes = off;
+    if (e->stage_busy) {
+      HIPCHK(hipEventSynchronize(e->ev_stage));
+      e->stage_busy = false;
+    }
+    if (e->stage_cap < bytes) {
+      if (e->stage) HIPCHK(hipHostFree(e->stage));
+      e->stage = nullptr;
+      e->stage_cap = std::max(bytes * 2, (size_t)1 << 20);
+      HIPCHK(hipHostMalloc((void**)&e->stage, e->stage_cap, hipHostMallocDefault));
+    }
+    char* S = e->stage;
+    std::memcpy(S + o_term, e->p_term.data(), n * 8);
+    std::memcpy(S + o_id, e->p_id.data(), n * 8);
+    std::memcpy(S + o_aux, e->p_aux.data(), n * 8);
+    std::memcpy(S + o_group, e->p_group.data(), n * 4);
+    std::memcpy(S + o_from, e->p_from.data(), n * 4);
+    std::memcpy(S + o_kind, e->p_kind.data(), n);
+    std::memcpy(S + o_flag, e->p_flag.data(), n);
+    if (nb) {
+      std::memcpy(S + o_bid, e->p_blk_id.data(), nb * 8);
+      std::memcpy(S + o_bnext, e->p_blk_next.data(), nb * 8);
+    }
+    Arena& ar = e->arenas[e->cur_arena];
+    char* B = nullptr;
+    uint8_t* d_keep = nullptr;
+    HIPCHK(ar.alloc(bytes, (void**)&B));
+    HIPCHK(ar.alloc(n, (void**)&d_keep));
+    HIPCHK(hipMemcpyAsync(B, S, bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipEventRecord(e->ev_stage, e->stream));
+    e->stage_busy = true;
+    bytes_up = bytes;
+    JgNodeRows rows{};
+    rows.n = (uint32_t)n;
+    rows.group = (const uint32_t*)(B + o_group), rows.kind = (const uint8_t*)(B + o_kind);
+    rows.from = (const uint32_t*)(B + o_from), rows.term = (const uint64_t*)(B + o_term);
+    rows.id = (const uint64_t*)(B + o_id), rows.aux = (const uint64_t*)(B + o_aux), rows.flag = (const uint8_t*)(B + o_flag);
+    rows.blk_id = (const uint64_t*)(B + o_bid), rows.blk_next = (const uint64_t*)(B + o_bnext), rows.n_blocks = nb;
+    const uint32_t rgrid = grid_for(n, 4096);
+    HIPCHK(hipMemsetAsync(nd.d_nsparse, 0, 8, e->stream));
+    hipLaunchKernelGGL(k_node_classify, dim3(rgrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rows, e->uniform_self,
+                       halves, both_beats);
+    hipLaunchKernelGGL(k_node_route, dim3(rgrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rows, e->uniform_self,
+                       both_beats, d_keep, nd.d_nsparse);
+    HIPCHK(hipGetLastError());
+    e->n_launch += 3;
+    // the one synchronisation of the step: how many rows take the general path sizes that launch
+    HIPCHK(hipMemcpyAsync(nd.h_nsparse, nd.d_nsparse, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->stage_busy = false;
+    n_sparse = nd.h_nsparse[0];
+    if (n_sparse) {
+      // order-preserving compaction of the flagged rows, then a stable sort by group: the batch k_apply_rows takes
+      uint32_t *idx = nullptr, *idx2 = nullptr, *keys = nullptr, *keys2 = nullptr;
+      HIPCHK(ar.alloc((size_t)n * 4, (void**)&idx));
+      HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&idx2));
+      HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&keys));
+      HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&keys2));
+      size_t need_a = 0, need_b = 0;
+      rocprim::counting_iterator<uint32_t> iota(0);
+      HIPCHK(rocprim::select(nullptr, need_a, iota, d_keep, idx, nd.d_nsparse + 1, n, e->stream));
+      HIPCHK(rocprim::radix_sort_pairs(nullptr, need_b, keys, keys2, idx, idx2, (size_t)n_sparse, 0, nd.group_bits, e->stream));
+      const size_t need = std::max(need_a, need_b);
+      if (nd.tmp_bytes < need) {
+        if (nd.tmp) HIPCHK(hipFree(nd.tmp));
+        nd.tmp_bytes = 2 * need;
+        HIPCHK(hipMalloc(&nd.tmp, nd.tmp_bytes));
+      }
+      size_t tb = nd.tmp_bytes;
+      HIPCHK(rocprim::select(nd.tmp, tb, iota, d_keep, idx, nd.d_nsparse + 1, n, e->stream));
+      const uint32_t sgrid = (n_sparse + JG_BLOCK - 1) / JG_BLOCK;
+      hipLaunchKernelGGL(k_node_keys, dim3(sgrid), dim3(JG_BLOCK), 0, e->stream, n_sparse, (const uint32_t*)idx, rows.group, keys);
+      tb = nd.tmp_bytes;
+      HIPCHK(rocprim::radix_sort_pairs(nd.tmp, tb, keys, keys2, idx, idx2, (size_t)n_sparse, 0, nd.group_bits, e->stream));
+      JgNodeSorted so{};
+      char* M = nullptr;
+      const size_t ns = n_sparse;
+      HIPCHK(ar.alloc(ns * 34 + 64, (void**)&M));  // 3 x 8 + 2 x 4 + 2 x 1 bytes per row, widest columns first
+      so.term = (uint64_t*)M, M += ns * 8;
+      so.id = (uint64_t*)M, M += ns * 8;
+      so.aux = (uint64_t*)M, M += ns * 8;
+      so.group = (uint32_t*)M, M += ns * 4;
+      so.from = (uint32_t*)M, M += ns * 4;
+      so.kind = (uint8_t*)M, M += ns;
+      so.flag = (uint8_t*)M;
+      hipLaunchKernelGGL(k_node_gather_rows, dim3(sgrid), dim3(JG_BLOCK), 0, e->stream, n_sparse, (const uint32_t*)idx2, rows, so);
+      HIPCHK(hipGetLastError());
+      e->n_launch += 4;
+      e->seq++;
+      if ((rc = launch_rows(e, n_sparse, so.group, so.kind, so.from, so.term, so.id, so.aux, so.flag,
+                            nb ? rows.blk_id : (const uint64_t*)e->d_ones, nb ? rows.blk_next : (const uint64_t*)e->d_ones, nb, now_ms)))
+        return rc;
+    }
+    e->p_kind.clear(), e->p_flag.clear(), e->p_group.clear(), e->p_from.clear(), e->p_term.clear(), e->p_id.clear();
+    e->p_aux.clear(), e->p_blk_id.clear(), e->p_blk_next.clear();
+  }
+  // the dense halves: every partition, the ones whose rows went the general way included (they are ticked here)
+  uint64_t bytes_down = 0;
+  if (halves & JG_NODE_LEADER_HALF) {
+    JgLeaderNode ln{};
+    ln.hbr_commit = nd.cols.hbr_commit;
+    ln.packed = 1;
+    ln.ack_stride = 1;
+    if (tick) ln.o_beat = nd.o_beat, ln.o_ae = nd.o_ae;
+    ln.now = now_ms;
+    ln.fsm_delta = nd.cols.fsm_delta, ln.fsm_prev = nd.cols.fsm_prev;
+    if ((rc = dense_step(e, nd.cols.answers, 1, &ln))) return rc;
+    if (tick) {
+      HIPCHK(hipMemcpyAsync(nd.h_beat, nd.o_beat, (size_t)G * sizeof(jg_leader_beat), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(nd.h_ae, nd.o_ae, (size_t)R * G * 8, hipMemcpyDeviceToHost, e->stream));
+      bytes_down += (size_t)G * (sizeof(jg_leader_beat) + (size_t)R * 8);
+    }
+  }
+  if (halves & JG_NODE_FOLLOWER_HALF) {
+    jg_follower_inbox fi{};
+    fi.leader = nd.cols.f_leader, fi.beat = nd.cols.f_beat, fi.ae = nd.cols.f_ae;
+    const jg_follower_outbox fo{nd.o_answer, nd.o_hbc};
+    if ((rc = follower_half(e, now_ms, &fi, &fo, tick ? 1 : 0, nd.cols.fsm_delta, nd.cols.fsm_prev))) return rc;
+    HIPCHK(hipMemcpyAsync(nd.h_answer, nd.o_answer, (size_t)G * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(nd.h_hbc, nd.o_hbc, (size_t)G * 8, hipMemcpyDeviceToHost, e->stream));
+    bytes_down += (size_t)G * 16;
+  }
+  {  // fsm_tx rows of the dense halves -> a step record of its own (per-group regions; compacted by the drains)
+    StepRec rec;
+    rec.n = G;
+    rec.seq = e->seq;
+    rec.msg_per_row = 0;
+    rec.fsm_per_row = 2;
+    Arena& ar = e->arenas[e->cur_arena];
+    const uint32_t n_tiles = (G + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
+    HIPCHK(ar.alloc((size_t)G * 4, (void**)&rec.d_fsm_cnt));
+    HIPCHK(ar.alloc((size_t)G * 2 * sizeof(jg_fsm_row), (void**)&rec.d_fsm));
+    HIPCHK(ar.alloc((size_t)n_tiles * 8, (void**)&rec.d_bsum_f));
+    hipLaunchKernelGGL(k_node_fsm_build, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rec.d_fsm, rec.d_fsm_cnt,
+                       rec.d_bsum_f);
+    HIPCHK(hipGetLastError());
+    e->n_launch++;
+    e->recs.push_back(rec);
+  }
+  HIPCHK(hipEventRecord(nd.ev_out, e->stream));
+  nd.last = jg_node_outbox{};
+  nd.last.rows = n, nd.last.rows_general = n_sparse, nd.last.bytes_h2d = bytes_up, nd.last.bytes_d2h = bytes_down;
+  nd.last_flags = flags;
+  return JG_OK;
+}
+}  // namespace
+
+int jg_step_node(jg_engine* e, uint64_t now_ms, uint32_t flags) {
+  if (!e) return fail(JG_EINVAL, "null argument");
+  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~7u))
+    return fail(JG_EINVAL, "jg_step_node: flags = JG_NODE_LEADER_HALF and / or JG_NODE_FOLLOWER_HALF [| JG_NODE_TICK]");
+  if (e->router) return router_step_node(e, now_ms, flags);
+  if (e->inflight.phase) return fail(JG_EINVAL, "a drain is in transfer: jg_drain_wait first");
+  return node_step(e, now_ms, flags);
+}
+
+int jg_node_outbox_view(jg_engine* e, jg_node_outbox* out) {
+  if (!e || !out) return fail(JG_EINVAL, "null argument");
+  if (e->router) return router_node_outbox(e, out);
+  jg_engine::NodeStep& nd = e->node;
+  if (!nd.ready || !nd.last_flags) return fail(JG_EINVAL, "no jg_step_node yet");
+  int rc = sync_and_check(e);  // (the columns have landed; device-side error flags surface here)
+  if (rc) return rc;
+  *out = nd.last;
+  if ((nd.last_flags & JG_NODE_LEADER_HALF) && (nd.last_flags & JG_NODE_TICK)) out->beat = nd.h_beat, out->ae = nd.h_ae;
+  if (nd.last_flags & JG_NODE_FOLLOWER_HALF) out->answer = nd.h_answer, out->hb_commit = nd.h_hbc;
   return JG_OK;
 }
 
@@ -1802,7 +2083,7 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
       jg_engine* e = c->nodes[s];
       const JgRouteTable t = table(s);
       for (const StepRec& r : e->recs)
-        if (r.seq > seq_base[s])
+        if (r.seq > seq_base[s] && r.d_msg)
           hipLaunchKernelGGL(k_route_rec, dim3((r.n + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS)), dim3(JG_BLOCK), 0, st, t, r.n, r.msg_per_row,
                              r.seq - seq_base[s], (const uint32_t*)r.d_msg_cnt, (const jg_msg_row*)r.d_msg, (const uint32_t*)r.d_fsm_cnt);
       hipLaunchKernelGGL(k_route_xq<false>, dim3(1024), dim3(JG_BLOCK), 0, st, t, (const JgXqRec*)e->dev.xq, (const uint32_t*)e->dev.xq_n,

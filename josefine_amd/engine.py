@@ -272,6 +272,34 @@ class BatchedRaft:
         assert a.shape == (self.R, self.G), a.shape
         self._check(self.api.step_dense_acks(self._h, a.ctypes.data))
 
+    def step_node(self, now_ms: int = 0, leader: bool = True, follower: bool = True, tick: bool = True) -> dict:
+        """jg_step_node: a node's whole tick from the rows submitted since the last step - rows in the
+        mailbox vocabulary through the dense kernels, everything else through the general state
+        machine first - then Command::Tick for every partition.  Returns the outbox columns (host
+        copies): beat_term / beat_commit [G], ae [R, G] words, answer / hb_commit [G], and the step's
+        row / PCIe byte counts."""
+        self._flush_pending()
+        flags = (capi.NODE_LEADER_HALF if leader else 0) | (capi.NODE_FOLLOWER_HALF if follower else 0) | \
+                (capi.NODE_TICK if tick else 0)
+        self._check(self.api.step_node(self._h, int(now_ms), flags))
+        o = capi.NodeOutbox()
+        self._check(self.api.node_outbox_view(self._h, C.byref(o)))
+        G, R = self.G, self.R
+
+        def arr(p, dt, shape):
+            if not p:
+                return None
+            n = int(np.prod(shape))
+            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(p)
+            return np.frombuffer(buf, dtype=dt).reshape(shape).copy()
+
+        beat = arr(o.beat, np.dtype([("term", "<u8"), ("hb_commit", "<u8")]), (G,))
+        return {"beat_term": None if beat is None else beat["term"].copy(),
+                "beat_commit": None if beat is None else beat["hb_commit"].copy(),
+                "ae": arr(o.ae, np.uint64, (R, G)), "answer": arr(o.answer, np.uint64, (G,)),
+                "hb_commit": arr(o.hb_commit, np.uint64, (G,)), "rows": int(o.rows), "rows_general": int(o.rows_general),
+                "bytes_h2d": int(o.bytes_h2d), "bytes_d2h": int(o.bytes_d2h)}
+
     def upload_rows(self, kind, group, from_=None, term=None, id=None, aux=None, flag=None,
                     blk_id=None, blk_next=None) -> "DeviceRows":
         """Sort a command batch by group (stable) on the host and park it in device memory for

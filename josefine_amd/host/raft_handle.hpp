@@ -413,7 +413,6 @@ class DenseCluster {
 // hipGraph), and - round_routed - with the library's device-side transport for everything outside the
 // mailbox vocabulary: the votes of an election travel between the nodes' engines without a host in
 // between (the in-process stand-in for rpc_tx -> tcp.rs -> the peer's event_loop, server.rs:127-137).
-#ifndef JG_TEST_AGAINST_ORACLE
 class LibraryCluster {
  public:
   LibraryCluster(const std::vector<jg_engine*>& nodes, uint32_t lead) : R_((uint32_t)nodes.size()) {
@@ -438,7 +437,6 @@ class LibraryCluster {
   uint32_t R_;
   jg_dense_cluster* c_ = nullptr;
 };
-#endif
 
 // ---- fsm::Driver and server::event_loop for many partitions ---------------------------------------
 // The two tasks on either side of Raft<T> in a josefine process, batched over every partition the

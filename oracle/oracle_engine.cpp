@@ -30,6 +30,15 @@ struct jo_engine {
   std::vector<jg_compact_row> compacted;
   uint64_t counters[4] = {0, 0, 0, 0};
   unsigned threads = 1;
+  // jo_step_node: the step's inbox / outbox columns (host vectors) and what jo_node_outbox_view reports
+  std::vector<uint64_t> n_answers, n_hbr, n_token, n_f_ae, n_o_ae, n_o_answer, n_o_hbc;
+  std::vector<jg_leader_beat> n_f_beat, n_o_beat;
+  std::vector<uint32_t> n_f_leader;
+  std::vector<jg_fsm_row> n_fsm;  // fsm rows of the dense halves of the step in progress
+  bool node_keep_fsm = false;
+  const uint64_t* node_tokens = nullptr;
+  jg_node_outbox n_last{};
+  uint32_t n_last_flags = 0;
 };
 
 static thread_local std::string g_err;
@@ -273,6 +282,27 @@ static void note_fault(jo_engine* e, uint32_t g, int before) {
   if (r.fault && r.fault != before) e->faults.push_back(jg_fault_row{g, (uint32_t)r.fault});
 }
 
+// jo_step_node: the fsm_tx rows a group pushed during a dense half, run-length encoded the way
+// include/josefine_gpu.h specifies for that entry point: consecutive Apply ranges of one kind
+// ([a,b] then [b,c]) are one range [a,c] (leader.rs:93 / follower.rs:204 ranges concatenate exactly).
+static void node_take_fsm(jo_engine* e, uint32_t g) {
+  Raft& r = e->groups[g];
+  size_t first = e->n_fsm.size();
+  for (const FsmRow& f : r.fsm) {
+    if (f.kind != JG_FSM_NOTIFY && e->n_fsm.size() > first) {
+      jg_fsm_row& last = e->n_fsm.back();
+      if (last.kind == f.kind && last.b == f.a) {
+        last.b = f.b;
+        continue;
+      }
+    }
+    jg_fsm_row row;
+    std::memset(&row, 0, sizeof row);
+    row.group = g, row.kind = f.kind, row.a = f.a, row.b = f.b;
+    e->n_fsm.push_back(row);
+  }
+}
+
 int jo_step_dense_leader(jo_engine* e, uint64_t now_ms, const jg_leader_inbox* in, const jg_leader_outbox* out) {
   e->stepped = true;
   const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
@@ -320,6 +350,7 @@ int jo_step_dense_leader(jo_engine* e, uint64_t now_ms, const jg_leader_inbox* i
     // 2. appends, then acks in ascending slot order
     c = Cmd();
     c.kind = JG_CMD_CLIENT_REQUEST;
+    if (e->node_tokens) c.id = e->node_tokens[g];  // (jo_step_node: the request's token, Notify.id)
     for (uint64_t i = 0; i < n_append && !r.fault; i++) {
       r.apply(c, now_ms);
       e->counters[0]++;
@@ -336,10 +367,16 @@ int jo_step_dense_leader(jo_engine* e, uint64_t now_ms, const jg_leader_inbox* i
       e->counters[0]++;
     }
     r.rpc.clear();
+    if (e->node_keep_fsm) node_take_fsm(e, g);  // jo_step_node queues them
     r.fsm.clear();  // dense steps report deltas, not rows
     // 3. Tick: columns if the chain is in run form built by append only, rows otherwise
     if (out && !r.fault) {
-      const bool columns = r.chain.run_form_by_append();
+      // columns stand for a Tick only when every AppendEntries word can hold its range start key: a
+      // progress head at or above 2^56 - 1 (a forged AppendResponse: heads only grow, progress.rs:133-140)
+      // does not fit the 56-bit field, so that leader's Tick travels as rows
+      bool columns = r.chain.run_form_by_append();
+      for (const auto& kv : r.progress.progress)
+        if (kv.first != r.id && kv.second.head >= JG_MAILBOX_NONE) columns = false;
       if (columns && r.chain.head >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words: loud, never wrong
         r.fault = JG_FAULT_ENGINE_MAILBOX_RANGE;
         note_fault(e, g, fault0);
@@ -426,6 +463,7 @@ int jo_step_dense_follower(jo_engine* e, uint64_t now_ms, const jg_follower_inbo
     }
     out->answer[g] = JG_ANSWER(o_ack, o_has);
     r.rpc.clear();
+    if (e->node_keep_fsm) node_take_fsm(e, g);
     r.fsm.clear();
     note_fault(e, g, fault0);
     e->counters[1] += r.decisions;
@@ -600,6 +638,167 @@ int jo_synth_fill_acks(jo_engine* e, uint32_t mode, uint64_t tick, uint64_t* sim
       }
     }
   }
+  return JG_OK;
+}
+
+// ---- jo_step_node: the specification of jg_step_node, restated over host vectors -------------------
+// Classify the queued rows per partition exactly as include/josefine_gpu.h words it, apply the rows
+// of the partitions that do not fit the mailbox vocabulary through jo_step (stream order), build the
+// inbox columns from the others, then run the two dense halves (which apply the commands the columns
+// stand for one by one through Raft::apply) and queue their fsm rows.
+int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
+  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~7u)) return fail(JG_EINVAL, "jg_step_node: bad flags");
+  e->stepped = true;
+  const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  const bool lead_half = flags & JG_NODE_LEADER_HALF, fol_half = flags & JG_NODE_FOLLOWER_HALF, tick = flags & JG_NODE_TICK;
+  e->n_answers.assign((size_t)R * G, JG_NO_ACK);
+  e->n_hbr.assign((size_t)R * G, 0);
+  e->n_token.assign(G, 0);
+  e->n_f_beat.assign(G, jg_leader_beat{0, JG_NO_ACK});
+  e->n_f_ae.assign(G, JG_NO_ACK);
+  e->n_f_leader.assign(G, 0);
+  for (uint32_t g = 0; g < G; g++) e->n_answers[(size_t)e->self_slot[g] * G + g] = JG_ANSWER(0, JG_HB_NONE);
+  // pass 1: which mailbox entries each partition's rows fill; what cannot be a column
+  struct Cls {
+    uint32_t seen = 0;  // bits 0-7 AppendResponse per slot, 8-15 HeartbeatResponse per slot, 16 Heartbeat, 17 AppendEntries, 18 ClientRequest
+    bool general = false;
+    uint64_t hb_term = 0, ae_term = 0;
+    uint32_t hb_from = 0, ae_from = 0;
+  };
+  std::vector<Cls> cls(G);
+  uint64_t n_rows = 0, n_general = 0;
+  std::sort(e->touched.begin(), e->touched.end());
+  auto run_of = [](const Cmd& c, uint64_t* from) {  // AppendEntries blocks = the run (from, from + n]?
+    const size_t n = c.blocks.size();
+    if (n > 0xfe) return false;
+    if (n == 0) {
+      *from = 0;
+      return true;
+    }
+    const uint64_t id0 = c.blocks[0].id;
+    if (id0 == 0 || id0 - 1 + n >= JG_MAILBOX_NONE) return false;
+    for (size_t k = 0; k < n; k++)
+      if (c.blocks[k].id != id0 + k || c.blocks[k].next != id0 + k - 1) return false;
+    *from = id0 - 1;
+    return true;
+  };
+  for (uint32_t g : e->touched) {
+    Cls& k = cls[g];
+    const Raft& r = e->groups[g];
+    for (const Cmd& c : e->pending[g]) {
+      n_rows++;
+      uint32_t bit = 0;
+      bool general = false;
+      switch (c.kind) {
+        case JG_CMD_APPEND_RESPONSE:
+        case JG_CMD_HEARTBEAT_RESPONSE: {
+          const int s = slot_of_id(e, c.from);
+          general = !lead_half || s < 0 || (uint32_t)s == e->self_slot[g] || (c.kind == JG_CMD_APPEND_RESPONSE && c.id >= JG_MAILBOX_NONE);
+          if (s >= 0) bit = 1u << ((c.kind == JG_CMD_APPEND_RESPONSE ? 0 : 8) + s);
+          break;
+        }
+        case JG_CMD_CLIENT_REQUEST:
+          general = !lead_half || r.role != JG_ROLE_LEADER;
+          bit = 1u << 18;
+          break;
+        case JG_CMD_HEARTBEAT:
+          general = !fol_half || c.id == JG_NO_ACK || c.from == 0;
+          bit = 1u << 16;
+          k.hb_term = c.term, k.hb_from = c.from;
+          break;
+        case JG_CMD_APPEND_ENTRIES: {
+          uint64_t from;
+          general = !fol_half || c.from == 0 || !run_of(c, &from);
+          bit = 1u << 17;
+          k.ae_term = c.term, k.ae_from = c.from;
+          break;
+        }
+        default: general = true;
+      }
+      if (general || (k.seen & bit)) k.general = true;  // outside the vocabulary / a second row for one mailbox entry
+      k.seen |= bit;
+    }
+    if ((k.seen & (3u << 16)) == (3u << 16) && (k.hb_term != k.ae_term || k.hb_from != k.ae_from)) k.general = true;
+  }
+  // pass 2: column-form partitions fill the inbox; the others keep their rows for jo_step
+  std::vector<uint32_t> still;
+  for (uint32_t g : e->touched) {
+    if (cls[g].general) {
+      n_general += e->pending[g].size();
+      still.push_back(g);
+      continue;
+    }
+    for (const Cmd& c : e->pending[g]) {
+      switch (c.kind) {
+        case JG_CMD_APPEND_RESPONSE: {
+          uint64_t& w = e->n_answers[(size_t)slot_of_id(e, c.from) * G + g];
+          w = (c.id << 8) | (w & 0xffu);
+          break;
+        }
+        case JG_CMD_HEARTBEAT_RESPONSE: {
+          const size_t at = (size_t)slot_of_id(e, c.from) * G + g;
+          e->n_answers[at] = (e->n_answers[at] & ~0xffull) | (c.flag ? 1u : 0u);
+          if (!c.flag) e->n_hbr[at] = c.id;
+          break;
+        }
+        case JG_CMD_CLIENT_REQUEST:
+          e->n_answers[(size_t)e->self_slot[g] * G + g] = JG_ANSWER(1, JG_HB_NONE);
+          e->n_token[g] = c.id;
+          break;
+        case JG_CMD_HEARTBEAT:
+          e->n_f_beat[g] = jg_leader_beat{c.term, c.id};
+          e->n_f_leader[g] = c.from;
+          break;
+        default: {  // AppendEntries
+          uint64_t from = 0;
+          (void)run_of(c, &from);
+          e->n_f_ae[g] = JG_AE(from, c.blocks.size());
+          e->n_f_beat[g].term = c.term;
+          e->n_f_leader[g] = c.from;
+        }
+      }
+      e->counters[0]++;
+    }
+    e->pending[g].clear();
+  }
+  e->touched.swap(still);
+  int rc = jo_step(e, now_ms);  // the general path, first
+  if (rc) return rc;
+  e->n_fsm.clear();
+  e->node_keep_fsm = true;
+  e->node_tokens = e->n_token.data();
+  e->n_o_beat.assign(G, jg_leader_beat{0, JG_NO_ACK});
+  e->n_o_ae.assign((size_t)R * G, JG_NO_ACK);
+  e->n_o_answer.assign(G, JG_NO_ACK);
+  e->n_o_hbc.assign(G, 0);
+  if (lead_half) {
+    const jg_leader_inbox in{e->n_answers.data(), e->n_hbr.data()};
+    const jg_leader_outbox out{e->n_o_beat.data(), e->n_o_ae.data()};
+    rc = jo_step_dense_leader(e, now_ms, &in, tick ? &out : nullptr);
+  }
+  if (!rc && fol_half) {
+    jg_follower_inbox in{};
+    in.leader = e->n_f_leader.data(), in.beat = e->n_f_beat.data(), in.ae = e->n_f_ae.data();
+    const jg_follower_outbox out{e->n_o_answer.data(), e->n_o_hbc.data()};
+    rc = jo_step_dense_follower(e, now_ms, &in, &out, tick ? 1 : 0);
+  }
+  e->node_keep_fsm = false;
+  e->node_tokens = nullptr;
+  // the dense halves' fsm rows of one step: partitions ascending (at most one half emits for a partition)
+  std::stable_sort(e->n_fsm.begin(), e->n_fsm.end(), [](const jg_fsm_row& a, const jg_fsm_row& b) { return a.group < b.group; });
+  e->fsms.insert(e->fsms.end(), e->n_fsm.begin(), e->n_fsm.end());
+  e->n_fsm.clear();
+  e->n_last = jg_node_outbox{};
+  e->n_last.rows = n_rows, e->n_last.rows_general = n_general;
+  e->n_last_flags = flags;
+  return rc;
+}
+
+int jo_node_outbox_view(jo_engine* e, jg_node_outbox* out) {
+  if (!e->n_last_flags) return fail(JG_EINVAL, "no jg_step_node yet");
+  *out = e->n_last;
+  if ((e->n_last_flags & JG_NODE_LEADER_HALF) && (e->n_last_flags & JG_NODE_TICK)) out->beat = e->n_o_beat.data(), out->ae = e->n_o_ae.data();
+  if (e->n_last_flags & JG_NODE_FOLLOWER_HALF) out->answer = e->n_o_answer.data(), out->hb_commit = e->n_o_hbc.data();
   return JG_OK;
 }
 

@@ -1,0 +1,204 @@
+"""jg_step_node — a node's whole tick from host rows, the dense kernels behind the Apply surface
+(server::event_loop for many partitions: src/raft/server.rs:103-165).
+
+Two links of one chain:
+  1. (CPU) the oracle's restatement of the entry point (jo_step_node: classification, inbox columns,
+     the two dense halves applying what the columns stand for one command at a time) is
+     indistinguishable from PLAIN Apply::apply in the canonical order the header defines - state,
+     faults, fsm rows (run-length decoded), and every message, columns and rows alike;
+  2. (GPU) the HIP engine's jg_step_node is bit-identical to the oracle's: every state column, every
+     drained row, every outbox word, tick after tick, on mixed leader / follower / candidate
+     populations with traffic that exercises every reason to leave the column path.
+"""
+import numpy as np
+import pytest
+
+from josefine_amd import BatchedRaft, capi
+from node_step import classify, columns_as_rows, compare_outboxes, elect_some, node_traffic, plain_apply_equivalent
+from oracle_lib import oracle_engine
+from parity import compare_drains, compare_snapshots
+
+
+def msg_tuples(rows, drop_from=True):
+    out = []
+    for r in rows:
+        term = None if int(r["kind"]) == capi.CMD_APPEND_RESPONSE else int(r["term"])
+        out.append((int(r["group"]), int(r["kind"]), int(r["to_kind"]), int(r["to_id"]), int(r["flag"]), term, int(r["id"]), int(r["aux"])))
+    return out
+
+
+def coalesce_fsm(rows):
+    """[a,b] + [b,c] of one partition and kind -> [a,c] (what jg_step_node's run-length encoding does)."""
+    out = []
+    for r in rows:
+        t = (int(r["group"]), int(r["kind"]), int(r["a"]), int(r["b"]))
+        if out and t[1] != capi.FSM_NOTIFY and out[-1][0] == t[0] and out[-1][1] == t[1] and out[-1][3] == t[2]:
+            out[-1] = (t[0], t[1], out[-1][2], t[3])
+        else:
+            out.append(t)
+    return out
+
+
+def mixed_pair(make_a, make_b, G, R, seed, lead_frac=0.6, **kw):
+    a, b = make_a(G, R, seed=seed, **kw), make_b(G, R, seed=seed, **kw)
+    rng = np.random.default_rng(seed)
+    mask = rng.random(G) < lead_frac
+    for e in (a, b):
+        elect_some(e, mask)
+        e.drain_messages(), e.drain_applies(), e.drain_faults()
+    return a, b, rng
+
+
+@pytest.mark.parametrize("R,flags", [(3, 0), (5, 0), (5, capi.CFG_SEPARATE_COMMIT_KEY), (4, 0), (1, 0)])
+def test_oracle_node_step_is_plain_apply_in_canonical_order(R, flags):
+    G, T = 400, 40
+    node, plain, rng = mixed_pair(oracle_engine, oracle_engine, G, R, seed=11 + R, flags=flags,
+                                  election_timeout_ms=(700, 1500))
+    ids = np.array(node.node_ids)
+    dense_rows = general_rows = 0
+    for t in range(T):
+        now = 100 * (t + 1)
+        cols = node_traffic(rng, node, token0=1000 * t)
+        slots, role0 = node.read("self_slot"), node.read("role")
+        node.submit_columns(**cols)
+        out = node.step_node(now)
+        general = plain_apply_equivalent(plain, cols, now)
+        assert np.array_equal(general, classify(cols, role0, slots, node.node_ids))
+        assert out["rows"] == len(cols["kind"]) and out["rows_general"] == int(general[cols["group"]].sum())
+        dense_rows += out["rows"] - out["rows_general"]
+        general_rows += out["rows_general"]
+        compare_snapshots(node, plain, f"tick {t}")
+        fa, fb = node.drain_faults(), plain.drain_faults()
+        assert sorted(map(tuple, fa.tolist())) == sorted(map(tuple, fb.tolist())), t
+        assert [tuple(int(x) for x in (r["group"], r["kind"], r["a"], r["b"])) for r in node.drain_applies()] == \
+            [tuple(int(x) for x in (r["group"], r["kind"], r["a"], r["b"])) for r in plain.plain_fsm_general] + \
+            coalesce_fsm(plain.drain_applies()), t
+        # messages: the node step's rows + what its columns stand for == the plain path's rows
+        leader_of = np.zeros(G, np.int64)
+        for i in range(len(cols["kind"])):
+            if cols["kind"][i] in (capi.CMD_HEARTBEAT, capi.CMD_APPEND_ENTRIES) and not general[cols["group"][i]]:
+                leader_of[cols["group"][i]] = cols["from_"][i]
+        got = msg_tuples(node.drain_messages()) + columns_as_rows(out, ids, slots, leader_of)
+        want = msg_tuples(plain.drain_messages())
+        assert sorted(got, key=repr) == sorted(want, key=repr), t
+    assert dense_rows > 5 * general_rows > 0  # the traffic is mostly steady state, and the general path was exercised
+
+
+def fsm_equal_per_partition(a_rows, b_rows):
+    """fsm rows of one step: per partition the same rows in the same order (b run-length decoded like a)."""
+    def per(rows):
+        d = {}
+        for t in rows:
+            d.setdefault(t[0], []).append(t)
+        return d
+    a = [tuple(int(x) for x in (r["group"], r["kind"], r["a"], r["b"])) for r in a_rows]
+    pa, pb = per(a), per(coalesce_fsm(b_rows))
+    return {g: coalesce_fsm_tuples(v) for g, v in pa.items()} == {g: coalesce_fsm_tuples(v) for g, v in pb.items()}
+
+
+def coalesce_fsm_tuples(rows):
+    out = []
+    for t in rows:
+        if out and t[1] != capi.FSM_NOTIFY and out[-1][1] == t[1] and out[-1][3] == t[2]:
+            out[-1] = (t[0], t[1], out[-1][2], t[3])
+        else:
+            out.append(t)
+    return out
+
+
+@pytest.mark.parametrize("R", [3, 5])
+def test_oracle_node_step_fsm_rows_decode_to_the_plain_paths(R):
+    """The fsm_tx side of link 1, strictly: per partition and tick the node step's rows are the
+    plain path's, run-length encoded (Notify first, then ONE Apply range)."""
+    G, T = 300, 60
+    node, plain, rng = mixed_pair(oracle_engine, oracle_engine, G, R, seed=5 + R, flags=capi.CFG_SEPARATE_COMMIT_KEY,
+                                  election_timeout_ms=(700, 1500))
+    n_notify = n_apply = 0
+    for t in range(T):
+        now = 100 * (t + 1)
+        cols = node_traffic(rng, node, token0=1000 * t, p_noise=0.02)
+        node.submit_columns(**cols)
+        node.step_node(now)
+        plain_apply_equivalent(plain, cols, now)
+        a, b = node.drain_applies(), np.concatenate([plain.plain_fsm_general, plain.drain_applies()])
+        assert fsm_equal_per_partition(a, b), t
+        n_notify += int((a["kind"] == capi.FSM_NOTIFY).sum())
+        n_apply += int((a["kind"] != capi.FSM_NOTIFY).sum())
+        node.drain_messages(), plain.drain_messages(), node.drain_faults(), plain.drain_faults()
+    assert n_notify > G and n_apply > G  # commits did advance: the rows are not vacuous
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,flags,G", [(3, 0, 3000), (5, capi.CFG_SEPARATE_COMMIT_KEY, 3000), (5, 0, 700), (4, 0, 500), (2, 0, 300), (1, 0, 200)])
+def test_node_step_parity(R, flags, G):
+    T = 60
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=21 + R, flags=flags, election_timeout_ms=(700, 1500))
+    dense_rows = general_rows = 0
+    for t in range(T):
+        now = 100 * (t + 1)
+        cols = node_traffic(rng, ora, token0=1000 * t)
+        outs = []
+        for e in (dev, ora):
+            e.submit_columns(**cols)
+            outs.append(e.step_node(now))
+        compare_outboxes(outs[0], outs[1], f"tick {t}")
+        compare_snapshots(dev, ora, f"tick {t}")
+        compare_drains(dev, ora, f"tick {t}")
+        dense_rows += outs[1]["rows"] - outs[1]["rows_general"]
+        general_rows += outs[1]["rows_general"]
+    assert dense_rows > 5 * general_rows > 0
+    assert dev.counters()["decisions"] == ora.counters()["decisions"]
+    assert outs[0]["bytes_h2d"] > 0 and outs[0]["bytes_d2h"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("leader,follower,tick", [(True, False, True), (False, True, True), (True, True, False)])
+def test_node_step_halves_and_no_tick(leader, follower, tick):
+    G, R = 1500, 3
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=77, election_timeout_ms=(700, 1500))
+    for t in range(30):
+        now = 100 * (t + 1)
+        cols = node_traffic(rng, ora, token0=1000 * t)
+        outs = []
+        for e in (dev, ora):
+            e.submit_columns(**cols)
+            outs.append(e.step_node(now, leader=leader, follower=follower, tick=tick))
+        compare_outboxes(outs[0], outs[1], f"tick {t}")
+        compare_snapshots(dev, ora, f"tick {t}")
+        compare_drains(dev, ora, f"tick {t}")
+
+
+@pytest.mark.gpu
+def test_node_step_mixed_with_the_other_entry_points_and_multi_device():
+    """Node steps interleaved with plain steps and dense ack ticks; and the same through ONE handle
+    over three shards (aliased onto the one GPU): rows bucketed by owner, columns concatenated."""
+    G, R = 2000, 3
+    ora = oracle_engine(G, R, seed=3, election_timeout_ms=(700, 1500))
+    devs = [BatchedRaft(G, R, seed=3, election_timeout_ms=(700, 1500)),
+            BatchedRaft(G, R, seed=3, election_timeout_ms=(700, 1500), device_ids=[0, 0, 0])]
+    rng = np.random.default_rng(8)
+    mask = rng.random(G) < 0.5
+    for e in [ora] + devs:
+        elect_some(e, mask)
+        e.drain_messages(), e.drain_applies(), e.drain_faults()
+    for t in range(24):
+        now = 100 * (t + 1)
+        cols = node_traffic(rng, ora, token0=1000 * t)
+        want = None
+        for e in [ora] + devs:
+            e.submit_columns(**cols)
+            out = e.step_node(now)
+            if t % 4 == 3:  # a plain step in between
+                e.apply_all(__import__("josefine_amd").Command.Tick(), now_ms=now + 1)
+            if want is None:
+                want = out
+            else:
+                compare_outboxes(out, want, f"tick {t}")
+        for d in devs:
+            compare_snapshots(d, ora, f"tick {t}")
+        if t % 3 == 2:  # rows of several steps drained at once
+            a = [ora.drain_messages(), ora.drain_applies(), ora.drain_faults()]
+            for d in devs:
+                b = [d.drain_messages(), d.drain_applies(), d.drain_faults()]
+                for x, y in zip(a, b):
+                    assert x.tobytes() == y.tobytes(), t
