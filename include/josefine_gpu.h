@@ -288,6 +288,30 @@ int jg_set_self_slots(jg_engine* e, const uint8_t* slots /* [G] host */);
  * queued by earlier jg_submit calls. */
 int jg_submit(jg_engine* e, const jg_cmd_batch* batch);
 
+/* Zero-copy jg_submit for a caller that produces rows itself (a transport's receive task decoding
+ * straight into the engine's pinned columns, src/raft/tcp.rs:139-170 -> server.rs:126-137): room for n
+ * more rows and n_blocks side-array entries at the tail of the pending batch; the caller fills kind,
+ * group, id and whichever optional columns it needs in place (an AppendEntries row's id indexes THIS
+ * reservation's side-array entries) and commits how many it wrote, and which optional columns
+ * (JG_COL_*): a column not named is all zeros for these rows and costs nothing - jg_step_node does not
+ * even upload a column that no submit of the step provided.  jg_submit_commit checks what jg_submit
+ * checks.  The pointers are good until the next jg_submit* or step call.  Single-device engines (or a
+ * shard's own handle). */
+typedef struct jg_cmd_cols {
+  uint8_t* kind;
+  uint32_t* group;
+  uint32_t* from;
+  uint64_t* term;
+  uint64_t* id;
+  uint64_t* aux;
+  uint8_t* flag;
+  uint64_t* blk_id;
+  uint64_t* blk_next;
+} jg_cmd_cols;
+enum { JG_COL_FROM = 1u, JG_COL_TERM = 2u, JG_COL_AUX = 4u, JG_COL_FLAG = 8u };
+int jg_submit_reserve(jg_engine* e, size_t n, size_t n_blocks, jg_cmd_cols* cols);
+int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_columns);
+
 /* Apply everything queued since the last step: for each group, `apply(cmd)` in
  * stream order (src/raft/mod.rs:471-479).  `now_ms` is the logical clock that
  * replaces Instant::now() (mod.rs:352-357, follower.rs:110-113, leader.rs:78-84).

@@ -109,6 +109,14 @@ class NodeOutbox(C.Structure):
                 ("rows", C.c_uint64), ("rows_general", C.c_uint64), ("bytes_h2d", C.c_uint64), ("bytes_d2h", C.c_uint64)]
 
 
+class CmdCols(C.Structure):
+    """jg_cmd_cols."""
+    _fields_ = [(k, C.c_void_p) for k in ("kind", "group", "from_", "term", "id", "aux", "flag", "blk_id", "blk_next")]
+
+
+COL_FROM, COL_TERM, COL_AUX, COL_FLAG = 1, 2, 4, 8
+
+
 class CmdBatch(C.Structure):
     _fields_ = [
         ("n", C.c_size_t),
@@ -238,6 +246,8 @@ class Api:
         "timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
         "synth_fill_acks_device": (C.c_int, [_P, C.c_uint32, C.c_uint64, _P, _P]),
         "calibrate_stream": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_float)]),
+        "submit_reserve": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(CmdCols)]),
+        "submit_commit": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_uint32]),
         "dense_cluster_create": (C.c_int, [C.POINTER(_P), C.c_uint32, C.c_uint32, C.POINTER(_P)]),
         "dense_cluster_destroy": (None, [_P]),
         "dense_cluster_set_appends": (C.c_int, [_P, C.c_uint64, _P]),
@@ -286,5 +296,5 @@ HEADER_SYMBOLS = [
     "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_drain_prefetch", "jg_drain_flush", "jg_drain_wait", "jg_read_state", "jg_get_counters",
     "jg_device_alloc", "jg_device_free", "jg_device_upload", "jg_device_download",
     "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_dense_cluster_create", "jg_dense_cluster_destroy", "jg_dense_cluster_set_appends", "jg_dense_cluster_rounds", "jg_dense_cluster_mailboxes", "jg_dense_cluster_round_routed", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",
-    "jg_step_node", "jg_node_outbox_view",
+    "jg_step_node", "jg_node_outbox_view", "jg_submit_reserve", "jg_submit_commit",
 ]

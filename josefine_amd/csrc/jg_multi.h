@@ -237,8 +237,10 @@ int router_submit(jg_engine* p, const jg_cmd_batch* b) {
     if (k.kind.empty()) continue;
     jg_cmd_batch s{};
     s.n = k.kind.size();
-    s.kind = k.kind.data(), s.group = k.group.data(), s.from = k.from.data(), s.term = k.term.data();
-    s.id = k.id.data(), s.aux = k.aux.data(), s.flag = k.flag.data();
+    s.kind = k.kind.data(), s.group = k.group.data(), s.id = k.id.data();
+    // (a column the caller did not provide stays absent: the shard's node step does not upload it)
+    s.from = b->from ? k.from.data() : nullptr, s.term = b->term ? k.term.data() : nullptr;
+    s.aux = (b->aux || b->n_blocks) ? k.aux.data() : nullptr, s.flag = b->flag ? k.flag.data() : nullptr;
     s.n_blocks = k.blk_id.size(), s.blk_id = k.blk_id.data(), s.blk_next = k.blk_next.data();
     rc = jg_submit(r.sh[d], &s);  // (copies into the shard's pending columns)
     if (rc) return rc;

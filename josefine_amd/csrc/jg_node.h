@@ -63,7 +63,7 @@ struct JgNodeRows {  // the step's command rows in device memory, unsorted (stre
   uint32_t n;
   const uint32_t* group;
   const uint8_t* kind;
-  const uint32_t* from;
+  const uint32_t* from;  // null: all zeros (as are term, aux, flag)
   const uint64_t* term;
   const uint64_t* id;
   const uint64_t* aux;
@@ -71,6 +71,10 @@ struct JgNodeRows {  // the step's command rows in device memory, unsorted (stre
   const uint64_t* blk_id;
   const uint64_t* blk_next;
   uint64_t n_blocks;
+  __device__ __forceinline__ uint32_t from_of(uint32_t i) const { return from ? from[i] : 0u; }
+  __device__ __forceinline__ uint64_t term_of(uint32_t i) const { return term ? term[i] : 0ull; }
+  __device__ __forceinline__ uint64_t aux_of(uint32_t i) const { return aux ? aux[i] : 0ull; }
+  __device__ __forceinline__ uint32_t flag_of(uint32_t i) const { return flag ? flag[i] : 0u; }
 };
 
 __global__ __launch_bounds__(JG_BLOCK) void k_node_prefill(JgDev d, JgNodeCols c, int us, uint32_t leader_half,
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_classify(JgDev d, JgNodeCols 
       case JG_CMD_HEARTBEAT_RESPONSE: {
         const uint32_t f = d.flags[g];
         const uint32_t self = us >= 0 ? (uint32_t)us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
-        const int s = jg_node_slot_of(d, a.from[i]);
+        const int s = jg_node_slot_of(d, a.from_of(i));
         // a sender outside the membership (progress.rs:43 panics on it), the own id (the own slot of the
         // inbox block carries the number of appends), a head a mailbox word cannot hold: general path
         sparse = !(halves & 1u) || s < 0 || (uint32_t)s == self ||
@@ -148,12 +152,12 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_classify(JgDev d, JgNodeCols 
         break;
       }
       case JG_CMD_HEARTBEAT:
-        sparse = !(halves & 2u) || a.id[i] == JG_NO_ACK || a.from[i] == 0;  // (JG_NO_ACK in the beat means "no heartbeat")
+        sparse = !(halves & 2u) || a.id[i] == JG_NO_ACK || a.from_of(i) == 0;  // (JG_NO_ACK in the beat means "no heartbeat")
         bit = JGN_HB;
         break;
       case JG_CMD_APPEND_ENTRIES: {
         uint64_t from;
-        sparse = !(halves & 2u) || a.from[i] == 0 || !jg_node_ae_run(a, a.id[i], a.aux[i], &from);
+        sparse = !(halves & 2u) || a.from_of(i) == 0 || !jg_node_ae_run(a, a.id[i], a.aux_of(i), &from);
         bit = JGN_AE;
         break;
       }
@@ -161,10 +165,10 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_classify(JgDev d, JgNodeCols 
     }
     if (both_beats && (kind == JG_CMD_HEARTBEAT || kind == JG_CMD_APPEND_ENTRIES)) {
       // one beat word carries the term and the sender of both: they must agree (decided in k_node_route)
-      atomicMax((unsigned long long*)&c.lt_max[g], (unsigned long long)a.term[i]);
-      atomicMin((unsigned long long*)&c.lt_min[g], (unsigned long long)a.term[i]);
-      atomicMax(&c.lf_max[g], a.from[i]);
-      atomicMin(&c.lf_min[g], a.from[i]);
+      atomicMax((unsigned long long*)&c.lt_max[g], (unsigned long long)a.term_of(i));
+      atomicMin((unsigned long long*)&c.lt_min[g], (unsigned long long)a.term_of(i));
+      atomicMax(&c.lf_max[g], a.from_of(i));
+      atomicMin(&c.lf_min[g], a.from_of(i));
     }
     const uint32_t old = atomicOr(&c.cls[g], bit | (sparse ? JGN_SPARSE : 0u));
     if ((old & bit) && !sparse) atomicOr(&c.cls[g], JGN_SPARSE);  // a second row for the same mailbox entry
@@ -198,14 +202,14 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
     const uint32_t kind = a.kind[i];
     switch (kind) {
       case JG_CMD_APPEND_RESPONSE: {  // bits 63..8 of the sender's answer word (all ones before)
-        const int s = jg_node_slot_of(d, a.from[i]);
+        const int s = jg_node_slot_of(d, a.from_of(i));
         (void)__hip_atomic_fetch_and(&c.answers[(size_t)s * G + g], (a.id[i] << 8) | 0xffull, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
       case JG_CMD_HEARTBEAT_RESPONSE: {  // low byte of the same word
-        const int s = jg_node_slot_of(d, a.from[i]);
-        const uint64_t has = a.flag[i] ? 1 : 0;
+        const int s = jg_node_slot_of(d, a.from_of(i));
+        const uint64_t has = a.flag_of(i) ? 1 : 0;
         (void)__hip_atomic_fetch_and(&c.answers[(size_t)s * G + g], ~0xffull | has, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
         if (!has) c.hbr_commit[(size_t)s * G + g] = a.id[i];
@@ -218,16 +222,16 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
         break;
       }
       case JG_CMD_HEARTBEAT:
-        c.f_beat[g] = jg_leader_beat{a.term[i], a.id[i]};
-        c.f_leader[g] = a.from[i];
+        c.f_beat[g] = jg_leader_beat{a.term_of(i), a.id[i]};
+        c.f_leader[g] = a.from_of(i);
         break;
       default: {  // JG_CMD_APPEND_ENTRIES
         uint64_t from = 0;
-        (void)jg_node_ae_run(a, a.id[i], a.aux[i], &from);
-        c.f_ae[g] = JG_AE(from, a.aux[i]);
+        (void)jg_node_ae_run(a, a.id[i], a.aux_of(i), &from);
+        c.f_ae[g] = JG_AE(from, a.aux_of(i));
         if (!(w & JGN_HB)) {  // (with a Heartbeat in the batch: the same term and sender, written by its row)
-          c.f_beat[g].term = a.term[i];
-          c.f_leader[g] = a.from[i];
+          c.f_beat[g].term = a.term_of(i);
+          c.f_leader[g] = a.from_of(i);
         }
       }
     }
@@ -257,11 +261,11 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_gather_rows(uint32_t n, const
   const uint32_t i = order[p];
   o.group[p] = a.group[i];
   o.kind[p] = a.kind[i];
-  o.from[p] = a.from[i];
-  o.term[p] = a.term[i];
+  o.from[p] = a.from_of(i);
+  o.term[p] = a.term_of(i);
   o.id[p] = a.id[i];
-  o.aux[p] = a.aux[i];
-  o.flag[p] = a.flag[i];
+  o.aux[p] = a.aux_of(i);
+  o.flag[p] = a.flag_of(i);
 }
 __global__ __launch_bounds__(JG_BLOCK) void k_node_keys(uint32_t n, const uint32_t* __restrict__ idx,
                                                         const uint32_t* __restrict__ group, uint32_t* __restrict__ keys) {

@@ -133,6 +133,47 @@ struct PinnedQueue {
   }
 };
 
+// A column of the commands queued by jg_submit, in pinned host memory: jg_step_node uploads it as it is
+// (no staging copy), and jg_submit_reserve hands its tail out for the caller to fill in place.
+template <typename T>
+struct PinnedVec {
+  T* p = nullptr;
+  size_t n = 0, cap = 0;
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  void clear() { n = 0; }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  hipError_t reserve(size_t want) {
+    if (want <= cap) return hipSuccess;
+    const size_t ncap = std::max<size_t>(want + want / 2, 4096);
+    T* q = nullptr;
+    hipError_t e = hipHostMalloc((void**)&q, ncap * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (n) std::memcpy(q, p, n * sizeof(T));
+    if (p) (void)hipHostFree(p);
+    p = q;
+    cap = ncap;
+    return hipSuccess;
+  }
+  // append src[0..k) (or k zeros)
+  hipError_t append(const T* src, size_t k) {
+    hipError_t e = reserve(n + k);
+    if (e != hipSuccess) return e;
+    if (src) std::memcpy(p + n, src, k * sizeof(T));
+    else std::memset(p + n, 0, k * sizeof(T));
+    n += k;
+    return hipSuccess;
+  }
+  void destroy() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = cap = 0;
+  }
+};
+
 // A run of queued output rows that came out of one step (multi-device merge: jg_multi.h).
 struct JgSeg {
   uint32_t seq;
@@ -163,9 +204,12 @@ struct jg_engine {
   uint64_t* d_acks_staging = nullptr;  // [R][G] for the host-buffer dense entry point
   uint64_t* d_ones = nullptr;  // one all-ones word: the stride-0 stand-in for an absent ack block / HeartbeatResponse column
   // commands queued by jg_submit (host SoA)
-  std::vector<uint8_t> p_kind, p_flag;
-  std::vector<uint32_t> p_group, p_from;
-  std::vector<uint64_t> p_term, p_id, p_aux, p_blk_id, p_blk_next;
+  PinnedVec<uint8_t> p_kind, p_flag;
+  PinnedVec<uint32_t> p_group, p_from;
+  PinnedVec<uint64_t> p_term, p_id, p_aux, p_blk_id, p_blk_next;
+  // which optional columns some jg_submit since the last step actually provided (an absent column is
+  // all zeros: jg_step_node does not upload it)
+  bool p_has_from = false, p_has_term = false, p_has_aux = false, p_has_flag = false;
   // pinned staging for the upload of one step (reused; guarded by ev_stage)
   char* stage = nullptr;
   size_t stage_cap = 0;
@@ -903,18 +947,61 @@ int drain_view(jg_engine* e, PinnedQueue<Row>& q, int mask, const Row** rows, si
   return JG_OK;
 }
 
+// The optional columns (from, term, aux, flag) of rows [at, at + n) of the pending batch: copied where the
+// caller provided one, zero-filled LAZILY otherwise - a column nobody provides between two steps is never
+// written (jg_step_node then does not upload it either); the first submit that does provide it zero-fills
+// the rows queued before it, and from then on absent columns are zero-filled as they come.
+template <typename T>
+hipError_t pending_col(PinnedVec<T>& v, bool& has, size_t at, size_t n, const T* src) {
+  hipError_t e = v.reserve(at + n);
+  if (e != hipSuccess) return e;
+  if (src) {
+    if (!has && at) std::memset(v.p, 0, at * sizeof(T));
+    has = true;
+    std::memcpy(v.p + at, src, n * sizeof(T));
+  } else if (has) {
+    std::memset(v.p + at, 0, n * sizeof(T));
+  }
+  v.n = at + n;
+  return hipSuccess;
+}
+int pending_optional(jg_engine* e, size_t at, size_t n, const uint32_t* from, const uint64_t* term, const uint64_t* aux,
+                     const uint8_t* flag) {
+  HIPCHK(pending_col(e->p_from, e->p_has_from, at, n, from));
+  HIPCHK(pending_col(e->p_term, e->p_has_term, at, n, term));
+  HIPCHK(pending_col(e->p_aux, e->p_has_aux, at, n, aux));
+  HIPCHK(pending_col(e->p_flag, e->p_has_flag, at, n, flag));
+  return JG_OK;
+}
+// every optional column materialised (the general step gathers all seven)
+void pending_materialise(jg_engine* e) {
+  const size_t n = e->p_kind.size();
+  if (!e->p_has_from && n) std::memset(e->p_from.p, 0, n * 4);
+  if (!e->p_has_term && n) std::memset(e->p_term.p, 0, n * 8);
+  if (!e->p_has_aux && n) std::memset(e->p_aux.p, 0, n * 8);
+  if (!e->p_has_flag && n) std::memset(e->p_flag.p, 0, n);
+  e->p_has_from = e->p_has_term = e->p_has_aux = e->p_has_flag = true;
+}
+
 // jg_submit's argument checks (shared with the multi-device router)
 int validate_batch(uint32_t n_groups, const jg_cmd_batch* b) {
   if (b->n && (!b->kind || !b->group)) return fail(JG_EINVAL, "kind/group columns are required");
   if (b->n_blocks && (!b->blk_id || !b->blk_next)) return fail(JG_EINVAL, "block side arrays are required");
+  // (two branch-free passes the compiler vectorises - a batch is millions of rows per tick through
+  // jg_step_node - and the per-row checks only where an AppendEntries row is present)
+  uint32_t bad_group = 0, bad_kind = 0, has_ae = 0;
+  for (size_t i = 0; i < b->n; i++) bad_group |= b->group[i] >= n_groups;
   for (size_t i = 0; i < b->n; i++) {
-    if (b->group[i] >= n_groups) return fail(JG_EINVAL, "group out of range");
-    if (b->kind[i] >= JG_CMD__COUNT) return fail(JG_EINVAL, "unknown command kind");
-    if (b->kind[i] == JG_CMD_APPEND_ENTRIES) {
-      if (!b->id || !b->aux) return fail(JG_EINVAL, "AppendEntries needs id/aux columns");
-      if (b->aux[i] > b->n_blocks || b->id[i] > b->n_blocks - b->aux[i])  // (overflow-safe)
+    bad_kind |= b->kind[i] >= JG_CMD__COUNT;
+    has_ae |= b->kind[i] == JG_CMD_APPEND_ENTRIES;
+  }
+  if (bad_group) return fail(JG_EINVAL, "group out of range");
+  if (bad_kind) return fail(JG_EINVAL, "unknown command kind");
+  if (has_ae) {
+    if (!b->id || !b->aux) return fail(JG_EINVAL, "AppendEntries needs id/aux columns");
+    for (size_t i = 0; i < b->n; i++)
+      if (b->kind[i] == JG_CMD_APPEND_ENTRIES && (b->aux[i] > b->n_blocks || b->id[i] > b->n_blocks - b->aux[i]))  // (overflow-safe)
         return fail(JG_EINVAL, "block side-array range out of bounds");
-    }
   }
   return JG_OK;
 }
@@ -930,8 +1017,7 @@ size_t field_width(int field) {
 }
 
 // Stable LSD radix sort of row indices by group id: per-group stream order = row order.
-void sort_rows_by_group(const std::vector<uint32_t>& group, uint32_t n_groups, std::vector<uint32_t>& order) {
-  const size_t n = group.size();
+void sort_rows_by_group(const uint32_t* group, size_t n, uint32_t n_groups, std::vector<uint32_t>& order) {
   order.resize(n);
   std::iota(order.begin(), order.end(), 0u);
   bool sorted = true;
@@ -1188,6 +1274,8 @@ void jg_engine_destroy(jg_engine* e) {
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->h_jobs) (void)hipHostFree(e->h_jobs);
   if (e->h_totals) (void)hipHostFree(e->h_totals);
+  e->p_kind.destroy(), e->p_flag.destroy(), e->p_group.destroy(), e->p_from.destroy(), e->p_term.destroy();
+  e->p_id.destroy(), e->p_aux.destroy(), e->p_blk_id.destroy(), e->p_blk_next.destroy();
   for (void* p : {(void*)e->node.h_beat, (void*)e->node.h_ae, (void*)e->node.h_answer, (void*)e->node.h_hbc, (void*)e->node.h_nsparse})
     if (p) (void)hipHostFree(p);
   if (e->node.tmp) (void)hipFree(e->node.tmp);
@@ -1251,24 +1339,77 @@ int jg_submit(jg_engine* e, const jg_cmd_batch* b) {
   }
   const size_t at = e->p_kind.size(), n = b->n;
   const uint64_t blk_shift = e->p_blk_id.size();
-  auto put = [&](auto& vec, auto* src) {
-    if (src) vec.insert(vec.end(), src, src + n);
-    else vec.resize(at + n, 0);
-  };
-  put(e->p_kind, b->kind);
-  put(e->p_group, b->group);
-  put(e->p_from, b->from);
-  put(e->p_term, b->term);
-  put(e->p_id, b->id);
-  put(e->p_aux, b->aux);
-  put(e->p_flag, b->flag);
-  if (blk_shift)  // side arrays of successive submits are concatenated
+  HIPCHK(e->p_kind.append(b->kind, n));
+  HIPCHK(e->p_group.append(b->group, n));
+  HIPCHK(e->p_id.append(b->id, n));
+  {
+    const int rc = pending_optional(e, at, n, b->from, b->term, b->aux, b->flag);
+    if (rc) return rc;
+  }
+  if (blk_shift && b->n_blocks)  // side arrays of successive submits are concatenated
     for (size_t i = 0; i < n; i++)
       if (b->kind[i] == JG_CMD_APPEND_ENTRIES) e->p_id[at + i] += blk_shift;
   if (b->n_blocks) {
-    e->p_blk_id.insert(e->p_blk_id.end(), b->blk_id, b->blk_id + b->n_blocks);
-    e->p_blk_next.insert(e->p_blk_next.end(), b->blk_next, b->blk_next + b->n_blocks);
+    HIPCHK(e->p_blk_id.append(b->blk_id, b->n_blocks));
+    HIPCHK(e->p_blk_next.append(b->blk_next, b->n_blocks));
   }
+  return JG_OK;
+}
+
+int jg_submit_reserve(jg_engine* e, size_t n, size_t n_blocks, jg_cmd_cols* cols) {
+  if (!e || !cols) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "jg_submit_reserve: the columns are per shard: call this on a shard handle (jg_get_shard)");
+  const size_t at = e->p_kind.size(), bat = e->p_blk_id.size();
+  HIPCHK(e->p_kind.reserve(at + n));
+  HIPCHK(e->p_group.reserve(at + n));
+  HIPCHK(e->p_from.reserve(at + n));
+  HIPCHK(e->p_term.reserve(at + n));
+  HIPCHK(e->p_id.reserve(at + n));
+  HIPCHK(e->p_aux.reserve(at + n));
+  HIPCHK(e->p_flag.reserve(at + n));
+  HIPCHK(e->p_blk_id.reserve(bat + n_blocks));
+  HIPCHK(e->p_blk_next.reserve(bat + n_blocks));
+  cols->kind = e->p_kind.p + at, cols->group = e->p_group.p + at, cols->from = e->p_from.p + at, cols->term = e->p_term.p + at;
+  cols->id = e->p_id.p + at, cols->aux = e->p_aux.p + at, cols->flag = e->p_flag.p + at;
+  cols->blk_id = e->p_blk_id.p + bat, cols->blk_next = e->p_blk_next.p + bat;
+  return JG_OK;
+}
+
+int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_columns) {
+  if (!e) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "jg_submit_commit: the columns are per shard: call this on a shard handle (jg_get_shard)");
+  if (optional_columns & ~15u) return fail(JG_EINVAL, "unknown column bit");
+  const size_t at = e->p_kind.size(), bat = e->p_blk_id.size();
+  if (at + n > e->p_kind.cap || at + n > e->p_group.cap || at + n > e->p_id.cap || bat + n_blocks > e->p_blk_id.cap)
+    return fail(JG_EINVAL, "jg_submit_commit: more rows than jg_submit_reserve made room for");
+  jg_cmd_batch b{};  // what was written in place, as a batch: the same checks as jg_submit
+  b.n = n, b.kind = e->p_kind.p + at, b.group = e->p_group.p + at, b.id = e->p_id.p + at, b.aux = e->p_aux.p + at;
+  b.n_blocks = n_blocks, b.blk_id = e->p_blk_id.p + bat, b.blk_next = e->p_blk_next.p + bat;
+  if (!(optional_columns & JG_COL_AUX))
+    for (size_t i = 0; i < n; i++)
+      if (b.kind[i] == JG_CMD_APPEND_ENTRIES) return fail(JG_EINVAL, "AppendEntries needs id/aux columns");
+  int rc = validate_batch(e->cfg.n_groups, &b);
+  if (rc) return rc;
+  e->p_kind.n = e->p_group.n = e->p_id.n = at + n;
+  // an optional column the caller filled is adopted where it lies (src == its own place: no copy)
+  auto adopt = [&](auto& v, bool& has, bool given) {
+    using T = typename std::remove_reference<decltype(*v.p)>::type;
+    if (given) {
+      if (!has && at) std::memset(v.p, 0, at * sizeof(T));
+      has = true;
+    } else if (has) {
+      std::memset(v.p + at, 0, n * sizeof(T));
+    }
+    v.n = at + n;
+  };
+  adopt(e->p_from, e->p_has_from, (optional_columns & JG_COL_FROM) != 0);
+  adopt(e->p_term, e->p_has_term, (optional_columns & JG_COL_TERM) != 0);
+  adopt(e->p_aux, e->p_has_aux, (optional_columns & JG_COL_AUX) != 0);
+  adopt(e->p_flag, e->p_has_flag, (optional_columns & JG_COL_FLAG) != 0);
+  if (bat && n_blocks)
+    for (size_t i = 0; i < n; i++)
+      if (b.kind[i] == JG_CMD_APPEND_ENTRIES) e->p_id[at + i] += bat;
+  e->p_blk_id.n = e->p_blk_next.n = bat + n_blocks;
   return JG_OK;
 }
 
@@ -1281,8 +1422,9 @@ int jg_step(jg_engine* e, uint64_t now_ms) {
   if (n > 0x7fffffffull) return fail(JG_EINVAL, "batch too large: split it");
   HIPCHK(hipSetDevice(e->device));
   e->seq++;
+  pending_materialise(e);
   std::vector<uint32_t> order;
-  sort_rows_by_group(e->p_group, e->cfg.n_groups, order);
+  sort_rows_by_group(e->p_group.data(), n, e->cfg.n_groups, order);
   const size_t nb = e->p_blk_id.size();
 
   // one blob: 8-byte columns first, then 4-byte, then 1-byte (16-byte aligned sections)
@@ -1343,6 +1485,7 @@ int jg_step(jg_engine* e, uint64_t now_ms) {
   e->p_aux.clear();
   e->p_blk_id.clear();
   e->p_blk_next.clear();
+  e->p_has_from = e->p_has_term = e->p_has_aux = e->p_has_flag = false;
   return JG_OK;
 }
 
@@ -1537,52 +1680,47 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   uint64_t bytes_up = 0;
   uint32_t n_sparse = 0;
   if (n) {
-    // one blob, the rows in stream order: 8-byte columns first (16-byte aligned sections)
+    // the rows in stream order, straight out of the pinned columns jg_submit (or the caller, in place:
+    // jg_submit_reserve) filled: one copy per column that is present - an optional column nobody
+    // provided is all zeros and is not uploaded at all (an AppendResponse row is 18 bytes then, not 34)
     size_t off = 0;
     auto sect = [&](size_t bytes) {
       size_t at = off;
       off = (off + bytes + 15) & ~size_t(15);
       return at;
     };
-    const size_t o_term = sect(n * 8), o_id = sect(n * 8), o_aux = sect(n * 8), o_bid = sect(nb * 8), o_bnext = sect(nb * 8),
-                 o_group = sect(n * 4), o_from = sect(n * 4), o_kind = sect(n), o_flag = sect(n);
+    const bool has_from = e->p_has_from, has_term = e->p_has_term, has_aux = e->p_has_aux, has_flag = e->p_has_flag;
+    const size_t o_id = sect(n * 8), o_term = sect(has_term ? n * 8 : 0), o_aux = sect(has_aux ? n * 8 : 0), o_bid = sect(nb * 8),
+                 o_bnext = sect(nb * 8), o_group = sect(n * 4), o_from = sect(has_from ? n * 4 : 0), o_kind = sect(n),
+                 o_flag = sect(has_flag ? n : 0);
     const size_t bytes = off;
-    if (e->stage_busy) {
-      HIPCHK(hipEventSynchronize(e->ev_stage));
-      e->stage_busy = false;
-    }
-    if (e->stage_cap < bytes) {
-      if (e->stage) HIPCHK(hipHostFree(e->stage));
-      e->stage = nullptr;
-      e->stage_cap = std::max(bytes * 2, (size_t)1 << 20);
-      HIPCHK(hipHostMalloc((void**)&e->stage, e->stage_cap, hipHostMallocDefault));
-    }
-    char* S = e->stage;
-    std::memcpy(S + o_term, e->p_term.data(), n * 8);
-    std::memcpy(S + o_id, e->p_id.data(), n * 8);
-    std::memcpy(S + o_aux, e->p_aux.data(), n * 8);
-    std::memcpy(S + o_group, e->p_group.data(), n * 4);
-    std::memcpy(S + o_from, e->p_from.data(), n * 4);
-    std::memcpy(S + o_kind, e->p_kind.data(), n);
-    std::memcpy(S + o_flag, e->p_flag.data(), n);
-    if (nb) {
-      std::memcpy(S + o_bid, e->p_blk_id.data(), nb * 8);
-      std::memcpy(S + o_bnext, e->p_blk_next.data(), nb * 8);
-    }
     Arena& ar = e->arenas[e->cur_arena];
     char* B = nullptr;
     uint8_t* d_keep = nullptr;
     HIPCHK(ar.alloc(bytes, (void**)&B));
     HIPCHK(ar.alloc(n, (void**)&d_keep));
-    HIPCHK(hipMemcpyAsync(B, S, bytes, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipEventRecord(e->ev_stage, e->stream));
-    e->stage_busy = true;
-    bytes_up = bytes;
+    auto up = [&](size_t at, const void* src, size_t nbytes) -> hipError_t {
+      bytes_up += nbytes;
+      return hipMemcpyAsync(B + at, src, nbytes, hipMemcpyHostToDevice, e->stream);
+    };
+    HIPCHK(up(o_id, e->p_id.data(), n * 8));
+    if (has_term) HIPCHK(up(o_term, e->p_term.data(), n * 8));
+    if (has_aux) HIPCHK(up(o_aux, e->p_aux.data(), n * 8));
+    HIPCHK(up(o_group, e->p_group.data(), n * 4));
+    if (has_from) HIPCHK(up(o_from, e->p_from.data(), n * 4));
+    HIPCHK(up(o_kind, e->p_kind.data(), n));
+    if (has_flag) HIPCHK(up(o_flag, e->p_flag.data(), n));
+    if (nb) {
+      HIPCHK(up(o_bid, e->p_blk_id.data(), nb * 8));
+      HIPCHK(up(o_bnext, e->p_blk_next.data(), nb * 8));
+    }
+    // (the pinned columns are free again after the synchronisation below)
     JgNodeRows rows{};
     rows.n = (uint32_t)n;
     rows.group = (const uint32_t*)(B + o_group), rows.kind = (const uint8_t*)(B + o_kind);
-    rows.from = (const uint32_t*)(B + o_from), rows.term = (const uint64_t*)(B + o_term);
-    rows.id = (const uint64_t*)(B + o_id), rows.aux = (const uint64_t*)(B + o_aux), rows.flag = (const uint8_t*)(B + o_flag);
+    rows.from = has_from ? (const uint32_t*)(B + o_from) : nullptr, rows.term = has_term ? (const uint64_t*)(B + o_term) : nullptr;
+    rows.id = (const uint64_t*)(B + o_id), rows.aux = has_aux ? (const uint64_t*)(B + o_aux) : nullptr;
+    rows.flag = has_flag ? (const uint8_t*)(B + o_flag) : nullptr;
     rows.blk_id = (const uint64_t*)(B + o_bid), rows.blk_next = (const uint64_t*)(B + o_bnext), rows.n_blocks = nb;
     const uint32_t rgrid = grid_for(n, 4096);
     HIPCHK(hipMemsetAsync(nd.d_nsparse, 0, 8, e->stream));
@@ -1595,7 +1733,6 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     // the one synchronisation of the step: how many rows take the general path sizes that launch
     HIPCHK(hipMemcpyAsync(nd.h_nsparse, nd.d_nsparse, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->stage_busy = false;
     n_sparse = nd.h_nsparse[0];
     if (n_sparse) {
       // order-preserving compaction of the flagged rows, then a stable sort by group: the batch k_apply_rows takes
@@ -1641,6 +1778,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     }
     e->p_kind.clear(), e->p_flag.clear(), e->p_group.clear(), e->p_from.clear(), e->p_term.clear(), e->p_id.clear();
     e->p_aux.clear(), e->p_blk_id.clear(), e->p_blk_next.clear();
+    e->p_has_from = e->p_has_term = e->p_has_aux = e->p_has_flag = false;
   }
   // the dense halves: every partition, the ones whose rows went the general way included (they are ticked here)
   uint64_t bytes_down = 0;

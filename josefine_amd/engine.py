@@ -206,7 +206,7 @@ class BatchedRaft:
 
         def col(x, dt):
             if x is None:
-                return np.zeros(n, dtype=dt)
+                return None  # an absent column: all zeros, and not even uploaded by jg_step_node
             return np.ascontiguousarray(x, dtype=dt)
 
         cols = [col(kind, np.uint8), col(group, np.uint32), col(from_, np.uint32), col(term, np.uint64),
@@ -215,7 +215,7 @@ class BatchedRaft:
         bn = np.ascontiguousarray(blk_next if blk_next is not None else [], dtype=np.uint64)
         b = capi.CmdBatch()
         b.n = n
-        (b.kind, b.group, b.from_, b.term, b.id, b.aux, b.flag) = [c.ctypes.data for c in cols]
+        (b.kind, b.group, b.from_, b.term, b.id, b.aux, b.flag) = [None if c is None else c.ctypes.data for c in cols]
         b.n_blocks = len(bi)
         b.blk_id, b.blk_next = bi.ctypes.data, bn.ctypes.data
         self._check(self.api.submit(self._h, C.byref(b)))

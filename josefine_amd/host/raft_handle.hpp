@@ -126,6 +126,53 @@ class EngineError : public std::runtime_error {  // anyhow::Error
   int status;
 };
 
+// Command rows in the shape of jg_cmd_batch (structure of arrays): what a batched event loop queues
+// between two ticks instead of one heap object per message.
+struct RowQueue {
+  std::vector<uint8_t> kind, flag;
+  std::vector<uint32_t> group, from;
+  std::vector<uint64_t> term, id, aux, blk_id, blk_next;
+  size_t size() const { return kind.size(); }
+  bool empty() const { return kind.empty(); }
+  void clear() {
+    kind.clear(), flag.clear(), group.clear(), from.clear(), term.clear(), id.clear(), aux.clear(), blk_id.clear(), blk_next.clear();
+  }
+  void push(uint32_t g, uint8_t k, NodeId f = 0, Term t = 0, uint64_t i = 0, uint64_t a = 0, uint8_t fl = 0) {
+    kind.push_back(k), group.push_back(g), from.push_back(f), term.push_back(t), id.push_back(i), aux.push_back(a), flag.push_back(fl);
+  }
+  // AppendEntries{term, leader_id, blocks}: the (id, next) pairs go to the side arrays (mod.rs:196-203)
+  void push_append_entries(uint32_t g, NodeId leader, Term t, const Block* blocks, size_t n) {
+    push(g, JG_CMD_APPEND_ENTRIES, leader, t, blk_id.size(), n, 0);
+    for (size_t k = 0; k < n; k++) blk_id.push_back(blocks[k].id), blk_next.push_back(blocks[k].next);
+  }
+  // the blocks (first, first + n] of a run: next = id - 1 each (what a JG_AE mailbox word stands for)
+  void push_append_run(uint32_t g, NodeId leader, Term t, BlockId from_id, uint32_t n) {
+    push(g, JG_CMD_APPEND_ENTRIES, leader, t, blk_id.size(), n, 0);
+    for (uint32_t k = 0; k < n; k++) blk_id.push_back(from_id + 1 + k), blk_next.push_back(from_id + k);
+  }
+  void append(const jg_cmd_batch& b) {  // bulk: a peer's whole frame
+    const uint64_t shift = blk_id.size();
+    const size_t at = size();
+    kind.insert(kind.end(), b.kind, b.kind + b.n), group.insert(group.end(), b.group, b.group + b.n);
+    auto put = [&](auto& v, auto* src) {
+      if (src) v.insert(v.end(), src, src + b.n);
+      else v.resize(at + b.n, 0);
+    };
+    put(from, b.from), put(term, b.term), put(id, b.id), put(aux, b.aux), put(flag, b.flag);
+    if (shift)
+      for (size_t i = 0; i < b.n; i++)
+        if (b.kind[i] == JG_CMD_APPEND_ENTRIES) id[at + i] += shift;
+    if (b.n_blocks) blk_id.insert(blk_id.end(), b.blk_id, b.blk_id + b.n_blocks), blk_next.insert(blk_next.end(), b.blk_next, b.blk_next + b.n_blocks);
+  }
+  jg_cmd_batch view() const {
+    jg_cmd_batch b{};
+    b.n = kind.size();
+    b.kind = kind.data(), b.group = group.data(), b.from = from.data(), b.term = term.data(), b.id = id.data(), b.aux = aux.data();
+    b.flag = flag.data(), b.n_blocks = blk_id.size(), b.blk_id = blk_id.data(), b.blk_next = blk_next.data();
+    return b;
+  }
+};
+
 class BatchedRaft;
 
 class RaftHandle {  // mod.rs:417-468, a view of one group
@@ -156,6 +203,13 @@ class BatchedRaft {
   // sinks: everything the groups push on the two channels, in per-group order
   std::function<void(const Message&)> rpc_tx;
   std::function<void(const Instruction&)> fsm_tx;
+  // batch sinks: the same two channels, a whole step at a time and in wire form - the rows as the engine
+  // drains them (views of its pinned queues: no copy, no per-row object) and, for step_node, the mailbox
+  // columns.  A sink that is set replaces the per-row expansion of its channel; what the rows / columns
+  // stand for is in include/josefine_gpu.h.
+  std::function<void(const jg_msg_row*, size_t)> msg_rows_tx;
+  std::function<void(const jg_fsm_row*, size_t)> fsm_rows_tx;
+  std::function<void(const jg_node_outbox&)> columns_tx;
 
   // RaftHandle::new for n_groups groups (mod.rs:428-435)
   // `devices`: shard the groups over these HIP devices behind this one handle (jg_config.n_devices:
@@ -217,6 +271,49 @@ class BatchedRaft {
   }
 
   void step(uint64_t now_ms) {
+    flush_rows();
+    check(jg_step(e_, now_ms));
+    after_step();
+  }
+
+  // a whole frame of rows at once (no payloads: block data and proposals travel through submit())
+  void submit_rows(const jg_cmd_batch& b) {
+    flush_rows();
+    check(jg_submit(e_, &b));
+  }
+  // What event_loop does between two ticks, for every partition at once (jg_step_node): the queued rows
+  // - the steady-state vocabulary through the dense kernels, anything else through the general state
+  // machine - then Command::Tick (JG_NODE_TICK).  The Tick's messages and the followers' answers leave as
+  // mailbox columns (columns_tx, or expanded into Messages for rpc_tx); `answers_to[g]`: the NodeId a
+  // follower's dense answers are addressed to (the sender of the partition's Heartbeat / AppendEntries).
+  void step_node(uint64_t now_ms, uint32_t flags, const std::vector<NodeId>* answers_to = nullptr) {
+    flush_rows();
+    check(jg_step_node(e_, now_ms, flags));
+    jg_node_outbox o{};
+    check(jg_node_outbox_view(e_, &o));
+    last_outbox_ = o;
+    after_step();
+    if (columns_tx) columns_tx(o);
+    else if (rpc_tx) expand_columns(o, answers_to);
+  }
+  const jg_node_outbox& last_outbox() const { return last_outbox_; }
+  // payload mirrors for rows that were queued in bulk (submit_rows): a ClientRequest's proposal, a block's data
+  void note_proposal(uint32_t g, uint64_t request_id, std::vector<uint8_t> proposal) { pending_reqs_[{g, request_id}] = std::move(proposal); }
+  void note_block(uint32_t g, const Block& b) { pending_blocks_.push_back({g, b}); }
+  void store_block(uint32_t g, const Block& b) { stores_[g][b.id] = b; }
+  NodeId self_id(uint32_t g) {
+    uint8_t s = 0;
+    check(jg_read_state(e_, JG_FIELD_SELF_SLOT, 0, &s, g, 1));
+    return ids_[s];
+  }
+
+ private:
+  friend class RaftHandle;
+  void check(int rc) {
+    if (rc != JG_OK) throw EngineError(rc, jg_last_error());
+  }
+  void flush_rows() {
+    if (kind_.empty()) return;
     jg_cmd_batch b{};
     b.n = kind_.size();
     b.kind = kind_.data(), b.group = group_.data(), b.from = from_.data(), b.term = term_.data();
@@ -225,25 +322,73 @@ class BatchedRaft {
     check(jg_submit(e_, &b));
     kind_.clear(), group_.clear(), from_.clear(), term_.clear(), id_.clear(), aux_.clear(), flag_.clear();
     blk_id_.clear(), blk_next_.clear();
-    check(jg_step(e_, now_ms));
+  }
+  void after_step() {
     // followers store the payloads of the blocks they were sent (chain.rs:187-189); a
     // block whose extend failed is harmless here: its id is never reported as applied.
     for (auto& pb : pending_blocks_) stores_[pb.first][pb.second.id] = pb.second;
     pending_blocks_.clear();
     pump();
   }
-
- private:
-  friend class RaftHandle;
-  void check(int rc) {
-    if (rc != JG_OK) throw EngineError(rc, jg_last_error());
+  // the mailbox columns as the Messages they stand for (include/josefine_gpu.h, "dense node tick")
+  void expand_columns(const jg_node_outbox& o, const std::vector<NodeId>* answers_to) {
+    const uint32_t G = (uint32_t)stores_.size(), R = (uint32_t)ids_.size();
+    if (o.beat)
+      for (uint32_t g = 0; g < G; g++) {
+        jg_msg_row r{};
+        r.group = g, r.term = o.beat[g].term;
+        bool have_from = false;
+        auto from = [&] {
+          if (!have_from) r.from = self_id(g), have_from = true;
+        };
+        if (o.beat[g].hb_commit != JG_NO_ACK) {  // Heartbeat{term, commit, leader_id} to everybody (leader.rs:44-51)
+          from();
+          r.kind = JG_CMD_HEARTBEAT, r.to_kind = JG_TO_PEERS, r.to_id = 0, r.id = o.beat[g].hb_commit, r.aux = 0;
+          emit(r, r.id);
+        }
+        for (uint32_t q = 0; q < R; q++) {  // AppendEntries per follower, ascending slot (leader.rs:124-174)
+          const uint64_t w = o.ae[(size_t)q * G + g];
+          if (w == JG_NO_ACK) continue;
+          from();
+          r.kind = JG_CMD_APPEND_ENTRIES, r.to_kind = JG_TO_PEER, r.to_id = ids_[q], r.id = w >> 8, r.aux = w & 0xffu;
+          emit(r, r.id);
+        }
+      }
+    if (o.answer)
+      for (uint32_t g = 0; g < G; g++) {
+        const uint64_t w = o.answer[g];
+        if (w == JG_NO_ACK) continue;
+        jg_msg_row r{};
+        r.group = g, r.from = self_id(g), r.to_kind = JG_TO_PEER, r.to_id = answers_to ? (*answers_to)[g] : 0;
+        if ((w & 0xffu) != JG_HB_NONE) {  // HeartbeatResponse first: the Heartbeat was applied first (follower.rs:209-215)
+          r.kind = JG_CMD_HEARTBEAT_RESPONSE, r.flag = (uint8_t)(w & 0xffu), r.term = 0, r.id = o.hb_commit[g], r.aux = 0;
+          emit(r, r.id);
+        }
+        if ((w >> 8) != JG_MAILBOX_NONE) {  // AppendResponse{node_id, head, success} (follower.rs:163-172); its `term` is
+          r.kind = JG_CMD_APPEND_RESPONSE, r.flag = 1, r.term = 0, r.id = w >> 8, r.aux = 0;  // not on the dense wire: no
+          emit(r, r.id);                                                                    // leader reads it (leader.rs:211-219)
+        }
+      }
   }
 
   void pump() {
     size_t n = 0;
+    if (fsm_rows_tx && msg_rows_tx) {  // batch sinks on both channels: the engine's pinned queues as they are
+      const jg_fsm_row* fv = nullptr;
+      check(jg_drain_applies_view(e_, &fv, &n));
+      if (n) fsm_rows_tx(fv, n);
+      const jg_msg_row* mv = nullptr;
+      check(jg_drain_messages_view(e_, &mv, &n));
+      if (n) msg_rows_tx(mv, n);
+      return;
+    }
     check(jg_drain_applies(e_, nullptr, 0, &n));
     std::vector<jg_fsm_row> fr(n);
     if (n) check(jg_drain_applies(e_, fr.data(), n, &n));
+    if (fsm_rows_tx) {
+      if (n) fsm_rows_tx(fr.data(), n);
+      fr.clear();
+    }
     for (const jg_fsm_row& r : fr) {
       BlockStore& st = stores_[r.group];
       if (r.kind == JG_FSM_NOTIFY) {
@@ -282,6 +427,10 @@ class BatchedRaft {
     check(jg_drain_messages(e_, nullptr, 0, &n));
     std::vector<jg_msg_row> mr(n);
     if (n) check(jg_drain_messages(e_, mr.data(), n, &n));
+    if (msg_rows_tx) {
+      if (n) msg_rows_tx(mr.data(), n);
+      mr.clear();
+    }
     for (const jg_msg_row& r : mr) {
       std::deque<uint64_t>& q = queued_[r.group];
       if (r.kind == JG_CMD_CLIENT_REQUEST && r.to_kind == JG_TO_QUEUE) {
@@ -329,6 +478,7 @@ class BatchedRaft {
   }
 
   jg_engine* e_ = nullptr;
+  jg_node_outbox last_outbox_{};
   std::vector<BlockStore> stores_;
   std::vector<std::deque<uint64_t>> queued_;
   std::vector<NodeId> ids_;
@@ -464,18 +614,44 @@ class BatchedEventLoop {
   // Fsm::transition (fsm.rs:16): state machine of one partition; an exception is a ResponseError
   std::function<std::vector<uint8_t>(uint32_t group, const std::vector<uint8_t>& data)> fsm;
   std::function<void(const Message&)> tcp_tx;  // to the peer transport (tcp.rs), by partition
+  // What the interval's Tick is (server.rs:125): JG_NODE_TICK through jg_step_node - ONE flag for all
+  // partitions, the inbound rows classified and served by the dense kernels on the device - or, with
+  // dense = false, one Tick row per partition through jg_submit + jg_step (the general state machine only:
+  // round 2's loop, kept for the A/B in tests/cpp/bench_event_loop.cpp).
+  bool dense = true;
+  uint32_t halves = JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF;
 
-  explicit BatchedEventLoop(BatchedRaft& raft, uint32_t n_groups) : raft_(raft), G_(n_groups) {
+  explicit BatchedEventLoop(BatchedRaft& raft, uint32_t n_groups) : raft_(raft), G_(n_groups), answers_to_(n_groups, 0) {
     raft_.rpc_tx = [this](const Message& m) { on_message(m); };
     raft_.fsm_tx = [this](const Instruction& i) { on_instruction(i); };
   }
-  // a message from a peer's event loop (tcp_rx, server.rs:126-137)
-  void tcp_rx(const Message& m) { inbound_.push_back(m); }
+  // a message from a peer's event loop (tcp_rx, server.rs:126-137): queued as a ROW (structure of arrays),
+  // applied at the next step; block payloads go to the partition's store when the step has extended the chain
+  void tcp_rx(const Message& m) {
+    const Command& c = m.command;
+    if (c.kind == JG_CMD_APPEND_ENTRIES) {
+      in_.push_append_entries(m.group, c.from, c.term, c.blocks.data(), c.blocks.size());
+      for (const Block& b : c.blocks) in_blocks_.push_back({m.group, b});
+    } else {
+      // (a HeartbeatResponse does not name its sender in the Command; the Message does: rpc.rs:17-27)
+      const NodeId from = c.kind == JG_CMD_HEARTBEAT_RESPONSE ? m.from.peer : c.from;
+      in_.push(m.group, c.kind, from, c.term, c.id, c.aux, c.flag ? 1 : 0);
+      if (c.kind == JG_CMD_CLIENT_REQUEST) proxied_[{m.group, c.id}] = c.proposal;
+    }
+    if (c.kind == JG_CMD_HEARTBEAT || c.kind == JG_CMD_APPEND_ENTRIES) answers_to_[m.group] = c.from;
+  }
+  // a peer's whole frame of rows at once (payload-free: a columnar transport ships block data separately)
+  void tcp_rx_rows(const jg_cmd_batch& b) {
+    in_.append(b);
+    for (size_t i = 0; i < b.n; i++)
+      if (b.kind[i] == JG_CMD_HEARTBEAT || b.kind[i] == JG_CMD_APPEND_ENTRIES) answers_to_[b.group[i]] = b.from ? b.from[i] : 0;
+  }
   // RaftClient::propose (client.rs:35): returns the request id (Uuid::new_v4 -> a counter)
   uint64_t propose(uint32_t group, std::vector<uint8_t> proposal, Response on_response) {
     const uint64_t id = ++next_request_;
     requests_[id] = std::move(on_response);
-    client_.push_back({group, Command::ClientRequest(id, std::move(proposal))});
+    in_.push(group, JG_CMD_CLIENT_REQUEST, 0, 0, id, 0, 0);
+    proposals_.push_back({group, id, std::move(proposal)});
     return id;
   }
   // Advance logical time to now_ms: everything that arrived is applied, a Tick per partition
@@ -484,24 +660,35 @@ class BatchedEventLoop {
     for (;;) {
       const bool tick = next_tick_ <= now_ms;
       const uint64_t at = tick ? next_tick_ : now_ms;
-      if (!tick && inbound_.empty() && client_.empty()) break;
+      if (!tick && in_.empty()) break;
       step(at, tick);
       if (tick) next_tick_ += TICK_MS;
     }
   }
   size_t pending_requests() const { return requests_.size(); }
+  size_t queued_rows() const { return in_.size(); }
 
  private:
   void step(uint64_t at, bool tick) {
-    std::deque<Message> in;
-    in.swap(inbound_);
-    for (const Message& m : in) raft_.submit(m.group, m.command);
-    std::deque<std::pair<uint32_t, Command>> cl;
-    cl.swap(client_);
-    for (auto& c : cl) raft_.submit(c.first, c.second);
-    if (tick)
-      for (uint32_t g = 0; g < G_; g++) raft_.submit(g, Command::Tick());
-    raft_.step(at);
+    // payload-carrying rows (client proposals, blocks) go through submit() so that BatchedRaft's request /
+    // block mirrors see them; everything else is one bulk jg_submit of the row queue
+    for (auto& p : proposals_) raft_.note_proposal(p.group, p.id, std::move(p.data));
+    proposals_.clear();
+    for (auto& kv : proxied_) raft_.note_proposal(kv.first.first, kv.first.second, kv.second);
+    proxied_.clear();
+    for (auto& pb : in_blocks_) raft_.note_block(pb.first, pb.second);
+    in_blocks_.clear();
+    if (dense) {
+      if (!in_.empty()) raft_.submit_rows(in_.view());
+      in_.clear();
+      raft_.step_node(at, halves | (tick ? (uint32_t)JG_NODE_TICK : 0u), &answers_to_);
+    } else {
+      if (tick)
+        for (uint32_t g = 0; g < G_; g++) in_.push(g, JG_CMD_TICK);
+      if (!in_.empty()) raft_.submit_rows(in_.view());
+      in_.clear();
+      raft_.step(at);
+    }
     // Address::Local messages (server.rs:143) are applied before anything new is accepted
     int guard = 0;
     while (!local_.empty() && guard++ < 64) {
@@ -550,11 +737,20 @@ class BatchedEventLoop {
     if (cb) cb(ok, res);
   }
 
+  struct Proposal {
+    uint32_t group;
+    uint64_t id;
+    std::vector<uint8_t> data;
+  };
   BatchedRaft& raft_;
   uint32_t G_;
   uint64_t next_tick_ = 0, next_request_ = 0;
-  std::deque<Message> inbound_, local_;
-  std::deque<std::pair<uint32_t, Command>> client_;
+  RowQueue in_;                                           // tcp_rx + client_rx since the last step, stream order
+  std::vector<std::pair<uint32_t, Block>> in_blocks_;     // payloads of the AppendEntries rows in in_
+  std::vector<Proposal> proposals_;                       // payloads of the ClientRequest rows in in_
+  std::map<std::pair<uint32_t, uint64_t>, std::vector<uint8_t>> proxied_;
+  std::vector<NodeId> answers_to_;                        // per partition: who its Heartbeat / AppendEntries came from
+  std::deque<Message> local_;
   std::map<uint64_t, Response> requests_;
   std::map<std::pair<uint32_t, BlockId>, uint64_t> notifications_;
 };

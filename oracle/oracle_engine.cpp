@@ -35,6 +35,8 @@ struct jo_engine {
   std::vector<jg_leader_beat> n_f_beat, n_o_beat;
   std::vector<uint32_t> n_f_leader;
   std::vector<jg_fsm_row> n_fsm;  // fsm rows of the dense halves of the step in progress
+  std::vector<jg_msg_row> v_msgs;  // rows handed out by the *_view drains
+  std::vector<jg_fsm_row> v_fsms;
   bool node_keep_fsm = false;
   const uint64_t* node_tokens = nullptr;
   jg_node_outbox n_last{};
@@ -532,6 +534,19 @@ int jo_drain_compacted(jo_engine* e, jg_compact_row* out, size_t cap, size_t* n)
 int jo_drain_messages(jo_engine* e, jg_msg_row* out, size_t cap, size_t* n) { DRAIN(msgs, jg_msg_row) }
 int jo_drain_applies(jo_engine* e, jg_fsm_row* out, size_t cap, size_t* n) { DRAIN(fsms, jg_fsm_row) }
 int jo_drain_faults(jo_engine* e, jg_fault_row* out, size_t cap, size_t* n) { DRAIN(faults, jg_fault_row) }
+// the view forms (tests/cpp drives the C++ host mirror against this library): rows stay put until the next view of the queue
+int jo_drain_messages_view(jo_engine* e, const jg_msg_row** rows, size_t* n) {
+  e->v_msgs.clear();
+  e->v_msgs.swap(e->msgs);
+  *rows = e->v_msgs.data(), *n = e->v_msgs.size();
+  return JG_OK;
+}
+int jo_drain_applies_view(jo_engine* e, const jg_fsm_row** rows, size_t* n) {
+  e->v_fsms.clear();
+  e->v_fsms.swap(e->fsms);
+  *rows = e->v_fsms.data(), *n = e->v_fsms.size();
+  return JG_OK;
+}
 
 int jo_read_state(jo_engine* e, int field, uint32_t replica, void* out, uint32_t g0, uint32_t n) {
   if ((uint64_t)g0 + n > e->cfg.n_groups) return fail(JG_EINVAL, "group range out of bounds");

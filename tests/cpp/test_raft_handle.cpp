@@ -23,6 +23,10 @@
 #define jg_drain_faults jo_drain_faults
 #define jg_read_state jo_read_state
 #define jg_last_error jo_last_error
+#define jg_step_node jo_step_node
+#define jg_node_outbox_view jo_node_outbox_view
+#define jg_drain_messages_view jo_drain_messages_view
+#define jg_drain_applies_view jo_drain_applies_view
 #endif
 #include "../../josefine_amd/host/raft_handle.hpp"
 

@@ -56,3 +56,56 @@ def test_cpp_adapter_runs_reference_tests():
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "cpp adapter ok" in r.stdout
+
+
+# ---- a whole cluster through BatchedEventLoop (the dense kernels behind the Apply surface) -----------
+CL_SRC = os.path.join(ROOT, "tests", "cpp", "test_event_loop_cluster.cpp")
+CL_EXE = os.path.join(ROOT, "tests", "cpp", "test_event_loop_cluster")
+
+
+def build_cluster_test(oracle: bool) -> str:
+    if oracle:
+        odir = os.path.join(ROOT, "oracle")
+        subprocess.run(["make", "-C", odir], check=True, capture_output=True)
+        exe = CL_EXE + "_oracle"
+        subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-DJG_TEST_AGAINST_ORACLE", "-o", exe, CL_SRC, f"-L{odir}",
+                        "-ljosefine_oracle", f"-Wl,-rpath,{odir}"], check=True)
+        return exe
+    build_hip()
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-o", CL_EXE, CL_SRC, f"-L{CSRC}", "-ljosefine_gpu",
+                    f"-Wl,-rpath,{CSRC}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return CL_EXE
+
+
+def run_cluster(exe, *args, timeout=900):
+    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("cluster ")][0]
+    assert line.startswith("cluster ok"), line
+    return line
+
+
+def test_event_loop_cluster_host_logic_on_oracle():
+    """CPU: R BatchedEventLoops over R oracle engines, wired through the host transport: the steady
+    state after a scripted election (every row in column form) and an election by the timers alone
+    (votes travel as rows through the general path)."""
+    exe = build_cluster_test(oracle=True)
+    line = run_cluster(exe, 2000, 5, 50, "scripted")
+    assert "leaders=2000" in line and "rows_general=0 " in line and "max_head=50" in line
+    line = run_cluster(exe, 500, 3, 80, "elect")
+    assert "leaders=500" in line and "faults=0" in line and "rows_general=0 " not in line
+    build_cluster_test(oracle=False)  # (links against the C ABI: compile check without a GPU)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [(100_000, 5, 50, "scripted"), (3000, 3, 80, "elect"), (20_000, 3, 40, "scripted")])
+def test_event_loop_cluster_equals_the_oracle_backed_loops(args):
+    """VERDICT r2 #2 'Done': 100 k x 5 partitions for 50 ticks through BatchedEventLoop - five loops, five
+    engines, every message between them through the host - with EVERY rpc_tx / fsm_tx row and outbox word
+    equal to the same loops over the oracle library (one hash over all of them, tick by tick, plus the final
+    state columns), and an election by timers at R = 3 the same way."""
+    dev = run_cluster(build_cluster_test(oracle=False), *args)
+    ora = run_cluster(build_cluster_test(oracle=True), *args)
+    assert dev == ora, (dev, ora)
+    if args[3] == "scripted":
+        assert f"leaders={args[0]}" in dev and "rows_general=0 " in dev and f"max_head={args[2]}" in dev

@@ -202,3 +202,76 @@ def test_node_step_mixed_with_the_other_entry_points_and_multi_device():
                 b = [d.drain_messages(), d.drain_applies(), d.drain_faults()]
                 for x, y in zip(a, b):
                     assert x.tobytes() == y.tobytes(), t
+
+
+@pytest.mark.gpu
+def test_absent_columns_and_in_place_submit():
+    """Rows written in place into the engine's pinned columns (jg_submit_reserve / _commit) and rows
+    submitted with absent optional columns are the same rows: pieces of one tick's traffic go in
+    through jg_submit without term / aux, through jg_submit with every column, and in place with some
+    optional columns named - against the oracle fed the whole batch at once."""
+    import ctypes as C
+    G, R = 2000, 3
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=5, election_timeout_ms=(700, 1500))
+    for t in range(20):
+        now = 100 * (t + 1)
+        cols = node_traffic(rng, ora, token0=1000 * t)
+        n = len(cols["kind"])
+        ora.submit_columns(**cols)
+        # piece 1: leader-side rows only (term and aux are not needed: absent), plain jg_submit
+        k = cols["kind"]
+        lead = np.isin(k, (capi.CMD_APPEND_RESPONSE, capi.CMD_HEARTBEAT_RESPONSE, capi.CMD_CLIENT_REQUEST))
+        cut = n // 2
+        p1 = np.nonzero(lead & (np.arange(n) < cut))[0]
+        p2 = np.nonzero(~lead & (np.arange(n) < cut))[0]
+        p3 = np.arange(cut, n)
+        # (the oracle applies a partition's rows in stream order; keep that order per partition on the device:
+        #  p1, p2, p3 partition the first half by kind - only safe if no partition is split by it: use
+        #  whole-partition pieces instead)
+        first_half_groups = set(cols["group"][:cut].tolist())
+        p3 = np.array([i for i in range(n) if i >= cut and int(cols["group"][i]) not in first_half_groups], dtype=np.int64)
+        rest = np.array([i for i in range(n) if i >= cut and int(cols["group"][i]) in first_half_groups], dtype=np.int64)
+        lead_groups = set(cols["group"][p1].tolist())
+        p2_groups = set(cols["group"][p2].tolist())
+        mixed = lead_groups & p2_groups
+        order = []
+        if len(p1):
+            sel = np.array([i for i in p1 if int(cols["group"][i]) not in mixed], dtype=np.int64)
+            if len(sel):
+                dev.submit_columns(cols["kind"][sel], cols["group"][sel], from_=cols["from_"][sel], id=cols["id"][sel], flag=cols["flag"][sel])
+                order.append(sel)
+        sel = np.array(sorted([i for i in range(cut) if not (lead[i] and int(cols["group"][i]) not in mixed)] + rest.tolist()), dtype=np.int64)
+        if len(sel):
+            dev.submit_columns(cols["kind"][sel], cols["group"][sel], cols["from_"][sel], cols["term"][sel], cols["id"][sel], cols["aux"][sel],
+                               cols["flag"][sel], cols["blk_id"], cols["blk_next"])
+            order.append(sel)
+        if len(p3):  # in place
+            c = capi.CmdCols()
+            nb = len(cols["blk_id"])
+            dev._check(dev.api.submit_reserve(dev._h, len(p3), nb, C.byref(c)))
+
+            def view(ptr, dt, m):
+                return np.frombuffer((C.c_char * (m * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt)
+            view(c.kind, np.uint8, len(p3))[:] = cols["kind"][p3]
+            view(c.group, np.uint32, len(p3))[:] = cols["group"][p3]
+            view(c.from_, np.uint32, len(p3))[:] = cols["from_"][p3]
+            view(c.term, np.uint64, len(p3))[:] = cols["term"][p3]
+            view(c.id, np.uint64, len(p3))[:] = cols["id"][p3]
+            view(c.aux, np.uint64, len(p3))[:] = cols["aux"][p3]
+            view(c.flag, np.uint8, len(p3))[:] = cols["flag"][p3]
+            if nb:
+                view(c.blk_id, np.uint64, nb)[:] = cols["blk_id"]
+                view(c.blk_next, np.uint64, nb)[:] = cols["blk_next"]
+            dev._check(dev.api.submit_commit(dev._h, len(p3), nb, capi.COL_FROM | capi.COL_TERM | capi.COL_AUX | capi.COL_FLAG))
+        a, b = dev.step_node(now), ora.step_node(now)
+        compare_outboxes(a, b, f"tick {t}")
+        compare_snapshots(dev, ora, f"tick {t}")
+        compare_drains(dev, ora, f"tick {t}")
+    # a commit beyond the reservation, an unknown column bit, AppendEntries without the aux column
+    c = capi.CmdCols()
+    dev._check(dev.api.submit_reserve(dev._h, 4, 0, C.byref(c)))
+    assert dev.api.submit_commit(dev._h, 1 << 40, 0, 0) == capi.EINVAL
+    assert dev.api.submit_commit(dev._h, 1, 0, 64) == capi.EINVAL
+    np.frombuffer((C.c_char * 1).from_address(c.kind), dtype=np.uint8)[0] = capi.CMD_APPEND_ENTRIES
+    np.frombuffer((C.c_char * 4).from_address(c.group), dtype=np.uint32)[0] = 0
+    assert dev.api.submit_commit(dev._h, 1, 0, capi.COL_FROM) == capi.EINVAL
