@@ -30,3 +30,20 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
     return LIB
+
+
+HOST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host")
+EVENT_LOOP_BENCH = os.path.join(HOST, "bench_event_loop")
+
+
+def build_event_loop_bench(force: bool = False) -> str:
+    """g++ -> josefine_amd/host/bench_event_loop: josefine::BatchedEventLoop (host/raft_handle.hpp) over
+    libjosefine_gpu.so, the binary behind `bench.py --event-loop`."""
+    src = os.path.join(HOST, "bench_event_loop.cpp")
+    deps = [src, os.path.join(HOST, "raft_handle.hpp"), os.path.join(CSRC, "..", "..", "include", "josefine_gpu.h")]
+    build_hip()
+    if not force and os.path.exists(EVENT_LOOP_BENCH) and all(os.path.getmtime(d) <= os.path.getmtime(EVENT_LOOP_BENCH) for d in deps):
+        return EVENT_LOOP_BENCH
+    subprocess.run(["g++", "-std=c++17", "-O2", "-march=native", "-Wall", "-o", EVENT_LOOP_BENCH, src, f"-L{CSRC}", "-ljosefine_gpu",
+                    f"-Wl,-rpath,{CSRC}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return EVENT_LOOP_BENCH

@@ -210,6 +210,7 @@ struct jg_engine {
   // which optional columns some jg_submit since the last step actually provided (an absent column is
   // all zeros: jg_step_node does not upload it)
   bool p_has_from = false, p_has_term = false, p_has_aux = false, p_has_flag = false;
+  uint32_t p_kinds_seen = 0;  // bit 0: an AppendEntries row is queued, bit 1: a Heartbeat row
   // pinned staging for the upload of one step (reused; guarded by ev_stage)
   char* stage = nullptr;
   size_t stage_cap = 0;
@@ -984,19 +985,21 @@ void pending_materialise(jg_engine* e) {
 }
 
 // jg_submit's argument checks (shared with the multi-device router)
-int validate_batch(uint32_t n_groups, const jg_cmd_batch* b) {
+int validate_batch(uint32_t n_groups, const jg_cmd_batch* b, uint32_t* kinds_seen = nullptr) {
   if (b->n && (!b->kind || !b->group)) return fail(JG_EINVAL, "kind/group columns are required");
   if (b->n_blocks && (!b->blk_id || !b->blk_next)) return fail(JG_EINVAL, "block side arrays are required");
   // (two branch-free passes the compiler vectorises - a batch is millions of rows per tick through
   // jg_step_node - and the per-row checks only where an AppendEntries row is present)
-  uint32_t bad_group = 0, bad_kind = 0, has_ae = 0;
+  uint32_t bad_group = 0, bad_kind = 0, has_ae = 0, has_hb = 0;
   for (size_t i = 0; i < b->n; i++) bad_group |= b->group[i] >= n_groups;
   for (size_t i = 0; i < b->n; i++) {
     bad_kind |= b->kind[i] >= JG_CMD__COUNT;
     has_ae |= b->kind[i] == JG_CMD_APPEND_ENTRIES;
+    has_hb |= b->kind[i] == JG_CMD_HEARTBEAT;
   }
   if (bad_group) return fail(JG_EINVAL, "group out of range");
   if (bad_kind) return fail(JG_EINVAL, "unknown command kind");
+  if (kinds_seen) *kinds_seen = (has_ae ? 1u : 0u) | (has_hb ? 2u : 0u);
   if (has_ae) {
     if (!b->id || !b->aux) return fail(JG_EINVAL, "AppendEntries needs id/aux columns");
     for (size_t i = 0; i < b->n; i++)
@@ -1334,8 +1337,10 @@ int jg_submit(jg_engine* e, const jg_cmd_batch* b) {
   if (!e || !b) return fail(JG_EINVAL, "null argument");
   if (e->router) return router_submit(e, b);
   {
-    const int rc = validate_batch(e->cfg.n_groups, b);
+    uint32_t seen = 0;
+    const int rc = validate_batch(e->cfg.n_groups, b, &seen);
     if (rc) return rc;
+    e->p_kinds_seen |= seen;
   }
   const size_t at = e->p_kind.size(), n = b->n;
   const uint64_t blk_shift = e->p_blk_id.size();
@@ -1385,11 +1390,11 @@ int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_
   jg_cmd_batch b{};  // what was written in place, as a batch: the same checks as jg_submit
   b.n = n, b.kind = e->p_kind.p + at, b.group = e->p_group.p + at, b.id = e->p_id.p + at, b.aux = e->p_aux.p + at;
   b.n_blocks = n_blocks, b.blk_id = e->p_blk_id.p + bat, b.blk_next = e->p_blk_next.p + bat;
-  if (!(optional_columns & JG_COL_AUX))
-    for (size_t i = 0; i < n; i++)
-      if (b.kind[i] == JG_CMD_APPEND_ENTRIES) return fail(JG_EINVAL, "AppendEntries needs id/aux columns");
-  int rc = validate_batch(e->cfg.n_groups, &b);
+  uint32_t seen = 0;
+  int rc = validate_batch(e->cfg.n_groups, &b, &seen);
   if (rc) return rc;
+  if ((seen & 1u) && !(optional_columns & JG_COL_AUX)) return fail(JG_EINVAL, "AppendEntries needs id/aux columns");
+  e->p_kinds_seen |= seen;
   e->p_kind.n = e->p_group.n = e->p_id.n = at + n;
   // an optional column the caller filled is adopted where it lies (src == its own place: no copy)
   auto adopt = [&](auto& v, bool& has, bool given) {
@@ -1486,6 +1491,7 @@ int jg_step(jg_engine* e, uint64_t now_ms) {
   e->p_blk_id.clear();
   e->p_blk_next.clear();
   e->p_has_from = e->p_has_term = e->p_has_aux = e->p_has_flag = false;
+  e->p_kinds_seen = 0;
   return JG_OK;
 }
 
@@ -1671,9 +1677,11 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   const size_t n = e->p_kind.size(), nb = e->p_blk_id.size();
   if (n > 0x7fffffffull) return fail(JG_EINVAL, "batch too large: split it");
   const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
-  size_t n_hb = 0, n_ae = 0;
-  for (size_t i = 0; i < n; i++) n_hb += e->p_kind[i] == JG_CMD_HEARTBEAT, n_ae += e->p_kind[i] == JG_CMD_APPEND_ENTRIES;
-  const uint32_t both_beats = n_hb && n_ae;
+  static const bool trace = std::getenv("JG_TRACE_NODE") != nullptr;
+  auto clk = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double T0 = clk();
+  double T1 = T0, T2 = T0;
+  const uint32_t both_beats = (e->p_kinds_seen & 3u) == 3u;  // (a batch with Heartbeat AND AppendEntries rows: their consistency columns are needed)
   const uint32_t ggrid = grid_for(G, 4096);
   hipLaunchKernelGGL(k_node_prefill, dim3(ggrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, e->uniform_self,
                      halves & JG_NODE_LEADER_HALF, halves & JG_NODE_FOLLOWER_HALF, both_beats);
@@ -1732,7 +1740,9 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     e->n_launch += 3;
     // the one synchronisation of the step: how many rows take the general path sizes that launch
     HIPCHK(hipMemcpyAsync(nd.h_nsparse, nd.d_nsparse, 4, hipMemcpyDeviceToHost, e->stream));
+    T1 = clk();
     HIPCHK(hipStreamSynchronize(e->stream));
+    T2 = clk();
     n_sparse = nd.h_nsparse[0];
     if (n_sparse) {
       // order-preserving compaction of the flagged rows, then a stable sort by group: the batch k_apply_rows takes
@@ -1779,6 +1789,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     e->p_kind.clear(), e->p_flag.clear(), e->p_group.clear(), e->p_from.clear(), e->p_term.clear(), e->p_id.clear();
     e->p_aux.clear(), e->p_blk_id.clear(), e->p_blk_next.clear();
     e->p_has_from = e->p_has_term = e->p_has_aux = e->p_has_flag = false;
+  e->p_kinds_seen = 0;
   }
   // the dense halves: every partition, the ones whose rows went the general way included (they are ticked here)
   uint64_t bytes_down = 0;
@@ -1824,6 +1835,9 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     e->recs.push_back(rec);
   }
   HIPCHK(hipEventRecord(nd.ev_out, e->stream));
+  if (trace)
+    std::fprintf(stderr, "[jg node] %zu rows: uploads + classify + route issued in %.0f us, waited %.0f us (H2D %.1f MB), halves + fsm build + outbox copies issued in %.0f us\n",
+                 n, T1 - T0, T2 - T1, bytes_up / 1e6, clk() - T2);
   nd.last = jg_node_outbox{};
   nd.last.rows = n, nd.last.rows_general = n_sparse, nd.last.bytes_h2d = bytes_up, nd.last.bytes_d2h = bytes_down;
   nd.last_flags = flags;

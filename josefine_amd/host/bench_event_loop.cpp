@@ -1,0 +1,165 @@
+// bench_event_loop — decisions/s THROUGH the reference's driver surface (bench.py --event-loop).
+//
+// One node that leads G partitions of R replicas, driven the way server::event_loop drives Raft<T>
+// (src/raft/server.rs:103-165) - inbound messages as rows, one Tick per 100 ms of logical time, outputs
+// on the two channels - but for every partition at once: josefine::BatchedRaft::step_node (jg_step_node)
+// under josefine::BatchedEventLoop's row queues.  Per tick and partition the node receives what a leader
+// in steady state receives: one ClientRequest, one AppendResponse from every follower (acknowledging the
+// previous tick's block) and, every other tick (the heartbeat period), one HeartbeatResponse from every
+// follower; rows arrive shuffled across partitions.  The followers are synthetic (their answers are
+// computed on the host, like the device-resident ack stream of the headline bench); a full cluster of
+// real loops is tests/cpp/test_event_loop_cluster.cpp.
+//
+// modes
+//   inplace   the "transport" writes the rows straight into the engine's pinned columns
+//             (jg_submit_reserve / jg_submit_commit): no host copy at all
+//   copy      rows handed over as a jg_cmd_batch (BatchedEventLoop::tcp_rx_rows + run_until): two host copies
+//   general   round 2's loop: every row and one Tick ROW per partition through jg_submit + jg_step (the
+//             general state machine, host radix sort) - the A/B
+// Both channels are consumed by batch sinks that read every byte they are handed (a 64-bit sum).
+// Prints one JSON object.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+
+#include "raft_handle.hpp"
+
+using namespace josefine;
+using Clock = std::chrono::steady_clock;
+static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+static uint64_t sum_words(const void* p, size_t bytes) {
+  const uint64_t* w = (const uint64_t*)p;
+  uint64_t s = 0;
+  for (size_t i = 0; i < bytes / 8; i++) s += w[i];
+  return s;
+}
+
+int main(int argc, char** argv) {
+  const uint32_t G = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 100000;
+  const uint32_t R = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 5;
+  const uint32_t T = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 50;
+  const uint32_t W = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 10;
+  const std::string mode = argc > 5 ? argv[5] : "inplace";
+  const int device = argc > 6 ? std::atoi(argv[6]) : 0;
+  try {
+    std::vector<NodeId> ids;
+    for (uint32_t r = 0; r < R; r++) ids.push_back(r + 1);
+    BatchedRaft raft(G, ids, device, 42, JG_CFG_SEPARATE_COMMIT_KEY);
+    BatchedEventLoop loop(raft, G);
+    loop.halves = JG_NODE_LEADER_HALF;  // this node leads every partition
+    loop.dense = mode != "general";
+    uint64_t sink = 0, fsm_rows = 0, msg_rows = 0, col_bytes = 0, up_bytes = 0, general = 0;
+    raft.fsm_rows_tx = [&](const jg_fsm_row* r, size_t n) { sink += sum_words(r, n * sizeof(jg_fsm_row)), fsm_rows += n; };
+    raft.msg_rows_tx = [&](const jg_msg_row* r, size_t n) { sink += sum_words(r, n * sizeof(jg_msg_row)), msg_rows += n; };
+    raft.columns_tx = [&](const jg_node_outbox& o) {
+      if (o.beat) sink += sum_words(o.beat, (size_t)G * 16) + sum_words(o.ae, (size_t)R * G * 8);
+      col_bytes += o.bytes_d2h, up_bytes += o.bytes_h2d, general += o.rows_general;
+    };
+    {  // this node wins every election the reference's way: Timeout, then granted votes until quorum
+      RowQueue q;
+      for (uint32_t g = 0; g < G; g++) q.push(g, JG_CMD_TIMEOUT);
+      raft.submit_rows(q.view());
+      raft.step(0);
+      for (uint32_t k = 1; k <= R / 2; k++) {
+        q.clear();
+        for (uint32_t g = 0; g < G; g++) q.push(g, JG_CMD_VOTE_RESPONSE, ids[k], 1, 0, 0, 1);
+        raft.submit_rows(q.view());
+        raft.step(0);
+      }
+    }
+    // a fixed shuffle of the partitions: rows arrive in no particular order
+    std::vector<uint32_t> perm(G);
+    std::iota(perm.begin(), perm.end(), 0u);
+    uint64_t x = 88172645463325252ull;
+    for (uint32_t i = G - 1; i > 0; i--) {
+      x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+      std::swap(perm[i], perm[(uint32_t)(x % (i + 1))]);
+    }
+    // tick t's inbound rows, written by `put(i, kind, group, from, id, flag)` - the transport's decoder
+    auto rows_of_tick = [&](uint32_t t) { return (size_t)G * (1 + (R - 1) * ((t & 1) ? 2 : 1)); };
+    auto fill = [&](uint32_t t, uint8_t* kind, uint32_t* group, uint32_t* from, uint64_t* id, uint8_t* flag) {
+      size_t i = 0;
+      const bool hb = t & 1;  // a follower answers the heartbeat it got with the previous tick's messages
+      for (uint32_t k = 0; k < G; k++) {
+        const uint32_t g = perm[k];
+        kind[i] = JG_CMD_CLIENT_REQUEST, group[i] = g, from[i] = 0, id[i] = (uint64_t)t * G + g, flag[i] = 0, i++;
+      }
+      for (uint32_t r = 1; r < R; r++)
+        for (uint32_t k = 0; k < G; k++) {
+          const uint32_t g = perm[(k + 7919u * r) % G];
+          if (hb) kind[i] = JG_CMD_HEARTBEAT_RESPONSE, group[i] = g, from[i] = ids[r], id[i] = t ? t - 1 : 0, flag[i] = 1, i++;
+          kind[i] = JG_CMD_APPEND_RESPONSE, group[i] = g, from[i] = ids[r], id[i] = t, flag[i] = 1, i++;
+        }
+      return i;
+    };
+    uint64_t c0[4], c1[4];
+    double t_fill = 0, t_submit = 0, t_step = 0;
+    uint64_t rows_in = 0;
+    RowQueue staged;
+    Clock::time_point t_begin{};
+    if (jg_kernel_timing(raft.raw(), 1) != JG_OK) throw std::runtime_error("jg_kernel_timing");
+    for (uint32_t t = 0; t < W + T; t++) {
+      if (t == W) {
+        if (jg_sync(raft.raw()) != JG_OK || jg_get_counters(raft.raw(), c0) != JG_OK) throw std::runtime_error("counters");
+        sink = fsm_rows = msg_rows = col_bytes = up_bytes = general = rows_in = 0;
+        t_fill = t_submit = t_step = 0;
+        t_begin = Clock::now();
+      }
+      const uint64_t now = 100ull * (t + 1);
+      const size_t n = rows_of_tick(t);
+      auto a = Clock::now();
+      if (mode == "inplace") {
+        const jg_cmd_cols c = loop.tcp_rx_reserve(n);
+        const size_t k = fill(t, c.kind, c.group, c.from, c.id, c.flag);
+        t_fill += ms_since(a), a = Clock::now();
+        loop.tcp_rx_commit(k, 0, JG_COL_FROM | JG_COL_FLAG);
+        t_submit += ms_since(a), a = Clock::now();
+        loop.run_until(now);
+        t_step += ms_since(a);
+      } else {
+        staged.kind.resize(n), staged.group.resize(n), staged.from.resize(n), staged.id.resize(n), staged.flag.resize(n);
+        fill(t, staged.kind.data(), staged.group.data(), staged.from.data(), staged.id.data(), staged.flag.data());
+        t_fill += ms_since(a), a = Clock::now();
+        jg_cmd_batch b{};
+        b.n = n, b.kind = staged.kind.data(), b.group = staged.group.data(), b.from = staged.from.data(), b.id = staged.id.data();
+        b.flag = staged.flag.data();
+        loop.tcp_rx_rows(b);
+        t_submit += ms_since(a), a = Clock::now();
+        loop.run_until(now);
+        t_step += ms_since(a);
+      }
+      rows_in += n;
+    }
+    const double wall_ms = ms_since(t_begin);
+    if (jg_sync(raft.raw()) != JG_OK || jg_get_counters(raft.raw(), c1) != JG_OK) throw std::runtime_error("counters");
+    float k_us = 0;
+    uint32_t k_n = 0;
+    (void)jg_kernel_timing_read(raft.raw(), &k_us, &k_n);
+    // the closed form of this stream: every leader appended one block per tick and committed the previous one
+    std::vector<uint64_t> head(G), commit(G);
+    std::vector<uint8_t> fault(G);
+    jg_read_state(raft.raw(), JG_FIELD_HEAD, 0, head.data(), 0, G);
+    jg_read_state(raft.raw(), JG_FIELD_COMMIT, 0, commit.data(), 0, G);
+    jg_read_state(raft.raw(), JG_FIELD_FAULT, 0, fault.data(), 0, G);
+    bool ok = true;
+    for (uint32_t g = 0; g < G; g++) ok = ok && head[g] == W + T && commit[g] == W + T - 1 && fault[g] == 0;
+    const uint64_t decisions = c1[1] - c0[1];
+    const uint64_t down = col_bytes + fsm_rows * sizeof(jg_fsm_row) + msg_rows * sizeof(jg_msg_row);
+    std::printf("{\"ok\": %s, \"mode\": \"%s\", \"G\": %u, \"R\": %u, \"ticks\": %u, \"warmup\": %u, \"decisions\": %llu, \"wall_ms\": %.3f, "
+                "\"decisions_per_s\": %.6g, \"ms_per_tick\": %.4f, \"ms_fill\": %.4f, \"ms_submit\": %.4f, \"ms_step_and_drain\": %.4f, "
+                "\"rows_in_per_tick\": %.1f, \"rows_general\": %llu, \"fsm_rows_per_tick\": %.1f, \"msg_rows_per_tick\": %.1f, "
+                "\"pcie_h2d_bytes_per_tick\": %.1f, \"pcie_d2h_bytes_per_tick\": %.1f, \"leader_kernel_us\": %.3f, \"leader_kernel_launches\": %u, "
+                "\"sink\": %llu}\n",
+                ok ? "true" : "false", mode.c_str(), G, R, T, W, (unsigned long long)decisions, wall_ms, decisions / (wall_ms / 1e3), wall_ms / T,
+                t_fill / T, t_submit / T, t_step / T, (double)rows_in / T, (unsigned long long)general, (double)fsm_rows / T, (double)msg_rows / T,
+                (double)up_bytes / T, (double)down / T, k_us, k_n, (unsigned long long)sink);
+    return ok ? 0 : 1;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "exception: %s\n", e.what());
+    return 2;
+  }
+}

@@ -296,6 +296,14 @@ class BatchedRaft {
     if (columns_tx) columns_tx(o);
     else if (rpc_tx) expand_columns(o, answers_to);
   }
+  // zero-copy inbound rows: the engine's own pinned columns, filled in place by the transport's decoder
+  jg_cmd_cols reserve_rows(size_t n, size_t n_blocks = 0) {
+    flush_rows();
+    jg_cmd_cols c{};
+    check(jg_submit_reserve(e_, n, n_blocks, &c));
+    return c;
+  }
+  void commit_rows(size_t n, size_t n_blocks, uint32_t optional_columns) { check(jg_submit_commit(e_, n, n_blocks, optional_columns)); }
   const jg_node_outbox& last_outbox() const { return last_outbox_; }
   // payload mirrors for rows that were queued in bulk (submit_rows): a ClientRequest's proposal, a block's data
   void note_proposal(uint32_t g, uint64_t request_id, std::vector<uint8_t> proposal) { pending_reqs_[{g, request_id}] = std::move(proposal); }
@@ -646,6 +654,13 @@ class BatchedEventLoop {
     for (size_t i = 0; i < b.n; i++)
       if (b.kind[i] == JG_CMD_HEARTBEAT || b.kind[i] == JG_CMD_APPEND_ENTRIES) answers_to_[b.group[i]] = b.from ? b.from[i] : 0;
   }
+  // ... or decoded straight into the engine's pinned columns: no copy on the host at all (rows committed this
+  // way are applied before the rows queued through tcp_rx / tcp_rx_rows of the same step)
+  jg_cmd_cols tcp_rx_reserve(size_t n, size_t n_blocks = 0) { return raft_.reserve_rows(n, n_blocks); }
+  void tcp_rx_commit(size_t n, size_t n_blocks, uint32_t optional_columns) {
+    raft_.commit_rows(n, n_blocks, optional_columns);
+    direct_rows_ += n;
+  }
   // RaftClient::propose (client.rs:35): returns the request id (Uuid::new_v4 -> a counter)
   uint64_t propose(uint32_t group, std::vector<uint8_t> proposal, Response on_response) {
     const uint64_t id = ++next_request_;
@@ -660,7 +675,7 @@ class BatchedEventLoop {
     for (;;) {
       const bool tick = next_tick_ <= now_ms;
       const uint64_t at = tick ? next_tick_ : now_ms;
-      if (!tick && in_.empty()) break;
+      if (!tick && in_.empty() && !direct_rows_) break;
       step(at, tick);
       if (tick) next_tick_ += TICK_MS;
     }
@@ -678,6 +693,7 @@ class BatchedEventLoop {
     proxied_.clear();
     for (auto& pb : in_blocks_) raft_.note_block(pb.first, pb.second);
     in_blocks_.clear();
+    direct_rows_ = 0;
     if (dense) {
       if (!in_.empty()) raft_.submit_rows(in_.view());
       in_.clear();
@@ -745,6 +761,7 @@ class BatchedEventLoop {
   BatchedRaft& raft_;
   uint32_t G_;
   uint64_t next_tick_ = 0, next_request_ = 0;
+  size_t direct_rows_ = 0;                                // rows committed in place since the last step
   RowQueue in_;                                           // tcp_rx + client_rx since the last step, stream order
   std::vector<std::pair<uint32_t, Block>> in_blocks_;     // payloads of the AppendEntries rows in in_
   std::vector<Proposal> proposals_;                       // payloads of the ClientRequest rows in in_
