@@ -337,12 +337,30 @@ __device__ __forceinline__ void jg_defer_mark(const JgDev& d, uint32_t g, bool w
 // Logical time and step numbers of a closed loop that is replayed as a hipGraph
 // (jg_dense_cluster_rounds): kernel arguments are frozen in a graph, so the clock lives in device
 // memory and the graph's first node advances it.
-struct JgClock {
+// The clock advances itself - no kernel of its own in the replayed round (an empty launch costs what a
+// tenth of a follower half costs).  Two values, two index words, each index written only by a kernel
+// during which nobody reads it:
+//   the leader half (first kernel of a round)  reads v[idx_lead]; its first thread sets idx_rest = idx_lead
+//   the leader's slow kernel (second)          reads v[idx_rest]; its first thread, when the kernel's own
+//                                              work is done, writes v[idx_rest ^ 1] = this round + dt
+//                                              (every node one step further) and points idx_lead at it
+//   every later kernel of the round            reads v[idx_rest]
+struct JgClockVal {
   uint64_t now;
   uint32_t seq[JG_MAX_REPLICAS];  // per node of the cluster
 };
+struct JgClock {
+  uint32_t idx_lead, idx_rest;
+  uint64_t dt;
+  uint32_t n_nodes, pad;
+  JgClockVal v[2];
+};
+__device__ __forceinline__ void jg_clock_read(const JgClock* c, uint32_t slot, uint64_t& now, uint32_t& seq) {
+  const JgClockVal& v = c->v[c->idx_rest & 1u];
+  now = v.now, seq = v.seq[slot];
+}
 struct JgLeaderNode {
-  const JgClock* clock;        // non-null: `now` and the step number come from here (slot clock_slot)
+  JgClock* clock;              // non-null: `now` and the step number come from here (slot clock_slot)
   uint32_t clock_slot, pad_;
   uint32_t ack_stride;         // 1, or 0: nothing came in (the `acks` argument points at an all-ones word)
   uint32_t packed;             // 1: `acks` holds jg_leader_inbox answer words (JG_ANSWER), not bare heads
@@ -731,7 +749,11 @@ template <int R, bool FSM>
 __global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDenseHot h, const JgDev* __restrict__ dp,
                                                                 const uint64_t* __restrict__ acks, uint32_t seq, int us,
                                                                 JgLeaderNode nd) {
-  if (nd.clock) nd.now = nd.clock->now, seq = nd.clock->seq[nd.clock_slot];
+  if (nd.clock) {  // a replayed round: the first kernel of the round (see JgClock)
+    const uint32_t a = nd.clock->idx_lead & 1u;
+    nd.now = nd.clock->v[a].now, seq = nd.clock->v[a].seq[nd.clock_slot];
+    if (blockIdx.x == 0 && threadIdx.x == 0) nd.clock->idx_rest = a;
+  }
   JgDecCount dec;
   if (us >= 0) dec = jg_dense_tick_body<R, true, true, true, FSM>(h, dp, acks, seq, (uint32_t)us, nd, nullptr);
   else dec = jg_dense_tick_body<R, false, true, true, FSM>(h, dp, acks, seq, 0, nd, nullptr);

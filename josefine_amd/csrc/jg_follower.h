@@ -35,7 +35,7 @@ struct JgFollowerArgs {
   uint64_t now;
   uint32_t seq;
   uint32_t tick;
-  const JgClock* clock;  // non-null: `now` and `seq` come from here (slot clock_slot): a replayed round
+  const JgClock* clock;  // non-null: `now` and `seq` come from here (slot clock_slot): a replayed round (see JgClock)
   uint32_t clock_slot, pad_;
   // jg_step_node: what the step pushed on fsm_tx, one word per group (jg_dense.h JG_FSM_*_BIT); null otherwise
   uint32_t* fsm_delta;
@@ -52,8 +52,8 @@ __device__ __forceinline__ void jg_follower_fsm_note(const JgFollowerArgs& a, ui
   }
 }
 
-__global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFollowerArgs a) {
-  if (a.clock) a.now = a.clock->now, a.seq = a.clock->seq[a.clock_slot];
+__device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollowerArgs a) {
+  if (a.clock) jg_clock_read(a.clock, a.clock_slot, a.now, a.seq);
   const uint32_t G = d.G;
   for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
     // every load is independent of the others
@@ -177,10 +177,24 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFol
   }
 }
 
+__global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFollowerArgs a) { jg_follower_fast_body(d, a); }
+
+// The follower halves of several nodes that share a device in ONE launch (blockIdx.y = node): what a
+// replayed cluster round uses - a kernel costs ~4.6 us before it does anything, and a round had four of these
+// and four slow kernels behind them.  The jobs live in device memory (written when the round is captured).
+struct JgFollowerJob {
+  JgDev d;
+  JgFollowerArgs a;
+};
+__global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense_multi(const JgFollowerJob* __restrict__ jobs) {
+  const JgFollowerJob& j = jobs[blockIdx.y];
+  jg_follower_fast_body(j.d, j.a);
+}
+
 // The deferred groups through the general state machine.  AppendResponse / HeartbeatResponse
 // rows are captured into the outbox columns, everything else goes to the exceptional queue.
-__global__ __launch_bounds__(JG_BLOCK) void k_follower_slow(JgDev d, JgFollowerArgs a) {
-  if (a.clock) a.now = a.clock->now, a.seq = a.clock->seq[a.clock_slot];
+__device__ __forceinline__ void jg_follower_slow_body(const JgDev& d, JgFollowerArgs a) {
+  if (a.clock) jg_clock_read(a.clock, a.clock_slot, a.now, a.seq);
   uint32_t dec = 0;
   const uint32_t n = d.slow_cnt[blockIdx.x] < d.slow_cap ? d.slow_cnt[blockIdx.x] : d.slow_cap;
   const uint32_t* list = d.slow_list + (size_t)blockIdx.x * d.slow_cap;
@@ -250,4 +264,9 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_slow(JgDev d, JgFollowerA
   __syncthreads();
   if (threadIdx.x == 0) d.slow_cnt[blockIdx.x] = 0;
   jg_block_count(d.blk_decisions, dec);
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_follower_slow(JgDev d, JgFollowerArgs a) { jg_follower_slow_body(d, a); }
+__global__ __launch_bounds__(JG_BLOCK) void k_follower_slow_multi(const JgFollowerJob* __restrict__ jobs) {
+  const JgFollowerJob& j = jobs[blockIdx.y];
+  jg_follower_slow_body(j.d, j.a);
 }

@@ -28,7 +28,7 @@
 template <bool NODE>
 __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
                                                           size_t tick_stride, uint32_t seq0, JgLeaderNode nd) {
-  if (nd.clock) nd.now = nd.clock->now, seq0 = nd.clock->seq[nd.clock_slot];
+  if (nd.clock) jg_clock_read(nd.clock, nd.clock_slot, nd.now, seq0);
   uint32_t dec = 0;
   // this workgroup's shard of the deferral bitmap (jg_defer_mark) -> its list; the words are
   // cleared for the next launch.  (Order within the list is immaterial: groups are independent,
@@ -173,6 +173,15 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
   }
   __syncthreads();
   if (threadIdx.x == 0) d.slow_cnt[blockIdx.x] = 0;
+  if (NODE && nd.clock && blockIdx.x == 0 && threadIdx.x == 0) {  // the next round's clock (see JgClock)
+    JgClock* c = nd.clock;
+    const uint32_t b = c->idx_rest & 1u;
+    JgClockVal nv = c->v[b];
+    nv.now += c->dt;
+    for (uint32_t r = 0; r < c->n_nodes; r++) nv.seq[r] += 1;  // every node takes one step per round
+    c->v[b ^ 1u] = nv;
+    c->idx_lead = b ^ 1u;
+  }
   jg_block_count(d.blk_decisions, dec);
 }
 
@@ -211,17 +220,8 @@ __global__ void k_chain_compact(size_t n_trees, const uint64_t* __restrict__ off
 }
 
 // ---- the clock of a replayed closed loop (JgClock) ----------------------------------------------
-__global__ void k_clock_set(JgClock* c, uint64_t now, JgClock init) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    *c = init;
-    c->now = now;
-  }
-}
-__global__ void k_clock_advance(JgClock* c, uint64_t dt, uint32_t n_nodes) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    c->now += dt;
-    for (uint32_t r = 0; r < n_nodes; r++) c->seq[r] += 1;  // every node takes one step per round
-  }
+__global__ void k_clock_set(JgClock* c, JgClock init) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *c = init;
 }
 
 // ---- Chain::compact on the engine's own chains (chain.rs:239-253) ------------------------------

@@ -297,7 +297,7 @@ struct jg_engine {
   uint64_t n_cmds = 0, n_dense = 0, n_launch = 0;
   // set while a jg_dense_cluster round is being captured into a hipGraph: the node kernels then
   // take logical time and step number from this device-resident clock instead of their arguments
-  const JgClock* replay_clock = nullptr;
+  JgClock* replay_clock = nullptr;
   uint32_t replay_slot = 0;
   // jg_step_node: the inbox / outbox columns of the node step, their pinned host mirrors, rocPRIM scratch
   struct NodeStep {
@@ -1877,6 +1877,7 @@ struct jg_dense_cluster {
   // one protocol round captured as a hipGraph (ten launches and nine cross-stream dependencies per
   // round cost more host time than the round's kernels take on the device)
   JgClock* clock = nullptr;
+  JgFollowerJob* d_jobs = nullptr;  // the follower halves of a replayed round as ONE launch (k_follower_tick_dense_multi)
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   uint64_t sig = 0, graph_dt = 0;
@@ -2003,7 +2004,20 @@ int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_lead
 
 namespace {
 // the body of one round; `leading_waits`: the leader's stream first waits for the followers' last answers
-int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits) {
+// the follower job of node r as the replayed round's kernels see it
+JgFollowerJob cluster_job(const jg_dense_cluster* c, uint32_t r) {
+  const jg_engine* e = c->nodes[r];
+  JgFollowerJob j{};
+  j.d = e->dev;
+  j.a.clock = c->clock, j.a.clock_slot = r;
+  j.a.leader = nullptr, j.a.leader_id = c->lead_id;
+  j.a.beat = c->o_beat, j.a.ae = c->o_ae + (size_t)r * c->G;
+  j.a.o_answer = c->acks + (size_t)r * c->G, j.a.o_hbc = c->hbr_commit + (size_t)r * c->G;
+  j.a.tick = 1;
+  return j;
+}
+
+int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits, bool multi = false) {
   jg_engine* L = c->nodes[c->lead];
   const size_t G = c->G;
   const jg_leader_inbox in{c->acks, c->hbr_commit};
@@ -2013,6 +2027,12 @@ int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits)
     for (uint32_t r = 0; r < c->R; r++)
       if (r != c->lead && (rc = jg_stream_wait(L, c->nodes[r]))) return rc;
   if ((rc = jg_step_dense_leader(L, now_ms, &in, &out))) return rc;
+  if (multi) {  // (a captured round whose nodes share the lead node's stream) every follower half in ONE launch
+    hipLaunchKernelGGL(k_follower_tick_dense_multi, dim3(L->dense_grid, c->R - 1), dim3(JG_BLOCK), 0, L->stream, (const JgFollowerJob*)c->d_jobs);
+    hipLaunchKernelGGL(k_follower_slow_multi, dim3(JG_SHARDS, c->R - 1), dim3(JG_BLOCK), 0, L->stream, (const JgFollowerJob*)c->d_jobs);
+    HIPCHK(hipGetLastError());
+    return JG_OK;  // (the host-side bookkeeping of a replayed round is done per graph launch)
+  }
   for (uint32_t r = 0; r < c->R; r++) {
     if (r == c->lead) continue;
     if ((rc = jg_stream_wait(c->nodes[r], L))) return rc;
@@ -2051,10 +2071,25 @@ int cluster_capture(jg_dense_cluster* c, uint64_t dt_ms) {
     e->replay_clock = c->clock, e->replay_slot = r;
   }
   int rc = JG_OK;
+  // all nodes on the lead node's stream (the default while clustered): the R - 1 follower halves are one launch,
+  // their slow kernels another; the jobs are written here, outside the capture
+  bool multi = c->R > 1;
+  for (jg_engine* e : c->nodes) multi = multi && e->stream == L->stream;
+  static const bool no_multi = std::getenv("JG_CLUSTER_SEPARATE_HALVES") != nullptr;  // (A/B: one launch per follower half, as in round 2)
+  if (no_multi) multi = false;
+  if (multi) {
+    if (!c->d_jobs) {
+      HIPCHK(hipMalloc((void**)&c->d_jobs, (size_t)JG_MAX_REPLICAS * sizeof(JgFollowerJob)));
+      c->bufs.push_back(c->d_jobs);
+    }
+    std::vector<JgFollowerJob> jobs;
+    for (uint32_t r = 0; r < c->R; r++)
+      if (r != c->lead) jobs.push_back(cluster_job(c, r));
+    HIPCHK(hipMemcpy(c->d_jobs, jobs.data(), jobs.size() * sizeof(JgFollowerJob), hipMemcpyHostToDevice));
+  }
   hipError_t he = hipStreamBeginCapture(L->stream, hipStreamCaptureModeRelaxed);
   if (he == hipSuccess) {
-    hipLaunchKernelGGL(k_clock_advance, dim3(1), dim3(1), 0, L->stream, c->clock, dt_ms, c->R);
-    rc = cluster_round_body(c, 0, false);
+    rc = cluster_round_body(c, 0, false, multi);
     for (uint32_t r = 0; r < c->R && !rc; r++)  // every forked stream joins the leader's again
       if (r != c->lead) rc = jg_stream_wait(L, c->nodes[r]);
     he = hipStreamEndCapture(L->stream, &c->graph);
@@ -2100,9 +2135,11 @@ int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms
     if ((rc = cluster_capture(c, dt_ms))) return rc;
   for (uint32_t r = 0; r < c->R; r++)  // the followers' earlier work first
     if (r != c->lead && (rc = jg_stream_wait(L, c->nodes[r]))) return rc;
-  JgClock init{};
-  for (uint32_t r = 0; r < c->R; r++) init.seq[r] = c->nodes[r]->seq;
-  hipLaunchKernelGGL(k_clock_set, dim3(1), dim3(1), 0, L->stream, c->clock, now_ms - dt_ms, init);
+  JgClock init{};  // the first replayed round's time and step numbers; the rounds advance it themselves (JgClock)
+  init.dt = dt_ms, init.n_nodes = c->R;
+  init.v[0].now = now_ms;
+  for (uint32_t r = 0; r < c->R; r++) init.v[0].seq[r] = c->nodes[r]->seq + 1;
+  hipLaunchKernelGGL(k_clock_set, dim3(1), dim3(1), 0, L->stream, c->clock, init);
   for (uint32_t k = 0; k < n_rounds; k++) {
     HIPCHK(hipGraphLaunch(c->exec, L->stream));
     for (uint32_t r = 0; r < c->R; r++) {  // what the eager calls would have recorded on the host
