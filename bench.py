@@ -49,6 +49,38 @@ def survey_bytes_per_group_step(R: int) -> int:
     return 24 * R + 36
 
 
+def kernel_source_sha(name: str = "jg_dense.h") -> str:
+    """sha256 (first 16 hex digits) of the header that holds the dense kernels: what a PMC traffic figure in
+    profiles/traffic.json is valid for."""
+    import hashlib
+    with open(os.path.join(ROOT, "josefine_amd", "csrc", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def pmc_traffic(key: str):
+    """roofline.traffic: the HBM bytes per launch that rocprofv3's PMC passes measured for this workload
+    (profiles/traffic.json, written by profiles/update_traffic.py from the committed counter files), together
+    with where it comes from - and REFUSED (bytes = null) when the kernel source has changed since the
+    counters were collected: a constant read from a file is not a measurement of this run."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    with open(tpath) as f:
+        data = json.load(f)
+    v = data.get(key)
+    if v is None:
+        return None
+    meta = data.get("_collected", {}).get(key, {})
+    now = kernel_source_sha()
+    same = meta.get("kernel_sha") == now
+    out = {"bytes": v if same else None, "source": "profiles/traffic.json", "collected_from": meta.get("from"),
+           "kernel_sha_at_collection": meta.get("kernel_sha"), "kernel_sha_now": now, "kernel_unchanged_since_collection": same}
+    if not same:
+        out["stale_bytes"] = v
+        out["note"] = "jg_dense.h changed since these counters were collected: re-run profiles/collect_round.sh + update_traffic.py"
+    return out
+
+
 def effective_cores() -> int:
     """Host cores this process may actually use: the scheduler affinity mask and the cgroup CPU
     quota (the GPU box advertises 256 hardware threads and grants 16 CPUs' worth of time)."""
@@ -261,6 +293,8 @@ def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
             "config": {"workload": f"closed loop: {R} nodes x {G} partitions on one GPU, 1 append per partition per round, "
                                    "leader half + follower halves over dense mailboxes (no synthetic acks)",
                        "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world,
+                       "q9": "off (JG_CFG_SEPARATE_COMMIT_KEY: bit-exact vs the oracle with the same switch; the reference would "
+                             "panic at the first replicate() to a caught-up follower, leader.rs:152-157)",
                        "parallelism": f"{world} independent shard(s), no collective", **devices_config(args, world)},
             "group_rounds_per_s": G * world * K / wall,
             "roofline": {"bound": "hbm", "achieved": alg / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -379,6 +413,8 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
                                    "follower times out and campaigns, votes answered through can_vote and routed between "
                                    "the nodes on the device, applied the round after; 1 client request per led partition per round",
                        "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world,
+                       "q9": "off (JG_CFG_SEPARATE_COMMIT_KEY: bit-exact vs the oracle with the same switch; the reference would "
+                             "panic at the first replicate() to a caught-up follower, leader.rs:152-157)",
                        "parallelism": f"{world} independent shard(s), no collective", **devices_config(args, world)},
             "group_rounds_per_s": G * world * K / wall,
             "leaderless_fraction": {"at_start_of_timed_region": None, "at_end": float(failed.mean())},
@@ -789,12 +825,8 @@ def main():
         ticks_per_launch = K / n_launches
         alg = alg_bytes_per_group_step(R, args.mode) * G * ticks_per_launch
         achieved = alg / launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(f"G{G}_R{R}_mode{args.mode}" + ("" if T == 1 else f"_T{T}")
-                                           + (f"_failures{args.failures}" if args.failures else ""))
+        traffic = pmc_traffic(f"G{G}_R{R}_mode{args.mode}" + ("" if T == 1 else f"_T{T}")
+                              + (f"_failures{args.failures}" if args.failures else ""))
         out = {
             "metric": "Raft quorum decisions/sec over N partitions; achieved HBM GB/s vs roofline",
             "value": decisions_all / wall,

@@ -33,116 +33,6 @@
 namespace josefine {
 namespace formats {
 
-using Bytes = std::string;  // raw bytes
-
-struct FormatError : std::runtime_error {
-  using std::runtime_error::runtime_error;
-};
-
-// ---- bincode (chain store values) ---------------------------------------------------------------
-inline void put_u64_le(Bytes& o, uint64_t v) {
-  for (int i = 0; i < 8; i++) o.push_back((char)((v >> (8 * i)) & 0xff));
-}
-inline Bytes block_key(BlockId id) {  // BlockId::new, chain.rs:63-67 — also the sled key
-  Bytes k(8, '\0');
-  for (int i = 0; i < 8; i++) k[i] = (char)((id >> (8 * (7 - i))) & 0xff);
-  return k;
-}
-inline BlockId key_block_id(const Bytes& k) {
-  if (k.size() != 8) throw FormatError("block key is not 8 bytes");
-  BlockId id = 0;
-  for (int i = 0; i < 8; i++) id = (id << 8) | (uint8_t)k[i];
-  return id;
-}
-inline Bytes encode_block_id(BlockId id) {  // bincode::serialize(&BlockId): chain.rs:346-350
-  Bytes o;
-  put_u64_le(o, 8);
-  o += block_key(id);
-  return o;
-}
-inline Bytes encode_block(const Block& b) {  // bincode::serialize(&block), chain.rs:149,168,187
-  Bytes o = encode_block_id(b.id);
-  o += encode_block_id(b.next);
-  put_u64_le(o, b.data.size());
-  o.append((const char*)b.data.data(), b.data.size());
-  return o;
-}
-struct Reader {
-  const Bytes& s;
-  size_t at = 0;
-  uint64_t u64_le() {
-    if (at + 8 > s.size()) throw FormatError("bincode: unexpected end of input");
-    uint64_t v = 0;
-    for (int i = 0; i < 8; i++) v |= (uint64_t)(uint8_t)s[at + i] << (8 * i);
-    at += 8;
-    return v;
-  }
-  Bytes bytes() {
-    const uint64_t n = u64_le();
-    if (n > s.size() - at) throw FormatError("bincode: length prefix runs past the end of input");
-    Bytes b = s.substr(at, n);
-    at += n;
-    return b;
-  }
-};
-inline BlockId decode_block_id(const Bytes& v) {
-  Reader r{v};
-  return key_block_id(r.bytes());
-}
-// bincode::deserialize::<Block> — fails on the "commit" key's 8-byte value exactly as the
-// reference does (chain.rs:219-226: the length prefix it reads is the big-endian id seen
-// little-endian: astronomically large)
-inline Block decode_block(const Bytes& v) {
-  Reader r{v};
-  Block b;
-  b.id = key_block_id(r.bytes());
-  b.next = key_block_id(r.bytes());
-  const Bytes d = r.bytes();
-  b.data.assign(d.begin(), d.end());
-  return b;
-}
-
-// The chain's sled tree as the reference lays it out: ONE ordered byte-key map holding the blocks
-// and the "commit" key.  What a drop-in keeps on disk next to the engine (the engine itself only
-// knows ids and parent pointers).
-class ChainStore {
- public:
-  static const Bytes& commit_key() {
-    static const Bytes k = "commit";  // chain.rs:120,198
-    return k;
-  }
-  void insert(const Block& b) { kv_[block_key(b.id)] = encode_block(b); }  // upsert, chain.rs:149,168,187
-  bool has(BlockId id) const { return kv_.count(block_key(id)) != 0; }     // chain.rs:155-157
-  void remove(BlockId id) { kv_.erase(block_key(id)); }                    // chain.rs:246
-  void set_commit(BlockId id) { kv_[commit_key()] = block_key(id); }       // chain.rs:198
-  uint64_t commit() const {                                                // chain.rs:119-123
-    auto it = kv_.find(commit_key());
-    return it == kv_.end() ? 0 : key_block_id(it->second);
-  }
-  Block get(BlockId id) const {
-    auto it = kv_.find(block_key(id));
-    if (it == kv_.end()) throw FormatError("no such block");
-    return decode_block(it->second);
-  }
-  // Chain::range(lo..) / (lo..hi) / (lo..=hi): blocks in key order, at most `limit` of them.  An
-  // unbounded range runs into the "commit" key once the blocks are exhausted and dies there, as
-  // the reference's iterator does (chain.rs:219-226) — unless the caller has
-  // stopped pulling before (`limit`).
-  std::vector<Block> range(BlockId lo, const BlockId* hi, bool hi_inclusive, size_t limit = SIZE_MAX) const {
-    std::vector<Block> out;
-    const Bytes hk = hi ? block_key(*hi) : Bytes();
-    for (auto it = kv_.lower_bound(block_key(lo)); it != kv_.end() && out.size() < limit; ++it) {
-      if (hi && (it->first > hk || (it->first == hk && !hi_inclusive))) break;
-      out.push_back(decode_block(it->second));  // throws on the commit key's value
-    }
-    return out;
-  }
-  size_t entries() const { return kv_.size(); }
-  const std::map<Bytes, Bytes>& raw() const { return kv_; }
-
- private:
-  std::map<Bytes, Bytes> kv_;  // byte-wise key order = sled's
-};
 
 // ---- serde_json(Message) + LengthDelimitedCodec (peer wire) -----------------------------------
 inline void json_bytes(std::string& o, const uint8_t* p, size_t n) {
@@ -439,7 +329,19 @@ inline Command decode_command(Json& j) {
   j.expect('}');
   return c;
 }
-inline Message decode_message(const std::string& payload) {  // serde_json::from_slice::<Message>
+// `as_the_reference_reads`: the documented switch.  The reference's BlockId deserializer asks serde for a
+// BORROWED byte slice (chain.rs:55-61); serde_json offers a sequence, so a stock josefine peer fails to
+// decode every message that carries a BlockId - VoteRequest, AppendEntries with blocks, AppendResponse,
+// Heartbeat, HeartbeatResponse - and only BlockId-free messages (Tick, VoteResponse, ClientRequest, an
+// empty AppendEntries ...) survive its own wire.  With the switch on, decode_message fails where it does.
+inline bool carries_block_id(const Command& c) {
+  switch (c.kind) {
+    case JG_CMD_VOTE_REQUEST: case JG_CMD_APPEND_RESPONSE: case JG_CMD_HEARTBEAT: case JG_CMD_HEARTBEAT_RESPONSE: return true;
+    case JG_CMD_APPEND_ENTRIES: return !c.blocks.empty();
+    default: return false;
+  }
+}
+inline Message decode_message(const std::string& payload, bool as_the_reference_reads = false) {  // serde_json::from_slice::<Message>
   Json j(payload);
   Message m;
   j.expect('{');
@@ -448,6 +350,8 @@ inline Message decode_message(const std::string& payload) {  // serde_json::from
   j.key("command"); m.command = decode_command(j);
   j.expect('}');
   if (!j.done()) throw FormatError("json: trailing characters");
+  if (as_the_reference_reads && carries_block_id(m.command))
+    throw FormatError("json: invalid type: sequence, expected a borrowed byte array (BlockId, chain.rs:55-61)");
   return m;
 }
 

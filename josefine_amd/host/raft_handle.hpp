@@ -27,104 +27,14 @@
 
 #include "../../include/josefine_gpu.h"
 
+#include "types.hpp"
+#include "chain_store.hpp"
+
 namespace josefine {
 
-using NodeId = uint32_t;   // mod.rs:136
-using Term = uint64_t;     // mod.rs:139
-using BlockId = uint64_t;  // chain.rs:29-36 (8-byte BE id, numeric order)
-
-struct Block {  // chain.rs:86-91
-  BlockId id = 0, next = 0;
-  std::vector<uint8_t> data;
-};
-
-struct Command {  // mod.rs:160-227
-  uint8_t kind = JG_CMD_NOOP;
-  NodeId from = 0;
-  Term term = 0;
-  uint64_t id = 0, aux = 0;
-  bool flag = false;
-  std::vector<Block> blocks;      // AppendEntries
-  std::vector<uint8_t> proposal;  // ClientRequest payload (rpc.rs:30-40)
-
-  static Command Tick() { return mk(JG_CMD_TICK); }
-  static Command Propose() { return mk(JG_CMD_PROPOSE); }
-  static Command Timeout() { return mk(JG_CMD_TIMEOUT); }
-  static Command Noop() { return mk(JG_CMD_NOOP); }
-  static Command VoteRequest(Term term, NodeId candidate_id, Term last_term, BlockId head) {
-    Command c = mk(JG_CMD_VOTE_REQUEST);
-    c.term = term, c.from = candidate_id, c.aux = last_term, c.id = head;
-    return c;
-  }
-  static Command VoteResponse(Term term, NodeId from, bool granted) {
-    Command c = mk(JG_CMD_VOTE_RESPONSE);
-    c.term = term, c.from = from, c.flag = granted;
-    return c;
-  }
-  static Command AppendEntries(Term term, NodeId leader_id, std::vector<Block> blocks) {
-    Command c = mk(JG_CMD_APPEND_ENTRIES);
-    c.term = term, c.from = leader_id, c.blocks = std::move(blocks);
-    return c;
-  }
-  static Command AppendResponse(NodeId node_id, Term term, BlockId head, bool success) {
-    Command c = mk(JG_CMD_APPEND_RESPONSE);
-    c.from = node_id, c.term = term, c.id = head, c.flag = success;
-    return c;
-  }
-  static Command Heartbeat(Term term, BlockId commit, NodeId leader_id) {
-    Command c = mk(JG_CMD_HEARTBEAT);
-    c.term = term, c.id = commit, c.from = leader_id;
-    return c;
-  }
-  static Command HeartbeatResponse(BlockId commit, bool has_committed) {
-    Command c = mk(JG_CMD_HEARTBEAT_RESPONSE);
-    c.id = commit, c.flag = has_committed;
-    return c;
-  }
-  static Command ClientRequest(uint64_t request_id, std::vector<uint8_t> proposal) {
-    Command c = mk(JG_CMD_CLIENT_REQUEST);
-    c.id = request_id, c.proposal = std::move(proposal);
-    return c;
-  }
-  static Command ClientResponse(uint64_t request_id) {
-    Command c = mk(JG_CMD_CLIENT_RESPONSE);
-    c.id = request_id;
-    return c;
-  }
-
- private:
-  static Command mk(uint8_t k) {
-    Command c;
-    c.kind = k;
-    return c;
-  }
-};
-
-struct Address {  // rpc.rs:5-14
-  uint8_t kind = JG_TO_PEERS;
-  NodeId peer = 0;
-};
-struct Message {  // rpc.rs:17-27
-  uint32_t group = 0;
-  Address from, to;
-  Command command;
-};
-struct Instruction {  // fsm.rs:20-29
-  enum Kind { Apply, Notify } kind = Apply;
-  uint32_t group = 0;
-  Block block;              // Apply
-  uint64_t request_id = 0;  // Notify
-  BlockId block_id = 0;     // Notify
-};
-
-// Host block store of one group: what sled holds in the reference (chain.rs:99-104).
-using BlockStore = std::map<BlockId, Block>;
-
-class EngineError : public std::runtime_error {  // anyhow::Error
- public:
-  EngineError(int status, const char* msg) : std::runtime_error(std::string("josefine engine: ") + msg), status(status) {}
-  int status;
-};
+// Host block store of one group: what sled holds in the reference (chain.rs:99-104) - in the reference's own
+// byte layout (chain_store.hpp: 8-byte big-endian keys, bincode values, the "commit" key in the same tree).
+using BlockStore = formats::ChainStore;
 
 // Command rows in the shape of jg_cmd_batch (structure of arrays): what a batched event loop queues
 // between two ticks instead of one heap object per message.
@@ -232,7 +142,7 @@ class BatchedRaft {
     c.seed = seed;
     c.flags = flags;
     check(jg_engine_create(&c, &e_));
-    for (auto& s : stores_) s[0] = Block{0, 0, {}};  // genesis (chain.rs:139-153)
+    for (auto& s : stores_) s.insert(Block{0, 0, {}});  // genesis (chain.rs:139-153)
   }
   ~BatchedRaft() { jg_engine_destroy(e_); }
   BatchedRaft(const BatchedRaft&) = delete;
@@ -308,7 +218,20 @@ class BatchedRaft {
   // payload mirrors for rows that were queued in bulk (submit_rows): a ClientRequest's proposal, a block's data
   void note_proposal(uint32_t g, uint64_t request_id, std::vector<uint8_t> proposal) { pending_reqs_[{g, request_id}] = std::move(proposal); }
   void note_block(uint32_t g, const Block& b) { pending_blocks_.push_back({g, b}); }
-  void store_block(uint32_t g, const Block& b) { stores_[g][b.id] = b; }
+  void store_block(uint32_t g, const Block& b) { stores_[g].insert(b); }
+  // process restart of partition g's replica: the sled tree is re-opened from its bytes (ChainStore::from_raw)
+  // and the engine restarts the instance on its own image of it (JG_CMD_RESTART = Raft::new + Chain::new on the
+  // persisted tree, follower.rs:68-95, chain.rs:117-137); returns what Chain::new finds in the re-opened tree
+  formats::ChainStore::Reopened restart(uint32_t g, uint64_t now_ms = 0) {
+    stores_[g] = formats::ChainStore::from_raw(stores_[g].raw());
+    const formats::ChainStore::Reopened r = stores_[g].reopen();
+    queued_[g].clear();
+    Command c;
+    c.kind = JG_CMD_RESTART;
+    submit(g, c);
+    step(now_ms);
+    return r;
+  }
   NodeId self_id(uint32_t g) {
     uint8_t s = 0;
     check(jg_read_state(e_, JG_FIELD_SELF_SLOT, 0, &s, g, 1));
@@ -334,7 +257,7 @@ class BatchedRaft {
   void after_step() {
     // followers store the payloads of the blocks they were sent (chain.rs:187-189); a
     // block whose extend failed is harmless here: its id is never reported as applied.
-    for (auto& pb : pending_blocks_) stores_[pb.first][pb.second.id] = pb.second;
+    for (auto& pb : pending_blocks_) stores_[pb.first].insert(pb.second);
     pending_blocks_.clear();
     pump();
   }
@@ -401,13 +324,13 @@ class BatchedRaft {
       BlockStore& st = stores_[r.group];
       if (r.kind == JG_FSM_NOTIFY) {
         // leader append (leader.rs:177-188): the block now exists with the request's payload
-        Block b{r.a, r.a ? prev_head(st, r.a) : 0, {}};
+        Block b{r.a, r.a ? st.prev_key(r.a) : 0, {}};
         auto it = pending_reqs_.find({r.group, r.b});
         if (it != pending_reqs_.end()) {
           b.data = it->second;
           pending_reqs_.erase(it);
         }
-        st[b.id] = b;
+        st.insert(b);
         if (fsm_tx) {
           Instruction ins;
           ins.kind = Instruction::Notify, ins.group = r.group, ins.request_id = r.b, ins.block_id = r.a;
@@ -416,17 +339,18 @@ class BatchedRaft {
       } else {
         // range(a..=b).skip(1) for the leader (leader.rs:93), range(a..b) for a follower
         // (follower.rs:204): by key order over what is stored, not by parent pointers.
-        auto lo = st.lower_bound(r.a);
-        auto hi = r.kind == JG_FSM_APPLY_LEADER ? st.upper_bound(r.b) : st.lower_bound(r.b);
+        st.set_commit(r.b);  // chain.commit(id) persists the "commit" key first (chain.rs:195-205)
+        const BlockId hi = r.b;
+        const std::vector<Block> blocks = st.range(r.a, &hi, r.kind == JG_FSM_APPLY_LEADER);
         bool skip = r.kind == JG_FSM_APPLY_LEADER;
-        for (auto it = lo; it != hi; ++it) {
+        for (const Block& blk : blocks) {
           if (skip) {
             skip = false;
             continue;
           }
           if (fsm_tx) {
             Instruction ins;
-            ins.kind = Instruction::Apply, ins.group = r.group, ins.block = it->second;
+            ins.kind = Instruction::Apply, ins.group = r.group, ins.block = blk;
             fsm_tx(ins);
           }
         }
@@ -467,10 +391,9 @@ class BatchedRaft {
     m.command.aux = r.aux;
     m.command.flag = r.flag != 0 && r.kind != JG_CMD_CLIENT_REQUEST;
     if (r.kind == JG_CMD_APPEND_ENTRIES) {  // leader.rs:124-174: range(id..).skip(1).take(aux)
-      const BlockStore& st = stores_[r.group];
-      auto it = st.lower_bound(r.id);
-      if (it != st.end()) ++it;
-      for (uint64_t k = 0; k < r.aux && it != st.end(); ++k, ++it) m.command.blocks.push_back(it->second);
+      // (the engine has counted the blocks: the iterator is never pulled past them into the "commit" key, Q9)
+      const std::vector<Block> blocks = stores_[r.group].range(r.id, nullptr, false, (size_t)r.aux + 1);
+      for (size_t k = 1; k < blocks.size(); k++) m.command.blocks.push_back(blocks[k]);
     }
     if (r.kind == JG_CMD_CLIENT_REQUEST) {
       auto it = pending_reqs_.find({r.group, id});
@@ -478,13 +401,6 @@ class BatchedRaft {
     }
     rpc_tx(m);
   }
-  // Chain::append sets next = the head before the append (chain.rs:164-167): the
-  // largest key below the new id for a leader that only appends.
-  static BlockId prev_head(const BlockStore& st, BlockId id) {
-    auto it = st.lower_bound(id);
-    return it == st.begin() ? 0 : std::prev(it)->first;
-  }
-
   jg_engine* e_ = nullptr;
   jg_node_outbox last_outbox_{};
   std::vector<BlockStore> stores_;

@@ -28,7 +28,7 @@
 #define jg_drain_messages_view jo_drain_messages_view
 #define jg_drain_applies_view jo_drain_applies_view
 #endif
-#include "../../josefine_amd/host/raft_handle.hpp"
+#include "../../josefine_amd/host/formats.hpp"  // (includes raft_handle.hpp)
 
 using namespace josefine;
 
@@ -53,9 +53,8 @@ static void apply_entry_single_node() {
   node = node.apply(Command::Tick());
   CHECK(node.is_leader());
   // let block = leader.chain.range(..).take(2).last().unwrap();
-  auto it = raft.store(0).begin();
-  ++it;
-  CHECK(it->second.data == std::vector<uint8_t>{magic_number});
+  const std::vector<Block> two = raft.store(0).range(0, nullptr, false, 2);
+  CHECK(two.size() == 2 && two[1].data == std::vector<uint8_t>{magic_number});
   CHECK(fsm_rx.size() == 2);
   CHECK(fsm_rx[0].kind == Instruction::Notify && fsm_rx[0].block_id == 1 && fsm_rx[0].request_id == 77);
   CHECK(fsm_rx[1].kind == Instruction::Apply && fsm_rx[1].block.data == std::vector<uint8_t>{magic_number});
@@ -338,6 +337,131 @@ static void server_event_loop_multi_device() {
   for (uint32_t g = 0; g < G; g++) CHECK((applied_multi[g] == std::vector<uint8_t>{(uint8_t)(g + 1), 9}));
 }
 
+// SURVEY.md §8(f) rank 4 wired in: the host block store IS the reference's sled layout (ChainStore: 8-byte
+// big-endian keys, bincode values, the "commit" key in the same tree).  A replica restarts: the tree is
+// re-opened from its bytes and Chain::new (chain.rs:117-137) finds head = id_gen = commit - NOT the last stored
+// block (Q8) - which is exactly what JG_CMD_RESTART makes of the engine's own image of the chain.
+static void chain_store_restart() {
+  auto read64 = [](BatchedRaft& r, int f, uint32_t g) {
+    uint64_t v = 0;
+    CHECK(jg_read_state(r.raw(), f, 0, &v, g, 1) == JG_OK);
+    return v;
+  };
+  {  // a single-node leader with three committed blocks
+    BatchedRaft raft(1, {1});
+    raft.handle(0).apply(Command::Timeout());
+    for (uint8_t k = 1; k <= 3; k++) raft.handle(0).apply(Command::ClientRequest(k, {k, k}));
+    CHECK(raft.handle(0).head() == 3 && raft.handle(0).commit() == 3);
+    CHECK(raft.store(0).entries() == 5 && raft.store(0).commit() == 3);  // blocks 0..3 + the "commit" key
+    CHECK(raft.store(0).raw().rbegin()->first == formats::ChainStore::commit_key());  // ... which sorts after every block key
+    CHECK(raft.store(0).at(2).data == (std::vector<uint8_t>{2, 2}) && raft.store(0).at(2).next == 1);
+    const formats::ChainStore::Reopened r = raft.restart(0, 1000);
+    CHECK(r.commit == 3 && r.head == 3 && r.id_gen == 3);
+    RaftHandle h = raft.handle(0);
+    CHECK(h.is_follower() && h.current_term() == 0 && !h.has_voted() && h.fault() == 0);
+    CHECK(h.head() == r.head && h.commit() == r.commit && read64(raft, JG_FIELD_ID_GEN, 0) == r.id_gen);
+    CHECK(raft.store(0).entries() == 5 && raft.store(0).at(3).data == (std::vector<uint8_t>{3, 3}));  // nothing was lost on disk
+    // Q8: the restarted node wins its election again and dies on its first append (id_gen.fetch_add -> 3,
+    // assert!(id > head) with head == 3: chain.rs:161-163)
+    h = h.apply(Command::Timeout(), 2000);
+    CHECK(h.is_leader());
+    h = h.apply(Command::ClientRequest(9, {9}), 2100);
+    CHECK(h.fault() == JG_FAULT_APPEND_ID_NOT_ABOVE_HEAD);
+  }
+  {  // a follower that holds blocks beyond its commit index: the restart puts its head BACK to the commit
+    BatchedRaft raft(1, {1, 2, 3});
+    auto blk = [](BlockId id) {
+      Block b;
+      b.id = id, b.next = id - 1, b.data = {(uint8_t)id};
+      return b;
+    };
+    raft.handle(0).apply(Command::AppendEntries(1, 2, {blk(1), blk(2), blk(3), blk(4)}));
+    raft.handle(0).apply(Command::Heartbeat(1, 2, 2));
+    CHECK(raft.handle(0).head() == 4 && raft.handle(0).commit() == 2 && raft.store(0).commit() == 2);
+    const formats::ChainStore::Reopened r = raft.restart(0, 500);
+    CHECK(r.commit == 2 && r.head == 2 && r.id_gen == 2);
+    CHECK(raft.handle(0).head() == 2 && raft.handle(0).commit() == 2 && read64(raft, JG_FIELD_ID_GEN, 0) == 2);
+    CHECK(raft.store(0).has(3) && raft.store(0).has(4));  // still in the tree: extend() will meet them again
+    raft.handle(0).apply(Command::AppendEntries(1, 2, {blk(3), blk(4), blk(5)}), 600);
+    CHECK(raft.handle(0).head() == 5 && raft.handle(0).fault() == 0 && raft.store(0).at(5).data == std::vector<uint8_t>{5});
+  }
+  {  // a tree without a commit key: Chain::new initialises it (genesis, id_gen 1)
+    BatchedRaft raft(1, {1, 2, 3});
+    const formats::ChainStore::Reopened r = raft.restart(0);
+    CHECK(r.commit == 0 && r.head == 0 && r.id_gen == 1 && raft.handle(0).head() == 0 && read64(raft, JG_FIELD_ID_GEN, 0) == 1);
+  }
+}
+
+// Three event loops that talk through BYTES: every message a loop emits is serde_json-encoded and framed the way
+// tcp.rs frames it (4-byte big-endian length, tcp.rs:40-51,143-156), travels through a byte pipe per (peer,
+// partition) connection, and is unframed and decoded on the other side - the reference's wire, end to end.
+// Decoded leniently the cluster elects its leaders by the timers and commits a proposal, as it does in memory;
+// decoded as the reference itself reads (`as_the_reference_reads`) every BlockId-bearing frame is refused, so
+// no VoteRequest ever arrives and nobody is ever elected - which is what would happen between stock josefine peers.
+static void event_loops_over_the_wire() {
+  for (int strict = 0; strict < 2; strict++) {
+    const uint32_t G = 4, N = 3;
+    std::vector<std::unique_ptr<BatchedRaft>> rafts;
+    std::vector<std::unique_ptr<BatchedEventLoop>> loops;
+    std::map<std::pair<uint32_t, uint32_t>, formats::Bytes> pipe;  // (destination node, partition) -> bytes in flight
+    uint64_t frames = 0, refused = 0, bytes = 0;
+    for (uint32_t n = 0; n < N; n++) {
+      rafts.emplace_back(new BatchedRaft(G, {1, 2, 3}, 0, 300 + n, JG_CFG_SEPARATE_COMMIT_KEY));
+      std::vector<uint8_t> slots(G, (uint8_t)n);
+      CHECK(jg_set_self_slots(rafts[n]->raw(), slots.data()) == JG_OK);
+      loops.emplace_back(new BatchedEventLoop(*rafts[n], G));
+    }
+    for (uint32_t n = 0; n < N; n++)
+      loops[n]->tcp_tx = [&, n](const Message& m) {
+        const formats::Bytes f = formats::frame(formats::encode_message(m));
+        for (uint32_t dst = 0; dst < N; dst++)
+          if (dst != n && (m.to.kind == JG_TO_PEERS || m.to.peer == dst + 1)) pipe[{dst, m.group}] += f, frames++, bytes += f.size();
+      };
+    auto deliver = [&] {
+      for (auto& kv : pipe) {
+        std::string payload;
+        while (formats::unframe(kv.second, &payload)) {
+          try {
+            Message m = formats::decode_message(payload, strict != 0);
+            m.group = kv.first.second;
+            loops[kv.first.first]->tcp_rx(m);
+          } catch (const formats::FormatError&) {
+            refused++;  // tcp.rs logs the error and drops the frame
+          }
+        }
+      }
+    };
+    auto run_all = [&](uint64_t from, uint64_t to) {
+      for (uint64_t t = from; t <= to; t += 10) {
+        deliver();
+        for (uint32_t n = 0; n < N; n++) loops[n]->run_until(t);
+      }
+    };
+    run_all(0, 3000);
+    uint32_t leaders = 0;
+    for (uint32_t g = 0; g < G; g++)
+      for (uint32_t n = 0; n < N; n++) leaders += rafts[n]->handle(g).is_leader();
+    if (strict) {
+      CHECK(leaders == 0 && refused > 0 && frames > 0);  // VoteRequests carry a BlockId (`head`): refused, every one
+      continue;
+    }
+    CHECK(leaders == G && refused == 0 && bytes > 0);
+    uint32_t answered = 0;
+    for (uint32_t g = 0; g < G; g++)
+      for (uint32_t n = 0; n < N; n++)
+        if (rafts[n]->handle(g).is_leader())
+          loops[n]->propose(g, {(uint8_t)(70 + g)}, [&answered](bool ok, const std::vector<uint8_t>&) { answered += ok; });
+    run_all(3010, 4000);
+    CHECK(answered == G);
+    for (uint32_t g = 0; g < G; g++)
+      for (uint32_t n = 0; n < N; n++) {
+        CHECK(rafts[n]->handle(g).head() == 1 && rafts[n]->handle(g).commit() == 1 && rafts[n]->handle(g).fault() == 0);
+        CHECK(rafts[n]->store(g).at(1).data == std::vector<uint8_t>{(uint8_t)(70 + g)});  // the payload crossed the wire as JSON
+        CHECK(rafts[n]->store(g).commit() == 1);
+      }
+  }
+}
+
 // fsm fan-out where KEY order is not PARENT order: a follower whose chain
 // holds a dead branch.  range(prev..commit) (follower.rs:204) walks the keys, so the dead block is
 // applied too, exactly as the reference's sled iterator would deliver it: ids 1 <- 2 <- 3 (dead) and
@@ -402,6 +526,8 @@ int main() {
 #endif
     server_event_loop_single_node();
     server_event_loops_three_nodes();
+    chain_store_restart();
+    event_loops_over_the_wire();
     fsm_apply_walks_keys_not_parents();
     fsm_fanout_throughput();
 #ifndef JG_TEST_AGAINST_ORACLE

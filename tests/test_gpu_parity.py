@@ -6,7 +6,7 @@ import pytest
 from josefine_amd import BatchedRaft, Command, capi
 from oracle_lib import oracle_engine
 from parity import compare_drains, compare_snapshots, elect_all, run_dense_ticks
-from fuzz import random_batch
+from fuzz import assert_live, random_batch, random_batch_aware
 
 pytestmark = pytest.mark.gpu
 
@@ -71,6 +71,30 @@ def test_fuzz_command_stream_parity(R):
     roles = ora.read("role")
     assert len(np.unique(roles)) >= 2
     assert (ora.read("fault") != 0).any()
+
+
+@pytest.mark.parametrize("R,flags", [(1, 0), (3, capi.CFG_SEPARATE_COMMIT_KEY), (5, capi.CFG_SEPARATE_COMMIT_KEY), (3, 0), (5, 0)])
+def test_fuzz_state_aware_stream_parity(R, flags):
+    """The LIVE fuzz: the command kind is chosen from what the group is (leaders get acks, requests and Ticks,
+    candidates get votes, followers their leader's traffic and election timeouts, faulted groups restarts),
+    with a few percent of anything at all mixed in - the general state machine (k_apply_rows) under traffic
+    that keeps most groups alive and a large share of them LED.  Asserted: >= 30 % of the commands reach
+    un-faulted groups, >= 10 % of the groups are led on average (R >= 3), >= 0.1 decisions per command."""
+    G = 512
+    dev, ora = pair(G, R, seed=99, flags=flags, election_timeout_ms=(300, 700))
+    rng = np.random.default_rng(4321 + R + flags)
+    stats = {}
+    now = 0
+    for step in range(60):
+        batch = random_batch_aware(rng, ora, 1500, stats)
+        now += int(rng.integers(0, 200))
+        for e in (dev, ora):
+            e.submit_columns(**batch)
+            e.step(now)
+        compare_snapshots(dev, ora, f"aware fuzz R={R} step {step}")
+        compare_drains(dev, ora, f"aware fuzz R={R} step {step}")
+    assert dev.counters()["decisions"] == ora.counters()["decisions"]
+    assert_live(stats, ora.counters()["decisions"], R)
 
 
 def test_dense_equals_sparse_path():
