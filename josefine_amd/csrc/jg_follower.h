@@ -266,7 +266,14 @@ __device__ __forceinline__ void jg_follower_slow_body(const JgDev& d, JgFollower
   jg_block_count(d.blk_decisions, dec);
 }
 __global__ __launch_bounds__(JG_BLOCK) void k_follower_slow(JgDev d, JgFollowerArgs a) { jg_follower_slow_body(d, a); }
-__global__ __launch_bounds__(JG_BLOCK) void k_follower_slow_multi(const JgFollowerJob* __restrict__ jobs) {
-  const JgFollowerJob& j = jobs[blockIdx.y];
-  jg_follower_slow_body(j.d, j.a);
+// The slow kernels' jobs travel as KERNEL ARGUMENTS (an array in the kernarg segment, indexed by blockIdx.y):
+// the general state machine reads JgDev's pointers around every store; through a reference into global memory
+// they were re-loaded each time, a by-value copy of the job went to scratch - 1 ms per launch either way as soon
+// as the lists were not empty (the routed round of configs[4]).  7 jobs: 4 KB of kernel arguments is the limit.
+#define JG_FOLLOWER_MULTI 7
+struct JgFollowerJobs {
+  JgFollowerJob j[JG_FOLLOWER_MULTI];
+};
+__global__ __launch_bounds__(JG_BLOCK) void k_follower_slow_multi(JgFollowerJobs jobs) {
+  jg_follower_slow_body(jobs.j[blockIdx.y].d, jobs.j[blockIdx.y].a);
 }

@@ -74,18 +74,19 @@ __device__ __forceinline__ void jg_route_tally(const JgRouteTable& t, uint64_t p
   __shared__ uint32_t tally_s[JG_MAX_REPLICAS + 2];
   if (threadIdx.x < JG_MAX_REPLICAS + 2) tally_s[threadIdx.x] = 0;
   __syncthreads();
+  // (the 16-bit fields are PER LANE - a lane never counts 65 536 rows for one destination in a launch - and are
+  // widened before they are added up: summed across a wave in their packed form, a wave total of 65 536 rows
+  // to one destination used to carry into its neighbour's field)
+  for (uint32_t n = 0; n < t.R; n++) {
+    const uint32_t v = (uint32_t)((n < 4 ? pd_lo : pd_hi) >> (16 * (n & 3u))) & 0xffffu;
+    if (v) atomicAdd(&tally_s[n], v);
+  }
 #pragma unroll
   for (int off = 32; off; off >>= 1) {
-    pd_lo += __shfl_down(pd_lo, off, 64);
-    pd_hi += __shfl_down(pd_hi, off, 64);
     kept += __shfl_down(kept, off, 64);
     fsm += __shfl_down(fsm, off, 64);
   }
   if ((threadIdx.x & 63u) == 0) {
-    for (uint32_t n = 0; n < t.R; n++) {
-      const uint32_t v = (uint32_t)((n < 4 ? pd_lo : pd_hi) >> (16 * (n & 3u))) & 0xffffu;
-      if (v) atomicAdd(&tally_s[n], v);
-    }
     if (kept) atomicAdd(&tally_s[JG_MAX_REPLICAS], kept);
     if (fsm) atomicAdd(&tally_s[JG_MAX_REPLICAS + 1], fsm);
   }
@@ -103,10 +104,10 @@ __device__ __forceinline__ void jg_route_note(uint64_t& pd_lo, uint64_t& pd_hi, 
 // The slots of one sparse step: every deliverable row goes to the staging (nothing is modified: the
 // pass can be repeated with a larger staging); rows that stay and FSM rows are counted.
 #define JG_ROUTE_ITEMS 2  // slots per thread: a workgroup serves a tile of JG_BLOCK * JG_ROUTE_ITEMS
-__global__ __launch_bounds__(JG_BLOCK) void k_route_rec(JgRouteTable t, uint32_t n, uint32_t per_row, uint32_t step,
-                                                        const uint32_t* __restrict__ msg_cnt,
-                                                        const jg_msg_row* __restrict__ msg,
-                                                        const uint32_t* __restrict__ fsm_cnt) {
+__device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_t n, uint32_t per_row, uint32_t step,
+                                                  const uint32_t* __restrict__ msg_cnt, const jg_msg_row* __restrict__ msg,
+                                                  const uint32_t* __restrict__ fsm_cnt) {
+  if (blockIdx.x * (JG_BLOCK * JG_ROUTE_ITEMS) >= n) return;  // (a multi launch is as wide as its largest job)
   const uint32_t tile0 = blockIdx.x * (JG_BLOCK * JG_ROUTE_ITEMS) + threadIdx.x;
   uint32_t cnt[JG_ROUTE_ITEMS];
   uint32_t c = 0, kept = 0, f = 0;
@@ -147,6 +148,24 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_rec(JgRouteTable t, uint32_t
   }
   jg_route_tally(t, pd_lo, pd_hi, kept, JG_ROUTE_KEPT, f);
 }
+__global__ __launch_bounds__(JG_BLOCK) void k_route_rec(JgRouteTable t, uint32_t n, uint32_t per_row, uint32_t step,
+                                                        const uint32_t* __restrict__ msg_cnt,
+                                                        const jg_msg_row* __restrict__ msg,
+                                                        const uint32_t* __restrict__ fsm_cnt) {
+  jg_route_rec_body(t, n, per_row, step, msg_cnt, msg, fsm_cnt);
+}
+// every (sender, step) of a round in ONE launch: blockIdx.y = job (7-8 launches of ~20 us before)
+struct JgRouteRecJob {
+  JgRouteTable t;
+  uint32_t n, per_row, step, pad;
+  const uint32_t* msg_cnt;
+  const jg_msg_row* msg;
+  const uint32_t* fsm_cnt;
+};
+__global__ __launch_bounds__(JG_BLOCK) void k_route_rec_multi(const JgRouteRecJob* __restrict__ jobs) {
+  const JgRouteRecJob j = jobs[blockIdx.y];
+  jg_route_rec_body(j.t, j.n, j.per_row, j.step, j.msg_cnt, j.msg, j.fsm_cnt);
+}
 // second pass, only for a step that keeps rows for the host: the delivered rows leave their slots
 __global__ __launch_bounds__(JG_BLOCK) void k_route_rec_compact(JgRouteTable t, uint32_t n, uint32_t per_row,
                                                                 uint32_t* __restrict__ msg_cnt, jg_msg_row* __restrict__ msg) {
@@ -168,10 +187,9 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_rec_compact(JgRouteTable t, 
 // COMPACT = true: the rows that stay are appended to `keep` (the queue is unordered; its rows carry
 // their own step and emission index).
 template <bool COMPACT>
-__global__ __launch_bounds__(JG_BLOCK) void k_route_xq(JgRouteTable t, const JgXqRec* __restrict__ xq,
-                                                       const uint32_t* __restrict__ xq_n, uint32_t xq_cap,
-                                                       uint32_t seq_base, JgXqRec* __restrict__ keep,
-                                                       uint32_t* __restrict__ keep_n) {
+__device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const JgXqRec* __restrict__ xq,
+                                                 const uint32_t* __restrict__ xq_n, uint32_t xq_cap, uint32_t seq_base,
+                                                 JgXqRec* __restrict__ keep, uint32_t* __restrict__ keep_n) {
   const uint32_t n = min(*xq_n, xq_cap);
   const uint32_t lane = threadIdx.x & 63u;
   uint64_t pd_lo = 0, pd_hi = 0;
@@ -210,6 +228,24 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_xq(JgRouteTable t, const JgX
   if (!COMPACT) jg_route_tally(t, pd_lo, pd_hi, stays, JG_ROUTE_KEPT_XQ, 0);
 }
 
+template <bool COMPACT>
+__global__ __launch_bounds__(JG_BLOCK) void k_route_xq(JgRouteTable t, const JgXqRec* __restrict__ xq,
+                                                       const uint32_t* __restrict__ xq_n, uint32_t xq_cap,
+                                                       uint32_t seq_base, JgXqRec* __restrict__ keep,
+                                                       uint32_t* __restrict__ keep_n) {
+  jg_route_xq_body<COMPACT>(t, xq, xq_n, xq_cap, seq_base, keep, keep_n);
+}
+struct JgRouteXqJob {  // the delivering pass over every sender's exceptional-row queue in one launch
+  JgRouteTable t;
+  const JgXqRec* xq;
+  const uint32_t* xq_n;
+  uint32_t xq_cap, seq_base;
+};
+__global__ __launch_bounds__(JG_BLOCK) void k_route_xq_multi(const JgRouteXqJob* __restrict__ jobs) {
+  const JgRouteXqJob j = jobs[blockIdx.y];
+  jg_route_xq_body<false>(j.t, j.xq, j.xq_n, j.xq_cap, j.seq_base, nullptr, nullptr);
+}
+
 // sorted staging -> the command columns k_apply_rows consumes
 struct JgRouteCols {
   uint8_t *kind, *flag;
@@ -228,6 +264,157 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_build(uint32_t n, const uint
   c.term[p] = r.term;
   c.id[p] = r.id;
   c.aux[p] = r.aux;
+}
+
+// ---- ordering the staged rows without a library sort ------------------------------------------------
+// The addressees apply their batch per group, so the staging has to come out ordered by (destination,
+// group, sender slot, step, emission index) - the 64-bit key above.  Round 2 did that with one rocPRIM
+// radix sort over all staged pairs: 5-7 passes, ~15 launches, 240 us per 1.4 M rows, in the timed
+// region of a BASELINE config.  The rows are nearly ordered already (every sender's output is
+// group-major), and what the addressee needs is only *group order with a fixed order inside a group*:
+//   k_route_hist     rows per bucket, a bucket = (destination, tile of 2^JG_ROUTE_TILE_BITS groups)
+//   k_route_scan     exclusive scan of the bucket counts (one workgroup; buckets are destination-major,
+//                    so a destination's rows end up contiguous: its batch is a slice)
+//   k_route_scatter  every staged (key, index) pair into its bucket (order inside a bucket: arbitrary)
+//   k_route_sort_build  one workgroup per bucket: its pairs sorted by key in LDS (bitonic), and the
+//                    command columns of the addressees' next step written straight from the sorted
+//                    order (the old k_route_build fused in)
+// A bucket holds a few hundred rows at configs[4]'s rates (860 k of a round's 1.3 M rows go to the one
+// candidate node: 220 per tile of 256 groups); one that outgrows the LDS tile is ranked in global memory by
+// its workgroup (slow, exact).
+#define JG_ROUTE_TILE_BITS 8u
+#define JG_ROUTE_SORT_CAP 1024u  // pairs a workgroup sorts in LDS (12 KB: a dozen workgroups per CU)
+struct JgRouteBuckets {
+  uint32_t n_buckets;
+  uint32_t shift;   // key >> shift = bucket id
+  uint32_t* hist;   // [n_buckets + 1] counts, then (after the scan) exclusive offsets
+  uint32_t* cur;    // [n_buckets] scatter cursors
+};
+// A workgroup's 256 staged pairs sit in a handful of buckets (a sender's output is group-major; a row is
+// staged once per addressee, so neighbouring entries alternate between the destinations' regions): the
+// workgroup tallies them in a small LDS table first and touches global memory once per (workgroup, bucket) -
+// per row the two passes took 184 + 197 us per 1.3 M rows (a few thousand hot addresses).
+#define JG_ROUTE_TABLE 512u  // LDS table slots (open addressing; >= 2 x the pairs of a tile)
+struct JgBucketTable {
+  uint32_t key[JG_ROUTE_TABLE];  // bucket id + 1, 0 = free
+  uint32_t cnt[JG_ROUTE_TABLE];
+  uint32_t base[JG_ROUTE_TABLE];
+};
+__device__ __forceinline__ void jg_table_clear(JgBucketTable& t) {
+  for (uint32_t i = threadIdx.x; i < JG_ROUTE_TABLE; i += JG_BLOCK) t.key[i] = 0, t.cnt[i] = 0;
+  __syncthreads();
+}
+// the slot of bucket `bk` (inserted if new) and this entry's rank among the workgroup's entries of that bucket
+__device__ __forceinline__ uint32_t jg_table_add(JgBucketTable& t, uint32_t bk, uint32_t& rank) {
+  uint32_t s = (bk * 2654435761u) >> 23;  // 9 bits
+  for (;;) {
+    const uint32_t old = atomicCAS(&t.key[s], 0u, bk + 1u);
+    if (old == 0u || old == bk + 1u) break;
+    s = (s + 1u) & (JG_ROUTE_TABLE - 1u);
+  }
+  rank = atomicAdd(&t.cnt[s], 1u);
+  return s;
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_route_hist(uint32_t n, const uint64_t* __restrict__ key, JgRouteBuckets b) {
+  __shared__ JgBucketTable t;
+  for (uint32_t base = blockIdx.x * JG_BLOCK; base < n; base += gridDim.x * JG_BLOCK) {  // (workgroup-uniform trips)
+    jg_table_clear(t);
+    const uint32_t i = base + threadIdx.x;
+    uint32_t rank;
+    if (i < n) (void)jg_table_add(t, (uint32_t)(key[i] >> b.shift), rank);
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < JG_ROUTE_TABLE; s += JG_BLOCK)
+      if (t.key[s]) (void)__hip_atomic_fetch_add(&b.hist[t.key[s] - 1u], t.cnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_route_scan(JgRouteBuckets b) {
+  // one workgroup, one pass: every thread sums its own contiguous chunk, one block scan of the 256 chunk sums,
+  // then the chunk's exclusive offsets (20 k buckets in 10 rounds of block scans took 33 us)
+  const uint32_t n = b.n_buckets, per = (n + JG_BLOCK) / JG_BLOCK;  // ceil((n + 1) / JG_BLOCK)
+  const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n + 1u);
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; i++) sum += i < n ? b.hist[i] : 0u;
+  uint32_t tot;
+  uint32_t ex = jg_block_exclusive_scan(sum, &tot);
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint32_t v = i < n ? b.hist[i] : 0u;
+    b.hist[i] = ex;  // (entry n: the grand total)
+    if (i < n) b.cur[i] = 0;
+    ex += v;
+  }
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_route_scatter(uint32_t n, const uint64_t* __restrict__ key, const uint32_t* __restrict__ idx,
+                                                            JgRouteBuckets b, uint64_t* __restrict__ key_out, uint32_t* __restrict__ idx_out) {
+  __shared__ JgBucketTable t;
+  for (uint32_t base = blockIdx.x * JG_BLOCK; base < n; base += gridDim.x * JG_BLOCK) {
+    jg_table_clear(t);
+    const uint32_t i = base + threadIdx.x;
+    const bool live = i < n;
+    const uint64_t k = live ? key[i] : 0ull;
+    uint32_t rank = 0, slot = 0;
+    if (live) slot = jg_table_add(t, (uint32_t)(k >> b.shift), rank);
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < JG_ROUTE_TABLE; s += JG_BLOCK)  // one reservation per (workgroup, bucket)
+      if (t.key[s]) t.base[s] = b.hist[t.key[s] - 1u] + atomicAdd(&b.cur[t.key[s] - 1u], t.cnt[s]);
+    __syncthreads();
+    if (live) {
+      const uint32_t at = t.base[slot] + rank;
+      key_out[at] = k;
+      idx_out[at] = idx[i];
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_route_sort_build(JgRouteBuckets b, uint64_t* __restrict__ key, uint32_t* __restrict__ idx,
+                                                               const jg_msg_row* __restrict__ rows, JgRouteCols c) {
+  __shared__ uint64_t s_key[JG_ROUTE_SORT_CAP];
+  __shared__ uint32_t s_idx[JG_ROUTE_SORT_CAP];
+  const uint32_t lo = b.hist[blockIdx.x], n = b.hist[blockIdx.x + 1] - lo;
+  if (!n) return;
+  if (n <= JG_ROUTE_SORT_CAP) {
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    for (uint32_t i = threadIdx.x; i < m; i += JG_BLOCK) {
+      s_key[i] = i < n ? key[lo + i] : ~0ull;  // (padding sorts last; real keys are < 2^64 - 1: destination < 8)
+      s_idx[i] = i < n ? idx[lo + i] : 0u;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = threadIdx.x; i < m; i += JG_BLOCK) {
+          const uint32_t p = i ^ j;
+          if (p > i) {
+            const bool up = (i & k) == 0;
+            const uint64_t a = s_key[i], q = s_key[p];
+            if ((a > q) == up) {
+              s_key[i] = q, s_key[p] = a;
+              const uint32_t t = s_idx[i];
+              s_idx[i] = s_idx[p], s_idx[p] = t;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) {
+      const jg_msg_row r = rows[s_idx[i]];
+      const uint32_t p = lo + i;
+      c.kind[p] = r.kind, c.flag[p] = r.flag, c.group[p] = r.group, c.from[p] = r.from;
+      c.term[p] = r.term, c.id[p] = r.id, c.aux[p] = r.aux;
+    }
+    return;
+  }
+  // a bucket larger than the LDS tile: every pair's rank by counting the smaller keys (keys are unique:
+  // destination, group, sender, step and emission index name one row)
+  for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) {
+    const uint64_t k = key[lo + i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; j++) rank += key[lo + j] < k;
+    const jg_msg_row r = rows[idx[lo + i]];
+    const uint32_t p = lo + rank;
+    c.kind[p] = r.kind, c.flag[p] = r.flag, c.group[p] = r.group, c.from[p] = r.from;
+    c.term[p] = r.term, c.id[p] = r.id, c.aux[p] = r.aux;
+  }
 }
 
 // ClientRequests are offered only where the lead node leads (at a leaderless replica the reference

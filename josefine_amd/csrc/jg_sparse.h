@@ -44,7 +44,7 @@ struct JgRowsArgs {
 // its rows itself: one dependent trip to memory per row — a candidate's sixteen VoteResponses took the
 // batch's owner lanes sixteen round trips (profiles/README.md, the routed round).  Rows of a run that
 // continue in the next wave are still loaded by the owner.
-__global__ __launch_bounds__(JG_BLOCK) void k_apply_rows(JgDev d, JgRowsArgs a) {
+__device__ __forceinline__ void jg_apply_rows_body(const JgDev& d, const JgRowsArgs& a) {
   uint32_t dec = 0;
   const uint32_t lane = threadIdx.x & 63u;
   for (uint32_t base = blockIdx.x * JG_BLOCK; base < a.n; base += gridDim.x * JG_BLOCK) {  // (workgroup-uniform trips)
@@ -154,6 +154,19 @@ __global__ __launch_bounds__(JG_BLOCK) void k_apply_rows(JgDev d, JgRowsArgs a) 
     __syncthreads();
   }
   jg_block_count(d.blk_decisions, dec);
+}
+
+__global__ __launch_bounds__(JG_BLOCK) void k_apply_rows(JgDev d, JgRowsArgs a) { jg_apply_rows_body(d, a); }
+// The steps of several engines that share a stream in ONE launch (blockIdx.y = engine): the routed round of a
+// cluster applies up to two batches per node and round - seven launches of ~30 us one behind the other, the
+// longest (the candidate node's) setting the pace of each.  Jobs live in device memory.
+struct JgApplyJob {
+  JgDev d;
+  JgRowsArgs a;
+};
+__global__ __launch_bounds__(JG_BLOCK) void k_apply_rows_multi(const JgApplyJob* __restrict__ jobs) {
+  const JgApplyJob& j = jobs[blockIdx.y];  // (through the reference: 64 us per launch; a by-value copy of the job went to scratch: 198 us)
+  jg_apply_rows_body(j.d, j.a);
 }
 
 // ---- drain-time compaction, entirely on the device -------------------------------------------

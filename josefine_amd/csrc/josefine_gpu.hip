@@ -1046,9 +1046,10 @@ void sort_rows_by_group(const uint32_t* group, size_t n, uint32_t n_groups, std:
 }
 
 // Launch k_apply_rows over device-resident, group-sorted command columns.
-int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* kind, const uint32_t* from,
-                const uint64_t* term, const uint64_t* id, const uint64_t* aux, const uint8_t* flag,
-                const uint64_t* blk_id, const uint64_t* blk_next, uint64_t n_blocks, uint64_t now_ms) {
+// everything of a k_apply_rows step but the launch: output regions, the step record, the host-side bookkeeping
+int prepare_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* kind, const uint32_t* from,
+                 const uint64_t* term, const uint64_t* id, const uint64_t* aux, const uint8_t* flag,
+                 const uint64_t* blk_id, const uint64_t* blk_next, uint64_t n_blocks, uint64_t now_ms, JgRowsArgs* out) {
   StepRec rec;
   rec.n = n;
   rec.msg_per_row = msg_bound(e->cfg.n_replicas);
@@ -1085,14 +1086,23 @@ int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* 
   a.now = now_ms;
   a.seq = e->seq;
   rec.seq = e->seq;
-  hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(n, e->count_slots)), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
-  HIPCHK(hipGetLastError());
   e->n_launch += 1;
   e->recs.push_back(rec);
   e->n_cmds += n;
   e->maybe_irregular = true;  // until the device flag says otherwise (sync_and_check)
   e->flag_check_pending = true;
   e->irr_gen++;
+  *out = a;
+  return JG_OK;
+}
+int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* kind, const uint32_t* from,
+                const uint64_t* term, const uint64_t* id, const uint64_t* aux, const uint8_t* flag,
+                const uint64_t* blk_id, const uint64_t* blk_next, uint64_t n_blocks, uint64_t now_ms) {
+  JgRowsArgs a;
+  const int rc = prepare_rows(e, n, group, kind, from, term, id, aux, flag, blk_id, blk_next, n_blocks, now_ms, &a);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(n, e->count_slots)), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
+  HIPCHK(hipGetLastError());
   return JG_OK;
 }
 
@@ -1905,6 +1915,12 @@ struct jg_dense_cluster {
     std::vector<JgXqRec*> xq_keep;  // per node, lazily: where the exceptional rows that stay are compacted
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    uint32_t *bk_hist = nullptr, *bk_cur = nullptr;  // bucket counts / offsets and scatter cursors (k_route_hist ... _sort_build)
+    uint32_t bk_cap = 0;
+    // job tables of the round's multi launches (one launch for all nodes / senders / steps): a pinned staging
+    // the host fills and its device copy, in slices of JOB_SLICE bytes
+    static constexpr size_t JOB_SLICE = 16384;
+    char *h_jobs = nullptr, *d_jobs = nullptr;
     uint32_t group_bits = 1;
     bool ready = false;
   } rt;
@@ -1977,6 +1993,10 @@ void jg_dense_cluster_destroy(jg_dense_cluster* c) {
   for (JgXqRec* p : c->rt.xq_keep)
     if (p) (void)hipFree(p);
   if (c->rt.sort_tmp) (void)hipFree(c->rt.sort_tmp);
+  if (c->rt.h_jobs) (void)hipHostFree(c->rt.h_jobs);
+  if (c->rt.d_jobs) (void)hipFree(c->rt.d_jobs);
+  if (c->rt.bk_hist) (void)hipFree(c->rt.bk_hist);
+  if (c->rt.bk_cur) (void)hipFree(c->rt.bk_cur);
   if (c->rt.d_count) (void)hipFree(c->rt.d_count);
   if (c->rt.h_count) (void)hipHostFree(c->rt.h_count);
   delete c;
@@ -2017,7 +2037,8 @@ JgFollowerJob cluster_job(const jg_dense_cluster* c, uint32_t r) {
   return j;
 }
 
-int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits, bool multi = false) {
+int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits, bool multi = false, char* h_slice = nullptr,
+                       char* d_slice = nullptr) {
   jg_engine* L = c->nodes[c->lead];
   const size_t G = c->G;
   const jg_leader_inbox in{c->acks, c->hbr_commit};
@@ -2029,9 +2050,42 @@ int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits,
   if ((rc = jg_step_dense_leader(L, now_ms, &in, &out))) return rc;
   if (multi) {  // (a captured round whose nodes share the lead node's stream) every follower half in ONE launch
     hipLaunchKernelGGL(k_follower_tick_dense_multi, dim3(L->dense_grid, c->R - 1), dim3(JG_BLOCK), 0, L->stream, (const JgFollowerJob*)c->d_jobs);
-    hipLaunchKernelGGL(k_follower_slow_multi, dim3(JG_SHARDS, c->R - 1), dim3(JG_BLOCK), 0, L->stream, (const JgFollowerJob*)c->d_jobs);
+    {
+      JgFollowerJobs kj{};
+      uint32_t k = 0;
+      for (uint32_t r = 0; r < c->R; r++)
+        if (r != c->lead) kj.j[k++] = cluster_job(c, r);
+      hipLaunchKernelGGL(k_follower_slow_multi, dim3(JG_SHARDS, c->R - 1), dim3(JG_BLOCK), 0, L->stream, kj);
+    }
     HIPCHK(hipGetLastError());
     return JG_OK;  // (the host-side bookkeeping of a replayed round is done per graph launch)
+  }
+  if (h_slice) {  // an eager round whose nodes share the lead node's stream: the same two launches, jobs with this round's time
+    std::vector<JgFollowerJob> jobs;
+    for (uint32_t r = 0; r < c->R; r++) {
+      if (r == c->lead) continue;
+      jg_engine* e = c->nodes[r];
+      if ((rc = ensure_xq(e))) return rc;
+      e->stepped = true;
+      e->seq++;
+      JgFollowerJob j = cluster_job(c, r);
+      j.a.clock = nullptr, j.a.now = now_ms, j.a.seq = e->seq;
+      jobs.push_back(j);
+      e->slow_scheduled_ever = true;
+      e->n_launch += 2;
+      e->n_dense += e->cfg.n_groups;
+      e->maybe_irregular = true, e->flag_check_pending = true, e->irr_gen++;
+    }
+    if (!jobs.empty()) {
+      std::memcpy(h_slice, jobs.data(), jobs.size() * sizeof(JgFollowerJob));
+      HIPCHK(hipMemcpyAsync(d_slice, h_slice, jobs.size() * sizeof(JgFollowerJob), hipMemcpyHostToDevice, L->stream));
+      hipLaunchKernelGGL(k_follower_tick_dense_multi, dim3(L->dense_grid, (uint32_t)jobs.size()), dim3(JG_BLOCK), 0, L->stream, (const JgFollowerJob*)d_slice);
+      JgFollowerJobs kj{};
+      for (size_t k = 0; k < jobs.size(); k++) kj.j[k] = jobs[k];
+      hipLaunchKernelGGL(k_follower_slow_multi, dim3(JG_SHARDS, (uint32_t)jobs.size()), dim3(JG_BLOCK), 0, L->stream, kj);
+      HIPCHK(hipGetLastError());
+    }
+    return JG_OK;
   }
   for (uint32_t r = 0; r < c->R; r++) {
     if (r == c->lead) continue;
@@ -2221,26 +2275,83 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
     if ((rc = route_grow(rt, 1))) return rc;
     rt.ready = true;
   }
-  // -- 1. what the transport delivered last round, then this round's injected rows (per group: in that order)
+  // -- 1. what the transport delivered last round, then this round's injected rows (per group: in that order).
+  // Nodes that share the lead node's stream take each of the two in ONE launch (k_apply_rows_multi).
+  bool one_stream = true;
+  for (jg_engine* e : c->nodes) one_stream = one_stream && e->stream == L->stream;
+  static const bool no_multi = std::getenv("JG_ROUTE_SEPARATE_LAUNCHES") != nullptr;  // (A/B: round 2's launch per node / sender / step)
+  const bool multi = one_stream && !no_multi;
+  if (!rt.h_jobs) {
+    HIPCHK(hipHostMalloc((void**)&rt.h_jobs, 6 * jg_dense_cluster::Route::JOB_SLICE, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&rt.d_jobs, 6 * jg_dense_cluster::Route::JOB_SLICE));
+  }
+  static_assert(JG_MAX_REPLICAS * sizeof(JgApplyJob) <= jg_dense_cluster::Route::JOB_SLICE, "job slice too small");
+  static_assert(JG_MAX_REPLICAS * sizeof(JgFollowerJob) <= jg_dense_cluster::Route::JOB_SLICE, "job slice too small");
+  auto slice_h = [&](int k) { return rt.h_jobs + (size_t)k * jg_dense_cluster::Route::JOB_SLICE; };
+  auto slice_d = [&](int k) { return rt.d_jobs + (size_t)k * jg_dense_cluster::Route::JOB_SLICE; };
+  auto apply_all = [&](int slice, std::vector<JgApplyJob>& jobs, uint32_t widest) -> int {
+    if (jobs.empty()) return JG_OK;
+    if (!multi) {
+      for (size_t k = 0; k < jobs.size(); k++)
+        hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(jobs[k].a.n, L->count_slots)), dim3(JG_BLOCK), 0, L->stream, jobs[k].d, jobs[k].a);
+    } else {
+      std::memcpy(slice_h(slice), jobs.data(), jobs.size() * sizeof(JgApplyJob));
+      HIPCHK(hipMemcpyAsync(slice_d(slice), slice_h(slice), jobs.size() * sizeof(JgApplyJob), hipMemcpyHostToDevice, L->stream));
+      hipLaunchKernelGGL(k_apply_rows_multi, dim3(grid_for(widest, L->count_slots), (uint32_t)jobs.size()), dim3(JG_BLOCK), 0, L->stream,
+                         (const JgApplyJob*)slice_d(slice));
+    }
+    HIPCHK(hipGetLastError());
+    return JG_OK;
+  };
   std::vector<uint32_t> seq_base(R);
-  for (uint32_t n = 0; n < R; n++) {
-    jg_engine* e = c->nodes[n];
-    seq_base[n] = e->seq;
-    if (rt.n_in[n]) {
+  for (uint32_t n = 0; n < R; n++) seq_base[n] = c->nodes[n]->seq;
+  {
+    std::vector<JgApplyJob> jobs;
+    uint32_t widest = 0;
+    for (uint32_t n = 0; n < R; n++) {
+      jg_engine* e = c->nodes[n];
+      if (!rt.n_in[n]) continue;
       const size_t o = rt.in_off[n];
       e->stepped = true;
       e->seq++;
-      if ((rc = launch_rows(e, rt.n_in[n], rt.cols.group + o, rt.cols.kind + o, rt.cols.from + o, rt.cols.term + o, rt.cols.id + o,
-                            rt.cols.aux + o, rt.cols.flag + o, nullptr, nullptr, 0, now_ms)))
+      JgApplyJob j{};
+      j.d = e->dev;
+      if ((rc = prepare_rows(e, rt.n_in[n], rt.cols.group + o, rt.cols.kind + o, rt.cols.from + o, rt.cols.term + o, rt.cols.id + o,
+                             rt.cols.aux + o, rt.cols.flag + o, nullptr, nullptr, 0, now_ms, &j.a)))
         return rc;
+      if (e->stream != L->stream) {  // (its own stream: its own launch)
+        hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(j.a.n, e->count_slots)), dim3(JG_BLOCK), 0, e->stream, j.d, j.a);
+      } else {
+        widest = std::max(widest, j.a.n);
+        jobs.push_back(j);
+      }
       rt.n_in[n] = 0;
     }
-    if (inject && inject[n].n && (rc = jg_step_device_rows(e, &inject[n], now_ms))) return rc;
+    if ((rc = apply_all(0, jobs, widest))) return rc;
+    jobs.clear(), widest = 0;
+    for (uint32_t n = 0; inject && n < R; n++) {
+      jg_engine* e = c->nodes[n];
+      const jg_cmd_batch& b = inject[n];
+      if (!b.n) continue;
+      e->stepped = true;
+      e->seq++;
+      JgApplyJob j{};
+      j.d = e->dev;
+      const uint64_t* none = (const uint64_t*)e->d_ones;  // (injected rows carry no blocks: checked above)
+      if ((rc = prepare_rows(e, (uint32_t)b.n, b.group, b.kind, b.from, b.term, b.id, b.aux, b.flag, none, none, 0, now_ms, &j.a))) return rc;
+      if (e->stream != L->stream) {
+        hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(j.a.n, e->count_slots)), dim3(JG_BLOCK), 0, e->stream, j.d, j.a);
+      } else {
+        widest = std::max(widest, j.a.n);
+        jobs.push_back(j);
+      }
+    }
+    if ((rc = apply_all(1, jobs, widest))) return rc;
   }
   // -- 2. the dense round; ClientRequests only where the lead node (still) leads
   hipLaunchKernelGGL(k_route_mask_appends, dim3((c->G + 255) / 256), dim3(256), 0, L->stream, c->G, (const uint32_t*)L->dev.flags,
                      (const uint64_t*)c->offered, c->acks + (size_t)c->lead * c->G);
-  if ((rc = cluster_round_body(c, now_ms, true))) return rc;
+  if ((rc = cluster_round_body(c, now_ms, true, false, multi ? slice_h(2) : nullptr, multi ? slice_d(2) : nullptr))) return rc;
   T1 = clk();
   // -- 3. the transport, on the lead node's stream behind everybody's round
   for (uint32_t r = 0; r < R; r++)
@@ -2268,15 +2379,49 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
   const uint32_t* h_cursor = rt.h_count + (size_t)R * ROUTE_WORDS;
   for (int attempt = 0;; attempt++) {  // (repeated once when the staging turns out too small: the pass modifies nothing)
     HIPCHK(hipMemsetAsync(rt.d_count, 0, words * 4, st));
+    std::vector<JgRouteRecJob> rjobs;
+    std::vector<JgRouteXqJob> xjobs;
+    uint32_t widest = 0;
     for (uint32_t s = 0; s < R; s++) {
       jg_engine* e = c->nodes[s];
       const JgRouteTable t = table(s);
       for (const StepRec& r : e->recs)
-        if (r.seq > seq_base[s] && r.d_msg)
-          hipLaunchKernelGGL(k_route_rec, dim3((r.n + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS)), dim3(JG_BLOCK), 0, st, t, r.n, r.msg_per_row,
-                             r.seq - seq_base[s], (const uint32_t*)r.d_msg_cnt, (const jg_msg_row*)r.d_msg, (const uint32_t*)r.d_fsm_cnt);
-      hipLaunchKernelGGL(k_route_xq<false>, dim3(1024), dim3(JG_BLOCK), 0, st, t, (const JgXqRec*)e->dev.xq, (const uint32_t*)e->dev.xq_n,
-                         e->dev.xq_cap, seq_base[s], (JgXqRec*)nullptr, (uint32_t*)nullptr);
+        if (r.seq > seq_base[s] && r.d_msg) {
+          if (multi) {
+            JgRouteRecJob j{};
+            j.t = t, j.n = r.n, j.per_row = r.msg_per_row, j.step = r.seq - seq_base[s];
+            j.msg_cnt = r.d_msg_cnt, j.msg = r.d_msg, j.fsm_cnt = r.d_fsm_cnt;
+            rjobs.push_back(j);
+            widest = std::max(widest, r.n);
+          } else {
+            hipLaunchKernelGGL(k_route_rec, dim3((r.n + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS)), dim3(JG_BLOCK), 0, st, t, r.n, r.msg_per_row,
+                               r.seq - seq_base[s], (const uint32_t*)r.d_msg_cnt, (const jg_msg_row*)r.d_msg, (const uint32_t*)r.d_fsm_cnt);
+          }
+        }
+      if (multi) {
+        JgRouteXqJob j{};
+        j.t = t, j.xq = e->dev.xq, j.xq_n = e->dev.xq_n, j.xq_cap = e->dev.xq_cap, j.seq_base = seq_base[s];
+        xjobs.push_back(j);
+      } else {
+        hipLaunchKernelGGL(k_route_xq<false>, dim3(1024), dim3(JG_BLOCK), 0, st, t, (const JgXqRec*)e->dev.xq, (const uint32_t*)e->dev.xq_n,
+                           e->dev.xq_cap, seq_base[s], (JgXqRec*)nullptr, (uint32_t*)nullptr);
+      }
+    }
+    if (multi) {  // every (sender, step) in one launch, every sender's exceptional-row queue in another
+      if (rjobs.size() * sizeof(JgRouteRecJob) > jg_dense_cluster::Route::JOB_SLICE || xjobs.size() * sizeof(JgRouteXqJob) > jg_dense_cluster::Route::JOB_SLICE)
+        return fail(JG_ECAPACITY, "routed round: too many undrained steps for the transport's job table");
+      // (every attempt ends with a synchronisation - the counts - so the staging is free again)
+      const int sa = 3;
+      char* hs = slice_h(sa);
+      const size_t rb = rjobs.size() * sizeof(JgRouteRecJob), xb = xjobs.size() * sizeof(JgRouteXqJob);
+      if (rb + xb > jg_dense_cluster::Route::JOB_SLICE) return fail(JG_ECAPACITY, "routed round: too many undrained steps for the transport's job table");
+      std::memcpy(hs, rjobs.data(), rb);
+      std::memcpy(hs + rb, xjobs.data(), xb);
+      HIPCHK(hipMemcpyAsync(slice_d(sa), hs, rb + xb, hipMemcpyHostToDevice, st));
+      if (!rjobs.empty())
+        hipLaunchKernelGGL(k_route_rec_multi, dim3((widest + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS), (uint32_t)rjobs.size()), dim3(JG_BLOCK), 0, st,
+                           (const JgRouteRecJob*)slice_d(sa));
+      hipLaunchKernelGGL(k_route_xq_multi, dim3(1024, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteXqJob*)(slice_d(sa) + rb));
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(rt.h_count, rt.d_count, words * 4, hipMemcpyDeviceToHost, st));
@@ -2327,8 +2472,32 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
       HIPCHK(hipMemsetAsync(e->dev.xq_n, 0, 4, st));
     }
   }
-  // one sort for all destinations, then the command columns of every node's next round
-  if (total) {
+  // the staged rows in (destination, group, sender, step, emission) order -> the command columns of every
+  // node's next round: bucket by (destination, group tile), sort every bucket in LDS (jg_route.h); the
+  // library sort stays behind JG_ROUTE_LIBRARY_SORT=1 for an A/B
+  static const bool library_sort = std::getenv("JG_ROUTE_LIBRARY_SORT") != nullptr;
+  if (total && !library_sort) {
+    JgRouteBuckets bk{};
+    const uint32_t tile_bits = std::min<uint32_t>(JG_ROUTE_TILE_BITS, rt.group_bits);
+    bk.shift = ord_bits + 5 + tile_bits;
+    bk.n_buckets = R << (rt.group_bits - tile_bits);
+    if (rt.bk_cap < bk.n_buckets + 1) {
+      if (rt.bk_hist) HIPCHK(hipFree(rt.bk_hist));
+      if (rt.bk_cur) HIPCHK(hipFree(rt.bk_cur));
+      rt.bk_cap = bk.n_buckets + 1;
+      HIPCHK(hipMalloc((void**)&rt.bk_hist, (size_t)rt.bk_cap * 4));
+      HIPCHK(hipMalloc((void**)&rt.bk_cur, (size_t)rt.bk_cap * 4));
+    }
+    bk.hist = rt.bk_hist, bk.cur = rt.bk_cur;
+    HIPCHK(hipMemsetAsync(bk.hist, 0, (size_t)(bk.n_buckets + 1) * 4, st));
+    const uint32_t grid = std::min<uint32_t>((total + JG_BLOCK - 1) / JG_BLOCK, 4096);
+    hipLaunchKernelGGL(k_route_hist, dim3(grid), dim3(JG_BLOCK), 0, st, total, (const uint64_t*)rt.key, bk);
+    hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(JG_BLOCK), 0, st, bk);
+    hipLaunchKernelGGL(k_route_scatter, dim3(grid), dim3(JG_BLOCK), 0, st, total, (const uint64_t*)rt.key, (const uint32_t*)rt.idx, bk,
+                       rt.key_alt, rt.idx_alt);
+    hipLaunchKernelGGL(k_route_sort_build, dim3(bk.n_buckets), dim3(JG_BLOCK), 0, st, bk, rt.key_alt, rt.idx_alt, (const jg_msg_row*)rt.row,
+                       rt.cols);
+  } else if (total) {
     const uint32_t end_bit = ord_bits + 5 + rt.group_bits + 3;
     size_t need = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, need, rt.key, rt.key_alt, rt.idx, rt.idx_alt, (size_t)total, 0, end_bit, st));
