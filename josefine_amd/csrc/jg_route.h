@@ -284,11 +284,17 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_build(uint32_t n, const uint
 // its workgroup (slow, exact).
 #define JG_ROUTE_TILE_BITS 8u
 #define JG_ROUTE_SORT_CAP 1024u  // pairs a workgroup sorts in LDS (12 KB: a dozen workgroups per CU)
+#define JG_ROUTE_SCAN_TILE 1024u  // buckets one workgroup of k_route_scan scans (4 per thread, one 16-byte access)
 struct JgRouteBuckets {
   uint32_t n_buckets;
   uint32_t shift;   // key >> shift = bucket id
-  uint32_t* hist;   // [n_buckets + 1] counts, then (after the scan) exclusive offsets
-  uint32_t* cur;    // [n_buckets] scatter cursors
+  uint32_t* hist;   // [n_buckets rounded up to the scan tile] counts, then (after the scan) offsets within the scan tile
+  uint32_t* cur;    // [n_buckets] scatter cursors (zeroed with hist)
+  uint32_t* tile;   // [n_tiles + 1] rows before each scan tile; entry n_tiles: all rows
+  // first staging position of bucket i (i == n_buckets: the number of staged rows)
+  __device__ __forceinline__ uint32_t off(uint32_t i) const {
+    return i >= n_buckets ? tile[(n_buckets + JG_ROUTE_SCAN_TILE - 1u) / JG_ROUTE_SCAN_TILE] : tile[i / JG_ROUTE_SCAN_TILE] + hist[i];
+  }
 };
 // A workgroup's 256 staged pairs sit in a handful of buckets (a sender's output is group-major; a row is
 // staged once per addressee, so neighbouring entries alternate between the destinations' regions): the
@@ -328,20 +334,32 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_hist(uint32_t n, const uint6
     __syncthreads();
   }
 }
+// exclusive scan of the bucket counts in two small launches: every workgroup scans its own tile of 1024 buckets
+// (one 16-byte access per thread; a single workgroup walking all 20 k buckets took 33-56 us), the tile totals
+// (a few dozen) are scanned by one wave's worth of a second launch
 __global__ __launch_bounds__(JG_BLOCK) void k_route_scan(JgRouteBuckets b) {
-  // one workgroup, one pass: every thread sums its own contiguous chunk, one block scan of the 256 chunk sums,
-  // then the chunk's exclusive offsets (20 k buckets in 10 rounds of block scans took 33 us)
-  const uint32_t n = b.n_buckets, per = (n + JG_BLOCK) / JG_BLOCK;  // ceil((n + 1) / JG_BLOCK)
-  const uint32_t lo = threadIdx.x * per, hi = min(lo + per, n + 1u);
-  uint32_t sum = 0;
-  for (uint32_t i = lo; i < hi; i++) sum += i < n ? b.hist[i] : 0u;
+  static_assert(JG_ROUTE_SCAN_TILE == 4 * JG_BLOCK, "4 buckets per thread");
+  uint4* p = (uint4*)(b.hist + (size_t)blockIdx.x * JG_ROUTE_SCAN_TILE) + threadIdx.x;
+  const uint4 v = *p;  // (the array is padded to whole tiles and zeroed)
   uint32_t tot;
-  uint32_t ex = jg_block_exclusive_scan(sum, &tot);
-  for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t v = i < n ? b.hist[i] : 0u;
-    b.hist[i] = ex;  // (entry n: the grand total)
-    if (i < n) b.cur[i] = 0;
-    ex += v;
+  const uint32_t ex = jg_block_exclusive_scan(v.x + v.y + v.z + v.w, &tot);
+  *p = uint4{ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z};
+  if (threadIdx.x == 0) b.tile[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_route_scan_tiles(JgRouteBuckets b) {
+  const uint32_t n_tiles = (b.n_buckets + JG_ROUTE_SCAN_TILE - 1u) / JG_ROUTE_SCAN_TILE;
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base <= n_tiles; base += JG_BLOCK) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < n_tiles ? b.tile[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = carry_s + jg_block_exclusive_scan(v, &tot);
+    __syncthreads();
+    if (i <= n_tiles) b.tile[i] = ex;
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
   }
 }
 __global__ __launch_bounds__(JG_BLOCK) void k_route_scatter(uint32_t n, const uint64_t* __restrict__ key, const uint32_t* __restrict__ idx,
@@ -356,7 +374,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_scatter(uint32_t n, const ui
     if (live) slot = jg_table_add(t, (uint32_t)(k >> b.shift), rank);
     __syncthreads();
     for (uint32_t s = threadIdx.x; s < JG_ROUTE_TABLE; s += JG_BLOCK)  // one reservation per (workgroup, bucket)
-      if (t.key[s]) t.base[s] = b.hist[t.key[s] - 1u] + atomicAdd(&b.cur[t.key[s] - 1u], t.cnt[s]);
+      if (t.key[s]) t.base[s] = b.off(t.key[s] - 1u) + atomicAdd(&b.cur[t.key[s] - 1u], t.cnt[s]);
     __syncthreads();
     if (live) {
       const uint32_t at = t.base[slot] + rank;
@@ -370,7 +388,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_sort_build(JgRouteBuckets b,
                                                                const jg_msg_row* __restrict__ rows, JgRouteCols c) {
   __shared__ uint64_t s_key[JG_ROUTE_SORT_CAP];
   __shared__ uint32_t s_idx[JG_ROUTE_SORT_CAP];
-  const uint32_t lo = b.hist[blockIdx.x], n = b.hist[blockIdx.x + 1] - lo;
+  const uint32_t lo = b.off(blockIdx.x), n = b.off(blockIdx.x + 1) - lo;
   if (!n) return;
   if (n <= JG_ROUTE_SORT_CAP) {
     uint32_t m = 1;

@@ -77,6 +77,20 @@ struct Arena {
     c.off += bytes;
     return hipSuccess;
   }
+  // one chunk of at least `bytes` up front (an idle arena only): a hipMalloc of a few hundred MB takes
+  // 6-8 ms on some boxes, and a workload whose steps grow slowly (the routed round of configs[4]) otherwise pays
+  // one per doubling and node inside its timed region
+  hipError_t reserve(size_t bytes) {
+    for (const Chunk& c : chunks)
+      if (c.off) return hipSuccess;  // in use: leave it alone
+    if (!chunks.empty() && chunks.back().cap >= bytes) return hipSuccess;
+    destroy();
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return e;
+    chunks.push_back(Chunk{(char*)p, bytes, 0});
+    return hipSuccess;
+  }
   void reset() {  // keep the largest chunk
     while (chunks.size() > 1) {
       (void)hipFree(chunks.front().p);
@@ -1915,7 +1929,7 @@ struct jg_dense_cluster {
     std::vector<JgXqRec*> xq_keep;  // per node, lazily: where the exceptional rows that stay are compacted
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
-    uint32_t *bk_hist = nullptr, *bk_cur = nullptr;  // bucket counts / offsets and scatter cursors (k_route_hist ... _sort_build)
+    uint32_t* bk_hist = nullptr;  // bucket counts / offsets, scatter cursors, scan-tile bases (k_route_hist ... _sort_build)
     uint32_t bk_cap = 0;
     // job tables of the round's multi launches (one launch for all nodes / senders / steps): a pinned staging
     // the host fills and its device copy, in slices of JOB_SLICE bytes
@@ -1996,7 +2010,6 @@ void jg_dense_cluster_destroy(jg_dense_cluster* c) {
   if (c->rt.h_jobs) (void)hipHostFree(c->rt.h_jobs);
   if (c->rt.d_jobs) (void)hipFree(c->rt.d_jobs);
   if (c->rt.bk_hist) (void)hipFree(c->rt.bk_hist);
-  if (c->rt.bk_cur) (void)hipFree(c->rt.bk_cur);
   if (c->rt.d_count) (void)hipFree(c->rt.d_count);
   if (c->rt.h_count) (void)hipHostFree(c->rt.h_count);
   delete c;
@@ -2272,7 +2285,11 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
     rt.xq_keep.assign(R, nullptr);
     while (rt.group_bits < 32 && (c->G - 1) >> rt.group_bits) rt.group_bits++;
     if (rt.group_bits > 29) return fail(JG_EINVAL, "routed rounds: too many groups for the transport's ordering key");
-    if ((rc = route_grow(rt, 1))) return rc;
+    // room for a round's worth of rows everywhere, allocated once: 2 rows per partition and node with their output
+    // regions (this is a 288 GB device: 640 B per partition and node is 3.2 GB at 5 x 1 M)
+    if ((rc = route_grow(rt, (size_t)c->G * 2))) return rc;
+    for (jg_engine* e : c->nodes)
+      if (e->recs.empty()) HIPCHK(e->arenas[e->cur_arena].reserve((size_t)c->G * 640));
     rt.ready = true;
   }
   // -- 1. what the transport delivered last round, then this round's injected rows (per group: in that order).
@@ -2481,18 +2498,19 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
     const uint32_t tile_bits = std::min<uint32_t>(JG_ROUTE_TILE_BITS, rt.group_bits);
     bk.shift = ord_bits + 5 + tile_bits;
     bk.n_buckets = R << (rt.group_bits - tile_bits);
-    if (rt.bk_cap < bk.n_buckets + 1) {
+    const uint32_t n_tiles = (bk.n_buckets + JG_ROUTE_SCAN_TILE - 1) / JG_ROUTE_SCAN_TILE;
+    const size_t words = (size_t)n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets + n_tiles + 1;  // hist (whole tiles) | cur | tile
+    if (rt.bk_cap < words) {
       if (rt.bk_hist) HIPCHK(hipFree(rt.bk_hist));
-      if (rt.bk_cur) HIPCHK(hipFree(rt.bk_cur));
-      rt.bk_cap = bk.n_buckets + 1;
-      HIPCHK(hipMalloc((void**)&rt.bk_hist, (size_t)rt.bk_cap * 4));
-      HIPCHK(hipMalloc((void**)&rt.bk_cur, (size_t)rt.bk_cap * 4));
+      rt.bk_cap = (uint32_t)words;
+      HIPCHK(hipMalloc((void**)&rt.bk_hist, words * 4));
     }
-    bk.hist = rt.bk_hist, bk.cur = rt.bk_cur;
-    HIPCHK(hipMemsetAsync(bk.hist, 0, (size_t)(bk.n_buckets + 1) * 4, st));
+    bk.hist = rt.bk_hist, bk.cur = bk.hist + (size_t)n_tiles * JG_ROUTE_SCAN_TILE, bk.tile = bk.cur + bk.n_buckets;
+    HIPCHK(hipMemsetAsync(bk.hist, 0, ((size_t)n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets) * 4, st));  // counts and cursors
     const uint32_t grid = std::min<uint32_t>((total + JG_BLOCK - 1) / JG_BLOCK, 4096);
     hipLaunchKernelGGL(k_route_hist, dim3(grid), dim3(JG_BLOCK), 0, st, total, (const uint64_t*)rt.key, bk);
-    hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(JG_BLOCK), 0, st, bk);
+    hipLaunchKernelGGL(k_route_scan, dim3(n_tiles), dim3(JG_BLOCK), 0, st, bk);
+    hipLaunchKernelGGL(k_route_scan_tiles, dim3(1), dim3(JG_BLOCK), 0, st, bk);
     hipLaunchKernelGGL(k_route_scatter, dim3(grid), dim3(JG_BLOCK), 0, st, total, (const uint64_t*)rt.key, (const uint32_t*)rt.idx, bk,
                        rt.key_alt, rt.idx_alt);
     hipLaunchKernelGGL(k_route_sort_build, dim3(bk.n_buckets), dim3(JG_BLOCK), 0, st, bk, rt.key_alt, rt.idx_alt, (const jg_msg_row*)rt.row,
