@@ -468,6 +468,7 @@ def event_loop_main(args):
         return json.loads(r.stdout.strip().splitlines()[-1])
 
     d = run("inplace", K, W)
+    colm = run("columns", K, W)  # the followers' answers as columns (batched peers), only the client requests as rows
     copy = run("copy", K, W)
     old = run("general", max(3, min(K, 10)), 2)  # round 2's loop: one Tick ROW per partition, the general state machine only
     lb = node_alg_bytes(R)[0] + 4  # the leader half of the node tick + the fsm delta word it leaves behind
@@ -494,6 +495,13 @@ def event_loop_main(args):
             "pcie_bytes_per_tick": {"h2d": d["pcie_h2d_bytes_per_tick"], "d2h": d["pcie_d2h_bytes_per_tick"]},
             "pcie_bytes_per_decision": (d["pcie_h2d_bytes_per_tick"] + d["pcie_d2h_bytes_per_tick"]) * d["ticks"] / d["decisions"],
             "with_two_host_copies_decisions_per_s": copy["decisions_per_s"],
+            "column_inbound": {
+                "what": "the R - 1 followers are batched peers: each ships its answers as ONE column of JG_ANSWER words "
+                        "(jg_node_inbox_columns, written in place), only the ClientRequests are rows",
+                "decisions_per_s": colm["decisions_per_s"], "ms_per_tick": colm["ms_per_tick"],
+                "loop_only_decisions_per_s": colm["decisions"] / ((colm["ms_submit"] + colm["ms_step_and_drain"]) * colm["ticks"] / 1e3),
+                "pcie_bytes_per_tick": {"h2d": colm["pcie_h2d_bytes_per_tick"], "d2h": colm["pcie_d2h_bytes_per_tick"]},
+                "pcie_bytes_per_decision": (colm["pcie_h2d_bytes_per_tick"] + colm["pcie_d2h_bytes_per_tick"]) * colm["ticks"] / colm["decisions"]},
             "round2_loop_decisions_per_s": old["decisions_per_s"],
             "round2_loop": "BatchedEventLoop.dense = false: every row and one Tick ROW per partition through jg_submit + jg_step",
             "speedup_over_round2_loop": d["decisions_per_s"] / old["decisions_per_s"],

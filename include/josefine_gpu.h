@@ -476,6 +476,19 @@ typedef struct jg_node_outbox { /* host pointers into the engine's pinned buffer
   uint64_t bytes_h2d;          /* PCIe: uploaded for this step                                                 */
   uint64_t bytes_d2h;          /* PCIe: outbox columns downloaded for this step (drains not included)          */
 } jg_node_outbox;
+/* Column inbound for jg_step_node: a peer that is itself a batched engine ships its followers' answers as the
+ * column it produced (jg_node_outbox.answer / .hb_commit) instead of two rows per partition.  The call hands out
+ * where member slot `slot`'s column lives in the engine's pinned memory - *answer: [G] JG_ANSWER words (JG_NO_ACK:
+ * nothing from that peer for the partition), *hb_commit: [G] HeartbeatResponse.commit (read only where the word
+ * carries has_committed == 0); the caller fills them IN PLACE before the next jg_step_node, whose leader half applies
+ * them for EVERY partition (after that step's general-path rows), exactly as if each word had been an
+ * AppendResponse / HeartbeatResponse row of a column-form partition.  hb_commit == NULL: the commit is 0 for every
+ * has_committed == 0 response of the column (not uploaded).  The hand-out covers ONE step.  `slot` must not be the
+ * own slot of any partition (that word carries the append count), and a ROW of the same step that names the same
+ * sender is an error (JG_EINVAL at the next synchronising call): a peer speaks columns or rows within one tick.
+ * Single-device engines (or a shard's own handle). */
+int jg_node_inbox_columns(jg_engine* e, uint32_t slot, uint64_t** answer, uint64_t** hb_commit);
+
 /* Apply everything queued by jg_submit since the last step as described above (`flags`: JG_NODE_*; at
  * least one half).  Asynchronous like jg_step except for one synchronisation after the classification
  * (the number of general-path rows sizes that step's launch). */

@@ -222,6 +222,7 @@ class Api:
         "abi_version": (C.c_uint32, []),
         "step_node": (C.c_int, [_P, C.c_uint64, C.c_uint32]),
         "node_outbox_view": (C.c_int, [_P, C.POINTER(NodeOutbox)]),
+        "node_inbox_columns": (C.c_int, [_P, C.c_uint32, C.POINTER(_P), C.POINTER(_P)]),
     }
     # only the device engine has these
     _DEVICE_PROTOS = {
@@ -296,5 +297,5 @@ HEADER_SYMBOLS = [
     "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_drain_prefetch", "jg_drain_flush", "jg_drain_wait", "jg_read_state", "jg_get_counters",
     "jg_device_alloc", "jg_device_free", "jg_device_upload", "jg_device_download",
     "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_dense_cluster_create", "jg_dense_cluster_destroy", "jg_dense_cluster_set_appends", "jg_dense_cluster_rounds", "jg_dense_cluster_mailboxes", "jg_dense_cluster_round_routed", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",
-    "jg_step_node", "jg_node_outbox_view", "jg_submit_reserve", "jg_submit_commit",
+    "jg_step_node", "jg_node_outbox_view", "jg_submit_reserve", "jg_submit_commit", "jg_node_inbox_columns",
 ]

@@ -77,15 +77,20 @@ struct JgNodeRows {  // the step's command rows in device memory, unsorted (stre
   __device__ __forceinline__ uint32_t flag_of(uint32_t i) const { return flag ? flag[i] : 0u; }
 };
 
+// `col_mask`: member slots whose answers arrived as a column (jg_node_inbox_columns: already copied into
+// c.answers): left alone - except where the slot is the group's own, whose word always carries the append count
 __global__ __launch_bounds__(JG_BLOCK) void k_node_prefill(JgDev d, JgNodeCols c, int us, uint32_t leader_half,
-                                                           uint32_t follower_half, uint32_t both_beats) {
+                                                           uint32_t follower_half, uint32_t both_beats, uint32_t col_mask) {
   const uint32_t G = d.G;
   for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
     c.cls[g] = 0;
     c.fsm_delta[g] = 0;
     if (leader_half) {
       const uint32_t s = us >= 0 ? (uint32_t)us : (d.flags[g] & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
-      for (uint32_t r = 0; r < d.R; r++) c.answers[(size_t)r * G + g] = r == s ? JG_ANSWER(0, JG_HB_NONE) : JG_NO_ACK;
+      for (uint32_t r = 0; r < d.R; r++) {
+        if (r == s) c.answers[(size_t)r * G + g] = JG_ANSWER(0, JG_HB_NONE);
+        else if (!((col_mask >> r) & 1u)) c.answers[(size_t)r * G + g] = JG_NO_ACK;
+      }
     }
     if (follower_half) {
       c.f_beat[g] = jg_leader_beat{0, JG_NO_ACK};
@@ -124,7 +129,7 @@ __device__ __forceinline__ bool jg_node_ae_run(const JgNodeRows& a, uint64_t fir
 }
 
 __global__ __launch_bounds__(JG_BLOCK) void k_node_classify(JgDev d, JgNodeCols c, JgNodeRows a, int us, uint32_t halves,
-                                                            uint32_t both_beats) {
+                                                            uint32_t both_beats, uint32_t col_mask) {
   for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < a.n; i += gridDim.x * JG_BLOCK) {
     const uint32_t g = a.group[i];
     const uint32_t kind = a.kind[i];
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_classify(JgDev d, JgNodeCols 
         const uint32_t f = d.flags[g];
         const uint32_t self = us >= 0 ? (uint32_t)us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
         const int s = jg_node_slot_of(d, a.from_of(i));
+        if (s >= 0 && ((col_mask >> s) & 1u)) *d.err = 6;  // this sender's answers arrived as a column: rows AND a column in one tick
         // a sender outside the membership (progress.rs:43 panics on it), the own id (the own slot of the
         // inbox block carries the number of appends), a head a mailbox word cannot hold: general path
         sparse = !(halves & 1u) || s < 0 || (uint32_t)s == self ||

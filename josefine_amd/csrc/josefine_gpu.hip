@@ -321,6 +321,8 @@ struct jg_engine {
     uint64_t *o_ae = nullptr, *o_answer = nullptr, *o_hbc = nullptr;
     jg_leader_beat* h_beat = nullptr;  // pinned mirrors
     uint64_t *h_ae = nullptr, *h_answer = nullptr, *h_hbc = nullptr;
+    uint64_t *h_in_answers = nullptr, *h_in_hbc = nullptr;  // pinned [R][G]: column inbound (jg_node_inbox_columns)
+    uint32_t col_mask = 0, col_hbc_mask = 0;                // slots handed out for the next step / with their hb_commit column
     uint32_t* d_nsparse = nullptr;     // {general-path rows, rocprim::select's count}
     uint32_t* h_nsparse = nullptr;     // pinned
     void* tmp = nullptr;
@@ -483,6 +485,7 @@ int status_check(const jg_engine* e, const uint32_t* st) {
   if (err == 3) return fail(JG_EINVAL, "device command rows name a group out of range");
   if (err == 4) return fail(JG_EDEVICE, "internal: deferred-group list overflow");
   if (err == 5) return fail(JG_EINVAL, "device command rows: an AppendEntries row's block range is outside the side arrays");
+  if (err == 6) return fail(JG_EINVAL, "jg_step_node: a row names a sender whose answers arrived as a column (jg_node_inbox_columns) in the same step");
   if (st[4] > e->dev.xq_cap || st[7] > e->dev.xq_cap)
     return fail(JG_ECAPACITY, "exceptional-message queue overflow: drain the messages more often");
   return JG_OK;
@@ -1303,7 +1306,8 @@ void jg_engine_destroy(jg_engine* e) {
   if (e->h_totals) (void)hipHostFree(e->h_totals);
   e->p_kind.destroy(), e->p_flag.destroy(), e->p_group.destroy(), e->p_from.destroy(), e->p_term.destroy();
   e->p_id.destroy(), e->p_aux.destroy(), e->p_blk_id.destroy(), e->p_blk_next.destroy();
-  for (void* p : {(void*)e->node.h_beat, (void*)e->node.h_ae, (void*)e->node.h_answer, (void*)e->node.h_hbc, (void*)e->node.h_nsparse})
+  for (void* p : {(void*)e->node.h_beat, (void*)e->node.h_ae, (void*)e->node.h_answer, (void*)e->node.h_hbc, (void*)e->node.h_nsparse,
+                  (void*)e->node.h_in_answers, (void*)e->node.h_in_hbc})
     if (p) (void)hipHostFree(p);
   if (e->node.tmp) (void)hipFree(e->node.tmp);
   if (e->node.ev_out) (void)hipEventDestroy(e->node.ev_out);
@@ -1683,6 +1687,8 @@ int node_ensure(jg_engine* e) {
   HIPCHK(hipHostMalloc((void**)&n.h_answer, std::max<size_t>(G * 8, 16), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&n.h_hbc, std::max<size_t>(G * 8, 16), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&n.h_nsparse, 16, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&n.h_in_answers, std::max<size_t>(R * G * 8, 16), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&n.h_in_hbc, std::max<size_t>(R * G * 8, 16), hipHostMallocDefault));
   HIPCHK(hipEventCreateWithFlags(&n.ev_out, hipEventDisableTiming));
   while (n.group_bits < 32 && (G - 1) >> n.group_bits) n.group_bits++;
   n.ready = true;
@@ -1707,9 +1713,28 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   double T1 = T0, T2 = T0;
   const uint32_t both_beats = (e->p_kinds_seen & 3u) == 3u;  // (a batch with Heartbeat AND AppendEntries rows: their consistency columns are needed)
   const uint32_t ggrid = grid_for(G, 4096);
-  hipLaunchKernelGGL(k_node_prefill, dim3(ggrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, e->uniform_self,
-                     halves & JG_NODE_LEADER_HALF, halves & JG_NODE_FOLLOWER_HALF, both_beats);
   uint64_t bytes_up = 0;
+  // column inbound: the handed-out slots' columns go up as they are (8 bytes per partition and peer instead of two rows)
+  const uint32_t col_mask = (halves & JG_NODE_LEADER_HALF) ? nd.col_mask : 0u;
+  for (uint32_t r = 0; r < R;) {  // (neighbouring slots travel in one copy: a copy costs ~10 us before its first byte)
+    if (!((col_mask >> r) & 1u)) {
+      r++;
+      continue;
+    }
+    uint32_t r1 = r + 1;
+    while (r1 < R && ((col_mask >> r1) & 1u) && (((nd.col_hbc_mask >> r1) & 1u) == ((nd.col_hbc_mask >> r) & 1u))) r1++;
+    const size_t at = (size_t)r * G, len = (size_t)(r1 - r) * G * 8;
+    HIPCHK(hipMemcpyAsync(nd.cols.answers + at, nd.h_in_answers + at, len, hipMemcpyHostToDevice, e->stream));
+    if ((nd.col_hbc_mask >> r) & 1u)
+      HIPCHK(hipMemcpyAsync(nd.cols.hbr_commit + at, nd.h_in_hbc + at, len, hipMemcpyHostToDevice, e->stream));
+    else
+      HIPCHK(hipMemsetAsync(nd.cols.hbr_commit + at, 0, len, e->stream));
+    bytes_up += len * (((nd.col_hbc_mask >> r) & 1u) ? 2 : 1);
+    r = r1;
+  }
+  nd.col_mask = nd.col_hbc_mask = 0;  // (a hand-out covers one step)
+  hipLaunchKernelGGL(k_node_prefill, dim3(ggrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, e->uniform_self,
+                     halves & JG_NODE_LEADER_HALF, halves & JG_NODE_FOLLOWER_HALF, both_beats, col_mask);
   uint32_t n_sparse = 0;
   if (n) {
     // the rows in stream order, straight out of the pinned columns jg_submit (or the caller, in place:
@@ -1757,7 +1782,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     const uint32_t rgrid = grid_for(n, 4096);
     HIPCHK(hipMemsetAsync(nd.d_nsparse, 0, 8, e->stream));
     hipLaunchKernelGGL(k_node_classify, dim3(rgrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rows, e->uniform_self,
-                       halves, both_beats);
+                       halves, both_beats, col_mask);
     hipLaunchKernelGGL(k_node_route, dim3(rgrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rows, e->uniform_self,
                        both_beats, d_keep, nd.d_nsparse);
     HIPCHK(hipGetLastError());
@@ -1876,6 +1901,28 @@ int jg_step_node(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   if (e->router) return router_step_node(e, now_ms, flags);
   if (e->inflight.phase) return fail(JG_EINVAL, "a drain is in transfer: jg_drain_wait first");
   return node_step(e, now_ms, flags);
+}
+
+int jg_node_inbox_columns(jg_engine* e, uint32_t slot, uint64_t** answer, uint64_t** hb_commit) {
+  if (!e || !answer) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "jg_node_inbox_columns: the columns are per shard: call this on a shard handle (jg_get_shard)");
+  if (slot >= e->cfg.n_replicas) return fail(JG_EINVAL, "slot out of range");
+  if (e->uniform_self >= 0 && (uint32_t)e->uniform_self == slot)
+    return fail(JG_EINVAL, "jg_node_inbox_columns: the own slot's word carries the append count");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = node_ensure(e);
+  if (rc) return rc;
+  jg_engine::NodeStep& nd = e->node;
+  const size_t G = e->cfg.n_groups;
+  *answer = nd.h_in_answers + (size_t)slot * G;
+  nd.col_mask |= 1u << slot;
+  if (hb_commit) {
+    *hb_commit = nd.h_in_hbc + (size_t)slot * G;
+    nd.col_hbc_mask |= 1u << slot;
+  } else {
+    nd.col_hbc_mask &= ~(1u << slot);
+  }
+  return JG_OK;
 }
 
 int jg_node_outbox_view(jg_engine* e, jg_node_outbox* out) {

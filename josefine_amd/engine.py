@@ -300,6 +300,17 @@ class BatchedRaft:
                 "hb_commit": arr(o.hb_commit, np.uint64, (G,)), "rows": int(o.rows), "rows_general": int(o.rows_general),
                 "bytes_h2d": int(o.bytes_h2d), "bytes_d2h": int(o.bytes_d2h)}
 
+    def node_inbox_columns(self, slot: int, answer, hb_commit=None) -> None:
+        """jg_node_inbox_columns: member slot `slot`'s AppendResponse / HeartbeatResponse for every partition
+        as ONE column of JG_ANSWER words (and, optionally, the HeartbeatResponse.commit column) for the next
+        step_node - what a batched peer ships instead of two rows per partition."""
+        pa, ph = C.c_void_p(), C.c_void_p()
+        self._check(self.api.node_inbox_columns(self._h, int(slot), C.byref(pa), C.byref(ph) if hb_commit is not None else None))
+        G = self.G
+        np.frombuffer((C.c_char * (8 * G)).from_address(pa.value), dtype=np.uint64)[:] = np.asarray(answer, dtype=np.uint64)
+        if hb_commit is not None:
+            np.frombuffer((C.c_char * (8 * G)).from_address(ph.value), dtype=np.uint64)[:] = np.asarray(hb_commit, dtype=np.uint64)
+
     def upload_rows(self, kind, group, from_=None, term=None, id=None, aux=None, flag=None,
                     blk_id=None, blk_next=None) -> "DeviceRows":
         """Sort a command batch by group (stable) on the host and park it in device memory for

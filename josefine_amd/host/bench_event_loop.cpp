@@ -13,6 +13,8 @@
 // modes
 //   inplace   the "transport" writes the rows straight into the engine's pinned columns
 //             (jg_submit_reserve / jg_submit_commit): no host copy at all
+//   columns   the followers are batched peers: each ships its answers as the column it produced (one JG_ANSWER word
+//             per partition: jg_node_inbox_columns), written in place; only the ClientRequests are rows
 //   copy      rows handed over as a jg_cmd_batch (BatchedEventLoop::tcp_rx_rows + run_until): two host copies
 //   general   round 2's loop: every row and one Tick ROW per partition through jg_submit + jg_step (the
 //             general state machine, host radix sort) - the A/B
@@ -112,7 +114,23 @@ int main(int argc, char** argv) {
       const uint64_t now = 100ull * (t + 1);
       const size_t n = rows_of_tick(t);
       auto a = Clock::now();
-      if (mode == "inplace") {
+      if (mode == "columns") {
+        const bool hb = t & 1;
+        for (uint32_t r = 1; r < R; r++) {  // peer r's answers to last tick's Heartbeat / AppendEntries: one word per partition
+          uint64_t* ans = nullptr;
+          loop.tcp_rx_answer_column(r, &ans, nullptr);
+          const uint64_t w = JG_ANSWER((uint64_t)t, hb ? 1u : JG_HB_NONE);
+          for (uint32_t g = 0; g < G; g++) ans[g] = w;
+        }
+        const jg_cmd_cols c = loop.tcp_rx_reserve(G);
+        for (uint32_t k = 0; k < G; k++) c.kind[k] = JG_CMD_CLIENT_REQUEST, c.group[k] = perm[k], c.id[k] = (uint64_t)t * G + perm[k];
+        t_fill += ms_since(a), a = Clock::now();
+        loop.tcp_rx_commit(G, 0, 0);
+        t_submit += ms_since(a), a = Clock::now();
+        loop.run_until(now);
+        t_step += ms_since(a);
+        rows_in += G - n;  // (n is added below: count the rows actually submitted)
+      } else if (mode == "inplace") {
         const jg_cmd_cols c = loop.tcp_rx_reserve(n);
         const size_t k = fill(t, c.kind, c.group, c.from, c.id, c.flag);
         t_fill += ms_since(a), a = Clock::now();

@@ -214,6 +214,9 @@ class BatchedRaft {
     return c;
   }
   void commit_rows(size_t n, size_t n_blocks, uint32_t optional_columns) { check(jg_submit_commit(e_, n, n_blocks, optional_columns)); }
+  // column inbound (jg_node_inbox_columns): where member slot `slot`'s answer words (and HeartbeatResponse.commit
+  // values) for the next step_node are to be written, in the engine's pinned memory
+  void inbox_columns(uint32_t slot, uint64_t** answer, uint64_t** hb_commit) { check(jg_node_inbox_columns(e_, slot, answer, hb_commit)); }
   const jg_node_outbox& last_outbox() const { return last_outbox_; }
   // payload mirrors for rows that were queued in bulk (submit_rows): a ClientRequest's proposal, a block's data
   void note_proposal(uint32_t g, uint64_t request_id, std::vector<uint8_t> proposal) { pending_reqs_[{g, request_id}] = std::move(proposal); }
@@ -576,6 +579,12 @@ class BatchedEventLoop {
   void tcp_rx_commit(size_t n, size_t n_blocks, uint32_t optional_columns) {
     raft_.commit_rows(n, n_blocks, optional_columns);
     direct_rows_ += n;
+  }
+  // ... and a batched peer ships its answers as the COLUMN it produced (jg_node_outbox.answer): 8 bytes per partition
+  // instead of two rows; filled in place, applied by the next step's leader half (hb_commit == nullptr: not needed)
+  void tcp_rx_answer_column(uint32_t peer_slot, uint64_t** answer, uint64_t** hb_commit) {
+    raft_.inbox_columns(peer_slot, answer, hb_commit);
+    direct_rows_ += 1;  // (something to apply even without a Tick)
   }
   // RaftClient::propose (client.rs:35): returns the request id (Uuid::new_v4 -> a counter)
   uint64_t propose(uint32_t group, std::vector<uint8_t> proposal, Response on_response) {

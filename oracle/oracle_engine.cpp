@@ -35,6 +35,8 @@ struct jo_engine {
   std::vector<jg_leader_beat> n_f_beat, n_o_beat;
   std::vector<uint32_t> n_f_leader;
   std::vector<jg_fsm_row> n_fsm;  // fsm rows of the dense halves of the step in progress
+  std::vector<uint64_t> n_in_answers, n_in_hbc;  // jo_node_inbox_columns: [R][G] columns handed out for the next step
+  uint32_t n_col_mask = 0, n_col_hbc_mask = 0;
   std::vector<jg_msg_row> v_msgs;  // rows handed out by the *_view drains
   std::vector<jg_fsm_row> v_fsms;
   bool node_keep_fsm = false;
@@ -673,6 +675,16 @@ int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
   e->n_f_ae.assign(G, JG_NO_ACK);
   e->n_f_leader.assign(G, 0);
   for (uint32_t g = 0; g < G; g++) e->n_answers[(size_t)e->self_slot[g] * G + g] = JG_ANSWER(0, JG_HB_NONE);
+  // column inbound (jo_node_inbox_columns): a sender that spoke a column this step may not also speak rows
+  const uint32_t col_mask = lead_half ? e->n_col_mask : 0u, col_hbc = e->n_col_hbc_mask;
+  e->n_col_mask = e->n_col_hbc_mask = 0;
+  if (col_mask)
+    for (uint32_t g : e->touched)
+      for (const Cmd& c : e->pending[g])
+        if (c.kind == JG_CMD_APPEND_RESPONSE || c.kind == JG_CMD_HEARTBEAT_RESPONSE) {
+          const int s = slot_of_id(e, c.from);
+          if (s >= 0 && ((col_mask >> s) & 1u)) return fail(JG_EINVAL, "jg_step_node: a row names a sender whose answers arrived as a column");
+        }
   // pass 1: which mailbox entries each partition's rows fill; what cannot be a column
   struct Cls {
     uint32_t seen = 0;  // bits 0-7 AppendResponse per slot, 8-15 HeartbeatResponse per slot, 16 Heartbeat, 17 AppendEntries, 18 ClientRequest
@@ -776,6 +788,16 @@ int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
     }
     e->pending[g].clear();
   }
+  // the columns: every partition's word of a handed-out slot, as if it had been that peer's rows (the own slot's word
+  // stays what it is: the append count)
+  for (uint32_t q = 0; q < R; q++) {
+    if (!((col_mask >> q) & 1u)) continue;
+    for (uint32_t g = 0; g < G; g++) {
+      if (q == e->self_slot[g]) continue;
+      e->n_answers[(size_t)q * G + g] = e->n_in_answers[(size_t)q * G + g];
+      e->n_hbr[(size_t)q * G + g] = ((col_hbc >> q) & 1u) ? e->n_in_hbc[(size_t)q * G + g] : 0;
+    }
+  }
   e->touched.swap(still);
   int rc = jo_step(e, now_ms);  // the general path, first
   if (rc) return rc;
@@ -807,6 +829,24 @@ int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
   e->n_last.rows = n_rows, e->n_last.rows_general = n_general;
   e->n_last_flags = flags;
   return rc;
+}
+
+int jo_node_inbox_columns(jo_engine* e, uint32_t slot, uint64_t** answer, uint64_t** hb_commit) {
+  const size_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  if (slot >= R) return fail(JG_EINVAL, "slot out of range");
+  bool uniform = true;
+  for (size_t g = 1; g < G; g++) uniform = uniform && e->self_slot[g] == e->self_slot[0];
+  if (uniform && e->self_slot[0] == slot) return fail(JG_EINVAL, "jg_node_inbox_columns: the own slot's word carries the append count");
+  e->n_in_answers.resize(R * G), e->n_in_hbc.resize(R * G);
+  *answer = e->n_in_answers.data() + slot * G;
+  e->n_col_mask |= 1u << slot;
+  if (hb_commit) {
+    *hb_commit = e->n_in_hbc.data() + slot * G;
+    e->n_col_hbc_mask |= 1u << slot;
+  } else {
+    e->n_col_hbc_mask &= ~(1u << slot);
+  }
+  return JG_OK;
 }
 
 int jo_node_outbox_view(jo_engine* e, jg_node_outbox* out) {

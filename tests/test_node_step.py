@@ -275,3 +275,108 @@ def test_absent_columns_and_in_place_submit():
     np.frombuffer((C.c_char * 1).from_address(c.kind), dtype=np.uint8)[0] = capi.CMD_APPEND_ENTRIES
     np.frombuffer((C.c_char * 4).from_address(c.group), dtype=np.uint32)[0] = 0
     assert dev.api.submit_commit(dev._h, 1, 0, capi.COL_FROM) == capi.EINVAL
+
+
+def split_columns(cols, ora, col_slots):
+    """Move the AppendResponse / HeartbeatResponse rows of `col_slots` out of a traffic batch into answer /
+    hb_commit columns (one word per partition and slot; a second row for the same entry is dropped: a column
+    has one)."""
+    G = ora.G
+    ids = list(ora.node_ids)
+    answer = {r: np.full(G, capi.NO_ACK, np.uint64) for r in col_slots}
+    hbc = {r: np.zeros(G, np.uint64) for r in col_slots}
+    keep = np.ones(len(cols["kind"]), bool)
+    for i in range(len(cols["kind"])):
+        k, f = int(cols["kind"][i]), int(cols["from_"][i])
+        if k not in (capi.CMD_APPEND_RESPONSE, capi.CMD_HEARTBEAT_RESPONSE) or f not in ids or ids.index(f) not in col_slots:
+            continue
+        r, g = ids.index(f), int(cols["group"][i])
+        keep[i] = False
+        w = int(answer[r][g])
+        if k == capi.CMD_APPEND_RESPONSE:
+            if int(cols["id"][i]) >= capi.MAILBOX_NONE or (w >> 8) != capi.MAILBOX_NONE:
+                continue
+            w = (int(cols["id"][i]) << 8) | (w & 0xff)
+        else:
+            if (w & 0xff) != capi.HB_NONE:
+                continue
+            has = 1 if cols["flag"][i] else 0
+            w = (w & ~0xff) | has
+            if not has:
+                hbc[r][g] = cols["id"][i]
+        answer[r][g] = w
+    rest = {k: (v[keep] if k not in ("blk_id", "blk_next") else v) for k, v in cols.items()}
+    return rest, answer, hbc
+
+
+@pytest.mark.parametrize("R", [3, 5])
+def test_oracle_column_inbound_is_the_row_inbound(R):
+    """jo_node_inbox_columns: a peer's answers as ONE column are indistinguishable from the same answers as rows
+    (for partitions in column form: with noise-free leader traffic every led partition is)."""
+    G, T = 300, 40
+    rows_e, cols_e, rng = mixed_pair(oracle_engine, oracle_engine, G, R, seed=31 + R, flags=capi.CFG_SEPARATE_COMMIT_KEY,
+                                     election_timeout_ms=(700, 1500))
+    col_slots = list(range(1, R))
+    for t in range(T):
+        now = 100 * (t + 1)
+        cols = node_traffic(rng, rows_e, token0=1000 * t, p_noise=0.0)
+        rest, answer, hbc = split_columns(cols, rows_e, col_slots)
+        # the row engine gets exactly what the columns hold (duplicates dropped), as rows
+        kept_rows = []
+        for r in col_slots:
+            ack = answer[r] >> np.uint64(8)
+            for g in np.nonzero(answer[r] != np.uint64(capi.NO_ACK))[0]:
+                w = int(answer[r][g])
+                if (w & 0xff) != capi.HB_NONE:
+                    kept_rows.append((capi.CMD_HEARTBEAT_RESPONSE, int(g), rows_e.node_ids[r], 0, int(hbc[r][g]), 0, w & 0xff, None))
+                if (w >> 8) != capi.MAILBOX_NONE:
+                    kept_rows.append((capi.CMD_APPEND_RESPONSE, int(g), rows_e.node_ids[r], 0, int(ack[g]), 0, 1, None))
+        from node_step import rows_to_columns
+        extra = rows_to_columns(kept_rows)
+        rows_e.submit_columns(**rest)
+        rows_e.submit_columns(**{k: v for k, v in extra.items()})
+        for r in col_slots:
+            cols_e.node_inbox_columns(r, answer[r], hbc[r])
+        cols_e.submit_columns(**rest)
+        a, b = rows_e.step_node(now), cols_e.step_node(now)
+        for k in ("beat_term", "beat_commit", "ae", "answer"):
+            assert np.array_equal(a[k], b[k]), (t, k)
+        compare_snapshots(cols_e, rows_e, f"tick {t}")
+        compare_drains(cols_e, rows_e, f"tick {t}")
+    assert rows_e.counters()["decisions"] == cols_e.counters()["decisions"] > G
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,with_hbc", [(3, True), (5, True), (5, False)])
+def test_node_step_column_inbound_parity(R, with_hbc):
+    """jg_node_inbox_columns on the device == the oracle's: answers of the other members as columns, everything
+    else (client requests, the follower side, the noise) as rows; with and without the hb_commit column."""
+    G, T = 2500, 40
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=41 + R, election_timeout_ms=(700, 1500))
+    col_slots = list(range(1, R))
+    for t in range(T):
+        now = 100 * (t + 1)
+        cols = node_traffic(rng, ora, token0=1000 * t)
+        rest, answer, hbc = split_columns(cols, ora, col_slots)
+        outs = []
+        for e in (dev, ora):
+            for r in col_slots:
+                e.node_inbox_columns(r, answer[r], hbc[r] if with_hbc else None)
+            e.submit_columns(**rest)
+            outs.append(e.step_node(now))
+        compare_outboxes(outs[0], outs[1], f"tick {t}")
+        compare_snapshots(dev, ora, f"tick {t}")
+        compare_drains(dev, ora, f"tick {t}")
+    assert dev.counters()["decisions"] == ora.counters()["decisions"]
+    # rows AND a column from one sender in one step: refused, on both
+    from josefine_amd import EngineError
+    one = dict(kind=np.array([capi.CMD_APPEND_RESPONSE], np.uint8), group=np.array([0], np.uint32), from_=np.array([dev.node_ids[1]], np.uint32),
+               id=np.array([0], np.uint64))
+    for e in (ora, dev):
+        e.node_inbox_columns(1, np.full(G, capi.NO_ACK, np.uint64))
+        e.submit_columns(**one)
+        with pytest.raises(EngineError):
+            e.step_node(5000)
+            e.read("term")
+    with pytest.raises(EngineError):
+        dev.node_inbox_columns(0, np.zeros(G, np.uint64))  # the own slot
