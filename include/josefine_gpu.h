@@ -537,7 +537,10 @@ int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_lead
  *      ClientRequest rows (instructions to the host adapter about its request mirror): those, and
  *      everything addressed elsewhere, stay queued for jg_drain_messages, as do FSM rows.
  * A sender whose round left nothing for the host needs no drain (its output regions are recycled).
- * The nodes must share a device.  Synchronises with the host once per call (row counts). */
+ * The nodes must share a device.  Synchronises with the host once per call (row counts).  Arguments are checked
+ * before anything is launched; an error after the round has begun to consume the delivered rows (a HIP failure,
+ * an internal inconsistency) leaves messages lost in flight: the cluster is marked failed and every later call
+ * returns JG_EDEVICE - destroy it. */
 typedef struct jg_route_stats {
   uint64_t delivered[JG_MAX_REPLICAS]; /* rows queued for node n's next routed round                   */
   uint64_t kept;                       /* message rows of this round left for jg_drain_messages        */

@@ -1949,6 +1949,7 @@ struct jg_dense_cluster {
   // round cost more host time than the round's kernels take on the device)
   JgClock* clock = nullptr;
   JgFollowerJob* d_jobs = nullptr;  // the follower halves of a replayed round as ONE launch (k_follower_tick_dense_multi)
+  bool failed = false;  // a routed round failed after it had consumed the delivered rows: the in-flight votes are gone
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   uint64_t sig = 0, graph_dt = 0;
@@ -2300,8 +2301,19 @@ int route_grow(jg_dense_cluster::Route& d, size_t need) {
 }
 }  // namespace
 
+static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_batch* inject, jg_route_stats* stats, bool* started);
 int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_batch* inject, jg_route_stats* stats) {
   if (!c) return fail(JG_EINVAL, "null argument");
+  // Everything that can be checked is checked before the first launch; an error AFTER the round has begun to
+  // consume the rows the transport delivered (a HIP failure, an internal inconsistency) leaves in-flight messages
+  // lost or half-routed: the cluster says so from then on instead of carrying on quietly.
+  if (c->failed) return fail(JG_EDEVICE, "jg_dense_cluster_round_routed: an earlier routed round failed half-way: destroy the cluster");
+  bool started = false;
+  const int rc = round_routed_impl(c, now_ms, inject, stats, &started);
+  if (rc && started) c->failed = true;
+  return rc;
+}
+static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_batch* inject, jg_route_stats* stats, bool* started) {
   jg_engine* L = c->nodes[c->lead];
   const uint32_t R = c->R;
   int rc = JG_OK;
@@ -2369,6 +2381,7 @@ int jg_dense_cluster_round_routed(jg_dense_cluster* c, uint64_t now_ms, const jg
   };
   std::vector<uint32_t> seq_base(R);
   for (uint32_t n = 0; n < R; n++) seq_base[n] = c->nodes[n]->seq;
+  *started = true;
   {
     std::vector<JgApplyJob> jobs;
     uint32_t widest = 0;
