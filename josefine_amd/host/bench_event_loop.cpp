@@ -19,13 +19,23 @@
 //   general   round 2's loop: every row and one Tick ROW per partition through jg_submit + jg_step (the
 //             general state machine, host radix sort) - the A/B
 // Both channels are consumed by batch sinks that read every byte they are handed (a 64-bit sum).
+//
+// loops (argument 7, default 1): the process hosts the G partitions on that many event loops, one thread and
+// one engine (its own HIP stream) each, G / loops partitions per loop - the reference runs one event_loop task
+// per partition on tokio's worker threads (src/raft/server.rs:103, src/lib.rs); here a loop is a BATCH of
+// partitions.  While one loop waits for its step, the others decode, commit and consume: host work, PCIe
+// transfers (both directions) and kernels of different loops overlap.  The timed region starts when every loop
+// has finished its warm-up ticks and ends when the last loop has finished its last tick.
 // Prints one JSON object.
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 
 #include "raft_handle.hpp"
 
@@ -40,17 +50,41 @@ static uint64_t sum_words(const void* p, size_t bytes) {
   return s;
 }
 
-int main(int argc, char** argv) {
-  const uint32_t G = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 100000;
-  const uint32_t R = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 5;
-  const uint32_t T = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 50;
-  const uint32_t W = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 10;
-  const std::string mode = argc > 5 ? argv[5] : "inplace";
-  const int device = argc > 6 ? std::atoi(argv[6]) : 0;
+// every loop arrives; the last one to arrive stamps the time all of them then share
+struct Rendezvous {
+  std::mutex m;
+  std::condition_variable cv;
+  uint32_t n, here = 0, round = 0;
+  Clock::time_point stamp{};
+  explicit Rendezvous(uint32_t n_) : n(n_) {}
+  Clock::time_point arrive() {
+    std::unique_lock<std::mutex> lk(m);
+    const uint32_t r = round;
+    if (++here == n) {
+      here = 0, round++, stamp = Clock::now();
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return round != r; });
+    }
+    return stamp;
+  }
+};
+struct LoopResult {
+  bool ok = false;
+  std::string error;
+  uint64_t decisions = 0, rows_in = 0, general = 0, fsm_rows = 0, msg_rows = 0, up_bytes = 0, down_bytes = 0, sink = 0;
+  double wall_ms = 0, t_fill = 0, t_submit = 0, t_step = 0;
+  float k_us = 0;
+  uint32_t k_n = 0;
+};
+
+static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::string& mode, int device, uint64_t seed,
+                     Rendezvous& rv, LoopResult& out) {
+  bool started = false, finished = false;  // (a loop that fails still arrives: the others must not wait for ever)
   try {
     std::vector<NodeId> ids;
     for (uint32_t r = 0; r < R; r++) ids.push_back(r + 1);
-    BatchedRaft raft(G, ids, device, 42, JG_CFG_SEPARATE_COMMIT_KEY);
+    BatchedRaft raft(G, ids, device, seed, JG_CFG_SEPARATE_COMMIT_KEY);
     BatchedEventLoop loop(raft, G);
     loop.halves = JG_NODE_LEADER_HALF;  // this node leads every partition
     loop.dense = mode != "general";
@@ -76,7 +110,7 @@ int main(int argc, char** argv) {
     // a fixed shuffle of the partitions: rows arrive in no particular order
     std::vector<uint32_t> perm(G);
     std::iota(perm.begin(), perm.end(), 0u);
-    uint64_t x = 88172645463325252ull;
+    uint64_t x = 88172645463325252ull + seed;
     for (uint32_t i = G - 1; i > 0; i--) {
       x ^= x << 13, x ^= x >> 7, x ^= x << 17;
       std::swap(perm[i], perm[(uint32_t)(x % (i + 1))]);
@@ -109,7 +143,7 @@ int main(int argc, char** argv) {
         if (jg_sync(raft.raw()) != JG_OK || jg_get_counters(raft.raw(), c0) != JG_OK) throw std::runtime_error("counters");
         sink = fsm_rows = msg_rows = col_bytes = up_bytes = general = rows_in = 0;
         t_fill = t_submit = t_step = 0;
-        t_begin = Clock::now();
+        t_begin = rv.arrive(), started = true;
       }
       const uint64_t now = 100ull * (t + 1);
       const size_t n = rows_of_tick(t);
@@ -152,11 +186,11 @@ int main(int argc, char** argv) {
       }
       rows_in += n;
     }
-    const double wall_ms = ms_since(t_begin);
+    const Clock::time_point t_end = rv.arrive();
+    finished = true;
+    out.wall_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
     if (jg_sync(raft.raw()) != JG_OK || jg_get_counters(raft.raw(), c1) != JG_OK) throw std::runtime_error("counters");
-    float k_us = 0;
-    uint32_t k_n = 0;
-    (void)jg_kernel_timing_read(raft.raw(), &k_us, &k_n);
+    (void)jg_kernel_timing_read(raft.raw(), &out.k_us, &out.k_n);
     // the closed form of this stream: every leader appended one block per tick and committed the previous one
     std::vector<uint64_t> head(G), commit(G);
     std::vector<uint8_t> fault(G);
@@ -165,19 +199,56 @@ int main(int argc, char** argv) {
     jg_read_state(raft.raw(), JG_FIELD_FAULT, 0, fault.data(), 0, G);
     bool ok = true;
     for (uint32_t g = 0; g < G; g++) ok = ok && head[g] == W + T && commit[g] == W + T - 1 && fault[g] == 0;
-    const uint64_t decisions = c1[1] - c0[1];
-    const uint64_t down = col_bytes + fsm_rows * sizeof(jg_fsm_row) + msg_rows * sizeof(jg_msg_row);
-    std::printf("{\"ok\": %s, \"mode\": \"%s\", \"G\": %u, \"R\": %u, \"ticks\": %u, \"warmup\": %u, \"decisions\": %llu, \"wall_ms\": %.3f, "
-                "\"decisions_per_s\": %.6g, \"ms_per_tick\": %.4f, \"ms_fill\": %.4f, \"ms_submit\": %.4f, \"ms_step_and_drain\": %.4f, "
-                "\"rows_in_per_tick\": %.1f, \"rows_general\": %llu, \"fsm_rows_per_tick\": %.1f, \"msg_rows_per_tick\": %.1f, "
-                "\"pcie_h2d_bytes_per_tick\": %.1f, \"pcie_d2h_bytes_per_tick\": %.1f, \"leader_kernel_us\": %.3f, \"leader_kernel_launches\": %u, "
-                "\"sink\": %llu}\n",
-                ok ? "true" : "false", mode.c_str(), G, R, T, W, (unsigned long long)decisions, wall_ms, decisions / (wall_ms / 1e3), wall_ms / T,
-                t_fill / T, t_submit / T, t_step / T, (double)rows_in / T, (unsigned long long)general, (double)fsm_rows / T, (double)msg_rows / T,
-                (double)up_bytes / T, (double)down / T, k_us, k_n, (unsigned long long)sink);
-    return ok ? 0 : 1;
+    out.decisions = c1[1] - c0[1];
+    out.down_bytes = col_bytes + fsm_rows * sizeof(jg_fsm_row) + msg_rows * sizeof(jg_msg_row);
+    out.rows_in = rows_in, out.general = general, out.fsm_rows = fsm_rows, out.msg_rows = msg_rows, out.up_bytes = up_bytes, out.sink = sink;
+    out.t_fill = t_fill, out.t_submit = t_submit, out.t_step = t_step;
+    out.ok = ok;
   } catch (const std::exception& e) {
-    std::fprintf(stderr, "exception: %s\n", e.what());
+    out.ok = false, out.error = e.what();
+    if (!started) rv.arrive();
+    if (!finished) rv.arrive();
+  }
+}
+
+int main(int argc, char** argv) {
+  const uint32_t G = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 100000;
+  const uint32_t R = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 5;
+  const uint32_t T = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 50;
+  const uint32_t W = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 10;
+  const std::string mode = argc > 5 ? argv[5] : "inplace";
+  const int device = argc > 6 ? std::atoi(argv[6]) : 0;
+  const uint32_t L = argc > 7 ? (uint32_t)std::max(1, std::atoi(argv[7])) : 1;
+  if (G % L) {
+    std::fprintf(stderr, "the partitions do not divide over %u loops\n", L);
     return 2;
   }
+  Rendezvous rv(L);
+  std::vector<LoopResult> res(L);
+  std::vector<std::thread> th;
+  for (uint32_t l = 1; l < L; l++) th.emplace_back([&, l] { run_loop(G / L, R, T, W, mode, device, 42 + l, rv, res[l]); });
+  run_loop(G / L, R, T, W, mode, device, 42, rv, res[0]);
+  for (std::thread& t : th) t.join();
+  LoopResult a;
+  a.ok = true;
+  double k_us = 0;
+  for (const LoopResult& r : res) {
+    if (!r.ok) std::fprintf(stderr, "loop failed: %s\n", r.error.empty() ? "the closed form of the stream is violated" : r.error.c_str());
+    a.ok = a.ok && r.ok;
+    a.decisions += r.decisions, a.rows_in += r.rows_in, a.general += r.general, a.fsm_rows += r.fsm_rows, a.msg_rows += r.msg_rows;
+    a.up_bytes += r.up_bytes, a.down_bytes += r.down_bytes, a.sink += r.sink;
+    a.wall_ms = std::max(a.wall_ms, r.wall_ms);
+    a.t_fill += r.t_fill / L, a.t_submit += r.t_submit / L, a.t_step += r.t_step / L;  // (per loop: they run side by side)
+    k_us += r.k_us / L, a.k_n += r.k_n;
+  }
+  std::printf("{\"ok\": %s, \"mode\": \"%s\", \"G\": %u, \"R\": %u, \"loops\": %u, \"ticks\": %u, \"warmup\": %u, \"decisions\": %llu, \"wall_ms\": %.3f, "
+              "\"decisions_per_s\": %.6g, \"ms_per_tick\": %.4f, \"ms_fill\": %.4f, \"ms_submit\": %.4f, \"ms_step_and_drain\": %.4f, "
+              "\"rows_in_per_tick\": %.1f, \"rows_general\": %llu, \"fsm_rows_per_tick\": %.1f, \"msg_rows_per_tick\": %.1f, "
+              "\"pcie_h2d_bytes_per_tick\": %.1f, \"pcie_d2h_bytes_per_tick\": %.1f, \"leader_kernel_us\": %.3f, \"leader_kernel_launches\": %u, "
+              "\"sink\": %llu}\n",
+              a.ok ? "true" : "false", mode.c_str(), G, R, L, T, W, (unsigned long long)a.decisions, a.wall_ms, a.decisions / (a.wall_ms / 1e3),
+              a.wall_ms / T, a.t_fill / T, a.t_submit / T, a.t_step / T, (double)a.rows_in / T, (unsigned long long)a.general,
+              (double)a.fsm_rows / T, (double)a.msg_rows / T, (double)a.up_bytes / T, (double)a.down_bytes / T, k_us, a.k_n,
+              (unsigned long long)a.sink);
+  return a.ok ? 0 : 1;
 }

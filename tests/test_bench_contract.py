@@ -124,13 +124,15 @@ def test_event_loop_line():
     """bench.py --event-loop: decisions/s through josefine::BatchedEventLoop over jg_step_node, with the PCIe
     bytes per tick, the A/B against round 2's loop (one Tick row per partition through the general state
     machine) and the roofline of the dense leader half as timed inside the loop."""
-    d = run(["--event-loop", "--groups", "20000", "--steps", "20", "--warmup", "5", "--cpu-budget", "1"])
+    d = run(["--event-loop", "--groups", "20000", "--loops", "4", "--steps", "20", "--warmup", "5", "--cpu-budget", "1"])
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["value"] > 0 and "Apply surface" in d["config"]["workload"]
     ev = d["event_loop"]
     assert ev["rows_on_the_general_path"] == 0 and ev["rows_in_per_tick"] > 20000 * 5 and ev["fsm_rows_per_tick"] == 2 * 20000
     assert ev["pcie_bytes_per_tick"]["h2d"] > 0 and ev["pcie_bytes_per_tick"]["d2h"] > 0
     assert ev["speedup_over_round2_loop"] > 2, ev
-    assert ev["loop_only_decisions_per_s"] >= d["value"]
+    assert ev["loops"] == 4 and d["config"]["loops"] == 4 and "4 event loop(s) of 5000 partitions" in d["config"]["parallelism"]
+    assert ev["loop_only_decisions_per_s"] >= ev["one_loop"]["decisions_per_s"] > 0
+    assert ev["column_inbound"]["loops"] == 4 and ev["column_inbound"]["one_loop_decisions_per_s"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["avg_launch_us"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] == "port"
