@@ -146,7 +146,18 @@ int main(int argc, char** argv) {
     const auto t0 = std::chrono::steady_clock::now();
     uint64_t proposals = 0;
     std::vector<uint8_t> role(G);
+    // the last quarter of the run, when the elections have settled: leadership lies where the timers put it (on
+    // every node), and the partitions replicate under THOSE leaders - in the dense kernels, nothing on the general path
+    const uint32_t tail_from = T - T / 4;
+    uint64_t general_before_tail = 0;
+    std::vector<std::vector<uint64_t>> commit_at_tail(R, std::vector<uint64_t>(G, 0));
     for (uint32_t t = 0; t < T; t++) {
+      if (t == tail_from) {
+        for (uint32_t n = 0; n < R; n++) {
+          general_before_tail += n_general[n];
+          if (jg_read_state(rafts[n]->raw(), JG_FIELD_COMMIT, 0, commit_at_tail[n].data(), 0, G) != JG_OK) throw std::runtime_error("read commit");
+        }
+      }
       now += BatchedEventLoop::TICK_MS;
       for (uint32_t n = 0; n < R; n++) {
         BatchedEventLoop& loop = *loops[n];
@@ -179,6 +190,8 @@ int main(int argc, char** argv) {
     std::vector<uint64_t> col(G);
     std::vector<uint8_t> b8(G);
     uint64_t min_commit = ~0ull, max_head = 0;
+    std::vector<uint64_t> leads(R, 0);
+    uint64_t tail_committing = 0;  // partitions whose LEADER's commit index advanced during the tail
     for (uint32_t n = 0; n < R; n++) {
       all.u64(hash[n].h);
       for (int f : {JG_FIELD_TERM, JG_FIELD_HEAD, JG_FIELD_COMMIT}) {
@@ -188,6 +201,11 @@ int main(int argc, char** argv) {
           for (uint32_t g = 0; g < G; g++) max_head = std::max(max_head, col[g]);
         if (f == JG_FIELD_COMMIT && n == 0)
           for (uint32_t g = 0; g < G; g++) min_commit = std::min(min_commit, col[g]);
+        if (f == JG_FIELD_COMMIT) {
+          if (jg_read_state(rafts[n]->raw(), JG_FIELD_ROLE, 0, b8.data(), 0, G) != JG_OK) throw std::runtime_error("read");
+          for (uint32_t g = 0; g < G; g++)
+            if (b8[g] == JG_ROLE_LEADER) leads[n]++, tail_committing += col[g] > commit_at_tail[n][g];
+        }
       }
       for (int f : {JG_FIELD_ROLE, JG_FIELD_FAULT}) {
         if (jg_read_state(rafts[n]->raw(), f, 0, b8.data(), 0, G) != JG_OK) throw std::runtime_error("read");
@@ -206,12 +224,16 @@ int main(int argc, char** argv) {
     bool ok = faults == 0;
     if (scripted) ok = ok && leaders == G && max_head == T && min_commit + 4 >= T && general == 0;
     else ok = ok && leaders <= G;
+    std::string by_node;
+    for (uint32_t n = 0; n < R; n++) by_node += (n ? "/" : "") + std::to_string(leads[n]);
     std::printf("cluster %s hash=%016llx G=%u R=%u T=%u mode=%s leaders=%llu faults=%llu proposals=%llu fsm_rows=%llu msg_rows=%llu "
-                "column_messages=%llu rows_in=%llu rows_general=%llu decisions=%llu max_head=%llu min_commit_node1=%llu\n",
+                "column_messages=%llu rows_in=%llu rows_general=%llu decisions=%llu max_head=%llu min_commit_node1=%llu "
+                "leaders_by_node=%s tail_ticks=%u tail_rows_general=%llu tail_partitions_committing=%llu\n",
                 ok ? "ok" : "FAILED", (unsigned long long)all.h, G, R, T, scripted ? "scripted" : "elect", (unsigned long long)leaders,
                 (unsigned long long)faults, (unsigned long long)proposals, (unsigned long long)fsm, (unsigned long long)msg,
                 (unsigned long long)cols, (unsigned long long)rows, (unsigned long long)general, (unsigned long long)decisions,
-                (unsigned long long)max_head, (unsigned long long)min_commit);
+                (unsigned long long)max_head, (unsigned long long)min_commit, by_node.c_str(), T - tail_from,
+                (unsigned long long)(general - general_before_tail), (unsigned long long)tail_committing);
     std::fprintf(stderr, "[%.2f s for %u ticks of %u nodes x %u partitions: %.3g decisions/s through the loops incl. the host transport]\n", secs, T, R,
                  G, (double)decisions / secs);
     return ok ? 0 : 1;

@@ -91,10 +91,22 @@ def test_event_loop_cluster_host_logic_on_oracle():
     (votes travel as rows through the general path)."""
     exe = build_cluster_test(oracle=True)
     line = run_cluster(exe, 2000, 5, 50, "scripted")
-    assert "leaders=2000" in line and "rows_general=0 " in line and "max_head=50" in line
+    assert "leaders=2000" in line and " rows_general=0 " in line and "max_head=50" in line
     line = run_cluster(exe, 500, 3, 80, "elect")
-    assert "leaders=500" in line and "faults=0" in line and "rows_general=0 " not in line
+    assert "leaders=500" in line and "faults=0" in line and " rows_general=0 " not in line
+    leadership_moved_and_stays_dense(line, 500)
     build_cluster_test(oracle=False)  # (links against the C ABI: compile check without a GPU)
+
+
+def leadership_moved_and_stays_dense(line, G):
+    """Elect mode (R = 3, configs[3]'s replica count): the timers put the leaders on EVERY node (per-partition
+    leadership, not one lead node), and in the last quarter of the run every partition keeps committing under
+    the leader it elected with no row on the general path: AppendEntries / Heartbeat / the answers all travel in
+    column form through the dense halves of jg_step_node (candidate.rs:108-113 -> leader.rs:124-174)."""
+    f = dict(kv.split("=") for kv in line.split() if "=" in kv)
+    by_node = [int(x) for x in f["leaders_by_node"].split("/")]
+    assert sum(by_node) == G and all(n > 0 for n in by_node), line
+    assert int(f["tail_ticks"]) >= 10 and int(f["tail_rows_general"]) == 0 and int(f["tail_partitions_committing"]) == G, line
 
 
 @pytest.mark.gpu
@@ -108,4 +120,6 @@ def test_event_loop_cluster_equals_the_oracle_backed_loops(args):
     ora = run_cluster(build_cluster_test(oracle=True), *args)
     assert dev == ora, (dev, ora)
     if args[3] == "scripted":
-        assert f"leaders={args[0]}" in dev and "rows_general=0 " in dev and f"max_head={args[2]}" in dev
+        assert f"leaders={args[0]}" in dev and " rows_general=0 " in dev and f"max_head={args[2]}" in dev
+    else:
+        leadership_moved_and_stays_dense(dev, args[0])
