@@ -238,9 +238,12 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
   L.xq_on = 0;
   L.xq_k = 0;
 }
+// CHAIN = false: the commands applied since jg_load cannot have touched the chain (jg_apply<JG_KINDS_ELECTION>): a
+// chain that was normalised when it was stored is still normalised, the pass over its segments is not compiled in
+template <bool CHAIN = true>
 __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   uint32_t g = L.g;
-  if (jg_wcnt(L)) jg_chain_normalize(d, L);
+  if (CHAIN && jg_wcnt(L)) jg_chain_normalize(d, L);
   const bool run = (L.run_hi == L.head) && (jg_wcnt(L) == 0) && !(L.flags & JGF_NO_GENESIS);
   const bool fast = run && (L.id_gen == L.head + 1);
   L.flags = run ? (L.flags | JGF_RUN) : (L.flags & ~JGF_RUN);
@@ -774,30 +777,42 @@ __device__ inline void jg_enqueue(const JgDev& d, JgLane& L, uint64_t token) {
   L.queued++;
 }
 
+// KINDS (here and below): the command kinds the caller's batch can hold, as a bit mask over JG_CMD_* - a compile-time
+// promise (the caller has a census of its batch).  Code for a kind outside the mask is not compiled in: a launch that
+// only carries an election's traffic (JG_KINDS_ELECTION: VoteRequest, VoteResponse, Timeout) has no chain code at
+// all, half the registers and twice the waves per SIMD.  A row of a kind outside the mask is a no-op, never undefined.
+#define JG_KINDS_ALL 0xffffffffu
+#define JG_KINDS_ELECTION ((1u << JG_CMD_VOTE_REQUEST) | (1u << JG_CMD_VOTE_RESPONSE) | (1u << JG_CMD_TIMEOUT))
+#define JG_KIND_IN(K) ((KINDS >> (K)) & 1u)
+template <uint32_t KINDS = JG_KINDS_ALL>
 __device__ inline uint32_t jg_follower_apply(const JgDev& d, JgLane& L, const JgCmd& c, const uint64_t* blk_id,
                                              const uint64_t* blk_next) {  // follower.rs:36-64
   switch (c.kind) {
-    case JG_CMD_TICK: return jg_needs_election(L) ? jg_follower_timeout(d, L) : 0;  // :121-128
-    case JG_CMD_APPEND_ENTRIES: return jg_follower_append_entries(d, L, c, blk_id, blk_next);
-    case JG_CMD_HEARTBEAT: return jg_follower_heartbeat(d, L, c.from, c.term, c.id);
-    case JG_CMD_VOTE_REQUEST: return jg_follower_vote_request(d, L, c.from, c.aux, c.id);
-    case JG_CMD_TIMEOUT: return jg_follower_timeout(d, L);
+    case JG_CMD_TICK: if (!JG_KIND_IN(JG_CMD_TICK)) return 0; return jg_needs_election(L) ? jg_follower_timeout(d, L) : 0;  // :121-128
+    case JG_CMD_APPEND_ENTRIES: if (!JG_KIND_IN(JG_CMD_APPEND_ENTRIES)) return 0; return jg_follower_append_entries(d, L, c, blk_id, blk_next);
+    case JG_CMD_HEARTBEAT: if (!JG_KIND_IN(JG_CMD_HEARTBEAT)) return 0; return jg_follower_heartbeat(d, L, c.from, c.term, c.id);
+    case JG_CMD_VOTE_REQUEST: if (!JG_KIND_IN(JG_CMD_VOTE_REQUEST)) return 0; return jg_follower_vote_request(d, L, c.from, c.aux, c.id);
+    case JG_CMD_TIMEOUT: if (!JG_KIND_IN(JG_CMD_TIMEOUT)) return 0; return jg_follower_timeout(d, L);
     case JG_CMD_CLIENT_REQUEST:  // :258-270
+      if (!JG_KIND_IN(JG_CMD_CLIENT_REQUEST)) return 0;
       if (L.flags & JGF_HAS_LEADER)
         jg_emit_msg(d, L, JG_CMD_CLIENT_REQUEST, JG_TO_PEER, L.leader_id, 0, 0, c.id, 0);
       else
         jg_enqueue(d, L, c.id);
       return 0;
     case JG_CMD_CLIENT_RESPONSE:  // :272-282
+      if (!JG_KIND_IN(JG_CMD_CLIENT_RESPONSE)) return 0;
       jg_emit_msg(d, L, JG_CMD_CLIENT_RESPONSE, JG_TO_CLIENT, 0, 0, 0, c.id, 0);
       return 0;
     default: return 0;  // apply_self
   }
 }
+template <uint32_t KINDS = JG_KINDS_ALL>
 __device__ inline uint32_t jg_candidate_apply(const JgDev& d, JgLane& L, const JgCmd& c) {  // candidate.rs:170-196
   switch (c.kind) {
-    case JG_CMD_TICK: return jg_candidate_tick(d, L);
+    case JG_CMD_TICK: if (!JG_KIND_IN(JG_CMD_TICK)) return 0; return jg_candidate_tick(d, L);
     case JG_CMD_VOTE_REQUEST:  // :71-88
+      if (!JG_KIND_IN(JG_CMD_VOTE_REQUEST)) return 0;
       if (c.term > L.term) {
         jg_set_term(L, c.term);
         jg_follower_from_candidate(L);
@@ -805,11 +820,13 @@ __device__ inline uint32_t jg_candidate_apply(const JgDev& d, JgLane& L, const J
       }
       jg_emit_msg(d, L, JG_CMD_VOTE_RESPONSE, JG_TO_PEER, c.from, 0, L.term, 0, 0);
       return 0;
-    case JG_CMD_VOTE_RESPONSE: return jg_candidate_vote_response(d, L, c.flag != 0, c.from);
+    case JG_CMD_VOTE_RESPONSE: if (!JG_KIND_IN(JG_CMD_VOTE_RESPONSE)) return 0; return jg_candidate_vote_response(d, L, c.flag != 0, c.from);
     case JG_CMD_APPEND_ENTRIES:  // :116-134
+      if (!JG_KIND_IN(JG_CMD_APPEND_ENTRIES)) return 0;
       if (c.term >= L.term) jg_follower_from_candidate(L);
       return 0;
     case JG_CMD_HEARTBEAT: {  // :137-157
+      if (!JG_KIND_IN(JG_CMD_HEARTBEAT)) return 0;
       bool has_committed = jg_chain_has(d, L, c.id);
       uint64_t own = L.commit;
       jg_set_term(L, c.term);
@@ -819,25 +836,29 @@ __device__ inline uint32_t jg_candidate_apply(const JgDev& d, JgLane& L, const J
       return 0;
     }
     case JG_CMD_CLIENT_REQUEST:  // :190-193
+      if (!JG_KIND_IN(JG_CMD_CLIENT_REQUEST)) return 0;
       jg_enqueue(d, L, c.id);
       return 0;
     default: return 0;
   }
 }
+template <uint32_t KINDS = JG_KINDS_ALL>
 __device__ inline uint32_t jg_leader_apply(const JgDev& d, JgLane& L, const JgCmd& c) {  // leader.rs:248-266
   switch (c.kind) {
-    case JG_CMD_TICK: return jg_leader_tick(d, L);
+    case JG_CMD_TICK: if (!JG_KIND_IN(JG_CMD_TICK)) return 0; return jg_leader_tick(d, L);
     case JG_CMD_HEARTBEAT_RESPONSE:  // :222-231
+      if (!JG_KIND_IN(JG_CMD_HEARTBEAT_RESPONSE)) return 0;
       return (!c.flag && c.id > 0) ? jg_leader_replicate(d, L) : 0;
-    case JG_CMD_APPEND_RESPONSE: return jg_leader_append_response(d, L, c.from, c.id);
+    case JG_CMD_APPEND_RESPONSE: if (!JG_KIND_IN(JG_CMD_APPEND_RESPONSE)) return 0; return jg_leader_append_response(d, L, c.from, c.id);
     case JG_CMD_APPEND_ENTRIES:  // :200-208
+      if (!JG_KIND_IN(JG_CMD_APPEND_ENTRIES)) return 0;
       if (c.term > L.term) {
         uint32_t f = jg_set_term(L, c.term);  // unimplemented!() (Q3)
         if (f) return f;
         jg_follower_from_leader(L);
       }
       return 0;
-    case JG_CMD_CLIENT_REQUEST: return jg_leader_client_request(d, L, c.id);
+    case JG_CMD_CLIENT_REQUEST: if (!JG_KIND_IN(JG_CMD_CLIENT_REQUEST)) return 0; return jg_leader_client_request(d, L, c.id);
     default: return 0;
   }
 }
@@ -857,18 +878,21 @@ __device__ inline void jg_restart(const JgDev& d, JgLane& L) {
 }
 
 // RaftHandle::apply, mod.rs:471-479
+template <uint32_t KINDS = JG_KINDS_ALL>
 __device__ inline void jg_apply(const JgDev& d, JgLane& L, const JgCmd& c, const uint64_t* blk_id,
                                 const uint64_t* blk_next) {
-  if (c.kind == JG_CMD_RESTART) {
+  if (JG_KIND_IN(JG_CMD_RESTART) && c.kind == JG_CMD_RESTART) {
     jg_restart(d, L);
     return;
   }
   if (jg_fault(L)) return;  // the reference process is gone
   uint32_t f;
   switch (jg_role(L)) {
-    case JG_ROLE_FOLLOWER: f = jg_follower_apply(d, L, c, blk_id, blk_next); break;
-    case JG_ROLE_CANDIDATE: f = jg_candidate_apply(d, L, c); break;
-    default: f = jg_leader_apply(d, L, c); break;
+    case JG_ROLE_FOLLOWER: f = jg_follower_apply<KINDS>(d, L, c, blk_id, blk_next); break;
+    case JG_ROLE_CANDIDATE: f = jg_candidate_apply<KINDS>(d, L, c); break;
+    default: f = jg_leader_apply<KINDS>(d, L, c); break;
   }
   if (f) jg_raise(d, L, f);
 }
+// whether a census of command kinds (bit k: some row of kind k) stays inside a mask
+__host__ __device__ inline bool jg_kinds_within(uint32_t census, uint32_t mask) { return (census & ~mask) == 0; }

@@ -28,11 +28,13 @@ struct JgRouteTable {
   uint32_t group_bits;                  // bits of a group index
   uint32_t ord_bits;                    // bits of the emission-index field
   uint32_t cap;                         // entries of the staging below
+  uint32_t seg_cap, seg_mask;           // the staging is n_seg = seg_mask + 1 segments of seg_cap entries, each with its own cursor
   uint64_t* key;                        // staging shared by all destinations (the sort separates them)
   uint32_t* idx;
   jg_msg_row* row;
-  uint32_t* cursor;                     // staging entries reserved so far
+  uint32_t* cursor;                     // [JG_ROUTE_SEGS] staging entries reserved so far, per segment
   uint32_t* count;                      // [R+4] of this sender: rows per destination, then JG_ROUTE_*
+  uint32_t* kinds;                      // [R] per destination: the command kinds delivered to it this round (bit k: JG_CMD_* k)
 };
 enum { JG_ROUTE_KEPT = 0, JG_ROUTE_FSM = 1, JG_ROUTE_OVERFLOW = 2, JG_ROUTE_KEPT_XQ = 3 };  // count[R + …]
 
@@ -55,25 +57,46 @@ __device__ __forceinline__ uint64_t jg_route_key(const JgRouteTable& t, uint32_t
 }
 // One staging reservation per workgroup and tile (every wave of a launch reserving for itself made the
 // one cursor the bottleneck: a returning atomic on a single address retires every ~18 ns, 85 us for the
-// 4.7 k waves of a 300 k-slot step).  Returns the calling thread's first position.
-__device__ __forceinline__ uint32_t jg_route_reserve(const JgRouteTable& t, uint32_t c) {
+// 4.7 k waves of a 300 k-slot step) - and, since ~3 000 workgroup reservations of a round's delivering pass were
+// still 54 us of that queue, on one of JG_ROUTE_SEGS cursors: workgroup x takes segment x mod n_seg of the staging
+// (neighbouring workgroups run on different XCDs, so a cursor is mostly one XCD's).  The staged entries need no
+// particular place: the ordering keys are unique and the bucket pass reads every segment.  Returns the calling
+// thread's first position; `lim`: the end of the segment (a position at or beyond it is not written: the host
+// sees the cursor above seg_cap, grows the staging and repeats the pass).
+#define JG_ROUTE_SEGS 8u
+__device__ __forceinline__ uint32_t jg_route_reserve(const JgRouteTable& t, uint32_t c, uint32_t& lim) {
   __shared__ uint32_t base_s;
   uint32_t tot;
   const uint32_t excl = jg_block_exclusive_scan(c, &tot);
-  if (threadIdx.x == 0) base_s = tot ? atomicAdd(t.cursor, tot) : 0u;
+  const uint32_t seg = blockIdx.x & t.seg_mask;
+  if (threadIdx.x == 0) base_s = tot ? atomicAdd(t.cursor + seg, tot) : 0u;
   __syncthreads();
-  const uint32_t pos = base_s + excl;
+  lim = seg * t.seg_cap + t.seg_cap;
+  const uint32_t pos = seg * t.seg_cap + min(base_s + excl, t.seg_cap);  // (saturating: beyond the segment is never a valid position)
   __syncthreads();  // (base_s is reused by the next tile)
   return pos;
 }
 // The launch's tallies -> the sender's count words, one global atomic per workgroup and word (per wave
 // they queued up behind each other on a handful of addresses).  `pd_*`: rows per destination, 16 bits
 // each (destinations 0-3 in lo, 4-7 in hi); call once, at the end of the kernel, from every thread.
+// `kd_*`: the kinds of the rows noted per destination, 16 bits each (JG_CMD__COUNT <= 16), or-ed into t.kinds: the
+// census that lets the addressee's next step pick a kernel without the code for kinds that are not there.
 __device__ __forceinline__ void jg_route_tally(const JgRouteTable& t, uint64_t pd_lo, uint64_t pd_hi, uint32_t kept,
-                                               uint32_t kept_word, uint32_t fsm) {
-  __shared__ uint32_t tally_s[JG_MAX_REPLICAS + 2];
-  if (threadIdx.x < JG_MAX_REPLICAS + 2) tally_s[threadIdx.x] = 0;
+                                               uint32_t kept_word, uint32_t fsm, uint64_t kd_lo, uint64_t kd_hi) {
+  static_assert(JG_CMD__COUNT <= 16, "a destination's kinds field is 16 bits");
+  __shared__ uint32_t tally_s[2 * JG_MAX_REPLICAS + 2];
+  if (threadIdx.x < 2 * JG_MAX_REPLICAS + 2) tally_s[threadIdx.x] = 0;
   __syncthreads();
+#pragma unroll
+  for (int off = 32; off; off >>= 1) {
+    kd_lo |= __shfl_xor(kd_lo, off, 64);
+    kd_hi |= __shfl_xor(kd_hi, off, 64);
+  }
+  if ((threadIdx.x & 63u) == 0)
+    for (uint32_t n = 0; n < t.R; n++) {
+      const uint32_t v = (uint32_t)((n < 4 ? kd_lo : kd_hi) >> (16 * (n & 3u))) & 0xffffu;
+      if (v) atomicOr(&tally_s[JG_MAX_REPLICAS + 2 + n], v);
+    }
   // (the 16-bit fields are PER LANE - a lane never counts 65 536 rows for one destination in a launch - and are
   // widened before they are added up: summed across a wave in their packed form, a wave total of 65 536 rows
   // to one destination used to carry into its neighbour's field)
@@ -95,10 +118,17 @@ __device__ __forceinline__ void jg_route_tally(const JgRouteTable& t, uint64_t p
   if (threadIdx.x == JG_MAX_REPLICAS && tally_s[JG_MAX_REPLICAS]) atomicAdd(&t.count[t.R + kept_word], tally_s[JG_MAX_REPLICAS]);
   if (threadIdx.x == JG_MAX_REPLICAS + 1 && tally_s[JG_MAX_REPLICAS + 1])
     atomicAdd(&t.count[t.R + JG_ROUTE_FSM], tally_s[JG_MAX_REPLICAS + 1]);
+  if (threadIdx.x >= 64 && threadIdx.x - 64 < t.R && tally_s[JG_MAX_REPLICAS + 2 + threadIdx.x - 64])
+    atomicOr(&t.kinds[threadIdx.x - 64], tally_s[JG_MAX_REPLICAS + 2 + threadIdx.x - 64]);
 }
 __device__ __forceinline__ void jg_route_note(uint64_t& pd_lo, uint64_t& pd_hi, uint32_t dest) {
   if (dest < 4) pd_lo += 1ull << (16 * dest);
   else pd_hi += 1ull << (16 * (dest - 4));
+}
+__device__ __forceinline__ void jg_route_note_kind(uint64_t& kd_lo, uint64_t& kd_hi, uint32_t dest, uint32_t kind) {
+  const uint64_t bit = 1ull << (kind & 15u);
+  if (dest < 4) kd_lo |= bit << (16 * dest);
+  else kd_hi |= bit << (16 * (dest - 4));
 }
 
 // The slots of one sparse step: every deliverable row goes to the staging (nothing is modified: the
@@ -111,7 +141,7 @@ __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_
   const uint32_t tile0 = blockIdx.x * (JG_BLOCK * JG_ROUTE_ITEMS) + threadIdx.x;
   uint32_t cnt[JG_ROUTE_ITEMS];
   uint32_t c = 0, kept = 0, f = 0;
-  uint64_t pd_lo = 0, pd_hi = 0;
+  uint64_t pd_lo = 0, pd_hi = 0, kd_lo = 0, kd_hi = 0;
 #pragma unroll
   for (int k = 0; k < JG_ROUTE_ITEMS; k++) {
     const uint32_t i = tile0 + k * JG_BLOCK;
@@ -125,10 +155,14 @@ __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_
       const uint32_t m = jg_route_dests(mine[j], t);
       c += __popc(m);
       kept += !m;
-      for (uint32_t b = m; b; b &= b - 1) jg_route_note(pd_lo, pd_hi, (uint32_t)__ffs(b) - 1u);
+      for (uint32_t b = m; b; b &= b - 1) {
+        jg_route_note(pd_lo, pd_hi, (uint32_t)__ffs(b) - 1u);
+        jg_route_note_kind(kd_lo, kd_hi, (uint32_t)__ffs(b) - 1u, mine[j].kind);
+      }
     }
   }
-  uint32_t pos = jg_route_reserve(t, c);
+  uint32_t lim;
+  uint32_t pos = jg_route_reserve(t, c, lim);
   if (c) {
 #pragma unroll
     for (int k = 0; k < JG_ROUTE_ITEMS; k++) {
@@ -137,7 +171,7 @@ __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_
       for (uint32_t j = 0; j < cnt[k]; j++) {
         const jg_msg_row r = mine[j];
         for (uint32_t b = jg_route_dests(r, t); b; b &= b - 1, pos++) {
-          if (pos >= t.cap) continue;  // (the host sees cursor > cap, grows the staging and repeats the pass)
+          if (pos >= lim) continue;  // (the host sees the cursor above the segment, grows the staging and repeats the pass)
           // (a run's rows lie back to back from its first slot: j is the emission index within the group's step)
           t.key[pos] = jg_route_key(t, (uint32_t)__ffs(b) - 1u, r.group, step, j);
           t.idx[pos] = pos;
@@ -146,7 +180,7 @@ __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_
       }
     }
   }
-  jg_route_tally(t, pd_lo, pd_hi, kept, JG_ROUTE_KEPT, f);
+  jg_route_tally(t, pd_lo, pd_hi, kept, JG_ROUTE_KEPT, f, kd_lo, kd_hi);
 }
 __global__ __launch_bounds__(JG_BLOCK) void k_route_rec(JgRouteTable t, uint32_t n, uint32_t per_row, uint32_t step,
                                                         const uint32_t* __restrict__ msg_cnt,
@@ -192,7 +226,7 @@ __device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const Jg
                                                  JgXqRec* __restrict__ keep, uint32_t* __restrict__ keep_n) {
   const uint32_t n = min(*xq_n, xq_cap);
   const uint32_t lane = threadIdx.x & 63u;
-  uint64_t pd_lo = 0, pd_hi = 0;
+  uint64_t pd_lo = 0, pd_hi = 0, kd_lo = 0, kd_hi = 0;
   uint32_t stays = 0;
   for (uint32_t i0 = blockIdx.x * JG_BLOCK; i0 < n; i0 += gridDim.x * JG_BLOCK) {  // (block-uniform trip count)
     const uint32_t i = i0 + threadIdx.x;
@@ -215,17 +249,19 @@ __device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const Jg
       continue;
     }
     const uint32_t step = q.seq - seq_base;
-    uint32_t pos = jg_route_reserve(t, __popc(mask));
+    uint32_t lim;
+    uint32_t pos = jg_route_reserve(t, __popc(mask), lim);
     stays += stay;
     for (uint32_t b = mask; b; b &= b - 1, pos++) {
       jg_route_note(pd_lo, pd_hi, (uint32_t)__ffs(b) - 1u);
-      if (pos >= t.cap) continue;
+      jg_route_note_kind(kd_lo, kd_hi, (uint32_t)__ffs(b) - 1u, q.row.kind);
+      if (pos >= lim) continue;
       t.key[pos] = jg_route_key(t, (uint32_t)__ffs(b) - 1u, q.row.group, step & 3u, q.k);
       t.idx[pos] = pos;
       t.row[pos] = q.row;
     }
   }
-  if (!COMPACT) jg_route_tally(t, pd_lo, pd_hi, stays, JG_ROUTE_KEPT_XQ, 0);
+  if (!COMPACT) jg_route_tally(t, pd_lo, pd_hi, stays, JG_ROUTE_KEPT_XQ, 0, kd_lo, kd_hi);
 }
 
 template <bool COMPACT>
@@ -321,8 +357,12 @@ __device__ __forceinline__ uint32_t jg_table_add(JgBucketTable& t, uint32_t bk, 
   rank = atomicAdd(&t.cnt[s], 1u);
   return s;
 }
-__global__ __launch_bounds__(JG_BLOCK) void k_route_hist(uint32_t n, const uint64_t* __restrict__ key, JgRouteBuckets b) {
+// (blockIdx.y = staging segment: its entries are [y * seg_cap, y * seg_cap + seg_n[y]))
+__global__ __launch_bounds__(JG_BLOCK) void k_route_hist(const uint32_t* __restrict__ seg_n, uint32_t seg_cap, const uint64_t* __restrict__ key,
+                                                         JgRouteBuckets b) {
   __shared__ JgBucketTable t;
+  const uint32_t n = min(seg_n[blockIdx.y], seg_cap);
+  key += (size_t)blockIdx.y * seg_cap;
   for (uint32_t base = blockIdx.x * JG_BLOCK; base < n; base += gridDim.x * JG_BLOCK) {  // (workgroup-uniform trips)
     jg_table_clear(t);
     const uint32_t i = base + threadIdx.x;
@@ -362,9 +402,12 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_scan_tiles(JgRouteBuckets b)
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(JG_BLOCK) void k_route_scatter(uint32_t n, const uint64_t* __restrict__ key, const uint32_t* __restrict__ idx,
-                                                            JgRouteBuckets b, uint64_t* __restrict__ key_out, uint32_t* __restrict__ idx_out) {
+__global__ __launch_bounds__(JG_BLOCK) void k_route_scatter(const uint32_t* __restrict__ seg_n, uint32_t seg_cap, const uint64_t* __restrict__ key,
+                                                            const uint32_t* __restrict__ idx, JgRouteBuckets b, uint64_t* __restrict__ key_out,
+                                                            uint32_t* __restrict__ idx_out) {
   __shared__ JgBucketTable t;
+  const uint32_t n = min(seg_n[blockIdx.y], seg_cap);
+  key += (size_t)blockIdx.y * seg_cap, idx += (size_t)blockIdx.y * seg_cap;
   for (uint32_t base = blockIdx.x * JG_BLOCK; base < n; base += gridDim.x * JG_BLOCK) {
     jg_table_clear(t);
     const uint32_t i = base + threadIdx.x;
@@ -390,6 +433,39 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_sort_build(JgRouteBuckets b,
   __shared__ uint32_t s_idx[JG_ROUTE_SORT_CAP];
   const uint32_t lo = b.off(blockIdx.x), n = b.off(blockIdx.x + 1) - lo;
   if (!n) return;
+  if (n <= JG_BLOCK) {
+    // the usual bucket (a tile of 256 groups holds ~64 rows of a round): every key's rank by counting the smaller
+    // ones - the keys are unique - with all JG_BLOCK threads on it: `per` neighbouring lanes share a key and a
+    // stride of the scan (n = 64: 16 LDS reads per thread and no barrier but one, against the 21 compare-exchange
+    // stages and barriers of the bitonic network below: this kernel was 68 us of a round)
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    const uint32_t per = JG_BLOCK / m;  // 1 .. 256, a power of two; lanes [k * per, (k + 1) * per) work on key k
+    if (threadIdx.x < n) s_key[threadIdx.x] = key[lo + threadIdx.x], s_idx[threadIdx.x] = idx[lo + threadIdx.x];
+    __syncthreads();
+    const uint32_t ki = threadIdx.x / per, part = threadIdx.x % per;
+    const uint64_t k = ki < n ? s_key[ki] : 0ull;
+    uint32_t rank = 0;
+    if (ki < n)
+      for (uint32_t j = part; j < n; j += per) rank += s_key[j] < k;
+    if (per > 64) {  // (n <= 2: the lanes of a key span waves)
+      __shared__ uint32_t s_rank[2];
+      if (threadIdx.x < 2) s_rank[threadIdx.x] = 0;
+      __syncthreads();
+      if (ki < n && rank) atomicAdd(&s_rank[ki], rank);
+      __syncthreads();
+      rank = ki < n ? s_rank[ki] : 0u;
+    } else {
+      for (uint32_t off = per >> 1; off; off >>= 1) rank += __shfl_xor(rank, (int)off, 64);
+    }
+    if (ki < n && part == 0) {
+      const jg_msg_row r = rows[s_idx[ki]];
+      const uint32_t p = lo + rank;
+      c.kind[p] = r.kind, c.flag[p] = r.flag, c.group[p] = r.group, c.from[p] = r.from;
+      c.term[p] = r.term, c.id[p] = r.id, c.aux[p] = r.aux;
+    }
+    return;
+  }
   if (n <= JG_ROUTE_SORT_CAP) {
     uint32_t m = 1;
     while (m < n) m <<= 1;
@@ -433,6 +509,22 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_sort_build(JgRouteBuckets b,
     c.kind[p] = r.kind, c.flag[p] = r.flag, c.group[p] = r.group, c.from[p] = r.from;
     c.term[p] = r.term, c.id[p] = r.id, c.aux[p] = r.aux;
   }
+}
+
+// The round's counters back to zero in ONE launch each (a hipMemsetAsync is up to three fill kernels of ~4 us, and a
+// round had seven of them): two word ranges; and up to JG_MAX_REPLICAS single words named by pointer.
+__global__ __launch_bounds__(JG_BLOCK) void k_route_clear(uint32_t* __restrict__ a, uint32_t na, uint32_t* __restrict__ b, uint32_t nb) {
+  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < na + nb; i += gridDim.x * JG_BLOCK) {
+    if (i < na) a[i] = 0;
+    else b[i - na] = 0;
+  }
+}
+struct JgWordList {
+  uint32_t* p[JG_MAX_REPLICAS];
+  uint32_t n;
+};
+__global__ void k_route_clear_words(JgWordList w) {
+  if (threadIdx.x < w.n) *w.p[threadIdx.x] = 0;
 }
 
 // ClientRequests are offered only where the lead node leads (at a leaderless replica the reference

@@ -44,6 +44,7 @@ struct JgRowsArgs {
 // its rows itself: one dependent trip to memory per row — a candidate's sixteen VoteResponses took the
 // batch's owner lanes sixteen round trips (profiles/README.md, the routed round).  Rows of a run that
 // continue in the next wave are still loaded by the owner.
+template <uint32_t KINDS = JG_KINDS_ALL>
 __device__ __forceinline__ void jg_apply_rows_body(const JgDev& d, const JgRowsArgs& a) {
   uint32_t dec = 0;
   const uint32_t lane = threadIdx.x & 63u;
@@ -123,7 +124,7 @@ __device__ __forceinline__ void jg_apply_rows_body(const JgDev& d, const JgRowsA
           c.aux = a.aux[k];
           if (c.kind == JG_CMD_APPEND_ENTRIES && a.blk_id && (c.aux > a.n_blocks || c.id > a.n_blocks - c.aux)) c.kind = JG_CMD_NOOP;
         }
-        jg_apply(d, L, c, a.blk_id, a.blk_next);
+        jg_apply<KINDS>(d, L, c, a.blk_id, a.blk_next);
       }
     }
     uint32_t cm = 0, cf = 0;
@@ -133,7 +134,7 @@ __device__ __forceinline__ void jg_apply_rows_body(const JgDev& d, const JgRowsA
       a.fsm_cnt[i] = cf;
       if (L.overflow) *a.err = 1;
       dec += L.decisions;
-      jg_store(d, L);
+      jg_store<KINDS != JG_KINDS_ELECTION>(d, L);
     }
     // the tile's sums (tile = the JG_BLOCK rows this workgroup just served)
     __shared__ uint32_t red_m[JG_BLOCK / 64], red_f[JG_BLOCK / 64];
@@ -167,6 +168,12 @@ struct JgApplyJob {
 __global__ __launch_bounds__(JG_BLOCK) void k_apply_rows_multi(const JgApplyJob* __restrict__ jobs) {
   const JgApplyJob& j = jobs[blockIdx.y];  // (through the reference: 64 us per launch; a by-value copy of the job went to scratch: 198 us)
   jg_apply_rows_body(j.d, j.a);
+}
+// ... and for jobs whose batches hold an election's traffic only (the census comes with the rows: the cluster
+// transport tallies the kinds it delivers): no chain code, half the registers
+__global__ __launch_bounds__(JG_BLOCK) void k_apply_votes_multi(const JgApplyJob* __restrict__ jobs) {
+  const JgApplyJob& j = jobs[blockIdx.y];
+  jg_apply_rows_body<JG_KINDS_ELECTION>(j.d, j.a);
 }
 
 // ---- drain-time compaction, entirely on the device -------------------------------------------

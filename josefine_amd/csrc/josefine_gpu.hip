@@ -1963,7 +1963,8 @@ struct jg_dense_cluster {
   // jg_dense_cluster_round_routed: per destination node, the staging the senders' rows are scattered
   // into, its sort scratch, and the command columns of the node's next round (all grow-only)
   struct Route {
-    uint32_t* d_count = nullptr;  // [R][R+4] per sender: rows per destination + JG_ROUTE_*; then the staging cursor; then [R] kept exceptional rows
+    uint32_t* d_count = nullptr;  // [R][R+4] per sender: rows per destination + JG_ROUTE_*; then the JG_ROUTE_SEGS staging cursors; then [R] kept exceptional rows; then [R] the kinds delivered per destination
+    std::vector<uint32_t> kinds_in;  // per node: the census of command kinds of the rows waiting for its next round (bit k: JG_CMD_* k)
     uint32_t* h_count = nullptr;  // pinned mirror
     // staging shared by all destinations, its sort scratch, the sorted command columns (node n's rows
     // are the slice [in_off[n], in_off[n] + n_in[n]) of every column); all grow-only
@@ -2098,8 +2099,29 @@ JgFollowerJob cluster_job(const jg_dense_cluster* c, uint32_t r) {
   return j;
 }
 
+// the follower halves of an eager round as jobs (with this round's time and step numbers) + the host-side bookkeeping
+// of the two launches that serve them
+int cluster_follower_jobs(jg_dense_cluster* c, uint64_t now_ms, std::vector<JgFollowerJob>& jobs) {
+  int rc = JG_OK;
+  for (uint32_t r = 0; r < c->R; r++) {
+    if (r == c->lead) continue;
+    jg_engine* e = c->nodes[r];
+    if ((rc = ensure_xq(e))) return rc;
+    e->stepped = true;
+    e->seq++;
+    JgFollowerJob j = cluster_job(c, r);
+    j.a.clock = nullptr, j.a.now = now_ms, j.a.seq = e->seq;
+    jobs.push_back(j);
+    e->slow_scheduled_ever = true;
+    e->n_launch += 2;
+    e->n_dense += e->cfg.n_groups;
+    e->maybe_irregular = true, e->flag_check_pending = true, e->irr_gen++;
+  }
+  return JG_OK;
+}
+// `prepared`: the caller has the jobs already (cluster_follower_jobs) and their device copy at d_slice is on its way
 int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits, bool multi = false, char* h_slice = nullptr,
-                       char* d_slice = nullptr) {
+                       char* d_slice = nullptr, const std::vector<JgFollowerJob>* prepared = nullptr) {
   jg_engine* L = c->nodes[c->lead];
   const size_t G = c->G;
   const jg_leader_inbox in{c->acks, c->hbr_commit};
@@ -2122,24 +2144,14 @@ int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits,
     return JG_OK;  // (the host-side bookkeeping of a replayed round is done per graph launch)
   }
   if (h_slice) {  // an eager round whose nodes share the lead node's stream: the same two launches, jobs with this round's time
-    std::vector<JgFollowerJob> jobs;
-    for (uint32_t r = 0; r < c->R; r++) {
-      if (r == c->lead) continue;
-      jg_engine* e = c->nodes[r];
-      if ((rc = ensure_xq(e))) return rc;
-      e->stepped = true;
-      e->seq++;
-      JgFollowerJob j = cluster_job(c, r);
-      j.a.clock = nullptr, j.a.now = now_ms, j.a.seq = e->seq;
-      jobs.push_back(j);
-      e->slow_scheduled_ever = true;
-      e->n_launch += 2;
-      e->n_dense += e->cfg.n_groups;
-      e->maybe_irregular = true, e->flag_check_pending = true, e->irr_gen++;
-    }
+    std::vector<JgFollowerJob> own;
+    if (!prepared && (rc = cluster_follower_jobs(c, now_ms, own))) return rc;
+    const std::vector<JgFollowerJob>& jobs = prepared ? *prepared : own;
     if (!jobs.empty()) {
-      std::memcpy(h_slice, jobs.data(), jobs.size() * sizeof(JgFollowerJob));
-      HIPCHK(hipMemcpyAsync(d_slice, h_slice, jobs.size() * sizeof(JgFollowerJob), hipMemcpyHostToDevice, L->stream));
+      if (!prepared) {
+        std::memcpy(h_slice, jobs.data(), jobs.size() * sizeof(JgFollowerJob));
+        HIPCHK(hipMemcpyAsync(d_slice, h_slice, jobs.size() * sizeof(JgFollowerJob), hipMemcpyHostToDevice, L->stream));
+      }
       hipLaunchKernelGGL(k_follower_tick_dense_multi, dim3(L->dense_grid, (uint32_t)jobs.size()), dim3(JG_BLOCK), 0, L->stream, (const JgFollowerJob*)d_slice);
       JgFollowerJobs kj{};
       for (size_t k = 0; k < jobs.size(); k++) kj.j[k] = jobs[k];
@@ -2280,7 +2292,7 @@ int route_grow(jg_dense_cluster::Route& d, size_t need) {
   if (need <= d.cap) return JG_OK;
   for (void* p : {(void*)d.key, (void*)d.key_alt, (void*)d.idx, (void*)d.idx_alt, (void*)d.row, (void*)d.cols_mem})
     if (p) HIPCHK(hipFree(p));
-  const size_t cap = std::max<size_t>(need + need / 2, 65536);
+  const size_t cap = (std::max<size_t>(need + need / 2, 65536) + 63) & ~size_t(63);  // (whole segments: jg_route_reserve)
   if (cap > 0x7fffffffull) return fail(JG_ECAPACITY, "routed round: too many rows");
   HIPCHK(hipMalloc((void**)&d.key, cap * 8));
   HIPCHK(hipMalloc((void**)&d.key_alt, cap * 8));
@@ -2336,11 +2348,11 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   const double T0 = clk();
   double T1 = T0, T2 = T0, T3 = T0, T4 = T0;
   jg_dense_cluster::Route& rt = c->rt;
-  const size_t words = (size_t)R * ROUTE_WORDS + 1 + R;
+  const size_t words = (size_t)R * ROUTE_WORDS + JG_ROUTE_SEGS + 2 * R;
   if (!rt.ready) {
     HIPCHK(hipMalloc((void**)&rt.d_count, words * 4));
     HIPCHK(hipHostMalloc((void**)&rt.h_count, words * 4, hipHostMallocDefault));
-    rt.n_in.assign(R, 0), rt.in_off.assign(R, 0);
+    rt.n_in.assign(R, 0), rt.in_off.assign(R, 0), rt.kinds_in.assign(R, 0);
     rt.xq_keep.assign(R, nullptr);
     while (rt.group_bits < 32 && (c->G - 1) >> rt.group_bits) rt.group_bits++;
     if (rt.group_bits > 29) return fail(JG_EINVAL, "routed rounds: too many groups for the transport's ordering key");
@@ -2365,14 +2377,14 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   static_assert(JG_MAX_REPLICAS * sizeof(JgFollowerJob) <= jg_dense_cluster::Route::JOB_SLICE, "job slice too small");
   auto slice_h = [&](int k) { return rt.h_jobs + (size_t)k * jg_dense_cluster::Route::JOB_SLICE; };
   auto slice_d = [&](int k) { return rt.d_jobs + (size_t)k * jg_dense_cluster::Route::JOB_SLICE; };
+  // (multi: the job tables of the whole round - both sparse steps, the follower halves, the delivering pass - are
+  // written first and travel in ONE copy: every table is host bookkeeping only, and a copy costs ~10 us of stream time)
   auto apply_all = [&](int slice, std::vector<JgApplyJob>& jobs, uint32_t widest) -> int {
     if (jobs.empty()) return JG_OK;
     if (!multi) {
       for (size_t k = 0; k < jobs.size(); k++)
         hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(jobs[k].a.n, L->count_slots)), dim3(JG_BLOCK), 0, L->stream, jobs[k].d, jobs[k].a);
     } else {
-      std::memcpy(slice_h(slice), jobs.data(), jobs.size() * sizeof(JgApplyJob));
-      HIPCHK(hipMemcpyAsync(slice_d(slice), slice_h(slice), jobs.size() * sizeof(JgApplyJob), hipMemcpyHostToDevice, L->stream));
       hipLaunchKernelGGL(k_apply_rows_multi, dim3(grid_for(widest, L->count_slots), (uint32_t)jobs.size()), dim3(JG_BLOCK), 0, L->stream,
                          (const JgApplyJob*)slice_d(slice));
     }
@@ -2382,10 +2394,16 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   std::vector<uint32_t> seq_base(R);
   for (uint32_t n = 0; n < R; n++) seq_base[n] = c->nodes[n]->seq;
   *started = true;
+  // (jobs_v: delivered batches that hold an election's traffic only - the transport's census says so - take the
+  // kernel without the chain code: k_apply_votes_multi.  JG_ROUTE_NO_VOTES_KERNEL=1: the general one for all, an A/B)
+  static const bool no_votes_kernel = std::getenv("JG_ROUTE_NO_VOTES_KERNEL") != nullptr;
+  std::vector<JgApplyJob> jobs_a, jobs_v, jobs_b;
+  uint32_t widest_a = 0, widest_v = 0, widest_b = 0;
   {
-    std::vector<JgApplyJob> jobs;
-    uint32_t widest = 0;
     for (uint32_t n = 0; n < R; n++) {
+      const bool votes = multi && !no_votes_kernel && jg_kinds_within(rt.kinds_in[n], JG_KINDS_ELECTION);
+      std::vector<JgApplyJob>& jobs = votes ? jobs_v : jobs_a;
+      uint32_t& widest = votes ? widest_v : widest_a;
       jg_engine* e = c->nodes[n];
       if (!rt.n_in[n]) continue;
       const size_t o = rt.in_off[n];
@@ -2404,8 +2422,10 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       }
       rt.n_in[n] = 0;
     }
-    if ((rc = apply_all(0, jobs, widest))) return rc;
-    jobs.clear(), widest = 0;
+  }
+  {
+    std::vector<JgApplyJob>& jobs = jobs_b;
+    uint32_t& widest = widest_b;
     for (uint32_t n = 0; inject && n < R; n++) {
       jg_engine* e = c->nodes[n];
       const jg_cmd_batch& b = inject[n];
@@ -2423,19 +2443,16 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
         jobs.push_back(j);
       }
     }
-    if ((rc = apply_all(1, jobs, widest))) return rc;
   }
-  // -- 2. the dense round; ClientRequests only where the lead node (still) leads
-  hipLaunchKernelGGL(k_route_mask_appends, dim3((c->G + 255) / 256), dim3(256), 0, L->stream, c->G, (const uint32_t*)L->dev.flags,
-                     (const uint64_t*)c->offered, c->acks + (size_t)c->lead * c->G);
-  if ((rc = cluster_round_body(c, now_ms, true, false, multi ? slice_h(2) : nullptr, multi ? slice_d(2) : nullptr))) return rc;
-  T1 = clk();
-  // -- 3. the transport, on the lead node's stream behind everybody's round
-  for (uint32_t r = 0; r < R; r++)
-    if (r != c->lead && (rc = jg_stream_wait(L, c->nodes[r]))) return rc;
+  std::vector<JgFollowerJob> fjobs;
+  if (multi && (rc = cluster_follower_jobs(c, now_ms, fjobs))) return rc;
   hipStream_t st = L->stream;
   uint32_t* d_cursor = rt.d_count + (size_t)R * ROUTE_WORDS;
-  uint32_t* d_keep_n = d_cursor + 1;
+  uint32_t* d_keep_n = d_cursor + JG_ROUTE_SEGS;
+  // the staging in segments, one cursor each (jg_route_reserve); the library sort of the A/B wants it in one piece
+  static const bool library_sort = std::getenv("JG_ROUTE_LIBRARY_SORT") != nullptr;
+  static const bool one_cursor = library_sort || std::getenv("JG_ROUTE_ONE_CURSOR") != nullptr;
+  const uint32_t n_seg = one_cursor ? 1u : JG_ROUTE_SEGS;
   // (JG_ROUTE_NARROW_BITS: test hook - a field too narrow for the trace exercises the repeat with the wide one)
   static const uint32_t narrow = std::getenv("JG_ROUTE_NARROW_BITS") ? (uint32_t)std::atoi(std::getenv("JG_ROUTE_NARROW_BITS")) : JG_ROUTE_ORD_BITS_FAST;
   uint32_t ord_bits = std::min<uint32_t>(std::max<uint32_t>(narrow, 1u), JG_ROUTE_ORD_BITS);
@@ -2444,9 +2461,11 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     t.R = R, t.src = s;
     for (uint32_t n = 0; n < R; n++) t.member_id[n] = c->nodes[n]->cfg.node_ids[n];
     t.group_bits = rt.group_bits, t.ord_bits = ord_bits, t.cap = rt.cap;
+    t.seg_cap = rt.cap / n_seg, t.seg_mask = n_seg - 1;
     t.key = rt.key, t.idx = rt.idx, t.row = rt.row;
     t.cursor = d_cursor;
     t.count = rt.d_count + (size_t)s * ROUTE_WORDS;
+    t.kinds = d_keep_n + R;
     return t;
   };
   for (uint32_t s = 0; s < R; s++)
@@ -2454,51 +2473,92 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       if (r.seq > seq_base[s] && r.seq - seq_base[s] > 3)
         return fail(JG_ECAPACITY, "routed round: more steps than the transport's ordering key numbers");
   const uint32_t* h_cursor = rt.h_count + (size_t)R * ROUTE_WORDS;
-  for (int attempt = 0;; attempt++) {  // (repeated once when the staging turns out too small: the pass modifies nothing)
-    HIPCHK(hipMemsetAsync(rt.d_count, 0, words * 4, st));
-    std::vector<JgRouteRecJob> rjobs;
-    std::vector<JgRouteXqJob> xjobs;
-    uint32_t widest = 0;
+  // the bucket pass's counters (their size does not depend on the round's rows): cleared with the tallies, in one launch
+  JgRouteBuckets bk{};
+  const uint32_t tile_bits = std::min<uint32_t>(JG_ROUTE_TILE_BITS, rt.group_bits);
+  bk.n_buckets = R << (rt.group_bits - tile_bits);
+  const uint32_t n_tiles = (bk.n_buckets + JG_ROUTE_SCAN_TILE - 1) / JG_ROUTE_SCAN_TILE;
+  {
+    const size_t bk_words = (size_t)n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets + n_tiles + 1;  // hist (whole tiles) | cur | tile
+    if (rt.bk_cap < bk_words) {
+      if (rt.bk_hist) HIPCHK(hipFree(rt.bk_hist));
+      rt.bk_cap = (uint32_t)bk_words;
+      HIPCHK(hipMalloc((void**)&rt.bk_hist, bk_words * 4));
+    }
+    bk.hist = rt.bk_hist, bk.cur = bk.hist + (size_t)n_tiles * JG_ROUTE_SCAN_TILE, bk.tile = bk.cur + bk.n_buckets;
+  }
+  const uint32_t bk_clear = n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets;  // counts and cursors
+  // the delivering pass's jobs: every (sender, step) in one launch, every sender's exceptional-row queue in another
+  std::vector<JgRouteRecJob> rjobs;
+  std::vector<JgRouteXqJob> xjobs;
+  uint32_t widest_r = 0;
+  size_t rb = 0, xb = 0;
+  auto route_jobs = [&]() -> int {  // (again on a repeated attempt: the table carries the staging's size and the key layout)
+    rjobs.clear(), xjobs.clear(), widest_r = 0;
     for (uint32_t s = 0; s < R; s++) {
       jg_engine* e = c->nodes[s];
       const JgRouteTable t = table(s);
       for (const StepRec& r : e->recs)
         if (r.seq > seq_base[s] && r.d_msg) {
-          if (multi) {
-            JgRouteRecJob j{};
-            j.t = t, j.n = r.n, j.per_row = r.msg_per_row, j.step = r.seq - seq_base[s];
-            j.msg_cnt = r.d_msg_cnt, j.msg = r.d_msg, j.fsm_cnt = r.d_fsm_cnt;
-            rjobs.push_back(j);
-            widest = std::max(widest, r.n);
-          } else {
-            hipLaunchKernelGGL(k_route_rec, dim3((r.n + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS)), dim3(JG_BLOCK), 0, st, t, r.n, r.msg_per_row,
-                               r.seq - seq_base[s], (const uint32_t*)r.d_msg_cnt, (const jg_msg_row*)r.d_msg, (const uint32_t*)r.d_fsm_cnt);
-          }
+          JgRouteRecJob j{};
+          j.t = t, j.n = r.n, j.per_row = r.msg_per_row, j.step = r.seq - seq_base[s];
+          j.msg_cnt = r.d_msg_cnt, j.msg = r.d_msg, j.fsm_cnt = r.d_fsm_cnt;
+          rjobs.push_back(j);
+          widest_r = std::max(widest_r, r.n);
         }
-      if (multi) {
-        JgRouteXqJob j{};
-        j.t = t, j.xq = e->dev.xq, j.xq_n = e->dev.xq_n, j.xq_cap = e->dev.xq_cap, j.seq_base = seq_base[s];
-        xjobs.push_back(j);
-      } else {
-        hipLaunchKernelGGL(k_route_xq<false>, dim3(1024), dim3(JG_BLOCK), 0, st, t, (const JgXqRec*)e->dev.xq, (const uint32_t*)e->dev.xq_n,
-                           e->dev.xq_cap, seq_base[s], (JgXqRec*)nullptr, (uint32_t*)nullptr);
-      }
+      JgRouteXqJob j{};
+      j.t = t, j.xq = e->dev.xq, j.xq_n = e->dev.xq_n, j.xq_cap = e->dev.xq_cap, j.seq_base = seq_base[s];
+      xjobs.push_back(j);
     }
-    if (multi) {  // every (sender, step) in one launch, every sender's exceptional-row queue in another
-      if (rjobs.size() * sizeof(JgRouteRecJob) > jg_dense_cluster::Route::JOB_SLICE || xjobs.size() * sizeof(JgRouteXqJob) > jg_dense_cluster::Route::JOB_SLICE)
-        return fail(JG_ECAPACITY, "routed round: too many undrained steps for the transport's job table");
-      // (every attempt ends with a synchronisation - the counts - so the staging is free again)
-      const int sa = 3;
-      char* hs = slice_h(sa);
-      const size_t rb = rjobs.size() * sizeof(JgRouteRecJob), xb = xjobs.size() * sizeof(JgRouteXqJob);
-      if (rb + xb > jg_dense_cluster::Route::JOB_SLICE) return fail(JG_ECAPACITY, "routed round: too many undrained steps for the transport's job table");
-      std::memcpy(hs, rjobs.data(), rb);
-      std::memcpy(hs + rb, xjobs.data(), xb);
-      HIPCHK(hipMemcpyAsync(slice_d(sa), hs, rb + xb, hipMemcpyHostToDevice, st));
+    rb = rjobs.size() * sizeof(JgRouteRecJob), xb = xjobs.size() * sizeof(JgRouteXqJob);
+    if (rb + xb > jg_dense_cluster::Route::JOB_SLICE) return fail(JG_ECAPACITY, "routed round: too many undrained steps for the transport's job table");
+    std::memcpy(slice_h(3), rjobs.data(), rb);
+    std::memcpy(slice_h(3) + rb, xjobs.data(), xb);
+    return JG_OK;
+  };
+  if ((rc = route_jobs())) return rc;
+  if (multi) {  // slices 0-3 in one copy
+    if (!jobs_a.empty()) std::memcpy(slice_h(0), jobs_a.data(), jobs_a.size() * sizeof(JgApplyJob));
+    if (!jobs_v.empty()) std::memcpy(slice_h(0) + jobs_a.size() * sizeof(JgApplyJob), jobs_v.data(), jobs_v.size() * sizeof(JgApplyJob));
+    if (!jobs_b.empty()) std::memcpy(slice_h(1), jobs_b.data(), jobs_b.size() * sizeof(JgApplyJob));
+    if (!fjobs.empty()) std::memcpy(slice_h(2), fjobs.data(), fjobs.size() * sizeof(JgFollowerJob));
+    HIPCHK(hipMemcpyAsync(slice_d(0), slice_h(0), 4 * jg_dense_cluster::Route::JOB_SLICE, hipMemcpyHostToDevice, st));
+  }
+  // -- 1. (launches) what the transport delivered last round, then this round's injected rows
+  if ((rc = apply_all(0, jobs_a, widest_a))) return rc;
+  if (!jobs_v.empty()) {  // (different nodes than jobs_a's: the two launches are independent of each other)
+    hipLaunchKernelGGL(k_apply_votes_multi, dim3(grid_for(widest_v, L->count_slots), (uint32_t)jobs_v.size()), dim3(JG_BLOCK), 0, L->stream,
+                       (const JgApplyJob*)slice_d(0) + jobs_a.size());
+    HIPCHK(hipGetLastError());
+  }
+  if ((rc = apply_all(1, jobs_b, widest_b))) return rc;
+  // -- 2. the dense round; ClientRequests only where the lead node (still) leads
+  hipLaunchKernelGGL(k_route_mask_appends, dim3((c->G + 255) / 256), dim3(256), 0, L->stream, c->G, (const uint32_t*)L->dev.flags,
+                     (const uint64_t*)c->offered, c->acks + (size_t)c->lead * c->G);
+  if ((rc = cluster_round_body(c, now_ms, true, false, multi ? slice_h(2) : nullptr, multi ? slice_d(2) : nullptr, multi ? &fjobs : nullptr))) return rc;
+  T1 = clk();
+  // -- 3. the transport, on the lead node's stream behind everybody's round
+  for (uint32_t r = 0; r < R; r++)
+    if (r != c->lead && (rc = jg_stream_wait(L, c->nodes[r]))) return rc;
+  for (int attempt = 0;; attempt++) {  // (repeated once when the staging turns out too small: the pass modifies nothing)
+    hipLaunchKernelGGL(k_route_clear, dim3(64), dim3(JG_BLOCK), 0, st, rt.d_count, (uint32_t)words, bk.hist, bk_clear);
+    if (attempt) {  // (every attempt ends with a synchronisation - the counts - so the staging is free again)
+      if ((rc = route_jobs())) return rc;
+      if (multi) HIPCHK(hipMemcpyAsync(slice_d(3), slice_h(3), rb + xb, hipMemcpyHostToDevice, st));
+    }
+    if (multi) {
       if (!rjobs.empty())
-        hipLaunchKernelGGL(k_route_rec_multi, dim3((widest + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS), (uint32_t)rjobs.size()), dim3(JG_BLOCK), 0, st,
-                           (const JgRouteRecJob*)slice_d(sa));
-      hipLaunchKernelGGL(k_route_xq_multi, dim3(1024, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteXqJob*)(slice_d(sa) + rb));
+        hipLaunchKernelGGL(k_route_rec_multi, dim3((widest_r + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS), (uint32_t)rjobs.size()), dim3(JG_BLOCK), 0, st,
+                           (const JgRouteRecJob*)slice_d(3));
+      // (256 workgroups per queue: a round's queue holds a few ten thousand rows, and every workgroup - busy or not - pays the tally)
+      hipLaunchKernelGGL(k_route_xq_multi, dim3(256, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteXqJob*)(slice_d(3) + rb));
+    } else {
+      for (const JgRouteRecJob& j : rjobs)
+        hipLaunchKernelGGL(k_route_rec, dim3((j.n + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS)), dim3(JG_BLOCK), 0, st, j.t, j.n, j.per_row,
+                           j.step, j.msg_cnt, j.msg, j.fsm_cnt);
+      for (const JgRouteXqJob& j : xjobs)
+        hipLaunchKernelGGL(k_route_xq<false>, dim3(1024), dim3(JG_BLOCK), 0, st, j.t, j.xq, j.xq_n, j.xq_cap, j.seq_base, (JgXqRec*)nullptr,
+                           (uint32_t*)nullptr);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(rt.h_count, rt.d_count, words * 4, hipMemcpyDeviceToHost, st));
@@ -2507,15 +2567,19 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     T3 = clk();
     bool wide = false;  // some group emitted more rows in one step than the narrow index field numbers
     for (uint32_t s = 0; s < R; s++) wide = wide || rt.h_count[(size_t)s * ROUTE_WORDS + R + JG_ROUTE_OVERFLOW];
-    if (*h_cursor <= rt.cap && !wide) break;
+    uint64_t fullest = 0;  // (a segment that ran over: every segment gets that much room, and the pass is repeated)
+    for (uint32_t k = 0; k < n_seg; k++) fullest = std::max<uint64_t>(fullest, h_cursor[k]);
+    const bool fits = fullest <= rt.cap / n_seg;
+    if (fits && !wide) break;
     if (attempt >= 2) return fail(JG_EDEVICE, "internal: routed round: the delivering pass does not settle");
     if (wide) {
       if (ord_bits == JG_ROUTE_ORD_BITS) return fail(JG_ECAPACITY, "routed round: a group emitted too many rows in one step");
       ord_bits = JG_ROUTE_ORD_BITS;
     }
-    if (*h_cursor > rt.cap && (rc = route_grow(rt, *h_cursor))) return rc;
+    if (!fits && (rc = route_grow(rt, fullest * n_seg))) return rc;
   }
-  const uint32_t total = *h_cursor;
+  uint32_t total = 0, fullest_seg = 0;
+  for (uint32_t k = 0; k < n_seg; k++) total += h_cursor[k], fullest_seg = std::max(fullest_seg, h_cursor[k]);
   std::vector<uint64_t> to(R, 0), from(R, 0);
   uint64_t kept = 0, fsm = 0;
   for (uint32_t s = 0; s < R; s++) {
@@ -2525,6 +2589,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     fsm += h[R + JG_ROUTE_FSM];
   }
   // senders that keep rows for the host: the delivered ones leave their slots / the exceptional queue
+  JgWordList emptied{};  // exceptional-row queues that were delivered whole: their counts go to zero in one launch
   for (uint32_t s = 0; s < R; s++) {
     jg_engine* e = c->nodes[s];
     const uint32_t* h = rt.h_count + (size_t)s * ROUTE_WORDS;
@@ -2546,33 +2611,22 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       HIPCHK(hipMemcpyAsync(e->dev.xq, rt.xq_keep[s], (size_t)kx * sizeof(JgXqRec), hipMemcpyDeviceToDevice, st));
       HIPCHK(hipMemcpyAsync(e->dev.xq_n, d_keep_n + s, 4, hipMemcpyDeviceToDevice, st));
     } else {
-      HIPCHK(hipMemsetAsync(e->dev.xq_n, 0, 4, st));
+      emptied.p[emptied.n++] = e->dev.xq_n;
     }
   }
+  if (emptied.n) hipLaunchKernelGGL(k_route_clear_words, dim3(1), dim3(64), 0, st, emptied);
   // the staged rows in (destination, group, sender, step, emission) order -> the command columns of every
   // node's next round: bucket by (destination, group tile), sort every bucket in LDS (jg_route.h); the
   // library sort stays behind JG_ROUTE_LIBRARY_SORT=1 for an A/B
-  static const bool library_sort = std::getenv("JG_ROUTE_LIBRARY_SORT") != nullptr;
   if (total && !library_sort) {
-    JgRouteBuckets bk{};
-    const uint32_t tile_bits = std::min<uint32_t>(JG_ROUTE_TILE_BITS, rt.group_bits);
-    bk.shift = ord_bits + 5 + tile_bits;
-    bk.n_buckets = R << (rt.group_bits - tile_bits);
-    const uint32_t n_tiles = (bk.n_buckets + JG_ROUTE_SCAN_TILE - 1) / JG_ROUTE_SCAN_TILE;
-    const size_t words = (size_t)n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets + n_tiles + 1;  // hist (whole tiles) | cur | tile
-    if (rt.bk_cap < words) {
-      if (rt.bk_hist) HIPCHK(hipFree(rt.bk_hist));
-      rt.bk_cap = (uint32_t)words;
-      HIPCHK(hipMalloc((void**)&rt.bk_hist, words * 4));
-    }
-    bk.hist = rt.bk_hist, bk.cur = bk.hist + (size_t)n_tiles * JG_ROUTE_SCAN_TILE, bk.tile = bk.cur + bk.n_buckets;
-    HIPCHK(hipMemsetAsync(bk.hist, 0, ((size_t)n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets) * 4, st));  // counts and cursors
-    const uint32_t grid = std::min<uint32_t>((total + JG_BLOCK - 1) / JG_BLOCK, 4096);
-    hipLaunchKernelGGL(k_route_hist, dim3(grid), dim3(JG_BLOCK), 0, st, total, (const uint64_t*)rt.key, bk);
+    bk.shift = ord_bits + 5 + tile_bits;  // (its counters were cleared with the tallies, before the delivering pass)
+    const uint32_t grid = std::min<uint32_t>((fullest_seg + JG_BLOCK - 1) / JG_BLOCK, 4096 / n_seg);
+    const uint32_t seg_cap = rt.cap / n_seg;
+    hipLaunchKernelGGL(k_route_hist, dim3(grid, n_seg), dim3(JG_BLOCK), 0, st, (const uint32_t*)d_cursor, seg_cap, (const uint64_t*)rt.key, bk);
     hipLaunchKernelGGL(k_route_scan, dim3(n_tiles), dim3(JG_BLOCK), 0, st, bk);
     hipLaunchKernelGGL(k_route_scan_tiles, dim3(1), dim3(JG_BLOCK), 0, st, bk);
-    hipLaunchKernelGGL(k_route_scatter, dim3(grid), dim3(JG_BLOCK), 0, st, total, (const uint64_t*)rt.key, (const uint32_t*)rt.idx, bk,
-                       rt.key_alt, rt.idx_alt);
+    hipLaunchKernelGGL(k_route_scatter, dim3(grid, n_seg), dim3(JG_BLOCK), 0, st, (const uint32_t*)d_cursor, seg_cap, (const uint64_t*)rt.key,
+                       (const uint32_t*)rt.idx, bk, rt.key_alt, rt.idx_alt);
     hipLaunchKernelGGL(k_route_sort_build, dim3(bk.n_buckets), dim3(JG_BLOCK), 0, st, bk, rt.key_alt, rt.idx_alt, (const jg_msg_row*)rt.row,
                        rt.cols);
   } else if (total) {
@@ -2591,6 +2645,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   }
   uint32_t off = 0;
   for (uint32_t n = 0; n < R; n++) {
+    rt.kinds_in[n] = rt.h_count[(size_t)R * ROUTE_WORDS + JG_ROUTE_SEGS + R + n];
     rt.in_off[n] = off, rt.n_in[n] = (uint32_t)to[n];
     off += (uint32_t)to[n];
   }
