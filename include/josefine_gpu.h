@@ -399,7 +399,11 @@ typedef struct jg_leader_inbox { /* device pointers; answers == NULL: nothing ca
 typedef struct jg_leader_outbox { /* device pointers, all required */
   jg_leader_beat* beat; /* [G]                                                                        */
   uint64_t* ae;         /* [R][G] JG_AE(range start key = progress head of slot r, number of blocks
-                           0..JG_MAX_INFLIGHT) (leader.rs:135,152), or JG_NO_ACK: nothing for slot r  */
+                           0..JG_MAX_INFLIGHT) (leader.rs:135,152), or JG_NO_ACK: nothing for slot r.
+                           Row [own slot] is nobody's mail: while every group of the engine has the same
+                           own slot (the default; jg_set_self_slots with one value) the kernel does NOT
+                           write it - fill it with JG_NO_ACK once if something walks all R rows (the
+                           engine's own blocks - jg_dense_cluster, jg_step_node - are filled that way) */
 } jg_leader_outbox;
 
 typedef struct jg_follower_inbox { /* device pointers */

@@ -414,24 +414,28 @@ __device__ __forceinline__ int jg_dense_classify(const JgDev& d, uint32_t g, uin
 // NodeId).  Otherwise the own slot comes from the flag word and the other loads wait for it.
 // (A two-groups-per-lane variant with 16-B accesses measured no faster — the kernel is
 // bandwidth-, not issue-bound: profiles/README.md round 1 — and was dropped.)
-template <int R>
-__device__ __forceinline__ void jg_dense_outbox_none(uint32_t G, const JgLeaderNode& nd, uint32_t g) {
+// SKIP_OWN (here and below): every group of the engine has own slot `s`: row s of the `ae` block - nobody's mail,
+// JG_NO_ACK by definition - is not written at all (8 of the node tick's 64 written bytes per group; the block's
+// owner fills the row once).
+template <int R, bool SKIP_OWN>
+__device__ __forceinline__ void jg_dense_outbox_none(uint32_t G, const JgLeaderNode& nd, uint32_t g, uint32_t s) {
   nd.o_beat[g] = jg_leader_beat{0, JG_NO_ACK};
 #pragma unroll
-  for (int r = 0; r < R; r++) nd.o_ae[(size_t)r * G + g] = JG_NO_ACK;
+  for (int r = 0; r < R; r++)
+    if (!(SKIP_OWN && (uint32_t)r == s)) nd.o_ae[(size_t)r * G + g] = JG_NO_ACK;
 }
 // Command::Tick of a FAST leader into the outbox columns (leader.rs:234-245): heartbeat() if due,
 // then replicate() — per other slot the range start key (= its progress head) and the number
 // of blocks after it (Probe: nth(1) -> 1, Replicate: skip(1).take(5), leader.rs:135,152-157).
 // `mo_of(r)` = progress head of slot r; returns the flag word (with the Q9 fault if it was raised).
-template <int R, class MoOf>
+template <int R, bool SKIP_OWN, class MoOf>
 __device__ __forceinline__ uint32_t jg_dense_leader_tick(const JgDenseHot& h, const JgDev* dp, const JgLeaderNode& nd,
                                                          uint32_t g, uint32_t seq, uint32_t s, uint64_t term,
                                                          uint64_t hbt, uint64_t head, uint64_t commit, uint32_t nf,
                                                          MoOf mo_of) {
   const uint32_t G = h.G;
   if (head >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words: loud, never wrong
-    jg_dense_outbox_none<R>(G, nd, g);
+    jg_dense_outbox_none<R, SKIP_OWN>(G, nd, g, s);
     jg_push_fault(*dp, g, JG_FAULT_ENGINE_MAILBOX_RANGE, seq);
     return nf | (JG_FAULT_ENGINE_MAILBOX_RANGE << JGF_FAULT_SHIFT);
   }
@@ -468,7 +472,8 @@ __device__ __forceinline__ uint32_t jg_dense_leader_tick(const JgDenseHot& h, co
   if (due) h.heartbeat_time[g] = nd.now;
   nd.o_beat[g] = jg_leader_beat{term, hb};  // one 16-byte store
 #pragma unroll
-  for (int r = 0; r < R; r++) nd.o_ae[(size_t)r * G + g] = word[r];
+  for (int r = 0; r < R; r++)
+    if (!(SKIP_OWN && (uint32_t)r == s)) nd.o_ae[(size_t)r * G + g] = word[r];
   return nf;
 }
 
@@ -675,7 +680,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   if (!NODE) jg_count_step(h.blk_decisions, dec, hot, dl);
   if (__builtin_expect(hot, 1)) {
     if (emit)  // Command::Tick into the outbox; may raise the Q9 fault
-      lt.nf = jg_dense_leader_tick<R>(h, dp, nd, g, seq, s, term, hbt, lt.head1, lt.head1 - lt.l[R], lt.nf, [&](int r) {
+      lt.nf = jg_dense_leader_tick<R, UNIFORM>(h, dp, nd, g, seq, s, term, hbt, lt.head1, lt.head1 - lt.l[R], lt.nf, [&](int r) {
         return lt.l[r] == 0xffffffffu ? dp->match_wide[(size_t)r * h.G + g] : lt.head1 - lt.l[r];  // BEHIND: wide column
       });
     if (lt.w1 != mword0) h.mlag[g] = lt.w1;
@@ -702,7 +707,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   if ((NODE || DEFER) && cls == JG_DENSE_RUN) cls = JG_DENSE_DEFER;
   jg_defer_mark(d, g, cls == JG_DENSE_DEFER);
   if (NODE) {
-    if (emit) jg_dense_outbox_none<R>(h.G, nd, g);
+    if (emit) jg_dense_outbox_none<R, UNIFORM>(h.G, nd, g, s);
     return;
   }
   if (DEFER || cls != JG_DENSE_RUN) return;

@@ -1678,12 +1678,14 @@ int node_ensure(jg_engine* e) {
   A(n.cols.fsm_prev, G);
   A(n.o_beat, G);
   A(n.o_ae, R * G);
+  HIPCHK(hipMemsetAsync(n.o_ae, 0xff, std::max<size_t>(R * G * 8, 16), e->stream));  // (the own slot's row is never written: JG_NO_ACK once)
   A(n.o_answer, G);
   A(n.o_hbc, G);
   A(n.d_nsparse, 4);
 #undef A
   HIPCHK(hipHostMalloc((void**)&n.h_beat, std::max<size_t>(G * sizeof(jg_leader_beat), 16), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&n.h_ae, std::max<size_t>(R * G * 8, 16), hipHostMallocDefault));
+  std::memset(n.h_ae, 0xff, std::max<size_t>(R * G * 8, 16));  // (the own slot's row is not downloaded while it is the same for every group)
   HIPCHK(hipHostMalloc((void**)&n.h_answer, std::max<size_t>(G * 8, 16), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&n.h_hbc, std::max<size_t>(G * 8, 16), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&n.h_nsparse, 16, hipHostMallocDefault));
@@ -1853,8 +1855,13 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     if ((rc = dense_step(e, nd.cols.answers, 1, &ln))) return rc;
     if (tick) {
       HIPCHK(hipMemcpyAsync(nd.h_beat, nd.o_beat, (size_t)G * sizeof(jg_leader_beat), hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipMemcpyAsync(nd.h_ae, nd.o_ae, (size_t)R * G * 8, hipMemcpyDeviceToHost, e->stream));
-      bytes_down += (size_t)G * (sizeof(jg_leader_beat) + (size_t)R * 8);
+      // (the own slot's row is JG_NO_ACK on both sides and stays there: not written, not downloaded)
+      const uint32_t own = e->uniform_self >= 0 ? (uint32_t)e->uniform_self : R;
+      if (own > 0) HIPCHK(hipMemcpyAsync(nd.h_ae, nd.o_ae, (size_t)std::min(own, R) * G * 8, hipMemcpyDeviceToHost, e->stream));
+      if (own + 1 < R)
+        HIPCHK(hipMemcpyAsync(nd.h_ae + (size_t)(own + 1) * G, nd.o_ae + (size_t)(own + 1) * G, (size_t)(R - own - 1) * G * 8, hipMemcpyDeviceToHost,
+                              e->stream));
+      bytes_down += (size_t)G * (sizeof(jg_leader_beat) + (size_t)(own < R ? R - 1 : R) * 8);
     }
   }
   if (halves & JG_NODE_FOLLOWER_HALF) {
@@ -2019,7 +2026,9 @@ int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t 
   // (JG_NO_ACK there is outside the own slot's domain: JG_FAULT_ENGINE_DENSE_APPENDS)
   for (size_t g = 0; g < G; g++) a[(size_t)lead * G + g] = JG_ANSWER(0, JG_HB_NONE);
   if ((rc = jg_device_upload(L, c->acks, a.data(), a.size() * 8)) ||
-      (rc = jg_device_upload(L, c->offered, a.data() + (size_t)lead * G, G * 8))) {
+      (rc = jg_device_upload(L, c->offered, a.data() + (size_t)lead * G, G * 8)) ||
+      // (the lead node's own row of the AppendEntries block is never written by its kernel: JG_NO_ACK once)
+      hipMemsetAsync(c->o_ae, 0xff, 8 * R * G, L->stream) != hipSuccess) {
     jg_dense_cluster_destroy(c);
     return rc;
   }

@@ -415,6 +415,11 @@ class BatchedRaft:
             outbox = capi.LeaderOutbox()
             beat, outbox.beat = self._out_buffer((self.G, 2), np.uint64, keep)
             ae, outbox.ae = self._out_buffer((self.R, self.G), np.uint64, keep)
+            # (row [own slot] of the block is nobody's mail and is not written while the own slot is the same for
+            # every group: JG_NO_ACK by the block's owner, include/josefine_gpu.h jg_leader_outbox)
+            ae[:] = np.uint64(capi.NO_ACK)
+            if self._is_device():
+                self._check(self.api.device_upload(self._h, C.c_void_p(outbox.ae), ae.ctypes.data, ae.nbytes))
             outs = [(beat, outbox.beat), (ae, outbox.ae)]
             outbox_p = C.byref(outbox)
         try:

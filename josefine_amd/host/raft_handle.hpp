@@ -436,6 +436,8 @@ class DenseCluster {
     std::vector<uint64_t> a((size_t)R_ * G_, JG_NO_ACK);  // nothing from anybody; own slot: zero appends
     for (uint32_t g = 0; g < G_; g++) a[(size_t)lead_ * G_ + g] = JG_ANSWER(0, JG_HB_NONE);
     check(jg_device_upload(L, answers_, a.data(), a.size() * 8));
+    std::fill(a.begin(), a.end(), JG_NO_ACK);  // (the lead node's own row of the AppendEntries block is never written: jg_leader_outbox)
+    check(jg_device_upload(L, o_ae_, a.data(), a.size() * 8));
   }
   ~DenseCluster() {
     for (void* p : bufs_) (void)jg_device_free(nodes_[lead_], p);
