@@ -155,10 +155,13 @@ struct JgLane {
   jg_fsm_row* fend;
   uint32_t overflow;  // an output row did not fit its bound (engine bug guard)
   uint32_t xq_on;     // 1: message rows go to the exceptional queue d.xq instead of [mp, mend);
-                      // 2: the same, but AppendResponse / HeartbeatResponse are captured below
+                      // 2: the same, but AppendResponse / HeartbeatResponse are captured below;
+                      // 3: the same, but a leader Tick's Heartbeat is captured (cap_hbc) and its AppendEntries
+                      //    go straight into the outbox block cap_ae (k_dense_slow: no row buffer in scratch)
   uint32_t xq_k;      // emission index within this step
   uint64_t cap_ack, cap_hbc;  // follower half of the dense node tick: outbox row of this group
   uint32_t cap_has;
+  uint64_t* cap_ae;           // leader half (xq_on == 3): the [R][G] AppendEntries block of the outbox
 };
 
 __device__ __forceinline__ uint32_t jg_role(const JgLane& L) { return L.flags & JGF_ROLE_MASK; }
@@ -273,6 +276,8 @@ __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   d.votes[g] = L.votes;
 }
 
+__device__ inline int jg_slot_of(const JgDev& d, uint32_t node_id);
+
 // ---- output rows ------------------------------------------------------------------
 __device__ inline void jg_emit_msg(const JgDev& d, JgLane& L, uint8_t kind, uint8_t to_kind, uint32_t to_id,
                                    uint8_t flag, uint64_t term, uint64_t id, uint64_t aux) {
@@ -288,6 +293,17 @@ __device__ inline void jg_emit_msg(const JgDev& d, JgLane& L, uint8_t kind, uint
     if (kind == JG_CMD_HEARTBEAT_RESPONSE) {
       L.cap_hbc = id;
       L.cap_has = flag;
+      return;
+    }
+  }
+  if (L.xq_on == 3) {  // dense mailbox vocabulary of the leader half's Tick (leader.rs:234-245)
+    if (kind == JG_CMD_HEARTBEAT) {
+      L.cap_hbc = id;  // Heartbeat.commit
+      return;
+    }
+    if (kind == JG_CMD_APPEND_ENTRIES) {  // to one peer: (range start key, number of blocks)
+      const int r = jg_slot_of(d, to_id);
+      if (r >= 0) L.cap_ae[(size_t)r * d.G + L.g] = JG_AE(id, aux);
       return;
     }
   }

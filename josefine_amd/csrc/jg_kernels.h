@@ -140,22 +140,12 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
         jg_apply(d, L, c, nullptr, nullptr);  // rows: the blocks are not id-consecutive
       } else if (L.head >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words
         jg_raise(d, L, JG_FAULT_ENGINE_MAILBOX_RANGE);
-      } else {                                // columns, via a local row buffer
-        jg_msg_row loc[JG_MAX_REPLICAS + 1];
-        L.xq_on = 0;
-        L.mp = loc;
-        L.mend = loc + JG_MAX_REPLICAS + 1;
+      } else {                                // columns: the Tick's rows are captured as they are emitted
+        L.xq_on = 3;
+        L.cap_hbc = JG_NO_ACK;
+        L.cap_ae = nd.o_ae;
         jg_apply(d, L, c, nullptr, nullptr);
-        uint64_t hb = JG_NO_ACK;
-        for (jg_msg_row* m = loc; m < L.mp; m++) {
-          if (m->kind == JG_CMD_HEARTBEAT) {
-            hb = m->id;
-          } else {  // AppendEntries to one peer
-            const int r = jg_slot_of(d, m->to_id);
-            nd.o_ae[(size_t)r * d.G + g] = JG_AE(m->id, m->aux);
-          }
-        }
-        nd.o_beat[g] = jg_leader_beat{L.term, hb};
+        nd.o_beat[g] = jg_leader_beat{L.term, L.cap_hbc};
       }
     }
     if (NODE && nd.fsm_delta) {
