@@ -463,8 +463,16 @@ def event_loop_main(args):
     cands = sorted({max(1, int(x)) for x in str(args.loops).split(",") if x.strip()})
     cands = [c for c in cands if G % c == 0] or [1]  # (the partitions divide evenly over the loops)
 
+    def hw_queues(loops):
+        """Every loop has two streams (steps, drains); the HIP runtime multiplexes a process's streams onto 4 hardware
+        queues unless told otherwise (GPU_MAX_HW_QUEUES), and streams that share one run one behind the other."""
+        return os.environ.get("GPU_MAX_HW_QUEUES") or (str(2 * loops) if loops > 2 else None)
+
     def run(mode, k, w, loops=1):
-        r = subprocess.run([exe, str(G), str(R), str(k), str(w), mode, "0", str(loops)], capture_output=True, text=True, timeout=1200)
+        env = dict(os.environ)
+        if hw_queues(loops):
+            env["GPU_MAX_HW_QUEUES"] = hw_queues(loops)
+        r = subprocess.run([exe, str(G), str(R), str(k), str(w), mode, "0", str(loops)], capture_output=True, text=True, timeout=1200, env=env)
         if r.returncode != 0:
             raise SystemExit(f"bench_event_loop {mode} x {loops} failed: {r.stdout} {r.stderr}")
         return json.loads(r.stdout.strip().splitlines()[-1])
@@ -499,6 +507,8 @@ def event_loop_main(args):
                    "q9": "off (JG_CFG_SEPARATE_COMMIT_KEY)", "devices": [0], "devices_aliased": False},
         "event_loop": {
             "loops": L, "decisions_per_s_by_loops": d_by_loops,
+            "hip_hardware_queues": {"GPU_MAX_HW_QUEUES": hw_queues(L), "note": "2 per loop (its step stream and its drain stream); the runtime's default of 4 "
+                                    "makes the loops' streams share queues: 8.5-8.9e8/s instead of 1.0e9 with row inbound on 8 loops"},
             "ms_per_tick_per_loop": {"transport_decode_into_pinned_columns": d["ms_fill"], "submit_commit_validation": d["ms_submit"],
                                      "step_node_and_drains": d["ms_step_and_drain"], "all_loops_side_by_side": d["ms_per_tick"]},
             "one_loop": {"what": "ONE loop (one host thread, one engine) owns every partition: nothing overlaps",
