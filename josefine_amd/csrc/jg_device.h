@@ -278,6 +278,50 @@ __device__ inline void jg_store(const JgDev& d, JgLane& L) {
 
 __device__ inline int jg_slot_of(const JgDev& d, uint32_t node_id);
 
+// jg_store for a lane whose state as loaded is still at hand (`O`: a copy of the lane right after jg_load): only the
+// columns whose value changed are written.  The general kernels touch a group here and a group there: every
+// 4- or 8-byte store is a memory transaction of its own, and a step that flips a vote wrote all fourteen columns
+// (the routed round's state machine launches and the slow kernels are bound by exactly these transactions).
+// A role change switches the commit index's representation (packed into mlag for leaders): everything is written then.
+template <bool CHAIN = true>
+__device__ inline void jg_store_dirty(const JgDev& d, JgLane& L, const JgLane& O) {
+  if (jg_role(L) != jg_role(O)) {
+    jg_store<CHAIN>(d, L);
+    return;
+  }
+  const uint32_t g = L.g;
+  if (CHAIN && jg_wcnt(L)) jg_chain_normalize(d, L);
+  const bool run = (L.run_hi == L.head) && (jg_wcnt(L) == 0) && !(L.flags & JGF_NO_GENESIS);
+  const bool fast = run && (L.id_gen == L.head + 1);
+  L.flags = run ? (L.flags | JGF_RUN) : (L.flags & ~JGF_RUN);
+  L.flags = fast ? (L.flags | JGF_FAST) : (L.flags & ~JGF_FAST);
+  if (!fast && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L)) *d.irregular_seen = 1;
+  if (jg_role(L) == JG_ROLE_LEADER) {
+    if (L.mbase != L.head) jg_match_rebase(d, L);
+    const uint64_t fc = jg_lag_encode(L.commit, L.head, d.R);
+    if (jg_lag_wide(fc, d.R)) d.commit[g] = L.commit;
+    const uint64_t w = jg_lag_with(L.mword, d.R, d.R, fc);
+    if (w != O.mword) d.mlag[g] = w;  // (O.mword: the packed word as loaded, commit field included)
+  } else if (L.commit != O.commit) {
+    d.commit[g] = L.commit;
+  }
+  if (L.flags != O.flags) d.flags[g] = L.flags;
+  if (L.term != O.term) d.term[g] = L.term;
+  if (L.head != O.head) d.head[g] = L.head;
+  // (these two are implicit while the chain is in FAST / RUN form - jg_load and jg_read_state do not look at the
+  // columns then - so they are written when the lane LEAVES that form or changes them outside it)
+  if (!fast && (L.id_gen != O.id_gen || (O.flags & JGF_FAST))) d.id_gen[g] = L.id_gen;
+  if (!run && (L.run_hi != O.run_hi || (O.flags & JGF_RUN))) d.run_hi[g] = L.run_hi;
+  if (L.election_time != O.election_time) d.election_time[g] = L.election_time;
+  if (L.heartbeat_time != O.heartbeat_time) d.heartbeat_time[g] = L.heartbeat_time;
+  if (L.voted_for != O.voted_for) d.voted_for[g] = L.voted_for;
+  if (L.leader_id != O.leader_id) d.leader_id[g] = L.leader_id;
+  if (L.election_timeout != O.election_timeout) d.election_timeout[g] = L.election_timeout;
+  if (L.rng_draws != O.rng_draws) d.rng_draws[g] = L.rng_draws;
+  if (L.queued != O.queued) d.queued[g] = L.queued;
+  if (L.votes != O.votes) d.votes[g] = L.votes;
+}
+
 // ---- output rows ------------------------------------------------------------------
 __device__ inline void jg_emit_msg(const JgDev& d, JgLane& L, uint8_t kind, uint8_t to_kind, uint32_t to_id,
                                    uint8_t flag, uint64_t term, uint64_t id, uint64_t aux) {

@@ -90,11 +90,12 @@ __device__ __forceinline__ void jg_apply_rows_body(const JgDev& d, const JgRowsA
     uint32_t longest = run;
 #pragma unroll
     for (int off = 32; off; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off, 64));
-    JgLane L;
+    JgLane L, O;  // (O: the lane as loaded - jg_store_dirty writes what changed)
     jg_msg_row* m0 = nullptr;
     jg_fsm_row* f0 = nullptr;
     if (owner) {
       jg_load(d, L, g);
+      O = L;
       L.now = a.now;
       L.seq = a.seq;
       m0 = a.msg_out + (size_t)i * a.msg_per_row;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void jg_apply_rows_body(const JgDev& d, const JgRowsA
       a.fsm_cnt[i] = cf;
       if (L.overflow) *a.err = 1;
       dec += L.decisions;
-      jg_store<KINDS != JG_KINDS_ELECTION>(d, L);
+      jg_store_dirty<KINDS != JG_KINDS_ELECTION>(d, L, O);
     }
     // the tile's sums (tile = the JG_BLOCK rows this workgroup just served)
     __shared__ uint32_t red_m[JG_BLOCK / 64], red_f[JG_BLOCK / 64];
@@ -174,6 +175,117 @@ __global__ __launch_bounds__(JG_BLOCK) void k_apply_rows_multi(const JgApplyJob*
 __global__ __launch_bounds__(JG_BLOCK) void k_apply_votes_multi(const JgApplyJob* __restrict__ jobs) {
   const JgApplyJob& j = jobs[blockIdx.y];
   jg_apply_rows_body<JG_KINDS_ELECTION>(j.d, j.a);
+}
+
+// ---- a RUN per lane -----------------------------------------------------------------------------------
+// The batches a cluster's transport delivers are runs of 4 to 16 rows per group (a voter's four copies of a
+// VoteRequest, candidate.rs:30-37; a candidate's sixteen VoteResponses): with a lane per ROW, one lane of the
+// wave walks the run while the run's other lanes wait - 10 lanes of 64 at work, every wave as slow as its
+// longest run (104 us for the 1.3 M delivered rows of a configs[4] round).  Here a workgroup stages a tile of
+// JG_RUN_TILE rows in LDS (coalesced loads, as before), compacts the run starts of the tile into a list, and
+// every lane takes a RUN off that list: ~160 of 256 lanes at work.  A run that crosses the tile's end is
+// finished from global memory by the lane that started it.  Outputs, counts and tile sums exactly as
+// jg_apply_rows_body leaves them.
+#define JG_RUN_TILE 1024u
+template <uint32_t KINDS = JG_KINDS_ALL>
+__device__ __forceinline__ void jg_apply_runs_body(const JgDev& d, const JgRowsArgs& a) {
+  static_assert(JG_RUN_TILE % JG_BLOCK == 0 && JG_RUN_TILE <= 65536, "tile geometry");
+  constexpr uint32_t T = JG_RUN_TILE, SUB = JG_RUN_TILE / JG_BLOCK;
+  __shared__ uint64_t s_term[T], s_id[T], s_aux[T];
+  __shared__ uint32_t s_group[T], s_from[T];
+  __shared__ uint8_t s_kind[T], s_flag[T];
+  __shared__ uint16_t s_start[T];
+  __shared__ uint32_t s_n, s_bm[SUB], s_bf[SUB];
+  uint32_t dec = 0;
+  for (uint32_t tile0 = blockIdx.x * T; tile0 < a.n; tile0 += gridDim.x * T) {  // (workgroup-uniform trips)
+    if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x < SUB) s_bm[threadIdx.x] = 0, s_bf[threadIdx.x] = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SUB; k++) {
+      const uint32_t j = k * JG_BLOCK + threadIdx.x, i = tile0 + j;
+      if (i >= a.n) continue;
+      uint8_t kind = a.kind[i];
+      const uint64_t id = a.id[i], aux = a.aux[i];
+      // (a device-resident batch is not validated by the host: see jg_apply_rows_body)
+      if (kind == JG_CMD_APPEND_ENTRIES && a.blk_id && (aux > a.n_blocks || id > a.n_blocks - aux)) {
+        *a.err = 5;
+        kind = JG_CMD_NOOP;
+      }
+      s_kind[j] = kind, s_flag[j] = a.flag[i], s_from[j] = a.from[i], s_group[j] = a.group[i];
+      s_term[j] = a.term[i], s_id[j] = id, s_aux[j] = aux;
+      a.msg_cnt[i] = 0;
+      a.fsm_cnt[i] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < SUB; k++) {
+      const uint32_t j = k * JG_BLOCK + threadIdx.x, i = tile0 + j;
+      if (i >= a.n) continue;
+      const uint32_t g = s_group[j];
+      const uint32_t gp = j ? s_group[j - 1] : (i ? a.group[i - 1] : 0xffffffffu);
+      const bool start = !(i && gp == g);
+      if (start && i && gp > g) *a.err = 2;
+      if (start && g >= d.G) *a.err = 3;
+      if (start && g < d.G) s_start[atomicAdd(&s_n, 1u)] = (uint16_t)j;  // (the order of the list is immaterial: groups are independent)
+    }
+    __syncthreads();
+    const uint32_t n_runs = s_n;
+    for (uint32_t r = threadIdx.x; r < n_runs; r += JG_BLOCK) {
+      const uint32_t j = s_start[r], i = tile0 + j, g = s_group[j];
+      uint32_t run = 1;
+      while (j + run < T && i + run < a.n && s_group[j + run] == g) run++;
+      if (j + run == T)
+        while (i + run < a.n && a.group[i + run] == g) run++;
+      JgLane L;
+      jg_load(d, L, g);
+      const JgLane O = L;
+      L.now = a.now;
+      L.seq = a.seq;
+      jg_msg_row* const m0 = a.msg_out + (size_t)i * a.msg_per_row;
+      jg_fsm_row* const f0 = a.fsm_out + (size_t)i * a.fsm_per_row;
+      L.mp = m0;
+      L.mend = m0 + (size_t)run * a.msg_per_row;
+      L.fp = f0;
+      L.fend = f0 + (size_t)run * a.fsm_per_row;
+      for (uint32_t t = 0; t < run; t++) {
+        JgCmd c;
+        if (j + t < T) {
+          c.kind = s_kind[j + t], c.from = s_from[j + t], c.flag = s_flag[j + t];
+          c.term = s_term[j + t], c.id = s_id[j + t], c.aux = s_aux[j + t];
+        } else {  // the run continues in the next tile's rows
+          const uint32_t k = i + t;
+          c.kind = a.kind[k], c.from = a.from[k], c.flag = a.flag[k];
+          c.term = a.term[k], c.id = a.id[k], c.aux = a.aux[k];
+          if (c.kind == JG_CMD_APPEND_ENTRIES && a.blk_id && (c.aux > a.n_blocks || c.id > a.n_blocks - c.aux)) c.kind = JG_CMD_NOOP;
+        }
+        jg_apply<KINDS>(d, L, c, a.blk_id, a.blk_next);
+      }
+      const uint32_t cm = (uint32_t)(L.mp - m0), cf = (uint32_t)(L.fp - f0);
+      a.msg_cnt[i] = cm;
+      a.fsm_cnt[i] = cf;
+      if (cm) atomicAdd(&s_bm[j / JG_BLOCK], cm);
+      if (cf) atomicAdd(&s_bf[j / JG_BLOCK], cf);
+      if (L.overflow) *a.err = 1;
+      dec += L.decisions;
+      jg_store_dirty<KINDS != JG_KINDS_ELECTION>(d, L, O);
+    }
+    __syncthreads();
+    // the sums of the JG_BLOCK-row tiles the drain's scan starts from
+    if (threadIdx.x < SUB && tile0 + threadIdx.x * JG_BLOCK < a.n) {
+      a.bsum_m[tile0 / JG_BLOCK + threadIdx.x] = s_bm[threadIdx.x];
+      a.bsum_f[tile0 / JG_BLOCK + threadIdx.x] = s_bf[threadIdx.x];
+    }
+    __syncthreads();
+  }
+  jg_block_count(d.blk_decisions, dec);
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_apply_runs_multi(const JgApplyJob* __restrict__ jobs) {
+  const JgApplyJob& j = jobs[blockIdx.y];
+  jg_apply_runs_body(j.d, j.a);
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_apply_vote_runs_multi(const JgApplyJob* __restrict__ jobs) {
+  const JgApplyJob& j = jobs[blockIdx.y];
+  jg_apply_runs_body<JG_KINDS_ELECTION>(j.d, j.a);
 }
 
 // ---- drain-time compaction, entirely on the device -------------------------------------------

@@ -1066,10 +1066,13 @@ void sort_rows_by_group(const uint32_t* group, size_t n, uint32_t n_groups, std:
 // everything of a k_apply_rows step but the launch: output regions, the step record, the host-side bookkeeping
 int prepare_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* kind, const uint32_t* from,
                  const uint64_t* term, const uint64_t* id, const uint64_t* aux, const uint8_t* flag,
-                 const uint64_t* blk_id, const uint64_t* blk_next, uint64_t n_blocks, uint64_t now_ms, JgRowsArgs* out) {
+                 const uint64_t* blk_id, const uint64_t* blk_next, uint64_t n_blocks, uint64_t now_ms, JgRowsArgs* out,
+                 uint32_t msg_per_row = 0) {
+  // msg_per_row != 0: the caller knows the kinds of its rows and with them a tighter bound on the message rows one
+  // command can emit (the slots of a command lie msg_per_row rows apart: what reads them back reads that much less)
   StepRec rec;
   rec.n = n;
-  rec.msg_per_row = msg_bound(e->cfg.n_replicas);
+  rec.msg_per_row = msg_per_row ? msg_per_row : msg_bound(e->cfg.n_replicas);
   rec.fsm_per_row = fsm_bound();
   if ((uint64_t)n * rec.msg_per_row > 0xffffffffull) return fail(JG_EINVAL, "batch too large: split it");
   HIPCHK(e->arenas[e->cur_arena].alloc((size_t)n * 4, (void**)&rec.d_msg_cnt));
@@ -2388,11 +2391,16 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   auto slice_d = [&](int k) { return rt.d_jobs + (size_t)k * jg_dense_cluster::Route::JOB_SLICE; };
   // (multi: the job tables of the whole round - both sparse steps, the follower halves, the delivering pass - are
   // written first and travel in ONE copy: every table is host bookkeeping only, and a copy costs ~10 us of stream time)
+  static const bool row_per_lane = std::getenv("JG_ROUTE_ROW_PER_LANE") != nullptr;  // (A/B: the row-per-lane kernels for the delivered rows)
+  auto run_grid = [&](uint32_t widest) { return std::min<uint32_t>(std::max<uint32_t>((widest + JG_RUN_TILE - 1) / JG_RUN_TILE, 1u), L->count_slots); };
   auto apply_all = [&](int slice, std::vector<JgApplyJob>& jobs, uint32_t widest) -> int {
     if (jobs.empty()) return JG_OK;
     if (!multi) {
       for (size_t k = 0; k < jobs.size(); k++)
         hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(jobs[k].a.n, L->count_slots)), dim3(JG_BLOCK), 0, L->stream, jobs[k].d, jobs[k].a);
+    } else if (slice == 0 && !row_per_lane) {  // delivered rows: runs of 4-16 rows per group, a RUN per lane (jg_apply_runs_body)
+      hipLaunchKernelGGL(k_apply_runs_multi, dim3(run_grid(widest), (uint32_t)jobs.size()), dim3(JG_BLOCK), 0, L->stream,
+                         (const JgApplyJob*)slice_d(slice));
     } else {
       hipLaunchKernelGGL(k_apply_rows_multi, dim3(grid_for(widest, L->count_slots), (uint32_t)jobs.size()), dim3(JG_BLOCK), 0, L->stream,
                          (const JgApplyJob*)slice_d(slice));
@@ -2420,8 +2428,10 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       e->seq++;
       JgApplyJob j{};
       j.d = e->dev;
+      // VoteRequest -> one VoteResponse; VoteResponse -> DROP + Heartbeat on elect() (candidate.rs:108-113): two slots per row
+      const bool two = votes && jg_kinds_within(rt.kinds_in[n], (1u << JG_CMD_VOTE_REQUEST) | (1u << JG_CMD_VOTE_RESPONSE));
       if ((rc = prepare_rows(e, rt.n_in[n], rt.cols.group + o, rt.cols.kind + o, rt.cols.from + o, rt.cols.term + o, rt.cols.id + o,
-                             rt.cols.aux + o, rt.cols.flag + o, nullptr, nullptr, 0, now_ms, &j.a)))
+                             rt.cols.aux + o, rt.cols.flag + o, nullptr, nullptr, 0, now_ms, &j.a, two ? 2u : 0u)))
         return rc;
       if (e->stream != L->stream) {  // (its own stream: its own launch)
         hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(j.a.n, e->count_slots)), dim3(JG_BLOCK), 0, e->stream, j.d, j.a);
@@ -2536,8 +2546,12 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   // -- 1. (launches) what the transport delivered last round, then this round's injected rows
   if ((rc = apply_all(0, jobs_a, widest_a))) return rc;
   if (!jobs_v.empty()) {  // (different nodes than jobs_a's: the two launches are independent of each other)
-    hipLaunchKernelGGL(k_apply_votes_multi, dim3(grid_for(widest_v, L->count_slots), (uint32_t)jobs_v.size()), dim3(JG_BLOCK), 0, L->stream,
-                       (const JgApplyJob*)slice_d(0) + jobs_a.size());
+    if (row_per_lane)
+      hipLaunchKernelGGL(k_apply_votes_multi, dim3(grid_for(widest_v, L->count_slots), (uint32_t)jobs_v.size()), dim3(JG_BLOCK), 0, L->stream,
+                         (const JgApplyJob*)slice_d(0) + jobs_a.size());
+    else
+      hipLaunchKernelGGL(k_apply_vote_runs_multi, dim3(run_grid(widest_v), (uint32_t)jobs_v.size()), dim3(JG_BLOCK), 0, L->stream,
+                         (const JgApplyJob*)slice_d(0) + jobs_a.size());
     HIPCHK(hipGetLastError());
   }
   if ((rc = apply_all(1, jobs_b, widest_b))) return rc;

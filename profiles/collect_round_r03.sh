@@ -21,7 +21,7 @@ $B --failures 1 --steps 160 --warmup 64 --no-cpu-baseline > $OUT/bench_failures_
 $B --cluster --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_cluster_1M.json 2>/dev/null
 JG_CLUSTER_SEPARATE_HALVES=1 $B --cluster --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_cluster_1M_separate_halves.json 2>/dev/null
 $B --cluster --failures 1 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_cluster_failures_1pct.json 2>/dev/null
-JG_ROUTE_SEPARATE_LAUNCHES=1 JG_ROUTE_LIBRARY_SORT=1 JG_CLUSTER_SEPARATE_HALVES=1 JG_ROUTE_NO_VOTES_KERNEL=1 $B --cluster --failures 1 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_cluster_failures_1pct_round2_config.json 2>/dev/null
+JG_ROUTE_SEPARATE_LAUNCHES=1 JG_ROUTE_LIBRARY_SORT=1 JG_CLUSTER_SEPARATE_HALVES=1 JG_ROUTE_NO_VOTES_KERNEL=1 JG_ROUTE_ROW_PER_LANE=1 $B --cluster --failures 1 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_cluster_failures_1pct_round2_config.json 2>/dev/null
 $B --event-loop --groups 100000 --loops 2,4 > $OUT/bench_event_loop_100k.json 2>/dev/null
 $B --event-loop > $OUT/bench_event_loop_1M.json 2>/dev/null   # 1 M x 5, one loop and the best of 4 / 8 loops
 $B --event-loop --groups 10000 --replicas 3 --loops 1 --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_event_loop_10k_x3.json 2>/dev/null
