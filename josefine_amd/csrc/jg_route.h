@@ -64,17 +64,51 @@ __device__ __forceinline__ uint64_t jg_route_key(const JgRouteTable& t, uint32_t
 // thread's first position; `lim`: the end of the segment (a position at or beyond it is not written: the host
 // sees the cursor above seg_cap, grows the staging and repeats the pass).
 #define JG_ROUTE_SEGS 8u
-__device__ __forceinline__ uint32_t jg_route_reserve(const JgRouteTable& t, uint32_t c, uint32_t& lim) {
+struct JgRouteSpot {
+  uint32_t pos, lim;   // the calling thread's first position; the end of the segment
+  uint32_t base, tot;  // the workgroup's first position and its number of entries (whole: base + tot <= lim, or `whole` is false)
+  uint32_t excl;       // the calling thread's offset within the workgroup's entries
+  bool whole;
+};
+__device__ __forceinline__ JgRouteSpot jg_route_reserve(const JgRouteTable& t, uint32_t c) {
   __shared__ uint32_t base_s;
-  uint32_t tot;
-  const uint32_t excl = jg_block_exclusive_scan(c, &tot);
+  JgRouteSpot s;
+  s.excl = jg_block_exclusive_scan(c, &s.tot);
   const uint32_t seg = blockIdx.x & t.seg_mask;
-  if (threadIdx.x == 0) base_s = tot ? atomicAdd(t.cursor + seg, tot) : 0u;
+  if (threadIdx.x == 0) base_s = s.tot ? atomicAdd(t.cursor + seg, s.tot) : 0u;
   __syncthreads();
-  lim = seg * t.seg_cap + t.seg_cap;
-  const uint32_t pos = seg * t.seg_cap + min(base_s + excl, t.seg_cap);  // (saturating: beyond the segment is never a valid position)
+  const uint32_t b = base_s;
+  s.lim = seg * t.seg_cap + t.seg_cap;
+  s.base = seg * t.seg_cap + min(b, t.seg_cap);
+  s.whole = b <= t.seg_cap && s.tot <= t.seg_cap - b;
+  s.pos = seg * t.seg_cap + min(b + s.excl, t.seg_cap);  // (saturating: beyond the segment is never a valid position)
   __syncthreads();  // (base_s is reused by the next tile)
-  return pos;
+  return s;
+}
+// The workgroup's entries are one contiguous range of the staging: they are collected in LDS and leave in whole
+// lines, 8 bytes per lane and lanes side by side (written from the lanes that found them - a 40-byte row per lane,
+// five partial stores per line - the delivering pass put 104 MB on the bus for 34 MB of entries).
+template <uint32_t CAP>
+struct JgRouteStage {
+  uint64_t key[CAP];
+  uint64_t row[CAP * 5];
+};
+static_assert(sizeof(jg_msg_row) == 40, "a staged row is five 8-byte words");
+template <uint32_t CAP>
+__device__ __forceinline__ void jg_stage_put(JgRouteStage<CAP>& st, uint32_t at, uint64_t key, const jg_msg_row& r) {
+  st.key[at] = key;
+  uint64_t w[5];
+  __builtin_memcpy(w, &r, sizeof(w));
+#pragma unroll
+  for (int k = 0; k < 5; k++) st.row[at * 5 + k] = w[k];
+}
+template <uint32_t CAP>
+__device__ __forceinline__ void jg_stage_flush(const JgRouteStage<CAP>& st, const JgRouteTable& t, uint32_t base, uint32_t tot) {
+  __syncthreads();
+  for (uint32_t w = threadIdx.x; w < tot; w += JG_BLOCK) t.key[base + w] = st.key[w], t.idx[base + w] = base + w;
+  uint64_t* rows = (uint64_t*)(t.row + base);
+  for (uint32_t w = threadIdx.x; w < tot * 5; w += JG_BLOCK) rows[w] = st.row[w];
+  __syncthreads();
 }
 // The launch's tallies -> the sender's count words, one global atomic per workgroup and word (per wave
 // they queued up behind each other on a handful of addresses).  `pd_*`: rows per destination, 16 bits
@@ -161,8 +195,12 @@ __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_
       }
     }
   }
-  uint32_t lim;
-  uint32_t pos = jg_route_reserve(t, c, lim);
+  constexpr uint32_t CAP = JG_BLOCK * JG_ROUTE_ITEMS;  // (one delivered row per slot is the usual yield: 24 KB of LDS)
+  __shared__ JgRouteStage<CAP> st;
+  const JgRouteSpot sp = jg_route_reserve(t, c);
+  const bool staged = sp.whole && sp.tot <= CAP;  // (workgroup-uniform)
+  uint32_t pos = sp.pos, at = sp.excl;
+  const uint32_t lim = sp.lim;
   if (c) {
 #pragma unroll
     for (int k = 0; k < JG_ROUTE_ITEMS; k++) {
@@ -170,7 +208,11 @@ __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_
       const jg_msg_row* mine = msg + (size_t)i * per_row;
       for (uint32_t j = 0; j < cnt[k]; j++) {
         const jg_msg_row r = mine[j];
-        for (uint32_t b = jg_route_dests(r, t); b; b &= b - 1, pos++) {
+        for (uint32_t b = jg_route_dests(r, t); b; b &= b - 1, pos++, at++) {
+          if (staged) {
+            jg_stage_put(st, at, jg_route_key(t, (uint32_t)__ffs(b) - 1u, r.group, step, j), r);
+            continue;
+          }
           if (pos >= lim) continue;  // (the host sees the cursor above the segment, grows the staging and repeats the pass)
           // (a run's rows lie back to back from its first slot: j is the emission index within the group's step)
           t.key[pos] = jg_route_key(t, (uint32_t)__ffs(b) - 1u, r.group, step, j);
@@ -180,6 +222,7 @@ __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_
       }
     }
   }
+  if (staged) jg_stage_flush(st, t, sp.base, sp.tot);
   jg_route_tally(t, pd_lo, pd_hi, kept, JG_ROUTE_KEPT, f, kd_lo, kd_hi);
 }
 __global__ __launch_bounds__(JG_BLOCK) void k_route_rec(JgRouteTable t, uint32_t n, uint32_t per_row, uint32_t step,
@@ -249,17 +292,26 @@ __device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const Jg
       continue;
     }
     const uint32_t step = q.seq - seq_base;
-    uint32_t lim;
-    uint32_t pos = jg_route_reserve(t, __popc(mask), lim);
+    // (a tile of JG_BLOCK queue entries yields up to JG_BLOCK * (R - 1) staged rows: a campaign's VoteRequest goes to every peer)
+    constexpr uint32_t CAP = JG_BLOCK * 4;
+    __shared__ JgRouteStage<CAP> st;
+    const JgRouteSpot sp = jg_route_reserve(t, __popc(mask));
+    const bool staged = sp.whole && sp.tot <= CAP;  // (workgroup-uniform)
+    uint32_t pos = sp.pos, at = sp.excl;
     stays += stay;
-    for (uint32_t b = mask; b; b &= b - 1, pos++) {
+    for (uint32_t b = mask; b; b &= b - 1, pos++, at++) {
       jg_route_note(pd_lo, pd_hi, (uint32_t)__ffs(b) - 1u);
       jg_route_note_kind(kd_lo, kd_hi, (uint32_t)__ffs(b) - 1u, q.row.kind);
-      if (pos >= lim) continue;
+      if (staged) {
+        jg_stage_put(st, at, jg_route_key(t, (uint32_t)__ffs(b) - 1u, q.row.group, step & 3u, q.k), q.row);
+        continue;
+      }
+      if (pos >= sp.lim) continue;
       t.key[pos] = jg_route_key(t, (uint32_t)__ffs(b) - 1u, q.row.group, step & 3u, q.k);
       t.idx[pos] = pos;
       t.row[pos] = q.row;
     }
+    if (staged) jg_stage_flush(st, t, sp.base, sp.tot);
   }
   if (!COMPACT) jg_route_tally(t, pd_lo, pd_hi, stays, JG_ROUTE_KEPT_XQ, 0, kd_lo, kd_hi);
 }
