@@ -279,6 +279,8 @@ __device__ __forceinline__ void jg_apply_runs_body(const JgDev& d, const JgRowsA
   }
   jg_block_count(d.blk_decisions, dec);
 }
+// (one batch, arguments by value: what jg_step takes with JG_APPLY_RUNS=1 - the fuzz suites then run through this body)
+__global__ __launch_bounds__(JG_BLOCK) void k_apply_runs(JgDev d, JgRowsArgs a) { jg_apply_runs_body(d, a); }
 __global__ __launch_bounds__(JG_BLOCK) void k_apply_runs_multi(const JgApplyJob* __restrict__ jobs) {
   const JgApplyJob& j = jobs[blockIdx.y];
   jg_apply_runs_body(j.d, j.a);

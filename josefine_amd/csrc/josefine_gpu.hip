@@ -1121,7 +1121,14 @@ int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* 
   JgRowsArgs a;
   const int rc = prepare_rows(e, n, group, kind, from, term, id, aux, flag, blk_id, blk_next, n_blocks, now_ms, &a);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(n, e->count_slots)), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
+  // JG_APPLY_RUNS=1 (test hook): the run-per-lane body the cluster transport's batches take (jg_apply_runs_body) for
+  // every batch - the fuzz and parity suites then hold it to the oracle with runs of every length across its tiles
+  static const bool runs = std::getenv("JG_APPLY_RUNS") != nullptr;
+  if (runs)
+    hipLaunchKernelGGL(k_apply_runs, dim3(std::min<uint32_t>((n + JG_RUN_TILE - 1) / JG_RUN_TILE, e->count_slots)), dim3(JG_BLOCK), 0, e->stream,
+                       e->dev, a);
+  else
+    hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(n, e->count_slots)), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
   HIPCHK(hipGetLastError());
   return JG_OK;
 }
