@@ -795,7 +795,7 @@ def main():
     if fail_rows is not None:  # one more full drain cycle outside the timed region (pinned queues at their working size)
         eng.drain_flush()
         consume()
-        eng._check(api.kernel_timing(h, 1))
+        eng._check(api.kernel_timing(h, 4))  # (every 4th dense launch: the event pair is not free in a tick of three small kernels)
     barrier()
     c0 = eng.counters()
     barrier()

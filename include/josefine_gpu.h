@@ -650,7 +650,9 @@ int jg_synth_fill_acks_device(jg_engine* e, uint32_t mode, uint64_t tick, uint64
  * _n / k_leader_node_tick — not the k_dense_slow launch that may follow it), recorded on the
  * engine's stream for every dense step while enabled; jg_kernel_timing_read synchronises and
  * returns the average over the most recent launches (a ring of 256).  What bench.py prices the
- * roofline with when a step is more than one kernel (configs[4], the closed loop). */
+ * roofline with when a step is more than one kernel (configs[4], the closed loop).
+ * enable: 0 off, 1 every dense step, N > 1 every N-th (a pair of event records costs the stream a few
+ * microseconds: a tick of three small kernels is measurably longer with every launch timed). */
 int jg_kernel_timing(jg_engine* e, int enable);
 int jg_kernel_timing_read(jg_engine* e, float* avg_us, uint32_t* n_launches);
 

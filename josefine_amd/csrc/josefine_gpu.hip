@@ -341,6 +341,7 @@ struct jg_engine {
   std::vector<hipEvent_t> kt_ev;  // 2 * KT_RING once enabled
   bool kt_on = false;
   uint64_t kt_n = 0;
+  uint32_t kt_every = 1, kt_seen = 0;  // every kt_every-th dense launch is timed (two event records cost the stream a few microseconds)
 };
 
 namespace {
@@ -377,11 +378,12 @@ void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks, const Jg
   const size_t stride = (size_t)e->cfg.n_groups * e->cfg.n_replicas;
   struct Lap {  // (event pair around the one launch below, when jg_kernel_timing is on)
     jg_engine* e;
-    explicit Lap(jg_engine* e_) : e(e_) {
-      if (e->kt_on) (void)hipEventRecord(e->kt_ev[2 * (e->kt_n % jg_engine::KT_RING)], e->stream);
+    bool on;
+    explicit Lap(jg_engine* e_) : e(e_), on(e_->kt_on && e_->kt_seen++ % e_->kt_every == 0) {
+      if (on) (void)hipEventRecord(e->kt_ev[2 * (e->kt_n % jg_engine::KT_RING)], e->stream);
     }
     ~Lap() {
-      if (e->kt_on) (void)hipEventRecord(e->kt_ev[2 * (e->kt_n++ % jg_engine::KT_RING) + 1], e->stream);
+      if (on) (void)hipEventRecord(e->kt_ev[2 * (e->kt_n++ % jg_engine::KT_RING) + 1], e->stream);
     }
   } lap(e);
   if (nd) {  // node tick: HeartbeatResponses in, the Tick's outbox out
@@ -3149,7 +3151,8 @@ int jg_kernel_timing(jg_engine* e, int enable) {
     for (hipEvent_t& ev : e->kt_ev) HIPCHK(hipEventCreate(&ev));
   }
   e->kt_on = enable != 0;
-  e->kt_n = 0;
+  e->kt_every = enable > 1 ? (uint32_t)enable : 1u;
+  e->kt_n = 0, e->kt_seen = 0;
   return JG_OK;
 }
 
