@@ -757,6 +757,8 @@ def main():
         fail_rows = [eng.upload_rows(**failure_rows(args.seed, t, rank * G, G, R, eng.node_ids, slots, args.failures)[0])
                      for t in range(W + K)]
 
+    DRAIN_EVERY = int(os.environ.get("JG_BENCH_DRAIN_EVERY", "16"))  # ticks per drain batch of the failure trace
+
     def run_ticks(t0_, t1_):
         """Apply ticks [t0_, t1_) — exactly t1_-t0_ steps — in launches of up to T ticks."""
         n_launch = 0
@@ -770,7 +772,7 @@ def main():
                 eng._check(api.step_dense_acks_device_n(h, ptr, n))
             if fail_rows is not None and fail_rows[t].n:
                 eng.step_device_rows(fail_rows[t], now_ms=100 * (t + 1))
-                if t % 16 == 15:
+                if t % DRAIN_EVERY == DRAIN_EVERY - 1:
                     # the host consumes the outbound messages as it goes (pinned views): the batch
                     # whose transfer was started 16 ticks ago, then the next transfer is started
                     # (jg_drain_prefetch) - PCIe and host time overlap the device time of the next ticks
