@@ -94,7 +94,7 @@ def test_cluster_and_failure_modes():
     d = run(["--failures", "1", "--groups", "100000", "--steps", "24", "--warmup", "8", "--no-cpu-baseline"])
     assert KEYS <= set(d) and d["value"] > 0
     r = d["roofline"]  # the dominant kernel under failures, priced with its own HIP event pairs
-    assert r["bound"] == "hbm" and r["avg_launch_us"] > 0 and r["launches_timed"] == 24
+    assert r["bound"] == "hbm" and r["avg_launch_us"] > 0 and r["launches_timed"] == 24 // 4  # (every 4th dense launch is timed)
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["rows_delivered_to_host"]["messages"] > 0 and d["rows_delivered_to_host"]["faults"] > 0
     # configs[4] as specified: real votes, routed between the nodes on the device
