@@ -204,7 +204,6 @@ __device__ __forceinline__ void jg_follower_slow_body(const JgDev& d, JgFollower
     const bool tick_only = (entry & JG_DEFER_TICK_ONLY) != 0;
     JgLane L;
     jg_load(d, L, g);
-    const JgLane O = L;  // (jg_store_dirty: only what changed is written back)
     const uint64_t fsm_commit0 = L.commit;
     L.now = a.now;
     L.seq = a.seq;
@@ -260,7 +259,7 @@ __device__ __forceinline__ void jg_follower_slow_body(const JgDev& d, JgFollower
     // Heartbeat does not move its commit index, candidate.rs:137-157, leader.rs:263)
     jg_follower_fsm_note(a, g, fsm_commit0, L.commit);
     dec += L.decisions;
-    jg_store_dirty(d, L, O);
+    jg_store(d, L);
   }
   __syncthreads();
   if (threadIdx.x == 0) d.slow_cnt[blockIdx.x] = 0;

@@ -61,7 +61,6 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
     const uint32_t g = list[i];
     JgLane L;
     jg_load(d, L, g);
-    const JgLane O = L;  // (jg_store_dirty: only what changed is written back)
     const uint64_t fsm_head0 = L.head, fsm_commit0 = L.commit;  // (jg_step_node: what this tick pushes on fsm_tx)
     L.now = nd.now;
     L.mp = L.mend = nullptr;
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
       nd.fsm_delta[g] = w;
     }
     dec += L.decisions;
-    jg_store_dirty(d, L, O);
+    jg_store(d, L);
   }
   __syncthreads();
   if (threadIdx.x == 0) d.slow_cnt[blockIdx.x] = 0;

@@ -90,12 +90,11 @@ __device__ __forceinline__ void jg_apply_rows_body(const JgDev& d, const JgRowsA
     uint32_t longest = run;
 #pragma unroll
     for (int off = 32; off; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off, 64));
-    JgLane L, O;  // (O: the lane as loaded - jg_store_dirty writes what changed)
+    JgLane L;
     jg_msg_row* m0 = nullptr;
     jg_fsm_row* f0 = nullptr;
     if (owner) {
       jg_load(d, L, g);
-      O = L;
       L.now = a.now;
       L.seq = a.seq;
       m0 = a.msg_out + (size_t)i * a.msg_per_row;
@@ -135,7 +134,7 @@ __device__ __forceinline__ void jg_apply_rows_body(const JgDev& d, const JgRowsA
       a.fsm_cnt[i] = cf;
       if (L.overflow) *a.err = 1;
       dec += L.decisions;
-      jg_store_dirty<KINDS != JG_KINDS_ELECTION>(d, L, O);
+      jg_store<KINDS != JG_KINDS_ELECTION>(d, L);  // (jg_store_dirty measured no gain here and costs 26 VGPRs: the run-per-lane body has it)
     }
     // the tile's sums (tile = the JG_BLOCK rows this workgroup just served)
     __shared__ uint32_t red_m[JG_BLOCK / 64], red_f[JG_BLOCK / 64];
