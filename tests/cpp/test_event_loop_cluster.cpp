@@ -10,7 +10,7 @@
 // channels of every node emitted, tick by tick (fsm_tx rows, rpc_tx rows, outbox columns) and the final
 // state; the test compares the two lines.
 //
-//   usage: test_event_loop_cluster G R T mode      mode: scripted | elect
+//   usage: test_event_loop_cluster G R T mode      mode: scripted | elect | failover
 //     scripted  node 1 wins every election up front (Timeout + granted votes), then T ticks with one
 //               ClientRequest per partition per tick at the leader: the steady state
 //     elect     nobody is told anything: the timers elect (votes travel as rows through the transport),
@@ -57,6 +57,10 @@ int main(int argc, char** argv) {
   const uint32_t R = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 5;
   const uint32_t T = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 50;
   const bool scripted = argc > 4 ? std::string(argv[4]) == "scripted" : true;
+  // failover: like elect, and at tick T / 3 every node's process "crashes and restarts" for the partitions it leads
+  // (JG_CMD_RESTART = Raft::new on the persisted chain, follower.rs:68-95: term 0, no vote, a follower): those partitions
+  // are leaderless until a follower's timer fires and a NEW leader - necessarily on another node - is elected
+  const bool failover = argc > 4 && std::string(argv[4]) == "failover";
   try {
     std::vector<NodeId> ids;
     for (uint32_t r = 0; r < R; r++) ids.push_back(r + 1);
@@ -151,7 +155,21 @@ int main(int argc, char** argv) {
     const uint32_t tail_from = T - T / 4;
     uint64_t general_before_tail = 0;
     std::vector<std::vector<uint64_t>> commit_at_tail(R, std::vector<uint64_t>(G, 0));
+    std::vector<std::vector<uint8_t>> led_before(R, std::vector<uint8_t>(G, 0));
+    uint64_t restarted = 0, moved = 0;
     for (uint32_t t = 0; t < T; t++) {
+      if (failover && t == T / 3) {
+        for (uint32_t n = 0; n < R; n++) {
+          if (jg_read_state(rafts[n]->raw(), JG_FIELD_ROLE, 0, role.data(), 0, G) != JG_OK) throw std::runtime_error("read role");
+          RowQueue q;
+          for (uint32_t g = 0; g < G; g++)
+            if (role[g] == JG_ROLE_LEADER) q.push(g, JG_CMD_RESTART), led_before[n][g] = 1, restarted++;
+          if (!q.empty()) {
+            rafts[n]->submit_rows(q.view());
+            rafts[n]->step(now);
+          }
+        }
+      }
       if (t == tail_from) {
         for (uint32_t n = 0; n < R; n++) {
           general_before_tail += n_general[n];
@@ -204,7 +222,7 @@ int main(int argc, char** argv) {
         if (f == JG_FIELD_COMMIT) {
           if (jg_read_state(rafts[n]->raw(), JG_FIELD_ROLE, 0, b8.data(), 0, G) != JG_OK) throw std::runtime_error("read");
           for (uint32_t g = 0; g < G; g++)
-            if (b8[g] == JG_ROLE_LEADER) leads[n]++, tail_committing += col[g] > commit_at_tail[n][g];
+            if (b8[g] == JG_ROLE_LEADER) leads[n]++, tail_committing += col[g] > commit_at_tail[n][g], moved += failover && !led_before[n][g];
         }
       }
       for (int f : {JG_FIELD_ROLE, JG_FIELD_FAULT}) {
@@ -228,12 +246,14 @@ int main(int argc, char** argv) {
     for (uint32_t n = 0; n < R; n++) by_node += (n ? "/" : "") + std::to_string(leads[n]);
     std::printf("cluster %s hash=%016llx G=%u R=%u T=%u mode=%s leaders=%llu faults=%llu proposals=%llu fsm_rows=%llu msg_rows=%llu "
                 "column_messages=%llu rows_in=%llu rows_general=%llu decisions=%llu max_head=%llu min_commit_node1=%llu "
-                "leaders_by_node=%s tail_ticks=%u tail_rows_general=%llu tail_partitions_committing=%llu\n",
-                ok ? "ok" : "FAILED", (unsigned long long)all.h, G, R, T, scripted ? "scripted" : "elect", (unsigned long long)leaders,
+                "leaders_by_node=%s tail_ticks=%u tail_rows_general=%llu tail_partitions_committing=%llu restarted_leaders=%llu "
+                "led_by_another_node_now=%llu\n",
+                ok ? "ok" : "FAILED", (unsigned long long)all.h, G, R, T, scripted ? "scripted" : failover ? "failover" : "elect", (unsigned long long)leaders,
                 (unsigned long long)faults, (unsigned long long)proposals, (unsigned long long)fsm, (unsigned long long)msg,
                 (unsigned long long)cols, (unsigned long long)rows, (unsigned long long)general, (unsigned long long)decisions,
                 (unsigned long long)max_head, (unsigned long long)min_commit, by_node.c_str(), T - tail_from,
-                (unsigned long long)(general - general_before_tail), (unsigned long long)tail_committing);
+                (unsigned long long)(general - general_before_tail), (unsigned long long)tail_committing, (unsigned long long)restarted,
+                (unsigned long long)moved);
     std::fprintf(stderr, "[%.2f s for %u ticks of %u nodes x %u partitions: %.3g decisions/s through the loops incl. the host transport]\n", secs, T, R,
                  G, (double)decisions / secs);
     return ok ? 0 : 1;
