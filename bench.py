@@ -455,7 +455,11 @@ def event_loop_main(args):
     HeartbeatResponses per partition and tick, shuffled) decoded straight into the engine's pinned columns,
     classified and scattered into the dense mailboxes ON THE DEVICE, the Tick as a flag; fsm_tx rows and the
     Tick's outbox columns come back over PCIe and are read by batch sinks.  The followers are synthetic, as
-    the ack stream of the headline line is.  The binary is josefine_amd/host/bench_event_loop.cpp."""
+    the ack stream of the headline line is.  The binary is josefine_amd/host/bench_event_loop.cpp.
+    `value` is the process hosting the G partitions on several such loops (--loops: one host thread, one engine,
+    two HIP streams each - the reference runs a task per partition; a batched loop is synchronous per tick, so
+    loops side by side are what overlaps decode, both directions of the bus and kernels); the one-loop figures,
+    the column-inbound figures (batched peers) and round 2's loop are in the `event_loop` object."""
     import subprocess
     from josefine_amd.build import build_event_loop_bench
     exe = build_event_loop_bench()

@@ -60,9 +60,10 @@ __device__ __forceinline__ uint64_t jg_route_key(const JgRouteTable& t, uint32_t
 // 4.7 k waves of a 300 k-slot step) - and, since ~3 000 workgroup reservations of a round's delivering pass were
 // still 54 us of that queue, on one of JG_ROUTE_SEGS cursors: workgroup x takes segment x mod n_seg of the staging
 // (neighbouring workgroups run on different XCDs, so a cursor is mostly one XCD's).  The staged entries need no
-// particular place: the ordering keys are unique and the bucket pass reads every segment.  Returns the calling
-// thread's first position; `lim`: the end of the segment (a position at or beyond it is not written: the host
-// sees the cursor above seg_cap, grows the staging and repeats the pass).
+// particular place: the ordering keys are unique and the bucket pass reads every segment.  A position at or beyond
+// the end of the segment is not written: the host sees the cursor above seg_cap, grows the staging and repeats the
+// pass (segmenting turned out not to be what bounded the pass - JG_ROUTE_ONE_CURSOR=1 measures the same - and stays
+// as the cheaper bound on that queue).
 #define JG_ROUTE_SEGS 8u
 struct JgRouteSpot {
   uint32_t pos, lim;   // the calling thread's first position; the end of the segment
