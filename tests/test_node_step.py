@@ -49,11 +49,19 @@ def mixed_pair(make_a, make_b, G, R, seed, lead_frac=0.6, **kw):
     return a, b, rng
 
 
+def ref_py_engine(*a, **kw):
+    from ref_py.engine import RefEngine
+    return RefEngine(*a, **kw)
+
+
+@pytest.mark.parametrize("plain_backend", ["oracle", "ref_py"])
 @pytest.mark.parametrize("R,flags", [(3, 0), (5, 0), (5, capi.CFG_SEPARATE_COMMIT_KEY), (4, 0), (1, 0)])
-def test_oracle_node_step_is_plain_apply_in_canonical_order(R, flags):
-    G, T = 400, 40
-    node, plain, rng = mixed_pair(oracle_engine, oracle_engine, G, R, seed=11 + R, flags=flags,
-                                  election_timeout_ms=(700, 1500))
+def test_oracle_node_step_is_plain_apply_in_canonical_order(R, flags, plain_backend):
+    """... and with plain_backend = ref_py the plain path is the independent Python reading of the Rust
+    (tests/ref_py): jg_step_node's semantics are then held to a restatement that shares no code with the oracle."""
+    G, T = (400, 40) if plain_backend == "oracle" else (160, 25)
+    node, plain, rng = mixed_pair(oracle_engine, oracle_engine if plain_backend == "oracle" else ref_py_engine, G, R, seed=11 + R,
+                                  flags=flags, election_timeout_ms=(700, 1500))
     ids = np.array(node.node_ids)
     dense_rows = general_rows = 0
     for t in range(T):
