@@ -216,3 +216,32 @@ def test_routed_cluster_ref_py_vs_oracle(R, also):
         assert ref.kept[n].tobytes() == ora.kept[n].tobytes()
     if R == 3 and also:  # with a majority of fresh replicas the candidate wins: leadership really moved
         assert (ora.nodes[1].read("role") == capi.ROLE_LEADER).any()
+
+
+@pytest.mark.parametrize("R,percent,also", [(3, 4, ()), (5, 3, ()), (5, 3, (2,)), (3, 4, (2,))])
+def test_routed_failure_cluster_oracle_vs_ref_py(R, percent, also):
+    """BASELINE configs[4] as the cluster runs it - R nodes, dense mailboxes for the steady-state traffic, every
+    other message (the votes of the re-elections, a winner's Heartbeat) routed between the nodes as rows, leaders
+    crashing and restarting (tests/dense_node.py::RoutedCluster, the host-side statement the device transport is
+    held to) - once over the C++ oracle and once over the independent Python reading of the Rust: every state
+    column of every node after every round, the rows delivered per node and the rows kept for the host.  The
+    R >= 2 semantics of that trace are then pinned by two restatements that share no code."""
+    from dense_node import RoutedCluster, cluster_failure_rows
+    from parity import compare_snapshots
+    G, T = 120, 36
+    ora = RoutedCluster(oracle_engine, G, R, seed=5)
+    ref = RoutedCluster(lambda *a, **kw: RefEngine(*a, **kw), G, R, seed=5)
+    moved = 0
+    for t in range(T):
+        inj = cluster_failure_rows(99, t, G, R, percent, also=also) if t >= 3 else [None] * R
+        ora.round(np.ones(G, np.uint64), inject=inj)
+        ref.round(np.ones(G, np.uint64), inject=[None if c is None else dict(c) for c in inj])
+        for n in range(R):
+            compare_snapshots(ref.nodes[n], ora.nodes[n], f"routed round {t} node {n}")
+            if n != ora.lead:
+                moved = max(moved, int((ora.nodes[n].read("role") == capi.ROLE_LEADER).sum()))
+        assert ora.delivered.tolist() == ref.delivered.tolist(), t
+        assert [k.tobytes() for k in ora.kept] == [k.tobytes() for k in ref.kept], t
+    assert ora.delivered.sum() > 10 * G // 10  # elections did run through the transport
+    if also and R == 3:
+        assert moved > 0  # ... and with the extra restart the candidate wins: a node other than the lead one leads
