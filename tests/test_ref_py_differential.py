@@ -245,3 +245,32 @@ def test_routed_failure_cluster_oracle_vs_ref_py(R, percent, also):
     assert ora.delivered.sum() > 10 * G // 10  # elections did run through the transport
     if also and R == 3:
         assert moved > 0  # ... and with the extra restart the candidate wins: a node other than the lead one leads
+
+
+@pytest.mark.parametrize("R,P,seed,chaos", [(3, 30, 1, False), (5, 20, 2, False), (3, 30, 3, True), (5, 20, 4, True)])
+def test_closed_loop_cluster_oracle_vs_ref_py(R, P, seed, chaos):
+    """tests/cluster_sim.py - every replica of every partition an instance of ONE engine, every output row of a round
+    the next round's input: elections with real vote grants, heartbeats, replicate(), follower commit advance, and
+    (chaos) message loss, duplication and process restarts that drive the cluster into the reference's own panic
+    paths - once over the C++ oracle and once over ref_py: each round's message, fsm and fault rows byte for byte
+    and every state column, or the two clusters drift apart within a round or two."""
+    from cluster_sim import Cluster
+
+    def make(factory):
+        e = factory(P * R, R, seed=40 + seed, self_slots=Cluster.self_slots(P, R), flags=capi.CFG_SEPARATE_COMMIT_KEY)
+        return Cluster(e, P, R, **({"chaos_seed": 1000 + seed} if chaos else {}))
+
+    ora, ref = make(oracle_engine), make(lambda *a, **kw: RefEngine(*a, **kw))
+    rng_o, rng_r = np.random.default_rng(9), np.random.default_rng(9)
+    codes = set()
+    for rnd in range(90):
+        mo, fo, xo = ora.round(rng=rng_o)
+        mr, fr, xr = ref.round(rng=rng_r)
+        assert mo.tobytes() == mr.tobytes(), f"round {rnd}: messages differ"
+        assert fo.tobytes() == fr.tobytes(), f"round {rnd}: fsm rows differ"
+        assert xo.tobytes() == xr.tobytes(), f"round {rnd}: fault rows differ"
+        compare_snapshots(ref.e, ora.e, f"cluster R={R} round {rnd}")
+        codes |= set(int(c) for c in xo["code"])
+    assert (ora.e.read("role") == capi.ROLE_LEADER).sum() > (0.3 if chaos else 0.8) * P
+    assert int(ora.e.read("commit").max()) > 3
+    assert all(c < 128 for c in codes), codes  # only the reference's own failure modes, never an engine limit
