@@ -242,6 +242,36 @@ __device__ __forceinline__ bool jg_lag_tick(uint32_t s, uint32_t f, uint64_t w0,
   return true;
 }
 
+// jg_step_node: the acknowledgements that arrived BEFORE the tick's ClientRequest (`pre`: one bit per slot) met
+// the chain head before the append.  The reference evaluated Leader::commit after each of them: the commit
+// index they reached is what fsm_tx saw before the Notify (adv_pre), and chain.rs:197-202 holds them to the OLD
+// head - one above it is the slow kernel's (replay in arrival order, a fault where the reference panics).
+template <int R>
+__device__ __forceinline__ bool jg_lag_pre(uint32_t s, uint64_t w0, uint64_t head0, const uint64_t (&a)[R], uint32_t pre,
+                                           uint32_t& adv_pre) {
+  constexpr uint32_t B = 64u / (R + 1u);
+  constexpr uint32_t ESC = (uint32_t)((1ull << (B > 21 ? 21 : B)) - 1ull);
+  constexpr uint32_t BEHIND = ESC - 1u, INF = 0xffffffffu;
+  bool bad = false;
+  uint32_t l[R + 1];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const uint32_t fr = (uint32_t)(w0 >> (r * B)) & ESC;
+    const uint64_t ar = a[r];
+    const bool some = (uint32_t)r != s && ((pre >> r) & 1u) && ar != JG_NO_ACK;
+    const uint64_t dk = head0 - ar;
+    uint32_t dl = (uint32_t)(dk >> 32) ? INF : (uint32_t)dk;
+    dl = some ? dl : INF;
+    bad |= some && ar > head0;
+    l[r] = fr == BEHIND ? INF : min(fr, dl);  // (an ack for a BEHIND slot, an escaped field: jg_lag_tick refuses those)
+  }
+  const uint32_t fc = (uint32_t)(w0 >> (R * B)) & ESC;
+  const uint32_t lc = fc == BEHIND ? INF : fc;
+  const uint32_t ql = jg_kth_lag<R>(l);
+  adv_pre = lc - min(lc, ql);  // (meaningless when the old commit index is in the wide column: not the hot path's)
+  return !bad;
+}
+
 // The same tick on lags that are already unpacked (the T-tick kernel carries them in registers from
 // tick to tick and packs once per launch): l[r] may exceed its field between ticks, only 2^30 is a
 // hard bound here; the caller checks the field width when it packs.
@@ -371,10 +401,20 @@ struct JgLeaderNode {
   // jg_step_node: what the step pushed on fsm_tx, as one word per group (jg_node.h JGN_FSM_*); null otherwise
   uint32_t* fsm_delta;         // [G]
   uint64_t* fsm_prev;          // [G] the commit index before the step where the word says JGN_FSM_WIDE
+  uint64_t* fsm_mid;           // [G] ... and at the moment the ClientRequest was applied
+  // jg_step_node: the arrival index + 1 of the row behind every inbox entry ([2R][G], jg_node.h JgNodeCols::arr): the
+  // slow kernel replays a group's commands in that order; slots in `col_mask` spoke a column (after the rows)
+  const uint32_t* arr;
+  uint32_t col_mask, pad2_;
 };
 #define JG_FSM_APPENDED_BIT (1u << 31)
 #define JG_FSM_WIDE_BIT (1u << 30)
 #define JG_FSM_FOLLOWER_BIT (1u << 29)
+#define JG_FSM_PRE_SHIFT 14            // bits 14-27: the commit advance BEFORE the Notify; bits 0-13: of the whole step
+#define JG_FSM_ADV_MASK 0x3fffu
+// jg_step_node: the own slot's append count (0 or 1) carries, from bit JG_NODE_PRE_SHIFT up, one bit per slot whose
+// AppendResponse arrived BEFORE the ClientRequest (k_node_route)
+#define JG_NODE_PRE_SHIFT 32
 
 // jg_leader_inbox answer word -> AppendResponse head (JG_NO_ACK: none) / HeartbeatResponse code
 __device__ __forceinline__ uint64_t jg_answer_ack(uint64_t w) {
@@ -663,6 +703,11 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
 #pragma unroll
   for (int r = 1; r < R; r++) n_app = (uint32_t)r == s ? a[r] : n_app;
   if (NODE && !nd.ack_stride) n_app = 0;
+  uint32_t pre = 0;  // jg_step_node: slots whose AppendResponse arrived before the ClientRequest
+  if (FSM) {
+    pre = (uint32_t)(n_app >> JG_NODE_PRE_SHIFT) & 0xffu;
+    n_app &= (1ull << JG_NODE_PRE_SHIFT) - 1ull;
+  }
   // ---- hot path: a healthy leader in FAST form whose tick stays in lag space --------------------
   // straight-line 32-bit arithmetic, evaluated for every lane; everything else is behind one
   // (normally wave-uniform, not taken) branch
@@ -675,6 +720,8 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   // fsm rows come from the (appended?, commit advance) word: one Notify at most, and a commit index whose old
   // value is in the packed word - anything else is the general state machine's (k_dense_slow)
   if (FSM) hot = hot && n_app <= 1 && !lt.cwide;
+  uint32_t adv_pre = 0;
+  if (FSM && __builtin_expect(pre != 0, 0)) hot = jg_lag_pre<R>(s, mword0, head0, a, pre, adv_pre) && hot;
   // (the node tick counts behind its stores: the counter's atomic would otherwise be one more thing the
   // waits inside the Tick's emission wait for)
   if (!NODE) jg_count_step(h.blk_decisions, dec, hot, dl);
@@ -687,7 +734,13 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
     if (lt.head1 != head0) h.head[g] = lt.head1;
     if (lt.nf != f) h.flags[g] = lt.nf;
     if (FSM) {  // (a Q9 fault raised by the Tick comes after the appends and acks: their rows stand)
-      const uint32_t w = (n_app ? JG_FSM_APPENDED_BIT : 0u) | lt.adv;
+      uint32_t w = (n_app ? JG_FSM_APPENDED_BIT : 0u) | lt.adv | (adv_pre << JG_FSM_PRE_SHIFT);
+      if (__builtin_expect(lt.adv > JG_FSM_ADV_MASK, 0)) {  // (16-bit lag fields at R = 3: a commit index that jumps by 2^14 blocks)
+        const uint64_t commit0 = lt.head1 - lt.l[R] - lt.adv;
+        nd.fsm_prev[g] = commit0;
+        nd.fsm_mid[g] = commit0 + adv_pre;
+        w = (n_app ? JG_FSM_APPENDED_BIT : 0u) | JG_FSM_WIDE_BIT;
+      }
       if (w) nd.fsm_delta[g] = w;  // (the column was zeroed by the step's prefill)
     }
     if (NODE) jg_count_step(h.blk_decisions, dec, true, dl);  // (the ballots see the lanes of this branch: the hot ones)

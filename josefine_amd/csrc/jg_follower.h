@@ -44,7 +44,7 @@ struct JgFollowerArgs {
 __device__ __forceinline__ void jg_follower_fsm_note(const JgFollowerArgs& a, uint32_t g, uint64_t commit0, uint64_t commit1) {
   if (!a.fsm_delta || commit1 == commit0) return;  // follower.rs:201-207: one Apply range per Heartbeat that advances
   const uint64_t adv = commit1 - commit0;
-  if (adv < JG_FSM_FOLLOWER_BIT) {
+  if (adv <= JG_FSM_ADV_MASK) {
     a.fsm_delta[g] = JG_FSM_FOLLOWER_BIT | (uint32_t)adv;
   } else {
     a.fsm_prev[g] = commit0;
@@ -205,6 +205,9 @@ __device__ __forceinline__ void jg_follower_slow_body(const JgDev& d, JgFollower
     JgLane L;
     jg_load(d, L, g);
     const uint64_t fsm_commit0 = L.commit;
+    // the Tick of a group the leader half ticks is not this half's: a leader that steps down on its way through the
+    // inputs (leader.rs:200-208) has had its Tick for this round (the role at entry decides, not the role after)
+    const bool was_leader = jg_role(L) == JG_ROLE_LEADER;
     L.now = a.now;
     L.seq = a.seq;
     L.mp = L.mend = nullptr;
@@ -243,7 +246,7 @@ __device__ __forceinline__ void jg_follower_slow_body(const JgDev& d, JgFollower
         }
       }
     }
-    if (a.tick && jg_role(L) != JG_ROLE_LEADER) {
+    if (a.tick && !was_leader && jg_role(L) != JG_ROLE_LEADER) {
       c.kind = JG_CMD_TICK;
       c.from = 0;
       c.term = c.id = c.aux = 0;

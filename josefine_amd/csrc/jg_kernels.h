@@ -76,53 +76,100 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
     // (node tick: the block holds answer words, JG_ANSWER(head, HeartbeatResponse code))
     const bool packed = NODE && nd.packed != 0;
     auto ack_of = [=](uint64_t w) { return packed ? jg_answer_ack(w) : w; };
-    if (acks && n_ticks && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L) &&
+    // (jg_step_node: the word holds 0 or 1 and, above JG_NODE_PRE_SHIFT, the arrival bits)
+    if (!(NODE && nd.arr) && acks && n_ticks && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L) &&
         ack_of(acks[(size_t)s * d.G + g]) >= JG_MAX_DENSE_APPENDS) {
       L.seq = seq0;
       jg_raise(d, L, JG_FAULT_ENGINE_DENSE_APPENDS);
     }
-    if (NODE && packed && acks && !jg_fault(L)) {  // 1. HeartbeatResponses, ascending slot (leader.rs:222-231)
+    uint64_t fsm_mid = fsm_commit0;  // (jg_step_node: the commit index at the moment the ClientRequest was applied)
+    if (NODE && nd.arr && packed && acks) {
+      // jg_step_node: the group's commands one at a time IN THE ORDER THEY ARRIVED (server.rs:120-161) - the inbox
+      // entries sorted by the arrival index k_node_classify left with each (selection: at most 2R entries); a slot
+      // that spoke a column comes after the rows, HeartbeatResponse then AppendResponse
       L.seq = seq0;
-      c.kind = JG_CMD_HEARTBEAT_RESPONSE;
-      for (uint32_t r = 0; r < d.R && !jg_fault(L); r++) {
-        if (r == s) continue;
-        const uint32_t has = jg_answer_hb(acks[(size_t)r * d.G + g]);
-        if (has == JG_HB_NONE) continue;
+      uint32_t last = 0;
+      for (;;) {
+        uint32_t best = 0xffffffffu, be = 0;
+        for (uint32_t e2 = 0; e2 < 2u * d.R; e2++) {
+          const bool is_ack = e2 < d.R;
+          const uint32_t r = is_ack ? e2 : e2 - d.R;
+          const uint64_t w = acks[(size_t)r * d.G + g];
+          bool present;
+          if (r == s) present = is_ack && (uint32_t)(w >> 8) != 0;  // the ClientRequest
+          else present = is_ack ? (w >> 8) != JG_MAILBOX_NONE : jg_answer_hb(w) != JG_HB_NONE;
+          if (!present) continue;
+          const uint32_t key = (r != s && ((nd.col_mask >> r) & 1u)) ? 0x80000000u + 2u * r + (is_ack ? 1u : 0u)
+                                                                     : nd.arr[(size_t)e2 * d.G + g];
+          if (key > last && key < best) best = key, be = e2;
+        }
+        if (best == 0xffffffffu || jg_fault(L)) break;
+        last = best;
+        const bool is_ack = be < d.R;
+        const uint32_t r = is_ack ? be : be - d.R;
+        const uint64_t w = acks[(size_t)r * d.G + g];
         c.from = d.node_ids[r];
-        c.flag = has;
-        c.id = has ? 0 : nd.hbr_commit[(size_t)r * d.G + g];
+        c.term = c.aux = 0;
+        if (r == s) {
+          if ((uint32_t)(w >> 8) > 1u) *d.err = 1;  // (jg_step_node offers at most one: one Notify per step)
+          fsm_mid = L.commit;
+          c.kind = JG_CMD_CLIENT_REQUEST, c.from = 0, c.flag = 0, c.id = 0;
+        } else if (is_ack) {
+          c.kind = JG_CMD_APPEND_RESPONSE, c.flag = 1, c.id = w >> 8;
+        } else {
+          const uint32_t has = jg_answer_hb(w);
+          c.kind = JG_CMD_HEARTBEAT_RESPONSE, c.flag = (uint8_t)has, c.id = has ? 0 : nd.hbr_commit[(size_t)r * d.G + g];
+        }
+        L.fp = sink;
+        L.fend = sink + 2;
         jg_apply(d, L, c, nullptr, nullptr);
       }
       c.from = 0;
       c.id = 0;
-    }
-    for (uint32_t t = 0; acks && t < n_ticks && !jg_fault(L); t++) {  // 2. appends, then acks
-      const uint64_t* A = acks + (size_t)t * tick_stride;
-      L.seq = seq0 + t;
-      uint64_t n_app = ack_of(A[(size_t)s * d.G + L.g]);
-      if (n_app >= JG_MAX_DENSE_APPENDS) {
-        jg_raise(d, L, JG_FAULT_ENGINE_DENSE_APPENDS);
-        break;
+    } else {
+      if (NODE && packed && acks && !jg_fault(L)) {  // 1. HeartbeatResponses, ascending slot (leader.rs:222-231)
+        L.seq = seq0;
+        c.kind = JG_CMD_HEARTBEAT_RESPONSE;
+        for (uint32_t r = 0; r < d.R && !jg_fault(L); r++) {
+          if (r == s) continue;
+          const uint32_t has = jg_answer_hb(acks[(size_t)r * d.G + g]);
+          if (has == JG_HB_NONE) continue;
+          c.from = d.node_ids[r];
+          c.flag = has;
+          c.id = has ? 0 : nd.hbr_commit[(size_t)r * d.G + g];
+          jg_apply(d, L, c, nullptr, nullptr);
+        }
+        c.from = 0;
+        c.id = 0;
       }
-      if (NODE && nd.fsm_delta && n_app > 1) *d.err = 1;  // (jg_step_node offers at most one: the word below holds one Notify)
-      c.kind = JG_CMD_CLIENT_REQUEST;
-      c.flag = 0;
-      for (uint64_t k = 0; k < n_app && !jg_fault(L); k++) {
-        L.fp = sink;
-        L.fend = sink + 2;
-        jg_apply(d, L, c, nullptr, nullptr);
-      }
-      c.kind = JG_CMD_APPEND_RESPONSE;
-      c.flag = 1;
-      for (uint32_t r = 0; r < d.R && !jg_fault(L); r++) {
-        if (r == s) continue;
-        uint64_t h = ack_of(A[(size_t)r * d.G + L.g]);
-        if (h == JG_NO_ACK) continue;
-        c.from = d.node_ids[r];
-        c.id = h;
-        L.fp = sink;
-        L.fend = sink + 2;
-        jg_apply(d, L, c, nullptr, nullptr);
+      for (uint32_t t = 0; acks && t < n_ticks && !jg_fault(L); t++) {  // 2. appends, then acks
+        const uint64_t* A = acks + (size_t)t * tick_stride;
+        L.seq = seq0 + t;
+        uint64_t n_app = ack_of(A[(size_t)s * d.G + L.g]);
+        if (n_app >= JG_MAX_DENSE_APPENDS) {
+          jg_raise(d, L, JG_FAULT_ENGINE_DENSE_APPENDS);
+          break;
+        }
+        if (NODE && nd.fsm_delta && n_app > 1) *d.err = 1;  // (jg_step_node offers at most one: the word below holds one Notify)
+        c.kind = JG_CMD_CLIENT_REQUEST;
+        c.flag = 0;
+        for (uint64_t k = 0; k < n_app && !jg_fault(L); k++) {
+          L.fp = sink;
+          L.fend = sink + 2;
+          jg_apply(d, L, c, nullptr, nullptr);
+        }
+        c.kind = JG_CMD_APPEND_RESPONSE;
+        c.flag = 1;
+        for (uint32_t r = 0; r < d.R && !jg_fault(L); r++) {
+          if (r == s) continue;
+          uint64_t h = ack_of(A[(size_t)r * d.G + L.g]);
+          if (h == JG_NO_ACK) continue;
+          c.from = d.node_ids[r];
+          c.id = h;
+          L.fp = sink;
+          L.fend = sink + 2;
+          jg_apply(d, L, c, nullptr, nullptr);
+        }
       }
     }
     if (NODE && nd.o_beat && !jg_fault(L)) {  // 3. Command::Tick (leader.rs:234-245)
@@ -155,6 +202,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
       if (L.commit != fsm_commit0) {
         w |= JG_FSM_WIDE_BIT;
         nd.fsm_prev[g] = fsm_commit0;
+        nd.fsm_mid[g] = fsm_mid;
       }
       nd.fsm_delta[g] = w;
     }

@@ -15,10 +15,25 @@
 //                    step's rows fill, and whether the group can be served in column form at all
 //                    (a kind outside the vocabulary, two rows for one mailbox entry, a value a
 //                    mailbox word cannot hold, a ClientRequest for a group this node does not
-//                    lead: the whole group takes the general path, so that its rows keep their
-//                    stream order)
+//                    lead, a Heartbeat / AppendEntries for one it does lead, an AppendEntries that
+//                    arrived before the Heartbeat: the whole group takes the general path, whose
+//                    rows keep their stream order); every row also leaves its ARRIVAL INDEX with the
+//                    mailbox entry it fills
 //   k_node_route     rows of column-form groups are scattered into the inbox columns; the others
 //                    are flagged for the general path (k_apply_rows, before the dense halves)
+//
+// Arrival order (server.rs:120-161: the event loop applies what its channels deliver one command at a
+// time).  The dense halves must be indistinguishable from that, so what a mailbox column forgets - the
+// order of the rows - is kept where it can matter:
+//   * an AppendResponse that arrived BEFORE the group's ClientRequest met the chain head before the
+//     append: the own slot's word carries one bit per slot for them (JGN_PRE_SHIFT); the lag-space tick
+//     evaluates the majority once over those acknowledgements alone (the commit index the Notify is
+//     preceded by on fsm_tx, and the bound chain.rs:197-202 holds them to) and once over all;
+//   * everything the lag-space tick does not serve (a HeartbeatResponse without the commit: replicate()
+//     on the progress as it is THEN, leader.rs:222-231; escaped fields; forged acks) is replayed by
+//     k_dense_slow one command at a time in arrival order, from the indices in `arr`;
+//   * a follower's answer word holds HeartbeatResponse, AppendResponse in that order: a group whose
+//     AppendEntries arrived first is a general-path group.
 //   k_node_fsm_build the fsm_tx rows of the dense halves (Instruction::Notify / Apply, fsm.rs:20-29),
 //                    from the per-group deltas the tick kernels leave behind
 //
@@ -34,12 +49,15 @@
 #define JGN_AE (1u << 17)          // an AppendEntries
 #define JGN_CR (1u << 18)          // a ClientRequest
 #define JGN_SPARSE (1u << 31)      // the group's rows take the general path (k_apply_rows)
+// own slot's answer word of a node step: JG_ANSWER(#ClientRequests (0 or 1) | pre << 32, JG_HB_NONE), pre = one bit per
+// slot whose AppendResponse arrived before the ClientRequest
+#define JGN_PRE_SHIFT (8 + JG_NODE_PRE_SHIFT)
 
 // fsm delta word a dense half leaves per group (k_node_fsm_build turns it into rows)
 #define JGN_FSM_APPENDED JG_FSM_APPENDED_BIT  // leader: one block was appended (Notify)
 #define JGN_FSM_WIDE JG_FSM_WIDE_BIT          // the commit index before the step is in fsm_prev[g] (else: commit_after - low bits)
 #define JGN_FSM_FOLLOWER JG_FSM_FOLLOWER_BIT  // the range is a follower's: range(prev..commit), follower.rs:204
-#define JGN_FSM_ADV_MASK (JG_FSM_FOLLOWER_BIT - 1u)
+#define JGN_FSM_ADV_MASK JG_FSM_ADV_MASK       // bits 0-13: how far the commit index moved in the step; bits 14-27: ... before the Notify
 
 struct JgNodeCols {  // device scratch of the node step (engine-owned, grow-only)
   // leader half inbox
@@ -54,9 +72,13 @@ struct JgNodeCols {  // device scratch of the node step (engine-owned, grow-only
   uint32_t* cls;           // [G]
   uint64_t *lt_max, *lt_min;  // [G] max / min term over the group's Heartbeat + AppendEntries rows
   uint32_t *lf_max, *lf_min;  // [G] ... and sender
+  // arrival index + 1 of the row that filled a mailbox entry (stream order of the step's batch)
+  uint32_t* arr;         // [2R][G]  [r]: AppendResponse of slot r (own slot: the ClientRequest), [R + r]: HeartbeatResponse of slot r
+  uint32_t* fo;          // [2][G]   the Heartbeat, the AppendEntries
   // fsm deltas of the dense halves
   uint32_t* fsm_delta;   // [G]
-  uint64_t* fsm_prev;    // [G]
+  uint64_t* fsm_prev;    // [G] JGN_FSM_WIDE: the commit index before the step
+  uint64_t* fsm_mid;     // [G] JGN_FSM_WIDE, leader: ... and when the ClientRequest was applied
 };
 
 struct JgNodeRows {  // the step's command rows in device memory, unsorted (stream order)
@@ -147,6 +169,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_classify(JgDev d, JgNodeCols 
         sparse = !(halves & 1u) || s < 0 || (uint32_t)s == self ||
                  (kind == JG_CMD_APPEND_RESPONSE && a.id[i] >= JG_MAILBOX_NONE);
         bit = s < 0 ? 0u : 1u << ((kind == JG_CMD_APPEND_RESPONSE ? JGN_ACK_SHIFT : JGN_HBR_SHIFT) + (uint32_t)s);
+        if (!sparse) c.arr[(size_t)((kind == JG_CMD_APPEND_RESPONSE ? 0u : d.R) + (uint32_t)s) * d.G + g] = i + 1u;
         break;
       }
       case JG_CMD_CLIENT_REQUEST: {
@@ -155,16 +178,23 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_classify(JgDev d, JgNodeCols 
         const uint32_t f = d.flags[g];
         sparse = !(halves & 1u) || (f & JGF_ROLE_MASK) != JG_ROLE_LEADER;
         bit = JGN_CR;
+        if (!sparse) c.arr[(size_t)(us >= 0 ? (uint32_t)us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT) * d.G + g] = i + 1u;
         break;
       }
+      // (a leader's answer to a Heartbeat / AppendEntries is a role change or nothing, leader.rs:200-208,263 - never an
+      //  answer word, and its Tick must come AFTER the row: the general path)
       case JG_CMD_HEARTBEAT:
-        sparse = !(halves & 2u) || a.id[i] == JG_NO_ACK || a.from_of(i) == 0;  // (JG_NO_ACK in the beat means "no heartbeat")
+        sparse = !(halves & 2u) || a.id[i] == JG_NO_ACK || a.from_of(i) == 0 ||  // (JG_NO_ACK in the beat means "no heartbeat")
+                 (d.flags[g] & JGF_ROLE_MASK) == JG_ROLE_LEADER;
         bit = JGN_HB;
+        c.fo[g] = i + 1u;
         break;
       case JG_CMD_APPEND_ENTRIES: {
         uint64_t from;
-        sparse = !(halves & 2u) || a.from_of(i) == 0 || !jg_node_ae_run(a, a.id[i], a.aux_of(i), &from);
+        sparse = !(halves & 2u) || a.from_of(i) == 0 || !jg_node_ae_run(a, a.id[i], a.aux_of(i), &from) ||
+                 (d.flags[g] & JGF_ROLE_MASK) == JG_ROLE_LEADER;
         bit = JGN_AE;
+        c.fo[d.G + g] = i + 1u;
         break;
       }
       default: sparse = true;  // votes, Timeout, Restart, explicit Tick rows, ...: the general state machine
@@ -182,10 +212,12 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_classify(JgDev d, JgNodeCols 
 }
 
 // final verdict on a group (every row of the group evaluates the same data: no ordering between rows)
-__device__ __forceinline__ bool jg_node_group_sparse(const JgNodeCols& c, uint32_t g, uint32_t w, uint32_t both_beats) {
+__device__ __forceinline__ bool jg_node_group_sparse(const JgNodeCols& c, uint32_t G, uint32_t g, uint32_t w, uint32_t both_beats) {
   if (w & JGN_SPARSE) return true;
+  // one beat word carries the term and the sender of both rows, one answer word the two responses in the order
+  // HeartbeatResponse, AppendResponse: an AppendEntries that arrived BEFORE the Heartbeat is answered the other way round
   if (both_beats && (w & (JGN_HB | JGN_AE)) == (JGN_HB | JGN_AE))
-    return c.lt_max[g] != c.lt_min[g] || c.lf_max[g] != c.lf_min[g];
+    return c.lt_max[g] != c.lt_min[g] || c.lf_max[g] != c.lf_min[g] || c.fo[G + g] < c.fo[g];
   return false;
 }
 
@@ -201,7 +233,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
   for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < a.n; i += gridDim.x * JG_BLOCK) {
     const uint32_t g = a.group[i];
     const uint32_t w = c.cls[g];
-    const bool sparse = jg_node_group_sparse(c, g, w, both_beats);
+    const bool sparse = jg_node_group_sparse(c, G, g, w, both_beats);
     keep[i] = sparse ? 1 : 0;
     mine += sparse;
     if (sparse) continue;
@@ -211,6 +243,12 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
         const int s = jg_node_slot_of(d, a.from_of(i));
         (void)__hip_atomic_fetch_and(&c.answers[(size_t)s * G + g], (a.id[i] << 8) | 0xffull, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
+        if (w & JGN_CR) {  // did it arrive before the group's ClientRequest?  (it met the head before the append)
+          const uint32_t self = us >= 0 ? (uint32_t)us : (d.flags[g] & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
+          if (i + 1u < c.arr[(size_t)self * G + g])
+            (void)__hip_atomic_fetch_or(&c.answers[(size_t)self * G + g], 1ull << (JGN_PRE_SHIFT + (uint32_t)s), __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+        }
         break;
       }
       case JG_CMD_HEARTBEAT_RESPONSE: {  // low byte of the same word
@@ -223,7 +261,8 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
       }
       case JG_CMD_CLIENT_REQUEST: {
         const uint32_t self = us >= 0 ? (uint32_t)us : (d.flags[g] & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
-        c.answers[(size_t)self * G + g] = JG_ANSWER(1, JG_HB_NONE);
+        // (an atomic: the AppendResponse rows that arrived before this one set their bits in the same word)
+        (void)__hip_atomic_fetch_or(&c.answers[(size_t)self * G + g], 1ull << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c.token[g] = a.id[i];
         break;
       }
@@ -281,17 +320,24 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_keys(uint32_t n, const uint32
 
 // ---- fsm_tx rows of the dense halves -------------------------------------------------------------
 // A dense half leaves one word per group (JGN_FSM_*): what the reference pushed on fsm_tx while the
-// group's tick was applied is fully determined by it and the state after the step:
-//   leader    Notify{block_id = head_after, id = token}           if a block was appended (leader.rs:184-188)
-//             Apply for range(commit_before..=commit_after).skip(1)   if the commit index moved (leader.rs:93;
-//             consecutive ranges of one tick concatenate exactly: match[] only grows)
-//   follower  Apply for range(commit_before..commit_after)        if the commit index moved (follower.rs:204)
-// Rows go to a [G][2] region with per-group counts and the drain's tile sums: from there on the
+// group's rows and Tick were applied is fully determined by it and the state after the step:
+//   leader    Apply for range(commit_before..=commit_mid).skip(1)    what the AppendResponses that arrived BEFORE the
+//                                                                    ClientRequest committed (leader.rs:93)
+//             Notify{block_id = head_after, id = token}              if a block was appended (leader.rs:184-188)
+//             Apply for range(commit_mid..=commit_after).skip(1)     the self-ack and the AppendResponses after it
+//             (consecutive ranges concatenate exactly: match[] only grows)
+//   follower  Apply for range(commit_before..commit_after)           if the commit index moved (follower.rs:204)
+// Rows go to a [G][3] region with per-group counts and the drain's tile sums: from there on the
 // ordinary drain machinery (scan + gather) delivers them, in step order with everything else.
+#define JGN_FSM_ROWS 3
 __device__ __forceinline__ uint64_t jg_node_commit_of(const JgDev& d, uint32_t g, uint32_t f, uint64_t head) {
   if ((f & JGF_ROLE_MASK) != JG_ROLE_LEADER) return d.commit[g];
   const uint64_t fc = jg_lag_field(d.mlag[g], d.R, d.R);
   return jg_lag_wide(fc, d.R) ? d.commit[g] : head - fc;
+}
+__device__ __forceinline__ void jg_node_fsm_row(jg_fsm_row& r, uint32_t g, uint32_t kind, uint64_t a, uint64_t b) {
+  r.group = g, r.kind = (uint8_t)kind, r.pad[0] = r.pad[1] = r.pad[2] = 0;
+  r.a = a, r.b = b;
 }
 __global__ __launch_bounds__(JG_BLOCK) void k_node_fsm_build(JgDev d, JgNodeCols c, jg_fsm_row* __restrict__ out,
                                                              uint32_t* __restrict__ cnt, uint64_t* __restrict__ bsum) {
@@ -303,18 +349,22 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_fsm_build(JgDev d, JgNodeCols
       const uint32_t f = d.flags[g];
       const uint64_t head = d.head[g];
       const uint64_t commit1 = jg_node_commit_of(d, g, f, head);
-      const uint64_t commit0 = (w & JGN_FSM_WIDE) ? c.fsm_prev[g] : commit1 - (w & JGN_FSM_ADV_MASK);
-      jg_fsm_row* r = out + (size_t)g * 2;
-      if (w & JGN_FSM_APPENDED) {
-        r[n].group = g, r[n].kind = JG_FSM_NOTIFY, r[n].pad[0] = r[n].pad[1] = r[n].pad[2] = 0;
-        r[n].a = head, r[n].b = c.token[g];
-        n++;
+      const bool fol = (w & JGN_FSM_FOLLOWER) != 0;
+      uint64_t commit0, mid;
+      if (w & JGN_FSM_WIDE) {
+        commit0 = c.fsm_prev[g];
+        mid = fol ? commit0 : c.fsm_mid[g];
+      } else {
+        commit0 = commit1 - (w & JGN_FSM_ADV_MASK);
+        mid = commit0 + ((w >> JG_FSM_PRE_SHIFT) & JGN_FSM_ADV_MASK);
       }
-      if (commit1 != commit0) {
-        r[n].group = g, r[n].kind = (w & JGN_FSM_FOLLOWER) ? JG_FSM_APPLY_FOLLOWER : JG_FSM_APPLY_LEADER;
-        r[n].pad[0] = r[n].pad[1] = r[n].pad[2] = 0;
-        r[n].a = commit0, r[n].b = commit1;
-        n++;
+      jg_fsm_row* r = out + (size_t)g * JGN_FSM_ROWS;
+      if (fol) {
+        if (commit1 != commit0) jg_node_fsm_row(r[n++], g, JG_FSM_APPLY_FOLLOWER, commit0, commit1);
+      } else {
+        if (mid != commit0) jg_node_fsm_row(r[n++], g, JG_FSM_APPLY_LEADER, commit0, mid);
+        if (w & JGN_FSM_APPENDED) jg_node_fsm_row(r[n++], g, JG_FSM_NOTIFY, head, c.token[g]);
+        if (commit1 != mid) jg_node_fsm_row(r[n++], g, JG_FSM_APPLY_LEADER, mid, commit1);
       }
     }
     cnt[g] = n;

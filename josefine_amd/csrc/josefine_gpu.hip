@@ -1688,6 +1688,9 @@ int node_ensure(jg_engine* e) {
   A(n.cols.lf_min, G);
   A(n.cols.fsm_delta, G);
   A(n.cols.fsm_prev, G);
+  A(n.cols.fsm_mid, G);
+  A(n.cols.arr, 2 * R * G);
+  A(n.cols.fo, 2 * G);
   A(n.o_beat, G);
   A(n.o_ae, R * G);
   HIPCHK(hipMemsetAsync(n.o_ae, 0xff, std::max<size_t>(R * G * 8, 16), e->stream));  // (the own slot's row is never written: JG_NO_ACK once)
@@ -1863,7 +1866,8 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     ln.ack_stride = 1;
     if (tick) ln.o_beat = nd.o_beat, ln.o_ae = nd.o_ae;
     ln.now = now_ms;
-    ln.fsm_delta = nd.cols.fsm_delta, ln.fsm_prev = nd.cols.fsm_prev;
+    ln.fsm_delta = nd.cols.fsm_delta, ln.fsm_prev = nd.cols.fsm_prev, ln.fsm_mid = nd.cols.fsm_mid;
+    ln.arr = nd.cols.arr, ln.col_mask = col_mask;  // (the slow kernel replays its groups in arrival order)
     if ((rc = dense_step(e, nd.cols.answers, 1, &ln))) return rc;
     if (tick) {
       HIPCHK(hipMemcpyAsync(nd.h_beat, nd.o_beat, (size_t)G * sizeof(jg_leader_beat), hipMemcpyDeviceToHost, e->stream));
@@ -1890,11 +1894,11 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     rec.n = G;
     rec.seq = e->seq;
     rec.msg_per_row = 0;
-    rec.fsm_per_row = 2;
+    rec.fsm_per_row = JGN_FSM_ROWS;
     Arena& ar = e->arenas[e->cur_arena];
     const uint32_t n_tiles = (G + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
     HIPCHK(ar.alloc((size_t)G * 4, (void**)&rec.d_fsm_cnt));
-    HIPCHK(ar.alloc((size_t)G * 2 * sizeof(jg_fsm_row), (void**)&rec.d_fsm));
+    HIPCHK(ar.alloc((size_t)G * JGN_FSM_ROWS * sizeof(jg_fsm_row), (void**)&rec.d_fsm));
     HIPCHK(ar.alloc((size_t)n_tiles * 8, (void**)&rec.d_bsum_f));
     hipLaunchKernelGGL(k_node_fsm_build, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rec.d_fsm, rec.d_fsm_cnt,
                        rec.d_bsum_f);

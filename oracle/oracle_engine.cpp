@@ -30,17 +30,14 @@ struct jo_engine {
   std::vector<jg_compact_row> compacted;
   uint64_t counters[4] = {0, 0, 0, 0};
   unsigned threads = 1;
-  // jo_step_node: the step's inbox / outbox columns (host vectors) and what jo_node_outbox_view reports
-  std::vector<uint64_t> n_answers, n_hbr, n_token, n_f_ae, n_o_ae, n_o_answer, n_o_hbc;
-  std::vector<jg_leader_beat> n_f_beat, n_o_beat;
-  std::vector<uint32_t> n_f_leader;
+  // jo_step_node: the step's outbox columns (host vectors) and what jo_node_outbox_view reports
+  std::vector<uint64_t> n_o_ae, n_o_answer, n_o_hbc;
+  std::vector<jg_leader_beat> n_o_beat;
   std::vector<jg_fsm_row> n_fsm;  // fsm rows of the dense halves of the step in progress
   std::vector<uint64_t> n_in_answers, n_in_hbc;  // jo_node_inbox_columns: [R][G] columns handed out for the next step
   uint32_t n_col_mask = 0, n_col_hbc_mask = 0;
   std::vector<jg_msg_row> v_msgs;  // rows handed out by the *_view drains
   std::vector<jg_fsm_row> v_fsms;
-  bool node_keep_fsm = false;
-  const uint64_t* node_tokens = nullptr;
   jg_node_outbox n_last{};
   uint32_t n_last_flags = 0;
 };
@@ -307,6 +304,61 @@ static void node_take_fsm(jo_engine* e, uint32_t g) {
   }
 }
 
+// Command::Tick of a leader (leader.rs:234-245) into the outbox: columns if the chain is in run form built by
+// append only and every AppendEntries word can hold its range start key, rows otherwise.
+static void leader_tick_out(jo_engine* e, uint32_t g, uint64_t now_ms, const jg_leader_outbox* out) {
+  const uint32_t G = e->cfg.n_groups;
+  Raft& r = e->groups[g];
+  // columns stand for a Tick only when every AppendEntries word can hold its range start key: a
+  // progress head at or above 2^56 - 1 (a forged AppendResponse: heads only grow, progress.rs:133-140)
+  // does not fit the 56-bit field, so that leader's Tick travels as rows
+  bool columns = r.chain.run_form_by_append();
+  for (const auto& kv : r.progress.progress)
+    if (kv.first != r.id && kv.second.head >= JG_MAILBOX_NONE) columns = false;
+  if (columns && r.chain.head >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words: loud, never wrong
+    r.fault = JG_FAULT_ENGINE_MAILBOX_RANGE;
+    return;
+  }
+  Cmd c;
+  c.kind = JG_CMD_TICK;
+  r.apply(c, now_ms);
+  e->counters[0]++;
+  if (columns) {
+    out->beat[g].term = r.current_term;
+    for (const Msg& m : r.rpc) {
+      if (m.kind == JG_CMD_HEARTBEAT) {
+        out->beat[g].hb_commit = m.id;
+      } else {
+        const int q = slot_of_id(e, m.to_id);
+        out->ae[(size_t)q * G + g] = JG_AE(m.id, m.aux);
+      }
+    }
+  } else {
+    for (const Msg& m : r.rpc) push_row(e, g, m);
+  }
+  r.rpc.clear();
+}
+
+// What a non-leader pushed on rpc_tx during its half: AppendResponse / HeartbeatResponse into the answer word
+// (56-bit block ids in mailbox words: the callers raise the fault where the answer is produced), everything else as rows.
+static void follower_answers_out(jo_engine* e, uint32_t g, const jg_follower_outbox* out) {
+  Raft& r = e->groups[g];
+  uint64_t o_ack = JG_MAILBOX_NONE;
+  uint8_t o_has = JG_HB_NONE;
+  for (const Msg& m : r.rpc) {
+    if (m.kind == JG_CMD_APPEND_RESPONSE) {
+      if (m.id < JG_MAILBOX_NONE) o_ack = m.id;
+    } else if (m.kind == JG_CMD_HEARTBEAT_RESPONSE) {
+      out->hb_commit[g] = m.id;
+      o_has = m.flag;
+    } else {
+      push_row(e, g, m);
+    }
+  }
+  out->answer[g] = JG_ANSWER(o_ack, o_has);
+  r.rpc.clear();
+}
+
 int jo_step_dense_leader(jo_engine* e, uint64_t now_ms, const jg_leader_inbox* in, const jg_leader_outbox* out) {
   e->stepped = true;
   const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
@@ -354,7 +406,6 @@ int jo_step_dense_leader(jo_engine* e, uint64_t now_ms, const jg_leader_inbox* i
     // 2. appends, then acks in ascending slot order
     c = Cmd();
     c.kind = JG_CMD_CLIENT_REQUEST;
-    if (e->node_tokens) c.id = e->node_tokens[g];  // (jo_step_node: the request's token, Notify.id)
     for (uint64_t i = 0; i < n_append && !r.fault; i++) {
       r.apply(c, now_ms);
       e->counters[0]++;
@@ -371,40 +422,9 @@ int jo_step_dense_leader(jo_engine* e, uint64_t now_ms, const jg_leader_inbox* i
       e->counters[0]++;
     }
     r.rpc.clear();
-    if (e->node_keep_fsm) node_take_fsm(e, g);  // jo_step_node queues them
     r.fsm.clear();  // dense steps report deltas, not rows
     // 3. Tick: columns if the chain is in run form built by append only, rows otherwise
-    if (out && !r.fault) {
-      // columns stand for a Tick only when every AppendEntries word can hold its range start key: a
-      // progress head at or above 2^56 - 1 (a forged AppendResponse: heads only grow, progress.rs:133-140)
-      // does not fit the 56-bit field, so that leader's Tick travels as rows
-      bool columns = r.chain.run_form_by_append();
-      for (const auto& kv : r.progress.progress)
-        if (kv.first != r.id && kv.second.head >= JG_MAILBOX_NONE) columns = false;
-      if (columns && r.chain.head >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words: loud, never wrong
-        r.fault = JG_FAULT_ENGINE_MAILBOX_RANGE;
-        note_fault(e, g, fault0);
-        continue;
-      }
-      c = Cmd();
-      c.kind = JG_CMD_TICK;
-      r.apply(c, now_ms);
-      e->counters[0]++;
-      if (columns) {
-        out->beat[g].term = r.current_term;
-        for (const Msg& m : r.rpc) {
-          if (m.kind == JG_CMD_HEARTBEAT) {
-            out->beat[g].hb_commit = m.id;
-          } else {
-            const int q = slot_of_id(e, m.to_id);
-            out->ae[(size_t)q * G + g] = JG_AE(m.id, m.aux);
-          }
-        }
-      } else {
-        for (const Msg& m : r.rpc) push_row(e, g, m);
-      }
-      r.rpc.clear();
-    }
+    if (out && !r.fault) leader_tick_out(e, g, now_ms, out);
     note_fault(e, g, fault0);
     e->counters[1] += r.decisions;
     r.decisions = 0;
@@ -421,8 +441,7 @@ int jo_step_dense_follower(jo_engine* e, uint64_t now_ms, const jg_follower_inbo
     Raft& r = e->groups[g];
     out->answer[g] = JG_NO_ACK;
     if (r.fault) continue;
-    uint64_t o_ack = JG_MAILBOX_NONE;
-    uint8_t o_has = JG_HB_NONE;
+    const bool was_leader = r.role == JG_ROLE_LEADER;
     const uint64_t in_term = in->beat[g].term, in_hbc = in->beat[g].hb_commit;
     const uint64_t in_from = in->ae[g] >> 8;
     const uint32_t in_n = (uint32_t)(in->ae[g] & 0xffu);
@@ -449,25 +468,15 @@ int jo_step_dense_follower(jo_engine* e, uint64_t now_ms, const jg_follower_inbo
       for (const Msg& m : r.rpc)
         if (m.kind == JG_CMD_APPEND_RESPONSE && m.id >= JG_MAILBOX_NONE && !r.fault) r.fault = JG_FAULT_ENGINE_MAILBOX_RANGE;
     }
-    if (tick && r.role != JG_ROLE_LEADER && !r.fault) {
+    // the Tick of a group the leader half ticks is not this half's: a leader that steps down on the way (leader.rs:200-208)
+    // has had its Tick for this round (role at entry, not the role after the inputs)
+    if (tick && !was_leader && r.role != JG_ROLE_LEADER && !r.fault) {
       c = Cmd();
       c.kind = JG_CMD_TICK;
       r.apply(c, now_ms);
       e->counters[0]++;
     }
-    for (const Msg& m : r.rpc) {
-      if (m.kind == JG_CMD_APPEND_RESPONSE) {
-        if (m.id < JG_MAILBOX_NONE) o_ack = m.id;
-      } else if (m.kind == JG_CMD_HEARTBEAT_RESPONSE) {
-        out->hb_commit[g] = m.id;
-        o_has = m.flag;
-      } else {
-        push_row(e, g, m);
-      }
-    }
-    out->answer[g] = JG_ANSWER(o_ack, o_has);
-    r.rpc.clear();
-    if (e->node_keep_fsm) node_take_fsm(e, g);
+    follower_answers_out(e, g, out);
     r.fsm.clear();
     note_fault(e, g, fault0);
     e->counters[1] += r.decisions;
@@ -659,22 +668,16 @@ int jo_synth_fill_acks(jo_engine* e, uint32_t mode, uint64_t tick, uint64_t* sim
 }
 
 // ---- jo_step_node: the specification of jg_step_node, restated over host vectors -------------------
-// Classify the queued rows per partition exactly as include/josefine_gpu.h words it, apply the rows
-// of the partitions that do not fit the mailbox vocabulary through jo_step (stream order), build the
-// inbox columns from the others, then run the two dense halves (which apply the commands the columns
-// stand for one by one through Raft::apply) and queue their fsm rows.
+// What server::event_loop does between two firings of its interval (src/raft/server.rs:120-161), for every
+// partition the node hosts: Apply::apply of every queued row IN THE ORDER IT ARRIVED (mod.rs:471-479), then
+// Command::Tick.  The classification below decides nothing about results - only about the REPRESENTATION
+// the engine reports (which partitions count as rows_general, which messages leave as mailbox columns and
+// which as rows); every partition's rows are applied one command at a time in stream order either way.
 int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
   if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~7u)) return fail(JG_EINVAL, "jg_step_node: bad flags");
   e->stepped = true;
   const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
   const bool lead_half = flags & JG_NODE_LEADER_HALF, fol_half = flags & JG_NODE_FOLLOWER_HALF, tick = flags & JG_NODE_TICK;
-  e->n_answers.assign((size_t)R * G, JG_NO_ACK);
-  e->n_hbr.assign((size_t)R * G, 0);
-  e->n_token.assign(G, 0);
-  e->n_f_beat.assign(G, jg_leader_beat{0, JG_NO_ACK});
-  e->n_f_ae.assign(G, JG_NO_ACK);
-  e->n_f_leader.assign(G, 0);
-  for (uint32_t g = 0; g < G; g++) e->n_answers[(size_t)e->self_slot[g] * G + g] = JG_ANSWER(0, JG_HB_NONE);
   // column inbound (jo_node_inbox_columns): a sender that spoke a column this step may not also speak rows
   const uint32_t col_mask = lead_half ? e->n_col_mask : 0u, col_hbc = e->n_col_hbc_mask;
   e->n_col_mask = e->n_col_hbc_mask = 0;
@@ -685,35 +688,34 @@ int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
           const int s = slot_of_id(e, c.from);
           if (s >= 0 && ((col_mask >> s) & 1u)) return fail(JG_EINVAL, "jg_step_node: a row names a sender whose answers arrived as a column");
         }
-  // pass 1: which mailbox entries each partition's rows fill; what cannot be a column
+  // pass 1: which mailbox entries each partition's rows fill; what cannot be served in column form
   struct Cls {
     uint32_t seen = 0;  // bits 0-7 AppendResponse per slot, 8-15 HeartbeatResponse per slot, 16 Heartbeat, 17 AppendEntries, 18 ClientRequest
     bool general = false;
     uint64_t hb_term = 0, ae_term = 0;
     uint32_t hb_from = 0, ae_from = 0;
+    size_t hb_at = 0, ae_at = 0;  // position in the partition's stream
   };
   std::vector<Cls> cls(G);
   uint64_t n_rows = 0, n_general = 0;
   std::sort(e->touched.begin(), e->touched.end());
-  auto run_of = [](const Cmd& c, uint64_t* from) {  // AppendEntries blocks = the run (from, from + n]?
+  auto run_of = [](const Cmd& c) {  // AppendEntries blocks = a run (from, from + n]: what one JG_AE word can stand for?
     const size_t n = c.blocks.size();
     if (n > 0xfe) return false;
-    if (n == 0) {
-      *from = 0;
-      return true;
-    }
+    if (n == 0) return true;
     const uint64_t id0 = c.blocks[0].id;
     if (id0 == 0 || id0 - 1 + n >= JG_MAILBOX_NONE) return false;
     for (size_t k = 0; k < n; k++)
       if (c.blocks[k].id != id0 + k || c.blocks[k].next != id0 + k - 1) return false;
-    *from = id0 - 1;
     return true;
   };
   for (uint32_t g : e->touched) {
     Cls& k = cls[g];
     const Raft& r = e->groups[g];
+    size_t at = 0;
     for (const Cmd& c : e->pending[g]) {
       n_rows++;
+      at++;
       uint32_t bit = 0;
       bool general = false;
       switch (c.kind) {
@@ -729,98 +731,123 @@ int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
           bit = 1u << 18;
           break;
         case JG_CMD_HEARTBEAT:
-          general = !fol_half || c.id == JG_NO_ACK || c.from == 0;
+          // (a leader's answer to these is a role change or nothing, leader.rs:200-208,263: never an answer word)
+          general = !fol_half || c.id == JG_NO_ACK || c.from == 0 || r.role == JG_ROLE_LEADER;
           bit = 1u << 16;
-          k.hb_term = c.term, k.hb_from = c.from;
+          k.hb_term = c.term, k.hb_from = c.from, k.hb_at = at;
           break;
-        case JG_CMD_APPEND_ENTRIES: {
-          uint64_t from;
-          general = !fol_half || c.from == 0 || !run_of(c, &from);
+        case JG_CMD_APPEND_ENTRIES:
+          general = !fol_half || c.from == 0 || !run_of(c) || r.role == JG_ROLE_LEADER;
           bit = 1u << 17;
-          k.ae_term = c.term, k.ae_from = c.from;
+          k.ae_term = c.term, k.ae_from = c.from, k.ae_at = at;
           break;
-        }
         default: general = true;
       }
       if (general || (k.seen & bit)) k.general = true;  // outside the vocabulary / a second row for one mailbox entry
       k.seen |= bit;
     }
-    if ((k.seen & (3u << 16)) == (3u << 16) && (k.hb_term != k.ae_term || k.hb_from != k.ae_from)) k.general = true;
+    // one answer word holds the follower's two responses in the order HeartbeatResponse, AppendResponse (and one
+    // beat word the term and the sender of both rows): an AppendEntries that arrived BEFORE the Heartbeat is answered
+    // in the other order - rows
+    if ((k.seen & (3u << 16)) == (3u << 16) && (k.hb_term != k.ae_term || k.hb_from != k.ae_from || k.ae_at < k.hb_at)) k.general = true;
   }
-  // pass 2: column-form partitions fill the inbox; the others keep their rows for jo_step
+  // pass 2: the general partitions' rows go through jo_step (first); the others keep theirs for the halves
   std::vector<uint32_t> still;
   for (uint32_t g : e->touched) {
-    if (cls[g].general) {
-      n_general += e->pending[g].size();
-      still.push_back(g);
-      continue;
-    }
-    for (const Cmd& c : e->pending[g]) {
-      switch (c.kind) {
-        case JG_CMD_APPEND_RESPONSE: {
-          uint64_t& w = e->n_answers[(size_t)slot_of_id(e, c.from) * G + g];
-          w = (c.id << 8) | (w & 0xffu);
-          break;
-        }
-        case JG_CMD_HEARTBEAT_RESPONSE: {
-          const size_t at = (size_t)slot_of_id(e, c.from) * G + g;
-          e->n_answers[at] = (e->n_answers[at] & ~0xffull) | (c.flag ? 1u : 0u);
-          if (!c.flag) e->n_hbr[at] = c.id;
-          break;
-        }
-        case JG_CMD_CLIENT_REQUEST:
-          e->n_answers[(size_t)e->self_slot[g] * G + g] = JG_ANSWER(1, JG_HB_NONE);
-          e->n_token[g] = c.id;
-          break;
-        case JG_CMD_HEARTBEAT:
-          e->n_f_beat[g] = jg_leader_beat{c.term, c.id};
-          e->n_f_leader[g] = c.from;
-          break;
-        default: {  // AppendEntries
-          uint64_t from = 0;
-          (void)run_of(c, &from);
-          e->n_f_ae[g] = JG_AE(from, c.blocks.size());
-          e->n_f_beat[g].term = c.term;
-          e->n_f_leader[g] = c.from;
-        }
-      }
-      e->counters[0]++;
-    }
-    e->pending[g].clear();
+    if (!cls[g].general) continue;
+    n_general += e->pending[g].size();
+    still.push_back(g);
   }
-  // the columns: every partition's word of a handed-out slot, as if it had been that peer's rows (the own slot's word
-  // stays what it is: the append count)
-  for (uint32_t q = 0; q < R; q++) {
-    if (!((col_mask >> q) & 1u)) continue;
-    for (uint32_t g = 0; g < G; g++) {
-      if (q == e->self_slot[g]) continue;
-      e->n_answers[(size_t)q * G + g] = e->n_in_answers[(size_t)q * G + g];
-      e->n_hbr[(size_t)q * G + g] = ((col_hbc >> q) & 1u) ? e->n_in_hbc[(size_t)q * G + g] : 0;
-    }
-  }
-  e->touched.swap(still);
-  int rc = jo_step(e, now_ms);  // the general path, first
+  e->touched.swap(still);  // (`still` = every partition with rows, ascending)
+  int rc = jo_step(e, now_ms);
   if (rc) return rc;
   e->n_fsm.clear();
-  e->node_keep_fsm = true;
-  e->node_tokens = e->n_token.data();
   e->n_o_beat.assign(G, jg_leader_beat{0, JG_NO_ACK});
   e->n_o_ae.assign((size_t)R * G, JG_NO_ACK);
   e->n_o_answer.assign(G, JG_NO_ACK);
   e->n_o_hbc.assign(G, 0);
-  if (lead_half) {
-    const jg_leader_inbox in{e->n_answers.data(), e->n_hbr.data()};
-    const jg_leader_outbox out{e->n_o_beat.data(), e->n_o_ae.data()};
-    rc = jo_step_dense_leader(e, now_ms, &in, tick ? &out : nullptr);
+  const jg_leader_outbox l_out{e->n_o_beat.data(), e->n_o_ae.data()};
+  const jg_follower_outbox f_out{e->n_o_answer.data(), e->n_o_hbc.data()};
+  // the rows of a column-form partition, one command at a time in the order they arrived
+  auto apply_rows = [&](uint32_t g) {
+    Raft& r = e->groups[g];
+    for (const Cmd& c : e->pending[g]) {
+      r.apply(c, now_ms);
+      e->counters[0]++;
+      // 56-bit block ids in mailbox words: raised where the answer is produced
+      if (c.kind == JG_CMD_APPEND_ENTRIES)
+        for (const Msg& m : r.rpc)
+          if (m.kind == JG_CMD_APPEND_RESPONSE && m.id >= JG_MAILBOX_NONE && !r.fault) r.fault = JG_FAULT_ENGINE_MAILBOX_RANGE;
+    }
+    e->pending[g].clear();
+  };
+  if (lead_half) {  // ---- the partitions this node leads: their rows, the peers' columns, the Tick
+    for (uint32_t g = 0; g < G; g++) {
+      Raft& r = e->groups[g];
+      if (r.fault || r.role != JG_ROLE_LEADER) continue;
+      const int fault0 = r.fault;
+      const uint32_t s = e->self_slot[g];
+      apply_rows(g);
+      // a peer's column is its answers of the tick, after the rows: per slot HeartbeatResponse, AppendResponse
+      // (a follower answers the Heartbeat before the AppendEntries of one Tick, leader.rs:234-245)
+      for (uint32_t q = 0; q < R; q++) {
+        if (!((col_mask >> q) & 1u) || q == s) continue;
+        const uint64_t w = e->n_in_answers[(size_t)q * G + g];
+        Cmd c;
+        c.from = e->cfg.node_ids[q];
+        if ((w & 0xffu) != JG_HB_NONE) {
+          c.kind = JG_CMD_HEARTBEAT_RESPONSE;
+          c.flag = (uint8_t)(w & 0xffu);
+          c.id = c.flag ? 0 : (((col_hbc >> q) & 1u) ? e->n_in_hbc[(size_t)q * G + g] : 0);
+          r.apply(c, now_ms);
+          e->counters[0]++;
+        }
+        if ((w >> 8) != JG_MAILBOX_NONE) {
+          c.kind = JG_CMD_APPEND_RESPONSE;
+          c.flag = 1;
+          c.id = w >> 8;
+          r.apply(c, now_ms);
+          e->counters[0]++;
+        }
+      }
+      for (const Msg& m : r.rpc) push_row(e, g, m);  // (the extra AppendEntries of apply_heartbeat_response, leader.rs:222-231)
+      r.rpc.clear();
+      node_take_fsm(e, g);
+      r.fsm.clear();
+      if (tick && !r.fault) leader_tick_out(e, g, now_ms, &l_out);
+      note_fault(e, g, fault0);
+      e->counters[1] += r.decisions;
+      r.decisions = 0;
+    }
+    e->counters[2] += G;
   }
-  if (!rc && fol_half) {
-    jg_follower_inbox in{};
-    in.leader = e->n_f_leader.data(), in.beat = e->n_f_beat.data(), in.ae = e->n_f_ae.data();
-    const jg_follower_outbox out{e->n_o_answer.data(), e->n_o_hbc.data()};
-    rc = jo_step_dense_follower(e, now_ms, &in, &out, tick ? 1 : 0);
+  if (fol_half) {  // ---- everybody else: Heartbeat / AppendEntries rows, the Tick; the answers as words
+    for (uint32_t g = 0; g < G; g++) {
+      Raft& r = e->groups[g];
+      if (r.fault || r.role == JG_ROLE_LEADER) continue;
+      const int fault0 = r.fault;
+      apply_rows(g);
+      if (tick && r.role != JG_ROLE_LEADER && !r.fault) {
+        Cmd c;
+        c.kind = JG_CMD_TICK;
+        r.apply(c, now_ms);
+        e->counters[0]++;
+      }
+      follower_answers_out(e, g, &f_out);
+      node_take_fsm(e, g);
+      r.fsm.clear();
+      note_fault(e, g, fault0);
+      e->counters[1] += r.decisions;
+      r.decisions = 0;
+    }
+    e->counters[2] += G;
   }
-  e->node_keep_fsm = false;
-  e->node_tokens = nullptr;
+  // rows nobody applies: a faulted partition's (its process is gone), AppendResponse / HeartbeatResponse rows of a
+  // partition this node does not lead when only the leader half runs (ignored: follower.rs:62, candidate.rs:194)
+  for (uint32_t g : still) {
+    e->counters[0] += e->pending[g].size();
+    e->pending[g].clear();
+  }
   // the dense halves' fsm rows of one step: partitions ascending (at most one half emits for a partition)
   std::stable_sort(e->n_fsm.begin(), e->n_fsm.end(), [](const jg_fsm_row& a, const jg_fsm_row& b) { return a.group < b.group; });
   e->fsms.insert(e->fsms.end(), e->n_fsm.begin(), e->n_fsm.end());
@@ -828,7 +855,7 @@ int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
   e->n_last = jg_node_outbox{};
   e->n_last.rows = n_rows, e->n_last.rows_general = n_general;
   e->n_last_flags = flags;
-  return rc;
+  return JG_OK;
 }
 
 int jo_node_inbox_columns(jo_engine* e, uint32_t slot, uint64_t** answer, uint64_t** hb_commit) {

@@ -5,10 +5,11 @@
   Heartbeat / AppendEntries for followers) plus everything that must push a partition onto the
   general path (duplicates, votes, Timeout, explicit Tick rows, Restart, forged senders, blocks that
   are not a run, ClientRequests at followers, heads a mailbox word cannot hold), shuffled;
-* `plain_apply_equivalent`: the SPECIFICATION of the node step, in numpy and twenty lines of loops:
-  which partitions take the general path, and for the others the canonical command order - applied
-  through plain jg_submit + jg_step (Apply::apply, one command at a time).  What jo_step_node /
-  jg_step_node must be indistinguishable from;
+* `plain_apply_equivalent`: the SPECIFICATION of the node step: every row through plain jg_submit +
+  jg_step (Apply::apply, one command at a time) IN THE ORDER GIVEN (server.rs:120-161), then the
+  Ticks.  What jo_step_node / jg_step_node must be indistinguishable from - state, faults, and per
+  partition the order of every fsm_tx and rpc_tx row; `classify` restates which partitions the
+  engine reports as rows_general (a matter of representation, not of results);
 * `columns_as_rows`: the mailbox columns of a node outbox as the message rows they stand for.
 """
 import numpy as np
@@ -16,8 +17,6 @@ import numpy as np
 from josefine_amd import capi
 
 NO = capi.NO_ACK
-LEADER_VOCAB = (capi.CMD_APPEND_RESPONSE, capi.CMD_HEARTBEAT_RESPONSE, capi.CMD_CLIENT_REQUEST)
-FOLLOWER_VOCAB = (capi.CMD_HEARTBEAT, capi.CMD_APPEND_ENTRIES)
 
 
 def elect_some(e, mask, now_ms=0):
@@ -36,7 +35,7 @@ def elect_some(e, mask, now_ms=0):
         e.step(now_ms)
 
 
-def node_traffic(rng, ora, token0=0, p_noise=0.03, quiet=0.15):
+def node_traffic(rng, ora, token0=0, p_noise=0.03, quiet=0.15, p_reorder=0.08):
     """One tick's inbound rows for the node `ora` models, as kwargs for submit_columns."""
     G, R = ora.G, ora.R
     ids = np.array(ora.node_ids, dtype=np.uint32)
@@ -64,6 +63,12 @@ def node_traffic(rng, ora, token0=0, p_noise=0.03, quiet=0.15):
                     add(capi.CMD_HEARTBEAT_RESPONSE, g, ids[r], 0, max(c + int(rng.integers(-2, 2)), 0), 0, int(has))
             if rng.random() < 0.6:
                 add(capi.CMD_CLIENT_REQUEST, g, 0, 0, token0 + g)
+            if rng.random() < p_noise / 2:  # somebody else leads at a higher term (leader.rs:200-208: step down; :263: ignored)
+                other = ids[(s + 1) % R]
+                if rng.random() < 0.5:
+                    add(capi.CMD_HEARTBEAT, g, other, t + 1, int(rng.integers(0, h + 2)))
+                if rng.random() < 0.7:
+                    add(capi.CMD_APPEND_ENTRIES, g, other, t + int(rng.integers(0, 3)), 0, 0, 0, [(h + 1, h)] if rng.random() < 0.5 else [])
         else:
             lead = ids[(s + 1) % R]
             lt = t + int(rng.choice([0, 0, 0, 1, 2]))
@@ -102,6 +107,22 @@ def node_traffic(rng, ora, token0=0, p_noise=0.03, quiet=0.15):
                 add(capi.CMD_RESTART, g)
     order = rng.permutation(len(rows))
     rows = [rows[i] for i in order]
+    # the interleaving of different peers' messages and of client requests is the network's; ONE peer's
+    # messages mostly keep the order it sent them in (a follower answers the Heartbeat before the
+    # AppendEntries of a Tick, leader.rs:234-245) - mostly: the other order happens too (a replicate()
+    # triggered by a HeartbeatResponse, then the next Tick's Heartbeat) and must be served exactly as well
+    first = {}
+    for i, r in enumerate(rows):
+        k, g, f = r[0], r[1], r[2]
+        if k in (capi.CMD_HEARTBEAT, capi.CMD_HEARTBEAT_RESPONSE):
+            first.setdefault((g, f), []).append(i)
+    for i, r in enumerate(rows):
+        k, g, f = r[0], r[1], r[2]
+        if k in (capi.CMD_APPEND_ENTRIES, capi.CMD_APPEND_RESPONSE) and (g, f) in first:
+            j = first[(g, f)][0]
+            if (i < j) != (rng.random() < p_reorder):
+                rows[i], rows[j] = rows[j], rows[i]
+                first[(g, f)][0] = i
     return rows_to_columns(rows)
 
 
@@ -134,6 +155,7 @@ def classify(cols, role, self_slot, node_ids, leader=True, follower=True):
     general = np.zeros(G, bool)
     seen = [set() for _ in range(G)]
     beat = [{} for _ in range(G)]
+    at = [{} for _ in range(G)]
     for i in range(len(cols["kind"])):
         k, g, f = int(cols["kind"][i]), int(cols["group"][i]), int(cols["from_"][i])
         key = None
@@ -145,18 +167,21 @@ def classify(cols, role, self_slot, node_ids, leader=True, follower=True):
             bad = not leader or role[g] != capi.ROLE_LEADER
             key = (k,)
         elif k == capi.CMD_HEARTBEAT:
-            bad = not follower or int(cols["id"][i]) == NO or f == 0
+            # (a leader's answer to these is a role change or nothing, never an answer word: rows)
+            bad = not follower or int(cols["id"][i]) == NO or f == 0 or role[g] == capi.ROLE_LEADER
             key = (k,)
             beat[g]["hb"] = (int(cols["term"][i]), f)
+            at[g]["hb"] = i
         elif k == capi.CMD_APPEND_ENTRIES:
             first, n = int(cols["id"][i]), int(cols["aux"][i])
             b = cols["blk_id"][first:first + n].astype(object)
             nx = cols["blk_next"][first:first + n].astype(object)
             run = n <= 0xfe and (n == 0 or (int(b[0]) >= 1 and int(b[0]) - 1 + n < capi.MAILBOX_NONE and
                                           all(int(b[j]) == int(b[0]) + j and int(nx[j]) == int(b[0]) + j - 1 for j in range(n))))
-            bad = not follower or f == 0 or not run
+            bad = not follower or f == 0 or not run or role[g] == capi.ROLE_LEADER
             key = (k,)
             beat[g]["ae"] = (int(cols["term"][i]), f)
+            at[g]["ae"] = i
         else:
             bad = True
         if bad or (key is not None and key in seen[g]):
@@ -164,71 +189,40 @@ def classify(cols, role, self_slot, node_ids, leader=True, follower=True):
         if key is not None:
             seen[g].add(key)
     for g in range(G):
-        if len(beat[g]) == 2 and beat[g]["hb"] != beat[g]["ae"]:
+        # one answer word holds HeartbeatResponse then AppendResponse: an AppendEntries BEFORE the Heartbeat is rows
+        if len(beat[g]) == 2 and (beat[g]["hb"] != beat[g]["ae"] or at[g]["ae"] < at[g]["hb"]):
             general[g] = True
     return general
 
 
 def plain_apply_equivalent(e, cols, now_ms, leader=True, follower=True, tick=True):
-    """Apply one node step to engine `e` through plain submit + step only: the general partitions'
-    rows in stream order, then every partition's column-form rows in the canonical order with the
-    Tick where the dense halves put it."""
-    G, R = e.G, e.R
-    ids = list(e.node_ids)
-    slots = e.read("self_slot")
-    general = classify(cols, e.read("role"), slots, ids, leader, follower)
-    n = len(cols["kind"])
-    is_gen = general[cols["group"]] if n else np.zeros(0, bool)
-
-    def submit(idx):
-        if not len(idx):
-            return
-        idx = np.asarray(idx, dtype=np.int64)
-        e.submit_columns(cols["kind"][idx], cols["group"][idx], cols["from_"][idx], cols["term"][idx], cols["id"][idx],
-                         cols["aux"][idx], cols["flag"][idx], cols["blk_id"], cols["blk_next"])
-
-    submit(np.nonzero(is_gen)[0])
+    """Apply one node step to engine `e` through plain submit + step only: EVERY row in the order given
+    (per partition: the stream order, mod.rs:471-479), then Command::Tick for the partitions whose half
+    runs (the role after the rows decides which).  Returns which partitions the engine reports as general
+    (`classify`); leaves the fsm rows of the step in `e.plain_fsm` (drained)."""
+    general = classify(cols, e.read("role"), e.read("self_slot"), list(e.node_ids), leader, follower)
+    if len(cols["kind"]):
+        e.submit_columns(cols["kind"], cols["group"], cols["from_"], cols["term"], cols["id"], cols["aux"], cols["flag"],
+                         cols["blk_id"], cols["blk_next"])
     e.step(now_ms)
-    e.plain_fsm_general = e.drain_applies()  # (the general path's fsm rows are not run-length encoded)
-    # canonical order per partition; the Tick's place depends on the role AFTER the general rows
-    role = e.read("role")
-    per = [[] for _ in range(G)]
-    for i in np.nonzero(~is_gen)[0]:
-        per[int(cols["group"][i])].append(int(i))
-
-    def rank(i):
-        k, f = int(cols["kind"][i]), int(cols["from_"][i])
-        s = ids.index(f) if f in ids else 0
-        return {capi.CMD_HEARTBEAT_RESPONSE: (0, s), capi.CMD_CLIENT_REQUEST: (1, 0), capi.CMD_APPEND_RESPONSE: (2, s),
-                capi.CMD_HEARTBEAT: (4, 0), capi.CMD_APPEND_ENTRIES: (5, 0)}[k]
-
-    kind, group, frm, term, idc, aux, flag = [], [], [], [], [], [], []
-
-    def push(i=None, g=None):
-        if i is None:
-            kind.append(capi.CMD_TICK), group.append(g), frm.append(0), term.append(0), idc.append(0), aux.append(0), flag.append(0)
-        else:
-            kind.append(cols["kind"][i]), group.append(cols["group"][i]), frm.append(cols["from_"][i]), term.append(cols["term"][i])
-            idc.append(cols["id"][i]), aux.append(cols["aux"][i]), flag.append(cols["flag"][i])
-
-    for g in range(G):
-        mine = sorted(per[g], key=rank)
-        lead_rows = [i for i in mine if int(cols["kind"][i]) in LEADER_VOCAB]
-        fol_rows = [i for i in mine if int(cols["kind"][i]) in FOLLOWER_VOCAB]
-        is_leader = role[g] == capi.ROLE_LEADER
-        for i in lead_rows:
-            push(i)
-        if tick and leader and is_leader:
-            push(None, g)
-        for i in fol_rows:
-            push(i)
-        if tick and follower and not is_leader:
-            push(None, g)
-    if kind:
-        e.submit_columns(np.array(kind, np.uint8), np.array(group, np.uint32), np.array(frm, np.uint32), np.array(term, np.uint64),
-                         np.array(idc, np.uint64), np.array(aux, np.uint64), np.array(flag, np.uint8), cols["blk_id"], cols["blk_next"])
+    fsm = [e.drain_applies()]
+    if tick:
+        role = e.read("role")
+        g = np.nonzero(((role == capi.ROLE_LEADER) & leader) | ((role != capi.ROLE_LEADER) & follower))[0].astype(np.uint32)
+        if len(g):
+            e.submit_columns(np.full(len(g), capi.CMD_TICK, np.uint8), g)
     e.step(now_ms)
+    fsm.append(e.drain_applies())
+    e.plain_fsm = np.concatenate(fsm)
     return general
+
+
+def msgs_per_partition(rows):
+    """message tuples -> {partition: [tuples in order]}"""
+    d = {}
+    for t in rows:
+        d.setdefault(t[0], []).append(t)
+    return d
 
 
 def columns_as_rows(out, node_ids, self_slot, leader_of=None):

@@ -460,6 +460,8 @@ class RefEngine:
             if self.fault[g]:
                 continue
             r = self.groups[g]
+            # (the leader half ticks the groups that are leaders when the round begins: one Tick per group and round)
+            was_leader = r.role.name == "Leader"
             lead = int(leader[g]) if leader is not None else int(leader_id)
             rows = []
             if int(hb_commit[g]) != capi.NO_ACK:
@@ -470,7 +472,7 @@ class RefEngine:
                 blocks = [rr.Block(f + 1 + k, f + k) for k in range(n)]
                 rows += self._apply(g, rr.Command("AppendEntries", term=int(term[g]), leader_id=lead, blocks=blocks),
                                     now_ms, rows=False)
-            if tick and not self.fault[g] and self.groups[g].role.name != "Leader":
+            if tick and not self.fault[g] and not was_leader and self.groups[g].role.name != "Leader":
                 rows += self._apply(g, rr.Command("Tick"), now_ms, rows=False)
             keep = self._step_msgs.setdefault(g, [])
             for row in rows:

@@ -14,7 +14,8 @@ import numpy as np
 import pytest
 
 from josefine_amd import BatchedRaft, capi
-from node_step import classify, columns_as_rows, compare_outboxes, elect_some, node_traffic, plain_apply_equivalent
+from node_step import (classify, columns_as_rows, compare_outboxes, elect_some, msgs_per_partition, node_traffic, plain_apply_equivalent,
+                       rows_to_columns)
 from oracle_lib import oracle_engine
 from parity import compare_drains, compare_snapshots
 
@@ -54,11 +55,53 @@ def ref_py_engine(*a, **kw):
     return RefEngine(*a, **kw)
 
 
+def fsm_tuples(rows):
+    return [tuple(int(x) for x in (r["group"], r["kind"], r["a"], r["b"])) for r in rows]
+
+
+def expected_node_fsm(plain_rows, general):
+    """The fsm rows jg_step_node queues for one step, from the plain path's: the general partitions' rows as they
+    are (first: that launch comes first), then the column-form partitions' run-length encoded, partitions ascending."""
+    t = fsm_tuples(plain_rows)
+    gen = [x for x in t if general[x[0]]]
+    per = {}
+    for x in t:
+        if not general[x[0]]:
+            per.setdefault(x[0], []).append(x)
+    return gen + [y for g in sorted(per) for y in coalesce_fsm_tuples(per[g])]
+
+
+def node_messages_per_partition(node_rows, out, ids, slots, leader_of):
+    """rpc_tx of one node step per partition, in emission order (include/josefine_gpu.h, jg_step_node "Outputs"): where
+    an answer word is set - the queue the Heartbeat flushed (ClientRequest rows, follower.rs:190-197), the
+    HeartbeatResponse, the AppendResponse, then whatever the Tick sent; a leader's Tick columns come after its rows."""
+    rows = msgs_per_partition(msg_tuples(node_rows))
+    answers = msgs_per_partition(columns_as_rows({"answer": out.get("answer"), "hb_commit": out.get("hb_commit")}, ids, slots, leader_of))
+    ticks = msgs_per_partition(columns_as_rows({"beat_term": out.get("beat_term"), "beat_commit": out.get("beat_commit"), "ae": out.get("ae")},
+                                               ids, slots, leader_of))
+    out = {}
+    for g in set(rows) | set(answers) | set(ticks):
+        mine = rows.get(g, [])
+        flushed = [r for r in mine if g in answers and r[1] == capi.CMD_CLIENT_REQUEST]
+        out[g] = flushed + answers.get(g, []) + [r for r in mine if r not in flushed] + ticks.get(g, [])
+    return out
+
+
+def leader_of_rows(cols, general, G):
+    leader_of = np.zeros(G, np.int64)
+    for i in range(len(cols["kind"])):
+        if cols["kind"][i] in (capi.CMD_HEARTBEAT, capi.CMD_APPEND_ENTRIES) and not general[cols["group"][i]]:
+            leader_of[cols["group"][i]] = cols["from_"][i]
+    return leader_of
+
+
 @pytest.mark.parametrize("plain_backend", ["oracle", "ref_py"])
 @pytest.mark.parametrize("R,flags", [(3, 0), (5, 0), (5, capi.CFG_SEPARATE_COMMIT_KEY), (4, 0), (1, 0)])
-def test_oracle_node_step_is_plain_apply_in_canonical_order(R, flags, plain_backend):
-    """... and with plain_backend = ref_py the plain path is the independent Python reading of the Rust
-    (tests/ref_py): jg_step_node's semantics are then held to a restatement that shares no code with the oracle."""
+def test_oracle_node_step_is_plain_apply_in_arrival_order(R, flags, plain_backend):
+    """jo_step_node == every row through plain Apply::apply IN THE ORDER GIVEN, then the Ticks (server.rs:120-161):
+    state, faults, per partition the exact sequence of fsm_tx rows and of rpc_tx messages (columns and rows alike).
+    With plain_backend = ref_py the plain path is the independent Python reading of the Rust (tests/ref_py):
+    jg_step_node's semantics are then held to a restatement that shares no code with the oracle."""
     G, T = (400, 40) if plain_backend == "oracle" else (160, 25)
     node, plain, rng = mixed_pair(oracle_engine, oracle_engine if plain_backend == "oracle" else ref_py_engine, G, R, seed=11 + R,
                                   flags=flags, election_timeout_ms=(700, 1500))
@@ -67,29 +110,102 @@ def test_oracle_node_step_is_plain_apply_in_canonical_order(R, flags, plain_back
     for t in range(T):
         now = 100 * (t + 1)
         cols = node_traffic(rng, node, token0=1000 * t)
-        slots, role0 = node.read("self_slot"), node.read("role")
+        slots = node.read("self_slot")
         node.submit_columns(**cols)
         out = node.step_node(now)
         general = plain_apply_equivalent(plain, cols, now)
-        assert np.array_equal(general, classify(cols, role0, slots, node.node_ids))
         assert out["rows"] == len(cols["kind"]) and out["rows_general"] == int(general[cols["group"]].sum())
         dense_rows += out["rows"] - out["rows_general"]
         general_rows += out["rows_general"]
         compare_snapshots(node, plain, f"tick {t}")
         fa, fb = node.drain_faults(), plain.drain_faults()
         assert sorted(map(tuple, fa.tolist())) == sorted(map(tuple, fb.tolist())), t
-        assert [tuple(int(x) for x in (r["group"], r["kind"], r["a"], r["b"])) for r in node.drain_applies()] == \
-            [tuple(int(x) for x in (r["group"], r["kind"], r["a"], r["b"])) for r in plain.plain_fsm_general] + \
-            coalesce_fsm(plain.drain_applies()), t
-        # messages: the node step's rows + what its columns stand for == the plain path's rows
-        leader_of = np.zeros(G, np.int64)
-        for i in range(len(cols["kind"])):
-            if cols["kind"][i] in (capi.CMD_HEARTBEAT, capi.CMD_APPEND_ENTRIES) and not general[cols["group"][i]]:
-                leader_of[cols["group"][i]] = cols["from_"][i]
-        got = msg_tuples(node.drain_messages()) + columns_as_rows(out, ids, slots, leader_of)
-        want = msg_tuples(plain.drain_messages())
-        assert sorted(got, key=repr) == sorted(want, key=repr), t
+        assert fsm_tuples(node.drain_applies()) == expected_node_fsm(plain.plain_fsm, general), t
+        # messages: per partition, the node step's rows and what its columns stand for == the plain path's rows, in order
+        got = node_messages_per_partition(node.drain_messages(), out, ids, slots, leader_of_rows(cols, general, G))
+        want = msgs_per_partition(msg_tuples(plain.drain_messages()))
+        assert got == want, (t, [(g, got.get(g), want.get(g)) for g in set(got) | set(want) if got.get(g) != want.get(g)][:3])
     assert dense_rows > 5 * general_rows > 0  # the traffic is mostly steady state, and the general path was exercised
+
+
+def one_led_partition(make, R=3, head=0, **kw):
+    """One partition led by this node, `head` blocks appended and committed by everybody."""
+    e = make(1, R, seed=1, flags=capi.CFG_SEPARATE_COMMIT_KEY, election_timeout_ms=(700, 1500), **kw)
+    elect_some(e, np.array([True]))
+    ids = e.node_ids
+    for h in range(1, head + 1):
+        rows = [(capi.CMD_CLIENT_REQUEST, 0, 0, 0, h, 0, 0, None)] + [(capi.CMD_APPEND_RESPONSE, 0, ids[r], 1, h, 0, 1, None) for r in range(1, R)]
+        e.submit_columns(**rows_to_columns(rows))
+        e.step(10 * h)
+    e.drain_messages(), e.drain_applies(), e.drain_faults()
+    return e
+
+
+ARRIVAL_KATS = {
+    # round-3 review: acknowledgements of a block the leader has not appended yet, BEFORE the ClientRequest:
+    # the second one completes a majority for head + 1 while the chain ends at head - chain.rs:197-202 panics
+    "acks_above_the_head_before_the_append": (0, lambda ids: [(capi.CMD_APPEND_RESPONSE, 0, ids[1], 1, 1, 0, 1, None),
+                                                               (capi.CMD_APPEND_RESPONSE, 0, ids[2], 1, 1, 0, 1, None),
+                                                               (capi.CMD_CLIENT_REQUEST, 0, 0, 0, 77, 0, 0, None)]),
+    # ... the same acknowledgements AFTER it are legitimate: commit 1
+    "acks_of_the_new_head_after_the_append": (0, lambda ids: [(capi.CMD_CLIENT_REQUEST, 0, 0, 0, 77, 0, 0, None),
+                                                               (capi.CMD_APPEND_RESPONSE, 0, ids[1], 1, 1, 0, 1, None),
+                                                               (capi.CMD_APPEND_RESPONSE, 0, ids[2], 1, 1, 0, 1, None)]),
+    # legitimate traffic, ack first: fsm_tx is Apply(0..=1) THEN Notify(2) (head 1 / commit 0 before the step)
+    "ack_then_request": (-1, lambda ids: [(capi.CMD_APPEND_RESPONSE, 0, ids[1], 1, 1, 0, 1, None), (capi.CMD_CLIENT_REQUEST, 0, 0, 0, 78, 0, 0, None)]),
+    "request_then_ack": (-1, lambda ids: [(capi.CMD_CLIENT_REQUEST, 0, 0, 0, 78, 0, 0, None), (capi.CMD_APPEND_RESPONSE, 0, ids[1], 1, 1, 0, 1, None)]),
+    # a HeartbeatResponse without the commit makes the leader replicate() on the progress AS IT IS THEN (leader.rs:222-231)
+    "ack_then_heartbeat_response": (2, lambda ids: [(capi.CMD_APPEND_RESPONSE, 0, ids[1], 1, 1, 0, 1, None),
+                                                     (capi.CMD_HEARTBEAT_RESPONSE, 0, ids[1], 0, 1, 0, 0, None)]),
+    "heartbeat_response_then_ack": (2, lambda ids: [(capi.CMD_HEARTBEAT_RESPONSE, 0, ids[1], 0, 1, 0, 0, None),
+                                                     (capi.CMD_APPEND_RESPONSE, 0, ids[1], 1, 1, 0, 1, None)]),
+    "request_then_heartbeat_response": (2, lambda ids: [(capi.CMD_CLIENT_REQUEST, 0, 0, 0, 79, 0, 0, None),
+                                                         (capi.CMD_HEARTBEAT_RESPONSE, 0, ids[2], 0, 2, 0, 0, None)]),
+}
+
+
+def run_arrival_kat(make, name):
+    head, rows_of = ARRIVAL_KATS[name]
+    node, plain = one_led_partition(make, head=max(head, 0)), one_led_partition(oracle_engine, head=max(head, 0))
+    if head < 0:  # head 1 / commit 0: one block appended, nobody has acknowledged it
+        for e in (node, plain):
+            e.submit_columns(**rows_to_columns([(capi.CMD_CLIENT_REQUEST, 0, 0, 0, 5, 0, 0, None)]))
+            e.step(5)
+            e.drain_messages(), e.drain_applies(), e.drain_faults()
+    cols = rows_to_columns(rows_of(node.node_ids))
+    node.submit_columns(**cols)
+    out = node.step_node(1000)
+    general = plain_apply_equivalent(plain, cols, 1000)
+    compare_snapshots(node, plain, name)
+    assert node.drain_faults().tolist() == plain.drain_faults().tolist(), name
+    assert fsm_tuples(node.drain_applies()) == expected_node_fsm(plain.plain_fsm, general), name
+    got = node_messages_per_partition(node.drain_messages(), out, np.array(node.node_ids), node.read("self_slot"), np.zeros(1, np.int64))
+    assert got == msgs_per_partition(msg_tuples(plain.drain_messages())), name
+    return node, out
+
+
+@pytest.mark.parametrize("name", sorted(ARRIVAL_KATS))
+def test_oracle_node_step_arrival_order_kats(name):
+    node, out = run_arrival_kat(oracle_engine, name)
+    if name == "acks_above_the_head_before_the_append":
+        assert node.read("fault")[0] == capi.FAULT_COMMIT_MISSING_BLOCK and node.read("head")[0] == 0 and node.read("commit")[0] == 0
+    if name == "acks_of_the_new_head_after_the_append":
+        assert node.read("fault")[0] == 0 and node.read("head")[0] == 1 and node.read("commit")[0] == 1
+    assert out["rows_general"] == 0  # every one of these partitions stays in column form
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(ARRIVAL_KATS))
+def test_node_step_arrival_order_kats(name):
+    node, out = run_arrival_kat(BatchedRaft, name)
+    assert out["rows_general"] == 0
+
+
+def fsm_per_partition(rows):
+    d = {}
+    for t in fsm_tuples(rows):
+        d.setdefault(t[0], []).append(t)
+    return d
 
 
 def fsm_equal_per_partition(a_rows, b_rows):
@@ -117,23 +233,27 @@ def coalesce_fsm_tuples(rows):
 @pytest.mark.parametrize("R", [3, 5])
 def test_oracle_node_step_fsm_rows_decode_to_the_plain_paths(R):
     """The fsm_tx side of link 1, strictly: per partition and tick the node step's rows are the
-    plain path's, run-length encoded (Notify first, then ONE Apply range)."""
+    plain path's in the plain path's order, run-length encoded (an Apply range the acknowledgements that arrived
+    before the ClientRequest completed, the Notify, the Apply range of the ones after it)."""
     G, T = 300, 60
     node, plain, rng = mixed_pair(oracle_engine, oracle_engine, G, R, seed=5 + R, flags=capi.CFG_SEPARATE_COMMIT_KEY,
                                   election_timeout_ms=(700, 1500))
-    n_notify = n_apply = 0
+    n_notify = n_apply = n_apply_first = 0
     for t in range(T):
         now = 100 * (t + 1)
         cols = node_traffic(rng, node, token0=1000 * t, p_noise=0.02)
         node.submit_columns(**cols)
         node.step_node(now)
         plain_apply_equivalent(plain, cols, now)
-        a, b = node.drain_applies(), np.concatenate([plain.plain_fsm_general, plain.drain_applies()])
+        a, b = node.drain_applies(), plain.plain_fsm
         assert fsm_equal_per_partition(a, b), t
+        n_apply_first += sum(1 for g, rows in fsm_per_partition(a).items() if len(rows) > 1 and rows[0][1] != capi.FSM_NOTIFY and
+                             any(x[1] == capi.FSM_NOTIFY for x in rows))
         n_notify += int((a["kind"] == capi.FSM_NOTIFY).sum())
         n_apply += int((a["kind"] != capi.FSM_NOTIFY).sum())
         node.drain_messages(), plain.drain_messages(), node.drain_faults(), plain.drain_faults()
     assert n_notify > G and n_apply > G  # commits did advance: the rows are not vacuous
+    assert n_apply_first > G / 10        # ... and acknowledgements did complete a majority BEFORE the tick's ClientRequest
 
 
 @pytest.mark.gpu
