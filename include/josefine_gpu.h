@@ -433,7 +433,8 @@ int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* i
  *   1. Heartbeat{beat.term, beat.hb_commit, leader}    if beat[g].hb_commit != JG_NO_ACK (follower.rs:178-217)
  *   2. AppendEntries{beat.term, leader, blocks}        if ae[g] != JG_NO_ACK             (follower.rs:130-176)
  *   3. Command::Tick                                   if tick != 0     (follower.rs:121-128, candidate.rs:48-68)
- * Leaders apply 1-2 as the reference does (leader.rs:200-208,263) and are not ticked here.
+ * Leaders apply 1-2 as the reference does (leader.rs:200-208,263) and are not ticked here: the leader half ticks
+ * whoever is a leader when the round begins - also one that steps down in 1-2 (one Tick per group and round).
  * Equivalent to submitting those commands through jg_submit/jg_step, except that
  * AppendResponse / HeartbeatResponse go to the outbox columns and no FSM rows are queued. */
 int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in,
@@ -441,30 +442,45 @@ int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbo
 
 /* ---- a node's whole tick from host rows: the dense kernels behind the Apply surface ---------------
  * What server::event_loop (src/raft/server.rs:103-165) does between two ticks of its interval, for
- * every partition this node hosts at once: apply whatever tcp_rx / client_rx delivered (jg_submit:
- * rows in ANY order, no sorting on the host), then Command::Tick.  The rows are uploaded as they are
- * and classified on the device.  A partition whose rows all fit the mailbox vocabulary -
+ * every partition this node hosts at once: apply whatever tcp_rx / client_rx delivered, one command at a
+ * time IN THE ORDER IT ARRIVED (jg_submit: the rows of a partition in their stream order, partitions
+ * interleaved in any way, no sorting on the host), then Command::Tick.  The result - state, faults, and per
+ * partition the sequence of everything pushed on fsm_tx and rpc_tx - is that of jg_submit + jg_step over the
+ * same rows followed by a Tick row per partition: Apply::apply in arrival order (mod.rs:471-479).  Nothing is
+ * re-ordered.  The rows are uploaded as they are and classified on the device.  A partition whose rows all fit
+ * the mailbox vocabulary -
  *     at most one AppendResponse and one HeartbeatResponse per member slot (heads < JG_MAILBOX_NONE),
  *     at most one ClientRequest, and only if this node leads the partition,
- *     at most one Heartbeat and one AppendEntries, from the same sender with the same term, the
- *     AppendEntries' blocks a run (ids consecutive, each block's parent its predecessor, <= 254 blocks)
- * - is served in column form by the dense node tick (jg_step_dense_leader / _follower: the HBM-bound
- * kernels), in the order those define: HeartbeatResponses (ascending slot), the ClientRequest,
- * AppendResponses (ascending slot), the leader's Tick; then Heartbeat, AppendEntries, the follower's
- * Tick.  That is one legal schedule of the reference's event loop: messages of one peer keep their
- * order (a follower answers the Heartbeat before the AppendEntries of the same Tick, leader.rs:234-245),
- * and the interleaving of different peers' messages and client requests is the network's.  Every row
- * of any OTHER partition (votes, Timeout, Restart, explicit Tick rows, duplicates, a ClientRequest at a
- * non-leader, ...) is applied first, in stream order, by the general state machine exactly as
- * jg_submit + jg_step would; that partition then takes part in the Tick like everybody else.
+ *     at most one Heartbeat and one AppendEntries, only if this node does NOT lead the partition (a leader
+ *     answers them with a role change or not at all, leader.rs:200-208,263), from the same sender with the
+ *     same term, the Heartbeat first (one answer word holds HeartbeatResponse, AppendResponse in that order),
+ *     the AppendEntries' blocks a run (ids consecutive, each block's parent its predecessor, <= 254 blocks)
+ * - is served in column form by the dense node tick (the HBM-bound kernels).  A column forgets the order of
+ * the rows that filled it; what of that order can matter travels with the columns: which AppendResponses
+ * arrived BEFORE the ClientRequest (they met the chain head before the append: chain.rs:197-202 holds them to
+ * it, and what they committed precedes the Notify on fsm_tx), and for every partition the lag-space tick does
+ * not serve (a HeartbeatResponse without the commit makes the leader replicate() on the progress as it is at
+ * that moment, leader.rs:222-231; forged or far-behind heads) the arrival index of every row: those are
+ * replayed one command at a time in arrival order.  Every row of any OTHER partition (votes, Timeout, Restart,
+ * explicit Tick rows, duplicates, a ClientRequest at a non-leader, ...) is applied by the general state machine
+ * exactly as jg_submit + jg_step would (stream order); that partition then takes part in the Tick like
+ * everybody else.  `rows_general` counts those rows: a matter of cost, never of results.
+ * A column handed out by jg_node_inbox_columns stands for that peer's answers AFTER the step's rows, per
+ * partition HeartbeatResponse then AppendResponse, slots ascending.
  *
  * Outputs: rpc_tx - the Tick's Heartbeat / AppendEntries and the followers' answers as the mailbox
  * columns of jg_node_outbox (pinned host memory, one copy per column), everything else as rows through
- * jg_drain_messages; fsm_tx - unlike the plain dense entry points, jg_step_node QUEUES the FSM rows of
- * its dense halves for jg_drain_applies, run-length encoded per partition and step: at most one
- * JG_FSM_NOTIFY {a = block id, b = the ClientRequest's token} followed by at most one Apply range
- * (JG_FSM_APPLY_LEADER range(a..=b).skip(1) resp. JG_FSM_APPLY_FOLLOWER range(a..b)) - consecutive
- * ranges of one tick concatenate exactly (the progress heads only grow).  Faults: jg_drain_faults. */
+ * jg_drain_messages.  Per partition the reference's emission order is: where an answer word is set - the
+ * ClientRequest rows of the step (the queue the Heartbeat flushed, follower.rs:190-197), the word's
+ * HeartbeatResponse, its AppendResponse, then the partition's other rows (what its Tick sent); elsewhere - the
+ * partition's rows (a leader's extra AppendEntries of apply_heartbeat_response), then the Tick's words:
+ * Heartbeat, AppendEntries by ascending slot.  fsm_tx - unlike the plain dense entry points, jg_step_node
+ * QUEUES the FSM rows of its dense halves for jg_drain_applies, run-length encoded per partition and step, in
+ * emission order: the Apply range (JG_FSM_APPLY_LEADER range(a..=b).skip(1)) committed by the
+ * AppendResponses that arrived before the ClientRequest, the JG_FSM_NOTIFY {a = block id, b = the
+ * ClientRequest's token}, the Apply range of the self-ack and the AppendResponses after it; a follower: one
+ * JG_FSM_APPLY_FOLLOWER range(a..b) - consecutive ranges concatenate exactly (the progress heads only
+ * grow).  Faults: jg_drain_faults. */
 enum {
   JG_NODE_LEADER_HALF = 1u,   /* serve the partitions this node leads (jg_step_dense_leader)            */
   JG_NODE_FOLLOWER_HALF = 2u, /* serve the partitions it follows (jg_step_dense_follower)              */

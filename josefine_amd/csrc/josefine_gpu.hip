@@ -329,6 +329,8 @@ struct jg_engine {
     size_t tmp_bytes = 0;
     uint32_t group_bits = 1;
     hipEvent_t ev_out = nullptr;
+    hipEvent_t ev_cols = nullptr;      // behind the uploads of the handed-out columns: the pinned buffers are free again
+    bool cols_in_flight = false;
     jg_node_outbox last{};
     uint32_t last_flags = 0;
     // multi-device parent: the shards' columns concatenated
@@ -1323,6 +1325,7 @@ void jg_engine_destroy(jg_engine* e) {
     if (p) (void)hipHostFree(p);
   if (e->node.tmp) (void)hipFree(e->node.tmp);
   if (e->node.ev_out) (void)hipEventDestroy(e->node.ev_out);
+  if (e->node.ev_cols) (void)hipEventDestroy(e->node.ev_cols);
   e->q_msgs.destroy();
   e->q_fsm.destroy();
   e->l_msgs.destroy();
@@ -1707,6 +1710,7 @@ int node_ensure(jg_engine* e) {
   HIPCHK(hipHostMalloc((void**)&n.h_in_answers, std::max<size_t>(R * G * 8, 16), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&n.h_in_hbc, std::max<size_t>(R * G * 8, 16), hipHostMallocDefault));
   HIPCHK(hipEventCreateWithFlags(&n.ev_out, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&n.ev_cols, hipEventDisableTiming));
   while (n.group_bits < 32 && (G - 1) >> n.group_bits) n.group_bits++;
   n.ready = true;
   return JG_OK;
@@ -1732,7 +1736,9 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   const uint32_t ggrid = grid_for(G, 4096);
   uint64_t bytes_up = 0;
   // column inbound: the handed-out slots' columns go up as they are (8 bytes per partition and peer instead of two rows)
-  const uint32_t col_mask = (halves & JG_NODE_LEADER_HALF) ? nd.col_mask : 0u;
+  if (nd.col_mask && !(halves & JG_NODE_LEADER_HALF))  // (never dropped silently: the leader half is what applies them)
+    return fail(JG_EINVAL, "jg_step_node: a column was handed out (jg_node_inbox_columns) but the leader half does not run");
+  const uint32_t col_mask = nd.col_mask;
   for (uint32_t r = 0; r < R;) {  // (neighbouring slots travel in one copy: a copy costs ~10 us before its first byte)
     if (!((col_mask >> r) & 1u)) {
       r++;
@@ -1749,10 +1755,17 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     bytes_up += len * (((nd.col_hbc_mask >> r) & 1u) ? 2 : 1);
     r = r1;
   }
+  if (col_mask) {  // (jg_node_inbox_columns waits for this before it hands the same pinned buffers out again)
+    HIPCHK(hipEventRecord(nd.ev_cols, e->stream));
+    nd.cols_in_flight = true;
+  }
   nd.col_mask = nd.col_hbc_mask = 0;  // (a hand-out covers one step)
   hipLaunchKernelGGL(k_node_prefill, dim3(ggrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, e->uniform_self,
                      halves & JG_NODE_LEADER_HALF, halves & JG_NODE_FOLLOWER_HALF, both_beats, col_mask);
   uint32_t n_sparse = 0;
+  // the general path's sequence number is taken whether or not it runs: the shards of a multi-device engine must leave
+  // one node step with the same numbers (the router merges their rows by step number first: jg_multi.h)
+  e->seq++;
   if (n) {
     // the rows in stream order, straight out of the pinned columns jg_submit (or the caller, in place:
     // jg_submit_reserve) filled: one copy per column that is present - an optional column nobody
@@ -1847,7 +1860,6 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
       hipLaunchKernelGGL(k_node_gather_rows, dim3(sgrid), dim3(JG_BLOCK), 0, e->stream, n_sparse, (const uint32_t*)idx2, rows, so);
       HIPCHK(hipGetLastError());
       e->n_launch += 4;
-      e->seq++;
       if ((rc = launch_rows(e, n_sparse, so.group, so.kind, so.from, so.term, so.id, so.aux, so.flag,
                             nb ? rows.blk_id : (const uint64_t*)e->d_ones, nb ? rows.blk_next : (const uint64_t*)e->d_ones, nb, now_ms)))
         return rc;
@@ -1937,6 +1949,10 @@ int jg_node_inbox_columns(jg_engine* e, uint32_t slot, uint64_t** answer, uint64
   if (rc) return rc;
   jg_engine::NodeStep& nd = e->node;
   const size_t G = e->cfg.n_groups;
+  if (nd.cols_in_flight) {  // the previous step's uploads out of these buffers (a step without rows never synchronises)
+    HIPCHK(hipEventSynchronize(nd.ev_cols));
+    nd.cols_in_flight = false;
+  }
   *answer = nd.h_in_answers + (size_t)slot * G;
   nd.col_mask |= 1u << slot;
   if (hb_commit) {

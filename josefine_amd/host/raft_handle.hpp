@@ -16,10 +16,12 @@
 // ranges into blocks in key order (leader.rs:93, follower.rs:204).  No state-machine
 // arithmetic happens here: every decision comes out of the device engine.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <deque>
 #include <functional>
 #include <map>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -227,6 +229,7 @@ class BatchedRaft {
   // persisted tree, follower.rs:68-95, chain.rs:117-137); returns what Chain::new finds in the re-opened tree
   formats::ChainStore::Reopened restart(uint32_t g, uint64_t now_ms = 0) {
     stores_[g] = formats::ChainStore::from_raw(stores_[g].raw());
+    extend_failed_.erase(g);
     const formats::ChainStore::Reopened r = stores_[g].reopen();
     queued_[g].clear();
     Command c;
@@ -258,9 +261,27 @@ class BatchedRaft {
     blk_id_.clear(), blk_next_.clear();
   }
   void after_step() {
-    // followers store the payloads of the blocks they were sent (chain.rs:187-189); a
-    // block whose extend failed is harmless here: its id is never reported as applied.
-    for (auto& pb : pending_blocks_) stores_[pb.first].insert(pb.second);
+    // followers store the payloads of the blocks they were sent exactly as Chain::extend does (chain.rs:178-192): a
+    // block whose parent is missing returns Err BEFORE db.insert, the event loop of that partition ends there
+    // (server.rs:125-159 propagates with `?`) and nothing behind it is stored; a partition whose process was gone
+    // before the AppendEntries (or that died of something else on the way: the stale-leader assert of
+    // follower.rs:147-154 comes before the extends) stores nothing - the tree must stay byte for byte what sled holds.
+    if (!pending_blocks_.empty()) {
+      uint32_t lo = pending_blocks_.front().first, hi = lo;
+      for (auto& pb : pending_blocks_) lo = std::min(lo, pb.first), hi = std::max(hi, pb.first);
+      std::vector<uint8_t> fault(hi - lo + 1);
+      check(jg_read_state(e_, JG_FIELD_FAULT, 0, fault.data(), lo, hi - lo + 1));
+      for (auto& pb : pending_blocks_) {
+        const uint32_t g = pb.first;
+        uint8_t& f = fault[g - lo];
+        if (f && (f != JG_FAULT_EXTEND_MISSING_PARENT || extend_failed_.count(g))) continue;
+        if (f == JG_FAULT_EXTEND_MISSING_PARENT && !stores_[g].has(pb.second.next)) {
+          extend_failed_.insert(g);  // the failing block: dropped, and everything of this partition behind it
+          continue;
+        }
+        stores_[g].insert(pb.second);
+      }
+    }
     pending_blocks_.clear();
     pump();
   }
@@ -413,6 +434,7 @@ class BatchedRaft {
   std::vector<uint32_t> group_, from_;
   std::vector<uint64_t> term_, id_, aux_, blk_id_, blk_next_;
   std::vector<std::pair<uint32_t, Block>> pending_blocks_;
+  std::set<uint32_t> extend_failed_;  // partitions whose process died in Chain::extend (until their restart)
   std::map<std::pair<uint32_t, uint64_t>, std::vector<uint8_t>> pending_reqs_;
 };
 

@@ -679,7 +679,8 @@ int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
   const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
   const bool lead_half = flags & JG_NODE_LEADER_HALF, fol_half = flags & JG_NODE_FOLLOWER_HALF, tick = flags & JG_NODE_TICK;
   // column inbound (jo_node_inbox_columns): a sender that spoke a column this step may not also speak rows
-  const uint32_t col_mask = lead_half ? e->n_col_mask : 0u, col_hbc = e->n_col_hbc_mask;
+  if (e->n_col_mask && !lead_half) return fail(JG_EINVAL, "jg_step_node: a column was handed out but the leader half does not run");
+  const uint32_t col_mask = e->n_col_mask, col_hbc = e->n_col_hbc_mask;
   e->n_col_mask = e->n_col_hbc_mask = 0;
   if (col_mask)
     for (uint32_t g : e->touched)

@@ -2,13 +2,15 @@
 (server::event_loop for many partitions: src/raft/server.rs:103-165).
 
 Two links of one chain:
-  1. (CPU) the oracle's restatement of the entry point (jo_step_node: classification, inbox columns,
-     the two dense halves applying what the columns stand for one command at a time) is
-     indistinguishable from PLAIN Apply::apply in the canonical order the header defines - state,
-     faults, fsm rows (run-length decoded), and every message, columns and rows alike;
+  1. (CPU) the oracle's restatement of the entry point (jo_step_node: every row through Raft::apply in
+     arrival order, then the Tick; the classification only decides what is reported as columns) is
+     indistinguishable from PLAIN jg_submit + jg_step over the same rows IN THE ORDER GIVEN - state,
+     faults, and per partition the exact sequence of fsm rows (run-length decoded) and of messages,
+     columns and rows alike; the plain path also run on tests/ref_py;
   2. (GPU) the HIP engine's jg_step_node is bit-identical to the oracle's: every state column, every
      drained row, every outbox word, tick after tick, on mixed leader / follower / candidate
-     populations with traffic that exercises every reason to leave the column path.
+     populations with traffic that exercises every reason to leave the column path - and, directly,
+     to its OWN plain path (jg_submit + jg_step on a second device engine) in the order given.
 """
 import numpy as np
 import pytest
@@ -103,8 +105,19 @@ def test_oracle_node_step_is_plain_apply_in_arrival_order(R, flags, plain_backen
     With plain_backend = ref_py the plain path is the independent Python reading of the Rust (tests/ref_py):
     jg_step_node's semantics are then held to a restatement that shares no code with the oracle."""
     G, T = (400, 40) if plain_backend == "oracle" else (160, 25)
-    node, plain, rng = mixed_pair(oracle_engine, oracle_engine if plain_backend == "oracle" else ref_py_engine, G, R, seed=11 + R,
-                                  flags=flags, election_timeout_ms=(700, 1500))
+    arrival_order_differential(oracle_engine, oracle_engine if plain_backend == "oracle" else ref_py_engine, G, R, T, flags, seed=11 + R)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,flags,G", [(3, 0, 2500), (5, capi.CFG_SEPARATE_COMMIT_KEY, 2500), (5, 0, 600), (2, 0, 300), (1, 0, 200)])
+def test_node_step_is_plain_apply_in_arrival_order_on_the_device(R, flags, G):
+    """The round-3 review's differential, on the device alone: jg_step_node on one engine, jg_submit + jg_step over the
+    same rows in the order given (+ a Tick row per partition) on another - no oracle in between."""
+    arrival_order_differential(BatchedRaft, BatchedRaft, G, R, 40, flags, seed=51 + R)
+
+
+def arrival_order_differential(make_node, make_plain, G, R, T, flags, seed):
+    node, plain, rng = mixed_pair(make_node, make_plain, G, R, seed=seed, flags=flags, election_timeout_ms=(700, 1500))
     ids = np.array(node.node_ids)
     dense_rows = general_rows = 0
     for t in range(T):
