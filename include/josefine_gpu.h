@@ -531,10 +531,28 @@ int jg_node_outbox_view(jg_engine* e, jg_node_outbox* out);
  * (tick = 1) on the others (josefine::DenseCluster::round in josefine_amd/host/raft_handle.hpp).
  * Engines are borrowed: destroy the cluster BEFORE them (it gives them their streams back). */
 typedef struct jg_dense_cluster jg_dense_cluster;
+/* lead = JG_CLUSTER_ANY_LEADER: PER-PARTITION LEADERSHIP - every node leads the partitions it was elected for and
+ * follows the others (what a josefine cluster looks like after its elections: candidate.rs:101-113 -> leader.rs:124-174).
+ * The mailbox columns are then the CLUSTER's, indexed by group and slot: whoever leads group g reads row r of the
+ * answers as slot r's answer and writes the beat and the AppendEntries words of g; every other node reads its
+ * word, follows and answers into its own row.  A round is
+ *   0. the claim: owner[g] = the lowest slot whose node is a healthy leader of g (JG_OWNER: nobody);
+ *   1. every node's leader half over the groups it leads - the owner's exactly as jg_step_dense_leader (its own slot's
+ *      word = the ClientRequests jg_dense_cluster_set_appends offers to whoever owns g), its Tick into the columns;
+ *      a leader that is NOT the owner (two terms' leaders in one round) gets no inbox and no ClientRequest, and its
+ *      Tick travels as rows (Heartbeat rows are delivered by the routed round's transport, AppendEntries rows stay
+ *      queued for the host like every AppendEntries row);
+ *   2. every node's follower half over the groups it does not lead, tick = 1, sender = the owner's NodeId - mail only
+ *      where somebody else owns the group.
+ * Equivalent, call for call, to that sequence of jg_step_dense_leader / jg_step_dense_follower calls with the inboxes
+ * masked accordingly (tests/dense_node.py::AnyLeaderCluster states it in numpy).  Each node takes two steps per round.
+ * The nodes must share a device; n_nodes <= 6; nodes[r] hosts replica slot r of every group. */
+#define JG_CLUSTER_ANY_LEADER 0xFFFFFFFFu
 int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t lead, jg_dense_cluster** out);
 void jg_dense_cluster_destroy(jg_dense_cluster* c);
 /* ClientRequests every group appends per round (leader.rs:177-197): the same number for all groups,
- * or (per_group != NULL) one value per group from host memory. */
+ * or (per_group != NULL) one value per group from host memory.  (JG_CLUSTER_ANY_LEADER: offered to whoever owns the
+ * group that round; a group nobody leads is offered nothing.) */
 int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const uint64_t* per_group);
 /* n_rounds protocol rounds at logical times now_ms, now_ms + dt_ms, ...; asynchronous (jg_sync the nodes). */
 int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms, uint32_t n_rounds);
@@ -551,7 +569,8 @@ int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_lead
  *      the order (sender slot, emission order), then the injected ones;
  *   2. the dense round of jg_dense_cluster_rounds at now_ms, except that the ClientRequests of
  *      jg_dense_cluster_set_appends are offered only to groups nodes[lead] leads at that moment (a
- *      replica without a leader queues them, follower.rs:258-270: not a dense append);
+ *      replica without a leader queues them, follower.rs:258-270: not a dense append; with per-partition
+ *      leadership: to whoever owns the group);
  *   3. the transport: rows addressed to members (JG_TO_PEERS: all other members; JG_TO_PEER: to_id)
  *      are delivered, EXCEPT AppendEntries rows (the payload is the sender's block store) and
  *      ClientRequest rows (instructions to the host adapter about its request mirror): those, and

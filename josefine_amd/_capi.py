@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 
 ABI_VERSION = 4
+CLUSTER_ANY_LEADER = 0xFFFFFFFF
 MAX_REPLICAS = 8
 CHAIN_WINDOW = 8
 MAX_INFLIGHT = 5

@@ -382,7 +382,7 @@ struct JgClockVal {
 struct JgClock {
   uint32_t idx_lead, idx_rest;
   uint64_t dt;
-  uint32_t n_nodes, pad;
+  uint32_t n_nodes, seq_step;  // seq_step: steps a node takes per round (1; 2 with per-partition leadership: both halves)
   JgClockVal v[2];
 };
 __device__ __forceinline__ void jg_clock_read(const JgClock* c, uint32_t slot, uint64_t& now, uint32_t& seq) {
@@ -406,7 +406,15 @@ struct JgLeaderNode {
   // slow kernel replays a group's commands in that order; slots in `col_mask` spoke a column (after the rows)
   const uint32_t* arr;
   uint32_t col_mask, pad2_;
+  // a cluster with per-partition leadership (jg_dense_cluster_create, JG_CLUSTER_ANY_LEADER): the mailboxes are the
+  // CLUSTER's, indexed by group - whoever leads a group reads its inbox and writes its outbox.  owner[g] = the slot
+  // whose Tick travels in the columns this round (k_cluster_claim: the lowest slot that leads g, 0xff: nobody);
+  // a leader that is not the owner (two terms' leaders in one round) has no inbox and sends its Tick as rows.
+  // offered[g] = the own slot's word (JG_ANSWER(#ClientRequests, none)) for whoever owns g.
+  const uint8_t* owner;
+  const uint64_t* offered;
 };
+#define JG_OWNER_NONE 0xffu
 #define JG_FSM_APPENDED_BIT (1u << 31)
 #define JG_FSM_WIDE_BIT (1u << 30)
 #define JG_FSM_FOLLOWER_BIT (1u << 29)
@@ -530,8 +538,9 @@ struct JgDenseIn {
   uint32_t f;
   uint64_t a[R], w, head;
   uint64_t term, hbt;  // NODE
+  uint32_t own;        // ANY: owner[g]
 };
-template <int R, bool UNIFORM, bool NODE>
+template <int R, bool UNIFORM, bool NODE, bool ANY = false>
 __device__ __forceinline__ void jg_dense_issue(const JgDenseHot& h, const JgDev* dp,
                                                const uint64_t* __restrict__ acks, uint32_t us,
                                                const JgLeaderNode& nd, bool emit, uint32_t g, JgDenseIn<R>& in) {
@@ -547,7 +556,9 @@ __device__ __forceinline__ void jg_dense_issue(const JgDenseHot& h, const JgDev*
     // per slot carries both answers of that follower (JG_ANSWER): R loads, not 2R + R byte loads - the
     // kernel's time follows the number of its memory instructions (profiles/README.md).
 #pragma unroll
-    for (int r = 0; r < R; r++) in.a[r] = __builtin_nontemporal_load(&acks[((size_t)r * h.G + g) * nd.ack_stride]);
+    for (int r = 0; r < R; r++)
+      in.a[r] = (ANY && (uint32_t)r == us) ? nd.offered[g] : __builtin_nontemporal_load(&acks[((size_t)r * h.G + g) * nd.ack_stride]);
+    if (ANY) in.own = nd.owner[g];
     in.w = h.mlag[g];
     in.head = h.head[g];
     in.term = h.term[g];
@@ -684,7 +695,7 @@ __device__ __forceinline__ void jg_dense_cold_lds(const JgDev& d, const uint64_t
 // DEFER: the host has k_dense_slow scheduled behind this launch: everything that is not served in
 // lag space goes there.  A compile-time switch on purpose: as a run-time flag it cost the hot path
 // of the 1 M x 5 launch 0.5 us (the compiler prepared general-path operands ahead of the branch).
-template <int R, bool UNIFORM, bool NODE, bool DEFER, bool FSM = false>
+template <int R, bool UNIFORM, bool NODE, bool DEFER, bool FSM = false, bool ANY = false>
 __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev* dp,
                                                const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us, const JgLeaderNode& nd, bool emit, uint32_t g,
                                                const JgDenseIn<R>& in, JgDecCount& dec, uint64_t (*sm)[JG_BLOCK]) {
@@ -703,6 +714,15 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
 #pragma unroll
   for (int r = 1; r < R; r++) n_app = (uint32_t)r == s ? a[r] : n_app;
   if (NODE && !nd.ack_stride) n_app = 0;
+  // per-partition leadership: the group's mailboxes belong to its owner; a leader that is not (another term's leader
+  // in the same round) has no inbox, appends nothing and sends its Tick as rows (k_dense_slow)
+  const bool mine = !ANY || in.own == s;
+  if (ANY && !mine) {
+#pragma unroll
+    for (int r = 0; r < R; r++) a[r] = JG_NO_ACK;
+    n_app = 0;
+    hbr_trigger = false;
+  }
   uint32_t pre = 0;  // jg_step_node: slots whose AppendResponse arrived before the ClientRequest
   if (FSM) {
     pre = (uint32_t)(n_app >> JG_NODE_PRE_SHIFT) & 0xffu;
@@ -716,6 +736,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   uint32_t dl = 0;
   bool hot = (f & (JGF_FAULT_MASK | JGF_ROLE_MASK | JGF_FAST)) == (JG_ROLE_LEADER | JGF_FAST);
   if (NODE) hot = hot && !hbr_trigger;
+  if (ANY) hot = hot && mine;
   hot = jg_lag_tick<R>(s, f, mword0, head0, n_app, a, lt, dl) && hot;
   // fsm rows come from the (appended?, commit advance) word: one Notify at most, and a commit index whose old
   // value is in the packed word - anything else is the general state machine's (k_dense_slow)
@@ -760,7 +781,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   if ((NODE || DEFER) && cls == JG_DENSE_RUN) cls = JG_DENSE_DEFER;
   jg_defer_mark(d, g, cls == JG_DENSE_DEFER);
   if (NODE) {
-    if (emit) jg_dense_outbox_none<R, UNIFORM>(h.G, nd, g, s);
+    if (emit && mine) jg_dense_outbox_none<R, UNIFORM>(h.G, nd, g, s);  // (ANY: another node's mail is not this one's to erase)
     return;
   }
   if (DEFER || cls != JG_DENSE_RUN) return;
@@ -772,7 +793,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
 
 // Grid-stride loop over the groups (a software prefetch of the next group's loads measured no gain
 // and cost 13 VGPRs: profiles/README.md).
-template <int R, bool UNIFORM, bool NODE, bool DEFER, bool FSM = false>
+template <int R, bool UNIFORM, bool NODE, bool DEFER, bool FSM = false, bool ANY = false>
 __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, const JgDev* dp,
                                                        const uint64_t* __restrict__ acks, uint32_t seq, uint32_t us,
                                                        const JgLeaderNode& nd, uint64_t (*sm)[JG_BLOCK]) {
@@ -781,9 +802,13 @@ __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, co
   JgDecCount dec;
   uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x;
   for (; g < G; g += stride) {
+    if (ANY) {  // the flag word first: a wave that leads none of its 64 groups loads nothing else (a node leads G / R of them)
+      const uint32_t f0 = h.flags[g];
+      if (__ballot((f0 & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER) == 0) continue;
+    }
     JgDenseIn<R> in;
-    jg_dense_issue<R, UNIFORM, NODE>(h, dp, acks, us, nd, emit, g, in);
-    jg_dense_group<R, UNIFORM, NODE, DEFER, FSM>(h, dp, acks, seq, us, nd, emit, g, in, dec, sm);
+    jg_dense_issue<R, UNIFORM, NODE, ANY>(h, dp, acks, us, nd, emit, g, in);
+    jg_dense_group<R, UNIFORM, NODE, DEFER, FSM, ANY>(h, dp, acks, seq, us, nd, emit, g, in, dec, sm);
   }
   return dec;
 }
@@ -816,6 +841,57 @@ __global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDenseHot h, con
   if (us >= 0) dec = jg_dense_tick_body<R, true, true, true, FSM>(h, dp, acks, seq, (uint32_t)us, nd, nullptr);
   else dec = jg_dense_tick_body<R, false, true, true, FSM>(h, dp, acks, seq, 0, nd, nullptr);
   jg_wave_count(h.blk_decisions, dec);
+}
+
+// Per-partition leadership (jg_dense_cluster, JG_CLUSTER_ANY_LEADER): the leader halves of ALL nodes of a cluster in one
+// launch, blockIdx.y = node; every node's lanes serve the groups that node leads, out of the cluster's mailboxes.
+struct JgLeaderJob {
+  JgDenseHot h;
+  const JgDev* dp;
+  const uint64_t* acks;
+  uint32_t seq;
+  int us;
+  JgLeaderNode nd;
+};
+template <int R>
+__global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick_any(const JgLeaderJob* __restrict__ jobs) {
+  const JgLeaderJob& j = jobs[blockIdx.y];
+  JgLeaderNode nd = j.nd;
+  uint32_t seq = j.seq;
+  if (nd.clock) {  // a replayed round: the first kernel of the round that reads the clock (see JgClock)
+    const uint32_t a = nd.clock->idx_lead & 1u;
+    nd.now = nd.clock->v[a].now, seq = nd.clock->v[a].seq[nd.clock_slot];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nd.clock->idx_rest = a;
+  }
+  const JgDecCount dec = jg_dense_tick_body<R, true, true, true, false, true>(j.h, j.dp, j.acks, seq, (uint32_t)j.us, nd, nullptr);
+  jg_wave_count(j.h.blk_decisions, dec);
+}
+
+// owner[g] = the lowest slot whose node leads group g (healthy leaders only), JG_OWNER_NONE: nobody - four groups per lane
+struct JgClaimArgs {
+  const uint32_t* flags[JG_MAX_REPLICAS];
+  uint32_t R, G;
+  uint8_t* owner;
+};
+__global__ __launch_bounds__(JG_BLOCK) void k_cluster_claim(JgClaimArgs a) {
+  const uint32_t n4 = (a.G + 3u) / 4u;
+  constexpr uint32_t M = JGF_ROLE_MASK | JGF_FAULT_MASK;
+  for (uint32_t q = blockIdx.x * JG_BLOCK + threadIdx.x; q < n4; q += gridDim.x * JG_BLOCK) {
+    uint32_t o[4] = {JG_OWNER_NONE, JG_OWNER_NONE, JG_OWNER_NONE, JG_OWNER_NONE};
+    if (q * 4u + 3u < a.G) {  // one 16-byte load per node (the flag columns are 16-byte aligned)
+      for (uint32_t r = a.R; r-- > 0;) {
+        const uint4 f = ((const uint4*)a.flags[r])[q];
+        o[0] = (f.x & M) == JG_ROLE_LEADER ? r : o[0];
+        o[1] = (f.y & M) == JG_ROLE_LEADER ? r : o[1];
+        o[2] = (f.z & M) == JG_ROLE_LEADER ? r : o[2];
+        o[3] = (f.w & M) == JG_ROLE_LEADER ? r : o[3];
+      }
+    } else {
+      for (uint32_t k = 0; k < 4; k++)
+        for (uint32_t r = a.R; q * 4u + k < a.G && r-- > 0;) o[k] = (a.flags[r][q * 4u + k] & M) == JG_ROLE_LEADER ? r : o[k];
+    }
+    ((uint32_t*)a.owner)[q] = o[0] | o[1] << 8 | o[2] << 16 | o[3] << 24;  // (the column is allocated in whole words)
+  }
 }
 
 // ---- T consecutive ticks per launch (temporal fusion) ----------------------------------------

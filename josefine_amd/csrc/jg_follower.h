@@ -40,7 +40,18 @@ struct JgFollowerArgs {
   // jg_step_node: what the step pushed on fsm_tx, one word per group (jg_dense.h JG_FSM_*_BIT); null otherwise
   uint32_t* fsm_delta;
   uint64_t* fsm_prev;
+  // a cluster with per-partition leadership (JgLeaderNode::owner): the sender of a group's mail is its owner; there is
+  // mail only where somebody else owns the group (the columns keep last round's words where nobody wrote)
+  const uint8_t* owner;
+  uint32_t self_slot;
+  uint32_t seq_off;  // added to the clock's step number (the follower half is the node's second step of a round there)
 };
+__device__ __forceinline__ uint32_t jg_member_id(const JgDev& d, uint32_t slot) {
+  uint32_t id = 0;
+#pragma unroll
+  for (uint32_t r = 0; r < JG_MAX_REPLICAS; r++) id = r == slot ? d.node_ids[r] : id;
+  return id;
+}
 __device__ __forceinline__ void jg_follower_fsm_note(const JgFollowerArgs& a, uint32_t g, uint64_t commit0, uint64_t commit1) {
   if (!a.fsm_delta || commit1 == commit0) return;  // follower.rs:201-207: one Apply range per Heartbeat that advances
   const uint64_t adv = commit1 - commit0;
@@ -52,18 +63,26 @@ __device__ __forceinline__ void jg_follower_fsm_note(const JgFollowerArgs& a, ui
   }
 }
 
+template <bool ANY = false>
 __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollowerArgs a) {
-  if (a.clock) jg_clock_read(a.clock, a.clock_slot, a.now, a.seq);
+  if (a.clock) jg_clock_read(a.clock, a.clock_slot, a.now, a.seq), a.seq += a.seq_off;
   const uint32_t G = d.G;
   for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
     // every load is independent of the others
     const uint32_t f = d.flags[g];
-    const jg_leader_beat beat = a.beat[g];  // one 16-byte load
+    uint32_t own = 0;
+    if (ANY) {  // a wave whose 64 groups this node all leads (and owns) has nothing to do here, and its word of the answers is nobody's
+      own = a.owner[g];
+      if (__ballot(!((f & JGF_ROLE_MASK) == JG_ROLE_LEADER && own == a.self_slot)) == 0) continue;
+    }
+    const bool mail = !ANY || (own != JG_OWNER_NONE && own != a.self_slot);
+    jg_leader_beat beat = a.beat[g];  // one 16-byte load
+    uint64_t in_ae = __builtin_nontemporal_load(&a.ae[g]);
+    if (ANY && !mail) beat = jg_leader_beat{0, JG_NO_ACK}, in_ae = JG_NO_ACK;
     const uint64_t in_term = beat.term, in_hbc = beat.hb_commit;
-    const uint64_t in_ae = __builtin_nontemporal_load(&a.ae[g]);
     const uint64_t in_from = in_ae >> 8;
     const uint32_t in_n = (uint32_t)in_ae & 0xffu;
-    const uint32_t lead = a.leader ? a.leader[g] : a.leader_id;
+    const uint32_t lead = ANY ? jg_member_id(d, own) : (a.leader ? a.leader[g] : a.leader_id);
     uint64_t term = d.term[g], head = d.head[g], commit = d.commit[g];
     uint32_t voted_for = d.voted_for[g], leader_id = d.leader_id[g];
     const uint32_t queued = d.queued[g];
@@ -88,7 +107,8 @@ __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollower
     const bool defer = !dead && !idle_leader && !nothing && !fast;
     jg_defer_push(d, g, defer);
     if (dead || idle_leader || nothing || defer) {
-      a.o_answer[g] = JG_NO_ACK;  // nothing; the slow kernel overwrites the words of its groups
+      // nothing; the slow kernel overwrites the words of its groups (ANY: the own slot's word of a group this node owns is nobody's)
+      if (!(ANY && idle_leader && own == a.self_slot)) a.o_answer[g] = JG_NO_ACK;
       continue;
     }
     uint64_t o_ack = JG_MAILBOX_NONE;
@@ -177,7 +197,7 @@ __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollower
   }
 }
 
-__global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFollowerArgs a) { jg_follower_fast_body(d, a); }
+__global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense(JgDev d, JgFollowerArgs a) { jg_follower_fast_body<false>(d, a); }
 
 // The follower halves of several nodes that share a device in ONE launch (blockIdx.y = node): what a
 // replayed cluster round uses - a kernel costs ~4.6 us before it does anything, and a round had four of these
@@ -188,13 +208,17 @@ struct JgFollowerJob {
 };
 __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense_multi(const JgFollowerJob* __restrict__ jobs) {
   const JgFollowerJob& j = jobs[blockIdx.y];
-  jg_follower_fast_body(j.d, j.a);
+  jg_follower_fast_body<false>(j.d, j.a);
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense_any(const JgFollowerJob* __restrict__ jobs) {  // (per-partition leadership)
+  const JgFollowerJob& j = jobs[blockIdx.y];
+  jg_follower_fast_body<true>(j.d, j.a);
 }
 
 // The deferred groups through the general state machine.  AppendResponse / HeartbeatResponse
 // rows are captured into the outbox columns, everything else goes to the exceptional queue.
 __device__ __forceinline__ void jg_follower_slow_body(const JgDev& d, JgFollowerArgs a) {
-  if (a.clock) jg_clock_read(a.clock, a.clock_slot, a.now, a.seq);
+  if (a.clock) jg_clock_read(a.clock, a.clock_slot, a.now, a.seq), a.seq += a.seq_off;
   uint32_t dec = 0;
   const uint32_t n = d.slow_cnt[blockIdx.x] < d.slow_cap ? d.slow_cnt[blockIdx.x] : d.slow_cap;
   const uint32_t* list = d.slow_list + (size_t)blockIdx.x * d.slow_cap;
@@ -216,15 +240,17 @@ __device__ __forceinline__ void jg_follower_slow_body(const JgDev& d, JgFollower
     L.cap_ack = JG_NO_ACK;
     L.cap_hbc = 0;
     L.cap_has = JG_HB_NONE;
-    const uint32_t lead = a.leader ? a.leader[g] : a.leader_id;
+    const uint32_t own = a.owner ? a.owner[g] : 0u;
+    const bool mail = !a.owner || (own != JG_OWNER_NONE && own != a.self_slot);  // (per-partition leadership: see JgFollowerArgs)
+    const uint32_t lead = a.owner ? jg_member_id(d, own) : (a.leader ? a.leader[g] : a.leader_id);
     JgCmd c;
     c.from = lead;
     c.flag = 0;
     c.term = a.beat[g].term;
     c.aux = 0;
     if (!tick_only) {
-      const uint64_t hbc = a.beat[g].hb_commit;
-      const uint64_t ae = a.ae[g];
+      const uint64_t hbc = mail ? a.beat[g].hb_commit : JG_NO_ACK;
+      const uint64_t ae = mail ? a.ae[g] : JG_NO_ACK;
       const uint32_t n_blk = (uint32_t)ae & 0xffu;
       if (hbc != JG_NO_ACK) {
         c.kind = JG_CMD_HEARTBEAT;

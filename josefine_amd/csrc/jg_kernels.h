@@ -26,8 +26,8 @@
 // NODE: behind a node tick (HeartbeatResponses in, the Tick's outbox out).  A template parameter so that the
 // instance behind the ack-only kernels carries neither the Tick's local row buffer (scratch) nor its code.
 template <bool NODE>
-__global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
-                                                          size_t tick_stride, uint32_t seq0, JgLeaderNode nd) {
+__device__ __forceinline__ void jg_dense_slow_body(const JgDev& d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
+                                                   size_t tick_stride, uint32_t seq0, JgLeaderNode nd, bool advance_clock) {
   if (nd.clock) jg_clock_read(nd.clock, nd.clock_slot, nd.now, seq0);
   uint32_t dec = 0;
   // this workgroup's shard of the deferral bitmap (jg_defer_mark) -> its list; the words are
@@ -76,14 +76,19 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
     // (node tick: the block holds answer words, JG_ANSWER(head, HeartbeatResponse code))
     const bool packed = NODE && nd.packed != 0;
     auto ack_of = [=](uint64_t w) { return packed ? jg_answer_ack(w) : w; };
+    // per-partition leadership (JgLeaderNode::owner): the group's mailboxes are its owner's; a leader that is not the
+    // owner has no inbox, appends nothing and its Tick travels as rows; the own slot's word comes from `offered`
+    const bool mine = !(NODE && nd.owner) || nd.owner[g] == s;
+    const uint64_t* const ga = mine ? acks : nullptr;  // this group's inbox
+    auto own_word = [=](const uint64_t* A) { return (NODE && nd.offered) ? nd.offered[g] : A[(size_t)s * d.G + g]; };
     // (jg_step_node: the word holds 0 or 1 and, above JG_NODE_PRE_SHIFT, the arrival bits)
-    if (!(NODE && nd.arr) && acks && n_ticks && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L) &&
-        ack_of(acks[(size_t)s * d.G + g]) >= JG_MAX_DENSE_APPENDS) {
+    if (!(NODE && nd.arr) && ga && n_ticks && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L) &&
+        ack_of(own_word(ga)) >= JG_MAX_DENSE_APPENDS) {
       L.seq = seq0;
       jg_raise(d, L, JG_FAULT_ENGINE_DENSE_APPENDS);
     }
     uint64_t fsm_mid = fsm_commit0;  // (jg_step_node: the commit index at the moment the ClientRequest was applied)
-    if (NODE && nd.arr && packed && acks) {
+    if (NODE && nd.arr && packed && ga) {
       // jg_step_node: the group's commands one at a time IN THE ORDER THEY ARRIVED (server.rs:120-161) - the inbox
       // entries sorted by the arrival index k_node_classify left with each (selection: at most 2R entries); a slot
       // that spoke a column comes after the rows, HeartbeatResponse then AppendResponse
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
         for (uint32_t e2 = 0; e2 < 2u * d.R; e2++) {
           const bool is_ack = e2 < d.R;
           const uint32_t r = is_ack ? e2 : e2 - d.R;
-          const uint64_t w = acks[(size_t)r * d.G + g];
+          const uint64_t w = ga[(size_t)r * d.G + g];
           bool present;
           if (r == s) present = is_ack && (uint32_t)(w >> 8) != 0;  // the ClientRequest
           else present = is_ack ? (w >> 8) != JG_MAILBOX_NONE : jg_answer_hb(w) != JG_HB_NONE;
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
         last = best;
         const bool is_ack = be < d.R;
         const uint32_t r = is_ack ? be : be - d.R;
-        const uint64_t w = acks[(size_t)r * d.G + g];
+        const uint64_t w = ga[(size_t)r * d.G + g];
         c.from = d.node_ids[r];
         c.term = c.aux = 0;
         if (r == s) {
@@ -127,12 +132,12 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
       c.from = 0;
       c.id = 0;
     } else {
-      if (NODE && packed && acks && !jg_fault(L)) {  // 1. HeartbeatResponses, ascending slot (leader.rs:222-231)
+      if (NODE && packed && ga && !jg_fault(L)) {  // 1. HeartbeatResponses, ascending slot (leader.rs:222-231)
         L.seq = seq0;
         c.kind = JG_CMD_HEARTBEAT_RESPONSE;
         for (uint32_t r = 0; r < d.R && !jg_fault(L); r++) {
           if (r == s) continue;
-          const uint32_t has = jg_answer_hb(acks[(size_t)r * d.G + g]);
+          const uint32_t has = jg_answer_hb(ga[(size_t)r * d.G + g]);
           if (has == JG_HB_NONE) continue;
           c.from = d.node_ids[r];
           c.flag = has;
@@ -142,10 +147,10 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
         c.from = 0;
         c.id = 0;
       }
-      for (uint32_t t = 0; acks && t < n_ticks && !jg_fault(L); t++) {  // 2. appends, then acks
-        const uint64_t* A = acks + (size_t)t * tick_stride;
+      for (uint32_t t = 0; ga && t < n_ticks && !jg_fault(L); t++) {  // 2. appends, then ga
+        const uint64_t* A = ga + (size_t)t * tick_stride;
         L.seq = seq0 + t;
-        uint64_t n_app = ack_of(A[(size_t)s * d.G + L.g]);
+        uint64_t n_app = ack_of(own_word(A));
         if (n_app >= JG_MAX_DENSE_APPENDS) {
           jg_raise(d, L, JG_FAULT_ENGINE_DENSE_APPENDS);
           break;
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
       // ... and every AppendEntries word must be able to hold its range start key (a progress head forged
       // up to 2^56 - 1 or beyond does not fit the 56-bit field): otherwise the Tick travels as rows
       for (uint32_t r = 0; r < d.R; r++) fast = fast && (r == s || jg_match_get(d, L, r) < JG_MAILBOX_NONE);
+      fast = fast && mine;  // (the columns hold the owner's Tick)
       if (!fast) {
         jg_apply(d, L, c, nullptr, nullptr);  // rows: the blocks are not id-consecutive
       } else if (L.head >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words
@@ -211,16 +217,37 @@ __global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t
   }
   __syncthreads();
   if (threadIdx.x == 0) d.slow_cnt[blockIdx.x] = 0;
-  if (NODE && nd.clock && blockIdx.x == 0 && threadIdx.x == 0) {  // the next round's clock (see JgClock)
+  if (NODE && nd.clock && advance_clock && blockIdx.x == 0 && threadIdx.x == 0) {  // the next round's clock (see JgClock)
     JgClock* c = nd.clock;
     const uint32_t b = c->idx_rest & 1u;
     JgClockVal nv = c->v[b];
     nv.now += c->dt;
-    for (uint32_t r = 0; r < c->n_nodes; r++) nv.seq[r] += 1;  // every node takes one step per round
+    for (uint32_t r = 0; r < c->n_nodes; r++) nv.seq[r] += c->seq_step;  // every node takes one step per round (two: both halves)
     c->v[b ^ 1u] = nv;
     c->idx_lead = b ^ 1u;
   }
   jg_block_count(d.blk_decisions, dec);
+}
+template <bool NODE>
+__global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
+                                                          size_t tick_stride, uint32_t seq0, JgLeaderNode nd) {
+  jg_dense_slow_body<NODE>(d, acks, n_ticks, tick_stride, seq0, nd, true);
+}
+// The leader slow kernels of all nodes of a cluster with per-partition leadership in ONE launch (blockIdx.y = node);
+// the jobs travel as kernel arguments for the reason k_follower_slow_multi's do.
+#define JG_LEADER_MULTI 6
+struct JgLeaderSlowJob {
+  JgDev d;
+  const uint64_t* acks;
+  uint32_t seq0, pad;
+  JgLeaderNode nd;
+};
+struct JgLeaderSlowJobs {
+  JgLeaderSlowJob j[JG_LEADER_MULTI];
+};
+__global__ __launch_bounds__(JG_BLOCK) void k_dense_slow_multi(JgLeaderSlowJobs jobs) {
+  const JgLeaderSlowJob& j = jobs.j[blockIdx.y];
+  jg_dense_slow_body<true>(j.d, j.acks, 1, 0, j.seq0, j.nd, blockIdx.y == 0);
 }
 
 #include "jg_sparse.h"  // k_apply_rows, k_gather_rows

@@ -17,10 +17,11 @@
 #include "jg_device.h"
 #include "jg_sparse.h"
 
-#define JG_ROUTE_ORD_BITS 27u       // widest emission-index field: the key then has 35 + bits(G) <= 64 bits (G <= 2^29)
+#define JG_ROUTE_ORD_BITS 26u       // widest emission-index field: the key then has 35 + bits(G) <= 64 bits (G <= 2^29)
+#define JG_ROUTE_STEP_BITS 3u       // a node takes up to 4 steps per routed round (delivered rows, injected rows, leader half, follower half)
 #define JG_ROUTE_ORD_BITS_FAST 12u  // what a round's keys are built with first: 5 sort passes instead of 7 at 1 M groups
 // ordering key of a delivered row, most significant first: destination member (3 bits, right above
-// the group's bits), group, sender slot (3), step of the round (2), emission index within the group's
+// the group's bits), group, sender slot (3), step of the round (3), emission index within the group's
 // step (ord_bits: the pass reports an index that does not fit and is repeated with the wide field)
 struct JgRouteTable {
   uint32_t R, src;                      // members, the sending member's index
@@ -53,7 +54,7 @@ __device__ __forceinline__ uint32_t jg_route_dests(const jg_msg_row& r, const Jg
 __device__ __forceinline__ uint64_t jg_route_key(const JgRouteTable& t, uint32_t dest, uint32_t group, uint32_t step,
                                                  uint32_t ord) {
   if (ord >> t.ord_bits) t.count[t.R + JG_ROUTE_OVERFLOW] = 1;
-  return ((((uint64_t)dest << t.group_bits | group) << 3 | t.src) << 2 | step) << t.ord_bits | ord;
+  return ((((uint64_t)dest << t.group_bits | group) << 3 | t.src) << JG_ROUTE_STEP_BITS | step) << t.ord_bits | ord;
 }
 // One staging reservation per workgroup and tile (every wave of a launch reserving for itself made the
 // one cursor the bottleneck: a returning atomic on a single address retires every ~18 ns, 85 us for the
@@ -279,7 +280,7 @@ __device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const Jg
     if (i < n) {
       q = xq[i];
       // (rows of steps before this round - left undrained by the caller - are not this round's mail: they stay)
-      mask = (q.seq - seq_base - 1u < 3u) ? jg_route_dests(q.row, t) : 0u;
+      mask = (q.seq - seq_base - 1u < 7u) ? jg_route_dests(q.row, t) : 0u;  // (steps 1..7 of the round: JG_ROUTE_STEP_BITS)
     }
     const bool stay = i < n && !mask;
     if (COMPACT) {
@@ -304,11 +305,11 @@ __device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const Jg
       jg_route_note(pd_lo, pd_hi, (uint32_t)__ffs(b) - 1u);
       jg_route_note_kind(kd_lo, kd_hi, (uint32_t)__ffs(b) - 1u, q.row.kind);
       if (staged) {
-        jg_stage_put(st, at, jg_route_key(t, (uint32_t)__ffs(b) - 1u, q.row.group, step & 3u, q.k), q.row);
+        jg_stage_put(st, at, jg_route_key(t, (uint32_t)__ffs(b) - 1u, q.row.group, step & 7u, q.k), q.row);
         continue;
       }
       if (pos >= sp.lim) continue;
-      t.key[pos] = jg_route_key(t, (uint32_t)__ffs(b) - 1u, q.row.group, step & 3u, q.k);
+      t.key[pos] = jg_route_key(t, (uint32_t)__ffs(b) - 1u, q.row.group, step & 7u, q.k);
       t.idx[pos] = pos;
       t.row[pos] = q.row;
     }

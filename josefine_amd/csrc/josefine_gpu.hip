@@ -1993,6 +1993,14 @@ struct jg_dense_cluster {
   hipGraphExec_t exec = nullptr;
   uint64_t sig = 0, graph_dt = 0;
   uint64_t* offered = nullptr;  // [G] the ClientRequests per round as set by jg_dense_cluster_set_appends
+  // per-partition leadership (lead == JG_CLUSTER_ANY_LEADER at creation): every node runs both halves over the
+  // cluster's mailboxes; owner[g] = whose Tick the columns carry this round (k_cluster_claim)
+  bool any = false;
+  uint8_t* owner = nullptr;
+  char *any_h_jobs = nullptr, *any_d_jobs = nullptr;  // the round's job tables (leader halves | follower halves): pinned / device
+  hipEvent_t any_ev = nullptr;  // behind the upload of an eager round's tables: the pinned copy may be rewritten
+  bool any_ev_pending = false;
+  static constexpr size_t ANY_SLICE = 8192;
   // While clustered, nodes that share the lead node's device run on ITS stream: the halves of a round
   // are bandwidth-bound, so running them side by side buys nothing (each then takes 50-60 us instead
   // of 20), five streams do not fit four hardware queues (two follower halves ended up behind each
@@ -2029,13 +2037,19 @@ struct jg_dense_cluster {
 };
 
 int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t lead, jg_dense_cluster** out) {
+  const bool any = lead == JG_CLUSTER_ANY_LEADER;
+  if (any) lead = 0;  // (the node whose stream and device the cluster's work is issued on)
   if (!nodes || !out || !n_nodes || lead >= n_nodes) return fail(JG_EINVAL, "bad argument");
   for (uint32_t r = 0; r < n_nodes; r++) {
     if (!nodes[r] || nodes[r]->router) return fail(JG_EINVAL, "a dense cluster takes single-device engines (or shard handles)");
     if (nodes[r]->cfg.n_groups != nodes[0]->cfg.n_groups || nodes[r]->cfg.n_replicas != n_nodes)
       return fail(JG_EINVAL, "every node hosts the same groups, one replica slot each");
+    if (any && (nodes[r]->device != nodes[0]->device || nodes[r]->uniform_self != (int)r))
+      return fail(JG_EINVAL, "per-partition leadership: the nodes share a device and nodes[r] hosts replica slot r of every group");
   }
+  if (any && n_nodes > JG_LEADER_MULTI) return fail(JG_EINVAL, "per-partition leadership: at most 6 nodes");
   jg_dense_cluster* c = new jg_dense_cluster();
+  c->any = any;
   c->nodes.assign(nodes, nodes + n_nodes);
   c->G = nodes[0]->cfg.n_groups, c->R = n_nodes, c->lead = lead;
   c->lead_id = nodes[lead]->cfg.node_ids[lead];
@@ -2057,8 +2071,22 @@ int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t 
   // ... and the lead node's own slot carries the number of appends: zero, with no HeartbeatResponse
   // (JG_NO_ACK there is outside the own slot's domain: JG_FAULT_ENGINE_DENSE_APPENDS)
   for (size_t g = 0; g < G; g++) a[(size_t)lead * G + g] = JG_ANSWER(0, JG_HB_NONE);
+  if (any) {  // (whoever owns a group reads its own slot's word from `offered`: every row of the inbox is a peer's)
+    const size_t ob = (G + 15) & ~size_t(15);
+    if ((rc = alloc(ob, (void**)&c->owner)) || hipMemsetAsync(c->owner, 0xff, ob, L->stream) != hipSuccess ||
+        hipHostMalloc((void**)&c->any_h_jobs, 2 * jg_dense_cluster::ANY_SLICE, hipHostMallocDefault) != hipSuccess ||
+        (rc = alloc(2 * jg_dense_cluster::ANY_SLICE, (void**)&c->any_d_jobs))) {
+      jg_dense_cluster_destroy(c);
+      return rc ? rc : fail(JG_EDEVICE, "per-partition leadership: allocation failed");
+    }
+  }
+  if ((rc = jg_device_upload(L, c->offered, a.data() + (size_t)lead * G, G * 8))) {
+    jg_dense_cluster_destroy(c);
+    return rc;
+  }
+  if (any)
+    for (size_t g = 0; g < G; g++) a[(size_t)lead * G + g] = JG_NO_ACK;
   if ((rc = jg_device_upload(L, c->acks, a.data(), a.size() * 8)) ||
-      (rc = jg_device_upload(L, c->offered, a.data() + (size_t)lead * G, G * 8)) ||
       // (the lead node's own row of the AppendEntries block is never written by its kernel: JG_NO_ACK once)
       hipMemsetAsync(c->o_ae, 0xff, 8 * R * G, L->stream) != hipSuccess) {
     jg_dense_cluster_destroy(c);
@@ -2091,6 +2119,8 @@ void jg_dense_cluster_destroy(jg_dense_cluster* c) {
     }
   if (c->exec) (void)hipGraphExecDestroy(c->exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
+  if (c->any_h_jobs) (void)hipHostFree(c->any_h_jobs);
+  if (c->any_ev) (void)hipEventDestroy(c->any_ev);
   for (void* p : c->bufs) (void)jg_device_free(c->nodes[c->lead], p);
   for (void* p : {(void*)c->rt.key, (void*)c->rt.key_alt, (void*)c->rt.idx, (void*)c->rt.idx_alt, (void*)c->rt.row, (void*)c->rt.cols_mem})
     if (p) (void)hipFree(p);
@@ -2114,7 +2144,7 @@ int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const ui
   }
   const uint64_t* src = v.data();
   int rc = jg_device_upload(c->nodes[c->lead], c->offered, src, (size_t)c->G * 8);
-  if (rc) return rc;
+  if (rc || c->any) return rc;  // (per-partition leadership: the kernels read `offered` itself)
   return jg_device_upload(c->nodes[c->lead], c->acks + (size_t)c->lead * c->G, src, (size_t)c->G * 8);
 }
 
@@ -2213,6 +2243,102 @@ int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits,
   return JG_OK;
 }
 
+// ---- a round with per-partition leadership (JG_CLUSTER_ANY_LEADER) --------------------------------
+// Five launches on the cluster's stream: k_cluster_claim (who owns each group's columns this round), the leader
+// halves of all nodes (k_leader_node_tick_any, blockIdx.y = node), their slow kernels (k_dense_slow_multi), the
+// follower halves of all nodes (k_follower_tick_dense_any), their slow kernels (k_follower_slow_multi).  Every node
+// takes TWO steps per round (leader half, follower half).  `replay`: the round is being captured - time and step
+// numbers come from the device-resident clock, the host-side bookkeeping is done per graph launch.
+int cluster_tables_any(jg_dense_cluster* c, uint64_t now_ms, bool replay) {
+  jg_engine* L = c->nodes[c->lead];
+  const uint32_t R = c->R;
+  const size_t G = c->G;
+  int rc = JG_OK;
+  JgLeaderJob* lj = (JgLeaderJob*)c->any_h_jobs;
+  JgFollowerJob* fj = (JgFollowerJob*)(c->any_h_jobs + jg_dense_cluster::ANY_SLICE);
+  static_assert(JG_LEADER_MULTI * sizeof(JgLeaderJob) <= jg_dense_cluster::ANY_SLICE, "job slice too small");
+  static_assert(JG_LEADER_MULTI * sizeof(JgFollowerJob) <= jg_dense_cluster::ANY_SLICE, "job slice too small");
+  if (!c->any_ev) HIPCHK(hipEventCreateWithFlags(&c->any_ev, hipEventDisableTiming));
+  if (c->any_ev_pending) {  // (the previous eager round's upload out of the same pinned tables)
+    HIPCHK(hipEventSynchronize(c->any_ev));
+    c->any_ev_pending = false;
+  }
+  for (uint32_t r = 0; r < R; r++) {
+    jg_engine* e = c->nodes[r];
+    if (!replay) {
+      if ((rc = ensure_xq(e))) return rc;
+      e->stepped = true;
+      e->seq += 2;  // leader half: seq - 1, follower half: seq
+      e->slow_scheduled_ever = true;
+      e->n_launch += 4;
+      e->n_dense += 2 * G;
+      e->maybe_irregular = true, e->flag_check_pending = true, e->irr_gen++;
+    }
+    JgLeaderNode nd{};
+    nd.clock = replay ? c->clock : nullptr, nd.clock_slot = r;
+    nd.ack_stride = 1, nd.packed = 1;
+    nd.hbr_commit = c->hbr_commit;
+    nd.o_beat = c->o_beat, nd.o_ae = c->o_ae;
+    nd.now = now_ms;
+    nd.owner = c->owner, nd.offered = c->offered;
+    JgLeaderJob& j = lj[r];
+    j.h = jg_dense_hot_of(e->dev), j.dp = e->d_dev, j.acks = c->acks, j.seq = e->seq - 1, j.us = (int)r, j.nd = nd;
+    JgFollowerJob& f = fj[r];
+    f = JgFollowerJob{};
+    f.d = e->dev;
+    f.a.clock = replay ? c->clock : nullptr, f.a.clock_slot = r, f.a.seq_off = 1;
+    f.a.leader = nullptr, f.a.leader_id = 0;
+    f.a.beat = c->o_beat, f.a.ae = c->o_ae + (size_t)r * G;
+    f.a.o_answer = c->acks + (size_t)r * G, f.a.o_hbc = c->hbr_commit + (size_t)r * G;
+    f.a.now = now_ms, f.a.seq = e->seq, f.a.tick = 1;
+    f.a.owner = c->owner, f.a.self_slot = r;
+  }
+  // (replay: the tables are written once, outside the capture; an eager round's carry its time and step numbers)
+  if (replay) HIPCHK(hipMemcpy(c->any_d_jobs, c->any_h_jobs, 2 * jg_dense_cluster::ANY_SLICE, hipMemcpyHostToDevice));
+  else {
+    HIPCHK(hipMemcpyAsync(c->any_d_jobs, c->any_h_jobs, 2 * jg_dense_cluster::ANY_SLICE, hipMemcpyHostToDevice, L->stream));
+    HIPCHK(hipEventRecord(c->any_ev, L->stream));
+    c->any_ev_pending = true;
+  }
+  return JG_OK;
+}
+// (the launches, separately: a capture writes its tables before hipStreamBeginCapture)
+int cluster_launch_any(jg_dense_cluster* c) {
+  jg_engine* L = c->nodes[c->lead];
+  const uint32_t R = c->R;
+  hipStream_t st = L->stream;
+  JgClaimArgs ca{};
+  ca.R = R, ca.G = c->G, ca.owner = c->owner;
+  for (uint32_t r = 0; r < R; r++) ca.flags[r] = c->nodes[r]->dev.flags;
+  hipLaunchKernelGGL(k_cluster_claim, dim3(grid_for((c->G + 3) / 4, 2048)), dim3(JG_BLOCK), 0, st, ca);
+  const JgLeaderJob* lj = (const JgLeaderJob*)c->any_d_jobs;
+#define JG_LAUNCH_ANY(RR) hipLaunchKernelGGL((k_leader_node_tick_any<RR>), dim3(L->dense_grid, R), dim3(JG_BLOCK), 0, st, lj)
+  switch (R) {
+    case 1: JG_LAUNCH_ANY(1); break;
+    case 2: JG_LAUNCH_ANY(2); break;
+    case 3: JG_LAUNCH_ANY(3); break;
+    case 4: JG_LAUNCH_ANY(4); break;
+    case 5: JG_LAUNCH_ANY(5); break;
+    default: JG_LAUNCH_ANY(6); break;
+  }
+#undef JG_LAUNCH_ANY
+  // the slow kernels' jobs as kernel arguments: rebuilt from the tables the fast kernels read
+  JgLeaderSlowJobs sj{};
+  JgFollowerJobs fsj{};
+  const JgLeaderJob* hl = (const JgLeaderJob*)c->any_h_jobs;
+  const JgFollowerJob* hf = (const JgFollowerJob*)(c->any_h_jobs + jg_dense_cluster::ANY_SLICE);
+  for (uint32_t r = 0; r < R; r++) {
+    sj.j[r].d = c->nodes[r]->dev, sj.j[r].acks = hl[r].acks, sj.j[r].seq0 = hl[r].seq, sj.j[r].nd = hl[r].nd;
+    fsj.j[r] = hf[r];
+  }
+  hipLaunchKernelGGL(k_dense_slow_multi, dim3(JG_SHARDS, R), dim3(JG_BLOCK), 0, st, sj);
+  hipLaunchKernelGGL(k_follower_tick_dense_any, dim3(L->dense_grid, R), dim3(JG_BLOCK), 0, st,
+                     (const JgFollowerJob*)(c->any_d_jobs + jg_dense_cluster::ANY_SLICE));
+  hipLaunchKernelGGL(k_follower_slow_multi, dim3(JG_SHARDS, R), dim3(JG_BLOCK), 0, st, fsj);
+  HIPCHK(hipGetLastError());
+  return JG_OK;
+}
+
 // what a captured round depends on besides the mailboxes: recapture when any of it changes
 uint64_t cluster_signature(const jg_dense_cluster* c, uint64_t dt) {
   uint64_t h = 0x9e3779b97f4a7c15ull ^ dt;
@@ -2241,7 +2367,7 @@ int cluster_capture(jg_dense_cluster* c, uint64_t dt_ms) {
   int rc = JG_OK;
   // all nodes on the lead node's stream (the default while clustered): the R - 1 follower halves are one launch,
   // their slow kernels another; the jobs are written here, outside the capture
-  bool multi = c->R > 1;
+  bool multi = c->R > 1 && !c->any;
   for (jg_engine* e : c->nodes) multi = multi && e->stream == L->stream;
   static const bool no_multi = std::getenv("JG_CLUSTER_SEPARATE_HALVES") != nullptr;  // (A/B: one launch per follower half, as in round 2)
   if (no_multi) multi = false;
@@ -2255,9 +2381,10 @@ int cluster_capture(jg_dense_cluster* c, uint64_t dt_ms) {
       if (r != c->lead) jobs.push_back(cluster_job(c, r));
     HIPCHK(hipMemcpy(c->d_jobs, jobs.data(), jobs.size() * sizeof(JgFollowerJob), hipMemcpyHostToDevice));
   }
+  if (c->any && (rc = cluster_tables_any(c, 0, true))) return rc;  // (the tables, before the capture begins)
   hipError_t he = hipStreamBeginCapture(L->stream, hipStreamCaptureModeRelaxed);
   if (he == hipSuccess) {
-    rc = cluster_round_body(c, 0, false, multi);
+    rc = c->any ? cluster_launch_any(c) : cluster_round_body(c, 0, false, multi);
     for (uint32_t r = 0; r < c->R && !rc; r++)  // every forked stream joins the leader's again
       if (r != c->lead) rc = jg_stream_wait(L, c->nodes[r]);
     he = hipStreamEndCapture(L->stream, &c->graph);
@@ -2283,6 +2410,14 @@ int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms
   static const bool no_graph = std::getenv("JG_NO_GRAPH") != nullptr;
   bool same_device = true;
   for (jg_engine* e : c->nodes) same_device = same_device && e->device == L->device;
+  if (c->any && (no_graph || n_rounds < 2)) {  // per-partition leadership, eager (the nodes share a device and a stream)
+    HIPCHK(hipSetDevice(L->device));
+    for (jg_engine* e : c->nodes)
+      if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
+    for (uint32_t k = 0; k < n_rounds; k++, now_ms += dt_ms)
+      if ((rc = cluster_tables_any(c, now_ms, false)) || (rc = cluster_launch_any(c))) return rc;
+    return JG_OK;
+  }
   if (no_graph || !same_device || n_rounds < 2) {  // eager: one round at a time
     for (uint32_t k = 0; k < n_rounds; k++, now_ms += dt_ms)
       if ((rc = cluster_round_body(c, now_ms, true))) return rc;
@@ -2304,7 +2439,7 @@ int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms
   for (uint32_t r = 0; r < c->R; r++)  // the followers' earlier work first
     if (r != c->lead && (rc = jg_stream_wait(L, c->nodes[r]))) return rc;
   JgClock init{};  // the first replayed round's time and step numbers; the rounds advance it themselves (JgClock)
-  init.dt = dt_ms, init.n_nodes = c->R;
+  init.dt = dt_ms, init.n_nodes = c->R, init.seq_step = c->any ? 2 : 1;
   init.v[0].now = now_ms;
   for (uint32_t r = 0; r < c->R; r++) init.v[0].seq[r] = c->nodes[r]->seq + 1;
   hipLaunchKernelGGL(k_clock_set, dim3(1), dim3(1), 0, L->stream, c->clock, init);
@@ -2312,12 +2447,12 @@ int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms
     HIPCHK(hipGraphLaunch(c->exec, L->stream));
     for (uint32_t r = 0; r < c->R; r++) {  // what the eager calls would have recorded on the host
       jg_engine* e = c->nodes[r];
-      e->seq += 1;
+      e->seq += c->any ? 2 : 1;
       e->stepped = true;
-      e->n_dense += c->G;
-      e->n_launch += 2;
+      e->n_dense += c->any ? 2 * (uint64_t)c->G : c->G;
+      e->n_launch += c->any ? 4 : 2;
       e->slow_scheduled_ever = true;
-      if (r != c->lead) e->maybe_irregular = true, e->flag_check_pending = true, e->irr_gen++;
+      if (c->any || r != c->lead) e->maybe_irregular = true, e->flag_check_pending = true, e->irr_gen++;
     }
   }
   HIPCHK(hipGetLastError());
@@ -2493,7 +2628,10 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     }
   }
   std::vector<JgFollowerJob> fjobs;
-  if (multi && (rc = cluster_follower_jobs(c, now_ms, fjobs))) return rc;
+  if (c->any) {
+    if (!one_stream) return fail(JG_EINVAL, "per-partition leadership: the nodes share the cluster's stream");
+    if ((rc = cluster_tables_any(c, now_ms, false))) return rc;  // (its own copy, behind the sparse steps' tables)
+  } else if (multi && (rc = cluster_follower_jobs(c, now_ms, fjobs))) return rc;
   hipStream_t st = L->stream;
   uint32_t* d_cursor = rt.d_count + (size_t)R * ROUTE_WORDS;
   uint32_t* d_keep_n = d_cursor + JG_ROUTE_SEGS;
@@ -2518,7 +2656,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   };
   for (uint32_t s = 0; s < R; s++)
     for (const StepRec& r : c->nodes[s]->recs)
-      if (r.seq > seq_base[s] && r.seq - seq_base[s] > 3)
+      if (r.seq > seq_base[s] && r.seq - seq_base[s] > 7)
         return fail(JG_ECAPACITY, "routed round: more steps than the transport's ordering key numbers");
   const uint32_t* h_cursor = rt.h_count + (size_t)R * ROUTE_WORDS;
   // the bucket pass's counters (their size does not depend on the round's rows): cleared with the tallies, in one launch
@@ -2585,9 +2723,13 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   }
   if ((rc = apply_all(1, jobs_b, widest_b))) return rc;
   // -- 2. the dense round; ClientRequests only where the lead node (still) leads
-  hipLaunchKernelGGL(k_route_mask_appends, dim3((c->G + 255) / 256), dim3(256), 0, L->stream, c->G, (const uint32_t*)L->dev.flags,
-                     (const uint64_t*)c->offered, c->acks + (size_t)c->lead * c->G);
-  if ((rc = cluster_round_body(c, now_ms, true, false, multi ? slice_h(2) : nullptr, multi ? slice_d(2) : nullptr, multi ? &fjobs : nullptr))) return rc;
+  if (c->any) {  // (whoever owns a group reads `offered`: nothing to mask)
+    if ((rc = cluster_launch_any(c))) return rc;
+  } else {
+    hipLaunchKernelGGL(k_route_mask_appends, dim3((c->G + 255) / 256), dim3(256), 0, L->stream, c->G, (const uint32_t*)L->dev.flags,
+                       (const uint64_t*)c->offered, c->acks + (size_t)c->lead * c->G);
+    if ((rc = cluster_round_body(c, now_ms, true, false, multi ? slice_h(2) : nullptr, multi ? slice_d(2) : nullptr, multi ? &fjobs : nullptr))) return rc;
+  }
   T1 = clk();
   // -- 3. the transport, on the lead node's stream behind everybody's round
   for (uint32_t r = 0; r < R; r++)
@@ -2671,7 +2813,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   // node's next round: bucket by (destination, group tile), sort every bucket in LDS (jg_route.h); the
   // library sort stays behind JG_ROUTE_LIBRARY_SORT=1 for an A/B
   if (total && !library_sort) {
-    bk.shift = ord_bits + 5 + tile_bits;  // (its counters were cleared with the tallies, before the delivering pass)
+    bk.shift = ord_bits + 3 + JG_ROUTE_STEP_BITS + tile_bits;  // (its counters were cleared with the tallies, before the delivering pass)
     const uint32_t grid = std::min<uint32_t>((fullest_seg + JG_BLOCK - 1) / JG_BLOCK, 4096 / n_seg);
     const uint32_t seg_cap = rt.cap / n_seg;
     hipLaunchKernelGGL(k_route_hist, dim3(grid, n_seg), dim3(JG_BLOCK), 0, st, (const uint32_t*)d_cursor, seg_cap, (const uint64_t*)rt.key, bk);
@@ -2682,7 +2824,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     hipLaunchKernelGGL(k_route_sort_build, dim3(bk.n_buckets), dim3(JG_BLOCK), 0, st, bk, rt.key_alt, rt.idx_alt, (const jg_msg_row*)rt.row,
                        rt.cols);
   } else if (total) {
-    const uint32_t end_bit = ord_bits + 5 + rt.group_bits + 3;
+    const uint32_t end_bit = ord_bits + 3 + JG_ROUTE_STEP_BITS + rt.group_bits + 3;
     size_t need = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, need, rt.key, rt.key_alt, rt.idx, rt.idx_alt, (size_t)total, 0, end_bit, st));
     if (rt.sort_tmp_bytes < need) {

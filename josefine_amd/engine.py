@@ -665,12 +665,14 @@ class DenseCluster:
     ticks").  `nodes[r]` hosts replica slot r of every group; nodes[lead] is made leader by the
     caller (traces.elect_all)."""
 
-    def __init__(self, nodes, lead: int = 0):
+    def __init__(self, nodes, lead=0):
+        """lead = None: per-partition leadership (JG_CLUSTER_ANY_LEADER) - every node leads the partitions it was
+        elected for and follows the others."""
         self.nodes, self.lead, self.R = list(nodes), lead, len(nodes)
         self.api = nodes[0].api
         arr = (C.c_void_p * self.R)(*[n._h for n in nodes])
         self._h = C.c_void_p()
-        nodes[0]._check(self.api.dense_cluster_create(arr, self.R, lead, C.byref(self._h)))
+        nodes[0]._check(self.api.dense_cluster_create(arr, self.R, capi.CLUSTER_ANY_LEADER if lead is None else lead, C.byref(self._h)))
 
     def close(self) -> None:
         if self._h:

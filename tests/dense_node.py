@@ -149,10 +149,7 @@ class RoutedCluster(DenseCluster):
                 self.delivered[n] += len(cols["kind"])
                 self.nodes[n].submit_columns(**cols)
                 self.nodes[n].step(now)
-        # client requests are offered only where the lead node leads: at a leaderless replica the
-        # reference queues them (follower.rs:258-270), which the dense append column cannot express
-        leads = self.nodes[self.lead].read("role") == capi.ROLE_LEADER
-        outs = super().round(np.where(leads, np.asarray(appends, dtype=np.uint64), np.uint64(0)), dt_ms)
+        outs = self.dense_round(appends, dt_ms)
         drained = self.rows.pop()
         for s in range(self.R):
             rows = drained[s]
@@ -166,6 +163,121 @@ class RoutedCluster(DenseCluster):
                 if to_n.any():
                     self.inbound[n].append((s, rows[to_n]))
         return outs
+
+
+    def dense_round(self, appends, dt_ms):
+        # client requests are offered only where the lead node leads: at a leaderless replica the
+        # reference queues them (follower.rs:258-270), which the dense append column cannot express
+        leads = self.nodes[self.lead].read("role") == capi.ROLE_LEADER
+        return DenseCluster.round(self, np.where(leads, np.asarray(appends, dtype=np.uint64), np.uint64(0)), dt_ms)
+
+
+OWNER_NONE = 255
+
+
+class AnyLeaderCluster(RoutedCluster):
+    """PER-PARTITION LEADERSHIP (jg_dense_cluster_create with JG_CLUSTER_ANY_LEADER): every node leads the groups it was
+    elected for and follows the others; the mailbox columns are the cluster's, indexed by group and slot.  The numpy
+    statement of one round, over the per-node dense entry points of any backend:
+      0. owner[g] = the lowest slot whose node is a healthy leader of g;
+      1. every node's leader half: inbox and ClientRequests only where it owns the group; the owner's Tick goes into the
+         cluster's columns, a leader's that is not the owner (two terms' leaders in one round) travels as ROWS;
+      2. every node's follower half: mail (sender = the owner) only where somebody else owns the group.
+    Rows are transported exactly as RoutedCluster does."""
+
+    def __init__(self, factory, G, R, seed=3, group_base=0):
+        self.G, self.R, self.lead = G, R, 0
+        self.nodes = [factory(G, R, seed=seed + r, self_slots=np.full(G, r, np.uint8), group_base=group_base,
+                              flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
+        self.now = 0
+        self.acks = np.full((R, G), NO, dtype=np.uint64)
+        self.hbr_has = np.full((R, G), capi.HB_NONE, dtype=np.uint8)
+        self.hbr_commit = np.zeros((R, G), dtype=np.uint64)
+        self.o_term = np.zeros(G, np.uint64)
+        self.o_hbc = np.full(G, NO, np.uint64)
+        self.o_from = np.zeros((R, G), np.uint64)
+        self.o_n = np.full((R, G), capi.AE_NONE, np.uint8)
+        self.rows = []
+        self.member_ids = np.array([self.nodes[r].node_ids[r] for r in range(R)], dtype=np.uint32)
+        self.inbound = [[] for _ in range(R)]
+        self.kept = [np.zeros(0, dtype=capi.MSG_DTYPE) for _ in range(R)]
+        self.delivered = np.zeros(R, dtype=np.int64)
+        self.owner = np.full(G, OWNER_NONE, np.uint8)
+
+    def tick_rows(self, n, out, groups):
+        """The Tick of node n for `groups`, as the message rows its column words stand for (leader.rs:234-245)."""
+        rows = []
+        for g in groups:
+            if int(out["hb_commit"][g]) != NO:
+                rows.append((g, capi.CMD_HEARTBEAT, capi.TO_PEERS, 0, 0, 0, self.member_ids[n], int(out["term"][g]), int(out["hb_commit"][g]), 0))
+            for r in range(self.R):
+                if int(out["ae_n"][r][g]) != capi.AE_NONE:
+                    rows.append((g, capi.CMD_APPEND_ENTRIES, capi.TO_PEER, 0, 0, self.member_ids[r], self.member_ids[n], int(out["term"][g]),
+                                 int(out["ae_from"][r][g]), int(out["ae_n"][r][g])))
+        return np.array(rows, dtype=capi.MSG_DTYPE) if rows else np.zeros(0, dtype=capi.MSG_DTYPE)
+
+    def dense_round(self, appends, dt_ms):
+        self.now += dt_ms
+        G, R = self.G, self.R
+        appends = np.broadcast_to(np.asarray(appends, dtype=np.uint64), (G,))
+        leads = np.stack([(n.read("role") == capi.ROLE_LEADER) & (n.read("fault") == 0) for n in self.nodes])
+        owner = np.full(G, OWNER_NONE, np.uint8)
+        for r in reversed(range(R)):
+            owner[leads[r]] = r
+        self.owner = owner
+        drained = [None] * R
+        outs = {}
+        for n in range(R):  # 1. the leader halves
+            mine = owner == n
+            acks = np.where(mine[None, :], self.acks, np.uint64(NO))
+            acks[n] = np.where(mine, appends, np.uint64(0))
+            has = np.where(mine[None, :], self.hbr_has, np.uint8(capi.HB_NONE)).astype(np.uint8)
+            out = self.nodes[n].step_dense_leader(self.now, acks, has, self.hbr_commit, tick=True)
+            outs[n] = out
+            self.o_term[mine], self.o_hbc[mine] = out["term"][mine], out["hb_commit"][mine]
+            self.o_from[:, mine], self.o_n[:, mine] = out["ae_from"][:, mine], out["ae_n"][:, mine]
+            lose = np.nonzero(leads[n] & ~mine)[0]
+            rows = np.concatenate([self.nodes[n].drain_messages(), self.tick_rows(n, out, lose)])
+            drained[n] = rows[np.argsort(rows["group"], kind="stable")]
+        for n in range(R):  # 2. the follower halves
+            mail = (owner != OWNER_NONE) & (owner != n)
+            sender = self.member_ids[np.where(mail, owner, 0)].astype(np.uint32)
+            fo = self.nodes[n].step_dense_follower(self.now, np.where(mail, self.o_term, np.uint64(0)), np.where(mail, self.o_hbc, np.uint64(NO)),
+                                                   np.where(mail, self.o_from[n], np.uint64(0)),
+                                                   np.where(mail, self.o_n[n], np.uint8(capi.AE_NONE)).astype(np.uint8), leader=sender, tick=True)
+            keep = owner != n  # (the own slot's word of a group this node owns is nobody's: whoever owns a group reads `appends`)
+            self.acks[n] = np.where(keep, fo["ack_head"], self.acks[n])
+            self.hbr_has[n] = np.where(keep, fo["hb_has"], self.hbr_has[n])
+            self.hbr_commit[n] = np.where(keep, fo["hb_commit"], self.hbr_commit[n])
+            drained[n] = np.concatenate([drained[n], self.nodes[n].drain_messages()])
+        self.rows.append(drained)
+        return outs
+
+
+def any_failure_rows(seed, tick, G, R, percent, leader_of, group_base=0, whole_group=True, skip=None):
+    """configs[4] with per-partition leadership: every group fails with probability percent/100 per tick (the hash of
+    failure_rows); in a failing group the leader's replica (leader_of[g]) crashes and restarts, the next replica - restarted
+    too: voted_for == None, §7.3 Q4 - receives Timeout and campaigns; whole_group: every other replica restarts as well (a
+    rack going down: otherwise they remember their vote and refuse, and the group stays leaderless).  `skip`: groups
+    left alone.  One group-sorted column dict (or None) per node."""
+    from josefine_amd.traces import synth_hash
+    gg = np.arange(G, dtype=np.uint64) + np.uint64(group_base)
+    failing = synth_hash(seed, tick, gg, 7) % np.uint64(100) < np.uint64(percent)
+    if skip is not None:
+        failing &= ~skip
+    failing = np.nonzero(failing)[0].astype(np.uint32)
+    out = [None] * R
+    for n in range(R):
+        kinds, groups = [], []
+        for g in failing:
+            lead = int(leader_of[g])
+            if n == lead or whole_group or n == (lead + 1) % R:
+                kinds.append(capi.CMD_RESTART), groups.append(g)
+            if n == (lead + 1) % R:
+                kinds.append(capi.CMD_TIMEOUT), groups.append(g)
+        if kinds:
+            out[n] = dict(kind=np.array(kinds, np.uint8), group=np.array(groups, np.uint32))
+    return out, failing
 
 
 from josefine_amd.traces import cluster_failure_rows  # noqa: E402,F401  (shared with bench.py)
