@@ -206,6 +206,8 @@ def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
     from josefine_amd import BatchedRaft, capi
     from josefine_amd.traces import elect_all
 
+    if args.any_leader:
+        return cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev)
     if args.failures:
         return cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev)
     G, R, K, W = args.groups, args.replicas, args.steps, args.warmup
@@ -313,6 +315,211 @@ def cluster_main(args, torch, dist, rank, world, dev_index, red_dev):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
+    """--cluster --any-leader: PER-PARTITION LEADERSHIP inside the device-resident cluster (jg_dense_cluster_create with
+    JG_CLUSTER_ANY_LEADER).  Leaders are ELECTED, through the library's transport: every partition's designated
+    candidate (--leadership blocked: node g*R/G, interleaved: node g % R) receives Timeout, campaigns, its VoteRequests
+    reach the peers as routed rows, they answer through can_vote, the first majority makes it leader
+    (candidate.rs:101-113) - then every node leads G/R partitions and follows the rest, and the timed region is the closed
+    loop over the cluster's mailbox columns with every winner replicating in column form (leader.rs:124-174).
+    With --failures p: per round p % of the partitions lose their leader - at R = 3 the whole group restarts (a rack),
+    the next replica campaigns and WINS through the transport, leadership moves and stays in the columns; the client
+    withdraws its proposals from a partition whose leader it lost (what the reference makes of a re-elected leader is
+    Q8: its first append panics, chain.rs:163)."""
+    import numpy as np
+    from josefine_amd import BatchedRaft, DenseCluster, capi
+    from josefine_amd.traces import any_failure_rows
+
+    G, R, K, W = args.groups, args.replicas, args.steps, args.warmup
+    nodes = [BatchedRaft(G, R, seed=args.seed + r, device_id=dev_index, group_base=rank * G,
+                         self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
+    L = nodes[0]
+    api = L.api
+    lib = DenseCluster(nodes, lead=None)
+    lib.set_appends(0)
+    g = np.arange(G, dtype=np.int64)
+    leader_of = (g * R // G) if args.leadership == "blocked" else g % R
+
+    def sync_all():
+        for e in nodes:
+            e._check(api.sync(e._h))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        sync_all()
+
+    now = [0]
+
+    def routed(inject=None):
+        now[0] += 100
+        return lib.round_routed(now[0], inject)
+
+    # -- the elections, through the transport (R <= 3; a five-node election cannot be won over a transport that delivers
+    # every sender's answers back to back: the candidate sends nodes.len() copies of its VoteRequest, the voter grants
+    # the first and refuses the rest, and Election::vote lets the later answer overwrite the earlier - candidate.rs:30-37,
+    # election.rs:34; DESIGN.md "The cluster transport" - so R > 3 gets synthetic votes, and says so)
+    through_transport = R <= 3
+    votes_routed = 0
+    sync_all()
+    t0 = time.perf_counter()
+    if through_transport:
+        inj = []
+        for n in range(R):
+            mine = np.nonzero(leader_of == n)[0].astype(np.uint32)
+            inj.append(nodes[n].upload_rows(kind=np.full(len(mine), capi.CMD_TIMEOUT, np.uint8), group=mine) if len(mine) else None)
+        sync_all()
+        t0 = time.perf_counter()
+        votes_routed = sum(routed(inj)["delivered"])
+        for _ in range(3):  # VoteRequest -> VoteResponse -> elect()
+            votes_routed += sum(routed()["delivered"])
+        sync_all()
+        for rows in inj:
+            if rows is not None:
+                rows.free()
+    else:
+        from josefine_amd.traces import elect_where
+        for n, e in enumerate(nodes):
+            elect_where(e, leader_of == n)
+            e.drain_messages(), e.drain_applies()
+    election_ms = (time.perf_counter() - t0) * 1e3
+    for n, e in enumerate(nodes):
+        role = e.read("role")
+        assert (role[leader_of == n] == capi.ROLE_LEADER).all() and (role[leader_of != n] != capi.ROLE_LEADER).all(), \
+            f"node {n}: the elections did not make it leader of its partitions"
+    lib.set_appends(1)
+    appended_from = now[0]
+
+    failed = np.zeros(G, bool)
+    trace, withdraw = [], []
+    if args.failures:
+        whole = R == 3
+        for t in range(W + K):
+            cols, failing = any_failure_rows(args.seed, t, G, R, args.failures, leader_of, group_base=rank * G, whole_group=whole, skip=failed)
+            failed[failing] = True
+            trace.append([None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(cols)])
+            wl = None
+            if len(failing):
+                p = C.c_void_p()
+                L._check(api.device_alloc(L._h, max(failing.nbytes, 16), C.byref(p)))
+                L._check(api.device_upload(L._h, p, failing.ctypes.data, failing.nbytes))
+                wl = (p, len(failing))
+            withdraw.append(wl)
+    sync_all()
+
+    delivered = [0, 0]
+    kept = [0]
+
+    def rounds(t0_, t1_, which):
+        if not args.failures:
+            lib.rounds(now[0] + 100, 100, t1_ - t0_)
+            now[0] += 100 * (t1_ - t0_)
+            return
+        for t in range(t0_, t1_):
+            if withdraw[t] is not None:
+                lib.withdraw_appends(withdraw[t][0].value, withdraw[t][1])
+            st = routed(trace[t])
+            delivered[which] += sum(st["delivered"])
+            kept[0] += st["kept"]
+
+    rounds(0, W, 0)
+    barrier()
+    c0 = sum(e.counters()["decisions"] for e in nodes)
+    failed_at_start = float(failed_before(args, np, G, R, leader_of, rank, W).mean()) if args.failures else 0.0
+    barrier()
+    t0 = time.perf_counter()
+    L._check(api.timer_start(L._h))
+    rounds(W, W + K, 1)
+    ev_ms = C.c_float(0)
+    L._check(api.timer_stop(L._h, C.byref(ev_ms)))
+    sync_all()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    barrier()
+    decisions = float(sum(e.counters()["decisions"] for e in nodes) - c0)
+
+    # full-size properties (window parity against the numpy statement over oracle engines: tests/test_gpu_fullsize.py)
+    T = (now[0] - appended_from) // 100
+    healthy = ~failed
+    led = np.zeros(G, bool)
+    won = 0
+    for n, e in enumerate(nodes):
+        role, head, commit, fault = e.read("role"), e.read("head"), e.read("commit"), e.read("fault")
+        mine = healthy & (leader_of == n)
+        assert (role[mine] == capi.ROLE_LEADER).all() and (head[mine] == T).all() and (commit[mine] >= T - 3).all(), f"node {n}: its partitions"
+        other = healthy & (leader_of != n)
+        assert (role[other] == capi.ROLE_FOLLOWER).all() and (head[other] >= T - 1).all() and (commit[other] >= T - 5).all(), f"node {n}: as a follower"
+        assert not fault[healthy].any()
+        lead_now = (role == capi.ROLE_LEADER) & (fault == 0)
+        led |= lead_now
+        won += int((lead_now & failed & ((leader_of + 1) % R == n)).sum())
+    rows_left = sum(len(e.drain_messages()) for e in nodes)
+    if not args.failures:
+        assert rows_left == 0, "rows left the mailbox vocabulary"
+
+    if world > 1:
+        tw = torch.tensor([wall, ev_ms.value], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        td = torch.tensor([decisions, float(delivered[1])], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(td, op=dist.ReduceOp.SUM)
+        wall, decisions, delivered[1] = tw[0].item(), td[0].item(), td[1].item()
+    if rank == 0:
+        lb, fb = node_alg_bytes(R)
+        alg = (lb + (R - 1) * fb) * G
+        round_s = (ev_ms.value / 1e3 if not args.failures else wall) / K
+        out = {
+            "metric": "Raft quorum decisions/sec over N partitions; achieved HBM GB/s vs roofline",
+            "value": decisions / wall, "unit": "decisions/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall * 1e3 / K, "ms_per_step_events": ev_ms.value / K, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": (f"per-partition leadership: {R} nodes x {G} partitions on one GPU, leaders elected " + ("THROUGH the device transport" if R <= 3 else "(synthetic votes)") + " "
+                                    f"({args.leadership}: every node leads G/R partitions and follows the rest), closed loop over the "
+                                    "cluster's mailbox columns, 1 client request per led partition per round"
+                                    + (f"; {args.failures} %/round of the partitions lose their leader"
+                                       + (" (the whole group restarts), the next replica campaigns and wins through the transport, leadership "
+                                          "moves and stays in column form; the client withdraws its proposals from such a partition (Q8)"
+                                          if R == 3 else " (crash + restart; the other replicas remember their vote: Q4, the partition stays leaderless)")
+                                       if args.failures else "")),
+                       "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world, "leadership": args.leadership,
+                       "q9": "off (JG_CFG_SEPARATE_COMMIT_KEY: bit-exact vs the oracle with the same switch; the reference would "
+                             "panic at the first replicate() to a caught-up follower, leader.rs:152-157)",
+                       "parallelism": f"{world} independent shard(s), no collective", **devices_config(args, world)},
+            "group_rounds_per_s": G * world * K / wall,
+            "elections": {"partitions": G, "won_through_the_transport": through_transport, "rounds": 4 if through_transport else None, "wall_ms": election_ms,
+                          "rows_routed": votes_routed, "leaders_per_node": [int((leader_of == n).sum()) for n in range(R)]},
+            "roofline": {"bound": "hbm", "achieved": alg / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": f"one round: k_cluster_claim + k_leader_node_tick_any<{R}> (all nodes) + k_follower_tick_dense_any (all nodes) "
+                                   "+ the two slow kernels" + (" + the sparse steps over the routed rows + the transport" if args.failures else ""),
+                         "alg_bytes_per_launch": alg, "avg_launch_us": round_s * 1e6,
+                         "alg_bytes_per_group": {"leader_half": lb, "follower_half": fb},
+                         "frac_of_measured_copy": alg / round_s / 1e9 / 6290.0,
+                         "note": "priced with what ONE leader step and R - 1 follower steps per partition must move (the single-lead "
+                                 "closed loop's bytes): every node runs both halves here, each over the partitions its role selects"},
+        }
+        if args.failures:
+            out["leaderless_fraction"] = {"at_start_of_timed_region": None, "at_end": float((~led).mean())}
+            out["failed_fraction"] = {"at_start_of_timed_region": failed_at_start, "at_end": float(failed.mean())}
+            out["elections_won_after_failures"] = won
+            out["rows_routed_per_round"] = delivered[1] / K / world
+            out["rows_left_for_the_host"] = rows_left
+        print(json.dumps(out), flush=True)
+    lib.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def failed_before(args, np, G, R, leader_of, rank, upto):
+    from josefine_amd.traces import any_failure_rows
+    failed = np.zeros(G, bool)
+    for t in range(upto):
+        _, failing = any_failure_rows(args.seed, t, G, R, args.failures, leader_of, group_base=rank * G, skip=failed)
+        failed[failing] = True
+    return failed
 
 
 def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
@@ -663,6 +870,12 @@ def main():
     ap.add_argument("--cluster", action="store_true",
                     help="closed loop: all R replicas of every partition on this GPU as R engines exchanging dense "
                          "mailbox columns (jg_step_dense_leader / jg_step_dense_follower); secondary measurement")
+    ap.add_argument("--any-leader", action="store_true",
+                    help="with --cluster: per-partition leadership (JG_CLUSTER_ANY_LEADER) - leaders elected through the device transport on "
+                         "every node, every node runs both halves over the cluster's mailbox columns")
+    ap.add_argument("--leadership", choices=["blocked", "interleaved"], default="blocked",
+                    help="with --any-leader: node g*R/G (contiguous blocks: what an adapter that numbers its partitions by preferred "
+                         "leader gets) or node g %% R leads partition g")
     ap.add_argument("--single-process", action="store_true",
                     help="one process, one engine handle over --gpus shards (jg_config.n_devices) instead of one "
                          "process per GPU; run it directly, not under torch.distributed.run")

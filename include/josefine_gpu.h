@@ -554,6 +554,11 @@ void jg_dense_cluster_destroy(jg_dense_cluster* c);
  * or (per_group != NULL) one value per group from host memory.  (JG_CLUSTER_ANY_LEADER: offered to whoever owns the
  * group that round; a group nobody leads is offered nothing.) */
 int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const uint64_t* per_group);
+/* No more ClientRequests for the n groups listed in DEVICE memory (ascending or not; duplicates allowed): their
+ * offered count becomes 0 from the next round on - a client that has lost its partition's leader stops proposing
+ * (what the reference makes of a re-elected leader is Q8: its first append panics, chain.rs:163).  Asynchronous on the
+ * cluster's stream; the list must stay valid until then (jg_sync). */
+int jg_dense_cluster_withdraw_appends(jg_dense_cluster* c, const uint32_t* groups_dev, uint32_t n);
 /* n_rounds protocol rounds at logical times now_ms, now_ms + dt_ms, ...; asynchronous (jg_sync the nodes). */
 int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms, uint32_t n_rounds);
 /* The mailbox columns, for inspection: the leader's inbox / outbox as the structs above. */

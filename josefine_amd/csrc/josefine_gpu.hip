@@ -2148,6 +2148,17 @@ int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const ui
   return jg_device_upload(c->nodes[c->lead], c->acks + (size_t)c->lead * c->G, src, (size_t)c->G * 8);
 }
 
+int jg_dense_cluster_withdraw_appends(jg_dense_cluster* c, const uint32_t* groups_dev, uint32_t n) {
+  if (!c || (n && !groups_dev)) return fail(JG_EINVAL, "null argument");
+  if (!n) return JG_OK;
+  jg_engine* L = c->nodes[c->lead];
+  HIPCHK(hipSetDevice(L->device));
+  hipLaunchKernelGGL(k_withdraw_appends, dim3((n + 255) / 256), dim3(256), 0, L->stream, n, groups_dev, c->G, c->offered,
+                     c->any ? (uint64_t*)nullptr : c->acks + (size_t)c->lead * c->G);
+  HIPCHK(hipGetLastError());
+  return JG_OK;
+}
+
 int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_leader_outbox* out) {
   if (!c) return fail(JG_EINVAL, "null argument");
   if (in) *in = jg_leader_inbox{c->acks, c->hbr_commit};

@@ -689,6 +689,10 @@ class DenseCluster:
         p = None if per_group is None else np.ascontiguousarray(per_group, dtype=np.uint64).ctypes.data
         self.nodes[0]._check(self.api.dense_cluster_set_appends(self._h, int(uniform), p))
 
+    def withdraw_appends(self, groups_dev_ptr: int, n: int) -> None:
+        """jg_dense_cluster_withdraw_appends: no more ClientRequests for the n groups listed in device memory."""
+        self.nodes[0]._check(self.api.dense_cluster_withdraw_appends(self._h, C.c_void_p(groups_dev_ptr), int(n)))
+
     def rounds(self, now_ms: int, dt_ms: int, n: int) -> None:
         self.nodes[0]._check(self.api.dense_cluster_rounds(self._h, int(now_ms), int(dt_ms), int(n)))
 

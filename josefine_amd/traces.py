@@ -82,6 +82,22 @@ def elect_all(e, now_ms: int = 0) -> None:
         e.step(now_ms)
 
 
+def elect_where(e, mask, now_ms: int = 0) -> None:
+    """elect_all for the groups in `mask` only: Timeout + granted VoteResponses from the next R/2 slots."""
+    g = np.nonzero(mask)[0].astype(np.uint32)
+    n = len(g)
+    if not n:
+        return
+    e.submit_columns(np.full(n, capi.CMD_TIMEOUT, np.uint8), g)
+    e.step(now_ms)
+    slots = e.read("self_slot")[g].astype(np.int64)
+    ids = np.array(e.node_ids, dtype=np.uint32)
+    for k in range(1, e.R // 2 + 1):
+        e.submit_columns(np.full(n, capi.CMD_VOTE_RESPONSE, np.uint8), g, from_=ids[(slots + k) % e.R],
+                         term=np.ones(n, np.uint64), flag=np.ones(n, np.uint8))
+        e.step(now_ms)
+
+
 def failure_rows(seed, tick, group_base, G, R, node_ids, self_slots, percent=1):
     """BASELINE.json configs[4]: the command rows of one tick's leader failures.
 
@@ -129,3 +145,30 @@ def cluster_failure_rows(seed, tick, G, R, percent=1, lead=0, candidate=1, also=
         out[candidate] = dict(kind=np.stack([restart, np.full(n, capi.CMD_TIMEOUT, np.uint8)], axis=1).reshape(-1),
                               group=np.repeat(failing, 2))
     return out
+
+
+def any_failure_rows(seed, tick, G, R, percent, leader_of, group_base=0, whole_group=True, skip=None):
+    """configs[4] with PER-PARTITION LEADERSHIP (jg_dense_cluster_create, JG_CLUSTER_ANY_LEADER): every group fails with
+    probability percent/100 per tick (the hash of failure_rows); in a failing group the leader's replica
+    (leader_of[g]) crashes and restarts, the next replica - restarted too: voted_for == None, SURVEY.md 7.3 Q4 - receives
+    Timeout and campaigns; whole_group: every other replica restarts as well (a rack going down: otherwise they
+    remember their vote and refuse, and the group stays leaderless).  `skip`: groups left alone.
+    Returns (one group-sorted column dict or None per node, the failing groups)."""
+    gg = np.arange(G, dtype=np.uint64) + np.uint64(group_base)
+    failing = synth_hash(seed, tick, gg, 7) % np.uint64(100) < np.uint64(percent)
+    if skip is not None:
+        failing &= ~np.asarray(skip, bool)
+    failing = np.nonzero(failing)[0].astype(np.uint32)
+    lead = np.asarray(leader_of)[failing].astype(np.int64)
+    out = [None] * R
+    for n in range(R):
+        cand = (lead + 1) % R == n
+        restart = (lead == n) | cand | bool(whole_group)
+        # per failing group, in group order: Restart (if this node restarts), then Timeout (if it is the candidate)
+        m = len(failing)
+        kind = np.stack([np.full(m, capi.CMD_RESTART, np.uint8), np.full(m, capi.CMD_TIMEOUT, np.uint8)], axis=1).reshape(-1)
+        keep = np.stack([restart, cand], axis=1).reshape(-1)
+        group = np.repeat(failing, 2)
+        if keep.any():
+            out[n] = dict(kind=kind[keep], group=group[keep])
+    return out, failing

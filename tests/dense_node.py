@@ -254,30 +254,4 @@ class AnyLeaderCluster(RoutedCluster):
         return outs
 
 
-def any_failure_rows(seed, tick, G, R, percent, leader_of, group_base=0, whole_group=True, skip=None):
-    """configs[4] with per-partition leadership: every group fails with probability percent/100 per tick (the hash of
-    failure_rows); in a failing group the leader's replica (leader_of[g]) crashes and restarts, the next replica - restarted
-    too: voted_for == None, §7.3 Q4 - receives Timeout and campaigns; whole_group: every other replica restarts as well (a
-    rack going down: otherwise they remember their vote and refuse, and the group stays leaderless).  `skip`: groups
-    left alone.  One group-sorted column dict (or None) per node."""
-    from josefine_amd.traces import synth_hash
-    gg = np.arange(G, dtype=np.uint64) + np.uint64(group_base)
-    failing = synth_hash(seed, tick, gg, 7) % np.uint64(100) < np.uint64(percent)
-    if skip is not None:
-        failing &= ~skip
-    failing = np.nonzero(failing)[0].astype(np.uint32)
-    out = [None] * R
-    for n in range(R):
-        kinds, groups = [], []
-        for g in failing:
-            lead = int(leader_of[g])
-            if n == lead or whole_group or n == (lead + 1) % R:
-                kinds.append(capi.CMD_RESTART), groups.append(g)
-            if n == (lead + 1) % R:
-                kinds.append(capi.CMD_TIMEOUT), groups.append(g)
-        if kinds:
-            out[n] = dict(kind=np.array(kinds, np.uint8), group=np.array(groups, np.uint32))
-    return out, failing
-
-
-from josefine_amd.traces import cluster_failure_rows  # noqa: E402,F401  (shared with bench.py)
+from josefine_amd.traces import any_failure_rows, cluster_failure_rows  # noqa: E402,F401  (shared with bench.py)

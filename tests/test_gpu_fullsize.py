@@ -168,3 +168,77 @@ def test_full_size_routed_cluster_failures():
                          "vote_granted", "repl_state", "fault"):
                 assert np.array_equal(nodes[r].read(name, 0, base, W), oc.nodes[r].read(name)), (base, r, name)
     lib.close()
+
+
+def test_full_size_any_leader_cluster_elections_and_failures():
+    """Per-partition leadership at full size (jg_dense_cluster_create, JG_CLUSTER_ANY_LEADER): 3 nodes x 1 M partitions;
+    every partition's leader is ELECTED through the device transport (Timeout at the designated candidate, VoteRequests
+    routed, answered through can_vote, the first majority elects: candidate.rs:101-113), then every node leads a third
+    of the partitions and follows the rest over the cluster's mailbox columns; from round 8 on 1 % of the partitions per
+    round lose their whole group (restart), the next replica campaigns and wins through the transport, leadership moves.
+    Windows of the partitions are re-run by the numpy statement of the round over oracle engines
+    (tests/dense_node.py::AnyLeaderCluster) and must agree on every state column of every node; the whole population is
+    checked through what the trace implies."""
+    from josefine_amd import DenseCluster as LibCluster
+    from josefine_amd.traces import any_failure_rows
+    from dense_node import AnyLeaderCluster
+
+    G, R, T, W, P, F0 = 1_000_000, 3, 26, 1024, 1, 8
+    nodes = [BatchedRaft(G, R, seed=9 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY)
+             for r in range(R)]
+    lib = LibCluster(nodes, lead=None)
+    leader_of = np.arange(G) % R  # (interleaved: every wave serves both roles)
+
+    def trace(t, n, base, failed):
+        """round t's injected rows for the partitions [base, base + n) and what it offers: (columns per node, appends)"""
+        if t == 0:  # the campaigns
+            cols = []
+            for r in range(R):
+                mine = np.nonzero(leader_of[base:base + n] == r)[0].astype(np.uint32)
+                cols.append(dict(kind=np.full(len(mine), capi.CMD_TIMEOUT, np.uint8), group=mine) if len(mine) else None)
+            return cols, 0
+        if t < F0:
+            return [None] * R, int(t >= 4)
+        cols, failing = any_failure_rows(SEED, t, n, R, P, leader_of[base:base + n], group_base=base, whole_group=True, skip=failed)
+        failed[failing] = True
+        return cols, 1
+
+    failed = np.zeros(G, bool)
+    offered = np.zeros(G, np.uint64)
+    delivered = 0
+    for t in range(T):
+        cols, app = trace(t, G, 0, failed)
+        offered = np.where(failed, np.uint64(0), np.uint64(app))  # the client withdraws from a partition that lost its leader
+        lib.set_appends(per_group=offered)
+        up = [None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(cols)]
+        st = lib.round_routed((t + 1) * 100, up)
+        delivered += sum(st["delivered"])
+        for rows in up:
+            if rows is not None:
+                rows.free()
+    assert delivered >= 4 * G  # every election's VoteRequests and VoteResponses went through the transport
+    assert 0.1 * G < failed.sum() < 0.25 * G
+    healthy = ~failed
+    rounds_with_appends = T - 4
+    led = np.zeros(G, bool)
+    for n, e in enumerate(nodes):
+        role, head, commit, fault = e.read("role"), e.read("head"), e.read("commit"), e.read("fault")
+        mine = healthy & (leader_of == n)
+        assert (role[mine] == capi.ROLE_LEADER).all() and (head[mine] == rounds_with_appends).all() and (commit[mine] >= rounds_with_appends - 3).all()
+        assert (role[healthy & (leader_of != n)] == capi.ROLE_FOLLOWER).all() and not fault[healthy].any()
+        led |= (role == capi.ROLE_LEADER) & (fault == 0)
+    assert led[healthy].all() and led[failed].mean() > 0.7  # the campaigns after the failures were won: leadership moved
+    for base in (0, 333_333, G - W):
+        oc = AnyLeaderCluster(oracle_engine, W, R, seed=9, group_base=base)
+        f = np.zeros(W, bool)
+        for t in range(T):
+            cols, app = trace(t, W, base, f)
+            oc.round(np.where(f, np.uint64(0), np.uint64(app)), inject=cols)
+        assert np.array_equal(f, failed[base:base + W])
+        for r in range(R):
+            for name in ("commit", "head", "term", "voted_for", "role", "leader_id", "election_timeout", "vote_seen",
+                         "vote_granted", "repl_state", "fault"):
+                assert np.array_equal(nodes[r].read(name, 0, base, W), oc.nodes[r].read(name)), (base, r, name)
+            for q in range(R):
+                assert np.array_equal(nodes[r].read("match", q, base, W), oc.nodes[r].read("match", q)), (base, r, q)
+    lib.close()
