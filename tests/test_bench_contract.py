@@ -49,11 +49,55 @@ def test_two_ranks_aggregate():
         port = s.getsockname()[1]
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                 "--master-addr", "127.0.0.1", "--master-port", str(port)]
-    d = run(["--gpus", "2", "--groups", "50000", "--steps", "30", "--warmup", "5"], env={"JG_BENCH_BACKEND": "gloo"},
+    d = run(["--gpus", "2", "--groups", "50000", "--steps", "30", "--warmup", "5", "--cpu-budget", "1"], env={"JG_BENCH_BACKEND": "gloo"},
             launcher=launcher)
     assert d["n_gpus"] == 2 and d["config"]["partitions_total"] == 100000
     assert abs(d["value"] / d["group_steps_per_s"] - 5.0) < 1e-6
-    assert d["cpu_baseline"] is None  # rank 0 at N = 1 only
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0  # rank 0 measures it for every N
+    pr = d["per_rank"]
+    assert len(pr["decisions_per_s"]) == 2 and len(pr["avg_launch_us"]) == 2 and min(pr["decisions_per_s"]) > 0
+    # a short run: the timed region is repeated and the median reported (steps keeps its meaning: one region)
+    tr = d["timed_regions"]
+    assert tr["n"] == 9 and tr["reported"] == "median" and len(tr["ms_per_step_each"]) == 9
+    assert sorted(tr["ms_per_step_each"])[4] == pytest.approx(d["ms_per_step"])
+
+
+def launch_two(args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_scaling_presets_two_ranks():
+    """--config 3 / 4: BASELINE.json configs[3] and configs[4] as the scaling run sees them (two ranks, aliased on a
+    one-GPU box): one GPU's share each, per-rank rates on the line."""
+    d = launch_two(["--config", "3", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["config"]["partitions_per_gpu"] == 1_250_000 and d["config"]["replicas"] == 3
+    assert d["config"]["partitions_total"] == 2_500_000 and len(d["per_rank"]["decisions_per_s"]) == 2
+    assert abs(d["value"] / d["group_steps_per_s"] - 3.0) < 1e-6
+    d = launch_two(["--config", "4", "--steps", "12", "--warmup", "4", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["config"]["partitions_per_gpu"] == 125_000 and d["config"]["replicas"] == 5
+    assert "configs[4]" in d["config"]["workload"] and len(d["per_rank"]["decisions_per_s"]) == 2
+    d = launch_two(["--config", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-secondary"])
+    assert d["config"]["partitions_per_gpu"] == 1_000_000 and d["config"]["replicas"] == 5
+
+
+def test_default_line_carries_the_secondaries():
+    """The driver's N = 1 line also carries the other modes (short sub-runs of bench.py itself), each with its own roofline
+    fraction - so that BENCH_rNN.json holds more than the headline."""
+    d = run(["--groups", "100000", "--steps", "40", "--warmup", "5", "--no-cpu-baseline"], env={"JG_BENCH_SECONDARY": "1"})
+    sec = d["secondary"]
+    assert set(sec) == {"closed_loop", "routed_round", "per_partition_leadership", "failures_tick", "event_loop"}
+    for k, v in sec.items():
+        assert "error" not in v, (k, v)
+    assert sec["closed_loop"]["round_us"] > 0 and 0 < sec["closed_loop"]["frac"] < 1
+    assert sec["routed_round"]["round_ms"] > 0 and sec["per_partition_leadership"]["elections"]["won_through_the_transport"] is True
+    assert sec["event_loop"]["decisions_per_s"] > 0 and sec["event_loop"]["rows_on_the_general_path"] == 0
+    assert sec["failures_tick"]["tick_ms"] > 0
 
 
 def test_plain_gpus_n_launches_n_ranks_itself():
