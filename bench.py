@@ -575,9 +575,18 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
     c0 = sum(e.counters()["decisions"] for e in nodes)
     L._check(api.kernel_timing(L._h, 1))
     barrier()
+    # The workload is NOT stationary: a partition that lost its leader stays leaderless (Q4) and keeps producing vote
+    # traffic, so the leaderless fraction grows by ~p % per round and ms/round with it.  The K rounds are therefore also
+    # timed in four consecutive windows (a routed round synchronises with the host anyway: the window marks add nothing),
+    # each reported against the leaderless fraction it ran at.
+    marks = [W + (K * q) // 4 for q in range(5)]
+    window_s = []
     t0 = time.perf_counter()
     L._check(api.timer_start(L._h))
-    rounds(W, W + K, 1)
+    for q in range(4):
+        tq = time.perf_counter()
+        rounds(marks[q], marks[q + 1], 1)
+        window_s.append(time.perf_counter() - tq)
     ev_ms = C.c_float(0)
     L._check(api.timer_stop(L._h, C.byref(ev_ms)))
     for e in nodes:
@@ -635,7 +644,8 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
             "roofline": {"bound": "hbm", "achieved": alg / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel": f"one round: k_leader_node_tick<{R}> + {R - 1} x k_follower_tick_dense + slow kernels "
-                                   f"+ {R} x k_apply_rows over the routed rows + the transport (k_route_*, radix sort)",
+                                   f"+ the sparse steps over the routed rows (k_apply_vote_runs_multi / k_apply_rows_multi) + the transport "
+                                   "(k_route_rec_multi / _xq_multi, bucket pass + k_route_sort_build: no library sort)",
                          "alg_bytes_per_launch": alg, "avg_launch_us": round_s * 1e6,
                          "alg_bytes_per_group": {"leader_half": lb, "follower_half": fb},
                          "frac_of_measured_copy": alg / round_s / 1e9 / 6290.0,
@@ -654,6 +664,19 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
             if c is not None:
                 W_failed[c["group"]] = True
         out["leaderless_fraction"]["at_start_of_timed_region"] = float(W_failed.mean())
+        fr = [float(W_failed.mean())]
+        acc = W_failed.copy()
+        for q in range(4):
+            for t in range(marks[q], marks[q + 1]):
+                c = cluster_failure_rows(args.seed, t, G, R, args.failures, group_base=rank * G)[0]
+                if c is not None:
+                    acc[c["group"]] = True
+            fr.append(float(acc.mean()))
+        out["ms_per_round_by_leaderless_fraction"] = [
+            {"rounds": [marks[q] - W, marks[q + 1] - W], "leaderless_fraction": [fr[q], fr[q + 1]],
+             "ms_per_round": window_s[q] * 1e3 / max(marks[q + 1] - marks[q], 1)} for q in range(4)]
+        out["config"]["stationary"] = ("no: a partition that lost its leader stays leaderless (SURVEY.md 7.3 Q4) and campaigns at every election "
+                                       "timeout; ms_per_round_by_leaderless_fraction times the same run in four windows")
         print(json.dumps(out), flush=True)
     lib.close()
     if world > 1:
