@@ -721,6 +721,8 @@ def event_loop_main(args):
         runs = [one if c == 1 else run(mode, K, W, c) for c in cands]
         return max(runs, key=lambda r: r["decisions_per_s"]), {str(r["loops"]): r["decisions_per_s"] for r in runs}
 
+    p1 = run("pipe", K, W)         # ONE loop that overlaps with itself: tick t + 1 is decoded while tick t runs and lands
+    pc1 = run("pipecolumns", K, W)
     d1 = run("inplace", K, W)   # ONE loop owns every partition
     d, d_by_loops = best("inplace", d1)
     colm1 = run("columns", K, W)  # the followers' answers as columns (batched peers), only the client requests as rows
@@ -751,6 +753,17 @@ def event_loop_main(args):
                                     "makes the loops' streams share queues: 8.5-8.9e8/s instead of 1.0e9 with row inbound on 8 loops"},
             "ms_per_tick_per_loop": {"transport_decode_into_pinned_columns": d["ms_fill"], "submit_commit_validation": d["ms_submit"],
                                      "step_node_and_drains": d["ms_step_and_drain"], "all_loops_side_by_side": d["ms_per_tick"]},
+            "one_loop_pipelined": {
+                "what": "ONE loop (one host thread, one engine) that overlaps with itself: a step returns once its rows are on the device "
+                        "and classified, the transport decodes the next tick into the freed pinned columns while the dense halves run and "
+                        "the outputs travel home, fsm_tx / rpc_tx are fed at the start of the next step; rows validated on the device "
+                        "(JG_COL_UNCHECKED)",
+                "decisions_per_s": p1["decisions_per_s"], "ms_per_tick": p1["ms_per_tick"],
+                "ms_per_tick_parts": {"transport_decode_into_pinned_columns": p1["ms_fill"], "submit_commit": p1["ms_submit"],
+                                      "step_begin_and_previous_outputs": p1["ms_step_and_drain"]},
+                "column_inbound_decisions_per_s": pc1["decisions_per_s"], "column_inbound_ms_per_tick": pc1["ms_per_tick"],
+                "speedup_over_the_synchronous_loop": p1["decisions_per_s"] / d1["decisions_per_s"],
+                "rows_on_the_general_path": p1["rows_general"]},
             "one_loop": {"what": "ONE loop (one host thread, one engine) owns every partition: nothing overlaps",
                          "decisions_per_s": d1["decisions_per_s"],
                          "ms_per_tick": {"transport_decode_into_pinned_columns": d1["ms_fill"], "submit_commit_validation": d1["ms_submit"],
@@ -895,6 +908,8 @@ def secondary_lines(args):
     out["event_loop"] = x if "error" in x else {
         "command": x["command"], "decisions_per_s": x["line"]["value"], "loops": x["line"]["event_loop"]["loops"],
         "one_loop_decisions_per_s": x["line"]["event_loop"]["one_loop"]["decisions_per_s"],
+        "one_loop_pipelined_decisions_per_s": x["line"]["event_loop"]["one_loop_pipelined"]["decisions_per_s"],
+        "one_loop_pipelined_column_inbound_decisions_per_s": x["line"]["event_loop"]["one_loop_pipelined"]["column_inbound_decisions_per_s"],
         "column_inbound_decisions_per_s": x["line"]["event_loop"]["column_inbound"]["decisions_per_s"],
         "rows_on_the_general_path": x["line"]["event_loop"]["rows_on_the_general_path"],
         "pcie_bytes_per_decision": x["line"]["event_loop"]["pcie_bytes_per_decision"]}

@@ -308,7 +308,11 @@ typedef struct jg_cmd_cols {
   uint64_t* blk_id;
   uint64_t* blk_next;
 } jg_cmd_cols;
-enum { JG_COL_FROM = 1u, JG_COL_TERM = 2u, JG_COL_AUX = 4u, JG_COL_FLAG = 8u };
+enum { JG_COL_FROM = 1u, JG_COL_TERM = 2u, JG_COL_AUX = 4u, JG_COL_FLAG = 8u,
+       /* no validation pass over the rows on the host (it costs 2.5 ms per 9 M rows): jg_step_node's classification
+        * checks group and kind on the device - a row out of range is not applied and the next synchronising call
+        * returns JG_EINVAL.  Only jg_step_node takes such a batch (jg_step refuses it). */
+       JG_COL_UNCHECKED = 16u };
 int jg_submit_reserve(jg_engine* e, size_t n, size_t n_blocks, jg_cmd_cols* cols);
 int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_columns);
 

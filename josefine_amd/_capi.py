@@ -115,7 +115,7 @@ class CmdCols(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("kind", "group", "from_", "term", "id", "aux", "flag", "blk_id", "blk_next")]
 
 
-COL_FROM, COL_TERM, COL_AUX, COL_FLAG = 1, 2, 4, 8
+COL_FROM, COL_TERM, COL_AUX, COL_FLAG, COL_UNCHECKED = 1, 2, 4, 8, 16
 
 
 class CmdBatch(C.Structure):

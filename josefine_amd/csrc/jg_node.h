@@ -155,6 +155,10 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_classify(JgDev d, JgNodeCols 
   for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < a.n; i += gridDim.x * JG_BLOCK) {
     const uint32_t g = a.group[i];
     const uint32_t kind = a.kind[i];
+    if (g >= d.G || kind >= JG_CMD__COUNT) {  // (rows committed with JG_COL_UNCHECKED are validated here: not applied, JG_EINVAL)
+      *d.err = 7;
+      continue;
+    }
     uint32_t bit = 0;
     bool sparse = false;
     switch (kind) {
@@ -232,6 +236,10 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
   uint32_t mine = 0;
   for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < a.n; i += gridDim.x * JG_BLOCK) {
     const uint32_t g = a.group[i];
+    if (g >= G || a.kind[i] >= JG_CMD__COUNT) {  // (reported by k_node_classify)
+      keep[i] = 0;
+      continue;
+    }
     const uint32_t w = c.cls[g];
     const bool sparse = jg_node_group_sparse(c, G, g, w, both_beats);
     keep[i] = sparse ? 1 : 0;

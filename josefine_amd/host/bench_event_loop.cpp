@@ -78,8 +78,13 @@ struct LoopResult {
   uint32_t k_n = 0;
 };
 
-static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::string& mode, int device, uint64_t seed,
+static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::string& mode_arg, int device, uint64_t seed,
                      Rendezvous& rv, LoopResult& out) {
+  // "pipe" / "pipecolumns": the loop overlaps with itself (BatchedEventLoop::pipelined) and its rows are validated on the
+  // device (JG_COL_UNCHECKED) - otherwise exactly "inplace" / "columns"
+  const bool pipe = mode_arg.rfind("pipe", 0) == 0;
+  const std::string mode = !pipe ? mode_arg : (mode_arg == "pipecolumns" ? "columns" : "inplace");
+  const uint32_t unchecked = pipe ? (uint32_t)JG_COL_UNCHECKED : 0u;
   bool started = false, finished = false;  // (a loop that fails still arrives: the others must not wait for ever)
   try {
     std::vector<NodeId> ids;
@@ -88,6 +93,7 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
     BatchedEventLoop loop(raft, G);
     loop.halves = JG_NODE_LEADER_HALF;  // this node leads every partition
     loop.dense = mode != "general";
+    loop.pipelined = pipe;
     uint64_t sink = 0, fsm_rows = 0, msg_rows = 0, col_bytes = 0, up_bytes = 0, general = 0;
     raft.fsm_rows_tx = [&](const jg_fsm_row* r, size_t n) { sink += sum_words(r, n * sizeof(jg_fsm_row)), fsm_rows += n; };
     raft.msg_rows_tx = [&](const jg_msg_row* r, size_t n) { sink += sum_words(r, n * sizeof(jg_msg_row)), msg_rows += n; };
@@ -140,6 +146,7 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
     if (jg_kernel_timing(raft.raw(), 1) != JG_OK) throw std::runtime_error("jg_kernel_timing");
     for (uint32_t t = 0; t < W + T; t++) {
       if (t == W) {
+        loop.flush();
         if (jg_sync(raft.raw()) != JG_OK || jg_get_counters(raft.raw(), c0) != JG_OK) throw std::runtime_error("counters");
         sink = fsm_rows = msg_rows = col_bytes = up_bytes = general = rows_in = 0;
         t_fill = t_submit = t_step = 0;
@@ -159,7 +166,7 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
         const jg_cmd_cols c = loop.tcp_rx_reserve(G);
         for (uint32_t k = 0; k < G; k++) c.kind[k] = JG_CMD_CLIENT_REQUEST, c.group[k] = perm[k], c.id[k] = (uint64_t)t * G + perm[k];
         t_fill += ms_since(a), a = Clock::now();
-        loop.tcp_rx_commit(G, 0, 0);
+        loop.tcp_rx_commit(G, 0, unchecked);
         t_submit += ms_since(a), a = Clock::now();
         loop.run_until(now);
         t_step += ms_since(a);
@@ -168,7 +175,7 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
         const jg_cmd_cols c = loop.tcp_rx_reserve(n);
         const size_t k = fill(t, c.kind, c.group, c.from, c.id, c.flag);
         t_fill += ms_since(a), a = Clock::now();
-        loop.tcp_rx_commit(k, 0, JG_COL_FROM | JG_COL_FLAG);
+        loop.tcp_rx_commit(k, 0, JG_COL_FROM | JG_COL_FLAG | unchecked);
         t_submit += ms_since(a), a = Clock::now();
         loop.run_until(now);
         t_step += ms_since(a);
@@ -186,6 +193,7 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
       }
       rows_in += n;
     }
+    loop.flush();  // (pipelined: the last tick's outputs)
     const Clock::time_point t_end = rv.arrive();
     finished = true;
     out.wall_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();

@@ -199,8 +199,22 @@ class BatchedRaft {
   // mailbox columns (columns_tx, or expanded into Messages for rpc_tx); `answers_to[g]`: the NodeId a
   // follower's dense answers are addressed to (the sender of the partition's Heartbeat / AppendEntries).
   void step_node(uint64_t now_ms, uint32_t flags, const std::vector<NodeId>* answers_to = nullptr) {
+    step_node_begin(now_ms, flags);
+    step_node_finish(answers_to);
+  }
+  // The node step in two halves, so that ONE loop overlaps with itself: begin() returns as soon as the rows are on the
+  // device and classified (the engine's pinned input columns are free again) with the dense halves, the fsm build and the
+  // downloads of the outputs still running; the caller decodes the NEXT tick's traffic meanwhile and calls finish() -
+  // which waits for the outputs, feeds fsm_tx / rpc_tx / the column sink - right before the next begin().
+  void step_node_begin(uint64_t now_ms, uint32_t flags) {
     flush_rows();
     check(jg_step_node(e_, now_ms, flags));
+    node_step_open_ = true;
+  }
+  bool node_step_open() const { return node_step_open_; }
+  void step_node_finish(const std::vector<NodeId>* answers_to = nullptr) {
+    if (!node_step_open_) return;
+    node_step_open_ = false;
     jg_node_outbox o{};
     check(jg_node_outbox_view(e_, &o));
     last_outbox_ = o;
@@ -434,6 +448,7 @@ class BatchedRaft {
   std::vector<uint32_t> group_, from_;
   std::vector<uint64_t> term_, id_, aux_, blk_id_, blk_next_;
   std::vector<std::pair<uint32_t, Block>> pending_blocks_;
+  bool node_step_open_ = false;
   std::set<uint32_t> extend_failed_;  // partitions whose process died in Chain::extend (until their restart)
   std::map<std::pair<uint32_t, uint64_t>, std::vector<uint8_t>> pending_reqs_;
 };
@@ -571,6 +586,11 @@ class BatchedEventLoop {
   // round 2's loop, kept for the A/B in tests/cpp/bench_event_loop.cpp).
   bool dense = true;
   uint32_t halves = JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF;
+  // ONE loop that overlaps with itself: a step returns as soon as its rows are on the device and classified; what it
+  // pushed on fsm_tx / rpc_tx is delivered at the start of the NEXT step (or by flush()) - the channels of the
+  // reference are asynchronous too (mod.rs:337-340) -, so that the transport decodes tick t + 1 into the engine's
+  // pinned columns while the device runs tick t's kernels and sends its outputs home.
+  bool pipelined = false;
 
   explicit BatchedEventLoop(BatchedRaft& raft, uint32_t n_groups) : raft_(raft), G_(n_groups), answers_to_(n_groups, 0) {
     raft_.rpc_tx = [this](const Message& m) { on_message(m); };
@@ -629,6 +649,12 @@ class BatchedEventLoop {
       if (tick) next_tick_ += TICK_MS;
     }
   }
+  // pipelined: deliver what the last step pushed on fsm_tx / rpc_tx (run_until does it at the start of the next step)
+  void flush() {
+    if (!raft_.node_step_open()) return;
+    raft_.step_node_finish(&answers_to_);
+    drain_local(last_at_);
+  }
   size_t pending_requests() const { return requests_.size(); }
   size_t queued_rows() const { return in_.size(); }
 
@@ -644,9 +670,13 @@ class BatchedEventLoop {
     in_blocks_.clear();
     direct_rows_ = 0;
     if (dense) {
+      flush();  // (pipelined: the previous step's outputs first - its pinned queues and outbox are about to be reused)
       if (!in_.empty()) raft_.submit_rows(in_.view());
       in_.clear();
-      raft_.step_node(at, halves | (tick ? (uint32_t)JG_NODE_TICK : 0u), &answers_to_);
+      last_at_ = at;
+      raft_.step_node_begin(at, halves | (tick ? (uint32_t)JG_NODE_TICK : 0u));
+      if (pipelined) return;
+      raft_.step_node_finish(&answers_to_);
     } else {
       if (tick)
         for (uint32_t g = 0; g < G_; g++) in_.push(g, JG_CMD_TICK);
@@ -654,7 +684,10 @@ class BatchedEventLoop {
       in_.clear();
       raft_.step(at);
     }
-    // Address::Local messages (server.rs:143) are applied before anything new is accepted
+    drain_local(at);
+  }
+  // Address::Local messages (server.rs:143) are applied before anything new is accepted
+  void drain_local(uint64_t at) {
     int guard = 0;
     while (!local_.empty() && guard++ < 64) {
       std::deque<Message> lo;
@@ -709,7 +742,7 @@ class BatchedEventLoop {
   };
   BatchedRaft& raft_;
   uint32_t G_;
-  uint64_t next_tick_ = 0, next_request_ = 0;
+  uint64_t next_tick_ = 0, next_request_ = 0, last_at_ = 0;
   size_t direct_rows_ = 0;                                // rows committed in place since the last step
   RowQueue in_;                                           // tcp_rx + client_rx since the last step, stream order
   std::vector<std::pair<uint32_t, Block>> in_blocks_;     // payloads of the AppendEntries rows in in_

@@ -75,6 +75,8 @@ int main(int argc, char** argv) {
       std::vector<uint8_t> slots(G, (uint8_t)n);
       if (jg_set_self_slots(rafts[n]->raw(), slots.data()) != JG_OK) throw std::runtime_error("jg_set_self_slots");
       loops.emplace_back(new BatchedEventLoop(*rafts[n], G));
+      // JG_CLUSTER_PIPELINED=1: every loop overlaps with itself (a step's outputs are delivered at the start of the next)
+      loops[n]->pipelined = std::getenv("JG_CLUSTER_PIPELINED") != nullptr;
     }
     for (uint32_t n = 0; n < R; n++) {
       BatchedRaft& raft = *rafts[n];
@@ -159,6 +161,7 @@ int main(int argc, char** argv) {
     uint64_t restarted = 0, moved = 0;
     for (uint32_t t = 0; t < T; t++) {
       if (failover && t == T / 3) {
+        for (uint32_t n = 0; n < R; n++) loops[n]->flush();
         for (uint32_t n = 0; n < R; n++) {
           if (jg_read_state(rafts[n]->raw(), JG_FIELD_ROLE, 0, role.data(), 0, G) != JG_OK) throw std::runtime_error("read role");
           RowQueue q;
@@ -201,6 +204,7 @@ int main(int argc, char** argv) {
       // travel while the interval runs: they are next tick's input)
       for (uint32_t n = 0; n < R; n++) loops[n]->run_until(now);
     }
+    for (uint32_t n = 0; n < R; n++) loops[n]->flush();  // (pipelined: the last tick's outputs)
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     // final state into the hash; invariants
     Fnv all;
@@ -240,7 +244,9 @@ int main(int argc, char** argv) {
     uint64_t fsm = 0, msg = 0, cols = 0, general = 0, rows = 0;
     for (uint32_t n = 0; n < R; n++) fsm += n_fsm[n], msg += n_msg[n], cols += n_cols[n], general += n_general[n], rows += n_rows[n];
     bool ok = faults == 0;
-    if (scripted) ok = ok && leaders == G && max_head == T && min_commit + 4 >= T && general == 0;
+    // (pipelined loops deliver a step's outputs at the start of the next: the round trip is two ticks longer)
+    const uint64_t lag = std::getenv("JG_CLUSTER_PIPELINED") ? 8 : 4;
+    if (scripted) ok = ok && leaders == G && max_head == T && min_commit + lag >= T && general == 0;
     else ok = ok && leaders <= G;
     std::string by_node;
     for (uint32_t n = 0; n < R; n++) by_node += (n ? "/" : "") + std::to_string(leads[n]);

@@ -77,8 +77,8 @@ def build_cluster_test(oracle: bool) -> str:
     return CL_EXE
 
 
-def run_cluster(exe, *args, timeout=900):
-    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+def run_cluster(exe, *args, timeout=900, env=None):
+    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout, env={**os.environ, **(env or {})})
     assert r.returncode == 0, r.stdout + r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith("cluster ")][0]
     assert line.startswith("cluster ok"), line
@@ -131,3 +131,17 @@ def test_event_loop_cluster_equals_the_oracle_backed_loops(args):
         leadership_moved_and_stays_dense(dev, args[0])
     else:  # failover: the reference's dead end (Q4), identically on both
         assert f"restarted_leaders={args[0]}" in dev and "leaders=0 " in dev and "faults=0" in dev
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [(50_000, 5, 40, "scripted"), (3000, 3, 80, "elect")])
+def test_pipelined_event_loops_equal_the_oracle_backed_ones(args):
+    """BatchedEventLoop::pipelined (ONE loop that overlaps with itself: a step returns once its rows are on the device and
+    classified, its outputs are delivered at the start of the next step) - the same cluster of loops, every rpc_tx / fsm_tx
+    row and outbox word equal to the pipelined loops over the oracle library; and the run still does what the synchronous
+    one does (leaders elected, every partition committing)."""
+    env = {"JG_CLUSTER_PIPELINED": "1"}
+    dev = run_cluster(build_cluster_test(oracle=False), *args, env=env)
+    ora = run_cluster(build_cluster_test(oracle=True), *args, env=env)
+    assert dev == ora, (dev, ora)
+    assert f"leaders={args[0]}" in dev and "faults=0" in dev

@@ -521,3 +521,49 @@ def test_node_step_column_inbound_parity(R, with_hbc):
             e.read("term")
     with pytest.raises(EngineError):
         dev.node_inbox_columns(0, np.zeros(G, np.uint64))  # the own slot
+
+
+@pytest.mark.gpu
+def test_unchecked_rows_are_validated_on_the_device():
+    """JG_COL_UNCHECKED: no validation pass on the host - the classification checks group and kind; a row out of range is
+    not applied and the next synchronising call says so; the same rows without the bad one behave as ever."""
+    import ctypes as C
+    from josefine_amd import EngineError
+    G, R = 500, 3
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=9, election_timeout_ms=(700, 1500))
+    cols = node_traffic(rng, ora, token0=0, p_noise=0.0)
+    n = len(cols["kind"])
+
+    def put(kind, group):
+        c = capi.CmdCols()
+        nb = len(cols["blk_id"])
+        dev._check(dev.api.submit_reserve(dev._h, n, nb, C.byref(c)))
+
+        def view(ptr, dt, m):
+            return np.frombuffer((C.c_char * (m * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt)
+        view(c.kind, np.uint8, n)[:] = kind
+        view(c.group, np.uint32, n)[:] = group
+        view(c.from_, np.uint32, n)[:] = cols["from_"]
+        view(c.term, np.uint64, n)[:] = cols["term"]
+        view(c.id, np.uint64, n)[:] = cols["id"]
+        view(c.aux, np.uint64, n)[:] = cols["aux"]
+        view(c.flag, np.uint8, n)[:] = cols["flag"]
+        if nb:
+            view(c.blk_id, np.uint64, nb)[:] = cols["blk_id"]
+            view(c.blk_next, np.uint64, nb)[:] = cols["blk_next"]
+        dev._check(dev.api.submit_commit(dev._h, n, nb, capi.COL_FROM | capi.COL_TERM | capi.COL_AUX | capi.COL_FLAG | capi.COL_UNCHECKED))
+
+    put(cols["kind"], cols["group"])
+    with pytest.raises(EngineError):
+        dev.step(50)  # only jg_step_node takes an unchecked batch
+    ora.submit_columns(**cols)
+    a, b = dev.step_node(100), ora.step_node(100)
+    compare_outboxes(a, b, "unchecked")
+    compare_snapshots(dev, ora, "unchecked")
+    compare_drains(dev, ora, "unchecked")
+    bad_group = cols["group"].copy()
+    bad_group[3] = G + 7
+    put(cols["kind"], bad_group)
+    with pytest.raises(EngineError, match="out of range"):
+        dev.step_node(200)
+        dev.read("term")
