@@ -57,6 +57,34 @@ struct JgFaultRec {
 
 // Structure-of-arrays state in HBM; column c of group g is c[g], replica-major
 // for the [R][G] / [W][G] arrays so that a wave reads contiguous lanes.
+// What the elections and the timers of a group touch, in ONE 32-byte record: the general state machine visits a
+// group here and a group there, and every column it reads is a memory transaction of its own (a 64-byte sector per
+// 4-byte value: the routed round's state machine launch fetched 1.5 KB per group visit, profiles/README.md round 3) -
+// seven of them are one sector this way.  The dense follower half reads the record with two 16-byte loads per lane,
+// lanes side by side: as coalesced as the seven columns were.
+struct __attribute__((aligned(32))) JgCold {
+  uint64_t election_time;     // State.election_time (ms)               mod.rs:281
+  uint32_t voted_for;         // State.voted_for                        mod.rs:279
+  uint32_t leader_id;         // Follower.leader_id                     follower.rs:20
+  uint32_t election_timeout;  // State.election_timeout (ms)            mod.rs:283
+  uint32_t rng_draws;         // draws taken from the timeout RNG
+  uint32_t queued;            // queued_reqs.len()                      follower.rs:22
+  uint32_t votes;             // Election.votes: seen | granted << 8    election.rs:8
+                              //   bits 16-23 / 24-31: the same two masks for voters OUTSIDE the membership
+};
+static_assert(sizeof(JgCold) == 32, "JgCold is one 32-byte record");
+__device__ __forceinline__ JgCold jg_cold_load(const JgCold* p) {
+  const uint4 a = ((const uint4*)p)[0], b = ((const uint4*)p)[1];
+  JgCold c;
+  c.election_time = (uint64_t)a.x | (uint64_t)a.y << 32;
+  c.voted_for = a.z, c.leader_id = a.w, c.election_timeout = b.x, c.rng_draws = b.y, c.queued = b.z, c.votes = b.w;
+  return c;
+}
+__device__ __forceinline__ void jg_cold_store(JgCold* p, const JgCold& c) {
+  ((uint4*)p)[0] = make_uint4((uint32_t)c.election_time, (uint32_t)(c.election_time >> 32), c.voted_for, c.leader_id);
+  ((uint4*)p)[1] = make_uint4(c.election_timeout, c.rng_draws, c.queued, c.votes);
+}
+
 struct JgDev {
   uint32_t G, R;
   uint32_t node_ids[JG_MAX_REPLICAS];
@@ -69,19 +97,12 @@ struct JgDev {
   uint64_t* run_hi;          // segment 0: ids [0, run_hi], next = id-1 (valid unless FAST)
   uint64_t* mlag;            // [G] leaders: Progress.head of all R slots + Chain.commit, packed as lags below the chain head
   uint64_t* match_wide;      // [R][G] Progress.head of the slots whose lag field holds the escape value
-  uint64_t* election_time;   // State.election_time (ms)               mod.rs:281
   uint64_t* heartbeat_time;  // Leader.heartbeat_time (ms)             leader.rs:27
   uint64_t* win_lo;          // [W][G] chain segments besides the run: first id,
   uint64_t* win_hi;          // [W][G]   last id,
   uint64_t* win_next;        // [W][G]   parent pointer of the first id
   uint32_t* flags;
-  uint32_t* voted_for;       // State.voted_for                        mod.rs:279
-  uint32_t* leader_id;       // Follower.leader_id                     follower.rs:20
-  uint32_t* election_timeout;// State.election_timeout (ms)            mod.rs:283
-  uint32_t* rng_draws;       // draws taken from the timeout RNG
-  uint32_t* queued;          // queued_reqs.len()                      follower.rs:22
-  uint32_t* votes;           // Election.votes: seen | granted << 8    election.rs:8
-                             //   bits 16-23 / 24-31: the same two masks for voters OUTSIDE the membership
+  JgCold* cold;              // [G] election timer, vote, leader id, timeout, RNG draws, queue length, vote masks
   uint32_t* fvote_id;        // [JG_FOREIGN_VOTERS][G] their NodeIds (election.rs:33-35 counts whoever answers)
   uint64_t* blk_decisions;   // per-workgroup decision counters (no atomics on the hot path)
   JgFaultRec* fault_q;
@@ -219,14 +240,12 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
   L.head = d.head[g];
   L.id_gen = (L.flags & JGF_FAST) ? L.head + 1 : d.id_gen[g];
   L.run_hi = (L.flags & JGF_RUN) ? L.head : d.run_hi[g];
-  L.election_time = d.election_time[g];
   L.heartbeat_time = d.heartbeat_time[g];
-  L.voted_for = d.voted_for[g];
-  L.leader_id = d.leader_id[g];
-  L.election_timeout = d.election_timeout[g];
-  L.rng_draws = d.rng_draws[g];
-  L.queued = d.queued[g];
-  L.votes = d.votes[g];
+  {
+    const JgCold c = jg_cold_load(d.cold + g);
+    L.election_time = c.election_time, L.voted_for = c.voted_for, L.leader_id = c.leader_id;
+    L.election_timeout = c.election_timeout, L.rng_draws = c.rng_draws, L.queued = c.queued, L.votes = c.votes;
+  }
   L.mword = 0;
   L.mbase = L.head;
   if ((L.flags & JGF_ROLE_MASK) == JG_ROLE_LEADER) {
@@ -266,14 +285,8 @@ __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   d.head[g] = L.head;
   d.id_gen[g] = L.id_gen;
   d.run_hi[g] = L.run_hi;
-  d.election_time[g] = L.election_time;
   d.heartbeat_time[g] = L.heartbeat_time;
-  d.voted_for[g] = L.voted_for;
-  d.leader_id[g] = L.leader_id;
-  d.election_timeout[g] = L.election_timeout;
-  d.rng_draws[g] = L.rng_draws;
-  d.queued[g] = L.queued;
-  d.votes[g] = L.votes;
+  jg_cold_store(d.cold + g, JgCold{L.election_time, L.voted_for, L.leader_id, L.election_timeout, L.rng_draws, L.queued, L.votes});
 }
 
 __device__ inline int jg_slot_of(const JgDev& d, uint32_t node_id);
@@ -312,14 +325,10 @@ __device__ inline void jg_store_dirty(const JgDev& d, JgLane& L, const JgLane& O
   // columns then - so they are written when the lane LEAVES that form or changes them outside it)
   if (!fast && (L.id_gen != O.id_gen || (O.flags & JGF_FAST))) d.id_gen[g] = L.id_gen;
   if (!run && (L.run_hi != O.run_hi || (O.flags & JGF_RUN))) d.run_hi[g] = L.run_hi;
-  if (L.election_time != O.election_time) d.election_time[g] = L.election_time;
   if (L.heartbeat_time != O.heartbeat_time) d.heartbeat_time[g] = L.heartbeat_time;
-  if (L.voted_for != O.voted_for) d.voted_for[g] = L.voted_for;
-  if (L.leader_id != O.leader_id) d.leader_id[g] = L.leader_id;
-  if (L.election_timeout != O.election_timeout) d.election_timeout[g] = L.election_timeout;
-  if (L.rng_draws != O.rng_draws) d.rng_draws[g] = L.rng_draws;
-  if (L.queued != O.queued) d.queued[g] = L.queued;
-  if (L.votes != O.votes) d.votes[g] = L.votes;
+  if (L.election_time != O.election_time || L.voted_for != O.voted_for || L.leader_id != O.leader_id ||
+      L.election_timeout != O.election_timeout || L.rng_draws != O.rng_draws || L.queued != O.queued || L.votes != O.votes)
+    jg_cold_store(d.cold + g, JgCold{L.election_time, L.voted_for, L.leader_id, L.election_timeout, L.rng_draws, L.queued, L.votes});
 }
 
 // ---- output rows ------------------------------------------------------------------

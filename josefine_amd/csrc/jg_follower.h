@@ -84,12 +84,14 @@ __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollower
     const uint32_t in_n = (uint32_t)in_ae & 0xffu;
     const uint32_t lead = ANY ? jg_member_id(d, own) : (a.leader ? a.leader[g] : a.leader_id);
     uint64_t term = d.term[g], head = d.head[g], commit = d.commit[g];
-    uint32_t voted_for = d.voted_for[g], leader_id = d.leader_id[g];
-    const uint32_t queued = d.queued[g];
-    // the election timer: a heartbeat redraws it (needs rng_draws), a Tick without one reads it
-    const uint32_t draws = d.rng_draws[g];
-    uint64_t et = d.election_time[g];
-    uint32_t eto = d.election_timeout[g];
+    // the vote, the leader id, the queue length and the election timer (a heartbeat redraws it: rng_draws; a Tick
+    // without one reads it): one 32-byte record, two 16-byte loads
+    const JgCold cold0 = jg_cold_load(d.cold + g);
+    uint32_t voted_for = cold0.voted_for, leader_id = cold0.leader_id;
+    const uint32_t queued = cold0.queued;
+    uint32_t draws = cold0.rng_draws;
+    uint64_t et = cold0.election_time;
+    uint32_t eto = cold0.election_timeout;
     const bool has_hb = in_hbc != JG_NO_ACK, has_ae = in_n != JG_AE_NONE;
 
     const uint32_t role = f & JGF_ROLE_MASK;
@@ -126,7 +128,7 @@ __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollower
       const uint64_t r = jg_mix64(d.seed ^ jg_mix64((d.group_base + g) * 0xd1342543de82ef95ull + draws));
       eto = d.el_min + (span ? (uint32_t)(r % span) : 0u);
       et = a.now;
-      d.rng_draws[g] = draws + 1;
+      draws += 1;
       timer_dirty = true;
       term = in_term;                     // :185, unconditional (Q6)
       nf |= JGF_HAS_LEADER | JGF_VOTED;   // :186-187
@@ -185,12 +187,8 @@ __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollower
     if (head != head0) d.head[g] = head;
     if (commit != commit0) d.commit[g] = commit;
     jg_follower_fsm_note(a, g, commit0, commit);
-    if (voted_for != vf0) d.voted_for[g] = voted_for;
-    if (leader_id != lid0) d.leader_id[g] = leader_id;
-    if (timer_dirty) {
-      d.election_time[g] = et;
-      d.election_timeout[g] = eto;
-    }
+    if (voted_for != vf0 || leader_id != lid0 || timer_dirty)
+      jg_cold_store(d.cold + g, JgCold{et, voted_for, leader_id, eto, draws, queued, cold0.votes});
     if (nf != f) d.flags[g] = nf;
     // (divergent use of the wave-aggregated push is fine: the ballot covers the active lanes)
     jg_defer_push(d, g, tick_defer, JG_DEFER_TICK_ONLY);

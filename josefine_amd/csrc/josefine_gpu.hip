@@ -1218,18 +1218,12 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.run_hi, G);
   A(d.mlag, G);
   A(d.match_wide, G * R);
-  A(d.election_time, G);
   A(d.heartbeat_time, G);
   A(d.win_lo, G * JG_CHAIN_WINDOW);
   A(d.win_hi, G * JG_CHAIN_WINDOW);
   A(d.win_next, G * JG_CHAIN_WINDOW);
   A(d.flags, G);
-  A(d.voted_for, G);
-  A(d.leader_id, G);
-  A(d.election_timeout, G);
-  A(d.rng_draws, G);
-  A(d.queued, G);
-  A(d.votes, G);
+  A(d.cold, G);
   A(d.fvote_id, G * JG_FOREIGN_VOTERS);
   A(d.blk_decisions, e->count_slots);
   d.fault_q_cap = (uint32_t)std::max<size_t>(2 * G, 1024);
@@ -3136,17 +3130,17 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
     HIPCHK(hipMemcpy(t64.data(), col + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
     return JG_OK;
   };
-  auto get32 = [&](const uint32_t* col) -> int {
-    t32.resize(n);
-    HIPCHK(hipMemcpy(t32.data(), col + g0, (size_t)n * 4, hipMemcpyDeviceToHost));
+  // a field of the 32-byte cold record (JgCold), for groups [g0, g0 + n): a strided copy
+  auto cold_field = [&](size_t offset, size_t width, void* dst) -> int {
+    HIPCHK(hipMemcpy2D(dst, width, (const char*)(d.cold + g0) + offset, sizeof(JgCold), width, n, hipMemcpyDeviceToHost));
     return JG_OK;
+  };
+  auto cold32 = [&](size_t offset) -> int {
+    t32.resize(n);
+    return cold_field(offset, 4, t32.data());
   };
   auto copy64 = [&](const uint64_t* col) -> int {  // straight column -> caller's buffer
     HIPCHK(hipMemcpy(out, col + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
-    return JG_OK;
-  };
-  auto copy32 = [&](const uint32_t* col) -> int {
-    HIPCHK(hipMemcpy(out, col + g0, (size_t)n * 4, hipMemcpyDeviceToHost));
     return JG_OK;
   };
   uint64_t* o64 = (uint64_t*)out;
@@ -3166,9 +3160,9 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
       return JG_OK;
     }
     case JG_FIELD_HEAD: return copy64(d.head);
-    case JG_FIELD_ELECTION_TIME: return copy64(d.election_time);
-    case JG_FIELD_ELECTION_TIMEOUT: return copy32(d.election_timeout);
-    case JG_FIELD_QUEUED_REQS: return copy32(d.queued);
+    case JG_FIELD_ELECTION_TIME: return cold_field(offsetof(JgCold, election_time), 8, out);
+    case JG_FIELD_ELECTION_TIMEOUT: return cold_field(offsetof(JgCold, election_timeout), 4, out);
+    case JG_FIELD_QUEUED_REQS: return cold_field(offsetof(JgCold, queued), 4, out);
     case JG_FIELD_ID_GEN: {  // implicit (head + 1) while the chain is in FAST form
       std::vector<uint64_t> head(n);
       HIPCHK(hipMemcpy(head.data(), d.head + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
@@ -3192,17 +3186,17 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
       for (uint32_t i = 0; i < n; i++) o64[i] = role(i) == JG_ROLE_LEADER ? t64[i] : 0;
       return JG_OK;
     case JG_FIELD_VOTED_FOR:
-      if ((rc = get32(d.voted_for))) return rc;
+      if ((rc = cold32(offsetof(JgCold, voted_for)))) return rc;
       for (uint32_t i = 0; i < n; i++) o32[i] = (fl[i] & JGF_VOTED) ? t32[i] : 0;
       return JG_OK;
     case JG_FIELD_LEADER_ID:
-      if ((rc = get32(d.leader_id))) return rc;
+      if ((rc = cold32(offsetof(JgCold, leader_id)))) return rc;
       for (uint32_t i = 0; i < n; i++)
         o32[i] = (role(i) == JG_ROLE_FOLLOWER && (fl[i] & JGF_HAS_LEADER)) ? t32[i] : 0;
       return JG_OK;
     case JG_FIELD_VOTE_SEEN:
     case JG_FIELD_VOTE_GRANTED:
-      if ((rc = get32(d.votes))) return rc;
+      if ((rc = cold32(offsetof(JgCold, votes)))) return rc;
       for (uint32_t i = 0; i < n; i++) {
         uint32_t v = field == JG_FIELD_VOTE_SEEN ? (t32[i] & 0xff) : ((t32[i] >> 8) & 0xff);
         o8[i] = role(i) == JG_ROLE_CANDIDATE ? (uint8_t)v : 0;
