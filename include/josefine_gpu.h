@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define JG_ABI_VERSION 4u
+#define JG_ABI_VERSION 5u /* v5: jg_step_node = arrival-order Apply (fsm_tx: Apply / Notify / Apply per partition), JG_CLUSTER_ANY_LEADER,
+                             jg_dense_cluster_withdraw_appends, JG_COL_UNCHECKED */
 #define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
 #define JG_CHAIN_WINDOW 8u  /* chain segments (gaps / forks) per group besides the main run */
 #define JG_MAX_INFLIGHT 5u  /* src/raft/progress.rs:117                                    */

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 CLUSTER_ANY_LEADER = 0xFFFFFFFF
 MAX_REPLICAS = 8
 CHAIN_WINDOW = 8

@@ -25,3 +25,10 @@ d = json.load(open("$O/bench_any_failures_1pct_x3.json"))
 print(d["ms_per_step"], d["roofline"]["frac"], d.get("leaderless_fraction"), d.get("failed_fraction"), d.get("elections_won_after_failures"), d.get("rows_routed_per_round"), d.get("rows_left_for_the_host"))
 PY
 fi
+if [ "$part" = routed ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_routed -o x -- python bench.py --cluster --failures 1 --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_cluster_failures_1pct.json 2>/dev/null
+  cp $(find $O/prof_routed -name "*kernel_stats.csv" | head -1) $O/kernel_stats_cluster_failures_1pct.csv
+  head -22 $O/kernel_stats_cluster_failures_1pct.csv | cut -c1-150
+  python -c "
+import json; d=json.load(open('$O/bench_cluster_failures_1pct.json')); print(d['ms_per_step'], d['roofline']['frac'], d.get('ms_per_round_by_leaderless_fraction'))"
+fi
