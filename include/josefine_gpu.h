@@ -489,7 +489,15 @@ int jg_step_dense_follower(jg_engine* e, uint64_t now_ms, const jg_follower_inbo
 enum {
   JG_NODE_LEADER_HALF = 1u,   /* serve the partitions this node leads (jg_step_dense_leader)            */
   JG_NODE_FOLLOWER_HALF = 2u, /* serve the partitions it follows (jg_step_dense_follower)              */
-  JG_NODE_TICK = 4u           /* Command::Tick for every partition after its rows (server.rs:125)      */
+  JG_NODE_TICK = 4u,          /* Command::Tick for every partition after its rows (server.rs:125)      */
+  /* No synchronisation inside the call: it returns as soon as everything is ENQUEUED - uploads, classification, the
+   * dense halves, the downloads of the outbox columns - and the engine's pinned input columns (jg_submit_reserve) are
+   * a second set from then on, so that the next tick can be decoded while this one runs.  The dense halves of such a
+   * step leave the partitions whose rows take the general path alone; the step is SETTLED by the next call that looks at
+   * the engine (jg_node_outbox_view first of all; any step, drain, read or jg_sync): the row count has landed by then,
+   * and if it is not zero those rows are applied and the halves come back for exactly those partitions - the same
+   * results and the same record order as the synchronous step, one pass later.  Single-device engines or shards. */
+  JG_NODE_ASYNC = 8u
 };
 typedef struct jg_node_outbox { /* host pointers into the engine's pinned buffers; NULL: that half did not run */
   const jg_leader_beat* beat;  /* [G]    what a leader's followers read of its Tick (jg_leader_outbox.beat)   */
@@ -516,7 +524,7 @@ int jg_node_inbox_columns(jg_engine* e, uint32_t slot, uint64_t** answer, uint64
 
 /* Apply everything queued by jg_submit since the last step as described above (`flags`: JG_NODE_*; at
  * least one half).  Asynchronous like jg_step except for one synchronisation after the classification
- * (the number of general-path rows sizes that step's launch). */
+ * (the number of general-path rows sizes that step's launch) - none at all with JG_NODE_ASYNC. */
 int jg_step_node(jg_engine* e, uint64_t now_ms, uint32_t flags);
 /* The mailbox columns the last jg_step_node produced: waits for them to land; the pointers stay valid
  * until the next jg_step_node.  On a multi-device engine the columns are the shards' concatenated. */

@@ -46,7 +46,7 @@ FAULT_ENGINE_DENSE_APPENDS = 132
 FAULT_ENGINE_MAILBOX_RANGE = 133
 
 CFG_SEPARATE_COMMIT_KEY = 1
-NODE_LEADER_HALF, NODE_FOLLOWER_HALF, NODE_TICK = 1, 2, 4
+NODE_LEADER_HALF, NODE_FOLLOWER_HALF, NODE_TICK, NODE_ASYNC = 1, 2, 4, 8
 
 FSM_APPLY_LEADER, FSM_APPLY_FOLLOWER, FSM_NOTIFY = 0, 1, 2
 

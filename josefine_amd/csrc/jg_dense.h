@@ -413,8 +413,16 @@ struct JgLeaderNode {
   // offered[g] = the own slot's word (JG_ANSWER(#ClientRequests, none)) for whoever owns g.
   const uint8_t* owner;
   const uint64_t* offered;
+  // jg_step_node, JG_NODE_ASYNC: bit g of sparse_bits = group g's rows take the general path.  sparse_mode 1: the half
+  // leaves those groups alone (their rows have not been applied yet); 2: it serves ONLY those (the catch-up pass)
+  const uint64_t* sparse_bits;
+  uint32_t sparse_mode, pad3_;
 };
 #define JG_OWNER_NONE 0xffu
+__device__ __forceinline__ bool jg_sparse_skip(const uint64_t* bits, uint32_t mode, uint32_t g) {
+  const bool sp = (bits[g >> 6] >> (g & 63u)) & 1ull;
+  return mode == 1u ? sp : !sp;
+}
 #define JG_FSM_APPENDED_BIT (1u << 31)
 #define JG_FSM_WIDE_BIT (1u << 30)
 #define JG_FSM_FOLLOWER_BIT (1u << 29)
@@ -802,6 +810,7 @@ __device__ __forceinline__ JgDecCount jg_dense_tick_body(const JgDenseHot& h, co
   JgDecCount dec;
   uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x;
   for (; g < G; g += stride) {
+    if (FSM && nd.sparse_bits && jg_sparse_skip(nd.sparse_bits, nd.sparse_mode, g)) continue;
     if (ANY) {  // the flag word first: a wave that leads none of its 64 groups loads nothing else (a node leads G / R of them)
       const uint32_t f0 = h.flags[g];
       if (__ballot((f0 & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER) == 0) continue;

@@ -45,6 +45,8 @@ struct JgFollowerArgs {
   const uint8_t* owner;
   uint32_t self_slot;
   uint32_t seq_off;  // added to the clock's step number (the follower half is the node's second step of a round there)
+  const uint64_t* sparse_bits;  // jg_step_node, JG_NODE_ASYNC: see JgLeaderNode
+  uint32_t sparse_mode, pad3_;
 };
 __device__ __forceinline__ uint32_t jg_member_id(const JgDev& d, uint32_t slot) {
   uint32_t id = 0;
@@ -68,6 +70,7 @@ __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollower
   if (a.clock) jg_clock_read(a.clock, a.clock_slot, a.now, a.seq), a.seq += a.seq_off;
   const uint32_t G = d.G;
   for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
+    if (a.sparse_bits && jg_sparse_skip(a.sparse_bits, a.sparse_mode, g)) continue;
     // every load is independent of the others
     const uint32_t f = d.flags[g];
     uint32_t own = 0;

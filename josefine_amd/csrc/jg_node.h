@@ -75,6 +75,9 @@ struct JgNodeCols {  // device scratch of the node step (engine-owned, grow-only
   // arrival index + 1 of the row that filled a mailbox entry (stream order of the step's batch)
   uint32_t* arr;         // [2R][G]  [r]: AppendResponse of slot r (own slot: the ClientRequest), [R + r]: HeartbeatResponse of slot r
   uint32_t* fo;          // [2][G]   the Heartbeat, the AppendEntries
+  // bit g: group g's rows take the general path (the verdict of k_node_route, one word per 64 groups): what the dense
+  // halves of an ASYNCHRONOUS step skip - and come back for, once the host has seen that the general path is not empty
+  uint64_t* sparse_bits;  // [ceil(G / 64)]
   // fsm deltas of the dense halves
   uint32_t* fsm_delta;   // [G]
   uint64_t* fsm_prev;    // [G] JGN_FSM_WIDE: the commit index before the step
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_prefill(JgDev d, JgNodeCols c
   for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) {
     c.cls[g] = 0;
     c.fsm_delta[g] = 0;
+    if ((g & 63u) == 0) c.sparse_bits[g >> 6] = 0;
     if (leader_half) {
       const uint32_t s = us >= 0 ? (uint32_t)us : (d.flags[g] & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
       for (uint32_t r = 0; r < d.R; r++) {
@@ -244,7 +248,10 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
     const bool sparse = jg_node_group_sparse(c, G, g, w, both_beats);
     keep[i] = sparse ? 1 : 0;
     mine += sparse;
-    if (sparse) continue;
+    if (sparse) {
+      (void)__hip_atomic_fetch_or(&c.sparse_bits[g >> 6], 1ull << (g & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
     const uint32_t kind = a.kind[i];
     switch (kind) {
       case JG_CMD_APPEND_RESPONSE: {  // bits 63..8 of the sender's answer word (all ones before)

@@ -181,10 +181,21 @@ struct PinnedVec {
     n += k;
     return hipSuccess;
   }
+  // Two buffers: flip() makes the other one current (empty) and leaves this one as it is - an asynchronous copy out of
+  // it may still be in flight (jg_step_node returns before its uploads have completed; the buffer comes round again two
+  // steps later, behind that step's synchronisation).  Only the current buffer ever grows or is freed.
+  T* alt = nullptr;
+  size_t alt_cap = 0;
+  void flip() {
+    std::swap(p, alt);
+    std::swap(cap, alt_cap);
+    n = 0;
+  }
   void destroy() {
     if (p) (void)hipHostFree(p);
-    p = nullptr;
-    n = cap = 0;
+    if (alt) (void)hipHostFree(alt);
+    p = alt = nullptr;
+    n = cap = alt_cap = 0;
   }
 };
 
@@ -332,6 +343,15 @@ struct jg_engine {
     hipEvent_t ev_out = nullptr;
     hipEvent_t ev_cols = nullptr;      // behind the uploads of the handed-out columns: the pinned buffers are free again
     bool cols_in_flight = false;
+    // JG_NODE_ASYNC: a step that returned without looking at its general-path row count (settled by node_settle)
+    struct Pending {
+      bool on = false;
+      JgNodeRows rows{};
+      uint8_t* d_keep = nullptr;
+      size_t n = 0, nb = 0, fsm_rec_seq = 0;
+      uint64_t now_ms = 0;
+      uint32_t flags = 0, col_mask = 0, seq_general = 0, seq_leader = 0, seq_follower = 0, seq_end = 0;
+    } pending;
     jg_node_outbox last{};
     uint32_t last_flags = 0;
     // multi-device parent: the shards' columns concatenated
@@ -411,7 +431,12 @@ void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks, const Jg
                        jg_dense_hot_of(e->dev), (const JgDev*)e->d_dev, acks, e->seq, e->uniform_self);
 }
 
+int node_settle(jg_engine* e);  // (jg_step_node with JG_NODE_ASYNC: the step's general path, if it has one, runs when the step is settled)
 int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1, const JgLeaderNode* nd = nullptr) {
+  if (!(nd && nd->sparse_mode == 2u)) {  // (not from inside node_settle's own catch-up pass)
+    const int rc = node_settle(e);
+    if (rc) return rc;
+  }
   e->stepped = true;
   e->seq++;  // tick t of this launch carries sequence number seq + t
   switch (e->cfg.n_replicas) {
@@ -501,6 +526,10 @@ int status_check(const jg_engine* e, const uint32_t* st) {
 // device-side error flags, and settle the lazily-read irregular-chain flag.
 int sync_and_check(jg_engine* e) {
   HIPCHK(hipSetDevice(e->device));
+  {
+    const int rc = node_settle(e);
+    if (rc) return rc;
+  }
   HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->stage_busy = false;
@@ -847,6 +876,10 @@ int inflight_finish(jg_engine* e) {
 // blocks: while a batch is still in transfer it starts nothing (the next call takes more steps)
 int drain_prefetch(jg_engine* e, bool wait) {
   HIPCHK(hipSetDevice(e->device));
+  {
+    const int rc = node_settle(e);
+    if (rc) return rc;
+  }
   e->pipelined = true;
   if (!wait && !inflight_landed(e)) return JG_OK;
   int rc = inflight_finish(e);
@@ -1467,6 +1500,10 @@ int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_
 int jg_step(jg_engine* e, uint64_t now_ms) {
   if (!e) return fail(JG_EINVAL, "null argument");
   if (e->router) return router_step(e, now_ms);
+  {
+    const int rc = node_settle(e);
+    if (rc) return rc;
+  }
   e->stepped = true;
   const size_t n = e->p_kind.size();
   if (!n) return JG_OK;
@@ -1546,6 +1583,10 @@ int jg_step_device_rows(jg_engine* e, const jg_cmd_batch* b, uint64_t now_ms) {
   if (!e || !b) return fail(JG_EINVAL, "null argument");
   if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
   if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
+  {
+    const int rc = node_settle(e);
+    if (rc) return rc;
+  }
   e->stepped = true;
   if (!b->n) return JG_OK;
   if (b->n > 0x7fffffffull) return fail(JG_EINVAL, "batch too large: split it");
@@ -1626,7 +1667,11 @@ int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* i
 namespace {
 // the two launches of a follower half; `fsm_*`: jg_step_node's fsm delta columns (or null)
 int follower_half(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in, const jg_follower_outbox* out, int tick,
-                  uint32_t* fsm_delta, uint64_t* fsm_prev) {
+                  uint32_t* fsm_delta, uint64_t* fsm_prev, const uint64_t* sparse_bits = nullptr, uint32_t sparse_mode = 0) {
+  if (sparse_mode != 2u) {  // (not from inside node_settle's own catch-up pass)
+    const int rc = node_settle(e);
+    if (rc) return rc;
+  }
   e->stepped = true;
   e->seq++;
   JgFollowerArgs a{};
@@ -1642,6 +1687,7 @@ int follower_half(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in, co
   a.tick = tick ? 1 : 0;
   a.fsm_delta = fsm_delta;
   a.fsm_prev = fsm_prev;
+  a.sparse_bits = sparse_bits, a.sparse_mode = sparse_mode;
   hipLaunchKernelGGL(k_follower_tick_dense, dim3(e->dense_grid), dim3(JG_BLOCK), 0, e->stream, e->dev, a);
   // always scheduled: which groups need the general state machine is only known on the device
   // (empty lists cost a few microseconds)
@@ -1698,6 +1744,7 @@ int node_ensure(jg_engine* e) {
   A(n.cols.fsm_mid, G);
   A(n.cols.arr, 2 * R * G);
   A(n.cols.fo, 2 * G);
+  A(n.cols.sparse_bits, (G + 63) / 64);
   A(n.o_beat, G);
   A(n.o_ae, R * G);
   HIPCHK(hipMemsetAsync(n.o_ae, 0xff, std::max<size_t>(R * G * 8, 16), e->stream));  // (the own slot's row is never written: JG_NO_ACK once)
@@ -1720,15 +1767,23 @@ int node_ensure(jg_engine* e) {
   return JG_OK;
 }
 
+int node_dense_halves(jg_engine* e, uint64_t now_ms, uint32_t flags, uint32_t col_mask, uint32_t sparse_mode, uint64_t* bytes_down);
+int node_general(jg_engine* e, const JgNodeRows& rows, uint8_t* d_keep, size_t n, size_t nb, uint32_t n_sparse, uint64_t now_ms);
+
 int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   jg_engine::NodeStep& nd = e->node;
   const uint32_t halves = flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF);
-  const bool tick = (flags & JG_NODE_TICK) != 0;
+  // JG_NODE_ASYNC: no synchronisation inside the step - the general-path row count is looked at when the step is settled
+  const bool async = (flags & JG_NODE_ASYNC) != 0;
   HIPCHK(hipSetDevice(e->device));
   int rc = node_ensure(e);
   if (rc) return rc;
+  if ((rc = node_settle(e))) return rc;  // (an earlier asynchronous step)
   if ((rc = ensure_xq(e))) return rc;
   e->stepped = true;
+  jg_engine::NodeStep::Pending& pend = nd.pending;
+  pend = jg_engine::NodeStep::Pending{};
+  const uint32_t seq0 = e->seq;
   const size_t n = e->p_kind.size(), nb = e->p_blk_id.size();
   if (n > 0x7fffffffull) return fail(JG_EINVAL, "batch too large: split it");
   const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
@@ -1769,7 +1824,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   uint32_t n_sparse = 0;
   // the general path's sequence number is taken whether or not it runs: the shards of a multi-device engine must leave
   // one node step with the same numbers (the router merges their rows by step number first: jg_multi.h)
-  e->seq++;
+  e->seq = seq0 + 1;
   if (n) {
     // the rows in stream order, straight out of the pinned columns jg_submit (or the caller, in place:
     // jg_submit_reserve) filled: one copy per column that is present - an optional column nobody
@@ -1821,91 +1876,29 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
                        both_beats, d_keep, nd.d_nsparse);
     HIPCHK(hipGetLastError());
     e->n_launch += 3;
-    // the one synchronisation of the step: how many rows take the general path sizes that launch
     HIPCHK(hipMemcpyAsync(nd.h_nsparse, nd.d_nsparse, 4, hipMemcpyDeviceToHost, e->stream));
-    T1 = clk();
-    HIPCHK(hipStreamSynchronize(e->stream));
-    T2 = clk();
-    n_sparse = nd.h_nsparse[0];
-    if (n_sparse) {
-      // order-preserving compaction of the flagged rows, then a stable sort by group: the batch k_apply_rows takes
-      uint32_t *idx = nullptr, *idx2 = nullptr, *keys = nullptr, *keys2 = nullptr;
-      HIPCHK(ar.alloc((size_t)n * 4, (void**)&idx));
-      HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&idx2));
-      HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&keys));
-      HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&keys2));
-      size_t need_a = 0, need_b = 0;
-      rocprim::counting_iterator<uint32_t> iota(0);
-      HIPCHK(rocprim::select(nullptr, need_a, iota, d_keep, idx, nd.d_nsparse + 1, n, e->stream));
-      HIPCHK(rocprim::radix_sort_pairs(nullptr, need_b, keys, keys2, idx, idx2, (size_t)n_sparse, 0, nd.group_bits, e->stream));
-      const size_t need = std::max(need_a, need_b);
-      if (nd.tmp_bytes < need) {
-        if (nd.tmp) HIPCHK(hipFree(nd.tmp));
-        nd.tmp_bytes = 2 * need;
-        HIPCHK(hipMalloc(&nd.tmp, nd.tmp_bytes));
-      }
-      size_t tb = nd.tmp_bytes;
-      HIPCHK(rocprim::select(nd.tmp, tb, iota, d_keep, idx, nd.d_nsparse + 1, n, e->stream));
-      const uint32_t sgrid = (n_sparse + JG_BLOCK - 1) / JG_BLOCK;
-      hipLaunchKernelGGL(k_node_keys, dim3(sgrid), dim3(JG_BLOCK), 0, e->stream, n_sparse, (const uint32_t*)idx, rows.group, keys);
-      tb = nd.tmp_bytes;
-      HIPCHK(rocprim::radix_sort_pairs(nd.tmp, tb, keys, keys2, idx, idx2, (size_t)n_sparse, 0, nd.group_bits, e->stream));
-      JgNodeSorted so{};
-      char* M = nullptr;
-      const size_t ns = n_sparse;
-      HIPCHK(ar.alloc(ns * 34 + 64, (void**)&M));  // 3 x 8 + 2 x 4 + 2 x 1 bytes per row, widest columns first
-      so.term = (uint64_t*)M, M += ns * 8;
-      so.id = (uint64_t*)M, M += ns * 8;
-      so.aux = (uint64_t*)M, M += ns * 8;
-      so.group = (uint32_t*)M, M += ns * 4;
-      so.from = (uint32_t*)M, M += ns * 4;
-      so.kind = (uint8_t*)M, M += ns;
-      so.flag = (uint8_t*)M;
-      hipLaunchKernelGGL(k_node_gather_rows, dim3(sgrid), dim3(JG_BLOCK), 0, e->stream, n_sparse, (const uint32_t*)idx2, rows, so);
-      HIPCHK(hipGetLastError());
-      e->n_launch += 4;
-      if ((rc = launch_rows(e, n_sparse, so.group, so.kind, so.from, so.term, so.id, so.aux, so.flag,
-                            nb ? rows.blk_id : (const uint64_t*)e->d_ones, nb ? rows.blk_next : (const uint64_t*)e->d_ones, nb, now_ms)))
-        return rc;
+    if (!async) {
+      // the one synchronisation of a synchronous step: how many rows take the general path sizes that launch
+      T1 = clk();
+      HIPCHK(hipStreamSynchronize(e->stream));
+      T2 = clk();
+      n_sparse = nd.h_nsparse[0];
+      if (n_sparse && (rc = node_general(e, rows, d_keep, n, nb, n_sparse, now_ms))) return rc;
     }
-    e->p_kind.clear(), e->p_flag.clear(), e->p_group.clear(), e->p_from.clear(), e->p_term.clear(), e->p_id.clear();
-    e->p_aux.clear(), e->p_blk_id.clear(), e->p_blk_next.clear();
+    pend.rows = rows, pend.d_keep = d_keep, pend.n = n, pend.nb = nb;
+    // the pinned columns: the OTHER set from here on (an asynchronous step's uploads may still be reading this one)
+    e->p_kind.flip(), e->p_flag.flip(), e->p_group.flip(), e->p_from.flip(), e->p_term.flip(), e->p_id.flip();
+    e->p_aux.flip(), e->p_blk_id.flip(), e->p_blk_next.flip();
     e->p_has_from = e->p_has_term = e->p_has_aux = e->p_has_flag = false;
-  e->p_kinds_seen = 0;
-  e->p_unchecked = false;
+    e->p_kinds_seen = 0;
+    e->p_unchecked = false;
   }
-  // the dense halves: every partition, the ones whose rows went the general way included (they are ticked here)
+  // the dense halves: every partition, the ones whose rows went the general way included (they are ticked here) -
+  // except in an asynchronous step, whose halves leave those partitions to the catch-up pass (node_settle)
+  pend.now_ms = now_ms, pend.flags = flags, pend.col_mask = col_mask;
+  e->seq = seq0 + 1;  // (the general path's number: taken above whether or not it runs)
   uint64_t bytes_down = 0;
-  if (halves & JG_NODE_LEADER_HALF) {
-    JgLeaderNode ln{};
-    ln.hbr_commit = nd.cols.hbr_commit;
-    ln.packed = 1;
-    ln.ack_stride = 1;
-    if (tick) ln.o_beat = nd.o_beat, ln.o_ae = nd.o_ae;
-    ln.now = now_ms;
-    ln.fsm_delta = nd.cols.fsm_delta, ln.fsm_prev = nd.cols.fsm_prev, ln.fsm_mid = nd.cols.fsm_mid;
-    ln.arr = nd.cols.arr, ln.col_mask = col_mask;  // (the slow kernel replays its groups in arrival order)
-    if ((rc = dense_step(e, nd.cols.answers, 1, &ln))) return rc;
-    if (tick) {
-      HIPCHK(hipMemcpyAsync(nd.h_beat, nd.o_beat, (size_t)G * sizeof(jg_leader_beat), hipMemcpyDeviceToHost, e->stream));
-      // (the own slot's row is JG_NO_ACK on both sides and stays there: not written, not downloaded)
-      const uint32_t own = e->uniform_self >= 0 ? (uint32_t)e->uniform_self : R;
-      if (own > 0) HIPCHK(hipMemcpyAsync(nd.h_ae, nd.o_ae, (size_t)std::min(own, R) * G * 8, hipMemcpyDeviceToHost, e->stream));
-      if (own + 1 < R)
-        HIPCHK(hipMemcpyAsync(nd.h_ae + (size_t)(own + 1) * G, nd.o_ae + (size_t)(own + 1) * G, (size_t)(R - own - 1) * G * 8, hipMemcpyDeviceToHost,
-                              e->stream));
-      bytes_down += (size_t)G * (sizeof(jg_leader_beat) + (size_t)(own < R ? R - 1 : R) * 8);
-    }
-  }
-  if (halves & JG_NODE_FOLLOWER_HALF) {
-    jg_follower_inbox fi{};
-    fi.leader = nd.cols.f_leader, fi.beat = nd.cols.f_beat, fi.ae = nd.cols.f_ae;
-    const jg_follower_outbox fo{nd.o_answer, nd.o_hbc};
-    if ((rc = follower_half(e, now_ms, &fi, &fo, tick ? 1 : 0, nd.cols.fsm_delta, nd.cols.fsm_prev))) return rc;
-    HIPCHK(hipMemcpyAsync(nd.h_answer, nd.o_answer, (size_t)G * 8, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(nd.h_hbc, nd.o_hbc, (size_t)G * 8, hipMemcpyDeviceToHost, e->stream));
-    bytes_down += (size_t)G * 16;
-  }
+  if ((rc = node_dense_halves(e, now_ms, flags, col_mask, async && n ? 1u : 0u, &bytes_down))) return rc;
   {  // fsm_tx rows of the dense halves -> a step record of its own (per-group regions; compacted by the drains)
     StepRec rec;
     rec.n = G;
@@ -1922,7 +1915,9 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     HIPCHK(hipGetLastError());
     e->n_launch++;
     e->recs.push_back(rec);
+    pend.fsm_rec_seq = rec.seq;
   }
+  pend.seq_general = seq0 + 1, pend.seq_end = e->seq;
   HIPCHK(hipEventRecord(nd.ev_out, e->stream));
   if (trace)
     std::fprintf(stderr, "[jg node] %zu rows: uploads + classify + route issued in %.0f us, waited %.0f us (H2D %.1f MB), halves + fsm build + outbox copies issued in %.0f us\n",
@@ -1930,14 +1925,145 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   nd.last = jg_node_outbox{};
   nd.last.rows = n, nd.last.rows_general = n_sparse, nd.last.bytes_h2d = bytes_up, nd.last.bytes_d2h = bytes_down;
   nd.last_flags = flags;
+  pend.on = async && n != 0;  // (nothing is pending when there were no rows: no general path to come back for)
+  return JG_OK;
+}
+
+// The dense halves of a node step + the downloads of their outbox columns.  sparse_mode: 0 every partition; 1 all but
+// the partitions whose rows take the general path (an asynchronous step, first pass); 2 only those (its catch-up pass).
+int node_dense_halves(jg_engine* e, uint64_t now_ms, uint32_t flags, uint32_t col_mask, uint32_t sparse_mode, uint64_t* bytes_down) {
+  jg_engine::NodeStep& nd = e->node;
+  const uint32_t halves = flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF);
+  const bool tick = (flags & JG_NODE_TICK) != 0;
+  const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  int rc = JG_OK;
+  if (halves & JG_NODE_LEADER_HALF) {
+    JgLeaderNode ln{};
+    ln.hbr_commit = nd.cols.hbr_commit;
+    ln.packed = 1;
+    ln.ack_stride = 1;
+    if (tick) ln.o_beat = nd.o_beat, ln.o_ae = nd.o_ae;
+    ln.now = now_ms;
+    ln.fsm_delta = nd.cols.fsm_delta, ln.fsm_prev = nd.cols.fsm_prev, ln.fsm_mid = nd.cols.fsm_mid;
+    ln.arr = nd.cols.arr, ln.col_mask = col_mask;  // (the slow kernel replays its groups in arrival order)
+    if (sparse_mode) ln.sparse_bits = nd.cols.sparse_bits, ln.sparse_mode = sparse_mode;
+    if ((rc = dense_step(e, nd.cols.answers, 1, &ln))) return rc;
+    if (tick) {
+      HIPCHK(hipMemcpyAsync(nd.h_beat, nd.o_beat, (size_t)G * sizeof(jg_leader_beat), hipMemcpyDeviceToHost, e->stream));
+      // (the own slot's row is JG_NO_ACK on both sides and stays there: not written, not downloaded)
+      const uint32_t own = e->uniform_self >= 0 ? (uint32_t)e->uniform_self : R;
+      if (own > 0) HIPCHK(hipMemcpyAsync(nd.h_ae, nd.o_ae, (size_t)std::min(own, R) * G * 8, hipMemcpyDeviceToHost, e->stream));
+      if (own + 1 < R)
+        HIPCHK(hipMemcpyAsync(nd.h_ae + (size_t)(own + 1) * G, nd.o_ae + (size_t)(own + 1) * G, (size_t)(R - own - 1) * G * 8, hipMemcpyDeviceToHost,
+                              e->stream));
+      *bytes_down += (size_t)G * (sizeof(jg_leader_beat) + (size_t)(own < R ? R - 1 : R) * 8);
+    }
+  }
+  if (halves & JG_NODE_FOLLOWER_HALF) {
+    jg_follower_inbox fi{};
+    fi.leader = nd.cols.f_leader, fi.beat = nd.cols.f_beat, fi.ae = nd.cols.f_ae;
+    const jg_follower_outbox fo{nd.o_answer, nd.o_hbc};
+    if ((rc = follower_half(e, now_ms, &fi, &fo, tick ? 1 : 0, nd.cols.fsm_delta, nd.cols.fsm_prev,
+                            sparse_mode ? nd.cols.sparse_bits : nullptr, sparse_mode)))
+      return rc;
+    HIPCHK(hipMemcpyAsync(nd.h_answer, nd.o_answer, (size_t)G * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(nd.h_hbc, nd.o_hbc, (size_t)G * 8, hipMemcpyDeviceToHost, e->stream));
+    *bytes_down += (size_t)G * 16;
+  }
+  return JG_OK;
+}
+
+// The general path of a node step: order-preserving compaction of the flagged rows, a stable sort by group, the batch
+// k_apply_rows takes - exactly jg_submit + jg_step for those partitions, in stream order.
+int node_general(jg_engine* e, const JgNodeRows& rows, uint8_t* d_keep, size_t n, size_t nb, uint32_t n_sparse, uint64_t now_ms) {
+  jg_engine::NodeStep& nd = e->node;
+  Arena& ar = e->arenas[e->cur_arena];
+  int rc = JG_OK;
+  uint32_t *idx = nullptr, *idx2 = nullptr, *keys = nullptr, *keys2 = nullptr;
+  HIPCHK(ar.alloc((size_t)n * 4, (void**)&idx));
+  HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&idx2));
+  HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&keys));
+  HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&keys2));
+  size_t need_a = 0, need_b = 0;
+  rocprim::counting_iterator<uint32_t> iota(0);
+  HIPCHK(rocprim::select(nullptr, need_a, iota, d_keep, idx, nd.d_nsparse + 1, n, e->stream));
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, need_b, keys, keys2, idx, idx2, (size_t)n_sparse, 0, nd.group_bits, e->stream));
+  const size_t need = std::max(need_a, need_b);
+  if (nd.tmp_bytes < need) {
+    if (nd.tmp) HIPCHK(hipFree(nd.tmp));
+    nd.tmp_bytes = 2 * need;
+    HIPCHK(hipMalloc(&nd.tmp, nd.tmp_bytes));
+  }
+  size_t tb = nd.tmp_bytes;
+  HIPCHK(rocprim::select(nd.tmp, tb, iota, d_keep, idx, nd.d_nsparse + 1, n, e->stream));
+  const uint32_t sgrid = (n_sparse + JG_BLOCK - 1) / JG_BLOCK;
+  hipLaunchKernelGGL(k_node_keys, dim3(sgrid), dim3(JG_BLOCK), 0, e->stream, n_sparse, (const uint32_t*)idx, rows.group, keys);
+  tb = nd.tmp_bytes;
+  HIPCHK(rocprim::radix_sort_pairs(nd.tmp, tb, keys, keys2, idx, idx2, (size_t)n_sparse, 0, nd.group_bits, e->stream));
+  JgNodeSorted so{};
+  char* M = nullptr;
+  const size_t ns = n_sparse;
+  HIPCHK(ar.alloc(ns * 34 + 64, (void**)&M));  // 3 x 8 + 2 x 4 + 2 x 1 bytes per row, widest columns first
+  so.term = (uint64_t*)M, M += ns * 8;
+  so.id = (uint64_t*)M, M += ns * 8;
+  so.aux = (uint64_t*)M, M += ns * 8;
+  so.group = (uint32_t*)M, M += ns * 4;
+  so.from = (uint32_t*)M, M += ns * 4;
+  so.kind = (uint8_t*)M, M += ns;
+  so.flag = (uint8_t*)M;
+  hipLaunchKernelGGL(k_node_gather_rows, dim3(sgrid), dim3(JG_BLOCK), 0, e->stream, n_sparse, (const uint32_t*)idx2, rows, so);
+  HIPCHK(hipGetLastError());
+  e->n_launch += 4;
+  if ((rc = launch_rows(e, n_sparse, so.group, so.kind, so.from, so.term, so.id, so.aux, so.flag,
+                        nb ? rows.blk_id : (const uint64_t*)e->d_ones, nb ? rows.blk_next : (const uint64_t*)e->d_ones, nb, now_ms)))
+    return rc;
+  return JG_OK;
+}
+
+// An asynchronous node step is settled the first time anything looks at the engine again: the general-path row count
+// has landed by then; if it is not zero, those rows are applied now (their sequence number was reserved) and the dense
+// halves come back for exactly the partitions they left alone - same results, same record order, one pass later.
+int node_settle(jg_engine* e) {
+  jg_engine::NodeStep& nd = e->node;
+  jg_engine::NodeStep::Pending& pd = nd.pending;
+  if (!pd.on) return JG_OK;
+  pd.on = false;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const uint32_t n_sparse = nd.h_nsparse[0];
+  nd.last.rows_general = n_sparse;
+  if (!n_sparse) return JG_OK;
+  int rc = JG_OK;
+  const uint32_t seq_end = e->seq;
+  e->seq = pd.seq_general;
+  const size_t recs_before = e->recs.size();
+  if ((rc = node_general(e, pd.rows, pd.d_keep, pd.n, pd.nb, n_sparse, pd.now_ms))) return rc;
+  // the general path's record belongs BEFORE the dense halves' fsm record (steps in order)
+  if (e->recs.size() == recs_before + 1) {
+    size_t at = recs_before;
+    while (at > 0 && e->recs[at - 1].seq > pd.seq_general) at--;
+    std::rotate(e->recs.begin() + at, e->recs.begin() + recs_before, e->recs.end());
+  }
+  uint64_t bytes_down = 0;
+  e->seq = pd.seq_general;  // (the halves number themselves from here exactly as in the first pass)
+  if ((rc = node_dense_halves(e, pd.now_ms, pd.flags, pd.col_mask, 2u, &bytes_down))) return rc;
+  for (StepRec& rec : e->recs)
+    if (rec.seq == pd.fsm_rec_seq && rec.fsm_per_row == JGN_FSM_ROWS && rec.msg_per_row == 0) {
+      const uint32_t n_tiles = (e->cfg.n_groups + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
+      hipLaunchKernelGGL(k_node_fsm_build, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rec.d_fsm, rec.d_fsm_cnt, rec.d_bsum_f);
+      e->n_launch++;
+    }
+  HIPCHK(hipGetLastError());
+  e->seq = seq_end;
+  HIPCHK(hipStreamSynchronize(e->stream));
   return JG_OK;
 }
 }  // namespace
 
 int jg_step_node(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   if (!e) return fail(JG_EINVAL, "null argument");
-  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~7u))
-    return fail(JG_EINVAL, "jg_step_node: flags = JG_NODE_LEADER_HALF and / or JG_NODE_FOLLOWER_HALF [| JG_NODE_TICK]");
+  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~15u))
+    return fail(JG_EINVAL, "jg_step_node: flags = JG_NODE_LEADER_HALF and / or JG_NODE_FOLLOWER_HALF [| JG_NODE_TICK] [| JG_NODE_ASYNC]");
   if (e->router) return router_step_node(e, now_ms, flags);
   if (e->inflight.phase) return fail(JG_EINVAL, "a drain is in transfer: jg_drain_wait first");
   return node_step(e, now_ms, flags);

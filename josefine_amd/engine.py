@@ -272,7 +272,8 @@ class BatchedRaft:
         assert a.shape == (self.R, self.G), a.shape
         self._check(self.api.step_dense_acks(self._h, a.ctypes.data))
 
-    def step_node(self, now_ms: int = 0, leader: bool = True, follower: bool = True, tick: bool = True) -> dict:
+    def step_node(self, now_ms: int = 0, leader: bool = True, follower: bool = True, tick: bool = True, async_: bool = False,
+                  between=None) -> dict:
         """jg_step_node: a node's whole tick from the rows submitted since the last step - rows in the
         mailbox vocabulary through the dense kernels, everything else through the general state
         machine first - then Command::Tick for every partition.  Returns the outbox columns (host
@@ -280,8 +281,10 @@ class BatchedRaft:
         row / PCIe byte counts."""
         self._flush_pending()
         flags = (capi.NODE_LEADER_HALF if leader else 0) | (capi.NODE_FOLLOWER_HALF if follower else 0) | \
-                (capi.NODE_TICK if tick else 0)
+                (capi.NODE_TICK if tick else 0) | (capi.NODE_ASYNC if async_ else 0)
         self._check(self.api.step_node(self._h, int(now_ms), flags))
+        if between is not None:  # (async_: what the caller does while the step runs - submits for the next one, say)
+            between()
         o = capi.NodeOutbox()
         self._check(self.api.node_outbox_view(self._h, C.byref(o)))
         G, R = self.G, self.R

@@ -206,9 +206,11 @@ class BatchedRaft {
   // device and classified (the engine's pinned input columns are free again) with the dense halves, the fsm build and the
   // downloads of the outputs still running; the caller decodes the NEXT tick's traffic meanwhile and calls finish() -
   // which waits for the outputs, feeds fsm_tx / rpc_tx / the column sink - right before the next begin().
-  void step_node_begin(uint64_t now_ms, uint32_t flags) {
+  void step_node_begin(uint64_t now_ms, uint32_t flags, bool async = false) {
     flush_rows();
-    check(jg_step_node(e_, now_ms, flags));
+    // async: no synchronisation at all inside the call (JG_NODE_ASYNC) - the engine settles the step (its general path, if
+    // it has one) when step_node_finish asks for the outbox
+    check(jg_step_node(e_, now_ms, flags | (async ? (uint32_t)JG_NODE_ASYNC : 0u)));
     node_step_open_ = true;
   }
   bool node_step_open() const { return node_step_open_; }
@@ -674,7 +676,7 @@ class BatchedEventLoop {
       if (!in_.empty()) raft_.submit_rows(in_.view());
       in_.clear();
       last_at_ = at;
-      raft_.step_node_begin(at, halves | (tick ? (uint32_t)JG_NODE_TICK : 0u));
+      raft_.step_node_begin(at, halves | (tick ? (uint32_t)JG_NODE_TICK : 0u), pipelined);
       if (pipelined) return;
       raft_.step_node_finish(&answers_to_);
     } else {

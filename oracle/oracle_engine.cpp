@@ -674,7 +674,7 @@ int jo_synth_fill_acks(jo_engine* e, uint32_t mode, uint64_t tick, uint64_t* sim
 // the engine reports (which partitions count as rows_general, which messages leave as mailbox columns and
 // which as rows); every partition's rows are applied one command at a time in stream order either way.
 int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
-  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~7u)) return fail(JG_EINVAL, "jg_step_node: bad flags");
+  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~15u)) return fail(JG_EINVAL, "jg_step_node: bad flags");  // (JG_NODE_ASYNC: a matter of when the engine looks at its own counts)
   e->stepped = true;
   const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
   const bool lead_half = flags & JG_NODE_LEADER_HALF, fol_half = flags & JG_NODE_FOLLOWER_HALF, tick = flags & JG_NODE_TICK;

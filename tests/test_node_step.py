@@ -567,3 +567,32 @@ def test_unchecked_rows_are_validated_on_the_device():
     with pytest.raises(EngineError, match="out of range"):
         dev.step_node(200)
         dev.read("term")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,flags,G", [(3, 0, 3000), (5, capi.CFG_SEPARATE_COMMIT_KEY, 3000), (1, 0, 200)])
+def test_node_step_async_parity(R, flags, G):
+    """JG_NODE_ASYNC: the step returns with nothing synchronised - its dense halves leave the general-path partitions
+    alone, the engine comes back for them when the step is settled - and the NEXT tick's rows are submitted (into the
+    second set of pinned columns) before this tick's outbox is asked for.  Every outbox word, state column and drained
+    row equals the oracle's synchronous step."""
+    T = 50
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=31 + R, flags=flags, election_timeout_ms=(700, 1500))
+    general_ticks = 0
+    nxt = node_traffic(rng, ora, token0=0)
+    dev.submit_columns(**nxt)
+    for t in range(T):
+        now = 100 * (t + 1)
+        cols = nxt
+        ora.submit_columns(**cols)
+        b = ora.step_node(now)
+        # (the next tick's traffic is generated from the oracle's state AFTER this tick, and submitted to the device while
+        #  its asynchronous step is still in flight)
+        nxt = node_traffic(rng, ora, token0=1000 * (t + 1), p_noise=0.03 if t % 3 else 0.0, p_reorder=0.08 if t % 3 else 0.0)
+        a = dev.step_node(now, async_=True, between=lambda: dev.submit_columns(**nxt))
+        compare_outboxes(a, b, f"tick {t}")
+        compare_snapshots(dev, ora, f"tick {t}")
+        compare_drains(dev, ora, f"tick {t}")
+        general_ticks += b["rows_general"] > 0
+    assert general_ticks > 5  # (the catch-up pass ran; steps without general rows: tests/cpp/test_event_loop_cluster.cpp, pipelined)
+    assert dev.counters()["decisions"] == ora.counters()["decisions"]
