@@ -229,29 +229,35 @@ __device__ __forceinline__ bool jg_node_group_sparse(const JgNodeCols& c, uint32
   return false;
 }
 
-// Scatter the rows of column-form groups into the inbox columns; flag the others (keep[i] = 1) and
-// count them: *n_sparse, one atomic per workgroup.
+// Scatter the rows of column-form groups into the inbox columns; list the others for the general path.
+// General-path rows are appended to a list as (group << 32 | arrival index, arrival index) pairs - in no particular
+// order: the key says where a row belongs (group-major, a group's rows in the order they arrived) and the bucket
+// ordering of jg_route.h puts it there; *n_sparse counts them.
 __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, JgNodeRows a, int us, uint32_t both_beats,
-                                                         uint8_t* __restrict__ keep, uint32_t* __restrict__ n_sparse) {
-  __shared__ uint32_t s_cnt;
-  if (threadIdx.x == 0) s_cnt = 0;
-  __syncthreads();
+                                                         uint64_t* __restrict__ sp_key, uint32_t* __restrict__ sp_idx,
+                                                         uint32_t* __restrict__ n_sparse) {
   const uint32_t G = d.G;
-  uint32_t mine = 0;
-  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < a.n; i += gridDim.x * JG_BLOCK) {
-    const uint32_t g = a.group[i];
-    if (g >= G || a.kind[i] >= JG_CMD__COUNT) {  // (reported by k_node_classify)
-      keep[i] = 0;
-      continue;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n_up = (a.n + 63u) & ~63u;  // (whole waves take every iteration together: the appends are wave-aggregated)
+  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < n_up; i += gridDim.x * JG_BLOCK) {
+    const bool in = i < a.n;
+    const uint32_t g = in ? a.group[i] : 0u;
+    const bool valid = in && g < G && a.kind[i] < JG_CMD__COUNT;  // (an invalid row: reported by k_node_classify, not applied)
+    const uint32_t w = valid ? c.cls[g] : 0u;
+    const bool sparse = valid && jg_node_group_sparse(c, G, g, w, both_beats);
+    const uint64_t m = __ballot(sparse);
+    if (m) {
+      uint32_t base = 0;
+      if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(n_sparse, (uint32_t)__popcll(m));
+      base = __shfl(base, __ffsll((long long)m) - 1, 64);
+      if (sparse) {
+        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        sp_key[at] = (uint64_t)g << 32 | i;
+        sp_idx[at] = i;
+        (void)__hip_atomic_fetch_or(&c.sparse_bits[g >> 6], 1ull << (g & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
-    const uint32_t w = c.cls[g];
-    const bool sparse = jg_node_group_sparse(c, G, g, w, both_beats);
-    keep[i] = sparse ? 1 : 0;
-    mine += sparse;
-    if (sparse) {
-      (void)__hip_atomic_fetch_or(&c.sparse_bits[g >> 6], 1ull << (g & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      continue;
-    }
+    if (!valid || sparse) continue;
     const uint32_t kind = a.kind[i];
     switch (kind) {
       case JG_CMD_APPEND_RESPONSE: {  // bits 63..8 of the sender's answer word (all ones before)
@@ -296,11 +302,6 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
       }
     }
   }
-#pragma unroll
-  for (int off = 32; off; off >>= 1) mine += __shfl_down(mine, off, 64);
-  if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(&s_cnt, mine);
-  __syncthreads();
-  if (threadIdx.x == 0 && s_cnt) atomicAdd(n_sparse, s_cnt);
 }
 
 // keep-flagged rows, already compacted (stream order) and sorted by group (stable): index list -> the
@@ -326,11 +327,6 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_gather_rows(uint32_t n, const
   o.id[p] = a.id[i];
   o.aux[p] = a.aux_of(i);
   o.flag[p] = a.flag_of(i);
-}
-__global__ __launch_bounds__(JG_BLOCK) void k_node_keys(uint32_t n, const uint32_t* __restrict__ idx,
-                                                        const uint32_t* __restrict__ group, uint32_t* __restrict__ keys) {
-  const uint32_t p = blockIdx.x * JG_BLOCK + threadIdx.x;
-  if (p < n) keys[p] = group[idx[p]];
 }
 
 // ---- fsm_tx rows of the dense halves -------------------------------------------------------------

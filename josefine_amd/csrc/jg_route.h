@@ -565,6 +565,35 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_sort_build(JgRouteBuckets b,
   }
 }
 
+// The same ordering for any list of (64-bit key, 32-bit value) pairs with UNIQUE keys (k_route_hist / _scan /
+// _scan_tiles / _scatter as above, then this instead of k_route_sort_build): one workgroup per bucket ranks its
+// pairs and writes the values in key order.  jg_step_node's general path orders its rows with it (key = group << 32 |
+// arrival index: group-major, a group's rows in the order they arrived) - no library sort on that path either.
+__global__ __launch_bounds__(JG_BLOCK) void k_bucket_order(JgRouteBuckets b, const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
+                                                           uint32_t* __restrict__ val_out) {
+  __shared__ uint64_t s_key[JG_ROUTE_SORT_CAP];
+  __shared__ uint32_t s_val[JG_ROUTE_SORT_CAP];
+  const uint32_t lo = b.off(blockIdx.x), n = b.off(blockIdx.x + 1) - lo;
+  if (!n) return;
+  if (n <= JG_ROUTE_SORT_CAP) {
+    for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) s_key[i] = key[lo + i], s_val[i] = val[lo + i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) {  // rank by counting the smaller keys (unique): n <= 1024
+      const uint64_t k = s_key[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < n; j++) rank += s_key[j] < k;
+      val_out[lo + rank] = s_val[i];
+    }
+    return;
+  }
+  for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) {  // a bucket larger than the LDS tile: ranked in global memory
+    const uint64_t k = key[lo + i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; j++) rank += key[lo + j] < k;
+    val_out[lo + rank] = val[lo + i];
+  }
+}
+
 // The round's counters back to zero in ONE launch each (a hipMemsetAsync is up to three fill kernels of ~4 us, and a
 // round had seven of them): two word ranges; and up to JG_MAX_REPLICAS single words named by pointer.
 __global__ __launch_bounds__(JG_BLOCK) void k_route_clear(uint32_t* __restrict__ a, uint32_t na, uint32_t* __restrict__ b, uint32_t nb) {

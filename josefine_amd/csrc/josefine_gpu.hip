@@ -335,10 +335,15 @@ struct jg_engine {
     uint64_t *h_ae = nullptr, *h_answer = nullptr, *h_hbc = nullptr;
     uint64_t *h_in_answers = nullptr, *h_in_hbc = nullptr;  // pinned [R][G]: column inbound (jg_node_inbox_columns)
     uint32_t col_mask = 0, col_hbc_mask = 0;                // slots handed out for the next step / with their hb_commit column
-    uint32_t* d_nsparse = nullptr;     // {general-path rows, rocprim::select's count}
+    uint32_t* d_nsparse = nullptr;     // {general-path rows}
     uint32_t* h_nsparse = nullptr;     // pinned
-    void* tmp = nullptr;
-    size_t tmp_bytes = 0;
+    // the general path's rows as (group << 32 | arrival index, arrival index) pairs, appended by k_node_route (grow-only),
+    // and the bucket pass that orders them (jg_route.h: hist / scan / scatter + k_bucket_order)
+    uint64_t* sp_key = nullptr;
+    uint32_t* sp_idx = nullptr;
+    size_t sp_cap = 0;
+    uint32_t* bk_mem = nullptr;
+    uint32_t bk_words = 0, bk_buckets = 0, bk_tile_bits = 0;
     uint32_t group_bits = 1;
     hipEvent_t ev_out = nullptr;
     hipEvent_t ev_cols = nullptr;      // behind the uploads of the handed-out columns: the pinned buffers are free again
@@ -347,7 +352,6 @@ struct jg_engine {
     struct Pending {
       bool on = false;
       JgNodeRows rows{};
-      uint8_t* d_keep = nullptr;
       size_t n = 0, nb = 0, fsm_rec_seq = 0;
       uint64_t now_ms = 0;
       uint32_t flags = 0, col_mask = 0, seq_general = 0, seq_leader = 0, seq_follower = 0, seq_end = 0;
@@ -1352,7 +1356,8 @@ void jg_engine_destroy(jg_engine* e) {
   for (void* p : {(void*)e->node.h_beat, (void*)e->node.h_ae, (void*)e->node.h_answer, (void*)e->node.h_hbc, (void*)e->node.h_nsparse,
                   (void*)e->node.h_in_answers, (void*)e->node.h_in_hbc})
     if (p) (void)hipHostFree(p);
-  if (e->node.tmp) (void)hipFree(e->node.tmp);
+  if (e->node.sp_key) (void)hipFree(e->node.sp_key);
+  if (e->node.sp_idx) (void)hipFree(e->node.sp_idx);
   if (e->node.ev_out) (void)hipEventDestroy(e->node.ev_out);
   if (e->node.ev_cols) (void)hipEventDestroy(e->node.ev_cols);
   e->q_msgs.destroy();
@@ -1751,6 +1756,8 @@ int node_ensure(jg_engine* e) {
   A(n.o_answer, G);
   A(n.o_hbc, G);
   A(n.d_nsparse, 4);
+#define A2(ptr, cnt) \
+  if ((rc = dev_alloc(e, &ptr, (cnt))) != JG_OK) return rc
 #undef A
   HIPCHK(hipHostMalloc((void**)&n.h_beat, std::max<size_t>(G * sizeof(jg_leader_beat), 16), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&n.h_ae, std::max<size_t>(R * G * 8, 16), hipHostMallocDefault));
@@ -1763,12 +1770,17 @@ int node_ensure(jg_engine* e) {
   HIPCHK(hipEventCreateWithFlags(&n.ev_out, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&n.ev_cols, hipEventDisableTiming));
   while (n.group_bits < 32 && (G - 1) >> n.group_bits) n.group_bits++;
+  n.bk_tile_bits = std::min<uint32_t>(JG_ROUTE_TILE_BITS, n.group_bits);
+  n.bk_buckets = ((uint32_t)G + (1u << n.bk_tile_bits) - 1u) >> n.bk_tile_bits;
+  const uint32_t bk_tiles = (n.bk_buckets + JG_ROUTE_SCAN_TILE - 1) / JG_ROUTE_SCAN_TILE;
+  n.bk_words = bk_tiles * JG_ROUTE_SCAN_TILE + n.bk_buckets + bk_tiles + 1;  // hist (whole tiles) | cur | tile
+  A2(n.bk_mem, n.bk_words);
   n.ready = true;
   return JG_OK;
 }
 
 int node_dense_halves(jg_engine* e, uint64_t now_ms, uint32_t flags, uint32_t col_mask, uint32_t sparse_mode, uint64_t* bytes_down);
-int node_general(jg_engine* e, const JgNodeRows& rows, uint8_t* d_keep, size_t n, size_t nb, uint32_t n_sparse, uint64_t now_ms);
+int node_general(jg_engine* e, const JgNodeRows& rows, size_t n, size_t nb, uint32_t n_sparse, uint64_t now_ms);
 
 int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   jg_engine::NodeStep& nd = e->node;
@@ -1842,9 +1854,14 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     const size_t bytes = off;
     Arena& ar = e->arenas[e->cur_arena];
     char* B = nullptr;
-    uint8_t* d_keep = nullptr;
     HIPCHK(ar.alloc(bytes, (void**)&B));
-    HIPCHK(ar.alloc(n, (void**)&d_keep));
+    if (nd.sp_cap < n) {  // (room for every row on the general path; grow-only, like the pinned columns)
+      if (nd.sp_key) HIPCHK(hipFree(nd.sp_key));
+      if (nd.sp_idx) HIPCHK(hipFree(nd.sp_idx));
+      nd.sp_cap = n + n / 2;
+      HIPCHK(hipMalloc((void**)&nd.sp_key, nd.sp_cap * 8));
+      HIPCHK(hipMalloc((void**)&nd.sp_idx, nd.sp_cap * 4));
+    }
     auto up = [&](size_t at, const void* src, size_t nbytes) -> hipError_t {
       bytes_up += nbytes;
       return hipMemcpyAsync(B + at, src, nbytes, hipMemcpyHostToDevice, e->stream);
@@ -1873,7 +1890,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     hipLaunchKernelGGL(k_node_classify, dim3(rgrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rows, e->uniform_self,
                        halves, both_beats, col_mask);
     hipLaunchKernelGGL(k_node_route, dim3(rgrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rows, e->uniform_self,
-                       both_beats, d_keep, nd.d_nsparse);
+                       both_beats, nd.sp_key, nd.sp_idx, nd.d_nsparse);
     HIPCHK(hipGetLastError());
     e->n_launch += 3;
     HIPCHK(hipMemcpyAsync(nd.h_nsparse, nd.d_nsparse, 4, hipMemcpyDeviceToHost, e->stream));
@@ -1883,9 +1900,9 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
       HIPCHK(hipStreamSynchronize(e->stream));
       T2 = clk();
       n_sparse = nd.h_nsparse[0];
-      if (n_sparse && (rc = node_general(e, rows, d_keep, n, nb, n_sparse, now_ms))) return rc;
+      if (n_sparse && (rc = node_general(e, rows, n, nb, n_sparse, now_ms))) return rc;
     }
-    pend.rows = rows, pend.d_keep = d_keep, pend.n = n, pend.nb = nb;
+    pend.rows = rows, pend.n = n, pend.nb = nb;
     // the pinned columns: the OTHER set from here on (an asynchronous step's uploads may still be reading this one)
     e->p_kind.flip(), e->p_flag.flip(), e->p_group.flip(), e->p_from.flip(), e->p_term.flip(), e->p_id.flip();
     e->p_aux.flip(), e->p_blk_id.flip(), e->p_blk_next.flip();
@@ -1973,33 +1990,34 @@ int node_dense_halves(jg_engine* e, uint64_t now_ms, uint32_t flags, uint32_t co
   return JG_OK;
 }
 
-// The general path of a node step: order-preserving compaction of the flagged rows, a stable sort by group, the batch
-// k_apply_rows takes - exactly jg_submit + jg_step for those partitions, in stream order.
-int node_general(jg_engine* e, const JgNodeRows& rows, uint8_t* d_keep, size_t n, size_t nb, uint32_t n_sparse, uint64_t now_ms) {
+// The general path of a node step: the rows k_node_route listed (in no particular order) are put into group-major
+// order, a group's rows in the order they arrived, by the bucket pass of jg_route.h - key = group << 32 | arrival index,
+// a bucket = 256 groups, one workgroup ranks a bucket - and become the batch k_apply_rows takes: exactly jg_submit +
+// jg_step for those partitions, in stream order.  (Round 3: rocprim::select + radix_sort_pairs.)
+int node_general(jg_engine* e, const JgNodeRows& rows, size_t n, size_t nb, uint32_t n_sparse, uint64_t now_ms) {
   jg_engine::NodeStep& nd = e->node;
   Arena& ar = e->arenas[e->cur_arena];
   int rc = JG_OK;
-  uint32_t *idx = nullptr, *idx2 = nullptr, *keys = nullptr, *keys2 = nullptr;
-  HIPCHK(ar.alloc((size_t)n * 4, (void**)&idx));
-  HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&idx2));
-  HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&keys));
-  HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&keys2));
-  size_t need_a = 0, need_b = 0;
-  rocprim::counting_iterator<uint32_t> iota(0);
-  HIPCHK(rocprim::select(nullptr, need_a, iota, d_keep, idx, nd.d_nsparse + 1, n, e->stream));
-  HIPCHK(rocprim::radix_sort_pairs(nullptr, need_b, keys, keys2, idx, idx2, (size_t)n_sparse, 0, nd.group_bits, e->stream));
-  const size_t need = std::max(need_a, need_b);
-  if (nd.tmp_bytes < need) {
-    if (nd.tmp) HIPCHK(hipFree(nd.tmp));
-    nd.tmp_bytes = 2 * need;
-    HIPCHK(hipMalloc(&nd.tmp, nd.tmp_bytes));
-  }
-  size_t tb = nd.tmp_bytes;
-  HIPCHK(rocprim::select(nd.tmp, tb, iota, d_keep, idx, nd.d_nsparse + 1, n, e->stream));
+  (void)n;
+  uint64_t* key_alt = nullptr;
+  uint32_t *idx_alt = nullptr, *order = nullptr;
+  HIPCHK(ar.alloc((size_t)n_sparse * 8, (void**)&key_alt));
+  HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&idx_alt));
+  HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&order));
+  JgRouteBuckets bk{};
+  bk.n_buckets = nd.bk_buckets, bk.shift = 32 + nd.bk_tile_bits;
+  const uint32_t bk_tiles = (bk.n_buckets + JG_ROUTE_SCAN_TILE - 1) / JG_ROUTE_SCAN_TILE;
+  bk.hist = nd.bk_mem, bk.cur = bk.hist + (size_t)bk_tiles * JG_ROUTE_SCAN_TILE, bk.tile = bk.cur + bk.n_buckets;
+  hipStream_t st = e->stream;
+  hipLaunchKernelGGL(k_route_clear, dim3(64), dim3(JG_BLOCK), 0, st, bk.hist, bk_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets, bk.tile, bk_tiles + 1);
+  const uint32_t grid = std::min<uint32_t>((n_sparse + JG_BLOCK - 1) / JG_BLOCK, 4096);
+  hipLaunchKernelGGL(k_route_hist, dim3(grid, 1), dim3(JG_BLOCK), 0, st, (const uint32_t*)nd.d_nsparse, (uint32_t)nd.sp_cap, (const uint64_t*)nd.sp_key, bk);
+  hipLaunchKernelGGL(k_route_scan, dim3(bk_tiles), dim3(JG_BLOCK), 0, st, bk);
+  hipLaunchKernelGGL(k_route_scan_tiles, dim3(1), dim3(JG_BLOCK), 0, st, bk);
+  hipLaunchKernelGGL(k_route_scatter, dim3(grid, 1), dim3(JG_BLOCK), 0, st, (const uint32_t*)nd.d_nsparse, (uint32_t)nd.sp_cap, (const uint64_t*)nd.sp_key,
+                     (const uint32_t*)nd.sp_idx, bk, key_alt, idx_alt);
+  hipLaunchKernelGGL(k_bucket_order, dim3(bk.n_buckets), dim3(JG_BLOCK), 0, st, bk, (const uint64_t*)key_alt, (const uint32_t*)idx_alt, order);
   const uint32_t sgrid = (n_sparse + JG_BLOCK - 1) / JG_BLOCK;
-  hipLaunchKernelGGL(k_node_keys, dim3(sgrid), dim3(JG_BLOCK), 0, e->stream, n_sparse, (const uint32_t*)idx, rows.group, keys);
-  tb = nd.tmp_bytes;
-  HIPCHK(rocprim::radix_sort_pairs(nd.tmp, tb, keys, keys2, idx, idx2, (size_t)n_sparse, 0, nd.group_bits, e->stream));
   JgNodeSorted so{};
   char* M = nullptr;
   const size_t ns = n_sparse;
@@ -2011,9 +2029,9 @@ int node_general(jg_engine* e, const JgNodeRows& rows, uint8_t* d_keep, size_t n
   so.from = (uint32_t*)M, M += ns * 4;
   so.kind = (uint8_t*)M, M += ns;
   so.flag = (uint8_t*)M;
-  hipLaunchKernelGGL(k_node_gather_rows, dim3(sgrid), dim3(JG_BLOCK), 0, e->stream, n_sparse, (const uint32_t*)idx2, rows, so);
+  hipLaunchKernelGGL(k_node_gather_rows, dim3(sgrid), dim3(JG_BLOCK), 0, st, n_sparse, (const uint32_t*)order, rows, so);
   HIPCHK(hipGetLastError());
-  e->n_launch += 4;
+  e->n_launch += 7;
   if ((rc = launch_rows(e, n_sparse, so.group, so.kind, so.from, so.term, so.id, so.aux, so.flag,
                         nb ? rows.blk_id : (const uint64_t*)e->d_ones, nb ? rows.blk_next : (const uint64_t*)e->d_ones, nb, now_ms)))
     return rc;
@@ -2037,7 +2055,7 @@ int node_settle(jg_engine* e) {
   const uint32_t seq_end = e->seq;
   e->seq = pd.seq_general;
   const size_t recs_before = e->recs.size();
-  if ((rc = node_general(e, pd.rows, pd.d_keep, pd.n, pd.nb, n_sparse, pd.now_ms))) return rc;
+  if ((rc = node_general(e, pd.rows, pd.n, pd.nb, n_sparse, pd.now_ms))) return rc;
   // the general path's record belongs BEFORE the dense halves' fsm record (steps in order)
   if (e->recs.size() == recs_before + 1) {
     size_t at = recs_before;
