@@ -249,6 +249,7 @@ struct jg_engine {
   struct DrainBatch {
     std::vector<StepRec> recs;
     int arena = 0, set = 0, phase = 0;
+    uint32_t seq_hi = 0;  // the engine's step number when the batch was formed (every record of it is at or below)
     bool to_landing = false;  // rows go to l_msgs / l_fsm (from offset 0) instead of behind q_msgs / q_fsm
     size_t at_m = 0, at_f = 0, add_m = 0, add_f = 0;
     uint32_t nf = 0, nx = 0;
@@ -295,6 +296,9 @@ struct jg_engine {
   jg_fault_row* fs_rows = nullptr;
   void* fs_tmp = nullptr;
   size_t fs_cap = 0, fs_tmp_bytes = 0;
+  uint32_t* fs_bk = nullptr;  // the fault sort's bucket counters (grow-only)
+  size_t fs_bk_words = 0;
+  uint32_t fault_floor[2] = {0, 0};  // per buffer set: a step number below every record the set can hold
   PinnedQueue<JgXqRec> h_xq;
   // the gathers compact into device memory and ONE copy per queue takes the rows to the pinned host
   // queue (a DMA engine's work, not the gather kernels' across PCIe)
@@ -561,11 +565,37 @@ int sync_and_check(jg_engine* e) {
 // in queue order (= emission order: one lane owns a group for a step).  They are sorted on the
 // device, on the stream that drains them: a stable LSD radix sort (rocPRIM) of (step << 32 | group)
 // keys.  (On the host this was the largest single cost of a configs[4] drain: 0.9 ms per 160 k records.)
-__global__ void k_fault_split(const JgFaultRec* __restrict__ q, uint32_t n, uint64_t* __restrict__ keys,
-                              uint32_t* __restrict__ vals) {
+// Round 4: no library sort here either.  key = (step - floor) << bits(G) | group with `floor` below every step of the
+// batch, value = the record's position in the queue; the bucket pass of jg_route.h (a bucket = the key's top 16 bits or
+// fewer) + k_fault_order, which ranks a bucket's pairs by (key, queue position): equal keys keep their queue order.
+__global__ void k_fault_split(const JgFaultRec* __restrict__ q, uint32_t n, uint32_t floor, uint32_t group_bits,
+                              uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    keys[i] = ((uint64_t)q[i].seq << 32) | q[i].group;
-    vals[i] = q[i].code;
+    keys[i] = ((uint64_t)(q[i].seq - floor) << group_bits) | q[i].group;
+    vals[i] = i;
+  }
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_fault_order(JgRouteBuckets b, const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
+                                                          uint32_t* __restrict__ val_out) {
+  __shared__ uint64_t s_key[JG_ROUTE_SORT_CAP];
+  __shared__ uint32_t s_val[JG_ROUTE_SORT_CAP];
+  const uint32_t lo = b.off(blockIdx.x), n = b.off(blockIdx.x + 1) - lo;
+  if (!n) return;
+  const bool lds = n <= JG_ROUTE_SORT_CAP;
+  if (lds) {
+    for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) s_key[i] = key[lo + i], s_val[i] = val[lo + i];
+    __syncthreads();
+  }
+  for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) {
+    const uint64_t k = lds ? s_key[i] : key[lo + i];
+    const uint32_t v = lds ? s_val[i] : val[lo + i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; j++) {
+      const uint64_t kj = lds ? s_key[j] : key[lo + j];
+      const uint32_t vj = lds ? s_val[j] : val[lo + j];
+      rank += kj < k || (kj == k && vj < v);
+    }
+    val_out[lo + rank] = v;
   }
 }
 // the same for the rows of jg_chain_compact_resident: key = (group, position in the walk), value = id
@@ -582,11 +612,12 @@ __global__ void k_compact_join(const uint64_t* __restrict__ keys, const uint64_t
     rows[i] = jg_compact_row{(uint32_t)(keys[i] >> 8), 0, vals[i]};
 }
 
-__global__ void k_fault_join(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
+__global__ void k_fault_join(const JgFaultRec* __restrict__ q, const uint32_t* __restrict__ order, uint32_t n,
                              jg_fault_row* __restrict__ rows, uint32_t* __restrict__ seqs) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    rows[i] = jg_fault_row{(uint32_t)keys[i], vals[i]};
-    seqs[i] = (uint32_t)(keys[i] >> 32);
+    const JgFaultRec r = q[order[i]];
+    rows[i] = jg_fault_row{r.group, r.code};
+    seqs[i] = r.seq;
   }
 }
 
@@ -701,21 +732,38 @@ int drain_gather(jg_engine* e, jg_engine::DrainBatch& b, const std::vector<StepR
       HIPCHK(hipMalloc((void**)&e->fs_seq, e->fs_cap * 4));
       HIPCHK(hipMalloc((void**)&e->fs_rows, e->fs_cap * sizeof(jg_fault_row)));
     }
-    size_t need = 0;
-    HIPCHK(rocprim::radix_sort_pairs(nullptr, need, e->fs_k0, e->fs_k1, e->fs_v0, e->fs_v1, n, 0, 64, st));
-    if (e->fs_tmp_bytes < need) {
-      if (e->fs_tmp) HIPCHK(hipFree(e->fs_tmp));
-      e->fs_tmp_bytes = 2 * need;
-      HIPCHK(hipMalloc(&e->fs_tmp, e->fs_tmp_bytes));
+    // the key's layout and the buckets: (step - floor) << bits(G) | group, a bucket = its top 16 bits at most
+    uint32_t gb = 1;
+    while (gb < 32 && (e->cfg.n_groups - 1) >> gb) gb++;
+    const uint32_t floor = e->fault_floor[b.set];
+    const uint64_t k_max = ((uint64_t)(b.seq_hi - floor) << gb) | (e->cfg.n_groups - 1);
+    uint32_t bits = 0;
+    while (bits < 64 && (k_max >> bits)) bits++;
+    JgRouteBuckets bk{};
+    bk.shift = bits > 16 ? bits - 16 : 0;
+    bk.n_buckets = (uint32_t)(k_max >> bk.shift) + 1;
+    const uint32_t bk_tiles = (bk.n_buckets + JG_ROUTE_SCAN_TILE - 1) / JG_ROUTE_SCAN_TILE;
+    const size_t bk_words = (size_t)bk_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets + bk_tiles + 1;
+    if (e->fs_bk_words < bk_words) {
+      if (e->fs_bk) HIPCHK(hipFree(e->fs_bk));
+      e->fs_bk_words = bk_words;
+      HIPCHK(hipMalloc((void**)&e->fs_bk, bk_words * 4));
     }
+    bk.hist = e->fs_bk, bk.cur = bk.hist + (size_t)bk_tiles * JG_ROUTE_SCAN_TILE, bk.tile = bk.cur + bk.n_buckets;
     g2 = now();
     const uint32_t grid = grid_for(n, 1024);
-    hipLaunchKernelGGL(k_fault_split, dim3(grid), dim3(JG_BLOCK), 0, st, (const JgFaultRec*)e->fq[b.set], (uint32_t)n,
+    const uint32_t* d_n = e->d_status + (b.set ? 6 : 3);  // (the queue's own count word: the bucket pass reads it on the device)
+    hipLaunchKernelGGL(k_fault_split, dim3(grid), dim3(JG_BLOCK), 0, st, (const JgFaultRec*)e->fq[b.set], (uint32_t)n, floor, gb,
                        e->fs_k0, e->fs_v0);
-    size_t tmp_bytes = e->fs_tmp_bytes;
-    HIPCHK(rocprim::radix_sort_pairs(e->fs_tmp, tmp_bytes, e->fs_k0, e->fs_k1, e->fs_v0, e->fs_v1, n, 0, 64, st));
-    hipLaunchKernelGGL(k_fault_join, dim3(grid), dim3(JG_BLOCK), 0, st, (const uint64_t*)e->fs_k1,
-                       (const uint32_t*)e->fs_v1, (uint32_t)n, e->fs_rows, e->fs_seq);
+    hipLaunchKernelGGL(k_route_clear, dim3(64), dim3(JG_BLOCK), 0, st, bk.hist, bk_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets, bk.tile, bk_tiles + 1);
+    hipLaunchKernelGGL(k_route_hist, dim3(grid, 1), dim3(JG_BLOCK), 0, st, d_n, (uint32_t)e->fs_cap, (const uint64_t*)e->fs_k0, bk);
+    hipLaunchKernelGGL(k_route_scan, dim3(bk_tiles), dim3(JG_BLOCK), 0, st, bk);
+    hipLaunchKernelGGL(k_route_scan_tiles, dim3(1), dim3(JG_BLOCK), 0, st, bk);
+    hipLaunchKernelGGL(k_route_scatter, dim3(grid, 1), dim3(JG_BLOCK), 0, st, d_n, (uint32_t)e->fs_cap, (const uint64_t*)e->fs_k0,
+                       (const uint32_t*)e->fs_v0, bk, e->fs_k1, e->fs_v1);
+    hipLaunchKernelGGL(k_fault_order, dim3(bk.n_buckets), dim3(JG_BLOCK), 0, st, bk, (const uint64_t*)e->fs_k1, (const uint32_t*)e->fs_v1, e->fs_v0);
+    hipLaunchKernelGGL(k_fault_join, dim3(grid), dim3(JG_BLOCK), 0, st, (const JgFaultRec*)e->fq[b.set], (const uint32_t*)e->fs_v0, (uint32_t)n,
+                       e->fs_rows, e->fs_seq);
     HIPCHK(hipGetLastError());
     g3 = now();
     HIPCHK(e->h_faults.reserve(2 * n));  // (headroom: the count wobbles from batch to batch, pinned reallocation is slow)
@@ -906,7 +954,9 @@ int drain_prefetch(jg_engine* e, bool wait) {
   e->cur_arena ^= 1;
   // kernels launched from here on append to the other fault / exceptional-row queues
   b.set = e->cur_set;
+  b.seq_hi = e->seq;
   e->cur_set ^= 1;
+  e->fault_floor[e->cur_set] = e->seq;  // (what the other set collects from here on is later than this point)
   e->dev = dev_for_set(e, e->cur_set);
   e->d_dev = e->d_dev2[e->cur_set];  // (both device copies were written up front: nothing to upload here)
   HIPCHK(hipEventRecord(e->ev_steps, e->stream));
@@ -959,6 +1009,7 @@ int collect(jg_engine* e, int release_mask) {
   const double t1 = now();
   jg_engine::DrainBatch b;
   b.set = e->cur_set;
+  b.seq_hi = e->seq;
   b.nf = e->h_status[b.set ? 6 : 3], b.nx = e->h_status[b.set ? 7 : 4];
   const size_t nrec = e->recs.size();
   rc = drain_scan(e, e->recs, e->stream);
@@ -970,6 +1021,7 @@ int collect(jg_engine* e, int release_mask) {
   if (nrec || b.nf || b.nx) HIPCHK(hipStreamSynchronize(e->stream));
   const double t3 = now();
   rc = drain_finish(e, b, e->recs, e->arenas[e->cur_arena]);
+  e->fault_floor[b.set] = b.seq_hi;  // (the set is empty again: whatever it collects next is later than this batch)
   if (trace && nrec)
     std::fprintf(stderr, "[jg drain] %zu steps: sync %.3f ms, scan %.3f ms, gather+copy %.3f ms, host tail %.3f ms (%zu msg rows, %u faults)\n",
                  nrec, t1 - t0, t2 - t1, t3 - t2, now() - t3, e->q_msgs.n, b.nf);
@@ -1356,6 +1408,7 @@ void jg_engine_destroy(jg_engine* e) {
   for (void* p : {(void*)e->node.h_beat, (void*)e->node.h_ae, (void*)e->node.h_answer, (void*)e->node.h_hbc, (void*)e->node.h_nsparse,
                   (void*)e->node.h_in_answers, (void*)e->node.h_in_hbc})
     if (p) (void)hipHostFree(p);
+  if (e->fs_bk) (void)hipFree(e->fs_bk);
   if (e->node.sp_key) (void)hipFree(e->node.sp_key);
   if (e->node.sp_idx) (void)hipFree(e->node.sp_idx);
   if (e->node.ev_out) (void)hipEventDestroy(e->node.ev_out);
