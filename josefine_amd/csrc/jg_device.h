@@ -63,11 +63,13 @@ struct JgFaultRec {
 // seven of them are one sector this way.  The dense follower half reads the record with two 16-byte loads per lane,
 // lanes side by side: as coalesced as the seven columns were.
 struct __attribute__((aligned(32))) JgCold {
+  // first 16 bytes: the election timer - what a Heartbeat rewrites (follower.rs:103-113), every other round in steady state
   uint64_t election_time;     // State.election_time (ms)               mod.rs:281
-  uint32_t voted_for;         // State.voted_for                        mod.rs:279
-  uint32_t leader_id;         // Follower.leader_id                     follower.rs:20
   uint32_t election_timeout;  // State.election_timeout (ms)            mod.rs:283
   uint32_t rng_draws;         // draws taken from the timeout RNG
+  // second 16 bytes: what changes with leadership only
+  uint32_t voted_for;         // State.voted_for                        mod.rs:279
+  uint32_t leader_id;         // Follower.leader_id                     follower.rs:20
   uint32_t queued;            // queued_reqs.len()                      follower.rs:22
   uint32_t votes;             // Election.votes: seen | granted << 8    election.rs:8
                               //   bits 16-23 / 24-31: the same two masks for voters OUTSIDE the membership
@@ -77,12 +79,25 @@ __device__ __forceinline__ JgCold jg_cold_load(const JgCold* p) {
   const uint4 a = ((const uint4*)p)[0], b = ((const uint4*)p)[1];
   JgCold c;
   c.election_time = (uint64_t)a.x | (uint64_t)a.y << 32;
-  c.voted_for = a.z, c.leader_id = a.w, c.election_timeout = b.x, c.rng_draws = b.y, c.queued = b.z, c.votes = b.w;
+  c.election_timeout = a.z, c.rng_draws = a.w, c.voted_for = b.x, c.leader_id = b.y, c.queued = b.z, c.votes = b.w;
   return c;
 }
+__device__ __forceinline__ void jg_cold_store_timer(JgCold* p, const JgCold& c) {  // (the first half only)
+  ((uint4*)p)[0] = make_uint4((uint32_t)c.election_time, (uint32_t)(c.election_time >> 32), c.election_timeout, c.rng_draws);
+}
+__device__ __forceinline__ void jg_cold_store_rest(JgCold* p, const JgCold& c) {
+  ((uint4*)p)[1] = make_uint4(c.voted_for, c.leader_id, c.queued, c.votes);
+}
 __device__ __forceinline__ void jg_cold_store(JgCold* p, const JgCold& c) {
-  ((uint4*)p)[0] = make_uint4((uint32_t)c.election_time, (uint32_t)(c.election_time >> 32), c.voted_for, c.leader_id);
-  ((uint4*)p)[1] = make_uint4(c.election_timeout, c.rng_draws, c.queued, c.votes);
+  jg_cold_store_timer(p, c);
+  jg_cold_store_rest(p, c);
+}
+__device__ __forceinline__ JgCold jg_cold_of(uint64_t election_time, uint32_t voted_for, uint32_t leader_id, uint32_t election_timeout,
+                                             uint32_t rng_draws, uint32_t queued, uint32_t votes) {
+  JgCold c;
+  c.election_time = election_time, c.election_timeout = election_timeout, c.rng_draws = rng_draws;
+  c.voted_for = voted_for, c.leader_id = leader_id, c.queued = queued, c.votes = votes;
+  return c;
 }
 
 struct JgDev {
@@ -286,7 +301,7 @@ __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   d.id_gen[g] = L.id_gen;
   d.run_hi[g] = L.run_hi;
   d.heartbeat_time[g] = L.heartbeat_time;
-  jg_cold_store(d.cold + g, JgCold{L.election_time, L.voted_for, L.leader_id, L.election_timeout, L.rng_draws, L.queued, L.votes});
+  jg_cold_store(d.cold + g, jg_cold_of(L.election_time, L.voted_for, L.leader_id, L.election_timeout, L.rng_draws, L.queued, L.votes));
 }
 
 __device__ inline int jg_slot_of(const JgDev& d, uint32_t node_id);
@@ -328,7 +343,7 @@ __device__ inline void jg_store_dirty(const JgDev& d, JgLane& L, const JgLane& O
   if (L.heartbeat_time != O.heartbeat_time) d.heartbeat_time[g] = L.heartbeat_time;
   if (L.election_time != O.election_time || L.voted_for != O.voted_for || L.leader_id != O.leader_id ||
       L.election_timeout != O.election_timeout || L.rng_draws != O.rng_draws || L.queued != O.queued || L.votes != O.votes)
-    jg_cold_store(d.cold + g, JgCold{L.election_time, L.voted_for, L.leader_id, L.election_timeout, L.rng_draws, L.queued, L.votes});
+    jg_cold_store(d.cold + g, jg_cold_of(L.election_time, L.voted_for, L.leader_id, L.election_timeout, L.rng_draws, L.queued, L.votes));
 }
 
 // ---- output rows ------------------------------------------------------------------

@@ -190,8 +190,11 @@ __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollower
     if (head != head0) d.head[g] = head;
     if (commit != commit0) d.commit[g] = commit;
     jg_follower_fsm_note(a, g, commit0, commit);
-    if (voted_for != vf0 || leader_id != lid0 || timer_dirty)
-      jg_cold_store(d.cold + g, JgCold{et, voted_for, leader_id, eto, draws, queued, cold0.votes});
+    {  // (a heartbeat rewrites the timer half of the record; the other half only when the vote or the leader changed)
+      const JgCold c = jg_cold_of(et, voted_for, leader_id, eto, draws, queued, cold0.votes);
+      if (timer_dirty) jg_cold_store_timer(d.cold + g, c);
+      if (voted_for != vf0 || leader_id != lid0) jg_cold_store_rest(d.cold + g, c);
+    }
     if (nf != f) d.flags[g] = nf;
     // (divergent use of the wave-aggregated push is fine: the ballot covers the active lanes)
     jg_defer_push(d, g, tick_defer, JG_DEFER_TICK_ONLY);
