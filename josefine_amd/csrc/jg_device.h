@@ -57,40 +57,50 @@ struct JgFaultRec {
 
 // Structure-of-arrays state in HBM; column c of group g is c[g], replica-major
 // for the [R][G] / [W][G] arrays so that a wave reads contiguous lanes.
-// What the elections and the timers of a group touch, in ONE 32-byte record: the general state machine visits a
-// group here and a group there, and every column it reads is a memory transaction of its own (a 64-byte sector per
-// 4-byte value: the routed round's state machine launch fetched 1.5 KB per group visit, profiles/README.md round 3) -
-// seven of them are one sector this way.  The dense follower half reads the record with two 16-byte loads per lane,
-// lanes side by side: as coalesced as the seven columns were.
-struct __attribute__((aligned(32))) JgCold {
-  // first 16 bytes: the election timer - what a Heartbeat rewrites (follower.rs:103-113), every other round in steady state
+// What the elections and the timers of a group touch, in TWO 16-byte records (two arrays): the general state machine
+// visits a group here and a group there, and every column it reads is a memory transaction of its own (a 64-byte
+// sector per 4-byte value: the routed round's state machine launch fetched 1.5 KB per group visit, profiles/README.md
+// round 3) - seven of them are two sectors this way.  The dense follower half reads each with one 16-byte load per
+// lane, lanes side by side (as coalesced as the seven columns were), and a Heartbeat's timer store is one 16-byte
+// store per lane into the timer array: whole sectors, nothing but the timer rewritten.
+struct JgCold {
+  // cold_t[g]: the election timer - what a Heartbeat rewrites (follower.rs:103-113), every other round in steady state
   uint64_t election_time;     // State.election_time (ms)               mod.rs:281
   uint32_t election_timeout;  // State.election_timeout (ms)            mod.rs:283
   uint32_t rng_draws;         // draws taken from the timeout RNG
-  // second 16 bytes: what changes with leadership only
+  // cold_v[g]: what changes with leadership only
   uint32_t voted_for;         // State.voted_for                        mod.rs:279
   uint32_t leader_id;         // Follower.leader_id                     follower.rs:20
   uint32_t queued;            // queued_reqs.len()                      follower.rs:22
   uint32_t votes;             // Election.votes: seen | granted << 8    election.rs:8
                               //   bits 16-23 / 24-31: the same two masks for voters OUTSIDE the membership
 };
-static_assert(sizeof(JgCold) == 32, "JgCold is one 32-byte record");
-__device__ __forceinline__ JgCold jg_cold_load(const JgCold* p) {
-  const uint4 a = ((const uint4*)p)[0], b = ((const uint4*)p)[1];
+struct JgColdCols {
+  uint4* t;  // [G] {election_time lo, hi, election_timeout, rng_draws}
+  uint4* v;  // [G] {voted_for, leader_id, queued, votes}
+};
+#define JG_COLD_T_ELECTION_TIME 0
+#define JG_COLD_T_ELECTION_TIMEOUT 8
+#define JG_COLD_V_VOTED_FOR 0
+#define JG_COLD_V_LEADER_ID 4
+#define JG_COLD_V_QUEUED 8
+#define JG_COLD_V_VOTES 12
+__device__ __forceinline__ JgCold jg_cold_load(const JgColdCols& p, uint32_t g) {
+  const uint4 a = p.t[g], b = p.v[g];
   JgCold c;
   c.election_time = (uint64_t)a.x | (uint64_t)a.y << 32;
   c.election_timeout = a.z, c.rng_draws = a.w, c.voted_for = b.x, c.leader_id = b.y, c.queued = b.z, c.votes = b.w;
   return c;
 }
-__device__ __forceinline__ void jg_cold_store_timer(JgCold* p, const JgCold& c) {  // (the first half only)
-  ((uint4*)p)[0] = make_uint4((uint32_t)c.election_time, (uint32_t)(c.election_time >> 32), c.election_timeout, c.rng_draws);
+__device__ __forceinline__ void jg_cold_store_timer(const JgColdCols& p, uint32_t g, const JgCold& c) {
+  p.t[g] = make_uint4((uint32_t)c.election_time, (uint32_t)(c.election_time >> 32), c.election_timeout, c.rng_draws);
 }
-__device__ __forceinline__ void jg_cold_store_rest(JgCold* p, const JgCold& c) {
-  ((uint4*)p)[1] = make_uint4(c.voted_for, c.leader_id, c.queued, c.votes);
+__device__ __forceinline__ void jg_cold_store_rest(const JgColdCols& p, uint32_t g, const JgCold& c) {
+  p.v[g] = make_uint4(c.voted_for, c.leader_id, c.queued, c.votes);
 }
-__device__ __forceinline__ void jg_cold_store(JgCold* p, const JgCold& c) {
-  jg_cold_store_timer(p, c);
-  jg_cold_store_rest(p, c);
+__device__ __forceinline__ void jg_cold_store(const JgColdCols& p, uint32_t g, const JgCold& c) {
+  jg_cold_store_timer(p, g, c);
+  jg_cold_store_rest(p, g, c);
 }
 __device__ __forceinline__ JgCold jg_cold_of(uint64_t election_time, uint32_t voted_for, uint32_t leader_id, uint32_t election_timeout,
                                              uint32_t rng_draws, uint32_t queued, uint32_t votes) {
@@ -117,7 +127,7 @@ struct JgDev {
   uint64_t* win_hi;          // [W][G]   last id,
   uint64_t* win_next;        // [W][G]   parent pointer of the first id
   uint32_t* flags;
-  JgCold* cold;              // [G] election timer, vote, leader id, timeout, RNG draws, queue length, vote masks
+  JgColdCols cold;           // [G] x 2: election timer, timeout, RNG draws | vote, leader id, queue length, vote masks
   uint32_t* fvote_id;        // [JG_FOREIGN_VOTERS][G] their NodeIds (election.rs:33-35 counts whoever answers)
   uint64_t* blk_decisions;   // per-workgroup decision counters (no atomics on the hot path)
   JgFaultRec* fault_q;
@@ -257,7 +267,7 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
   L.run_hi = (L.flags & JGF_RUN) ? L.head : d.run_hi[g];
   L.heartbeat_time = d.heartbeat_time[g];
   {
-    const JgCold c = jg_cold_load(d.cold + g);
+    const JgCold c = jg_cold_load(d.cold, g);
     L.election_time = c.election_time, L.voted_for = c.voted_for, L.leader_id = c.leader_id;
     L.election_timeout = c.election_timeout, L.rng_draws = c.rng_draws, L.queued = c.queued, L.votes = c.votes;
   }
@@ -301,7 +311,7 @@ __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   d.id_gen[g] = L.id_gen;
   d.run_hi[g] = L.run_hi;
   d.heartbeat_time[g] = L.heartbeat_time;
-  jg_cold_store(d.cold + g, jg_cold_of(L.election_time, L.voted_for, L.leader_id, L.election_timeout, L.rng_draws, L.queued, L.votes));
+  jg_cold_store(d.cold, g, jg_cold_of(L.election_time, L.voted_for, L.leader_id, L.election_timeout, L.rng_draws, L.queued, L.votes));
 }
 
 __device__ inline int jg_slot_of(const JgDev& d, uint32_t node_id);
@@ -343,7 +353,7 @@ __device__ inline void jg_store_dirty(const JgDev& d, JgLane& L, const JgLane& O
   if (L.heartbeat_time != O.heartbeat_time) d.heartbeat_time[g] = L.heartbeat_time;
   if (L.election_time != O.election_time || L.voted_for != O.voted_for || L.leader_id != O.leader_id ||
       L.election_timeout != O.election_timeout || L.rng_draws != O.rng_draws || L.queued != O.queued || L.votes != O.votes)
-    jg_cold_store(d.cold + g, jg_cold_of(L.election_time, L.voted_for, L.leader_id, L.election_timeout, L.rng_draws, L.queued, L.votes));
+    jg_cold_store(d.cold, g, jg_cold_of(L.election_time, L.voted_for, L.leader_id, L.election_timeout, L.rng_draws, L.queued, L.votes));
 }
 
 // ---- output rows ------------------------------------------------------------------

@@ -88,8 +88,8 @@ __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollower
     const uint32_t lead = ANY ? jg_member_id(d, own) : (a.leader ? a.leader[g] : a.leader_id);
     uint64_t term = d.term[g], head = d.head[g], commit = d.commit[g];
     // the vote, the leader id, the queue length and the election timer (a heartbeat redraws it: rng_draws; a Tick
-    // without one reads it): one 32-byte record, two 16-byte loads
-    const JgCold cold0 = jg_cold_load(d.cold + g);
+    // without one reads it): two 16-byte records, one 16-byte load each
+    const JgCold cold0 = jg_cold_load(d.cold, g);
     uint32_t voted_for = cold0.voted_for, leader_id = cold0.leader_id;
     const uint32_t queued = cold0.queued;
     uint32_t draws = cold0.rng_draws;
@@ -192,8 +192,8 @@ __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollower
     jg_follower_fsm_note(a, g, commit0, commit);
     {  // (a heartbeat rewrites the timer half of the record; the other half only when the vote or the leader changed)
       const JgCold c = jg_cold_of(et, voted_for, leader_id, eto, draws, queued, cold0.votes);
-      if (timer_dirty) jg_cold_store_timer(d.cold + g, c);
-      if (voted_for != vf0 || leader_id != lid0) jg_cold_store_rest(d.cold + g, c);
+      if (timer_dirty) jg_cold_store_timer(d.cold, g, c);
+      if (voted_for != vf0 || leader_id != lid0) jg_cold_store_rest(d.cold, g, c);
     }
     if (nf != f) d.flags[g] = nf;
     // (divergent use of the wave-aggregated push is fine: the ballot covers the active lanes)

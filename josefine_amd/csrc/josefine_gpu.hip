@@ -1312,7 +1312,8 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.win_hi, G * JG_CHAIN_WINDOW);
   A(d.win_next, G * JG_CHAIN_WINDOW);
   A(d.flags, G);
-  A(d.cold, G);
+  A(d.cold.t, G);
+  A(d.cold.v, G);
   A(d.fvote_id, G * JG_FOREIGN_VOTERS);
   A(d.blk_decisions, e->count_slots);
   d.fault_q_cap = (uint32_t)std::max<size_t>(2 * G, 1024);
@@ -3327,14 +3328,14 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
     HIPCHK(hipMemcpy(t64.data(), col + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
     return JG_OK;
   };
-  // a field of the 32-byte cold record (JgCold), for groups [g0, g0 + n): a strided copy
-  auto cold_field = [&](size_t offset, size_t width, void* dst) -> int {
-    HIPCHK(hipMemcpy2D(dst, width, (const char*)(d.cold + g0) + offset, sizeof(JgCold), width, n, hipMemcpyDeviceToHost));
+  // a field of one of the two 16-byte cold records (JgColdCols), for groups [g0, g0 + n): a strided copy
+  auto cold_field = [&](const uint4* col, size_t offset, size_t width, void* dst) -> int {
+    HIPCHK(hipMemcpy2D(dst, width, (const char*)(col + g0) + offset, sizeof(uint4), width, n, hipMemcpyDeviceToHost));
     return JG_OK;
   };
   auto cold32 = [&](size_t offset) -> int {
     t32.resize(n);
-    return cold_field(offset, 4, t32.data());
+    return cold_field(d.cold.v, offset, 4, t32.data());
   };
   auto copy64 = [&](const uint64_t* col) -> int {  // straight column -> caller's buffer
     HIPCHK(hipMemcpy(out, col + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
@@ -3357,9 +3358,9 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
       return JG_OK;
     }
     case JG_FIELD_HEAD: return copy64(d.head);
-    case JG_FIELD_ELECTION_TIME: return cold_field(offsetof(JgCold, election_time), 8, out);
-    case JG_FIELD_ELECTION_TIMEOUT: return cold_field(offsetof(JgCold, election_timeout), 4, out);
-    case JG_FIELD_QUEUED_REQS: return cold_field(offsetof(JgCold, queued), 4, out);
+    case JG_FIELD_ELECTION_TIME: return cold_field(d.cold.t, JG_COLD_T_ELECTION_TIME, 8, out);
+    case JG_FIELD_ELECTION_TIMEOUT: return cold_field(d.cold.t, JG_COLD_T_ELECTION_TIMEOUT, 4, out);
+    case JG_FIELD_QUEUED_REQS: return cold_field(d.cold.v, JG_COLD_V_QUEUED, 4, out);
     case JG_FIELD_ID_GEN: {  // implicit (head + 1) while the chain is in FAST form
       std::vector<uint64_t> head(n);
       HIPCHK(hipMemcpy(head.data(), d.head + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
@@ -3383,17 +3384,17 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
       for (uint32_t i = 0; i < n; i++) o64[i] = role(i) == JG_ROLE_LEADER ? t64[i] : 0;
       return JG_OK;
     case JG_FIELD_VOTED_FOR:
-      if ((rc = cold32(offsetof(JgCold, voted_for)))) return rc;
+      if ((rc = cold32(JG_COLD_V_VOTED_FOR))) return rc;
       for (uint32_t i = 0; i < n; i++) o32[i] = (fl[i] & JGF_VOTED) ? t32[i] : 0;
       return JG_OK;
     case JG_FIELD_LEADER_ID:
-      if ((rc = cold32(offsetof(JgCold, leader_id)))) return rc;
+      if ((rc = cold32(JG_COLD_V_LEADER_ID))) return rc;
       for (uint32_t i = 0; i < n; i++)
         o32[i] = (role(i) == JG_ROLE_FOLLOWER && (fl[i] & JGF_HAS_LEADER)) ? t32[i] : 0;
       return JG_OK;
     case JG_FIELD_VOTE_SEEN:
     case JG_FIELD_VOTE_GRANTED:
-      if ((rc = cold32(offsetof(JgCold, votes)))) return rc;
+      if ((rc = cold32(JG_COLD_V_VOTES))) return rc;
       for (uint32_t i = 0; i < n; i++) {
         uint32_t v = field == JG_FIELD_VOTE_SEEN ? (t32[i] & 0xff) : ((t32[i] >> 8) & 0xff);
         o8[i] = role(i) == JG_ROLE_CANDIDATE ? (uint8_t)v : 0;
