@@ -372,8 +372,10 @@ int jg_step_dense_acks_shards(jg_engine* e, const uint64_t* const* acks_dev, uin
  *   Heartbeat{term, commit, leader_id}      -> beat[g] = {term, commit}
  *   AppendEntries{term, leader_id, blocks}  -> beat[g].term, ae[r][g] = JG_AE(from, n): the blocks are
  *       ids from+1 .. from+n, each with next = id-1 — expressible exactly when the leader's chain is
- *       in run form (id set [0, head] built by append only: every FAST-path leader); a leader whose
- *       chain is not sends all messages of its Tick as rows instead
+ *       a run (the id set is [0, top] and every block's parent its predecessor: what append builds -
+ *       and what a restarted replica re-opens, its head at its commit index possibly BELOW the top,
+ *       chain.rs:117-137; replicate() ranges over the stored keys, leader.rs:135,152-157); a leader
+ *       whose chain is not sends all messages of its Tick as rows instead
  *   AppendResponse{node_id, head}           -> answer[g], bits 63..8 (one word of the leader's inbox block)
  *   HeartbeatResponse{commit, has_committed}-> answer[g], bits 7..0 = has_committed; commit -> hb_commit[g]
  * Block ids in mailbox words are 56 bits wide: a group whose head reaches JG_MAILBOX_NONE raises

@@ -184,14 +184,17 @@ __device__ __forceinline__ void jg_dense_slow_body(const JgDev& d, const uint64_
       c.flag = 0;
       c.id = 0;
       if (jg_wcnt(L)) jg_chain_normalize(d, L);
-      bool fast = L.run_hi == L.head && L.id_gen == L.head + 1 && jg_wcnt(L) == 0 && !(L.flags & JGF_NO_GENESIS);
+      // the Tick fits the columns when the id set is a run [0, run_hi] with every parent id - 1 - whatever head and id_gen
+      // are: a re-elected leader that was restarted has its head at its commit index, below the top of what sled kept
+      // (chain.rs:117-137), and replicates out of that run (leader.rs:135,152-157 range over the stored keys)
+      bool fast = jg_wcnt(L) == 0 && !(L.flags & JGF_NO_GENESIS);
       // ... and every AppendEntries word must be able to hold its range start key (a progress head forged
       // up to 2^56 - 1 or beyond does not fit the 56-bit field): otherwise the Tick travels as rows
       for (uint32_t r = 0; r < d.R; r++) fast = fast && (r == s || jg_match_get(d, L, r) < JG_MAILBOX_NONE);
       fast = fast && mine;  // (the columns hold the owner's Tick)
       if (!fast) {
         jg_apply(d, L, c, nullptr, nullptr);  // rows: the blocks are not id-consecutive
-      } else if (L.head >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words
+      } else if (L.run_hi >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words (the top of the run: what a word may name)
         jg_raise(d, L, JG_FAULT_ENGINE_MAILBOX_RANGE);
       } else {                                // columns: the Tick's rows are captured as they are emitted
         L.xq_on = 3;

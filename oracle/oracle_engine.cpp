@@ -312,10 +312,10 @@ static void leader_tick_out(jo_engine* e, uint32_t g, uint64_t now_ms, const jg_
   // columns stand for a Tick only when every AppendEntries word can hold its range start key: a
   // progress head at or above 2^56 - 1 (a forged AppendResponse: heads only grow, progress.rs:133-140)
   // does not fit the 56-bit field, so that leader's Tick travels as rows
-  bool columns = r.chain.run_form_by_append();
+  bool columns = r.chain.run_form();  // (the id set is a run [0, top], every parent id - 1: whatever head and id_gen are)
   for (const auto& kv : r.progress.progress)
     if (kv.first != r.id && kv.second.head >= JG_MAILBOX_NONE) columns = false;
-  if (columns && r.chain.head >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words: loud, never wrong
+  if (columns && r.chain.top() >= JG_MAILBOX_NONE) {  // 56-bit block ids in mailbox words: loud, never wrong
     r.fault = JG_FAULT_ENGINE_MAILBOX_RANGE;
     return;
   }

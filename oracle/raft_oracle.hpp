@@ -171,6 +171,16 @@ struct Chain {
       if (kv.second.next != (kv.first ? kv.first - 1 : 0)) return false;
     return !db.empty() && db.rbegin()->first == head;
   }
+  // The id set is a run [0, top] and every block's parent its predecessor - whatever head and id_gen are (a restarted
+  // replica's head is its commit index, below the top of what sled kept: chain.rs:117-137): blocks after any key are
+  // id-consecutive, so an AppendEntries still fits the (from, n) mailbox word.
+  bool run_form() const {
+    if (db.empty() || db.size() != db.rbegin()->first + 1) return false;
+    for (auto& kv : db)
+      if (kv.second.next != (kv.first ? kv.first - 1 : 0)) return false;
+    return true;
+  }
+  BlockId top() const { return db.empty() ? 0 : db.rbegin()->first; }
 };
 
 // ---------------------------------------------------------------------------

@@ -387,18 +387,21 @@ class RefEngine:
         return True
 
     @staticmethod
-    def _run_form_by_append(r):
-        """"the leader's chain is in run form (id set [0, head] built by append only)": what the
-        (from, n) mailbox encoding of AppendEntries can express."""
+    def _run_form(r):
+        """"the leader's chain is a run: the id set is [0, top] and every block's parent its predecessor" - what the
+        (from, n) mailbox encoding of AppendEntries can express, whatever head and id_gen are."""
         ch = r.chain
         keys = [k for k in ch.db.keys if len(k) == 8]
-        if len(keys) != ch.head + 1 or ch.id_gen != ch.head + 1:
-            return False
         for i, k in enumerate(keys):
             b = ch.db.map[k]
             if b.id != i or b.next != (i - 1 if i else 0):
                 return False
-        return True
+        return len(keys) > 0
+
+    @staticmethod
+    def _top(r):
+        keys = [k for k in r.chain.db.keys if len(k) == 8]
+        return r.chain.db.map[keys[-1]].id if keys else 0
 
     def step_dense_leader(self, now_ms=0, acks=None, hbr_has=None, hbr_commit=None, tick=True):
         G, R = self.G, self.R
@@ -433,7 +436,7 @@ class RefEngine:
             if not self.fault[g]:                         # 2. appends + acks
                 self._dense_acks_group(g, acks, now_ms)
             if tick and not self.fault[g]:                # 3. Command::Tick -> columns (or rows)
-                columns = self._run_form_by_append(r)
+                columns = self._run_form(r)
                 trows = self._apply(g, rr.Command("Tick"), now_ms, rows=False)
                 if not columns:
                     rows.extend(trows)

@@ -109,20 +109,32 @@ def test_dense_leader_tick_parity(R, flags, layout):
 
 
 @pytest.mark.gpu
-def test_dense_leader_tick_irregular_leaders_send_rows():
-    """A leader whose chain is not in run form (restarted with a commit, then re-elected) cannot
-    use the (from, n) columns: its Tick goes out as rows, exactly as the oracle says."""
+def test_dense_leader_tick_restarted_leaders_send_columns_irregular_ones_rows():
+    """The (from, n) columns can express a Tick exactly when the leader's chain is a run: the id set is [0, top], every
+    parent id - 1.  A leader that was restarted with a commit and re-elected still has one (its head at its commit
+    index, id_gen re-seeded: chain.rs:117-137; it can never append again, Q8, but it replicates): columns.  A leader
+    whose chain has a gap does not: its Tick goes out as rows.  Exactly as the oracle says, both."""
     G, R = 600, 3
     dev = BatchedRaft(G, R, seed=2, flags=capi.CFG_SEPARATE_COMMIT_KEY)
     ora = oracle_engine(G, R, seed=2, flags=capi.CFG_SEPARATE_COMMIT_KEY)
+    gap = np.arange(2, G, 4, dtype=np.uint32)       # a block far up the id space whose parent is genesis: {0, 9}
+    restarted = np.arange(0, G, 4, dtype=np.uint32)
     for e in (dev, ora):
+        n = len(gap)
+        e.submit_columns(np.full(n, capi.CMD_APPEND_ENTRIES, np.uint8), gap, from_=np.full(n, 2, np.uint32), term=np.ones(n, np.uint64),
+                         id=np.arange(n, dtype=np.uint64), aux=np.ones(n, np.uint64), blk_id=np.full(n, 9, np.uint64), blk_next=np.zeros(n, np.uint64))
+        e.step(0)
+        e.submit_columns(np.full(n, capi.CMD_RESTART, np.uint8), gap)  # (voted for node 2 by now: only a restart lets them campaign, Q4)
+        e.step(0)
         elect_all(e)
         acks = np.full((R, G), NO, np.uint64)
         acks[0] = 2
+        acks[0][gap] = 0
         e.step_dense_leader(100, acks, tick=False)
         acks[0], acks[1] = 0, 2
+        acks[1][gap] = NO
         e.step_dense_leader(200, acks, tick=False)  # commit 2
-        g = np.arange(0, G, 2, dtype=np.uint32)
+        g = restarted
         e.submit_columns(np.full(len(g), capi.CMD_RESTART, np.uint8), g)
         e.step(300)
         e.submit_columns(np.full(len(g), capi.CMD_TIMEOUT, np.uint8), g)
@@ -130,17 +142,20 @@ def test_dense_leader_tick_irregular_leaders_send_rows():
                          term=np.ones(len(g), np.uint64), flag=np.ones(len(g), np.uint8))
         e.step(300)
         e.drain_messages(), e.drain_applies(), e.drain_faults()
-    assert (ora.read("role") == capi.ROLE_LEADER).all() and int(ora.read("id_gen")[0]) == 2
+    role = ora.read("role")
+    assert (role == capi.ROLE_LEADER).all() and int(ora.read("id_gen")[0]) == 2 and not ora.read("fault").any()
     acks[:] = NO
     acks[0] = 0
     for t in range(3):
         oa = dev.step_dense_leader(500 + 150 * t, acks, tick=True)
         ob = ora.step_dense_leader(500 + 150 * t, acks, tick=True)
         _cmp_cols(oa, ob, f"tick {t}")
-        assert (ob["ae_n"][1][0::2] == capi.AE_NONE).all() and (ob["ae_n"][1][1::2] != capi.AE_NONE).all()
+        assert (ob["ae_n"][1][restarted] != capi.AE_NONE).all() and (ob["ae_n"][1][1::2] != capi.AE_NONE).all()  # columns
+        assert (ob["ae_n"][1][gap] == capi.AE_NONE).all()                                                       # rows
         compare_snapshots(dev, ora, f"irregular leaders tick {t}")
         a, b = dev.drain_messages(), ora.drain_messages()
-        assert a.tobytes() == b.tobytes() and len(b) >= G // 2 * (R - 1)
+        assert a.tobytes() == b.tobytes() and len(b) >= len(gap) * (R - 1)
+        assert set(b["group"].tolist()) <= set(gap.tolist())
 
 
 def _mixed_role_engines(G, R, seed):
