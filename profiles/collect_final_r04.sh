@@ -77,3 +77,8 @@ if [ "$part" = cluster_ab ]; then
   for c in FETCH_SIZE WRITE_SIZE; do pmc ${c}_cluster $c $B --cluster --steps 30 --warmup 10 --no-cpu-baseline; done
   KERNEL=k_follower_tick_dense python profiles/summarize_counters.py $O | grep -A3 cluster
 fi
+if [ "$part" = anyfail ]; then
+  stats any_failures_x3 $B --cluster --any-leader --replicas 3 --failures 1 --steps 100 --warmup 20
+  head -16 $O/kernel_stats_any_failures_x3.csv | cut -c1-150
+  $B --cluster --any-leader --replicas 3 --failures 1 --steps 100 --warmup 20 > $O/bench_any_failures_1pct_x3.json 2>/dev/null; line $O/bench_any_failures_1pct_x3.json
+fi
