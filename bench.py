@@ -900,6 +900,11 @@ def secondary_lines(args):
     out["per_partition_leadership"] = x if "error" in x else {
         "command": x["command"], "round_us": x["line"]["ms_per_step_events"] * 1e3, "frac": x["line"]["roofline"]["frac"],
         "elections": x["line"]["elections"], "decisions_per_s": x["line"]["value"]}
+    x = run("any_leader_failures", ["--cluster", "--any-leader", "--replicas", "3", "--failures", "1", "--steps", "60", "--warmup", "10"])
+    out["per_partition_leadership_failures"] = x if "error" in x else {
+        "command": x["command"], "round_ms": x["line"]["ms_per_step"], "frac": x["line"]["roofline"]["frac"],
+        "elections_won_after_failures": x["line"]["elections_won_after_failures"], "leaderless_fraction": x["line"]["leaderless_fraction"],
+        "rows_left_for_the_host": x["line"]["rows_left_for_the_host"], "decisions_per_s": x["line"]["value"]}
     x = run("failures_tick", ["--failures", "1", "--steps", "96", "--warmup", "32"])
     out["failures_tick"] = x if "error" in x else {
         "command": x["command"], "tick_ms": x["line"]["ms_per_step"], "dense_kernel_us": x["line"]["roofline"]["avg_launch_us"],

@@ -91,7 +91,9 @@ def test_default_line_carries_the_secondaries():
     fraction - so that BENCH_rNN.json holds more than the headline."""
     d = run(["--groups", "100000", "--steps", "40", "--warmup", "5", "--no-cpu-baseline"], env={"JG_BENCH_SECONDARY": "1"})
     sec = d["secondary"]
-    assert set(sec) == {"closed_loop", "routed_round", "per_partition_leadership", "failures_tick", "event_loop"}
+    assert set(sec) == {"closed_loop", "routed_round", "per_partition_leadership", "per_partition_leadership_failures", "failures_tick",
+                        "event_loop"}
+    assert sec["per_partition_leadership_failures"]["rows_left_for_the_host"] == 0
     for k, v in sec.items():
         assert "error" not in v, (k, v)
     assert sec["closed_loop"]["round_us"] > 0 and 0 < sec["closed_loop"]["frac"] < 1
