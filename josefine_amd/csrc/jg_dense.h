@@ -743,14 +743,27 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   lt.cwide = false, lt.adv = 0;
   uint32_t dl = 0;
   bool hot = (f & (JGF_FAULT_MASK | JGF_ROLE_MASK | JGF_FAST)) == (JG_ROLE_LEADER | JGF_FAST);
+  // A healthy leader whose chain is not in FAST form but still the run [0, top] - a restarted leader, head at its
+  // commit index below the top of what the store kept, or id_gen off the head (Q8: it cannot append any more, but it
+  // counts acknowledgements, commits and ticks for as long as it leads): its lags are relative to that top
+  // (jg_lag_base_is_run_hi), every valid ack is at or below it, and the tick is the same arithmetic.  An append
+  // there is the slow kernel's (the Q8 fault).  One more load, behind a branch only such a group's wave takes.
+  uint64_t base0 = head0;
+  if (NODE) {
+    const bool runx = (f & (JGF_FAULT_MASK | JGF_ROLE_MASK | JGF_FAST | JGF_WIN_MASK | JGF_NO_GENESIS)) == JG_ROLE_LEADER && n_app == 0;
+    if (__builtin_expect(runx, 0)) {
+      if (!(f & JGF_RUN)) base0 = dp->run_hi[g];
+      hot = true;
+    }
+  }
   if (NODE) hot = hot && !hbr_trigger;
   if (ANY) hot = hot && mine;
-  hot = jg_lag_tick<R>(s, f, mword0, head0, n_app, a, lt, dl) && hot;
+  hot = jg_lag_tick<R>(s, f, mword0, base0, n_app, a, lt, dl) && hot;
   // fsm rows come from the (appended?, commit advance) word: one Notify at most, and a commit index whose old
   // value is in the packed word - anything else is the general state machine's (k_dense_slow)
   if (FSM) hot = hot && n_app <= 1 && !lt.cwide;
   uint32_t adv_pre = 0;
-  if (FSM && __builtin_expect(pre != 0, 0)) hot = jg_lag_pre<R>(s, mword0, head0, a, pre, adv_pre) && hot;
+  if (FSM && __builtin_expect(pre != 0, 0)) hot = jg_lag_pre<R>(s, mword0, base0, a, pre, adv_pre) && hot;
   // (the node tick counts behind its stores: the counter's atomic would otherwise be one more thing the
   // waits inside the Tick's emission wait for)
   if (!NODE) jg_count_step(h.blk_decisions, dec, hot, dl);
@@ -760,7 +773,7 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
         return lt.l[r] == 0xffffffffu ? dp->match_wide[(size_t)r * h.G + g] : lt.head1 - lt.l[r];  // BEHIND: wide column
       });
     if (lt.w1 != mword0) h.mlag[g] = lt.w1;
-    if (lt.head1 != head0) h.head[g] = lt.head1;
+    if (lt.head1 != base0) h.head[g] = lt.head1;  // (an append: FAST form, base0 = the head)
     if (lt.nf != f) h.flags[g] = lt.nf;
     if (FSM) {  // (a Q9 fault raised by the Tick comes after the appends and acks: their rows stand)
       uint32_t w = (n_app ? JG_FSM_APPENDED_BIT : 0u) | lt.adv | (adv_pre << JG_FSM_PRE_SHIFT);

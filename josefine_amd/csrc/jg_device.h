@@ -236,6 +236,18 @@ __device__ inline void jg_raise(const JgDev& d, JgLane& L, uint32_t code) {
 
 __device__ inline void jg_chain_normalize(const JgDev& d, JgLane& L);
 
+// What the lags of a leader's packed word are relative to: the TOP of its chain where that is known from the flag
+// word - the chain is the run [0, run_hi] (no window segments, genesis present) - else the head.  The two agree
+// for a chain in RUN form; a restarted leader (jg_restart_groups / the durable-store restart: head = the commit
+// index, the run above it still there) keeps its lags below run_hi, so every valid ack (chain.rs:197-202: a
+// block the chain holds) is in range and the node tick serves the group in lag space (jg_dense_group).
+// (for readers of the columns: run_hi[g] is not kept up to date while the chain is in RUN form, where it equals the head)
+__host__ __device__ __forceinline__ bool jg_lag_base_is_run_hi(uint32_t flags) {
+  return (flags & (JGF_WIN_MASK | JGF_NO_GENESIS | JGF_RUN)) == 0;
+}
+__device__ __forceinline__ uint64_t jg_lane_base(const JgLane& L) {  // (L.run_hi is the head in RUN form: jg_load)
+  return (L.flags & (JGF_WIN_MASK | JGF_NO_GENESIS)) == 0 ? L.run_hi : L.head;
+}
 // Progress.head of slot r of the lane's group (leaders)
 __device__ inline uint64_t jg_match_get(const JgDev& d, const JgLane& L, uint32_t r) {
   const uint64_t f = jg_lag_field(L.mword, r, d.R);
@@ -246,16 +258,16 @@ __device__ inline void jg_match_set(const JgDev& d, JgLane& L, uint32_t r, uint6
   if (jg_lag_wide(f, d.R)) d.match_wide[(size_t)r * d.G + L.g] = v;
   L.mword = jg_lag_with(L.mword, r, d.R, f);
 }
-__device__ inline void jg_match_rebase(const JgDev& d, JgLane& L) {
+__device__ inline void jg_match_rebase(const JgDev& d, JgLane& L, uint64_t base) {
   uint64_t w = 0;
   for (uint32_t r = 0; r < d.R; r++) {
     const uint64_t v = jg_match_get(d, L, r);
-    const uint64_t f = jg_lag_encode(v, L.head, d.R);
+    const uint64_t f = jg_lag_encode(v, base, d.R);
     if (jg_lag_wide(f, d.R)) d.match_wide[(size_t)r * d.G + L.g] = v;
     w = jg_lag_with(w, r, d.R, f);
   }
   L.mword = w;
-  L.mbase = L.head;
+  L.mbase = base;
 }
 
 __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
@@ -272,11 +284,11 @@ __device__ inline void jg_load(const JgDev& d, JgLane& L, uint32_t g) {
     L.election_timeout = c.election_timeout, L.rng_draws = c.rng_draws, L.queued = c.queued, L.votes = c.votes;
   }
   L.mword = 0;
-  L.mbase = L.head;
+  L.mbase = jg_lane_base(L);
   if ((L.flags & JGF_ROLE_MASK) == JG_ROLE_LEADER) {
     L.mword = d.mlag[g];
     const uint64_t fc = jg_lag_field(L.mword, d.R, d.R);
-    L.commit = jg_lag_wide(fc, d.R) ? d.commit[g] : L.head - fc;
+    L.commit = jg_lag_wide(fc, d.R) ? d.commit[g] : L.mbase - fc;
   } else {
     L.commit = d.commit[g];
   }
@@ -298,8 +310,9 @@ __device__ inline void jg_store(const JgDev& d, JgLane& L) {
   // the host then schedules the slow kernel behind the dense leader kernel
   if (!fast && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L)) *d.irregular_seen = 1;
   if (jg_role(L) == JG_ROLE_LEADER) {
-    if (L.mbase != L.head) jg_match_rebase(d, L);  // the head moved: the lags are relative to it
-    const uint64_t fc = jg_lag_encode(L.commit, L.head, d.R);
+    const uint64_t base = jg_lane_base(L);
+    if (L.mbase != base) jg_match_rebase(d, L, base);  // the chain grew: the lags are relative to its top
+    const uint64_t fc = jg_lag_encode(L.commit, base, d.R);
     if (jg_lag_wide(fc, d.R)) d.commit[g] = L.commit;
     d.mlag[g] = jg_lag_with(L.mword, d.R, d.R, fc);
   } else {
@@ -335,8 +348,9 @@ __device__ inline void jg_store_dirty(const JgDev& d, JgLane& L, const JgLane& O
   L.flags = fast ? (L.flags | JGF_FAST) : (L.flags & ~JGF_FAST);
   if (!fast && jg_role(L) == JG_ROLE_LEADER && !jg_fault(L)) *d.irregular_seen = 1;
   if (jg_role(L) == JG_ROLE_LEADER) {
-    if (L.mbase != L.head) jg_match_rebase(d, L);
-    const uint64_t fc = jg_lag_encode(L.commit, L.head, d.R);
+    const uint64_t base = jg_lane_base(L);
+    if (L.mbase != base) jg_match_rebase(d, L, base);
+    const uint64_t fc = jg_lag_encode(L.commit, base, d.R);
     if (jg_lag_wide(fc, d.R)) d.commit[g] = L.commit;
     const uint64_t w = jg_lag_with(L.mword, d.R, d.R, fc);
     if (w != O.mword) d.mlag[g] = w;  // (O.mword: the packed word as loaded, commit field included)
@@ -670,7 +684,7 @@ __device__ inline void jg_follower_from_leader(JgLane& L) {  // leader.rs:268-28
 }
 __device__ inline void jg_become_leader(const JgDev& d, JgLane& L) {  // candidate.rs:216-238
   L.mword = 0;
-  L.mbase = L.head;
+  L.mbase = jg_lane_base(L);
   for (uint32_t r = 0; r < d.R; r++) jg_match_set(d, L, r, 0);            // progress.rs:155-162
   L.flags &= ~JGF_REPL_MASK;
   L.heartbeat_time = L.now;

@@ -344,7 +344,8 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_gather_rows(uint32_t n, const
 __device__ __forceinline__ uint64_t jg_node_commit_of(const JgDev& d, uint32_t g, uint32_t f, uint64_t head) {
   if ((f & JGF_ROLE_MASK) != JG_ROLE_LEADER) return d.commit[g];
   const uint64_t fc = jg_lag_field(d.mlag[g], d.R, d.R);
-  return jg_lag_wide(fc, d.R) ? d.commit[g] : head - fc;
+  if (jg_lag_wide(fc, d.R)) return d.commit[g];
+  return (jg_lag_base_is_run_hi(f) ? d.run_hi[g] : head) - fc;  // (a restarted leader: lags below the top of its run)
 }
 __device__ __forceinline__ void jg_node_fsm_row(jg_fsm_row& r, uint32_t g, uint32_t kind, uint64_t a, uint64_t b) {
   r.group = g, r.kind = (uint8_t)kind, r.pad[0] = r.pad[1] = r.pad[2] = 0;

@@ -3337,6 +3337,14 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
     t32.resize(n);
     return cold_field(d.cold.v, offset, 4, t32.data());
   };
+  auto lag_base = [&](std::vector<uint64_t>& base) -> int {  // what a leader's lags are relative to (jg_lag_base_is_run_hi)
+    std::vector<uint64_t> top(n);
+    HIPCHK(hipMemcpy(base.data(), d.head + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(top.data(), d.run_hi + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++)
+      if (jg_lag_base_is_run_hi(fl[i])) base[i] = top[i];
+    return JG_OK;
+  };
   auto copy64 = [&](const uint64_t* col) -> int {  // straight column -> caller's buffer
     HIPCHK(hipMemcpy(out, col + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
     return JG_OK;
@@ -3348,7 +3356,7 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
     case JG_FIELD_TERM: return copy64(d.term);
     case JG_FIELD_COMMIT: {  // leaders: packed as a lag below the head (field R of mlag), escape -> column
       std::vector<uint64_t> head(n), col(n);
-      HIPCHK(hipMemcpy(head.data(), d.head + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
+      if ((rc = lag_base(head))) return rc;
       HIPCHK(hipMemcpy(col.data(), d.commit + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
       if ((rc = get64(d.mlag))) return rc;
       for (uint32_t i = 0; i < n; i++) {
@@ -3370,7 +3378,7 @@ int jg_read_state(jg_engine* e, int field, uint32_t replica, void* out, uint32_t
     }
     case JG_FIELD_MATCH: {  // delta-packed: head - lag, or the wide column where the lag field is the escape
       std::vector<uint64_t> head(n), wide(n);
-      HIPCHK(hipMemcpy(head.data(), d.head + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
+      if ((rc = lag_base(head))) return rc;
       HIPCHK(hipMemcpy(wide.data(), d.match_wide + (size_t)replica * d.G + g0, (size_t)n * 8, hipMemcpyDeviceToHost));
       if ((rc = get64(d.mlag))) return rc;
       for (uint32_t i = 0; i < n; i++) {

@@ -158,6 +158,97 @@ def test_dense_leader_tick_restarted_leaders_send_columns_irregular_ones_rows():
         assert set(b["group"].tolist()) <= set(gap.tolist())
 
 
+def _restarted_leaders_below_their_top(G, R, seed):
+    """Both engines with every group led by slot 0, chain [0, 5], commit index 2; every other group then restarted and
+    re-elected: head = 2 (chain.rs:117-137), the run above it still in the store, progress heads 0 (Q10)."""
+    dev = BatchedRaft(G, R, seed=seed, flags=capi.CFG_SEPARATE_COMMIT_KEY)
+    ora = oracle_engine(G, R, seed=seed, flags=capi.CFG_SEPARATE_COMMIT_KEY)
+    g = np.arange(0, G, 2, dtype=np.uint32)
+    for e in (dev, ora):
+        elect_all(e)
+        acks = np.full((R, G), NO, np.uint64)
+        acks[0] = 2
+        e.step_dense_leader(100, acks, tick=False)
+        acks[0], acks[1] = 3, 2
+        e.step_dense_leader(200, acks, tick=False)  # head 5, commit 2
+        e.submit_columns(np.full(len(g), capi.CMD_RESTART, np.uint8), g)
+        e.step(300)
+        e.submit_columns(np.full(len(g), capi.CMD_TIMEOUT, np.uint8), g)
+        e.submit_columns(np.full(len(g), capi.CMD_VOTE_RESPONSE, np.uint8), g, from_=np.full(len(g), 2, np.uint32),
+                         term=np.ones(len(g), np.uint64), flag=np.ones(len(g), np.uint8))
+        e.step(300)
+        e.drain_messages(), e.drain_applies(), e.drain_faults()
+    assert (ora.read("role") == capi.ROLE_LEADER).all() and not ora.read("fault").any()
+    assert (ora.read("head")[g] == 2).all() and (ora.read("commit")[g] == 2).all() and (ora.read("head")[1::2] == 5).all()
+    return dev, ora, g
+
+
+@pytest.mark.gpu
+def test_dense_leader_tick_restarted_leader_counts_acks_above_its_head():
+    """A restarted, re-elected leader's head sits at its commit index, BELOW the top of the run its store kept: the
+    acknowledgements it receives name blocks above its head, all of them blocks it holds (chain.rs:197-202 looks the
+    key up, it does not compare with the head), so its commit index moves past its head; an acknowledgement above the
+    TOP is recorded like any other (progress.rs:133-140) and panics only once the majority rests on it.  The node tick
+    keeps such a leader's progress heads as lags below that top; state, columns and faults as the oracle's, tick by
+    tick."""
+    G, R = 640, 3
+    dev, ora, g = _restarted_leaders_below_their_top(G, R, seed=4)
+    script = [({}, "quiet"), ({1: 4}, "one ack above the head"), ({2: 5}, "majority at 4"), ({1: 3}, "a stale ack"),
+              ({1: 6}, "an ack above the top: recorded"), ({2: 5}, "again"), ({2: 7}, "the majority above the top: panic")]
+    for t, (acked, what) in enumerate(script):
+        acks = np.full((R, G), NO, np.uint64)
+        acks[0] = 0
+        for r, h in acked.items():
+            acks[r][g] = h
+            acks[r][1::2] = min(h, 5)
+        oa = dev.step_dense_leader(500 + 150 * t, acks, tick=True)
+        ob = ora.step_dense_leader(500 + 150 * t, acks, tick=True)
+        _cmp_cols(oa, ob, f"tick {t} ({what})")
+        compare_snapshots(dev, ora, f"restarted leaders, tick {t} ({what})")
+        assert dev.drain_messages().tobytes() == ora.drain_messages().tobytes()
+        assert dev.drain_faults().tobytes() == ora.drain_faults().tobytes()
+        if t == 2:
+            assert (ora.read("commit")[g] == 4).all() and (ora.read("head")[g] == 2).all()
+        if t < 6:
+            assert not ora.read("fault").any()
+    assert (ora.read("fault")[g] == capi.FAULT_COMMIT_MISSING_BLOCK).all() and not ora.read("fault")[1::2].any()
+
+
+@pytest.mark.gpu
+def test_step_node_restarted_leader_counts_acks_above_its_head():
+    """The same leaders through jg_step_node (rows in, fsm rows out): the Apply ranges of a commit index that moves
+    above the head, and a ClientRequest at such a leader - the re-seeded id generator hands out an id the chain holds
+    (Q8): the panic of chain.rs:166-176 as a fault, at that group only."""
+    G, R = 640, 3
+    dev, ora, g = _restarted_leaders_below_their_top(G, R, seed=5)
+    all_g = np.arange(G, dtype=np.uint32)
+
+    def feed(e, rows):
+        for kind, groups, kw in rows:
+            e.submit_columns(np.full(len(groups), kind, np.uint8), groups, **kw)
+
+    def ar(slot, head, groups=all_g):
+        n = len(groups)
+        return (capi.CMD_APPEND_RESPONSE, groups, dict(from_=np.full(n, slot + 1, np.uint32), term=np.ones(n, np.uint64),
+                                                       id=np.minimum(np.full(n, head, np.uint64), np.where(np.isin(groups, g), head, 5).astype(np.uint64)),
+                                                       flag=np.ones(n, np.uint8)))
+    script = [[], [ar(1, 4)], [ar(2, 5)], [ar(1, 3), ar(2, 5)],
+              [(capi.CMD_CLIENT_REQUEST, all_g[::5], dict(id=np.arange(len(all_g[::5]), dtype=np.uint64)))], [ar(1, 5)]]
+    for t, rows in enumerate(script):
+        for e in (dev, ora):
+            feed(e, rows)
+        oa = dev.step_node(500 + 150 * t)
+        ob = ora.step_node(500 + 150 * t)
+        for k in ("beat_term", "beat_commit", "ae", "answer", "hb_commit"):
+            assert np.array_equal(oa[k], ob[k]), f"tick {t}: outbox column {k}"
+        compare_snapshots(dev, ora, f"restarted leaders through step_node, tick {t}")
+        assert dev.drain_messages().tobytes() == ora.drain_messages().tobytes()
+        assert dev.drain_applies().tobytes() == ora.drain_applies().tobytes()
+        assert dev.drain_faults().tobytes() == ora.drain_faults().tobytes()
+    f = ora.read("fault")
+    assert f[g[np.isin(g, all_g[::5])]].all() and not f[1::2].any()
+
+
 def _mixed_role_engines(G, R, seed):
     dev = BatchedRaft(G, R, seed=seed, election_timeout_ms=(300, 600))
     ora = oracle_engine(G, R, seed=seed, election_timeout_ms=(300, 600))
