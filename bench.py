@@ -723,6 +723,8 @@ def event_loop_main(args):
 
     p1 = run("pipe", K, W)         # ONE loop that overlaps with itself: tick t + 1 is decoded while tick t runs and lands
     pc1 = run("pipecolumns", K, W)
+    pt1 = run("pipetasks", K, W)   # ... with the reference's other tasks (connection readers, channel consumers) on threads of their own
+    ptc1 = run("pipetaskscolumns", K, W)
     d1 = run("inplace", K, W)   # ONE loop owns every partition
     d, d_by_loops = best("inplace", d1)
     colm1 = run("columns", K, W)  # the followers' answers as columns (batched peers), only the client requests as rows
@@ -764,6 +766,21 @@ def event_loop_main(args):
                 "column_inbound_decisions_per_s": pc1["decisions_per_s"], "column_inbound_ms_per_tick": pc1["ms_per_tick"],
                 "speedup_over_the_synchronous_loop": p1["decisions_per_s"] / d1["decisions_per_s"],
                 "rows_on_the_general_path": p1["rows_general"]},
+            "one_loop_with_transport_and_consumer_tasks": {
+                "what": "the same ONE pipelined event loop (one engine, every engine call on the loop's thread) with the work the reference "
+                        "does not do on the loop's task taken off its thread: frames are decoded by the per-connection read tasks "
+                        "(src/raft/tcp.rs:139-170; the loop receives Commands from a channel, server.rs:120-137), fsm_tx is consumed by "
+                        "the driver task (src/raft/fsm.rs), rpc_tx by the per-peer senders (tcp.rs:87-137) - here "
+                        f"{pt1['task_threads_beside_each_loop']} helper threads beside the loop's, fork-join: the decoders fill their "
+                        "slices of the pinned columns, the consumers read their slices of the output batches",
+                "task_threads_beside_the_loop": pt1["task_threads_beside_each_loop"],
+                "decisions_per_s": pt1["decisions_per_s"], "ms_per_tick": pt1["ms_per_tick"],
+                "ms_per_tick_parts": {"transport_decode_into_pinned_columns": pt1["ms_fill"], "submit_commit": pt1["ms_submit"],
+                                      "step_begin_and_previous_outputs": pt1["ms_step_and_drain"]},
+                "column_inbound_decisions_per_s": ptc1["decisions_per_s"], "column_inbound_ms_per_tick": ptc1["ms_per_tick"],
+                "column_inbound_ms_per_tick_parts": {"transport_decode_into_pinned_columns": ptc1["ms_fill"], "submit_commit": ptc1["ms_submit"],
+                                                     "step_begin_and_previous_outputs": ptc1["ms_step_and_drain"]},
+                "rows_on_the_general_path": pt1["rows_general"] + ptc1["rows_general"]},
             "one_loop": {"what": "ONE loop (one host thread, one engine) owns every partition: nothing overlaps",
                          "decisions_per_s": d1["decisions_per_s"],
                          "ms_per_tick": {"transport_decode_into_pinned_columns": d1["ms_fill"], "submit_commit_validation": d1["ms_submit"],
@@ -915,6 +932,8 @@ def secondary_lines(args):
         "one_loop_decisions_per_s": x["line"]["event_loop"]["one_loop"]["decisions_per_s"],
         "one_loop_pipelined_decisions_per_s": x["line"]["event_loop"]["one_loop_pipelined"]["decisions_per_s"],
         "one_loop_pipelined_column_inbound_decisions_per_s": x["line"]["event_loop"]["one_loop_pipelined"]["column_inbound_decisions_per_s"],
+        "one_loop_with_tasks_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["decisions_per_s"],
+        "one_loop_with_tasks_column_inbound_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["column_inbound_decisions_per_s"],
         "column_inbound_decisions_per_s": x["line"]["event_loop"]["column_inbound"]["decisions_per_s"],
         "rows_on_the_general_path": x["line"]["event_loop"]["rows_on_the_general_path"],
         "pcie_bytes_per_decision": x["line"]["event_loop"]["pcie_bytes_per_decision"]}

@@ -19,6 +19,14 @@
 //   general   round 2's loop: every row and one Tick ROW per partition through jg_submit + jg_step (the
 //             general state machine, host radix sort) - the A/B
 // Both channels are consumed by batch sinks that read every byte they are handed (a 64-bit sum).
+//   pipe / pipecolumns            inplace / columns with ONE loop that overlaps with itself (BatchedEventLoop::pipelined)
+//   pipetasks / pipetaskscolumns  the same loop with the work the reference does NOT do on the event loop's task taken
+//             off its thread: frames are decoded by the per-connection read tasks (src/raft/tcp.rs:139-170 - the loop
+//             receives Commands from a channel, server.rs:120-137), fsm_tx is consumed by the driver task (src/raft/fsm.rs)
+//             and rpc_tx by the per-peer senders (tcp.rs:87-137).  Here: `helpers` (argument 8, default R - 1) threads
+//             beside the loop's own, fork-join - the per-connection decoders fill their slices of the pinned columns,
+//             the consumers read their slices of the output batches; the loop thread works along and goes on when all
+//             are done.  Everything that touches the engine stays on the loop thread.
 //
 // loops (argument 7, default 1): the process hosts the G partitions on that many event loops, one thread and
 // one engine (its own HIP stream) each, G / loops partitions per loop - the reference runs one event_loop task
@@ -27,11 +35,13 @@
 // transfers (both directions) and kernels of different loops overlap.  The timed region starts when every loop
 // has finished its warm-up ticks and ends when the last loop has finished its last tick.
 // Prints one JSON object.
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -49,6 +59,83 @@ static uint64_t sum_words(const void* p, size_t bytes) {
   for (size_t i = 0; i < bytes / 8; i++) s += w[i];
   return s;
 }
+
+// The tasks beside the event loop (decoders, channel consumers) as a fork-join pool: run(n, f) executes f(0..n-1) on the
+// helpers and the caller (jobs handed out by an atomic counter) and returns when all of them are done.
+class Tasks {
+ public:
+  explicit Tasks(uint32_t helpers) {
+    for (uint32_t i = 0; i < helpers; i++) th_.emplace_back([this] { work(); });
+  }
+  ~Tasks() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (std::thread& t : th_) t.join();
+  }
+  uint32_t threads() const { return (uint32_t)th_.size() + 1; }
+  template <class F>
+  void run(uint32_t n, F&& f) {
+    if (th_.empty() || n <= 1) {
+      for (uint32_t i = 0; i < n; i++) f(i);
+      return;
+    }
+    Run r;  // (lives until every helper that picked it up has let go of it)
+    r.job = f, r.n = n;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      cur_ = &r, left_ = n, users_ = 0, epoch_++;
+    }
+    cv_.notify_all();
+    drain(r);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return left_ == 0 && users_ == 0; });
+    cur_ = nullptr;
+  }
+
+ private:
+  struct Run {
+    std::function<void(uint32_t)> job;
+    uint32_t n = 0;
+    std::atomic<uint32_t> next{0};
+  };
+  void drain(Run& r) {
+    for (;;) {
+      const uint32_t i = r.next.fetch_add(1);
+      if (i >= r.n) return;
+      r.job(i);
+      std::lock_guard<std::mutex> lk(m_);
+      if (--left_ == 0) done_.notify_all();
+    }
+  }
+  void work() {
+    uint64_t seen = 0;
+    for (;;) {
+      Run* r;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+        if (stop_) return;
+        seen = epoch_;
+        r = cur_;
+        if (!r) continue;  // (woke up after the run was over)
+        users_++;
+      }
+      drain(*r);
+      std::lock_guard<std::mutex> lk(m_);
+      if (--users_ == 0) done_.notify_all();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  Run* cur_ = nullptr;
+  uint32_t left_ = 0, users_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
 
 // every loop arrives; the last one to arrive stamps the time all of them then share
 struct Rendezvous {
@@ -79,12 +166,26 @@ struct LoopResult {
 };
 
 static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::string& mode_arg, int device, uint64_t seed,
-                     Rendezvous& rv, LoopResult& out) {
+                     uint32_t helpers, Rendezvous& rv, LoopResult& out) {
   // "pipe" / "pipecolumns": the loop overlaps with itself (BatchedEventLoop::pipelined) and its rows are validated on the
-  // device (JG_COL_UNCHECKED) - otherwise exactly "inplace" / "columns"
+  // device (JG_COL_UNCHECKED) - otherwise exactly "inplace" / "columns"; "pipetasks…": with the decoder / consumer tasks
   const bool pipe = mode_arg.rfind("pipe", 0) == 0;
-  const std::string mode = !pipe ? mode_arg : (mode_arg == "pipecolumns" ? "columns" : "inplace");
+  const bool with_tasks = mode_arg.rfind("pipetasks", 0) == 0;
+  const bool cols_in = mode_arg.size() >= 7 && mode_arg.compare(mode_arg.size() - 7, 7, "columns") == 0;
+  const std::string mode = !pipe ? mode_arg : (cols_in ? "columns" : "inplace");
   const uint32_t unchecked = pipe ? (uint32_t)JG_COL_UNCHECKED : 0u;
+  Tasks tasks(with_tasks ? helpers : 0u);  // (no helpers: run() is a plain loop on the calling thread)
+  constexpr uint32_t SPLIT = 8;            // jobs per batch and connection: the helpers draw them as they come free
+  auto sum_split = [&](const void* p, size_t items, size_t item_bytes) {
+    uint64_t part[SPLIT] = {};
+    tasks.run(SPLIT, [&](uint32_t j) {
+      const size_t a = items * j / SPLIT, b = items * (j + 1) / SPLIT;
+      part[j] = sum_words((const uint8_t*)p + a * item_bytes, (b - a) * item_bytes);
+    });
+    uint64_t s = 0;
+    for (uint64_t v : part) s += v;
+    return s;
+  };
   bool started = false, finished = false;  // (a loop that fails still arrives: the others must not wait for ever)
   try {
     std::vector<NodeId> ids;
@@ -95,10 +196,10 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
     loop.dense = mode != "general";
     loop.pipelined = pipe;
     uint64_t sink = 0, fsm_rows = 0, msg_rows = 0, col_bytes = 0, up_bytes = 0, general = 0;
-    raft.fsm_rows_tx = [&](const jg_fsm_row* r, size_t n) { sink += sum_words(r, n * sizeof(jg_fsm_row)), fsm_rows += n; };
-    raft.msg_rows_tx = [&](const jg_msg_row* r, size_t n) { sink += sum_words(r, n * sizeof(jg_msg_row)), msg_rows += n; };
+    raft.fsm_rows_tx = [&](const jg_fsm_row* r, size_t n) { sink += sum_split(r, n, sizeof(jg_fsm_row)), fsm_rows += n; };
+    raft.msg_rows_tx = [&](const jg_msg_row* r, size_t n) { sink += sum_split(r, n, sizeof(jg_msg_row)), msg_rows += n; };
     raft.columns_tx = [&](const jg_node_outbox& o) {
-      if (o.beat) sink += sum_words(o.beat, (size_t)G * 16) + sum_words(o.ae, (size_t)R * G * 8);
+      if (o.beat) sink += sum_split(o.beat, G, 16) + sum_split(o.ae, (size_t)R * G, 8);
       col_bytes += o.bytes_d2h, up_bytes += o.bytes_h2d, general += o.rows_general;
     };
     {  // this node wins every election the reference's way: Timeout, then granted votes until quorum
@@ -123,20 +224,31 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
     }
     // tick t's inbound rows, written by `put(i, kind, group, from, id, flag)` - the transport's decoder
     auto rows_of_tick = [&](uint32_t t) { return (size_t)G * (1 + (R - 1) * ((t & 1) ? 2 : 1)); };
-    auto fill = [&](uint32_t t, uint8_t* kind, uint32_t* group, uint32_t* from, uint64_t* id, uint8_t* flag) {
-      size_t i = 0;
+    // connection s (0: the clients, r >= 1: peer r) delivers its rows of tick t into its own stretch of the batch; job j of
+    // SPLIT covers the j-th part of the connection's partitions
+    auto fill_part = [&](uint32_t t, uint32_t s, uint32_t j, uint8_t* kind, uint32_t* group, uint32_t* from, uint64_t* id, uint8_t* flag) {
       const bool hb = t & 1;  // a follower answers the heartbeat it got with the previous tick's messages
-      for (uint32_t k = 0; k < G; k++) {
-        const uint32_t g = perm[k];
-        kind[i] = JG_CMD_CLIENT_REQUEST, group[i] = g, from[i] = 0, id[i] = (uint64_t)t * G + g, flag[i] = 0, i++;
-      }
-      for (uint32_t r = 1; r < R; r++)
-        for (uint32_t k = 0; k < G; k++) {
-          const uint32_t g = perm[(k + 7919u * r) % G];
-          if (hb) kind[i] = JG_CMD_HEARTBEAT_RESPONSE, group[i] = g, from[i] = ids[r], id[i] = t ? t - 1 : 0, flag[i] = 1, i++;
-          kind[i] = JG_CMD_APPEND_RESPONSE, group[i] = g, from[i] = ids[r], id[i] = t, flag[i] = 1, i++;
+      const uint32_t k0 = (uint32_t)((uint64_t)G * j / SPLIT), k1 = (uint32_t)((uint64_t)G * (j + 1) / SPLIT);
+      if (s == 0) {
+        for (uint32_t k = k0; k < k1; k++) {
+          const uint32_t g = perm[k];
+          kind[k] = JG_CMD_CLIENT_REQUEST, group[k] = g, from[k] = 0, id[k] = (uint64_t)t * G + g, flag[k] = 0;
         }
-      return i;
+        return;
+      }
+      const size_t per = hb ? 2 : 1;
+      size_t i = (size_t)G + (size_t)(s - 1) * G * per + (size_t)k0 * per;
+      uint32_t at = (uint32_t)((k0 + 7919ull * s) % G);  // (peer s's rows: the shuffle, rotated)
+      for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t g = perm[at];
+        at = at + 1 == G ? 0 : at + 1;
+        if (hb) kind[i] = JG_CMD_HEARTBEAT_RESPONSE, group[i] = g, from[i] = ids[s], id[i] = t ? t - 1 : 0, flag[i] = 1, i++;
+        kind[i] = JG_CMD_APPEND_RESPONSE, group[i] = g, from[i] = ids[s], id[i] = t, flag[i] = 1, i++;
+      }
+    };
+    auto fill = [&](uint32_t t, uint8_t* kind, uint32_t* group, uint32_t* from, uint64_t* id, uint8_t* flag) {
+      tasks.run(R * SPLIT, [&](uint32_t job) { fill_part(t, job / SPLIT, job % SPLIT, kind, group, from, id, flag); });
+      return rows_of_tick(t);
     };
     uint64_t c0[4], c1[4];
     double t_fill = 0, t_submit = 0, t_step = 0;
@@ -157,14 +269,19 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
       auto a = Clock::now();
       if (mode == "columns") {
         const bool hb = t & 1;
-        for (uint32_t r = 1; r < R; r++) {  // peer r's answers to last tick's Heartbeat / AppendEntries: one word per partition
-          uint64_t* ans = nullptr;
-          loop.tcp_rx_answer_column(r, &ans, nullptr);
-          const uint64_t w = JG_ANSWER((uint64_t)t, hb ? 1u : JG_HB_NONE);
-          for (uint32_t g = 0; g < G; g++) ans[g] = w;
-        }
+        uint64_t* ans[JG_MAX_REPLICAS] = {};
+        for (uint32_t r = 1; r < R; r++) loop.tcp_rx_answer_column(r, &ans[r], nullptr);
         const jg_cmd_cols c = loop.tcp_rx_reserve(G);
-        for (uint32_t k = 0; k < G; k++) c.kind[k] = JG_CMD_CLIENT_REQUEST, c.group[k] = perm[k], c.id[k] = (uint64_t)t * G + perm[k];
+        const uint64_t w = JG_ANSWER((uint64_t)t, hb ? 1u : JG_HB_NONE);
+        tasks.run(R * SPLIT, [&](uint32_t job) {
+          const uint32_t s = job / SPLIT, j = job % SPLIT;
+          const uint32_t k0 = (uint32_t)((uint64_t)G * j / SPLIT), k1 = (uint32_t)((uint64_t)G * (j + 1) / SPLIT);
+          if (s) {  // peer s's answers to last tick's Heartbeat / AppendEntries: one word per partition
+            for (uint32_t g = k0; g < k1; g++) ans[s][g] = w;
+          } else {
+            for (uint32_t k = k0; k < k1; k++) c.kind[k] = JG_CMD_CLIENT_REQUEST, c.group[k] = perm[k], c.id[k] = (uint64_t)t * G + perm[k];
+          }
+        });
         t_fill += ms_since(a), a = Clock::now();
         loop.tcp_rx_commit(G, 0, unchecked);
         t_submit += ms_since(a), a = Clock::now();
@@ -219,7 +336,34 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
   }
 }
 
+// `bench_event_loop tasks-selftest`: the fork-join pool alone (no engine, no GPU): every job of every run exactly once
+static int tasks_selftest() {
+  Tasks tasks(4);
+  uint64_t x = 1;
+  for (uint32_t round = 0; round < 20000; round++) {
+    x = x * 6364136223846793005ull + 1442695040888963407ull;
+    const uint32_t n = (uint32_t)(x >> 33) % 41;
+    std::vector<std::atomic<uint32_t>> hit(n);
+    for (auto& h : hit) h.store(0);
+    std::atomic<uint64_t> spun{0};
+    tasks.run(n, [&](uint32_t i) {
+      uint64_t v = i;
+      for (uint32_t k = 0; k < (round % 7) * 400u; k++) v = v * 6364136223846793005ull + k;  // (long enough for the helpers to join in)
+      spun.fetch_add(v);
+      hit[i].fetch_add(1);
+    });
+    for (uint32_t i = 0; i < n; i++)
+      if (hit[i].load() != 1) {
+        std::fprintf(stderr, "run %u: job %u of %u ran %u times\n", round, i, n, hit[i].load());
+        return 1;
+      }
+  }
+  std::printf("{\"ok\": true, \"threads\": %u}\n", tasks.threads());
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "tasks-selftest") return tasks_selftest();
   const uint32_t G = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 100000;
   const uint32_t R = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 5;
   const uint32_t T = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 50;
@@ -227,6 +371,7 @@ int main(int argc, char** argv) {
   const std::string mode = argc > 5 ? argv[5] : "inplace";
   const int device = argc > 6 ? std::atoi(argv[6]) : 0;
   const uint32_t L = argc > 7 ? (uint32_t)std::max(1, std::atoi(argv[7])) : 1;
+  const uint32_t helpers = argc > 8 ? (uint32_t)std::max(0, std::atoi(argv[8])) : R - 1;
   if (G % L) {
     std::fprintf(stderr, "the partitions do not divide over %u loops\n", L);
     return 2;
@@ -234,8 +379,8 @@ int main(int argc, char** argv) {
   Rendezvous rv(L);
   std::vector<LoopResult> res(L);
   std::vector<std::thread> th;
-  for (uint32_t l = 1; l < L; l++) th.emplace_back([&, l] { run_loop(G / L, R, T, W, mode, device, 42 + l, rv, res[l]); });
-  run_loop(G / L, R, T, W, mode, device, 42, rv, res[0]);
+  for (uint32_t l = 1; l < L; l++) th.emplace_back([&, l] { run_loop(G / L, R, T, W, mode, device, 42 + l, helpers, rv, res[l]); });
+  run_loop(G / L, R, T, W, mode, device, 42, helpers, rv, res[0]);
   for (std::thread& t : th) t.join();
   LoopResult a;
   a.ok = true;
@@ -249,12 +394,12 @@ int main(int argc, char** argv) {
     a.t_fill += r.t_fill / L, a.t_submit += r.t_submit / L, a.t_step += r.t_step / L;  // (per loop: they run side by side)
     k_us += r.k_us / L, a.k_n += r.k_n;
   }
-  std::printf("{\"ok\": %s, \"mode\": \"%s\", \"G\": %u, \"R\": %u, \"loops\": %u, \"ticks\": %u, \"warmup\": %u, \"decisions\": %llu, \"wall_ms\": %.3f, "
+  std::printf("{\"ok\": %s, \"mode\": \"%s\", \"G\": %u, \"R\": %u, \"loops\": %u, \"task_threads_beside_each_loop\": %u, \"ticks\": %u, \"warmup\": %u, \"decisions\": %llu, \"wall_ms\": %.3f, "
               "\"decisions_per_s\": %.6g, \"ms_per_tick\": %.4f, \"ms_fill\": %.4f, \"ms_submit\": %.4f, \"ms_step_and_drain\": %.4f, "
               "\"rows_in_per_tick\": %.1f, \"rows_general\": %llu, \"fsm_rows_per_tick\": %.1f, \"msg_rows_per_tick\": %.1f, "
               "\"pcie_h2d_bytes_per_tick\": %.1f, \"pcie_d2h_bytes_per_tick\": %.1f, \"leader_kernel_us\": %.3f, \"leader_kernel_launches\": %u, "
               "\"sink\": %llu}\n",
-              a.ok ? "true" : "false", mode.c_str(), G, R, L, T, W, (unsigned long long)a.decisions, a.wall_ms, a.decisions / (a.wall_ms / 1e3),
+              a.ok ? "true" : "false", mode.c_str(), G, R, L, mode.rfind("pipetasks", 0) == 0 ? helpers : 0u, T, W, (unsigned long long)a.decisions, a.wall_ms, a.decisions / (a.wall_ms / 1e3),
               a.wall_ms / T, a.t_fill / T, a.t_submit / T, a.t_step / T, (double)a.rows_in / T, (unsigned long long)a.general,
               (double)a.fsm_rows / T, (double)a.msg_rows / T, (double)a.up_bytes / T, (double)a.down_bytes / T, k_us, a.k_n,
               (unsigned long long)a.sink);

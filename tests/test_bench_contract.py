@@ -179,6 +179,9 @@ def test_event_loop_line():
     assert ev["loops"] == 4 and d["config"]["loops"] == 4 and "4 event loop(s) of 5000 partitions" in d["config"]["parallelism"]
     assert ev["loop_only_decisions_per_s"] >= ev["one_loop"]["decisions_per_s"] > 0
     assert ev["column_inbound"]["loops"] == 4 and ev["column_inbound"]["one_loop_decisions_per_s"] > 0
+    tk = ev["one_loop_with_transport_and_consumer_tasks"]  # (the binary checks the closed form of the stream in every mode)
+    assert tk["task_threads_beside_the_loop"] == 4 and tk["decisions_per_s"] > 0 and tk["column_inbound_decisions_per_s"] > 0
+    assert tk["rows_on_the_general_path"] == 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["avg_launch_us"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] == "port"
