@@ -2236,6 +2236,8 @@ struct jg_dense_cluster {
     char *h_jobs = nullptr, *d_jobs = nullptr;
     uint32_t group_bits = 1;
     bool ready = false;
+    hipEvent_t ev_counts = nullptr;               // behind the delivering pass's counts on their way to the host
+    uint32_t last_total = 0, last_fullest_seg = 0;  // the previous round's rows: what the ordering pass is sized for before the counts are in
   } rt;
 };
 
@@ -2324,6 +2326,7 @@ void jg_dense_cluster_destroy(jg_dense_cluster* c) {
   if (c->graph) (void)hipGraphDestroy(c->graph);
   if (c->any_h_jobs) (void)hipHostFree(c->any_h_jobs);
   if (c->any_ev) (void)hipEventDestroy(c->any_ev);
+  if (c->rt.ev_counts) (void)hipEventDestroy(c->rt.ev_counts);
   for (void* p : c->bufs) (void)jg_device_free(c->nodes[c->lead], p);
   for (void* p : {(void*)c->rt.key, (void*)c->rt.key_alt, (void*)c->rt.idx, (void*)c->rt.idx_alt, (void*)c->rt.row, (void*)c->rt.cols_mem})
     if (p) (void)hipFree(p);
@@ -2948,6 +2951,28 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   // -- 3. the transport, on the lead node's stream behind everybody's round
   for (uint32_t r = 0; r < R; r++)
     if (r != c->lead && (rc = jg_stream_wait(L, c->nodes[r]))) return rc;
+  // The ordering pass (bucket by (destination, group tile), sort every bucket in LDS: jg_route.h) takes everything it
+  // needs to know about the round's rows from the device - the segments' cursors - so it is launched BEHIND the
+  // delivering pass before the host has seen the counts: the host then waits for the counts' copy only (an event),
+  // with the ordering still queued, and does its bookkeeping and the next round's preparation while the device
+  // works.  (Waiting first left the device idle for the wake-up and the five launches: JG_ROUTE_SYNC_FIRST=1, the A/B.)
+  // A pass that has to be repeated (staging too small, emission index too wide) repeats the ordering with it.
+  static const bool sync_first = std::getenv("JG_ROUTE_SYNC_FIRST") != nullptr;
+  const bool optimistic = multi && !library_sort && !sync_first && rt.last_total != 0;
+  if (!rt.ev_counts) HIPCHK(hipEventCreateWithFlags(&rt.ev_counts, hipEventDisableTiming));
+  auto launch_order = [&](uint32_t fullest_seg) {
+    bk.shift = ord_bits + 3 + JG_ROUTE_STEP_BITS + tile_bits;  // (its counters were cleared with the tallies, before the delivering pass)
+    const uint32_t seg_cap = rt.cap / n_seg;
+    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((std::min(fullest_seg, seg_cap) + JG_BLOCK - 1) / JG_BLOCK, 4096 / n_seg));
+    hipLaunchKernelGGL(k_route_hist, dim3(grid, n_seg), dim3(JG_BLOCK), 0, st, (const uint32_t*)d_cursor, seg_cap, (const uint64_t*)rt.key, bk);
+    hipLaunchKernelGGL(k_route_scan, dim3(n_tiles), dim3(JG_BLOCK), 0, st, bk);
+    hipLaunchKernelGGL(k_route_scan_tiles, dim3(1), dim3(JG_BLOCK), 0, st, bk);
+    hipLaunchKernelGGL(k_route_scatter, dim3(grid, n_seg), dim3(JG_BLOCK), 0, st, (const uint32_t*)d_cursor, seg_cap, (const uint64_t*)rt.key,
+                       (const uint32_t*)rt.idx, bk, rt.key_alt, rt.idx_alt);
+    hipLaunchKernelGGL(k_route_sort_build, dim3(bk.n_buckets), dim3(JG_BLOCK), 0, st, bk, rt.key_alt, rt.idx_alt, (const jg_msg_row*)rt.row,
+                       rt.cols);
+  };
+  bool ordered = false;
   for (int attempt = 0;; attempt++) {  // (repeated once when the staging turns out too small: the pass modifies nothing)
     hipLaunchKernelGGL(k_route_clear, dim3(64), dim3(JG_BLOCK), 0, st, rt.d_count, (uint32_t)words, bk.hist, bk_clear);
     if (attempt) {  // (every attempt ends with a synchronisation - the counts - so the staging is free again)
@@ -2970,8 +2995,16 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(rt.h_count, rt.d_count, words * 4, hipMemcpyDeviceToHost, st));
+    ordered = false;
+    if (optimistic) {
+      HIPCHK(hipEventRecord(rt.ev_counts, st));
+      launch_order(2 * rt.last_fullest_seg + JG_BLOCK);  // (a round's rows come in the numbers the last round's did; the kernels stride)
+      HIPCHK(hipGetLastError());
+      ordered = true;
+    }
     T2 = clk();
-    HIPCHK(hipStreamSynchronize(st));
+    if (optimistic) HIPCHK(hipEventSynchronize(rt.ev_counts));
+    else HIPCHK(hipStreamSynchronize(st));
     T3 = clk();
     bool wide = false;  // some group emitted more rows in one step than the narrow index field numbers
     for (uint32_t s = 0; s < R; s++) wide = wide || rt.h_count[(size_t)s * ROUTE_WORDS + R + JG_ROUTE_OVERFLOW];
@@ -3026,17 +3059,9 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   // the staged rows in (destination, group, sender, step, emission) order -> the command columns of every
   // node's next round: bucket by (destination, group tile), sort every bucket in LDS (jg_route.h); the
   // library sort stays behind JG_ROUTE_LIBRARY_SORT=1 for an A/B
+  rt.last_total = total, rt.last_fullest_seg = fullest_seg;
   if (total && !library_sort) {
-    bk.shift = ord_bits + 3 + JG_ROUTE_STEP_BITS + tile_bits;  // (its counters were cleared with the tallies, before the delivering pass)
-    const uint32_t grid = std::min<uint32_t>((fullest_seg + JG_BLOCK - 1) / JG_BLOCK, 4096 / n_seg);
-    const uint32_t seg_cap = rt.cap / n_seg;
-    hipLaunchKernelGGL(k_route_hist, dim3(grid, n_seg), dim3(JG_BLOCK), 0, st, (const uint32_t*)d_cursor, seg_cap, (const uint64_t*)rt.key, bk);
-    hipLaunchKernelGGL(k_route_scan, dim3(n_tiles), dim3(JG_BLOCK), 0, st, bk);
-    hipLaunchKernelGGL(k_route_scan_tiles, dim3(1), dim3(JG_BLOCK), 0, st, bk);
-    hipLaunchKernelGGL(k_route_scatter, dim3(grid, n_seg), dim3(JG_BLOCK), 0, st, (const uint32_t*)d_cursor, seg_cap, (const uint64_t*)rt.key,
-                       (const uint32_t*)rt.idx, bk, rt.key_alt, rt.idx_alt);
-    hipLaunchKernelGGL(k_route_sort_build, dim3(bk.n_buckets), dim3(JG_BLOCK), 0, st, bk, rt.key_alt, rt.idx_alt, (const jg_msg_row*)rt.row,
-                       rt.cols);
+    if (!ordered) launch_order(fullest_seg);
   } else if (total) {
     const uint32_t end_bit = ord_bits + 3 + JG_ROUTE_STEP_BITS + rt.group_bits + 3;
     size_t need = 0;
