@@ -185,11 +185,16 @@ __global__ __launch_bounds__(JG_BLOCK) void k_apply_votes_multi(const JgApplyJob
 // every lane takes a RUN off that list: ~160 of 256 lanes at work.  A run that crosses the tile's end is
 // finished from global memory by the lane that started it.  Outputs, counts and tile sums exactly as
 // jg_apply_rows_body leaves them.
+// A small batch (a round of a 3-replica cluster's elections: 20 k rows per node in runs of 2-4) takes tiles of
+// JG_RUN_TILE_SMALL rows: four times the workgroups (21 tiles of 1024 do not fill a device of 256 CUs), and a tile's
+// ~100 runs are one trip of its 256 lanes where the ~400 runs of a 1024-row tile were two, one behind the other.
 #define JG_RUN_TILE 1024u
-template <uint32_t KINDS = JG_KINDS_ALL>
+#define JG_RUN_TILE_SMALL 256u
+#define JG_RUN_SMALL_BATCH 200000u  // rows: batches up to here take the small tile
+template <uint32_t KINDS = JG_KINDS_ALL, uint32_t TILE = JG_RUN_TILE>
 __device__ __forceinline__ void jg_apply_runs_body(const JgDev& d, const JgRowsArgs& a) {
-  static_assert(JG_RUN_TILE % JG_BLOCK == 0 && JG_RUN_TILE <= 65536, "tile geometry");
-  constexpr uint32_t T = JG_RUN_TILE, SUB = JG_RUN_TILE / JG_BLOCK;
+  static_assert(TILE % JG_BLOCK == 0 && TILE <= 65536, "tile geometry");
+  constexpr uint32_t T = TILE, SUB = TILE / JG_BLOCK;
   __shared__ uint64_t s_term[T], s_id[T], s_aux[T];
   __shared__ uint32_t s_group[T], s_from[T];
   __shared__ uint8_t s_kind[T], s_flag[T];
@@ -280,6 +285,7 @@ __device__ __forceinline__ void jg_apply_runs_body(const JgDev& d, const JgRowsA
 }
 // (one batch, arguments by value: what jg_step takes with JG_APPLY_RUNS=1 - the fuzz suites then run through this body)
 __global__ __launch_bounds__(JG_BLOCK) void k_apply_runs(JgDev d, JgRowsArgs a) { jg_apply_runs_body(d, a); }
+__global__ __launch_bounds__(JG_BLOCK) void k_apply_runs_small(JgDev d, JgRowsArgs a) { jg_apply_runs_body<JG_KINDS_ALL, JG_RUN_TILE_SMALL>(d, a); }
 __global__ __launch_bounds__(JG_BLOCK) void k_apply_runs_multi(const JgApplyJob* __restrict__ jobs) {
   const JgApplyJob& j = jobs[blockIdx.y];
   jg_apply_runs_body(j.d, j.a);
@@ -287,6 +293,14 @@ __global__ __launch_bounds__(JG_BLOCK) void k_apply_runs_multi(const JgApplyJob*
 __global__ __launch_bounds__(JG_BLOCK) void k_apply_vote_runs_multi(const JgApplyJob* __restrict__ jobs) {
   const JgApplyJob& j = jobs[blockIdx.y];
   jg_apply_runs_body<JG_KINDS_ELECTION>(j.d, j.a);
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_apply_runs_multi_small(const JgApplyJob* __restrict__ jobs) {
+  const JgApplyJob& j = jobs[blockIdx.y];
+  jg_apply_runs_body<JG_KINDS_ALL, JG_RUN_TILE_SMALL>(j.d, j.a);
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_apply_vote_runs_multi_small(const JgApplyJob* __restrict__ jobs) {
+  const JgApplyJob& j = jobs[blockIdx.y];
+  jg_apply_runs_body<JG_KINDS_ELECTION, JG_RUN_TILE_SMALL>(j.d, j.a);
 }
 
 // ---- drain-time compaction, entirely on the device -------------------------------------------

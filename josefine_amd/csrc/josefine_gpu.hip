@@ -1218,8 +1218,13 @@ int launch_rows(jg_engine* e, uint32_t n, const uint32_t* group, const uint8_t* 
   if (rc) return rc;
   // JG_APPLY_RUNS=1 (test hook): the run-per-lane body the cluster transport's batches take (jg_apply_runs_body) for
   // every batch - the fuzz and parity suites then hold it to the oracle with runs of every length across its tiles
-  static const bool runs = std::getenv("JG_APPLY_RUNS") != nullptr;
-  if (runs)
+  // (JG_APPLY_RUNS=small: with the 256-row tiles small batches take)
+  static const char* runs_env = std::getenv("JG_APPLY_RUNS");
+  static const bool runs = runs_env != nullptr, runs_small = runs_env && std::string(runs_env) == "small";
+  if (runs_small)
+    hipLaunchKernelGGL(k_apply_runs_small, dim3(std::min<uint32_t>((n + JG_RUN_TILE_SMALL - 1) / JG_RUN_TILE_SMALL, e->count_slots)), dim3(JG_BLOCK), 0,
+                       e->stream, e->dev, a);
+  else if (runs)
     hipLaunchKernelGGL(k_apply_runs, dim3(std::min<uint32_t>((n + JG_RUN_TILE - 1) / JG_RUN_TILE, e->count_slots)), dim3(JG_BLOCK), 0, e->stream,
                        e->dev, a);
   else
@@ -2773,15 +2778,20 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   // (multi: the job tables of the whole round - both sparse steps, the follower halves, the delivering pass - are
   // written first and travel in ONE copy: every table is host bookkeeping only, and a copy costs ~10 us of stream time)
   static const bool row_per_lane = std::getenv("JG_ROUTE_ROW_PER_LANE") != nullptr;  // (A/B: the row-per-lane kernels for the delivered rows)
-  auto run_grid = [&](uint32_t widest) { return std::min<uint32_t>(std::max<uint32_t>((widest + JG_RUN_TILE - 1) / JG_RUN_TILE, 1u), L->count_slots); };
+  static const bool big_tiles_only = std::getenv("JG_ROUTE_BIG_TILES") != nullptr;  // (A/B: 1024-row tiles whatever the batch)
+  auto small_tiles = [&](uint32_t widest) { return widest <= JG_RUN_SMALL_BATCH && !big_tiles_only; };
+  auto run_grid = [&](uint32_t widest) {
+    const uint32_t tile = small_tiles(widest) ? JG_RUN_TILE_SMALL : JG_RUN_TILE;
+    return std::min<uint32_t>(std::max<uint32_t>((widest + tile - 1) / tile, 1u), L->count_slots);
+  };
   auto apply_all = [&](int slice, std::vector<JgApplyJob>& jobs, uint32_t widest) -> int {
     if (jobs.empty()) return JG_OK;
     if (!multi) {
       for (size_t k = 0; k < jobs.size(); k++)
         hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(jobs[k].a.n, L->count_slots)), dim3(JG_BLOCK), 0, L->stream, jobs[k].d, jobs[k].a);
     } else if (slice == 0 && !row_per_lane) {  // delivered rows: runs of 4-16 rows per group, a RUN per lane (jg_apply_runs_body)
-      hipLaunchKernelGGL(k_apply_runs_multi, dim3(run_grid(widest), (uint32_t)jobs.size()), dim3(JG_BLOCK), 0, L->stream,
-                         (const JgApplyJob*)slice_d(slice));
+      hipLaunchKernelGGL(small_tiles(widest) ? k_apply_runs_multi_small : k_apply_runs_multi, dim3(run_grid(widest), (uint32_t)jobs.size()),
+                         dim3(JG_BLOCK), 0, L->stream, (const JgApplyJob*)slice_d(slice));
     } else {
       hipLaunchKernelGGL(k_apply_rows_multi, dim3(grid_for(widest, L->count_slots), (uint32_t)jobs.size()), dim3(JG_BLOCK), 0, L->stream,
                          (const JgApplyJob*)slice_d(slice));
@@ -2934,7 +2944,8 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       hipLaunchKernelGGL(k_apply_votes_multi, dim3(grid_for(widest_v, L->count_slots), (uint32_t)jobs_v.size()), dim3(JG_BLOCK), 0, L->stream,
                          (const JgApplyJob*)slice_d(0) + jobs_a.size());
     else
-      hipLaunchKernelGGL(k_apply_vote_runs_multi, dim3(run_grid(widest_v), (uint32_t)jobs_v.size()), dim3(JG_BLOCK), 0, L->stream,
+      hipLaunchKernelGGL(small_tiles(widest_v) ? k_apply_vote_runs_multi_small : k_apply_vote_runs_multi,
+                         dim3(run_grid(widest_v), (uint32_t)jobs_v.size()), dim3(JG_BLOCK), 0, L->stream,
                          (const JgApplyJob*)slice_d(0) + jobs_a.size());
     HIPCHK(hipGetLastError());
   }

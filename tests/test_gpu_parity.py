@@ -585,16 +585,18 @@ def test_follower_down_stays_on_the_fast_path_and_exact(R, entry):
     assert (h > 2 * esc).all() and not ora.read("fault").any() and (m1 > 0).all()
 
 
-@pytest.mark.parametrize("which", ["fuzz", "dense_equals_sparse or election_setup or device_r or chain_window or follower_down"])
-def test_run_per_lane_state_machine_kernel_holds_the_same_parity(which):
-    """jg_apply_runs_body - a RUN of a group's rows per lane, tiles of 1024 rows staged in LDS: what the cluster
-    transport's delivered batches take - behind jg_step for every batch (JG_APPLY_RUNS=1, read once per process:
-    hence the subprocess): the blind and the state-aware fuzz streams (runs of every length, runs that cross a
-    tile's end, tiles inside one run) and the election / dense-equals-sparse suites against the oracle."""
+@pytest.mark.parametrize("which,tile", [("fuzz", "1"), ("fuzz", "small"),
+                                        ("dense_equals_sparse or election_setup or device_r or chain_window or follower_down", "1")])
+def test_run_per_lane_state_machine_kernel_holds_the_same_parity(which, tile):
+    """jg_apply_runs_body - a RUN of a group's rows per lane, tiles of 1024 rows staged in LDS (256 for small batches:
+    JG_APPLY_RUNS=small): what the cluster transport's delivered batches take - behind jg_step for every batch
+    (JG_APPLY_RUNS, read once per process: hence the subprocess): the blind and the state-aware fuzz streams (runs of
+    every length, runs that cross a tile's end, tiles inside one run) and the election / dense-equals-sparse suites
+    against the oracle."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", f"({which}) and not run_per_lane"],
-                       capture_output=True, text=True, timeout=900, cwd=root, env={**os.environ, "JG_APPLY_RUNS": "1"})
+                       capture_output=True, text=True, timeout=900, cwd=root, env={**os.environ, "JG_APPLY_RUNS": tile})
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
