@@ -352,15 +352,16 @@ __device__ __forceinline__ void jg_defer_push(const JgDev& d, uint32_t g, bool w
 // base to the wave: at 1 % deferred groups per tick half the waves of a launch sat out a trip to
 // L2 for it and the configs[4] tick of this kernel took 39 us instead of 11.)  k_dense_slow turns
 // its shard of the bitmap into its list.
-__device__ __forceinline__ void jg_defer_mark(const JgDev& d, uint32_t g, bool want) {
+__device__ __forceinline__ void jg_defer_mark_in(uint64_t* bits, const JgDev& d, uint32_t g, bool want) {
   const uint64_t mask = __ballot(want);
   if (!mask) return;
   const int first = __ffsll((long long)mask) - 1;
   if ((int)(threadIdx.x & 63u) == first) {
-    (void)__hip_atomic_fetch_or(&d.defer_bits[g >> 6], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_or(&bits[g >> 6], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *d.deferred_seen = 1;  // lets the host verify that the slow kernel was scheduled
   }
 }
+__device__ __forceinline__ void jg_defer_mark(const JgDev& d, uint32_t g, bool want) { jg_defer_mark_in(d.defer_bits, d, g, want); }
 
 // Node-tick extras of the leader kernel (jg_step_dense_leader): HeartbeatResponse input and the
 // Tick's outbox (leader.rs:234-245).  All pointers may be null (= plain jg_step_dense_acks).

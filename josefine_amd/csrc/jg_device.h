@@ -137,6 +137,7 @@ struct JgDev {
   uint32_t* slow_list;       // [JG_SHARDS][ceil(G/JG_SHARDS)] deferred groups per shard
   uint32_t* slow_cnt;        // [JG_SHARDS]
   uint64_t* defer_bits;      // [ceil(G/64)] groups a dense leader kernel handed to k_dense_slow (bit g & 63 of word g >> 6)
+  uint64_t* fdefer_bits;     // [2][ceil(G/64)] ... the dense follower half handed to k_follower_slow: [0] inputs and Tick, [1] the Tick only
   uint32_t* irregular_seen;  // set when a leader is stored with a chain that is not in FAST form
   uint32_t* cold_seen;       // set when the ack-only dense kernel took its in-kernel general path
   JgXqRec* xq;               // exceptional message rows of dense node steps (lazily allocated)

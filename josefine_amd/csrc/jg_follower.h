@@ -15,7 +15,7 @@
 //   Tick           election timer; a follower that has voted never campaigns (follower.rs:249, Q4)
 //
 // Everything else (candidates whose timer fires, leaders with input, input for irregular chains or
-// with queued requests, a timer that fires on a follower that has not voted) is deferred (jg_defer_push) to k_follower_slow,
+// with queued requests, a timer that fires on a follower that has not voted) is deferred (jg_defer_mark_in) to k_follower_slow,
 // which runs the general state machine and maps AppendResponse / HeartbeatResponse rows back to
 // the outbox columns; rows outside the mailbox vocabulary go to the exceptional queue.
 //
@@ -110,7 +110,7 @@ __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollower
     const bool nothing = (!has_hb && !has_ae && !a.tick) || quiet;
     const bool fast = role == JG_ROLE_FOLLOWER && (f & JGF_RUN) && queued == 0;
     const bool defer = !dead && !idle_leader && !nothing && !fast;
-    jg_defer_push(d, g, defer);
+    jg_defer_mark_in(d.fdefer_bits, d, g, defer);
     if (dead || idle_leader || nothing || defer) {
       // nothing; the slow kernel overwrites the words of its groups (ANY: the own slot's word of a group this node owns is nobody's)
       if (!(ANY && idle_leader && own == a.self_slot)) a.o_answer[g] = JG_NO_ACK;
@@ -196,8 +196,8 @@ __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollower
       if (voted_for != vf0 || leader_id != lid0) jg_cold_store_rest(d.cold, g, c);
     }
     if (nf != f) d.flags[g] = nf;
-    // (divergent use of the wave-aggregated push is fine: the ballot covers the active lanes)
-    jg_defer_push(d, g, tick_defer, JG_DEFER_TICK_ONLY);
+    // (divergent use of the wave-aggregated mark is fine: the ballot covers the active lanes)
+    jg_defer_mark_in(d.fdefer_bits + (G + 63u) / 64u, d, g, tick_defer);
   }
 }
 
@@ -224,8 +224,35 @@ __global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense_any(const JgFo
 __device__ __forceinline__ void jg_follower_slow_body(const JgDev& d, JgFollowerArgs a) {
   if (a.clock) jg_clock_read(a.clock, a.clock_slot, a.now, a.seq), a.seq += a.seq_off;
   uint32_t dec = 0;
-  const uint32_t n = d.slow_cnt[blockIdx.x] < d.slow_cap ? d.slow_cnt[blockIdx.x] : d.slow_cap;
-  const uint32_t* list = d.slow_list + (size_t)blockIdx.x * d.slow_cap;
+  // this workgroup's shard of the two deferral bitmaps (jg_defer_mark_in: a wave of the dense half or-s its ballot in
+  // and goes on - appending to a list made every wave with a deferred group wait for its slot) -> its list, the
+  // words cleared for the next launch; the order within the list is immaterial (see k_dense_slow)
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  uint32_t* list = d.slow_list + (size_t)blockIdx.x * d.slow_cap;
+  {
+    const uint32_t n_words = (d.G + 63u) / 64u;
+    const uint32_t wpb = (n_words + gridDim.x - 1) / gridDim.x;
+    const uint32_t w0 = blockIdx.x * wpb, w1 = w0 + wpb < n_words ? w0 + wpb : n_words;
+    for (uint32_t w = w0 + threadIdx.x; w < w1; w += JG_BLOCK) {
+      uint64_t m = d.fdefer_bits[w], mt = d.fdefer_bits[n_words + w];
+      if (!(m | mt)) continue;
+      if (m) d.fdefer_bits[w] = 0;
+      if (mt) d.fdefer_bits[n_words + w] = 0;
+      uint32_t at = atomicAdd(&s_n, (uint32_t)(__popcll(m) + __popcll(mt)));
+      for (int pass = 0; pass < 2; pass++) {
+        uint64_t b = pass ? mt : m;
+        for (; b; b &= b - 1, at++) {
+          const uint32_t g = w * 64u + (uint32_t)__ffsll((long long)b) - 1u;
+          if (at < d.slow_cap) list[at] = g | (pass ? JG_DEFER_TICK_ONLY : 0u);
+          else *d.err = 4;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t n = s_n < d.slow_cap ? s_n : d.slow_cap;
   for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) {
     const uint32_t entry = list[i];
     const uint32_t g = entry & ~JG_DEFER_TICK_ONLY;
@@ -294,8 +321,6 @@ __device__ __forceinline__ void jg_follower_slow_body(const JgDev& d, JgFollower
     dec += L.decisions;
     jg_store(d, L);
   }
-  __syncthreads();
-  if (threadIdx.x == 0) d.slow_cnt[blockIdx.x] = 0;
   jg_block_count(d.blk_decisions, dec);
 }
 __global__ __launch_bounds__(JG_BLOCK) void k_follower_slow(JgDev d, JgFollowerArgs a) { jg_follower_slow_body(d, a); }

@@ -1346,6 +1346,7 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   A(d.slow_list, (size_t)JG_SHARDS * d.slow_cap);
   A(d.slow_cnt, JG_SHARDS);
   A(d.defer_bits, (G + 63) / 64);
+  A(d.fdefer_bits, 2 * ((G + 63) / 64));
   A(e->d_ones, 2);
   A(e->d_dev2[0], 1);
   A(e->d_dev2[1], 1);
