@@ -26,6 +26,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
            "-Wno-unused-function", "-o", LIB, os.path.join(CSRC, "josefine_gpu.hip")]
     if os.environ.get("JG_BLOCK"):  # workgroup-size experiments (profiles/README.md); default 256
         cmd.insert(1, "-DJG_BLOCK=" + os.environ["JG_BLOCK"])
+    if os.environ.get("JG_GSM_WAVES"):  # occupancy experiment: the general state machine's kernels held to 512 / N VGPRs
+        cmd.insert(1, "-DJG_GSM_WAVES=" + os.environ["JG_GSM_WAVES"])
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -29,6 +29,12 @@
 #define JGF_HAS_LEADER (1u << 3)
 #define JGF_FAST (1u << 4)
 #define JGF_COMMIT_KEY (1u << 5)
+// (experiment: -DJG_GSM_WAVES=4 holds the general state machine's kernels to 128 VGPRs - the rest goes to scratch)
+#ifdef JG_GSM_WAVES
+#define JG_GSM_OCC __attribute__((amdgpu_waves_per_eu(JG_GSM_WAVES)))
+#else
+#define JG_GSM_OCC
+#endif
 #define JGF_NO_GENESIS (1u << 6)
 #define JGF_RUN (1u << 7)
 #define JGF_REPL_SHIFT 8

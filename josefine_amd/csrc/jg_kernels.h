@@ -232,7 +232,7 @@ __device__ __forceinline__ void jg_dense_slow_body(const JgDev& d, const uint64_
   jg_block_count(d.blk_decisions, dec);
 }
 template <bool NODE>
-__global__ __launch_bounds__(JG_BLOCK) void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
+__global__ __launch_bounds__(JG_BLOCK) JG_GSM_OCC void k_dense_slow(JgDev d, const uint64_t* __restrict__ acks, uint32_t n_ticks,
                                                           size_t tick_stride, uint32_t seq0, JgLeaderNode nd) {
   jg_dense_slow_body<NODE>(d, acks, n_ticks, tick_stride, seq0, nd, true);
 }
@@ -248,7 +248,7 @@ struct JgLeaderSlowJob {
 struct JgLeaderSlowJobs {
   JgLeaderSlowJob j[JG_LEADER_MULTI];
 };
-__global__ __launch_bounds__(JG_BLOCK) void k_dense_slow_multi(JgLeaderSlowJobs jobs) {
+__global__ __launch_bounds__(JG_BLOCK) JG_GSM_OCC void k_dense_slow_multi(JgLeaderSlowJobs jobs) {
   const JgLeaderSlowJob& j = jobs.j[blockIdx.y];
   jg_dense_slow_body<true>(j.d, j.acks, 1, 0, j.seq0, j.nd, blockIdx.y == 0);
 }

@@ -157,7 +157,7 @@ __device__ __forceinline__ void jg_apply_rows_body(const JgDev& d, const JgRowsA
   jg_block_count(d.blk_decisions, dec);
 }
 
-__global__ __launch_bounds__(JG_BLOCK) void k_apply_rows(JgDev d, JgRowsArgs a) { jg_apply_rows_body(d, a); }
+__global__ __launch_bounds__(JG_BLOCK) JG_GSM_OCC void k_apply_rows(JgDev d, JgRowsArgs a) { jg_apply_rows_body(d, a); }
 // The steps of several engines that share a stream in ONE launch (blockIdx.y = engine): the routed round of a
 // cluster applies up to two batches per node and round - seven launches of ~30 us one behind the other, the
 // longest (the candidate node's) setting the pace of each.  Jobs live in device memory.
@@ -165,7 +165,7 @@ struct JgApplyJob {
   JgDev d;
   JgRowsArgs a;
 };
-__global__ __launch_bounds__(JG_BLOCK) void k_apply_rows_multi(const JgApplyJob* __restrict__ jobs) {
+__global__ __launch_bounds__(JG_BLOCK) JG_GSM_OCC void k_apply_rows_multi(const JgApplyJob* __restrict__ jobs) {
   const JgApplyJob& j = jobs[blockIdx.y];  // (through the reference: 64 us per launch; a by-value copy of the job went to scratch: 198 us)
   jg_apply_rows_body(j.d, j.a);
 }
@@ -284,9 +284,9 @@ __device__ __forceinline__ void jg_apply_runs_body(const JgDev& d, const JgRowsA
   jg_block_count(d.blk_decisions, dec);
 }
 // (one batch, arguments by value: what jg_step takes with JG_APPLY_RUNS=1 - the fuzz suites then run through this body)
-__global__ __launch_bounds__(JG_BLOCK) void k_apply_runs(JgDev d, JgRowsArgs a) { jg_apply_runs_body(d, a); }
-__global__ __launch_bounds__(JG_BLOCK) void k_apply_runs_small(JgDev d, JgRowsArgs a) { jg_apply_runs_body<JG_KINDS_ALL, JG_RUN_TILE_SMALL>(d, a); }
-__global__ __launch_bounds__(JG_BLOCK) void k_apply_runs_multi(const JgApplyJob* __restrict__ jobs) {
+__global__ __launch_bounds__(JG_BLOCK) JG_GSM_OCC void k_apply_runs(JgDev d, JgRowsArgs a) { jg_apply_runs_body(d, a); }
+__global__ __launch_bounds__(JG_BLOCK) JG_GSM_OCC void k_apply_runs_small(JgDev d, JgRowsArgs a) { jg_apply_runs_body<JG_KINDS_ALL, JG_RUN_TILE_SMALL>(d, a); }
+__global__ __launch_bounds__(JG_BLOCK) JG_GSM_OCC void k_apply_runs_multi(const JgApplyJob* __restrict__ jobs) {
   const JgApplyJob& j = jobs[blockIdx.y];
   jg_apply_runs_body(j.d, j.a);
 }
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_apply_vote_runs_multi(const JgAppl
   const JgApplyJob& j = jobs[blockIdx.y];
   jg_apply_runs_body<JG_KINDS_ELECTION>(j.d, j.a);
 }
-__global__ __launch_bounds__(JG_BLOCK) void k_apply_runs_multi_small(const JgApplyJob* __restrict__ jobs) {
+__global__ __launch_bounds__(JG_BLOCK) JG_GSM_OCC void k_apply_runs_multi_small(const JgApplyJob* __restrict__ jobs) {
   const JgApplyJob& j = jobs[blockIdx.y];
   jg_apply_runs_body<JG_KINDS_ALL, JG_RUN_TILE_SMALL>(j.d, j.a);
 }

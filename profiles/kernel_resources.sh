@@ -13,9 +13,11 @@ for ln in sys.stdin:
     if m and cur: rows[cur][m.group(1).strip()] = m.group(2)
 import subprocess
 def dem(n):
-    try: return subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', n], capture_output=True, text=True).stdout.strip().split('(')[0]
+    try: return subprocess.run(['c++filt', n], capture_output=True, text=True).stdout.strip().replace('(anonymous namespace)::', '').split('(')[0]
     except Exception: return n
 print('kernel, VGPRs, AGPRs, SGPRs, scratch B/lane, LDS B/workgroup, occupancy waves/SIMD')
-for k, v in sorted(rows.items(), key=lambda kv: dem(kv[0])):
+lib = [k for k in rows if 'rocprim' in k]
+print('# (%d rocprim instantiations omitted: the library radix sort behind JG_ROUTE_LIBRARY_SORT=1, an A/B only)' % len(lib))
+for k, v in sorted(((k, v) for k, v in rows.items() if 'rocprim' not in k), key=lambda kv: dem(kv[0])):
     print(', '.join([dem(k), v.get('VGPRs','?'), v.get('AGPRs','?'), v.get('TotalSGPRs','?'), v.get('ScratchSize [bytes/lane]','?'), v.get('LDS Size [bytes/block]','?'), v.get('Occupancy [waves/SIMD]','?')]))
 "
