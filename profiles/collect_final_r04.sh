@@ -48,6 +48,7 @@ if [ "$part" = all ] || [ "$part" = stats ]; then
   stats cluster_failures_1pct $B --cluster --failures 1 --steps 50 --warmup 10 --no-cpu-baseline
   stats failures_1pct $B --failures 1 --steps 160 --warmup 64 --no-cpu-baseline
   stats event_loop_100k $E 100000 5 30 5 pipe
+  stats any_failures_x3 $B --cluster --any-leader --replicas 3 --failures 1 --steps 100 --warmup 20
   head -4 $O/kernel_stats_1M.csv | cut -c1-160
 fi
 pmc() {  # name, counter, command...
