@@ -2200,6 +2200,11 @@ struct jg_dense_cluster {
   bool failed = false;  // a routed round failed after it had consumed the delivered rows: the in-flight votes are gone
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  // ... and `many_rounds` consecutive rounds as ONE graph (the clock advances itself: JgClock): a graph launch costs
+  // a few microseconds of its own beside its nodes', shared by the rounds it holds
+  hipGraph_t graph_many = nullptr;
+  hipGraphExec_t exec_many = nullptr;
+  uint32_t many_rounds = 0;
   uint64_t sig = 0, graph_dt = 0;
   uint64_t* offered = nullptr;  // [G] the ClientRequests per round as set by jg_dense_cluster_set_appends
   // per-partition leadership (lead == JG_CLUSTER_ANY_LEADER at creation): every node runs both halves over the
@@ -2330,6 +2335,8 @@ void jg_dense_cluster_destroy(jg_dense_cluster* c) {
     }
   if (c->exec) (void)hipGraphExecDestroy(c->exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
+  if (c->exec_many) (void)hipGraphExecDestroy(c->exec_many);
+  if (c->graph_many) (void)hipGraphDestroy(c->graph_many);
   if (c->any_h_jobs) (void)hipHostFree(c->any_h_jobs);
   if (c->any_ev) (void)hipEventDestroy(c->any_ev);
   if (c->rt.ev_counts) (void)hipEventDestroy(c->rt.ev_counts);
@@ -2573,10 +2580,12 @@ uint64_t cluster_signature(const jg_dense_cluster* c, uint64_t dt) {
   return h;
 }
 
-int cluster_capture(jg_dense_cluster* c, uint64_t dt_ms) {
+int cluster_capture(jg_dense_cluster* c, uint64_t dt_ms, uint32_t rounds = 1) {
   jg_engine* L = c->nodes[c->lead];
-  if (c->exec) (void)hipGraphExecDestroy(c->exec), c->exec = nullptr;
-  if (c->graph) (void)hipGraphDestroy(c->graph), c->graph = nullptr;
+  hipGraph_t& graph = rounds > 1 ? c->graph_many : c->graph;
+  hipGraphExec_t& exec = rounds > 1 ? c->exec_many : c->exec;
+  if (exec) (void)hipGraphExecDestroy(exec), exec = nullptr;
+  if (graph) (void)hipGraphDestroy(graph), graph = nullptr;
   struct Saved {
     uint32_t seq;
     uint64_t n_dense, n_launch;
@@ -2607,10 +2616,12 @@ int cluster_capture(jg_dense_cluster* c, uint64_t dt_ms) {
   if (c->any && (rc = cluster_tables_any(c, 0, true))) return rc;  // (the tables, before the capture begins)
   hipError_t he = hipStreamBeginCapture(L->stream, hipStreamCaptureModeRelaxed);
   if (he == hipSuccess) {
-    rc = c->any ? cluster_launch_any(c) : cluster_round_body(c, 0, false, multi);
-    for (uint32_t r = 0; r < c->R && !rc; r++)  // every forked stream joins the leader's again
-      if (r != c->lead) rc = jg_stream_wait(L, c->nodes[r]);
-    he = hipStreamEndCapture(L->stream, &c->graph);
+    for (uint32_t k = 0; k < rounds && !rc; k++) {
+      rc = c->any ? cluster_launch_any(c) : cluster_round_body(c, 0, false, multi);
+      for (uint32_t r = 0; r < c->R && !rc; r++)  // every forked stream joins the leader's again
+        if (r != c->lead) rc = jg_stream_wait(L, c->nodes[r]);
+    }
+    he = hipStreamEndCapture(L->stream, &graph);
   }
   for (uint32_t r = 0; r < c->R; r++) {  // nothing has run: the host-side bookkeeping of the captured calls is undone
     jg_engine* e = c->nodes[r];
@@ -2619,8 +2630,9 @@ int cluster_capture(jg_dense_cluster* c, uint64_t dt_ms) {
   }
   if (rc) return rc;
   if (he != hipSuccess) return fail(JG_EDEVICE, std::string("hipGraph capture: ") + hipGetErrorString(he));
-  HIPCHK(hipGraphInstantiate(&c->exec, c->graph, nullptr, nullptr, 0));
-  c->sig = cluster_signature(c, dt_ms);
+  HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  if (rounds > 1) c->many_rounds = rounds;
+  else c->sig = cluster_signature(c, dt_ms);
   return JG_OK;
 }
 }  // namespace
@@ -2657,8 +2669,17 @@ int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms
     HIPCHK(hipMalloc((void**)&c->clock, sizeof(JgClock)));
     c->bufs.push_back(c->clock);
   }
-  if (!c->exec || c->sig != cluster_signature(c, dt_ms))
+  // (JG_CLUSTER_ROUNDS_PER_GRAPH: how many rounds the long graph holds - 1: none, the A/B; kernel timing brackets single launches)
+  static const uint32_t per_graph = std::getenv("JG_CLUSTER_ROUNDS_PER_GRAPH") ? (uint32_t)std::atoi(std::getenv("JG_CLUSTER_ROUNDS_PER_GRAPH")) : 8u;
+  if (!c->exec || c->sig != cluster_signature(c, dt_ms)) {
+    if (c->exec_many) (void)hipGraphExecDestroy(c->exec_many), c->exec_many = nullptr;  // (captured against the same state: both again)
     if ((rc = cluster_capture(c, dt_ms))) return rc;
+  }
+  bool timing = false;
+  for (jg_engine* e : c->nodes) timing = timing || e->kt_on;
+  const uint32_t many = (per_graph > 1 && !timing && n_rounds >= per_graph) ? per_graph : 0u;
+  if (many && (!c->exec_many || c->many_rounds != many))
+    if ((rc = cluster_capture(c, dt_ms, many))) return rc;
   for (uint32_t r = 0; r < c->R; r++)  // the followers' earlier work first
     if (r != c->lead && (rc = jg_stream_wait(L, c->nodes[r]))) return rc;
   JgClock init{};  // the first replayed round's time and step numbers; the rounds advance it themselves (JgClock)
@@ -2666,16 +2687,18 @@ int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms
   init.v[0].now = now_ms;
   for (uint32_t r = 0; r < c->R; r++) init.v[0].seq[r] = c->nodes[r]->seq + 1;
   hipLaunchKernelGGL(k_clock_set, dim3(1), dim3(1), 0, L->stream, c->clock, init);
-  for (uint32_t k = 0; k < n_rounds; k++) {
-    HIPCHK(hipGraphLaunch(c->exec, L->stream));
+  for (uint32_t k = 0; k < n_rounds;) {
+    const uint32_t held = (many && n_rounds - k >= many) ? many : 1u;
+    HIPCHK(hipGraphLaunch(held > 1 ? c->exec_many : c->exec, L->stream));
+    k += held;
     for (uint32_t r = 0; r < c->R; r++) {  // what the eager calls would have recorded on the host
       jg_engine* e = c->nodes[r];
-      e->seq += c->any ? 2 : 1;
+      e->seq += (c->any ? 2 : 1) * held;
       e->stepped = true;
-      e->n_dense += c->any ? 2 * (uint64_t)c->G : c->G;
-      e->n_launch += c->any ? 4 : 2;
+      e->n_dense += (c->any ? 2 * (uint64_t)c->G : c->G) * held;
+      e->n_launch += (c->any ? 4 : 2) * held;
       e->slow_scheduled_ever = true;
-      if (c->any || r != c->lead) e->maybe_irregular = true, e->flag_check_pending = true, e->irr_gen++;
+      if (c->any || r != c->lead) e->maybe_irregular = true, e->flag_check_pending = true, e->irr_gen += held;
     }
   }
   HIPCHK(hipGetLastError());
