@@ -26,6 +26,9 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
            "-Wno-unused-function", "-o", LIB, os.path.join(CSRC, "josefine_gpu.hip")]
     if os.environ.get("JG_BLOCK"):  # workgroup-size experiments (profiles/README.md); default 256
         cmd.insert(1, "-DJG_BLOCK=" + os.environ["JG_BLOCK"])
+    for k in ("JG_LEADER_WAVES", "JG_FOLLOWER_WAVES"):  # occupancy experiments on the dense halves
+        if os.environ.get(k):
+            cmd.insert(1, f"-D{k}=" + os.environ[k])
     if os.environ.get("JG_GSM_WAVES"):  # occupancy experiment: the general state machine's kernels held to 512 / N VGPRs
         cmd.insert(1, "-DJG_GSM_WAVES=" + os.environ["JG_GSM_WAVES"])
     if verbose:

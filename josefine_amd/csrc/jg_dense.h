@@ -851,8 +851,20 @@ __global__ __launch_bounds__(JG_BLOCK) void k_leader_tick_dense(JgDenseHot h, co
 
 // jg_step_dense_leader: the same tick with HeartbeatResponses in and / or the Tick's outbox out
 // FSM (jg_step_node): the step's fsm_tx output is left behind as one word per group (nd.fsm_delta)
+// (experiment: -DJG_LEADER_WAVES=n / -DJG_FOLLOWER_WAVES=n cap the dense halves' occupancy - what they would run at
+// if they carried the general state machine's registers: profiles/r04/ab_dense_occupancy.txt)
+#ifdef JG_LEADER_WAVES
+#define JG_LEADER_OCC __attribute__((amdgpu_waves_per_eu(JG_LEADER_WAVES, JG_LEADER_WAVES)))
+#else
+#define JG_LEADER_OCC
+#endif
+#ifdef JG_FOLLOWER_WAVES
+#define JG_FOLLOWER_OCC __attribute__((amdgpu_waves_per_eu(JG_FOLLOWER_WAVES, JG_FOLLOWER_WAVES)))
+#else
+#define JG_FOLLOWER_OCC
+#endif
 template <int R, bool FSM>
-__global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick(JgDenseHot h, const JgDev* __restrict__ dp,
+__global__ __launch_bounds__(JG_BLOCK) JG_LEADER_OCC void k_leader_node_tick(JgDenseHot h, const JgDev* __restrict__ dp,
                                                                 const uint64_t* __restrict__ acks, uint32_t seq, int us,
                                                                 JgLeaderNode nd) {
   if (nd.clock) {  // a replayed round: the first kernel of the round (see JgClock)

@@ -210,7 +210,7 @@ struct JgFollowerJob {
   JgDev d;
   JgFollowerArgs a;
 };
-__global__ __launch_bounds__(JG_BLOCK) void k_follower_tick_dense_multi(const JgFollowerJob* __restrict__ jobs) {
+__global__ __launch_bounds__(JG_BLOCK) JG_FOLLOWER_OCC void k_follower_tick_dense_multi(const JgFollowerJob* __restrict__ jobs) {
   const JgFollowerJob& j = jobs[blockIdx.y];
   jg_follower_fast_body<false>(j.d, j.a);
 }

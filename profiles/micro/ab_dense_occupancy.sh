@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B: the dense halves of the closed loop at the occupancy they would have with the general state machine's registers
+#   a = as built (leader 7, follower 7 waves/SIMD)   b = leader 3, follower 4   c = leader 2, follower 3
+line() { python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('$1', 'us/round %.2f' % (1e3 * d['ms_per_step']), 'frac %.3f' % d['roofline']['frac'])"; }
+C=josefine_amd/csrc
+for v in a b c a b c; do
+  cp $C/lib_$v.so.keep $C/libjosefine_gpu.so; touch $C/libjosefine_gpu.so
+  python bench.py --cluster --steps 224 --warmup 32 --no-cpu-baseline 2>/dev/null | line closed_loop_x5_$v
+done
+cp $C/lib_a.so.keep $C/libjosefine_gpu.so
