@@ -772,7 +772,8 @@ def event_loop_main(args):
                         "(src/raft/tcp.rs:139-170; the loop receives Commands from a channel, server.rs:120-137), fsm_tx is consumed by "
                         "the driver task (src/raft/fsm.rs), rpc_tx by the per-peer senders (tcp.rs:87-137) - here "
                         f"{pt1['task_threads_beside_each_loop']} helper threads beside the loop's, fork-join: the decoders fill their "
-                        "slices of the pinned columns, the consumers read their slices of the output batches",
+                        "slices of the pinned columns, the consumers read their slices of the output batches; the committed batch leaves "
+                        "for the device at once (JG_COL_UPLOAD_NOW: a copy stream of its own, while the previous step's outputs travel the other way)",
                 "task_threads_beside_the_loop": pt1["task_threads_beside_each_loop"],
                 "decisions_per_s": pt1["decisions_per_s"], "ms_per_tick": pt1["ms_per_tick"],
                 "ms_per_tick_parts": {"transport_decode_into_pinned_columns": pt1["ms_fill"], "submit_commit": pt1["ms_submit"],

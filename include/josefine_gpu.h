@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define JG_ABI_VERSION 5u /* v5: jg_step_node = arrival-order Apply (fsm_tx: Apply / Notify / Apply per partition), JG_CLUSTER_ANY_LEADER,
-                             jg_dense_cluster_withdraw_appends, JG_COL_UNCHECKED */
+                             jg_dense_cluster_withdraw_appends, JG_COL_UNCHECKED, JG_COL_UPLOAD_NOW */
 #define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
 #define JG_CHAIN_WINDOW 8u  /* chain segments (gaps / forks) per group besides the main run */
 #define JG_MAX_INFLIGHT 5u  /* src/raft/progress.rs:117                                    */
@@ -313,7 +313,12 @@ enum { JG_COL_FROM = 1u, JG_COL_TERM = 2u, JG_COL_AUX = 4u, JG_COL_FLAG = 8u,
        /* no validation pass over the rows on the host (it costs 2.5 ms per 9 M rows): jg_step_node's classification
         * checks group and kind on the device - a row out of range is not applied and the next synchronising call
         * returns JG_EINVAL.  Only jg_step_node takes such a batch (jg_step refuses it). */
-       JG_COL_UNCHECKED = 16u };
+       JG_COL_UNCHECKED = 16u,
+       /* these rows are the whole batch of the next jg_step_node (nothing was committed before them since the last
+        * step, nothing follows): their upload starts NOW, on a copy stream of its own - while the previous step's
+        * kernels run and its outputs travel the other way - instead of at the head of the step.  A batch that turns
+        * out not to be the step's whole input is simply uploaded again by the step. */
+       JG_COL_UPLOAD_NOW = 32u };
 int jg_submit_reserve(jg_engine* e, size_t n, size_t n_blocks, jg_cmd_cols* cols);
 int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_columns);
 

@@ -236,6 +236,29 @@ struct jg_engine {
   // all zeros: jg_step_node does not upload it)
   bool p_has_from = false, p_has_term = false, p_has_aux = false, p_has_flag = false;
   bool p_unchecked = false;  // some rows were committed with JG_COL_UNCHECKED: only jg_step_node may take this batch
+  // JG_COL_UPLOAD_NOW: the committed batch on its way to the device before the step is called, on a copy stream of
+  // its own (the two directions of the bus are independent: the previous step's outputs travel home meanwhile).
+  // Two device buffers by turns: a step's rows are read until the step is settled, the next upload must not wait for that
+  struct RowLayout {
+    size_t n = 0, nb = 0, bytes = 0;
+    bool has_from = false, has_term = false, has_aux = false, has_flag = false;
+    size_t o_id = 0, o_term = 0, o_aux = 0, o_bid = 0, o_bnext = 0, o_group = 0, o_from = 0, o_kind = 0, o_flag = 0;
+    bool same_batch(const RowLayout& o) const {
+      return n == o.n && nb == o.nb && has_from == o.has_from && has_term == o.has_term && has_aux == o.has_aux && has_flag == o.has_flag;
+    }
+  };
+  struct EarlyUpload {
+    hipStream_t st = nullptr;
+    hipEvent_t ev_up = nullptr;               // behind the copies of the batch in flight
+    hipEvent_t ev_free[2] = {nullptr, nullptr};  // behind the last step (and its settling) that read buf[k]
+    bool read[2] = {false, false};
+    char* buf[2] = {nullptr, nullptr};
+    size_t cap[2] = {0, 0};
+    int turn = 0;        // the buffer the next upload takes
+    int last_used = -1;  // the buffer the last node step read its rows from (-1: the arena's)
+    bool valid = false;  // a batch is on its way / there, laid out as `lay`
+    RowLayout lay;
+  } up;
   uint32_t p_kinds_seen = 0;  // bit 0: an AppendEntries row is queued, bit 1: a Heartbeat row
   // pinned staging for the upload of one step (reused; guarded by ev_stage)
   char* stage = nullptr;
@@ -1415,6 +1438,14 @@ void jg_engine_destroy(jg_engine* e) {
   for (void* p : {(void*)e->node.h_beat, (void*)e->node.h_ae, (void*)e->node.h_answer, (void*)e->node.h_hbc, (void*)e->node.h_nsparse,
                   (void*)e->node.h_in_answers, (void*)e->node.h_in_hbc})
     if (p) (void)hipHostFree(p);
+  if (e->up.st) {
+    (void)hipStreamSynchronize(e->up.st);
+    (void)hipStreamDestroy(e->up.st);
+    (void)hipEventDestroy(e->up.ev_up);
+    for (hipEvent_t ev : e->up.ev_free) (void)hipEventDestroy(ev);
+  }
+  for (char* p : e->up.buf)
+    if (p) (void)hipFree(p);
   if (e->fs_bk) (void)hipFree(e->fs_bk);
   if (e->node.sp_key) (void)hipFree(e->node.sp_key);
   if (e->node.sp_idx) (void)hipFree(e->node.sp_idx);
@@ -1498,6 +1529,73 @@ int jg_submit(jg_engine* e, const jg_cmd_batch* b) {
   return JG_OK;
 }
 
+namespace {
+// the device image of a node step's rows: one section per column that is present, 16-byte aligned
+void node_row_layout(const jg_engine* e, size_t n, size_t nb, jg_engine::RowLayout& l) {
+  l = jg_engine::RowLayout{};
+  l.n = n, l.nb = nb;
+  l.has_from = e->p_has_from, l.has_term = e->p_has_term, l.has_aux = e->p_has_aux, l.has_flag = e->p_has_flag;
+  size_t off = 0;
+  auto sect = [&](size_t bytes) {
+    size_t at = off;
+    off = (off + bytes + 15) & ~size_t(15);
+    return at;
+  };
+  l.o_id = sect(n * 8), l.o_term = sect(l.has_term ? n * 8 : 0), l.o_aux = sect(l.has_aux ? n * 8 : 0), l.o_bid = sect(nb * 8);
+  l.o_bnext = sect(nb * 8), l.o_group = sect(n * 4), l.o_from = sect(l.has_from ? n * 4 : 0), l.o_kind = sect(n);
+  l.o_flag = sect(l.has_flag ? n : 0);
+  l.bytes = off;
+}
+// the pinned columns -> the device image at B, on stream st
+int upload_node_rows(jg_engine* e, const jg_engine::RowLayout& l, char* B, hipStream_t st, uint64_t* bytes_up) {
+  const size_t n = l.n, nb = l.nb;
+  auto up = [&](size_t at, const void* src, size_t nbytes) -> hipError_t {
+    if (bytes_up) *bytes_up += nbytes;
+    return hipMemcpyAsync(B + at, src, nbytes, hipMemcpyHostToDevice, st);
+  };
+  HIPCHK(up(l.o_id, e->p_id.data(), n * 8));
+  if (l.has_term) HIPCHK(up(l.o_term, e->p_term.data(), n * 8));
+  if (l.has_aux) HIPCHK(up(l.o_aux, e->p_aux.data(), n * 8));
+  HIPCHK(up(l.o_group, e->p_group.data(), n * 4));
+  if (l.has_from) HIPCHK(up(l.o_from, e->p_from.data(), n * 4));
+  HIPCHK(up(l.o_kind, e->p_kind.data(), n));
+  if (l.has_flag) HIPCHK(up(l.o_flag, e->p_flag.data(), n));
+  if (nb) {
+    HIPCHK(up(l.o_bid, e->p_blk_id.data(), nb * 8));
+    HIPCHK(up(l.o_bnext, e->p_blk_next.data(), nb * 8));
+  }
+  return JG_OK;
+}
+// JG_COL_UPLOAD_NOW: everything committed so far leaves for the device
+int upload_rows_now(jg_engine* e) {
+  jg_engine::EarlyUpload& u = e->up;
+  u.valid = false;
+  const size_t n = e->p_kind.size(), nb = e->p_blk_id.size();
+  if (!n || n > 0x7fffffffull) return JG_OK;  // (the step says what is wrong with such a batch)
+  HIPCHK(hipSetDevice(e->device));
+  if (!u.st) {
+    HIPCHK(hipStreamCreateWithFlags(&u.st, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&u.ev_up, hipEventDisableTiming));
+    for (hipEvent_t& ev : u.ev_free) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  jg_engine::RowLayout l;
+  node_row_layout(e, n, nb, l);
+  const int k = u.turn;
+  if (u.cap[k] < l.bytes) {  // (grow-only; hipFree waits for whoever still reads the old one)
+    if (u.buf[k]) HIPCHK(hipFree(u.buf[k]));
+    u.buf[k] = nullptr, u.read[k] = false;
+    u.cap[k] = l.bytes + l.bytes / 2;
+    HIPCHK(hipMalloc((void**)&u.buf[k], u.cap[k]));
+  }
+  if (u.read[k]) HIPCHK(hipStreamWaitEvent(u.st, u.ev_free[k], 0));  // (the step before last read its rows here)
+  int rc = upload_node_rows(e, l, u.buf[k], u.st, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(u.ev_up, u.st));
+  u.lay = l, u.valid = true;
+  return JG_OK;
+}
+}  // namespace
+
 int jg_submit_reserve(jg_engine* e, size_t n, size_t n_blocks, jg_cmd_cols* cols) {
   if (!e || !cols) return fail(JG_EINVAL, "null argument");
   if (e->router) return fail(JG_EINVAL, "jg_submit_reserve: the columns are per shard: call this on a shard handle (jg_get_shard)");
@@ -1520,7 +1618,7 @@ int jg_submit_reserve(jg_engine* e, size_t n, size_t n_blocks, jg_cmd_cols* cols
 int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_columns) {
   if (!e) return fail(JG_EINVAL, "null argument");
   if (e->router) return fail(JG_EINVAL, "jg_submit_commit: the columns are per shard: call this on a shard handle (jg_get_shard)");
-  if (optional_columns & ~31u) return fail(JG_EINVAL, "unknown column bit");
+  if (optional_columns & ~63u) return fail(JG_EINVAL, "unknown column bit");
   const size_t at = e->p_kind.size(), bat = e->p_blk_id.size();
   if (at + n > e->p_kind.cap || at + n > e->p_group.cap || at + n > e->p_id.cap || bat + n_blocks > e->p_blk_id.cap)
     return fail(JG_EINVAL, "jg_submit_commit: more rows than jg_submit_reserve made room for");
@@ -1559,6 +1657,8 @@ int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_
     for (size_t i = 0; i < n; i++)
       if (b.kind[i] == JG_CMD_APPEND_ENTRIES) e->p_id[at + i] += bat;
   e->p_blk_id.n = e->p_blk_next.n = bat + n_blocks;
+  if (optional_columns & JG_COL_UPLOAD_NOW) return upload_rows_now(e);
+  e->up.valid = false;  // (rows behind an early upload: the step uploads the whole batch itself)
   return JG_OK;
 }
 
@@ -1630,6 +1730,7 @@ int jg_step(jg_engine* e, uint64_t now_ms) {
                        (const uint64_t*)(B + o_aux), (const uint8_t*)(B + o_flag), (const uint64_t*)(B + o_bid),
                        (const uint64_t*)(B + o_bnext), nb, now_ms);
   if (rc) return rc;
+  e->up.valid = false;
   e->p_kind.clear();
   e->p_flag.clear();
   e->p_group.clear();
@@ -1901,20 +2002,11 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     // the rows in stream order, straight out of the pinned columns jg_submit (or the caller, in place:
     // jg_submit_reserve) filled: one copy per column that is present - an optional column nobody
     // provided is all zeros and is not uploaded at all (an AppendResponse row is 18 bytes then, not 34)
-    size_t off = 0;
-    auto sect = [&](size_t bytes) {
-      size_t at = off;
-      off = (off + bytes + 15) & ~size_t(15);
-      return at;
-    };
-    const bool has_from = e->p_has_from, has_term = e->p_has_term, has_aux = e->p_has_aux, has_flag = e->p_has_flag;
-    const size_t o_id = sect(n * 8), o_term = sect(has_term ? n * 8 : 0), o_aux = sect(has_aux ? n * 8 : 0), o_bid = sect(nb * 8),
-                 o_bnext = sect(nb * 8), o_group = sect(n * 4), o_from = sect(has_from ? n * 4 : 0), o_kind = sect(n),
-                 o_flag = sect(has_flag ? n : 0);
-    const size_t bytes = off;
-    Arena& ar = e->arenas[e->cur_arena];
-    char* B = nullptr;
-    HIPCHK(ar.alloc(bytes, (void**)&B));
+    jg_engine::RowLayout lay;
+    node_row_layout(e, n, nb, lay);
+    const bool has_from = lay.has_from, has_term = lay.has_term, has_aux = lay.has_aux, has_flag = lay.has_flag;
+    const size_t o_id = lay.o_id, o_term = lay.o_term, o_aux = lay.o_aux, o_bid = lay.o_bid, o_bnext = lay.o_bnext, o_group = lay.o_group,
+                 o_from = lay.o_from, o_kind = lay.o_kind, o_flag = lay.o_flag;
     if (nd.sp_cap < n) {  // (room for every row on the general path; grow-only, like the pinned columns)
       if (nd.sp_key) HIPCHK(hipFree(nd.sp_key));
       if (nd.sp_idx) HIPCHK(hipFree(nd.sp_idx));
@@ -1922,21 +2014,26 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
       HIPCHK(hipMalloc((void**)&nd.sp_key, nd.sp_cap * 8));
       HIPCHK(hipMalloc((void**)&nd.sp_idx, nd.sp_cap * 4));
     }
-    auto up = [&](size_t at, const void* src, size_t nbytes) -> hipError_t {
-      bytes_up += nbytes;
-      return hipMemcpyAsync(B + at, src, nbytes, hipMemcpyHostToDevice, e->stream);
-    };
-    HIPCHK(up(o_id, e->p_id.data(), n * 8));
-    if (has_term) HIPCHK(up(o_term, e->p_term.data(), n * 8));
-    if (has_aux) HIPCHK(up(o_aux, e->p_aux.data(), n * 8));
-    HIPCHK(up(o_group, e->p_group.data(), n * 4));
-    if (has_from) HIPCHK(up(o_from, e->p_from.data(), n * 4));
-    HIPCHK(up(o_kind, e->p_kind.data(), n));
-    if (has_flag) HIPCHK(up(o_flag, e->p_flag.data(), n));
-    if (nb) {
-      HIPCHK(up(o_bid, e->p_blk_id.data(), nb * 8));
-      HIPCHK(up(o_bnext, e->p_blk_next.data(), nb * 8));
+    char* B = nullptr;
+    jg_engine::EarlyUpload& u = e->up;
+    if (u.last_used >= 0) {  // whoever read the last step's rows (its settling included) is in the stream by now
+      HIPCHK(hipEventRecord(u.ev_free[u.last_used], e->stream));
+      u.read[u.last_used] = true;
+      u.last_used = -1;
     }
+    if (u.valid && u.lay.same_batch(lay)) {
+      // JG_COL_UPLOAD_NOW: the batch left when it was committed - the kernels wait for its copies, nothing else does
+      B = u.buf[u.turn];
+      HIPCHK(hipStreamWaitEvent(e->stream, u.ev_up, 0));
+      bytes_up += n * (8u + 4u + 1u + (has_term ? 8u : 0u) + (has_aux ? 8u : 0u) + (has_from ? 4u : 0u) + (has_flag ? 1u : 0u)) + nb * 16u;
+      u.last_used = u.turn;
+      u.turn ^= 1;
+    } else {
+      Arena& ar = e->arenas[e->cur_arena];
+      HIPCHK(ar.alloc(lay.bytes, (void**)&B));
+      if ((rc = upload_node_rows(e, lay, B, e->stream, &bytes_up))) return rc;
+    }
+    u.valid = false;
     // (the pinned columns are free again after the synchronisation below)
     JgNodeRows rows{};
     rows.n = (uint32_t)n;

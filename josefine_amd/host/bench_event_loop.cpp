@@ -173,7 +173,13 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
   const bool with_tasks = mode_arg.rfind("pipetasks", 0) == 0;
   const bool cols_in = mode_arg.size() >= 7 && mode_arg.compare(mode_arg.size() - 7, 7, "columns") == 0;
   const std::string mode = !pipe ? mode_arg : (cols_in ? "columns" : "inplace");
-  const uint32_t unchecked = pipe ? (uint32_t)JG_COL_UNCHECKED : 0u;
+  // (with the tasks: ... and the committed batch leaves for the device at once, JG_COL_UPLOAD_NOW, while the previous step's
+  // outputs travel the other way: 8.0 -> 11.1 x 10^8 decisions/s with row inbound.  A loop that decodes and consumes on its
+  // own thread is bound by that thread, and the copy engine reading the host's memory beside it costs it 10-20 %: it
+  // uploads at the head of the step as before.  JG_BENCH_EARLY_UPLOAD=0 / 1 overrides: the A/B)
+  const char* early_env = std::getenv("JG_BENCH_EARLY_UPLOAD");
+  const bool early = early_env ? early_env[0] == '1' : with_tasks;
+  const uint32_t unchecked = pipe ? (uint32_t)JG_COL_UNCHECKED | (early ? (uint32_t)JG_COL_UPLOAD_NOW : 0u) : 0u;
   Tasks tasks(with_tasks ? helpers : 0u);  // (no helpers: run() is a plain loop on the calling thread)
   constexpr uint32_t SPLIT = 8;            // jobs per batch and connection: the helpers draw them as they come free
   auto sum_split = [&](const void* p, size_t items, size_t item_bytes) {

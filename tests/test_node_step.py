@@ -596,3 +596,60 @@ def test_node_step_async_parity(R, flags, G):
         general_ticks += b["rows_general"] > 0
     assert general_ticks > 5  # (the catch-up pass ran; steps without general rows: tests/cpp/test_event_loop_cluster.cpp, pipelined)
     assert dev.counters()["decisions"] == ora.counters()["decisions"]
+
+
+def _commit_in_place(dev, cols, extra_flags, lo=0, hi=None):
+    """rows [lo, hi) of `cols` written straight into the engine's pinned columns (jg_submit_reserve / jg_submit_commit)"""
+    import ctypes as C
+    hi = len(cols["kind"]) if hi is None else hi
+    n = hi - lo
+    nb = len(cols["blk_id"]) if (lo == 0 and hi == len(cols["kind"])) else 0
+    c = capi.CmdCols()
+    dev._check(dev.api.submit_reserve(dev._h, n, nb, C.byref(c)))
+
+    def view(ptr, dt, m):
+        return np.frombuffer((C.c_char * (max(m, 1) * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt)[:m]
+    view(c.kind, np.uint8, n)[:] = cols["kind"][lo:hi]
+    view(c.group, np.uint32, n)[:] = cols["group"][lo:hi]
+    view(c.from_, np.uint32, n)[:] = cols["from_"][lo:hi]
+    view(c.term, np.uint64, n)[:] = cols["term"][lo:hi]
+    view(c.id, np.uint64, n)[:] = cols["id"][lo:hi]
+    view(c.aux, np.uint64, n)[:] = cols["aux"][lo:hi]
+    view(c.flag, np.uint8, n)[:] = cols["flag"][lo:hi]
+    if nb:
+        view(c.blk_id, np.uint64, nb)[:] = cols["blk_id"]
+        view(c.blk_next, np.uint64, nb)[:] = cols["blk_next"]
+    dev._check(dev.api.submit_commit(dev._h, n, nb, capi.COL_FROM | capi.COL_TERM | capi.COL_AUX | capi.COL_FLAG | extra_flags))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,flags,G", [(3, 0, 3000), (5, capi.CFG_SEPARATE_COMMIT_KEY, 2000)])
+def test_node_step_early_upload_parity(R, flags, G):
+    """JG_COL_UPLOAD_NOW: a committed batch leaves for the device at once, on a copy stream of its own, into one of two
+    device buffers by turns - while the previous (asynchronous) step is still in flight.  A batch that does not stay the
+    step's whole input (rows committed behind it: every 5th tick here; a batch without AppendEntries blocks only - the
+    blocks of a split batch go the plain way) is uploaded again by the step.  Every outbox word, state column and drained
+    row equals the oracle's synchronous step."""
+    T = 40
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=77 + R, flags=flags, election_timeout_ms=(700, 1500))
+
+    def commit(cols, t):
+        n = len(cols["kind"])
+        if t % 5 == 4 and n > 10 and not len(cols["blk_id"]):  # rows behind the early upload: the step uploads all of them itself
+            _commit_in_place(dev, cols, capi.COL_UNCHECKED | capi.COL_UPLOAD_NOW, 0, n // 2)
+            _commit_in_place(dev, cols, capi.COL_UNCHECKED, n // 2, n)
+        else:
+            _commit_in_place(dev, cols, capi.COL_UNCHECKED | capi.COL_UPLOAD_NOW)
+    nxt = node_traffic(rng, ora, token0=0)
+    commit(nxt, 0)
+    for t in range(T):
+        now = 100 * (t + 1)
+        cols = nxt
+        ora.submit_columns(**cols)
+        b = ora.step_node(now)
+        nxt = node_traffic(rng, ora, token0=1000 * (t + 1), p_noise=0.03 if t % 3 else 0.0, p_reorder=0.08 if t % 3 else 0.0)
+        a = dev.step_node(now, async_=True, between=lambda: commit(nxt, t + 1))
+        compare_outboxes(a, b, f"tick {t}")
+        compare_snapshots(dev, ora, f"tick {t}")
+        compare_drains(dev, ora, f"tick {t}")
+    assert dev.counters()["decisions"] == ora.counters()["decisions"]
