@@ -579,7 +579,9 @@ int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const ui
  * (what the reference makes of a re-elected leader is Q8: its first append panics, chain.rs:163).  Asynchronous on the
  * cluster's stream; the list must stay valid until then (jg_sync). */
 int jg_dense_cluster_withdraw_appends(jg_dense_cluster* c, const uint32_t* groups_dev, uint32_t n);
-/* n_rounds protocol rounds at logical times now_ms, now_ms + dt_ms, ...; asynchronous (jg_sync the nodes). */
+/* n_rounds protocol rounds at logical times now_ms, now_ms + dt_ms, ...; asynchronous (jg_sync the nodes).  Two or more
+ * rounds are replayed as captured graphs (logical time and step numbers live in a device-resident clock that advances
+ * itself), eight rounds to a graph where n_rounds allows; the results are those of n_rounds calls with one round each. */
 int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms, uint32_t n_rounds);
 /* The mailbox columns, for inspection: the leader's inbox / outbox as the structs above. */
 int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_leader_outbox* out);
