@@ -1511,6 +1511,10 @@ int jg_submit(jg_engine* e, const jg_cmd_batch* b) {
     e->p_kinds_seen |= seen;
   }
   const size_t at = e->p_kind.size(), n = b->n;
+  if (e->up.valid) {  // rows behind an early upload (JG_COL_UPLOAD_NOW): the step uploads the whole batch itself
+    HIPCHK(hipEventSynchronize(e->up.ev_up));  // (the columns may move when they grow)
+    e->up.valid = false;
+  }
   const uint64_t blk_shift = e->p_blk_id.size();
   HIPCHK(e->p_kind.append(b->kind, n));
   HIPCHK(e->p_group.append(b->group, n));
@@ -1600,6 +1604,7 @@ int jg_submit_reserve(jg_engine* e, size_t n, size_t n_blocks, jg_cmd_cols* cols
   if (!e || !cols) return fail(JG_EINVAL, "null argument");
   if (e->router) return fail(JG_EINVAL, "jg_submit_reserve: the columns are per shard: call this on a shard handle (jg_get_shard)");
   const size_t at = e->p_kind.size(), bat = e->p_blk_id.size();
+  if (e->up.valid) HIPCHK(hipEventSynchronize(e->up.ev_up));  // (rows behind an early upload: the columns may move when they grow)
   HIPCHK(e->p_kind.reserve(at + n));
   HIPCHK(e->p_group.reserve(at + n));
   HIPCHK(e->p_from.reserve(at + n));
