@@ -158,10 +158,11 @@ def test_dense_leader_tick_restarted_leaders_send_columns_irregular_ones_rows():
         assert set(b["group"].tolist()) <= set(gap.tolist())
 
 
-def _restarted_leaders_below_their_top(G, R, seed):
+def _restarted_leaders_below_their_top(G, R, seed, make=None):
     """Both engines with every group led by slot 0, chain [0, 5], commit index 2; every other group then restarted and
-    re-elected: head = 2 (chain.rs:117-137), the run above it still in the store, progress heads 0 (Q10)."""
-    dev = BatchedRaft(G, R, seed=seed, flags=capi.CFG_SEPARATE_COMMIT_KEY)
+    re-elected: head = 2 (chain.rs:117-137), the run above it still in the store, progress heads 0 (Q10).
+    `make`: the engine held against the oracle (default: the HIP engine)."""
+    dev = (make or BatchedRaft)(G, R, seed=seed, flags=capi.CFG_SEPARATE_COMMIT_KEY)
     ora = oracle_engine(G, R, seed=seed, flags=capi.CFG_SEPARATE_COMMIT_KEY)
     g = np.arange(0, G, 2, dtype=np.uint32)
     for e in (dev, ora):
@@ -183,16 +184,8 @@ def _restarted_leaders_below_their_top(G, R, seed):
     return dev, ora, g
 
 
-@pytest.mark.gpu
-def test_dense_leader_tick_restarted_leader_counts_acks_above_its_head():
-    """A restarted, re-elected leader's head sits at its commit index, BELOW the top of the run its store kept: the
-    acknowledgements it receives name blocks above its head, all of them blocks it holds (chain.rs:197-202 looks the
-    key up, it does not compare with the head), so its commit index moves past its head; an acknowledgement above the
-    TOP is recorded like any other (progress.rs:133-140) and panics only once the majority rests on it.  The node tick
-    keeps such a leader's progress heads as lags below that top; state, columns and faults as the oracle's, tick by
-    tick."""
-    G, R = 640, 3
-    dev, ora, g = _restarted_leaders_below_their_top(G, R, seed=4)
+def _restarted_leader_script(G, R, seed, make=None):
+    dev, ora, g = _restarted_leaders_below_their_top(G, R, seed=seed, make=make)
     script = [({}, "quiet"), ({1: 4}, "one ack above the head"), ({2: 5}, "majority at 4"), ({1: 3}, "a stale ack"),
               ({1: 6}, "an ack above the top: recorded"), ({2: 5}, "again"), ({2: 7}, "the majority above the top: panic")]
     for t, (acked, what) in enumerate(script):
@@ -212,6 +205,25 @@ def test_dense_leader_tick_restarted_leader_counts_acks_above_its_head():
         if t < 6:
             assert not ora.read("fault").any()
     assert (ora.read("fault")[g] == capi.FAULT_COMMIT_MISSING_BLOCK).all() and not ora.read("fault")[1::2].any()
+
+
+def test_restarted_leader_counts_acks_above_its_head_oracle_vs_the_python_restatement():
+    """CPU: the scenario of the next test on the C++ oracle against tests/ref_py (the independent transliteration of
+    the Rust): what a restarted, re-elected leader makes of acknowledgements above its head is not the oracle's
+    reading alone."""
+    from ref_py.engine import RefEngine
+    _restarted_leader_script(24, 3, seed=4, make=RefEngine)
+
+
+@pytest.mark.gpu
+def test_dense_leader_tick_restarted_leader_counts_acks_above_its_head():
+    """A restarted, re-elected leader's head sits at its commit index, BELOW the top of the run its store kept: the
+    acknowledgements it receives name blocks above its head, all of them blocks it holds (chain.rs:197-202 looks the
+    key up, it does not compare with the head), so its commit index moves past its head; an acknowledgement above the
+    TOP is recorded like any other (progress.rs:133-140) and panics only once the majority rests on it.  The node tick
+    keeps such a leader's progress heads as lags below that top; state, columns and faults as the oracle's, tick by
+    tick."""
+    _restarted_leader_script(640, 3, seed=4)
 
 
 @pytest.mark.gpu
