@@ -29,6 +29,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# How the host learns that the device is done: the ROCm runtime can take an interrupt per completion signal (its
+# default) or poll the signal.  A timed region of K steps ends with one such wait, and at K = 20 the interrupt's
+# wake-up is 3 % of the region (profiles/r04/ab_hsa_interrupt.txt: 3.90 -> 4.01 x 10^11 decisions/s on the driver's
+# command; nothing changes for the long regions).  The engine's thread polls unless the caller says otherwise; the
+# line says which (config.host_wait).  Set before anything loads the runtime.
+if "HSA_ENABLE_INTERRUPT" not in os.environ:
+    os.environ["HSA_ENABLE_INTERRUPT"] = "0"
+    os.environ["JG_BENCH_POLLING_DEFAULTED"] = "1"
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
 
@@ -710,6 +719,8 @@ def event_loop_main(args):
 
     def run(mode, k, w, loops=1):
         env = dict(os.environ)
+        if env.get("JG_BENCH_POLLING_DEFAULTED"):  # (several loop threads waiting side by side: the runtime's default, interrupts)
+            env.pop("HSA_ENABLE_INTERRUPT", None)
         if hw_queues(loops):
             env["GPU_MAX_HW_QUEUES"] = hw_queues(loops)
         r = subprocess.run([exe, str(G), str(R), str(k), str(w), mode, "0", str(loops)], capture_output=True, text=True, timeout=1200, env=env)
@@ -748,7 +759,9 @@ def event_loop_main(args):
                    "partitions_per_gpu": G, "replicas": R, "partitions_total": G,
                    "parallelism": f"{L} event loop(s) of {G // L} partitions each (one host thread + one engine + one HIP stream per loop), 1 GPU",
                    "loops": L,
-                   "q9": "off (JG_CFG_SEPARATE_COMMIT_KEY)", "devices": [0], "devices_aliased": False},
+                   "q9": "off (JG_CFG_SEPARATE_COMMIT_KEY)", "devices": [0], "devices_aliased": False,
+                   "host_wait": "completion signals by interrupt (the runtime's default)" if os.environ.get("JG_BENCH_POLLING_DEFAULTED")
+                   or os.environ.get("HSA_ENABLE_INTERRUPT") != "0" else "completion signals polled (HSA_ENABLE_INTERRUPT=0)"},
         "event_loop": {
             "loops": L, "decisions_per_s_by_loops": d_by_loops,
             "hip_hardware_queues": {"GPU_MAX_HW_QUEUES": hw_queues(L), "note": "2 per loop (its step stream and its drain stream); the runtime's default of 4 "
@@ -969,7 +982,10 @@ def self_launch(args):
 def devices_config(args, world):
     """config entries that say where the ranks ran"""
     devs = getattr(args, "devices_bound", [0])
-    return {"devices": devs, "devices_aliased": len(set(devs)) < world}
+    polled = os.environ.get("HSA_ENABLE_INTERRUPT") == "0"
+    return {"devices": devs, "devices_aliased": len(set(devs)) < world,
+            "host_wait": ("completion signals polled (HSA_ENABLE_INTERRUPT=0" + (", set by bench.py" if os.environ.get("JG_BENCH_POLLING_DEFAULTED") else "") + ")")
+            if polled else "completion signals by interrupt (the runtime's default)"}
 
 
 def main():
