@@ -1,5 +1,7 @@
 #!/bin/bash
 # A/B: the general state machine's kernels as the compiler sizes them (a) / held to 128 VGPRs = 4 waves per SIMD (b)
+# the two libraries: C=josefine_amd/csrc; build as is -> cp $C/libjosefine_gpu.so $C/lib_a.so.keep; JG_GSM_WAVES=4
+# python -c 'from josefine_amd import build; build.build_hip(force=True)' -> lib_b.so.keep (josefine_amd/build.py passes the macro on)
 line() { python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
