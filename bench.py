@@ -1025,7 +1025,7 @@ def main():
     ap.add_argument("--config", type=int, choices=[2, 3, 4], default=None,
                     help="BASELINE.json configs[N] presets for the scaling run: 2 = 1 M x 5 steady state per GPU (the default); "
                          "3 = 1.25 M x 3 per GPU (10 M x 3 over 8); 4 = 125 k x 5 per GPU (1 M x 5 over 8) as the routed cluster with "
-                         "1 %/round leader failures (--cluster --failures 1)")
+                         "1 %%/round leader failures (--cluster --failures 1)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements the default N = 1 line carries (closed loop, routed round, event loop, "
                          "failure tick, per-partition leadership: a few seconds each, short runs of the modes themselves)")
