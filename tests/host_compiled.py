@@ -1,0 +1,311 @@
+"""The device's general state machine - josefine_amd/csrc/jg_device.h as it stands: jg_load / jg_apply / jg_store, every
+role, the chain, the elections, the lag-packed progress heads - compiled for the HOST by g++ behind a twenty-line stand-in
+for <hip/hip_runtime.h>, and driven row by row the way k_apply_rows's owner lane drives it.
+
+TEST INFRASTRUCTURE, and nothing else: the library is built at test time into a temporary directory, nothing under
+josefine_amd/ can reach it, and it is no engine - no dense kernels, no transport, no drains of the product.  What it is
+for: the CPU suite (which runs where there is no GPU) holds the device SOURCE of the state machine to the oracle with
+the same fuzz the GPU suite runs through the real kernels (tests/test_host_compiled_state_machine.py): a change to
+jg_device.h is checked before a GPU-minute is spent on it."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+from josefine_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "josefine_amd", "csrc")
+
+HIP_SHIM = r'''
+#pragma once
+// stand-in for <hip/hip_runtime.h> when jg_device.h is compiled for the host (tests/host_compiled.py)
+#include <cstdint>
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline
+#define __restrict__
+#define __launch_bounds__(...)
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
+static inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
+'''
+
+HARNESS = r'''
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+#include "jg_device.h"
+
+struct Host {
+  JgDev d{};
+  std::vector<uint64_t> term, commit, head, id_gen, run_hi, mlag, match_wide, hbt, win_lo, win_hi, win_next, blk_dec;
+  std::vector<uint32_t> flags, fvote;
+  std::vector<uint4> cold_t, cold_v;
+  std::vector<JgFaultRec> fq;
+  uint32_t status[8] = {};
+  uint32_t seq = 0;
+  uint64_t n_cmds = 0, decisions = 0;
+  std::vector<jg_msg_row> msgs;
+  std::vector<jg_fsm_row> fsm;
+  std::vector<JgFaultRec> faults;
+  int err = 0;
+};
+
+extern "C" Host* hc_create(uint32_t G, uint32_t R, const uint32_t* node_ids, const uint8_t* self_slots, uint64_t seed, uint64_t group_base,
+                           uint32_t flags, uint32_t hb, uint32_t el_min, uint32_t el_max) {
+  Host* h = new Host;
+  JgDev& d = h->d;
+  d.G = G, d.R = R;
+  for (uint32_t r = 0; r < R; r++) d.node_ids[r] = node_ids[r];
+  d.hb_timeout = hb, d.el_min = el_min, d.el_max = el_max, d.cfg_flags = flags, d.seed = seed, d.group_base = group_base;
+  auto a64 = [&](std::vector<uint64_t>& v, size_t n) { v.assign(n, 0); return v.data(); };
+  d.term = a64(h->term, G), d.commit = a64(h->commit, G), d.head = a64(h->head, G), d.id_gen = a64(h->id_gen, G);
+  d.run_hi = a64(h->run_hi, G), d.mlag = a64(h->mlag, G), d.match_wide = a64(h->match_wide, (size_t)R * G);
+  d.heartbeat_time = a64(h->hbt, G);
+  d.win_lo = a64(h->win_lo, (size_t)JG_CHAIN_WINDOW * G), d.win_hi = a64(h->win_hi, (size_t)JG_CHAIN_WINDOW * G);
+  d.win_next = a64(h->win_next, (size_t)JG_CHAIN_WINDOW * G);
+  h->flags.assign(G, 0), d.flags = h->flags.data();
+  h->cold_t.assign(G, uint4{}), h->cold_v.assign(G, uint4{}), d.cold.t = h->cold_t.data(), d.cold.v = h->cold_v.data();
+  h->fvote.assign((size_t)JG_FOREIGN_VOTERS * G, 0), d.fvote_id = h->fvote.data();
+  d.blk_decisions = a64(h->blk_dec, 1);
+  h->fq.assign((size_t)8 * G + 4096, JgFaultRec{}), d.fault_q = h->fq.data(), d.fault_q_cap = (uint32_t)h->fq.size();
+  d.err = &h->status[0], d.irregular_seen = &h->status[1], d.deferred_seen = &h->status[2], d.fault_q_n = &h->status[3];
+  d.xq_n = &h->status[4], d.cold_seen = &h->status[5];
+  d.xq = nullptr, d.xq_cap = 0;
+  for (uint32_t g = 0; g < G; g++) {
+@INIT_BODY@
+  }
+  return h;
+}
+extern "C" void hc_destroy(Host* h) { delete h; }
+
+// jg_submit + jg_step of one batch: rows in any order, applied per group in the order given (stable by group), as the
+// owner lane of a run does in k_apply_rows (jg_sparse.h)
+extern "C" int hc_step(Host* h, uint32_t n, const uint8_t* kind, const uint32_t* group, const uint32_t* from, const uint64_t* term,
+                       const uint64_t* id, const uint64_t* aux, const uint8_t* flag, uint64_t nb, const uint64_t* blk_id,
+                       const uint64_t* blk_next, uint64_t now) {
+  const JgDev& d = h->d;
+  if (!n) return 0;
+  h->seq++;
+  std::vector<uint32_t> order(n);
+  std::iota(order.begin(), order.end(), 0u);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return group[a] < group[b]; });
+  const uint32_t msg_per_row = d.R + 1 < 2 ? 2 : d.R + 1, fsm_per_row = 2;
+  std::vector<jg_msg_row> mbuf;
+  std::vector<jg_fsm_row> fbuf;
+  for (uint32_t i = 0; i < n;) {
+    const uint32_t g = group[order[i]];
+    uint32_t run = 1;
+    while (i + run < n && group[order[i + run]] == g) run++;
+    if (g >= d.G) return 3;
+    mbuf.assign((size_t)run * msg_per_row, jg_msg_row{});
+    fbuf.assign((size_t)run * fsm_per_row, jg_fsm_row{});
+    JgLane L;
+    jg_load(d, L, g);
+    L.now = now;
+    L.seq = h->seq;
+    L.mp = mbuf.data(), L.mend = mbuf.data() + mbuf.size();
+    L.fp = fbuf.data(), L.fend = fbuf.data() + fbuf.size();
+    for (uint32_t t = 0; t < run; t++) {
+      const uint32_t k = order[i + t];
+      JgCmd c;
+      c.kind = kind[k], c.from = from[k], c.flag = flag[k], c.term = term[k], c.id = id[k], c.aux = aux[k];
+      if (c.kind == JG_CMD_APPEND_ENTRIES && (c.aux > nb || c.id > nb - c.aux)) return 5;
+      jg_apply<JG_KINDS_ALL>(d, L, c, blk_id, blk_next);
+    }
+    h->msgs.insert(h->msgs.end(), mbuf.data(), L.mp);
+    h->fsm.insert(h->fsm.end(), fbuf.data(), L.fp);
+    if (L.overflow) return 1;
+    h->decisions += L.decisions;
+    jg_store<true>(d, L);
+    i += run;
+  }
+  h->n_cmds += n;
+  // the step's fault records, in (step, group) order behind the earlier ones
+  const uint32_t nf = *d.fault_q_n;
+  std::vector<JgFaultRec> f(d.fault_q, d.fault_q + nf);
+  std::stable_sort(f.begin(), f.end(), [](const JgFaultRec& a, const JgFaultRec& b) { return a.seq != b.seq ? a.seq < b.seq : a.group < b.group; });
+  h->faults.insert(h->faults.end(), f.begin(), f.end());
+  *d.fault_q_n = 0;
+  return (int)h->status[0];
+}
+extern "C" size_t hc_drain_messages(Host* h, jg_msg_row* out, size_t cap) {
+  const size_t n = h->msgs.size();
+  if (out && cap >= n) {
+    if (n) std::memcpy(out, h->msgs.data(), n * sizeof(jg_msg_row));
+    h->msgs.clear();
+  }
+  return n;
+}
+extern "C" size_t hc_drain_applies(Host* h, jg_fsm_row* out, size_t cap) {
+  const size_t n = h->fsm.size();
+  if (out && cap >= n) {
+    if (n) std::memcpy(out, h->fsm.data(), n * sizeof(jg_fsm_row));
+    h->fsm.clear();
+  }
+  return n;
+}
+extern "C" size_t hc_drain_faults(Host* h, jg_fault_row* out, size_t cap) {
+  const size_t n = h->faults.size();
+  if (out && cap >= n) {
+    for (size_t i = 0; i < n; i++) out[i] = jg_fault_row{h->faults[i].group, h->faults[i].code};
+    h->faults.clear();
+  }
+  return n;
+}
+extern "C" void hc_counters(Host* h, uint64_t* out) { out[0] = h->n_cmds, out[1] = h->decisions, out[2] = 0, out[3] = 0; }
+// jg_read_state's decoding, through the state machine's own jg_load
+extern "C" int hc_read(Host* h, int field, uint32_t replica, void* out) {
+  const JgDev& d = h->d;
+  uint64_t* o64 = (uint64_t*)out;
+  uint32_t* o32 = (uint32_t*)out;
+  uint8_t* o8 = (uint8_t*)out;
+  for (uint32_t g = 0; g < d.G; g++) {
+    JgLane L;
+    jg_load(d, L, g);
+    const uint32_t role = jg_role(L);
+    switch (field) {
+      case JG_FIELD_TERM: o64[g] = L.term; break;
+      case JG_FIELD_COMMIT: o64[g] = L.commit; break;
+      case JG_FIELD_HEAD: o64[g] = L.head; break;
+      case JG_FIELD_ID_GEN: o64[g] = L.id_gen; break;
+      case JG_FIELD_MATCH: o64[g] = role == JG_ROLE_LEADER ? jg_match_get(d, L, replica) : 0; break;
+      case JG_FIELD_ELECTION_TIME: o64[g] = L.election_time; break;
+      case JG_FIELD_HEARTBEAT_TIME: o64[g] = role == JG_ROLE_LEADER ? L.heartbeat_time : 0; break;
+      case JG_FIELD_VOTED_FOR: o32[g] = (L.flags & JGF_VOTED) ? L.voted_for : 0; break;
+      case JG_FIELD_LEADER_ID: o32[g] = (role == JG_ROLE_FOLLOWER && (L.flags & JGF_HAS_LEADER)) ? L.leader_id : 0; break;
+      case JG_FIELD_ELECTION_TIMEOUT: o32[g] = L.election_timeout; break;
+      case JG_FIELD_QUEUED_REQS: o32[g] = L.queued; break;
+      case JG_FIELD_VOTE_SEEN: o8[g] = role == JG_ROLE_CANDIDATE ? (uint8_t)(L.votes & 0xff) : 0; break;
+      case JG_FIELD_VOTE_GRANTED: o8[g] = role == JG_ROLE_CANDIDATE ? (uint8_t)((L.votes >> 8) & 0xff) : 0; break;
+      case JG_FIELD_HAS_VOTED: o8[g] = (L.flags & JGF_VOTED) ? 1 : 0; break;
+      case JG_FIELD_ROLE: o8[g] = (uint8_t)role; break;
+      case JG_FIELD_REPL_STATE: o8[g] = role == JG_ROLE_LEADER ? (uint8_t)((L.flags & JGF_REPL_MASK) >> JGF_REPL_SHIFT) : 0; break;
+      case JG_FIELD_FAULT: o8[g] = (uint8_t)jg_fault(L); break;
+      case JG_FIELD_HAS_LEADER: o8[g] = (role == JG_ROLE_FOLLOWER && (L.flags & JGF_HAS_LEADER)) ? 1 : 0; break;
+      case JG_FIELD_SELF_SLOT: o8[g] = (uint8_t)jg_self(L); break;
+      default: return -1;
+    }
+  }
+  return 0;
+}
+'''
+
+_lib = None
+
+
+def build():
+    """g++ -> a shared library in a temporary directory (once per process)"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    kernels = open(os.path.join(CSRC, "jg_kernels.h")).read()
+    a = kernels.index("__global__ void k_init_groups")
+    a = kernels.index("JgLane L;", a)
+    b = kernels.index("jg_store(d, L);", a) + len("jg_store(d, L);")
+    init_body = kernels[a:b]  # RaftHandle::new for one group, as the init kernel does it
+    tmp = tempfile.mkdtemp(prefix="jg_host_compiled_")
+    os.makedirs(os.path.join(tmp, "shim", "hip"))
+    open(os.path.join(tmp, "shim", "hip", "hip_runtime.h"), "w").write(HIP_SHIM)
+    cpp, so = os.path.join(tmp, "host_compiled.cpp"), os.path.join(tmp, "libhost_compiled.so")
+    open(cpp, "w").write(HARNESS.replace("@INIT_BODY@", init_body))
+    subprocess.run(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-Wno-unused-function", f"-I{os.path.join(tmp, 'shim')}", f"-I{CSRC}",
+                    "-o", so, cpp], check=True)
+    lib = C.CDLL(so)
+    lib.hc_create.restype = C.c_void_p
+    lib.hc_create.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.hc_destroy.argtypes = [C.c_void_p]
+    lib.hc_step.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    for f in (lib.hc_drain_messages, lib.hc_drain_applies, lib.hc_drain_faults):
+        f.restype = C.c_size_t
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.hc_counters.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hc_read.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+class HostCompiled:
+    """the subset of BatchedRaft's interface the sparse parity suites use, over the host-compiled state machine"""
+
+    def __init__(self, n_groups, n_replicas=1, node_ids=None, self_slots=None, seed=0, device_id=0, group_base=0, flags=0,
+                 heartbeat_timeout_ms=100, election_timeout_ms=(500, 1000)):
+        self.lib = build()
+        self.G, self.R = int(n_groups), int(n_replicas)
+        self.node_ids = list(node_ids) if node_ids is not None else list(range(1, self.R + 1))
+        ids = np.array(self.node_ids, np.uint32)
+        ss = None if self_slots is None else np.ascontiguousarray(self_slots, np.uint8)
+        self._h = self.lib.hc_create(self.G, self.R, ids.ctypes.data, None if ss is None else ss.ctypes.data, int(seed), int(group_base),
+                                     int(flags), int(heartbeat_timeout_ms), int(election_timeout_ms[0]), int(election_timeout_ms[1]))
+        self._pending = []
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib.hc_destroy(self._h)
+            self._h = None
+
+    def submit_columns(self, kind, group, from_=None, term=None, id=None, aux=None, flag=None, blk_id=None, blk_next=None):
+        n = len(kind)
+        z = lambda v, dt: np.zeros(n, dt) if v is None else np.ascontiguousarray(v, dt)  # noqa: E731
+        self._pending.append(dict(kind=np.ascontiguousarray(kind, np.uint8), group=np.ascontiguousarray(group, np.uint32), from_=z(from_, np.uint32),
+                                  term=z(term, np.uint64), id=z(id, np.uint64), aux=z(aux, np.uint64), flag=z(flag, np.uint8),
+                                  blk_id=np.zeros(0, np.uint64) if blk_id is None else np.ascontiguousarray(blk_id, np.uint64),
+                                  blk_next=np.zeros(0, np.uint64) if blk_next is None else np.ascontiguousarray(blk_next, np.uint64)))
+
+    def step(self, now_ms=0):
+        if not self._pending:
+            return
+        parts, self._pending = self._pending, []
+        shift = 0
+        for p in parts:  # (AppendEntries rows index the batch's block side arrays: jg_submit shifts them as batches are appended)
+            ae = p["kind"] == capi.CMD_APPEND_ENTRIES
+            p["id"] = np.where(ae, p["id"] + np.uint64(shift), p["id"])
+            shift += len(p["blk_id"])
+        cols = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+        n, nb = len(cols["kind"]), len(cols["blk_id"])
+        bid = cols["blk_id"] if nb else np.zeros(1, np.uint64)
+        bnx = cols["blk_next"] if nb else np.zeros(1, np.uint64)
+        rc = self.lib.hc_step(self._h, n, cols["kind"].ctypes.data, cols["group"].ctypes.data, cols["from_"].ctypes.data, cols["term"].ctypes.data,
+                              cols["id"].ctypes.data, cols["aux"].ctypes.data, cols["flag"].ctypes.data, nb, bid.ctypes.data, bnx.ctypes.data, int(now_ms))
+        assert rc == 0, f"host-compiled state machine: error {rc}"
+
+    def apply_all(self, cmd, now_ms=0):
+        n = self.G
+        self.submit_columns(np.full(n, cmd.kind, np.uint8), np.arange(n, dtype=np.uint32), np.full(n, cmd.from_, np.uint32),
+                            np.full(n, cmd.term, np.uint64), np.full(n, cmd.id, np.uint64), np.full(n, cmd.aux, np.uint64), np.full(n, cmd.flag, np.uint8))
+        self.step(now_ms)
+
+    def _drain(self, fn, dtype):
+        n = fn(self._h, None, 0)
+        out = np.zeros(n, dtype=dtype)
+        if n:
+            fn(self._h, out.ctypes.data, n)
+        return out
+
+    def drain_messages(self, copy=True):
+        return self._drain(self.lib.hc_drain_messages, capi.MSG_DTYPE)
+
+    def drain_applies(self, copy=True):
+        return self._drain(self.lib.hc_drain_applies, capi.FSM_DTYPE)
+
+    def drain_faults(self):
+        return self._drain(self.lib.hc_drain_faults, capi.FAULT_DTYPE)
+
+    def counters(self):
+        arr = (C.c_uint64 * 4)()
+        self.lib.hc_counters(self._h, arr)
+        return {"commands": arr[0], "decisions": arr[1], "dense_group_steps": 0, "launches": 0}
+
+    def read(self, field_name, replica=0, g0=0, n=None):
+        fld = capi.FIELD_NAMES[field_name]
+        out = np.zeros(self.G, dtype=capi.FIELD_DTYPES[fld])
+        assert self.lib.hc_read(self._h, fld, int(replica), out.ctypes.data) == 0
+        n = self.G - g0 if n is None else n
+        return out[g0:g0 + n]
