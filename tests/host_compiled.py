@@ -21,19 +21,44 @@ CSRC = os.path.join(ROOT, "josefine_amd", "csrc")
 
 HIP_SHIM = r'''
 #pragma once
-// stand-in for <hip/hip_runtime.h> when jg_device.h is compiled for the host (tests/host_compiled.py)
+// stand-in for <hip/hip_runtime.h> when the device headers are compiled for the host (tests/host_compiled.py).  ONE lane:
+// JG_BLOCK is 1, a ballot is the lane's own bit, a shuffle from another lane finds nothing - good for code whose lanes work
+// on their own (the general state machine, the slow kernels' list walks), NOT for the dense kernels' wave logic.
 #include <cstdint>
+#include <cstddef>
+#include <algorithm>
 #define __device__
 #define __host__
 #define __global__
 #define __forceinline__ inline
 #define __restrict__
 #define __launch_bounds__(...)
+#define __shared__ static
 struct uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct dim3 { uint32_t x = 1, y = 1, z = 1; };
+static dim3 threadIdx{0, 0, 0}, blockIdx{0, 0, 0}, blockDim{1, 1, 1}, gridDim{1, 1, 1};
+static inline void __syncthreads() {}
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
 static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
+static inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
 static inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline uint64_t __ballot(bool x) { return x ? 1ull : 0ull; }
+template <class T> static inline T __shfl(T v, int, int = 64) { return v; }
+template <class T> static inline T __shfl_down(T, int, int = 64) { return T(0); }
+template <class T> static inline T __shfl_xor(T, int, int = 64) { return T(0); }
+template <class T> static inline T __shfl_up(T, int, int = 64) { return T(0); }
+static inline uint32_t __builtin_amdgcn_readlane(uint32_t v, int) { return v; }
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_fetch_or(p, v, order, scope) atomicOr((p), (v))
+#define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (decltype(*(p) + 0))(v))
+using std::max;
+using std::min;
 '''
 
 HARNESS = r'''
@@ -41,7 +66,9 @@ HARNESS = r'''
 #include <cstring>
 #include <numeric>
 #include <vector>
-#include "jg_device.h"
+#define JG_BLOCK 1
+#include "jg_kernels.h"   // (jg_device.h, jg_dense.h, jg_sparse.h: the slow leader kernel's body)
+#include "jg_follower.h"  // (... and the follower's)
 
 struct Host {
   JgDev d{};
@@ -49,6 +76,9 @@ struct Host {
   std::vector<uint32_t> flags, fvote;
   std::vector<uint4> cold_t, cold_v;
   std::vector<JgFaultRec> fq;
+  std::vector<uint64_t> defer_bits, fdefer_bits;
+  std::vector<uint32_t> slow_list, slow_cnt;
+  std::vector<JgXqRec> xq;
   uint32_t status[8] = {};
   uint32_t seq = 0;
   uint64_t n_cmds = 0, decisions = 0;
@@ -79,6 +109,13 @@ extern "C" Host* hc_create(uint32_t G, uint32_t R, const uint32_t* node_ids, con
   d.err = &h->status[0], d.irregular_seen = &h->status[1], d.deferred_seen = &h->status[2], d.fault_q_n = &h->status[3];
   d.xq_n = &h->status[4], d.cold_seen = &h->status[5];
   d.xq = nullptr, d.xq_cap = 0;
+  h->blk_dec.assign(4096, 0), d.blk_decisions = h->blk_dec.data();
+  h->defer_bits.assign((G + 63) / 64, 0), d.defer_bits = h->defer_bits.data();
+  h->fdefer_bits.assign(2 * ((G + 63) / 64), 0), d.fdefer_bits = h->fdefer_bits.data();
+  d.slow_cap = G + 64;
+  h->slow_list.assign((size_t)JG_SHARDS * d.slow_cap, 0), d.slow_list = h->slow_list.data();
+  h->slow_cnt.assign(JG_SHARDS, 0), d.slow_cnt = h->slow_cnt.data();
+  h->xq.assign((size_t)(R + 3) * G + 64, JgXqRec{});
   for (uint32_t g = 0; g < G; g++) {
 @INIT_BODY@
   }
@@ -196,9 +233,98 @@ extern "C" int hc_read(Host* h, int field, uint32_t replica, void* out) {
   }
   return 0;
 }
+
+// ---- the slow kernels' bodies, one lane, every shard in turn ----------------------------------------------------
+static void collect_after_dense(Host* h) {
+  JgDev& d = h->d;
+  const uint32_t nx = *d.xq_n;
+  std::vector<JgXqRec> x(h->xq.data(), h->xq.data() + nx);
+  std::sort(x.begin(), x.end(), [](const JgXqRec& a, const JgXqRec& b) {  // the drain's merge order (josefine_gpu.hip::drain_finish)
+    if (a.seq != b.seq) return a.seq < b.seq;
+    if (a.row.group != b.row.group) return a.row.group < b.row.group;
+    return a.k < b.k;
+  });
+  for (const JgXqRec& r : x) h->msgs.push_back(r.row);
+  *d.xq_n = 0;
+  const uint32_t nf = *d.fault_q_n;
+  std::vector<JgFaultRec> f(d.fault_q, d.fault_q + nf);
+  std::stable_sort(f.begin(), f.end(), [](const JgFaultRec& a, const JgFaultRec& b) { return a.seq != b.seq ? a.seq < b.seq : a.group < b.group; });
+  h->faults.insert(h->faults.end(), f.begin(), f.end());
+  *d.fault_q_n = 0;
+  for (uint64_t& v : h->blk_dec) h->decisions += v, v = 0;
+}
+// jg_step_dense_leader with EVERY healthy leader handed to k_dense_slow<true> (the dense kernel's part for the others:
+// an empty outbox row); answers: [R][G] JG_ANSWER words or null, o_beat / o_ae: null = no Tick
+extern "C" int hc_leader_half(Host* h, uint64_t now, const uint64_t* answers, const uint64_t* hbr_commit, jg_leader_beat* o_beat, uint64_t* o_ae) {
+  JgDev& d = h->d;
+  h->seq++;
+  d.xq = h->xq.data(), d.xq_cap = (uint32_t)h->xq.size();
+  JgLeaderNode nd{};
+  nd.hbr_commit = hbr_commit, nd.packed = 1, nd.now = now, nd.ack_stride = answers ? 1 : 0;
+  nd.o_beat = o_beat, nd.o_ae = o_ae;
+  for (uint32_t g = 0; g < d.G; g++) {
+    const uint32_t f = d.flags[g];
+    if (o_beat) {
+      o_beat[g] = jg_leader_beat{0, JG_NO_ACK};
+      for (uint32_t r = 0; r < d.R; r++) o_ae[(size_t)r * d.G + g] = JG_NO_ACK;
+    }
+    if ((f & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER) d.defer_bits[g >> 6] |= 1ull << (g & 63u);
+  }
+  gridDim.x = JG_SHARDS;
+  for (uint32_t b = 0; b < JG_SHARDS; b++) {
+    blockIdx.x = b;
+    jg_dense_slow_body<true>(d, answers, 1, (size_t)d.R * d.G, h->seq, nd, false);
+  }
+  blockIdx.x = 0, gridDim.x = 1;
+  collect_after_dense(h);
+  d.xq = nullptr, d.xq_cap = 0;
+  return (int)h->status[0];
+}
+// jg_step_dense_follower with EVERY live group handed to k_follower_slow
+extern "C" int hc_follower_half(Host* h, uint64_t now, const jg_leader_beat* beat, const uint64_t* ae, const uint32_t* leader, uint32_t leader_id,
+                                int tick, uint64_t* o_answer, uint64_t* o_hbc) {
+  JgDev& d = h->d;
+  h->seq++;
+  d.xq = h->xq.data(), d.xq_cap = (uint32_t)h->xq.size();
+  JgFollowerArgs a{};
+  a.leader = leader, a.leader_id = leader_id, a.beat = beat, a.ae = ae, a.o_answer = o_answer, a.o_hbc = o_hbc;
+  a.now = now, a.seq = h->seq, a.tick = tick ? 1 : 0;
+  for (uint32_t g = 0; g < d.G; g++) {
+    o_answer[g] = JG_NO_ACK;
+    if (!(d.flags[g] & JGF_FAULT_MASK)) d.fdefer_bits[g >> 6] |= 1ull << (g & 63u);
+  }
+  gridDim.x = JG_SHARDS;
+  for (uint32_t b = 0; b < JG_SHARDS; b++) {
+    blockIdx.x = b;
+    jg_follower_slow_body(d, a);
+  }
+  blockIdx.x = 0, gridDim.x = 1;
+  collect_after_dense(h);
+  d.xq = nullptr, d.xq_cap = 0;
+  return (int)h->status[0];
+}
 '''
 
 _lib = None
+
+
+def _patched_sources():
+    """a copy of the device headers with ONE textual substitution: jg_block_count sizes its per-wave scratch as
+    JG_BLOCK / 64 words - zero with the one-lane JG_BLOCK this build uses"""
+    import shutil
+    tmp = tempfile.mkdtemp(prefix="jg_host_src_")
+    dst = os.path.join(tmp, "josefine_amd", "csrc")
+    shutil.copytree(CSRC, dst, ignore=shutil.ignore_patterns("*.so", "*.o"))
+    os.makedirs(os.path.join(tmp, "include"))
+    shutil.copy(os.path.join(ROOT, "include", "josefine_gpu.h"), os.path.join(tmp, "include"))
+    p = os.path.join(dst, "jg_dense.h")
+    text = open(p).read()
+    a = text.index("__device__ __forceinline__ void jg_block_count(")
+    b = text.index("}\n", text.index("__hip_atomic_fetch_add(&slots[blockIdx.x]", a))
+    body = text[a:b]
+    assert body.count("JG_BLOCK / 64") == 2
+    open(p, "w").write(text[:a] + body.replace("JG_BLOCK / 64", "((JG_BLOCK + 63) / 64)") + text[b:])
+    return dst
 
 
 def build():
@@ -206,7 +332,8 @@ def build():
     global _lib
     if _lib is not None:
         return _lib
-    kernels = open(os.path.join(CSRC, "jg_kernels.h")).read()
+    src = _patched_sources()
+    kernels = open(os.path.join(src, "jg_kernels.h")).read()
     a = kernels.index("__global__ void k_init_groups")
     a = kernels.index("JgLane L;", a)
     b = kernels.index("jg_store(d, L);", a) + len("jg_store(d, L);")
@@ -216,7 +343,7 @@ def build():
     open(os.path.join(tmp, "shim", "hip", "hip_runtime.h"), "w").write(HIP_SHIM)
     cpp, so = os.path.join(tmp, "host_compiled.cpp"), os.path.join(tmp, "libhost_compiled.so")
     open(cpp, "w").write(HARNESS.replace("@INIT_BODY@", init_body))
-    subprocess.run(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-Wno-unused-function", f"-I{os.path.join(tmp, 'shim')}", f"-I{CSRC}",
+    subprocess.run(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-Wno-unused-function", f"-I{os.path.join(tmp, 'shim')}", f"-I{src}",
                     "-o", so, cpp], check=True)
     lib = C.CDLL(so)
     lib.hc_create.restype = C.c_void_p
@@ -228,6 +355,8 @@ def build():
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.hc_counters.argtypes = [C.c_void_p, C.c_void_p]
     lib.hc_read.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+    lib.hc_leader_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hc_follower_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 
@@ -309,3 +438,41 @@ class HostCompiled:
         assert self.lib.hc_read(self._h, fld, int(replica), out.ctypes.data) == 0
         n = self.G - g0 if n is None else n
         return out[g0:g0 + n]
+
+    # -- the dense halves, every group through the slow kernels' bodies (the interface of BatchedRaft's column forms) --
+    def step_dense_leader(self, now_ms=0, acks=None, hbr_has=None, hbr_commit=None, tick=True):
+        assert not self._pending
+        G, R = self.G, self.R
+        ans = hbc = None
+        if acks is not None or hbr_has is not None:
+            a = np.full((R, G), capi.NO_ACK, np.uint64) if acks is None else np.asarray(acks, np.uint64).reshape(R, G)
+            if acks is None:
+                a[self.read("self_slot"), np.arange(G)] = 0
+            hh = np.full((R, G), capi.HB_NONE, np.uint8) if hbr_has is None else np.asarray(hbr_has, np.uint8).reshape(R, G)
+            hbc = np.ascontiguousarray(np.zeros((R, G), np.uint64) if hbr_commit is None else np.asarray(hbr_commit, np.uint64).reshape(R, G))
+            ans = np.ascontiguousarray(capi.pack_answers(a, hh))
+        beat = np.zeros((G, 2), np.uint64)
+        ae = np.full((R, G), capi.NO_ACK, np.uint64)
+        rc = self.lib.hc_leader_half(self._h, int(now_ms), None if ans is None else ans.ctypes.data, None if hbc is None else hbc.ctypes.data,
+                                     beat.ctypes.data if tick else None, ae.ctypes.data if tick else None)
+        assert rc == 0, f"host-compiled leader half: error {rc}"
+        if not tick:
+            return None
+        own = self.read("self_slot")
+        ae[own, np.arange(G)] = np.uint64(capi.NO_ACK)  # (the own slot's row is nobody's mail)
+        ae_from, ae_n = capi.unpack_ae(ae)
+        return {"term": np.ascontiguousarray(beat[:, 0]), "hb_commit": np.ascontiguousarray(beat[:, 1]), "ae_from": ae_from, "ae_n": ae_n}
+
+    def step_dense_follower(self, now_ms, term, hb_commit, ae_from, ae_n, leader=None, leader_id=0, tick=True):
+        assert not self._pending
+        G = self.G
+        beat = np.ascontiguousarray(np.stack([np.asarray(term, np.uint64), np.asarray(hb_commit, np.uint64)], axis=1))
+        ae = np.ascontiguousarray(capi.pack_ae(np.asarray(ae_from, np.uint64), np.asarray(ae_n, np.uint8)))
+        ld = None if leader is None else np.ascontiguousarray(leader, np.uint32)
+        ans = np.zeros(G, np.uint64)
+        hbc = np.zeros(G, np.uint64)
+        rc = self.lib.hc_follower_half(self._h, int(now_ms), beat.ctypes.data, ae.ctypes.data, None if ld is None else ld.ctypes.data, int(leader_id),
+                                       1 if tick else 0, ans.ctypes.data, hbc.ctypes.data)
+        assert rc == 0, f"host-compiled follower half: error {rc}"
+        ack_head, hb_has = capi.unpack_answers(ans)
+        return {"ack_head": ack_head, "hb_commit": np.where(hb_has != capi.HB_NONE, hbc, 0).astype(np.uint64), "hb_has": hb_has}

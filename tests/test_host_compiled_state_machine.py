@@ -96,3 +96,70 @@ def test_restarted_reelected_leader_keeps_its_lags_below_the_top_of_its_run():
         if t == 4:
             assert (ora.read("role") == capi.ROLE_LEADER).all() and (ora.read("head") == 2).all() and (ora.read("commit") == 4).all()
     assert (ora.read("fault") == capi.FAULT_COMMIT_MISSING_BLOCK).all()
+
+
+@pytest.mark.parametrize("R,flags", [(3, 0), (5, capi.CFG_SEPARATE_COMMIT_KEY), (2, 0), (8, capi.CFG_SEPARATE_COMMIT_KEY), (3, capi.CFG_SEPARATE_COMMIT_KEY)])
+def test_the_slow_kernels_bodies_serve_the_dense_halves(R, flags):
+    """k_dense_slow<true> / k_follower_slow - the general state machine over the mailbox words: the leaders' HeartbeatResponses,
+    appends, acknowledgements and Tick (as columns where the chain is a run, as rows otherwise), the followers' Heartbeat /
+    AppendEntries / Tick with their answers captured into words - compiled for the host, ONE lane walking every shard's list,
+    with EVERY live group handed to them: jg_step_dense_leader / jg_step_dense_follower as the header specifies them, against
+    the oracle, over random mailboxes into mixed roles (the traffic of tests/test_ref_py_differential.py::test_dense_node_ticks)."""
+    from dense_node import random_follower_inbox, random_leader_inbox
+    G, ticks = 160, 40
+    rng = np.random.default_rng(29000 + R + flags)
+    slots = np.full(G, int(rng.integers(0, R)), np.uint8)  # (one NodeId per node: the own slot is the engine's)
+    dev, ora = pair(G, R, seed=60 + R, self_slots=slots, flags=flags, election_timeout_ms=(300, 600))
+    lead = np.arange(G) % 3 != 0  # two thirds of the groups are led here, the others follow
+    for e in (dev, ora):
+        g = np.nonzero(lead)[0].astype(np.uint32)
+        e.submit_columns(np.full(len(g), capi.CMD_TIMEOUT, np.uint8), g)
+        e.step(0)
+        ids = np.array(e.node_ids, np.uint32)
+        for k in range(1, R // 2 + 1):
+            e.submit_columns(np.full(len(g), capi.CMD_VOTE_RESPONSE, np.uint8), g, from_=ids[(slots[g].astype(np.int64) + k) % R],
+                             term=np.ones(len(g), np.uint64), flag=np.ones(len(g), np.uint8))
+            e.step(0)
+    compare_snapshots(dev, ora, "node set-up")
+    compare_drains(dev, ora, "node set-up")
+    now = 0
+    self_ids = np.array(ora.node_ids, np.uint32)[slots]
+    for t in range(ticks):
+        now += int(rng.integers(40, 260))
+        acks, hbr_has, hbr_commit = random_leader_inbox(rng, G, R, slots, ora.read("head").astype(np.uint64))
+        # (a ClientRequest count at a group that does not lead is the dense kernel's own fault path, not the slow body's)
+        not_led = (ora.read("role") != capi.ROLE_LEADER) | (ora.read("fault") != 0)
+        acks[slots, np.arange(G)] = np.where(not_led, 0, acks[slots, np.arange(G)])
+        outs = [e.step_dense_leader(now, acks, hbr_has, hbr_commit, tick=True) for e in (dev, ora)]
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k], outs[1][k]), f"R={R} tick {t}: leader outbox {k}: {np.nonzero(outs[0][k] != outs[1][k])}"
+        compare_drains(dev, ora, f"R={R} leader half {t}")
+        if R > 1:
+            fin = random_follower_inbox(rng, G, ora.node_ids, self_ids, ora.read("head"), ora.read("commit"), ora.read("term"))
+            outs = [e.step_dense_follower(now, **fin, tick=True) for e in (dev, ora)]
+            for k in outs[0]:
+                assert np.array_equal(outs[0][k], outs[1][k]), f"R={R} tick {t}: follower outbox {k}"
+        compare_drains(dev, ora, f"R={R} follower half {t}")
+        if t % 5 == 4 or t == ticks - 1:
+            compare_snapshots(dev, ora, f"R={R} node tick {t}")
+    assert dev.counters()["decisions"] == ora.counters()["decisions"] > 0
+
+
+def test_an_append_entries_at_a_higher_term_kills_a_leader_in_the_follower_half():
+    """leader.rs:200-208 calls Role::term, which is `unimplemented!()` for a leader (leader.rs:33-35, Q3): the AppendEntries of a
+    newer leader does not make the old one a follower, it ends its process - through the follower half's slow body as through
+    Apply; the Tick that follows finds nobody (a faulted group is not ticked)."""
+    G, R = 96, 3
+    dev, ora = pair(G, R, seed=8, flags=capi.CFG_SEPARATE_COMMIT_KEY, election_timeout_ms=(300, 600))
+    for e in (dev, ora):
+        elect_all(e)
+        e.drain_messages(), e.drain_applies()
+    fin = dict(term=np.full(G, 2, np.uint64), hb_commit=np.full(G, capi.NO_ACK, np.uint64), ae_from=np.zeros(G, np.uint64),
+               ae_n=np.where(np.arange(G) % 2 == 0, 1, capi.AE_NONE).astype(np.uint8), leader_id=2)
+    outs = [e.step_dense_follower(50_000, **fin, tick=True) for e in (dev, ora)]
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    compare_drains(dev, ora, "a newer leader's AppendEntries")
+    compare_snapshots(dev, ora, "a newer leader's AppendEntries")
+    assert (ora.read("fault")[0::2] == capi.FAULT_LEADER_TERM_UNIMPLEMENTED).all() and not ora.read("fault")[1::2].any()
+    assert (ora.read("role") == capi.ROLE_LEADER).all() and (ora.read("term")[1::2] == 1).all()  # (Raft::term had set the term when Role::term panicked)
