@@ -40,7 +40,10 @@ struct dim3 { uint32_t x = 1, y = 1, z = 1; };
 static dim3 threadIdx{0, 0, 0}, blockIdx{0, 0, 0}, blockDim{1, 1, 1}, gridDim{1, 1, 1};
 static inline void __syncthreads() {}
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
-template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T, class U> static inline T atomicOr(T* p, U v) { T o = *p; *p = o | (T)v; return o; }
+template <class T, class U> static inline T atomicAnd(T* p, U v) { T o = *p; *p = o & (T)v; return o; }
+template <class T, class U> static inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
+template <class T, class U> static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
 template <class T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
 static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 static inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
@@ -56,6 +59,7 @@ static inline uint32_t __builtin_amdgcn_readlane(uint32_t v, int) { return v; }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_fetch_or(p, v, order, scope) atomicOr((p), (v))
+#define __hip_atomic_fetch_and(p, v, order, scope) atomicAnd((p), (v))
 #define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (decltype(*(p) + 0))(v))
 using std::max;
 using std::min;
@@ -69,6 +73,7 @@ HARNESS = r'''
 #define JG_BLOCK 1
 #include "jg_kernels.h"   // (jg_device.h, jg_dense.h, jg_sparse.h: the slow leader kernel's body)
 #include "jg_follower.h"  // (... and the follower's)
+#include "jg_node.h"      // (jg_step_node's row passes: prefill, classify, route, fsm build)
 
 struct Host {
   JgDev d{};
@@ -303,6 +308,117 @@ extern "C" int hc_follower_half(Host* h, uint64_t now, const jg_leader_beat* bea
   d.xq = nullptr, d.xq_cap = 0;
   return (int)h->status[0];
 }
+
+// ---- jg_step_node, synchronous: the device's row passes as they are, the two halves through the slow kernels' bodies ----
+// josefine_gpu.hip::node_step in a few lines: k_node_prefill, k_node_classify, k_node_route over the unsorted rows; the
+// general-path rows in (group, arrival) order through the state machine (the step's first sequence number); the leader half
+// (arrival replay by nd.arr, fsm words) and the follower half over the mailbox columns the route pass filled; k_node_fsm_build.
+struct NodeScratch {
+  std::vector<uint64_t> answers, hbr_commit, token, f_ae, lt_max, lt_min, fsm_prev, fsm_mid, sparse_bits, sp_key;
+  std::vector<jg_leader_beat> f_beat;
+  std::vector<uint32_t> f_leader, cls, lf_max, lf_min, fsm_delta, arr, fo, sp_idx;
+};
+extern "C" int hc_step_node(Host* h, uint32_t n, const uint8_t* kind, const uint32_t* group, const uint32_t* from, const uint64_t* term,
+                            const uint64_t* id, const uint64_t* aux, const uint8_t* flag, uint64_t nb, const uint64_t* blk_id,
+                            const uint64_t* blk_next, uint64_t now, uint32_t flags, int uniform_self, uint32_t kinds_seen,
+                            jg_leader_beat* o_beat, uint64_t* o_ae, uint64_t* o_answer, uint64_t* o_hbc, uint64_t* n_general) {
+  JgDev& d = h->d;
+  const uint32_t G = d.G, R = d.R;
+  const uint32_t halves = flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF);
+  const bool tick = (flags & JG_NODE_TICK) != 0;
+  NodeScratch s;
+  s.answers.assign((size_t)R * G, 0), s.hbr_commit.assign((size_t)R * G, 0), s.token.assign(G, 0), s.f_ae.assign(G, 0);
+  s.lt_max.assign(G, 0), s.lt_min.assign(G, 0), s.fsm_prev.assign(G, 0), s.fsm_mid.assign(G, 0), s.sparse_bits.assign((G + 63) / 64, 0);
+  s.f_beat.assign(G, jg_leader_beat{}), s.f_leader.assign(G, 0), s.cls.assign(G, 0), s.lf_max.assign(G, 0), s.lf_min.assign(G, 0);
+  s.fsm_delta.assign(G, 0), s.arr.assign((size_t)2 * R * G, 0), s.fo.assign((size_t)2 * G, 0);
+  s.sp_key.assign(n + 1, 0), s.sp_idx.assign(n + 1, 0);
+  JgNodeCols c{};
+  c.answers = s.answers.data(), c.hbr_commit = s.hbr_commit.data(), c.token = s.token.data(), c.f_beat = s.f_beat.data(), c.f_ae = s.f_ae.data();
+  c.f_leader = s.f_leader.data(), c.cls = s.cls.data(), c.lt_max = s.lt_max.data(), c.lt_min = s.lt_min.data(), c.lf_max = s.lf_max.data();
+  c.lf_min = s.lf_min.data(), c.arr = s.arr.data(), c.fo = s.fo.data(), c.sparse_bits = s.sparse_bits.data(), c.fsm_delta = s.fsm_delta.data();
+  c.fsm_prev = s.fsm_prev.data(), c.fsm_mid = s.fsm_mid.data();
+  const uint32_t seq0 = h->seq;
+  const uint32_t both_beats = (kinds_seen & 3u) == 3u;
+  blockIdx.x = 0, gridDim.x = 1;
+  k_node_prefill(d, c, uniform_self, halves & JG_NODE_LEADER_HALF, halves & JG_NODE_FOLLOWER_HALF, both_beats, 0);
+  h->seq = seq0 + 1;  // the general path's number: taken whether or not it runs
+  *n_general = 0;
+  if (n) {
+    JgNodeRows rows{};
+    rows.n = n, rows.group = group, rows.kind = kind, rows.from = from, rows.term = term, rows.id = id, rows.aux = aux, rows.flag = flag;
+    rows.blk_id = blk_id, rows.blk_next = blk_next, rows.n_blocks = nb;
+    uint32_t nsp[2] = {0, 0};
+    k_node_classify(d, c, rows, uniform_self, halves, both_beats, 0);
+    k_node_route(d, c, rows, uniform_self, both_beats, s.sp_key.data(), s.sp_idx.data(), nsp);
+    if (h->status[0]) return (int)h->status[0];
+    const uint32_t ns = nsp[0];
+    *n_general = ns;
+    if (ns) {  // (group, arrival index): what the bucket pass + k_bucket_order produce on the device
+      std::vector<uint32_t> order(ns);
+      std::iota(order.begin(), order.end(), 0u);
+      std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return s.sp_key[a] < s.sp_key[b]; });
+      std::vector<uint8_t> k2(ns), f2(ns);
+      std::vector<uint32_t> g2(ns), fr2(ns);
+      std::vector<uint64_t> t2(ns), i2(ns), a2(ns);
+      for (uint32_t p = 0; p < ns; p++) {
+        const uint32_t i = s.sp_idx[order[p]];
+        k2[p] = kind[i], g2[p] = group[i], fr2[p] = from[i], t2[p] = term[i], i2[p] = id[i], a2[p] = aux[i], f2[p] = flag[i];
+      }
+      h->seq = seq0;  // (hc_step takes the next number itself)
+      const int rc = hc_step(h, ns, k2.data(), g2.data(), fr2.data(), t2.data(), i2.data(), a2.data(), f2.data(), nb, blk_id, blk_next, now);
+      if (rc) return rc;
+    }
+  }
+  h->seq = seq0 + 1;
+  d.xq = h->xq.data(), d.xq_cap = (uint32_t)h->xq.size();
+  gridDim.x = JG_SHARDS;
+  if (halves & JG_NODE_LEADER_HALF) {
+    h->seq++;
+    JgLeaderNode ln{};
+    ln.hbr_commit = c.hbr_commit, ln.packed = 1, ln.ack_stride = 1, ln.now = now;
+    if (tick) ln.o_beat = o_beat, ln.o_ae = o_ae;
+    ln.fsm_delta = c.fsm_delta, ln.fsm_prev = c.fsm_prev, ln.fsm_mid = c.fsm_mid, ln.arr = c.arr, ln.col_mask = 0;
+    for (uint32_t g = 0; g < G; g++) {
+      if (tick) {
+        o_beat[g] = jg_leader_beat{0, JG_NO_ACK};
+        for (uint32_t r = 0; r < R; r++) o_ae[(size_t)r * G + g] = JG_NO_ACK;
+      }
+      if ((d.flags[g] & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER) d.defer_bits[g >> 6] |= 1ull << (g & 63u);
+    }
+    for (uint32_t b = 0; b < JG_SHARDS; b++) {
+      blockIdx.x = b;
+      jg_dense_slow_body<true>(d, c.answers, 1, (size_t)R * G, h->seq, ln, false);
+    }
+  }
+  if (halves & JG_NODE_FOLLOWER_HALF) {
+    h->seq++;
+    JgFollowerArgs a{};
+    a.leader = c.f_leader, a.beat = c.f_beat, a.ae = c.f_ae, a.o_answer = o_answer, a.o_hbc = o_hbc;
+    a.now = now, a.seq = h->seq, a.tick = tick ? 1 : 0, a.fsm_delta = c.fsm_delta, a.fsm_prev = c.fsm_prev;
+    for (uint32_t g = 0; g < G; g++) {
+      o_answer[g] = JG_NO_ACK;
+      if (!(d.flags[g] & JGF_FAULT_MASK)) d.fdefer_bits[g >> 6] |= 1ull << (g & 63u);
+    }
+    for (uint32_t b = 0; b < JG_SHARDS; b++) {
+      blockIdx.x = b;
+      jg_follower_slow_body(d, a);
+    }
+  }
+  blockIdx.x = 0, gridDim.x = 1;
+  collect_after_dense(h);
+  d.xq = nullptr, d.xq_cap = 0;
+  // the halves' fsm words -> rows, partitions ascending (k_node_fsm_build: one group per lane)
+  std::vector<jg_fsm_row> fr((size_t)G * JGN_FSM_ROWS);
+  std::vector<uint32_t> cnt(G, 0);
+  std::vector<uint64_t> bsum(G + 1, 0);
+  for (uint32_t g = 0; g < G; g++) {
+    blockIdx.x = g;
+    k_node_fsm_build(d, c, fr.data(), cnt.data(), bsum.data());
+    for (uint32_t k = 0; k < cnt[g]; k++) h->fsm.push_back(fr[(size_t)g * JGN_FSM_ROWS + k]);
+  }
+  blockIdx.x = 0;
+  return (int)h->status[0];
+}
 '''
 
 _lib = None
@@ -324,6 +440,12 @@ def _patched_sources():
     body = text[a:b]
     assert body.count("JG_BLOCK / 64") == 2
     open(p, "w").write(text[:a] + body.replace("JG_BLOCK / 64", "((JG_BLOCK + 63) / 64)") + text[b:])
+    # ... and the transport's scan kernel asserts its tile of 4 buckets per thread of a 256-thread workgroup: not called here
+    p = os.path.join(dst, "jg_route.h")
+    text = open(p).read()
+    line = '  static_assert(JG_ROUTE_SCAN_TILE == 4 * JG_BLOCK, "4 buckets per thread");'
+    assert text.count(line) == 1
+    open(p, "w").write(text.replace(line, "  // (one-lane host build: " + line.strip() + ")"))
     return dst
 
 
@@ -357,6 +479,8 @@ def build():
     lib.hc_read.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
     lib.hc_leader_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hc_follower_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    lib.hc_step_node.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32] + \
+        [C.c_void_p] * 5
     _lib = lib
     return lib
 
@@ -476,3 +600,42 @@ class HostCompiled:
         assert rc == 0, f"host-compiled follower half: error {rc}"
         ack_head, hb_has = capi.unpack_answers(ans)
         return {"ack_head": ack_head, "hb_commit": np.where(hb_has != capi.HB_NONE, hbc, 0).astype(np.uint64), "hb_has": hb_has}
+
+    def step_node(self, now_ms=0, leader=True, follower=True, tick=True, async_=False, between=None):
+        """jg_step_node (synchronous) over the rows submitted since the last step"""
+        parts, self._pending = self._pending, []
+        G, R = self.G, self.R
+        if parts:
+            shift = 0
+            for p in parts:
+                ae = p["kind"] == capi.CMD_APPEND_ENTRIES
+                p["id"] = np.where(ae, p["id"] + np.uint64(shift), p["id"])
+                shift += len(p["blk_id"])
+            cols = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+        else:
+            cols = dict(kind=np.zeros(0, np.uint8), group=np.zeros(0, np.uint32), from_=np.zeros(0, np.uint32), term=np.zeros(0, np.uint64),
+                        id=np.zeros(0, np.uint64), aux=np.zeros(0, np.uint64), flag=np.zeros(0, np.uint8), blk_id=np.zeros(0, np.uint64), blk_next=np.zeros(0, np.uint64))
+        n, nb = len(cols["kind"]), len(cols["blk_id"])
+        pad = lambda v, dt: v if len(v) else np.zeros(1, dt)  # noqa: E731
+        seen = (1 if (cols["kind"] == capi.CMD_APPEND_ENTRIES).any() else 0) | (2 if (cols["kind"] == capi.CMD_HEARTBEAT).any() else 0)
+        flags = (capi.NODE_LEADER_HALF if leader else 0) | (capi.NODE_FOLLOWER_HALF if follower else 0) | (capi.NODE_TICK if tick else 0)
+        slots = self.read("self_slot")
+        us = int(slots[0]) if (slots == slots[0]).all() else -1
+        beat = np.zeros((G, 2), np.uint64)
+        ae = np.full((R, G), capi.NO_ACK, np.uint64)
+        ans = np.full(G, capi.NO_ACK, np.uint64)
+        hbc = np.zeros(G, np.uint64)
+        ngen = C.c_uint64(0)
+        a = {k: pad(cols[k], cols[k].dtype) for k in cols}
+        rc = self.lib.hc_step_node(self._h, n, a["kind"].ctypes.data, a["group"].ctypes.data, a["from_"].ctypes.data, a["term"].ctypes.data,
+                                   a["id"].ctypes.data, a["aux"].ctypes.data, a["flag"].ctypes.data, nb, a["blk_id"].ctypes.data, a["blk_next"].ctypes.data,
+                                   int(now_ms), flags, us, seen, beat.ctypes.data, ae.ctypes.data, ans.ctypes.data, hbc.ctypes.data, C.byref(ngen))
+        assert rc == 0, f"host-compiled node step: error {rc}"
+        if between is not None:
+            between()
+        if us >= 0:
+            ae[us] = np.uint64(capi.NO_ACK)  # (the own slot's row is nobody's mail)
+        has_l, has_f = leader and tick, follower
+        return {"beat_term": np.ascontiguousarray(beat[:, 0]) if has_l else None, "beat_commit": np.ascontiguousarray(beat[:, 1]) if has_l else None,
+                "ae": ae if has_l else None, "answer": ans if has_f else None, "hb_commit": hbc if has_f else None,
+                "rows": n, "rows_general": int(ngen.value), "bytes_h2d": 0, "bytes_d2h": 0}

@@ -163,3 +163,31 @@ def test_an_append_entries_at_a_higher_term_kills_a_leader_in_the_follower_half(
     compare_snapshots(dev, ora, "a newer leader's AppendEntries")
     assert (ora.read("fault")[0::2] == capi.FAULT_LEADER_TERM_UNIMPLEMENTED).all() and not ora.read("fault")[1::2].any()
     assert (ora.read("role") == capi.ROLE_LEADER).all() and (ora.read("term")[1::2] == 1).all()  # (Raft::term had set the term when Role::term panicked)
+
+
+@pytest.mark.parametrize("R,flags,G", [(3, 0, 600), (5, capi.CFG_SEPARATE_COMMIT_KEY, 600), (1, 0, 100), (2, capi.CFG_SEPARATE_COMMIT_KEY, 300)])
+def test_the_node_steps_row_passes_and_arrival_replay(R, flags, G):
+    """jg_step_node on the host: the device's k_node_prefill / k_node_classify / k_node_route over the unsorted rows and
+    k_node_fsm_build as they are, the general-path rows through the state machine in (partition, arrival) order, both halves
+    through the slow kernels' bodies (the leader's replays a partition's mailbox entries by arrival index: nd.arr) - against
+    the oracle's jg_step_node = plain arrival-order Apply, under the traffic of tests/test_node_step.py (every reason to leave
+    the column path, out-of-order pairs of one peer, early acknowledgements): outbox words, state, every drained row."""
+    from node_step import compare_outboxes, node_traffic
+    from test_node_step import mixed_pair
+    T = 50
+    dev, ora, rng = mixed_pair(HostCompiled, oracle_engine, G, R, seed=21 + R, flags=flags, election_timeout_ms=(700, 1500))
+    dense_rows = general_rows = 0
+    for t in range(T):
+        now = 100 * (t + 1)
+        cols = node_traffic(rng, ora, token0=1000 * t)
+        outs = []
+        for e in (dev, ora):
+            e.submit_columns(**cols)
+            outs.append(e.step_node(now))
+        compare_outboxes(outs[0], outs[1], f"tick {t}")
+        compare_snapshots(dev, ora, f"tick {t}")
+        compare_drains(dev, ora, f"tick {t}")
+        dense_rows += outs[1]["rows"] - outs[1]["rows_general"]
+        general_rows += outs[1]["rows_general"]
+    assert dense_rows > (5 if R >= 3 else 1) * general_rows > 0
+    assert dev.counters()["decisions"] == ora.counters()["decisions"]
