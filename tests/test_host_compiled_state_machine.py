@@ -191,3 +191,50 @@ def test_the_node_steps_row_passes_and_arrival_replay(R, flags, G):
         general_rows += outs[1]["rows_general"]
     assert dense_rows > (5 if R >= 3 else 1) * general_rows > 0
     assert dev.counters()["decisions"] == ora.counters()["decisions"]
+
+
+@pytest.mark.parametrize("R", [3, 5])
+def test_per_partition_leadership_statement_over_the_host_compiled_halves(R):
+    """tests/dense_node.py::AnyLeaderCluster - the round of a cluster whose partitions are led wherever they were elected,
+    stated over jg_step / jg_step_dense_leader / jg_step_dense_follower calls - once over the oracle and once over the
+    host-compiled state machine and slow kernels' bodies: two leaders in some groups, whole groups restarting, the next
+    replica's campaign won through the rows, the new leader (head below the top of what its store kept) replicating out of
+    its run.  Every column of every node after every round, and the rows left for the host."""
+    from dense_node import AnyLeaderCluster
+    from josefine_amd.traces import any_failure_rows
+    from test_any_leader import spread_leaders
+    G, T = 90, 30
+    a, b = AnyLeaderCluster(oracle_engine, G, R, seed=7), AnyLeaderCluster(HostCompiled, G, R, seed=7)
+    for cl in (a, b):
+        spread_leaders(cl.nodes, G, R, dual_every=7)
+    leader_of = np.arange(G) % R
+    failed = np.zeros(G, bool)
+    for t in range(T):
+        inj, failing = any_failure_rows(3, t, G, R, 4, leader_of, whole_group=(R == 3), skip=failed) if t >= 3 else ([None] * R, [])
+        failed[failing] = True
+        for cl in (a, b):
+            cl.round(np.ones(G, np.uint64), inject=inj)
+        for n in range(R):
+            compare_snapshots(b.nodes[n], a.nodes[n], f"round {t} node {n}")
+    for n in range(R):
+        assert a.kept[n].tobytes() == b.kept[n].tobytes()
+    assert failed.sum() > 5
+
+
+@pytest.mark.parametrize("R,percent,also", [(3, 4, (2,)), (5, 3, ())])
+def test_routed_failure_cluster_over_the_host_compiled_halves(R, percent, also):
+    """BASELINE configs[4] as the cluster runs it (tests/dense_node.py::RoutedCluster: dense mailboxes, every other message
+    routed as rows, leaders crashing and restarting) over the oracle and over the host-compiled device source."""
+    from dense_node import RoutedCluster, cluster_failure_rows
+    G, T = 120, 36
+    ora = RoutedCluster(oracle_engine, G, R, seed=5)
+    dev = RoutedCluster(HostCompiled, G, R, seed=5)
+    for t in range(T):
+        inj = cluster_failure_rows(99, t, G, R, percent, also=also) if t >= 3 else [None] * R
+        ora.round(np.ones(G, np.uint64), inject=inj)
+        dev.round(np.ones(G, np.uint64), inject=[None if c is None else dict(c) for c in inj])
+        for n in range(R):
+            compare_snapshots(dev.nodes[n], ora.nodes[n], f"routed round {t} node {n}")
+        assert ora.delivered.tolist() == dev.delivered.tolist(), t
+        assert [k.tobytes() for k in ora.kept] == [k.tobytes() for k in dev.kept], t
+    assert ora.delivered.sum() > G // 10
