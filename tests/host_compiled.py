@@ -419,6 +419,71 @@ extern "C" int hc_step_node(Host* h, uint32_t n, const uint8_t* kind, const uint
   blockIdx.x = 0;
   return (int)h->status[0];
 }
+
+// ---- a round of a cluster with per-partition leadership (josefine_gpu.hip::cluster_tables_any / cluster_launch_any): the
+// claim kernel as it is, every node's leader half and follower half through the slow kernels' bodies with the cluster's
+// mailboxes (owner[g] / offered[g]: JgLeaderNode, JgFollowerArgs) - the any-leader branches of those bodies on the host
+extern "C" int hc_cluster_any_round(Host** hs, uint32_t R, uint64_t now, uint64_t* acks, uint64_t* hbr_commit, jg_leader_beat* o_beat,
+                                    uint64_t* o_ae, uint8_t* owner, const uint64_t* offered) {
+  const uint32_t G = hs[0]->d.G;
+  JgClaimArgs ca{};
+  ca.R = R, ca.G = G, ca.owner = owner;
+  for (uint32_t r = 0; r < R; r++) ca.flags[r] = hs[r]->d.flags;
+  blockIdx.x = 0, gridDim.x = 1;
+  k_cluster_claim(ca);
+  for (uint32_t r = 0; r < R; r++) hs[r]->seq += 2;  // leader half: seq - 1, follower half: seq
+  for (uint32_t r = 0; r < R; r++) {
+    Host* h = hs[r];
+    JgDev& d = h->d;
+    d.xq = h->xq.data(), d.xq_cap = (uint32_t)h->xq.size();
+    JgLeaderNode nd{};
+    nd.ack_stride = 1, nd.packed = 1, nd.hbr_commit = hbr_commit, nd.o_beat = o_beat, nd.o_ae = o_ae, nd.now = now;
+    nd.owner = owner, nd.offered = offered;
+    for (uint32_t g = 0; g < G; g++)
+      if ((d.flags[g] & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER) {
+        d.defer_bits[g >> 6] |= 1ull << (g & 63u);
+        if (owner[g] == r) {  // (what the dense half does before it hands an owned group over: jg_dense_outbox_none)
+          o_beat[g] = jg_leader_beat{0, JG_NO_ACK};
+          for (uint32_t q = 0; q < R; q++)
+            if (q != r) o_ae[(size_t)q * G + g] = JG_NO_ACK;
+        }
+      }
+    gridDim.x = JG_SHARDS;
+    for (uint32_t b = 0; b < JG_SHARDS; b++) {
+      blockIdx.x = b;
+      jg_dense_slow_body<true>(d, acks, 1, 0, h->seq - 1, nd, false);
+    }
+    blockIdx.x = 0, gridDim.x = 1;
+    collect_after_dense(h);
+    d.xq = nullptr, d.xq_cap = 0;
+    if (h->status[0]) return (int)h->status[0];
+  }
+  for (uint32_t r = 0; r < R; r++) {
+    Host* h = hs[r];
+    JgDev& d = h->d;
+    d.xq = h->xq.data(), d.xq_cap = (uint32_t)h->xq.size();
+    JgFollowerArgs a{};
+    a.beat = o_beat, a.ae = o_ae + (size_t)r * G, a.o_answer = acks + (size_t)r * G, a.o_hbc = hbr_commit + (size_t)r * G;
+    a.now = now, a.seq = h->seq, a.tick = 1, a.owner = owner, a.self_slot = r;
+    for (uint32_t g = 0; g < G; g++) {
+      const uint32_t f = d.flags[g];
+      const bool own_led = (f & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER && owner[g] == r;
+      if (own_led) continue;  // (the own slot's word of a group this node owns is nobody's: the dense half leaves it alone)
+      if (f & JGF_FAULT_MASK) a.o_answer[g] = JG_NO_ACK;
+      else d.fdefer_bits[g >> 6] |= 1ull << (g & 63u);
+    }
+    gridDim.x = JG_SHARDS;
+    for (uint32_t b = 0; b < JG_SHARDS; b++) {
+      blockIdx.x = b;
+      jg_follower_slow_body(d, a);
+    }
+    blockIdx.x = 0, gridDim.x = 1;
+    collect_after_dense(h);
+    d.xq = nullptr, d.xq_cap = 0;
+    if (h->status[0]) return (int)h->status[0];
+  }
+  return 0;
+}
 '''
 
 _lib = None
@@ -479,6 +544,7 @@ def build():
     lib.hc_read.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
     lib.hc_leader_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hc_follower_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    lib.hc_cluster_any_round.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 6
     lib.hc_step_node.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32] + \
         [C.c_void_p] * 5
     _lib = lib
@@ -639,3 +705,33 @@ class HostCompiled:
         return {"beat_term": np.ascontiguousarray(beat[:, 0]) if has_l else None, "beat_commit": np.ascontiguousarray(beat[:, 1]) if has_l else None,
                 "ae": ae if has_l else None, "answer": ans if has_f else None, "hb_commit": hbc if has_f else None,
                 "rows": n, "rows_general": int(ngen.value), "bytes_h2d": 0, "bytes_d2h": 0}
+
+
+def host_any_leader_cluster(G, R, seed=3):
+    """tests/dense_node.py::AnyLeaderCluster whose dense round is the DEVICE's own any-leader round on the host
+    (hc_cluster_any_round: k_cluster_claim + the slow bodies' owner / offered branches) instead of the numpy statement"""
+    from dense_node import AnyLeaderCluster
+
+    class HostAnyLeaderCluster(AnyLeaderCluster):
+        def __init__(self):
+            super().__init__(HostCompiled, G, R, seed=seed)
+            self.words = np.full((R, G), capi.NO_ACK, np.uint64)   # the cluster's answer words (acks + HeartbeatResponse code)
+            self.hbc_col = np.zeros((R, G), np.uint64)
+            self.beat = np.zeros((G, 2), np.uint64)
+            self.beat[:, 1] = np.uint64(capi.NO_ACK)
+            self.ae = np.full((R, G), capi.NO_ACK, np.uint64)
+            self.owner_col = np.full((G + 3) // 4 * 4, 255, np.uint8)  # (whole words: k_cluster_claim writes four groups at a time)
+
+        def dense_round(self, appends, dt_ms):
+            self.now += dt_ms
+            appends = np.broadcast_to(np.asarray(appends, dtype=np.uint64), (G,))
+            offered = np.ascontiguousarray(capi.pack_answers(appends, np.full(G, capi.HB_NONE, np.uint8)))
+            lib = self.nodes[0].lib
+            hs = (C.c_void_p * R)(*[n._h for n in self.nodes])
+            rc = lib.hc_cluster_any_round(hs, R, int(self.now), self.words.ctypes.data, self.hbc_col.ctypes.data, self.beat.ctypes.data,
+                                          self.ae.ctypes.data, self.owner_col.ctypes.data, offered.ctypes.data)
+            assert rc == 0, f"host-compiled any-leader round: error {rc}"
+            self.owner = self.owner_col[:G].copy()
+            self.rows.append([n.drain_messages() for n in self.nodes])
+            return {}
+    return HostAnyLeaderCluster()

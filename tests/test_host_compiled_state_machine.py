@@ -238,3 +238,33 @@ def test_routed_failure_cluster_over_the_host_compiled_halves(R, percent, also):
         assert ora.delivered.tolist() == dev.delivered.tolist(), t
         assert [k.tobytes() for k in ora.kept] == [k.tobytes() for k in dev.kept], t
     assert ora.delivered.sum() > G // 10
+
+
+@pytest.mark.parametrize("R", [3, 5, 2])
+def test_the_devices_any_leader_round_on_the_host(R):
+    """The round of a cluster with per-partition leadership as the DEVICE runs it - k_cluster_claim, then every node's leader
+    half and follower half over the cluster-owned mailboxes (the owner / offered branches of the slow kernels' bodies: a
+    leader that is not the owner has no inbox and sends its Tick as rows, the own slot's word of an owned group is nobody's) -
+    compiled for the host, against the numpy statement of that round over oracle engines: dual leaders, whole groups
+    restarting, campaigns won through the rows.  Every column of every node after every round, the rows left for the host."""
+    from dense_node import AnyLeaderCluster
+    from host_compiled import host_any_leader_cluster
+    from josefine_amd.traces import any_failure_rows
+    from test_any_leader import spread_leaders
+    G, T = 90, 30
+    a, b = AnyLeaderCluster(oracle_engine, G, R, seed=7), host_any_leader_cluster(G, R, seed=7)
+    for cl in (a, b):
+        spread_leaders(cl.nodes, G, R, dual_every=7)
+    leader_of = np.arange(G) % R
+    failed = np.zeros(G, bool)
+    for t in range(T):
+        inj, failing = any_failure_rows(3, t, G, R, 4, leader_of, whole_group=(R == 3), skip=failed) if t >= 3 else ([None] * R, [])
+        failed[failing] = True
+        for cl in (a, b):
+            cl.round(np.ones(G, np.uint64), inject=inj)
+        assert np.array_equal(a.owner, b.owner), t
+        for n in range(R):
+            compare_snapshots(b.nodes[n], a.nodes[n], f"round {t} node {n}")
+        assert a.delivered.tolist() == b.delivered.tolist(), t
+    for n in range(R):
+        assert a.kept[n].tobytes() == b.kept[n].tobytes()
