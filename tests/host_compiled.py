@@ -21,9 +21,11 @@ CSRC = os.path.join(ROOT, "josefine_amd", "csrc")
 
 HIP_SHIM = r'''
 #pragma once
-// stand-in for <hip/hip_runtime.h> when the device headers are compiled for the host (tests/host_compiled.py).  ONE lane:
-// JG_BLOCK is 1, a ballot is the lane's own bit, a shuffle from another lane finds nothing - good for code whose lanes work
-// on their own (the general state machine, the slow kernels' list walks), NOT for the dense kernels' wave logic.
+// stand-in for <hip/hip_runtime.h> when the device headers are compiled for the host (tests/host_compiled.py).  ONE lane at
+// a time: a ballot is the lane's own bit at its own position in the wave, a shuffle from another lane finds nothing - good
+// for code whose lanes work on their own (the general state machine, the slow kernels' list walks with JG_BLOCK = 1, the
+// dense kernels' per-group logic with the lane where the group puts it), NOT for anything lanes do together (the
+// transport's LDS staging and sorts, the wave reductions of the counters - those are added up by the harness).
 #include <cstdint>
 #include <cstddef>
 #include <algorithm>
@@ -49,7 +51,7 @@ static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 static inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
 static inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
-static inline uint64_t __ballot(bool x) { return x ? 1ull : 0ull; }
+static inline uint64_t __ballot(bool x) { return (x ? 1ull : 0ull) << (threadIdx.x & 63u); }  // (the only active lane of its wave)
 template <class T> static inline T __shfl(T v, int, int = 64) { return v; }
 template <class T> static inline T __shfl_down(T, int, int = 64) { return T(0); }
 template <class T> static inline T __shfl_xor(T, int, int = 64) { return T(0); }
@@ -65,16 +67,10 @@ using std::max;
 using std::min;
 '''
 
-HARNESS = r'''
-#include <algorithm>
-#include <cstring>
-#include <numeric>
+HOST_H = r'''
+#pragma once
 #include <vector>
-#define JG_BLOCK 1
-#include "jg_kernels.h"   // (jg_device.h, jg_dense.h, jg_sparse.h: the slow leader kernel's body)
-#include "jg_follower.h"  // (... and the follower's)
-#include "jg_node.h"      // (jg_step_node's row passes: prefill, classify, route, fsm build)
-
+#include "jg_device.h"
 struct Host {
   JgDev d{};
   std::vector<uint64_t> term, commit, head, id_gen, run_hi, mlag, match_wide, hbt, win_lo, win_hi, win_next, blk_dec;
@@ -92,6 +88,20 @@ struct Host {
   std::vector<JgFaultRec> faults;
   int err = 0;
 };
+#define VIS extern "C" __attribute__((visibility("default")))
+'''
+
+HARNESS = r'''
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+#define JG_BLOCK 1
+#include "jg_kernels.h"   // (jg_device.h, jg_dense.h, jg_sparse.h: the slow leader kernel's body)
+#include "jg_follower.h"  // (... and the follower's)
+#include "jg_node.h"      // (jg_step_node's row passes: prefill, classify, route, fsm build)
+
+#include "host.h"
 
 extern "C" Host* hc_create(uint32_t G, uint32_t R, const uint32_t* node_ids, const uint8_t* self_slots, uint64_t seed, uint64_t group_base,
                            uint32_t flags, uint32_t hb, uint32_t el_min, uint32_t el_max) {
@@ -109,12 +119,11 @@ extern "C" Host* hc_create(uint32_t G, uint32_t R, const uint32_t* node_ids, con
   h->flags.assign(G, 0), d.flags = h->flags.data();
   h->cold_t.assign(G, uint4{}), h->cold_v.assign(G, uint4{}), d.cold.t = h->cold_t.data(), d.cold.v = h->cold_v.data();
   h->fvote.assign((size_t)JG_FOREIGN_VOTERS * G, 0), d.fvote_id = h->fvote.data();
-  d.blk_decisions = a64(h->blk_dec, 1);
   h->fq.assign((size_t)8 * G + 4096, JgFaultRec{}), d.fault_q = h->fq.data(), d.fault_q_cap = (uint32_t)h->fq.size();
   d.err = &h->status[0], d.irregular_seen = &h->status[1], d.deferred_seen = &h->status[2], d.fault_q_n = &h->status[3];
   d.xq_n = &h->status[4], d.cold_seen = &h->status[5];
   d.xq = nullptr, d.xq_cap = 0;
-  h->blk_dec.assign(4096, 0), d.blk_decisions = h->blk_dec.data();
+  h->blk_dec.assign(std::max<size_t>(4096, G / 64 + 2), 0), d.blk_decisions = h->blk_dec.data();
   h->defer_bits.assign((G + 63) / 64, 0), d.defer_bits = h->defer_bits.data();
   h->fdefer_bits.assign(2 * ((G + 63) / 64), 0), d.fdefer_bits = h->fdefer_bits.data();
   d.slow_cap = G + 64;
@@ -260,20 +269,29 @@ static void collect_after_dense(Host* h) {
 }
 // jg_step_dense_leader with EVERY healthy leader handed to k_dense_slow<true> (the dense kernel's part for the others:
 // an empty outbox row); answers: [R][G] JG_ANSWER words or null, o_beat / o_ae: null = no Tick
-extern "C" int hc_leader_half(Host* h, uint64_t now, const uint64_t* answers, const uint64_t* hbr_commit, jg_leader_beat* o_beat, uint64_t* o_ae) {
+typedef int (*FastLeader)(Host*, const uint64_t* acks, uint32_t seq, int us, const JgLeaderNode* nd, int any);
+typedef int (*FastFollower)(Host*, const JgFollowerArgs* a, int any);
+static const uint64_t g_ones[2] = {~0ull, ~0ull};  // (an absent input column is a stride-0 view of one all-ones word)
+extern "C" int hc_leader_half(Host* h, uint64_t now, const uint64_t* answers, const uint64_t* hbr_commit, jg_leader_beat* o_beat, uint64_t* o_ae,
+                              FastLeader fast, int us) {
   JgDev& d = h->d;
   h->seq++;
   d.xq = h->xq.data(), d.xq_cap = (uint32_t)h->xq.size();
   JgLeaderNode nd{};
   nd.hbr_commit = hbr_commit, nd.packed = 1, nd.now = now, nd.ack_stride = answers ? 1 : 0;
   nd.o_beat = o_beat, nd.o_ae = o_ae;
-  for (uint32_t g = 0; g < d.G; g++) {
-    const uint32_t f = d.flags[g];
-    if (o_beat) {
-      o_beat[g] = jg_leader_beat{0, JG_NO_ACK};
-      for (uint32_t r = 0; r < d.R; r++) o_ae[(size_t)r * d.G + g] = JG_NO_ACK;
+  if (fast) {  // the dense kernel itself, a group at a time; what it cannot serve it marks for the slow body below
+    const int rc = fast(h, answers ? answers : g_ones, h->seq, us, &nd, 0);
+    if (rc) return rc;
+  } else {
+    for (uint32_t g = 0; g < d.G; g++) {
+      const uint32_t f = d.flags[g];
+      if (o_beat) {
+        o_beat[g] = jg_leader_beat{0, JG_NO_ACK};
+        for (uint32_t r = 0; r < d.R; r++) o_ae[(size_t)r * d.G + g] = JG_NO_ACK;
+      }
+      if ((f & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER) d.defer_bits[g >> 6] |= 1ull << (g & 63u);
     }
-    if ((f & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER) d.defer_bits[g >> 6] |= 1ull << (g & 63u);
   }
   gridDim.x = JG_SHARDS;
   for (uint32_t b = 0; b < JG_SHARDS; b++) {
@@ -287,16 +305,21 @@ extern "C" int hc_leader_half(Host* h, uint64_t now, const uint64_t* answers, co
 }
 // jg_step_dense_follower with EVERY live group handed to k_follower_slow
 extern "C" int hc_follower_half(Host* h, uint64_t now, const jg_leader_beat* beat, const uint64_t* ae, const uint32_t* leader, uint32_t leader_id,
-                                int tick, uint64_t* o_answer, uint64_t* o_hbc) {
+                                int tick, uint64_t* o_answer, uint64_t* o_hbc, FastFollower fast) {
   JgDev& d = h->d;
   h->seq++;
   d.xq = h->xq.data(), d.xq_cap = (uint32_t)h->xq.size();
   JgFollowerArgs a{};
   a.leader = leader, a.leader_id = leader_id, a.beat = beat, a.ae = ae, a.o_answer = o_answer, a.o_hbc = o_hbc;
   a.now = now, a.seq = h->seq, a.tick = tick ? 1 : 0;
-  for (uint32_t g = 0; g < d.G; g++) {
-    o_answer[g] = JG_NO_ACK;
-    if (!(d.flags[g] & JGF_FAULT_MASK)) d.fdefer_bits[g >> 6] |= 1ull << (g & 63u);
+  if (fast) {
+    const int rc = fast(h, &a, 0);
+    if (rc) return rc;
+  } else {
+    for (uint32_t g = 0; g < d.G; g++) {
+      o_answer[g] = JG_NO_ACK;
+      if (!(d.flags[g] & JGF_FAULT_MASK)) d.fdefer_bits[g >> 6] |= 1ull << (g & 63u);
+    }
   }
   gridDim.x = JG_SHARDS;
   for (uint32_t b = 0; b < JG_SHARDS; b++) {
@@ -321,7 +344,8 @@ struct NodeScratch {
 extern "C" int hc_step_node(Host* h, uint32_t n, const uint8_t* kind, const uint32_t* group, const uint32_t* from, const uint64_t* term,
                             const uint64_t* id, const uint64_t* aux, const uint8_t* flag, uint64_t nb, const uint64_t* blk_id,
                             const uint64_t* blk_next, uint64_t now, uint32_t flags, int uniform_self, uint32_t kinds_seen,
-                            jg_leader_beat* o_beat, uint64_t* o_ae, uint64_t* o_answer, uint64_t* o_hbc, uint64_t* n_general) {
+                            jg_leader_beat* o_beat, uint64_t* o_ae, uint64_t* o_answer, uint64_t* o_hbc, uint64_t* n_general,
+                            FastLeader fast_l, FastFollower fast_f) {
   JgDev& d = h->d;
   const uint32_t G = d.G, R = d.R;
   const uint32_t halves = flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF);
@@ -378,12 +402,19 @@ extern "C" int hc_step_node(Host* h, uint32_t n, const uint8_t* kind, const uint
     ln.hbr_commit = c.hbr_commit, ln.packed = 1, ln.ack_stride = 1, ln.now = now;
     if (tick) ln.o_beat = o_beat, ln.o_ae = o_ae;
     ln.fsm_delta = c.fsm_delta, ln.fsm_prev = c.fsm_prev, ln.fsm_mid = c.fsm_mid, ln.arr = c.arr, ln.col_mask = 0;
-    for (uint32_t g = 0; g < G; g++) {
-      if (tick) {
-        o_beat[g] = jg_leader_beat{0, JG_NO_ACK};
-        for (uint32_t r = 0; r < R; r++) o_ae[(size_t)r * G + g] = JG_NO_ACK;
+    if (fast_l) {
+      gridDim.x = 1;
+      const int rc = fast_l(h, c.answers, h->seq, uniform_self, &ln, 0);
+      if (rc) return rc;
+      gridDim.x = JG_SHARDS;
+    } else {
+      for (uint32_t g = 0; g < G; g++) {
+        if (tick) {
+          o_beat[g] = jg_leader_beat{0, JG_NO_ACK};
+          for (uint32_t r = 0; r < R; r++) o_ae[(size_t)r * G + g] = JG_NO_ACK;
+        }
+        if ((d.flags[g] & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER) d.defer_bits[g >> 6] |= 1ull << (g & 63u);
       }
-      if ((d.flags[g] & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER) d.defer_bits[g >> 6] |= 1ull << (g & 63u);
     }
     for (uint32_t b = 0; b < JG_SHARDS; b++) {
       blockIdx.x = b;
@@ -395,9 +426,16 @@ extern "C" int hc_step_node(Host* h, uint32_t n, const uint8_t* kind, const uint
     JgFollowerArgs a{};
     a.leader = c.f_leader, a.beat = c.f_beat, a.ae = c.f_ae, a.o_answer = o_answer, a.o_hbc = o_hbc;
     a.now = now, a.seq = h->seq, a.tick = tick ? 1 : 0, a.fsm_delta = c.fsm_delta, a.fsm_prev = c.fsm_prev;
-    for (uint32_t g = 0; g < G; g++) {
-      o_answer[g] = JG_NO_ACK;
-      if (!(d.flags[g] & JGF_FAULT_MASK)) d.fdefer_bits[g >> 6] |= 1ull << (g & 63u);
+    if (fast_f) {
+      gridDim.x = 1;
+      const int rc = fast_f(h, &a, 0);
+      if (rc) return rc;
+      gridDim.x = JG_SHARDS;
+    } else {
+      for (uint32_t g = 0; g < G; g++) {
+        o_answer[g] = JG_NO_ACK;
+        if (!(d.flags[g] & JGF_FAULT_MASK)) d.fdefer_bits[g >> 6] |= 1ull << (g & 63u);
+      }
     }
     for (uint32_t b = 0; b < JG_SHARDS; b++) {
       blockIdx.x = b;
@@ -424,7 +462,7 @@ extern "C" int hc_step_node(Host* h, uint32_t n, const uint8_t* kind, const uint
 // claim kernel as it is, every node's leader half and follower half through the slow kernels' bodies with the cluster's
 // mailboxes (owner[g] / offered[g]: JgLeaderNode, JgFollowerArgs) - the any-leader branches of those bodies on the host
 extern "C" int hc_cluster_any_round(Host** hs, uint32_t R, uint64_t now, uint64_t* acks, uint64_t* hbr_commit, jg_leader_beat* o_beat,
-                                    uint64_t* o_ae, uint8_t* owner, const uint64_t* offered) {
+                                    uint64_t* o_ae, uint8_t* owner, const uint64_t* offered, FastLeader fast_l, FastFollower fast_f) {
   const uint32_t G = hs[0]->d.G;
   JgClaimArgs ca{};
   ca.R = R, ca.G = G, ca.owner = owner;
@@ -439,15 +477,20 @@ extern "C" int hc_cluster_any_round(Host** hs, uint32_t R, uint64_t now, uint64_
     JgLeaderNode nd{};
     nd.ack_stride = 1, nd.packed = 1, nd.hbr_commit = hbr_commit, nd.o_beat = o_beat, nd.o_ae = o_ae, nd.now = now;
     nd.owner = owner, nd.offered = offered;
-    for (uint32_t g = 0; g < G; g++)
-      if ((d.flags[g] & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER) {
-        d.defer_bits[g >> 6] |= 1ull << (g & 63u);
-        if (owner[g] == r) {  // (what the dense half does before it hands an owned group over: jg_dense_outbox_none)
-          o_beat[g] = jg_leader_beat{0, JG_NO_ACK};
-          for (uint32_t q = 0; q < R; q++)
-            if (q != r) o_ae[(size_t)q * G + g] = JG_NO_ACK;
+    if (fast_l) {  // k_leader_node_tick_any's own per-group logic first
+      const int rc = fast_l(h, acks, h->seq - 1, (int)r, &nd, 1);
+      if (rc) return rc;
+    } else {
+      for (uint32_t g = 0; g < G; g++)
+        if ((d.flags[g] & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER) {
+          d.defer_bits[g >> 6] |= 1ull << (g & 63u);
+          if (owner[g] == r) {  // (what the dense half does before it hands an owned group over: jg_dense_outbox_none)
+            o_beat[g] = jg_leader_beat{0, JG_NO_ACK};
+            for (uint32_t q = 0; q < R; q++)
+              if (q != r) o_ae[(size_t)q * G + g] = JG_NO_ACK;
+          }
         }
-      }
+    }
     gridDim.x = JG_SHARDS;
     for (uint32_t b = 0; b < JG_SHARDS; b++) {
       blockIdx.x = b;
@@ -465,12 +508,17 @@ extern "C" int hc_cluster_any_round(Host** hs, uint32_t R, uint64_t now, uint64_
     JgFollowerArgs a{};
     a.beat = o_beat, a.ae = o_ae + (size_t)r * G, a.o_answer = acks + (size_t)r * G, a.o_hbc = hbr_commit + (size_t)r * G;
     a.now = now, a.seq = h->seq, a.tick = 1, a.owner = owner, a.self_slot = r;
-    for (uint32_t g = 0; g < G; g++) {
-      const uint32_t f = d.flags[g];
-      const bool own_led = (f & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER && owner[g] == r;
-      if (own_led) continue;  // (the own slot's word of a group this node owns is nobody's: the dense half leaves it alone)
-      if (f & JGF_FAULT_MASK) a.o_answer[g] = JG_NO_ACK;
-      else d.fdefer_bits[g >> 6] |= 1ull << (g & 63u);
+    if (fast_f) {  // k_follower_tick_dense_any's
+      const int rc = fast_f(h, &a, 1);
+      if (rc) return rc;
+    } else {
+      for (uint32_t g = 0; g < G; g++) {
+        const uint32_t f = d.flags[g];
+        const bool own_led = (f & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER && owner[g] == r;
+        if (own_led) continue;  // (the own slot's word of a group this node owns is nobody's: the dense half leaves it alone)
+        if (f & JGF_FAULT_MASK) a.o_answer[g] = JG_NO_ACK;
+        else d.fdefer_bits[g >> 6] |= 1ull << (g & 63u);
+      }
     }
     gridDim.x = JG_SHARDS;
     for (uint32_t b = 0; b < JG_SHARDS; b++) {
@@ -484,9 +532,92 @@ extern "C" int hc_cluster_any_round(Host** hs, uint32_t R, uint64_t now, uint64_
   }
   return 0;
 }
+
+// jg_step_dense_acks: the ack-only tick - the headline kernel's per-group body (its in-kernel general path over LDS included),
+// k_dense_slow<false> for the leaders it hands over (chains that are not in FAST form)
+extern "C" int hc_dense_acks(Host* h, const uint64_t* acks, FastLeader fast, int us) {
+  JgDev& d = h->d;
+  h->seq++;
+  if (fast) {
+    const int rc = fast(h, acks, h->seq, us, nullptr, 0);
+    if (rc) return rc;
+  } else {
+    for (uint32_t g = 0; g < d.G; g++)
+      if ((d.flags[g] & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_LEADER) d.defer_bits[g >> 6] |= 1ull << (g & 63u);
+  }
+  JgLeaderNode none{};
+  gridDim.x = JG_SHARDS;
+  for (uint32_t b = 0; b < JG_SHARDS; b++) {
+    blockIdx.x = b;
+    jg_dense_slow_body<false>(d, acks, 1, (size_t)d.R * d.G, h->seq, none, false);
+  }
+  blockIdx.x = 0, gridDim.x = 1;
+  collect_after_dense(h);
+  return (int)h->status[0];
+}
+'''
+
+FAST = r'''
+// the dense kernels' per-group logic on the host: JG_BLOCK = 64, one group per call with the lane where the group puts it
+// (blockIdx.x = g / 64, threadIdx.x = g % 64), so that the deferral bitmaps and the counters' ballots come out as on the
+// device; the wave reductions at the kernels' ends (jg_wave_count) are replaced by adding up what the bodies return
+#define JG_BLOCK 64
+#include "jg_dense.h"
+#include "jg_follower.h"
+#include "host.h"
+
+template <int R>
+static void leader_group(Host* h, const uint64_t* acks, uint32_t seq, int us, const JgLeaderNode* nd, int any) {
+  const JgDev& d = h->d;
+  const JgDenseHot hot = jg_dense_hot_of(d);
+  static uint64_t sm[2 * R][JG_BLOCK];
+  JgDecCount dec;
+  if (any) dec = jg_dense_tick_body<R, true, true, true, false, true>(hot, &d, acks, seq, (uint32_t)us, *nd, nullptr);
+  else if (nd && nd->fsm_delta) dec = us >= 0 ? jg_dense_tick_body<R, true, true, true, true>(hot, &d, acks, seq, (uint32_t)us, *nd, nullptr)
+                                              : jg_dense_tick_body<R, false, true, true, true>(hot, &d, acks, seq, 0, *nd, nullptr);
+  else if (nd) dec = us >= 0 ? jg_dense_tick_body<R, true, true, true, false>(hot, &d, acks, seq, (uint32_t)us, *nd, nullptr)
+                             : jg_dense_tick_body<R, false, true, true, false>(hot, &d, acks, seq, 0, *nd, nullptr);
+  else {
+    JgLeaderNode none{};
+    dec = us >= 0 ? jg_dense_tick_body<R, true, false, false>(hot, &d, acks, seq, (uint32_t)us, none, sm)
+                  : jg_dense_tick_body<R, false, false, false>(hot, &d, acks, seq, 0, none, sm);
+  }
+  h->decisions += dec.lane;
+}
+VIS int hf_leader_tick(Host* h, const uint64_t* acks, uint32_t seq, int us, const JgLeaderNode* nd, int any) {
+  const uint32_t G = h->d.G;
+  gridDim.x = (G + 63) / 64;
+  for (uint32_t g = 0; g < G; g++) {
+    blockIdx.x = g >> 6, threadIdx.x = g & 63u;
+    switch (h->d.R) {
+      case 1: leader_group<1>(h, acks, seq, us, nd, any); break;
+      case 2: leader_group<2>(h, acks, seq, us, nd, any); break;
+      case 3: leader_group<3>(h, acks, seq, us, nd, any); break;
+      case 4: leader_group<4>(h, acks, seq, us, nd, any); break;
+      case 5: leader_group<5>(h, acks, seq, us, nd, any); break;
+      case 6: leader_group<6>(h, acks, seq, us, nd, any); break;
+      case 7: leader_group<7>(h, acks, seq, us, nd, any); break;
+      default: leader_group<8>(h, acks, seq, us, nd, any); break;
+    }
+  }
+  blockIdx.x = 0, threadIdx.x = 0, gridDim.x = 1;
+  return (int)h->status[0];
+}
+VIS int hf_follower_tick(Host* h, const JgFollowerArgs* a, int any) {
+  const uint32_t G = h->d.G;
+  gridDim.x = (G + 63) / 64;
+  for (uint32_t g = 0; g < G; g++) {
+    blockIdx.x = g >> 6, threadIdx.x = g & 63u;
+    if (any) jg_follower_fast_body<true>(h->d, *a);
+    else jg_follower_fast_body<false>(h->d, *a);
+  }
+  blockIdx.x = 0, threadIdx.x = 0, gridDim.x = 1;
+  return (int)h->status[0];
+}
 '''
 
 _lib = None
+_fast = None
 
 
 def _patched_sources():
@@ -529,9 +660,16 @@ def build():
     os.makedirs(os.path.join(tmp, "shim", "hip"))
     open(os.path.join(tmp, "shim", "hip", "hip_runtime.h"), "w").write(HIP_SHIM)
     cpp, so = os.path.join(tmp, "host_compiled.cpp"), os.path.join(tmp, "libhost_compiled.so")
+    open(os.path.join(tmp, "host.h"), "w").write(HOST_H)
     open(cpp, "w").write(HARNESS.replace("@INIT_BODY@", init_body))
-    subprocess.run(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-Wno-unused-function", f"-I{os.path.join(tmp, 'shim')}", f"-I{src}",
-                    "-o", so, cpp], check=True)
+    cc = ["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-Wno-unused-function", "-Wl,-Bsymbolic", f"-I{os.path.join(tmp, 'shim')}", f"-I{src}", f"-I{tmp}"]
+    subprocess.run(cc + ["-o", so, cpp], check=True)
+    # the dense kernels' per-group logic: a library of its own (JG_BLOCK = 64 there, 1 here: nothing of the two may be merged)
+    global _fast
+    cpp2, so2 = os.path.join(tmp, "fast.cpp"), os.path.join(tmp, "libhost_fast.so")
+    open(cpp2, "w").write(FAST)
+    subprocess.run(cc + ["-fvisibility=hidden", "-o", so2, cpp2], check=True)
+    _fast = C.CDLL(so2)
     lib = C.CDLL(so)
     lib.hc_create.restype = C.c_void_p
     lib.hc_create.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -542,17 +680,20 @@ def build():
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.hc_counters.argtypes = [C.c_void_p, C.c_void_p]
     lib.hc_read.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
-    lib.hc_leader_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.hc_follower_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
-    lib.hc_cluster_any_round.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 6
+    lib.hc_leader_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.hc_follower_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hc_dense_acks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.hc_cluster_any_round.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 8
     lib.hc_step_node.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32] + \
-        [C.c_void_p] * 5
+        [C.c_void_p] * 7
     _lib = lib
     return lib
 
 
 class HostCompiled:
     """the subset of BatchedRaft's interface the sparse parity suites use, over the host-compiled state machine"""
+
+    fast = True  # the dense halves: the dense kernels' own per-group logic first, the slow bodies for what it defers (False: all slow)
 
     def __init__(self, n_groups, n_replicas=1, node_ids=None, self_slots=None, seed=0, device_id=0, group_base=0, flags=0,
                  heartbeat_timeout_ms=100, election_timeout_ms=(500, 1000)):
@@ -629,7 +770,25 @@ class HostCompiled:
         n = self.G - g0 if n is None else n
         return out[g0:g0 + n]
 
-    # -- the dense halves, every group through the slow kernels' bodies (the interface of BatchedRaft's column forms) --
+    def _us(self):
+        slots = self.read("self_slot")
+        return int(slots[0]) if (slots == slots[0]).all() else -1
+
+    def _fast_leader(self):
+        return C.cast(_fast.hf_leader_tick, C.c_void_p) if self.fast else None
+
+    def _fast_follower(self):
+        return C.cast(_fast.hf_follower_tick, C.c_void_p) if self.fast else None
+
+    # -- the dense halves: the dense kernels' per-group logic, then the slow kernels' bodies (the interface of BatchedRaft's column forms) --
+    def step_dense_acks(self, acks):
+        """jg_step_dense_acks: the ack-only leader tick from a host [R, G] array"""
+        assert not self._pending
+        a = np.ascontiguousarray(acks, np.uint64)
+        assert a.shape == (self.R, self.G)
+        rc = self.lib.hc_dense_acks(self._h, a.ctypes.data, self._fast_leader(), self._us())
+        assert rc == 0, f"host-compiled ack-only tick: error {rc}"
+
     def step_dense_leader(self, now_ms=0, acks=None, hbr_has=None, hbr_commit=None, tick=True):
         assert not self._pending
         G, R = self.G, self.R
@@ -644,7 +803,7 @@ class HostCompiled:
         beat = np.zeros((G, 2), np.uint64)
         ae = np.full((R, G), capi.NO_ACK, np.uint64)
         rc = self.lib.hc_leader_half(self._h, int(now_ms), None if ans is None else ans.ctypes.data, None if hbc is None else hbc.ctypes.data,
-                                     beat.ctypes.data if tick else None, ae.ctypes.data if tick else None)
+                                     beat.ctypes.data if tick else None, ae.ctypes.data if tick else None, self._fast_leader(), self._us())
         assert rc == 0, f"host-compiled leader half: error {rc}"
         if not tick:
             return None
@@ -662,7 +821,7 @@ class HostCompiled:
         ans = np.zeros(G, np.uint64)
         hbc = np.zeros(G, np.uint64)
         rc = self.lib.hc_follower_half(self._h, int(now_ms), beat.ctypes.data, ae.ctypes.data, None if ld is None else ld.ctypes.data, int(leader_id),
-                                       1 if tick else 0, ans.ctypes.data, hbc.ctypes.data)
+                                       1 if tick else 0, ans.ctypes.data, hbc.ctypes.data, self._fast_follower())
         assert rc == 0, f"host-compiled follower half: error {rc}"
         ack_head, hb_has = capi.unpack_answers(ans)
         return {"ack_head": ack_head, "hb_commit": np.where(hb_has != capi.HB_NONE, hbc, 0).astype(np.uint64), "hb_has": hb_has}
@@ -695,7 +854,8 @@ class HostCompiled:
         a = {k: pad(cols[k], cols[k].dtype) for k in cols}
         rc = self.lib.hc_step_node(self._h, n, a["kind"].ctypes.data, a["group"].ctypes.data, a["from_"].ctypes.data, a["term"].ctypes.data,
                                    a["id"].ctypes.data, a["aux"].ctypes.data, a["flag"].ctypes.data, nb, a["blk_id"].ctypes.data, a["blk_next"].ctypes.data,
-                                   int(now_ms), flags, us, seen, beat.ctypes.data, ae.ctypes.data, ans.ctypes.data, hbc.ctypes.data, C.byref(ngen))
+                                   int(now_ms), flags, us, seen, beat.ctypes.data, ae.ctypes.data, ans.ctypes.data, hbc.ctypes.data, C.byref(ngen),
+                                   self._fast_leader(), self._fast_follower())
         assert rc == 0, f"host-compiled node step: error {rc}"
         if between is not None:
             between()
@@ -729,7 +889,8 @@ def host_any_leader_cluster(G, R, seed=3):
             lib = self.nodes[0].lib
             hs = (C.c_void_p * R)(*[n._h for n in self.nodes])
             rc = lib.hc_cluster_any_round(hs, R, int(self.now), self.words.ctypes.data, self.hbc_col.ctypes.data, self.beat.ctypes.data,
-                                          self.ae.ctypes.data, self.owner_col.ctypes.data, offered.ctypes.data)
+                                          self.ae.ctypes.data, self.owner_col.ctypes.data, offered.ctypes.data,
+                                          self.nodes[0]._fast_leader(), self.nodes[0]._fast_follower())
             assert rc == 0, f"host-compiled any-leader round: error {rc}"
             self.owner = self.owner_col[:G].copy()
             self.rows.append([n.drain_messages() for n in self.nodes])

@@ -17,6 +17,14 @@ def pair(G, R, **kw):
     return HostCompiled(G, R, **kw), oracle_engine(G, R, **kw)
 
 
+@pytest.fixture(autouse=True, params=["dense kernels' own logic, then the slow bodies", "slow bodies only"])
+def dense_path(request, monkeypatch):
+    """every test twice: with the dense halves served the way the device serves them - the dense kernels' per-group logic
+    (jg_dense_tick_body, jg_follower_fast_body: one group per call, the lane where the group puts it), the slow kernels'
+    bodies for what they defer - and with every group handed to the slow bodies"""
+    monkeypatch.setattr(HostCompiled, "fast", request.param.startswith("dense"))
+
+
 @pytest.mark.parametrize("R", [1, 2, 3, 5, 8])
 def test_blind_command_streams(R):
     G, steps, rows = 192, 120, 800
@@ -268,3 +276,61 @@ def test_the_devices_any_leader_round_on_the_host(R):
         assert a.delivered.tolist() == b.delivered.tolist(), t
     for n in range(R):
         assert a.kept[n].tobytes() == b.kept[n].tobytes()
+
+
+def test_restarted_leader_scenario_through_the_dense_kernels_own_logic():
+    """tests/test_dense_node.py's restarted-leader script (a re-elected leader whose head sits below the top of its run counts
+    acknowledgements above its head, records one above the top, dies when the majority rests on it) over the host-compiled
+    leader half: the node tick's own per-group logic serves such a leader in lag space (fast) / the slow body alone does."""
+    from test_dense_node import _restarted_leader_script
+    _restarted_leader_script(128, 3, seed=4, make=HostCompiled)
+
+
+def test_follower_half_at_the_election_timers_boundary():
+    """follower.rs:121-128: the timer fires when MORE than the timeout has passed - the dense follower half's own test, at the
+    boundary, one millisecond before and after it"""
+    G, R = 192, 3
+    dev, ora = pair(G, R, seed=11, flags=capi.CFG_SEPARATE_COMMIT_KEY, election_timeout_ms=(300, 600))
+    eto = ora.read("election_timeout").astype(np.int64)
+    et = ora.read("election_time").astype(np.int64)
+    quiet = dict(term=np.zeros(G, np.uint64), hb_commit=np.full(G, capi.NO_ACK, np.uint64), ae_from=np.zeros(G, np.uint64),
+                 ae_n=np.full(G, capi.AE_NONE, np.uint8), leader_id=2)
+    for delta in (-1, 0, 1):
+        # every group ticked at ITS boundary + delta needs its own time: walk the distinct boundaries
+        for t in np.unique(et + eto)[:24]:
+            outs = [e.step_dense_follower(int(t + delta), **quiet, tick=True) for e in (dev, ora)]
+            for k in outs[0]:
+                assert np.array_equal(outs[0][k], outs[1][k]), (delta, t, k)
+            compare_drains(dev, ora, f"tick at {t}{delta:+d}")
+            compare_snapshots(dev, ora, f"tick at {t}{delta:+d}")
+    assert (ora.read("role") == capi.ROLE_CANDIDATE).any() and (ora.read("role") == capi.ROLE_FOLLOWER).any()
+
+
+@pytest.mark.parametrize("R,G,mode,ticks,layout", [(3, 1200, 1, 80, "slot0"), (5, 1200, 1, 50, "last"), (5, 1200, 0, 40, "mixed"), (1, 300, 1, 20, "slot0"),
+                                                   (2, 500, 1, 30, "mixed"), (4, 500, 1, 30, "last"), (8, 500, 1, 30, "mixed"), (3, 1001, 1, 20, "mixed")])
+def test_the_headline_kernels_tick_under_the_synthetic_ack_streams(R, G, mode, ticks, layout):
+    """jg_step_dense_acks on the host: k_leader_tick_dense's per-group body - the tick in lag space, its in-kernel general
+    path over LDS, the hand-over of leaders whose chain is not in FAST form - under the generator's streams (mode 0: the
+    steady state of the bench, mode 1: the ragged stream of configs[1]: drops, duplicates, 0-2 appends, acknowledgements above
+    the head), every own-slot layout, against the oracle after every tick."""
+    from parity import synth_tick_host
+    if not HostCompiled.fast:
+        pytest.skip("the ack-only tick has no all-slow form worth a second run")
+    slots = None if layout == "slot0" else np.full(G, R - 1, np.uint8) if layout == "last" else (np.arange(G) % R).astype(np.uint8)
+    dev, ora = pair(G, R, seed=0x6A6F7365 + R, self_slots=slots)
+    for e in (dev, ora):
+        elect_all(e)
+    sim = np.zeros((R, G), np.uint64)
+    fields = ("commit", "head", "match", "repl_state", "fault", "id_gen", "role", "term")
+    for t in range(ticks):
+        acks = synth_tick_host(ora, mode, t, sim)
+        dev.step_dense_acks(acks)
+        ora.step_dense_acks(acks)
+        for name in fields:
+            if name == "match":
+                for r in range(R):
+                    assert np.array_equal(dev.read("match", r), ora.read("match", r)), (t, r)
+            else:
+                assert np.array_equal(dev.read(name), ora.read(name)), (t, name)
+        compare_drains(dev, ora, f"dense tick {t}")
+    assert dev.counters()["decisions"] == ora.counters()["decisions"] and int(ora.read("commit").max()) > 0
