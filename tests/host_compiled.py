@@ -555,6 +555,31 @@ extern "C" int hc_dense_acks(Host* h, const uint64_t* acks, FastLeader fast, int
   collect_after_dense(h);
   return (int)h->status[0];
 }
+
+// jg_chain_compact: one lane per tree (k_chain_compact as it is)
+extern "C" void hc_chain_compact(size_t n_trees, const uint64_t* off, const uint64_t* ids, const uint64_t* nexts, const uint64_t* commits, uint8_t* removed) {
+  blockIdx.x = 0, threadIdx.x = 0, blockDim.x = 1, gridDim.x = 1;
+  k_chain_compact(n_trees, off, ids, nexts, commits, removed);
+}
+// jg_step_dense_acks_device_n: T ticks per launch - the T-tick kernel's per-group body (state in registers across the ticks),
+// k_dense_slow<false> replaying all T ticks for what it hands over
+typedef int (*FastTicks)(Host*, const uint64_t* acks, uint32_t n_ticks, uint32_t seq0, int us);
+extern "C" int hc_dense_acks_n(Host* h, const uint64_t* acks, uint32_t n_ticks, FastTicks fast, int us) {
+  JgDev& d = h->d;
+  h->seq++;
+  const int rc = fast(h, acks, n_ticks, h->seq, us);
+  if (rc) return rc;
+  JgLeaderNode none{};
+  gridDim.x = JG_SHARDS;
+  for (uint32_t b = 0; b < JG_SHARDS; b++) {
+    blockIdx.x = b;
+    jg_dense_slow_body<false>(d, acks, n_ticks, (size_t)d.R * d.G, h->seq, none, false);
+  }
+  blockIdx.x = 0, gridDim.x = 1;
+  collect_after_dense(h);
+  h->seq += n_ticks - 1;
+  return (int)h->status[0];
+}
 '''
 
 FAST = r'''
@@ -598,6 +623,32 @@ VIS int hf_leader_tick(Host* h, const uint64_t* acks, uint32_t seq, int us, cons
       case 6: leader_group<6>(h, acks, seq, us, nd, any); break;
       case 7: leader_group<7>(h, acks, seq, us, nd, any); break;
       default: leader_group<8>(h, acks, seq, us, nd, any); break;
+    }
+  }
+  blockIdx.x = 0, threadIdx.x = 0, gridDim.x = 1;
+  return (int)h->status[0];
+}
+
+template <int R>
+static void ticks_group(Host* h, const uint64_t* acks, uint32_t n_ticks, uint32_t seq0, int us) {
+  const size_t stride = (size_t)h->d.R * h->d.G;
+  h->decisions += us >= 0 ? jg_dense_ticks_body<R, true>(h->d, acks, n_ticks, stride, seq0, (uint32_t)us)
+                          : jg_dense_ticks_body<R, false>(h->d, acks, n_ticks, stride, seq0, 0);
+}
+VIS int hf_leader_ticks(Host* h, const uint64_t* acks, uint32_t n_ticks, uint32_t seq0, int us) {
+  const uint32_t G = h->d.G;
+  gridDim.x = (G + 63) / 64;
+  for (uint32_t g = 0; g < G; g++) {
+    blockIdx.x = g >> 6, threadIdx.x = g & 63u;
+    switch (h->d.R) {
+      case 1: ticks_group<1>(h, acks, n_ticks, seq0, us); break;
+      case 2: ticks_group<2>(h, acks, n_ticks, seq0, us); break;
+      case 3: ticks_group<3>(h, acks, n_ticks, seq0, us); break;
+      case 4: ticks_group<4>(h, acks, n_ticks, seq0, us); break;
+      case 5: ticks_group<5>(h, acks, n_ticks, seq0, us); break;
+      case 6: ticks_group<6>(h, acks, n_ticks, seq0, us); break;
+      case 7: ticks_group<7>(h, acks, n_ticks, seq0, us); break;
+      default: ticks_group<8>(h, acks, n_ticks, seq0, us); break;
     }
   }
   blockIdx.x = 0, threadIdx.x = 0, gridDim.x = 1;
@@ -683,6 +734,8 @@ def build():
     lib.hc_leader_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.hc_follower_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hc_dense_acks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.hc_dense_acks_n.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+    lib.hc_chain_compact.argtypes = [C.c_size_t] + [C.c_void_p] * 5
     lib.hc_cluster_any_round.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 8
     lib.hc_step_node.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32] + \
         [C.c_void_p] * 7
@@ -788,6 +841,27 @@ class HostCompiled:
         assert a.shape == (self.R, self.G)
         rc = self.lib.hc_dense_acks(self._h, a.ctypes.data, self._fast_leader(), self._us())
         assert rc == 0, f"host-compiled ack-only tick: error {rc}"
+
+    def step_dense_acks_n(self, acks):
+        """jg_step_dense_acks_device_n: T consecutive ticks from a host [T, R, G] array, state read and written once"""
+        assert not self._pending
+        a = np.ascontiguousarray(acks, np.uint64)
+        assert a.ndim == 3 and a.shape[1:] == (self.R, self.G)
+        rc = self.lib.hc_dense_acks_n(self._h, a.ctypes.data, a.shape[0], C.cast(_fast.hf_leader_ticks, C.c_void_p), self._us())
+        assert rc == 0, f"host-compiled T-tick launch: error {rc}"
+
+    def chain_compact(self, trees):
+        trees = list(trees)
+        off = np.zeros(len(trees) + 1, np.uint64)
+        for i, (blocks, _) in enumerate(trees):
+            off[i + 1] = off[i] + len(blocks)
+        ids = np.ascontiguousarray(np.array([b[0] for t in trees for b in t[0]], dtype=np.uint64))
+        nexts = np.ascontiguousarray(np.array([b[1] for t in trees for b in t[0]], dtype=np.uint64))
+        commits = np.array([t[1] for t in trees], dtype=np.uint64)
+        removed = np.zeros(max(int(off[-1]), 1), np.uint8)
+        self.lib.hc_chain_compact(len(trees), off.ctypes.data, ids.ctypes.data if len(ids) else None, nexts.ctypes.data if len(nexts) else None,
+                                  commits.ctypes.data, removed.ctypes.data)
+        return [removed[int(off[i]):int(off[i + 1])].copy() for i in range(len(trees))]
 
     def step_dense_leader(self, now_ms=0, acks=None, hbr_has=None, hbr_commit=None, tick=True):
         assert not self._pending

@@ -334,3 +334,55 @@ def test_the_headline_kernels_tick_under_the_synthetic_ack_streams(R, G, mode, t
                 assert np.array_equal(dev.read(name), ora.read(name)), (t, name)
         compare_drains(dev, ora, f"dense tick {t}")
     assert dev.counters()["decisions"] == ora.counters()["decisions"] and int(ora.read("commit").max()) > 0
+
+
+def test_chain_compact_walk():
+    """k_chain_compact (one lane per tree) on random forests against the oracle's Chain::compact walk (chain.rs:239-253, Q7)"""
+    rng = np.random.default_rng(377)
+    dev, ora = pair(1, 1)
+    trees = []
+    for _ in range(300):
+        n = int(rng.integers(0, 40))
+        ids, blocks = [0], [(0, 0)]
+        nxt = 1
+        for _ in range(n):
+            nxt += int(rng.integers(1, 3))
+            parent = ids[-1] if rng.random() < 0.7 else int(rng.choice(ids))
+            blocks.append((nxt, parent))
+            ids.append(nxt)
+        if n and rng.random() < 0.2:
+            blocks.append((ids[len(ids) // 2], ids[0]))  # an overwritten block (sled upsert: the last wins)
+        order = rng.permutation(len(blocks)) if (rng.random() < 0.5 and len(blocks) == len(ids)) else np.arange(len(blocks))
+        commit = int(rng.choice(ids)) if rng.random() < 0.8 else nxt + 5
+        trees.append(([blocks[i] for i in order], commit))
+    a, b = dev.chain_compact(trees), ora.chain_compact(trees)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), (i, trees[i])
+    assert sum(int(x.sum()) for x in b) > 50
+
+
+@pytest.mark.parametrize("R,T", [(3, 4), (5, 8), (2, 3)])
+def test_the_t_tick_kernels_body(R, T):
+    """jg_step_dense_acks_device_n: T ticks per launch with the state in registers across them (k_leader_tick_dense_n's
+    per-group body; what does not fit is replayed tick by tick by the slow body) == T single ticks on the oracle."""
+    from parity import synth_tick_host
+    if not HostCompiled.fast:
+        pytest.skip("one form")
+    G = 900
+    dev, ora = pair(G, R, seed=5 + R, self_slots=(np.arange(G) % R).astype(np.uint8) if R == 5 else None)
+    for e in (dev, ora):
+        elect_all(e)
+    sim = np.zeros((R, G), np.uint64)
+    t = 0
+    for launch in range(12):
+        block = np.stack([synth_tick_host(ora_sim, 1, t + k, sim) for k, ora_sim in enumerate([ora] * T)])
+        dev.step_dense_acks_n(block)
+        for k in range(T):
+            ora.step_dense_acks(block[k])
+        t += T
+        for name in ("commit", "head", "repl_state", "fault", "id_gen", "role", "term"):
+            assert np.array_equal(dev.read(name), ora.read(name)), (launch, name)
+        for r in range(R):
+            assert np.array_equal(dev.read("match", r), ora.read("match", r)), (launch, r)
+        compare_drains(dev, ora, f"launch {launch}")
+    assert dev.counters()["decisions"] == ora.counters()["decisions"] and int(ora.read("commit").max()) > 0
