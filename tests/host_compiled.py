@@ -6,7 +6,11 @@ TEST INFRASTRUCTURE, and nothing else: the library is built at test time into a 
 josefine_amd/ can reach it, and it is no engine - no dense kernels, no transport, no drains of the product.  What it is
 for: the CPU suite (which runs where there is no GPU) holds the device SOURCE of the state machine to the oracle with
 the same fuzz the GPU suite runs through the real kernels (tests/test_host_compiled_state_machine.py): a change to
-jg_device.h is checked before a GPU-minute is spent on it."""
+jg_device.h is checked before a GPU-minute is spent on it.
+
+Sanitizers: JG_HOST_SANITIZE=address,undefined ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so)
+python -m pytest tests/test_host_compiled_state_machine.py builds the harness instrumented (every column, list and queue
+is a std::vector here: an access outside one is reported)."""
 import ctypes as C
 import os
 import subprocess
@@ -714,6 +718,8 @@ def build():
     open(os.path.join(tmp, "host.h"), "w").write(HOST_H)
     open(cpp, "w").write(HARNESS.replace("@INIT_BODY@", init_body))
     cc = ["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-Wno-unused-function", "-Wl,-Bsymbolic", f"-I{os.path.join(tmp, 'shim')}", f"-I{src}", f"-I{tmp}"]
+    if os.environ.get("JG_HOST_SANITIZE"):  # e.g. "undefined" or "address,undefined" (the latter wants LD_PRELOAD=libasan.so for python)
+        cc += ["-g", "-fno-omit-frame-pointer", f"-fsanitize={os.environ['JG_HOST_SANITIZE']}", "-fno-sanitize-recover=all"]
     subprocess.run(cc + ["-o", so, cpp], check=True)
     # the dense kernels' per-group logic: a library of its own (JG_BLOCK = 64 there, 1 here: nothing of the two may be merged)
     global _fast
