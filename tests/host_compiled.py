@@ -795,6 +795,24 @@ class HostCompiled:
                               cols["id"].ctypes.data, cols["aux"].ctypes.data, cols["flag"].ctypes.data, nb, bid.ctypes.data, bnx.ctypes.data, int(now_ms))
         assert rc == 0, f"host-compiled state machine: error {rc}"
 
+    def submit(self, group, cmd):
+        """one Command for one group (josefine_amd.engine.Command), applied at the next step in submit order"""
+        c = cmd
+        if c.kind == capi.CMD_APPEND_ENTRIES:
+            bi, bn = [b[0] for b in c.blocks], [b[1] for b in c.blocks]
+            self.submit_columns([c.kind], [group], [c.from_], [c.term], [0], [len(bi)], [c.flag], bi, bn)
+        else:
+            self.submit_columns([c.kind], [group], [c.from_], [c.term], [c.id], [c.aux], [c.flag])
+
+    def apply(self, group, cmd, now_ms=0):
+        self.submit(group, cmd)
+        self.step(now_ms)
+        return self.handle(group)
+
+    def handle(self, group):
+        from josefine_amd.engine import RaftHandle
+        return RaftHandle(self, group)
+
     def apply_all(self, cmd, now_ms=0):
         n = self.G
         self.submit_columns(np.full(n, cmd.kind, np.uint8), np.arange(n, dtype=np.uint32), np.full(n, cmd.from_, np.uint32),
