@@ -13,13 +13,17 @@ from josefine_amd.traces import synth_fill_acks_host
 from parity import elect_all
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-BACKENDS = ["oracle", "ref_py", pytest.param("hip", marks=pytest.mark.gpu)]
+# "device source on the host": the device's state machine and dense kernels' per-group logic compiled by g++ (tests/host_compiled.py)
+BACKENDS = ["oracle", "ref_py", "device source on the host", pytest.param("hip", marks=pytest.mark.gpu)]
 
 
 def factory(backend):
     if backend == "ref_py":
         from ref_py.engine import RefEngine
         return RefEngine
+    if backend == "device source on the host":
+        from host_compiled import HostCompiled
+        return HostCompiled
     return oracle_engine if backend == "oracle" else BatchedRaft
 
 
