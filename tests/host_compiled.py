@@ -104,6 +104,7 @@ HARNESS = r'''
 #include "jg_kernels.h"   // (jg_device.h, jg_dense.h, jg_sparse.h: the slow leader kernel's body)
 #include "jg_follower.h"  // (... and the follower's)
 #include "jg_node.h"      // (jg_step_node's row passes: prefill, classify, route, fsm build)
+#include "jg_votes.h"     // (the election vocabulary as words: the receiving half - not part of the engine yet)
 
 #include "host.h"
 
@@ -584,6 +585,33 @@ extern "C" int hc_dense_acks_n(Host* h, const uint64_t* acks, uint32_t n_ticks, 
   h->seq += n_ticks - 1;
   return (int)h->status[0];
 }
+
+// the vote half (jg_votes.h) over one node: words in, this node's answer words and its exceptional rows (with their emission
+// index) out - the rows are handed to the caller, who merges them with the rows the words stand for
+extern "C" int hc_vote_half(Host* h, uint32_t self, uint64_t now, const uint64_t* q_term, const uint64_t* q_head, const uint8_t* q_n, const uint8_t* q_at,
+                            const uint64_t* a_term, const uint8_t* a_n, const uint8_t* a_at, const uint8_t* a_bits, const uint8_t* a_to,
+                            uint64_t* o_term, uint8_t* o_n, uint8_t* o_at, uint8_t* o_bits, uint8_t* o_to,
+                            jg_msg_row* x_rows, uint32_t* x_k, size_t x_cap, size_t* x_n) {
+  JgDev& d = h->d;
+  h->seq++;
+  d.xq = h->xq.data(), d.xq_cap = (uint32_t)h->xq.size();
+  const JgVoteIn in{q_term, q_head, q_n, q_at, a_term, a_n, a_at, a_bits, a_to};
+  const JgVoteOut out{o_term, o_n, o_at, o_bits, o_to};
+  for (uint32_t g = 0; g < d.G; g++) h->decisions += jg_vote_half_group(d, g, self, in, out, now, h->seq);
+  const uint32_t nx = *d.xq_n;
+  std::vector<JgXqRec> x(h->xq.data(), h->xq.data() + nx);
+  std::sort(x.begin(), x.end(), [](const JgXqRec& a, const JgXqRec& b) { return a.row.group != b.row.group ? a.row.group < b.row.group : a.k < b.k; });
+  *x_n = nx;
+  for (size_t i = 0; i < nx && i < x_cap; i++) x_rows[i] = x[i].row, x_k[i] = x[i].k;
+  *d.xq_n = 0;
+  d.xq = nullptr, d.xq_cap = 0;
+  const uint32_t nf = *d.fault_q_n;
+  std::vector<JgFaultRec> f(d.fault_q, d.fault_q + nf);
+  std::stable_sort(f.begin(), f.end(), [](const JgFaultRec& a, const JgFaultRec& b) { return a.seq != b.seq ? a.seq < b.seq : a.group < b.group; });
+  h->faults.insert(h->faults.end(), f.begin(), f.end());
+  *d.fault_q_n = 0;
+  return (int)h->status[0];
+}
 '''
 
 FAST = r'''
@@ -739,6 +767,7 @@ def build():
     lib.hc_read.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
     lib.hc_leader_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.hc_follower_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hc_vote_half.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 16 + [C.c_size_t, C.c_void_p]
     lib.hc_dense_acks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.hc_dense_acks_n.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
     lib.hc_chain_compact.argtypes = [C.c_size_t] + [C.c_void_p] * 5
@@ -858,6 +887,24 @@ class HostCompiled:
         return C.cast(_fast.hf_follower_tick, C.c_void_p) if self.fast else None
 
     # -- the dense halves: the dense kernels' per-group logic, then the slow kernels' bodies (the interface of BatchedRaft's column forms) --
+    def vote_half(self, self_slot, now_ms, words):
+        """jg_votes.h: one node's inbound vote words of a round (dict of [R, G] arrays: q_term, q_head, q_n, q_at, a_term, a_n,
+        a_at, a_bits, a_to) -> (this node's answer word columns, its exceptional rows, their emission indices)"""
+        assert not self._pending
+        G = self.G
+        w = {k: np.ascontiguousarray(v) for k, v in words.items()}
+        out = dict(term=np.zeros(G, np.uint64), n=np.zeros(G, np.uint8), at=np.zeros(G, np.uint8), bits=np.zeros(G, np.uint8), to=np.zeros(G, np.uint8))
+        cap = (self.R + 3) * G + 64
+        xr = np.zeros(cap, dtype=capi.MSG_DTYPE)
+        xk = np.zeros(cap, np.uint32)
+        xn = C.c_size_t(0)
+        rc = self.lib.hc_vote_half(self._h, int(self_slot), int(now_ms), w["q_term"].ctypes.data, w["q_head"].ctypes.data, w["q_n"].ctypes.data,
+                                   w["q_at"].ctypes.data, w["a_term"].ctypes.data, w["a_n"].ctypes.data, w["a_at"].ctypes.data, w["a_bits"].ctypes.data,
+                                   w["a_to"].ctypes.data, out["term"].ctypes.data, out["n"].ctypes.data, out["at"].ctypes.data, out["bits"].ctypes.data,
+                                   out["to"].ctypes.data, xr.ctypes.data, xk.ctypes.data, cap, C.byref(xn))
+        assert rc == 0, f"host-compiled vote half: error {rc}"
+        return out, xr[:xn.value].copy(), xk[:xn.value].copy()
+
     def step_dense_acks(self, acks):
         """jg_step_dense_acks: the ack-only leader tick from a host [R, G] array"""
         assert not self._pending
