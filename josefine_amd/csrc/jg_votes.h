@@ -1,57 +1,119 @@
-// jg_votes.h - the ELECTION vocabulary as mailbox words: the receiving half (DESIGN.md "What comes next").
+// jg_votes.h - the ELECTION vocabulary as mailbox words (DESIGN.md "What comes next").
 //
-// NOT part of the engine yet: nothing in josefine_gpu.hip includes this file.  It holds the per-group logic of the step
-// that is to replace the row transport for a routed round's vote traffic, developed against the oracle on the HOST
-// (tests/host_compiled.py compiles it with the device's state machine; tests/test_vote_half.py) so that the next round
-// spends its GPU-minutes on the integration and the memory system, not on the semantics.  What it says is in
+// OPT-IN: a routed round uses this only under JG_ROUTE_VOTE_WORDS=1 (josefine_gpu.hip::round_routed_impl); the default
+// path does not launch anything in this file.  The per-group logic was developed against the oracle on the HOST
+// (tests/host_compiled.py compiles it with the device's state machine; tests/test_vote_half.py, tests/test_vote_mail.py),
+// so that the GPU-minutes go to the integration and the memory system, not to the semantics.  What the words say is in
 // tests/election_words.py (numpy), held there to the rows the routed clusters really exchange.
 //
-// One round's inbound vote traffic of ONE node, per sender slot s and partition g:
-//   request   sender s campaigns (candidate.rs:24-44): q_n[s][g] identical VoteRequest{term, candidate_id = id(s),
-//             last_term = term, head} (q_n = config.nodes.len() = R - 1 copies, Q5; 0: none)
-//   answer    sender s answers a campaign of the node a_to[s][g] (follower.rs:219-246, candidate.rs:66-84): a_n[s][g]
-//             VoteResponse{from = id(s), term, granted}: the first `first`, every further one `rest`
-//   q_at / a_at: where the stretch begins in the sender's run for this partition (a sender that answers and campaigns
-//   within one round sends both; the transport's order is (sender slot, emission order))
-// The half applies them exactly as the rows would have been applied - per partition in the order (sender slot, emission
-// order), one jg_apply per copy, one election_status() per VoteResponse - and emits what the rows would have emitted:
-// the VoteResponses this node gives to ONE requester per partition as its own answer word (o_*), everything else (a second
-// requester's answers, the Heartbeat of elect(), candidate.rs:108-113) as rows on the exceptional queue with their emission
-// index, so that words and rows merge back into the reference's emission order.
+// One round's vote traffic, per SENDER slot s and partition g (JgVoteMail: two of them, a round reads the last one's
+// and fills its own):
+//   request   sender s campaigns (candidate.rs:24-44): config.nodes.len() = R - 1 identical broadcasts
+//             VoteRequest{term, candidate_id = id(s), last_term = term, head} (Q5).  Its rows are emitted as ever (the
+//             exceptional queue); the transport's census (jg_votes_census_row) counts the copies into q_ctl and the first
+//             one it sees writes (q_term, q_head).  A count other than R - 1 (a second campaign in one round) makes the
+//             partition's mail travel as rows for every addressee.
+//   answer    sender s answers a campaign of node `to` (follower.rs:219-246, candidate.rs:66-84): n VoteResponse{from =
+//             id(s), term, granted}, the first `first`, every further one `rest`.  Written by the vote half itself
+//             (single writer), never rows unless the addressee's partition has to take rows (jg_votes_expand_group).
+//   ord       where a stretch begins in the sender's emission order of the round: step << 8 | emission index (a sender
+//             that answers and campaigns within one round sends both; the transport's order is (sender slot, step, index))
+// and per ADDRESSEE d two bitmaps over the partitions: rowmail[d] - a row that is not such a word is on its way to d
+// for g - and wordmail[d] - a word is.  The rule (the same in the delivering pass, the expansion and the receiving half):
+// a partition's mail for d travels in words iff EVERYTHING d receives for it this round is such words
+// (jg_votes_as_rows is false); otherwise all of it travels as rows, in the transport's order, as without this file.
+//
+// The receiving half (jg_vote_half_group) applies the words exactly as the rows would have been applied - per partition
+// in the order (sender slot, emission order), one jg_apply per copy, one election_status() per VoteResponse - and emits
+// what the rows would have emitted: the VoteResponses this node gives to ONE requester per partition as its own answer
+// word, everything else (a second requester's answers, the Heartbeat of elect(), candidate.rs:108-113) as rows on the
+// exceptional queue with their emission index, so that words and rows merge back into the reference's emission order.
 #pragma once
 #include "jg_device.h"
 
-struct JgVoteIn {  // [R][G] each, indexed [sender slot][partition]
-  const uint64_t* q_term;
-  const uint64_t* q_head;
-  const uint8_t* q_n;   // copies (0: no request from this sender)
-  const uint8_t* q_at;
-  const uint64_t* a_term;
-  const uint8_t* a_n;   // copies (0: no answer from this sender)
-  const uint8_t* a_at;
-  const uint8_t* a_bits;  // bit 0: the first answer, bit 1: every further one
-  const uint8_t* a_to;    // the slot the answers are addressed to
+#define JG_VOTE_ORD_BITS 11u  // step (3) << 8 | emission index (8)
+struct JgVoteMail {
+  uint32_t R, G, words;  // words = ceil(G / 64): a bitmap's length
+  uint64_t* q_term;      // [R][G] by sender: valid where q_ctl counts copies
+  uint64_t* q_head;
+  uint32_t* q_ctl;       // [R][G] copies (bits 0-7) | the sum of their ords (bits 8-31); CLEARED every round
+  uint64_t* a_term;      // [R][G] by sender: valid where a_ctl says so
+  uint32_t* a_ctl;       // [R][G] n (bits 0-7, 0: none) | ord of the first (8-18) | first (19) | rest (20) | to (21-23); CLEARED every round
+  uint64_t* rowmail;     // [R][words] by addressee; CLEARED every round
+  uint64_t* wordmail;    // [R][words] by addressee; CLEARED every round
 };
-struct JgVoteOut {  // [G] each: this node's own answer word of the round
-  uint64_t* term;
-  uint8_t* n;     // 0: none
-  uint8_t* at;    // emission index of the first copy within this node's step for the partition
-  uint8_t* bits;
-  uint8_t* to;
-};
+__host__ __device__ inline uint32_t jg_vote_actl(uint32_t n, uint32_t ord, uint32_t first, uint32_t rest, uint32_t to) {
+  return n | ord << 8 | (first & 1u) << 19 | (rest & 1u) << 20 | to << 21;
+}
+// copies that are not a campaign's (Q5: config.nodes.len() of them): `need` = R - 1 in the engine; 0 accepts any count
+// (the host tests feed the half words no cluster would send)
+__device__ __forceinline__ bool jg_vote_q_ok(uint32_t ctl, uint32_t need) { return !need || (ctl & 0xffu) == need; }
 
-// one partition of one node; returns the number of quorum decisions taken (election_status evaluations)
-__device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32_t self, const JgVoteIn& in, const JgVoteOut& out,
-                                              uint64_t now, uint32_t seq) {
-  const uint32_t G = d.G, R = d.R;
-  out.n[g] = 0;
-  bool any = false;
-  for (uint32_t s = 0; s < R; s++) {
-    if (s == self) continue;
-    const size_t i = (size_t)s * G + g;
-    any = any || in.q_n[i] != 0 || (in.a_n[i] != 0 && in.a_to[i] == self);
+// is this row one copy of a campaign's broadcast, i.e. does it travel in a request word?
+__device__ __forceinline__ bool jg_vote_row_is_request_copy(const jg_msg_row& r, uint32_t sender_id, uint32_t k) {
+  return r.kind == JG_CMD_VOTE_REQUEST && r.to_kind == JG_TO_PEERS && r.from == sender_id && r.aux == r.term && r.flag == 0 && k < 256u;
+}
+// the transport's census, once per emitted row of the round (sender slot `src`, the row's step of the round and its
+// emission index; `dests`: the members it is addressed to, jg_route_dests) - BEFORE anything is delivered
+__device__ inline void jg_votes_census_row(const JgVoteMail& m, uint32_t src, uint32_t sender_id, const jg_msg_row& r, uint32_t step, uint32_t k,
+                                           uint32_t dests) {
+  if (!dests) return;
+  const uint32_t g = r.group;
+  const uint64_t bit = 1ull << (g & 63u);
+  if (jg_vote_row_is_request_copy(r, sender_id, k)) {
+    const size_t i = (size_t)src * m.G + g;
+    const uint32_t old = atomicAdd(&m.q_ctl[i], 1u | ((step & 7u) << 8 | k) << 8);
+    if ((old & 0xffu) == 0) {  // (every copy says the same; a second campaign's would not - and is not a word: the count)
+      m.q_term[i] = r.term, m.q_head[i] = r.id;
+      for (uint32_t b = dests; b; b &= b - 1) atomicOr((unsigned long long*)&m.wordmail[(size_t)(__ffs(b) - 1) * m.words + (g >> 6)], (unsigned long long)bit);
+    }
+    return;
   }
-  if (!any) return 0;
+  for (uint32_t b = dests; b; b &= b - 1) atomicOr((unsigned long long*)&m.rowmail[(size_t)(__ffs(b) - 1) * m.words + (g >> 6)], (unsigned long long)bit);
+}
+// does partition g's mail for addressee d travel as rows?  (final once the census is)
+__device__ inline bool jg_votes_as_rows(const JgVoteMail& m, uint32_t d, uint32_t g, uint32_t need) {
+  if ((m.rowmail[(size_t)d * m.words + (g >> 6)] >> (g & 63u)) & 1ull) return true;
+  for (uint32_t s = 0; s < m.R; s++) {
+    if (s == d) continue;
+    const uint32_t c = m.q_ctl[(size_t)s * m.G + g];
+    if ((c & 0xffu) && !jg_vote_q_ok(c, need)) return true;
+  }
+  return false;
+}
+// the delivering pass: does this row go to addressee d as a row?
+__device__ __forceinline__ bool jg_votes_row_travels(const JgVoteMail& m, uint32_t sender_id, const jg_msg_row& r, uint32_t k, uint32_t d, uint32_t need) {
+  return !jg_vote_row_is_request_copy(r, sender_id, k) || jg_votes_as_rows(m, d, r.group, need);
+}
+// sender s's answer word for partition g when its addressee's partition takes rows: the rows it stands for
+// (returns how many; row i's emission key is (*step, *k0 + i))
+__device__ inline uint32_t jg_votes_expand_group(const JgVoteMail& m, const JgDev& d, uint32_t s, uint32_t g, uint32_t need, jg_msg_row* out, uint32_t* to,
+                                                 uint32_t* step, uint32_t* k0) {
+  const size_t i = (size_t)s * m.G + g;
+  const uint32_t c = m.a_ctl[i], n = c & 0xffu;
+  if (!n) return 0;
+  *to = (c >> 21) & 7u;
+  if (!jg_votes_as_rows(m, *to, g, need)) return 0;
+  const uint32_t ord = (c >> 8) & ((1u << JG_VOTE_ORD_BITS) - 1u);
+  *step = ord >> 8, *k0 = ord & 0xffu;
+  jg_msg_row r;
+  r.group = g, r.kind = JG_CMD_VOTE_RESPONSE, r.to_kind = JG_TO_PEER, r.pad = 0;
+  r.to_id = d.node_ids[*to], r.from = d.node_ids[s];
+  r.term = m.a_term[i], r.id = 0, r.aux = 0;
+  for (uint32_t j = 0; j < n; j++) {
+    r.flag = (uint8_t)((c >> (j ? 20 : 19)) & 1u);
+    out[j] = r;
+  }
+  return n;
+}
+
+// one partition of one node: `in` is the last round's mail, `out` this round's; returns the number of quorum decisions
+// taken (election_status evaluations).  `step`: this step's number within the round (the ord of what it emits)
+__device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32_t self, const JgVoteMail& in, const JgVoteMail& out, uint32_t need,
+                                              uint64_t now, uint32_t seq, uint32_t step) {
+  const uint32_t G = d.G, R = d.R;
+  if (!((in.wordmail[(size_t)self * in.words + (g >> 6)] >> (g & 63u)) & 1ull)) return 0;
+  if (jg_votes_as_rows(in, self, g, need)) return 0;  // (its mail came as rows)
   JgLane L;
   jg_load(d, L, g);
   const JgLane O = L;
@@ -65,19 +127,23 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
   for (uint32_t s = 0; s < R; s++) {
     if (s == self) continue;
     const size_t i = (size_t)s * G + g;
-    const bool has_q = in.q_n[i] != 0, has_a = in.a_n[i] != 0 && in.a_to[i] == self;
+    const uint32_t qc = in.q_ctl[i], ac = in.a_ctl[i];
+    const uint32_t q_n = qc & 0xffu, a_n = (ac & 0xffu) && ((ac >> 21) & 7u) == self ? (ac & 0xffu) : 0u;
+    if (!q_n && !a_n) continue;
     // the sender's two stretches in its own emission order
+    const uint32_t q_ord = q_n ? ((qc >> 8) - q_n * (q_n - 1u) / 2u) / q_n : 0u;  // (the copies' ords are consecutive: candidate.rs:24-44 is one loop)
+    const uint32_t a_ord = (ac >> 8) & ((1u << JG_VOTE_ORD_BITS) - 1u);
+    const bool ans_first = q_n && a_n && a_ord < q_ord;
     for (int pass = 0; pass < 2; pass++) {
-      const bool ans_first = has_q && has_a && in.a_at[i] < in.q_at[i];
-      const bool do_ans = (pass == 0) == (ans_first || !has_q);
-      if (do_ans ? !has_a : !has_q) continue;
-      const uint32_t copies = do_ans ? in.a_n[i] : in.q_n[i];
+      const bool do_ans = (pass == 0) == (ans_first || !q_n);
+      if (do_ans ? !a_n : !q_n) continue;
+      const uint32_t copies = do_ans ? a_n : q_n;
       for (uint32_t c = 0; c < copies; c++) {
         JgCmd cmd;
         cmd.from = d.node_ids[s];
         if (do_ans) {
           cmd.kind = JG_CMD_VOTE_RESPONSE, cmd.term = in.a_term[i], cmd.id = 0, cmd.aux = 0;
-          cmd.flag = (in.a_bits[i] >> (c ? 1 : 0)) & 1u;
+          cmd.flag = (ac >> (c ? 20 : 19)) & 1u;
         } else {
           cmd.kind = JG_CMD_VOTE_REQUEST, cmd.term = in.q_term[i], cmd.id = in.q_head[i], cmd.aux = in.q_term[i], cmd.flag = 0;
         }
@@ -109,16 +175,37 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
       }
     }
   }
-  if (o_n) out.term[g] = o_term, out.n[g] = (uint8_t)o_n, out.at[g] = (uint8_t)o_at, out.bits[g] = (uint8_t)(o_first | o_rest << 1), out.to[g] = (uint8_t)o_to;
+  if (o_n) {
+    const size_t i = (size_t)self * G + g;
+    out.a_term[i] = o_term;
+    out.a_ctl[i] = jg_vote_actl(o_n, (step & 7u) << 8 | o_at, o_first, o_rest, o_to);
+    atomicOr((unsigned long long*)&out.wordmail[(size_t)o_to * out.words + (g >> 6)], 1ull << (g & 63u));
+  }
   const uint32_t dec = L.decisions;
   jg_store_dirty<false>(d, L, O);
   return dec;
 }
 
-// the half as a kernel: one lane per partition (HBM-bound once the words are packed: 2 x 16 B per sender and partition
-// read, the cold records of the partitions that have mail)
-__global__ __launch_bounds__(JG_BLOCK) void k_vote_half(JgDev d, uint32_t self, JgVoteIn in, JgVoteOut out, uint64_t now, uint32_t seq) {
+// ---- kernels (one lane per partition; every node of the cluster in one launch: blockIdx.y = node) -------------------
+struct JgVoteHalfJob {
+  JgDev d;
+  uint32_t self, seq, step, need;
+  uint64_t now;
+};
+// the receiving half: a wave skips 64 partitions without mail on one bitmap word (HBM: the bitmaps - G / 8 bytes per node -
+// and, per partition with mail, the senders' control words and the partition's cold record)
+__global__ __launch_bounds__(JG_BLOCK) void k_vote_half_multi(const JgVoteHalfJob* __restrict__ jobs, JgVoteMail in, JgVoteMail out) {
+  const JgVoteHalfJob j = jobs[blockIdx.y];
   uint32_t dec = 0;
-  for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < d.G; g += gridDim.x * JG_BLOCK) dec += jg_vote_half_group(d, g, self, in, out, now, seq);
-  if (dec) (void)__hip_atomic_fetch_add(&d.blk_decisions[blockIdx.x], (uint64_t)dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < j.d.G; g += gridDim.x * JG_BLOCK) {
+    if (!in.wordmail[(size_t)j.self * in.words + (g >> 6)]) continue;  // (wave-uniform: a wave's 64 lanes share the word)
+    dec += jg_vote_half_group(j.d, g, j.self, in, out, j.need, j.now, j.seq, j.step);
+  }
+  if (dec) (void)__hip_atomic_fetch_add(&j.d.blk_decisions[blockIdx.x], (uint64_t)dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a round's mail cleared: the control words and the bitmaps (the term / head columns are valid only where those say so)
+__global__ __launch_bounds__(JG_BLOCK) void k_votes_clear(JgVoteMail m) {
+  const size_t n = (size_t)m.R * m.G, nb = (size_t)m.R * m.words;
+  for (size_t i = (size_t)blockIdx.x * JG_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * JG_BLOCK) m.q_ctl[i] = 0, m.a_ctl[i] = 0;
+  for (size_t i = (size_t)blockIdx.x * JG_BLOCK + threadIdx.x; i < nb; i += (size_t)gridDim.x * JG_BLOCK) m.rowmail[i] = 0, m.wordmail[i] = 0;
 }

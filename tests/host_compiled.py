@@ -586,18 +586,14 @@ extern "C" int hc_dense_acks_n(Host* h, const uint64_t* acks, uint32_t n_ticks, 
   return (int)h->status[0];
 }
 
-// the vote half (jg_votes.h) over one node: words in, this node's answer words and its exceptional rows (with their emission
-// index) out - the rows are handed to the caller, who merges them with the rows the words stand for
-extern "C" int hc_vote_half(Host* h, uint32_t self, uint64_t now, const uint64_t* q_term, const uint64_t* q_head, const uint8_t* q_n, const uint8_t* q_at,
-                            const uint64_t* a_term, const uint8_t* a_n, const uint8_t* a_at, const uint8_t* a_bits, const uint8_t* a_to,
-                            uint64_t* o_term, uint8_t* o_n, uint8_t* o_at, uint8_t* o_bits, uint8_t* o_to,
+// the vote half (jg_votes.h) over one node: the last round's mail in, this round's mail (its answer words) and its
+// exceptional rows (with their emission index) out - the rows are handed to the caller, who plays the transport
+extern "C" int hc_vote_half(Host* h, uint32_t self, uint64_t now, uint32_t step, uint32_t need, const JgVoteMail* in, const JgVoteMail* out,
                             jg_msg_row* x_rows, uint32_t* x_k, size_t x_cap, size_t* x_n) {
   JgDev& d = h->d;
   h->seq++;
   d.xq = h->xq.data(), d.xq_cap = (uint32_t)h->xq.size();
-  const JgVoteIn in{q_term, q_head, q_n, q_at, a_term, a_n, a_at, a_bits, a_to};
-  const JgVoteOut out{o_term, o_n, o_at, o_bits, o_to};
-  for (uint32_t g = 0; g < d.G; g++) h->decisions += jg_vote_half_group(d, g, self, in, out, now, h->seq);
+  for (uint32_t g = 0; g < d.G; g++) h->decisions += jg_vote_half_group(d, g, self, *in, *out, need, now, h->seq, step);
   const uint32_t nx = *d.xq_n;
   std::vector<JgXqRec> x(h->xq.data(), h->xq.data() + nx);
   std::sort(x.begin(), x.end(), [](const JgXqRec& a, const JgXqRec& b) { return a.row.group != b.row.group ? a.row.group < b.row.group : a.k < b.k; });
@@ -611,6 +607,33 @@ extern "C" int hc_vote_half(Host* h, uint32_t self, uint64_t now, const uint64_t
   h->faults.insert(h->faults.end(), f.begin(), f.end());
   *d.fault_q_n = 0;
   return (int)h->status[0];
+}
+// the transport's side of the mail, row by row as the kernels' lanes call it: the census of one sender's emitted rows ...
+extern "C" void hc_votes_census(const JgVoteMail* m, uint32_t src, uint32_t sender_id, const jg_msg_row* rows, const uint32_t* step, const uint32_t* k,
+                                const uint32_t* dests, size_t n) {
+  for (size_t i = 0; i < n; i++) jg_votes_census_row(*m, src, sender_id, rows[i], step[i], k[i], dests[i]);
+}
+// ... which of them (per addressee: a bit mask within `dests`) still travel as rows once the census is final ...
+extern "C" void hc_votes_travels(const JgVoteMail* m, uint32_t sender_id, const jg_msg_row* rows, const uint32_t* k, const uint32_t* dests, size_t n,
+                                 uint32_t need, uint32_t* out) {
+  for (size_t i = 0; i < n; i++) {
+    uint32_t t = 0;
+    for (uint32_t b = dests[i]; b; b &= b - 1)
+      if (jg_votes_row_travels(*m, sender_id, rows[i], k[i], (uint32_t)__builtin_ctz(b), need)) t |= b & (~b + 1u);
+    out[i] = t;
+  }
+}
+// ... and the answer words of sender s that have to go as rows after all (out: up to 255 rows per partition)
+extern "C" size_t hc_votes_expand(Host* h, const JgVoteMail* m, uint32_t s, uint32_t need, jg_msg_row* rows, uint32_t* to, uint32_t* step, uint32_t* k,
+                                  size_t cap) {
+  size_t n = 0;
+  jg_msg_row buf[256];
+  for (uint32_t g = 0; g < m->G; g++) {
+    uint32_t t = 0, st = 0, k0 = 0;
+    const uint32_t c = jg_votes_expand_group(*m, h->d, s, g, need, buf, &t, &st, &k0);
+    for (uint32_t j = 0; j < c && n < cap; j++, n++) rows[n] = buf[j], to[n] = t, step[n] = st, k[n] = k0 + j;
+  }
+  return n;
 }
 '''
 
@@ -767,7 +790,13 @@ def build():
     lib.hc_read.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
     lib.hc_leader_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.hc_follower_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.hc_vote_half.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 16 + [C.c_size_t, C.c_void_p]
+    lib.hc_vote_half.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
+    lib.hc_votes_census.restype = None
+    lib.hc_votes_census.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_size_t]
+    lib.hc_votes_travels.restype = None
+    lib.hc_votes_travels.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 3 + [C.c_size_t, C.c_uint32, C.c_void_p]
+    lib.hc_votes_expand.restype = C.c_size_t
+    lib.hc_votes_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_size_t]
     lib.hc_dense_acks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.hc_dense_acks_n.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
     lib.hc_chain_compact.argtypes = [C.c_size_t] + [C.c_void_p] * 5
@@ -776,6 +805,35 @@ def build():
         [C.c_void_p] * 7
     _lib = lib
     return lib
+
+
+class _JgVoteMail(C.Structure):
+    _fields_ = [("R", C.c_uint32), ("G", C.c_uint32), ("words", C.c_uint32), ("q_term", C.c_void_p), ("q_head", C.c_void_p), ("q_ctl", C.c_void_p),
+                ("a_term", C.c_void_p), ("a_ctl", C.c_void_p), ("rowmail", C.c_void_p), ("wordmail", C.c_void_p)]
+
+
+class VoteMail:
+    """one round's election mail (jg_votes.h: JgVoteMail) in host arrays"""
+
+    def __init__(self, R, G):
+        self.R, self.G, self.words = R, G, (G + 63) // 64
+        self.q_term, self.q_head, self.a_term = (np.zeros((R, G), np.uint64) for _ in range(3))
+        self.q_ctl, self.a_ctl = np.zeros((R, G), np.uint32), np.zeros((R, G), np.uint32)
+        self.rowmail, self.wordmail = np.zeros((R, self.words), np.uint64), np.zeros((R, self.words), np.uint64)
+        self.c = _JgVoteMail(R, G, self.words, self.q_term.ctypes.data, self.q_head.ctypes.data, self.q_ctl.ctypes.data, self.a_term.ctypes.data,
+                             self.a_ctl.ctypes.data, self.rowmail.ctypes.data, self.wordmail.ctypes.data)
+
+    def clear(self):  # (k_votes_clear: the control words and the bitmaps; the term / head columns keep their garbage)
+        self.q_ctl[:], self.a_ctl[:], self.rowmail[:], self.wordmail[:] = 0, 0, 0, 0
+
+    @staticmethod
+    def set_bits(bitmap, d, groups):
+        for g in groups:
+            bitmap[d, g >> 6] |= np.uint64(1) << np.uint64(g & 63)
+
+    @staticmethod
+    def bits(bitmap, d, G):
+        return ((bitmap[d, np.arange(G) >> 6] >> (np.arange(G) & 63).astype(np.uint64)) & np.uint64(1)).astype(bool)
 
 
 class HostCompiled:
@@ -887,23 +945,41 @@ class HostCompiled:
         return C.cast(_fast.hf_follower_tick, C.c_void_p) if self.fast else None
 
     # -- the dense halves: the dense kernels' per-group logic, then the slow kernels' bodies (the interface of BatchedRaft's column forms) --
-    def vote_half(self, self_slot, now_ms, words):
-        """jg_votes.h: one node's inbound vote words of a round (dict of [R, G] arrays: q_term, q_head, q_n, q_at, a_term, a_n,
-        a_at, a_bits, a_to) -> (this node's answer word columns, its exceptional rows, their emission indices)"""
+    def vote_half(self, self_slot, now_ms, words, R=None):
+        """jg_votes.h's receiving half on words given as plain columns (dict of [R, G] arrays: q_term, q_head, q_n, q_at, a_term,
+        a_n, a_at, a_bits, a_to; any number of copies) -> (this node's answer word columns, its exceptional rows, their emission
+        indices)"""
+        G, R = self.G, self.R
+        inn, out = VoteMail(R, G), VoteMail(R, G)
+        n = words["q_n"].astype(np.uint32)
+        at = words["q_at"].astype(np.uint32)
+        inn.q_term[:], inn.q_head[:] = words["q_term"], words["q_head"]
+        inn.q_ctl[:] = n | (n * at + n * (n - np.minimum(n, 1)) // 2) << 8
+        inn.a_term[:] = words["a_term"]
+        a_n, bits = words["a_n"].astype(np.uint32), words["a_bits"].astype(np.uint32)
+        inn.a_ctl[:] = np.where(a_n != 0, a_n | words["a_at"].astype(np.uint32) << 8 | (bits & 1) << 19 | (bits >> 1 & 1) << 20 | words["a_to"].astype(np.uint32) << 21, 0)
+        mine = (a_n != 0) & (words["a_to"] == self_slot)
+        mine[self_slot] = False
+        has = ((n != 0) | mine)
+        has[self_slot] = False
+        inn.set_bits(inn.wordmail, self_slot, np.nonzero(has.any(axis=0))[0])
+        xrows, xk = self.vote_half_mail(self_slot, now_ms, inn, out, step=0, need=0)
+        c = out.a_ctl[self_slot]
+        res = dict(term=out.a_term[self_slot].copy(), n=(c & 0xff).astype(np.uint8), at=(c >> 8 & 0xff).astype(np.uint8),
+                   bits=((c >> 19) & 3).astype(np.uint8), to=((c >> 21) & 7).astype(np.uint8))
+        return res, xrows, xk
+
+    def vote_half_mail(self, self_slot, now_ms, mail_in, mail_out, step, need):
+        """the receiving half on the packed mail (VoteMail): last round's in, this round's out -> (exceptional rows, their emission indices)"""
         assert not self._pending
-        G = self.G
-        w = {k: np.ascontiguousarray(v) for k, v in words.items()}
-        out = dict(term=np.zeros(G, np.uint64), n=np.zeros(G, np.uint8), at=np.zeros(G, np.uint8), bits=np.zeros(G, np.uint8), to=np.zeros(G, np.uint8))
-        cap = (self.R + 3) * G + 64
+        cap = (self.R + 3) * self.G + 64
         xr = np.zeros(cap, dtype=capi.MSG_DTYPE)
         xk = np.zeros(cap, np.uint32)
         xn = C.c_size_t(0)
-        rc = self.lib.hc_vote_half(self._h, int(self_slot), int(now_ms), w["q_term"].ctypes.data, w["q_head"].ctypes.data, w["q_n"].ctypes.data,
-                                   w["q_at"].ctypes.data, w["a_term"].ctypes.data, w["a_n"].ctypes.data, w["a_at"].ctypes.data, w["a_bits"].ctypes.data,
-                                   w["a_to"].ctypes.data, out["term"].ctypes.data, out["n"].ctypes.data, out["at"].ctypes.data, out["bits"].ctypes.data,
-                                   out["to"].ctypes.data, xr.ctypes.data, xk.ctypes.data, cap, C.byref(xn))
+        rc = self.lib.hc_vote_half(self._h, int(self_slot), int(now_ms), int(step), int(need), C.addressof(mail_in.c), C.addressof(mail_out.c),
+                                   xr.ctypes.data, xk.ctypes.data, cap, C.byref(xn))
         assert rc == 0, f"host-compiled vote half: error {rc}"
-        return out, xr[:xn.value].copy(), xk[:xn.value].copy()
+        return xr[:xn.value].copy(), xk[:xn.value].copy()
 
     def step_dense_acks(self, acks):
         """jg_step_dense_acks: the ack-only leader tick from a host [R, G] array"""
