@@ -650,6 +650,8 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
             "leaderless_fraction": {"at_start_of_timed_region": None, "at_end": float(failed.mean())},
             "per_rank": per_rank,
             "rows_routed_per_round": delivered[1] / K / world,
+            "decisions_in_timed_region": decisions,
+            "vote_words": os.environ.get("JG_ROUTE_VOTE_WORDS", "0") not in ("", "0"),  # (opt-in A/B: jg_votes.h; rows_routed_per_round counts rows only)
             "roofline": {"bound": "hbm", "achieved": alg / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel": f"one round: k_leader_node_tick<{R}> + {R - 1} x k_follower_tick_dense + slow kernels "

@@ -16,6 +16,7 @@
 #pragma once
 #include "jg_device.h"
 #include "jg_sparse.h"
+#include "jg_votes.h"
 
 #define JG_ROUTE_ORD_BITS 26u       // widest emission-index field: the key then has 35 + bits(G) <= 64 bits (G <= 2^29)
 #define JG_ROUTE_STEP_BITS 3u       // a node takes up to 4 steps per routed round (delivered rows, injected rows, leader half, follower half)
@@ -50,6 +51,16 @@ __device__ __forceinline__ uint32_t jg_route_dests(const jg_msg_row& r, const Jg
   for (uint32_t n = 0; n < JG_MAX_REPLICAS; n++)
     if (n < t.R && t.member_id[n] == r.to_id) m |= 1u << n;
   return m & all;
+}
+// JG_ROUTE_VOTE_WORDS (WORDS): the members a row is delivered to AS A ROW - a campaign's broadcast stays away from the
+// addressees whose partition takes this round's mail in words (jg_votes.h; `k`: the row's emission index)
+template <bool WORDS>
+__device__ __forceinline__ uint32_t jg_route_dests_rows(const jg_msg_row& r, const JgRouteTable& t, uint32_t k, const JgVoteMail& vm) {
+  uint32_t m = jg_route_dests(r, t);
+  if (WORDS && m && jg_vote_row_is_request_copy(r, t.member_id[t.src], k))
+    for (uint32_t b = m; b; b &= b - 1)
+      if (!jg_votes_as_rows(vm, (uint32_t)__ffs(b) - 1u, r.group, t.R - 1u)) m &= ~(b & (~b + 1u));
+  return m;
 }
 __device__ __forceinline__ uint64_t jg_route_key(const JgRouteTable& t, uint32_t dest, uint32_t group, uint32_t step,
                                                  uint32_t ord) {
@@ -170,9 +181,10 @@ __device__ __forceinline__ void jg_route_note_kind(uint64_t& kd_lo, uint64_t& kd
 // The slots of one sparse step: every deliverable row goes to the staging (nothing is modified: the
 // pass can be repeated with a larger staging); rows that stay and FSM rows are counted.
 #define JG_ROUTE_ITEMS 2  // slots per thread: a workgroup serves a tile of JG_BLOCK * JG_ROUTE_ITEMS
+template <bool WORDS = false>
 __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_t n, uint32_t per_row, uint32_t step,
                                                   const uint32_t* __restrict__ msg_cnt, const jg_msg_row* __restrict__ msg,
-                                                  const uint32_t* __restrict__ fsm_cnt) {
+                                                  const uint32_t* __restrict__ fsm_cnt, const JgVoteMail& vm = JgVoteMail{}) {
   if (blockIdx.x * (JG_BLOCK * JG_ROUTE_ITEMS) >= n) return;  // (a multi launch is as wide as its largest job)
   const uint32_t tile0 = blockIdx.x * (JG_BLOCK * JG_ROUTE_ITEMS) + threadIdx.x;
   uint32_t cnt[JG_ROUTE_ITEMS];
@@ -188,9 +200,9 @@ __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_
   for (int k = 0; k < JG_ROUTE_ITEMS; k++) {
     const jg_msg_row* mine = msg + (size_t)(tile0 + k * JG_BLOCK) * per_row;
     for (uint32_t j = 0; j < cnt[k]; j++) {
-      const uint32_t m = jg_route_dests(mine[j], t);
+      const uint32_t m = jg_route_dests_rows<WORDS>(mine[j], t, j, vm);
       c += __popc(m);
-      kept += !m;
+      kept += WORDS ? !jg_route_dests(mine[j], t) : !m;  // (what a word carries does not stay either)
       for (uint32_t b = m; b; b &= b - 1) {
         jg_route_note(pd_lo, pd_hi, (uint32_t)__ffs(b) - 1u);
         jg_route_note_kind(kd_lo, kd_hi, (uint32_t)__ffs(b) - 1u, mine[j].kind);
@@ -210,7 +222,7 @@ __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_
       const jg_msg_row* mine = msg + (size_t)i * per_row;
       for (uint32_t j = 0; j < cnt[k]; j++) {
         const jg_msg_row r = mine[j];
-        for (uint32_t b = jg_route_dests(r, t); b; b &= b - 1, pos++, at++) {
+        for (uint32_t b = jg_route_dests_rows<WORDS>(r, t, j, vm); b; b &= b - 1, pos++, at++) {
           if (staged) {
             jg_stage_put(st, at, jg_route_key(t, (uint32_t)__ffs(b) - 1u, r.group, step, j), r);
             continue;
@@ -245,6 +257,19 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_rec_multi(const JgRouteRecJo
   const JgRouteRecJob j = jobs[blockIdx.y];
   jg_route_rec_body(j.t, j.n, j.per_row, j.step, j.msg_cnt, j.msg, j.fsm_cnt);
 }
+__global__ __launch_bounds__(JG_BLOCK) void k_route_rec_multi_words(const JgRouteRecJob* __restrict__ jobs, JgVoteMail vm) {
+  const JgRouteRecJob j = jobs[blockIdx.y];
+  jg_route_rec_body<true>(j.t, j.n, j.per_row, j.step, j.msg_cnt, j.msg, j.fsm_cnt, vm);
+}
+// the census of the same slots (jg_votes.h), before anything is delivered
+__global__ __launch_bounds__(JG_BLOCK) void k_votes_census_rec_multi(const JgRouteRecJob* __restrict__ jobs, JgVoteMail vm) {
+  const JgRouteRecJob j = jobs[blockIdx.y];
+  const uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x;
+  if (i >= j.n) return;
+  const uint32_t cnt = j.msg_cnt[i];
+  const jg_msg_row* mine = j.msg + (size_t)i * j.per_row;
+  for (uint32_t k = 0; k < cnt; k++) jg_votes_census_row(vm, j.t.src, j.t.member_id[j.t.src], mine[k], j.step, k, jg_route_dests(mine[k], j.t));
+}
 // second pass, only for a step that keeps rows for the host: the delivered rows leave their slots
 __global__ __launch_bounds__(JG_BLOCK) void k_route_rec_compact(JgRouteTable t, uint32_t n, uint32_t per_row,
                                                                 uint32_t* __restrict__ msg_cnt, jg_msg_row* __restrict__ msg) {
@@ -265,10 +290,10 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_rec_compact(JgRouteTable t, 
 // The exceptional-row queue of the dense steps.  COMPACT = false: deliver + count (nothing modified);
 // COMPACT = true: the rows that stay are appended to `keep` (the queue is unordered; its rows carry
 // their own step and emission index).
-template <bool COMPACT>
+template <bool COMPACT, bool WORDS = false>
 __device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const JgXqRec* __restrict__ xq,
                                                  const uint32_t* __restrict__ xq_n, uint32_t xq_cap, uint32_t seq_base,
-                                                 JgXqRec* __restrict__ keep, uint32_t* __restrict__ keep_n) {
+                                                 JgXqRec* __restrict__ keep, uint32_t* __restrict__ keep_n, const JgVoteMail& vm = JgVoteMail{}) {
   const uint32_t n = min(*xq_n, xq_cap);
   const uint32_t lane = threadIdx.x & 63u;
   uint64_t pd_lo = 0, pd_hi = 0, kd_lo = 0, kd_hi = 0;
@@ -283,6 +308,7 @@ __device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const Jg
       mask = (q.seq - seq_base - 1u < 7u) ? jg_route_dests(q.row, t) : 0u;  // (steps 1..7 of the round: JG_ROUTE_STEP_BITS)
     }
     const bool stay = i < n && !mask;
+    if (WORDS && mask) mask = jg_route_dests_rows<true>(q.row, t, q.k, vm);  // (a word's copies do not stay, and are not staged)
     if (COMPACT) {
       const uint64_t b = __ballot(stay);
       if (b) {
@@ -334,6 +360,41 @@ struct JgRouteXqJob {  // the delivering pass over every sender's exceptional-ro
 __global__ __launch_bounds__(JG_BLOCK) void k_route_xq_multi(const JgRouteXqJob* __restrict__ jobs) {
   const JgRouteXqJob j = jobs[blockIdx.y];
   jg_route_xq_body<false>(j.t, j.xq, j.xq_n, j.xq_cap, j.seq_base, nullptr, nullptr);
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_route_xq_multi_words(const JgRouteXqJob* __restrict__ jobs, JgVoteMail vm) {
+  const JgRouteXqJob j = jobs[blockIdx.y];
+  jg_route_xq_body<false, true>(j.t, j.xq, j.xq_n, j.xq_cap, j.seq_base, nullptr, nullptr, vm);
+}
+// the census of the same queues (jg_votes.h), before anything is delivered
+__global__ __launch_bounds__(JG_BLOCK) void k_votes_census_xq_multi(const JgRouteXqJob* __restrict__ jobs, JgVoteMail vm) {
+  const JgRouteXqJob j = jobs[blockIdx.y];
+  const uint32_t n = min(*j.xq_n, j.xq_cap);
+  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < n; i += gridDim.x * JG_BLOCK) {
+    const JgXqRec q = j.xq[i];
+    if (q.seq - j.seq_base - 1u >= 7u) continue;  // (not this round's mail)
+    jg_votes_census_row(vm, j.t.src, j.t.member_id[j.t.src], q.row, (q.seq - j.seq_base) & 7u, q.k, jg_route_dests(q.row, j.t));
+  }
+}
+// the answer words whose addressee's partition takes rows after all: staged as the rows they stand for (blockIdx.y = the
+// sender; its table comes with its queue's job).  Rare: written from the lanes that found them.
+__global__ __launch_bounds__(JG_BLOCK) void k_votes_expand_multi(const JgRouteXqJob* __restrict__ jobs, JgVoteMail vm) {
+  const JgRouteTable t = jobs[blockIdx.y].t;
+  uint64_t pd_lo = 0, pd_hi = 0, kd_lo = 0, kd_hi = 0;
+  for (uint32_t g0 = blockIdx.x * JG_BLOCK; g0 < vm.G; g0 += gridDim.x * JG_BLOCK) {  // (block-uniform trip count)
+    const uint32_t g = g0 + threadIdx.x;
+    uint32_t to = 0, step = 0, k0 = 0;
+    const uint32_t n = g < vm.G ? jg_votes_expand_count(vm, t.src, g, t.R - 1u, &to, &step, &k0) : 0u;
+    const JgRouteSpot sp = jg_route_reserve(t, n);
+    for (uint32_t j = 0, pos = sp.pos; j < n; j++, pos++) {
+      jg_route_note(pd_lo, pd_hi, to);
+      jg_route_note_kind(kd_lo, kd_hi, to, JG_CMD_VOTE_RESPONSE);
+      if (pos >= sp.lim) continue;  // (the host sees the cursor above the segment, grows the staging and repeats the pass)
+      t.key[pos] = jg_route_key(t, to, g, step, k0 + j);
+      t.idx[pos] = pos;
+      t.row[pos] = jg_votes_expand_row(vm, t.member_id, t.src, g, j);
+    }
+  }
+  jg_route_tally(t, pd_lo, pd_hi, 0, JG_ROUTE_KEPT, 0, kd_lo, kd_hi);
 }
 
 // sorted staging -> the command columns k_apply_rows consumes

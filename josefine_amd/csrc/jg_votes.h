@@ -85,26 +85,27 @@ __device__ inline bool jg_votes_as_rows(const JgVoteMail& m, uint32_t d, uint32_
 __device__ __forceinline__ bool jg_votes_row_travels(const JgVoteMail& m, uint32_t sender_id, const jg_msg_row& r, uint32_t k, uint32_t d, uint32_t need) {
   return !jg_vote_row_is_request_copy(r, sender_id, k) || jg_votes_as_rows(m, d, r.group, need);
 }
-// sender s's answer word for partition g when its addressee's partition takes rows: the rows it stands for
-// (returns how many; row i's emission key is (*step, *k0 + i))
-__device__ inline uint32_t jg_votes_expand_group(const JgVoteMail& m, const JgDev& d, uint32_t s, uint32_t g, uint32_t need, jg_msg_row* out, uint32_t* to,
-                                                 uint32_t* step, uint32_t* k0) {
-  const size_t i = (size_t)s * m.G + g;
-  const uint32_t c = m.a_ctl[i], n = c & 0xffu;
+// sender s's answer word for partition g when its addressee's partition takes rows after all: how many rows it stands
+// for (0: none, or the word travels), to whom, and the emission key of the first - row j's is (*step, *k0 + j) ...
+__device__ inline uint32_t jg_votes_expand_count(const JgVoteMail& m, uint32_t s, uint32_t g, uint32_t need, uint32_t* to, uint32_t* step, uint32_t* k0) {
+  const uint32_t c = m.a_ctl[(size_t)s * m.G + g], n = c & 0xffu;
   if (!n) return 0;
   *to = (c >> 21) & 7u;
   if (!jg_votes_as_rows(m, *to, g, need)) return 0;
   const uint32_t ord = (c >> 8) & ((1u << JG_VOTE_ORD_BITS) - 1u);
   *step = ord >> 8, *k0 = ord & 0xffu;
+  return n;
+}
+// ... and row j of them (member_id: the NodeId of every slot)
+__device__ inline jg_msg_row jg_votes_expand_row(const JgVoteMail& m, const uint32_t* member_id, uint32_t s, uint32_t g, uint32_t j) {
+  const size_t i = (size_t)s * m.G + g;
+  const uint32_t c = m.a_ctl[i];
   jg_msg_row r;
   r.group = g, r.kind = JG_CMD_VOTE_RESPONSE, r.to_kind = JG_TO_PEER, r.pad = 0;
-  r.to_id = d.node_ids[*to], r.from = d.node_ids[s];
+  r.flag = (uint8_t)((c >> (j ? 20 : 19)) & 1u);
+  r.to_id = member_id[(c >> 21) & 7u], r.from = member_id[s];
   r.term = m.a_term[i], r.id = 0, r.aux = 0;
-  for (uint32_t j = 0; j < n; j++) {
-    r.flag = (uint8_t)((c >> (j ? 20 : 19)) & 1u);
-    out[j] = r;
-  }
-  return n;
+  return r;
 }
 
 // one partition of one node: `in` is the last round's mail, `out` this round's; returns the number of quorum decisions
@@ -119,7 +120,7 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
   const JgLane O = L;
   L.now = now;
   L.seq = seq;
-  jg_msg_row buf[JG_MAX_REPLICAS + 1];
+  jg_msg_row buf[3];  // (an election's command emits at most two rows - the answer; DROP + the Heartbeat of elect(): prepare_rows' bound for these kinds - and one to spare)
   jg_fsm_row sink[2];
   uint32_t k_emit = 0;  // emission index within this node's step for the partition
   uint64_t o_term = 0;
@@ -147,7 +148,7 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
         } else {
           cmd.kind = JG_CMD_VOTE_REQUEST, cmd.term = in.q_term[i], cmd.id = in.q_head[i], cmd.aux = in.q_term[i], cmd.flag = 0;
         }
-        L.mp = buf, L.mend = buf + JG_MAX_REPLICAS + 1;
+        L.mp = buf, L.mend = buf + 3;
         L.fp = sink, L.fend = sink + 2;
         jg_apply<JG_KINDS_ELECTION>(d, L, cmd, nullptr, nullptr);
         for (const jg_msg_row* r = buf; r != L.mp; r++, k_emit++) {
@@ -166,9 +167,7 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
               JgXqRec x;
               x.row = *r, x.seq = seq, x.k = k_emit;
               d.xq[q] = x;
-            } else {
-              *d.err = 6;
-            }
+            }  // (a queue that ran over is seen by the host: xq_n above xq_cap, as for jg_emit_msg's rows)
           }
         }
         if (L.overflow) *d.err = 1;

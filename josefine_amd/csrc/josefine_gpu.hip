@@ -2349,6 +2349,10 @@ struct jg_dense_cluster {
     char *h_jobs = nullptr, *d_jobs = nullptr;
     uint32_t group_bits = 1;
     bool ready = false;
+    // JG_ROUTE_VOTE_WORDS=1: the election vocabulary as mailbox words (jg_votes.h) - two rounds' mail, used in turn
+    JgVoteMail vm[2]{};
+    void* vm_mem = nullptr;
+    uint32_t vm_turn = 0;
     hipEvent_t ev_counts = nullptr;               // behind the delivering pass's counts on their way to the host
     uint32_t last_total = 0, last_fullest_seg = 0;  // the previous round's rows: what the ordering pass is sized for before the counts are in
   } rt;
@@ -2448,6 +2452,7 @@ void jg_dense_cluster_destroy(jg_dense_cluster* c) {
   for (JgXqRec* p : c->rt.xq_keep)
     if (p) (void)hipFree(p);
   if (c->rt.sort_tmp) (void)hipFree(c->rt.sort_tmp);
+  if (c->rt.vm_mem) (void)hipFree(c->rt.vm_mem);
   if (c->rt.h_jobs) (void)hipHostFree(c->rt.h_jobs);
   if (c->rt.d_jobs) (void)hipFree(c->rt.d_jobs);
   if (c->rt.bk_hist) (void)hipFree(c->rt.bk_hist);
@@ -2893,12 +2898,42 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   for (jg_engine* e : c->nodes) one_stream = one_stream && e->stream == L->stream;
   static const bool no_multi = std::getenv("JG_ROUTE_SEPARATE_LAUNCHES") != nullptr;  // (A/B: round 2's launch per node / sender / step)
   const bool multi = one_stream && !no_multi;
+  // JG_ROUTE_VOTE_WORDS=1 (OPT-IN, jg_votes.h): an election's traffic travels as mailbox words - the campaigns' broadcasts are
+  // counted into request words by a census of the emitted rows and are not staged, the answers are written as words by the
+  // receiving half (k_vote_half_multi) and never become rows - wherever EVERYTHING a node receives for a partition in a
+  // round is such words; every other partition's mail travels as rows, as without the switch.  Fixed for a cluster's life.
+  static const bool vote_words_env = std::getenv("JG_ROUTE_VOTE_WORDS") != nullptr && std::atoi(std::getenv("JG_ROUTE_VOTE_WORDS")) != 0;
+  const bool vwords = vote_words_env && multi && !c->any && R >= 2 && std::getenv("JG_ROUTE_LIBRARY_SORT") == nullptr;
+  if (vwords && !rt.vm_mem) {
+    const size_t RG = (size_t)R * c->G, wd = ((size_t)c->G + 63) / 64;
+    const size_t per = RG * (8 + 8 + 8 + 4 + 4) + 2 * R * wd * 8;
+    HIPCHK(hipMalloc(&rt.vm_mem, 2 * per));
+    HIPCHK(hipMemsetAsync(rt.vm_mem, 0, 2 * per, L->stream));  // (the first round reads the mail of a round that never was: none)
+    char* p = (char*)rt.vm_mem;
+    for (int k = 0; k < 2; k++) {
+      JgVoteMail& m = rt.vm[k];
+      m.R = R, m.G = c->G, m.words = (uint32_t)wd;
+      m.q_term = (uint64_t*)p, p += RG * 8;
+      m.q_head = (uint64_t*)p, p += RG * 8;
+      m.a_term = (uint64_t*)p, p += RG * 8;
+      m.q_ctl = (uint32_t*)p, p += RG * 4;
+      m.a_ctl = (uint32_t*)p, p += RG * 4;
+      m.rowmail = (uint64_t*)p, p += R * wd * 8;
+      m.wordmail = (uint64_t*)p, p += R * wd * 8;
+    }
+  }
+  const JgVoteMail vprev = rt.vm[rt.vm_turn ^ 1u], vcur = rt.vm[rt.vm_turn];  // (last round's mail is read, this round's filled)
+  if (vwords) {
+    hipLaunchKernelGGL(k_votes_clear, dim3(std::min<uint32_t>(((size_t)R * c->G + JG_BLOCK - 1) / JG_BLOCK, 2048u)), dim3(JG_BLOCK), 0, L->stream, vcur);
+    HIPCHK(hipGetLastError());
+  }
   if (!rt.h_jobs) {
     HIPCHK(hipHostMalloc((void**)&rt.h_jobs, 6 * jg_dense_cluster::Route::JOB_SLICE, hipHostMallocDefault));
     HIPCHK(hipMalloc((void**)&rt.d_jobs, 6 * jg_dense_cluster::Route::JOB_SLICE));
   }
   static_assert(JG_MAX_REPLICAS * sizeof(JgApplyJob) <= jg_dense_cluster::Route::JOB_SLICE, "job slice too small");
   static_assert(JG_MAX_REPLICAS * sizeof(JgFollowerJob) <= jg_dense_cluster::Route::JOB_SLICE, "job slice too small");
+  static_assert(JG_MAX_REPLICAS * sizeof(JgVoteHalfJob) <= jg_dense_cluster::Route::JOB_SLICE, "job slice too small");
   auto slice_h = [&](int k) { return rt.h_jobs + (size_t)k * jg_dense_cluster::Route::JOB_SLICE; };
   auto slice_d = [&](int k) { return rt.d_jobs + (size_t)k * jg_dense_cluster::Route::JOB_SLICE; };
   // (multi: the job tables of the whole round - both sparse steps, the follower halves, the delivering pass - are
@@ -2939,7 +2974,10 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       std::vector<JgApplyJob>& jobs = votes ? jobs_v : jobs_a;
       uint32_t& widest = votes ? widest_v : widest_a;
       jg_engine* e = c->nodes[n];
-      if (!rt.n_in[n]) continue;
+      if (!rt.n_in[n]) {
+        if (vwords) e->stepped = true, e->seq++;  // (the receiving half of the vote mail is this step too: it has a number on every node)
+        continue;
+      }
       const size_t o = rt.in_off[n];
       e->stepped = true;
       e->seq++;
@@ -3056,12 +3094,21 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     return JG_OK;
   };
   if ((rc = route_jobs())) return rc;
-  if (multi) {  // slices 0-3 in one copy
+  if (vwords) {  // the vote mail's receiving half on every node: the delivered step's number, slice 4
+    for (uint32_t n = 0; n < R; n++) {
+      jg_engine* e = c->nodes[n];
+      JgVoteHalfJob j{};
+      j.d = e->dev, j.self = n, j.seq = seq_base[n] + 1u, j.step = 1u, j.need = R - 1u, j.now = now_ms;
+      if (e->seq < j.seq) return fail(JG_EDEVICE, "internal: routed round: the delivered step has no number");
+      std::memcpy(slice_h(4) + (size_t)n * sizeof(JgVoteHalfJob), &j, sizeof(j));
+    }
+  }
+  if (multi) {  // slices 0-3 in one copy (0-4 with the vote mail)
     if (!jobs_a.empty()) std::memcpy(slice_h(0), jobs_a.data(), jobs_a.size() * sizeof(JgApplyJob));
     if (!jobs_v.empty()) std::memcpy(slice_h(0) + jobs_a.size() * sizeof(JgApplyJob), jobs_v.data(), jobs_v.size() * sizeof(JgApplyJob));
     if (!jobs_b.empty()) std::memcpy(slice_h(1), jobs_b.data(), jobs_b.size() * sizeof(JgApplyJob));
     if (!fjobs.empty()) std::memcpy(slice_h(2), fjobs.data(), fjobs.size() * sizeof(JgFollowerJob));
-    HIPCHK(hipMemcpyAsync(slice_d(0), slice_h(0), 4 * jg_dense_cluster::Route::JOB_SLICE, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(slice_d(0), slice_h(0), (vwords ? 5 : 4) * jg_dense_cluster::Route::JOB_SLICE, hipMemcpyHostToDevice, st));
   }
   // -- 1. (launches) what the transport delivered last round, then this round's injected rows
   if ((rc = apply_all(0, jobs_a, widest_a))) return rc;
@@ -3073,6 +3120,12 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       hipLaunchKernelGGL(small_tiles(widest_v) ? k_apply_vote_runs_multi_small : k_apply_vote_runs_multi,
                          dim3(run_grid(widest_v), (uint32_t)jobs_v.size()), dim3(JG_BLOCK), 0, L->stream,
                          (const JgApplyJob*)slice_d(0) + jobs_a.size());
+    HIPCHK(hipGetLastError());
+  }
+  if (vwords) {  // (partitions other than the rows': a partition's mail of a round is words or rows, never both)
+    uint32_t slots = L->count_slots;
+    for (jg_engine* e : c->nodes) slots = std::min(slots, e->count_slots);
+    hipLaunchKernelGGL(k_vote_half_multi, dim3(grid_for(c->G, slots), R), dim3(JG_BLOCK), 0, L->stream, (const JgVoteHalfJob*)slice_d(4), vprev, vcur);
     HIPCHK(hipGetLastError());
   }
   if ((rc = apply_all(1, jobs_b, widest_b))) return rc;
@@ -3110,13 +3163,27 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
                        rt.cols);
   };
   bool ordered = false;
+  if (vwords) {  // the census of everything the round emitted (once: a repeated delivering pass finds it done)
+    if (!rjobs.empty())
+      hipLaunchKernelGGL(k_votes_census_rec_multi, dim3((widest_r + JG_BLOCK - 1) / JG_BLOCK, (uint32_t)rjobs.size()), dim3(JG_BLOCK), 0, st,
+                         (const JgRouteRecJob*)slice_d(3), vcur);
+    hipLaunchKernelGGL(k_votes_census_xq_multi, dim3(256, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteXqJob*)(slice_d(3) + rb), vcur);
+    HIPCHK(hipGetLastError());
+  }
   for (int attempt = 0;; attempt++) {  // (repeated once when the staging turns out too small: the pass modifies nothing)
     hipLaunchKernelGGL(k_route_clear, dim3(64), dim3(JG_BLOCK), 0, st, rt.d_count, (uint32_t)words, bk.hist, bk_clear);
     if (attempt) {  // (every attempt ends with a synchronisation - the counts - so the staging is free again)
       if ((rc = route_jobs())) return rc;
       if (multi) HIPCHK(hipMemcpyAsync(slice_d(3), slice_h(3), rb + xb, hipMemcpyHostToDevice, st));
     }
-    if (multi) {
+    if (vwords) {  // (implies multi) the delivering pass leaves the words' copies where they are; the answer words that must be rows after all
+      if (!rjobs.empty())
+        hipLaunchKernelGGL(k_route_rec_multi_words, dim3((widest_r + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS), (uint32_t)rjobs.size()),
+                           dim3(JG_BLOCK), 0, st, (const JgRouteRecJob*)slice_d(3), vcur);
+      hipLaunchKernelGGL(k_route_xq_multi_words, dim3(256, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteXqJob*)(slice_d(3) + rb), vcur);
+      hipLaunchKernelGGL(k_votes_expand_multi, dim3(std::min<uint32_t>((c->G + JG_BLOCK - 1) / JG_BLOCK, 512u), (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st,
+                         (const JgRouteXqJob*)(slice_d(3) + rb), vcur);
+    } else if (multi) {
       if (!rjobs.empty())
         hipLaunchKernelGGL(k_route_rec_multi, dim3((widest_r + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS), (uint32_t)rjobs.size()), dim3(JG_BLOCK), 0, st,
                            (const JgRouteRecJob*)slice_d(3));
@@ -3171,7 +3238,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   for (uint32_t s = 0; s < R; s++) {
     jg_engine* e = c->nodes[s];
     const uint32_t* h = rt.h_count + (size_t)s * ROUTE_WORDS;
-    if (!from[s]) continue;
+    if (!from[s] && !vwords) continue;  // (a sender whose only mail was words' copies: they leave its queue too)
     const JgRouteTable t = table(s);
     if (h[R + JG_ROUTE_KEPT] || h[R + JG_ROUTE_FSM])  // (its steps stay queued for a drain: without the delivered rows)
       for (const StepRec& r : e->recs) {
@@ -3235,6 +3302,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       e->arenas[e->cur_arena].reset();
     }
   }
+  if (vwords) rt.vm_turn ^= 1u;
   T4 = clk();
   if (trace)
     std::fprintf(stderr, "[jg route] steps+round issued %.0f us, delivering pass issued %.0f us, wait %.0f us, sort+build issued %.0f us (%u rows)\n",

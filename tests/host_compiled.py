@@ -627,11 +627,10 @@ extern "C" void hc_votes_travels(const JgVoteMail* m, uint32_t sender_id, const 
 extern "C" size_t hc_votes_expand(Host* h, const JgVoteMail* m, uint32_t s, uint32_t need, jg_msg_row* rows, uint32_t* to, uint32_t* step, uint32_t* k,
                                   size_t cap) {
   size_t n = 0;
-  jg_msg_row buf[256];
   for (uint32_t g = 0; g < m->G; g++) {
     uint32_t t = 0, st = 0, k0 = 0;
-    const uint32_t c = jg_votes_expand_group(*m, h->d, s, g, need, buf, &t, &st, &k0);
-    for (uint32_t j = 0; j < c && n < cap; j++, n++) rows[n] = buf[j], to[n] = t, step[n] = st, k[n] = k0 + j;
+    const uint32_t c = jg_votes_expand_count(*m, s, g, need, &t, &st, &k0);
+    for (uint32_t j = 0; j < c && n < cap; j++, n++) rows[n] = jg_votes_expand_row(*m, h->d.node_ids, s, g, j), to[n] = t, step[n] = st, k[n] = k0 + j;
   }
   return n;
 }

@@ -1,0 +1,62 @@
+"""OPT-IN (JG_ROUTE_VOTE_WORDS=1 in the environment, which the library reads once): the routed round with the election
+vocabulary as mailbox words (josefine_amd/csrc/jg_votes.h) against the oracle clusters that move every message as a row.
+The switch changes what TRAVELS, not what the nodes compute: every state column of every node after every round, the rows
+left for the host, the faults and the applies are those of the row transport; the number of rows the transport moved is
+smaller (that is the point, and how the test knows the switch was on).
+
+    JG_ROUTE_VOTE_WORDS=1 python -m pytest tests/test_gpu_vote_words.py -m gpu -q
+
+Without the variable the tests are skipped: the driver's `-m gpu` run measures the default path, and the other routed tests
+(which count delivered rows against the row transport) are meant to run without it.  The per-partition logic behind the
+switch is held to the oracle on the CPU (tests/test_vote_half.py, tests/test_vote_mail.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from josefine_amd import BatchedRaft, capi
+from oracle_lib import oracle_engine
+from parity import compare_snapshots, elect_all
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("JG_ROUTE_VOTE_WORDS", "0") in ("", "0"),
+                                                   reason="opt-in: set JG_ROUTE_VOTE_WORDS=1 (see the module's docstring)")]
+
+
+@pytest.mark.parametrize("R,percent,also,G,T", [(3, 3, (), 3000, 50), (5, 2, (), 3000, 50), (5, 2, (2,), 3000, 50), (3, 3, (2,), 3000, 50),
+                                                (3, 25, (1, 2), 2000, 60), (5, 25, (1, 2, 3), 2000, 60), (4, 30, (1, 2), 2000, 60),
+                                                (5, 1, (), 300000, 30)])
+def test_routed_cluster_with_the_vote_mail(R, percent, also, G, T):
+    from josefine_amd import DenseCluster as LibCluster
+    from dense_node import RoutedCluster, cluster_failure_rows
+    ora = RoutedCluster(oracle_engine, G, R, seed=5)
+    nodes = [BatchedRaft(G, R, seed=5 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
+    elect_all(nodes[0])
+    nodes[0].drain_messages(), nodes[0].drain_applies()
+    lib = LibCluster(nodes)
+    lib.set_appends(1)
+    moved = moved_as_rows = 0
+    for t in range(T):
+        inj = cluster_failure_rows(99, t, G, R, percent, also=also) if t >= 3 else [None] * R
+        if t == 20 and G <= 3000:  # something the transport must leave alone: a client request at every replica of node 2
+            inj[2] = dict(kind=np.full(G, capi.CMD_CLIENT_REQUEST, np.uint8), group=np.arange(G, dtype=np.uint32), id=np.arange(G, dtype=np.uint64) + 1000)
+        up = [None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(inj)]
+        st = lib.round_routed((t + 1) * 100, up)
+        ora.round(np.ones(G, np.uint64), inject=inj)
+        if G <= 3000 or t % 5 == 4 or t == T - 1:
+            for n in range(R):
+                compare_snapshots(nodes[n], ora.nodes[n], f"routed round {t} node {n}")
+        want = [sum(len(r) for _, r in ora.inbound[n]) for n in range(R)]
+        assert all(a <= b for a, b in zip(st["delivered"], want)), (t, st["delivered"], want)
+        moved_as_rows += sum(st["delivered"])
+        moved += sum(want)
+        for rows in up:
+            if rows is not None:
+                rows.free()
+    assert moved > 0 and moved_as_rows < moved // 2, (moved_as_rows, moved)  # (most of the mail is an election's: it went as words)
+    for n in range(R):
+        got, want = nodes[n].drain_messages(), ora.kept[n]
+        assert got.tobytes() == want.tobytes(), (n, len(got), len(want))
+        assert nodes[n].drain_faults().tobytes() == ora.nodes[n].drain_faults().tobytes()
+        assert nodes[n].drain_applies().tobytes() == ora.nodes[n].drain_applies().tobytes()
+        assert nodes[n].counters()["decisions"] == ora.nodes[n].counters()["decisions"]
+    lib.close()
