@@ -170,7 +170,7 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
             }  // (a queue that ran over is seen by the host: xq_n above xq_cap, as for jg_emit_msg's rows)
           }
         }
-        if (L.overflow) *d.err = 1;
+        if (L.overflow || L.fp != sink) *d.err = 1;  // (an election's command queues nothing for the FSM: nothing is dropped silently)
       }
     }
   }
