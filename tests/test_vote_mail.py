@@ -162,18 +162,13 @@ def test_routed_round_with_the_vote_mail_equals_the_row_transport(R, percent, al
     print(f"R={R} also={also}: {dev.in_words} rows' worth in words, {dev.in_rows} rows delivered ({dev.vote_rows_as_rows} of them votes, {dev.expanded} expanded)")
 
 
-def _row(g, kind, to_kind, to_id, frm, term, id_=0, aux=0, flag=0):
-    r = np.zeros(1, capi.MSG_DTYPE)
-    r["group"], r["kind"], r["to_kind"], r["to_id"], r["from"], r["term"], r["id"], r["aux"], r["flag"] = g, kind, to_kind, to_id, frm, term, id_, aux, flag
-    return r
-
-
 @pytest.mark.parametrize("R,seed", [(3, 1), (4, 2), (5, 3), (5, 4)])
 def test_the_transports_functions_on_random_mail(R, seed):
-    """census / travels / expand on emissions no cluster would produce together (two campaigns of one sender in a round,
-    malformed requests, answers next to rows, rows to one addressee only): for every addressee and partition EITHER
-    everything arrives as rows - then exactly the rows the plain transport delivers, answer words written out, in its
-    order - OR nothing does, and the words read back (as the receiving half reads them) say exactly those rows"""
+    """census / travels / expand on emissions no cluster would produce together (tests/vote_mail_cases.py): for every
+    addressee and partition EITHER everything arrives as rows - then exactly the rows the plain transport delivers, answer
+    words written out, in its order - OR nothing does, and the words read back (as the receiving half reads them) say
+    exactly those rows"""
+    from vote_mail_cases import check_mail, random_emissions
     G = 96
     rng = np.random.default_rng(seed)
     node = HostCompiled(G, R, seed=1, self_slots=np.zeros(G, np.uint8))
@@ -182,70 +177,8 @@ def test_the_transports_functions_on_random_mail(R, seed):
     need = R - 1
     n_words = n_rows = n_expanded = n_double = 0
     for it in range(6):
-        mail = VoteMail(R, G)
-        mail.q_term[:], mail.q_head[:], mail.a_term[:] = rng.integers(0, 1 << 60, (3, R, G), dtype=np.uint64)  # (garbage where no control word says otherwise)
-        plain = {}  # (d, g) -> list of (s, step, k, row)
-        emitted = [[] for _ in range(R)]
-        for s in range(R):
-            for g in range(G):
-                if rng.random() < 0.55:
-                    continue
-                k = {1: 0, 2: 0, 3: 0}
-                events = []
-                if rng.random() < 0.3:  # (something said before the answers)
-                    events.append(("row", 1, k[1], _row(g, capi.CMD_HEARTBEAT_RESPONSE, capi.TO_PEER, ids[(s + 1) % R], ids[s], 1, 5)))
-                    k[1] += 1
-                if rng.random() < 0.5:  # an answer word (the vote half's: step 1)
-                    n, to = int(rng.integers(1, R + 1)), int((s + 1 + rng.integers(0, R - 1)) % R)
-                    first, rest, term = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(1, 9))
-                    events.append(("word", 1, k[1], n, to, first, rest, term))
-                    k[1] += n
-                for _ in range(int(rng.choice([0, 1, 1, 1, 2, 3]))):
-                    step = int(rng.integers(1, 4))
-                    kind = rng.choice(["campaign", "campaign", "campaign", "heartbeat", "response", "ae", "odd", "oddcampaign"])
-                    term, head = int(rng.integers(1, 9)), int(rng.integers(0, 50))
-                    if kind == "campaign":
-                        for _c in range(need):
-                            events.append(("row", step, k[step], _row(g, capi.CMD_VOTE_REQUEST, capi.TO_PEERS, 0, ids[s], term, head, term)))
-                            k[step] += 1
-                    elif kind == "oddcampaign":  # R - 1 broadcasts that are not a campaign's: last_term != term
-                        for _c in range(need):
-                            events.append(("row", step, k[step], _row(g, capi.CMD_VOTE_REQUEST, capi.TO_PEERS, 0, ids[s], term, head, term + 1)))
-                            k[step] += 1
-                    elif kind == "odd":  # a request that is not a campaign's copy: to one peer, or last_term != term
-                        to_one = rng.random() < 0.5
-                        events.append(("row", step, k[step], _row(g, capi.CMD_VOTE_REQUEST, capi.TO_PEER if to_one else capi.TO_PEERS,
-                                                                   ids[(s + 1) % R] if to_one else 0, ids[s], term, head, term if to_one else term + 1)))
-                        k[step] += 1
-                    elif kind == "heartbeat":
-                        events.append(("row", step, k[step], _row(g, capi.CMD_HEARTBEAT, capi.TO_PEERS, 0, ids[s], term, head)))
-                        k[step] += 1
-                    elif kind == "response":
-                        events.append(("row", step, k[step], _row(g, capi.CMD_VOTE_RESPONSE, capi.TO_PEER, ids[(s + 1 + rng.integers(0, R - 1)) % R], ids[s], term, 0, 0,
-                                                                   int(rng.integers(0, 2)))))
-                        k[step] += 1
-                    else:
-                        events.append(("row", step, k[step], _row(g, capi.CMD_APPEND_ENTRIES, capi.TO_PEER, ids[(s + 1) % R], ids[s], term, head, 1)))
-                        k[step] += 1
-                campaigns = sum(1 for e in events if e[0] == "row" and e[3]["kind"][0] == capi.CMD_VOTE_REQUEST and e[3]["to_kind"][0] == capi.TO_PEERS
-                                and e[3]["aux"][0] == e[3]["term"][0]) // need
-                n_double += campaigns > 1
-                for e in events:
-                    if e[0] == "word":
-                        _, step, k0, n, to, first, rest, term = e
-                        mail.a_term[s, g] = term
-                        mail.a_ctl[s, g] = n | (step << 8 | k0) << 8 | first << 19 | rest << 20 | to << 21
-                        VoteMail.set_bits(mail.wordmail, to, [g])
-                        for j in range(n):
-                            plain.setdefault((to, g), []).append((s, step, k0 + j, _row(g, capi.CMD_VOTE_RESPONSE, capi.TO_PEER, ids[to], ids[s], term, 0, 0, rest if j else first)))
-                    else:
-                        _, step, kk, row = e
-                        emitted[s].append((row, step, kk))
-                        if row["kind"][0] in (capi.CMD_APPEND_ENTRIES, capi.CMD_CLIENT_REQUEST):
-                            continue
-                        for d in range(R):
-                            if d != s and (row["to_kind"][0] == capi.TO_PEERS or row["to_id"][0] == ids[d]):
-                                plain.setdefault((d, g), []).append((s, step, kk, row))
+        mail, emitted, plain, nd = random_emissions(R, G, ids, rng)
+        n_double += nd
         got = {}
         flat = []
         for s in range(R):
@@ -277,35 +210,7 @@ def test_the_transports_functions_on_random_mail(R, seed):
             n_expanded += m
             for i in range(m):
                 got.setdefault((int(to[i]), int(xr["group"][i])), []).append((s, int(st[i]), int(kk[i]), xr[i:i + 1]))
-        for (d, g), want in plain.items():
-            want = sorted(want, key=lambda e: e[:3])
-            have = sorted(got.get((d, g), []), key=lambda e: e[:3])
-            if have:  # as rows: all of them
-                assert [e[:3] for e in have] == [e[:3] for e in want], (d, g)
-                assert b"".join(e[3].tobytes() for e in have) == b"".join(e[3].tobytes() for e in want), (d, g)
-                n_rows += len(have)
-                continue
-            assert VoteMail.bits(mail.wordmail, d, G)[g] and not VoteMail.bits(mail.rowmail, d, G)[g], (d, g)
-            said = []  # the words, read as jg_vote_half_group reads them
-            for s in range(R):
-                if s == d:
-                    continue
-                qc, ac = int(mail.q_ctl[s, g]), int(mail.a_ctl[s, g])
-                qn = qc & 0xff
-                if qn:
-                    assert qn == need
-                    q_ord = ((qc >> 8) - qn * (qn - 1) // 2) // qn
-                    for j in range(qn):
-                        said.append((s, q_ord >> 8, (q_ord & 0xff) + j, _row(g, capi.CMD_VOTE_REQUEST, capi.TO_PEERS, 0, ids[s], int(mail.q_term[s, g]),
-                                                                            int(mail.q_head[s, g]), int(mail.q_term[s, g]))))
-                if ac & 0xff and (ac >> 21) & 7 == d:
-                    a_ord = (ac >> 8) & 0x7ff
-                    for j in range(ac & 0xff):
-                        said.append((s, a_ord >> 8, (a_ord & 0xff) + j, _row(g, capi.CMD_VOTE_RESPONSE, capi.TO_PEER, ids[d], ids[s], int(mail.a_term[s, g]), 0, 0,
-                                                                            (ac >> (20 if j else 19)) & 1)))
-            said = sorted(said, key=lambda e: e[:3])
-            assert [e[:3] for e in said] == [e[:3] for e in want], (d, g)
-            assert b"".join(e[3].tobytes() for e in said) == b"".join(e[3].tobytes() for e in want), (d, g)
-            n_words += len(said)
-        assert not (set(got) - set(plain))
+        got_rows = {key: [e[3] for e in sorted(v, key=lambda e: e[:3])] for key, v in got.items()}
+        nw, nr = check_mail(R, G, ids, mail, plain, got_rows, need)
+        n_words, n_rows = n_words + nw, n_rows + nr
     assert n_words > 500 and n_rows > 500 and n_expanded > 50 and n_double > 10, (n_words, n_rows, n_expanded, n_double)
