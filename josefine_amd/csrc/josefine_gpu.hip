@@ -2903,7 +2903,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   // receiving half (k_vote_half_multi) and never become rows - wherever EVERYTHING a node receives for a partition in a
   // round is such words; every other partition's mail travels as rows, as without the switch.  Fixed for a cluster's life.
   static const bool vote_words_env = std::getenv("JG_ROUTE_VOTE_WORDS") != nullptr && std::atoi(std::getenv("JG_ROUTE_VOTE_WORDS")) != 0;
-  const bool vwords = vote_words_env && multi && !c->any && R >= 2 && std::getenv("JG_ROUTE_LIBRARY_SORT") == nullptr;
+  const bool vwords = vote_words_env && multi && R >= 2 && std::getenv("JG_ROUTE_LIBRARY_SORT") == nullptr;
   if (vwords && !rt.vm_mem) {
     const size_t RG = (size_t)R * c->G, wd = ((size_t)c->G + 63) / 64;
     const size_t per = RG * (8 + 8 + 8 + 4 + 4) + 2 * R * wd * 8;

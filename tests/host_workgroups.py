@@ -50,8 +50,10 @@ namespace wg {
 enum Wait { RUN = 0, AT_BLOCK = 1, AT_WAVE = 2, DONE = 3 };
 struct Fiber {
   ucontext_t ctx;
+  void* sp = nullptr;  // (x86-64: the fiber's saved stack pointer - the switch is a dozen instructions, no system call)
   char* stack = nullptr;
   int state = DONE;
+  const void* site = nullptr;  // AT_WAVE: which shuffle / ballot (lanes of a wave that diverged wait at different ones)
   dim3 tid;
 };
 struct Wave {
@@ -65,14 +67,66 @@ static Fiber* cur = nullptr;
 static ucontext_t sched;
 static const std::function<void()>* body = nullptr;
 static dim3 block_idx, grid_dim, block_dim;
+#if defined(__x86_64__)
+// swapcontext saves the signal mask with a system call on every switch - a launch is hundreds of thousands of fibers; this
+// saves what the ABI says a call preserves and swaps the stack pointer
+extern "C" void wg_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl wg_switch
+.type wg_switch,@function
+wg_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size wg_switch,.-wg_switch
+)");
+static void* sched_sp = nullptr;
+static void to_sched() { wg_switch(&cur->sp, sched_sp); }
+static void to_fiber(Fiber& f) { wg_switch(&sched_sp, f.sp); }
 static void trampoline() {
   (*body)();
   cur->state = DONE;
-  swapcontext(&cur->ctx, &sched);
+  to_sched();
+  std::abort();  // (a finished fiber is never resumed)
 }
-static void wait(int what) {
-  cur->state = what;
-  swapcontext(&cur->ctx, &sched);
+static void prepare(Fiber& f) {
+  uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+  void** sp = (void**)top;
+  *--sp = nullptr;              // (the return address trampoline never uses: the stack is aligned as after a call)
+  *--sp = (void*)&trampoline;   // where the first switch returns to
+  for (int r = 0; r < 6; r++) *--sp = nullptr;
+  f.sp = sp;
+}
+#else
+static void to_sched() { swapcontext(&cur->ctx, &sched); }
+static void to_fiber(Fiber& f) { swapcontext(&sched, &f.ctx); }
+static void trampoline() {
+  (*body)();
+  cur->state = DONE;
+  to_sched();
+}
+static void prepare(Fiber& f) {
+  getcontext(&f.ctx);
+  f.ctx.uc_stack.ss_sp = f.stack, f.ctx.uc_stack.ss_size = STACK, f.ctx.uc_link = &sched;
+  makecontext(&f.ctx, trampoline, 0);
+}
+#endif
+static void wait(int what, const void* site = nullptr) {
+  cur->state = what, cur->site = site;
+  to_sched();
 }
 // one workgroup: every fiber to its end
 static void run_block(uint32_t n_threads) {
@@ -84,9 +138,7 @@ static void run_block(uint32_t n_threads) {
   waves.assign((n_threads + 63) / 64, Wave{});
   for (uint32_t t = 0; t < n_threads; t++) {
     Fiber& f = fibers[t];
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = f.stack, f.ctx.uc_stack.ss_size = STACK, f.ctx.uc_link = &sched;
-    makecontext(&f.ctx, trampoline, 0);
+    prepare(f);
     f.state = RUN, f.tid = dim3(t);
   }
   for (;;) {
@@ -95,7 +147,7 @@ static void run_block(uint32_t n_threads) {
       Fiber& f = fibers[t];
       if (f.state != RUN) continue;
       cur = &f, ran = true;
-      swapcontext(&sched, &f.ctx);
+      to_fiber(f);
     }
     // rendezvous: a wave's, when every live lane of it waits there; the workgroup's, when every live thread does
     bool all_block = true;
@@ -111,22 +163,22 @@ static void run_block(uint32_t n_threads) {
         if (fibers[t].state == AT_BLOCK) fibers[t].state = RUN;
       released = true;
     }
+    // (a wave's lanes that diverged wait at different rendezvous: the lanes at ONE of them - the lowest waiting lane's - go on
+    // together, with that set as the active mask, as the hardware runs one side of a branch at a time)
     for (uint32_t w = 0; w < waves.size() && !all_block; w++) {
-      bool all_wave = true, any = false;
+      const void* site = nullptr;
       uint64_t m = 0;
       for (uint32_t l = 0; l < 64 && w * 64 + l < n_threads; l++) {
-        const int s = fibers[w * 64 + l].state;
-        if (s == DONE) continue;
-        any = true;
-        all_wave = all_wave && s == AT_WAVE;
-        m |= 1ull << l;
+        const Fiber& f = fibers[w * 64 + l];
+        if (f.state != AT_WAVE) continue;
+        if (!site) site = f.site;
+        if (f.site == site) m |= 1ull << l;
       }
-      if (any && all_wave) {
-        waves[w].mask = m;
-        for (uint32_t l = 0; l < 64 && w * 64 + l < n_threads; l++)
-          if (fibers[w * 64 + l].state == AT_WAVE) fibers[w * 64 + l].state = RUN;
-        released = true;
-      }
+      if (!m) continue;
+      waves[w].mask = m;
+      for (uint32_t l = 0; l < 64 && w * 64 + l < n_threads; l++)
+        if ((m >> l) & 1ull) fibers[w * 64 + l].state = RUN;
+      released = true;
     }
     if (!ran && !released) {
       std::fprintf(stderr, "host_workgroups: deadlock in workgroup (%u, %u): live threads wait at different rendezvous\n", block_idx.x, block_idx.y);
@@ -148,11 +200,11 @@ static void launch(dim3 grid, uint32_t n_threads, F&& f) {
 }
 static inline Wave& my_wave() { return waves[cur->tid.x >> 6]; }
 // a rendezvous of the wave's live lanes around a 64-bit value per lane
-static inline void bring(uint64_t v) {
+static inline void bring(uint64_t v, const void* site) {
   my_wave().slot[cur->tid.x & 63u] = v;
-  wait(AT_WAVE);
+  wait(AT_WAVE, site);
 }
-static inline void leave() { wait(AT_WAVE); }  // (nobody's slot is overwritten before everybody has read)
+static inline void leave(const void* site) { wait(AT_WAVE, (const char*)site + 1); }  // (nobody's slot is overwritten before everybody has read)
 }  // namespace wg
 #define threadIdx (wg::cur->tid)
 #define blockIdx (wg::block_idx)
@@ -171,40 +223,45 @@ static inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 template <class T> static inline uint64_t wg_bits(T v) { static_assert(sizeof(T) <= 8, "shuffles move up to 64 bits"); uint64_t b = 0; std::memcpy(&b, &v, sizeof(T)); return b; }
 template <class T> static inline T wg_from(uint64_t b) { T v; std::memcpy(&v, &b, sizeof(T)); return v; }
-static inline uint64_t __ballot(bool x) {
-  wg::bring(x ? 1 : 0);
+__attribute__((noinline)) static uint64_t __ballot(bool x) {
+  const void* site = __builtin_return_address(0);
+  wg::bring(x ? 1 : 0, site);
   const wg::Wave& w = wg::my_wave();
   uint64_t b = 0;
   for (uint32_t l = 0; l < 64; l++)
     if (((w.mask >> l) & 1ull) && w.slot[l]) b |= 1ull << l;
-  wg::leave();
+  wg::leave(site);
   return b;
 }
-template <class T> static inline T __shfl(T v, int src, int = 64) {
-  wg::bring(wg_bits(v));
+template <class T> __attribute__((noinline)) static T __shfl(T v, int src, int = 64) {
+  const void* site = __builtin_return_address(0);
+  wg::bring(wg_bits(v), site);
   const T r = wg_from<T>(wg::my_wave().slot[src & 63]);
-  wg::leave();
+  wg::leave(site);
   return r;
 }
-template <class T> static inline T __shfl_up(T v, int off, int = 64) {
+template <class T> __attribute__((noinline)) static T __shfl_up(T v, int off, int = 64) {
   const uint32_t lane = threadIdx.x & 63u;
-  wg::bring(wg_bits(v));
+  const void* site = __builtin_return_address(0);
+  wg::bring(wg_bits(v), site);
   const T r = lane >= (uint32_t)off ? wg_from<T>(wg::my_wave().slot[lane - off]) : v;
-  wg::leave();
+  wg::leave(site);
   return r;
 }
-template <class T> static inline T __shfl_down(T v, int off, int = 64) {
+template <class T> __attribute__((noinline)) static T __shfl_down(T v, int off, int = 64) {
   const uint32_t lane = threadIdx.x & 63u;
-  wg::bring(wg_bits(v));
+  const void* site = __builtin_return_address(0);
+  wg::bring(wg_bits(v), site);
   const T r = lane + (uint32_t)off < 64u ? wg_from<T>(wg::my_wave().slot[lane + off]) : v;
-  wg::leave();
+  wg::leave(site);
   return r;
 }
-template <class T> static inline T __shfl_xor(T v, int off, int = 64) {
+template <class T> __attribute__((noinline)) static T __shfl_xor(T v, int off, int = 64) {
   const uint32_t lane = threadIdx.x & 63u;
-  wg::bring(wg_bits(v));
+  const void* site = __builtin_return_address(0);
+  wg::bring(wg_bits(v), site);
   const T r = wg_from<T>(wg::my_wave().slot[(lane ^ (uint32_t)off) & 63u]);
-  wg::leave();
+  wg::leave(site);
   return r;
 }
 static inline uint32_t __builtin_amdgcn_readlane(uint32_t v, int l) { return __shfl(v, l); }

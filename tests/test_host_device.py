@@ -1,0 +1,35 @@
+"""The engine's own translation unit on an EMULATED device (CPU; tests/host_device.py): josefine_gpu.hip - the C ABI, its
+host code and every kernel as written - compiled for the host against a stand-in for the HIP runtime in which a workgroup
+is 256 cooperative fibers, loaded by a CHILD process through JOSEFINE_GPU_LIB, and driven by the GPU suite's own tests.
+
+What runs here is what no GPU-minute was left for at the end of round 4: the routed round with the election vocabulary
+as mailbox words (JG_ROUTE_VOTE_WORDS=1, josefine_amd/csrc/jg_votes.h) THROUGH round_routed_impl - its job tables, step
+numbers, the mail's two buffers, the census before and the word-aware delivering pass inside the repeat loop, the
+exceptional queues' clean-up - against the oracle clusters that move every message as a row (tests/test_gpu_vote_words.py,
+the cases small enough for fibers).  And, so that the stand-in itself is held to something, a slice of the default path's
+GPU tests, which the real device passes."""
+import pytest
+
+import host_device
+
+
+def _run(args, env=None):
+    r = host_device.run_pytest(args, env=dict(JG_NO_GRAPH="1", **(env or {})))
+    tail = r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    assert r.returncode == 0, tail
+    return r.stdout
+
+
+def test_routed_round_with_the_vote_mail_through_the_engines_host_code():
+    """single lead (BASELINE configs[4]'s cluster) and per-partition leadership, under the switch"""
+    # (a minute of fibers; every case whose id starts with "small" runs here in five: -k small)
+    out = _run(["tests/test_gpu_vote_words.py", "-m", "gpu", "-k", "small-5-25-3-160 or small-3-25-7-160"], env=dict(JG_ROUTE_VOTE_WORDS="1"))
+    assert "2 passed" in out, out[-500:]
+
+
+def test_the_default_path_on_the_emulated_device():
+    """the stand-in held to tests the real device passes: the sparse step under the fuzzed command streams (every role, the
+    chain, elections), the dense tick against the sparse path, the T-tick kernel, device-resident rows - through the C ABI"""
+    out = _run(["tests/test_gpu_parity.py", "-m", "gpu", "-k", "test_fuzz_command_stream_parity or test_fuzz_state_aware_stream_parity or "
+                "test_dense_equals_sparse_path or test_dense_fused_ticks_parity or test_device_resident_rows_path or test_election_setup_parity"])
+    assert "22 passed" in out, out[-500:]
