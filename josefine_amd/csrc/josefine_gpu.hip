@@ -2924,7 +2924,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   }
   const JgVoteMail vprev = rt.vm[rt.vm_turn ^ 1u], vcur = rt.vm[rt.vm_turn];  // (last round's mail is read, this round's filled)
   if (vwords) {
-    hipLaunchKernelGGL(k_votes_clear, dim3(std::min<uint32_t>(((size_t)R * c->G + JG_BLOCK - 1) / JG_BLOCK, 2048u)), dim3(JG_BLOCK), 0, L->stream, vcur);
+    hipLaunchKernelGGL(k_votes_clear, dim3(std::min<uint32_t>((c->G + JG_BLOCK - 1) / JG_BLOCK, 2048u)), dim3(JG_BLOCK), 0, L->stream, vcur);
     HIPCHK(hipGetLastError());
   }
   if (!rt.h_jobs) {

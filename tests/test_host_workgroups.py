@@ -133,8 +133,8 @@ class KernelMailCluster(RoutedCluster):
         G, R = self.G, self.R
         now = self.now + dt_ms
         prev, cur = self.mail[(self.t + 1) & 1], self.mail[self.t & 1]
-        cur.q_ctl[:], cur.a_ctl[:], cur.rowmail[:], cur.wordmail[:] = 0xdeadbeef, 0xdeadbeef, ~np.uint64(0), ~np.uint64(0)
-        self.lib.hw_votes_clear(C.addressof(cur.c))
+        self.lib.hw_votes_clear(C.addressof(cur.c))  # (sparse: the control words of the partitions a wordmail bit names)
+        assert not (cur.q_ctl.any() or cur.a_ctl.any() or cur.rowmail.any() or cur.wordmail.any()), "the mail of two rounds ago was not cleared"
         seq = np.zeros(R, np.uint32)
         rc = self.lib.hw_vote_half_multi(self.handles, R, seq.ctypes.data, 1, now, C.addressof(prev.c), C.addressof(cur.c), 2)
         assert rc == 0, rc
