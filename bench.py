@@ -516,6 +516,8 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
             out["elections_won_after_failures"] = won
             out["rows_routed_per_round"] = delivered[1] / K / world
             out["rows_left_for_the_host"] = rows_left
+            out["decisions_in_timed_region"] = decisions
+            out["vote_words"] = os.environ.get("JG_ROUTE_VOTE_WORDS", "0") not in ("", "0")  # (opt-in A/B: jg_votes.h)
         print(json.dumps(out), flush=True)
     lib.close()
     if world > 1:

@@ -17,6 +17,13 @@ done
 tail -3 gpurun_out/err_words.txt
 python bench.py --cluster --failures 1 --replicas 3 --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | line routed_x3_rows
 JG_ROUTE_VOTE_WORDS=1 python bench.py --cluster --failures 1 --replicas 3 --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | line routed_x3_words
+# per-partition leadership under failures (whole groups restart, the campaigns are won through the mail)
+python bench.py --cluster --any-leader --replicas 3 --failures 1 --steps 100 --warmup 20 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('any_x3_rows', 'ms/round %.4f' % d['ms_per_step'], 'value %.4g' % d['value'], 'decisions %d' % d['decisions_in_timed_region'], 'won', d.get('elections_won_after_failures'))"
+JG_ROUTE_VOTE_WORDS=1 python bench.py --cluster --any-leader --replicas 3 --failures 1 --steps 100 --warmup 20 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('any_x3_words', 'ms/round %.4f' % d['ms_per_step'], 'value %.4g' % d['value'], 'decisions %d' % d['decisions_in_timed_region'], 'won', d.get('elections_won_after_failures'))"
 cd /tmp && export TMPDIR=/tmp
 for m in 0 1; do
   JG_ROUTE_VOTE_WORDS=$m rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/vw_$m -o x -- python /root/repo/bench.py --cluster --failures 1 --steps 50 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
