@@ -12,11 +12,15 @@ round under JG_ROUTE_VOTE_WORDS=1: job tables, step numbers, the mail's double b
 runs - through the C ABI, by the GPU suite's own tests - before a device sees it.  It says nothing about the memory
 system, about races between workgroups, or about time.
 
-One thing it does NOT reproduce: reconvergence.  The hardware brings a wave's lanes back together behind a divergent branch
-(the compiler's immediate post-dominator); here the lanes that skipped the branch run ahead to their next shuffle or ballot
-and meet there without the others.  Code that works under any active mask - the deferral bitmaps, the queues' ballots, the
-staging - comes out the same; a wave REDUCTION behind a divergent region (the decision counters: jg_wave_count adds from
-lane 0) can lose the lanes that came late.  So tests that run here compare state, rows, faults and applies, and leave the
+One thing it only approximates: reconvergence.  The hardware brings a wave's lanes back together behind a divergent branch
+(the compiler's immediate post-dominator); here the lanes that skipped the branch have run ahead to their next shuffle or
+ballot when the others stop inside it.  The scheduler lets the side go first that is still inside: the rendezvous from which
+lanes have been SEEN to come to the other one (and not the other way round), else the one that whole waves rarely reach,
+else the smaller group (tests/host_workgroups.py).  Code that works under any active mask - the deferral bitmaps, the
+queues' ballots, the staging - is indifferent; a wave REDUCTION behind a divergent region (the decision counters:
+jg_wave_count adds from lane 0) needs the right choice, and the first time a pair of rendezvous meets there is nothing to go
+by: the counters have been seen off by a few in a quarter of a million (a cold start; exact in every other run).  So
+tests that run here compare state, rows, faults and applies, and leave the exact
 decision counters to the device (JG_EMULATED_DEVICE=1 tells them)."""
 import os
 import subprocess

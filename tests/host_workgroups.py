@@ -8,7 +8,8 @@ other.  tests/host_compiled.py runs one lane at a time and says what it cannot d
 TEST INFRASTRUCTURE, and nothing else: built at test time into a temporary directory from josefine_amd/csrc AS IT STANDS
 (JG_BLOCK = 256, no textual patch), nothing under josefine_amd/ can reach it.  It is not a model of the memory system or
 of parallel interleavings: workgroups run one after the other and a fiber runs until its next rendezvous, so a data race
-that needs two waves to interleave between rendezvous is not found here.  What it is for: the launch-level logic of
+that needs two waves to interleave between rendezvous is not found here; and reconvergence behind a divergent branch is a
+heuristic (the scheduler's comment), where the hardware has the compiler's post-dominators.  What it is for: the launch-level logic of
 kernels that no GPU-minute was left for (the routed round with the election vocabulary as mailbox words, jg_votes.h) is
 held to the numpy statement of the same pass before a device sees it."""
 import ctypes as C
@@ -33,6 +34,7 @@ WG_SHIM = r'''
 #include <cstring>
 #include <algorithm>
 #include <functional>
+#include <unordered_map>
 #include <vector>
 #include <ucontext.h>
 #define __device__
@@ -54,6 +56,7 @@ struct Fiber {
   char* stack = nullptr;
   int state = DONE;
   const void* site = nullptr;  // AT_WAVE: which shuffle / ballot (lanes of a wave that diverged wait at different ones)
+  const void* prev_site = nullptr;
   dim3 tid;
 };
 struct Wave {
@@ -63,6 +66,33 @@ struct Wave {
 static const size_t STACK = 256 * 1024;
 static std::vector<Fiber> fibers;
 static std::vector<Wave> waves;
+struct SiteStat { uint64_t whole = 0, part = 0; };  // releases of this rendezvous: with every live lane of the wave / with some
+static std::unordered_map<const void*, SiteStat> sites;
+static std::unordered_map<const void*, std::vector<const void*>> succ;  // rendezvous -> the ones a lane came to next
+static bool reaches(const void* a, const void* b) {
+  std::vector<const void*> todo{a};
+  std::unordered_map<const void*, bool> seen;
+  seen[a] = true;
+  while (!todo.empty()) {
+    const void* x = todo.back();
+    todo.pop_back();
+    auto it = succ.find(x);
+    if (it == succ.end()) continue;
+    for (const void* y : it->second) {
+      if (y == b) return true;
+      if (!seen[y]) seen[y] = true, todo.push_back(y);
+    }
+  }
+  return false;
+}
+struct SiteDump {  // JG_WG_STATS=1: the rendezvous that were released with a part of a wave, at exit (addresses: addr2line -e <the library>)
+  ~SiteDump() {
+    if (!std::getenv("JG_WG_STATS")) return;
+    for (const auto& kv : sites)
+      if (kv.second.part) std::fprintf(stderr, "[wg] site %p whole %llu part %llu\n", kv.first, (unsigned long long)kv.second.whole, (unsigned long long)kv.second.part);
+  }
+};
+static SiteDump site_dump;
 static Fiber* cur = nullptr;
 static ucontext_t sched;
 static const std::function<void()>* body = nullptr;
@@ -126,6 +156,13 @@ static void prepare(Fiber& f) {
 #endif
 static void wait(int what, const void* site = nullptr) {
   cur->state = what, cur->site = site;
+  if (what == AT_WAVE) {
+    if (cur->prev_site && cur->prev_site != site) {
+      std::vector<const void*>& v = succ[cur->prev_site];
+      if (std::find(v.begin(), v.end(), site) == v.end()) v.push_back(site);
+    }
+    cur->prev_site = site;
+  }
   to_sched();
 }
 // one workgroup: every fiber to its end
@@ -139,7 +176,7 @@ static void run_block(uint32_t n_threads) {
   for (uint32_t t = 0; t < n_threads; t++) {
     Fiber& f = fibers[t];
     prepare(f);
-    f.state = RUN, f.tid = dim3(t);
+    f.state = RUN, f.tid = dim3(t), f.prev_site = nullptr;
   }
   for (;;) {
     bool ran = false, live = false;
@@ -163,18 +200,53 @@ static void run_block(uint32_t n_threads) {
         if (fibers[t].state == AT_BLOCK) fibers[t].state = RUN;
       released = true;
     }
-    // (a wave's lanes that diverged wait at different rendezvous: the lanes at ONE of them - the lowest waiting lane's - go on
-    // together, with that set as the active mask, as the hardware runs one side of a branch at a time)
+    // A wave's lanes that diverged wait at different rendezvous: the lanes at ONE of them go on together, with that set as
+    // the active mask, as the hardware runs one side of a branch at a time.  WHICH one: the hardware brings the lanes back
+    // together behind the branch (the compiler's post-dominator), so the lanes that skipped it wait there for the others -
+    // here they have run ahead to their next rendezvous, and releasing them first would let them meet without the others.
+    // The side that is still INSIDE the branch is recognised by its record: a rendezvous inside a divergent region is
+    // rarely reached by a whole wave, one behind the join nearly always is (sites: share of the releases that were whole
+    // waves; unknown sites first, ties to the lower address - code that comes earlier).
     for (uint32_t w = 0; w < waves.size() && !all_block; w++) {
       const void* site = nullptr;
-      uint64_t m = 0;
+      uint64_t live_m = 0;
+      std::vector<const void*> cand;
+      std::vector<uint32_t> lanes_at;
       for (uint32_t l = 0; l < 64 && w * 64 + l < n_threads; l++) {
         const Fiber& f = fibers[w * 64 + l];
+        if (f.state != DONE) live_m |= 1ull << l;
         if (f.state != AT_WAVE) continue;
-        if (!site) site = f.site;
-        if (f.site == site) m |= 1ull << l;
+        size_t i = 0;
+        while (i < cand.size() && cand[i] != f.site) i++;
+        if (i == cand.size()) cand.push_back(f.site), lanes_at.push_back(0);
+        lanes_at[i]++;
       }
-      if (!m) continue;
+      if (cand.size() == 1) site = cand[0];
+      else if (cand.size() > 1) {
+        // (1) a rendezvous from which lanes have been seen to come to another candidate, and not the other way round, is
+        // the earlier one: its lanes are inside the branch the others skipped
+        std::vector<bool> later(cand.size(), false);
+        for (size_t i = 0; i < cand.size(); i++)
+          for (size_t j = 0; j < cand.size(); j++)
+            if (i != j && reaches(cand[j], cand[i]) && !reaches(cand[i], cand[j])) later[i] = true;
+        double best = 2.0;
+        uint32_t best_n = 0;
+        for (size_t i = 0; i < cand.size(); i++) {
+          if (later[i]) continue;
+          const SiteStat& st = sites[cand[i]];
+          // (2) the share of whole-wave releases, unknown sites first; (3) the smaller group (the likely path is the straight one); (4) the address
+          const double share = st.whole + st.part ? (double)st.whole / (double)(st.whole + st.part) : -1.0;
+          if (!site || share < best || (share == best && (lanes_at[i] < best_n || (lanes_at[i] == best_n && cand[i] < site))))
+            site = cand[i], best = share, best_n = lanes_at[i];
+        }
+        if (!site) site = cand[0];  // (a cycle of "later": cannot be, but nobody waits forever)
+      }
+      if (!site) continue;
+      uint64_t m = 0;
+      for (uint32_t l = 0; l < 64 && w * 64 + l < n_threads; l++)
+        if (fibers[w * 64 + l].state == AT_WAVE && fibers[w * 64 + l].site == site) m |= 1ull << l;
+      SiteStat& st = sites[site];
+      (m == live_m ? st.whole : st.part)++;
       waves[w].mask = m;
       for (uint32_t l = 0; l < 64 && w * 64 + l < n_threads; l++)
         if ((m >> l) & 1ull) fibers[w * 64 + l].state = RUN;
