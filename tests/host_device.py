@@ -16,10 +16,11 @@ One thing it only approximates: reconvergence.  The hardware brings a wave's lan
 (the compiler's immediate post-dominator); here the lanes that skipped the branch have run ahead to their next shuffle or
 ballot when the others stop inside it.  The scheduler lets the side go first that is still inside: the rendezvous from which
 lanes have been SEEN to come to the other one (and not the other way round), else the one that whole waves rarely reach,
-else the smaller group (tests/host_workgroups.py).  Code that works under any active mask - the deferral bitmaps, the
+else the higher address - cold code is laid out last (tests/host_workgroups.py).  Code that works under any active mask - the deferral bitmaps, the
 queues' ballots, the staging - is indifferent; a wave REDUCTION behind a divergent region (the decision counters:
 jg_wave_count adds from lane 0) needs the right choice, and the first time a pair of rendezvous meets there is nothing to go
-by: the counters have been seen off by a few in a quarter of a million (a cold start; exact in every other run).  So
+by: the leader tick's counters have been seen off by 20 in 316 930 (tests/test_dense_node.py::test_dense_leader_tick_parity;
+exact in every other test run here).  So
 tests that run here compare state, rows, faults and applies, and leave the exact
 decision counters to the device (JG_EMULATED_DEVICE=1 tells them)."""
 import os

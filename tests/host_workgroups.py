@@ -234,9 +234,9 @@ static void run_block(uint32_t n_threads) {
         for (size_t i = 0; i < cand.size(); i++) {
           if (later[i]) continue;
           const SiteStat& st = sites[cand[i]];
-          // (2) the share of whole-wave releases, unknown sites first; (3) the smaller group (the likely path is the straight one); (4) the address
+          // (2) the share of whole-wave releases, unknown sites first; (3) the higher address (the unlikely side of a branch is laid out last)
           const double share = st.whole + st.part ? (double)st.whole / (double)(st.whole + st.part) : -1.0;
-          if (!site || share < best || (share == best && (lanes_at[i] < best_n || (lanes_at[i] == best_n && cand[i] < site))))
+          if (!site || share < best || (share == best && (cand[i] > site)))
             site = cand[i], best = share, best_n = lanes_at[i];
         }
         if (!site) site = cand[0];  // (a cycle of "later": cannot be, but nobody waits forever)
