@@ -97,7 +97,7 @@ static Fiber* cur = nullptr;
 static ucontext_t sched;
 static const std::function<void()>* body = nullptr;
 static dim3 block_idx, grid_dim, block_dim;
-#if defined(__x86_64__)
+#if defined(__x86_64__) && !defined(WG_UCONTEXT)
 // swapcontext saves the signal mask with a system call on every switch - a launch is hundreds of thousands of fibers; this
 // saves what the ABI says a call preserves and swaps the stack pointer
 extern "C" void wg_switch(void** save_sp, void* load_sp);
@@ -526,6 +526,8 @@ def build():
     open(cpp, "w").write(WG_HARNESS)
     cc = ["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-Wno-unused-function", "-Wno-unused-variable", "-Wl,-Bsymbolic", "-fvisibility=hidden",
           f"-I{os.path.join(tmp, 'shim')}", f"-I{CSRC}", f"-I{os.path.join(ROOT, 'include')}", f"-I{tmp}"]
+    if os.environ.get("JG_HOST_SANITIZE"):  # (as tests/host_compiled.py; the sanitizer follows swapcontext, not a hand-written switch)
+        cc += ["-g", "-fno-omit-frame-pointer", "-DWG_UCONTEXT", f"-fsanitize={os.environ['JG_HOST_SANITIZE']}", "-fno-sanitize-recover=all"]
     subprocess.run(cc + ["-o", so, cpp], check=True)
     lib = C.CDLL(so)
     lib.hw_selftest.restype = None
