@@ -34,14 +34,17 @@
 #define JG_VOTE_ORD_BITS 11u  // step (3) << 8 | emission index (8)
 struct JgVoteMail {
   uint32_t R, G, words;  // words = ceil(G / 64): a bitmap's length
-  uint64_t* q_term;      // [R][G] by sender: valid where q_ctl counts copies
+  // per (partition, sender slot), PARTITION-major ([G][R], jg_vote_at): the receiving half reads one partition's words of
+  // every sender - R neighbours, one or two 32-byte sectors per column instead of R sectors G entries apart
+  uint64_t* q_term;      // valid where q_ctl counts copies
   uint64_t* q_head;
-  uint32_t* q_ctl;       // [R][G] copies (bits 0-7) | the sum of their ords (bits 8-31); CLEARED every round
-  uint64_t* a_term;      // [R][G] by sender: valid where a_ctl says so
-  uint32_t* a_ctl;       // [R][G] n (bits 0-7, 0: none) | ord of the first (8-18) | first (19) | rest (20) | to (21-23); CLEARED every round
-  uint64_t* rowmail;     // [R][words] by addressee; CLEARED every round
-  uint64_t* wordmail;    // [R][words] by addressee; CLEARED every round
+  uint32_t* q_ctl;       // copies (bits 0-7) | the sum of their ords (bits 8-31); clear at the start of a round
+  uint64_t* a_term;      // valid where a_ctl says so
+  uint32_t* a_ctl;       // n (bits 0-7, 0: none) | ord of the first (8-18) | first (19) | rest (20) | to (21-23); clear at the start of a round
+  uint64_t* rowmail;     // [R][words] by addressee; clear at the start of a round
+  uint64_t* wordmail;    // [R][words] by addressee; clear at the start of a round
 };
+__host__ __device__ __forceinline__ size_t jg_vote_at(const JgVoteMail& m, uint32_t sender, uint32_t g) { return (size_t)g * m.R + sender; }
 __host__ __device__ inline uint32_t jg_vote_actl(uint32_t n, uint32_t ord, uint32_t first, uint32_t rest, uint32_t to) {
   return n | ord << 8 | (first & 1u) << 19 | (rest & 1u) << 20 | to << 21;
 }
@@ -61,7 +64,7 @@ __device__ inline void jg_votes_census_row(const JgVoteMail& m, uint32_t src, ui
   const uint32_t g = r.group;
   const uint64_t bit = 1ull << (g & 63u);
   if (jg_vote_row_is_request_copy(r, sender_id, k)) {
-    const size_t i = (size_t)src * m.G + g;
+    const size_t i = jg_vote_at(m, src, g);
     const uint32_t old = atomicAdd(&m.q_ctl[i], 1u | ((step & 7u) << 8 | k) << 8);
     if ((old & 0xffu) == 0) {  // (every copy says the same; a second campaign's would not - and is not a word: the count)
       m.q_term[i] = r.term, m.q_head[i] = r.id;
@@ -76,7 +79,7 @@ __device__ inline bool jg_votes_as_rows(const JgVoteMail& m, uint32_t d, uint32_
   if ((m.rowmail[(size_t)d * m.words + (g >> 6)] >> (g & 63u)) & 1ull) return true;
   for (uint32_t s = 0; s < m.R; s++) {
     if (s == d) continue;
-    const uint32_t c = m.q_ctl[(size_t)s * m.G + g];
+    const uint32_t c = m.q_ctl[jg_vote_at(m, s, g)];
     if ((c & 0xffu) && !jg_vote_q_ok(c, need)) return true;
   }
   return false;
@@ -88,7 +91,7 @@ __device__ __forceinline__ bool jg_votes_row_travels(const JgVoteMail& m, uint32
 // sender s's answer word for partition g when its addressee's partition takes rows after all: how many rows it stands
 // for (0: none, or the word travels), to whom, and the emission key of the first - row j's is (*step, *k0 + j) ...
 __device__ inline uint32_t jg_votes_expand_count(const JgVoteMail& m, uint32_t s, uint32_t g, uint32_t need, uint32_t* to, uint32_t* step, uint32_t* k0) {
-  const uint32_t c = m.a_ctl[(size_t)s * m.G + g], n = c & 0xffu;
+  const uint32_t c = m.a_ctl[jg_vote_at(m, s, g)], n = c & 0xffu;
   if (!n) return 0;
   *to = (c >> 21) & 7u;
   if (!jg_votes_as_rows(m, *to, g, need)) return 0;
@@ -98,7 +101,7 @@ __device__ inline uint32_t jg_votes_expand_count(const JgVoteMail& m, uint32_t s
 }
 // ... and row j of them (member_id: the NodeId of every slot)
 __device__ inline jg_msg_row jg_votes_expand_row(const JgVoteMail& m, const uint32_t* member_id, uint32_t s, uint32_t g, uint32_t j) {
-  const size_t i = (size_t)s * m.G + g;
+  const size_t i = jg_vote_at(m, s, g);
   const uint32_t c = m.a_ctl[i];
   jg_msg_row r;
   r.group = g, r.kind = JG_CMD_VOTE_RESPONSE, r.to_kind = JG_TO_PEER, r.pad = 0;
@@ -112,7 +115,7 @@ __device__ inline jg_msg_row jg_votes_expand_row(const JgVoteMail& m, const uint
 // taken (election_status evaluations).  `step`: this step's number within the round (the ord of what it emits)
 __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32_t self, const JgVoteMail& in, const JgVoteMail& out, uint32_t need,
                                               uint64_t now, uint32_t seq, uint32_t step) {
-  const uint32_t G = d.G, R = d.R;
+  const uint32_t R = d.R;
   if (!((in.wordmail[(size_t)self * in.words + (g >> 6)] >> (g & 63u)) & 1ull)) return 0;
   if (jg_votes_as_rows(in, self, g, need)) return 0;  // (its mail came as rows)
   JgLane L;
@@ -127,7 +130,7 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
   uint32_t o_n = 0, o_at = 0, o_first = 0, o_rest = 0, o_to = 0;
   for (uint32_t s = 0; s < R; s++) {
     if (s == self) continue;
-    const size_t i = (size_t)s * G + g;
+    const size_t i = jg_vote_at(in, s, g);
     const uint32_t qc = in.q_ctl[i], ac = in.a_ctl[i];
     const uint32_t q_n = qc & 0xffu, a_n = (ac & 0xffu) && ((ac >> 21) & 7u) == self ? (ac & 0xffu) : 0u;
     if (!q_n && !a_n) continue;
@@ -175,7 +178,7 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
     }
   }
   if (o_n) {
-    const size_t i = (size_t)self * G + g;
+    const size_t i = jg_vote_at(out, self, g);
     out.a_term[i] = o_term;
     out.a_ctl[i] = jg_vote_actl(o_n, (step & 7u) << 8 | o_at, o_first, o_rest, o_to);
     atomicOr((unsigned long long*)&out.wordmail[(size_t)o_to * out.words + (g >> 6)], 1ull << (g & 63u));
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_votes_clear(JgVoteMail m) {
       for (uint32_t d = 0; d < m.R; d++) u |= m.wordmail[(size_t)d * m.words + w];
     __syncthreads();
     if (g < m.G && ((u >> (g & 63u)) & 1ull))
-      for (uint32_t s = 0; s < m.R; s++) m.q_ctl[(size_t)s * m.G + g] = 0, m.a_ctl[(size_t)s * m.G + g] = 0;
+      for (uint32_t s = 0; s < m.R; s++) m.q_ctl[jg_vote_at(m, s, g)] = 0, m.a_ctl[jg_vote_at(m, s, g)] = 0;
     const uint32_t lane = threadIdx.x & 63u;
     if (w < m.words && lane < m.R) m.wordmail[(size_t)lane * m.words + w] = 0, m.rowmail[(size_t)lane * m.words + w] = 0;
   }

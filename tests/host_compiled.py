@@ -816,11 +816,11 @@ class VoteMail:
 
     def __init__(self, R, G):
         self.R, self.G, self.words = R, G, (G + 63) // 64
-        self.q_term, self.q_head, self.a_term = (np.zeros((R, G), np.uint64) for _ in range(3))
-        self.q_ctl, self.a_ctl = np.zeros((R, G), np.uint32), np.zeros((R, G), np.uint32)
+        # the device's layout is partition-major ([G][R], jg_vote_at); the tests index [sender, partition]: transposed views
+        self._base = [np.zeros((G, R), t) for t in (np.uint64, np.uint64, np.uint32, np.uint64, np.uint32)]
+        self.q_term, self.q_head, self.q_ctl, self.a_term, self.a_ctl = (b.T for b in self._base)
         self.rowmail, self.wordmail = np.zeros((R, self.words), np.uint64), np.zeros((R, self.words), np.uint64)
-        self.c = _JgVoteMail(R, G, self.words, self.q_term.ctypes.data, self.q_head.ctypes.data, self.q_ctl.ctypes.data, self.a_term.ctypes.data,
-                             self.a_ctl.ctypes.data, self.rowmail.ctypes.data, self.wordmail.ctypes.data)
+        self.c = _JgVoteMail(R, G, self.words, *[b.ctypes.data for b in self._base], self.rowmail.ctypes.data, self.wordmail.ctypes.data)
 
     def clear(self):  # (k_votes_clear: the control words and the bitmaps; the term / head columns keep their garbage)
         self.q_ctl[:], self.a_ctl[:], self.rowmail[:], self.wordmail[:] = 0, 0, 0, 0
