@@ -383,7 +383,12 @@ __global__ __launch_bounds__(JG_BLOCK) void k_votes_expand_multi(const JgRouteXq
   for (uint32_t g0 = blockIdx.x * JG_BLOCK; g0 < vm.G; g0 += gridDim.x * JG_BLOCK) {  // (block-uniform trip count)
     const uint32_t g = g0 + threadIdx.x;
     uint32_t to = 0, step = 0, k0 = 0;
-    const uint32_t n = g < vm.G ? jg_votes_expand_count(vm, t.src, g, t.R - 1u, &to, &step, &k0) : 0u;
+    // (an answer word has to be rows only where its addressee's partition has both kinds of mail: a wave skips 64
+    // partitions without such an addressee on the bitmaps, before it touches a control word)
+    uint64_t both = 0;
+    if (g < vm.G)
+      for (uint32_t d = 0; d < vm.R; d++) both |= vm.wordmail[(size_t)d * vm.words + (g >> 6)] & vm.rowmail[(size_t)d * vm.words + (g >> 6)];
+    const uint32_t n = (g < vm.G && ((both >> (g & 63u)) & 1ull)) ? jg_votes_expand_count(vm, t.src, g, t.R - 1u, &to, &step, &k0) : 0u;
     const JgRouteSpot sp = jg_route_reserve(t, n);
     for (uint32_t j = 0, pos = sp.pos; j < n; j++, pos++) {
       jg_route_note(pd_lo, pd_hi, to);

@@ -12,7 +12,7 @@
 //             VoteRequest{term, candidate_id = id(s), last_term = term, head} (Q5).  Its rows are emitted as ever (the
 //             exceptional queue); the transport's census (jg_votes_census_row) counts the copies into q_ctl and the first
 //             one it sees writes (q_term, q_head).  A count other than R - 1 (a second campaign in one round) makes the
-//             partition's mail travel as rows for every addressee.
+//             partition's mail travel as rows for every addressee (k_votes_validate, behind the census).
 //   answer    sender s answers a campaign of node `to` (follower.rs:219-246, candidate.rs:66-84): n VoteResponse{from =
 //             id(s), term, granted}, the first `first`, every further one `rest`.  Written by the vote half itself
 //             (single writer), never rows unless the addressee's partition has to take rows (jg_votes_expand_group).
@@ -74,15 +74,20 @@ __device__ inline void jg_votes_census_row(const JgVoteMail& m, uint32_t src, ui
   }
   for (uint32_t b = dests; b; b &= b - 1) atomicOr((unsigned long long*)&m.rowmail[(size_t)(__ffs(b) - 1) * m.words + (g >> 6)], (unsigned long long)bit);
 }
-// does partition g's mail for addressee d travel as rows?  (final once the census is)
-__device__ inline bool jg_votes_as_rows(const JgVoteMail& m, uint32_t d, uint32_t g, uint32_t need) {
-  if ((m.rowmail[(size_t)d * m.words + (g >> 6)] >> (g & 63u)) & 1ull) return true;
+// After the census, once per partition that has word mail: copies that are not a campaign's (Q5: config.nodes.len() of
+// them - a second campaign of one sender in a round, or a sender that is no candidate.rs) make the partition's mail
+// travel as rows for every addressee of that sender.  (`need` = R - 1; 0: any count is taken - host tests only.)
+__device__ inline void jg_votes_validate_group(const JgVoteMail& m, uint32_t g, uint32_t need) {
   for (uint32_t s = 0; s < m.R; s++) {
-    if (s == d) continue;
     const uint32_t c = m.q_ctl[jg_vote_at(m, s, g)];
-    if ((c & 0xffu) && !jg_vote_q_ok(c, need)) return true;
+    if (!(c & 0xffu) || jg_vote_q_ok(c, need)) continue;
+    for (uint32_t d = 0; d < m.R; d++)
+      if (d != s) atomicOr((unsigned long long*)&m.rowmail[(size_t)d * m.words + (g >> 6)], 1ull << (g & 63u));
   }
-  return false;
+}
+// does partition g's mail for addressee d travel as rows?  (final once the census and the validation are: one bit)
+__device__ __forceinline__ bool jg_votes_as_rows(const JgVoteMail& m, uint32_t d, uint32_t g, uint32_t /*need*/ = 0) {
+  return (m.rowmail[(size_t)d * m.words + (g >> 6)] >> (g & 63u)) & 1ull;
 }
 // the delivering pass: does this row go to addressee d as a row?
 __device__ __forceinline__ bool jg_votes_row_travels(const JgVoteMail& m, uint32_t sender_id, const jg_msg_row& r, uint32_t k, uint32_t d, uint32_t need) {
@@ -204,6 +209,14 @@ __global__ __launch_bounds__(JG_BLOCK) void k_vote_half_multi(const JgVoteHalfJo
     dec += jg_vote_half_group(j.d, g, j.self, in, out, j.need, j.now, j.seq, j.step);
   }
   if (dec) (void)__hip_atomic_fetch_add(&j.d.blk_decisions[blockIdx.x], (uint64_t)dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the validation (jg_votes_validate_group) of the partitions a wordmail bit names: a wave skips 64 partitions on R words
+__global__ __launch_bounds__(JG_BLOCK) void k_votes_validate(JgVoteMail m, uint32_t need) {
+  for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < m.G; g += gridDim.x * JG_BLOCK) {
+    uint64_t u = 0;
+    for (uint32_t d = 0; d < m.R; d++) u |= m.wordmail[(size_t)d * m.words + (g >> 6)];
+    if ((u >> (g & 63u)) & 1ull) jg_votes_validate_group(m, g, need);
+  }
 }
 // a round's mail cleared for its next use - where it was written: a control word is only ever written together with a
 // wordmail bit of its partition (the census's first copy, the receiving half's answer), so the union of the addressees'

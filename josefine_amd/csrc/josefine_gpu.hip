@@ -3168,6 +3168,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       hipLaunchKernelGGL(k_votes_census_rec_multi, dim3((widest_r + JG_BLOCK - 1) / JG_BLOCK, (uint32_t)rjobs.size()), dim3(JG_BLOCK), 0, st,
                          (const JgRouteRecJob*)slice_d(3), vcur);
     hipLaunchKernelGGL(k_votes_census_xq_multi, dim3(256, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteXqJob*)(slice_d(3) + rb), vcur);
+    hipLaunchKernelGGL(k_votes_validate, dim3(std::min<uint32_t>((c->G + JG_BLOCK - 1) / JG_BLOCK, 2048u)), dim3(JG_BLOCK), 0, st, vcur, R - 1u);
     HIPCHK(hipGetLastError());
   }
   for (int attempt = 0;; attempt++) {  // (repeated once when the staging turns out too small: the pass modifies nothing)

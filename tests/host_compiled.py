@@ -613,7 +613,11 @@ extern "C" void hc_votes_census(const JgVoteMail* m, uint32_t src, uint32_t send
                                 const uint32_t* dests, size_t n) {
   for (size_t i = 0; i < n; i++) jg_votes_census_row(*m, src, sender_id, rows[i], step[i], k[i], dests[i]);
 }
-// ... which of them (per addressee: a bit mask within `dests`) still travel as rows once the census is final ...
+// ... the validation of the counts, once the census is complete ...
+extern "C" void hc_votes_validate(const JgVoteMail* m, uint32_t need) {
+  for (uint32_t g = 0; g < m->G; g++) jg_votes_validate_group(*m, g, need);
+}
+// ... which of them (per addressee: a bit mask within `dests`) still travel as rows after that ...
 extern "C" void hc_votes_travels(const JgVoteMail* m, uint32_t sender_id, const jg_msg_row* rows, const uint32_t* k, const uint32_t* dests, size_t n,
                                  uint32_t need, uint32_t* out) {
   for (size_t i = 0; i < n; i++) {
@@ -792,6 +796,8 @@ def build():
     lib.hc_vote_half.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
     lib.hc_votes_census.restype = None
     lib.hc_votes_census.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_size_t]
+    lib.hc_votes_validate.restype = None
+    lib.hc_votes_validate.argtypes = [C.c_void_p, C.c_uint32]
     lib.hc_votes_travels.restype = None
     lib.hc_votes_travels.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 3 + [C.c_size_t, C.c_uint32, C.c_void_p]
     lib.hc_votes_expand.restype = C.c_size_t

@@ -437,6 +437,7 @@ VIS int hw_route(const WgRoute* rt, const WgSender* snd, const JgVoteMail* vm, u
     if (!rjobs.empty())
       wg::launch(dim3((widest_r + JG_BLOCK - 1) / JG_BLOCK, (uint32_t)rjobs.size()), JG_BLOCK, [&] { k_votes_census_rec_multi(rjobs.data(), m); });
     wg::launch(dim3(xgrid, (uint32_t)xjobs.size()), JG_BLOCK, [&] { k_votes_census_xq_multi(xjobs.data(), m); });
+    wg::launch(dim3(2), JG_BLOCK, [&] { k_votes_validate(m, R - 1u); });
   }
   wg::launch(dim3(2), JG_BLOCK, [&] { k_route_clear(rt->count, (uint32_t)words, bk.hist, bk_clear); });
   const dim3 rgrid((widest_r + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS), (uint32_t)rjobs.size());

@@ -103,6 +103,7 @@ class MailCluster(RoutedCluster):
             self.kept[s] = np.concatenate([self.kept[s], rows[d == 0]])
             lib.hc_votes_census(C.addressof(cur.c), s, int(self.member_ids[s]), rows.ctypes.data, step.ctypes.data, k.ctypes.data, d.ctypes.data, len(rows))
             flat.append((rows, step, k, d))
+        lib.hc_votes_validate(C.addressof(cur.c), self.need)
         for s in range(R):
             if flat[s] is not None:
                 rows, step, k, d = flat[s]
@@ -195,6 +196,7 @@ def test_the_transports_functions_on_random_mail(R, seed):
             d = np.ascontiguousarray(d)
             lib.hc_votes_census(C.addressof(mail.c), s, int(ids[s]), rows.ctypes.data, step.ctypes.data, k.ctypes.data, d.ctypes.data, len(rows))
             flat.append((rows, step, k, d))
+        lib.hc_votes_validate(C.addressof(mail.c), need)
         for s in range(R):
             rows, step, k, d = flat[s]
             travels = np.zeros(len(rows), np.uint32)
