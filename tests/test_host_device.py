@@ -33,3 +33,16 @@ def test_the_default_path_on_the_emulated_device():
     out = _run(["tests/test_gpu_parity.py", "-m", "gpu", "-k", "test_fuzz_command_stream_parity or test_fuzz_state_aware_stream_parity or "
                 "test_dense_equals_sparse_path or test_dense_fused_ticks_parity or test_device_resident_rows_path or test_election_setup_parity"])
     assert "22 passed" in out, out[-500:]
+
+
+def test_smoke_on_the_emulated_device():
+    """__graft_entry__.smoke() as the driver calls it on the MI355X, here against the emulated build: elections through the
+    general kernel, eight dense ticks of the ragged stream, six ticks through the Apply surface - every column, row and
+    word against the oracle (the two seconds that say the entry point itself is not what breaks on the GPU box)"""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(JOSEFINE_GPU_LIB=host_device.build(), JG_EMULATED_DEVICE="1", JG_NO_GRAPH="1")
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], env=e, capture_output=True, text=True, cwd=host_device.ROOT, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
