@@ -10,7 +10,8 @@ sets for a CHILD process - nothing under josefine_amd/ builds it, looks for it o
 fails loudly without the gfx950 library.  What it is for: host-side wiring that no GPU-minute was left for (the routed
 round under JG_ROUTE_VOTE_WORDS=1: job tables, step numbers, the mail's double buffering, the repeated delivering pass)
 runs - through the C ABI, by the GPU suite's own tests - before a device sees it.  It says nothing about the memory
-system, about races between workgroups, or about time.
+system, about races between workgroups, or about time.  (Host threads - the pipelined drain's worker, the router's pool -
+are serialised on the one emulated device: every call happens at the call, one at a time.)
 
 One thing it only approximates: reconvergence.  The hardware brings a wave's lanes back together behind a divergent branch
 (the compiler's immediate post-dominator); here the lanes that skipped the branch have run ahead to their next shuffle or
@@ -45,9 +46,14 @@ enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureMode
 #define hipHostMallocDefault 0u
 #define hipEventDisableTiming 2u
 #define hipStreamNonBlocking 1u
+#include <mutex>
 namespace wg {
 static wgGraphT* capturing = nullptr;  // (one stream captures at a time: the engine's closed loop)
+// the engine's host threads (the pipelined drain's worker, an event loop's tasks) share ONE device here: whatever they
+// ask of it happens at the call, one call at a time - which is an order the streams and events of the real runtime allow
+static std::recursive_mutex mu;
 template <class F> static inline void op(F&& f) {
+  std::lock_guard<std::recursive_mutex> lock(mu);
   if (capturing) capturing->ops.push_back(std::function<void()>(f));
   else f();
 }
@@ -66,7 +72,11 @@ template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return 
 template <class T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) { return wg_alloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
-static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+  std::lock_guard<std::recursive_mutex> lock(wg::mu);
+  std::memmove(d, s, n);
+  return hipSuccess;
+}
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) {
   wg::op([=] { std::memmove(d, s, n); });
   return hipSuccess;
@@ -99,7 +109,11 @@ static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode
 }
 static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = wg::capturing; wg::capturing = nullptr; return *g ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipGraphInstantiate(hipGraphExec_t* x, hipGraph_t g, void*, void*, size_t) { *x = new wgGraphT(*g); return hipSuccess; }
-static inline hipError_t hipGraphLaunch(hipGraphExec_t x, hipStream_t) { for (auto& f : x->ops) f(); return hipSuccess; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t x, hipStream_t) {
+  std::lock_guard<std::recursive_mutex> lock(wg::mu);
+  for (auto& f : x->ops) f();
+  return hipSuccess;
+}
 static inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
 static inline hipError_t hipGraphExecDestroy(hipGraphExec_t x) { delete x; return hipSuccess; }
 // a launch: every workgroup, one after the other, now (or when the captured graph is replayed)
