@@ -20,8 +20,9 @@ lanes have been SEEN to come to the other one (and not the other way round), els
 else the higher address - cold code is laid out last (tests/host_workgroups.py).  Code that works under any active mask - the deferral bitmaps, the
 queues' ballots, the staging - is indifferent; a wave REDUCTION behind a divergent region (the decision counters:
 jg_wave_count adds from lane 0) needs the right choice, and the first time a pair of rendezvous meets there is nothing to go
-by: the leader tick's counters have been seen off by 20 in 316 930 (tests/test_dense_node.py::test_dense_leader_tick_parity;
-exact in every other test run here).  So
+by: the leader tick's counters were off by 20 in 316 930 in the FIRST tick of a fresh process
+(tests/test_dense_node.py::test_dense_leader_tick_parity; the same forty ticks again in that process: exact; exact in every
+other test run here).  So
 tests that run here compare state, rows, faults and applies, and leave the exact
 decision counters to the device (JG_EMULATED_DEVICE=1 tells them)."""
 import os
