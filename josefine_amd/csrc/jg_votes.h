@@ -1,10 +1,12 @@
 // jg_votes.h - the ELECTION vocabulary as mailbox words (DESIGN.md "What comes next").
 //
 // OPT-IN: a routed round uses this only under JG_ROUTE_VOTE_WORDS=1 (josefine_gpu.hip::round_routed_impl); the default
-// path does not launch anything in this file.  The per-group logic was developed against the oracle on the HOST
-// (tests/host_compiled.py compiles it with the device's state machine; tests/test_vote_half.py, tests/test_vote_mail.py),
-// so that the GPU-minutes go to the integration and the memory system, not to the semantics.  What the words say is in
-// tests/election_words.py (numpy), held there to the rows the routed clusters really exchange.
+// path does not launch anything in this file.  Built when round 4's GPU-minutes were spent, so held to the oracle on the
+// HOST three ways: lane by lane in the device's state machine compiled for the host (tests/host_compiled.py;
+// tests/test_vote_half.py, tests/test_vote_mail.py), as kernels on a stand-in with a workgroup's semantics
+// (tests/test_host_workgroups.py), and through round_routed_impl itself on an emulated device (tests/test_host_device.py) -
+// so that the next GPU-minutes go to the memory system, not to the semantics (profiles/micro/ab_vote_words.sh is the A/B).
+// What the words say is in tests/election_words.py (numpy), held there to the rows the routed clusters really exchange.
 //
 // One round's vote traffic, per SENDER slot s and partition g (JgVoteMail: two of them, a round reads the last one's
 // and fills its own):
@@ -15,7 +17,7 @@
 //             partition's mail travel as rows for every addressee (k_votes_validate, behind the census).
 //   answer    sender s answers a campaign of node `to` (follower.rs:219-246, candidate.rs:66-84): n VoteResponse{from =
 //             id(s), term, granted}, the first `first`, every further one `rest`.  Written by the vote half itself
-//             (single writer), never rows unless the addressee's partition has to take rows (jg_votes_expand_group).
+//             (single writer), never rows unless the addressee's partition has to take rows (jg_votes_expand_count / _row).
 //   ord       where a stretch begins in the sender's emission order of the round: step << 8 | emission index (a sender
 //             that answers and campaigns within one round sends both; the transport's order is (sender slot, step, index))
 // and per ADDRESSEE d two bitmaps over the partitions: rowmail[d] - a row that is not such a word is on its way to d

@@ -1,7 +1,7 @@
 """The election vocabulary as mailbox words, with the TRANSPORT's side in the device's own functions (CPU): a routed cluster
 of host-compiled nodes (tests/host_compiled.py) in which every emitted row goes through jg_votes.h's census
 (jg_votes_census_row), the delivering pass asks jg_votes_row_travels per row and addressee, the answer words a partition
-cannot take are expanded back to rows (jg_votes_expand_group), and the receiving half (jg_vote_half_group) reads the packed
+cannot take are expanded back to rows (jg_votes_expand_count / _row), and the receiving half (jg_vote_half_group) reads the packed
 mail of the round before - i.e. the routed round under JG_ROUTE_VOTE_WORDS=1 with the staging and its ordering played in
 numpy - against the same cluster over oracle engines in which every message is a row: every column of every node after
 every round, the rows delivered and the rows kept."""
