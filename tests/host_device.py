@@ -168,6 +168,8 @@ def build():
     cxx = os.environ.get("JG_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
     cc = [cxx, "-std=c++17", "-O1", "-shared", "-fPIC", "-pthread", "-x", "c++", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
           f"-I{os.path.join(tmp, 'shim')}", f"-I{CSRC}", f"-I{os.path.join(ROOT, 'include')}", os.path.join(CSRC, "josefine_gpu.hip"), "-o", so]
+    if os.environ.get("JG_HOST_SANITIZE"):  # (as tests/host_compiled.py; clang's runtime: LD_PRELOAD its libclang_rt.asan-x86_64.so for the child's python)
+        cc += ["-g", "-fno-omit-frame-pointer", "-DWG_UCONTEXT", f"-fsanitize={os.environ['JG_HOST_SANITIZE']}", "-fno-sanitize-recover=all", "-shared-libsan"]
     r = subprocess.run(cc, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-6000:]
     _path = so
