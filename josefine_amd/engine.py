@@ -47,7 +47,12 @@ def device_api() -> capi.Api:
             raise ImportError(
                 f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        _device_api = capi.Api(_LIB_PATH, "jg_")
+        api = capi.Api(_LIB_PATH, "jg_")
+        # (tests/host_device.py compiles the engine for the host against an emulated runtime and marks that build: it is
+        # test infrastructure, loaded by the tests' child processes only - never a way to run the product without a GPU)
+        if hasattr(api.lib, "jg_emulated_device") and os.environ.get("JG_EMULATED_DEVICE") != "1":
+            raise ImportError(f"{_LIB_PATH} is the tests' emulated-device build, not the gfx950 engine. There is no CPU fallback.")
+        _device_api = api
     return _device_api
 
 

@@ -46,3 +46,17 @@ def test_smoke_on_the_emulated_device():
     e.update(JOSEFINE_GPU_LIB=host_device.build(), JG_EMULATED_DEVICE="1", JG_NO_GRAPH="1")
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], env=e, capture_output=True, text=True, cwd=host_device.ROOT, timeout=600)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_the_product_refuses_the_emulated_build():
+    """the emulated build is the tests': pointed at it without saying so (JG_EMULATED_DEVICE=1, which only the tests' child
+    processes set), josefine_amd fails loudly - there is no way to run the product without the gfx950 library"""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.pop("JG_EMULATED_DEVICE", None)
+    e.update(JOSEFINE_GPU_LIB=host_device.build())
+    r = subprocess.run([sys.executable, "-c", "from josefine_amd import BatchedRaft; BatchedRaft(4, 1)"], env=e, capture_output=True, text=True, cwd=host_device.ROOT,
+                       timeout=300)
+    assert r.returncode != 0 and "emulated-device build" in r.stderr and "no CPU fallback" in r.stderr, r.stderr[-1500:]
