@@ -347,7 +347,7 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
                          self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
     L = nodes[0]
     api = L.api
-    lib = DenseCluster(nodes, lead=None)
+    lib = DenseCluster(nodes, lead=None, vote_words=bool(args.vote_words))
     lib.set_appends(0)
     g = np.arange(G, dtype=np.int64)
     leader_of = (g * R // G) if args.leadership == "blocked" else g % R
@@ -517,7 +517,7 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
             out["rows_routed_per_round"] = delivered[1] / K / world
             out["rows_left_for_the_host"] = rows_left
             out["decisions_in_timed_region"] = decisions
-            out["vote_words"] = os.environ.get("JG_ROUTE_VOTE_WORDS", "0") not in ("", "0")  # (opt-in A/B: jg_votes.h)
+            out["vote_words"] = bool(args.vote_words)  # (JG_CLUSTER_OPT_VOTE_WORDS: jg_votes.h)
         print(json.dumps(out), flush=True)
     lib.close()
     if world > 1:
@@ -552,7 +552,7 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
     elect_all(L)
     L.drain_messages(), L.drain_applies()
     api = L.api
-    lib = DenseCluster(nodes)
+    lib = DenseCluster(nodes, vote_words=bool(args.vote_words))
     lib.set_appends(1)
     # the failure trace is resident in HBM before the timed region: per round and node one group-sorted batch
     failed = np.zeros(G, bool)
@@ -653,7 +653,7 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
             "per_rank": per_rank,
             "rows_routed_per_round": delivered[1] / K / world,
             "decisions_in_timed_region": decisions,
-            "vote_words": os.environ.get("JG_ROUTE_VOTE_WORDS", "0") not in ("", "0"),  # (opt-in A/B: jg_votes.h; rows_routed_per_round counts rows only)
+            "vote_words": bool(args.vote_words),  # (JG_CLUSTER_OPT_VOTE_WORDS: jg_votes.h; rows_routed_per_round counts rows only)
             "roofline": {"bound": "hbm", "achieved": alg / round_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / round_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel": f"one round: k_leader_node_tick<{R}> + {R - 1} x k_follower_tick_dense + slow kernels "
@@ -1011,6 +1011,8 @@ def main():
     ap.add_argument("--any-leader", action="store_true",
                     help="with --cluster: per-partition leadership (JG_CLUSTER_ANY_LEADER) - leaders elected through the device transport on "
                          "every node, every node runs both halves over the cluster's mailbox columns")
+    ap.add_argument("--vote-words", type=int, choices=[0, 1], default=0,
+                    help="--cluster with --failures: JG_CLUSTER_OPT_VOTE_WORDS - an election's traffic as mailbox words (csrc/jg_votes.h) instead of rows")
     ap.add_argument("--leadership", choices=["blocked", "interleaved"], default="blocked",
                     help="with --any-leader: node g*R/G (contiguous blocks: what an adapter that numbers its partitions by preferred "
                          "leader gets) or node g %% R leads partition g")

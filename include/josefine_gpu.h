@@ -35,8 +35,8 @@
 extern "C" {
 #endif
 
-#define JG_ABI_VERSION 5u /* v5: jg_step_node = arrival-order Apply (fsm_tx: Apply / Notify / Apply per partition), JG_CLUSTER_ANY_LEADER,
-                             jg_dense_cluster_withdraw_appends, JG_COL_UNCHECKED, JG_COL_UPLOAD_NOW */
+#define JG_ABI_VERSION 6u /* v5: jg_step_node = arrival-order Apply (fsm_tx: Apply / Notify / Apply per partition), JG_CLUSTER_ANY_LEADER,
+                             jg_dense_cluster_withdraw_appends, JG_COL_UNCHECKED, JG_COL_UPLOAD_NOW; v6: jg_dense_cluster_set_option */
 #define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
 #define JG_CHAIN_WINDOW 8u  /* chain segments (gaps / forks) per group besides the main run */
 #define JG_MAX_INFLIGHT 5u  /* src/raft/progress.rs:117                                    */
@@ -570,6 +570,15 @@ typedef struct jg_dense_cluster jg_dense_cluster;
 #define JG_CLUSTER_ANY_LEADER 0xFFFFFFFFu
 int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t lead, jg_dense_cluster** out);
 void jg_dense_cluster_destroy(jg_dense_cluster* c);
+/* Per-cluster options (fixed before the cluster's first routed round; JG_EINVAL afterwards or for an unknown option).
+ *   JG_CLUSTER_OPT_VOTE_WORDS (0 / 1): jg_dense_cluster_round_routed moves an ELECTION's traffic - a campaign's
+ *     VoteRequest broadcasts (candidate.rs:24-45) and the VoteResponses they are answered with (follower.rs:219-246,
+ *     candidate.rs:66-113) - as mailbox words per (partition, sender) read by a dense receiving half instead of as rows
+ *     through the row transport, wherever EVERYTHING a node receives for a partition in a round is such traffic; what the
+ *     nodes compute, emit and keep for the host is the row transport's, bit for bit (jg_route_stats.delivered counts rows
+ *     only and is smaller).  Needs nodes that share the cluster's stream (one device) and R >= 2; otherwise ignored. */
+enum { JG_CLUSTER_OPT_VOTE_WORDS = 1 };
+int jg_dense_cluster_set_option(jg_dense_cluster* c, uint32_t option, uint64_t value);
 /* ClientRequests every group appends per round (leader.rs:177-197): the same number for all groups,
  * or (per_group != NULL) one value per group from host memory.  (JG_CLUSTER_ANY_LEADER: offered to whoever owns the
  * group that round; a group nobody leads is offered nothing.) */

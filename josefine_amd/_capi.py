@@ -9,8 +9,9 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 CLUSTER_ANY_LEADER = 0xFFFFFFFF
+CLUSTER_OPT_VOTE_WORDS = 1
 MAX_REPLICAS = 8
 CHAIN_WINDOW = 8
 MAX_INFLIGHT = 5
@@ -252,6 +253,7 @@ class Api:
         "submit_commit": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_uint32]),
         "dense_cluster_create": (C.c_int, [C.POINTER(_P), C.c_uint32, C.c_uint32, C.POINTER(_P)]),
         "dense_cluster_destroy": (None, [_P]),
+        "dense_cluster_set_option": (C.c_int, [_P, C.c_uint32, C.c_uint64]),
         "dense_cluster_set_appends": (C.c_int, [_P, C.c_uint64, _P]),
         "dense_cluster_withdraw_appends": (C.c_int, [_P, _P, C.c_uint32]),
         "dense_cluster_rounds": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32]),
@@ -298,6 +300,6 @@ HEADER_SYMBOLS = [
     "jg_step_dense_leader", "jg_step_dense_follower", "jg_chain_compact", "jg_chain_compact_resident", "jg_drain_compacted", "jg_sync", "jg_stream_wait",
     "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_drain_prefetch", "jg_drain_flush", "jg_drain_wait", "jg_read_state", "jg_get_counters",
     "jg_device_alloc", "jg_device_free", "jg_device_upload", "jg_device_download",
-    "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_dense_cluster_create", "jg_dense_cluster_destroy", "jg_dense_cluster_set_appends", "jg_dense_cluster_withdraw_appends", "jg_dense_cluster_rounds", "jg_dense_cluster_mailboxes", "jg_dense_cluster_round_routed", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",
+    "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_dense_cluster_create", "jg_dense_cluster_destroy", "jg_dense_cluster_set_option", "jg_dense_cluster_set_appends", "jg_dense_cluster_withdraw_appends", "jg_dense_cluster_rounds", "jg_dense_cluster_mailboxes", "jg_dense_cluster_round_routed", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",
     "jg_step_node", "jg_node_outbox_view", "jg_submit_reserve", "jg_submit_commit", "jg_node_inbox_columns",
 ]

@@ -211,6 +211,7 @@ struct JgLane {
                       // 2: the same, but AppendResponse / HeartbeatResponse are captured below;
                       // 3: the same, but a leader Tick's Heartbeat is captured (cap_hbc) and its AppendEntries
                       //    go straight into the outbox block cap_ae (k_dense_slow: no row buffer in scratch)
+                      // 4: the same as 1, but the VoteResponses to one requester fold into cap_ack / cap_hbc (jg_votes.h)
   uint32_t xq_k;      // emission index within this step
   uint64_t cap_ack, cap_hbc;  // follower half of the dense node tick: outbox row of this group
   uint32_t cap_has;
@@ -403,6 +404,25 @@ __device__ inline void jg_emit_msg(const JgDev& d, JgLane& L, uint8_t kind, uint
     if (kind == JG_CMD_APPEND_ENTRIES) {  // to one peer: (range start key, number of blocks)
       const int r = jg_slot_of(d, to_id);
       if (r >= 0) L.cap_ae[(size_t)r * d.G + L.g] = JG_AE(id, aux);
+      return;
+    }
+  }
+  if (L.xq_on == 4 && kind == JG_CMD_VOTE_RESPONSE && to_kind == JG_TO_PEER && id == 0 && aux == 0 && L.xq_k < 256u) {
+    // the vote mail's receiving half (jg_votes.h): the VoteResponses this node gives to ONE requester, back to back in its
+    // emission order, fold into its answer word - cap_ack: their term, cap_hbc: n | index of the first << 8 | first
+    // answer << 19 | every further answer << 20 | addressee slot << 21 (jg_vote_actl with the step left out)
+    const int to = jg_slot_of(d, to_id);
+    const uint32_t n = (uint32_t)L.cap_hbc & 0xffu;
+    if (to >= 0 && !n) {
+      L.cap_ack = term;
+      L.cap_hbc = 1u | L.xq_k << 8 | (uint32_t)(flag & 1u) << 19 | (uint32_t)to << 21;
+      L.xq_k++;
+      return;
+    }
+    if (to >= 0 && (uint32_t)to == (((uint32_t)L.cap_hbc >> 21) & 7u) && term == L.cap_ack && L.xq_k == (((uint32_t)L.cap_hbc >> 8) & 0xffu) + n && n < 255u &&
+        (n == 1u || (uint32_t)(flag & 1u) == (((uint32_t)L.cap_hbc >> 20) & 1u))) {
+      L.cap_hbc = (((uint32_t)L.cap_hbc & ~(1u << 20)) | (uint32_t)(flag & 1u) << 20) + 1u;
+      L.xq_k++;
       return;
     }
   }

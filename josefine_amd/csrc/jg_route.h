@@ -27,6 +27,7 @@
 struct JgRouteTable {
   uint32_t R, src;                      // members, the sending member's index
   uint32_t member_id[JG_MAX_REPLICAS];  // NodeId of member n
+  uint32_t src_id, pad;                 // = member_id[src] (a dynamic index into a by-value copy of the table would put it in scratch)
   uint32_t group_bits;                  // bits of a group index
   uint32_t ord_bits;                    // bits of the emission-index field
   uint32_t cap;                         // entries of the staging below
@@ -57,7 +58,7 @@ __device__ __forceinline__ uint32_t jg_route_dests(const jg_msg_row& r, const Jg
 template <bool WORDS>
 __device__ __forceinline__ uint32_t jg_route_dests_rows(const jg_msg_row& r, const JgRouteTable& t, uint32_t k, const JgVoteMail& vm) {
   uint32_t m = jg_route_dests(r, t);
-  if (WORDS && m && jg_vote_row_is_request_copy(r, t.member_id[t.src], k))
+  if (WORDS && m && jg_vote_row_is_request_copy(r, t.src_id, k))
     for (uint32_t b = m; b; b &= b - 1)
       if (!jg_votes_as_rows(vm, (uint32_t)__ffs(b) - 1u, r.group, t.R - 1u)) m &= ~(b & (~b + 1u));
   return m;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_rec_multi_words(const JgRout
 }
 // the census of the same slots (jg_votes.h), before anything is delivered
 __global__ __launch_bounds__(JG_BLOCK) void k_votes_census_rec_multi(const JgRouteRecJob* __restrict__ jobs, JgVoteMail vm) {
-  const JgRouteRecJob j = jobs[blockIdx.y];
+  const JgRouteRecJob& j = jobs[blockIdx.y];  // (a by-value copy went to scratch: 168 B per lane)
   const uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x;
   if (i >= j.n) return;
   const uint32_t cnt = j.msg_cnt[i];
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_xq_multi_words(const JgRoute
 }
 // the census of the same queues (jg_votes.h), before anything is delivered
 __global__ __launch_bounds__(JG_BLOCK) void k_votes_census_xq_multi(const JgRouteXqJob* __restrict__ jobs, JgVoteMail vm) {
-  const JgRouteXqJob j = jobs[blockIdx.y];
+  const JgRouteXqJob& j = jobs[blockIdx.y];
   const uint32_t n = min(*j.xq_n, j.xq_cap);
   for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < n; i += gridDim.x * JG_BLOCK) {
     const JgXqRec q = j.xq[i];
@@ -375,32 +376,44 @@ __global__ __launch_bounds__(JG_BLOCK) void k_votes_census_xq_multi(const JgRout
     jg_votes_census_row(vm, j.t.src, j.t.member_id[j.t.src], q.row, (q.seq - j.seq_base) & 7u, q.k, jg_route_dests(q.row, j.t));
   }
 }
+#if JG_BLOCK % 64 == 0
 // the answer words whose addressee's partition takes rows after all: staged as the rows they stand for (blockIdx.y = the
-// sender; its table comes with its queue's job).  Rare: written from the lanes that found them.
+// sender; its table comes with its queue's job).  Rare - an answer word has to be rows only where its addressee's
+// partition has BOTH kinds of mail - so the pass runs over the bitmaps: a workgroup takes JG_VOTE_CHUNK words of
+// OR_d (wordmail[d] & rowmail[d]), a chunk without a bit costs nothing more (no reservation: the pass took 50 us of a
+// round that had nothing to expand), and the lanes take the set bits (JgBitChunk, jg_votes.h).
 __global__ __launch_bounds__(JG_BLOCK) void k_votes_expand_multi(const JgRouteXqJob* __restrict__ jobs, JgVoteMail vm) {
   const JgRouteTable t = jobs[blockIdx.y].t;
+  __shared__ JgBitChunk s;
   uint64_t pd_lo = 0, pd_hi = 0, kd_lo = 0, kd_hi = 0;
-  for (uint32_t g0 = blockIdx.x * JG_BLOCK; g0 < vm.G; g0 += gridDim.x * JG_BLOCK) {  // (block-uniform trip count)
-    const uint32_t g = g0 + threadIdx.x;
-    uint32_t to = 0, step = 0, k0 = 0;
-    // (an answer word has to be rows only where its addressee's partition has both kinds of mail: a wave skips 64
-    // partitions without such an addressee on the bitmaps, before it touches a control word)
+  const uint32_t n_chunks = (vm.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK;
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {  // (block-uniform trip counts)
+    const uint32_t w = c * JG_VOTE_CHUNK + threadIdx.x;
     uint64_t both = 0;
-    if (g < vm.G)
-      for (uint32_t d = 0; d < vm.R; d++) both |= vm.wordmail[(size_t)d * vm.words + (g >> 6)] & vm.rowmail[(size_t)d * vm.words + (g >> 6)];
-    const uint32_t n = (g < vm.G && ((both >> (g & 63u)) & 1ull)) ? jg_votes_expand_count(vm, t.src, g, t.R - 1u, &to, &step, &k0) : 0u;
-    const JgRouteSpot sp = jg_route_reserve(t, n);
-    for (uint32_t j = 0, pos = sp.pos; j < n; j++, pos++) {
-      jg_route_note(pd_lo, pd_hi, to);
-      jg_route_note_kind(kd_lo, kd_hi, to, JG_CMD_VOTE_RESPONSE);
-      if (pos >= sp.lim) continue;  // (the host sees the cursor above the segment, grows the staging and repeats the pass)
-      t.key[pos] = jg_route_key(t, to, g, step, k0 + j);
-      t.idx[pos] = pos;
-      t.row[pos] = jg_votes_expand_row(vm, t.member_id, t.src, g, j);
+    if (threadIdx.x < JG_VOTE_CHUNK && w < vm.words)
+      for (uint32_t d = 0; d < vm.R; d++) both |= vm.wordmail[(size_t)d * vm.words + w] & vm.rowmail[(size_t)d * vm.words + w];
+    const uint32_t total = jg_chunk_scan(s, both);
+    for (uint32_t t0 = 0; t0 < total; t0 += JG_BLOCK) {  // (the reservation is the workgroup's)
+      const uint32_t i = t0 + threadIdx.x;
+      uint32_t g = 0, n = 0, to = 0, step = 0, k0 = 0;
+      if (i < total) {
+        g = c * JG_VOTE_CHUNK * 64u + jg_chunk_pick(s, i);
+        n = jg_votes_expand_count(vm, t.src, g, t.R - 1u, &to, &step, &k0);
+      }
+      const JgRouteSpot sp = jg_route_reserve(t, n);
+      for (uint32_t j = 0, pos = sp.pos; j < n; j++, pos++) {
+        jg_route_note(pd_lo, pd_hi, to);
+        jg_route_note_kind(kd_lo, kd_hi, to, JG_CMD_VOTE_RESPONSE);
+        if (pos >= sp.lim) continue;  // (the host sees the cursor above the segment, grows the staging and repeats the pass)
+        t.key[pos] = jg_route_key(t, to, g, step, k0 + j);
+        t.idx[pos] = pos;
+        t.row[pos] = jg_votes_expand_row(vm, t.member_id, t.src, g, j);
+      }
     }
   }
   jg_route_tally(t, pd_lo, pd_hi, 0, JG_ROUTE_KEPT, 0, kd_lo, kd_hi);
 }
+#endif
 
 // sorted staging -> the command columns k_apply_rows consumes
 struct JgRouteCols {

@@ -32,6 +32,7 @@
 // exceptional queue with their emission index, so that words and rows merge back into the reference's emission order.
 #pragma once
 #include "jg_device.h"
+#include "jg_sparse.h"  // jg_block_exclusive_scan
 
 #define JG_VOTE_ORD_BITS 11u  // step (3) << 8 | emission index (8)
 struct JgVoteMail {
@@ -60,7 +61,7 @@ __device__ __forceinline__ bool jg_vote_row_is_request_copy(const jg_msg_row& r,
 }
 // the transport's census, once per emitted row of the round (sender slot `src`, the row's step of the round and its
 // emission index; `dests`: the members it is addressed to, jg_route_dests) - BEFORE anything is delivered
-__device__ inline void jg_votes_census_row(const JgVoteMail& m, uint32_t src, uint32_t sender_id, const jg_msg_row& r, uint32_t step, uint32_t k,
+__device__ __forceinline__ void jg_votes_census_row(const JgVoteMail& m, uint32_t src, uint32_t sender_id, const jg_msg_row& r, uint32_t step, uint32_t k,
                                            uint32_t dests) {
   if (!dests) return;
   const uint32_t g = r.group;
@@ -113,13 +114,33 @@ __device__ inline jg_msg_row jg_votes_expand_row(const JgVoteMail& m, const uint
   jg_msg_row r;
   r.group = g, r.kind = JG_CMD_VOTE_RESPONSE, r.to_kind = JG_TO_PEER, r.pad = 0;
   r.flag = (uint8_t)((c >> (j ? 20 : 19)) & 1u);
-  r.to_id = member_id[(c >> 21) & 7u], r.from = member_id[s];
+  r.to_id = 0, r.from = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < JG_MAX_REPLICAS; k++) {  // (no dynamic index: the caller's table is a by-value copy and would go to scratch)
+    if (k == ((c >> 21) & 7u)) r.to_id = member_id[k];
+    if (k == s) r.from = member_id[k];
+  }
   r.term = m.a_term[i], r.id = 0, r.aux = 0;
   return r;
 }
 
+// every field of a lane that a command can change (what jg_store writes): two lanes that agree here are the same replica
+__device__ __forceinline__ bool jg_lane_same_state(const JgLane& a, const JgLane& b) {
+  return a.term == b.term && a.commit == b.commit && a.head == b.head && a.id_gen == b.id_gen && a.run_hi == b.run_hi &&
+         a.election_time == b.election_time && a.heartbeat_time == b.heartbeat_time && a.mword == b.mword && a.mbase == b.mbase &&
+         a.flags == b.flags && a.voted_for == b.voted_for && a.leader_id == b.leader_id && a.election_timeout == b.election_timeout &&
+         a.rng_draws == b.rng_draws && a.queued == b.queued && a.votes == b.votes;
+}
+#define JG_KINDS_VOTES ((1u << JG_CMD_VOTE_REQUEST) | (1u << JG_CMD_VOTE_RESPONSE))
 // one partition of one node: `in` is the last round's mail, `out` this round's; returns the number of quorum decisions
-// taken (election_status evaluations).  `step`: this step's number within the round (the ord of what it emits)
+// taken (election_status evaluations).  `step`: this step's number within the round (the ord of what it emits).
+// What a copy emits goes where jg_emit_msg's mode 4 puts it: the VoteResponses to one requester into the lane's answer
+// word, everything else (a second requester's answers, the Heartbeat of elect(), candidate.rs:108-113) onto the
+// exceptional queue with its emission index - no row buffer.  A stretch is `copies` applications of ONE command (from the
+// second answer on: `rest`), and jg_apply is a function of (replica state, command): a copy that left the replica as it
+// found it says what every further copy does - nothing to the state, the same emission, the same decisions - so the rest
+// of the stretch is accounted for without being run (a voter's 2nd ... R-1st refusal, a candidate's 3rd ... overwrite
+// of one voter's `false`: half of a campaign's applications).
 __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32_t self, const JgVoteMail& in, const JgVoteMail& out, uint32_t need,
                                               uint64_t now, uint32_t seq, uint32_t step) {
   const uint32_t R = d.R;
@@ -130,11 +151,10 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
   const JgLane O = L;
   L.now = now;
   L.seq = seq;
-  jg_msg_row buf[3];  // (an election's command emits at most two rows - the answer; DROP + the Heartbeat of elect(): prepare_rows' bound for these kinds - and one to spare)
-  jg_fsm_row sink[2];
-  uint32_t k_emit = 0;  // emission index within this node's step for the partition
-  uint64_t o_term = 0;
-  uint32_t o_n = 0, o_at = 0, o_first = 0, o_rest = 0, o_to = 0;
+  L.xq_on = 4, L.xq_k = 0;  // (xq_k: the emission index within this node's step for the partition)
+  L.cap_ack = 0, L.cap_hbc = 0;
+  L.mp = L.mend = nullptr;
+  L.fp = L.fend = nullptr;  // (an election's command queues nothing for the FSM: a row would raise L.overflow)
   for (uint32_t s = 0; s < R; s++) {
     if (s == self) continue;
     const size_t i = jg_vote_at(in, s, g);
@@ -145,51 +165,38 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
     const uint32_t q_ord = q_n ? ((qc >> 8) - q_n * (q_n - 1u) / 2u) / q_n : 0u;  // (the copies' ords are consecutive: candidate.rs:24-44 is one loop)
     const uint32_t a_ord = (ac >> 8) & ((1u << JG_VOTE_ORD_BITS) - 1u);
     const bool ans_first = q_n && a_n && a_ord < q_ord;
+    JgCmd cmd;
+    cmd.from = d.node_ids[s];
     for (int pass = 0; pass < 2; pass++) {
       const bool do_ans = (pass == 0) == (ans_first || !q_n);
       if (do_ans ? !a_n : !q_n) continue;
       const uint32_t copies = do_ans ? a_n : q_n;
+      if (do_ans) cmd.kind = JG_CMD_VOTE_RESPONSE, cmd.term = in.a_term[i], cmd.id = 0, cmd.aux = 0;
+      else cmd.kind = JG_CMD_VOTE_REQUEST, cmd.term = in.q_term[i], cmd.id = in.q_head[i], cmd.aux = cmd.term, cmd.flag = 0;
       for (uint32_t c = 0; c < copies; c++) {
-        JgCmd cmd;
-        cmd.from = d.node_ids[s];
-        if (do_ans) {
-          cmd.kind = JG_CMD_VOTE_RESPONSE, cmd.term = in.a_term[i], cmd.id = 0, cmd.aux = 0;
-          cmd.flag = (ac >> (c ? 20 : 19)) & 1u;
-        } else {
-          cmd.kind = JG_CMD_VOTE_REQUEST, cmd.term = in.q_term[i], cmd.id = in.q_head[i], cmd.aux = in.q_term[i], cmd.flag = 0;
-        }
-        L.mp = buf, L.mend = buf + 3;
-        L.fp = sink, L.fend = sink + 2;
-        jg_apply<JG_KINDS_ELECTION>(d, L, cmd, nullptr, nullptr);
-        for (const jg_msg_row* r = buf; r != L.mp; r++, k_emit++) {
-          const int to = (r->kind == JG_CMD_VOTE_RESPONSE && r->to_kind == JG_TO_PEER) ? jg_slot_of(d, r->to_id) : -1;
-          bool folded = false;
-          if (to >= 0 && r->id == 0 && r->aux == 0 && k_emit < 256u) {
-            if (!o_n) {
-              o_term = r->term, o_n = 1, o_at = k_emit, o_first = r->flag, o_rest = 0, o_to = (uint32_t)to, folded = true;
-            } else if ((uint32_t)to == o_to && r->term == o_term && k_emit == o_at + o_n && o_n < 255u && (o_n == 1 || r->flag == o_rest)) {
-              o_rest = r->flag, o_n++, folded = true;
-            }
-          }
-          if (!folded) {  // a row after all: the exceptional queue, with its place in the emission order
-            const uint32_t q = atomicAdd(d.xq_n, 1u);
-            if (q < d.xq_cap) {
-              JgXqRec x;
-              x.row = *r, x.seq = seq, x.k = k_emit;
-              d.xq[q] = x;
-            }  // (a queue that ran over is seen by the host: xq_n above xq_cap, as for jg_emit_msg's rows)
-          }
-        }
-        if (L.overflow || L.fp != sink) *d.err = 1;  // (an election's command queues nothing for the FSM: nothing is dropped silently)
+        if (do_ans) cmd.flag = (ac >> (c ? 20 : 19)) & 1u;
+        const JgLane P = L;
+        jg_apply<JG_KINDS_VOTES>(d, L, cmd, nullptr, nullptr);
+        const uint32_t rem = copies - 1u - c;
+        if (!rem || (do_ans && !c) || !jg_lane_same_state(L, P)) continue;  // (the first answer may differ from the rest)
+        // every further copy repeats this one; what it emitted: nothing, or one answer that folded into the word
+        const uint32_t rows = L.xq_k - P.xq_k, n = (uint32_t)L.cap_hbc & 0xffu;
+        const bool folded = rows == 1u && n == ((uint32_t)P.cap_hbc & 0xffu) + 1u && n >= 2u;  // (n >= 2: `rest` is this copy's answer)
+        if (rows && !(folded && n + rem <= 255u && L.xq_k + rem <= 256u)) continue;  // (rows of its own: run every copy)
+        if (folded) L.cap_hbc += rem, L.xq_k += rem;
+        L.decisions += rem * (L.decisions - P.decisions);
+        break;
       }
     }
   }
-  if (o_n) {
+  if ((uint32_t)L.cap_hbc & 0xffu) {
     const size_t i = jg_vote_at(out, self, g);
-    out.a_term[i] = o_term;
-    out.a_ctl[i] = jg_vote_actl(o_n, (step & 7u) << 8 | o_at, o_first, o_rest, o_to);
-    atomicOr((unsigned long long*)&out.wordmail[(size_t)o_to * out.words + (g >> 6)], 1ull << (g & 63u));
+    const uint32_t w = (uint32_t)L.cap_hbc, to = (w >> 21) & 7u;
+    out.a_term[i] = L.cap_ack;
+    out.a_ctl[i] = jg_vote_actl(w & 0xffu, (step & 7u) << 8 | ((w >> 8) & 0xffu), (w >> 19) & 1u, (w >> 20) & 1u, to);
+    atomicOr((unsigned long long*)&out.wordmail[(size_t)to * out.words + (g >> 6)], 1ull << (g & 63u));
   }
+  if (L.overflow) *d.err = 1;  // (nothing is dropped silently)
   const uint32_t dec = L.decisions;
   jg_store_dirty<false>(d, L, O);
   return dec;
@@ -201,43 +208,119 @@ struct JgVoteHalfJob {
   uint32_t self, seq, step, need;
   uint64_t now;
 };
-// the receiving half: a wave skips 64 partitions without mail on one bitmap word (HBM: the bitmaps - G / 8 bytes per node -
-// and, per partition with mail, the senders' control words and the partition's cold record)
-__global__ __launch_bounds__(JG_BLOCK) void k_vote_half_multi(const JgVoteHalfJob* __restrict__ jobs, JgVoteMail in, JgVoteMail out) {
-  const JgVoteHalfJob j = jobs[blockIdx.y];
+// every node's job in the KERNEL ARGUMENTS (3 KB): read through a pointer into global memory the state machine re-loaded
+// every JgDev pointer after every store, copied by value the job went to scratch (344 B per lane: sizeof(JgDev)) - as for
+// the slow kernels (jg_follower.h: JgFollowerJobs)
+struct JgVoteHalfJobs {
+  JgVoteHalfJob j[JG_MAX_REPLICAS];
+};
+#if JG_BLOCK % 64 == 0  // (the kernels: whole waves; the one-lane host build of the tests calls the per-partition functions above)
+// ---- a workgroup over the SET BITS of a bitmap ----------------------------------------------------------------------
+// A round's mail names a few percent of the partitions (40 k campaigns at 1 M x 5 and 1 %/round).  With a lane per
+// PARTITION nearly every wave of the receiving half held one or two lanes with mail and waited for their dozen dependent
+// jg_apply calls with the other sixty idle (733 us per round on the MI355X, the chip latency-bound at 3 % lane
+// utilisation); with a lane per bitmap WORD the few waves there are walk their words' bits one after the other.  So: a
+// workgroup takes a CHUNK of the bitmap (JG_VOTE_CHUNK words = 2048 partitions; thread k < JG_VOTE_CHUNK brings word k),
+// the words and their prefix popcounts go to LDS, and lane i takes the i-th set bit - whole waves at work, the rest of
+// the workgroup idle.
+#define JG_VOTE_CHUNK 32u
+static_assert(JG_BLOCK >= JG_VOTE_CHUNK, "a thread per word of the chunk");
+struct JgBitChunk {
+  uint64_t w[JG_VOTE_CHUNK];
+  uint32_t pre[JG_VOTE_CHUNK + 1];
+};
+// every thread calls it (threads >= JG_VOTE_CHUNK with word = 0); returns the number of set bits (workgroup-uniform)
+__device__ __forceinline__ uint32_t jg_chunk_scan(JgBitChunk& s, uint64_t word) {
+  uint32_t total = 0;
+  __syncthreads();  // (the last chunk's lanes are done with s)
+  const uint32_t ex = jg_block_exclusive_scan(threadIdx.x < JG_VOTE_CHUNK ? (uint32_t)__popcll(word) : 0u, &total);
+  if (threadIdx.x < JG_VOTE_CHUNK) s.w[threadIdx.x] = word, s.pre[threadIdx.x] = ex;
+  if (threadIdx.x == 0) s.pre[JG_VOTE_CHUNK] = total;
+  __syncthreads();
+  return total;
+}
+// the position within the chunk (word * 64 + bit) of its i-th set bit, i < total
+__device__ __forceinline__ uint32_t jg_chunk_pick(const JgBitChunk& s, uint32_t i) {
+  uint32_t lo = 0, hi = JG_VOTE_CHUNK;  // the word that holds it: the last k with pre[k] <= i
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (s.pre[mid] <= i) lo = mid;
+    else hi = mid;
+  }
+  uint64_t u = s.w[lo];
+  for (uint32_t k = i - s.pre[lo]; k; k--) u &= u - 1;
+  return lo * 64u + (uint32_t)__ffsll((unsigned long long)u) - 1u;
+}
+
+// the receiving half, every node in one launch (blockIdx.y); the bitmap is the addressee's wordmail & ~rowmail (mail that
+// came as rows is the row path's).  What a partition costs is very uneven - a voter applies a campaign's R - 1 copies
+// (two of them run), a CANDIDATE the R - 1 answers of each of R - 1 voters - and a wave takes as long as its slowest
+// lane: the lanes that read answers go first (a second compaction in LDS), so that they share waves with each other.
+// (HBM: the bitmaps - G / 4 bytes per node - and, per partition with mail, the senders' control words and its columns.)
+__global__ __launch_bounds__(JG_BLOCK) void k_vote_half_multi(JgVoteHalfJobs jobs, JgVoteMail in, JgVoteMail out) {
+  const JgVoteHalfJob& j = jobs.j[blockIdx.y];
+  __shared__ JgBitChunk s;
+  __shared__ uint32_t s_g[JG_BLOCK];
   uint32_t dec = 0;
-  for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < j.d.G; g += gridDim.x * JG_BLOCK) {
-    if (!in.wordmail[(size_t)j.self * in.words + (g >> 6)]) continue;  // (wave-uniform: a wave's 64 lanes share the word)
-    dec += jg_vote_half_group(j.d, g, j.self, in, out, j.need, j.now, j.seq, j.step);
+  const uint32_t n_chunks = (in.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK;
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {  // (block-uniform trip counts throughout)
+    const uint32_t w = c * JG_VOTE_CHUNK + threadIdx.x;
+    const size_t at = (size_t)j.self * in.words + w;
+    const uint32_t total = jg_chunk_scan(s, threadIdx.x < JG_VOTE_CHUNK && w < in.words ? in.wordmail[at] & ~in.rowmail[at] : 0ull);
+    for (uint32_t t0 = 0; t0 < total; t0 += JG_BLOCK) {
+      const uint32_t n = min(total - t0, (uint32_t)JG_BLOCK);
+      uint32_t g = 0, heavy = 0;
+      if (threadIdx.x < n) {
+        g = c * JG_VOTE_CHUNK * 64u + jg_chunk_pick(s, t0 + threadIdx.x);
+        for (uint32_t q = 0; q < in.R; q++) {
+          const uint32_t ac = in.a_ctl[jg_vote_at(in, q, g)];
+          heavy |= (q != j.self && (ac & 0xffu) && ((ac >> 21) & 7u) == j.self) ? 1u : 0u;
+        }
+      }
+      uint32_t n_heavy = 0;
+      const uint32_t ex = jg_block_exclusive_scan(heavy, &n_heavy);
+      if (threadIdx.x < n) s_g[heavy ? ex : n_heavy + (threadIdx.x - ex)] = g;
+      __syncthreads();
+      if (threadIdx.x < n) dec += jg_vote_half_group(j.d, s_g[threadIdx.x], j.self, in, out, j.need, j.now, j.seq, j.step);
+      __syncthreads();  // (s_g is the next pass's)
+    }
   }
   if (dec) (void)__hip_atomic_fetch_add(&j.d.blk_decisions[blockIdx.x], (uint64_t)dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the validation (jg_votes_validate_group) of the partitions a wordmail bit names: a wave skips 64 partitions on R words
+// the validation (jg_votes_validate_group) of the partitions a wordmail bit names (any addressee's)
 __global__ __launch_bounds__(JG_BLOCK) void k_votes_validate(JgVoteMail m, uint32_t need) {
-  for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < m.G; g += gridDim.x * JG_BLOCK) {
+  __shared__ JgBitChunk s;
+  const uint32_t n_chunks = (m.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK;
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const uint32_t w = c * JG_VOTE_CHUNK + threadIdx.x;
     uint64_t u = 0;
-    for (uint32_t d = 0; d < m.R; d++) u |= m.wordmail[(size_t)d * m.words + (g >> 6)];
-    if ((u >> (g & 63u)) & 1ull) jg_votes_validate_group(m, g, need);
+    if (threadIdx.x < JG_VOTE_CHUNK && w < m.words)
+      for (uint32_t d = 0; d < m.R; d++) u |= m.wordmail[(size_t)d * m.words + w];
+    const uint32_t total = jg_chunk_scan(s, u);
+    for (uint32_t i = threadIdx.x; i < total; i += JG_BLOCK) jg_votes_validate_group(m, c * JG_VOTE_CHUNK * 64u + jg_chunk_pick(s, i), need);
   }
 }
 // a round's mail cleared for its next use - where it was written: a control word is only ever written together with a
 // wordmail bit of its partition (the census's first copy, the receiving half's answer), so the union of the addressees'
 // wordmail words says which partitions' control words are dirty (R x G / 8 bytes read instead of 8 x R x G bytes written
-// per round: 0.6 MB against 40 MB at 1 M x 5); then the bitmaps themselves.  A workgroup owns the partitions of its tile
-// and their bitmap words; the barrier keeps a lane from clearing a word its neighbours still have to read.
-#if JG_BLOCK % 64 == 0  // (a wave's 64 lanes share a bitmap word; the one-lane host build of the tests has no use for the kernel)
+// per round: 0.6 MB against 40 MB at 1 M x 5); then the bitmaps themselves (the thread that brought a word clears it: the
+// lanes work from the copy in LDS).
 __global__ __launch_bounds__(JG_BLOCK) void k_votes_clear(JgVoteMail m) {
-  const uint32_t padded = m.words * 64u;
-  for (uint32_t g0 = blockIdx.x * JG_BLOCK; g0 < padded; g0 += gridDim.x * JG_BLOCK) {  // (block-uniform trip count)
-    const uint32_t g = g0 + threadIdx.x, w = g >> 6;
+  __shared__ JgBitChunk s;
+  const uint32_t n_chunks = (m.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK;
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const uint32_t w = c * JG_VOTE_CHUNK + threadIdx.x;
     uint64_t u = 0;
-    if (w < m.words)
-      for (uint32_t d = 0; d < m.R; d++) u |= m.wordmail[(size_t)d * m.words + w];
-    __syncthreads();
-    if (g < m.G && ((u >> (g & 63u)) & 1ull))
-      for (uint32_t s = 0; s < m.R; s++) m.q_ctl[jg_vote_at(m, s, g)] = 0, m.a_ctl[jg_vote_at(m, s, g)] = 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    if (w < m.words && lane < m.R) m.wordmail[(size_t)lane * m.words + w] = 0, m.rowmail[(size_t)lane * m.words + w] = 0;
+    if (threadIdx.x < JG_VOTE_CHUNK && w < m.words)
+      for (uint32_t d = 0; d < m.R; d++) {
+        u |= m.wordmail[(size_t)d * m.words + w];
+        m.wordmail[(size_t)d * m.words + w] = 0, m.rowmail[(size_t)d * m.words + w] = 0;
+      }
+    const uint32_t total = jg_chunk_scan(s, u);
+    for (uint32_t i = threadIdx.x; i < total; i += JG_BLOCK) {
+      const uint32_t g = c * JG_VOTE_CHUNK * 64u + jg_chunk_pick(s, i);
+      for (uint32_t q = 0; q < m.R; q++) m.q_ctl[jg_vote_at(m, q, g)] = 0, m.a_ctl[jg_vote_at(m, q, g)] = 0;
+    }
   }
 }
 #endif

@@ -2349,7 +2349,8 @@ struct jg_dense_cluster {
     char *h_jobs = nullptr, *d_jobs = nullptr;
     uint32_t group_bits = 1;
     bool ready = false;
-    // JG_ROUTE_VOTE_WORDS=1: the election vocabulary as mailbox words (jg_votes.h) - two rounds' mail, used in turn
+    // JG_CLUSTER_OPT_VOTE_WORDS: the election vocabulary as mailbox words (jg_votes.h) - two rounds' mail, used in turn
+    bool vote_words = false;
     JgVoteMail vm[2]{};
     void* vm_mem = nullptr;
     uint32_t vm_turn = 0;
@@ -2459,6 +2460,19 @@ void jg_dense_cluster_destroy(jg_dense_cluster* c) {
   if (c->rt.d_count) (void)hipFree(c->rt.d_count);
   if (c->rt.h_count) (void)hipHostFree(c->rt.h_count);
   delete c;
+}
+
+int jg_dense_cluster_set_option(jg_dense_cluster* c, uint32_t option, uint64_t value) {
+  if (!c) return fail(JG_EINVAL, "null argument");
+  switch (option) {
+    case JG_CLUSTER_OPT_VOTE_WORDS:
+      if (c->rt.ready) return fail(JG_EINVAL, "JG_CLUSTER_OPT_VOTE_WORDS is fixed before the cluster's first routed round");
+      if (value > 1) return fail(JG_EINVAL, "JG_CLUSTER_OPT_VOTE_WORDS takes 0 or 1");
+      c->rt.vote_words = value != 0;
+      return JG_OK;
+    default:
+      return fail(JG_EINVAL, "unknown cluster option");
+  }
 }
 
 int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const uint64_t* per_group) {
@@ -2898,12 +2912,11 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   for (jg_engine* e : c->nodes) one_stream = one_stream && e->stream == L->stream;
   static const bool no_multi = std::getenv("JG_ROUTE_SEPARATE_LAUNCHES") != nullptr;  // (A/B: round 2's launch per node / sender / step)
   const bool multi = one_stream && !no_multi;
-  // JG_ROUTE_VOTE_WORDS=1 (OPT-IN, jg_votes.h): an election's traffic travels as mailbox words - the campaigns' broadcasts are
+  // JG_CLUSTER_OPT_VOTE_WORDS (jg_dense_cluster_set_option; jg_votes.h): an election's traffic travels as mailbox words - the campaigns' broadcasts are
   // counted into request words by a census of the emitted rows and are not staged, the answers are written as words by the
   // receiving half (k_vote_half_multi) and never become rows - wherever EVERYTHING a node receives for a partition in a
   // round is such words; every other partition's mail travels as rows, as without the switch.  Fixed for a cluster's life.
-  static const bool vote_words_env = std::getenv("JG_ROUTE_VOTE_WORDS") != nullptr && std::atoi(std::getenv("JG_ROUTE_VOTE_WORDS")) != 0;
-  const bool vwords = vote_words_env && multi && R >= 2 && std::getenv("JG_ROUTE_LIBRARY_SORT") == nullptr;
+  const bool vwords = rt.vote_words && multi && R >= 2 && std::getenv("JG_ROUTE_LIBRARY_SORT") == nullptr;
   if (vwords && !rt.vm_mem) {
     const size_t RG = (size_t)R * c->G, wd = ((size_t)c->G + 63) / 64;
     const size_t per = RG * (8 + 8 + 8 + 4 + 4) + 2 * R * wd * 8;
@@ -2924,7 +2937,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   }
   const JgVoteMail vprev = rt.vm[rt.vm_turn ^ 1u], vcur = rt.vm[rt.vm_turn];  // (last round's mail is read, this round's filled)
   if (vwords) {
-    hipLaunchKernelGGL(k_votes_clear, dim3(std::min<uint32_t>((c->G + JG_BLOCK - 1) / JG_BLOCK, 2048u)), dim3(JG_BLOCK), 0, L->stream, vcur);
+    hipLaunchKernelGGL(k_votes_clear, dim3((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK), dim3(JG_BLOCK), 0, L->stream, vcur);  // (a workgroup per chunk of the bitmaps)
     HIPCHK(hipGetLastError());
   }
   if (!rt.h_jobs) {
@@ -2933,7 +2946,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   }
   static_assert(JG_MAX_REPLICAS * sizeof(JgApplyJob) <= jg_dense_cluster::Route::JOB_SLICE, "job slice too small");
   static_assert(JG_MAX_REPLICAS * sizeof(JgFollowerJob) <= jg_dense_cluster::Route::JOB_SLICE, "job slice too small");
-  static_assert(JG_MAX_REPLICAS * sizeof(JgVoteHalfJob) <= jg_dense_cluster::Route::JOB_SLICE, "job slice too small");
+  static_assert(sizeof(JgVoteHalfJobs) + 2 * sizeof(JgVoteMail) <= 4096, "kernel arguments");
   auto slice_h = [&](int k) { return rt.h_jobs + (size_t)k * jg_dense_cluster::Route::JOB_SLICE; };
   auto slice_d = [&](int k) { return rt.d_jobs + (size_t)k * jg_dense_cluster::Route::JOB_SLICE; };
   // (multi: the job tables of the whole round - both sparse steps, the follower halves, the delivering pass - are
@@ -3037,6 +3050,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     JgRouteTable t{};
     t.R = R, t.src = s;
     for (uint32_t n = 0; n < R; n++) t.member_id[n] = c->nodes[n]->cfg.node_ids[n];
+    t.src_id = t.member_id[s];
     t.group_bits = rt.group_bits, t.ord_bits = ord_bits, t.cap = rt.cap;
     t.seg_cap = rt.cap / n_seg, t.seg_mask = n_seg - 1;
     t.key = rt.key, t.idx = rt.idx, t.row = rt.row;
@@ -3094,21 +3108,21 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     return JG_OK;
   };
   if ((rc = route_jobs())) return rc;
-  if (vwords) {  // the vote mail's receiving half on every node: the delivered step's number, slice 4
+  JgVoteHalfJobs vjobs{};  // the vote mail's receiving half on every node (the delivered step's number): kernel arguments
+  if (vwords) {
     for (uint32_t n = 0; n < R; n++) {
       jg_engine* e = c->nodes[n];
-      JgVoteHalfJob j{};
+      JgVoteHalfJob& j = vjobs.j[n];
       j.d = e->dev, j.self = n, j.seq = seq_base[n] + 1u, j.step = 1u, j.need = R - 1u, j.now = now_ms;
       if (e->seq < j.seq) return fail(JG_EDEVICE, "internal: routed round: the delivered step has no number");
-      std::memcpy(slice_h(4) + (size_t)n * sizeof(JgVoteHalfJob), &j, sizeof(j));
     }
   }
-  if (multi) {  // slices 0-3 in one copy (0-4 with the vote mail)
+  if (multi) {  // slices 0-3 in one copy
     if (!jobs_a.empty()) std::memcpy(slice_h(0), jobs_a.data(), jobs_a.size() * sizeof(JgApplyJob));
     if (!jobs_v.empty()) std::memcpy(slice_h(0) + jobs_a.size() * sizeof(JgApplyJob), jobs_v.data(), jobs_v.size() * sizeof(JgApplyJob));
     if (!jobs_b.empty()) std::memcpy(slice_h(1), jobs_b.data(), jobs_b.size() * sizeof(JgApplyJob));
     if (!fjobs.empty()) std::memcpy(slice_h(2), fjobs.data(), fjobs.size() * sizeof(JgFollowerJob));
-    HIPCHK(hipMemcpyAsync(slice_d(0), slice_h(0), (vwords ? 5 : 4) * jg_dense_cluster::Route::JOB_SLICE, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(slice_d(0), slice_h(0), 4 * jg_dense_cluster::Route::JOB_SLICE, hipMemcpyHostToDevice, st));
   }
   // -- 1. (launches) what the transport delivered last round, then this round's injected rows
   if ((rc = apply_all(0, jobs_a, widest_a))) return rc;
@@ -3125,7 +3139,8 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   if (vwords) {  // (partitions other than the rows': a partition's mail of a round is words or rows, never both)
     uint32_t slots = L->count_slots;
     for (jg_engine* e : c->nodes) slots = std::min(slots, e->count_slots);
-    hipLaunchKernelGGL(k_vote_half_multi, dim3(grid_for(c->G, slots), R), dim3(JG_BLOCK), 0, L->stream, (const JgVoteHalfJob*)slice_d(4), vprev, vcur);
+    const uint32_t n_chunks = (vprev.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK;  // (a workgroup per chunk of the bitmap; its counter slot is blockIdx.x)
+    hipLaunchKernelGGL(k_vote_half_multi, dim3(std::max(1u, std::min(n_chunks, slots)), R), dim3(JG_BLOCK), 0, L->stream, vjobs, vprev, vcur);
     HIPCHK(hipGetLastError());
   }
   if ((rc = apply_all(1, jobs_b, widest_b))) return rc;
@@ -3168,7 +3183,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       hipLaunchKernelGGL(k_votes_census_rec_multi, dim3((widest_r + JG_BLOCK - 1) / JG_BLOCK, (uint32_t)rjobs.size()), dim3(JG_BLOCK), 0, st,
                          (const JgRouteRecJob*)slice_d(3), vcur);
     hipLaunchKernelGGL(k_votes_census_xq_multi, dim3(256, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteXqJob*)(slice_d(3) + rb), vcur);
-    hipLaunchKernelGGL(k_votes_validate, dim3(std::min<uint32_t>((c->G + JG_BLOCK - 1) / JG_BLOCK, 2048u)), dim3(JG_BLOCK), 0, st, vcur, R - 1u);
+    hipLaunchKernelGGL(k_votes_validate, dim3((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK), dim3(JG_BLOCK), 0, st, vcur, R - 1u);
     HIPCHK(hipGetLastError());
   }
   for (int attempt = 0;; attempt++) {  // (repeated once when the staging turns out too small: the pass modifies nothing)
@@ -3182,7 +3197,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
         hipLaunchKernelGGL(k_route_rec_multi_words, dim3((widest_r + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS), (uint32_t)rjobs.size()),
                            dim3(JG_BLOCK), 0, st, (const JgRouteRecJob*)slice_d(3), vcur);
       hipLaunchKernelGGL(k_route_xq_multi_words, dim3(256, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteXqJob*)(slice_d(3) + rb), vcur);
-      hipLaunchKernelGGL(k_votes_expand_multi, dim3(std::min<uint32_t>((c->G + JG_BLOCK - 1) / JG_BLOCK, 512u), (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st,
+      hipLaunchKernelGGL(k_votes_expand_multi, dim3(std::min<uint32_t>((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK, 512u), (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st,
                          (const JgRouteXqJob*)(slice_d(3) + rb), vcur);
     } else if (multi) {
       if (!rjobs.empty())

@@ -673,14 +673,21 @@ class DenseCluster:
     ticks").  `nodes[r]` hosts replica slot r of every group; nodes[lead] is made leader by the
     caller (traces.elect_all)."""
 
-    def __init__(self, nodes, lead=0):
+    def __init__(self, nodes, lead=0, vote_words=False):
         """lead = None: per-partition leadership (JG_CLUSTER_ANY_LEADER) - every node leads the partitions it was
-        elected for and follows the others."""
+        elected for and follows the others.  vote_words: JG_CLUSTER_OPT_VOTE_WORDS (an election's traffic of the routed
+        round as mailbox words, csrc/jg_votes.h)."""
         self.nodes, self.lead, self.R = list(nodes), lead, len(nodes)
         self.api = nodes[0].api
         arr = (C.c_void_p * self.R)(*[n._h for n in nodes])
         self._h = C.c_void_p()
         nodes[0]._check(self.api.dense_cluster_create(arr, self.R, capi.CLUSTER_ANY_LEADER if lead is None else lead, C.byref(self._h)))
+        self.vote_words = bool(vote_words)
+        if vote_words:
+            self.set_option(capi.CLUSTER_OPT_VOTE_WORDS, 1)
+
+    def set_option(self, option: int, value: int) -> None:
+        self.nodes[0]._check(self.api.dense_cluster_set_option(self._h, int(option), int(value)))
 
     def close(self) -> None:
         if self._h:

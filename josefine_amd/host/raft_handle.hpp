@@ -611,14 +611,12 @@ class BatchedEventLoop {
       in_.push(m.group, c.kind, from, c.term, c.id, c.aux, c.flag ? 1 : 0);
       if (c.kind == JG_CMD_CLIENT_REQUEST) proxied_[{m.group, c.id}] = c.proposal;
     }
-    if (c.kind == JG_CMD_HEARTBEAT || c.kind == JG_CMD_APPEND_ENTRIES) answers_to_[m.group] = c.from;
+    // (who a partition's answers go to - the sender of the Heartbeat / AppendEntries being answered - is read off the
+    // row queue when the step that applies it begins: step(); a pipelined loop decodes tick t + 1 while tick t's
+    // answers are still to be addressed)
   }
   // a peer's whole frame of rows at once (payload-free: a columnar transport ships block data separately)
-  void tcp_rx_rows(const jg_cmd_batch& b) {
-    in_.append(b);
-    for (size_t i = 0; i < b.n; i++)
-      if (b.kind[i] == JG_CMD_HEARTBEAT || b.kind[i] == JG_CMD_APPEND_ENTRIES) answers_to_[b.group[i]] = b.from ? b.from[i] : 0;
-  }
+  void tcp_rx_rows(const jg_cmd_batch& b) { in_.append(b); }
   // ... or decoded straight into the engine's pinned columns: no copy on the host at all (rows committed this
   // way are applied before the rows queued through tcp_rx / tcp_rx_rows of the same step)
   jg_cmd_cols tcp_rx_reserve(size_t n, size_t n_blocks = 0) { return raft_.reserve_rows(n, n_blocks); }
@@ -662,6 +660,12 @@ class BatchedEventLoop {
 
  private:
   void step(uint64_t at, bool tick) {
+    // (pipelined: the previous step's outputs first - its pinned queues and outbox are about to be reused, the blocks
+    // noted below belong to THIS step (BatchedRaft::after_step stores a step's blocks where its extend succeeded), and
+    // its answers go to the senders of ITS Heartbeat / AppendEntries rows, not to this step's)
+    if (dense) flush();
+    for (size_t i = 0; i < in_.size(); i++)
+      if (in_.kind[i] == JG_CMD_HEARTBEAT || in_.kind[i] == JG_CMD_APPEND_ENTRIES) answers_to_[in_.group[i]] = in_.from[i];
     // payload-carrying rows (client proposals, blocks) go through submit() so that BatchedRaft's request /
     // block mirrors see them; everything else is one bulk jg_submit of the row queue
     for (auto& p : proposals_) raft_.note_proposal(p.group, p.id, std::move(p.data));
@@ -672,7 +676,6 @@ class BatchedEventLoop {
     in_blocks_.clear();
     direct_rows_ = 0;
     if (dense) {
-      flush();  // (pipelined: the previous step's outputs first - its pinned queues and outbox are about to be reused)
       if (!in_.empty()) raft_.submit_rows(in_.view());
       in_.clear();
       last_at_ = at;

@@ -462,6 +462,85 @@ static void event_loops_over_the_wire() {
   }
 }
 
+// A PIPELINED loop (BatchedEventLoop::pipelined: step t's outputs are delivered at the start of step t + 1) must be the
+// plain loop, only later: (1) a block whose Chain::extend fails in step t + 1 (missing parent, chain.rs:180-185) is not
+// persisted - the store stays byte for byte what the plain loop's holds; (2) step t's HeartbeatResponse / AppendResponse go
+// to the sender of the message they answer (follower.rs:163-172,209-215), not to whoever sent the partition's traffic of
+// step t + 1.  Both loops are fed the same frames; every message on tcp_tx and the sled images are compared.
+static void pipelined_loop_is_the_plain_loop_later() {
+  const uint32_t G = 4;
+  struct Out {
+    uint32_t group, to, kind;
+    uint64_t id;
+    bool operator==(const Out& o) const { return group == o.group && to == o.to && kind == o.kind && id == o.id; }
+  };
+  std::vector<std::vector<Out>> sent(2);
+  std::vector<std::unique_ptr<BatchedRaft>> rafts;
+  std::vector<std::unique_ptr<BatchedEventLoop>> loops;
+  for (int k = 0; k < 2; k++) {
+    rafts.emplace_back(new BatchedRaft(G, {1, 2, 3}, 0, 7, JG_CFG_SEPARATE_COMMIT_KEY));
+    std::vector<uint8_t> slots(G, 1);  // this process is node 2 of every partition
+    CHECK(jg_set_self_slots(rafts[k]->raw(), slots.data()) == JG_OK);
+    loops.emplace_back(new BatchedEventLoop(*rafts[k], G));
+    loops[k]->pipelined = k == 1;
+    loops[k]->tcp_tx = [&sent, k](const Message& m) { sent[k].push_back({m.group, m.to.peer, m.command.kind, m.command.id}); };
+  }
+  auto msg = [](uint32_t g, NodeId from, const Command& c) {
+    Message m;
+    m.group = g, m.from = Address{JG_TO_PEER, from}, m.to = Address{JG_TO_PEER, 2}, m.command = c;
+    return m;
+  };
+  auto ae = [](Term term, NodeId leader, std::vector<Block> blocks) {
+    Command c;
+    c.kind = JG_CMD_APPEND_ENTRIES, c.term = term, c.from = leader, c.blocks = std::move(blocks);
+    return c;
+  };
+  for (int k = 0; k < 2; k++) {
+    BatchedEventLoop& L = *loops[k];
+    // tick 0: node 1 leads everything at term 1; partitions 0-2 get block 1
+    for (uint32_t g = 0; g < G; g++) L.tcp_rx(msg(g, 1, Command::Heartbeat(1, 0, 1)));
+    for (uint32_t g = 0; g < 3; g++) L.tcp_rx(msg(g, 1, ae(1, 1, {Block{1, 0, {(uint8_t)(10 + g)}}})));
+    L.run_until(0);
+    // tick 1: partition 0: a block whose parent is missing (the process dies in extend: nothing stored);
+    //         partition 1: the next block; partition 2: a NEW leader (node 3, term 2) sends the partition's traffic;
+    //         partition 3: node 3's heartbeat at a higher term
+    L.tcp_rx(msg(0, 1, ae(1, 1, {Block{5, 4, {55}}, Block{6, 5, {66}}})));
+    L.tcp_rx(msg(1, 1, ae(1, 1, {Block{2, 1, {22}}})));
+    L.tcp_rx(msg(2, 3, Command::Heartbeat(2, 0, 3)));
+    L.tcp_rx(msg(2, 3, ae(2, 3, {Block{2, 1, {33}}})));
+    L.tcp_rx(msg(3, 3, Command::Heartbeat(2, 0, 3)));
+    L.run_until(100);
+    // tick 2: quiet, except partition 1
+    L.tcp_rx(msg(1, 1, ae(1, 1, {Block{3, 2, {44}}})));
+    L.run_until(200);
+    L.flush();
+  }
+  CHECK(!sent[0].empty() && sent[0].size() == sent[1].size());
+  // per partition the same messages in the same order (the pipelined loop hands a step's messages over one step later)
+  for (uint32_t g = 0; g < G; g++) {
+    std::vector<Out> a, b;
+    for (const Out& o : sent[0]) if (o.group == g) a.push_back(o);
+    for (const Out& o : sent[1]) if (o.group == g) b.push_back(o);
+    CHECK(a == b);
+  }
+  // step 0's answers went to node 1 although partition 2 / 3's next traffic came from node 3
+  for (int k = 0; k < 2; k++) {
+    uint32_t first_to[4] = {0, 0, 0, 0}, last_to[4] = {0, 0, 0, 0};
+    for (const Out& o : sent[k]) {
+      if (!first_to[o.group]) first_to[o.group] = o.to;
+      last_to[o.group] = o.to;
+    }
+    CHECK(first_to[2] == 1 && first_to[3] == 1 && last_to[2] == 3 && last_to[3] == 3 && last_to[1] == 1);
+  }
+  for (uint32_t g = 0; g < G; g++) {
+    CHECK(rafts[0]->store(g).raw() == rafts[1]->store(g).raw());
+    CHECK(rafts[0]->handle(g).fault() == rafts[1]->handle(g).fault() && rafts[0]->handle(g).head() == rafts[1]->handle(g).head());
+  }
+  CHECK(rafts[1]->handle(0).fault() == JG_FAULT_EXTEND_MISSING_PARENT);
+  CHECK(!rafts[1]->store(0).count(5) && !rafts[1]->store(0).count(6) && rafts[1]->store(0).count(1));
+  CHECK(rafts[1]->store(1).count(3) && rafts[1]->store(2).count(2) && rafts[1]->store(2).at(2).data == std::vector<uint8_t>{33});
+}
+
 // fsm fan-out where KEY order is not PARENT order: a follower whose chain
 // holds a dead branch.  range(prev..commit) (follower.rs:204) walks the keys, so the dead block is
 // applied too, exactly as the reference's sled iterator would deliver it: ids 1 <- 2 <- 3 (dead) and
@@ -528,6 +607,7 @@ int main() {
     server_event_loops_three_nodes();
     chain_store_restart();
     event_loops_over_the_wire();
+    pipelined_loop_is_the_plain_loop_later();
     fsm_apply_walks_keys_not_parents();
     fsm_fanout_throughput();
 #ifndef JG_TEST_AGAINST_ORACLE

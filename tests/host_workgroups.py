@@ -400,6 +400,7 @@ VIS int hw_route(const WgRoute* rt, const WgSender* snd, const JgVoteMail* vm, u
     JgRouteTable t{};
     t.R = R, t.src = s;
     for (uint32_t n = 0; n < R; n++) t.member_id[n] = rt->member_id[n];
+    t.src_id = t.member_id[s];
     t.group_bits = rt->group_bits, t.ord_bits = rt->ord_bits, t.cap = rt->cap;
     t.seg_cap = rt->cap / rt->n_seg, t.seg_mask = rt->n_seg - 1;
     t.key = rt->key, t.idx = rt->idx, t.row = rt->row;
@@ -471,7 +472,7 @@ VIS int hw_route(const WgRoute* rt, const WgSender* snd, const JgVoteMail* vm, u
 // ---- the receiving half as the kernel runs it: every node in one launch (each node's next step number: seq_out) ---------
 VIS int hw_vote_half_multi(Host** nodes, uint32_t R, uint32_t* seq_out, uint32_t step, uint64_t now, const JgVoteMail* in, const JgVoteMail* out,
                            uint32_t grid_x) {
-  std::vector<JgVoteHalfJob> jobs(R);
+  JgVoteHalfJobs jobs{};
   for (uint32_t n = 0; n < R; n++) {
     Host* h = nodes[n];
     h->seq++;
@@ -479,10 +480,10 @@ VIS int hw_vote_half_multi(Host** nodes, uint32_t R, uint32_t* seq_out, uint32_t
     h->d.xq = h->xq.data(), h->d.xq_cap = (uint32_t)h->xq.size();
     JgVoteHalfJob j{};
     j.d = h->d, j.self = n, j.seq = h->seq, j.step = step, j.need = R - 1u, j.now = now;
-    jobs[n] = j;
+    jobs.j[n] = j;
   }
   const JgVoteMail a = *in, b = *out;
-  wg::launch(dim3(grid_x, R), JG_BLOCK, [&] { k_vote_half_multi(jobs.data(), a, b); });
+  wg::launch(dim3(grid_x, R), JG_BLOCK, [&] { k_vote_half_multi(jobs, a, b); });
   int rc = 0;
   for (uint32_t n = 0; n < R; n++) {
     Host* h = nodes[n];

@@ -1,14 +1,12 @@
-"""OPT-IN (JG_ROUTE_VOTE_WORDS=1 in the environment, which the library reads once): the routed round with the election
+"""JG_CLUSTER_OPT_VOTE_WORDS (jg_dense_cluster_set_option, per cluster): the routed round with the election
 vocabulary as mailbox words (josefine_amd/csrc/jg_votes.h) against the oracle clusters that move every message as a row.
 The switch changes what TRAVELS, not what the nodes compute: every state column of every node after every round, the rows
 left for the host, the faults and the applies are those of the row transport; the number of rows the transport moved is
 smaller (that is the point, and how the test knows the switch was on).
 
-    JG_ROUTE_VOTE_WORDS=1 python -m pytest tests/test_gpu_vote_words.py -m gpu -q
-
-Without the variable the tests are skipped: the driver's `-m gpu` run measures the default path, and the other routed tests
-(which count delivered rows against the row transport) are meant to run without it.  The per-partition logic behind the
-switch is held to the oracle on the CPU (tests/test_vote_half.py, tests/test_vote_mail.py)."""
+The option is per cluster, so these run in the default `pytest -m gpu` beside the row transport's tests (which count
+delivered rows against the row transport and create their clusters without it).  The per-partition logic behind the
+option is also held to the oracle on the CPU (tests/test_vote_half.py, tests/test_vote_mail.py)."""
 import os
 
 import numpy as np
@@ -19,8 +17,7 @@ from oracle_lib import oracle_engine
 from parity import compare_snapshots, elect_all
 
 EMULATED = os.environ.get("JG_EMULATED_DEVICE") == "1"
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("JG_ROUTE_VOTE_WORDS", "0") in ("", "0"),
-                                                   reason="opt-in: set JG_ROUTE_VOTE_WORDS=1 (see the module's docstring)")]
+pytestmark = pytest.mark.gpu
 
 
 CASES = [(3, 3, (), 3000, 50), (5, 2, (), 3000, 50), (5, 2, (2,), 3000, 50), (3, 3, (2,), 3000, 50), (3, 25, (1, 2), 2000, 60), (5, 25, (1, 2, 3), 2000, 60),
@@ -37,7 +34,7 @@ def test_routed_cluster_with_the_vote_mail(R, percent, also, G, T):
     nodes = [BatchedRaft(G, R, seed=5 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
     elect_all(nodes[0])
     nodes[0].drain_messages(), nodes[0].drain_applies()
-    lib = LibCluster(nodes)
+    lib = LibCluster(nodes, vote_words=True)
     lib.set_appends(1)
     moved = moved_as_rows = 0
     for t in range(T):
@@ -82,7 +79,7 @@ def test_any_leader_cluster_with_the_vote_mail(R, percent, dual, G, T):
     nodes = [BatchedRaft(G, R, seed=5 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
     spread_leaders(ora.nodes, G, R, dual_every=dual)
     spread_leaders(nodes, G, R, dual_every=dual)
-    lib = LibCluster(nodes, lead=None)
+    lib = LibCluster(nodes, lead=None, vote_words=True)
     lib.set_appends(1)
     leader_of = np.arange(G) % R
     failed = np.zeros(G, bool)

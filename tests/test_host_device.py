@@ -3,7 +3,7 @@ host code and every kernel as written - compiled for the host against a stand-in
 is 256 cooperative fibers, loaded by a CHILD process through JOSEFINE_GPU_LIB, and driven by the GPU suite's own tests.
 
 What runs here is what no GPU-minute was left for at the end of round 4: the routed round with the election vocabulary
-as mailbox words (JG_ROUTE_VOTE_WORDS=1, josefine_amd/csrc/jg_votes.h) THROUGH round_routed_impl - its job tables, step
+as mailbox words (JG_CLUSTER_OPT_VOTE_WORDS, josefine_amd/csrc/jg_votes.h) THROUGH round_routed_impl - its job tables, step
 numbers, the mail's two buffers, the census before and the word-aware delivering pass inside the repeat loop, the
 exceptional queues' clean-up - against the oracle clusters that move every message as a row (tests/test_gpu_vote_words.py,
 the cases small enough for fibers).  And, so that the stand-in itself is held to something, a slice of the default path's
@@ -23,7 +23,7 @@ def _run(args, env=None):
 def test_routed_round_with_the_vote_mail_through_the_engines_host_code():
     """single lead (BASELINE configs[4]'s cluster) and per-partition leadership, under the switch"""
     # (a minute of fibers; every case whose id starts with "small" runs here in five: -k small)
-    out = _run(["tests/test_gpu_vote_words.py", "-m", "gpu", "-k", "small-5-25-3-160 or small-3-25-7-160"], env=dict(JG_ROUTE_VOTE_WORDS="1"))
+    out = _run(["tests/test_gpu_vote_words.py", "-m", "gpu", "-k", "small-5-25-3-160 or small-3-25-7-160"])
     assert "2 passed" in out, out[-500:]
 
 
