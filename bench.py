@@ -535,17 +535,24 @@ def failed_before(args, np, G, R, leader_of, rank, upto):
 
 
 def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
-    """--cluster --failures p: BASELINE.json configs[4] as SURVEY.md §8(d) #5 specifies it.  The closed
-    loop of --cluster, and per round p % of the partitions lose their leader: its replica crashes and
-    restarts, a restarted follower (voted_for == None, §7.3 Q4) times out and campaigns, the other
-    replicas answer its VoteRequests through can_vote on the device; every vote travels between the
-    engines through the library's device-side transport (jg_dense_cluster_round_routed) and is applied
-    the round after.  Nothing here is synthetic except the failures and the client requests."""
+    """--cluster --failures p: BASELINE.json configs[4] as SURVEY.md §8(d) #5 specifies it, as a STATIONARY trace
+    (josefine_amd.traces.FailureRepairTrace).  The closed loop of --cluster, and per round p % of the partitions that are
+    up lose their leader: its replica crashes and restarts, a restarted follower (voted_for == None, §7.3 Q4) times out
+    and campaigns, the other replicas answer its VoteRequests through can_vote on the device - they remember their
+    vote and refuse, the partition is leaderless and its candidate campaigns again at every election timeout; every vote
+    travels between the engines through the library's device-side transport (jg_dense_cluster_round_routed) and is
+    applied the round after.  The client stops proposing to it.  --repair-after D rounds later the partition is RE-CREATED
+    (what the reference leaves of it can never append again, Q8, and would be re-fed from block 1, Q10: every replica
+    restarts on an empty store - JG_CMD_RECREATE -, replica 0 is seated: Timeout + two injected grants, the trace's
+    only synthetic votes; its VoteRequests and its Heartbeat are routed) and is what every partition was at round 0, the
+    client proposing again: leaderless fraction (p x D), decisions per round and cost per round are flat.
+    --repair-after 0: no repairs (rounds 2-4's trace: the leaderless fraction grows by p per round)."""
     import numpy as np
     from josefine_amd import BatchedRaft, DenseCluster, capi
-    from josefine_amd.traces import cluster_failure_rows, elect_all
+    from josefine_amd.traces import FailureRepairTrace, elect_all
 
     G, R, K, W = args.groups, args.replicas, args.steps, args.warmup
+    D = args.repair_after
     nodes = [BatchedRaft(G, R, seed=args.seed + r, device_id=dev_index, group_base=rank * G,
                          self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
     L = nodes[0]
@@ -554,14 +561,20 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
     api = L.api
     lib = DenseCluster(nodes, vote_words=bool(args.vote_words))
     lib.set_appends(1)
-    # the failure trace is resident in HBM before the timed region: per round and node one group-sorted batch
-    failed = np.zeros(G, bool)
-    trace = []
-    for t in range(W + K):
-        cols = cluster_failure_rows(args.seed, t, G, R, args.failures, group_base=rank * G)
-        if cols[0] is not None:
-            failed[cols[0]["group"]] = True
+    # The trace is resident in HBM before the timed region: per round and node one group-sorted batch, and the list of the
+    # partitions the client stops proposing to.  The trace has run SETTLE rounds before the first timed one - W of them
+    # as the warm-up, the rest before that - so that the timed region starts in the trace's steady state (a repair
+    # schedule of D rounds needs D rounds to fill; election timeouts are 5-10 rounds)
+    settle = max(0, (2 * D + 10 if D else 0) - W)
+    tr = FailureRepairTrace(args.seed, G, R, args.failures, D if D else 1 << 40, group_base=rank * G, node_ids=[nodes[r].node_ids[r] for r in range(R)])
+    trace, withdraw, offer, frac = [], [], [], []
+    for t in range(settle + W + K):
+        cols, failing, repaired = tr.rows(t)
         trace.append([None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(cols)])
+        withdraw.append(L.upload_u32(failing) if len(failing) else None)   # the client stops proposing to a partition that lost its leader ...
+        offer.append(L.upload_u32(repaired) if len(repaired) else None)    # ... and proposes again to one that was re-created
+        frac.append(float(tr.leaderless().mean()))
+    W += settle  # (from here on the settle rounds are warm-up rounds)
     for e in nodes:
         e._check(api.sync(e._h))
 
@@ -574,22 +587,31 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
 
     delivered = [0, 0]  # [warm-up, timed] rows the transport moved
     kept = [0]
+    fsm = [0, 0]  # [queued by the rounds, handed to the host]: a repaired follower's first Heartbeat advances its commit index -
+    #               the Apply range (follower.rs:204-206) is the partition's state machine's, drained like any (jg_drain_applies_view)
 
     def rounds(t0_, t1_, which):
         for t in range(t0_, t1_):
+            if withdraw[t] is not None:
+                lib.withdraw_appends(withdraw[t].ptr, withdraw[t].n)
+            if offer[t] is not None:
+                lib.offer_appends(offer[t].ptr, offer[t].n, 1)
             st = lib.round_routed((t + 1) * 100, trace[t])
             delivered[which] += sum(st["delivered"])
-            kept[0] += st["kept"] + st["fsm_rows"]
+            kept[0] += st["kept"]
+            fsm[0] += st["fsm_rows"]
+            if st["fsm_rows"] and args.drain_applies:
+                for e in nodes:
+                    fsm[1] += len(e.drain_applies(copy=False))
 
     rounds(0, W, 0)
     barrier()
     c0 = sum(e.counters()["decisions"] for e in nodes)
     L._check(api.kernel_timing(L._h, 1))
     barrier()
-    # The workload is NOT stationary: a partition that lost its leader stays leaderless (Q4) and keeps producing vote
-    # traffic, so the leaderless fraction grows by ~p % per round and ms/round with it.  The K rounds are therefore also
-    # timed in four consecutive windows (a routed round synchronises with the host anyway: the window marks add nothing),
-    # each reported against the leaderless fraction it ran at.
+    # The K rounds are also timed in four consecutive windows (a routed round synchronises with the host anyway: the
+    # window marks add nothing), each reported against the leaderless fraction it ran at: flat with the repair schedule,
+    # growing without it.
     marks = [W + (K * q) // 4 for q in range(5)]
     window_s = []
     t0 = time.perf_counter()
@@ -610,16 +632,24 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
     L._check(api.kernel_timing_read(L._h, C.byref(k_us), C.byref(k_n)))
     L._check(api.kernel_timing(L._h, 0))
 
-    # full-size properties (window parity against oracle clusters: tests/test_gpu_fullsize.py): what the
-    # reference's rules make of this trace - a failing partition stays leaderless
-    # (every replica that was not restarted still remembers its vote and refuses), the others keep committing
+    # full-size properties (parity against oracle clusters: tests/test_dense_node.py::test_stationary_failure_repair_trace_*,
+    # tests/test_gpu_fullsize.py): what the reference's rules make of this trace - a failing partition
+    # is leaderless (every replica that was not restarted remembers its vote and refuses) until its repair, the partitions
+    # that never failed keep committing, nothing faults, no row leaves the transport's vocabulary
     T = W + K
+    down, never = tr.leaderless(), ~tr.ever_failed
     role = L.read("role")
-    assert (role[failed] == capi.ROLE_FOLLOWER).all() and (role[~failed] == capi.ROLE_LEADER).all(), "leadership"
-    assert (L.read("head")[~failed] == T).all() and (L.read("commit")[~failed] >= T - 3).all(), "healthy partitions commit"
+    assert (role[down] != capi.ROLE_LEADER).all() and (role[~down] == capi.ROLE_LEADER).all(), "leadership"
+    assert (L.read("head")[never] == T).all() and (L.read("commit")[never] >= T - 3).all(), "healthy partitions commit"
+    recreated = tr.ever_failed & ~down
+    assert not D or (recreated.any() and (L.read("head")[recreated] > 0).all() and (L.read("head")[recreated] < T).all()), "re-created partitions append again"
+    for e in nodes[1:]:
+        assert (e.read("role") != capi.ROLE_LEADER).all()
     for e in nodes:
-        assert not e.read("fault").any() and (e.read("role")[failed] != capi.ROLE_LEADER).all()
+        assert not e.read("fault").any()
     assert kept[0] == 0 and sum(len(e.drain_messages()) for e in nodes) == 0, "rows left the transport's vocabulary"
+    fsm[1] += sum(len(e.drain_applies(copy=False)) for e in nodes)
+    assert fsm[0] == fsm[1], "FSM rows"
 
     per_rank = None
     if world > 1:
@@ -637,19 +667,22 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
         round_s = wall / K
         out = {
             "metric": "Raft quorum decisions/sec over N partitions; achieved HBM GB/s vs roofline",
-            "value": decisions / wall, "unit": "decisions/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": decisions / wall, "unit": "decisions/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / K, "ms_per_step_events": ev_ms.value / K, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[4] as specified: closed loop of {R} nodes x {G} partitions on one GPU, "
-                                   f"{args.failures} %/round of the partitions lose their leader (crash + restart), a restarted "
-                                   "follower times out and campaigns, votes answered through can_vote and routed between "
-                                   "the nodes on the device, applied the round after; 1 client request per led partition per round",
+                                   f"{args.failures} %/round of the partitions that are up lose their leader (crash + restart), a restarted "
+                                   "follower times out and campaigns (again at every election timeout), votes answered through can_vote "
+                                   "and routed between the nodes on the device, applied the round after"
+                                   + (f"; {D} rounds after its failure a partition is RE-CREATED: every replica restarts on an empty store, replica 0 "
+                                      "is seated (Timeout + two injected grants: the only synthetic votes; its VoteRequests and its Heartbeat are routed)"
+                                      if D else "; no repairs: a failed partition stays leaderless")
+                                   + "; 1 client request per round for every partition that has a leader",
                        "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world,
                        "q9": "off (JG_CFG_SEPARATE_COMMIT_KEY: bit-exact vs the oracle with the same switch; the reference would "
                              "panic at the first replicate() to a caught-up follower, leader.rs:152-157)",
                        "parallelism": f"{world} independent shard(s), no collective", **devices_config(args, world)},
             "group_rounds_per_s": G * world * K / wall,
-            "leaderless_fraction": {"at_start_of_timed_region": None, "at_end": float(failed.mean())},
             "per_rank": per_rank,
             "rows_routed_per_round": delivered[1] / K / world,
             "decisions_in_timed_region": decisions,
@@ -671,25 +704,25 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
                                            "achieved": lb * G / (k_us.value * 1e-6) / 1e9 if k_us.value else None,
                                            "frac": lb * G / (k_us.value * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us.value else None}},
         }
-        W_failed = np.zeros(G, bool)
-        for t in range(W):
-            c = cluster_failure_rows(args.seed, t, G, R, args.failures, group_base=rank * G)[0]
-            if c is not None:
-                W_failed[c["group"]] = True
-        out["leaderless_fraction"]["at_start_of_timed_region"] = float(W_failed.mean())
-        fr = [float(W_failed.mean())]
-        acc = W_failed.copy()
-        for q in range(4):
-            for t in range(marks[q], marks[q + 1]):
-                c = cluster_failure_rows(args.seed, t, G, R, args.failures, group_base=rank * G)[0]
-                if c is not None:
-                    acc[c["group"]] = True
-            fr.append(float(acc.mean()))
+        lf = lambda t: frac[t - 1] if t else 0.0  # the leaderless fraction BEFORE round t
+        out["leaderless_fraction"] = {"at_start_of_timed_region": lf(W), "at_end": frac[W + K - 1]}
         out["ms_per_round_by_leaderless_fraction"] = [
-            {"rounds": [marks[q] - W, marks[q + 1] - W], "leaderless_fraction": [fr[q], fr[q + 1]],
+            {"rounds": [marks[q] - W, marks[q + 1] - W], "leaderless_fraction": [lf(marks[q]), frac[marks[q + 1] - 1]],
              "ms_per_round": window_s[q] * 1e3 / max(marks[q + 1] - marks[q], 1)} for q in range(4)]
-        out["config"]["stationary"] = ("no: a partition that lost its leader stays leaderless (SURVEY.md 7.3 Q4) and campaigns at every election "
-                                       "timeout; ms_per_round_by_leaderless_fraction times the same run in four windows")
+        out["partitions_that_failed_at_least_once"] = float(tr.ever_failed.mean())
+        out["fsm_rows_per_round"] = fsm[0] / (W + K)
+        out["config"]["fsm_rows"] = ("drained by the host every round (jg_drain_applies_view: the pinned queue, no copy)" if args.drain_applies
+                                     else "left queued until the end of the run (--drain-applies 0)")
+        out["config"]["repair_after_rounds"] = D
+        out["config"]["rounds_before_the_timed_region"] = W
+        out["config"]["stationary"] = (
+            f"yes: failures at {args.failures} %/round of the partitions that are up, each re-created {D} rounds later and then what every "
+            "partition was at round 0 (Q8 / Q10: what the reference leaves of a failed partition can neither append nor be "
+            "caught up at a cost that does not grow with the run) - leaderless fraction, decisions per round and cost per "
+            "round are flat (leaderless_fraction, ms_per_round_by_leaderless_fraction: the same run in four windows)"
+            if D else
+            "no (--repair-after 0): a partition that lost its leader stays leaderless (SURVEY.md 7.3 Q4) and campaigns at every "
+            "election timeout; ms_per_round_by_leaderless_fraction times the same run in four windows")
         print(json.dumps(out), flush=True)
     lib.close()
     if world > 1:
@@ -1013,6 +1046,11 @@ def main():
                          "every node, every node runs both halves over the cluster's mailbox columns")
     ap.add_argument("--vote-words", type=int, choices=[0, 1], default=0,
                     help="--cluster with --failures: JG_CLUSTER_OPT_VOTE_WORDS - an election's traffic as mailbox words (csrc/jg_votes.h) instead of rows")
+    ap.add_argument("--drain-applies", type=int, choices=[0, 1], default=1,
+                    help="--cluster --failures: hand the rounds' FSM rows (the Apply ranges of repaired followers) to the host every round")
+    ap.add_argument("--repair-after", type=int, default=10,
+                    help="--cluster --failures (single lead): rounds after which a failed partition is repaired (every replica restarts, "
+                         "replica 0 is re-seated) - the stationary configs[4] trace; 0: never (the leaderless fraction grows)")
     ap.add_argument("--leadership", choices=["blocked", "interleaved"], default="blocked",
                     help="with --any-leader: node g*R/G (contiguous blocks: what an adapter that numbers its partitions by preferred "
                          "leader gets) or node g %% R leads partition g")

@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define JG_ABI_VERSION 6u /* v5: jg_step_node = arrival-order Apply (fsm_tx: Apply / Notify / Apply per partition), JG_CLUSTER_ANY_LEADER,
-                             jg_dense_cluster_withdraw_appends, JG_COL_UNCHECKED, JG_COL_UPLOAD_NOW; v6: jg_dense_cluster_set_option */
+                             jg_dense_cluster_withdraw_appends, JG_COL_UNCHECKED, JG_COL_UPLOAD_NOW; v6: jg_dense_cluster_set_option, jg_dense_cluster_offer_appends, JG_CMD_RECREATE */
 #define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
 #define JG_CHAIN_WINDOW 8u  /* chain segments (gaps / forks) per group besides the main run */
 #define JG_MAX_INFLIGHT 5u  /* src/raft/progress.rs:117                                    */
@@ -73,6 +73,7 @@ enum { JG_ROLE_FOLLOWER = 0, JG_ROLE_CANDIDATE = 1, JG_ROLE_LEADER = 2 };
  *   CLIENT_REQUEST    -             -      request token -          -
  *   CLIENT_RESPONSE   -             -      request token -          -
  *   RESTART (engine)  -             -      -             -          -
+ *   RECREATE (engine) -             -      -             -          -
  * (*) index of the first of `aux` consecutive entries in the batch's
  *     blk_id/blk_next side arrays (Vec<Block>, payload stays on the host).
  * (**) the reference's handler does not look at the sender (leader.rs:222-231) and neither does
@@ -96,8 +97,13 @@ enum {
   JG_CMD_CLIENT_REQUEST = 10,
   JG_CMD_CLIENT_RESPONSE = 11,
   JG_CMD_RESTART = 12,
-  JG_CMD__COUNT = 13
+  JG_CMD_RECREATE = 13,
+  JG_CMD__COUNT = 14
 };
+/* The two engine commands (no reference Command): JG_CMD_RESTART = the replica's process restarts on its persisted tree
+ * (Raft::new + Chain::new on the sled directory it left: follower.rs:68-95, chain.rs:117-137); JG_CMD_RECREATE = on an
+ * EMPTY directory - the replica of a partition that was re-created: genesis only, no "commit" key (chain.rs:117-153), and
+ * the host's block store for the group starts over with it.  Both clear a fault; neither looks at the other columns. */
 
 /* ---- Address, src/raft/rpc.rs:5-14 ---------------------------------------- */
 enum { JG_TO_PEERS = 0, JG_TO_PEER = 1, JG_TO_LOCAL = 2, JG_TO_CLIENT = 3, JG_TO_QUEUE = 4 };
@@ -588,6 +594,9 @@ int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const ui
  * (what the reference makes of a re-elected leader is Q8: its first append panics, chain.rs:163).  Asynchronous on the
  * cluster's stream; the list must stay valid until then (jg_sync). */
 int jg_dense_cluster_withdraw_appends(jg_dense_cluster* c, const uint32_t* groups_dev, uint32_t n);
+/* ... and `per_round` ClientRequests per round for them from the next round on (0: withdraw) - the client proposes again to
+ * partitions that were re-created (JG_CMD_RECREATE) and have a leader that can append.  Same conventions. */
+int jg_dense_cluster_offer_appends(jg_dense_cluster* c, const uint32_t* groups_dev, uint32_t n, uint64_t per_round);
 /* n_rounds protocol rounds at logical times now_ms, now_ms + dt_ms, ...; asynchronous (jg_sync the nodes).  Two or more
  * rounds are replayed as captured graphs (logical time and step numbers live in a device-resident clock that advances
  * itself), eight rounds to a graph where n_rounds allows; the results are those of n_rounds calls with one round each. */

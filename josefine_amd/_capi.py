@@ -26,7 +26,7 @@ ROLE_FOLLOWER, ROLE_CANDIDATE, ROLE_LEADER = 0, 1, 2
 
 (CMD_TICK, CMD_PROPOSE, CMD_VOTE_REQUEST, CMD_VOTE_RESPONSE, CMD_APPEND_ENTRIES,
  CMD_APPEND_RESPONSE, CMD_HEARTBEAT, CMD_HEARTBEAT_RESPONSE, CMD_TIMEOUT, CMD_NOOP,
- CMD_CLIENT_REQUEST, CMD_CLIENT_RESPONSE, CMD_RESTART) = range(13)
+ CMD_CLIENT_REQUEST, CMD_CLIENT_RESPONSE, CMD_RESTART, CMD_RECREATE) = range(14)
 
 TO_PEERS, TO_PEER, TO_LOCAL, TO_CLIENT, TO_QUEUE = range(5)
 QUEUE_FLUSH, QUEUE_DROP = 1, 2
@@ -256,6 +256,7 @@ class Api:
         "dense_cluster_set_option": (C.c_int, [_P, C.c_uint32, C.c_uint64]),
         "dense_cluster_set_appends": (C.c_int, [_P, C.c_uint64, _P]),
         "dense_cluster_withdraw_appends": (C.c_int, [_P, _P, C.c_uint32]),
+        "dense_cluster_offer_appends": (C.c_int, [_P, _P, C.c_uint32, C.c_uint64]),
         "dense_cluster_rounds": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32]),
         "dense_cluster_mailboxes": (C.c_int, [_P, C.POINTER(LeaderInbox), C.POINTER(LeaderOutbox)]),
         "dense_cluster_round_routed": (C.c_int, [_P, C.c_uint64, C.POINTER(CmdBatch), C.POINTER(RouteStats)]),
@@ -300,6 +301,6 @@ HEADER_SYMBOLS = [
     "jg_step_dense_leader", "jg_step_dense_follower", "jg_chain_compact", "jg_chain_compact_resident", "jg_drain_compacted", "jg_sync", "jg_stream_wait",
     "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_drain_prefetch", "jg_drain_flush", "jg_drain_wait", "jg_read_state", "jg_get_counters",
     "jg_device_alloc", "jg_device_free", "jg_device_upload", "jg_device_download",
-    "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_dense_cluster_create", "jg_dense_cluster_destroy", "jg_dense_cluster_set_option", "jg_dense_cluster_set_appends", "jg_dense_cluster_withdraw_appends", "jg_dense_cluster_rounds", "jg_dense_cluster_mailboxes", "jg_dense_cluster_round_routed", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",
+    "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_dense_cluster_create", "jg_dense_cluster_destroy", "jg_dense_cluster_set_option", "jg_dense_cluster_set_appends", "jg_dense_cluster_withdraw_appends", "jg_dense_cluster_offer_appends", "jg_dense_cluster_rounds", "jg_dense_cluster_mailboxes", "jg_dense_cluster_round_routed", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",
     "jg_step_node", "jg_node_outbox_view", "jg_submit_reserve", "jg_submit_commit", "jg_node_inbox_columns",
 ]

@@ -998,8 +998,15 @@ __device__ inline uint32_t jg_leader_apply(const JgDev& d, JgLane& L, const JgCm
   }
 }
 
-// process restart: Raft::<Follower>::new (follower.rs:68-95) on the persisted chain
-__device__ inline void jg_restart(const JgDev& d, JgLane& L) {
+// process restart: Raft::<Follower>::new (follower.rs:68-95) on the persisted chain - or (`empty_store`: JG_CMD_RECREATE)
+// on an EMPTY data directory: the replica of a partition that was re-created starts over from Chain::new's genesis
+// (chain.rs:117-153: no blocks, no "commit" key)
+__device__ inline void jg_restart(const JgDev& d, JgLane& L, bool empty_store = false) {
+  if (empty_store) {
+    L.flags &= ~(JGF_COMMIT_KEY | JGF_WIN_MASK | JGF_NO_GENESIS);  // the id set is {0}: the run [0, 0], no segments
+    L.run_hi = 0;
+    L.commit = 0;
+  }
   L.flags &= ~(JGF_FAULT_MASK | JGF_ROLE_MASK | JGF_VOTED | JGF_HAS_LEADER | JGF_REPL_MASK);
   uint32_t f = jg_chain_reopen(d, L);
   L.term = 0;
@@ -1016,8 +1023,8 @@ __device__ inline void jg_restart(const JgDev& d, JgLane& L) {
 template <uint32_t KINDS = JG_KINDS_ALL>
 __device__ inline void jg_apply(const JgDev& d, JgLane& L, const JgCmd& c, const uint64_t* blk_id,
                                 const uint64_t* blk_next) {
-  if (JG_KIND_IN(JG_CMD_RESTART) && c.kind == JG_CMD_RESTART) {
-    jg_restart(d, L);
+  if (JG_KIND_IN(JG_CMD_RESTART) && (c.kind == JG_CMD_RESTART || c.kind == JG_CMD_RECREATE)) {  // (one mask bit for the two)
+    jg_restart(d, L, c.kind == JG_CMD_RECREATE);
     return;
   }
   if (jg_fault(L)) return;  // the reference process is gone

@@ -697,13 +697,13 @@ __global__ void k_route_mask_appends(uint32_t G, const uint32_t* __restrict__ fl
   if (g < G) own_col[g] = (flags[g] & JGF_ROLE_MASK) == JG_ROLE_LEADER ? offered[g] : JG_ANSWER(0, JG_HB_NONE);  // (answer words)
 }
 
-// jg_dense_cluster_withdraw_appends: no more ClientRequests for the listed groups
-__global__ void k_withdraw_appends(uint32_t n, const uint32_t* __restrict__ groups, uint32_t G, uint64_t* __restrict__ offered,
-                                   uint64_t* __restrict__ own_col) {
+// jg_dense_cluster_offer_appends / _withdraw_appends: `per_round` ClientRequests (0: no more) for the listed groups
+__global__ void k_offer_appends(uint32_t n, const uint32_t* __restrict__ groups, uint32_t G, uint64_t per_round, uint64_t* __restrict__ offered,
+                                uint64_t* __restrict__ own_col) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t g = groups[i];
   if (g >= G) return;
-  offered[g] = JG_ANSWER(0, JG_HB_NONE);
-  if (own_col) own_col[g] = JG_ANSWER(0, JG_HB_NONE);
+  offered[g] = JG_ANSWER(per_round, JG_HB_NONE);
+  if (own_col) own_col[g] = JG_ANSWER(per_round, JG_HB_NONE);
 }

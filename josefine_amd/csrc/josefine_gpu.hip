@@ -2488,15 +2488,19 @@ int jg_dense_cluster_set_appends(jg_dense_cluster* c, uint64_t uniform, const ui
   return jg_device_upload(c->nodes[c->lead], c->acks + (size_t)c->lead * c->G, src, (size_t)c->G * 8);
 }
 
-int jg_dense_cluster_withdraw_appends(jg_dense_cluster* c, const uint32_t* groups_dev, uint32_t n) {
+int jg_dense_cluster_offer_appends(jg_dense_cluster* c, const uint32_t* groups_dev, uint32_t n, uint64_t per_round) {
   if (!c || (n && !groups_dev)) return fail(JG_EINVAL, "null argument");
+  if (per_round >= JG_MAILBOX_NONE) return fail(JG_EINVAL, "appends per round: out of the own slot's domain");
   if (!n) return JG_OK;
   jg_engine* L = c->nodes[c->lead];
   HIPCHK(hipSetDevice(L->device));
-  hipLaunchKernelGGL(k_withdraw_appends, dim3((n + 255) / 256), dim3(256), 0, L->stream, n, groups_dev, c->G, c->offered,
+  hipLaunchKernelGGL(k_offer_appends, dim3((n + 255) / 256), dim3(256), 0, L->stream, n, groups_dev, c->G, per_round, c->offered,
                      c->any ? (uint64_t*)nullptr : c->acks + (size_t)c->lead * c->G);
   HIPCHK(hipGetLastError());
   return JG_OK;
+}
+int jg_dense_cluster_withdraw_appends(jg_dense_cluster* c, const uint32_t* groups_dev, uint32_t n) {
+  return jg_dense_cluster_offer_appends(c, groups_dev, n, 0);
 }
 
 int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_leader_outbox* out) {

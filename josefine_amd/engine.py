@@ -335,6 +335,10 @@ class BatchedRaft:
         side = [np.ascontiguousarray(x if x is not None else [], dtype=np.uint64) for x in (blk_id, blk_next)]
         return DeviceRows(self, cols, side)
 
+    def upload_u32(self, values) -> "DeviceList":
+        """A list of uint32 (group numbers) parked in device memory: jg_dense_cluster_withdraw_appends / _offer_appends."""
+        return DeviceList(self, np.ascontiguousarray(values, dtype=np.uint32))
+
     def step_device_rows(self, rows: "DeviceRows", now_ms: int = 0) -> None:
         """jg_step_device_rows: apply a device-resident, group-sorted batch (no host pass)."""
         self._flush_pending()
@@ -667,6 +671,27 @@ class DeviceRows:
         self._ptrs = []
 
 
+class DeviceList:
+    """uint32 values in device memory (jg_device_alloc + jg_device_upload); .ptr is the device address."""
+
+    def __init__(self, engine, values: np.ndarray):
+        self.engine, self.n = engine, len(values)
+        p = C.c_void_p()
+        engine._check(engine.api.device_alloc(engine._h, max(values.nbytes, 16), C.byref(p)))
+        self._p = p
+        if values.nbytes:
+            engine._check(engine.api.device_upload(engine._h, p, values.ctypes.data, values.nbytes))
+
+    @property
+    def ptr(self) -> int:
+        return self._p.value
+
+    def free(self) -> None:
+        if self._p:
+            self.engine.api.device_free(self.engine._h, self._p)
+            self._p = None
+
+
 class DenseCluster:
     """jg_dense_cluster: the R nodes of every partition as R engines of one process, their
     protocol rounds driven from inside the library (josefine_gpu.h, "a closed loop of dense node
@@ -707,6 +732,10 @@ class DenseCluster:
     def withdraw_appends(self, groups_dev_ptr: int, n: int) -> None:
         """jg_dense_cluster_withdraw_appends: no more ClientRequests for the n groups listed in device memory."""
         self.nodes[0]._check(self.api.dense_cluster_withdraw_appends(self._h, C.c_void_p(groups_dev_ptr), int(n)))
+
+    def offer_appends(self, groups_dev_ptr: int, n: int, per_round: int) -> None:
+        """jg_dense_cluster_offer_appends: `per_round` ClientRequests per round for the n groups listed in device memory."""
+        self.nodes[0]._check(self.api.dense_cluster_offer_appends(self._h, C.c_void_p(groups_dev_ptr), int(n), int(per_round)))
 
     def rounds(self, now_ms: int, dt_ms: int, n: int) -> None:
         self.nodes[0]._check(self.api.dense_cluster_rounds(self._h, int(now_ms), int(dt_ms), int(n)))

@@ -254,6 +254,18 @@ class BatchedRaft {
     step(now_ms);
     return r;
   }
+  // the replica of a partition that was RE-CREATED: an empty data directory (JG_CMD_RECREATE) - the host's block
+  // store of the group starts over with genesis (chain.rs:139-153), like the engine's image of it
+  void recreate(uint32_t g, uint64_t now_ms = 0) {
+    stores_[g] = BlockStore{};
+    stores_[g].insert(Block{0, 0, {}});
+    extend_failed_.erase(g);
+    queued_[g].clear();
+    Command c;
+    c.kind = JG_CMD_RECREATE;
+    submit(g, c);
+    step(now_ms);
+  }
   NodeId self_id(uint32_t g) {
     uint8_t s = 0;
     check(jg_read_state(e_, JG_FIELD_SELF_SLOT, 0, &s, g, 1));

@@ -172,3 +172,94 @@ def any_failure_rows(seed, tick, G, R, percent, leader_of, group_base=0, whole_g
         if keep.any():
             out[n] = dict(kind=kind[keep], group=group[keep])
     return out, failing
+
+
+class FailureRepairTrace:
+    """BASELINE.json configs[4] as a STATIONARY trace (cluster_failure_rows' failures + a repair schedule).
+
+    Failure, every tick, every partition that is up with probability percent/100 (the hash of failure_rows): the leader's
+    replica (`lead`) crashes and restarts, a designated follower (`candidate`) - restarted as well, so that voted_for ==
+    None: nobody else may campaign - receives Timeout and campaigns; the other replicas remember their
+    vote and refuse, so the partition stays leaderless and its candidate campaigns again at every election timeout -
+    every VoteRequest / VoteResponse of that travels through the cluster's transport.  The client stops proposing to it.
+    Repair, `repair_after` ticks later (an operator's runbook: SURVEY.md 7.3 Q4 allows any explicit trace).  What the
+    reference leaves of a partition whose leader failed cannot be brought back to where it was: no replica that led or
+    followed it can ever append again (Q8: chain.rs:163 - `id_gen` is re-seeded below the head), and a new leader re-sends
+    the chain from block 1 (Q10), longer with every round the benchmark has run.  So the operator RE-CREATES the partition:
+    every replica restarts on an empty data directory (JG_CMD_RECREATE: Raft::new + Chain::new's
+    genesis, chain.rs:117-153) and replica `lead` receives Timeout: it campaigns, its VoteRequests are routed and answered
+    through can_vote like any.  One tick later - when a real election's first answers would be in - it is seated: granted
+    VoteResponses from the next R/2 replicas, injected (traces.elect_where's rows, the trace's only synthetic votes: over a
+    transport that delivers each sender's answers back to back an election of more than three nodes cannot be WON,
+    DESIGN.md "The cluster transport"); it is elected, its Heartbeat brings the others in (the voters' real answers
+    arrive at a leader, which ignores them), and the client proposes again.  The partition is then exactly what every
+    partition was at tick 0: the trace is stationary in everything - leaderless fraction (about
+    percent x (repair_after + 1) / 100), decisions per round, cost per round.
+    rows(tick) must be called for tick = 0, 1, 2, ... in order; returns (per node one group-sorted column dict or None - for
+    jg_dense_cluster_round_routed's `inject` -, the partitions failing this tick, the partitions repaired this tick);
+    appends() = the ClientRequests per partition for the round of the last rows(): 0 where the partition is down (the
+    cluster offers them where the lead node leads when the dense round begins: a partition repaired in this round has its
+    leader by then)."""
+
+    def __init__(self, seed, G, R, percent=1, repair_after=10, lead=0, candidate=1, group_base=0, node_ids=None):
+        self.seed, self.G, self.R, self.percent, self.D = seed, G, R, percent, int(repair_after)
+        self.lead, self.candidate, self.group_base = lead, candidate, group_base
+        self.ids = np.arange(1, R + 1, dtype=np.uint32) if node_ids is None else np.asarray(node_ids, np.uint32)
+        self.down_since = np.full(G, -1, np.int64)
+        self.ever_failed = np.zeros(G, bool)
+        self.campaigning = np.zeros(G, bool)  # re-created in the last tick, to be seated in this one
+        self.next_tick = 0
+
+    def leaderless(self):
+        return self.down_since >= 0
+
+    def appends(self):
+        return np.where(self.down_since >= 0, 0, 1).astype(np.uint64)
+
+    def rows(self, tick):
+        assert tick == self.next_tick, "FailureRepairTrace.rows: ticks in order"
+        self.next_tick += 1
+        G, R = self.G, self.R
+        gg = np.arange(G, dtype=np.uint64) + np.uint64(self.group_base)
+        repaired = np.nonzero(self.campaigning)[0].astype(np.uint32)  # seated now: up again
+        recreated = np.nonzero((self.down_since >= 0) & (self.down_since == tick - self.D))[0].astype(np.uint32)
+        self.down_since[repaired] = -1
+        self.campaigning[:] = False
+        self.campaigning[recreated] = True
+        hit = synth_hash(self.seed, tick, gg, 7) % np.uint64(100) < np.uint64(self.percent)
+        up = self.down_since < 0
+        up[repaired] = False  # (not in the tick of its repair)
+        failing = np.nonzero(hit & up)[0].astype(np.uint32)
+        self.down_since[failing] = tick
+        self.ever_failed[failing] = True
+        out = [None] * R
+        nf, nc, nr = len(failing), len(recreated), len(repaired)
+        if not nf and not nc and not nr:
+            return out, failing, repaired
+        voters = [self.ids[(self.lead + k) % R] for k in range(1, R // 2 + 1)]
+        for n in range(R):
+            kinds, groups, froms, flags, within = [], [], [], [], []
+
+            def add(g, *rows_):  # rows_: (kind, from, flag) per partition of g, in that order
+                for k, (kind, frm, flag) in enumerate(rows_):
+                    kinds.append(np.full(len(g), kind, np.uint8)), groups.append(g), within.append(np.full(len(g), k, np.int64))
+                    froms.append(np.full(len(g), frm, np.uint32)), flags.append(np.full(len(g), flag, np.uint8))
+
+            if nf and n == self.lead:
+                add(failing, (capi.CMD_RESTART, 0, 0))
+            elif nf and n == self.candidate:
+                add(failing, (capi.CMD_RESTART, 0, 0), (capi.CMD_TIMEOUT, 0, 0))
+            if nc and n == self.lead:
+                add(recreated, (capi.CMD_RECREATE, 0, 0), (capi.CMD_TIMEOUT, 0, 0))
+            elif nc:
+                add(recreated, (capi.CMD_RECREATE, 0, 0))
+            if nr and n == self.lead:
+                add(repaired, *[(capi.CMD_VOTE_RESPONSE, v, 1) for v in voters])
+            if not kinds:
+                continue
+            group = np.concatenate(groups)
+            # group-sorted, a partition's rows in the order given above (the three sets are disjoint)
+            order = np.lexsort((np.concatenate(within), group))
+            out[n] = dict(kind=np.concatenate(kinds)[order], group=group[order], from_=np.concatenate(froms)[order],
+                          term=np.ones(len(group), np.uint64), flag=np.concatenate(flags)[order])
+        return out, failing, repaired

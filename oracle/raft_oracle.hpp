@@ -309,8 +309,10 @@ struct Raft {
     set_election_timeout(now);
   }
   // process restart: Chain::new on the persisted tree + fresh volatile state
-  void restart(uint64_t now) {
-    chain.reopen();
+  // (empty_store: JG_CMD_RECREATE - Chain::new on an empty directory, chain.rs:117-153)
+  void restart(uint64_t now, bool empty_store = false) {
+    if (empty_store) chain.open_fresh();
+    else chain.reopen();
     reset_volatile(now);
   }
 
@@ -400,8 +402,8 @@ struct Raft {
 
   // ---- Apply::apply dispatch (mod.rs:471-479) --------------------------------
   void apply(const Cmd& c, uint64_t now) {
-    if (c.kind == JG_CMD_RESTART) {
-      restart(now);
+    if (c.kind == JG_CMD_RESTART || c.kind == JG_CMD_RECREATE) {
+      restart(now, c.kind == JG_CMD_RECREATE);
       return;
     }
     if (fault) return;  // the process is gone

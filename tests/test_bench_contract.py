@@ -147,7 +147,15 @@ def test_cluster_and_failure_modes():
     # configs[4] as specified: real votes, routed between the nodes on the device
     d = run(["--cluster", "--failures", "2", "--groups", "40000", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
     assert KEYS <= set(d) and "configs[4] as specified" in d["config"]["workload"] and d["value"] > 0
-    assert d["rows_routed_per_round"] > 0 and 0 < d["leaderless_fraction"]["at_start_of_timed_region"] < d["leaderless_fraction"]["at_end"] < 1
+    lf = d["leaderless_fraction"]  # the stationary trace (failures + re-creation after --repair-after rounds): flat at about p x (D + 1)
+    assert d["rows_routed_per_round"] > 0 and 0.1 < lf["at_start_of_timed_region"] < 0.3 and abs(lf["at_start_of_timed_region"] - lf["at_end"]) < 0.02
+    assert d["config"]["stationary"].startswith("yes") and d["config"]["repair_after_rounds"] == 10 and d["steps"] == 20 and d["warmup"] == 5
+    ms = [w["ms_per_round"] for w in d["ms_per_round_by_leaderless_fraction"]]
+    assert len(ms) == 4 and min(ms) > 0
+    # ... and without repairs (rounds 2-4's trace), with the election vocabulary as mailbox words: the leaderless fraction grows
+    d = run(["--cluster", "--failures", "2", "--groups", "40000", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--repair-after", "0", "--vote-words", "1"])
+    lf = d["leaderless_fraction"]
+    assert d["vote_words"] is True and d["config"]["stationary"].startswith("no") and 0 < lf["at_start_of_timed_region"] < lf["at_end"] < 1
     r = d["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["leader_kernel"]["avg_launch_us"] > 0
 

@@ -427,6 +427,83 @@ def test_routed_cluster_elections_on_the_oracle():
     assert (cl.nodes[2].read("voted_for")[failed] == L.node_ids[0]).all()
 
 
+def test_stationary_failure_repair_trace_on_the_oracle():
+    """CPU: configs[4] with the repair schedule (josefine_amd.traces.FailureRepairTrace: bench.py --cluster --failures) through
+    the Python statement of the transport over oracle engines.  A failing partition is leaderless until its repair - it is
+    re-created: every replica restarts on an empty store, replica 0 is seated and its Heartbeat brings the others in - and is
+    led by node 0 again from the repair's round on, appending like a partition at tick 0; the leaderless fraction settles at
+    p x D; nothing faults; no row leaves the transport's vocabulary."""
+    from dense_node import RoutedCluster
+    from josefine_amd.traces import FailureRepairTrace
+    G, R, T, P, D = 800, 5, 70, 2, 6
+    cl = RoutedCluster(oracle_engine, G, R, seed=5)
+    tr = FailureRepairTrace(77, G, R, P, D, node_ids=cl.member_ids)
+    frac, up_for = [], np.zeros(G, np.int64)  # rounds a partition has been appending since tick 0 / its re-creation
+    for t in range(T):
+        inj, failing, repaired = tr.rows(t)
+        cl.round(tr.appends(), inject=inj)
+        down = tr.leaderless()
+        role = cl.nodes[0].read("role")
+        assert (role[down] != capi.ROLE_LEADER).all() and (role[~down] == capi.ROLE_LEADER).all(), t
+        frac.append(float(down.mean()))
+        up_for[repaired] = 0
+        up_for[~down] += 1
+        for n in cl.nodes:
+            assert (n.read("fault") == 0).all(), t
+    assert tr.ever_failed.sum() > G // 2
+    assert abs(np.mean(frac[20:45]) - np.mean(frac[45:])) < 0.02 and 0.06 < np.mean(frac[20:]) < 0.16  # flat, about p x D
+    assert sum(len(k) for k in cl.kept) == 0 and cl.delivered.sum() > 0
+    # a partition that is up appends one block per round since tick 0 or since it was re-created, and commits them
+    up = ~tr.leaderless()
+    assert (cl.nodes[0].read("head")[up] == up_for[up]).all()
+    settled = up & (up_for > 4)
+    assert settled.sum() > G // 2 and (cl.nodes[0].read("commit")[settled] >= up_for[settled] - 3).all()
+    rep = settled & tr.ever_failed  # ... re-created ones too: every replica follows the seated leader
+    assert rep.sum() > G // 4 and (cl.nodes[2].read("voted_for")[rep] == cl.member_ids[0]).all() and (cl.nodes[3].read("head")[rep] >= up_for[rep] - 2).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,words", [(5, False), (5, True), (3, True)])
+def test_stationary_failure_repair_trace_device_parity(R, words):
+    """the same trace through jg_dense_cluster_round_routed (rows, and with JG_CLUSTER_OPT_VOTE_WORDS): every state column of
+    every node after every round == the oracle cluster's; nothing left for the host; the client's proposals withdrawn and
+    offered again on the device (jg_dense_cluster_withdraw_appends / _offer_appends)"""
+    from josefine_amd import DenseCluster as LibCluster
+    from dense_node import RoutedCluster
+    from josefine_amd.traces import FailureRepairTrace
+    G, T, P, D = 3000, 60, 2, 6
+    ora = RoutedCluster(oracle_engine, G, R, seed=5)
+    nodes = [BatchedRaft(G, R, seed=5 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
+    elect_all(nodes[0])
+    nodes[0].drain_messages(), nodes[0].drain_applies()
+    lib = LibCluster(nodes, vote_words=words)
+    lib.set_appends(1)
+    tr = FailureRepairTrace(99, G, R, P, D, node_ids=ora.member_ids)
+    for t in range(T):
+        inj, failing, repaired = tr.rows(t)
+        lists = [nodes[0].upload_u32(x) if len(x) else None for x in (failing, repaired)]
+        if lists[0] is not None:
+            lib.withdraw_appends(lists[0].ptr, len(failing))
+        if lists[1] is not None:
+            lib.offer_appends(lists[1].ptr, len(repaired), 1)
+        up = [None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(inj)]
+        st = lib.round_routed((t + 1) * 100, up)
+        ora.round(tr.appends(), inject=inj)
+        for n in range(R):
+            compare_snapshots(nodes[n], ora.nodes[n], f"round {t} node {n}")
+        want = [sum(len(r) for _, r in ora.inbound[n]) for n in range(R)]
+        assert (st["delivered"] == want) if not words else all(a <= b for a, b in zip(st["delivered"], want)), (t, st["delivered"], want)
+        for rows in up + lists:
+            if rows is not None:
+                rows.free()
+    for n in range(R):
+        assert nodes[n].drain_messages().tobytes() == ora.kept[n].tobytes()
+        assert nodes[n].drain_faults().tobytes() == ora.nodes[n].drain_faults().tobytes()
+        assert nodes[n].drain_applies().tobytes() == ora.nodes[n].drain_applies().tobytes()
+        assert nodes[n].counters()["decisions"] == ora.nodes[n].counters()["decisions"]
+    lib.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("R,percent,also", [(3, 3, ()), (5, 2, ()), (5, 2, (2,)), (3, 3, (2,))])
 def test_routed_cluster_device_transport_parity(R, percent, also):
