@@ -959,11 +959,18 @@ def secondary_lines(args):
         "command": x["command"], "round_us": x["line"]["ms_per_step_events"] * 1e3 if "ms_per_step_events" in x["line"] else x["line"]["ms_per_step"] * 1e3,
         "frac": x["line"]["roofline"]["frac"], "leader_kernel_us": x["line"]["roofline"]["leader_kernel"]["avg_launch_us"],
         "leader_kernel_frac": x["line"]["roofline"]["leader_kernel"]["frac"], "decisions_per_s": x["line"]["value"]}
-    x = run("routed_round", ["--cluster", "--failures", "1", "--steps", "40", "--warmup", "10"])
-    out["routed_round"] = x if "error" in x else {
-        "command": x["command"], "round_ms": x["line"]["ms_per_step"], "frac": x["line"]["roofline"]["frac"],
-        "rows_routed_per_round": x["line"]["rows_routed_per_round"], "leaderless_fraction": x["line"]["leaderless_fraction"],
-        "decisions_per_s": x["line"]["value"]}
+    # configs[4] as specified, the STATIONARY trace (failures + re-creation after 10 rounds): the election vocabulary as
+    # mailbox words (JG_CLUSTER_OPT_VOTE_WORDS) and, beside it, everything as rows; then rounds 2-4's trace (no repairs:
+    # the leaderless fraction grows through the region) for continuity with their lines
+    def routed(x):
+        return x if "error" in x else {
+            "command": x["command"], "round_ms": x["line"]["ms_per_step"], "frac": x["line"]["roofline"]["frac"], "vote_words": x["line"]["vote_words"],
+            "rows_routed_per_round": x["line"]["rows_routed_per_round"], "leaderless_fraction": x["line"]["leaderless_fraction"],
+            "stationary": x["line"]["config"]["stationary"].split(":")[0], "round_ms_by_window": [w["ms_per_round"] for w in x["line"]["ms_per_round_by_leaderless_fraction"]],
+            "decisions_per_s": x["line"]["value"]}
+    out["routed_round"] = routed(run("routed_round", ["--cluster", "--failures", "1", "--steps", "40", "--warmup", "10", "--vote-words", "1"]))
+    out["routed_round_rows_only"] = routed(run("routed_round_rows_only", ["--cluster", "--failures", "1", "--steps", "40", "--warmup", "10", "--vote-words", "0"]))
+    out["routed_round_no_repairs"] = routed(run("routed_round_no_repairs", ["--cluster", "--failures", "1", "--steps", "40", "--warmup", "10", "--vote-words", "1", "--repair-after", "0"]))
     x = run("any_leader", ["--cluster", "--any-leader", "--replicas", "3", "--steps", "100", "--warmup", "10"])
     out["per_partition_leadership"] = x if "error" in x else {
         "command": x["command"], "round_us": x["line"]["ms_per_step_events"] * 1e3, "frac": x["line"]["roofline"]["frac"],
@@ -1044,7 +1051,7 @@ def main():
     ap.add_argument("--any-leader", action="store_true",
                     help="with --cluster: per-partition leadership (JG_CLUSTER_ANY_LEADER) - leaders elected through the device transport on "
                          "every node, every node runs both halves over the cluster's mailbox columns")
-    ap.add_argument("--vote-words", type=int, choices=[0, 1], default=0,
+    ap.add_argument("--vote-words", type=int, choices=[0, 1], default=1,
                     help="--cluster with --failures: JG_CLUSTER_OPT_VOTE_WORDS - an election's traffic as mailbox words (csrc/jg_votes.h) instead of rows")
     ap.add_argument("--drain-applies", type=int, choices=[0, 1], default=1,
                     help="--cluster --failures: hand the rounds' FSM rows (the Apply ranges of repaired followers) to the host every round")

@@ -92,13 +92,16 @@ def test_default_line_carries_the_secondaries():
     fraction - so that BENCH_rNN.json holds more than the headline."""
     d = run(["--groups", "100000", "--steps", "40", "--warmup", "5", "--no-cpu-baseline"], env={"JG_BENCH_SECONDARY": "1"})
     sec = d["secondary"]
-    assert set(sec) == {"closed_loop", "routed_round", "per_partition_leadership", "per_partition_leadership_failures", "failures_tick",
-                        "event_loop"}
+    assert set(sec) == {"closed_loop", "routed_round", "routed_round_rows_only", "routed_round_no_repairs", "per_partition_leadership",
+                        "per_partition_leadership_failures", "failures_tick", "event_loop"}
     assert sec["per_partition_leadership_failures"]["rows_left_for_the_host"] == 0
     for k, v in sec.items():
         assert "error" not in v, (k, v)
     assert sec["closed_loop"]["round_us"] > 0 and 0 < sec["closed_loop"]["frac"] < 1
     assert sec["routed_round"]["round_ms"] > 0 and sec["per_partition_leadership"]["elections"]["won_through_the_transport"] is True
+    assert sec["routed_round"]["vote_words"] is True and sec["routed_round"]["stationary"] == "yes" and sec["routed_round_rows_only"]["vote_words"] is False
+    lf = sec["routed_round"]["leaderless_fraction"]
+    assert abs(lf["at_start_of_timed_region"] - lf["at_end"]) < 0.02 and sec["routed_round_no_repairs"]["stationary"] == "no"
     assert sec["event_loop"]["decisions_per_s"] > 0 and sec["event_loop"]["rows_on_the_general_path"] == 0
     assert sec["failures_tick"]["tick_ms"] > 0
 
