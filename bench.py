@@ -980,9 +980,10 @@ def secondary_lines(args):
         "command": x["command"], "round_ms": x["line"]["ms_per_step"], "frac": x["line"]["roofline"]["frac"],
         "elections_won_after_failures": x["line"]["elections_won_after_failures"], "leaderless_fraction": x["line"]["leaderless_fraction"],
         "rows_left_for_the_host": x["line"]["rows_left_for_the_host"], "decisions_per_s": x["line"]["value"]}
-    x = run("failures_tick", ["--failures", "1", "--steps", "96", "--warmup", "32"])
+    x = run("failures_tick", ["--failures", "1", "--steps", "160", "--warmup", "64"])  # (profiles/*/bench_failures_1pct.json's command)
     out["failures_tick"] = x if "error" in x else {
         "command": x["command"], "tick_ms": x["line"]["ms_per_step"], "dense_kernel_us": x["line"]["roofline"]["avg_launch_us"],
+        "tick_ms_without_final_flush": x["line"]["drain_pipeline"]["ms_per_step_without_final_flush"], "final_flush_ms": x["line"]["drain_pipeline"]["final_flush_ms"],
         "frac": x["line"]["roofline"]["frac"], "decisions_per_s": x["line"]["value"]}
     x = run("event_loop", ["--event-loop", "--steps", "12", "--warmup", "3", "--loops", "4"], cap=240)
     out["event_loop"] = x if "error" in x else {
@@ -1198,9 +1199,13 @@ def main():
             t += n
             n_launch += 1
         if fail_rows is not None:  # everything stepped is delivered before the clock stops
+            tf = time.perf_counter()
             eng.drain_flush()
             consume()
+            tail_s[0] = time.perf_counter() - tf  # (the region's last batch: its transfer overlaps nothing)
         return n_launch
+
+    tail_s = [0.0]
 
     drained = {"messages": 0, "applies": 0, "faults": 0}
 
@@ -1394,6 +1399,11 @@ def main():
                         "takes alone (profiles/r02/kernel_stats_failures_1pct.csv)"}
             out["tick_us"] = launch_s * 1e6
             out["rows_delivered_to_host"] = drained
+            # the region ends with a full drain - everything stepped is in host memory before the clock stops - whose transfer
+            # overlaps no tick: a fixed cost, so ms_per_step depends on --steps (0.081 at 160, 0.118 at 96).  Beside it: the
+            # tick with that tail taken out (what a longer run converges to) and the dense kernel alone.
+            out["drain_pipeline"] = {"ticks_per_batch": DRAIN_EVERY, "final_flush_ms": tail_s[0] * 1e3,
+                                     "ms_per_step_without_final_flush": (wall - tail_s[0]) * 1e3 / K, "dense_kernel_us": k_us.value}
         if batched is not None:
             out["batched_ticks"] = batched
         if not args.no_cpu_baseline:  # (rank 0, after the timed regions and their barriers; the other ranks wait below)

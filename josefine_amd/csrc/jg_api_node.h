@@ -1,0 +1,397 @@
+// jg_api_node.h - jg_step_node: the dense kernels behind the Apply surface.  Part of josefine_gpu.hip's one translation unit.
+#pragma once
+// ---- jg_step_node: a node's whole tick from host rows (jg_node.h) -----------------------------------
+namespace {
+int node_ensure(jg_engine* e) {
+  jg_engine::NodeStep& n = e->node;
+  if (n.ready) return JG_OK;
+  const size_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  int rc = JG_OK;
+#define A(ptr, cnt) \
+  if ((rc = dev_alloc(e, &ptr, (cnt))) != JG_OK) return rc
+  A(n.cols.answers, R * G);
+  A(n.cols.hbr_commit, R * G);
+  A(n.cols.token, G);
+  A(n.cols.f_beat, G);
+  A(n.cols.f_ae, G);
+  A(n.cols.f_leader, G);
+  A(n.cols.cls, G);
+  A(n.cols.lt_max, G);
+  A(n.cols.lt_min, G);
+  A(n.cols.lf_max, G);
+  A(n.cols.lf_min, G);
+  A(n.cols.fsm_delta, G);
+  A(n.cols.fsm_prev, G);
+  A(n.cols.fsm_mid, G);
+  A(n.cols.arr, 2 * R * G);
+  A(n.cols.fo, 2 * G);
+  A(n.cols.sparse_bits, (G + 63) / 64);
+  A(n.o_beat, G);
+  A(n.o_ae, R * G);
+  HIPCHK(hipMemsetAsync(n.o_ae, 0xff, std::max<size_t>(R * G * 8, 16), e->stream));  // (the own slot's row is never written: JG_NO_ACK once)
+  A(n.o_answer, G);
+  A(n.o_hbc, G);
+  A(n.d_nsparse, 4);
+  HIPCHK(hipHostMalloc((void**)&n.h_beat, std::max<size_t>(G * sizeof(jg_leader_beat), 16), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&n.h_ae, std::max<size_t>(R * G * 8, 16), hipHostMallocDefault));
+  std::memset(n.h_ae, 0xff, std::max<size_t>(R * G * 8, 16));  // (the own slot's row is not downloaded while it is the same for every group)
+  HIPCHK(hipHostMalloc((void**)&n.h_answer, std::max<size_t>(G * 8, 16), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&n.h_hbc, std::max<size_t>(G * 8, 16), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&n.h_nsparse, 16, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&n.h_in_answers, std::max<size_t>(R * G * 8, 16), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&n.h_in_hbc, std::max<size_t>(R * G * 8, 16), hipHostMallocDefault));
+  HIPCHK(hipEventCreateWithFlags(&n.ev_out, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&n.ev_cols, hipEventDisableTiming));
+  while (n.group_bits < 32 && (G - 1) >> n.group_bits) n.group_bits++;
+  n.bk_tile_bits = std::min<uint32_t>(JG_ROUTE_TILE_BITS, n.group_bits);
+  n.bk_buckets = ((uint32_t)G + (1u << n.bk_tile_bits) - 1u) >> n.bk_tile_bits;
+  const uint32_t bk_tiles = (n.bk_buckets + JG_ROUTE_SCAN_TILE - 1) / JG_ROUTE_SCAN_TILE;
+  n.bk_words = bk_tiles * JG_ROUTE_SCAN_TILE + n.bk_buckets + bk_tiles + 1;  // hist (whole tiles) | cur | tile
+  A(n.bk_mem, n.bk_words);
+#undef A
+  n.ready = true;
+  return JG_OK;
+}
+
+int node_dense_halves(jg_engine* e, uint64_t now_ms, uint32_t flags, uint32_t col_mask, uint32_t sparse_mode, uint64_t* bytes_down);
+int node_general(jg_engine* e, const JgNodeRows& rows, size_t n, size_t nb, uint32_t n_sparse, uint64_t now_ms);
+
+int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
+  jg_engine::NodeStep& nd = e->node;
+  const uint32_t halves = flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF);
+  // JG_NODE_ASYNC: no synchronisation inside the step - the general-path row count is looked at when the step is settled
+  const bool async = (flags & JG_NODE_ASYNC) != 0;
+  HIPCHK(hipSetDevice(e->device));
+  int rc = node_ensure(e);
+  if (rc) return rc;
+  if ((rc = node_settle(e))) return rc;  // (an earlier asynchronous step)
+  if ((rc = ensure_xq(e))) return rc;
+  e->stepped = true;
+  jg_engine::NodeStep::Pending& pend = nd.pending;
+  pend = jg_engine::NodeStep::Pending{};
+  const uint32_t seq0 = e->seq;
+  const size_t n = e->p_kind.size(), nb = e->p_blk_id.size();
+  if (n > 0x7fffffffull) return fail(JG_EINVAL, "batch too large: split it");
+  const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  static const bool trace = std::getenv("JG_TRACE_NODE") != nullptr;
+  auto clk = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double T0 = clk();
+  double T1 = T0, T2 = T0;
+  const uint32_t both_beats = (e->p_kinds_seen & 3u) == 3u;  // (a batch with Heartbeat AND AppendEntries rows: their consistency columns are needed)
+  const uint32_t ggrid = grid_for(G, 4096);
+  uint64_t bytes_up = 0;
+  // column inbound: the handed-out slots' columns go up as they are (8 bytes per partition and peer instead of two rows)
+  if (nd.col_mask && !(halves & JG_NODE_LEADER_HALF))  // (never dropped silently: the leader half is what applies them)
+    return fail(JG_EINVAL, "jg_step_node: a column was handed out (jg_node_inbox_columns) but the leader half does not run");
+  const uint32_t col_mask = nd.col_mask;
+  for (uint32_t r = 0; r < R;) {  // (neighbouring slots travel in one copy: a copy costs ~10 us before its first byte)
+    if (!((col_mask >> r) & 1u)) {
+      r++;
+      continue;
+    }
+    uint32_t r1 = r + 1;
+    while (r1 < R && ((col_mask >> r1) & 1u) && (((nd.col_hbc_mask >> r1) & 1u) == ((nd.col_hbc_mask >> r) & 1u))) r1++;
+    const size_t at = (size_t)r * G, len = (size_t)(r1 - r) * G * 8;
+    HIPCHK(hipMemcpyAsync(nd.cols.answers + at, nd.h_in_answers + at, len, hipMemcpyHostToDevice, e->stream));
+    if ((nd.col_hbc_mask >> r) & 1u)
+      HIPCHK(hipMemcpyAsync(nd.cols.hbr_commit + at, nd.h_in_hbc + at, len, hipMemcpyHostToDevice, e->stream));
+    else
+      HIPCHK(hipMemsetAsync(nd.cols.hbr_commit + at, 0, len, e->stream));
+    bytes_up += len * (((nd.col_hbc_mask >> r) & 1u) ? 2 : 1);
+    r = r1;
+  }
+  if (col_mask) {  // (jg_node_inbox_columns waits for this before it hands the same pinned buffers out again)
+    HIPCHK(hipEventRecord(nd.ev_cols, e->stream));
+    nd.cols_in_flight = true;
+  }
+  nd.col_mask = nd.col_hbc_mask = 0;  // (a hand-out covers one step)
+  hipLaunchKernelGGL(k_node_prefill, dim3(ggrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, e->uniform_self,
+                     halves & JG_NODE_LEADER_HALF, halves & JG_NODE_FOLLOWER_HALF, both_beats, col_mask);
+  uint32_t n_sparse = 0;
+  // the general path's sequence number is taken whether or not it runs: the shards of a multi-device engine must leave
+  // one node step with the same numbers (the router merges their rows by step number first: jg_multi.h)
+  e->seq = seq0 + 1;
+  if (n) {
+    // the rows in stream order, straight out of the pinned columns jg_submit (or the caller, in place:
+    // jg_submit_reserve) filled: one copy per column that is present - an optional column nobody
+    // provided is all zeros and is not uploaded at all (an AppendResponse row is 18 bytes then, not 34)
+    jg_engine::RowLayout lay;
+    node_row_layout(e, n, nb, lay);
+    const bool has_from = lay.has_from, has_term = lay.has_term, has_aux = lay.has_aux, has_flag = lay.has_flag;
+    const size_t o_id = lay.o_id, o_term = lay.o_term, o_aux = lay.o_aux, o_bid = lay.o_bid, o_bnext = lay.o_bnext, o_group = lay.o_group,
+                 o_from = lay.o_from, o_kind = lay.o_kind, o_flag = lay.o_flag;
+    if (nd.sp_cap < n) {  // (room for every row on the general path; grow-only, like the pinned columns)
+      if (nd.sp_key) HIPCHK(hipFree(nd.sp_key));
+      if (nd.sp_idx) HIPCHK(hipFree(nd.sp_idx));
+      nd.sp_cap = n + n / 2;
+      HIPCHK(hipMalloc((void**)&nd.sp_key, nd.sp_cap * 8));
+      HIPCHK(hipMalloc((void**)&nd.sp_idx, nd.sp_cap * 4));
+    }
+    char* B = nullptr;
+    jg_engine::EarlyUpload& u = e->up;
+    if (u.last_used >= 0) {  // whoever read the last step's rows (its settling included) is in the stream by now
+      HIPCHK(hipEventRecord(u.ev_free[u.last_used], e->stream));
+      u.read[u.last_used] = true;
+      u.last_used = -1;
+    }
+    if (u.valid && u.lay.same_batch(lay)) {
+      // JG_COL_UPLOAD_NOW: the batch left when it was committed - the kernels wait for its copies, nothing else does
+      B = u.buf[u.turn];
+      HIPCHK(hipStreamWaitEvent(e->stream, u.ev_up, 0));
+      bytes_up += n * (8u + 4u + 1u + (has_term ? 8u : 0u) + (has_aux ? 8u : 0u) + (has_from ? 4u : 0u) + (has_flag ? 1u : 0u)) + nb * 16u;
+      u.last_used = u.turn;
+      u.turn ^= 1;
+    } else {
+      Arena& ar = e->arenas[e->cur_arena];
+      HIPCHK(ar.alloc(lay.bytes, (void**)&B));
+      if ((rc = upload_node_rows(e, lay, B, e->stream, &bytes_up))) return rc;
+    }
+    u.valid = false;
+    // (the pinned columns are free again after the synchronisation below)
+    JgNodeRows rows{};
+    rows.n = (uint32_t)n;
+    rows.group = (const uint32_t*)(B + o_group), rows.kind = (const uint8_t*)(B + o_kind);
+    rows.from = has_from ? (const uint32_t*)(B + o_from) : nullptr, rows.term = has_term ? (const uint64_t*)(B + o_term) : nullptr;
+    rows.id = (const uint64_t*)(B + o_id), rows.aux = has_aux ? (const uint64_t*)(B + o_aux) : nullptr;
+    rows.flag = has_flag ? (const uint8_t*)(B + o_flag) : nullptr;
+    rows.blk_id = (const uint64_t*)(B + o_bid), rows.blk_next = (const uint64_t*)(B + o_bnext), rows.n_blocks = nb;
+    const uint32_t rgrid = grid_for(n, 4096);
+    HIPCHK(hipMemsetAsync(nd.d_nsparse, 0, 8, e->stream));
+    hipLaunchKernelGGL(k_node_classify, dim3(rgrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rows, e->uniform_self,
+                       halves, both_beats, col_mask);
+    hipLaunchKernelGGL(k_node_route, dim3(rgrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rows, e->uniform_self,
+                       both_beats, nd.sp_key, nd.sp_idx, nd.d_nsparse);
+    HIPCHK(hipGetLastError());
+    e->n_launch += 3;
+    HIPCHK(hipMemcpyAsync(nd.h_nsparse, nd.d_nsparse, 4, hipMemcpyDeviceToHost, e->stream));
+    if (!async) {
+      // the one synchronisation of a synchronous step: how many rows take the general path sizes that launch
+      T1 = clk();
+      HIPCHK(hipStreamSynchronize(e->stream));
+      T2 = clk();
+      n_sparse = nd.h_nsparse[0];
+      if (n_sparse && (rc = node_general(e, rows, n, nb, n_sparse, now_ms))) return rc;
+    }
+    pend.rows = rows, pend.n = n, pend.nb = nb;
+    // the pinned columns: the OTHER set from here on (an asynchronous step's uploads may still be reading this one)
+    e->p_kind.flip(), e->p_flag.flip(), e->p_group.flip(), e->p_from.flip(), e->p_term.flip(), e->p_id.flip();
+    e->p_aux.flip(), e->p_blk_id.flip(), e->p_blk_next.flip();
+    e->p_has_from = e->p_has_term = e->p_has_aux = e->p_has_flag = false;
+    e->p_kinds_seen = 0;
+    e->p_unchecked = false;
+  }
+  // the dense halves: every partition, the ones whose rows went the general way included (they are ticked here) -
+  // except in an asynchronous step, whose halves leave those partitions to the catch-up pass (node_settle)
+  pend.now_ms = now_ms, pend.flags = flags, pend.col_mask = col_mask;
+  e->seq = seq0 + 1;  // (the general path's number: taken above whether or not it runs)
+  uint64_t bytes_down = 0;
+  if ((rc = node_dense_halves(e, now_ms, flags, col_mask, async && n ? 1u : 0u, &bytes_down))) return rc;
+  {  // fsm_tx rows of the dense halves -> a step record of its own (per-group regions; compacted by the drains)
+    StepRec rec;
+    rec.n = G;
+    rec.seq = e->seq;
+    rec.msg_per_row = 0;
+    rec.fsm_per_row = JGN_FSM_ROWS;
+    Arena& ar = e->arenas[e->cur_arena];
+    const uint32_t n_tiles = (G + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
+    HIPCHK(ar.alloc((size_t)G * 4, (void**)&rec.d_fsm_cnt));
+    HIPCHK(ar.alloc((size_t)G * JGN_FSM_ROWS * sizeof(jg_fsm_row), (void**)&rec.d_fsm));
+    HIPCHK(ar.alloc((size_t)n_tiles * 8, (void**)&rec.d_bsum_f));
+    hipLaunchKernelGGL(k_node_fsm_build, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rec.d_fsm, rec.d_fsm_cnt,
+                       rec.d_bsum_f);
+    HIPCHK(hipGetLastError());
+    e->n_launch++;
+    e->recs.push_back(rec);
+    pend.fsm_rec_seq = rec.seq;
+  }
+  pend.seq_general = seq0 + 1, pend.seq_end = e->seq;
+  HIPCHK(hipEventRecord(nd.ev_out, e->stream));
+  if (trace)
+    std::fprintf(stderr, "[jg node] %zu rows: uploads + classify + route issued in %.0f us, waited %.0f us (H2D %.1f MB), halves + fsm build + outbox copies issued in %.0f us\n",
+                 n, T1 - T0, T2 - T1, bytes_up / 1e6, clk() - T2);
+  nd.last = jg_node_outbox{};
+  nd.last.rows = n, nd.last.rows_general = n_sparse, nd.last.bytes_h2d = bytes_up, nd.last.bytes_d2h = bytes_down;
+  nd.last_flags = flags;
+  pend.on = async && n != 0;  // (nothing is pending when there were no rows: no general path to come back for)
+  return JG_OK;
+}
+
+// The dense halves of a node step + the downloads of their outbox columns.  sparse_mode: 0 every partition; 1 all but
+// the partitions whose rows take the general path (an asynchronous step, first pass); 2 only those (its catch-up pass).
+int node_dense_halves(jg_engine* e, uint64_t now_ms, uint32_t flags, uint32_t col_mask, uint32_t sparse_mode, uint64_t* bytes_down) {
+  jg_engine::NodeStep& nd = e->node;
+  const uint32_t halves = flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF);
+  const bool tick = (flags & JG_NODE_TICK) != 0;
+  const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  int rc = JG_OK;
+  if (halves & JG_NODE_LEADER_HALF) {
+    JgLeaderNode ln{};
+    ln.hbr_commit = nd.cols.hbr_commit;
+    ln.packed = 1;
+    ln.ack_stride = 1;
+    if (tick) ln.o_beat = nd.o_beat, ln.o_ae = nd.o_ae;
+    ln.now = now_ms;
+    ln.fsm_delta = nd.cols.fsm_delta, ln.fsm_prev = nd.cols.fsm_prev, ln.fsm_mid = nd.cols.fsm_mid;
+    ln.arr = nd.cols.arr, ln.col_mask = col_mask;  // (the slow kernel replays its groups in arrival order)
+    if (sparse_mode) ln.sparse_bits = nd.cols.sparse_bits, ln.sparse_mode = sparse_mode;
+    if ((rc = dense_step(e, nd.cols.answers, 1, &ln))) return rc;
+    if (tick) {
+      HIPCHK(hipMemcpyAsync(nd.h_beat, nd.o_beat, (size_t)G * sizeof(jg_leader_beat), hipMemcpyDeviceToHost, e->stream));
+      // (the own slot's row is JG_NO_ACK on both sides and stays there: not written, not downloaded)
+      const uint32_t own = e->uniform_self >= 0 ? (uint32_t)e->uniform_self : R;
+      if (own > 0) HIPCHK(hipMemcpyAsync(nd.h_ae, nd.o_ae, (size_t)std::min(own, R) * G * 8, hipMemcpyDeviceToHost, e->stream));
+      if (own + 1 < R)
+        HIPCHK(hipMemcpyAsync(nd.h_ae + (size_t)(own + 1) * G, nd.o_ae + (size_t)(own + 1) * G, (size_t)(R - own - 1) * G * 8, hipMemcpyDeviceToHost,
+                              e->stream));
+      *bytes_down += (size_t)G * (sizeof(jg_leader_beat) + (size_t)(own < R ? R - 1 : R) * 8);
+    }
+  }
+  if (halves & JG_NODE_FOLLOWER_HALF) {
+    jg_follower_inbox fi{};
+    fi.leader = nd.cols.f_leader, fi.beat = nd.cols.f_beat, fi.ae = nd.cols.f_ae;
+    const jg_follower_outbox fo{nd.o_answer, nd.o_hbc};
+    if ((rc = follower_half(e, now_ms, &fi, &fo, tick ? 1 : 0, nd.cols.fsm_delta, nd.cols.fsm_prev,
+                            sparse_mode ? nd.cols.sparse_bits : nullptr, sparse_mode)))
+      return rc;
+    HIPCHK(hipMemcpyAsync(nd.h_answer, nd.o_answer, (size_t)G * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(nd.h_hbc, nd.o_hbc, (size_t)G * 8, hipMemcpyDeviceToHost, e->stream));
+    *bytes_down += (size_t)G * 16;
+  }
+  return JG_OK;
+}
+
+// The general path of a node step: the rows k_node_route listed (in no particular order) are put into group-major
+// order, a group's rows in the order they arrived, by the bucket pass of jg_route.h - key = group << 32 | arrival index,
+// a bucket = 256 groups, one workgroup ranks a bucket - and become the batch k_apply_rows takes: exactly jg_submit +
+// jg_step for those partitions, in stream order.  (Round 3: rocprim::select + radix_sort_pairs.)
+int node_general(jg_engine* e, const JgNodeRows& rows, size_t n, size_t nb, uint32_t n_sparse, uint64_t now_ms) {
+  jg_engine::NodeStep& nd = e->node;
+  Arena& ar = e->arenas[e->cur_arena];
+  int rc = JG_OK;
+  (void)n;
+  uint64_t* key_alt = nullptr;
+  uint32_t *idx_alt = nullptr, *order = nullptr;
+  HIPCHK(ar.alloc((size_t)n_sparse * 8, (void**)&key_alt));
+  HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&idx_alt));
+  HIPCHK(ar.alloc((size_t)n_sparse * 4, (void**)&order));
+  JgRouteBuckets bk{};
+  bk.n_buckets = nd.bk_buckets, bk.shift = 32 + nd.bk_tile_bits;
+  const uint32_t bk_tiles = (bk.n_buckets + JG_ROUTE_SCAN_TILE - 1) / JG_ROUTE_SCAN_TILE;
+  bk.hist = nd.bk_mem, bk.cur = bk.hist + (size_t)bk_tiles * JG_ROUTE_SCAN_TILE, bk.tile = bk.cur + bk.n_buckets;
+  hipStream_t st = e->stream;
+  hipLaunchKernelGGL(k_route_clear, dim3(64), dim3(JG_BLOCK), 0, st, bk.hist, bk_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets, bk.tile, bk_tiles + 1);
+  const uint32_t grid = std::min<uint32_t>((n_sparse + JG_BLOCK - 1) / JG_BLOCK, 4096);
+  hipLaunchKernelGGL(k_route_hist, dim3(grid, 1), dim3(JG_BLOCK), 0, st, (const uint32_t*)nd.d_nsparse, (uint32_t)nd.sp_cap, (const uint64_t*)nd.sp_key, bk);
+  hipLaunchKernelGGL(k_route_scan, dim3(bk_tiles), dim3(JG_BLOCK), 0, st, bk);
+  hipLaunchKernelGGL(k_route_scan_tiles, dim3(1), dim3(JG_BLOCK), 0, st, bk);
+  hipLaunchKernelGGL(k_route_scatter, dim3(grid, 1), dim3(JG_BLOCK), 0, st, (const uint32_t*)nd.d_nsparse, (uint32_t)nd.sp_cap, (const uint64_t*)nd.sp_key,
+                     (const uint32_t*)nd.sp_idx, bk, key_alt, idx_alt);
+  hipLaunchKernelGGL(k_bucket_order, dim3(bk.n_buckets), dim3(JG_BLOCK), 0, st, bk, (const uint64_t*)key_alt, (const uint32_t*)idx_alt, order);
+  const uint32_t sgrid = (n_sparse + JG_BLOCK - 1) / JG_BLOCK;
+  JgNodeSorted so{};
+  char* M = nullptr;
+  const size_t ns = n_sparse;
+  HIPCHK(ar.alloc(ns * 34 + 64, (void**)&M));  // 3 x 8 + 2 x 4 + 2 x 1 bytes per row, widest columns first
+  so.term = (uint64_t*)M, M += ns * 8;
+  so.id = (uint64_t*)M, M += ns * 8;
+  so.aux = (uint64_t*)M, M += ns * 8;
+  so.group = (uint32_t*)M, M += ns * 4;
+  so.from = (uint32_t*)M, M += ns * 4;
+  so.kind = (uint8_t*)M, M += ns;
+  so.flag = (uint8_t*)M;
+  hipLaunchKernelGGL(k_node_gather_rows, dim3(sgrid), dim3(JG_BLOCK), 0, st, n_sparse, (const uint32_t*)order, rows, so);
+  HIPCHK(hipGetLastError());
+  e->n_launch += 7;
+  if ((rc = launch_rows(e, n_sparse, so.group, so.kind, so.from, so.term, so.id, so.aux, so.flag,
+                        nb ? rows.blk_id : (const uint64_t*)e->d_ones, nb ? rows.blk_next : (const uint64_t*)e->d_ones, nb, now_ms)))
+    return rc;
+  return JG_OK;
+}
+
+// An asynchronous node step is settled the first time anything looks at the engine again: the general-path row count
+// has landed by then; if it is not zero, those rows are applied now (their sequence number was reserved) and the dense
+// halves come back for exactly the partitions they left alone - same results, same record order, one pass later.
+int node_settle(jg_engine* e) {
+  jg_engine::NodeStep& nd = e->node;
+  jg_engine::NodeStep::Pending& pd = nd.pending;
+  if (!pd.on) return JG_OK;
+  pd.on = false;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const uint32_t n_sparse = nd.h_nsparse[0];
+  nd.last.rows_general = n_sparse;
+  if (!n_sparse) return JG_OK;
+  int rc = JG_OK;
+  const uint32_t seq_end = e->seq;
+  e->seq = pd.seq_general;
+  const size_t recs_before = e->recs.size();
+  if ((rc = node_general(e, pd.rows, pd.n, pd.nb, n_sparse, pd.now_ms))) return rc;
+  // the general path's record belongs BEFORE the dense halves' fsm record (steps in order)
+  if (e->recs.size() == recs_before + 1) {
+    size_t at = recs_before;
+    while (at > 0 && e->recs[at - 1].seq > pd.seq_general) at--;
+    std::rotate(e->recs.begin() + at, e->recs.begin() + recs_before, e->recs.end());
+  }
+  uint64_t bytes_down = 0;
+  e->seq = pd.seq_general;  // (the halves number themselves from here exactly as in the first pass)
+  if ((rc = node_dense_halves(e, pd.now_ms, pd.flags, pd.col_mask, 2u, &bytes_down))) return rc;
+  for (StepRec& rec : e->recs)
+    if (rec.seq == pd.fsm_rec_seq && rec.fsm_per_row == JGN_FSM_ROWS && rec.msg_per_row == 0) {
+      const uint32_t n_tiles = (e->cfg.n_groups + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
+      hipLaunchKernelGGL(k_node_fsm_build, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rec.d_fsm, rec.d_fsm_cnt, rec.d_bsum_f);
+      e->n_launch++;
+    }
+  HIPCHK(hipGetLastError());
+  e->seq = seq_end;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return JG_OK;
+}
+}  // namespace
+
+int jg_step_node(jg_engine* e, uint64_t now_ms, uint32_t flags) {
+  if (!e) return fail(JG_EINVAL, "null argument");
+  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~15u))
+    return fail(JG_EINVAL, "jg_step_node: flags = JG_NODE_LEADER_HALF and / or JG_NODE_FOLLOWER_HALF [| JG_NODE_TICK] [| JG_NODE_ASYNC]");
+  if (e->router) return router_step_node(e, now_ms, flags);
+  if (e->inflight.phase) return fail(JG_EINVAL, "a drain is in transfer: jg_drain_wait first");
+  return node_step(e, now_ms, flags);
+}
+
+int jg_node_inbox_columns(jg_engine* e, uint32_t slot, uint64_t** answer, uint64_t** hb_commit) {
+  if (!e || !answer) return fail(JG_EINVAL, "null argument");
+  if (e->router) return fail(JG_EINVAL, "jg_node_inbox_columns: the columns are per shard: call this on a shard handle (jg_get_shard)");
+  if (slot >= e->cfg.n_replicas) return fail(JG_EINVAL, "slot out of range");
+  if (e->uniform_self >= 0 && (uint32_t)e->uniform_self == slot)
+    return fail(JG_EINVAL, "jg_node_inbox_columns: the own slot's word carries the append count");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = node_ensure(e);
+  if (rc) return rc;
+  jg_engine::NodeStep& nd = e->node;
+  const size_t G = e->cfg.n_groups;
+  if (nd.cols_in_flight) {  // the previous step's uploads out of these buffers (a step without rows never synchronises)
+    HIPCHK(hipEventSynchronize(nd.ev_cols));
+    nd.cols_in_flight = false;
+  }
+  *answer = nd.h_in_answers + (size_t)slot * G;
+  nd.col_mask |= 1u << slot;
+  if (hb_commit) {
+    *hb_commit = nd.h_in_hbc + (size_t)slot * G;
+    nd.col_hbc_mask |= 1u << slot;
+  } else {
+    nd.col_hbc_mask &= ~(1u << slot);
+  }
+  return JG_OK;
+}
+
+int jg_node_outbox_view(jg_engine* e, jg_node_outbox* out) {
+  if (!e || !out) return fail(JG_EINVAL, "null argument");
+  if (e->router) return router_node_outbox(e, out);
+  jg_engine::NodeStep& nd = e->node;
+  if (!nd.ready || !nd.last_flags) return fail(JG_EINVAL, "no jg_step_node yet");
+  int rc = sync_and_check(e);  // (the columns have landed; device-side error flags surface here)
+  if (rc) return rc;
+  *out = nd.last;
+  if ((nd.last_flags & JG_NODE_LEADER_HALF) && (nd.last_flags & JG_NODE_TICK)) out->beat = nd.h_beat, out->ae = nd.h_ae;
+  if (nd.last_flags & JG_NODE_FOLLOWER_HALF) out->answer = nd.h_answer, out->hb_commit = nd.h_hbc;
+  return JG_OK;
+}

@@ -902,11 +902,16 @@ __global__ __launch_bounds__(JG_BLOCK) void k_leader_node_tick_any(const JgLeade
   jg_wave_count(j.h.blk_decisions, dec);
 }
 
-// owner[g] = the lowest slot whose node leads group g (healthy leaders only), JG_OWNER_NONE: nobody - four groups per lane
+// owner[g] = the lowest slot whose node leads group g (healthy leaders only), JG_OWNER_NONE: nobody - four groups per lane.
+// Where a group passes from one owner STRAIGHT to another (two terms' leaders in one round, the newer one in the lower
+// slot), the old owner's row of the answers still holds what it said when it last FOLLOWED - it never writes its own
+// row while it owns the group - and the new owner's leader half of this very round would read that as a fresh
+// AppendResponse / HeartbeatResponse: the claim withdraws it (JG_NO_ACK: nothing from that slot).
 struct JgClaimArgs {
   const uint32_t* flags[JG_MAX_REPLICAS];
   uint32_t R, G;
   uint8_t* owner;
+  uint64_t* answers;  // [R][G] the cluster's inbox
 };
 __global__ __launch_bounds__(JG_BLOCK) void k_cluster_claim(JgClaimArgs a) {
   const uint32_t n4 = (a.G + 3u) / 4u;
@@ -925,7 +930,13 @@ __global__ __launch_bounds__(JG_BLOCK) void k_cluster_claim(JgClaimArgs a) {
       for (uint32_t k = 0; k < 4; k++)
         for (uint32_t r = a.R; q * 4u + k < a.G && r-- > 0;) o[k] = (a.flags[r][q * 4u + k] & M) == JG_ROLE_LEADER ? r : o[k];
     }
-    ((uint32_t*)a.owner)[q] = o[0] | o[1] << 8 | o[2] << 16 | o[3] << 24;  // (the column is allocated in whole words)
+    const uint32_t now = o[0] | o[1] << 8 | o[2] << 16 | o[3] << 24, was = ((const uint32_t*)a.owner)[q];  // (the column is allocated in whole words)
+    if (now == was) continue;
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t p = (was >> (8 * k)) & 0xffu;
+      if (p != JG_OWNER_NONE && p != o[k] && o[k] != JG_OWNER_NONE && q * 4u + k < a.G) a.answers[(size_t)p * a.G + q * 4u + k] = JG_NO_ACK;
+    }
+    ((uint32_t*)a.owner)[q] = now;
   }
 }
 

@@ -75,7 +75,7 @@ __device__ __forceinline__ uint64_t jg_route_key(const JgRouteTable& t, uint32_t
 // (neighbouring workgroups run on different XCDs, so a cursor is mostly one XCD's).  The staged entries need no
 // particular place: the ordering keys are unique and the bucket pass reads every segment.  A position at or beyond
 // the end of the segment is not written: the host sees the cursor above seg_cap, grows the staging and repeats the
-// pass (segmenting turned out not to be what bounded the pass - JG_ROUTE_ONE_CURSOR=1 measures the same - and stays
+// pass (segmenting turned out not to be what bounded the pass - one cursor measured the same - and stays
 // as the cheaper bound on that queue).
 #define JG_ROUTE_SEGS 8u
 struct JgRouteSpot {
@@ -239,12 +239,6 @@ __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_
   }
   if (staged) jg_stage_flush(st, t, sp.base, sp.tot);
   jg_route_tally(t, pd_lo, pd_hi, kept, JG_ROUTE_KEPT, f, kd_lo, kd_hi);
-}
-__global__ __launch_bounds__(JG_BLOCK) void k_route_rec(JgRouteTable t, uint32_t n, uint32_t per_row, uint32_t step,
-                                                        const uint32_t* __restrict__ msg_cnt,
-                                                        const jg_msg_row* __restrict__ msg,
-                                                        const uint32_t* __restrict__ fsm_cnt) {
-  jg_route_rec_body(t, n, per_row, step, msg_cnt, msg, fsm_cnt);
 }
 // every (sender, step) of a round in ONE launch: blockIdx.y = job (7-8 launches of ~20 us before)
 struct JgRouteRecJob {
@@ -421,19 +415,6 @@ struct JgRouteCols {
   uint32_t *group, *from;
   uint64_t *term, *id, *aux;
 };
-__global__ __launch_bounds__(JG_BLOCK) void k_route_build(uint32_t n, const uint32_t* __restrict__ order,
-                                                          const jg_msg_row* __restrict__ rows, JgRouteCols c) {
-  const uint32_t p = blockIdx.x * JG_BLOCK + threadIdx.x;
-  if (p >= n) return;
-  const jg_msg_row r = rows[order[p]];
-  c.kind[p] = r.kind;
-  c.flag[p] = r.flag;
-  c.group[p] = r.group;
-  c.from[p] = r.from;
-  c.term[p] = r.term;
-  c.id[p] = r.id;
-  c.aux[p] = r.aux;
-}
 
 // ---- ordering the staged rows without a library sort ------------------------------------------------
 // The addressees apply their batch per group, so the staging has to come out ordered by (destination,

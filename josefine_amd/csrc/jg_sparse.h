@@ -169,12 +169,6 @@ __global__ __launch_bounds__(JG_BLOCK) JG_GSM_OCC void k_apply_rows_multi(const 
   const JgApplyJob& j = jobs[blockIdx.y];  // (through the reference: 64 us per launch; a by-value copy of the job went to scratch: 198 us)
   jg_apply_rows_body(j.d, j.a);
 }
-// ... and for jobs whose batches hold an election's traffic only (the census comes with the rows: the cluster
-// transport tallies the kinds it delivers): no chain code, half the registers
-__global__ __launch_bounds__(JG_BLOCK) void k_apply_votes_multi(const JgApplyJob* __restrict__ jobs) {
-  const JgApplyJob& j = jobs[blockIdx.y];
-  jg_apply_rows_body<JG_KINDS_ELECTION>(j.d, j.a);
-}
 
 // ---- a RUN per lane -----------------------------------------------------------------------------------
 // The batches a cluster's transport delivers are runs of 4 to 16 rows per group (a voter's four copies of a

@@ -69,6 +69,8 @@ __device__ __forceinline__ void jg_votes_census_row(const JgVoteMail& m, uint32_
   if (jg_vote_row_is_request_copy(r, sender_id, k)) {
     const size_t i = jg_vote_at(m, src, g);
     const uint32_t old = atomicAdd(&m.q_ctl[i], 1u | ((step & 7u) << 8 | k) << 8);
+    if ((old & 0xffu) >= 0x80u)  // (no campaign has that many copies, and the 8-bit count must not come round to R - 1 again: rows for everybody)
+      for (uint32_t b = dests; b; b &= b - 1) atomicOr((unsigned long long*)&m.rowmail[(size_t)(__ffs(b) - 1) * m.words + (g >> 6)], (unsigned long long)bit);
     if ((old & 0xffu) == 0) {  // (every copy says the same; a second campaign's would not - and is not a word: the count)
       m.q_term[i] = r.term, m.q_head[i] = r.id;
       for (uint32_t b = dests; b; b &= b - 1) atomicOr((unsigned long long*)&m.wordmail[(size_t)(__ffs(b) - 1) * m.words + (g >> 6)], (unsigned long long)bit);

@@ -224,6 +224,11 @@ class AnyLeaderCluster(RoutedCluster):
         owner = np.full(G, OWNER_NONE, np.uint8)
         for r in reversed(range(R)):
             owner[leads[r]] = r
+        # a group that passes from one owner straight to another: the old owner's row of the answers still holds what it said
+        # when it last followed (it never writes its own row while it owns the group) - withdrawn, not replayed to the new owner
+        handed = np.nonzero((owner != self.owner) & (owner != OWNER_NONE) & (self.owner != OWNER_NONE))[0]
+        self.acks[self.owner[handed], handed] = NO
+        self.hbr_has[self.owner[handed], handed] = capi.HB_NONE
         self.owner = owner
         drained = [None] * R
         outs = {}

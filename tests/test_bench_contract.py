@@ -63,9 +63,9 @@ def test_two_ranks_aggregate():
     assert sorted(tr["ms_per_step_each"])[4] == pytest.approx(d["ms_per_step"])
 
 
-def launch_two(args, timeout=900):
+def launch_two(args, timeout=900, n=2):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -85,6 +85,29 @@ def test_scaling_presets_two_ranks():
     assert "configs[4]" in d["config"]["workload"] and len(d["per_rank"]["decisions_per_s"]) == 2
     d = launch_two(["--config", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-secondary"])
     assert d["config"]["partitions_per_gpu"] == 1_000_000 and d["config"]["replicas"] == 5
+
+
+def test_scale_run_rehearsal_eight_ranks():
+    """The driver's scaling command at N = 8 - `python bench.py --gpus 8 --config {2, 3, 4}` - on whatever box this is (eight
+    ranks ALIASED onto its devices, barrier and reductions over gloo): the plumbing of the first real 8-GPU lease. Eight
+    per-rank entries, the aggregate is their sum over the slowest rank's clock, rank 0 brings the CPU baseline, the line says
+    which devices the ranks bound and that they were shared."""
+    import torch
+    aliased = torch.cuda.device_count() < 8
+    for cfg, groups, R, extra in ((2, 1_000_000, 5, ["--cpu-budget", "1"]), (3, 1_250_000, 3, ["--no-cpu-baseline"]), (4, 125_000, 5, ["--no-cpu-baseline"])):
+        d = launch_two(["--config", str(cfg), "--steps", "12", "--warmup", "4", "--no-secondary"] + extra, n=8, timeout=1200)
+        assert KEYS <= set(d) and d["n_gpus"] == 8 and d["steps"] == 12 and d["scaling"] == "weak", cfg
+        c = d["config"]
+        assert c["partitions_per_gpu"] == groups and c["replicas"] == R and c["partitions_total"] == 8 * groups, cfg
+        assert len(c["devices"]) == 8 and c["devices_aliased"] == aliased, c
+        pr = d["per_rank"]
+        assert len(pr["decisions_per_s"]) == 8 and len(pr["avg_launch_us"]) == 8 and min(pr["decisions_per_s"]) > 0, cfg
+        # the aggregate: all ranks' decisions over the slowest rank's time - between 8 x the slowest and the sum of the per-rank rates
+        assert 8 * min(pr["decisions_per_s"]) * 0.98 <= d["value"] <= sum(pr["decisions_per_s"]) * 1.02, (cfg, d["value"], pr)
+        if cfg == 2:
+            assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and "roofline" in d
+        if cfg == 4:
+            assert "configs[4]" in c["workload"] and c["stationary"].startswith("yes")
 
 
 def test_default_line_carries_the_secondaries():

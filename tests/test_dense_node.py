@@ -599,27 +599,6 @@ def test_routed_transport_repeats_with_wide_keys():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [
-    {"JG_ROUTE_ROW_PER_LANE": "1"},                                      # the row-per-lane state machine kernels for the delivered rows
-    {"JG_ROUTE_NO_VOTES_KERNEL": "1"},                                   # the general instance for every batch (no census-picked kernel)
-    {"JG_ROUTE_ONE_CURSOR": "1"},                                        # one staging segment, one cursor
-    {"JG_ROUTE_LIBRARY_SORT": "1", "JG_ROUTE_SEPARATE_LAUNCHES": "1",    # round 2's configuration: rocPRIM sort, a launch per
-     "JG_CLUSTER_SEPARATE_HALVES": "1", "JG_ROUTE_NO_VOTES_KERNEL": "1", "JG_ROUTE_ROW_PER_LANE": "1"},  # node / sender / step
-], ids=["row_per_lane", "no_votes_kernel", "one_cursor", "round2_config"])
-def test_routed_transport_ab_switches_keep_parity(env):
-    """The code paths the A/B figures of profiles/README.md are measured against (env switches, read once per
-    process: hence the subprocess) are held to the same oracle as the default path."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_dense_node.py"), "-q", "-m", "gpu", "-k",
-                        "test_routed_cluster_device_transport_parity"], capture_output=True, text=True, timeout=600,
-                       cwd=root, env={**os.environ, **env})
-    assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-@pytest.mark.gpu
 def test_routed_round_argument_checks():
     """Misuse is refused with JG_EINVAL, not executed: injected rows that carry blocks, a node with a
     drain in transfer."""

@@ -23,6 +23,9 @@ BUDGET = {
     "void k_leader_node_tick_any<3>": (64, 8),
     "void k_leader_node_tick_any<5>": (80, 6),
     "k_cluster_claim": (32, 8),
+    "k_vote_half_multi": (128, 4),                   # the vote mail's receiving half: no scratch (its jobs are kernel arguments)
+    "k_votes_census_rec_multi": (32, 8),
+    "k_votes_expand_multi": (64, 7),
     "k_node_classify": (40, 7),                      # jg_step_node's row passes
     "k_node_route": (40, 7),
 }
@@ -39,7 +42,7 @@ def report():
         f = [x.strip() for x in ln.rsplit(",", 6)]
         if len(f) == 7 and f[1].isdigit():
             rows[f[0]] = dict(vgprs=int(f[1]), scratch=int(f[4]), waves=int(f[6]))
-    assert len(rows) > 60, r.stdout[:2000]
+    assert len(rows) > 60 and not any("rocprim" in k for k in rows), r.stdout[:2000]
     return rows
 
 
@@ -52,8 +55,8 @@ def test_dense_kernels_keep_their_register_budget(report):
 
 
 def test_the_committed_report_is_the_code_objects(report):
-    """profiles/r04/kernel_resources.txt is what DESIGN.md quotes: it must be this source's"""
-    path = os.path.join(ROOT, "profiles", "r04", "kernel_resources.txt")
+    """profiles/r05/kernel_resources.txt is what DESIGN.md quotes: it must be this source's"""
+    path = os.path.join(ROOT, "profiles", "r05", "kernel_resources.txt")
     want = {}
     for ln in open(path):
         f = [x.strip() for x in ln.rsplit(",", 6)]
@@ -61,4 +64,4 @@ def test_the_committed_report_is_the_code_objects(report):
             want[f[0]] = (int(f[1]), int(f[4]), int(f[6]))
     got = {k: (v["vgprs"], v["scratch"], v["waves"]) for k, v in report.items()}
     diff = {k: (want.get(k), got.get(k)) for k in set(want) | set(got) if want.get(k) != got.get(k)}
-    assert not diff, f"re-run `bash profiles/kernel_resources.sh > profiles/r04/kernel_resources.txt`: {dict(list(diff.items())[:6])}"
+    assert not diff, f"re-run `bash profiles/kernel_resources.sh > profiles/r05/kernel_resources.txt`: {dict(list(diff.items())[:6])}"
