@@ -754,10 +754,12 @@ def event_loop_main(args):
         queues unless told otherwise (GPU_MAX_HW_QUEUES), and streams that share one run one behind the other."""
         return os.environ.get("GPU_MAX_HW_QUEUES") or (str(2 * loops) if loops > 2 else None)
 
-    def run(mode, k, w, loops=1):
+    def run(mode, k, w, loops=1, polled=False):
         env = dict(os.environ)
         if env.get("JG_BENCH_POLLING_DEFAULTED"):  # (several loop threads waiting side by side: the runtime's default, interrupts)
             env.pop("HSA_ENABLE_INTERRUPT", None)
+        if polled:  # (the A/B: the loop's thread spins on the completion signal instead of sleeping on an interrupt)
+            env["HSA_ENABLE_INTERRUPT"] = "0"
         if hw_queues(loops):
             env["GPU_MAX_HW_QUEUES"] = hw_queues(loops)
         r = subprocess.run([exe, str(G), str(R), str(k), str(w), mode, "0", str(loops)], capture_output=True, text=True, timeout=1200, env=env)
@@ -773,6 +775,10 @@ def event_loop_main(args):
     pc1 = run("pipecolumns", K, W)
     pt1 = run("pipetasks", K, W)   # ... with the reference's other tasks (connection readers, channel consumers) on threads of their own
     ptc1 = run("pipetaskscolumns", K, W)
+    pt1_polled = run("pipetasks", K, W, polled=True)
+    # ... and with the peers' traffic as the reference's BYTES (length-delimited serde_json frames, tcp.rs:139-170) through
+    # host/formats.hpp's decoder in the connection tasks: a few ticks (the senders' encoding of every tick comes first)
+    ptw = run("pipetaskswire", max(2, min(K, 4)), 2)
     d1 = run("inplace", K, W)   # ONE loop owns every partition
     d, d_by_loops = best("inplace", d1)
     colm1 = run("columns", K, W)  # the followers' answers as columns (batched peers), only the client requests as rows
@@ -831,7 +837,21 @@ def event_loop_main(args):
                 "column_inbound_decisions_per_s": ptc1["decisions_per_s"], "column_inbound_ms_per_tick": ptc1["ms_per_tick"],
                 "column_inbound_ms_per_tick_parts": {"transport_decode_into_pinned_columns": ptc1["ms_fill"], "submit_commit": ptc1["ms_submit"],
                                                      "step_begin_and_previous_outputs": ptc1["ms_step_and_drain"]},
-                "rows_on_the_general_path": pt1["rows_general"] + ptc1["rows_general"]},
+                "rows_on_the_general_path": pt1["rows_general"] + ptc1["rows_general"],
+                "host_wait": {"what": "these figures wait for completion signals by interrupt (the runtime's default: the loop's thread sleeps while the "
+                                      "device works, as a host that also runs the broker needs it); polled (HSA_ENABLE_INTERRUPT=0) a core spins per waiting thread",
+                              "interrupt_decisions_per_s": pt1["decisions_per_s"], "polled_decisions_per_s": pt1_polled["decisions_per_s"]},
+                "wire_decode": {
+                    "what": "the same loop and tasks, but the peers' AppendResponses / HeartbeatResponses arrive as what a stock josefine peer sends - "
+                            "LengthDelimitedCodec frames around serde_json(Message), one byte stream per connection (src/raft/tcp.rs:40-51,139-170) - "
+                            "and the connection tasks run host/formats.hpp's decode_message on every frame before they write the row (the other "
+                            "figures' decoder writes rows it computes: what a columnar transport would hand over)",
+                    "decisions_per_s": ptw["decisions_per_s"], "ms_per_tick": ptw["ms_per_tick"], "ticks": ptw["ticks"],
+                    "ms_per_tick_parts": {"transport_decode_into_pinned_columns": ptw["ms_fill"], "submit_commit": ptw["ms_submit"],
+                                          "step_begin_and_previous_outputs": ptw["ms_step_and_drain"]},
+                    "wire_bytes_decoded_per_tick": ptw["wire_bytes_decoded_per_tick"], "frames_per_tick": ptw["rows_in_per_tick"] - G,
+                    "decode_ns_per_frame_per_thread": ptw["ms_fill"] * 1e6 * (ptw["task_threads_beside_each_loop"] + 1) / max(ptw["rows_in_per_tick"] - G, 1),
+                    "rows_on_the_general_path": ptw["rows_general"]}},
             "one_loop": {"what": "ONE loop (one host thread, one engine) owns every partition: nothing overlaps",
                          "decisions_per_s": d1["decisions_per_s"],
                          "ms_per_tick": {"transport_decode_into_pinned_columns": d1["ms_fill"], "submit_commit_validation": d1["ms_submit"],

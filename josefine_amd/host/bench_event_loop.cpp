@@ -27,6 +27,12 @@
 //             beside the loop's own, fork-join - the per-connection decoders fill their slices of the pinned columns,
 //             the consumers read their slices of the output batches; the loop thread works along and goes on when all
 //             are done.  Everything that touches the engine stays on the loop thread.
+//   pipetaskswire  pipetasks with the peers' traffic as what a stock josefine peer puts on the wire: every AppendResponse /
+//             HeartbeatResponse is a LengthDelimitedCodec frame around serde_json(Message) (src/raft/tcp.rs:40-51,139-170;
+//             host/formats.hpp), one byte stream per connection - encoded before the timed region (the SENDERS' work) - and the
+//             connection tasks run formats::decode_message on every frame before they write the row: what the transport's
+//             decoder costs when it decodes the reference's bytes (the other modes' "decoder" writes rows it computes).  The
+//             ClientRequests stay rows: they reach the loop through client_rx, an in-process channel (server.rs:156-160).
 //
 // loops (argument 7, default 1): the process hosts the G partitions on that many event loops, one thread and
 // one engine (its own HIP stream) each, G / loops partitions per loop - the reference runs one event_loop task
@@ -47,7 +53,7 @@
 #include <string>
 #include <thread>
 
-#include "raft_handle.hpp"
+#include "formats.hpp"  // (includes raft_handle.hpp)
 
 using namespace josefine;
 using Clock = std::chrono::steady_clock;
@@ -159,7 +165,7 @@ struct Rendezvous {
 struct LoopResult {
   bool ok = false;
   std::string error;
-  uint64_t decisions = 0, rows_in = 0, general = 0, fsm_rows = 0, msg_rows = 0, up_bytes = 0, down_bytes = 0, sink = 0;
+  uint64_t decisions = 0, rows_in = 0, general = 0, fsm_rows = 0, msg_rows = 0, up_bytes = 0, down_bytes = 0, sink = 0, wire_bytes = 0;
   double wall_ms = 0, t_fill = 0, t_submit = 0, t_step = 0;
   float k_us = 0;
   uint32_t k_n = 0;
@@ -172,7 +178,8 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
   const bool pipe = mode_arg.rfind("pipe", 0) == 0;
   const bool with_tasks = mode_arg.rfind("pipetasks", 0) == 0;
   const bool cols_in = mode_arg.size() >= 7 && mode_arg.compare(mode_arg.size() - 7, 7, "columns") == 0;
-  const std::string mode = !pipe ? mode_arg : (cols_in ? "columns" : "inplace");
+  const bool wire = mode_arg.size() >= 4 && mode_arg.compare(mode_arg.size() - 4, 4, "wire") == 0;
+  const std::string mode = !pipe ? mode_arg : (cols_in ? "columns" : "inplace");  // ("pipetaskswire": inplace rows, decoded from frames)
   // (with the tasks: ... and the committed batch leaves for the device at once, JG_COL_UPLOAD_NOW, while the previous step's
   // outputs travel the other way: 8.0 -> 11.1 x 10^8 decisions/s with row inbound.  A loop that decodes and consumes on its
   // own thread is bound by that thread, and the copy engine reading the host's memory beside it costs it 10-20 %: it
@@ -252,8 +259,60 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
         kind[i] = JG_CMD_APPEND_RESPONSE, group[i] = g, from[i] = ids[s], id[i] = t, flag[i] = 1, i++;
       }
     };
+    // wire: connection s's byte stream of tick t - the frames of its rows in fill_part's order - and where job j's part begins
+    std::vector<std::vector<formats::Bytes>> wire_buf;
+    std::vector<std::vector<std::vector<size_t>>> wire_cut;
+    uint64_t wire_bytes = 0;
+    if (wire) {
+      wire_buf.assign(W + T, std::vector<formats::Bytes>(R));
+      wire_cut.assign(W + T, std::vector<std::vector<size_t>>(R, std::vector<size_t>(SPLIT + 1, 0)));
+      tasks.run((W + T) * (R - 1), [&](uint32_t job) {  // (the senders' work: outside the timed region)
+        const uint32_t t = job / (R - 1), sc = 1 + job % (R - 1);
+        const bool hb = t & 1;
+        formats::Bytes& b = wire_buf[t][sc];
+        Message m;
+        m.from = Address{JG_TO_PEER, ids[sc]}, m.to = Address{JG_TO_PEER, ids[0]};
+        for (uint32_t j = 0; j < SPLIT; j++) {
+          wire_cut[t][sc][j] = b.size();
+          const uint32_t k0 = (uint32_t)((uint64_t)G * j / SPLIT), k1 = (uint32_t)((uint64_t)G * (j + 1) / SPLIT);
+          for (uint32_t k = k0; k < k1; k++) {
+            if (hb) m.command = Command::HeartbeatResponse(t ? t - 1 : 0, true), b += formats::frame(formats::encode_message(m));
+            m.command = Command::AppendResponse(ids[sc], 0, t, true), b += formats::frame(formats::encode_message(m));
+          }
+        }
+        wire_cut[t][sc][SPLIT] = b.size();
+      });
+    }
+    // ... and its connection task: every frame through the reference's codec, the row written from what it says (the
+    // connection says which partition: a stock josefine process hosts one, its peers' connections are that partition's)
+    auto decode_part = [&](uint32_t t, uint32_t sc, uint32_t j, uint8_t* kind, uint32_t* group, uint32_t* from, uint64_t* id, uint8_t* flag) {
+      const bool hb = t & 1;
+      const uint32_t k0 = (uint32_t)((uint64_t)G * j / SPLIT);
+      const size_t per = hb ? 2 : 1;
+      size_t i = (size_t)G + (size_t)(sc - 1) * G * per + (size_t)k0 * per;
+      uint32_t at = (uint32_t)((k0 + 7919ull * sc) % G), seen = 0;
+      const formats::Bytes& b = wire_buf[t][sc];
+      std::string payload;
+      for (size_t p = wire_cut[t][sc][j], end = wire_cut[t][sc][j + 1]; p < end;) {
+        uint32_t n = 0;
+        for (int q = 0; q < 4; q++) n = (n << 8) | (uint8_t)b[p + q];
+        payload.assign(b, p + 4, n);
+        p += 4 + (size_t)n;
+        const Message m = formats::decode_message(payload);
+        const Command& c = m.command;
+        kind[i] = c.kind, group[i] = perm[at], id[i] = c.id, flag[i] = c.flag ? 1 : 0;
+        from[i] = c.kind == JG_CMD_HEARTBEAT_RESPONSE ? m.from.peer : c.from;  // (rpc.rs:17-27: the Message names the sender)
+        i++;
+        if (++seen == per) seen = 0, at = at + 1 == G ? 0 : at + 1;
+      }
+    };
     auto fill = [&](uint32_t t, uint8_t* kind, uint32_t* group, uint32_t* from, uint64_t* id, uint8_t* flag) {
-      tasks.run(R * SPLIT, [&](uint32_t job) { fill_part(t, job / SPLIT, job % SPLIT, kind, group, from, id, flag); });
+      tasks.run(R * SPLIT, [&](uint32_t job) {
+        if (wire && job / SPLIT) decode_part(t, job / SPLIT, job % SPLIT, kind, group, from, id, flag);
+        else fill_part(t, job / SPLIT, job % SPLIT, kind, group, from, id, flag);
+      });
+      if (wire)
+        for (uint32_t sc = 1; sc < R; sc++) wire_bytes += wire_buf[t][sc].size();
       return rows_of_tick(t);
     };
     uint64_t c0[4], c1[4];
@@ -266,7 +325,7 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
       if (t == W) {
         loop.flush();
         if (jg_sync(raft.raw()) != JG_OK || jg_get_counters(raft.raw(), c0) != JG_OK) throw std::runtime_error("counters");
-        sink = fsm_rows = msg_rows = col_bytes = up_bytes = general = rows_in = 0;
+        sink = fsm_rows = msg_rows = col_bytes = up_bytes = general = rows_in = wire_bytes = 0;
         t_fill = t_submit = t_step = 0;
         t_begin = rv.arrive(), started = true;
       }
@@ -334,6 +393,7 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
     out.down_bytes = col_bytes + fsm_rows * sizeof(jg_fsm_row) + msg_rows * sizeof(jg_msg_row);
     out.rows_in = rows_in, out.general = general, out.fsm_rows = fsm_rows, out.msg_rows = msg_rows, out.up_bytes = up_bytes, out.sink = sink;
     out.t_fill = t_fill, out.t_submit = t_submit, out.t_step = t_step;
+    out.wire_bytes = wire_bytes;
     out.ok = ok;
   } catch (const std::exception& e) {
     out.ok = false, out.error = e.what();
@@ -395,7 +455,7 @@ int main(int argc, char** argv) {
     if (!r.ok) std::fprintf(stderr, "loop failed: %s\n", r.error.empty() ? "the closed form of the stream is violated" : r.error.c_str());
     a.ok = a.ok && r.ok;
     a.decisions += r.decisions, a.rows_in += r.rows_in, a.general += r.general, a.fsm_rows += r.fsm_rows, a.msg_rows += r.msg_rows;
-    a.up_bytes += r.up_bytes, a.down_bytes += r.down_bytes, a.sink += r.sink;
+    a.up_bytes += r.up_bytes, a.down_bytes += r.down_bytes, a.sink += r.sink, a.wire_bytes += r.wire_bytes;
     a.wall_ms = std::max(a.wall_ms, r.wall_ms);
     a.t_fill += r.t_fill / L, a.t_submit += r.t_submit / L, a.t_step += r.t_step / L;  // (per loop: they run side by side)
     k_us += r.k_us / L, a.k_n += r.k_n;
@@ -404,10 +464,10 @@ int main(int argc, char** argv) {
               "\"decisions_per_s\": %.6g, \"ms_per_tick\": %.4f, \"ms_fill\": %.4f, \"ms_submit\": %.4f, \"ms_step_and_drain\": %.4f, "
               "\"rows_in_per_tick\": %.1f, \"rows_general\": %llu, \"fsm_rows_per_tick\": %.1f, \"msg_rows_per_tick\": %.1f, "
               "\"pcie_h2d_bytes_per_tick\": %.1f, \"pcie_d2h_bytes_per_tick\": %.1f, \"leader_kernel_us\": %.3f, \"leader_kernel_launches\": %u, "
-              "\"sink\": %llu}\n",
+              "\"wire_bytes_decoded_per_tick\": %.1f, \"sink\": %llu}\n",
               a.ok ? "true" : "false", mode.c_str(), G, R, L, mode.rfind("pipetasks", 0) == 0 ? helpers : 0u, T, W, (unsigned long long)a.decisions, a.wall_ms, a.decisions / (a.wall_ms / 1e3),
               a.wall_ms / T, a.t_fill / T, a.t_submit / T, a.t_step / T, (double)a.rows_in / T, (unsigned long long)a.general,
               (double)a.fsm_rows / T, (double)a.msg_rows / T, (double)a.up_bytes / T, (double)a.down_bytes / T, k_us, a.k_n,
-              (unsigned long long)a.sink);
+              (double)a.wire_bytes / T, (unsigned long long)a.sink);
   return a.ok ? 0 : 1;
 }

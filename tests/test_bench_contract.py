@@ -217,6 +217,9 @@ def test_event_loop_line():
     tk = ev["one_loop_with_transport_and_consumer_tasks"]  # (the binary checks the closed form of the stream in every mode)
     assert tk["task_threads_beside_the_loop"] == 4 and tk["decisions_per_s"] > 0 and tk["column_inbound_decisions_per_s"] > 0
     assert tk["rows_on_the_general_path"] == 0
+    wd = tk["wire_decode"]  # the peers' traffic as length-delimited serde_json frames through host/formats.hpp's decoder
+    assert wd["decisions_per_s"] > 0 and wd["rows_on_the_general_path"] == 0 and wd["frames_per_tick"] >= 20000 * 4 and wd["wire_bytes_decoded_per_tick"] > 100 * 20000 * 4
+    assert tk["host_wait"]["interrupt_decisions_per_s"] > 0 and tk["host_wait"]["polled_decisions_per_s"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["avg_launch_us"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] == "port"
