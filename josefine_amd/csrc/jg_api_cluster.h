@@ -6,6 +6,7 @@ struct jg_dense_cluster {
   uint32_t G = 0, R = 0, lead = 0;
   uint32_t lead_id = 0;
   uint64_t *acks = nullptr, *hbr_commit = nullptr, *o_ae = nullptr;  // acks: the lead node's inbox answer words
+  uint64_t* o_aec = nullptr;  // [G] the followers' AppendEntries word where it is the same for all of them (JgLeaderNode::o_aec)
   jg_leader_beat* o_beat = nullptr;
   std::vector<void*> bufs;
   // one protocol round captured as a hipGraph (ten launches and nine cross-stream dependencies per
@@ -96,7 +97,7 @@ int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t 
   };
   int rc = JG_OK;
   if ((rc = alloc(8 * R * G, (void**)&c->acks)) || (rc = alloc(8 * R * G, (void**)&c->hbr_commit)) ||
-      (rc = alloc(16 * G, (void**)&c->o_beat)) || (rc = alloc(8 * R * G, (void**)&c->o_ae)) ||
+      (rc = alloc(16 * G, (void**)&c->o_beat)) || (rc = alloc(8 * R * G, (void**)&c->o_ae)) || (rc = alloc(8 * G, (void**)&c->o_aec)) ||
       (rc = alloc(8 * G, (void**)&c->offered))) {
     jg_dense_cluster_destroy(c);
     return rc;
@@ -122,7 +123,7 @@ int jg_dense_cluster_create(jg_engine* const* nodes, uint32_t n_nodes, uint32_t 
     for (size_t g = 0; g < G; g++) a[(size_t)lead * G + g] = JG_NO_ACK;
   if ((rc = jg_device_upload(L, c->acks, a.data(), a.size() * 8)) ||
       // (the lead node's own row of the AppendEntries block is never written by its kernel: JG_NO_ACK once)
-      hipMemsetAsync(c->o_ae, 0xff, 8 * R * G, L->stream) != hipSuccess) {
+      hipMemsetAsync(c->o_ae, 0xff, 8 * R * G, L->stream) != hipSuccess || hipMemsetAsync(c->o_aec, 0xff, 8 * G, L->stream) != hipSuccess) {
     jg_dense_cluster_destroy(c);
     return rc;
   }
@@ -214,6 +215,14 @@ int jg_dense_cluster_withdraw_appends(jg_dense_cluster* c, const uint32_t* group
 
 int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_leader_outbox* out) {
   if (!c) return fail(JG_EINVAL, "null argument");
+  if (out) {  // the cluster keeps ONE AppendEntries word per group where every follower's is the same: written out into the block's rows here
+    jg_engine* L = c->nodes[c->lead];
+    HIPCHK(hipSetDevice(L->device));
+    hipLaunchKernelGGL(k_aec_expand, dim3((c->G + 255) / 256), dim3(256), 0, L->stream, c->G, c->R, c->any ? JG_OWNER_NONE : c->lead,
+                       (const uint8_t*)c->owner, (const uint64_t*)c->o_aec, c->o_ae);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(L->stream));
+  }
   if (in) *in = jg_leader_inbox{c->acks, c->hbr_commit};
   if (out) *out = jg_leader_outbox{c->o_beat, c->o_ae};
   return JG_OK;
@@ -228,7 +237,7 @@ JgFollowerJob cluster_job(const jg_dense_cluster* c, uint32_t r) {
   j.d = e->dev;
   j.a.clock = c->clock, j.a.clock_slot = r;
   j.a.leader = nullptr, j.a.leader_id = c->lead_id;
-  j.a.beat = c->o_beat, j.a.ae = c->o_ae + (size_t)r * c->G;
+  j.a.beat = c->o_beat, j.a.ae = c->o_ae + (size_t)r * c->G, j.a.aec = c->o_aec;
   j.a.o_answer = c->acks + (size_t)r * c->G, j.a.o_hbc = c->hbr_commit + (size_t)r * c->G;
   j.a.tick = 1;
   return j;
@@ -265,7 +274,10 @@ int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits,
   if (leading_waits)
     for (uint32_t r = 0; r < c->R; r++)
       if (r != c->lead && (rc = jg_stream_wait(L, c->nodes[r]))) return rc;
-  if ((rc = jg_step_dense_leader(L, now_ms, &in, &out))) return rc;
+  L->cluster_aec = c->o_aec;  // (the cluster's own mailboxes: the followers' AppendEntries words are one word where they agree)
+  rc = jg_step_dense_leader(L, now_ms, &in, &out);
+  L->cluster_aec = nullptr;
+  if (rc) return rc;
   if (multi) {  // (a captured round whose nodes share the lead node's stream) every follower half in ONE launch
     hipLaunchKernelGGL(k_follower_tick_dense_multi, dim3(L->dense_grid, c->R - 1), dim3(JG_BLOCK), 0, L->stream, (const JgFollowerJob*)c->d_jobs);
     {
@@ -302,7 +314,10 @@ int cluster_round_body(jg_dense_cluster* c, uint64_t now_ms, bool leading_waits,
     fi.leader = nullptr, fi.leader_id = c->lead_id;
     fi.beat = c->o_beat, fi.ae = c->o_ae + (size_t)r * G;
     const jg_follower_outbox fo{c->acks + (size_t)r * G, c->hbr_commit + (size_t)r * G};
-    if ((rc = jg_step_dense_follower(c->nodes[r], now_ms, &fi, &fo, 1))) return rc;
+    c->nodes[r]->cluster_aec = c->o_aec;
+    rc = jg_step_dense_follower(c->nodes[r], now_ms, &fi, &fo, 1);
+    c->nodes[r]->cluster_aec = nullptr;
+    if (rc) return rc;
   }
   return JG_OK;
 }
@@ -342,7 +357,7 @@ int cluster_tables_any(jg_dense_cluster* c, uint64_t now_ms, bool replay) {
     nd.clock = replay ? c->clock : nullptr, nd.clock_slot = r;
     nd.ack_stride = 1, nd.packed = 1;
     nd.hbr_commit = c->hbr_commit;
-    nd.o_beat = c->o_beat, nd.o_ae = c->o_ae;
+    nd.o_beat = c->o_beat, nd.o_ae = c->o_ae, nd.o_aec = c->o_aec;
     nd.now = now_ms;
     nd.owner = c->owner, nd.offered = c->offered;
     JgLeaderJob& j = lj[r];
@@ -352,7 +367,7 @@ int cluster_tables_any(jg_dense_cluster* c, uint64_t now_ms, bool replay) {
     f.d = e->dev;
     f.a.clock = replay ? c->clock : nullptr, f.a.clock_slot = r, f.a.seq_off = 1;
     f.a.leader = nullptr, f.a.leader_id = 0;
-    f.a.beat = c->o_beat, f.a.ae = c->o_ae + (size_t)r * G;
+    f.a.beat = c->o_beat, f.a.ae = c->o_ae + (size_t)r * G, f.a.aec = c->o_aec;
     f.a.o_answer = c->acks + (size_t)r * G, f.a.o_hbc = c->hbr_commit + (size_t)r * G;
     f.a.now = now_ms, f.a.seq = e->seq, f.a.tick = 1;
     f.a.owner = c->owner, f.a.self_slot = r;

@@ -564,6 +564,7 @@ int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* i
   if (out) {
     nd.o_beat = out->beat;
     nd.o_ae = out->ae;
+    nd.o_aec = e->cluster_aec;
   }
   nd.now = now_ms;
   const uint64_t* acks = in ? in->answers : nullptr;
@@ -588,6 +589,7 @@ int follower_half(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in, co
   a.leader_id = in->leader_id;
   a.beat = in->beat;
   a.ae = in->ae;
+  a.aec = e->cluster_aec;
   a.o_answer = out->answer;
   a.o_hbc = out->hb_commit;
   a.now = now_ms;

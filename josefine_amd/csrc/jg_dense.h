@@ -398,6 +398,12 @@ struct JgLeaderNode {
   const uint64_t* hbr_commit;  // [R][G] (slow kernel only)
   jg_leader_beat* o_beat;      // [G]     null: no Tick
   uint64_t* o_ae;              // [R][G]
+  // a jg_dense_cluster's mailboxes only (null otherwise): ONE AppendEntries word per group where every follower is sent
+  // the same one - the steady state: all of them in Replicate at the same head, or nobody sent anything - and
+  // JG_AEC_INDIVIDUAL where they differ (then, and only then, the rows of o_ae hold this round's words).  The leader half
+  // wrote 16 + 8 (R - 1) + 8 bytes per group, 59 MB of its 137 MB at 1 M x 5; now 32, and the R - 1 follower halves read one
+  // shared line instead of R - 1 private ones.
+  uint64_t* o_aec;             // [G]
   uint64_t now;
   // jg_step_node: what the step pushed on fsm_tx, as one word per group (jg_node.h JGN_FSM_*); null otherwise
   uint32_t* fsm_delta;         // [G]
@@ -420,6 +426,13 @@ struct JgLeaderNode {
   uint32_t sparse_mode, pad3_;
 };
 #define JG_OWNER_NONE 0xffu
+#define JG_AEC_INDIVIDUAL 0xfffffffffffffffeull  // (no JG_AE word: a range start key stays below JG_MAILBOX_NONE; not JG_NO_ACK: "nothing for anybody")
+// the follower's side: its AppendEntries word of group g (aec: the cluster's common column or null; ae: its row of the block)
+__device__ __forceinline__ uint64_t jg_ae_word_for(const uint64_t* __restrict__ aec, const uint64_t* __restrict__ ae, uint32_t g) {
+  if (!aec) return __builtin_nontemporal_load(&ae[g]);
+  const uint64_t c = aec[g];  // (every follower node reads this line: not a streaming load)
+  return __builtin_expect(c == JG_AEC_INDIVIDUAL, 0) ? ae[g] : c;
+}
 __device__ __forceinline__ bool jg_sparse_skip(const uint64_t* bits, uint32_t mode, uint32_t g) {
   const bool sp = (bits[g >> 6] >> (g & 63u)) & 1ull;
   return mode == 1u ? sp : !sp;
@@ -477,6 +490,10 @@ __device__ __forceinline__ int jg_dense_classify(const JgDev& d, uint32_t g, uin
 template <int R, bool SKIP_OWN>
 __device__ __forceinline__ void jg_dense_outbox_none(uint32_t G, const JgLeaderNode& nd, uint32_t g, uint32_t s) {
   nd.o_beat[g] = jg_leader_beat{0, JG_NO_ACK};
+  if (nd.o_aec) {  // (a cluster's mailboxes: nothing for anybody is one word; k_dense_slow fills the rows of what it serves in columns)
+    nd.o_aec[g] = JG_NO_ACK;
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < R; r++)
     if (!(SKIP_OWN && (uint32_t)r == s)) nd.o_ae[(size_t)r * G + g] = JG_NO_ACK;
@@ -528,6 +545,14 @@ __device__ __forceinline__ uint32_t jg_dense_leader_tick(const JgDenseHot& h, co
   if (dead) jg_push_fault(*dp, g, JG_FAULT_RANGE_HIT_COMMIT_KEY, seq);
   if (due) h.heartbeat_time[g] = nd.now;
   nd.o_beat[g] = jg_leader_beat{term, hb};  // one 16-byte store
+  if (nd.o_aec) {  // a cluster's mailboxes: the followers' words are one word where they agree (JgLeaderNode::o_aec)
+    const uint64_t first = s == 0 ? word[R > 1 ? 1 : 0] : word[0];
+    bool same = true;
+#pragma unroll
+    for (int r = 0; r < R; r++) same = same && ((uint32_t)r == s || word[r] == first);
+    nd.o_aec[g] = same ? first : JG_AEC_INDIVIDUAL;
+    if (__builtin_expect(same, 1)) return nf;
+  }
 #pragma unroll
   for (int r = 0; r < R; r++)
     if (!(SKIP_OWN && (uint32_t)r == s)) nd.o_ae[(size_t)r * G + g] = word[r];

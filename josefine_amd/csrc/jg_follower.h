@@ -30,6 +30,7 @@ struct JgFollowerArgs {
   uint32_t leader_id;
   const jg_leader_beat* beat;  // [G] {term, Heartbeat.commit or JG_NO_ACK}
   const uint64_t* ae;          // [G] JG_AE(from, n) or JG_NO_ACK
+  const uint64_t* aec;         // [G] a jg_dense_cluster's common AppendEntries word (JgLeaderNode::o_aec) or null
   uint64_t* o_answer;          // [G] JG_ANSWER(AppendResponse.head, HeartbeatResponse code)
   uint64_t* o_hbc;             // [G] HeartbeatResponse.commit, where there is one
   uint64_t now;
@@ -80,7 +81,7 @@ __device__ __forceinline__ void jg_follower_fast_body(const JgDev& d, JgFollower
     }
     const bool mail = !ANY || (own != JG_OWNER_NONE && own != a.self_slot);
     jg_leader_beat beat = a.beat[g];  // one 16-byte load
-    uint64_t in_ae = __builtin_nontemporal_load(&a.ae[g]);
+    uint64_t in_ae = jg_ae_word_for(a.aec, a.ae, g);
     if (ANY && !mail) beat = jg_leader_beat{0, JG_NO_ACK}, in_ae = JG_NO_ACK;
     const uint64_t in_term = beat.term, in_hbc = beat.hb_commit;
     const uint64_t in_from = in_ae >> 8;
@@ -281,7 +282,7 @@ __device__ __forceinline__ void jg_follower_slow_body(const JgDev& d, JgFollower
     c.aux = 0;
     if (!tick_only) {
       const uint64_t hbc = mail ? a.beat[g].hb_commit : JG_NO_ACK;
-      const uint64_t ae = mail ? a.ae[g] : JG_NO_ACK;
+      const uint64_t ae = mail ? jg_ae_word_for(a.aec, a.ae, g) : JG_NO_ACK;
       const uint32_t n_blk = (uint32_t)ae & 0xffu;
       if (hbc != JG_NO_ACK) {
         c.kind = JG_CMD_HEARTBEAT;

@@ -200,6 +200,10 @@ __device__ __forceinline__ void jg_dense_slow_body(const JgDev& d, const uint64_
         L.xq_on = 3;
         L.cap_hbc = JG_NO_ACK;
         L.cap_ae = nd.o_ae;
+        if (nd.o_aec) {  // a cluster's mailboxes: this group's words are in the rows (the general state machine writes them one by one)
+          for (uint32_t r = 0; r < d.R; r++) nd.o_ae[(size_t)r * d.G + g] = JG_NO_ACK;
+          nd.o_aec[g] = JG_AEC_INDIVIDUAL;
+        }
         jg_apply(d, L, c, nullptr, nullptr);
         nd.o_beat[g] = jg_leader_beat{L.term, L.cap_hbc};
       }

@@ -678,6 +678,18 @@ __global__ void k_route_mask_appends(uint32_t G, const uint32_t* __restrict__ fl
   if (g < G) own_col[g] = (flags[g] & JGF_ROLE_MASK) == JG_ROLE_LEADER ? offered[g] : JG_ANSWER(0, JG_HB_NONE);  // (answer words)
 }
 
+// jg_dense_cluster_mailboxes: the common AppendEntries word of a group (JgLeaderNode::o_aec) into the rows of the block -
+// every slot's but the sender's (lead, or with per-partition leadership the group's owner: none where nobody owns it)
+__global__ void k_aec_expand(uint32_t G, uint32_t R, uint32_t lead, const uint8_t* __restrict__ owner, const uint64_t* __restrict__ aec,
+                             uint64_t* __restrict__ ae) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const uint64_t c = aec[g];
+  const uint32_t from = owner ? owner[g] : lead;
+  if (c == JG_AEC_INDIVIDUAL || from == JG_OWNER_NONE) return;
+  for (uint32_t r = 0; r < R; r++)
+    if (r != from) ae[(size_t)r * G + g] = c;
+}
 // jg_dense_cluster_offer_appends / _withdraw_appends: `per_round` ClientRequests (0: no more) for the listed groups
 __global__ void k_offer_appends(uint32_t n, const uint32_t* __restrict__ groups, uint32_t G, uint64_t per_round, uint64_t* __restrict__ offered,
                                 uint64_t* __restrict__ own_col) {

@@ -20,7 +20,7 @@ BUDGET = {
     "k_follower_tick_dense_multi": (72, 7),          # ... and its follower halves
     "k_follower_tick_dense": (72, 7),
     "k_follower_tick_dense_any": (72, 7),            # per-partition leadership
-    "void k_leader_node_tick_any<3>": (64, 8),
+    "void k_leader_node_tick_any<3>": (64, 7),
     "void k_leader_node_tick_any<5>": (80, 6),
     "k_cluster_claim": (32, 8),
     "k_vote_half_multi": (128, 4),                   # the vote mail's receiving half: no scratch (its jobs are kernel arguments)
