@@ -989,7 +989,7 @@ def secondary_lines(args):
         return x if "error" in x else {
             "command": x["command"], "round_ms": x["line"]["ms_per_step"], "frac": x["line"]["roofline"]["frac"], "vote_words": x["line"]["vote_words"],
             "rows_routed_per_round": x["line"]["rows_routed_per_round"], "leaderless_fraction": x["line"]["leaderless_fraction"],
-            "stationary": x["line"]["config"]["stationary"].split(":")[0], "round_ms_by_window": [w["ms_per_round"] for w in x["line"]["ms_per_round_by_leaderless_fraction"]],
+            "stationary": x["line"]["config"]["stationary"].split(":")[0].split(" ")[0], "round_ms_by_window": [w["ms_per_round"] for w in x["line"]["ms_per_round_by_leaderless_fraction"]],
             "decisions_per_s": x["line"]["value"]}
     out["routed_round"] = routed(run("routed_round", ["--cluster", "--failures", "1", "--steps", "40", "--warmup", "10", "--vote-words", "1"]))
     out["routed_round_rows_only"] = routed(run("routed_round_rows_only", ["--cluster", "--failures", "1", "--steps", "40", "--warmup", "10", "--vote-words", "0"]))
@@ -1433,7 +1433,7 @@ def main():
             out["tick_us"] = launch_s * 1e6
             out["rows_delivered_to_host"] = drained
             # the region ends with a full drain - everything stepped is in host memory before the clock stops - whose transfer
-            # overlaps no tick: a fixed cost, so ms_per_step depends on --steps (0.081 at 160, 0.118 at 96).  Beside it: the
+            # overlaps no tick: a fixed cost (3-4 ms), so ms_per_step depends on --steps (0.081 at 160, 0.118 at 96).  Beside it: the
             # tick with that tail taken out (what a longer run converges to) and the dense kernel alone.
             out["drain_pipeline"] = {"ticks_per_batch": DRAIN_EVERY, "final_flush_ms": tail_s[0] * 1e3,
                                      "ms_per_step_without_final_flush": (wall - tail_s[0]) * 1e3 / K, "dense_kernel_us": k_us.value}

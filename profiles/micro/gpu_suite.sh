@@ -1,4 +1,12 @@
 #!/bin/bash
+# the whole GPU suite, then the driver's bench command with its wall time
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 > gpurun_out/gpu_suite.txt
-python bench.py --cluster --failures 1 --steps 40 --warmup 10 --no-cpu-baseline --vote-words 1 --repair-after 0 2>/dev/null | tail -1 | cut -c1-400 >> gpurun_out/gpu_suite.txt
+timeout 2400 python -m pytest ${SUITE:-tests} -m gpu -q 2>&1 | tail -8 > gpurun_out/gpu_suite.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 >> gpurun_out/gpu_suite.txt
+T0=$(date +%s.%N); python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; T1=$(date +%s.%N); echo "bench.py default: $(echo "$T1 - $T0" | bc) s wall" >> gpurun_out/gpu_suite.txt
+python - >> gpurun_out/gpu_suite.txt <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/bench_default.json') if l.startswith('{')][-1])
+print('headline', d['value'], d['ms_per_step'], d['roofline']['frac'], 'traffic', d['roofline']['traffic'])
+for k,v in d['secondary'].items(): print(k, 'ERROR' if 'error' in v else {a:b for a,b in v.items() if a not in ('command','elections','round_ms_by_window')})
+PY
