@@ -122,6 +122,11 @@ class Command:
         """Engine op: process restart (Raft::new + Chain::new on the persisted tree)."""
         return Command(capi.CMD_RESTART)
 
+    @staticmethod
+    def Recreate() -> "Command":
+        """Engine op: the replica of a partition that was re-created (Raft::new + Chain::new on an EMPTY directory)."""
+        return Command(capi.CMD_RECREATE)
+
 
 class BatchedRaft:
     """N independent Raft node instances behind one engine handle."""

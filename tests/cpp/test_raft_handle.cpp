@@ -390,6 +390,26 @@ static void chain_store_restart() {
     const formats::ChainStore::Reopened r = raft.restart(0);
     CHECK(r.commit == 0 && r.head == 0 && r.id_gen == 1 && raft.handle(0).head() == 0 && read64(raft, JG_FIELD_ID_GEN, 0) == 1);
   }
+  {  // a partition that was RE-CREATED (JG_CMD_RECREATE): an empty data directory - the store starts over with the engine's
+    // image of it, and unlike the restarted leader above this one can append again
+    BatchedRaft raft(1, {1});
+    std::vector<Instruction> fsm_rx;
+    raft.fsm_tx = [&](const Instruction& i) { fsm_rx.push_back(i); };
+    raft.handle(0).apply(Command::Timeout());
+    for (uint8_t k = 1; k <= 3; k++) raft.handle(0).apply(Command::ClientRequest(k, {k, k}));
+    CHECK(raft.store(0).entries() == 5 && raft.handle(0).commit() == 3);
+    raft.recreate(0, 1000);
+    RaftHandle h = raft.handle(0);
+    CHECK(h.is_follower() && h.current_term() == 0 && !h.has_voted() && h.fault() == 0 && h.head() == 0 && h.commit() == 0);
+    CHECK(read64(raft, JG_FIELD_ID_GEN, 0) == 1 && raft.store(0).entries() == 1 && raft.store(0).has(0) && !raft.store(0).has(1));
+    fsm_rx.clear();
+    h = h.apply(Command::Timeout(), 2000);
+    h = h.apply(Command::ClientRequest(9, {9, 9, 9}), 2100);
+    CHECK(h.is_leader() && h.fault() == 0 && h.head() == 1 && h.commit() == 1);
+    CHECK(raft.store(0).at(1).data == (std::vector<uint8_t>{9, 9, 9}) && raft.store(0).at(1).next == 0 && raft.store(0).commit() == 1);
+    CHECK(fsm_rx.size() == 2 && fsm_rx[0].kind == Instruction::Notify && fsm_rx[0].request_id == 9 && fsm_rx[1].kind == Instruction::Apply &&
+          fsm_rx[1].block.data == (std::vector<uint8_t>{9, 9, 9}));
+  }
 }
 
 // Three event loops that talk through BYTES: every message a loop emits is serde_json-encoded and framed the way

@@ -101,7 +101,7 @@ class RefEngine:
         flag = z if flag is None else flag
         for i in range(n):
             k, g = int(kind[i]), int(group[i])
-            assert 0 <= g < self.G and 0 <= k < 13
+            assert 0 <= g < self.G and 0 <= k < capi.CMD_RECREATE + 1
             blocks = None
             if k == capi.CMD_APPEND_ENTRIES:
                 a, b = int(id[i]), int(aux[i])
@@ -137,6 +137,8 @@ class RefEngine:
             return C("ClientRequest", req_id=id_)
         if k == capi.CMD_CLIENT_RESPONSE:
             return C("ClientResponse", req_id=id_)
+        if k == capi.CMD_RECREATE:
+            return C("Recreate")
         return C("Restart")
 
     def submit(self, group, cmd):
@@ -197,11 +199,11 @@ class RefEngine:
     def _apply(self, g, cmd, now, rows=True, capture=None):
         """RaftHandle::apply on group g; a panic becomes the sticky fault.  Returns the row-encoded
         messages (or feeds `capture`) and appends fsm rows unless rows is False."""
-        if cmd.kind == "Restart":  # process restart: Raft::new + Chain::new on the persisted tree
+        if cmd.kind in ("Restart", "Recreate"):  # process restart: Raft::new + Chain::new on the persisted tree - or (Recreate) on an empty one
             old = self.groups[g]
             self.fault[g] = 0
             try:
-                self.groups[g] = self._new_group(g, old.chain.db, now)
+                self.groups[g] = self._new_group(g, old.chain.db if cmd.kind == "Restart" else rr.Sled(), now)
             except rr.Panic as p:  # (cannot happen: Chain::new only asserts on a fresh tree)
                 self._raise(g, p)
             return []

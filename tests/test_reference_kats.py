@@ -485,6 +485,35 @@ def test_restart_reopens_chain(make):  # chain.rs:117-137: head = id_gen = commi
     assert h.fault == capi.FAULT_APPEND_ID_NOT_ABOVE_HEAD
 
 
+def test_recreate_starts_over_from_genesis(make):  # chain.rs:117-153 on an EMPTY directory: JG_CMD_RECREATE
+    """the replica of a partition that was re-created: unlike a restart on the persisted tree (Q8 above) it can lead AND
+    append again - genesis only, no "commit" key, id_gen = 1"""
+    e, h = new_leader(make, 1)
+    for _ in range(3):
+        h.apply(Command.ClientRequest())
+    assert h.commit == 3
+    h.apply(Command.Recreate())
+    assert h.is_follower() and h.current_term == 0 and h.voted_for is None and h.fault == 0
+    assert h.commit == 0 and h.head == 0 and int(e.read("id_gen")[0]) == 1
+    e.drain_messages(), e.drain_applies()
+    h.apply(Command.Timeout())
+    assert h.is_leader() and h.current_term == 1
+    h.apply(Command.ClientRequest())
+    assert h.fault == 0 and h.head == 1 and h.commit == 1
+    # a follower that was re-created extends from genesis again; a fault is cleared by it like by a restart
+    e2, f = new_follower(make, 3)
+    f.apply(Command.AppendEntries(1, 2, [(1, 0), (2, 1)]))
+    f.apply(Command.AppendEntries(1, 2, [(9, 8)]))             # missing parent: the process is gone
+    assert f.fault == capi.FAULT_EXTEND_MISSING_PARENT and f.head == 2
+    f.apply(Command.Recreate())
+    assert f.fault == 0 and f.head == 0 and f.commit == 0 and f.voted_for is None
+    f.apply(Command.AppendEntries(1, 2, [(2, 1)]))             # block 1 is gone with the old directory
+    assert f.fault == capi.FAULT_EXTEND_MISSING_PARENT
+    f.apply(Command.Recreate())
+    f.apply(Command.AppendEntries(1, 2, [(1, 0)]))
+    assert f.fault == 0 and f.head == 1
+
+
 def test_dense_tick_nonleader_append_is_loud(make):
     e, h = new_follower(make, 3)
     acks = np.full((3, 1), capi.NO_ACK, dtype=np.uint64)
