@@ -390,6 +390,7 @@ __device__ __forceinline__ void jg_clock_read(const JgClock* c, uint32_t slot, u
   const JgClockVal& v = c->v[c->idx_rest & 1u];
   now = v.now, seq = v.seq[slot];
 }
+#define JG_AEC_INDIVIDUAL 0xfffffffffffffffeull  // JgLeaderNode::o_aec: "see the rows" (no JG_AE word: a range start key stays below JG_MAILBOX_NONE; not JG_NO_ACK: "nothing for anybody")
 struct JgLeaderNode {
   JgClock* clock;              // non-null: `now` and the step number come from here (slot clock_slot)
   uint32_t clock_slot, pad_;
@@ -426,7 +427,6 @@ struct JgLeaderNode {
   uint32_t sparse_mode, pad3_;
 };
 #define JG_OWNER_NONE 0xffu
-#define JG_AEC_INDIVIDUAL 0xfffffffffffffffeull  // (no JG_AE word: a range start key stays below JG_MAILBOX_NONE; not JG_NO_ACK: "nothing for anybody")
 // the follower's side: its AppendEntries word of group g (aec: the cluster's common column or null; ae: its row of the block)
 __device__ __forceinline__ uint64_t jg_ae_word_for(const uint64_t* __restrict__ aec, const uint64_t* __restrict__ ae, uint32_t g) {
   if (!aec) return __builtin_nontemporal_load(&ae[g]);

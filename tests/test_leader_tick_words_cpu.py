@@ -50,6 +50,19 @@ static uint32_t emit(uint32_t s, uint64_t term, uint64_t hbt, uint64_t head, uin
   const uint32_t nf1 = jg_dense_leader_tick<R, true>(h, &d, nd, 0, 7, s, term, hbt, head, commit, nf, [&](int r) { return match[r]; });
   out[0] = beat.term, out[1] = beat.hb_commit, out[2] = nf1, out[3] = hbt_col[0], out[4] = fqn ? fq[0].code : 0;
   for (int r = 0; r < R; r++) out[5 + r] = ae[r];
+  // ... and as a jg_dense_cluster's mailboxes get it (JgLeaderNode::o_aec): ONE word where the followers' words agree, the rows
+  // only behind JG_AEC_INDIVIDUAL - read back the way the follower half reads it, it must be the same words
+  uint64_t hbt2[1] = {hbt}, aec = 0x1234, ae2[R];
+  uint32_t fqn2 = 0;
+  for (int r = 0; r < R; r++) ae2[r] = 0x5678;  // (a row that is not written must not be read)
+  h.heartbeat_time = hbt2, d.fault_q_n = &fqn2;
+  jg_leader_beat beat2{};
+  nd.o_beat = &beat2, nd.o_ae = ae2, nd.o_aec = &aec;
+  const uint32_t nf2 = jg_dense_leader_tick<R, true>(h, &d, nd, 0, 7, s, term, hbt, head, commit, nf, [&](int r) { return match[r]; });
+  uint64_t bad = nf2 != nf1 || beat2.term != beat.term || beat2.hb_commit != beat.hb_commit || hbt2[0] != hbt_col[0];
+  for (int r = 0; r < R; r++)
+    if ((uint32_t)r != s) bad |= (aec == JG_AEC_INDIVIDUAL ? ae2[r] : aec) != ae[r];
+  out[5 + R] = bad, out[6 + R] = aec == JG_AEC_INDIVIDUAL;
   return nf1;
 }
 extern "C" uint32_t tick_words(int R, uint32_t s, uint64_t term, uint64_t hbt, uint64_t head, uint64_t commit, uint32_t nf, const uint64_t* match,
@@ -115,7 +128,8 @@ def test_tick_words_equal_the_oracles_outbox(lib, R, cfg, own):
     # one Tick per `now` value on the oracle (the call takes one time): group by time
     want = {k: np.zeros(G, np.uint64) for k in ("term", "hb_commit")}
     want_ae = np.full((R, G), NO, np.uint64)
-    out = (C.c_uint64 * (5 + R))()
+    out = (C.c_uint64 * (7 + R))()
+    common = individual = 0
     got_fault = np.zeros(G, np.uint32)
     got_hbt = np.zeros(G, np.uint64)
     for g in range(G):
@@ -124,6 +138,9 @@ def test_tick_words_equal_the_oracles_outbox(lib, R, cfg, own):
         lib.tick_words(R, own, int(st["term"][g]), int(st["heartbeat_time"][g]), int(st["head"][g]), int(st["commit"][g]), nf, col.ctypes.data,
                        int(now[g]), 100, cfg, out)
         want["term"][g], want["hb_commit"][g] = out[0], out[1]
+        assert out[5 + R] == 0, (g, list(out))  # the cluster's common-word form reads back to the same words
+        individual += int(out[6 + R])
+        common += 1 - int(out[6 + R])
         got_fault[g] = out[4]
         got_hbt[g] = out[3]
         for r in range(R):
@@ -156,6 +173,7 @@ def test_tick_words_equal_the_oracles_outbox(lib, R, cfg, own):
         checked += int(ok.sum())
         faults += int((m & (f != 0)).sum())
     assert checked + faults == G and checked > 50
+    assert common > 0 and individual > 0, (common, individual)  # both forms of the cluster's AppendEntries column occurred
     if cfg == 0:
         assert faults > 0  # Q9: a caught-up follower's range runs into the "commit" key (chain.rs:219-226)
 
