@@ -170,6 +170,69 @@ def test_full_size_routed_cluster_failures():
     lib.close()
 
 
+def test_full_size_stationary_trace_with_the_vote_mail():
+    """BASELINE configs[4] as bench.py times it since round 5, at full size: 5 nodes x 1 M partitions, the STATIONARY trace
+    (josefine_amd.traces.FailureRepairTrace: 1 %/round failures, the partition re-created 8 rounds later - JG_CMD_RECREATE at
+    every replica, replica 0 seated a round after) with the election's traffic as mailbox words (JG_CLUSTER_OPT_VOTE_WORDS),
+    the client's proposals withdrawn and offered again on the device.  Oracle clusters that move every message as a row
+    re-run windows of the partitions and must agree on every state column of every node; the whole population through
+    what the trace implies (leadership exactly where it says, re-created partitions appending again, no fault, no row kept)."""
+    from josefine_amd import DenseCluster as LibCluster
+    from josefine_amd.traces import FailureRepairTrace, elect_all
+    from dense_node import RoutedCluster
+
+    G, R, T, W, P, D = 1_000_000, 5, 36, 1024, 1, 8
+    nodes = [BatchedRaft(G, R, seed=9 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY)
+             for r in range(R)]
+    elect_all(nodes[0])
+    nodes[0].drain_messages(), nodes[0].drain_applies()
+    lib = LibCluster(nodes, vote_words=True)
+    lib.set_appends(1)
+    tr = FailureRepairTrace(SEED, G, R, P, D, node_ids=[nodes[r].node_ids[r] for r in range(R)])
+    as_rows = 0
+    for t in range(T):
+        inj, failing, repaired = tr.rows(t)
+        lists = [nodes[0].upload_u32(x) if len(x) else None for x in (failing, repaired)]
+        if lists[0] is not None:
+            lib.withdraw_appends(lists[0].ptr, len(failing))
+        if lists[1] is not None:
+            lib.offer_appends(lists[1].ptr, len(repaired), 1)
+        up = [None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(inj)]
+        st = lib.round_routed((t + 1) * 100, up)
+        as_rows += sum(st["delivered"])
+        assert st["kept"] == 0 and st["fsm_rows"] == 0, t
+        for rows in up + lists:
+            if rows is not None:
+                rows.free()
+    L = nodes[0]
+    down = tr.leaderless()
+    assert 0.06 < down.mean() < 0.10 and tr.ever_failed.mean() > 0.25
+    role = L.read("role")
+    assert (role[down] != capi.ROLE_LEADER).all() and (role[~down] == capi.ROLE_LEADER).all()
+    never = ~tr.ever_failed
+    assert (L.read("head")[never] == T).all() and (L.read("commit")[never] >= T - 3).all()
+    again = tr.ever_failed & ~down
+    assert again.sum() > 0.15 * G and (L.read("head")[again] > 0).all() and (L.read("head")[again] < T).all()
+    for n in nodes:
+        assert not n.read("fault").any() and len(n.drain_messages()) == 0
+    for n in nodes[1:]:
+        assert (n.read("role") != capi.ROLE_LEADER).all()
+    # the campaigns of the leaderless partitions travelled as words: fewer rows than campaigns' copies alone would be
+    assert as_rows < 8 * (R - 1) * tr.ever_failed.sum()
+    for base in (0, 555_000, G - W):
+        oc = RoutedCluster(oracle_engine, W, R, seed=9, group_base=base)
+        tw = FailureRepairTrace(SEED, W, R, P, D, group_base=base, node_ids=oc.member_ids)
+        for t in range(T):
+            inj = tw.rows(t)[0]
+            oc.round(tw.appends(), inject=inj)
+        assert np.array_equal(tw.leaderless(), down[base:base + W])
+        for r in range(R):
+            for name in ("commit", "head", "term", "voted_for", "role", "leader_id", "election_timeout", "vote_seen",
+                         "vote_granted", "repl_state", "fault"):
+                assert np.array_equal(nodes[r].read(name, 0, base, W), oc.nodes[r].read(name)), (base, r, name)
+    lib.close()
+
+
 def test_full_size_any_leader_cluster_elections_and_failures():
     """Per-partition leadership at full size (jg_dense_cluster_create, JG_CLUSTER_ANY_LEADER): 3 nodes x 1 M partitions;
     every partition's leader is ELECTED through the device transport (Timeout at the designated candidate, VoteRequests
