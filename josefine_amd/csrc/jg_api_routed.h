@@ -63,18 +63,14 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   const bool vwords = rt.vote_words && R >= 2;
   if (vwords && !rt.vm_mem) {
     const size_t RG = (size_t)R * c->G, wd = ((size_t)c->G + 63) / 64;
-    const size_t per = RG * (8 + 8 + 8 + 4 + 4) + 2 * R * wd * 8;
+    const size_t per = RG * sizeof(JgVoteRec) + 2 * R * wd * 8;
     HIPCHK(hipMalloc(&rt.vm_mem, 2 * per));
     HIPCHK(hipMemsetAsync(rt.vm_mem, 0, 2 * per, L->stream));  // (the first round reads the mail of a round that never was: none)
     char* p = (char*)rt.vm_mem;
     for (int k = 0; k < 2; k++) {
       JgVoteMail& m = rt.vm[k];
       m.R = R, m.G = c->G, m.words = (uint32_t)wd;
-      m.q_term = (uint64_t*)p, p += RG * 8;
-      m.q_head = (uint64_t*)p, p += RG * 8;
-      m.a_term = (uint64_t*)p, p += RG * 8;
-      m.q_ctl = (uint32_t*)p, p += RG * 4;
-      m.a_ctl = (uint32_t*)p, p += RG * 4;
+      m.rec = (JgVoteRec*)p, p += RG * sizeof(JgVoteRec);
       m.rowmail = (uint64_t*)p, p += R * wd * 8;
       m.wordmail = (uint64_t*)p, p += R * wd * 8;
     }

@@ -35,17 +35,21 @@
 #include "jg_sparse.h"  // jg_block_exclusive_scan
 
 #define JG_VOTE_ORD_BITS 11u  // step (3) << 8 | emission index (8)
+// one sender's words for one partition: 32 bytes, so that a partition's mail from all R senders is ONE stretch of 32 R bytes
+// (partition-major, jg_vote_at) - as five columns it was five 128-byte lines per partition visit of the receiving half,
+// which is bound by exactly those transactions
+struct JgVoteRec {
+  uint64_t q_term, q_head;  // the request: valid where q_ctl counts copies
+  uint64_t a_term;          // the answer: valid where a_ctl says so
+  uint32_t q_ctl;           // copies (bits 0-7) | the sum of their ords (bits 8-31); clear at the start of a round
+  uint32_t a_ctl;           // n (bits 0-7, 0: none) | ord of the first (8-18) | first (19) | rest (20) | to (21-23); clear at the start of a round
+};
+static_assert(sizeof(JgVoteRec) == 32, "a sender's words are one 32-byte record");
 struct JgVoteMail {
-  uint32_t R, G, words;  // words = ceil(G / 64): a bitmap's length
-  // per (partition, sender slot), PARTITION-major ([G][R], jg_vote_at): the receiving half reads one partition's words of
-  // every sender - R neighbours, one or two 32-byte sectors per column instead of R sectors G entries apart
-  uint64_t* q_term;      // valid where q_ctl counts copies
-  uint64_t* q_head;
-  uint32_t* q_ctl;       // copies (bits 0-7) | the sum of their ords (bits 8-31); clear at the start of a round
-  uint64_t* a_term;      // valid where a_ctl says so
-  uint32_t* a_ctl;       // n (bits 0-7, 0: none) | ord of the first (8-18) | first (19) | rest (20) | to (21-23); clear at the start of a round
-  uint64_t* rowmail;     // [R][words] by addressee; clear at the start of a round
-  uint64_t* wordmail;    // [R][words] by addressee; clear at the start of a round
+  uint32_t R, G, words, pad;  // words = ceil(G / 64): a bitmap's length
+  JgVoteRec* rec;             // [G][R], jg_vote_at
+  uint64_t* rowmail;          // [R][words] by addressee; clear at the start of a round
+  uint64_t* wordmail;         // [R][words] by addressee; clear at the start of a round
 };
 __host__ __device__ __forceinline__ size_t jg_vote_at(const JgVoteMail& m, uint32_t sender, uint32_t g) { return (size_t)g * m.R + sender; }
 __host__ __device__ inline uint32_t jg_vote_actl(uint32_t n, uint32_t ord, uint32_t first, uint32_t rest, uint32_t to) {
@@ -68,11 +72,11 @@ __device__ __forceinline__ void jg_votes_census_row(const JgVoteMail& m, uint32_
   const uint64_t bit = 1ull << (g & 63u);
   if (jg_vote_row_is_request_copy(r, sender_id, k)) {
     const size_t i = jg_vote_at(m, src, g);
-    const uint32_t old = atomicAdd(&m.q_ctl[i], 1u | ((step & 7u) << 8 | k) << 8);
+    const uint32_t old = atomicAdd(&m.rec[i].q_ctl, 1u | ((step & 7u) << 8 | k) << 8);
     if ((old & 0xffu) >= 0x80u)  // (no campaign has that many copies, and the 8-bit count must not come round to R - 1 again: rows for everybody)
       for (uint32_t b = dests; b; b &= b - 1) atomicOr((unsigned long long*)&m.rowmail[(size_t)(__ffs(b) - 1) * m.words + (g >> 6)], (unsigned long long)bit);
     if ((old & 0xffu) == 0) {  // (every copy says the same; a second campaign's would not - and is not a word: the count)
-      m.q_term[i] = r.term, m.q_head[i] = r.id;
+      m.rec[i].q_term = r.term, m.rec[i].q_head = r.id;
       for (uint32_t b = dests; b; b &= b - 1) atomicOr((unsigned long long*)&m.wordmail[(size_t)(__ffs(b) - 1) * m.words + (g >> 6)], (unsigned long long)bit);
     }
     return;
@@ -84,7 +88,7 @@ __device__ __forceinline__ void jg_votes_census_row(const JgVoteMail& m, uint32_
 // travel as rows for every addressee of that sender.  (`need` = R - 1; 0: any count is taken - host tests only.)
 __device__ inline void jg_votes_validate_group(const JgVoteMail& m, uint32_t g, uint32_t need) {
   for (uint32_t s = 0; s < m.R; s++) {
-    const uint32_t c = m.q_ctl[jg_vote_at(m, s, g)];
+    const uint32_t c = m.rec[jg_vote_at(m, s, g)].q_ctl;
     if (!(c & 0xffu) || jg_vote_q_ok(c, need)) continue;
     for (uint32_t d = 0; d < m.R; d++)
       if (d != s) atomicOr((unsigned long long*)&m.rowmail[(size_t)d * m.words + (g >> 6)], 1ull << (g & 63u));
@@ -101,7 +105,7 @@ __device__ __forceinline__ bool jg_votes_row_travels(const JgVoteMail& m, uint32
 // sender s's answer word for partition g when its addressee's partition takes rows after all: how many rows it stands
 // for (0: none, or the word travels), to whom, and the emission key of the first - row j's is (*step, *k0 + j) ...
 __device__ inline uint32_t jg_votes_expand_count(const JgVoteMail& m, uint32_t s, uint32_t g, uint32_t need, uint32_t* to, uint32_t* step, uint32_t* k0) {
-  const uint32_t c = m.a_ctl[jg_vote_at(m, s, g)], n = c & 0xffu;
+  const uint32_t c = m.rec[jg_vote_at(m, s, g)].a_ctl, n = c & 0xffu;
   if (!n) return 0;
   *to = (c >> 21) & 7u;
   if (!jg_votes_as_rows(m, *to, g, need)) return 0;
@@ -112,7 +116,7 @@ __device__ inline uint32_t jg_votes_expand_count(const JgVoteMail& m, uint32_t s
 // ... and row j of them (member_id: the NodeId of every slot)
 __device__ inline jg_msg_row jg_votes_expand_row(const JgVoteMail& m, const uint32_t* member_id, uint32_t s, uint32_t g, uint32_t j) {
   const size_t i = jg_vote_at(m, s, g);
-  const uint32_t c = m.a_ctl[i];
+  const uint32_t c = m.rec[i].a_ctl;
   jg_msg_row r;
   r.group = g, r.kind = JG_CMD_VOTE_RESPONSE, r.to_kind = JG_TO_PEER, r.pad = 0;
   r.flag = (uint8_t)((c >> (j ? 20 : 19)) & 1u);
@@ -122,7 +126,7 @@ __device__ inline jg_msg_row jg_votes_expand_row(const JgVoteMail& m, const uint
     if (k == ((c >> 21) & 7u)) r.to_id = member_id[k];
     if (k == s) r.from = member_id[k];
   }
-  r.term = m.a_term[i], r.id = 0, r.aux = 0;
+  r.term = m.rec[i].a_term, r.id = 0, r.aux = 0;
   return r;
 }
 
@@ -148,8 +152,22 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
   const uint32_t R = d.R;
   if (!((in.wordmail[(size_t)self * in.words + (g >> 6)] >> (g & 63u)) & 1ull)) return 0;
   if (jg_votes_as_rows(in, self, g, need)) return 0;  // (its mail came as rows)
+  // A healthy FOLLOWER - four visits of five: the voters - stays one under these two kinds, and all they read or write of
+  // it is the flag word, the term, the commit index and the vote record (follower.rs:97-101,219-246; a VoteResponse at a
+  // follower is ignored): four lines instead of the seven jg_load touches, two stores instead of three.
   JgLane L;
-  jg_load(d, L, g);
+  const uint32_t f0 = d.flags[g];
+  const bool lean = (f0 & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_FOLLOWER;
+  if (lean) {
+    const uint4 v = d.cold.v[g];
+    L.g = g, L.flags = f0, L.term = d.term[g], L.commit = d.commit[g];
+    L.voted_for = v.x, L.leader_id = v.y, L.queued = v.z, L.votes = v.w;
+    L.head = L.id_gen = L.run_hi = L.heartbeat_time = L.election_time = 0, L.mword = L.mbase = 0;
+    L.election_timeout = L.rng_draws = 0;
+    L.decisions = 0, L.overflow = 0;
+  } else {
+    jg_load(d, L, g);
+  }
   const JgLane O = L;
   L.now = now;
   L.seq = seq;
@@ -160,7 +178,8 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
   for (uint32_t s = 0; s < R; s++) {
     if (s == self) continue;
     const size_t i = jg_vote_at(in, s, g);
-    const uint32_t qc = in.q_ctl[i], ac = in.a_ctl[i];
+    const JgVoteRec rc = in.rec[i];  // (two 16-byte loads: everything this sender said)
+    const uint32_t qc = rc.q_ctl, ac = rc.a_ctl;
     const uint32_t q_n = qc & 0xffu, a_n = (ac & 0xffu) && ((ac >> 21) & 7u) == self ? (ac & 0xffu) : 0u;
     if (!q_n && !a_n) continue;
     // the sender's two stretches in its own emission order
@@ -173,8 +192,8 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
       const bool do_ans = (pass == 0) == (ans_first || !q_n);
       if (do_ans ? !a_n : !q_n) continue;
       const uint32_t copies = do_ans ? a_n : q_n;
-      if (do_ans) cmd.kind = JG_CMD_VOTE_RESPONSE, cmd.term = in.a_term[i], cmd.id = 0, cmd.aux = 0;
-      else cmd.kind = JG_CMD_VOTE_REQUEST, cmd.term = in.q_term[i], cmd.id = in.q_head[i], cmd.aux = cmd.term, cmd.flag = 0;
+      if (do_ans) cmd.kind = JG_CMD_VOTE_RESPONSE, cmd.term = rc.a_term, cmd.id = 0, cmd.aux = 0;
+      else cmd.kind = JG_CMD_VOTE_REQUEST, cmd.term = rc.q_term, cmd.id = rc.q_head, cmd.aux = cmd.term, cmd.flag = 0;
       for (uint32_t c = 0; c < copies; c++) {
         if (do_ans) cmd.flag = (ac >> (c ? 20 : 19)) & 1u;
         const JgLane P = L;
@@ -194,13 +213,24 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
   if ((uint32_t)L.cap_hbc & 0xffu) {
     const size_t i = jg_vote_at(out, self, g);
     const uint32_t w = (uint32_t)L.cap_hbc, to = (w >> 21) & 7u;
-    out.a_term[i] = L.cap_ack;
-    out.a_ctl[i] = jg_vote_actl(w & 0xffu, (step & 7u) << 8 | ((w >> 8) & 0xffu), (w >> 19) & 1u, (w >> 20) & 1u, to);
+    out.rec[i].a_term = L.cap_ack;
+    out.rec[i].a_ctl = jg_vote_actl(w & 0xffu, (step & 7u) << 8 | ((w >> 8) & 0xffu), (w >> 19) & 1u, (w >> 20) & 1u, to);
     atomicOr((unsigned long long*)&out.wordmail[(size_t)to * out.words + (g >> 6)], 1ull << (g & 63u));
   }
   if (L.overflow) *d.err = 1;  // (nothing is dropped silently)
   const uint32_t dec = L.decisions;
-  jg_store_dirty<false>(d, L, O);
+  if (lean) {
+    // (what was not loaded must not have been looked at, let alone changed: a follower that left its role, its term or its
+    // commit index under a VoteRequest / VoteResponse would be an engine bug, loud)
+    if (jg_role(L) != JG_ROLE_FOLLOWER || L.term != O.term || L.commit != O.commit || L.head | L.id_gen | L.run_hi | L.heartbeat_time | L.election_time |
+        L.mword | L.election_timeout | L.rng_draws)
+      *d.err = 1;
+    if (L.flags != O.flags) d.flags[g] = L.flags;
+    if (L.voted_for != O.voted_for || L.leader_id != O.leader_id || L.queued != O.queued || L.votes != O.votes)
+      d.cold.v[g] = make_uint4(L.voted_for, L.leader_id, L.queued, L.votes);
+  } else {
+    jg_store_dirty<false>(d, L, O);
+  }
   return dec;
 }
 
@@ -275,7 +305,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_vote_half_multi(JgVoteHalfJobs job
       if (threadIdx.x < n) {
         g = c * JG_VOTE_CHUNK * 64u + jg_chunk_pick(s, t0 + threadIdx.x);
         for (uint32_t q = 0; q < in.R; q++) {
-          const uint32_t ac = in.a_ctl[jg_vote_at(in, q, g)];
+          const uint32_t ac = in.rec[jg_vote_at(in, q, g)].a_ctl;
           heavy |= (q != j.self && (ac & 0xffu) && ((ac >> 21) & 7u) == j.self) ? 1u : 0u;
         }
       }
@@ -321,7 +351,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_votes_clear(JgVoteMail m) {
     const uint32_t total = jg_chunk_scan(s, u);
     for (uint32_t i = threadIdx.x; i < total; i += JG_BLOCK) {
       const uint32_t g = c * JG_VOTE_CHUNK * 64u + jg_chunk_pick(s, i);
-      for (uint32_t q = 0; q < m.R; q++) m.q_ctl[jg_vote_at(m, q, g)] = 0, m.a_ctl[jg_vote_at(m, q, g)] = 0;
+      for (uint32_t q = 0; q < m.R; q++) *(uint64_t*)&m.rec[jg_vote_at(m, q, g)].q_ctl = 0;  // (q_ctl | a_ctl: one 8-byte store)
     }
   }
 }

@@ -813,8 +813,12 @@ def build():
 
 
 class _JgVoteMail(C.Structure):
-    _fields_ = [("R", C.c_uint32), ("G", C.c_uint32), ("words", C.c_uint32), ("q_term", C.c_void_p), ("q_head", C.c_void_p), ("q_ctl", C.c_void_p),
-                ("a_term", C.c_void_p), ("a_ctl", C.c_void_p), ("rowmail", C.c_void_p), ("wordmail", C.c_void_p)]
+    _fields_ = [("R", C.c_uint32), ("G", C.c_uint32), ("words", C.c_uint32), ("pad", C.c_uint32), ("rec", C.c_void_p), ("rowmail", C.c_void_p),
+                ("wordmail", C.c_void_p)]
+
+
+VOTE_REC = np.dtype([("q_term", "<u8"), ("q_head", "<u8"), ("a_term", "<u8"), ("q_ctl", "<u4"), ("a_ctl", "<u4")])  # jg_votes.h: JgVoteRec
+assert VOTE_REC.itemsize == 32
 
 
 class VoteMail:
@@ -822,11 +826,12 @@ class VoteMail:
 
     def __init__(self, R, G):
         self.R, self.G, self.words = R, G, (G + 63) // 64
-        # the device's layout is partition-major ([G][R], jg_vote_at); the tests index [sender, partition]: transposed views
-        self._base = [np.zeros((G, R), t) for t in (np.uint64, np.uint64, np.uint32, np.uint64, np.uint32)]
-        self.q_term, self.q_head, self.q_ctl, self.a_term, self.a_ctl = (b.T for b in self._base)
+        # the device's layout is one 32-byte record per (partition, sender), partition-major ([G][R], jg_vote_at); the tests
+        # index [sender, partition] field by field: transposed views of the record array's fields
+        self._rec = np.zeros((G, R), VOTE_REC)
+        self.q_term, self.q_head, self.q_ctl, self.a_term, self.a_ctl = (self._rec[f].T for f in ("q_term", "q_head", "q_ctl", "a_term", "a_ctl"))
         self.rowmail, self.wordmail = np.zeros((R, self.words), np.uint64), np.zeros((R, self.words), np.uint64)
-        self.c = _JgVoteMail(R, G, self.words, *[b.ctypes.data for b in self._base], self.rowmail.ctypes.data, self.wordmail.ctypes.data)
+        self.c = _JgVoteMail(R, G, self.words, 0, self._rec.ctypes.data, self.rowmail.ctypes.data, self.wordmail.ctypes.data)
 
     def clear(self):  # (k_votes_clear: the control words and the bitmaps; the term / head columns keep their garbage)
         self.q_ctl[:], self.a_ctl[:], self.rowmail[:], self.wordmail[:] = 0, 0, 0, 0
