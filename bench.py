@@ -405,14 +405,19 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
 
     failed = np.zeros(G, bool)
     trace, withdraw = [], []
+    recreate = bool(args.recreate) and R == 3
     if args.failures:
         whole = R == 3
         for t in range(W + K):
-            cols, failing = any_failure_rows(args.seed, t, G, R, args.failures, leader_of, group_base=rank * G, whole_group=whole, skip=failed)
+            # --recreate: the failing group comes back on EMPTY stores (JG_CMD_RECREATE): the election's winner can append
+            # (no Q8), the client keeps proposing, a group may fail any number of times - a stationary trace whose every vote
+            # is real (R = 3: the first grant is the quorum, the campaign is won through the transport)
+            cols, failing = any_failure_rows(args.seed, t, G, R, args.failures, leader_of, group_base=rank * G, whole_group=whole,
+                                             skip=None if recreate else failed, recreate=recreate)
             failed[failing] = True
             trace.append([None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(cols)])
             wl = None
-            if len(failing):
+            if len(failing) and not recreate:
                 p = C.c_void_p()
                 L._check(api.device_alloc(L._h, max(failing.nbytes, 16), C.byref(p)))
                 L._check(api.device_upload(L._h, p, failing.ctypes.data, failing.nbytes))
@@ -438,7 +443,13 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
     rounds(0, W, 0)
     barrier()
     c0 = sum(e.counters()["decisions"] for e in nodes)
-    failed_at_start = float(failed_before(args, np, G, R, leader_of, rank, W).mean()) if args.failures else 0.0
+    led_at_start = None
+    if args.failures:
+        led0 = np.zeros(G, bool)
+        for e in nodes:
+            led0 |= (e.read("role") == capi.ROLE_LEADER) & (e.read("fault") == 0)
+        led_at_start = float((~led0).mean())
+    failed_at_start = float(failed_before(args, np, G, R, leader_of, rank, W).mean()) if args.failures and not recreate else 0.0
     barrier()
     t0 = time.perf_counter()
     L._check(api.timer_start(L._h))
@@ -454,6 +465,7 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
     # full-size properties (window parity against the numpy statement over oracle engines: tests/test_gpu_fullsize.py)
     T = (now[0] - appended_from) // 100
     healthy = ~failed
+    appending_again = 0.0
     led = np.zeros(G, bool)
     won = 0
     for n, e in enumerate(nodes):
@@ -466,6 +478,10 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
         lead_now = (role == capi.ROLE_LEADER) & (fault == 0)
         led |= lead_now
         won += int((lead_now & failed & ((leader_of + 1) % R == n)).sum())
+        assert not recreate or not fault.any(), "a re-created group must not fault"
+        if recreate:  # the winners of re-created groups append again: a block per round since they were elected
+            mine_again = lead_now & failed & ((leader_of + 1) % R == n)
+            appending_again += float((mine_again & (head > 0)).sum()) / max(int(failed.sum()), 1)
     rows_left = sum(len(e.drain_messages()) for e in nodes)
     if not args.failures:
         assert rows_left == 0, "rows left the mailbox vocabulary"
@@ -489,7 +505,10 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
                                     f"({args.leadership}: every node leads G/R partitions and follows the rest), closed loop over the "
                                     "cluster's mailbox columns, 1 client request per led partition per round"
                                     + (f"; {args.failures} %/round of the partitions lose their leader"
-                                       + (" (the whole group restarts), the next replica campaigns and wins through the transport, leadership "
+                                       + (" (the whole group comes back on EMPTY stores, JG_CMD_RECREATE - again and again), the next replica campaigns and wins "
+                                          "through the transport - every vote real -, leads and APPENDS (a chain that starts over: no Q8); the client "
+                                          "keeps proposing: a stationary trace" if recreate else
+                                          " (the whole group restarts), the next replica campaigns and wins through the transport, leadership "
                                           "moves and stays in column form; the client withdraws its proposals from such a partition (Q8)"
                                           if R == 3 else " (crash + restart; the other replicas remember their vote: Q4, the partition stays leaderless)")
                                        if args.failures else "")),
@@ -511,7 +530,10 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
                                  "closed loop's bytes): every node runs both halves here, each over the partitions its role selects"},
         }
         if args.failures:
-            out["leaderless_fraction"] = {"at_start_of_timed_region": None, "at_end": float((~led).mean())}
+            out["leaderless_fraction"] = {"at_start_of_timed_region": led_at_start, "at_end": float((~led).mean())}
+            if recreate:
+                out["config"]["stationary"] = "yes: groups fail at any time, any number of times; every election is won through the transport and its winner appends"
+                out["winners_appending_again_fraction_of_failed_groups"] = appending_again
             out["failed_fraction"] = {"at_start_of_timed_region": failed_at_start, "at_end": float(failed.mean())}
             out["elections_won_after_failures"] = won
             out["rows_routed_per_round"] = delivered[1] / K / world
@@ -998,9 +1020,13 @@ def secondary_lines(args):
     out["per_partition_leadership"] = x if "error" in x else {
         "command": x["command"], "round_us": x["line"]["ms_per_step_events"] * 1e3, "frac": x["line"]["roofline"]["frac"],
         "elections": x["line"]["elections"], "decisions_per_s": x["line"]["value"]}
-    x = run("any_leader_failures", ["--cluster", "--any-leader", "--replicas", "3", "--failures", "1", "--steps", "60", "--warmup", "10"])
+    # (R = 3, the failing groups re-created - JG_CMD_RECREATE -, any number of times: every election WON through the transport,
+    # every vote real, the winners append: a stationary trace; without --recreate it is round 4's, Q8 and a withdrawing client)
+    x = run("any_leader_failures", ["--cluster", "--any-leader", "--replicas", "3", "--failures", "1", "--recreate", "--steps", "60", "--warmup", "30"])
     out["per_partition_leadership_failures"] = x if "error" in x else {
         "command": x["command"], "round_ms": x["line"]["ms_per_step"], "frac": x["line"]["roofline"]["frac"],
+        "stationary": x["line"]["config"].get("stationary", "no").split(":")[0],
+        "winners_appending_again_fraction_of_failed_groups": x["line"].get("winners_appending_again_fraction_of_failed_groups"),
         "elections_won_after_failures": x["line"]["elections_won_after_failures"], "leaderless_fraction": x["line"]["leaderless_fraction"],
         "rows_left_for_the_host": x["line"]["rows_left_for_the_host"], "decisions_per_s": x["line"]["value"]}
     x = run("failures_tick", ["--failures", "1", "--steps", "160", "--warmup", "64"])  # (profiles/*/bench_failures_1pct.json's command)
@@ -1087,6 +1113,9 @@ def main():
                          "traffic is the winners' Heartbeats - rows - and the word passes buy nothing: 0.32 against 0.27 ms)")
     ap.add_argument("--drain-applies", type=int, choices=[0, 1], default=1,
                     help="--cluster --failures: hand the rounds' FSM rows (the Apply ranges of repaired followers) to the host every round")
+    ap.add_argument("--recreate", action="store_true",
+                    help="--cluster --any-leader --failures p (R = 3): the failing group comes back on EMPTY stores (JG_CMD_RECREATE) - the campaign is won "
+                         "through the transport, the winner appends, groups may fail again: a stationary trace with no synthetic vote")
     ap.add_argument("--repair-after", type=int, default=10,
                     help="--cluster --failures (single lead): rounds after which a failed partition is repaired (every replica restarts, "
                          "replica 0 is re-seated) - the stationary configs[4] trace; 0: never (the leaderless fraction grows)")

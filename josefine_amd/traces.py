@@ -147,12 +147,15 @@ def cluster_failure_rows(seed, tick, G, R, percent=1, lead=0, candidate=1, also=
     return out
 
 
-def any_failure_rows(seed, tick, G, R, percent, leader_of, group_base=0, whole_group=True, skip=None):
+def any_failure_rows(seed, tick, G, R, percent, leader_of, group_base=0, whole_group=True, skip=None, recreate=False):
     """configs[4] with PER-PARTITION LEADERSHIP (jg_dense_cluster_create, JG_CLUSTER_ANY_LEADER): every group fails with
     probability percent/100 per tick (the hash of failure_rows); in a failing group the leader's replica
     (leader_of[g]) crashes and restarts, the next replica - restarted too: voted_for == None, SURVEY.md 7.3 Q4 - receives
     Timeout and campaigns; whole_group: every other replica restarts as well (a rack going down: otherwise they
-    remember their vote and refuse, and the group stays leaderless).  `skip`: groups left alone.
+    remember their vote and refuse, and the group stays leaderless).  `skip`: groups left alone.  `recreate`: the replicas come
+    back on EMPTY stores (JG_CMD_RECREATE instead of JG_CMD_RESTART: the rack's disks are gone) - the winner of the election is
+    then a leader that can append (Q8 does not apply to a chain that starts over), so a group may fail again and again and the
+    trace is stationary (bench.py --cluster --any-leader --failures p --recreate).
     Returns (one group-sorted column dict or None per node, the failing groups)."""
     gg = np.arange(G, dtype=np.uint64) + np.uint64(group_base)
     failing = synth_hash(seed, tick, gg, 7) % np.uint64(100) < np.uint64(percent)
@@ -166,7 +169,7 @@ def any_failure_rows(seed, tick, G, R, percent, leader_of, group_base=0, whole_g
         restart = (lead == n) | cand | bool(whole_group)
         # per failing group, in group order: Restart (if this node restarts), then Timeout (if it is the candidate)
         m = len(failing)
-        kind = np.stack([np.full(m, capi.CMD_RESTART, np.uint8), np.full(m, capi.CMD_TIMEOUT, np.uint8)], axis=1).reshape(-1)
+        kind = np.stack([np.full(m, capi.CMD_RECREATE if recreate else capi.CMD_RESTART, np.uint8), np.full(m, capi.CMD_TIMEOUT, np.uint8)], axis=1).reshape(-1)
         keep = np.stack([restart, cand], axis=1).reshape(-1)
         group = np.repeat(failing, 2)
         if keep.any():

@@ -40,6 +40,9 @@ if [ "$part" = all ] || [ "$part" = bench ]; then
   done
   $B --cluster --any-leader --replicas 5 --steps 200 --warmup 20 > $O/bench_any_1M_x5_blocked.json 2>/dev/null; line $O/bench_any_1M_x5_blocked.json
   $B --cluster --any-leader --replicas 3 --failures 1 --steps 100 --warmup 20 > $O/bench_any_failures_1pct_x3.json 2>/dev/null; line $O/bench_any_failures_1pct_x3.json
+  for k in 60 240; do  # the stationary form: the groups re-created, every election won through the transport
+    $B --cluster --any-leader --replicas 3 --failures 1 --recreate --steps $k --warmup 30 > $O/bench_any_recreate_1pct_x3_$k.json 2>/dev/null; line $O/bench_any_recreate_1pct_x3_$k.json
+  done
   $B --failures 1 --steps 160 --warmup 64 --no-cpu-baseline > $O/bench_failures_1pct.json 2>/dev/null; line $O/bench_failures_1pct.json
   $B --event-loop --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_event_loop_1M.json 2> $O/bench_event_loop_1M.err; line $O/bench_event_loop_1M.json
 fi

@@ -48,13 +48,15 @@ def test_any_leader_closed_loop_on_the_oracle():
     assert sum(len(k) for k in cl.kept) == 0 and cl.delivered.sum() == 0  # nothing ever left the mailbox vocabulary
 
 
-def run_trace(cl, G, R, T, percent, lib=None, nodes=None, seed=99):
+def run_trace(cl, G, R, T, percent, lib=None, nodes=None, seed=99, recreate=False):
     """A failure trace over a cluster (and, in lockstep, the library's cluster over `nodes`): groups fail once at most;
-    with R = 3 the whole group restarts, so that the next replica's campaign is won through the transport."""
+    with R = 3 the whole group restarts, so that the next replica's campaign is won through the transport.  recreate: the
+    replicas come back on EMPTY stores (JG_CMD_RECREATE) and a group may fail any number of times."""
     leader_of = np.arange(G) % R
     failed = np.zeros(G, bool)
     for t in range(T):
-        inj, failing = any_failure_rows(seed, t, G, R, percent, leader_of, whole_group=(R == 3), skip=failed) if t >= 3 else ([None] * R, [])
+        inj, failing = any_failure_rows(seed, t, G, R, percent, leader_of, whole_group=(R == 3), skip=None if recreate else failed,
+                                        recreate=recreate) if t >= 3 else ([None] * R, [])
         failed[failing] = True
         cl.round(np.ones(G, np.uint64), inject=inj)
         if lib is not None:
@@ -87,6 +89,42 @@ def test_any_leader_elections_are_won_through_the_transport_on_the_oracle():
     assert cl.delivered.sum() > 0
 
 
+def test_any_leader_recreated_groups_elect_and_append_again_on_the_oracle():
+    """R = 3, whole groups come back on EMPTY stores (JG_CMD_RECREATE), again and again: every campaign is won through the
+    transport - no synthetic vote anywhere - and the winner APPENDS (Q8 does not apply to a chain that starts over): the
+    trace is stationary.  Oracle and the independent Python reading agree on every column of every node after every round."""
+    G, R, T = 240, 3, 60
+    a, b = AnyLeaderCluster(oracle_engine, G, R, seed=5), AnyLeaderCluster(ref_py_engine, G, R, seed=5)
+    for cl in (a, b):
+        spread_leaders(cl.nodes, G, R, dual_every=0)
+    leader_of = np.arange(G) % R
+    failed = np.zeros(G, bool)
+    last = np.zeros(G, np.int64)
+    for t in range(T):
+        inj, failing = any_failure_rows(99, t, G, R, 4, leader_of, whole_group=True, recreate=True) if t >= 3 else ([None] * R, [])
+        failed[failing] = True
+        last[failing] = t
+        for cl in (a, b):
+            cl.round(np.ones(G, np.uint64), inject=inj)
+        for n in range(R):
+            compare_snapshots(b.nodes[n], a.nodes[n], f"round {t} node {n}")
+    assert failed.sum() > G // 2 and (np.bincount(last[failed]) > 0).sum() > 10
+    roles = np.stack([e.read("role") for e in a.nodes])
+    heads = np.stack([e.read("head") for e in a.nodes])
+    settled = failed & (last < T - 6)  # (an election takes three rounds)
+    lead = (leader_of + 1) % R
+    g = np.arange(G)
+    # the designated candidate won (a group that fails again while its election is in flight can leave it Defeated by votes
+    # that were meant for its previous campaign - it campaigns again at its next timeout: a few of a hundred) ...
+    won = settled & (roles[lead, g] == capi.ROLE_LEADER)
+    assert won.sum() > 0.9 * settled.sum() and settled.sum() > G // 3
+    assert (heads[lead[won], g[won]] >= T - last[won] - 5).all()       # ... and has appended a block per round since
+    assert (heads[lead[won], g[won]] <= T - last[won]).all()
+    for e in a.nodes:
+        assert not e.read("fault").any()
+    assert a.kept[0].tobytes() == b.kept[0].tobytes() and sum(len(k) for k in a.kept) == 0
+
+
 def ref_py_engine(*a, **kw):
     from ref_py.engine import RefEngine
     return RefEngine(*a, **kw)
@@ -114,17 +152,19 @@ def test_any_leader_cluster_oracle_vs_ref_py(R):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R,percent,dual", [(3, 3, 0), (3, 3, 9), (5, 2, 13), (2, 0, 5)])
+@pytest.mark.parametrize("R,percent,dual", [(3, 3, 0), (3, 3, 9), (5, 2, 13), (2, 0, 5), (3, -4, 0)])
 def test_any_leader_cluster_device_parity(R, percent, dual):
+    """(percent < 0: that many percent per round, the groups RE-CREATED - JG_CMD_RECREATE - and failing any number of times)"""
     from josefine_amd import DenseCluster as LibCluster
     G, T = 3000, 45
+    recreate, percent = percent < 0, abs(percent)
     ora = AnyLeaderCluster(oracle_engine, G, R, seed=5)
     nodes = [BatchedRaft(G, R, seed=5 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY) for r in range(R)]
     spread_leaders(ora.nodes, G, R, dual_every=dual)
     spread_leaders(nodes, G, R, dual_every=dual)
     lib = LibCluster(nodes, lead=None)
     lib.set_appends(1)
-    run_trace(ora, G, R, T, percent, lib=lib, nodes=nodes)
+    run_trace(ora, G, R, T, percent, lib=lib, nodes=nodes, recreate=recreate)
     assert sum(ora.delivered) > 0 or percent == 0
     for n in range(R):
         got, want = nodes[n].drain_messages(), ora.kept[n]

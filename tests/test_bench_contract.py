@@ -117,7 +117,9 @@ def test_default_line_carries_the_secondaries():
     sec = d["secondary"]
     assert set(sec) == {"closed_loop", "routed_round", "routed_round_rows_only", "routed_round_no_repairs", "per_partition_leadership",
                         "per_partition_leadership_failures", "failures_tick", "event_loop"}
-    assert sec["per_partition_leadership_failures"]["rows_left_for_the_host"] == 0
+    ppf = sec["per_partition_leadership_failures"]  # re-created groups: every election won through the transport, the winners append
+    assert ppf["rows_left_for_the_host"] == 0 and ppf["stationary"] == "yes" and ppf["winners_appending_again_fraction_of_failed_groups"] > 0.8
+    assert ppf["elections_won_after_failures"] > 0
     for k, v in sec.items():
         assert "error" not in v, (k, v)
     assert sec["closed_loop"]["round_us"] > 0 and 0 < sec["closed_loop"]["frac"] < 1
