@@ -233,8 +233,11 @@ def test_full_size_stationary_trace_with_the_vote_mail():
     lib.close()
 
 
-def test_full_size_any_leader_cluster_elections_and_failures():
-    """Per-partition leadership at full size (jg_dense_cluster_create, JG_CLUSTER_ANY_LEADER): 3 nodes x 1 M partitions;
+@pytest.mark.parametrize("recreate", [False, True], ids=["restart", "recreate"])
+def test_full_size_any_leader_cluster_elections_and_failures(recreate):
+    """(recreate: the failing groups come back on EMPTY stores, JG_CMD_RECREATE - any group, any number of times, the client
+    never stops proposing: bench.py --cluster --any-leader --failures 1 --recreate, the stationary trace whose every vote is real.)
+    Per-partition leadership at full size (jg_dense_cluster_create, JG_CLUSTER_ANY_LEADER): 3 nodes x 1 M partitions;
     every partition's leader is ELECTED through the device transport (Timeout at the designated candidate, VoteRequests
     routed, answered through can_vote, the first majority elects: candidate.rs:101-113), then every node leads a third
     of the partitions and follows the rest over the cluster's mailbox columns; from round 8 on 1 % of the partitions per
@@ -262,7 +265,8 @@ def test_full_size_any_leader_cluster_elections_and_failures():
             return cols, 0
         if t < F0:
             return [None] * R, int(t >= 4)
-        cols, failing = any_failure_rows(SEED, t, n, R, P, leader_of[base:base + n], group_base=base, whole_group=True, skip=failed)
+        cols, failing = any_failure_rows(SEED, t, n, R, P, leader_of[base:base + n], group_base=base, whole_group=True,
+                                         skip=None if recreate else failed, recreate=recreate)
         failed[failing] = True
         return cols, 1
 
@@ -271,7 +275,7 @@ def test_full_size_any_leader_cluster_elections_and_failures():
     delivered = 0
     for t in range(T):
         cols, app = trace(t, G, 0, failed)
-        offered = np.where(failed, np.uint64(0), np.uint64(app))  # the client withdraws from a partition that lost its leader
+        offered = np.where(failed & (not recreate), np.uint64(0), np.uint64(app))  # the client withdraws from a partition that lost its leader (not from a re-created one)
         lib.set_appends(per_group=offered)
         up = [None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(cols)]
         st = lib.round_routed((t + 1) * 100, up)
@@ -291,12 +295,17 @@ def test_full_size_any_leader_cluster_elections_and_failures():
         assert (role[healthy & (leader_of != n)] == capi.ROLE_FOLLOWER).all() and not fault[healthy].any()
         led |= (role == capi.ROLE_LEADER) & (fault == 0)
     assert led[healthy].all() and led[failed].mean() > 0.7  # the campaigns after the failures were won: leadership moved
+    if recreate:  # ... and the winners of re-created groups APPEND (no Q8 for a chain that starts over)
+        heads = np.stack([e.read("head") for e in nodes])
+        roles = np.stack([e.read("role") for e in nodes])
+        won = failed & (roles[(leader_of + 1) % R, np.arange(G)] == capi.ROLE_LEADER)
+        assert won.sum() > 0.7 * failed.sum() and (heads[(leader_of + 1) % R, np.arange(G)][won] > 0).mean() > 0.8
     for base in (0, 333_333, G - W):
         oc = AnyLeaderCluster(oracle_engine, W, R, seed=9, group_base=base)
         f = np.zeros(W, bool)
         for t in range(T):
             cols, app = trace(t, W, base, f)
-            oc.round(np.where(f, np.uint64(0), np.uint64(app)), inject=cols)
+            oc.round(np.where(f & (not recreate), np.uint64(0), np.uint64(app)), inject=cols)
         assert np.array_equal(f, failed[base:base + W])
         for r in range(R):
             for name in ("commit", "head", "term", "voted_for", "role", "leader_id", "election_timeout", "vote_seen",
