@@ -779,7 +779,7 @@ def event_loop_main(args):
         queues unless told otherwise (GPU_MAX_HW_QUEUES), and streams that share one run one behind the other."""
         return os.environ.get("GPU_MAX_HW_QUEUES") or (str(2 * loops) if loops > 2 else None)
 
-    def run(mode, k, w, loops=1, polled=False):
+    def run(mode, k, w, loops=1, polled=False, compact=False):
         env = dict(os.environ)
         if env.get("JG_BENCH_POLLING_DEFAULTED"):  # (several loop threads waiting side by side: the runtime's default, interrupts)
             env.pop("HSA_ENABLE_INTERRUPT", None)
@@ -787,7 +787,8 @@ def event_loop_main(args):
             env["HSA_ENABLE_INTERRUPT"] = "0"
         if hw_queues(loops):
             env["GPU_MAX_HW_QUEUES"] = hw_queues(loops)
-        r = subprocess.run([exe, str(G), str(R), str(k), str(w), mode, "0", str(loops)], capture_output=True, text=True, timeout=1200, env=env)
+        r = subprocess.run([exe, str(G), str(R), str(k), str(w), mode, "0", str(loops)] + ([str(R - 1), "compact"] if compact else []),
+                           capture_output=True, text=True, timeout=1200, env=env)
         if r.returncode != 0:
             raise SystemExit(f"bench_event_loop {mode} x {loops} failed: {r.stdout} {r.stderr}")
         return json.loads(r.stdout.strip().splitlines()[-1])
@@ -801,6 +802,11 @@ def event_loop_main(args):
     pt1 = run("pipetasks", K, W)   # ... with the reference's other tasks (connection readers, channel consumers) on threads of their own
     ptc1 = run("pipetaskscolumns", K, W)
     pt1_polled = run("pipetasks", K, W, polled=True)
+    # ... and with ABI v7's bus formats: sender slot and flag in the kind byte (13 B per inbound row, not 18), the Tick's
+    # AppendEntries words as one word per partition (8 B, not 8 (R - 1)), a leader's Apply + Notify of a tick as one fsm row
+    ptk = run("pipetasks", K, W, compact=True)
+    ptck = run("pipetaskscolumns", K, W, compact=True)
+    pk1 = run("pipe", K, W, compact=True)
     # ... and with the peers' traffic as the reference's BYTES (length-delimited serde_json frames, tcp.rs:139-170) through
     # host/formats.hpp's decoder in the connection tasks: a few ticks (the senders' encoding of every tick comes first)
     ptw = run("pipetaskswire", max(2, min(K, 4)), 2)
@@ -866,6 +872,23 @@ def event_loop_main(args):
                 "host_wait": {"what": "these figures wait for completion signals by interrupt (the runtime's default: the loop's thread sleeps while the "
                                       "device works, as a host that also runs the broker needs it); polled (HSA_ENABLE_INTERRUPT=0) a core spins per waiting thread",
                               "interrupt_decisions_per_s": pt1["decisions_per_s"], "polled_decisions_per_s": pt1_polled["decisions_per_s"]},
+                "compact_bus": {
+                    "what": "the same loop and tasks with the node step's compact formats (ABI v7): JG_COL_PACKED_KIND - the transport's decoder writes "
+                            "kind | sender slot << 4 | flag << 7 into one byte, no from / flag columns (13 B per inbound row instead of 18) -, "
+                            "JG_NODE_COMMON_AE - the Tick's AppendEntries words come home as ONE word per partition where every follower's is the "
+                            "same (8 B instead of 8 (R - 1); the rows are fetched only in a tick where some partition's words differ) - and "
+                            "JG_NODE_FSM_FUSED - a leader's Apply + Notify (+ Apply) of a tick as one 24-byte fsm row",
+                    "decisions_per_s": ptk["decisions_per_s"], "ms_per_tick": ptk["ms_per_tick"],
+                    "ms_per_tick_parts": {"transport_decode_into_pinned_columns": ptk["ms_fill"], "submit_commit": ptk["ms_submit"],
+                                          "step_begin_and_previous_outputs": ptk["ms_step_and_drain"]},
+                    "pcie_bytes_per_tick": {"h2d": ptk["pcie_h2d_bytes_per_tick"], "d2h": ptk["pcie_d2h_bytes_per_tick"]},
+                    "pcie_bytes_per_decision": (ptk["pcie_h2d_bytes_per_tick"] + ptk["pcie_d2h_bytes_per_tick"]) * ptk["ticks"] / ptk["decisions"],
+                    "pcie_bytes_per_decision_plain": (pt1["pcie_h2d_bytes_per_tick"] + pt1["pcie_d2h_bytes_per_tick"]) * pt1["ticks"] / pt1["decisions"],
+                    "fsm_rows_per_tick": ptk["fsm_rows_per_tick"], "fsm_rows_per_tick_plain": pt1["fsm_rows_per_tick"],
+                    "column_inbound_decisions_per_s": ptck["decisions_per_s"], "column_inbound_ms_per_tick": ptck["ms_per_tick"],
+                    "column_inbound_pcie_bytes_per_decision": (ptck["pcie_h2d_bytes_per_tick"] + ptck["pcie_d2h_bytes_per_tick"]) * ptck["ticks"] / ptck["decisions"],
+                    "one_thread_decisions_per_s": pk1["decisions_per_s"], "one_thread_ms_per_tick": pk1["ms_per_tick"],
+                    "rows_on_the_general_path": ptk["rows_general"] + ptck["rows_general"] + pk1["rows_general"]},
                 "wire_decode": {
                     "what": "the same loop and tasks, but the peers' AppendResponses / HeartbeatResponses arrive as what a stock josefine peer sends - "
                             "LengthDelimitedCodec frames around serde_json(Message), one byte stream per connection (src/raft/tcp.rs:40-51,139-170) - "
@@ -1044,7 +1067,9 @@ def secondary_lines(args):
         "one_loop_with_tasks_column_inbound_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["column_inbound_decisions_per_s"],
         "column_inbound_decisions_per_s": x["line"]["event_loop"]["column_inbound"]["decisions_per_s"],
         "rows_on_the_general_path": x["line"]["event_loop"]["rows_on_the_general_path"],
-        "pcie_bytes_per_decision": x["line"]["event_loop"]["pcie_bytes_per_decision"]}
+        "pcie_bytes_per_decision": x["line"]["event_loop"]["pcie_bytes_per_decision"],
+        "compact_bus_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["decisions_per_s"],
+        "compact_bus_pcie_bytes_per_decision": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["pcie_bytes_per_decision"]}
     return out
 
 

@@ -35,8 +35,9 @@
 extern "C" {
 #endif
 
-#define JG_ABI_VERSION 6u /* v5: jg_step_node = arrival-order Apply (fsm_tx: Apply / Notify / Apply per partition), JG_CLUSTER_ANY_LEADER,
-                             jg_dense_cluster_withdraw_appends, JG_COL_UNCHECKED, JG_COL_UPLOAD_NOW; v6: jg_dense_cluster_set_option, jg_dense_cluster_offer_appends, JG_CMD_RECREATE */
+#define JG_ABI_VERSION 7u /* v5: jg_step_node = arrival-order Apply (fsm_tx: Apply / Notify / Apply per partition), JG_CLUSTER_ANY_LEADER,
+                             jg_dense_cluster_withdraw_appends, JG_COL_UNCHECKED, JG_COL_UPLOAD_NOW; v6: jg_dense_cluster_set_option, jg_dense_cluster_offer_appends, JG_CMD_RECREATE;
+                             v7: the node step's bus formats - JG_COL_PACKED_KIND, JG_NODE_COMMON_AE (jg_node_outbox.aec), JG_NODE_FSM_FUSED (JG_FSM_LEADER_STEP) */
 #define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
 #define JG_CHAIN_WINDOW 8u  /* chain segments (gaps / forks) per group besides the main run */
 #define JG_MAX_INFLIGHT 5u  /* src/raft/progress.rs:117                                    */
@@ -216,8 +217,13 @@ typedef struct jg_msg_row {
  * ranges; the host expands them against its block store in key order:
  *   JG_FSM_APPLY_LEADER   : range(a..=b).skip(1)   (leader.rs:93)
  *   JG_FSM_APPLY_FOLLOWER : range(a..b)            (follower.rs:204, half-open)
- *   JG_FSM_NOTIFY         : Notify{block_id=a, id=b} (leader.rs:184-188) */
-enum { JG_FSM_APPLY_LEADER = 0, JG_FSM_APPLY_FOLLOWER = 1, JG_FSM_NOTIFY = 2 };
+ *   JG_FSM_NOTIFY         : Notify{block_id=a, id=b} (leader.rs:184-188)
+ *   JG_FSM_LEADER_STEP    : (jg_step_node with JG_NODE_FSM_FUSED only) everything a leader partition pushed in
+ *                           one step as ONE row: a = the appended block's id, b = the ClientRequest's token,
+ *                           pad[0..2] = a - c0, a - c1, a - c2 (each <= 255) standing for, in this order,
+ *                             JG_FSM_APPLY_LEADER {c0, c1} if c1 != c0;  JG_FSM_NOTIFY {a, b};
+ *                             JG_FSM_APPLY_LEADER {c1, c2} if c2 != c1 */
+enum { JG_FSM_APPLY_LEADER = 0, JG_FSM_APPLY_FOLLOWER = 1, JG_FSM_NOTIFY = 2, JG_FSM_LEADER_STEP = 3 };
 typedef struct jg_fsm_row {
   uint32_t group;
   uint8_t kind;
@@ -324,7 +330,14 @@ enum { JG_COL_FROM = 1u, JG_COL_TERM = 2u, JG_COL_AUX = 4u, JG_COL_FLAG = 8u,
         * step, nothing follows): their upload starts NOW, on a copy stream of its own - while the previous step's
         * kernels run and its outputs travel the other way - instead of at the head of the step.  A batch that turns
         * out not to be the step's whole input is simply uploaded again by the step. */
-       JG_COL_UPLOAD_NOW = 32u };
+       JG_COL_UPLOAD_NOW = 32u,
+       /* the kind column of these rows holds `kind | sender << 4 | flag << 7`: sender = the member slot (index into
+        * jg_config.node_ids, 3 bits) of Message.from for the kinds that carry one (VoteRequest ... HeartbeatResponse;
+        * a slot >= n_replicas reads as NodeId 0, the other kinds read 0 whatever the bits), flag as the flag column -
+        * neither a `from` nor a `flag` column exists for the step (naming JG_COL_FROM / JG_COL_FLAG with it is an
+        * error): an AppendResponse row is 13 bytes on the bus, not 18.  Every commit of a step must agree on it, it
+        * needs JG_COL_UNCHECKED (the device decodes and checks the byte), and jg_submit cannot add rows to such a step. */
+       JG_COL_PACKED_KIND = 64u };
 int jg_submit_reserve(jg_engine* e, size_t n, size_t n_blocks, jg_cmd_cols* cols);
 int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_columns);
 
@@ -510,17 +523,29 @@ enum {
    * the engine (jg_node_outbox_view first of all; any step, drain, read or jg_sync): the row count has landed by then,
    * and if it is not zero those rows are applied and the halves come back for exactly those partitions - the same
    * results and the same record order as the synchronous step, one pass later.  Single-device engines or shards. */
-  JG_NODE_ASYNC = 8u
+  JG_NODE_ASYNC = 8u,
+  /* The Tick's AppendEntries words as ONE word per partition where every addressee's word is the same (the steady state:
+   * every follower acknowledged the same head): jg_node_outbox.aec[g] is that word - JG_NO_ACK: nothing for anybody -
+   * or JG_AEC_INDIVIDUAL: the words are in jg_node_outbox.ae (valid for exactly those partitions: they differ by addressee,
+   * or the partition's rows took the general path in this step), which is
+   * NULL - and is not downloaded: 8 bytes per partition instead of 8 (R - 1) - when no partition of the step needs it
+   * (jg_node_outbox_view fetches the rows when one does).  Single-device engines or shards. */
+  JG_NODE_COMMON_AE = 16u,
+  /* A leader partition's fsm_tx rows of the step as one JG_FSM_LEADER_STEP row where the step appended a block and the
+   * commit index is within 255 of it (24 bytes instead of 48 or 72; other partitions: the plain rows as before). */
+  JG_NODE_FSM_FUSED = 32u
 };
+#define JG_AEC_INDIVIDUAL 0xfffffffffffffffeull /* jg_node_outbox.aec: "see the rows of ae" (no JG_AE word: a range start stays below JG_MAILBOX_NONE) */
 typedef struct jg_node_outbox { /* host pointers into the engine's pinned buffers; NULL: that half did not run */
   const jg_leader_beat* beat;  /* [G]    what a leader's followers read of its Tick (jg_leader_outbox.beat)   */
-  const uint64_t* ae;          /* [R][G] JG_AE(from, n) per addressee slot, JG_NO_ACK: none                    */
+  const uint64_t* ae;          /* [R][G] JG_AE(from, n) per addressee slot, JG_NO_ACK: none (JG_NODE_COMMON_AE: see there) */
   const uint64_t* answer;      /* [G]    JG_ANSWER(AppendResponse.head, has_committed) to the partition's leader */
   const uint64_t* hb_commit;   /* [G]    HeartbeatResponse.commit (valid where the answer carries a response)  */
   uint64_t rows;               /* command rows the step took                                                   */
   uint64_t rows_general;       /* ... of which went through the general state machine                          */
   uint64_t bytes_h2d;          /* PCIe: uploaded for this step                                                 */
   uint64_t bytes_d2h;          /* PCIe: outbox columns downloaded for this step (drains not included)          */
+  const uint64_t* aec;         /* [G]    JG_NODE_COMMON_AE: the partition's AppendEntries word for every addressee, else NULL */
 } jg_node_outbox;
 /* Column inbound for jg_step_node: a peer that is itself a batched engine ships its followers' answers as the
  * column it produced (jg_node_outbox.answer / .hb_commit) instead of two rows per partition.  The call hands out

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 CLUSTER_ANY_LEADER = 0xFFFFFFFF
 CLUSTER_OPT_VOTE_WORDS = 1
 MAX_REPLICAS = 8
@@ -19,6 +19,7 @@ MAX_DEVICES = 16
 FOREIGN_VOTERS = 8
 MAX_DENSE_APPENDS = 1 << 20
 NO_ACK = 0xFFFFFFFFFFFFFFFF
+AEC_INDIVIDUAL = 0xFFFFFFFFFFFFFFFE  # jg_node_outbox.aec: the partition's AppendEntries words differ by addressee (see .ae)
 
 OK, EINVAL, ENOMEM, EDEVICE, ECAPACITY = 0, -1, -2, -3, -4
 
@@ -47,9 +48,9 @@ FAULT_ENGINE_DENSE_APPENDS = 132
 FAULT_ENGINE_MAILBOX_RANGE = 133
 
 CFG_SEPARATE_COMMIT_KEY = 1
-NODE_LEADER_HALF, NODE_FOLLOWER_HALF, NODE_TICK, NODE_ASYNC = 1, 2, 4, 8
+NODE_LEADER_HALF, NODE_FOLLOWER_HALF, NODE_TICK, NODE_ASYNC, NODE_COMMON_AE, NODE_FSM_FUSED = 1, 2, 4, 8, 16, 32
 
-FSM_APPLY_LEADER, FSM_APPLY_FOLLOWER, FSM_NOTIFY = 0, 1, 2
+FSM_APPLY_LEADER, FSM_APPLY_FOLLOWER, FSM_NOTIFY, FSM_LEADER_STEP = 0, 1, 2, 3
 
 (FIELD_TERM, FIELD_VOTED_FOR, FIELD_HAS_VOTED, FIELD_ROLE, FIELD_COMMIT, FIELD_HEAD,
  FIELD_ID_GEN, FIELD_MATCH, FIELD_REPL_STATE, FIELD_VOTE_SEEN, FIELD_VOTE_GRANTED,
@@ -108,7 +109,8 @@ class RouteStats(C.Structure):
 class NodeOutbox(C.Structure):
     """jg_node_outbox."""
     _fields_ = [("beat", C.c_void_p), ("ae", C.c_void_p), ("answer", C.c_void_p), ("hb_commit", C.c_void_p),
-                ("rows", C.c_uint64), ("rows_general", C.c_uint64), ("bytes_h2d", C.c_uint64), ("bytes_d2h", C.c_uint64)]
+                ("rows", C.c_uint64), ("rows_general", C.c_uint64), ("bytes_h2d", C.c_uint64), ("bytes_d2h", C.c_uint64),
+                ("aec", C.c_void_p)]
 
 
 class CmdCols(C.Structure):
@@ -116,7 +118,7 @@ class CmdCols(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("kind", "group", "from_", "term", "id", "aux", "flag", "blk_id", "blk_next")]
 
 
-COL_FROM, COL_TERM, COL_AUX, COL_FLAG, COL_UNCHECKED, COL_UPLOAD_NOW = 1, 2, 4, 8, 16, 32
+COL_FROM, COL_TERM, COL_AUX, COL_FLAG, COL_UNCHECKED, COL_UPLOAD_NOW, COL_PACKED_KIND = 1, 2, 4, 8, 16, 32, 64
 
 
 class CmdBatch(C.Structure):

@@ -208,16 +208,17 @@ struct jg_engine {
   // which optional columns some jg_submit since the last step actually provided (an absent column is
   // all zeros: jg_step_node does not upload it)
   bool p_has_from = false, p_has_term = false, p_has_aux = false, p_has_flag = false;
+  bool p_packed = false;     // JG_COL_PACKED_KIND: the pending kind column holds kind | sender slot << 4 | flag << 7
   bool p_unchecked = false;  // some rows were committed with JG_COL_UNCHECKED: only jg_step_node may take this batch
   // JG_COL_UPLOAD_NOW: the committed batch on its way to the device before the step is called, on a copy stream of
   // its own (the two directions of the bus are independent: the previous step's outputs travel home meanwhile).
   // Two device buffers by turns: a step's rows are read until the step is settled, the next upload must not wait for that
   struct RowLayout {
     size_t n = 0, nb = 0, bytes = 0;
-    bool has_from = false, has_term = false, has_aux = false, has_flag = false;
+    bool has_from = false, has_term = false, has_aux = false, has_flag = false, packed = false;
     size_t o_id = 0, o_term = 0, o_aux = 0, o_bid = 0, o_bnext = 0, o_group = 0, o_from = 0, o_kind = 0, o_flag = 0;
     bool same_batch(const RowLayout& o) const {
-      return n == o.n && nb == o.nb && has_from == o.has_from && has_term == o.has_term && has_aux == o.has_aux && has_flag == o.has_flag;
+      return n == o.n && nb == o.nb && has_from == o.has_from && has_term == o.has_term && has_aux == o.has_aux && has_flag == o.has_flag && packed == o.packed;
     }
   };
   struct EarlyUpload {
@@ -332,11 +333,13 @@ struct jg_engine {
     JgNodeCols cols{};
     jg_leader_beat* o_beat = nullptr;  // device outbox
     uint64_t *o_ae = nullptr, *o_answer = nullptr, *o_hbc = nullptr;
+    uint64_t* o_aec = nullptr;         // JG_NODE_COMMON_AE: the common AppendEntries word (JgLeaderNode::o_aec), allocated at first use
     jg_leader_beat* h_beat = nullptr;  // pinned mirrors
-    uint64_t *h_ae = nullptr, *h_answer = nullptr, *h_hbc = nullptr;
+    uint64_t *h_ae = nullptr, *h_answer = nullptr, *h_hbc = nullptr, *h_aec = nullptr;
+    bool ae_rows_landed = false;       // JG_NODE_COMMON_AE: h_ae holds the last step's rows (fetched when a partition needs them)
     uint64_t *h_in_answers = nullptr, *h_in_hbc = nullptr;  // pinned [R][G]: column inbound (jg_node_inbox_columns)
     uint32_t col_mask = 0, col_hbc_mask = 0;                // slots handed out for the next step / with their hb_commit column
-    uint32_t* d_nsparse = nullptr;     // {general-path rows}
+    uint32_t* d_nsparse = nullptr;     // {general-path rows, -, partitions whose AppendEntries words differ by addressee (JG_NODE_COMMON_AE), -}
     uint32_t* h_nsparse = nullptr;     // pinned
     // the general path's rows as (group << 32 | arrival index, arrival index) pairs, appended by k_node_route (grow-only),
     // and the bucket pass that orders them (jg_route.h: hist / scan / scatter + k_bucket_order)

@@ -172,7 +172,7 @@ void jg_engine_destroy(jg_engine* e) {
   if (e->h_totals) (void)hipHostFree(e->h_totals);
   e->p_kind.destroy(), e->p_flag.destroy(), e->p_group.destroy(), e->p_from.destroy(), e->p_term.destroy();
   e->p_id.destroy(), e->p_aux.destroy(), e->p_blk_id.destroy(), e->p_blk_next.destroy();
-  for (void* p : {(void*)e->node.h_beat, (void*)e->node.h_ae, (void*)e->node.h_answer, (void*)e->node.h_hbc, (void*)e->node.h_nsparse,
+  for (void* p : {(void*)e->node.h_beat, (void*)e->node.h_ae, (void*)e->node.h_answer, (void*)e->node.h_hbc, (void*)e->node.h_nsparse, (void*)e->node.h_aec,
                   (void*)e->node.h_in_answers, (void*)e->node.h_in_hbc})
     if (p) (void)hipHostFree(p);
   if (e->up.st) {
@@ -248,6 +248,7 @@ int jg_submit(jg_engine* e, const jg_cmd_batch* b) {
     e->p_kinds_seen |= seen;
   }
   const size_t at = e->p_kind.size(), n = b->n;
+  if (at && e->p_packed) return fail(JG_EINVAL, "jg_submit: the step's rows so far were committed with JG_COL_PACKED_KIND");
   if (e->up.valid) {  // rows behind an early upload (JG_COL_UPLOAD_NOW): the step uploads the whole batch itself
     HIPCHK(hipEventSynchronize(e->up.ev_up));  // (the columns may move when they grow)
     e->up.valid = false;
@@ -275,7 +276,7 @@ namespace {
 void node_row_layout(const jg_engine* e, size_t n, size_t nb, jg_engine::RowLayout& l) {
   l = jg_engine::RowLayout{};
   l.n = n, l.nb = nb;
-  l.has_from = e->p_has_from, l.has_term = e->p_has_term, l.has_aux = e->p_has_aux, l.has_flag = e->p_has_flag;
+  l.has_from = e->p_has_from, l.has_term = e->p_has_term, l.has_aux = e->p_has_aux, l.has_flag = e->p_has_flag, l.packed = e->p_packed;
   size_t off = 0;
   auto sect = [&](size_t bytes) {
     size_t at = off;
@@ -360,8 +361,12 @@ int jg_submit_reserve(jg_engine* e, size_t n, size_t n_blocks, jg_cmd_cols* cols
 int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_columns) {
   if (!e) return fail(JG_EINVAL, "null argument");
   if (e->router) return fail(JG_EINVAL, "jg_submit_commit: the columns are per shard: call this on a shard handle (jg_get_shard)");
-  if (optional_columns & ~63u) return fail(JG_EINVAL, "unknown column bit");
+  if (optional_columns & ~127u) return fail(JG_EINVAL, "unknown column bit");
   const size_t at = e->p_kind.size(), bat = e->p_blk_id.size();
+  const bool packed = (optional_columns & JG_COL_PACKED_KIND) != 0;
+  if (packed && (!(optional_columns & JG_COL_UNCHECKED) || (optional_columns & (JG_COL_FROM | JG_COL_FLAG))))
+    return fail(JG_EINVAL, "JG_COL_PACKED_KIND: the byte carries sender and flag (no JG_COL_FROM / JG_COL_FLAG) and is checked on the device (JG_COL_UNCHECKED)");
+  if (at && packed != e->p_packed) return fail(JG_EINVAL, "JG_COL_PACKED_KIND: every commit of a step must agree on the kind column's format");
   if (at + n > e->p_kind.cap || at + n > e->p_group.cap || at + n > e->p_id.cap || bat + n_blocks > e->p_blk_id.cap)
     return fail(JG_EINVAL, "jg_submit_commit: more rows than jg_submit_reserve made room for");
   jg_cmd_batch b{};  // what was written in place, as a batch: the same checks as jg_submit
@@ -373,6 +378,7 @@ int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_
     // the device; what the rows may hold is assumed (a Heartbeat; an AppendEntries if the aux column is there)
     seen = 2u | ((optional_columns & JG_COL_AUX) ? 1u : 0u);
     e->p_unchecked = true;
+    e->p_packed = packed;
   } else {
     int rc = validate_batch(e->cfg.n_groups, &b, &seen);
     if (rc) return rc;
@@ -397,7 +403,7 @@ int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_
   adopt(e->p_flag, e->p_has_flag, (optional_columns & JG_COL_FLAG) != 0);
   if (bat && n_blocks)
     for (size_t i = 0; i < n; i++)
-      if (b.kind[i] == JG_CMD_APPEND_ENTRIES) e->p_id[at + i] += bat;
+      if ((packed ? b.kind[i] & 15u : b.kind[i]) == JG_CMD_APPEND_ENTRIES) e->p_id[at + i] += bat;
   e->p_blk_id.n = e->p_blk_next.n = bat + n_blocks;
   if (optional_columns & JG_COL_UPLOAD_NOW) return upload_rows_now(e);
   e->up.valid = false;  // (rows behind an early upload: the step uploads the whole batch itself)

@@ -154,6 +154,8 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     rows.from = has_from ? (const uint32_t*)(B + o_from) : nullptr, rows.term = has_term ? (const uint64_t*)(B + o_term) : nullptr;
     rows.id = (const uint64_t*)(B + o_id), rows.aux = has_aux ? (const uint64_t*)(B + o_aux) : nullptr;
     rows.flag = has_flag ? (const uint8_t*)(B + o_flag) : nullptr;
+    rows.packed = lay.packed ? 1u : 0u;
+    for (uint32_t r = 0; r < JG_MAX_REPLICAS; r++) rows.ids[r] = r < R ? e->cfg.node_ids[r] : 0u;
     rows.blk_id = (const uint64_t*)(B + o_bid), rows.blk_next = (const uint64_t*)(B + o_bnext), rows.n_blocks = nb;
     const uint32_t rgrid = grid_for(n, 4096);
     HIPCHK(hipMemsetAsync(nd.d_nsparse, 0, 8, e->stream));
@@ -178,7 +180,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     e->p_aux.flip(), e->p_blk_id.flip(), e->p_blk_next.flip();
     e->p_has_from = e->p_has_term = e->p_has_aux = e->p_has_flag = false;
     e->p_kinds_seen = 0;
-    e->p_unchecked = false;
+    e->p_unchecked = e->p_packed = false;
   }
   // the dense halves: every partition, the ones whose rows went the general way included (they are ticked here) -
   // except in an asynchronous step, whose halves leave those partitions to the catch-up pass (node_settle)
@@ -198,7 +200,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     HIPCHK(ar.alloc((size_t)G * JGN_FSM_ROWS * sizeof(jg_fsm_row), (void**)&rec.d_fsm));
     HIPCHK(ar.alloc((size_t)n_tiles * 8, (void**)&rec.d_bsum_f));
     hipLaunchKernelGGL(k_node_fsm_build, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rec.d_fsm, rec.d_fsm_cnt,
-                       rec.d_bsum_f);
+                       rec.d_bsum_f, (flags & JG_NODE_FSM_FUSED) ? 1u : 0u);
     HIPCHK(hipGetLastError());
     e->n_launch++;
     e->recs.push_back(rec);
@@ -229,13 +231,32 @@ int node_dense_halves(jg_engine* e, uint64_t now_ms, uint32_t flags, uint32_t co
     ln.hbr_commit = nd.cols.hbr_commit;
     ln.packed = 1;
     ln.ack_stride = 1;
+    const bool common = tick && (flags & JG_NODE_COMMON_AE);
+    if (common && !nd.o_aec) {
+      if ((rc = dev_alloc(e, &nd.o_aec, (size_t)G))) return rc;
+      HIPCHK(hipHostMalloc((void**)&nd.h_aec, std::max<size_t>((size_t)G * 8, 16), hipHostMallocDefault));
+    }
     if (tick) ln.o_beat = nd.o_beat, ln.o_ae = nd.o_ae;
+    if (common) ln.o_aec = nd.o_aec;
     ln.now = now_ms;
     ln.fsm_delta = nd.cols.fsm_delta, ln.fsm_prev = nd.cols.fsm_prev, ln.fsm_mid = nd.cols.fsm_mid;
     ln.arr = nd.cols.arr, ln.col_mask = col_mask;  // (the slow kernel replays its groups in arrival order)
     if (sparse_mode) ln.sparse_bits = nd.cols.sparse_bits, ln.sparse_mode = sparse_mode;
     if ((rc = dense_step(e, nd.cols.answers, 1, &ln))) return rc;
-    if (tick) {
+    if (common) {
+      // one word per partition; the rows only if some partition's words differ by addressee (fetched by
+      // jg_node_outbox_view, which sees the count: none in the steady state)
+      HIPCHK(hipMemsetAsync(nd.d_nsparse + 2, 0, 4, e->stream));
+      hipLaunchKernelGGL(k_node_count_individual, dim3(grid_for(G, 1024)), dim3(JG_BLOCK), 0, e->stream, (const uint64_t*)nd.o_aec, G, nd.d_nsparse + 2);
+      HIPCHK(hipGetLastError());
+      e->n_launch++;
+      HIPCHK(hipMemcpyAsync(nd.h_beat, nd.o_beat, (size_t)G * sizeof(jg_leader_beat), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(nd.h_aec, nd.o_aec, (size_t)G * 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(nd.h_nsparse + 2, nd.d_nsparse + 2, 4, hipMemcpyDeviceToHost, e->stream));
+      nd.ae_rows_landed = false;
+      *bytes_down += (size_t)G * (sizeof(jg_leader_beat) + 8) + 4;
+    } else if (tick) {
+      nd.ae_rows_landed = true;
       HIPCHK(hipMemcpyAsync(nd.h_beat, nd.o_beat, (size_t)G * sizeof(jg_leader_beat), hipMemcpyDeviceToHost, e->stream));
       // (the own slot's row is JG_NO_ACK on both sides and stays there: not written, not downloaded)
       const uint32_t own = e->uniform_self >= 0 ? (uint32_t)e->uniform_self : R;
@@ -338,7 +359,8 @@ int node_settle(jg_engine* e) {
   for (StepRec& rec : e->recs)
     if (rec.seq == pd.fsm_rec_seq && rec.fsm_per_row == JGN_FSM_ROWS && rec.msg_per_row == 0) {
       const uint32_t n_tiles = (e->cfg.n_groups + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
-      hipLaunchKernelGGL(k_node_fsm_build, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rec.d_fsm, rec.d_fsm_cnt, rec.d_bsum_f);
+      hipLaunchKernelGGL(k_node_fsm_build, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rec.d_fsm, rec.d_fsm_cnt, rec.d_bsum_f,
+                         (pd.flags & JG_NODE_FSM_FUSED) ? 1u : 0u);
       e->n_launch++;
     }
   HIPCHK(hipGetLastError());
@@ -350,8 +372,9 @@ int node_settle(jg_engine* e) {
 
 int jg_step_node(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   if (!e) return fail(JG_EINVAL, "null argument");
-  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~15u))
-    return fail(JG_EINVAL, "jg_step_node: flags = JG_NODE_LEADER_HALF and / or JG_NODE_FOLLOWER_HALF [| JG_NODE_TICK] [| JG_NODE_ASYNC]");
+  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~63u))
+    return fail(JG_EINVAL, "jg_step_node: flags = JG_NODE_LEADER_HALF and / or JG_NODE_FOLLOWER_HALF [| JG_NODE_TICK] [| JG_NODE_ASYNC] [| JG_NODE_COMMON_AE] [| JG_NODE_FSM_FUSED]");
+  if (e->router && (flags & JG_NODE_COMMON_AE)) return fail(JG_EINVAL, "jg_step_node: JG_NODE_COMMON_AE is per shard (jg_get_shard)");
   if (e->router) return router_step_node(e, now_ms, flags);
   if (e->inflight.phase) return fail(JG_EINVAL, "a drain is in transfer: jg_drain_wait first");
   return node_step(e, now_ms, flags);
@@ -391,7 +414,28 @@ int jg_node_outbox_view(jg_engine* e, jg_node_outbox* out) {
   int rc = sync_and_check(e);  // (the columns have landed; device-side error flags surface here)
   if (rc) return rc;
   *out = nd.last;
-  if ((nd.last_flags & JG_NODE_LEADER_HALF) && (nd.last_flags & JG_NODE_TICK)) out->beat = nd.h_beat, out->ae = nd.h_ae;
+  if ((nd.last_flags & JG_NODE_LEADER_HALF) && (nd.last_flags & JG_NODE_TICK)) {
+    out->beat = nd.h_beat, out->ae = nd.h_ae;
+    if (nd.last_flags & JG_NODE_COMMON_AE) {
+      out->aec = nd.h_aec, out->ae = nullptr;
+      if (nd.h_nsparse[2]) {  // some partition's words differ by addressee: the rows are wanted after all
+        if (!nd.ae_rows_landed) {
+          const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+          const uint32_t own = e->uniform_self >= 0 ? (uint32_t)e->uniform_self : R;
+          HIPCHK(hipSetDevice(e->device));
+          if (own > 0) HIPCHK(hipMemcpyAsync(nd.h_ae, nd.o_ae, (size_t)std::min(own, R) * G * 8, hipMemcpyDeviceToHost, e->stream));
+          if (own + 1 < R)
+            HIPCHK(hipMemcpyAsync(nd.h_ae + (size_t)(own + 1) * G, nd.o_ae + (size_t)(own + 1) * G, (size_t)(R - own - 1) * G * 8, hipMemcpyDeviceToHost,
+                                  e->stream));
+          HIPCHK(hipStreamSynchronize(e->stream));
+          nd.last.bytes_d2h += (size_t)G * (size_t)(own < R ? R - 1 : R) * 8;
+          out->bytes_d2h = nd.last.bytes_d2h;
+          nd.ae_rows_landed = true;
+        }
+        out->ae = nd.h_ae;
+      }
+    }
+  }
   if (nd.last_flags & JG_NODE_FOLLOWER_HALF) out->answer = nd.h_answer, out->hb_commit = nd.h_hbc;
   return JG_OK;
 }

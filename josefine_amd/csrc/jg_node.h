@@ -96,10 +96,23 @@ struct JgNodeRows {  // the step's command rows in device memory, unsorted (stre
   const uint64_t* blk_id;
   const uint64_t* blk_next;
   uint64_t n_blocks;
-  __device__ __forceinline__ uint32_t from_of(uint32_t i) const { return from ? from[i] : 0u; }
+  // JG_COL_PACKED_KIND: kind[i] = kind | sender slot << 4 | flag << 7 (no from / flag columns); ids = jg_config.node_ids
+  uint32_t packed;
+  uint32_t ids[JG_MAX_REPLICAS];
+  __device__ __forceinline__ uint32_t kind_of(uint32_t i) const { return packed ? kind[i] & 15u : kind[i]; }
+  __device__ __forceinline__ uint32_t from_of(uint32_t i) const {
+    if (!packed) return from ? from[i] : 0u;
+    const uint32_t b = kind[i];  // (VoteRequest ... HeartbeatResponse carry a sender: kinds 2-7)
+    if (!((0xfcu >> (b & 15u)) & 1u)) return 0u;
+    const uint32_t slot = (b >> 4) & 7u;
+    uint32_t id = 0;  // (a select per slot, not an indexed read of a kernel argument: that would go through scratch)
+#pragma unroll
+    for (uint32_t r = 0; r < JG_MAX_REPLICAS; r++) id = slot == r ? ids[r] : id;
+    return id;
+  }
   __device__ __forceinline__ uint64_t term_of(uint32_t i) const { return term ? term[i] : 0ull; }
   __device__ __forceinline__ uint64_t aux_of(uint32_t i) const { return aux ? aux[i] : 0ull; }
-  __device__ __forceinline__ uint32_t flag_of(uint32_t i) const { return flag ? flag[i] : 0u; }
+  __device__ __forceinline__ uint32_t flag_of(uint32_t i) const { return packed ? kind[i] >> 7 : (flag ? flag[i] : 0u); }
 };
 
 // `col_mask`: member slots whose answers arrived as a column (jg_node_inbox_columns: already copied into
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_classify(JgDev d, JgNodeCols 
                                                             uint32_t both_beats, uint32_t col_mask) {
   for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < a.n; i += gridDim.x * JG_BLOCK) {
     const uint32_t g = a.group[i];
-    const uint32_t kind = a.kind[i];
+    const uint32_t kind = a.kind_of(i);
     if (g >= d.G || kind >= JG_CMD__COUNT) {  // (rows committed with JG_COL_UNCHECKED are validated here: not applied, JG_EINVAL)
       *d.err = 7;
       continue;
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
   for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < n_up; i += gridDim.x * JG_BLOCK) {
     const bool in = i < a.n;
     const uint32_t g = in ? a.group[i] : 0u;
-    const bool valid = in && g < G && a.kind[i] < JG_CMD__COUNT;  // (an invalid row: reported by k_node_classify, not applied)
+    const bool valid = in && g < G && a.kind_of(i) < JG_CMD__COUNT;  // (an invalid row: reported by k_node_classify, not applied)
     const uint32_t w = valid ? c.cls[g] : 0u;
     const bool sparse = valid && jg_node_group_sparse(c, G, g, w, both_beats);
     const uint64_t m = __ballot(sparse);
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
       }
     }
     if (!valid || sparse) continue;
-    const uint32_t kind = a.kind[i];
+    const uint32_t kind = a.kind_of(i);
     switch (kind) {
       case JG_CMD_APPEND_RESPONSE: {  // bits 63..8 of the sender's answer word (all ones before)
         const int s = jg_node_slot_of(d, a.from_of(i));
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_gather_rows(uint32_t n, const
   if (p >= n) return;
   const uint32_t i = order[p];
   o.group[p] = a.group[i];
-  o.kind[p] = a.kind[i];
+  o.kind[p] = (uint8_t)a.kind_of(i);
   o.from[p] = a.from_of(i);
   o.term[p] = a.term_of(i);
   o.id[p] = a.id[i];
@@ -351,8 +364,10 @@ __device__ __forceinline__ void jg_node_fsm_row(jg_fsm_row& r, uint32_t g, uint3
   r.group = g, r.kind = (uint8_t)kind, r.pad[0] = r.pad[1] = r.pad[2] = 0;
   r.a = a, r.b = b;
 }
+// `fused` (JG_NODE_FSM_FUSED): a leader's rows of a step that appended, within 255 of the new block, are ONE
+// JG_FSM_LEADER_STEP row (josefine_gpu.h): the steady state pays 24 bytes per partition on the bus, not 48.
 __global__ __launch_bounds__(JG_BLOCK) void k_node_fsm_build(JgDev d, JgNodeCols c, jg_fsm_row* __restrict__ out,
-                                                             uint32_t* __restrict__ cnt, uint64_t* __restrict__ bsum) {
+                                                             uint32_t* __restrict__ cnt, uint64_t* __restrict__ bsum, uint32_t fused) {
   const uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x;  // one tile of JG_SCAN_TILE (= JG_BLOCK) groups per workgroup
   uint32_t n = 0;
   if (g < d.G) {
@@ -373,6 +388,11 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_fsm_build(JgDev d, JgNodeCols
       jg_fsm_row* r = out + (size_t)g * JGN_FSM_ROWS;
       if (fol) {
         if (commit1 != commit0) jg_node_fsm_row(r[n++], g, JG_FSM_APPLY_FOLLOWER, commit0, commit1);
+      } else if (fused && (w & JGN_FSM_APPENDED) && head >= commit1 && head - commit0 <= 255u && commit0 <= mid && mid <= commit1) {
+        jg_fsm_row& o = r[n++];
+        o.group = g, o.kind = (uint8_t)JG_FSM_LEADER_STEP;
+        o.pad[0] = (uint8_t)(head - commit0), o.pad[1] = (uint8_t)(head - mid), o.pad[2] = (uint8_t)(head - commit1);
+        o.a = head, o.b = c.token[g];
       } else {
         if (mid != commit0) jg_node_fsm_row(r[n++], g, JG_FSM_APPLY_LEADER, commit0, mid);
         if (w & JGN_FSM_APPENDED) jg_node_fsm_row(r[n++], g, JG_FSM_NOTIFY, head, c.token[g]);
@@ -384,4 +404,13 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_fsm_build(JgDev d, JgNodeCols
   uint32_t tot;
   (void)jg_block_exclusive_scan(n, &tot);
   if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// JG_NODE_COMMON_AE: how many partitions' AppendEntries words differ by addressee (their rows of `ae` are wanted on the host)
+__global__ __launch_bounds__(JG_BLOCK) void k_node_count_individual(const uint64_t* __restrict__ aec, uint32_t G, uint32_t* __restrict__ count) {
+  uint32_t n = 0;
+  for (uint32_t g = blockIdx.x * JG_BLOCK + threadIdx.x; g < G; g += gridDim.x * JG_BLOCK) n += aec[g] == JG_AEC_INDIVIDUAL;
+  uint32_t tot;
+  (void)jg_block_exclusive_scan(n, &tot);
+  if (threadIdx.x == 0 && tot) atomicAdd(count, tot);
 }

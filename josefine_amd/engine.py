@@ -128,6 +128,32 @@ class Command:
         return Command(capi.CMD_RECREATE)
 
 
+def expand_fsm_rows(rows: np.ndarray) -> np.ndarray:
+    """FSM rows (capi.FSM_DTYPE) with every FSM_LEADER_STEP row (jg_step_node with JG_NODE_FSM_FUSED) replaced by the rows
+    it stands for, in order: Apply {c0, c1} if c1 != c0, Notify {a, b}, Apply {c1, c2} if c2 != c1 (c_k = a - pad[k])."""
+    rows = np.asarray(rows)
+    fused = rows["kind"] == capi.FSM_LEADER_STEP
+    if not fused.any():
+        return rows
+    a = rows["a"].astype(np.uint64)
+    c = [a - rows["pad"][:, k].astype(np.uint64) for k in range(3)]
+    pre, post = fused & (c[1] != c[0]), fused & (c[2] != c[1])
+    count = np.where(fused, 1 + pre.astype(np.int64) + post.astype(np.int64), 1)
+    start = np.concatenate([[0], np.cumsum(count)[:-1]])
+    out = np.zeros(int(count.sum()), dtype=rows.dtype)
+    out[start[~fused]] = rows[~fused]
+    i = np.nonzero(fused)[0]
+    at = start[i]
+    p = pre[i]
+    out["group"][at[p]], out["kind"][at[p]], out["a"][at[p]], out["b"][at[p]] = rows["group"][i[p]], capi.FSM_APPLY_LEADER, c[0][i[p]], c[1][i[p]]
+    at = at + p
+    out["group"][at], out["kind"][at], out["a"][at], out["b"][at] = rows["group"][i], capi.FSM_NOTIFY, a[i], rows["b"][i]
+    at = at + 1
+    q = post[i]
+    out["group"][at[q]], out["kind"][at[q]], out["a"][at[q]], out["b"][at[q]] = rows["group"][i[q]], capi.FSM_APPLY_LEADER, c[1][i[q]], c[2][i[q]]
+    return out
+
+
 class BatchedRaft:
     """N independent Raft node instances behind one engine handle."""
 
@@ -283,15 +309,18 @@ class BatchedRaft:
         self._check(self.api.step_dense_acks(self._h, a.ctypes.data))
 
     def step_node(self, now_ms: int = 0, leader: bool = True, follower: bool = True, tick: bool = True, async_: bool = False,
-                  between=None) -> dict:
+                  between=None, common_ae: bool = False, fsm_fused: bool = False) -> dict:
         """jg_step_node: a node's whole tick from the rows submitted since the last step - rows in the
         mailbox vocabulary through the dense kernels, everything else through the general state
         machine first - then Command::Tick for every partition.  Returns the outbox columns (host
         copies): beat_term / beat_commit [G], ae [R, G] words, answer / hb_commit [G], and the step's
-        row / PCIe byte counts."""
+        row / PCIe byte counts.  common_ae (JG_NODE_COMMON_AE): "aec" [G] is the partition's AppendEntries word
+        for every addressee, "ae" only comes down (else None) when some partition's words differ (AEC_INDIVIDUAL);
+        fsm_fused (JG_NODE_FSM_FUSED): a leader's rows of a step as one FSM_LEADER_STEP row (`expand_fsm_rows`)."""
         self._flush_pending()
         flags = (capi.NODE_LEADER_HALF if leader else 0) | (capi.NODE_FOLLOWER_HALF if follower else 0) | \
-                (capi.NODE_TICK if tick else 0) | (capi.NODE_ASYNC if async_ else 0)
+                (capi.NODE_TICK if tick else 0) | (capi.NODE_ASYNC if async_ else 0) | \
+                (capi.NODE_COMMON_AE if common_ae else 0) | (capi.NODE_FSM_FUSED if fsm_fused else 0)
         self._check(self.api.step_node(self._h, int(now_ms), flags))
         if between is not None:  # (async_: what the caller does while the step runs - submits for the next one, say)
             between()
@@ -309,7 +338,7 @@ class BatchedRaft:
         beat = arr(o.beat, np.dtype([("term", "<u8"), ("hb_commit", "<u8")]), (G,))
         return {"beat_term": None if beat is None else beat["term"].copy(),
                 "beat_commit": None if beat is None else beat["hb_commit"].copy(),
-                "ae": arr(o.ae, np.uint64, (R, G)), "answer": arr(o.answer, np.uint64, (G,)),
+                "ae": arr(o.ae, np.uint64, (R, G)), "aec": arr(o.aec, np.uint64, (G,)), "answer": arr(o.answer, np.uint64, (G,)),
                 "hb_commit": arr(o.hb_commit, np.uint64, (G,)), "rows": int(o.rows), "rows_general": int(o.rows_general),
                 "bytes_h2d": int(o.bytes_h2d), "bytes_d2h": int(o.bytes_d2h)}
 

@@ -172,7 +172,7 @@ struct LoopResult {
 };
 
 static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::string& mode_arg, int device, uint64_t seed,
-                     uint32_t helpers, Rendezvous& rv, LoopResult& out) {
+                     uint32_t helpers, bool compact, Rendezvous& rv, LoopResult& out) {
   // "pipe" / "pipecolumns": the loop overlaps with itself (BatchedEventLoop::pipelined) and its rows are validated on the
   // device (JG_COL_UNCHECKED) - otherwise exactly "inplace" / "columns"; "pipetasks…": with the decoder / consumer tasks
   const bool pipe = mode_arg.rfind("pipe", 0) == 0;
@@ -187,6 +187,10 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
   const char* early_env = std::getenv("JG_BENCH_EARLY_UPLOAD");
   const bool early = early_env ? early_env[0] == '1' : with_tasks;
   const uint32_t unchecked = pipe ? (uint32_t)JG_COL_UNCHECKED | (early ? (uint32_t)JG_COL_UPLOAD_NOW : 0u) : 0u;
+  // compact (ABI v7's bus formats, pipelined modes): the transport's decoder writes kind | sender slot << 4 | flag << 7 into
+  // ONE byte (no from / flag columns: 13 bytes per row, not 18), the Tick's AppendEntries words come home as one word per
+  // partition (8 bytes, not 8 (R - 1)) and a leader's Apply + Notify of a tick as one fsm row (24 bytes, not 48)
+  const bool packed = compact && pipe && !cols_in;
   Tasks tasks(with_tasks ? helpers : 0u);  // (no helpers: run() is a plain loop on the calling thread)
   constexpr uint32_t SPLIT = 8;            // jobs per batch and connection: the helpers draw them as they come free
   auto sum_split = [&](const void* p, size_t items, size_t item_bytes) {
@@ -208,11 +212,12 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
     loop.halves = JG_NODE_LEADER_HALF;  // this node leads every partition
     loop.dense = mode != "general";
     loop.pipelined = pipe;
+    if (compact) loop.bus = JG_NODE_COMMON_AE | JG_NODE_FSM_FUSED;
     uint64_t sink = 0, fsm_rows = 0, msg_rows = 0, col_bytes = 0, up_bytes = 0, general = 0;
     raft.fsm_rows_tx = [&](const jg_fsm_row* r, size_t n) { sink += sum_split(r, n, sizeof(jg_fsm_row)), fsm_rows += n; };
     raft.msg_rows_tx = [&](const jg_msg_row* r, size_t n) { sink += sum_split(r, n, sizeof(jg_msg_row)), msg_rows += n; };
     raft.columns_tx = [&](const jg_node_outbox& o) {
-      if (o.beat) sink += sum_split(o.beat, G, 16) + sum_split(o.ae, (size_t)R * G, 8);
+      if (o.beat) sink += sum_split(o.beat, G, 16) + (o.aec ? sum_split(o.aec, G, 8) : 0) + (o.ae ? sum_split(o.ae, (size_t)R * G, 8) : 0);
       col_bytes += o.bytes_d2h, up_bytes += o.bytes_h2d, general += o.rows_general;
     };
     {  // this node wins every election the reference's way: Timeout, then granted votes until quorum
@@ -245,7 +250,8 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
       if (s == 0) {
         for (uint32_t k = k0; k < k1; k++) {
           const uint32_t g = perm[k];
-          kind[k] = JG_CMD_CLIENT_REQUEST, group[k] = g, from[k] = 0, id[k] = (uint64_t)t * G + g, flag[k] = 0;
+          kind[k] = JG_CMD_CLIENT_REQUEST, group[k] = g, id[k] = (uint64_t)t * G + g;
+          if (!packed) from[k] = 0, flag[k] = 0;
         }
         return;
       }
@@ -255,6 +261,12 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
       for (uint32_t k = k0; k < k1; k++) {
         const uint32_t g = perm[at];
         at = at + 1 == G ? 0 : at + 1;
+        if (packed) {  // (sender slot s and flag 1 in the kind byte)
+          const uint8_t hi = (uint8_t)(s << 4 | 0x80u);
+          if (hb) kind[i] = JG_CMD_HEARTBEAT_RESPONSE | hi, group[i] = g, id[i] = t ? t - 1 : 0, i++;
+          kind[i] = JG_CMD_APPEND_RESPONSE | hi, group[i] = g, id[i] = t, i++;
+          continue;
+        }
         if (hb) kind[i] = JG_CMD_HEARTBEAT_RESPONSE, group[i] = g, from[i] = ids[s], id[i] = t ? t - 1 : 0, flag[i] = 1, i++;
         kind[i] = JG_CMD_APPEND_RESPONSE, group[i] = g, from[i] = ids[s], id[i] = t, flag[i] = 1, i++;
       }
@@ -300,8 +312,15 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
         p += 4 + (size_t)n;
         const Message m = formats::decode_message(payload);
         const Command& c = m.command;
-        kind[i] = c.kind, group[i] = perm[at], id[i] = c.id, flag[i] = c.flag ? 1 : 0;
-        from[i] = c.kind == JG_CMD_HEARTBEAT_RESPONSE ? m.from.peer : c.from;  // (rpc.rs:17-27: the Message names the sender)
+        const NodeId sender = c.kind == JG_CMD_HEARTBEAT_RESPONSE ? m.from.peer : c.from;  // (rpc.rs:17-27: the Message names the sender)
+        group[i] = perm[at], id[i] = c.id;
+        if (packed) {
+          uint32_t slot = 7;  // (nobody: reads NodeId 0)
+          for (uint32_t q = 0; q < R; q++) slot = ids[q] == sender ? q : slot;
+          kind[i] = (uint8_t)(c.kind | slot << 4 | (c.flag ? 0x80u : 0u));
+        } else {
+          kind[i] = c.kind, flag[i] = c.flag ? 1 : 0, from[i] = sender;
+        }
         i++;
         if (++seen == per) seen = 0, at = at + 1 == G ? 0 : at + 1;
       }
@@ -357,7 +376,7 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
         const jg_cmd_cols c = loop.tcp_rx_reserve(n);
         const size_t k = fill(t, c.kind, c.group, c.from, c.id, c.flag);
         t_fill += ms_since(a), a = Clock::now();
-        loop.tcp_rx_commit(k, 0, JG_COL_FROM | JG_COL_FLAG | unchecked);
+        loop.tcp_rx_commit(k, 0, (packed ? (uint32_t)JG_COL_PACKED_KIND : (uint32_t)(JG_COL_FROM | JG_COL_FLAG)) | unchecked);
         t_submit += ms_since(a), a = Clock::now();
         loop.run_until(now);
         t_step += ms_since(a);
@@ -438,6 +457,7 @@ int main(int argc, char** argv) {
   const int device = argc > 6 ? std::atoi(argv[6]) : 0;
   const uint32_t L = argc > 7 ? (uint32_t)std::max(1, std::atoi(argv[7])) : 1;
   const uint32_t helpers = argc > 8 ? (uint32_t)std::max(0, std::atoi(argv[8])) : R - 1;
+  const bool compact = argc > 9 && std::string(argv[9]) == "compact";  // ABI v7's bus formats (pipelined modes)
   if (G % L) {
     std::fprintf(stderr, "the partitions do not divide over %u loops\n", L);
     return 2;
@@ -445,8 +465,8 @@ int main(int argc, char** argv) {
   Rendezvous rv(L);
   std::vector<LoopResult> res(L);
   std::vector<std::thread> th;
-  for (uint32_t l = 1; l < L; l++) th.emplace_back([&, l] { run_loop(G / L, R, T, W, mode, device, 42 + l, helpers, rv, res[l]); });
-  run_loop(G / L, R, T, W, mode, device, 42, helpers, rv, res[0]);
+  for (uint32_t l = 1; l < L; l++) th.emplace_back([&, l] { run_loop(G / L, R, T, W, mode, device, 42 + l, helpers, compact, rv, res[l]); });
+  run_loop(G / L, R, T, W, mode, device, 42, helpers, compact, rv, res[0]);
   for (std::thread& t : th) t.join();
   LoopResult a;
   a.ok = true;
@@ -460,12 +480,12 @@ int main(int argc, char** argv) {
     a.t_fill += r.t_fill / L, a.t_submit += r.t_submit / L, a.t_step += r.t_step / L;  // (per loop: they run side by side)
     k_us += r.k_us / L, a.k_n += r.k_n;
   }
-  std::printf("{\"ok\": %s, \"mode\": \"%s\", \"G\": %u, \"R\": %u, \"loops\": %u, \"task_threads_beside_each_loop\": %u, \"ticks\": %u, \"warmup\": %u, \"decisions\": %llu, \"wall_ms\": %.3f, "
+  std::printf("{\"ok\": %s, \"mode\": \"%s\", \"bus\": \"%s\", \"G\": %u, \"R\": %u, \"loops\": %u, \"task_threads_beside_each_loop\": %u, \"ticks\": %u, \"warmup\": %u, \"decisions\": %llu, \"wall_ms\": %.3f, "
               "\"decisions_per_s\": %.6g, \"ms_per_tick\": %.4f, \"ms_fill\": %.4f, \"ms_submit\": %.4f, \"ms_step_and_drain\": %.4f, "
               "\"rows_in_per_tick\": %.1f, \"rows_general\": %llu, \"fsm_rows_per_tick\": %.1f, \"msg_rows_per_tick\": %.1f, "
               "\"pcie_h2d_bytes_per_tick\": %.1f, \"pcie_d2h_bytes_per_tick\": %.1f, \"leader_kernel_us\": %.3f, \"leader_kernel_launches\": %u, "
               "\"wire_bytes_decoded_per_tick\": %.1f, \"sink\": %llu}\n",
-              a.ok ? "true" : "false", mode.c_str(), G, R, L, mode.rfind("pipetasks", 0) == 0 ? helpers : 0u, T, W, (unsigned long long)a.decisions, a.wall_ms, a.decisions / (a.wall_ms / 1e3),
+              a.ok ? "true" : "false", mode.c_str(), compact ? "compact (packed kind byte, common AppendEntries word, fused fsm row)" : "plain", G, R, L, mode.rfind("pipetasks", 0) == 0 ? helpers : 0u, T, W, (unsigned long long)a.decisions, a.wall_ms, a.decisions / (a.wall_ms / 1e3),
               a.wall_ms / T, a.t_fill / T, a.t_submit / T, a.t_step / T, (double)a.rows_in / T, (unsigned long long)a.general,
               (double)a.fsm_rows / T, (double)a.msg_rows / T, (double)a.up_bytes / T, (double)a.down_bytes / T, k_us, a.k_n,
               (double)a.wire_bytes / T, (unsigned long long)a.sink);

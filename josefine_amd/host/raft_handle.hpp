@@ -329,8 +329,13 @@ class BatchedRaft {
           r.kind = JG_CMD_HEARTBEAT, r.to_kind = JG_TO_PEERS, r.to_id = 0, r.id = o.beat[g].hb_commit, r.aux = 0;
           emit(r, r.id);
         }
+        // (JG_NODE_COMMON_AE: one word for every addressee unless the partition's words differ)
+        const bool common = o.aec && o.aec[g] != JG_AEC_INDIVIDUAL;
+        if (common && o.aec[g] == JG_NO_ACK) continue;
+        if (common) from();
         for (uint32_t q = 0; q < R; q++) {  // AppendEntries per follower, ascending slot (leader.rs:124-174)
-          const uint64_t w = o.ae[(size_t)q * G + g];
+          if (common && ids_[q] == r.from) continue;
+          const uint64_t w = common ? o.aec[g] : o.ae[(size_t)q * G + g];
           if (w == JG_NO_ACK) continue;
           from();
           r.kind = JG_CMD_APPEND_ENTRIES, r.to_kind = JG_TO_PEER, r.to_id = ids_[q], r.id = w >> 8, r.aux = w & 0xffu;
@@ -372,7 +377,7 @@ class BatchedRaft {
       if (n) fsm_rows_tx(fr.data(), n);
       fr.clear();
     }
-    for (const jg_fsm_row& r : fr) {
+    auto deliver = [&](const jg_fsm_row& r) {
       BlockStore& st = stores_[r.group];
       if (r.kind == JG_FSM_NOTIFY) {
         // leader append (leader.rs:177-188): the block now exists with the request's payload
@@ -407,6 +412,19 @@ class BatchedRaft {
           }
         }
       }
+    };
+    for (const jg_fsm_row& r : fr) {
+      if (r.kind != JG_FSM_LEADER_STEP) {
+        deliver(r);
+        continue;
+      }
+      // JG_NODE_FSM_FUSED: a leader's step as one row - Apply {c0, c1}, Notify {a, b}, Apply {c1, c2} (josefine_gpu.h)
+      const uint64_t c0 = r.a - r.pad[0], c1 = r.a - r.pad[1], c2 = r.a - r.pad[2];
+      jg_fsm_row x{};
+      x.group = r.group;
+      if (c1 != c0) x.kind = JG_FSM_APPLY_LEADER, x.a = c0, x.b = c1, deliver(x);
+      x.kind = JG_FSM_NOTIFY, x.a = r.a, x.b = r.b, deliver(x);
+      if (c2 != c1) x.kind = JG_FSM_APPLY_LEADER, x.a = c1, x.b = c2, deliver(x);
     }
     check(jg_drain_messages(e_, nullptr, 0, &n));
     std::vector<jg_msg_row> mr(n);
@@ -605,6 +623,10 @@ class BatchedEventLoop {
   // reference are asynchronous too (mod.rs:337-340) -, so that the transport decodes tick t + 1 into the engine's
   // pinned columns while the device runs tick t's kernels and sends its outputs home.
   bool pipelined = false;
+  // the node step's compact bus formats (ABI v7): JG_NODE_COMMON_AE - the Tick's AppendEntries words come home as one
+  // word per partition where the followers' agree - and / or JG_NODE_FSM_FUSED - a leader's fsm_tx rows of a step as one
+  // row; both are expanded again by BatchedRaft before rpc_tx / fsm_tx see them (a column / row sink sees the compact form)
+  uint32_t bus = 0;
 
   explicit BatchedEventLoop(BatchedRaft& raft, uint32_t n_groups) : raft_(raft), G_(n_groups), answers_to_(n_groups, 0) {
     raft_.rpc_tx = [this](const Message& m) { on_message(m); };
@@ -691,7 +713,7 @@ class BatchedEventLoop {
       if (!in_.empty()) raft_.submit_rows(in_.view());
       in_.clear();
       last_at_ = at;
-      raft_.step_node_begin(at, halves | (tick ? (uint32_t)JG_NODE_TICK : 0u), pipelined);
+      raft_.step_node_begin(at, halves | bus | (tick ? (uint32_t)JG_NODE_TICK : 0u), pipelined);
       if (pipelined) return;
       raft_.step_node_finish(&answers_to_);
     } else {

@@ -32,6 +32,8 @@ struct jo_engine {
   unsigned threads = 1;
   // jo_step_node: the step's outbox columns (host vectors) and what jo_node_outbox_view reports
   std::vector<uint64_t> n_o_ae, n_o_answer, n_o_hbc;
+  std::vector<uint64_t> n_o_aec;  // JG_NODE_COMMON_AE: the partition's AppendEntries word where every addressee's is the same
+  bool n_ae_individual = false;
   std::vector<jg_leader_beat> n_o_beat;
   std::vector<jg_fsm_row> n_fsm;  // fsm rows of the dense halves of the step in progress
   std::vector<uint64_t> n_in_answers, n_in_hbc;  // jo_node_inbox_columns: [R][G] columns handed out for the next step
@@ -674,7 +676,7 @@ int jo_synth_fill_acks(jo_engine* e, uint32_t mode, uint64_t tick, uint64_t* sim
 // the engine reports (which partitions count as rows_general, which messages leave as mailbox columns and
 // which as rows); every partition's rows are applied one command at a time in stream order either way.
 int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
-  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~15u)) return fail(JG_EINVAL, "jg_step_node: bad flags");  // (JG_NODE_ASYNC: a matter of when the engine looks at its own counts)
+  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~63u)) return fail(JG_EINVAL, "jg_step_node: bad flags");  // (JG_NODE_ASYNC: a matter of when the engine looks at its own counts)
   e->stepped = true;
   const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
   const bool lead_half = flags & JG_NODE_LEADER_HALF, fol_half = flags & JG_NODE_FOLLOWER_HALF, tick = flags & JG_NODE_TICK;
@@ -851,8 +853,59 @@ int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
   }
   // the dense halves' fsm rows of one step: partitions ascending (at most one half emits for a partition)
   std::stable_sort(e->n_fsm.begin(), e->n_fsm.end(), [](const jg_fsm_row& a, const jg_fsm_row& b) { return a.group < b.group; });
+  if (flags & JG_NODE_FSM_FUSED) {
+    // a leader partition's rows of the step - [Apply {c0, c1}] Notify {a, b} [Apply {c1, c2}] - as ONE JG_FSM_LEADER_STEP row
+    // where the commit index is within 255 of the appended block (josefine_gpu.h)
+    std::vector<jg_fsm_row> fused;
+    for (size_t i = 0; i < e->n_fsm.size();) {
+      size_t j = i;
+      while (j < e->n_fsm.size() && e->n_fsm[j].group == e->n_fsm[i].group) j++;
+      const jg_fsm_row* r = &e->n_fsm[i];
+      const size_t n = j - i;
+      size_t at = 0;
+      const jg_fsm_row* before = (n > at && r[at].kind == JG_FSM_APPLY_LEADER) ? &r[at++] : nullptr;
+      const jg_fsm_row* notify = (n > at && r[at].kind == JG_FSM_NOTIFY) ? &r[at++] : nullptr;
+      const jg_fsm_row* after = (n > at && r[at].kind == JG_FSM_APPLY_LEADER) ? &r[at++] : nullptr;
+      bool done = false;
+      if (notify && at == n) {
+        const uint64_t commit = e->groups[r[0].group].chain.commit;
+        const uint64_t c0 = before ? before->a : (after ? after->a : commit);
+        const uint64_t c1 = before ? before->b : c0;
+        const uint64_t c2 = after ? after->b : c1;
+        const uint64_t a = notify->a;
+        if (a >= c2 && a - c0 <= 255u && c0 <= c1 && c1 <= c2 && (!after || after->a == c1)) {
+          jg_fsm_row x;
+          std::memset(&x, 0, sizeof x);
+          x.group = r[0].group, x.kind = JG_FSM_LEADER_STEP, x.a = a, x.b = notify->b;
+          x.pad[0] = (uint8_t)(a - c0), x.pad[1] = (uint8_t)(a - c1), x.pad[2] = (uint8_t)(a - c2);
+          fused.push_back(x);
+          done = true;
+        }
+      }
+      if (!done) fused.insert(fused.end(), r, r + n);
+      i = j;
+    }
+    e->n_fsm.swap(fused);
+  }
   e->fsms.insert(e->fsms.end(), e->n_fsm.begin(), e->n_fsm.end());
   e->n_fsm.clear();
+  e->n_ae_individual = false;
+  if ((flags & JG_NODE_COMMON_AE) && lead_half && tick) {
+    e->n_o_aec.assign(G, JG_NO_ACK);
+    for (uint32_t g = 0; g < G; g++) {
+      const uint32_t s = e->self_slot[g];
+      uint64_t first = JG_NO_ACK;
+      bool have = false, same = true;
+      for (uint32_t q = 0; q < R; q++) {
+        if (q == s) continue;
+        const uint64_t w = e->n_o_ae[(size_t)q * G + g];
+        if (!have) first = w, have = true;
+        same = same && w == first;
+      }
+      e->n_o_aec[g] = same ? first : JG_AEC_INDIVIDUAL;
+      e->n_ae_individual = e->n_ae_individual || !same;
+    }
+  }
   e->n_last = jg_node_outbox{};
   e->n_last.rows = n_rows, e->n_last.rows_general = n_general;
   e->n_last_flags = flags;
@@ -880,7 +933,13 @@ int jo_node_inbox_columns(jo_engine* e, uint32_t slot, uint64_t** answer, uint64
 int jo_node_outbox_view(jo_engine* e, jg_node_outbox* out) {
   if (!e->n_last_flags) return fail(JG_EINVAL, "no jg_step_node yet");
   *out = e->n_last;
-  if ((e->n_last_flags & JG_NODE_LEADER_HALF) && (e->n_last_flags & JG_NODE_TICK)) out->beat = e->n_o_beat.data(), out->ae = e->n_o_ae.data();
+  if ((e->n_last_flags & JG_NODE_LEADER_HALF) && (e->n_last_flags & JG_NODE_TICK)) {
+    out->beat = e->n_o_beat.data(), out->ae = e->n_o_ae.data();
+    if (e->n_last_flags & JG_NODE_COMMON_AE) {
+      out->aec = e->n_o_aec.data();
+      if (!e->n_ae_individual) out->ae = nullptr;
+    }
+  }
   if (e->n_last_flags & JG_NODE_FOLLOWER_HALF) out->answer = e->n_o_answer.data(), out->hb_commit = e->n_o_hbc.data();
   return JG_OK;
 }

@@ -77,6 +77,9 @@ int main(int argc, char** argv) {
       loops.emplace_back(new BatchedEventLoop(*rafts[n], G));
       // JG_CLUSTER_PIPELINED=1: every loop overlaps with itself (a step's outputs are delivered at the start of the next)
       loops[n]->pipelined = std::getenv("JG_CLUSTER_PIPELINED") != nullptr;
+      // JG_CLUSTER_COMPACT=1: ABI v7's bus formats - the Tick's AppendEntries words as one word per partition where the
+      // followers' agree, a leader's fsm_tx rows of a step as one row (the sinks below see the compact forms)
+      if (std::getenv("JG_CLUSTER_COMPACT")) loops[n]->bus = JG_NODE_COMMON_AE | JG_NODE_FSM_FUSED;
     }
     for (uint32_t n = 0; n < R; n++) {
       BatchedRaft& raft = *rafts[n];
@@ -104,12 +107,21 @@ int main(int argc, char** argv) {
         if (std::getenv("JG_DEBUG_CLUSTER") && o.rows_general) std::fprintf(stderr, "node %u: %llu of %llu rows general\n", n, (unsigned long long)o.rows_general, (unsigned long long)o.rows);
         if (o.beat) {
           hash[n].bytes(o.beat, (size_t)G * sizeof(jg_leader_beat));
-          hash[n].bytes(o.ae, (size_t)R * G * 8);
+          // (compact: what the words STAND FOR is hashed - an engine may say JG_AEC_INDIVIDUAL where the words happen to agree)
+          auto ae_word = [&](uint32_t q, uint32_t g) {
+            return (o.aec && o.aec[g] != JG_AEC_INDIVIDUAL) ? (q == n ? (uint64_t)JG_NO_ACK : o.aec[g]) : o.ae[(size_t)q * G + g];
+          };
+          if (o.aec) {
+            for (uint32_t q = 0; q < R; q++)
+              for (uint32_t g = 0; g < G; g++) hash[n].u64(ae_word(q, g));
+          } else {
+            hash[n].bytes(o.ae, (size_t)R * G * 8);
+          }
           for (uint32_t g = 0; g < G; g++) {
             const bool hb = o.beat[g].hb_commit != JG_NO_ACK;
             for (uint32_t q = 0; q < R; q++) {
               if (q == n) continue;
-              const uint64_t w = o.ae[(size_t)q * G + g];
+              const uint64_t w = ae_word(q, g);
               if (hb) wire[q].push(g, JG_CMD_HEARTBEAT, ids[n], o.beat[g].term, o.beat[g].hb_commit), n_cols[n]++;
               if (w != JG_NO_ACK) wire[q].push_append_run(g, ids[n], o.beat[g].term, w >> 8, (uint32_t)(w & 0xffu)), n_cols[n]++;
               if (hb || w != JG_NO_ACK) answers_to[q][g] = ids[n];

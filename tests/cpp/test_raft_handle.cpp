@@ -246,7 +246,9 @@ static void server_event_loop_single_node() {
 // partitions, their event loops wired tcp_tx -> tcp_rx; timers are the only source of elections.
 // A proposal through whoever leads a partition comes back to the client once it is committed and
 // applied, and every node's state machine sees the same payload.
-static void server_event_loops_three_nodes() {
+// `bus`: the node step's compact formats (JG_NODE_COMMON_AE | JG_NODE_FSM_FUSED) - BatchedRaft expands them again before
+// rpc_tx / fsm_tx see anything: the same messages, the same transitions.
+static void server_event_loops_three_nodes(uint32_t bus = 0) {
   const uint32_t G = 8, N = 3;
   std::vector<std::unique_ptr<BatchedRaft>> rafts;
   std::vector<std::unique_ptr<BatchedEventLoop>> loops;
@@ -256,6 +258,7 @@ static void server_event_loops_three_nodes() {
     std::vector<uint8_t> slots(G, (uint8_t)n);
     CHECK(jg_set_self_slots(rafts[n]->raw(), slots.data()) == JG_OK);
     loops.emplace_back(new BatchedEventLoop(*rafts[n], G));
+    loops[n]->bus = bus;
     loops[n]->fsm = [&applied, n](uint32_t g, const std::vector<uint8_t>& data) {
       applied[n][g].insert(applied[n][g].end(), data.begin(), data.end());
       return data;
@@ -625,6 +628,7 @@ int main() {
 #endif
     server_event_loop_single_node();
     server_event_loops_three_nodes();
+    server_event_loops_three_nodes(JG_NODE_COMMON_AE | JG_NODE_FSM_FUSED);
     chain_store_restart();
     event_loops_over_the_wire();
     pipelined_loop_is_the_plain_loop_later();

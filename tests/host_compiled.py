@@ -456,7 +456,7 @@ extern "C" int hc_step_node(Host* h, uint32_t n, const uint8_t* kind, const uint
   std::vector<uint64_t> bsum(G + 1, 0);
   for (uint32_t g = 0; g < G; g++) {
     blockIdx.x = g;
-    k_node_fsm_build(d, c, fr.data(), cnt.data(), bsum.data());
+    k_node_fsm_build(d, c, fr.data(), cnt.data(), bsum.data(), 0u);
     for (uint32_t k = 0; k < cnt[g]; k++) h->fsm.push_back(fr[(size_t)g * JGN_FSM_ROWS + k]);
   }
   blockIdx.x = 0;

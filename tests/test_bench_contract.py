@@ -222,6 +222,10 @@ def test_event_loop_line():
     wd = tk["wire_decode"]  # the peers' traffic as length-delimited serde_json frames through host/formats.hpp's decoder
     assert wd["decisions_per_s"] > 0 and wd["rows_on_the_general_path"] == 0 and wd["frames_per_tick"] >= 20000 * 4 and wd["wire_bytes_decoded_per_tick"] > 100 * 20000 * 4
     assert tk["host_wait"]["interrupt_decisions_per_s"] > 0 and tk["host_wait"]["polled_decisions_per_s"] > 0
+    cb = tk["compact_bus"]  # ABI v7's formats: packed kind byte, common AppendEntries word, fused fsm row - the same stream, fewer bytes
+    assert cb["decisions_per_s"] > 0 and cb["rows_on_the_general_path"] == 0 and cb["fsm_rows_per_tick"] == 20000 == cb["fsm_rows_per_tick_plain"] / 2
+    assert cb["pcie_bytes_per_decision"] <= 32 < cb["pcie_bytes_per_decision_plain"], cb
+    assert cb["column_inbound_pcie_bytes_per_decision"] < cb["pcie_bytes_per_decision"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["avg_launch_us"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] == "port"

@@ -100,6 +100,15 @@ def test_event_loop_cluster_host_logic_on_oracle():
     # partitions stay leaderless (and fault-free) for good.  Restated here so that nobody "fixes" it on the device.
     line = run_cluster(exe, 500, 3, 150, "failover")
     assert "restarted_leaders=500" in line and "leaders=0 " in line and "faults=0" in line and "led_by_another_node_now=0" in line, line
+    # ABI v7's bus formats (JG_NODE_COMMON_AE + JG_NODE_FSM_FUSED): the same protocol - every message, decision, leader -
+    # with fewer fsm rows on the channel (a leader's Apply + Notify of a tick is one row)
+    def fields(line):
+        return dict(kv.split("=") for kv in line.split() if "=" in kv)
+    for args in ((2000, 5, 50, "scripted"), (500, 3, 80, "elect")):
+        plain, compact = fields(run_cluster(exe, *args)), fields(run_cluster(exe, *args, env={"JG_CLUSTER_COMPACT": "1"}))
+        for k in ("leaders", "faults", "proposals", "msg_rows", "column_messages", "rows_in", "rows_general", "decisions", "max_head", "leaders_by_node"):
+            assert plain[k] == compact[k], (args, k, plain[k], compact[k])
+        assert int(compact["fsm_rows"]) < int(plain["fsm_rows"])
     build_cluster_test(oracle=False)  # (links against the C ABI: compile check without a GPU)
 
 
@@ -141,6 +150,20 @@ def test_pipelined_event_loops_equal_the_oracle_backed_ones(args):
     row and outbox word equal to the pipelined loops over the oracle library; and the run still does what the synchronous
     one does (leaders elected, every partition committing)."""
     env = {"JG_CLUSTER_PIPELINED": "1"}
+    dev = run_cluster(build_cluster_test(oracle=False), *args, env=env)
+    ora = run_cluster(build_cluster_test(oracle=True), *args, env=env)
+    assert dev == ora, (dev, ora)
+    assert f"leaders={args[0]}" in dev and "faults=0" in dev
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,pipelined", [((50_000, 5, 40, "scripted"), False), ((3000, 3, 80, "elect"), False), ((3000, 3, 80, "elect"), True)])
+def test_compact_bus_event_loops_equal_the_oracle_backed_ones(args, pipelined):
+    """ABI v7's bus formats through the loops (BatchedEventLoop::bus = JG_NODE_COMMON_AE | JG_NODE_FSM_FUSED): the Tick's
+    AppendEntries words as one word per partition where the followers' agree, a leader's fsm_tx rows of a step as one row -
+    every fsm row as it is, every outbox word it stands for and every rpc_tx row equal to the same loops over the oracle
+    library, which restates the formats itself (oracle/oracle_engine.cpp)."""
+    env = {"JG_CLUSTER_COMPACT": "1", **({"JG_CLUSTER_PIPELINED": "1"} if pipelined else {})}
     dev = run_cluster(build_cluster_test(oracle=False), *args, env=env)
     ora = run_cluster(build_cluster_test(oracle=True), *args, env=env)
     assert dev == ora, (dev, ora)

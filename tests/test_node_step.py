@@ -653,3 +653,111 @@ def test_node_step_early_upload_parity(R, flags, G):
         compare_snapshots(dev, ora, f"tick {t}")
         compare_drains(dev, ora, f"tick {t}")
     assert dev.counters()["decisions"] == ora.counters()["decisions"]
+
+
+def _pack_kind(cols, ids, R):
+    """JG_COL_PACKED_KIND: kind | sender slot << 4 | flag << 7 - and what the rows then SAY: a stranger (no slot: 7, R < 8)
+    reads NodeId 0, a kind without a sender reads 0 whatever the bits"""
+    kind, frm = cols["kind"], cols["from_"]
+    slot = np.full(len(kind), 7, np.uint8)
+    for r, i in enumerate(ids):
+        slot[frm == i] = r
+    carries = (kind >= capi.CMD_VOTE_REQUEST) & (kind <= capi.CMD_HEARTBEAT_RESPONSE)
+    table = np.array(list(ids) + [0] * (8 - R), np.uint32)
+    said = np.where(carries, table[slot], 0).astype(np.uint32)
+    packed = (kind | (slot << 4) | ((cols["flag"] != 0).astype(np.uint8) << 7)).astype(np.uint8)
+    return packed, said
+
+
+def _expand_common_ae(a, own, R):
+    """the node outbox of JG_NODE_COMMON_AE as the [R][G] block it stands for"""
+    aec = a["aec"]
+    ind = aec == np.uint64(capi.AEC_INDIVIDUAL)
+    assert (a["ae"] is None) == (not ind.any())
+    ae = np.repeat(aec[None, :], R, axis=0)
+    ae[own] = np.uint64(NO_ACK)
+    if ind.any():
+        ae[:, ind] = a["ae"][:, ind]
+    return dict(a, ae=ae)
+
+
+NO_ACK = capi.NO_ACK
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,flags,G,async_", [(3, 0, 2500, True), (5, capi.CFG_SEPARATE_COMMIT_KEY, 2000, True), (5, 0, 600, False)])
+def test_node_step_compact_bus_parity(R, flags, G, async_):
+    """The node step's three bus formats of ABI v7 together: rows committed with JG_COL_PACKED_KIND (sender slot and flag in
+    the kind byte: no from / flag columns), the Tick's AppendEntries words as one word per partition (JG_NODE_COMMON_AE: the
+    rows come down only in the ticks where some partition's words differ), a leader's fsm_tx rows of a step as one
+    JG_FSM_LEADER_STEP row (JG_NODE_FSM_FUSED).  What they stand for - every outbox word, state column and drained row -
+    equals the oracle's step over the plain rows, tick after tick, on the mixed traffic of the other node-step tests."""
+    from josefine_amd import expand_fsm_rows
+    T = 40
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=123 + R, flags=flags, election_timeout_ms=(700, 1500))
+    _, ora2, _ = mixed_pair(oracle_engine, oracle_engine, G, R, seed=123 + R, flags=flags, election_timeout_ms=(700, 1500))  # the oracle, asked for the formats itself
+    ids = list(ora.node_ids)
+    own = int(ora.read("self_slot")[0])
+    seen = dict(individual=0, common_only=0, fused=0, plain_leader=0)
+
+    def commit(cols, packed):
+        import ctypes as C
+        n, nb = len(cols["kind"]), len(cols["blk_id"])
+        c = capi.CmdCols()
+        dev._check(dev.api.submit_reserve(dev._h, n, nb, C.byref(c)))
+
+        def view(ptr, dt, m):
+            return np.frombuffer((C.c_char * (max(m, 1) * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt)[:m]
+        view(c.kind, np.uint8, n)[:] = packed
+        view(c.group, np.uint32, n)[:] = cols["group"]
+        view(c.term, np.uint64, n)[:] = cols["term"]
+        view(c.id, np.uint64, n)[:] = cols["id"]
+        view(c.aux, np.uint64, n)[:] = cols["aux"]
+        if nb:
+            view(c.blk_id, np.uint64, nb)[:] = cols["blk_id"]
+            view(c.blk_next, np.uint64, nb)[:] = cols["blk_next"]
+        dev._check(dev.api.submit_commit(dev._h, n, nb, capi.COL_TERM | capi.COL_AUX | capi.COL_UNCHECKED | capi.COL_PACKED_KIND |
+                                         (capi.COL_UPLOAD_NOW if async_ else 0)))
+
+    def traffic(t):
+        cols = node_traffic(rng, ora, token0=1000 * t, p_noise=0.03 if t % 3 else 0.0, p_reorder=0.08 if t % 3 else 0.0)
+        packed, said = _pack_kind(cols, ids, R)
+        return dict(cols, from_=said, flag=(cols["flag"] != 0).astype(np.uint8)), packed
+    nxt, nxt_packed = traffic(0)
+    commit(nxt, nxt_packed)
+    for t in range(T):
+        now = 100 * (t + 1)
+        ora.submit_columns(**nxt)
+        ora2.submit_columns(**nxt)
+        b = ora.step_node(now)
+        b2 = ora2.step_node(now, common_ae=True, fsm_fused=True)
+        nxt, nxt_packed = traffic(t + 1)
+        a = dev.step_node(now, async_=async_, common_ae=True, fsm_fused=True, between=lambda: commit(nxt, nxt_packed))
+        assert a["aec"] is not None
+        seen["individual" if a["ae"] is not None else "common_only"] += 1
+        # (the device says INDIVIDUAL also where a partition's rows took the general path: its words are in the rows then)
+        common = a["aec"] != np.uint64(capi.AEC_INDIVIDUAL)
+        assert np.array_equal(a["aec"][common], b2["aec"][common]), t
+        a = _expand_common_ae(a, own, R)
+        compare_outboxes(a, b, f"tick {t}")
+        compare_outboxes(_expand_common_ae(b2, own, R), b, f"tick {t} (oracle's own formats)")
+        compare_snapshots(dev, ora, f"tick {t}")
+        for fn in ("drain_messages", "drain_faults"):
+            x, y = getattr(dev, fn)(), getattr(ora, fn)()
+            assert x.shape == y.shape and x.tobytes() == y.tobytes(), (t, fn)
+        x, y, y2 = dev.drain_applies(), ora.drain_applies(), ora2.drain_applies()
+        ora2.drain_messages(), ora2.drain_faults()
+        seen["fused"] += int((x["kind"] == capi.FSM_LEADER_STEP).sum())
+        seen["plain_leader"] += int((x["kind"] == capi.FSM_NOTIFY).sum())
+        assert x.shape == y2.shape and x.tobytes() == y2.tobytes(), (t, "drain_applies: the fused rows themselves")
+        x = expand_fsm_rows(x)
+        assert x.shape == y.shape and x.tobytes() == y.tobytes(), (t, "drain_applies")
+    # both forms of every format were exercised
+    assert seen["individual"] and seen["fused"] > 10 * T, seen
+    import os
+    if os.environ.get("JG_EMULATED_DEVICE") != "1":  # (the stand-in's wave reductions behind divergent code: tests/host_device.py)
+        assert dev.counters()["decisions"] == ora.counters()["decisions"]
+    # the formats' rules: a step's commits agree on the kind column's format; jg_submit cannot follow a packed commit
+    from josefine_amd import EngineError
+    with pytest.raises(EngineError, match="JG_COL_PACKED_KIND"):  # (the last tick's `between` left a packed batch pending)
+        dev.submit_columns(np.full(1, capi.CMD_TICK, np.uint8), np.zeros(1, np.uint32))
