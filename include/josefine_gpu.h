@@ -37,7 +37,7 @@ extern "C" {
 
 #define JG_ABI_VERSION 7u /* v5: jg_step_node = arrival-order Apply (fsm_tx: Apply / Notify / Apply per partition), JG_CLUSTER_ANY_LEADER,
                              jg_dense_cluster_withdraw_appends, JG_COL_UNCHECKED, JG_COL_UPLOAD_NOW; v6: jg_dense_cluster_set_option, jg_dense_cluster_offer_appends, JG_CMD_RECREATE;
-                             v7: the node step's bus formats - JG_COL_PACKED_KIND, JG_NODE_COMMON_AE (jg_node_outbox.aec), JG_NODE_FSM_FUSED (JG_FSM_LEADER_STEP) */
+                             v7: the node step's bus formats - JG_COL_PACKED_KIND, JG_COL_ID32, JG_NODE_COMMON_AE (jg_node_outbox.aec), JG_NODE_FSM_FUSED (JG_FSM_LEADER_STEP) */
 #define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
 #define JG_CHAIN_WINDOW 8u  /* chain segments (gaps / forks) per group besides the main run */
 #define JG_MAX_INFLIGHT 5u  /* src/raft/progress.rs:117                                    */
@@ -337,7 +337,12 @@ enum { JG_COL_FROM = 1u, JG_COL_TERM = 2u, JG_COL_AUX = 4u, JG_COL_FLAG = 8u,
         * neither a `from` nor a `flag` column exists for the step (naming JG_COL_FROM / JG_COL_FLAG with it is an
         * error): an AppendResponse row is 13 bytes on the bus, not 18.  Every commit of a step must agree on it, it
         * needs JG_COL_UNCHECKED (the device decodes and checks the byte), and jg_submit cannot add rows to such a step. */
-       JG_COL_PACKED_KIND = 64u };
+       JG_COL_PACKED_KIND = 64u,
+       /* the id column of these rows holds 32-bit values: the caller writes n uint32_t at (uint32_t*)cols.id (block ids,
+        * commit indices, request tokens, side-array indices - zero-extended on the device): 4 bytes per row on the bus
+        * instead of 8.  Only as the step's ONE commit (no rows before it, none after it, no jg_submit in the step); needs
+        * JG_COL_UNCHECKED. */
+       JG_COL_ID32 = 128u };
 int jg_submit_reserve(jg_engine* e, size_t n, size_t n_blocks, jg_cmd_cols* cols);
 int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_columns);
 

@@ -118,7 +118,7 @@ class CmdCols(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("kind", "group", "from_", "term", "id", "aux", "flag", "blk_id", "blk_next")]
 
 
-COL_FROM, COL_TERM, COL_AUX, COL_FLAG, COL_UNCHECKED, COL_UPLOAD_NOW, COL_PACKED_KIND = 1, 2, 4, 8, 16, 32, 64
+COL_FROM, COL_TERM, COL_AUX, COL_FLAG, COL_UNCHECKED, COL_UPLOAD_NOW, COL_PACKED_KIND, COL_ID32 = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class CmdBatch(C.Structure):

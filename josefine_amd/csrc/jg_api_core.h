@@ -208,6 +208,7 @@ struct jg_engine {
   // which optional columns some jg_submit since the last step actually provided (an absent column is
   // all zeros: jg_step_node does not upload it)
   bool p_has_from = false, p_has_term = false, p_has_aux = false, p_has_flag = false;
+  bool p_id32 = false;       // JG_COL_ID32: the pending id column holds 32-bit values (the step's one commit)
   bool p_packed = false;     // JG_COL_PACKED_KIND: the pending kind column holds kind | sender slot << 4 | flag << 7
   bool p_unchecked = false;  // some rows were committed with JG_COL_UNCHECKED: only jg_step_node may take this batch
   // JG_COL_UPLOAD_NOW: the committed batch on its way to the device before the step is called, on a copy stream of
@@ -215,10 +216,10 @@ struct jg_engine {
   // Two device buffers by turns: a step's rows are read until the step is settled, the next upload must not wait for that
   struct RowLayout {
     size_t n = 0, nb = 0, bytes = 0;
-    bool has_from = false, has_term = false, has_aux = false, has_flag = false, packed = false;
+    bool has_from = false, has_term = false, has_aux = false, has_flag = false, packed = false, id32 = false;
     size_t o_id = 0, o_term = 0, o_aux = 0, o_bid = 0, o_bnext = 0, o_group = 0, o_from = 0, o_kind = 0, o_flag = 0;
     bool same_batch(const RowLayout& o) const {
-      return n == o.n && nb == o.nb && has_from == o.has_from && has_term == o.has_term && has_aux == o.has_aux && has_flag == o.has_flag && packed == o.packed;
+      return n == o.n && nb == o.nb && has_from == o.has_from && has_term == o.has_term && has_aux == o.has_aux && has_flag == o.has_flag && packed == o.packed && id32 == o.id32;
     }
   };
   struct EarlyUpload {

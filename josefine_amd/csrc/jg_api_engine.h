@@ -248,7 +248,7 @@ int jg_submit(jg_engine* e, const jg_cmd_batch* b) {
     e->p_kinds_seen |= seen;
   }
   const size_t at = e->p_kind.size(), n = b->n;
-  if (at && e->p_packed) return fail(JG_EINVAL, "jg_submit: the step's rows so far were committed with JG_COL_PACKED_KIND");
+  if (at && (e->p_packed || e->p_id32)) return fail(JG_EINVAL, "jg_submit: the step's rows so far were committed with JG_COL_PACKED_KIND / JG_COL_ID32");
   if (e->up.valid) {  // rows behind an early upload (JG_COL_UPLOAD_NOW): the step uploads the whole batch itself
     HIPCHK(hipEventSynchronize(e->up.ev_up));  // (the columns may move when they grow)
     e->up.valid = false;
@@ -276,14 +276,14 @@ namespace {
 void node_row_layout(const jg_engine* e, size_t n, size_t nb, jg_engine::RowLayout& l) {
   l = jg_engine::RowLayout{};
   l.n = n, l.nb = nb;
-  l.has_from = e->p_has_from, l.has_term = e->p_has_term, l.has_aux = e->p_has_aux, l.has_flag = e->p_has_flag, l.packed = e->p_packed;
+  l.has_from = e->p_has_from, l.has_term = e->p_has_term, l.has_aux = e->p_has_aux, l.has_flag = e->p_has_flag, l.packed = e->p_packed, l.id32 = e->p_id32;
   size_t off = 0;
   auto sect = [&](size_t bytes) {
     size_t at = off;
     off = (off + bytes + 15) & ~size_t(15);
     return at;
   };
-  l.o_id = sect(n * 8), l.o_term = sect(l.has_term ? n * 8 : 0), l.o_aux = sect(l.has_aux ? n * 8 : 0), l.o_bid = sect(nb * 8);
+  l.o_id = sect(n * (l.id32 ? 4 : 8)), l.o_term = sect(l.has_term ? n * 8 : 0), l.o_aux = sect(l.has_aux ? n * 8 : 0), l.o_bid = sect(nb * 8);
   l.o_bnext = sect(nb * 8), l.o_group = sect(n * 4), l.o_from = sect(l.has_from ? n * 4 : 0), l.o_kind = sect(n);
   l.o_flag = sect(l.has_flag ? n : 0);
   l.bytes = off;
@@ -295,7 +295,7 @@ int upload_node_rows(jg_engine* e, const jg_engine::RowLayout& l, char* B, hipSt
     if (bytes_up) *bytes_up += nbytes;
     return hipMemcpyAsync(B + at, src, nbytes, hipMemcpyHostToDevice, st);
   };
-  HIPCHK(up(l.o_id, e->p_id.data(), n * 8));
+  HIPCHK(up(l.o_id, e->p_id.data(), n * (l.id32 ? 4 : 8)));
   if (l.has_term) HIPCHK(up(l.o_term, e->p_term.data(), n * 8));
   if (l.has_aux) HIPCHK(up(l.o_aux, e->p_aux.data(), n * 8));
   HIPCHK(up(l.o_group, e->p_group.data(), n * 4));
@@ -361,12 +361,15 @@ int jg_submit_reserve(jg_engine* e, size_t n, size_t n_blocks, jg_cmd_cols* cols
 int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_columns) {
   if (!e) return fail(JG_EINVAL, "null argument");
   if (e->router) return fail(JG_EINVAL, "jg_submit_commit: the columns are per shard: call this on a shard handle (jg_get_shard)");
-  if (optional_columns & ~127u) return fail(JG_EINVAL, "unknown column bit");
+  if (optional_columns & ~255u) return fail(JG_EINVAL, "unknown column bit");
   const size_t at = e->p_kind.size(), bat = e->p_blk_id.size();
   const bool packed = (optional_columns & JG_COL_PACKED_KIND) != 0;
   if (packed && (!(optional_columns & JG_COL_UNCHECKED) || (optional_columns & (JG_COL_FROM | JG_COL_FLAG))))
     return fail(JG_EINVAL, "JG_COL_PACKED_KIND: the byte carries sender and flag (no JG_COL_FROM / JG_COL_FLAG) and is checked on the device (JG_COL_UNCHECKED)");
   if (at && packed != e->p_packed) return fail(JG_EINVAL, "JG_COL_PACKED_KIND: every commit of a step must agree on the kind column's format");
+  const bool id32 = (optional_columns & JG_COL_ID32) != 0;
+  if (id32 && !(optional_columns & JG_COL_UNCHECKED)) return fail(JG_EINVAL, "JG_COL_ID32 needs JG_COL_UNCHECKED");
+  if (at && (id32 || e->p_id32)) return fail(JG_EINVAL, "JG_COL_ID32: only as the step's one commit (rows are pending / were committed with it)");
   if (at + n > e->p_kind.cap || at + n > e->p_group.cap || at + n > e->p_id.cap || bat + n_blocks > e->p_blk_id.cap)
     return fail(JG_EINVAL, "jg_submit_commit: more rows than jg_submit_reserve made room for");
   jg_cmd_batch b{};  // what was written in place, as a batch: the same checks as jg_submit
@@ -378,7 +381,7 @@ int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_
     // the device; what the rows may hold is assumed (a Heartbeat; an AppendEntries if the aux column is there)
     seen = 2u | ((optional_columns & JG_COL_AUX) ? 1u : 0u);
     e->p_unchecked = true;
-    e->p_packed = packed;
+    e->p_packed = packed, e->p_id32 = id32;
   } else {
     int rc = validate_batch(e->cfg.n_groups, &b, &seen);
     if (rc) return rc;
@@ -403,7 +406,10 @@ int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_
   adopt(e->p_flag, e->p_has_flag, (optional_columns & JG_COL_FLAG) != 0);
   if (bat && n_blocks)
     for (size_t i = 0; i < n; i++)
-      if ((packed ? b.kind[i] & 15u : b.kind[i]) == JG_CMD_APPEND_ENTRIES) e->p_id[at + i] += bat;
+      if ((packed ? b.kind[i] & 15u : b.kind[i]) == JG_CMD_APPEND_ENTRIES) {
+        if (id32) ((uint32_t*)e->p_id.p)[at + i] += (uint32_t)bat;
+        else e->p_id[at + i] += bat;
+      }
   e->p_blk_id.n = e->p_blk_next.n = bat + n_blocks;
   if (optional_columns & JG_COL_UPLOAD_NOW) return upload_rows_now(e);
   e->up.valid = false;  // (rows behind an early upload: the step uploads the whole batch itself)

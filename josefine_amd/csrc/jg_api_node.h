@@ -138,7 +138,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
       // JG_COL_UPLOAD_NOW: the batch left when it was committed - the kernels wait for its copies, nothing else does
       B = u.buf[u.turn];
       HIPCHK(hipStreamWaitEvent(e->stream, u.ev_up, 0));
-      bytes_up += n * (8u + 4u + 1u + (has_term ? 8u : 0u) + (has_aux ? 8u : 0u) + (has_from ? 4u : 0u) + (has_flag ? 1u : 0u)) + nb * 16u;
+      bytes_up += n * ((lay.id32 ? 4u : 8u) + 4u + 1u + (has_term ? 8u : 0u) + (has_aux ? 8u : 0u) + (has_from ? 4u : 0u) + (has_flag ? 1u : 0u)) + nb * 16u;
       u.last_used = u.turn;
       u.turn ^= 1;
     } else {
@@ -154,7 +154,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     rows.from = has_from ? (const uint32_t*)(B + o_from) : nullptr, rows.term = has_term ? (const uint64_t*)(B + o_term) : nullptr;
     rows.id = (const uint64_t*)(B + o_id), rows.aux = has_aux ? (const uint64_t*)(B + o_aux) : nullptr;
     rows.flag = has_flag ? (const uint8_t*)(B + o_flag) : nullptr;
-    rows.packed = lay.packed ? 1u : 0u;
+    rows.packed = lay.packed ? 1u : 0u, rows.id32 = lay.id32 ? 1u : 0u;
     for (uint32_t r = 0; r < JG_MAX_REPLICAS; r++) rows.ids[r] = r < R ? e->cfg.node_ids[r] : 0u;
     rows.blk_id = (const uint64_t*)(B + o_bid), rows.blk_next = (const uint64_t*)(B + o_bnext), rows.n_blocks = nb;
     const uint32_t rgrid = grid_for(n, 4096);
@@ -180,7 +180,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     e->p_aux.flip(), e->p_blk_id.flip(), e->p_blk_next.flip();
     e->p_has_from = e->p_has_term = e->p_has_aux = e->p_has_flag = false;
     e->p_kinds_seen = 0;
-    e->p_unchecked = e->p_packed = false;
+    e->p_unchecked = e->p_packed = e->p_id32 = false;
   }
   // the dense halves: every partition, the ones whose rows went the general way included (they are ticked here) -
   // except in an asynchronous step, whose halves leave those partitions to the catch-up pass (node_settle)

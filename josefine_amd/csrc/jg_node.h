@@ -98,7 +98,9 @@ struct JgNodeRows {  // the step's command rows in device memory, unsorted (stre
   uint64_t n_blocks;
   // JG_COL_PACKED_KIND: kind[i] = kind | sender slot << 4 | flag << 7 (no from / flag columns); ids = jg_config.node_ids
   uint32_t packed;
+  uint32_t id32;  // JG_COL_ID32: the id column holds 32-bit values (zero-extended here)
   uint32_t ids[JG_MAX_REPLICAS];
+  __device__ __forceinline__ uint64_t id_of(uint32_t i) const { return id32 ? (uint64_t)((const uint32_t*)id)[i] : id[i]; }
   __device__ __forceinline__ uint32_t kind_of(uint32_t i) const { return packed ? kind[i] & 15u : kind[i]; }
   __device__ __forceinline__ uint32_t from_of(uint32_t i) const {
     if (!packed) return from ? from[i] : 0u;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_classify(JgDev d, JgNodeCols 
         // a sender outside the membership (progress.rs:43 panics on it), the own id (the own slot of the
         // inbox block carries the number of appends), a head a mailbox word cannot hold: general path
         sparse = !(halves & 1u) || s < 0 || (uint32_t)s == self ||
-                 (kind == JG_CMD_APPEND_RESPONSE && a.id[i] >= JG_MAILBOX_NONE);
+                 (kind == JG_CMD_APPEND_RESPONSE && a.id_of(i) >= JG_MAILBOX_NONE);
         bit = s < 0 ? 0u : 1u << ((kind == JG_CMD_APPEND_RESPONSE ? JGN_ACK_SHIFT : JGN_HBR_SHIFT) + (uint32_t)s);
         if (!sparse) c.arr[(size_t)((kind == JG_CMD_APPEND_RESPONSE ? 0u : d.R) + (uint32_t)s) * d.G + g] = i + 1u;
         break;
@@ -205,14 +207,14 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_classify(JgDev d, JgNodeCols 
       // (a leader's answer to a Heartbeat / AppendEntries is a role change or nothing, leader.rs:200-208,263 - never an
       //  answer word, and its Tick must come AFTER the row: the general path)
       case JG_CMD_HEARTBEAT:
-        sparse = !(halves & 2u) || a.id[i] == JG_NO_ACK || a.from_of(i) == 0 ||  // (JG_NO_ACK in the beat means "no heartbeat")
+        sparse = !(halves & 2u) || a.id_of(i) == JG_NO_ACK || a.from_of(i) == 0 ||  // (JG_NO_ACK in the beat means "no heartbeat")
                  (d.flags[g] & JGF_ROLE_MASK) == JG_ROLE_LEADER;
         bit = JGN_HB;
         c.fo[g] = i + 1u;
         break;
       case JG_CMD_APPEND_ENTRIES: {
         uint64_t from;
-        sparse = !(halves & 2u) || a.from_of(i) == 0 || !jg_node_ae_run(a, a.id[i], a.aux_of(i), &from) ||
+        sparse = !(halves & 2u) || a.from_of(i) == 0 || !jg_node_ae_run(a, a.id_of(i), a.aux_of(i), &from) ||
                  (d.flags[g] & JGF_ROLE_MASK) == JG_ROLE_LEADER;
         bit = JGN_AE;
         c.fo[d.G + g] = i + 1u;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
     switch (kind) {
       case JG_CMD_APPEND_RESPONSE: {  // bits 63..8 of the sender's answer word (all ones before)
         const int s = jg_node_slot_of(d, a.from_of(i));
-        (void)__hip_atomic_fetch_and(&c.answers[(size_t)s * G + g], (a.id[i] << 8) | 0xffull, __ATOMIC_RELAXED,
+        (void)__hip_atomic_fetch_and(&c.answers[(size_t)s * G + g], (a.id_of(i) << 8) | 0xffull, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
         if (w & JGN_CR) {  // did it arrive before the group's ClientRequest?  (it met the head before the append)
           const uint32_t self = us >= 0 ? (uint32_t)us : (d.flags[g] & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
@@ -290,23 +292,23 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
         const uint64_t has = a.flag_of(i) ? 1 : 0;
         (void)__hip_atomic_fetch_and(&c.answers[(size_t)s * G + g], ~0xffull | has, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
-        if (!has) c.hbr_commit[(size_t)s * G + g] = a.id[i];
+        if (!has) c.hbr_commit[(size_t)s * G + g] = a.id_of(i);
         break;
       }
       case JG_CMD_CLIENT_REQUEST: {
         const uint32_t self = us >= 0 ? (uint32_t)us : (d.flags[g] & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
         // (an atomic: the AppendResponse rows that arrived before this one set their bits in the same word)
         (void)__hip_atomic_fetch_or(&c.answers[(size_t)self * G + g], 1ull << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.token[g] = a.id[i];
+        c.token[g] = a.id_of(i);
         break;
       }
       case JG_CMD_HEARTBEAT:
-        c.f_beat[g] = jg_leader_beat{a.term_of(i), a.id[i]};
+        c.f_beat[g] = jg_leader_beat{a.term_of(i), a.id_of(i)};
         c.f_leader[g] = a.from_of(i);
         break;
       default: {  // JG_CMD_APPEND_ENTRIES
         uint64_t from = 0;
-        (void)jg_node_ae_run(a, a.id[i], a.aux_of(i), &from);
+        (void)jg_node_ae_run(a, a.id_of(i), a.aux_of(i), &from);
         c.f_ae[g] = JG_AE(from, a.aux_of(i));
         if (!(w & JGN_HB)) {  // (with a Heartbeat in the batch: the same term and sender, written by its row)
           c.f_beat[g].term = a.term_of(i);
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_gather_rows(uint32_t n, const
   o.kind[p] = (uint8_t)a.kind_of(i);
   o.from[p] = a.from_of(i);
   o.term[p] = a.term_of(i);
-  o.id[p] = a.id[i];
+  o.id[p] = a.id_of(i);
   o.aux[p] = a.aux_of(i);
   o.flag[p] = a.flag_of(i);
 }

@@ -191,6 +191,12 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
   // ONE byte (no from / flag columns: 13 bytes per row, not 18), the Tick's AppendEntries words come home as one word per
   // partition (8 bytes, not 8 (R - 1)) and a leader's Apply + Notify of a tick as one fsm row (24 bytes, not 48)
   const bool packed = compact && pipe && !cols_in;
+  // ... and the ids (block ids, commit indices, request tokens: all below 2^32 here) as 32-bit values (JG_COL_ID32: one commit per tick)
+  const bool id32 = compact && pipe;
+  auto put_id = [id32](uint64_t* id, size_t i, uint64_t v) {
+    if (id32) ((uint32_t*)id)[i] = (uint32_t)v;
+    else id[i] = v;
+  };
   Tasks tasks(with_tasks ? helpers : 0u);  // (no helpers: run() is a plain loop on the calling thread)
   constexpr uint32_t SPLIT = 8;            // jobs per batch and connection: the helpers draw them as they come free
   auto sum_split = [&](const void* p, size_t items, size_t item_bytes) {
@@ -250,7 +256,7 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
       if (s == 0) {
         for (uint32_t k = k0; k < k1; k++) {
           const uint32_t g = perm[k];
-          kind[k] = JG_CMD_CLIENT_REQUEST, group[k] = g, id[k] = (uint64_t)t * G + g;
+          kind[k] = JG_CMD_CLIENT_REQUEST, group[k] = g, put_id(id, k, (uint64_t)t * G + g);
           if (!packed) from[k] = 0, flag[k] = 0;
         }
         return;
@@ -263,8 +269,8 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
         at = at + 1 == G ? 0 : at + 1;
         if (packed) {  // (sender slot s and flag 1 in the kind byte)
           const uint8_t hi = (uint8_t)(s << 4 | 0x80u);
-          if (hb) kind[i] = JG_CMD_HEARTBEAT_RESPONSE | hi, group[i] = g, id[i] = t ? t - 1 : 0, i++;
-          kind[i] = JG_CMD_APPEND_RESPONSE | hi, group[i] = g, id[i] = t, i++;
+          if (hb) kind[i] = JG_CMD_HEARTBEAT_RESPONSE | hi, group[i] = g, put_id(id, i, t ? t - 1 : 0), i++;
+          kind[i] = JG_CMD_APPEND_RESPONSE | hi, group[i] = g, put_id(id, i, t), i++;
           continue;
         }
         if (hb) kind[i] = JG_CMD_HEARTBEAT_RESPONSE, group[i] = g, from[i] = ids[s], id[i] = t ? t - 1 : 0, flag[i] = 1, i++;
@@ -313,7 +319,7 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
         const Message m = formats::decode_message(payload);
         const Command& c = m.command;
         const NodeId sender = c.kind == JG_CMD_HEARTBEAT_RESPONSE ? m.from.peer : c.from;  // (rpc.rs:17-27: the Message names the sender)
-        group[i] = perm[at], id[i] = c.id;
+        group[i] = perm[at], put_id(id, i, c.id);
         if (packed) {
           uint32_t slot = 7;  // (nobody: reads NodeId 0)
           for (uint32_t q = 0; q < R; q++) slot = ids[q] == sender ? q : slot;
@@ -363,11 +369,11 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
           if (s) {  // peer s's answers to last tick's Heartbeat / AppendEntries: one word per partition
             for (uint32_t g = k0; g < k1; g++) ans[s][g] = w;
           } else {
-            for (uint32_t k = k0; k < k1; k++) c.kind[k] = JG_CMD_CLIENT_REQUEST, c.group[k] = perm[k], c.id[k] = (uint64_t)t * G + perm[k];
+            for (uint32_t k = k0; k < k1; k++) c.kind[k] = JG_CMD_CLIENT_REQUEST, c.group[k] = perm[k], put_id(c.id, k, (uint64_t)t * G + perm[k]);
           }
         });
         t_fill += ms_since(a), a = Clock::now();
-        loop.tcp_rx_commit(G, 0, unchecked);
+        loop.tcp_rx_commit(G, 0, unchecked | (id32 ? (uint32_t)JG_COL_ID32 : 0u));
         t_submit += ms_since(a), a = Clock::now();
         loop.run_until(now);
         t_step += ms_since(a);
@@ -376,7 +382,7 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
         const jg_cmd_cols c = loop.tcp_rx_reserve(n);
         const size_t k = fill(t, c.kind, c.group, c.from, c.id, c.flag);
         t_fill += ms_since(a), a = Clock::now();
-        loop.tcp_rx_commit(k, 0, (packed ? (uint32_t)JG_COL_PACKED_KIND : (uint32_t)(JG_COL_FROM | JG_COL_FLAG)) | unchecked);
+        loop.tcp_rx_commit(k, 0, (packed ? (uint32_t)JG_COL_PACKED_KIND : (uint32_t)(JG_COL_FROM | JG_COL_FLAG)) | (id32 ? (uint32_t)JG_COL_ID32 : 0u) | unchecked);
         t_submit += ms_since(a), a = Clock::now();
         loop.run_until(now);
         t_step += ms_since(a);
@@ -485,7 +491,7 @@ int main(int argc, char** argv) {
               "\"rows_in_per_tick\": %.1f, \"rows_general\": %llu, \"fsm_rows_per_tick\": %.1f, \"msg_rows_per_tick\": %.1f, "
               "\"pcie_h2d_bytes_per_tick\": %.1f, \"pcie_d2h_bytes_per_tick\": %.1f, \"leader_kernel_us\": %.3f, \"leader_kernel_launches\": %u, "
               "\"wire_bytes_decoded_per_tick\": %.1f, \"sink\": %llu}\n",
-              a.ok ? "true" : "false", mode.c_str(), compact ? "compact (packed kind byte, common AppendEntries word, fused fsm row)" : "plain", G, R, L, mode.rfind("pipetasks", 0) == 0 ? helpers : 0u, T, W, (unsigned long long)a.decisions, a.wall_ms, a.decisions / (a.wall_ms / 1e3),
+              a.ok ? "true" : "false", mode.c_str(), compact ? "compact (packed kind byte, 32-bit ids, common AppendEntries word, fused fsm row)" : "plain", G, R, L, mode.rfind("pipetasks", 0) == 0 ? helpers : 0u, T, W, (unsigned long long)a.decisions, a.wall_ms, a.decisions / (a.wall_ms / 1e3),
               a.wall_ms / T, a.t_fill / T, a.t_submit / T, a.t_step / T, (double)a.rows_in / T, (unsigned long long)a.general,
               (double)a.fsm_rows / T, (double)a.msg_rows / T, (double)a.up_bytes / T, (double)a.down_bytes / T, k_us, a.k_n,
               (double)a.wire_bytes / T, (unsigned long long)a.sink);

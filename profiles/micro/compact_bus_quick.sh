@@ -4,10 +4,10 @@
 mkdir -p gpurun_out
 O=gpurun_out/compact_bus.txt
 : > $O
-timeout 900 python -m pytest tests/test_node_step.py tests/test_cpp_adapter.py -m gpu -q -x 2>&1 | tail -5 >> $O
+timeout 900 python -m pytest ${TESTS:-tests/test_node_step.py tests/test_cpp_adapter.py} -m gpu -q -x 2>&1 | tail -5 >> $O
 python -c "from josefine_amd.build import build_event_loop_bench as b; b()" 2>&1 | tail -1 >> $O
 B=josefine_amd/host/bench_event_loop
-for rep in 1 2; do
+for rep in ${REPS:-1 2}; do
   for mode in pipetasks pipetaskscolumns pipe; do
     for bus in plain compact; do
       extra=""; [ $bus = compact ] && extra="4 compact"

@@ -685,12 +685,12 @@ NO_ACK = capi.NO_ACK
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R,flags,G,async_", [(3, 0, 2500, True), (5, capi.CFG_SEPARATE_COMMIT_KEY, 2000, True), (5, 0, 600, False)])
-def test_node_step_compact_bus_parity(R, flags, G, async_):
+@pytest.mark.parametrize("R,flags,G,async_,id32", [(3, 0, 2500, True, False), (5, capi.CFG_SEPARATE_COMMIT_KEY, 2000, True, True), (5, 0, 600, False, True)])
+def test_node_step_compact_bus_parity(R, flags, G, async_, id32):
     """The node step's three bus formats of ABI v7 together: rows committed with JG_COL_PACKED_KIND (sender slot and flag in
     the kind byte: no from / flag columns), the Tick's AppendEntries words as one word per partition (JG_NODE_COMMON_AE: the
     rows come down only in the ticks where some partition's words differ), a leader's fsm_tx rows of a step as one
-    JG_FSM_LEADER_STEP row (JG_NODE_FSM_FUSED).  What they stand for - every outbox word, state column and drained row -
+    JG_FSM_LEADER_STEP row (JG_NODE_FSM_FUSED); id32: the id column as 32-bit values too (JG_COL_ID32).  What they stand for - every outbox word, state column and drained row -
     equals the oracle's step over the plain rows, tick after tick, on the mixed traffic of the other node-step tests."""
     from josefine_amd import expand_fsm_rows
     T = 40
@@ -711,17 +711,22 @@ def test_node_step_compact_bus_parity(R, flags, G, async_):
         view(c.kind, np.uint8, n)[:] = packed
         view(c.group, np.uint32, n)[:] = cols["group"]
         view(c.term, np.uint64, n)[:] = cols["term"]
-        view(c.id, np.uint64, n)[:] = cols["id"]
+        if id32:
+            view(c.id, np.uint32, n)[:] = cols["id"].astype(np.uint32)
+        else:
+            view(c.id, np.uint64, n)[:] = cols["id"]
         view(c.aux, np.uint64, n)[:] = cols["aux"]
         if nb:
             view(c.blk_id, np.uint64, nb)[:] = cols["blk_id"]
             view(c.blk_next, np.uint64, nb)[:] = cols["blk_next"]
         dev._check(dev.api.submit_commit(dev._h, n, nb, capi.COL_TERM | capi.COL_AUX | capi.COL_UNCHECKED | capi.COL_PACKED_KIND |
-                                         (capi.COL_UPLOAD_NOW if async_ else 0)))
+                                         (capi.COL_ID32 if id32 else 0) | (capi.COL_UPLOAD_NOW if async_ else 0)))
 
     def traffic(t):
         cols = node_traffic(rng, ora, token0=1000 * t, p_noise=0.03 if t % 3 else 0.0, p_reorder=0.08 if t % 3 else 0.0)
         packed, said = _pack_kind(cols, ids, R)
+        if id32:  # (the forged heads a mailbox word cannot hold do not fit 32 bits: what the rows then say, to both sides)
+            cols = dict(cols, id=cols["id"] & np.uint64(0xFFFFFFFF))
         return dict(cols, from_=said, flag=(cols["flag"] != 0).astype(np.uint8)), packed
     nxt, nxt_packed = traffic(0)
     commit(nxt, nxt_packed)
