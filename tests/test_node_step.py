@@ -693,9 +693,11 @@ def test_node_step_compact_bus_parity(R, flags, G, async_, id32):
     JG_FSM_LEADER_STEP row (JG_NODE_FSM_FUSED); id32: the id column as 32-bit values too (JG_COL_ID32).  What they stand for - every outbox word, state column and drained row -
     equals the oracle's step over the plain rows, tick after tick, on the mixed traffic of the other node-step tests."""
     from josefine_amd import expand_fsm_rows
+    import os
     T = 40
-    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=123 + R, flags=flags, election_timeout_ms=(700, 1500))
-    _, ora2, _ = mixed_pair(oracle_engine, oracle_engine, G, R, seed=123 + R, flags=flags, election_timeout_ms=(700, 1500))  # the oracle, asked for the formats itself
+    seed = 123 + R + int(os.environ.get("JG_SOAK_SEED", "0"))  # (profiles/micro/compact_bus_soak.sh: other seeds, on the device)
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=seed, flags=flags, election_timeout_ms=(700, 1500))
+    _, ora2, _ = mixed_pair(oracle_engine, oracle_engine, G, R, seed=seed, flags=flags, election_timeout_ms=(700, 1500))  # the oracle, asked for the formats itself
     ids = list(ora.node_ids)
     own = int(ora.read("self_slot")[0])
     seen = dict(individual=0, common_only=0, fused=0, plain_leader=0)
@@ -759,7 +761,6 @@ def test_node_step_compact_bus_parity(R, flags, G, async_, id32):
         assert x.shape == y.shape and x.tobytes() == y.tobytes(), (t, "drain_applies")
     # both forms of every format were exercised
     assert seen["individual"] and seen["fused"] > 10 * T, seen
-    import os
     if os.environ.get("JG_EMULATED_DEVICE") != "1":  # (the stand-in's wave reductions behind divergent code: tests/host_device.py)
         assert dev.counters()["decisions"] == ora.counters()["decisions"]
     # the formats' rules: a step's commits agree on the kind column's format; jg_submit cannot follow a packed commit
