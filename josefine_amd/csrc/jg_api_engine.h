@@ -249,6 +249,7 @@ int jg_submit(jg_engine* e, const jg_cmd_batch* b) {
   }
   const size_t at = e->p_kind.size(), n = b->n;
   if (at && (e->p_packed || e->p_id32)) return fail(JG_EINVAL, "jg_submit: the step's rows so far were committed with JG_COL_PACKED_KIND / JG_COL_ID32");
+  if (!at) e->p_packed = e->p_id32 = false;
   if (e->up.valid) {  // rows behind an early upload (JG_COL_UPLOAD_NOW): the step uploads the whole batch itself
     HIPCHK(hipEventSynchronize(e->up.ev_up));  // (the columns may move when they grow)
     e->up.valid = false;
@@ -381,13 +382,13 @@ int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_
     // the device; what the rows may hold is assumed (a Heartbeat; an AppendEntries if the aux column is there)
     seen = 2u | ((optional_columns & JG_COL_AUX) ? 1u : 0u);
     e->p_unchecked = true;
-    e->p_packed = packed, e->p_id32 = id32;
   } else {
     int rc = validate_batch(e->cfg.n_groups, &b, &seen);
     if (rc) return rc;
   }
   if ((seen & 1u) && !(optional_columns & JG_COL_AUX)) return fail(JG_EINVAL, "AppendEntries needs id/aux columns");
   e->p_kinds_seen |= seen;
+  if (!at) e->p_packed = packed, e->p_id32 = id32;  // (the step's first commit says what the kind / id columns hold; later ones agree)
   e->p_kind.n = e->p_group.n = e->p_id.n = at + n;
   // an optional column the caller filled is adopted where it lies (src == its own place: no copy)
   auto adopt = [&](auto& v, bool& has, bool given) {

@@ -39,8 +39,8 @@ def test_the_node_steps_bus_formats_on_the_emulated_device():
     """ABI v7's formats of the node step - the packed kind byte, the common AppendEntries word, the fused fsm row - through
     the engine's host code (early uploads, the asynchronous step's settling, the on-demand fetch of the rows) against the
     oracle's step over the plain rows"""
-    out = _run(["tests/test_node_step.py", "-m", "gpu", "-k", "compact_bus and (600 or 2000)"])
-    assert "2 passed" in out, out[-500:]
+    out = _run(["tests/test_node_step.py", "-m", "gpu", "-k", "(compact_bus and (600 or 2000)) or outlive"])
+    assert "3 passed" in out, out[-500:]
 
 
 def test_smoke_on_the_emulated_device():

@@ -767,3 +767,23 @@ def test_node_step_compact_bus_parity(R, flags, G, async_, id32):
     from josefine_amd import EngineError
     with pytest.raises(EngineError, match="JG_COL_PACKED_KIND"):  # (the last tick's `between` left a packed batch pending)
         dev.submit_columns(np.full(1, capi.CMD_TICK, np.uint8), np.zeros(1, np.uint32))
+
+
+@pytest.mark.gpu
+def test_bus_format_flags_do_not_outlive_an_empty_commit():
+    """An EMPTY commit that names JG_COL_PACKED_KIND / JG_COL_ID32 says nothing about the rows that follow it: the step's
+    first rows decide what the kind / id columns hold (plain rows through jg_submit here), tick after tick."""
+    import ctypes as C
+    G, R = 700, 3
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=5, election_timeout_ms=(700, 1500))
+    for t in range(6):
+        cols = node_traffic(rng, ora, token0=1000 * t)
+        c = capi.CmdCols()
+        dev._check(dev.api.submit_reserve(dev._h, 0, 0, C.byref(c)))
+        dev._check(dev.api.submit_commit(dev._h, 0, 0, capi.COL_UNCHECKED | capi.COL_PACKED_KIND | capi.COL_ID32))
+        dev.submit_columns(**cols)
+        ora.submit_columns(**cols)
+        a, b = dev.step_node(100 * (t + 1)), ora.step_node(100 * (t + 1))
+        compare_outboxes(a, b, f"tick {t}")
+        compare_snapshots(dev, ora, f"tick {t}")
+        compare_drains(dev, ora, f"tick {t}")
