@@ -242,7 +242,17 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
     std::vector<uint32_t> perm(G);
     std::iota(perm.begin(), perm.end(), 0u);
     uint64_t x = 88172645463325252ull + seed;
-    for (uint32_t i = G - 1; i > 0; i--) {
+    // (JG_BENCH_SHUFFLE_WINDOW=w: the shuffle only moves a partition within its window of w - how much of the
+    //  classification's cost is the disorder: 1 = rows in partition order)
+    const char* win_env = std::getenv("JG_BENCH_SHUFFLE_WINDOW");
+    const uint32_t win = win_env ? (uint32_t)std::max(1, std::atoi(win_env)) : 0u;
+    if (win)
+      for (uint32_t lo = 0; lo < G; lo += win)
+        for (uint32_t i = std::min(G, lo + win) - 1; i > lo; i--) {
+          x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+          std::swap(perm[i], perm[lo + (uint32_t)(x % (i - lo + 1))]);
+        }
+    for (uint32_t i = G - 1; i > 0 && !win; i--) {
       x ^= x << 13, x ^= x >> 7, x ^= x << 17;
       std::swap(perm[i], perm[(uint32_t)(x % (i + 1))]);
     }
