@@ -787,3 +787,32 @@ def test_bus_format_flags_do_not_outlive_an_empty_commit():
         compare_outboxes(a, b, f"tick {t}")
         compare_snapshots(dev, ora, f"tick {t}")
         compare_drains(dev, ora, f"tick {t}")
+
+
+@pytest.mark.parametrize("R,flags", [(3, 0), (5, capi.CFG_SEPARATE_COMMIT_KEY), (2, 0)])
+def test_oracle_bus_formats_stand_for_the_plain_step(R, flags):
+    """CPU: the oracle's own restatement of JG_NODE_COMMON_AE / JG_NODE_FSM_FUSED (what the device's rows are held to byte for
+    byte in test_node_step_compact_bus_parity) against the oracle's plain step: the common word expands to the [R][G] block,
+    the fused rows expand to Apply / Notify / Apply - and both forms of each occur."""
+    from josefine_amd import expand_fsm_rows
+    G, T = 1500, 40
+    a, b, rng = mixed_pair(oracle_engine, oracle_engine, G, R, seed=900 + R, flags=flags, election_timeout_ms=(700, 1500))
+    own = int(a.read("self_slot")[0])
+    seen = dict(fused=0, plain_notify=0, individual=0, common=0)
+    for t in range(T):
+        cols = node_traffic(rng, a, token0=1000 * t, p_noise=0.03 if t % 3 else 0.0)
+        a.submit_columns(**cols), b.submit_columns(**cols)
+        x, y = a.step_node(100 * (t + 1)), b.step_node(100 * (t + 1), common_ae=True, fsm_fused=True)
+        seen["individual" if y["ae"] is not None else "common"] += 1
+        compare_outboxes(_expand_common_ae(y, own, R), x, f"tick {t}")
+        compare_snapshots(b, a, f"tick {t}")
+        fx, fy = a.drain_applies(), b.drain_applies()
+        seen["fused"] += int((fy["kind"] == capi.FSM_LEADER_STEP).sum())
+        seen["plain_notify"] += int((fy["kind"] == capi.FSM_NOTIFY).sum())
+        assert len(fy) <= len(fx)
+        ey = expand_fsm_rows(fy)
+        assert ey.shape == fx.shape and ey.tobytes() == fx.tobytes(), t
+        for fn in ("drain_messages", "drain_faults"):
+            p, q = getattr(a, fn)(), getattr(b, fn)()
+            assert p.tobytes() == q.tobytes(), (t, fn)
+    assert seen["fused"] > 5 * T and (seen["individual"] or R == 2), seen  # (one follower: its word IS the common word)
