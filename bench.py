@@ -195,14 +195,17 @@ def workload_name(G: int, R: int, mode: int, failures: int) -> str:
     return f"{G} partitions x {R} replicas per GPU, {tag}; device-resident synthetic ack stream, mode {mode}"
 
 
-def node_alg_bytes(R: int):
+def node_alg_bytes(R: int, common_ae: bool = True):
     """Algorithmic bytes per group of one closed-loop protocol round (DESIGN.md "Dense node tick").
     Leader half: the 8R + 28 of the ack tick (the inbox's answer words are its ack block: the
-    HeartbeatResponse code rides in their low byte) + term 8 + heartbeat_time 8, outbox beat 16 +
-    (R-1) x ae word 8.  Follower half, per follower: state read 56 + inbox 24 (beat 16 + ae 8), written
-    head 8 + answer 8, and every other tick (heartbeat) HeartbeatResponse.commit 8 + commit 8 + election
-    timer 16."""
-    leader = (8 * R + 28) + 16 + 16 + 8 * (R - 1)
+    HeartbeatResponse code rides in their low byte) + term 8 + heartbeat_time 8, outbox beat 16 + the
+    AppendEntries words: ONE 8-byte word per group where every follower's is the same (JgLeaderNode::o_aec: what a
+    jg_dense_cluster and jg_step_node with JG_NODE_COMMON_AE write in the steady state; round 5 still priced the R - 1
+    words the kernel no longer moves - 132 B at R = 5 where PMC counts 112.7 MB per 1 M groups) = 108 B at R = 5,
+    or (common_ae = False: the plain jg_step_node outbox) R - 1 words.  Follower half, per follower: state read 56 +
+    inbox 24 (beat 16 + ae 8), written head 8 + answer 8, and every other tick (heartbeat)
+    HeartbeatResponse.commit 8 + commit 8 + election timer 16."""
+    leader = (8 * R + 28) + 16 + 16 + (8 if common_ae else 8 * (R - 1))
     follower = 56 + 24 + 8 + 8 + 16
     return leader, follower
 
@@ -368,11 +371,11 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
         now[0] += 100
         return lib.round_routed(now[0], inject)
 
-    # -- the elections, through the transport (R <= 3; a five-node election cannot be won over a transport that delivers
-    # every sender's answers back to back: the candidate sends nodes.len() copies of its VoteRequest, the voter grants
-    # the first and refuses the rest, and Election::vote lets the later answer overwrite the earlier - candidate.rs:30-37,
-    # election.rs:34; DESIGN.md "The cluster transport" - so R > 3 gets synthetic votes, and says so)
-    through_transport = R <= 3
+    # -- the elections, through the transport - at any R since round 6: it delivers every voter's first answer before
+    # anybody's second (jg_route.h: phase, emission index, sender), so the candidate sees its quorum of grants before the
+    # refusals of its further copies overwrite them (candidate.rs:30-37, election.rs:33-35; until round 5 each sender's
+    # answers came back to back and R > 3 needed synthetic votes).  --synthetic-votes 1 brings those back (an A/B).
+    through_transport = not args.synthetic_votes
     votes_routed = 0
     sync_all()
     t0 = time.perf_counter()
@@ -405,9 +408,9 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
 
     failed = np.zeros(G, bool)
     trace, withdraw = [], []
-    recreate = bool(args.recreate) and R == 3
+    recreate = bool(args.recreate)
+    whole = R == 3 or recreate
     if args.failures:
-        whole = R == 3
         for t in range(W + K):
             # --recreate: the failing group comes back on EMPTY stores (JG_CMD_RECREATE): the election's winner can append
             # (no Q8), the client keeps proposing, a group may fail any number of times - a stationary trace whose every vote
@@ -501,7 +504,7 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
             "value": decisions / wall, "unit": "decisions/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall * 1e3 / K, "ms_per_step_events": ev_ms.value / K, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": (f"per-partition leadership: {R} nodes x {G} partitions on one GPU, leaders elected " + ("THROUGH the device transport" if R <= 3 else "(synthetic votes)") + " "
+            "config": {"workload": (f"per-partition leadership: {R} nodes x {G} partitions on one GPU, leaders elected " + ("THROUGH the device transport" if through_transport else "(synthetic votes)") + " "
                                     f"({args.leadership}: every node leads G/R partitions and follows the rest), closed loop over the "
                                     "cluster's mailbox columns, 1 client request per led partition per round"
                                     + (f"; {args.failures} %/round of the partitions lose their leader"
@@ -510,7 +513,7 @@ def cluster_any_main(args, torch, dist, rank, world, dev_index, red_dev):
                                           "keeps proposing: a stationary trace" if recreate else
                                           " (the whole group restarts), the next replica campaigns and wins through the transport, leadership "
                                           "moves and stays in column form; the client withdraws its proposals from such a partition (Q8)"
-                                          if R == 3 else " (crash + restart; the other replicas remember their vote: Q4, the partition stays leaderless)")
+                                          if whole else " (crash + restart; the other replicas remember their vote: Q4, the partition stays leaderless)")
                                        if args.failures else "")),
                        "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world, "leadership": args.leadership,
                        "q9": "off (JG_CFG_SEPARATE_COMMIT_KEY: bit-exact vs the oracle with the same switch; the reference would "
@@ -565,9 +568,10 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
     travels between the engines through the library's device-side transport (jg_dense_cluster_round_routed) and is
     applied the round after.  The client stops proposing to it.  --repair-after D rounds later the partition is RE-CREATED
     (what the reference leaves of it can never append again, Q8, and would be re-fed from block 1, Q10: every replica
-    restarts on an empty store - JG_CMD_RECREATE -, replica 0 is seated: Timeout + two injected grants, the trace's
-    only synthetic votes; its VoteRequests and its Heartbeat are routed) and is what every partition was at round 0, the
-    client proposing again: leaderless fraction (p x D), decisions per round and cost per round are flat.
+    restarts on an empty store - JG_CMD_RECREATE -, replica 0 receives Timeout, campaigns, and is ELECTED two rounds later by
+    the answers the transport brings back - no synthetic vote anywhere since round 6: every voter's first answer is
+    delivered before anybody's second, so five nodes elect as three do) and is what every partition was at round 0, the
+    client proposing again: leaderless fraction (p x (D + 2)), decisions per round and cost per round are flat.
     --repair-after 0: no repairs (rounds 2-4's trace: the leaderless fraction grows by p per round)."""
     import numpy as np
     from josefine_amd import BatchedRaft, DenseCluster, capi
@@ -589,9 +593,10 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
     # schedule of D rounds needs D rounds to fill; election timeouts are 5-10 rounds)
     settle = max(0, (2 * D + 10 if D else 0) - W)
     tr = FailureRepairTrace(args.seed, G, R, args.failures, D if D else 1 << 40, group_base=rank * G, node_ids=[nodes[r].node_ids[r] for r in range(R)])
-    trace, withdraw, offer, frac = [], [], [], []
+    trace, withdraw, offer, frac, seated = [], [], [], [], []
     for t in range(settle + W + K):
         cols, failing, repaired = tr.rows(t)
+        seated.append(len(repaired))
         trace.append([None if c is None else nodes[n].upload_rows(**c) for n, c in enumerate(cols)])
         withdraw.append(L.upload_u32(failing) if len(failing) else None)   # the client stops proposing to a partition that lost its leader ...
         offer.append(L.upload_u32(repaired) if len(repaired) else None)    # ... and proposes again to one that was re-created
@@ -700,7 +705,8 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
                                    "follower times out and campaigns (again at every election timeout), votes answered through can_vote "
                                    "and routed between the nodes on the device, applied the round after"
                                    + (f"; {D} rounds after its failure a partition is RE-CREATED: every replica restarts on an empty store, replica 0 "
-                                      "is seated (Timeout + two injected grants: the only synthetic votes; its VoteRequests and its Heartbeat are routed)"
+                                      "receives Timeout, campaigns and is ELECTED through the transport two rounds later (no synthetic vote: its "
+                                      "VoteRequests, the voters' answers and its Heartbeat are all routed)"
                                       if D else "; no repairs: a failed partition stays leaderless")
                                    + "; 1 client request per round for every partition that has a leader",
                        "partitions_per_gpu": G, "replicas": R, "partitions_total": G * world,
@@ -735,6 +741,10 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
             {"rounds": [marks[q] - W, marks[q + 1] - W], "leaderless_fraction": [lf(marks[q]), frac[marks[q + 1] - 1]],
              "ms_per_round": window_s[q] * 1e3 / max(marks[q + 1] - marks[q], 1)} for q in range(4)]
         out["partitions_that_failed_at_least_once"] = float(tr.ever_failed.mean())
+        # every one of them checked above: a partition the trace counts as up is LED by replica 0 (`leadership`), and nothing
+        # but the transport's mail can have elected it - the trace injects Restart / Recreate / Timeout rows only
+        out["elections_won_through_the_transport"] = int(sum(seated[W:W + K])) if D else 0
+        out["synthetic_votes"] = 0
         out["fsm_rows_per_round"] = fsm[0] / (W + K)
         out["config"]["fsm_rows"] = ("drained by the host every round (jg_drain_applies_view: the pinned queue, no copy)" if args.drain_applies
                                      else "left queued until the end of the run (--drain-applies 0)")
@@ -817,7 +827,7 @@ def event_loop_main(args):
     L, Lc = d["loops"], colm["loops"]
     copy = run("copy", K, W)
     old = run("general", max(3, min(K, 10)), 2)  # round 2's loop: one Tick ROW per partition, the general state machine only
-    lb = node_alg_bytes(R)[0] + 4  # the leader half of the node tick + the fsm delta word it leaves behind
+    lb = node_alg_bytes(R, common_ae=False)[0] + 4  # the leader half of the node tick (d1: the plain outbox, R - 1 AppendEntries words) + the fsm delta word it leaves behind
     k_us = d1["leader_kernel_us"]  # (from the one-loop run: the kernel over all G partitions, nothing beside it)
     ach = lb * G / (k_us * 1e-6) / 1e9 if k_us else 0.0
     loop_ms = d1["ms_submit"] + d1["ms_step_and_drain"]
@@ -1138,8 +1148,11 @@ def main():
                          "traffic is the winners' Heartbeats - rows - and the word passes buy nothing: 0.32 against 0.27 ms)")
     ap.add_argument("--drain-applies", type=int, choices=[0, 1], default=1,
                     help="--cluster --failures: hand the rounds' FSM rows (the Apply ranges of repaired followers) to the host every round")
+    ap.add_argument("--synthetic-votes", type=int, choices=[0, 1], default=0,
+                    help="--cluster --any-leader: 1 = the initial leaders are seated with injected VoteResponses instead of being elected "
+                         "through the device transport (what R > 3 needed until round 6; kept as an A/B)")
     ap.add_argument("--recreate", action="store_true",
-                    help="--cluster --any-leader --failures p (R = 3): the failing group comes back on EMPTY stores (JG_CMD_RECREATE) - the campaign is won "
+                    help="--cluster --any-leader --failures p: the failing group comes back on EMPTY stores (JG_CMD_RECREATE) - the campaign is won "
                          "through the transport, the winner appends, groups may fail again: a stationary trace with no synthetic vote")
     ap.add_argument("--repair-after", type=int, default=10,
                     help="--cluster --failures (single lead): rounds after which a failed partition is repaired (every replica restarts, "

@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define JG_ABI_VERSION 7u /* v5: jg_step_node = arrival-order Apply (fsm_tx: Apply / Notify / Apply per partition), JG_CLUSTER_ANY_LEADER,
+#define JG_ABI_VERSION 8u /* v8: jg_dense_cluster_round_routed delivers a partition's mail in the order (phase, emission index, sender) instead of
+                             (sender, step, emission index) - same entry points, same layouts, different (legal) network schedule; v5: jg_step_node = arrival-order Apply (fsm_tx: Apply / Notify / Apply per partition), JG_CLUSTER_ANY_LEADER,
                              jg_dense_cluster_withdraw_appends, JG_COL_UNCHECKED, JG_COL_UPLOAD_NOW; v6: jg_dense_cluster_set_option, jg_dense_cluster_offer_appends, JG_CMD_RECREATE;
                              v7: the node step's bus formats - JG_COL_PACKED_KIND, JG_COL_ID32, JG_NODE_COMMON_AE (jg_node_outbox.aec), JG_NODE_FSM_FUSED (JG_FSM_LEADER_STEP) */
 #define JG_MAX_REPLICAS 8u  /* R <= 8: vote / progress-state masks are one byte            */
@@ -641,7 +642,16 @@ int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_lead
  * routed round.  Per node and call:
  *   1. jg_step over the rows delivered by the previous call, then over inject[node] (a device batch as
  *      for jg_step_device_rows, or n == 0; NULL = nothing for anybody) — per group: the peers' rows in
- *      the order (sender slot, emission order), then the injected ones;
+ *      the order (phase of the round they were emitted in, emission index within the sender's step,
+ *      sender slot), then the injected ones.  The phases are the steps the nodes take in lockstep: 1 = this
+ *      step over the delivered rows, 2 = the injected rows, 3 = the leader half, 4 = the follower half of the
+ *      dense round.  Every sender's stream arrives in its own order - all a network promises (one
+ *      connection per peer pair, tcp.rs:87-170) - and the senders are interleaved: everybody's first row of a
+ *      phase before anybody's second.  That interleaving is what lets an election of more than three nodes
+ *      complete: a candidate broadcasts its VoteRequest once per peer (candidate.rs:30-37), a voter grants
+ *      the first copy and refuses the rest, and a voter's later answer overwrites its earlier one
+ *      (election.rs:33-35) - the quorum has to be seen among the first answers.  (Until ABI v8 the order was
+ *      sender-major, each sender's rows back to back: five-node elections could not be won.);
  *   2. the dense round of jg_dense_cluster_rounds at now_ms, except that the ClientRequests of
  *      jg_dense_cluster_set_appends are offered only to groups nodes[lead] leads at that moment (a
  *      replica without a leader queues them, follower.rs:258-270: not a dense append; with per-partition

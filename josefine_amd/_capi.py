@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 CLUSTER_ANY_LEADER = 0xFFFFFFFF
 CLUSTER_OPT_VOTE_WORDS = 1
 MAX_REPLICAS = 8

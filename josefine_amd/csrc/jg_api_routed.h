@@ -110,6 +110,13 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   };
   std::vector<uint32_t> seq_base(R);
   for (uint32_t n = 0; n < R; n++) seq_base[n] = c->nodes[n]->seq;
+  // which of a node's steps of this round is which PHASE (jg_route.h: the transport orders a partition's mail by phase,
+  // emission index, sender): noted as the steps are numbered below
+  std::vector<uint32_t> phases(R, 0);
+  auto note_phase = [&](uint32_t n, uint32_t phase) {
+    const uint32_t step = c->nodes[n]->seq - seq_base[n];  // (the step that has just been numbered)
+    if (step < 8) phases[n] |= phase << (3u * step);
+  };
   *started = true;
   // (jobs_v: delivered batches that hold an election's traffic only - the transport's census says so - take the
   // kernel without the chain code: k_apply_vote_runs_multi)
@@ -122,12 +129,13 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       uint32_t& widest = votes ? widest_v : widest_a;
       jg_engine* e = c->nodes[n];
       if (!rt.n_in[n]) {
-        if (vwords) e->stepped = true, e->seq++;  // (the receiving half of the vote mail is this step too: it has a number on every node)
+        if (vwords) e->stepped = true, e->seq++, note_phase(n, JG_ROUTE_PHASE_DELIVERED);  // (the receiving half of the vote mail is this step too: it has a number on every node)
         continue;
       }
       const size_t o = rt.in_off[n];
       e->stepped = true;
       e->seq++;
+      note_phase(n, JG_ROUTE_PHASE_DELIVERED);
       JgApplyJob j{};
       j.d = e->dev;
       // VoteRequest -> one VoteResponse; VoteResponse -> DROP + Heartbeat on elect() (candidate.rs:108-113): two slots per row
@@ -149,6 +157,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       if (!b.n) continue;
       e->stepped = true;
       e->seq++;
+      note_phase(n, JG_ROUTE_PHASE_INJECTED);
       JgApplyJob j{};
       j.d = e->dev;
       const uint64_t* none = (const uint64_t*)e->d_ones;  // (injected rows carry no blocks: checked above)
@@ -160,7 +169,17 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   std::vector<JgFollowerJob> fjobs;
   if (c->any) {
     if ((rc = cluster_tables_any(c, now_ms, false))) return rc;  // (its own copy, behind the sparse steps' tables)
-  } else if ((rc = cluster_follower_jobs(c, now_ms, fjobs))) return rc;
+    for (uint32_t n = 0; n < R; n++) {  // (every node's two halves: seq - 1 and seq)
+      const uint32_t step = c->nodes[n]->seq - seq_base[n];
+      if (step < 8) phases[n] |= JG_ROUTE_PHASE_LEADER << (3u * (step - 1u)) | JG_ROUTE_PHASE_FOLLOWER << (3u * step);
+    }
+  } else {
+    if ((rc = cluster_follower_jobs(c, now_ms, fjobs))) return rc;
+    for (uint32_t n = 0; n < R; n++)
+      if (n != c->lead) note_phase(n, JG_ROUTE_PHASE_FOLLOWER);
+    // (the lead node's leader half is numbered by jg_step_dense_leader inside cluster_round_body: its next step)
+    if (L->seq - seq_base[c->lead] + 1u < 8) phases[c->lead] |= JG_ROUTE_PHASE_LEADER << (3u * (L->seq - seq_base[c->lead] + 1u));
+  }
   hipStream_t st = L->stream;
   uint32_t* d_cursor = rt.d_count + (size_t)R * ROUTE_WORDS;
   uint32_t* d_keep_n = d_cursor + JG_ROUTE_SEGS;
@@ -215,13 +234,13 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       for (const StepRec& r : e->recs)
         if (r.seq > seq_base[s] && r.d_msg) {
           JgRouteRecJob j{};
-          j.t = t, j.n = r.n, j.per_row = r.msg_per_row, j.step = r.seq - seq_base[s];
+          j.t = t, j.n = r.n, j.per_row = r.msg_per_row, j.step = jg_route_phase(phases[s], r.seq - seq_base[s]);
           j.msg_cnt = r.d_msg_cnt, j.msg = r.d_msg, j.fsm_cnt = r.d_fsm_cnt;
           rjobs.push_back(j);
           widest_r = std::max(widest_r, r.n);
         }
       JgRouteXqJob j{};
-      j.t = t, j.xq = e->dev.xq, j.xq_n = e->dev.xq_n, j.xq_cap = e->dev.xq_cap, j.seq_base = seq_base[s];
+      j.t = t, j.xq = e->dev.xq, j.xq_n = e->dev.xq_n, j.xq_cap = e->dev.xq_cap, j.seq_base = seq_base[s], j.phases = phases[s];
       xjobs.push_back(j);
     }
     rb = rjobs.size() * sizeof(JgRouteRecJob), xb = xjobs.size() * sizeof(JgRouteXqJob);
@@ -236,7 +255,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     for (uint32_t n = 0; n < R; n++) {
       jg_engine* e = c->nodes[n];
       JgVoteHalfJob& j = vjobs.j[n];
-      j.d = e->dev, j.self = n, j.seq = seq_base[n] + 1u, j.step = 1u, j.need = R - 1u, j.now = now_ms;
+      j.d = e->dev, j.self = n, j.seq = seq_base[n] + 1u, j.step = JG_ROUTE_PHASE_DELIVERED, j.need = R - 1u, j.now = now_ms;
       if (e->seq < j.seq) return fail(JG_EDEVICE, "internal: routed round: the delivered step has no number");
     }
   }
@@ -379,7 +398,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     if (kx) {
       if (!rt.xq_keep[s]) HIPCHK(hipMalloc((void**)&rt.xq_keep[s], (size_t)e->dev.xq_cap * sizeof(JgXqRec)));
       hipLaunchKernelGGL(k_route_xq<true>, dim3(256), dim3(JG_BLOCK), 0, st, t, (const JgXqRec*)e->dev.xq, (const uint32_t*)e->dev.xq_n,
-                         e->dev.xq_cap, seq_base[s], rt.xq_keep[s], d_keep_n + s);
+                         e->dev.xq_cap, seq_base[s], phases[s], rt.xq_keep[s], d_keep_n + s);
       HIPCHK(hipMemcpyAsync(e->dev.xq, rt.xq_keep[s], (size_t)kx * sizeof(JgXqRec), hipMemcpyDeviceToDevice, st));
       HIPCHK(hipMemcpyAsync(e->dev.xq_n, d_keep_n + s, 4, hipMemcpyDeviceToDevice, st));
     } else {
@@ -387,7 +406,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     }
   }
   if (emptied.n) hipLaunchKernelGGL(k_route_clear_words, dim3(1), dim3(64), 0, st, emptied);
-  // the staged rows in (destination, group, sender, step, emission) order -> the command columns of every
+  // the staged rows in (destination, group, phase, emission index, sender) order -> the command columns of every
   // node's next round: bucket by (destination, group tile), sort every bucket in LDS (jg_route.h; round 2's library
   // radix sort took 240 us per 1.4 M rows)
   rt.last_total = total, rt.last_fullest_seg = fullest_seg;

@@ -902,6 +902,9 @@ __device__ inline uint32_t jg_follower_heartbeat(const JgDev& d, JgLane& L, uint
 __device__ inline uint32_t jg_follower_vote_request(const JgDev& d, JgLane& L, uint32_t cand, uint64_t last_term,
                                                     uint64_t head) {
   // follower.rs:219-246 with can_vote 97-101
+  // (the vote mail's LEAN visit, jg_votes.h jg_vote_half_group, loads only what this function and jg_vote_for touch of a
+  // healthy follower - flags, term, commit, the {voted_for, leader_id, queued, votes} record - and zero-fills the rest of
+  // the lane: anything else read here must be loaded there too; tests/test_vote_half.py runs both against the oracle)
   bool can = !((L.flags & JGF_VOTED) || L.term > last_term || L.commit > head);
   jg_emit_msg(d, L, JG_CMD_VOTE_RESPONSE, JG_TO_PEER, cand, can ? 1 : 0, L.term, 0, 0);
   if (can) jg_vote_for(L, cand);  // :234

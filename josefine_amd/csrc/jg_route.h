@@ -7,7 +7,14 @@
 // 127-137, tcp.rs:139-170).  These kernels are that path for nodes that share a device: they
 // take the rows addressed to cluster members out of the senders' undrained output (the slots of
 // their sparse steps and their exceptional-row queues) and turn them into the addressees' next
-// command batch, per group in the order (sender slot, step, emission order).  Nothing here
+// command batch, per group in the order (phase of the round, emission index, sender slot): what every sender emitted
+// first in a phase travels before anybody's second row of it, the senders interleaved - each sender's own stream in its
+// own order, which is all a network promises (tcp.rs: one connection per peer pair).  The phases of a routed round are
+// the steps every node takes in lockstep: 1 = the rows delivered by the last round (and the vote mail's receiving half),
+// 2 = the rows injected for this round, 3 = the leader half, 4 = the follower half.  (Until round 6 the order was
+// sender-major - each sender's rows back to back - under which an election of more than three nodes cannot be won: a
+// candidate broadcasts its VoteRequest once per peer (candidate.rs:30-37), a voter grants the first copy and refuses the
+// rest, and the later answer of a voter overwrites the earlier, election.rs:33-35.)  Nothing here
 // interprets a row beyond its address.
 //
 // Not delivered (they stay queued for the host): AppendEntries rows — the payload is the
@@ -22,8 +29,8 @@
 #define JG_ROUTE_STEP_BITS 3u       // a node takes up to 4 steps per routed round (delivered rows, injected rows, leader half, follower half)
 #define JG_ROUTE_ORD_BITS_FAST 12u  // what a round's keys are built with first: 5 sort passes instead of 7 at 1 M groups
 // ordering key of a delivered row, most significant first: destination member (3 bits, right above
-// the group's bits), group, sender slot (3), step of the round (3), emission index within the group's
-// step (ord_bits: the pass reports an index that does not fit and is repeated with the wide field)
+// the group's bits), group, phase of the round (3), emission index within the group's step (ord_bits: the pass
+// reports an index that does not fit and is repeated with the wide field), sender slot (3)
 struct JgRouteTable {
   uint32_t R, src;                      // members, the sending member's index
   uint32_t member_id[JG_MAX_REPLICAS];  // NodeId of member n
@@ -66,8 +73,13 @@ __device__ __forceinline__ uint32_t jg_route_dests_rows(const jg_msg_row& r, con
 __device__ __forceinline__ uint64_t jg_route_key(const JgRouteTable& t, uint32_t dest, uint32_t group, uint32_t step,
                                                  uint32_t ord) {
   if (ord >> t.ord_bits) t.count[t.R + JG_ROUTE_OVERFLOW] = 1;
-  return ((((uint64_t)dest << t.group_bits | group) << 3 | t.src) << JG_ROUTE_STEP_BITS | step) << t.ord_bits | ord;
+  return ((((uint64_t)dest << t.group_bits | group) << JG_ROUTE_STEP_BITS | step) << t.ord_bits | ord) << 3 | t.src;
 }
+// A node's steps of a routed round -> the round's phases (JG_ROUTE_PHASE_*): which of its steps is which depends on what
+// the node had to do (no delivered rows: its first step of the round is the injected rows' or a dense half), so the host
+// hands the map along - 3 bits per step of the round, step i (1 .. 7) at bits [3 i, 3 i + 3).
+enum { JG_ROUTE_PHASE_DELIVERED = 1, JG_ROUTE_PHASE_INJECTED = 2, JG_ROUTE_PHASE_LEADER = 3, JG_ROUTE_PHASE_FOLLOWER = 4 };
+__host__ __device__ __forceinline__ uint32_t jg_route_phase(uint32_t phases, uint32_t step) { return (phases >> (3u * (step & 7u))) & 7u; }
 // One staging reservation per workgroup and tile (every wave of a launch reserving for itself made the
 // one cursor the bottleneck: a returning atomic on a single address retires every ~18 ns, 85 us for the
 // 4.7 k waves of a 300 k-slot step) - and, since ~3 000 workgroup reservations of a round's delivering pass were
@@ -243,7 +255,7 @@ __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_
 // every (sender, step) of a round in ONE launch: blockIdx.y = job (7-8 launches of ~20 us before)
 struct JgRouteRecJob {
   JgRouteTable t;
-  uint32_t n, per_row, step, pad;
+  uint32_t n, per_row, step, pad;  // step: the PHASE of the round this sparse step is (JG_ROUTE_PHASE_*)
   const uint32_t* msg_cnt;
   const jg_msg_row* msg;
   const uint32_t* fsm_cnt;
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_rec_compact(JgRouteTable t, 
 // their own step and emission index).
 template <bool COMPACT, bool WORDS = false>
 __device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const JgXqRec* __restrict__ xq,
-                                                 const uint32_t* __restrict__ xq_n, uint32_t xq_cap, uint32_t seq_base,
+                                                 const uint32_t* __restrict__ xq_n, uint32_t xq_cap, uint32_t seq_base, uint32_t phases,
                                                  JgXqRec* __restrict__ keep, uint32_t* __restrict__ keep_n, const JgVoteMail& vm = JgVoteMail{}) {
   const uint32_t n = min(*xq_n, xq_cap);
   const uint32_t lane = threadIdx.x & 63u;
@@ -314,7 +326,7 @@ __device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const Jg
       }
       continue;
     }
-    const uint32_t step = q.seq - seq_base;
+    const uint32_t step = jg_route_phase(phases, q.seq - seq_base);
     // (a tile of JG_BLOCK queue entries yields up to JG_BLOCK * (R - 1) staged rows: a campaign's VoteRequest goes to every peer)
     constexpr uint32_t CAP = JG_BLOCK * 4;
     __shared__ JgRouteStage<CAP> st;
@@ -326,11 +338,11 @@ __device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const Jg
       jg_route_note(pd_lo, pd_hi, (uint32_t)__ffs(b) - 1u);
       jg_route_note_kind(kd_lo, kd_hi, (uint32_t)__ffs(b) - 1u, q.row.kind);
       if (staged) {
-        jg_stage_put(st, at, jg_route_key(t, (uint32_t)__ffs(b) - 1u, q.row.group, step & 7u, q.k), q.row);
+        jg_stage_put(st, at, jg_route_key(t, (uint32_t)__ffs(b) - 1u, q.row.group, step, q.k), q.row);
         continue;
       }
       if (pos >= sp.lim) continue;
-      t.key[pos] = jg_route_key(t, (uint32_t)__ffs(b) - 1u, q.row.group, step & 7u, q.k);
+      t.key[pos] = jg_route_key(t, (uint32_t)__ffs(b) - 1u, q.row.group, step, q.k);
       t.idx[pos] = pos;
       t.row[pos] = q.row;
     }
@@ -342,23 +354,24 @@ __device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const Jg
 template <bool COMPACT>
 __global__ __launch_bounds__(JG_BLOCK) void k_route_xq(JgRouteTable t, const JgXqRec* __restrict__ xq,
                                                        const uint32_t* __restrict__ xq_n, uint32_t xq_cap,
-                                                       uint32_t seq_base, JgXqRec* __restrict__ keep,
+                                                       uint32_t seq_base, uint32_t phases, JgXqRec* __restrict__ keep,
                                                        uint32_t* __restrict__ keep_n) {
-  jg_route_xq_body<COMPACT>(t, xq, xq_n, xq_cap, seq_base, keep, keep_n);
+  jg_route_xq_body<COMPACT>(t, xq, xq_n, xq_cap, seq_base, phases, keep, keep_n);
 }
 struct JgRouteXqJob {  // the delivering pass over every sender's exceptional-row queue in one launch
   JgRouteTable t;
   const JgXqRec* xq;
   const uint32_t* xq_n;
   uint32_t xq_cap, seq_base;
+  uint32_t phases, pad;  // the sender's steps of the round as phases (jg_route_phase)
 };
 __global__ __launch_bounds__(JG_BLOCK) void k_route_xq_multi(const JgRouteXqJob* __restrict__ jobs) {
   const JgRouteXqJob j = jobs[blockIdx.y];
-  jg_route_xq_body<false>(j.t, j.xq, j.xq_n, j.xq_cap, j.seq_base, nullptr, nullptr);
+  jg_route_xq_body<false>(j.t, j.xq, j.xq_n, j.xq_cap, j.seq_base, j.phases, nullptr, nullptr);
 }
 __global__ __launch_bounds__(JG_BLOCK) void k_route_xq_multi_words(const JgRouteXqJob* __restrict__ jobs, JgVoteMail vm) {
   const JgRouteXqJob j = jobs[blockIdx.y];
-  jg_route_xq_body<false, true>(j.t, j.xq, j.xq_n, j.xq_cap, j.seq_base, nullptr, nullptr, vm);
+  jg_route_xq_body<false, true>(j.t, j.xq, j.xq_n, j.xq_cap, j.seq_base, j.phases, nullptr, nullptr, vm);
 }
 // the census of the same queues (jg_votes.h), before anything is delivered
 __global__ __launch_bounds__(JG_BLOCK) void k_votes_census_xq_multi(const JgRouteXqJob* __restrict__ jobs, JgVoteMail vm) {
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_votes_census_xq_multi(const JgRout
   for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < n; i += gridDim.x * JG_BLOCK) {
     const JgXqRec q = j.xq[i];
     if (q.seq - j.seq_base - 1u >= 7u) continue;  // (not this round's mail)
-    jg_votes_census_row(vm, j.t.src, j.t.member_id[j.t.src], q.row, (q.seq - j.seq_base) & 7u, q.k, jg_route_dests(q.row, j.t));
+    jg_votes_census_row(vm, j.t.src, j.t.member_id[j.t.src], q.row, jg_route_phase(j.phases, q.seq - j.seq_base), q.k, jg_route_dests(q.row, j.t));
   }
 }
 #if JG_BLOCK % 64 == 0
@@ -418,7 +431,7 @@ struct JgRouteCols {
 
 // ---- ordering the staged rows without a library sort ------------------------------------------------
 // The addressees apply their batch per group, so the staging has to come out ordered by (destination,
-// group, sender slot, step, emission index) - the 64-bit key above.  Round 2 did that with one rocPRIM
+// group, phase, emission index, sender slot) - the 64-bit key above.  Round 2 did that with one rocPRIM
 // radix sort over all staged pairs: 5-7 passes, ~15 launches, 240 us per 1.4 M rows, in the timed
 // region of a BASELINE config.  The rows are nearly ordered already (every sender's output is
 // group-major), and what the addressee needs is only *group order with a fixed order inside a group*:
@@ -613,7 +626,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_sort_build(JgRouteBuckets b,
     return;
   }
   // a bucket larger than the LDS tile: every pair's rank by counting the smaller keys (keys are unique:
-  // destination, group, sender, step and emission index name one row)
+  // destination, group, phase, emission index and sender name one row)
   for (uint32_t i = threadIdx.x; i < n; i += JG_BLOCK) {
     const uint64_t k = key[lo + i];
     uint32_t rank = 0;

@@ -1,11 +1,12 @@
-// jg_votes.h - the ELECTION vocabulary as mailbox words (DESIGN.md "What comes next").
-//
-// OPT-IN: a routed round uses this only under JG_ROUTE_VOTE_WORDS=1 (josefine_gpu.hip::round_routed_impl); the default
-// path does not launch anything in this file.  Built when round 4's GPU-minutes were spent, so held to the oracle on the
-// HOST three ways: lane by lane in the device's state machine compiled for the host (tests/host_compiled.py;
-// tests/test_vote_half.py, tests/test_vote_mail.py), as kernels on a stand-in with a workgroup's semantics
-// (tests/test_host_workgroups.py), and through round_routed_impl itself on an emulated device (tests/test_host_device.py) -
-// so that the next GPU-minutes go to the memory system, not to the semantics (profiles/micro/ab_vote_words.sh is the A/B).
+// jg_votes.h - the ELECTION vocabulary as mailbox words: JG_CLUSTER_OPT_VOTE_WORDS (jg_dense_cluster_set_option), a
+// per-cluster option of jg_dense_cluster_round_routed and what bench.py's configs[4] line runs with (DESIGN.md "The vote mail").
+// A campaign's R - 1 VoteRequest broadcasts and the VoteResponses they are answered with travel as ONE record per (sender,
+// partition) read by a dense receiving half (k_vote_half_multi) instead of as rows through the row transport (jg_route.h);
+// what the nodes compute, emit and keep for the host is the row transport's, bit for bit.  Held to the oracle clusters that
+// move every message as a row on the device (tests/test_gpu_vote_words.py, tests/test_dense_node.py::test_stationary_*,
+// tests/test_gpu_fullsize.py) and, without a GPU, lane by lane in the device's state machine compiled for the host
+// (tests/test_vote_half.py, tests/test_vote_mail.py), as kernels on a stand-in with a workgroup's semantics
+// (tests/test_host_workgroups.py) and through round_routed_impl itself on an emulated device (tests/test_host_device.py).
 // What the words say is in tests/election_words.py (numpy), held there to the rows the routed clusters really exchange.
 //
 // One round's vote traffic, per SENDER slot s and partition g (JgVoteMail: two of them, a round reads the last one's
@@ -16,20 +17,27 @@
 //             one it sees writes (q_term, q_head).  A count other than R - 1 (a second campaign in one round) makes the
 //             partition's mail travel as rows for every addressee (k_votes_validate, behind the census).
 //   answer    sender s answers a campaign of node `to` (follower.rs:219-246, candidate.rs:66-84): n VoteResponse{from =
-//             id(s), term, granted}, the first `first`, every further one `rest`.  Written by the vote half itself
-//             (single writer), never rows unless the addressee's partition has to take rows (jg_votes_expand_count / _row).
-//   ord       where a stretch begins in the sender's emission order of the round: step << 8 | emission index (a sender
-//             that answers and campaigns within one round sends both; the transport's order is (sender slot, step, index))
+//             id(s), term, granted}, the first `first`, every further one `rest`, at CONSECUTIVE emission indices.  Written
+//             by the vote half itself (single writer), never rows unless the addressee's partition has to take rows
+//             (jg_votes_expand_count / _row); an answer that does not continue the word - another requester's, or the same
+//             requester's after something else was emitted in between (two campaigns' copies arrive interleaved) - is a
+//             row on the exceptional queue, and the census then makes that addressee's partition take rows.
+//   ord       where a stretch begins in the sender's emission order of the round: phase << 8 | emission index (a sender
+//             that answers and campaigns within one round sends both; the transport's order is (phase, index, sender slot):
+//             jg_route.h)
 // and per ADDRESSEE d two bitmaps over the partitions: rowmail[d] - a row that is not such a word is on its way to d
 // for g - and wordmail[d] - a word is.  The rule (the same in the delivering pass, the expansion and the receiving half):
 // a partition's mail for d travels in words iff EVERYTHING d receives for it this round is such words
 // (jg_votes_as_rows is false); otherwise all of it travels as rows, in the transport's order, as without this file.
 //
 // The receiving half (jg_vote_half_group) applies the words exactly as the rows would have been applied - per partition
-// in the order (sender slot, emission order), one jg_apply per copy, one election_status() per VoteResponse - and emits
-// what the rows would have emitted: the VoteResponses this node gives to ONE requester per partition as its own answer
-// word, everything else (a second requester's answers, the Heartbeat of elect(), candidate.rs:108-113) as rows on the
-// exceptional queue with their emission index, so that words and rows merge back into the reference's emission order.
+// in the transport's order: the senders' stretches MERGED by (ord of the copy, sender slot), i.e. every sender's first
+// copy before anybody's second (what lets an election of five complete: the candidate sees a quorum of first answers
+// before the voters' refusals of the further copies overwrite them, election.rs:33-35), one jg_apply per copy, one
+// election_status() per VoteResponse - and emits what the rows would have emitted: the VoteResponses this node gives to
+// ONE requester per partition as its own answer word, everything else (a second requester's answers, the Heartbeat of
+// elect(), candidate.rs:108-113) as rows on the exceptional queue with their emission index, so that words and rows merge
+// back into the reference's emission order.
 #pragma once
 #include "jg_device.h"
 #include "jg_sparse.h"  // jg_block_exclusive_scan
@@ -139,22 +147,34 @@ __device__ __forceinline__ bool jg_lane_same_state(const JgLane& a, const JgLane
 }
 #define JG_KINDS_VOTES ((1u << JG_CMD_VOTE_REQUEST) | (1u << JG_CMD_VOTE_RESPONSE))
 // one partition of one node: `in` is the last round's mail, `out` this round's; returns the number of quorum decisions
-// taken (election_status evaluations).  `step`: this step's number within the round (the ord of what it emits).
-// What a copy emits goes where jg_emit_msg's mode 4 puts it: the VoteResponses to one requester into the lane's answer
-// word, everything else (a second requester's answers, the Heartbeat of elect(), candidate.rs:108-113) onto the
-// exceptional queue with its emission index - no row buffer.  A stretch is `copies` applications of ONE command (from the
-// second answer on: `rest`), and jg_apply is a function of (replica state, command): a copy that left the replica as it
-// found it says what every further copy does - nothing to the state, the same emission, the same decisions - so the rest
-// of the stretch is accounted for without being run (a voter's 2nd ... R-1st refusal, a candidate's 3rd ... overwrite
-// of one voter's `false`: half of a campaign's applications).
+// taken (election_status evaluations).  `step`: this step's phase of the round (the ord of what it emits).
+// The copies are applied in the TRANSPORT's order: merged over the senders by (ord of the copy, sender slot) - a sender's
+// request stretch holds the ords q_ord .. q_ord + q_n - 1, its answer stretch a_ord .. a_ord + a_n - 1.  The stretches'
+// cursors live in `st` - 2 x JG_MAX_REPLICAS words per lane, `stride` apart: LDS in the kernel (one word per lane and
+// stretch, lanes side by side: as register arrays they cost the kernel 45 VGPRs and a wave per SIMD, and a dynamic
+// index into registers is scratch), a local array on the host - as next ord | copies left << 12 | copies done << 20;
+// the next copy is the minimum of (next ord, sender, kind) over the unfinished stretches.
+// What a copy emits goes where jg_emit_msg's mode 4 puts it: the VoteResponses to one requester, at consecutive emission
+// indices, into the lane's answer word, everything else (a second requester's answers, the Heartbeat of elect(),
+// candidate.rs:108-113) onto the exceptional queue with its emission index - no row buffer.
+// Half of a campaign's applications are not run: where all the stretches of a partition are ALIGNED (the same first ord
+// and the same number of copies: a voter's one campaign; a candidate's R - 1 voters, each answering the R - 1 copies in
+// its delivered step from index 0) the merged order is level by level - copy c of every stretch, senders ascending - and
+// jg_apply is a function of (replica state, command): a level (c >= 1 where answers are read: the first answer may differ
+// from the rest) that left the replica as it found it says what every further level does - nothing to the state, the same
+// emission, the same decisions - so the rest is accounted for without being run (a voter's 2nd ... R-1st refusal, a
+// leader's or a defeated candidate's 2nd ... R-1st round of ignored answers).
+#define JG_VOTE_ST_WORDS (2u * JG_MAX_REPLICAS)
 __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32_t self, const JgVoteMail& in, const JgVoteMail& out, uint32_t need,
-                                              uint64_t now, uint32_t seq, uint32_t step) {
+                                              uint64_t now, uint32_t seq, uint32_t step, uint32_t* st, uint32_t stride) {
   const uint32_t R = d.R;
   if (!((in.wordmail[(size_t)self * in.words + (g >> 6)] >> (g & 63u)) & 1ull)) return 0;
   if (jg_votes_as_rows(in, self, g, need)) return 0;  // (its mail came as rows)
   // A healthy FOLLOWER - four visits of five: the voters - stays one under these two kinds, and all they read or write of
-  // it is the flag word, the term, the commit index and the vote record (follower.rs:97-101,219-246; a VoteResponse at a
-  // follower is ignored): four lines instead of the seven jg_load touches, two stores instead of three.
+  // it is the flag word, the term, the commit index and the vote record (follower.rs:97-101,219-246: can_vote and
+  // apply_vote_request - jg_follower_vote_request / jg_vote_for in jg_device.h must not come to read anything else of a
+  // follower, or this path computes on zeros; a VoteResponse at a follower is ignored): four lines instead of the seven
+  // jg_load touches, two stores instead of three.
   JgLane L;
   const uint32_t f0 = d.flags[g];
   const bool lean = (f0 & (JGF_ROLE_MASK | JGF_FAULT_MASK)) == JG_ROLE_FOLLOWER;
@@ -175,40 +195,65 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
   L.cap_ack = 0, L.cap_hbc = 0;
   L.mp = L.mend = nullptr;
   L.fp = L.fend = nullptr;  // (an election's command queues nothing for the FSM: a row would raise L.overflow)
+  // the senders' stretches: st[2 s] the request's, st[2 s + 1] the answer's; zero where there is none
+  uint32_t n_st = 0, n_ans = 0, ord0 = 0, cnt0 = 0;
+  bool aligned = true;
   for (uint32_t s = 0; s < R; s++) {
-    if (s == self) continue;
-    const size_t i = jg_vote_at(in, s, g);
-    const JgVoteRec rc = in.rec[i];  // (two 16-byte loads: everything this sender said)
-    const uint32_t qc = rc.q_ctl, ac = rc.a_ctl;
-    const uint32_t q_n = qc & 0xffu, a_n = (ac & 0xffu) && ((ac >> 21) & 7u) == self ? (ac & 0xffu) : 0u;
-    if (!q_n && !a_n) continue;
-    // the sender's two stretches in its own emission order
-    const uint32_t q_ord = q_n ? ((qc >> 8) - q_n * (q_n - 1u) / 2u) / q_n : 0u;  // (the copies' ords are consecutive: candidate.rs:24-44 is one loop)
-    const uint32_t a_ord = (ac >> 8) & ((1u << JG_VOTE_ORD_BITS) - 1u);
-    const bool ans_first = q_n && a_n && a_ord < q_ord;
+    uint32_t wq = 0, wa = 0;
+    if (s != self) {
+      const uint64_t ctl = *(const uint64_t*)&in.rec[jg_vote_at(in, s, g)].q_ctl;  // (q_ctl | a_ctl << 32: one 8-byte load)
+      const uint32_t qc = (uint32_t)ctl, ac = (uint32_t)(ctl >> 32);
+      const uint32_t q_n = qc & 0xffu, a_n = (ac & 0xffu) && ((ac >> 21) & 7u) == self ? (ac & 0xffu) : 0u;
+      if (q_n) {  // (the copies' ords are consecutive - candidate.rs:24-44 is one loop - and q_ctl holds their sum)
+        const uint32_t q_ord = ((qc >> 8) - q_n * (q_n - 1u) / 2u) / q_n;
+        wq = (q_ord & 0xfffu) | q_n << 12;
+        aligned = aligned && (!n_st || (q_ord == ord0 && q_n == cnt0));
+        if (!n_st) ord0 = q_ord, cnt0 = q_n;
+        n_st++;
+      }
+      if (a_n) {
+        const uint32_t a_ord = (ac >> 8) & ((1u << JG_VOTE_ORD_BITS) - 1u);
+        wa = a_ord | a_n << 12;
+        aligned = aligned && (!n_st || (a_ord == ord0 && a_n == cnt0));
+        if (!n_st) ord0 = a_ord, cnt0 = a_n;
+        n_st++, n_ans++;
+      }
+    }
+    st[(2u * s) * stride] = wq, st[(2u * s + 1u) * stride] = wa;
+  }
+  JgLane P = L;  // (aligned: the replica at the start of the level)
+  uint32_t in_level = 0, level = 0;
+  for (;;) {
+    uint32_t best = ~0u;  // (ord of the stretch's next copy) << 4 | sender << 1 | answer
+    for (uint32_t k = 0; k < 2u * R; k++) {
+      const uint32_t w = st[k * stride];
+      if ((w >> 12) & 0xffu) best = min(best, (w & 0xfffu) << 4 | k);
+    }
+    if (best == ~0u) break;
+    const uint32_t k = best & 15u, s = k >> 1;
+    const bool do_ans = k & 1u;
+    const uint32_t w = st[k * stride], c = w >> 20;  // (c: this copy's index within its stretch)
+    st[k * stride] = w + 1u - (1u << 12) + (1u << 20);
+    const JgVoteRec* rp = &in.rec[jg_vote_at(in, s, g)];  // (the lines the prologue loaded)
     JgCmd cmd;
     cmd.from = d.node_ids[s];
-    for (int pass = 0; pass < 2; pass++) {
-      const bool do_ans = (pass == 0) == (ans_first || !q_n);
-      if (do_ans ? !a_n : !q_n) continue;
-      const uint32_t copies = do_ans ? a_n : q_n;
-      if (do_ans) cmd.kind = JG_CMD_VOTE_RESPONSE, cmd.term = rc.a_term, cmd.id = 0, cmd.aux = 0;
-      else cmd.kind = JG_CMD_VOTE_REQUEST, cmd.term = rc.q_term, cmd.id = rc.q_head, cmd.aux = cmd.term, cmd.flag = 0;
-      for (uint32_t c = 0; c < copies; c++) {
-        if (do_ans) cmd.flag = (ac >> (c ? 20 : 19)) & 1u;
-        const JgLane P = L;
-        jg_apply<JG_KINDS_VOTES>(d, L, cmd, nullptr, nullptr);
-        const uint32_t rem = copies - 1u - c;
-        if (!rem || (do_ans && !c) || !jg_lane_same_state(L, P)) continue;  // (the first answer may differ from the rest)
-        // every further copy repeats this one; what it emitted: nothing, or one answer that folded into the word
-        const uint32_t rows = L.xq_k - P.xq_k, n = (uint32_t)L.cap_hbc & 0xffu;
-        const bool folded = rows == 1u && n == ((uint32_t)P.cap_hbc & 0xffu) + 1u && n >= 2u;  // (n >= 2: `rest` is this copy's answer)
-        if (rows && !(folded && n + rem <= 255u && L.xq_k + rem <= 256u)) continue;  // (rows of its own: run every copy)
+    if (do_ans) cmd.kind = JG_CMD_VOTE_RESPONSE, cmd.term = rp->a_term, cmd.id = 0, cmd.aux = 0, cmd.flag = (rp->a_ctl >> (c ? 20 : 19)) & 1u;
+    else cmd.kind = JG_CMD_VOTE_REQUEST, cmd.term = rp->q_term, cmd.id = rp->q_head, cmd.aux = cmd.term, cmd.flag = 0;
+    jg_apply<JG_KINDS_VOTES>(d, L, cmd, nullptr, nullptr);
+    if (!aligned || ++in_level != n_st) continue;
+    // a whole level: copy `level` of every stretch
+    const uint32_t rem = cnt0 - 1u - level;
+    if (rem && (level || !n_ans) && jg_lane_same_state(L, P)) {
+      // every further level repeats this one; what it emitted: nothing, or (one stretch) one answer that folded into the word
+      const uint32_t rows = L.xq_k - P.xq_k, n = (uint32_t)L.cap_hbc & 0xffu;
+      const bool folded = n_st == 1u && rows == 1u && n == ((uint32_t)P.cap_hbc & 0xffu) + 1u && n >= 2u;  // (n >= 2: `rest` is this copy's answer)
+      if (!rows || (folded && n + rem <= 255u && L.xq_k + rem <= 256u)) {
         if (folded) L.cap_hbc += rem, L.xq_k += rem;
         L.decisions += rem * (L.decisions - P.decisions);
         break;
       }
     }
+    P = L, in_level = 0, level++;
   }
   if ((uint32_t)L.cap_hbc & 0xffu) {
     const size_t i = jg_vote_at(out, self, g);
@@ -293,6 +338,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_vote_half_multi(JgVoteHalfJobs job
   const JgVoteHalfJob& j = jobs.j[blockIdx.y];
   __shared__ JgBitChunk s;
   __shared__ uint32_t s_g[JG_BLOCK];
+  __shared__ uint32_t s_st[JG_VOTE_ST_WORDS][JG_BLOCK];  // the lanes' stretch cursors (jg_vote_half_group): 16 KB
   uint32_t dec = 0;
   const uint32_t n_chunks = (in.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK;
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {  // (block-uniform trip counts throughout)
@@ -313,7 +359,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_vote_half_multi(JgVoteHalfJobs job
       const uint32_t ex = jg_block_exclusive_scan(heavy, &n_heavy);
       if (threadIdx.x < n) s_g[heavy ? ex : n_heavy + (threadIdx.x - ex)] = g;
       __syncthreads();
-      if (threadIdx.x < n) dec += jg_vote_half_group(j.d, s_g[threadIdx.x], j.self, in, out, j.need, j.now, j.seq, j.step);
+      if (threadIdx.x < n) dec += jg_vote_half_group(j.d, s_g[threadIdx.x], j.self, in, out, j.need, j.now, j.seq, j.step, &s_st[0][threadIdx.x], JG_BLOCK);
       __syncthreads();  // (s_g is the next pass's)
     }
   }

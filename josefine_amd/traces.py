@@ -191,15 +191,16 @@ class FailureRepairTrace:
     the chain from block 1 (Q10), longer with every round the benchmark has run.  So the operator RE-CREATES the partition:
     every replica restarts on an empty data directory (JG_CMD_RECREATE: Raft::new + Chain::new's
     genesis, chain.rs:117-153) and replica `lead` receives Timeout: it campaigns, its VoteRequests are routed and answered
-    through can_vote like any.  One tick later - when a real election's first answers would be in - it is seated: granted
-    VoteResponses from the next R/2 replicas, injected (traces.elect_where's rows, the trace's only synthetic votes: over a
-    transport that delivers each sender's answers back to back an election of more than three nodes cannot be WON,
-    DESIGN.md "The cluster transport"); it is elected, its Heartbeat brings the others in (the voters' real answers
-    arrive at a leader, which ignores them), and the client proposes again.  The partition is then exactly what every
-    partition was at tick 0: the trace is stationary in everything - leaderless fraction (about
-    percent x (repair_after + 1) / 100), decisions per round, cost per round.
+    through can_vote like any, the answers are routed back, and TWO ticks after the re-creation it counts them and is
+    ELECTED by them (candidate.rs:91-113) - NO synthetic vote anywhere in the trace since round 6: the transport delivers
+    every voter's first answer before anybody's second (jg_route.h), so the quorum of grants is seen before the refusals
+    of the further copies overwrite them (election.rs:33-35), also with five nodes.  Its Heartbeat brings the others in,
+    and the client proposes again.  The partition is then exactly what every partition was at tick 0: the trace is
+    stationary in everything - leaderless fraction (about percent x (repair_after + 2) / 100), decisions per round, cost
+    per round.
     rows(tick) must be called for tick = 0, 1, 2, ... in order; returns (per node one group-sorted column dict or None - for
-    jg_dense_cluster_round_routed's `inject` -, the partitions failing this tick, the partitions repaired this tick);
+    jg_dense_cluster_round_routed's `inject` -, the partitions failing this tick, the partitions whose new leader is seated
+    in this tick's round);
     appends() = the ClientRequests per partition for the round of the last rows(): 0 where the partition is down (the
     cluster offers them where the lead node leads when the dense round begins: a partition repaired in this round has its
     leader by then)."""
@@ -210,7 +211,7 @@ class FailureRepairTrace:
         self.ids = np.arange(1, R + 1, dtype=np.uint32) if node_ids is None else np.asarray(node_ids, np.uint32)
         self.down_since = np.full(G, -1, np.int64)
         self.ever_failed = np.zeros(G, bool)
-        self.campaigning = np.zeros(G, bool)  # re-created in the last tick, to be seated in this one
+        self.campaigning = np.zeros(G, np.int8)  # 1: re-created in the last tick (its VoteRequests are being answered), 2: the tick before (elected in this one)
         self.next_tick = 0
 
     def leaderless(self):
@@ -224,11 +225,12 @@ class FailureRepairTrace:
         self.next_tick += 1
         G, R = self.G, self.R
         gg = np.arange(G, dtype=np.uint64) + np.uint64(self.group_base)
-        repaired = np.nonzero(self.campaigning)[0].astype(np.uint32)  # seated now: up again
+        repaired = np.nonzero(self.campaigning == 2)[0].astype(np.uint32)  # the answers arrive in this round: elected, up again
         recreated = np.nonzero((self.down_since >= 0) & (self.down_since == tick - self.D))[0].astype(np.uint32)
         self.down_since[repaired] = -1
-        self.campaigning[:] = False
-        self.campaigning[recreated] = True
+        self.campaigning[repaired] = 0
+        self.campaigning[self.campaigning == 1] = 2
+        self.campaigning[recreated] = 1
         hit = synth_hash(self.seed, tick, gg, 7) % np.uint64(100) < np.uint64(self.percent)
         up = self.down_since < 0
         up[repaired] = False  # (not in the tick of its repair)
@@ -236,10 +238,9 @@ class FailureRepairTrace:
         self.down_since[failing] = tick
         self.ever_failed[failing] = True
         out = [None] * R
-        nf, nc, nr = len(failing), len(recreated), len(repaired)
-        if not nf and not nc and not nr:
+        nf, nc = len(failing), len(recreated)
+        if not nf and not nc:
             return out, failing, repaired
-        voters = [self.ids[(self.lead + k) % R] for k in range(1, R // 2 + 1)]
         for n in range(R):
             kinds, groups, froms, flags, within = [], [], [], [], []
 
@@ -256,12 +257,10 @@ class FailureRepairTrace:
                 add(recreated, (capi.CMD_RECREATE, 0, 0), (capi.CMD_TIMEOUT, 0, 0))
             elif nc:
                 add(recreated, (capi.CMD_RECREATE, 0, 0))
-            if nr and n == self.lead:
-                add(repaired, *[(capi.CMD_VOTE_RESPONSE, v, 1) for v in voters])
             if not kinds:
                 continue
             group = np.concatenate(groups)
-            # group-sorted, a partition's rows in the order given above (the three sets are disjoint)
+            # group-sorted, a partition's rows in the order given above (the two sets are disjoint)
             order = np.lexsort((np.concatenate(within), group))
             out[n] = dict(kind=np.concatenate(kinds)[order], group=group[order], from_=np.concatenate(froms)[order],
                           term=np.ones(len(group), np.uint64), flag=np.concatenate(flags)[order])

@@ -1,6 +1,6 @@
 #!/bin/bash
 # VGPR / SGPR / LDS / scratch per kernel, from the compiler's own resource report for the gfx950 code object
-# (hipcc -Rpass-analysis=kernel-resource-usage on the one translation unit): bash profiles/kernel_resources.sh > profiles/r05/kernel_resources.txt
+# (hipcc -Rpass-analysis=kernel-resource-usage on the one translation unit): bash profiles/kernel_resources.sh > profiles/r06/kernel_resources.txt
 cd "$(dirname "$0")/../josefine_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -c josefine_gpu.hip -o /tmp/jg_dev.o \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "

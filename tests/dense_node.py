@@ -92,7 +92,20 @@ class DenseCluster:
         return outs
 
 
-ROUTE_SRC_INJECT = 7  # injected rows sort after every peer's rows of the same group
+# The phases of a routed round (josefine_amd/csrc/jg_route.h JG_ROUTE_PHASE_*): the steps every node takes in lockstep.
+PHASE_DELIVERED, PHASE_INJECTED, PHASE_LEADER, PHASE_FOLLOWER = 1, 2, 3, 4
+
+
+def emission_index(groups):
+    """emission index of every row within its group, for the rows ONE step drained (group-major, a group's rows in
+    emission order)"""
+    g = np.asarray(groups, np.int64)
+    n = len(g)
+    if not n:
+        return np.zeros(0, np.int64)
+    first = np.r_[True, g[1:] != g[:-1]]
+    start = np.maximum.accumulate(np.where(first, np.arange(n), 0))
+    return np.arange(n) - start
 
 
 def routable(rows, member_ids):
@@ -108,62 +121,100 @@ def routable(rows, member_ids):
 
 
 class RoutedCluster(DenseCluster):
-    """DenseCluster + a transport for the rows outside the mailbox vocabulary (votes, …): what a
+    """DenseCluster + a transport for the rows outside the mailbox vocabulary (votes, ...): what a
     node emits in round t is applied by its addressees at the start of round t+1, per group in
-    the order (sender slot, emission order), followed by the rows injected for that round.  The
-    host-side statement of jg_dense_cluster_round_routed, for any backend."""
+    the order (phase of the round it was emitted in, emission index within the sender's step, sender
+    slot) - every sender's first row of a phase before anybody's second, each sender's stream in its
+    own order (one connection per peer pair: tcp.rs) - followed, as a step of its own, by the rows
+    injected for that round.  The phases are the steps the nodes take in lockstep: the delivered
+    rows, the injected rows, the leader half, the follower half.  The host-side statement of
+    jg_dense_cluster_round_routed, for any backend."""
 
     def __init__(self, factory, G, R, **kw):
         super().__init__(factory, G, R, **kw)
         self.member_ids = np.array([self.nodes[r].node_ids[r] for r in range(R)], dtype=np.uint32)
-        self.inbound = [[] for _ in range(R)]  # per node: list of (src, structured rows)
+        self.inbound = [[] for _ in range(R)]  # per node: list of (src, structured rows, their phases, their emission indices)
         self.kept = [np.zeros(0, dtype=capi.MSG_DTYPE) for _ in range(R)]
         self.delivered = np.zeros(R, dtype=np.int64)
 
-    def _inbound_columns(self, n, inject):
-        parts, srcs = [], []
-        for src, rows in self.inbound[n]:
-            parts.append(dict(kind=rows["kind"], group=rows["group"], from_=rows["from"], term=rows["term"],
-                              id=rows["id"], aux=rows["aux"], flag=rows["flag"]))
-            srcs.append(np.full(len(rows), src, np.int64))
-        if inject is not None and len(inject["kind"]):
-            m = len(inject["kind"])
-            z8, z4 = np.zeros(m, np.uint64), np.zeros(m, np.uint32)
-            parts.append(dict(kind=inject["kind"], group=inject["group"], from_=inject.get("from_", z4),
-                              term=inject.get("term", z8), id=inject.get("id", z8), aux=inject.get("aux", z8),
-                              flag=inject.get("flag", np.zeros(m, np.uint8))))
-            srcs.append(np.full(m, ROUTE_SRC_INJECT, np.int64))
-        self.inbound[n] = []
-        if not parts:
-            return None
-        cols = {k: np.concatenate([np.asarray(p[k]) for p in parts]) for k in parts[0]}
-        src = np.concatenate(srcs)
-        order = np.lexsort((np.arange(len(src)), src, cols["group"]))  # group, then sender, then emission order
-        return {k: v[order] for k, v in cols.items()}
+    def pending(self, n):
+        """rows queued for node n's next round"""
+        return sum(len(p[1]) for p in self.inbound[n])
 
-    def round(self, appends, inject=None, dt_ms=100):
-        now = self.now + dt_ms
-        for n in range(self.R):
-            cols = self._inbound_columns(n, inject[n] if inject else None)
-            if cols is not None:
-                self.delivered[n] += len(cols["kind"])
-                self.nodes[n].submit_columns(**cols)
-                self.nodes[n].step(now)
-        outs = self.dense_round(appends, dt_ms)
-        drained = self.rows.pop()
+    def inbound_order(self, n):
+        """node n's mail in the transport's order: (rows, sender slot of every row, its ord = phase << 8 | emission index)"""
+        parts = self.inbound[n]
+        if not parts:
+            return np.zeros(0, dtype=capi.MSG_DTYPE), np.zeros(0, np.int64), np.zeros(0, np.int64)
+        rows = np.concatenate([p[1] for p in parts])
+        src = np.concatenate([np.full(len(p[1]), p[0], np.int64) for p in parts])
+        phase, k = np.concatenate([p[2] for p in parts]), np.concatenate([p[3] for p in parts])
+        order = np.lexsort((src, k, phase, rows["group"]))  # group, then phase, then emission index, then sender
+        return rows[order], src[order], (phase << 8 | k)[order]
+
+    @staticmethod
+    def columns_of(rows):
+        return dict(kind=rows["kind"], group=rows["group"], from_=rows["from"], term=rows["term"], id=rows["id"], aux=rows["aux"], flag=rows["flag"])
+
+    def _inbound_columns(self, n):
+        rows = self.inbound_order(n)[0]
+        self.inbound[n] = []
+        return self.columns_of(rows) if len(rows) else None
+
+    @staticmethod
+    def _inject_columns(inject):
+        if inject is None or not len(inject["kind"]):
+            return None
+        m = len(inject["kind"])
+        z8, z4 = np.zeros(m, np.uint64), np.zeros(m, np.uint32)
+        return dict(kind=inject["kind"], group=inject["group"], from_=inject.get("from_", z4), term=inject.get("term", z8), id=inject.get("id", z8),
+                    aux=inject.get("aux", z8), flag=inject.get("flag", np.zeros(m, np.uint8)))
+
+    def sparse_steps(self, n, now, inject, emitted):
+        """node n's first two steps of a round: the delivered rows, then the injected ones; what they emit -> emitted"""
+        for phase, cols in ((PHASE_DELIVERED, self._inbound_columns(n)), (PHASE_INJECTED, self._inject_columns(inject))):
+            if cols is None:
+                continue
+            self.delivered[n] += len(cols["kind"])
+            self.nodes[n].submit_columns(**cols)
+            self.nodes[n].step(now)
+            out = self.nodes[n].drain_messages()
+            if len(out):
+                emitted.append((out, np.full(len(out), phase, np.int64), emission_index(out["group"])))
+
+    def transport(self, emitted):
+        """emitted[s]: list of (rows, phase, emission index) of sender s, in the order of its steps"""
         for s in range(self.R):
-            rows = drained[s]
+            if not emitted[s]:
+                continue
+            rows = np.concatenate([e[0] for e in emitted[s]])
+            phase, k = np.concatenate([e[1] for e in emitted[s]]), np.concatenate([e[2] for e in emitted[s]])
             ok = routable(rows, self.member_ids)
             self.kept[s] = np.concatenate([self.kept[s], rows[~ok]])
-            rows = rows[ok]
+            rows, phase, k = rows[ok], phase[ok], k[ok]
             for n in range(self.R):
                 if n == s:
                     continue
                 to_n = (rows["to_kind"] == capi.TO_PEERS) | (rows["to_id"] == self.member_ids[n])
                 if to_n.any():
-                    self.inbound[n].append((s, rows[to_n]))
+                    self.inbound[n].append((s, rows[to_n], phase[to_n], k[to_n]))
+
+    def round(self, appends, inject=None, dt_ms=100):
+        now = self.now + dt_ms
+        emitted = [[] for _ in range(self.R)]
+        for n in range(self.R):
+            self.sparse_steps(n, now, inject[n] if inject else None, emitted[n])
+        outs = self.dense_round(appends, dt_ms)
+        for s, parts in enumerate(self.dense_emitted()):
+            emitted[s].extend(parts)
+        self.transport(emitted)
         return outs
 
+    def dense_emitted(self):
+        """what the dense round just run left in self.rows, per node as (rows, phase, emission index) parts"""
+        drained = self.rows.pop()
+        return [[(rows, np.full(len(rows), PHASE_LEADER if s == self.lead else PHASE_FOLLOWER, np.int64), emission_index(rows["group"]))] if len(rows) else []
+                for s, rows in enumerate(drained)]
 
     def dense_round(self, appends, dt_ms):
         # client requests are offered only where the lead node leads: at a leaderless replica the
@@ -183,7 +234,7 @@ class AnyLeaderCluster(RoutedCluster):
       1. every node's leader half: inbox and ClientRequests only where it owns the group; the owner's Tick goes into the
          cluster's columns, a leader's that is not the owner (two terms' leaders in one round) travels as ROWS;
       2. every node's follower half: mail (sender = the owner) only where somebody else owns the group.
-    Rows are transported exactly as RoutedCluster does."""
+    Rows are transported exactly as RoutedCluster does (every node takes both halves: phases 3 and 4)."""
 
     def __init__(self, factory, G, R, seed=3, group_base=0):
         self.G, self.R, self.lead = G, R, 0
@@ -243,7 +294,7 @@ class AnyLeaderCluster(RoutedCluster):
             self.o_from[:, mine], self.o_n[:, mine] = out["ae_from"][:, mine], out["ae_n"][:, mine]
             lose = np.nonzero(leads[n] & ~mine)[0]
             rows = np.concatenate([self.nodes[n].drain_messages(), self.tick_rows(n, out, lose)])
-            drained[n] = rows[np.argsort(rows["group"], kind="stable")]
+            drained[n] = [rows[np.argsort(rows["group"], kind="stable")]]  # (the leader half's rows; the follower half's below)
         for n in range(R):  # 2. the follower halves
             mail = (owner != OWNER_NONE) & (owner != n)
             sender = self.member_ids[np.where(mail, owner, 0)].astype(np.uint32)
@@ -254,9 +305,14 @@ class AnyLeaderCluster(RoutedCluster):
             self.acks[n] = np.where(keep, fo["ack_head"], self.acks[n])
             self.hbr_has[n] = np.where(keep, fo["hb_has"], self.hbr_has[n])
             self.hbr_commit[n] = np.where(keep, fo["hb_commit"], self.hbr_commit[n])
-            drained[n] = np.concatenate([drained[n], self.nodes[n].drain_messages()])
+            drained[n].append(self.nodes[n].drain_messages())
         self.rows.append(drained)
         return outs
+
+    def dense_emitted(self):
+        drained = self.rows.pop()
+        return [[(rows, np.full(len(rows), phase, np.int64), emission_index(rows["group"])) for rows, phase in zip(halves, (PHASE_LEADER, PHASE_FOLLOWER)) if len(rows)]
+                for halves in drained]
 
 
 from josefine_amd.traces import any_failure_rows, cluster_failure_rows  # noqa: E402,F401  (shared with bench.py)

@@ -4,20 +4,22 @@ steady-state traffic were before their kernels existed (tests/dense_node.py).  T
 product reads this yet; tests/test_election_words.py holds it to the rows the Python statement of the transport
 (RoutedCluster) really delivers on the configs[4] traces, and counts what does not fit.
 
-One round's inbound rows of one node, per partition in the transport's order (sender slot, emission order):
+One round's inbound rows of one node, per partition in the transport's order (phase, emission index, sender slot) - every
+sender's stream in its own order, the senders interleaved (tests/dense_node.py::RoutedCluster); every row carries its
+ord = phase << 8 | emission index within its sender's step:
 
   request word   sender s campaigns (candidate.rs:24-44): `copies` identical VoteRequest{term, candidate_id, last_term = term,
-                 head} - the reference sends one broadcast per configured peer (Q5: `for _node in &self.config.nodes`), so copies == R - 1
-                   -> (term, head, copies)
+                 head} at consecutive ords - the reference sends one broadcast per configured peer (Q5: `for _node in
+                 &self.config.nodes`), so copies == R - 1
+                   -> (ord of the first, term, head, copies)
   answer word    sender s answers this node's campaign (follower.rs:219-246, candidate.rs:66-84): its VoteResponses
-                 {from = s's id, term, granted} to the copies, in order: the first through can_vote, every further one
-                 `false` once the first was granted (voted_for is set by then) or the same refusal again
-                   -> (term, first, rest, copies)   with rest == False whenever copies > 1 and first == True
+                 {from = s's id, term, granted} to the copies, at consecutive ords: the first through can_vote, every further
+                 one `false` once the first was granted (voted_for is set by then) or the same refusal again
+                   -> (ord of the first, term, first, rest, copies)   with rest == False whenever copies > 1 and first == True
 
-What is neither inside a sender's run - the Heartbeat of a fresh leader, its answer - stays a row and keeps its place in
-the run (the words carry where their stretch begins); a stretch that is not uniform (responses that change term halfway)
-stays rows as a whole; so does a voter that answers two candidates of one partition in one round (two
-addressees: the answer word has one)."""
+What is neither - the Heartbeat of a fresh leader, its answer - stays a row and keeps its ord; a stretch that is not uniform
+(responses that change term halfway) stays rows as a whole; so does a voter that answers two candidates of one partition in
+one round (two addressees: the answer word has one; their copies arrive interleaved, so neither's answers are consecutive)."""
 import numpy as np
 
 from josefine_amd import capi
@@ -26,55 +28,55 @@ REQ_DTYPE = np.dtype([("group", "<u4"), ("src", "<i8"), ("at", "<u4"), ("term", 
 ANS_DTYPE = np.dtype([("group", "<u4"), ("src", "<i8"), ("at", "<u4"), ("term", "<u8"), ("first", "u1"), ("rest", "u1"), ("copies", "<u4")])
 
 
-def encode(cols, src, member_ids):
-    """cols: a node's inbound command columns of one round, sorted (group, sender, emission); src: the sender slot of
-    every row (parallel array).  Returns (request words, answer words, mask of the rows that stay rows, every row's
-    ordinal within its (sender, partition) run).  A word stands for a maximal stretch of one sender's VoteRequests /
-    VoteResponses for one partition; `at` is where the stretch begins in the sender's run (a node that is elected and
-    campaigns again within one round sends Heartbeat, then VoteRequests: the stretch begins at 1)."""
+def encode(cols, src, ord_, member_ids):
+    """cols: a node's inbound command columns of one round (any order); src, ord_: the sender slot and the ord of every row
+    (parallel arrays).  Returns (request words, answer words, mask of the rows that stay rows).  A word stands for a maximal
+    stretch of one sender's VoteRequests / VoteResponses for one partition at CONSECUTIVE ords; `at` is the ord of its
+    first copy."""
     n = len(cols["kind"])
     stay = np.ones(n, bool)
-    ordinal = np.zeros(n, np.int64)
     reqs, anss = [], []
     if not n:
-        return np.zeros(0, REQ_DTYPE), np.zeros(0, ANS_DTYPE), stay, ordinal
-    key = cols["group"].astype(np.int64) * 16 + src
+        return np.zeros(0, REQ_DTYPE), np.zeros(0, ANS_DTYPE), stay
+    by = np.lexsort((ord_, src, cols["group"]))  # every (partition, sender) stream, in its own order
+    c = {k: np.asarray(v)[by] for k, v in cols.items()}
+    s_src, s_ord = np.asarray(src)[by], np.asarray(ord_)[by]
+    key = c["group"].astype(np.int64) * 16 + s_src
     starts = np.r_[0, np.nonzero(key[1:] != key[:-1])[0] + 1]
     ends = np.r_[starts[1:], n]
     for a, b in zip(starts, ends):
-        ordinal[a:b] = np.arange(b - a)
-        s = int(src[a])
+        s = int(s_src[a])
         if s < 0 or s >= len(member_ids):
-            continue  # injected rows: not mail
+            continue  # (not a member's mail)
         sid = member_ids[s]
-        k = cols["kind"][a:b]
+        k = c["kind"][a:b]
         i = 0
-        while i < b - a:  # maximal stretches of one vote kind
+        while i < b - a:  # maximal stretches of one vote kind at consecutive ords
             j = i + 1
-            while j < b - a and k[j] == k[i]:
+            while j < b - a and k[j] == k[i] and s_ord[a + j] == s_ord[a + j - 1] + 1:
                 j += 1
             lo, hi = a + i, a + j
             if k[i] == capi.CMD_VOTE_REQUEST:
-                same = (cols["term"][lo:hi] == cols["term"][lo]).all() and (cols["id"][lo:hi] == cols["id"][lo]).all() and \
-                    (cols["aux"][lo:hi] == cols["term"][lo]).all() and (cols["from_"][lo:hi] == sid).all() and (cols["flag"][lo:hi] == 0).all()
+                same = (c["term"][lo:hi] == c["term"][lo]).all() and (c["id"][lo:hi] == c["id"][lo]).all() and \
+                    (c["aux"][lo:hi] == c["term"][lo]).all() and (c["from_"][lo:hi] == sid).all() and (c["flag"][lo:hi] == 0).all()
                 if same:
-                    reqs.append((cols["group"][lo], s, i, cols["term"][lo], cols["id"][lo], hi - lo))
-                    stay[lo:hi] = False
+                    reqs.append((c["group"][lo], s, s_ord[lo], c["term"][lo], c["id"][lo], hi - lo))
+                    stay[by[lo:hi]] = False
             elif k[i] == capi.CMD_VOTE_RESPONSE:
-                f = cols["flag"][lo:hi]
+                f = c["flag"][lo:hi]
                 rest_ok = hi - lo == 1 or (f[1:] == f[1]).all()
-                same = (cols["term"][lo:hi] == cols["term"][lo]).all() and (cols["from_"][lo:hi] == sid).all() and \
-                    (cols["id"][lo:hi] == 0).all() and (cols["aux"][lo:hi] == 0).all()
+                same = (c["term"][lo:hi] == c["term"][lo]).all() and (c["from_"][lo:hi] == sid).all() and \
+                    (c["id"][lo:hi] == 0).all() and (c["aux"][lo:hi] == 0).all()
                 if same and rest_ok:
-                    anss.append((cols["group"][lo], s, i, cols["term"][lo], f[0], f[1] if hi - lo > 1 else 0, hi - lo))
-                    stay[lo:hi] = False
+                    anss.append((c["group"][lo], s, s_ord[lo], c["term"][lo], f[0], f[1] if hi - lo > 1 else 0, hi - lo))
+                    stay[by[lo:hi]] = False
             i = j
-    return np.array(reqs, REQ_DTYPE), np.array(anss, ANS_DTYPE), stay, ordinal
+    return np.array(reqs, REQ_DTYPE), np.array(anss, ANS_DTYPE), stay
 
 
 def decode(reqs, anss, rest, rest_src, rest_ord, member_ids):
-    """the words back into rows, merged with the rows that stayed rows (`rest` columns, their sender slots and ordinals),
-    in the transport's order - what a dense voter / candidate half has to apply"""
+    """the words back into rows, merged with the rows that stayed rows (`rest` columns, their sender slots and ords), in
+    the transport's order - what a dense voter / candidate half has to apply.  Returns (columns, sender slots, ords)."""
     parts, srcs, ords = [], [], []
 
     def rows(m, kind, group, frm, term, id_, aux, flag):
@@ -92,10 +94,10 @@ def decode(reqs, anss, rest, rest_src, rest_ord, member_ids):
         srcs.append(np.full(m, w["src"], np.int64)), ords.append(int(w["at"]) + np.arange(m))
     if len(rest["kind"]):
         parts.append(rest)
-        srcs.append(rest_src), ords.append(rest_ord)
+        srcs.append(np.asarray(rest_src, np.int64)), ords.append(np.asarray(rest_ord, np.int64))
     if not parts:
-        return None, None
+        return None, None, None
     cols = {k: np.concatenate([np.asarray(p[k]) for p in parts]) for k in parts[0]}
-    src = np.concatenate(srcs)
-    order = np.lexsort((np.concatenate(ords), src, cols["group"]))  # (group, sender, emission)
-    return {k: v[order] for k, v in cols.items()}, src[order]
+    src, ord_ = np.concatenate(srcs), np.concatenate(ords)
+    order = np.lexsort((src, ord_, cols["group"]))  # (group, ord, sender): a stable sort - a sender's request stretch before its answer stretch at equal ords
+    return {k: v[order] for k, v in cols.items()}, src[order], ord_[order]

@@ -88,6 +88,7 @@ struct Host {
   uint32_t seq = 0;
   uint64_t n_cmds = 0, decisions = 0;
   std::vector<jg_msg_row> msgs;
+  size_t msgs_mark = 0;  // (hc_cluster_any_round: the rows queued when the node's leader half was done - the follower half's come behind)
   std::vector<jg_fsm_row> fsm;
   std::vector<JgFaultRec> faults;
   int err = 0;
@@ -216,6 +217,7 @@ extern "C" size_t hc_drain_faults(Host* h, jg_fault_row* out, size_t cap) {
   }
   return n;
 }
+extern "C" size_t hc_msgs_mark(Host* h) { return h->msgs_mark; }
 extern "C" void hc_counters(Host* h, uint64_t* out) { out[0] = h->n_cmds, out[1] = h->decisions, out[2] = 0, out[3] = 0; }
 // jg_read_state's decoding, through the state machine's own jg_load
 extern "C" int hc_read(Host* h, int field, uint32_t replica, void* out) {
@@ -503,6 +505,7 @@ extern "C" int hc_cluster_any_round(Host** hs, uint32_t R, uint64_t now, uint64_
     }
     blockIdx.x = 0, gridDim.x = 1;
     collect_after_dense(h);
+    h->msgs_mark = h->msgs.size();
     d.xq = nullptr, d.xq_cap = 0;
     if (h->status[0]) return (int)h->status[0];
   }
@@ -593,7 +596,8 @@ extern "C" int hc_vote_half(Host* h, uint32_t self, uint64_t now, uint32_t step,
   JgDev& d = h->d;
   h->seq++;
   d.xq = h->xq.data(), d.xq_cap = (uint32_t)h->xq.size();
-  for (uint32_t g = 0; g < d.G; g++) h->decisions += jg_vote_half_group(d, g, self, *in, *out, need, now, h->seq, step);
+  uint32_t st[JG_VOTE_ST_WORDS];  // (a lane's stretch cursors: LDS on the device)
+  for (uint32_t g = 0; g < d.G; g++) h->decisions += jg_vote_half_group(d, g, self, *in, *out, need, now, h->seq, step, st, 1);
   const uint32_t nx = *d.xq_n;
   std::vector<JgXqRec> x(h->xq.data(), h->xq.data() + nx);
   std::sort(x.begin(), x.end(), [](const JgXqRec& a, const JgXqRec& b) { return a.row.group != b.row.group ? a.row.group < b.row.group : a.k < b.k; });
@@ -790,6 +794,8 @@ def build():
         f.restype = C.c_size_t
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.hc_counters.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hc_msgs_mark.restype = C.c_size_t
+    lib.hc_msgs_mark.argtypes = [C.c_void_p]
     lib.hc_read.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
     lib.hc_leader_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.hc_follower_half.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -955,10 +961,11 @@ class HostCompiled:
         return C.cast(_fast.hf_follower_tick, C.c_void_p) if self.fast else None
 
     # -- the dense halves: the dense kernels' per-group logic, then the slow kernels' bodies (the interface of BatchedRaft's column forms) --
-    def vote_half(self, self_slot, now_ms, words, R=None):
+    def vote_half(self, self_slot, now_ms, words, R=None, step=0):
         """jg_votes.h's receiving half on words given as plain columns (dict of [R, G] arrays: q_term, q_head, q_n, q_at, a_term,
-        a_n, a_at, a_bits, a_to; any number of copies) -> (this node's answer word columns, its exceptional rows, their emission
-        indices)"""
+        a_n, a_at, a_bits, a_to; q_at / a_at: the ord - phase << 8 | emission index - of a stretch's first copy; any number of
+        copies) -> (this node's answer word columns - `at`: its ord, `step` << 8 | emission index -, its exceptional rows, their
+        emission indices)"""
         G, R = self.G, self.R
         inn, out = VoteMail(R, G), VoteMail(R, G)
         n = words["q_n"].astype(np.uint32)
@@ -973,9 +980,9 @@ class HostCompiled:
         has = ((n != 0) | mine)
         has[self_slot] = False
         inn.set_bits(inn.wordmail, self_slot, np.nonzero(has.any(axis=0))[0])
-        xrows, xk = self.vote_half_mail(self_slot, now_ms, inn, out, step=0, need=0)
+        xrows, xk = self.vote_half_mail(self_slot, now_ms, inn, out, step=step, need=0)
         c = out.a_ctl[self_slot]
-        res = dict(term=out.a_term[self_slot].copy(), n=(c & 0xff).astype(np.uint8), at=(c >> 8 & 0xff).astype(np.uint8),
+        res = dict(term=out.a_term[self_slot].copy(), n=(c & 0xff).astype(np.uint8), at=(c >> 8 & 0x7ff).astype(np.uint32),
                    bits=((c >> 19) & 3).astype(np.uint8), to=((c >> 21) & 7).astype(np.uint8))
         return res, xrows, xk
 
@@ -1124,6 +1131,11 @@ def host_any_leader_cluster(G, R, seed=3):
                                           self.nodes[0]._fast_leader(), self.nodes[0]._fast_follower())
             assert rc == 0, f"host-compiled any-leader round: error {rc}"
             self.owner = self.owner_col[:G].copy()
-            self.rows.append([n.drain_messages() for n in self.nodes])
+            drained = []
+            for n in self.nodes:  # (a node's two halves are two steps: the leader half's rows, then the follower half's)
+                mark = int(lib.hc_msgs_mark(n._h))
+                rows = n.drain_messages()
+                drained.append([rows[:mark], rows[mark:]])
+            self.rows.append(drained)
             return {}
     return HostAnyLeaderCluster()

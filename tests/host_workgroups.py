@@ -374,7 +374,8 @@ VIS void hw_selftest(const uint32_t* in, uint32_t n, uint32_t* excl, uint32_t* t
 struct WgSender {           // what one sender emitted this round
   const JgXqRec* xq;        // its exceptional queue
   uint32_t xq_n, seq_base;
-  uint32_t rec_n, rec_per_row, rec_step;  // one sparse step's output region (rec_n = 0: none)
+  uint32_t rec_n, rec_per_row, rec_step;  // one sparse step's output region (rec_n = 0: none); rec_step: its PHASE of the round
+  uint32_t phases;                        // the sender's steps of the round as phases (jg_route_phase): for its exceptional queue's rows
   const uint32_t* msg_cnt;
   const jg_msg_row* msg;
   const uint32_t* fsm_cnt;
@@ -422,7 +423,7 @@ VIS int hw_route(const WgRoute* rt, const WgSender* snd, const JgVoteMail* vm, u
       widest_r = std::max(widest_r, j.n);
     }
     JgRouteXqJob j{};
-    j.t = t, j.xq = snd[s].xq, j.xq_n = &snd[s].xq_n, j.xq_cap = snd[s].xq_n + 1, j.seq_base = snd[s].seq_base;
+    j.t = t, j.xq = snd[s].xq, j.xq_n = &snd[s].xq_n, j.xq_cap = snd[s].xq_n + 1, j.seq_base = snd[s].seq_base, j.phases = snd[s].phases;
     xjobs.push_back(j);
   }
   JgRouteBuckets bk{};
@@ -546,7 +547,10 @@ def build():
 
 class _WgSender(C.Structure):
     _fields_ = [("xq", C.c_void_p), ("xq_n", C.c_uint32), ("seq_base", C.c_uint32), ("rec_n", C.c_uint32), ("rec_per_row", C.c_uint32),
-                ("rec_step", C.c_uint32), ("msg_cnt", C.c_void_p), ("msg", C.c_void_p), ("fsm_cnt", C.c_void_p)]
+                ("rec_step", C.c_uint32), ("phases", C.c_uint32), ("msg_cnt", C.c_void_p), ("msg", C.c_void_p), ("fsm_cnt", C.c_void_p)]
+
+
+PHASES_IDENTITY = sum(i << (3 * i) for i in range(1, 8))  # step i of the round IS phase i
 
 
 class _JgRouteCols(C.Structure):
@@ -590,7 +594,8 @@ class Transport:
                          term=np.zeros(cap, np.uint64), id=np.zeros(cap, np.uint64), aux=np.zeros(cap, np.uint64))
 
     def route(self, senders, mail):
-        """senders: per slot dict(xq=XQ_DTYPE array, seq_base, rec=None | (step, msg_cnt [n], msg [n, per_row] rows)); returns
+        """senders: per slot dict(xq=XQ_DTYPE array, seq_base, rec=None | (phase, msg_cnt [n], msg [n, per_row] rows)[, phases = the
+        map from the queue rows' steps to the round's phases: 3 bits per step, default the identity]); returns
         (per addressee: command columns, rows per (sender -> addressee), kinds per addressee, rows that stay per sender)"""
         R = self.R
         arr = (_WgSender * R)()
@@ -598,7 +603,7 @@ class Transport:
         for s, sd in enumerate(senders):
             xq = np.ascontiguousarray(sd["xq"])
             keep.append(xq)
-            arr[s].xq, arr[s].xq_n, arr[s].seq_base = xq.ctypes.data, len(xq), sd["seq_base"]
+            arr[s].xq, arr[s].xq_n, arr[s].seq_base, arr[s].phases = xq.ctypes.data, len(xq), sd["seq_base"], sd.get("phases", PHASES_IDENTITY)
             if sd.get("rec") is not None:
                 step, cnt, msg = sd["rec"]
                 cnt, msg = np.ascontiguousarray(cnt, np.uint32), np.ascontiguousarray(msg)

@@ -46,7 +46,7 @@ def one(seed, R, percent, also, G, T, stationary=False):
         ora.round(appends, inject=inj)
         for n in range(R):
             compare_snapshots(nodes[n], ora.nodes[n], f"seed {seed} round {t} node {n}")
-        want = [sum(len(r) for _, r in ora.inbound[n]) for n in range(R)]
+        want = [ora.pending(n) for n in range(R)]
         assert all(a <= b for a, b in zip(st["delivered"], want)), (seed, t, st["delivered"], want)
         as_rows += sum(st["delivered"])
         moved += sum(want)

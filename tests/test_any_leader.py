@@ -64,7 +64,7 @@ def run_trace(cl, G, R, T, percent, lib=None, nodes=None, seed=99, recreate=Fals
             st = lib.round_routed((t + 1) * 100, up)
             for n in range(R):
                 compare_snapshots(nodes[n], cl.nodes[n], f"round {t} node {n}")
-            assert st["delivered"] == [sum(len(r) for _, r in cl.inbound[n]) for n in range(R)], t
+            assert st["delivered"] == [cl.pending(n) for n in range(R)], t
             for rows in up:
                 if rows is not None:
                     rows.free()
@@ -194,7 +194,7 @@ def test_any_leader_rounds_replayed_as_a_graph(R):
         ora.dense_round(appends, 100)
     for n in range(R):
         compare_snapshots(nodes[n], ora.nodes[n], f"node {n}")
-        want = np.concatenate([rows[n] for rows in ora.rows])
+        want = np.concatenate([np.concatenate(rows[n]) for rows in ora.rows])  # (a node's two halves of a round: two steps)
         got = nodes[n].drain_messages()
         assert got.tobytes() == want.tobytes(), (n, len(got), len(want))
         assert nodes[n].drain_faults().tobytes() == ora.nodes[n].drain_faults().tobytes()

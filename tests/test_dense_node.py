@@ -491,7 +491,7 @@ def test_stationary_failure_repair_trace_device_parity(R, words):
         ora.round(tr.appends(), inject=inj)
         for n in range(R):
             compare_snapshots(nodes[n], ora.nodes[n], f"round {t} node {n}")
-        want = [sum(len(r) for _, r in ora.inbound[n]) for n in range(R)]
+        want = [ora.pending(n) for n in range(R)]
         assert (st["delivered"] == want) if not words else all(a <= b for a, b in zip(st["delivered"], want)), (t, st["delivered"], want)
         for rows in up + lists:
             if rows is not None:
@@ -537,7 +537,7 @@ def test_routed_cluster_device_transport_parity(R, percent, also):
         ora.round(np.ones(G, np.uint64), inject=inj)
         for n in range(R):
             compare_snapshots(nodes[n], ora.nodes[n], f"routed round {t} node {n}")
-        assert st["delivered"] == [sum(len(r) for _, r in ora.inbound[n]) for n in range(R)], t
+        assert st["delivered"] == [ora.pending(n) for n in range(R)], t
         if t == 25:
             assert st["fsm_rows"] > 0
         for rows in up:

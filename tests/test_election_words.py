@@ -5,35 +5,23 @@ import numpy as np
 import pytest
 
 from josefine_amd import capi
-from dense_node import ROUTE_SRC_INJECT, RoutedCluster, cluster_failure_rows
+from dense_node import RoutedCluster, cluster_failure_rows
 from election_words import decode, encode
 from oracle_lib import oracle_engine
 
 
 class Recording(RoutedCluster):
-    """RoutedCluster that keeps, per node and round, the inbound batch and the sender slot of every row"""
+    """RoutedCluster that keeps, per node and round, the delivered batch with the sender slot and the ord of every row"""
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self.batches = []
 
-    def _inbound_columns(self, n, inject):
-        srcs = [np.full(len(rows), src, np.int64) for src, rows in self.inbound[n]]
-        if inject is not None and len(inject["kind"]):
-            srcs.append(np.full(len(inject["kind"]), ROUTE_SRC_INJECT, np.int64))
-        cols = super()._inbound_columns(n, inject)
-        if cols is not None:
-            src = np.concatenate(srcs)
-            # the same stable order the statement used: group, then sender, then emission
-            parts_group = np.concatenate([rows["group"] for _, rows in self._last_inbound[n]] +
-                                         ([inject["group"]] if inject is not None and len(inject["kind"]) else []))
-            order = np.lexsort((np.arange(len(src)), src, parts_group))
-            self.batches.append((n, cols, src[order]))
-        return cols
-
-    def round(self, appends, inject=None, dt_ms=100):
-        self._last_inbound = [list(x) for x in self.inbound]
-        return super().round(appends, inject, dt_ms)
+    def _inbound_columns(self, n):
+        rows, src, ord_ = self.inbound_order(n)
+        if len(rows):
+            self.batches.append((n, self.columns_of(rows), src, ord_))
+        return super()._inbound_columns(n)
 
 
 @pytest.mark.parametrize("R,percent,also", [(5, 2, ()), (3, 3, (2,)), (5, 3, (2,))])
@@ -44,15 +32,14 @@ def test_vote_traffic_round_trips_through_the_words(R, percent, also):
         inj = cluster_failure_rows(99, t, G, R, percent, also=also) if t >= 3 else None
         cl.round(np.ones(G, np.uint64), inject=inj)
     votes = fit = words = two_addressees = 0
-    for n, cols, src in cl.batches:
-        mail = src != ROUTE_SRC_INJECT
-        is_vote = mail & np.isin(cols["kind"], (capi.CMD_VOTE_REQUEST, capi.CMD_VOTE_RESPONSE))
-        reqs, anss, stay, ordinal = encode(cols, src, cl.member_ids)
+    for n, cols, src, ord_ in cl.batches:
+        is_vote = np.isin(cols["kind"], (capi.CMD_VOTE_REQUEST, capi.CMD_VOTE_RESPONSE))
+        reqs, anss, stay = encode(cols, src, ord_, cl.member_ids)
         rest = {k: v[stay] for k, v in cols.items()}
-        back, back_src = decode(reqs, anss, rest, src[stay], ordinal[stay], cl.member_ids)
+        back, back_src, back_ord = decode(reqs, anss, rest, src[stay], ord_[stay], cl.member_ids)
         for k in cols:
             assert np.array_equal(back[k], cols[k]), (n, k)
-        assert np.array_equal(back_src, src)
+        assert np.array_equal(back_src, src) and np.array_equal(back_ord, ord_)
         votes += int(is_vote.sum())
         fit += int((is_vote & ~stay).sum())
         words += len(reqs) + len(anss)

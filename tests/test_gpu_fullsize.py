@@ -173,7 +173,7 @@ def test_full_size_routed_cluster_failures():
 def test_full_size_stationary_trace_with_the_vote_mail():
     """BASELINE configs[4] as bench.py times it since round 5, at full size: 5 nodes x 1 M partitions, the STATIONARY trace
     (josefine_amd.traces.FailureRepairTrace: 1 %/round failures, the partition re-created 8 rounds later - JG_CMD_RECREATE at
-    every replica, replica 0 seated a round after) with the election's traffic as mailbox words (JG_CLUSTER_OPT_VOTE_WORDS),
+    every replica, replica 0 campaigns and is ELECTED through the transport two rounds after: no synthetic vote) with the election's traffic as mailbox words (JG_CLUSTER_OPT_VOTE_WORDS),
     the client's proposals withdrawn and offered again on the device.  Oracle clusters that move every message as a row
     re-run windows of the partitions and must agree on every state column of every node; the whole population through
     what the trace implies (leadership exactly where it says, re-created partitions appending again, no fault, no row kept)."""
@@ -206,7 +206,7 @@ def test_full_size_stationary_trace_with_the_vote_mail():
                 rows.free()
     L = nodes[0]
     down = tr.leaderless()
-    assert 0.06 < down.mean() < 0.10 and tr.ever_failed.mean() > 0.25
+    assert 0.06 < down.mean() < 0.12 and tr.ever_failed.mean() > 0.25  # (about p x (D + 2): a re-created partition's election takes two rounds)
     role = L.read("role")
     assert (role[down] != capi.ROLE_LEADER).all() and (role[~down] == capi.ROLE_LEADER).all()
     never = ~tr.ever_failed
@@ -233,9 +233,11 @@ def test_full_size_stationary_trace_with_the_vote_mail():
     lib.close()
 
 
-@pytest.mark.parametrize("recreate", [False, True], ids=["restart", "recreate"])
-def test_full_size_any_leader_cluster_elections_and_failures(recreate):
-    """(recreate: the failing groups come back on EMPTY stores, JG_CMD_RECREATE - any group, any number of times, the client
+@pytest.mark.parametrize("R,recreate", [(3, False), (3, True), (5, False), (5, True)], ids=["restart-3", "recreate-3", "restart-5", "recreate-5"])
+def test_full_size_any_leader_cluster_elections_and_failures(R, recreate):
+    """(R = 5, since round 6: a FIVE-node election is won through the device transport like a three-node one - it delivers every
+    voter's first answer before anybody's second, so the candidate holds its quorum of grants before the refusals of its
+    further copies overwrite them: candidate.rs:30-37, election.rs:33-35.  recreate: the failing groups come back on EMPTY stores, JG_CMD_RECREATE - any group, any number of times, the client
     never stops proposing: bench.py --cluster --any-leader --failures 1 --recreate, the stationary trace whose every vote is real.)
     Per-partition leadership at full size (jg_dense_cluster_create, JG_CLUSTER_ANY_LEADER): 3 nodes x 1 M partitions;
     every partition's leader is ELECTED through the device transport (Timeout at the designated candidate, VoteRequests
@@ -249,7 +251,7 @@ def test_full_size_any_leader_cluster_elections_and_failures(recreate):
     from josefine_amd.traces import any_failure_rows
     from dense_node import AnyLeaderCluster
 
-    G, R, T, W, P, F0 = 1_000_000, 3, 26, 1024, 1, 8
+    G, T, W, P, F0 = 1_000_000, 26, 1024, 1, 8
     nodes = [BatchedRaft(G, R, seed=9 + r, self_slots=np.full(G, r, np.uint8), flags=capi.CFG_SEPARATE_COMMIT_KEY)
              for r in range(R)]
     lib = LibCluster(nodes, lead=None)
@@ -283,7 +285,7 @@ def test_full_size_any_leader_cluster_elections_and_failures(recreate):
         for rows in up:
             if rows is not None:
                 rows.free()
-    assert delivered >= 4 * G  # every election's VoteRequests and VoteResponses went through the transport
+    assert delivered >= 2 * (R - 1) * (R - 1) * G  # every election's VoteRequests and VoteResponses went through the transport: R - 1 copies to each of R - 1 peers, and as many answers
     assert 0.1 * G < failed.sum() < 0.25 * G
     healthy = ~failed
     rounds_with_appends = T - 4

@@ -47,7 +47,7 @@ def test_routed_cluster_with_the_vote_mail(R, percent, also, G, T):
         if G <= 3000 or t % 5 == 4 or t == T - 1:
             for n in range(R):
                 compare_snapshots(nodes[n], ora.nodes[n], f"routed round {t} node {n}")
-        want = [sum(len(r) for _, r in ora.inbound[n]) for n in range(R)]
+        want = [ora.pending(n) for n in range(R)]
         assert all(a <= b for a, b in zip(st["delivered"], want)), (t, st["delivered"], want)
         moved_as_rows += sum(st["delivered"])
         moved += sum(want)
@@ -92,7 +92,7 @@ def test_any_leader_cluster_with_the_vote_mail(R, percent, dual, G, T):
         st = lib.round_routed((t + 1) * 100, up)
         for n in range(R):
             compare_snapshots(nodes[n], ora.nodes[n], f"round {t} node {n}")
-        want = [sum(len(r) for _, r in ora.inbound[n]) for n in range(R)]
+        want = [ora.pending(n) for n in range(R)]
         assert all(a <= b for a, b in zip(st["delivered"], want)), (t, st["delivered"], want)
         moved_as_rows += sum(st["delivered"])
         moved += sum(want)

@@ -9,12 +9,11 @@ import numpy as np
 import pytest
 
 from josefine_amd import capi
-from dense_node import RoutedCluster, cluster_failure_rows, routable
+from dense_node import PHASE_DELIVERED, PHASE_FOLLOWER, PHASE_INJECTED, PHASE_LEADER, RoutedCluster, cluster_failure_rows, emission_index, routable
 from host_compiled import HostCompiled, VoteMail
 import host_workgroups as hw
 from oracle_lib import oracle_engine
 from parity import compare_snapshots
-from test_vote_mail import ranks_within_groups
 from vote_mail_cases import check_mail, random_emissions
 
 
@@ -82,7 +81,7 @@ def rows_by_partition(out, R):
 @pytest.mark.parametrize("R,seed,words", [(3, 1, False), (5, 2, False), (3, 3, True), (4, 4, True), (5, 5, True), (5, 6, True)])
 def test_the_transports_kernels_on_random_emissions(R, seed, words):
     """words = False: the product's default delivering pass + bucket pass + in-LDS sort deliver exactly the plain
-    transport's rows, per addressee in (partition, sender, step, emission) order; words = True: the census, the word-aware
+    transport's rows, per addressee in (partition, phase, emission index, sender) order; words = True: the census, the word-aware
     delivering pass and the expansion - per addressee and partition EITHER all of the plain rows OR words that say them"""
     G = 96
     rng = np.random.default_rng(seed)
@@ -136,7 +135,7 @@ class KernelMailCluster(RoutedCluster):
         self.lib.hw_votes_clear(C.addressof(cur.c))  # (sparse: the control words of the partitions a wordmail bit names)
         assert not (cur.q_ctl.any() or cur.a_ctl.any() or cur.rowmail.any() or cur.wordmail.any()), "the mail of two rounds ago was not cleared"
         seq = np.zeros(R, np.uint32)
-        rc = self.lib.hw_vote_half_multi(self.handles, R, seq.ctypes.data, 1, now, C.addressof(prev.c), C.addressof(cur.c), 2)
+        rc = self.lib.hw_vote_half_multi(self.handles, R, seq.ctypes.data, PHASE_DELIVERED, now, C.addressof(prev.c), C.addressof(cur.c), 2)
         assert rc == 0, rc
         senders = []
         kept_now = [[] for _ in range(R)]
@@ -144,44 +143,47 @@ class KernelMailCluster(RoutedCluster):
             cap = (R + 3) * G + 64
             q = np.zeros(cap, hw.XQ_DTYPE)
             m = self.lib.hw_take_xq(self.nodes[n]._h, q.ctypes.data, cap)
-            xq = [q[:m]]
+            xq = [q[:m]]  # (the vote half's rows: the step numbered seq_base + 1, phase 1)
             seq_base = int(seq[n]) - 1
+            # the delivered rows - phase 1 too, other partitions than the words' - as a sparse step's output region: a slot per
+            # partition, its rows back to back
             cols = self.next_rows[n]
-            inj = inject[n] if inject else None
-            if cols is None:
-                cols = {k: np.zeros(0, v) for k, v in dict(kind=np.uint8, group=np.uint32, from_=np.uint32, term=np.uint64, id=np.uint64, aux=np.uint64, flag=np.uint8).items()}
-            self.delivered[n] += len(cols["kind"])
-            self.rows_moved += len(cols["kind"])
-            if inj is not None and len(inj["kind"]):
-                m_ = len(inj["kind"])
-                z8, z4 = np.zeros(m_, np.uint64), np.zeros(m_, np.uint32)
-                ic = dict(kind=inj["kind"], group=inj["group"], from_=inj.get("from_", z4), term=inj.get("term", z8), id=inj.get("id", z8),
-                          aux=inj.get("aux", z8), flag=inj.get("flag", np.zeros(m_, np.uint8)))
-                cols = {k: np.concatenate([cols[k], np.asarray(ic[k])]) for k in cols}
-                order = np.argsort(cols["group"], kind="stable")
-                cols = {k: v[order] for k, v in cols.items()}
-                self.delivered[n] += m_
             rec = None
-            if len(cols["kind"]):
+            if cols is not None:
+                self.delivered[n] += len(cols["kind"])
+                self.rows_moved += len(cols["kind"])
                 self.nodes[n].submit_columns(**cols)
                 self.nodes[n].step(now)
                 out = self.nodes[n].drain_messages()
                 kept_now[n].append(out)
-                if len(out):  # a sparse step's output region: a slot per partition, its rows back to back
+                if len(out):
                     groups, first = np.unique(out["group"], return_index=True)
                     cnt = np.diff(np.r_[first, len(out)]).astype(np.uint32)
                     msg = np.zeros((len(groups), int(cnt.max())), capi.MSG_DTYPE)
                     for i, (a, c) in enumerate(zip(first, cnt)):
                         msg[i, :c] = out[a:a + c]
-                    rec = (2, cnt, msg)
-            senders.append(dict(xq=xq, seq_base=seq_base, rec=rec))
+                    rec = (PHASE_DELIVERED, cnt, msg)
+            # the injected rows: a step of their own (numbered seq_base + 2, phase 2); its rows reach the transport through the queue here
+            ic = self._inject_columns(inject[n] if inject else None)
+            if ic is not None:
+                self.delivered[n] += len(ic["kind"])
+                self.nodes[n].submit_columns(**ic)
+                self.nodes[n].step(now)
+                out = self.nodes[n].drain_messages()
+                kept_now[n].append(out)
+                q2 = np.zeros(len(out), hw.XQ_DTYPE)
+                q2["row"], q2["seq"], q2["k"] = out, seq_base + 2, emission_index(out["group"])
+                xq.append(q2)
+            # (the node's steps of the round -> phases: 1, 2, then its dense half - numbered seq_base + 3 below)
+            phases = PHASE_DELIVERED << 3 | PHASE_INJECTED << 6 | (PHASE_LEADER if n == self.lead else PHASE_FOLLOWER) << 9
+            senders.append(dict(xq=xq, seq_base=seq_base, rec=rec, phases=phases))
         outs = self.dense_round(appends, dt_ms)
         drained = self.rows.pop()
         for s in range(R):
             d = drained[s]
             kept_now[s].append(d)
             q = np.zeros(len(d), hw.XQ_DTYPE)
-            q["row"], q["seq"], q["k"] = d, senders[s]["seq_base"] + 3, ranks_within_groups(d["group"])
+            q["row"], q["seq"], q["k"] = d, senders[s]["seq_base"] + 3, emission_index(d["group"])
             senders[s]["xq"] = np.concatenate(senders[s]["xq"] + [q])
         for s in range(R):  # (the vote half's rows are all mail; what stays is what the rows' step and the dense round kept, in drain order)
             rows = np.concatenate(kept_now[s])
@@ -222,7 +224,7 @@ def test_routed_round_with_the_vote_mail_in_the_devices_kernels(R, percent, also
         assert dev.nodes[n].counters()["decisions"] == ora.nodes[n].counters()["decisions"], n
         assert dev.nodes[n].drain_faults().tobytes() == ora.nodes[n].drain_faults().tobytes()
     pending_dev = np.array([0 if c is None else len(c["kind"]) for c in dev.next_rows])
-    pending_ora = np.array([sum(len(rows) for _, rows in ora.inbound[n]) for n in range(R)])
+    pending_ora = np.array([ora.pending(n) for n in range(R)])
     # (rows are counted when applied, the words' copies when sent)
     assert (ora.delivered + pending_ora).tolist() == (dev.delivered + pending_dev).tolist()
     assert dev.rows_moved < int(ora.delivered.sum()) // 2 or percent >= 10

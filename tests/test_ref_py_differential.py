@@ -208,8 +208,8 @@ def test_routed_cluster_ref_py_vs_oracle(R, also):
                         assert np.array_equal(ref.nodes[n].read("match", q), ora.nodes[n].read("match", q)), (t, n, q)
                 else:
                     assert np.array_equal(ref.nodes[n].read(name), ora.nodes[n].read(name)), (t, n, name)
-            a = [r for _, r in ref.inbound[n]]
-            b = [r for _, r in ora.inbound[n]]
+            a = [p[1] for p in ref.inbound[n]]
+            b = [p[1] for p in ora.inbound[n]]
             assert len(a) == len(b) and all(x.tobytes() == y.tobytes() for x, y in zip(a, b)), (t, n)
     assert sum(ref.delivered) == sum(ora.delivered) > 0
     for n in range(R):

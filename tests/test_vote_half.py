@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from josefine_amd import capi
-from dense_node import ROUTE_SRC_INJECT, RoutedCluster, cluster_failure_rows, routable
+from dense_node import PHASE_DELIVERED, PHASE_INJECTED, RoutedCluster, cluster_failure_rows, emission_index
 from election_words import ANS_DTYPE, REQ_DTYPE, decode, encode
 from host_compiled import HostCompiled
 from oracle_lib import oracle_engine
@@ -18,7 +18,7 @@ from parity import compare_snapshots
 
 def emitted_rows(out, xrows, xk, n, member_ids):
     """what node n emitted in its vote half: its answer words as the rows they stand for and its exceptional rows, per
-    partition in emission order"""
+    partition in emission order -> (rows, their emission indices)"""
     parts, keys = [], []
     for g in np.nonzero(out["n"])[0]:
         m = int(out["n"][g])
@@ -28,19 +28,20 @@ def emitted_rows(out, xrows, xk, n, member_ids):
         r["flag"] = (int(out["bits"][g]) >> 1) & 1
         r["flag"][0] = int(out["bits"][g]) & 1
         parts.append(r)
-        keys.append(np.stack([np.full(m, g, np.int64), int(out["at"][g]) + np.arange(m)], axis=1))
+        keys.append(np.stack([np.full(m, g, np.int64), (int(out["at"][g]) & 0xff) + np.arange(m)], axis=1))
     if len(xrows):
         parts.append(xrows)
         keys.append(np.stack([xrows["group"].astype(np.int64), xk.astype(np.int64)], axis=1))
     if not parts:
-        return np.zeros(0, dtype=capi.MSG_DTYPE)
+        return np.zeros(0, dtype=capi.MSG_DTYPE), np.zeros(0, np.int64)
     rows, key = np.concatenate(parts), np.concatenate(keys)
-    return rows[np.lexsort((key[:, 1], key[:, 0]))]
+    order = np.lexsort((key[:, 1], key[:, 0]))
+    return rows[order], key[order, 1]
 
 
 def empty_words(R, G):
-    return dict(q_term=np.zeros((R, G), np.uint64), q_head=np.zeros((R, G), np.uint64), q_n=np.zeros((R, G), np.uint8), q_at=np.zeros((R, G), np.uint8),
-                a_term=np.zeros((R, G), np.uint64), a_n=np.zeros((R, G), np.uint8), a_at=np.zeros((R, G), np.uint8), a_bits=np.zeros((R, G), np.uint8),
+    return dict(q_term=np.zeros((R, G), np.uint64), q_head=np.zeros((R, G), np.uint64), q_n=np.zeros((R, G), np.uint8), q_at=np.zeros((R, G), np.uint32),
+                a_term=np.zeros((R, G), np.uint64), a_n=np.zeros((R, G), np.uint8), a_at=np.zeros((R, G), np.uint32), a_bits=np.zeros((R, G), np.uint8),
                 a_to=np.zeros((R, G), np.uint8))
 
 
@@ -51,67 +52,61 @@ class WordCluster(RoutedCluster):
         super().__init__(HostCompiled, G, R, **kw)
         self.word_rows = self.row_rows = self.vote_rows_as_rows = self.answered_in_words = self.exceptional = self.exceptional_answers = 0
 
-    def _inbound_with_src(self, n, inject):
-        srcs = [np.full(len(rows), src, np.int64) for src, rows in self.inbound[n]]
-        groups = [rows["group"] for _, rows in self.inbound[n]]
-        if inject is not None and len(inject["kind"]):
-            srcs.append(np.full(len(inject["kind"]), ROUTE_SRC_INJECT, np.int64))
-            groups.append(np.asarray(inject["group"]))
-        cols = self._inbound_columns(n, inject)
-        if cols is None:
-            return None, None
-        src = np.concatenate(srcs)
-        order = np.lexsort((np.arange(len(src)), src, np.concatenate(groups)))
-        return cols, src[order]
-
     def round(self, appends, inject=None, dt_ms=100):
         G, R = self.G, self.R
         now = self.now + dt_ms
-        extra = [np.zeros(0, dtype=capi.MSG_DTYPE) for _ in range(R)]
+        emitted = [[] for _ in range(R)]
         for n in range(R):
-            cols, src = self._inbound_with_src(n, inject[n] if inject else None)
-            if cols is None:
-                continue
-            self.delivered[n] += len(cols["kind"])
-            reqs, anss, stay, _ = encode(cols, src, self.member_ids)
-            # a partition travels in words when everything it receives this round is words (and one answer word can hold
-            # what it will say: one requester)
-            per_group_rows = np.bincount(cols["group"], minlength=G)
-            per_group_word_rows = np.bincount(cols["group"][~stay], minlength=G)
-            requesters = np.bincount(reqs["group"], minlength=G) if len(reqs) else np.zeros(G, np.int64)
-            in_words = (per_group_rows > 0) & (per_group_rows == per_group_word_rows) & (requesters <= 1)
-            as_rows = ~in_words[cols["group"]]
-            self.word_rows += int((~as_rows).sum())
-            self.row_rows += int(as_rows.sum())
-            self.vote_rows_as_rows += int((as_rows & ~stay).sum())
-            self.nodes[n].submit_columns(**{k: v[as_rows] for k, v in cols.items()})
-            self.nodes[n].step(now)
-            w = empty_words(R, G)
-            for q in reqs[in_words[reqs["group"]]] if len(reqs) else []:
-                s, g = int(q["src"]), int(q["group"])
-                w["q_term"][s, g], w["q_head"][s, g], w["q_n"][s, g], w["q_at"][s, g] = q["term"], q["head"], q["copies"], q["at"]
-            for a in anss[in_words[anss["group"]]] if len(anss) else []:
-                s, g = int(a["src"]), int(a["group"])
-                w["a_term"][s, g], w["a_n"][s, g], w["a_at"][s, g] = a["term"], a["copies"], a["at"]
-                w["a_bits"][s, g], w["a_to"][s, g] = int(a["first"]) | int(a["rest"]) << 1, n  # (delivered to this node: addressed to it)
-            out, xrows, xk = self.nodes[n].vote_half(n, now, w)
-            extra[n] = emitted_rows(out, xrows, xk, n, self.member_ids)
-            self.answered_in_words += int(out["n"].sum())
-            self.exceptional += len(xrows)
-            self.exceptional_answers += int((xrows["kind"] == capi.CMD_VOTE_RESPONSE).sum())
+            rows, src, ord_ = self.inbound_order(n)
+            self.inbound[n] = []
+            if len(rows):
+                cols = self.columns_of(rows)
+                self.delivered[n] += len(rows)
+                reqs, anss, stay = encode(cols, src, ord_, self.member_ids)
+                # a partition travels in words when everything it receives this round is words (and one answer word can hold
+                # what it will say: one requester)
+                per_group_rows = np.bincount(cols["group"], minlength=G)
+                per_group_word_rows = np.bincount(cols["group"][~stay], minlength=G)
+                requesters = np.bincount(reqs["group"], minlength=G) if len(reqs) else np.zeros(G, np.int64)
+                in_words = (per_group_rows > 0) & (per_group_rows == per_group_word_rows) & (requesters <= 1)
+                as_rows = ~in_words[cols["group"]]
+                self.word_rows += int((~as_rows).sum())
+                self.row_rows += int(as_rows.sum())
+                self.vote_rows_as_rows += int((as_rows & ~stay).sum())
+                # the delivered step: the rows through the state machine, the words through the receiving half (other partitions)
+                self.nodes[n].submit_columns(**{k: v[as_rows] for k, v in cols.items()})
+                self.nodes[n].step(now)
+                out1 = self.nodes[n].drain_messages()
+                w = empty_words(R, G)
+                for q in reqs[in_words[reqs["group"]]] if len(reqs) else []:
+                    s, g = int(q["src"]), int(q["group"])
+                    w["q_term"][s, g], w["q_head"][s, g], w["q_n"][s, g], w["q_at"][s, g] = q["term"], q["head"], q["copies"], q["at"]
+                for a in anss[in_words[anss["group"]]] if len(anss) else []:
+                    s, g = int(a["src"]), int(a["group"])
+                    w["a_term"][s, g], w["a_n"][s, g], w["a_at"][s, g] = a["term"], a["copies"], a["at"]
+                    w["a_bits"][s, g], w["a_to"][s, g] = int(a["first"]) | int(a["rest"]) << 1, n  # (delivered to this node: addressed to it)
+                out, xrows, xk = self.nodes[n].vote_half(n, now, w, step=PHASE_DELIVERED)
+                out2, k2 = emitted_rows(out, xrows, xk, n, self.member_ids)
+                self.answered_in_words += int(out["n"].sum())
+                self.exceptional += len(xrows)
+                self.exceptional_answers += int((xrows["kind"] == capi.CMD_VOTE_RESPONSE).sum())
+                # one step's emissions, partitions ascending (the two halves of it served different partitions)
+                both, k = np.concatenate([out1, out2]), np.concatenate([emission_index(out1["group"]), k2])
+                order = np.argsort(both["group"], kind="stable")
+                if len(both):
+                    emitted[n].append((both[order], np.full(len(both), PHASE_DELIVERED, np.int64), k[order]))
+            cols = self._inject_columns(inject[n] if inject else None)
+            if cols is not None:
+                self.delivered[n] += len(cols["kind"])
+                self.nodes[n].submit_columns(**cols)
+                self.nodes[n].step(now)
+                out = self.nodes[n].drain_messages()
+                if len(out):
+                    emitted[n].append((out, np.full(len(out), PHASE_INJECTED, np.int64), emission_index(out["group"])))
         outs = self.dense_round(appends, dt_ms)
-        drained = self.rows.pop()
-        for s in range(R):
-            rows = np.concatenate([extra[s], drained[s]])  # (the vote half's rows first: it came first)
-            ok = routable(rows, self.member_ids)
-            self.kept[s] = np.concatenate([self.kept[s], rows[~ok]])
-            rows = rows[ok]
-            for n in range(R):
-                if n == s:
-                    continue
-                to_n = (rows["to_kind"] == capi.TO_PEERS) | (rows["to_id"] == self.member_ids[n])
-                if to_n.any():
-                    self.inbound[n].append((s, rows[to_n]))
+        for s, parts in enumerate(self.dense_emitted()):
+            emitted[s].extend(parts)
+        self.transport(emitted)
         return outs
 
 
@@ -198,7 +193,7 @@ def test_random_words_on_every_role(R, seed):
             anss_else, anss = anss[elsewhere], anss[~elsewhere]
             none = dict(kind=np.zeros(0, np.uint8), group=np.zeros(0, np.uint32), from_=np.zeros(0, np.uint32), term=np.zeros(0, np.uint64),
                         id=np.zeros(0, np.uint64), aux=np.zeros(0, np.uint64), flag=np.zeros(0, np.uint8))
-            cols, _ = decode(reqs, anss, none, np.zeros(0, np.int64), np.zeros(0, np.int64), ids)
+            cols = decode(reqs, anss, none, np.zeros(0, np.int64), np.zeros(0, np.int64), ids)[0]
             if cols is None:
                 continue
             ora.nodes[n].submit_columns(**cols)
@@ -217,7 +212,7 @@ def test_random_words_on_every_role(R, seed):
                 w["a_bits"][s, g], w["a_to"][s, g] = int(a["first"]) | int(a["rest"]) << 1, (n + 1 + int(rng.integers(0, R - 1))) % R
             out, xrows, xk = dev.nodes[n].vote_half(n, now, w)
             compare_snapshots(dev.nodes[n], ora.nodes[n], f"iteration {it} node {n}")
-            want, got = ora.nodes[n].drain_messages(), emitted_rows(out, xrows, xk, n, ids)
+            want, got = ora.nodes[n].drain_messages(), emitted_rows(out, xrows, xk, n, ids)[0]
             assert len(want) == len(got) and want.tobytes() == got.tobytes(), (it, n, len(want), len(got))
             assert ora.nodes[n].drain_faults().tobytes() == dev.nodes[n].drain_faults().tobytes()
             assert ora.nodes[n].drain_applies().tobytes() == dev.nodes[n].drain_applies().tobytes()

@@ -11,22 +11,12 @@ import numpy as np
 import pytest
 
 from josefine_amd import capi
-from dense_node import RoutedCluster, cluster_failure_rows, routable
+from dense_node import PHASE_DELIVERED, PHASE_INJECTED, RoutedCluster, cluster_failure_rows, emission_index, routable
 from host_compiled import HostCompiled, VoteMail
 from oracle_lib import oracle_engine
 from parity import compare_snapshots
 
 ROUTE_DTYPE = np.dtype([("src", "<i8"), ("step", "<i8"), ("k", "<i8")])
-
-
-def ranks_within_groups(groups):
-    """emission index of every row within its group (rows in emission order per group)"""
-    k = np.zeros(len(groups), np.int64)
-    seen = {}
-    for i, g in enumerate(groups.tolist()):
-        k[i] = seen.get(g, 0)
-        seen[g] = k[i] + 1
-    return k
 
 
 class MailCluster(RoutedCluster):
@@ -54,42 +44,38 @@ class MailCluster(RoutedCluster):
         prev, cur = self.mail[(self.t + 1) & 1], self.mail[self.t & 1]
         cur.clear()
         lib = self.nodes[0].lib
-        emitted = [[] for _ in range(R)]  # per sender: (rows, step, k)
+        emitted = [[] for _ in range(R)]  # per sender: (rows, phase of the round, emission index)
         for n in range(R):
-            # step 1: what the transport delivered - the words (the receiving half) and, for the other partitions, the rows
-            xrows, xk = self.nodes[n].vote_half_mail(n, now, prev, cur, step=1, need=self.need)
-            if len(xrows):
-                emitted[n].append((xrows, np.full(len(xrows), 1, np.uint32), xk.astype(np.uint32)))
+            # phase 1: what the transport delivered - the words (the receiving half) and, for the other partitions, the rows
+            xrows, xk = self.nodes[n].vote_half_mail(n, now, prev, cur, step=PHASE_DELIVERED, need=self.need)
             parts = list(self.inrows[n])
             self.inrows[n] = []
             rows = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, capi.MSG_DTYPE)
             keys = np.concatenate([p[1] for p in parts]) if parts else np.zeros(0, ROUTE_DTYPE)
-            order = np.lexsort((keys["k"], keys["step"], keys["src"], rows["group"]))  # (the staging's ordering key)
+            order = np.lexsort((keys["src"], keys["k"], keys["step"], rows["group"]))  # (the staging's ordering key: partition, phase, emission index, sender)
             rows = rows[order]
-            cols = dict(kind=rows["kind"], group=rows["group"], from_=rows["from"], term=rows["term"], id=rows["id"], aux=rows["aux"], flag=rows["flag"])
             self.in_rows += len(rows)
             self.vote_rows_as_rows += int(np.isin(rows["kind"], (capi.CMD_VOTE_REQUEST, capi.CMD_VOTE_RESPONSE)).sum())
-            inj = inject[n] if inject else None
-            if inj is not None and len(inj["kind"]):  # step 2 on the device: after everything delivered, per partition
-                m = len(inj["kind"])
-                z8, z4 = np.zeros(m, np.uint64), np.zeros(m, np.uint32)
-                ic = dict(kind=inj["kind"], group=inj["group"], from_=inj.get("from_", z4), term=inj.get("term", z8), id=inj.get("id", z8),
-                          aux=inj.get("aux", z8), flag=inj.get("flag", np.zeros(m, np.uint8)))
-                cols = {k: np.concatenate([cols[k], np.asarray(ic[k])]) for k in cols}
-                order = np.argsort(cols["group"], kind="stable")
-                cols = {k: v[order] for k, v in cols.items()}
-                self.delivered[n] += m
-            if len(cols["kind"]):
+            out = np.zeros(0, capi.MSG_DTYPE)
+            if len(rows):
+                self.nodes[n].submit_columns(**self.columns_of(rows))
+                self.nodes[n].step(now)
+                out = self.nodes[n].drain_messages()
+            if len(out) + len(xrows):  # one step's emissions, partitions ascending (its two halves served different partitions)
+                both, k = np.concatenate([xrows, out]), np.concatenate([xk.astype(np.int64), emission_index(out["group"])])
+                order = np.argsort(both["group"], kind="stable")
+                emitted[n].append((both[order], np.full(len(both), PHASE_DELIVERED, np.uint32), k[order].astype(np.uint32)))
+            cols = self._inject_columns(inject[n] if inject else None)
+            if cols is not None:  # phase 2: the injected rows
+                self.delivered[n] += len(cols["kind"])
                 self.nodes[n].submit_columns(**cols)
                 self.nodes[n].step(now)
                 out = self.nodes[n].drain_messages()
                 if len(out):
-                    emitted[n].append((out, np.full(len(out), 2, np.uint32), ranks_within_groups(out["group"]).astype(np.uint32)))
+                    emitted[n].append((out, np.full(len(out), PHASE_INJECTED, np.uint32), emission_index(out["group"]).astype(np.uint32)))
         outs = self.dense_round(appends, dt_ms)
-        drained = self.rows.pop()
-        for s in range(R):
-            if len(drained[s]):
-                emitted[s].append((drained[s], np.full(len(drained[s]), 3, np.uint32), ranks_within_groups(drained[s]["group"]).astype(np.uint32)))
+        for s, parts in enumerate(self.dense_emitted()):
+            emitted[s].extend((rows, phase.astype(np.uint32), k.astype(np.uint32)) for rows, phase, k in parts)
         # -- the transport: census, then the delivering pass and the expansion (jg_votes.h)
         flat = []
         for s in range(R):
@@ -154,7 +140,7 @@ def test_routed_round_with_the_vote_mail_equals_the_row_transport(R, percent, al
         assert [k.tobytes() for k in ora.kept] == [k.tobytes() for k in dev.kept], t
     for n in range(R):
         assert dev.nodes[n].counters()["decisions"] == ora.nodes[n].counters()["decisions"], n
-    pending = np.array([sum(len(rows) for _, rows in ora.inbound[n]) for n in range(R)])
+    pending = np.array([ora.pending(n) for n in range(R)])
     assert (ora.delivered + pending).tolist() == dev.delivered.tolist()
     if percent < 10:  # the configs[4] rates: nearly all of the vote traffic is words
         assert dev.in_words > 10 * dev.vote_rows_as_rows and dev.in_words > G, (dev.in_words, dev.vote_rows_as_rows)
@@ -212,7 +198,7 @@ def test_the_transports_functions_on_random_mail(R, seed):
             n_expanded += m
             for i in range(m):
                 got.setdefault((int(to[i]), int(xr["group"][i])), []).append((s, int(st[i]), int(kk[i]), xr[i:i + 1]))
-        got_rows = {key: [e[3] for e in sorted(v, key=lambda e: e[:3])] for key, v in got.items()}
+        got_rows = {key: [e[3] for e in sorted(v, key=lambda e: (e[1], e[2], e[0]))] for key, v in got.items()}  # (phase, emission index, sender)
         nw, nr = check_mail(R, G, ids, mail, plain, got_rows, need)
         n_words, n_rows = n_words + nw, n_rows + nr
     assert n_words > 500 and n_rows > 500 and n_expanded > 50 and n_double > 10, (n_words, n_rows, n_expanded, n_double)

@@ -98,7 +98,7 @@ def check_mail(R, G, ids, mail, plain, got_rows, need):
     (rows' worth in words, rows as rows)"""
     n_words = n_rows = 0
     for (d, g), want in plain.items():
-        want = [e[3] for e in sorted(want, key=lambda e: e[:3])]
+        want = [e[3] for e in sorted(want, key=lambda e: (e[1], e[2], e[0]))]  # the transport's order: (phase, emission index, sender)
         have = got_rows.get((d, g), [])
         if have:  # as rows: all of them, in the plain transport's order
             assert command_bytes(have) == command_bytes(want), (d, g, len(have), len(want))
@@ -122,7 +122,7 @@ def check_mail(R, G, ids, mail, plain, got_rows, need):
                 for j in range(ac & 0xff):
                     said.append((s, a_ord >> 8, (a_ord & 0xff) + j, row(g, capi.CMD_VOTE_RESPONSE, capi.TO_PEER, ids[d], ids[s], int(mail.a_term[s, g]), 0, 0,
                                                                        (ac >> (20 if j else 19)) & 1)))
-        said = [e[3] for e in sorted(said, key=lambda e: e[:3])]
+        said = [e[3] for e in sorted(said, key=lambda e: (e[1], e[2], e[0]))]
         assert command_bytes(said) == command_bytes(want), (d, g)
         n_words += len(said)
     assert not (set(k for k, v in got_rows.items() if v) - set(plain))
