@@ -326,6 +326,7 @@ struct jg_engine {
   // set while a jg_dense_cluster round is being captured into a hipGraph: the node kernels then
   // take logical time and step number from this device-resident clock instead of their arguments
   JgClock* replay_clock = nullptr;
+  bool cluster_mask_offers = false;  // set by a routed round around its single-lead leader half (JgLeaderNode::mask_offers)
   uint64_t* cluster_aec = nullptr;  // set by a jg_dense_cluster around ITS dense halves: the cluster's common AppendEntries column (JgLeaderNode::o_aec)
   uint32_t replay_slot = 0;
   // jg_step_node: the inbox / outbox columns of the node step, their pinned host mirrors, rocPRIM scratch

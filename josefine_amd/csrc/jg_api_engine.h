@@ -574,6 +574,7 @@ int jg_step_dense_leader(jg_engine* e, uint64_t now_ms, const jg_leader_inbox* i
   nd.clock = e->replay_clock, nd.clock_slot = e->replay_slot;
   nd.hbr_commit = in ? in->hbr_commit : nullptr;
   nd.packed = 1;
+  nd.mask_offers = e->cluster_mask_offers ? 1u : 0u;
   if (out) {
     nd.o_beat = out->beat;
     nd.o_ae = out->ae;

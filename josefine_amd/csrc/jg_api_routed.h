@@ -76,10 +76,6 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     }
   }
   const JgVoteMail vprev = rt.vm[rt.vm_turn ^ 1u], vcur = rt.vm[rt.vm_turn];  // (last round's mail is read, this round's filled)
-  if (vwords) {
-    hipLaunchKernelGGL(k_votes_clear, dim3((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK), dim3(JG_BLOCK), 0, L->stream, vcur);  // (a workgroup per chunk of the bitmaps)
-    HIPCHK(hipGetLastError());
-  }
   if (!rt.h_jobs) {
     HIPCHK(hipHostMalloc((void**)&rt.h_jobs, 6 * jg_dense_cluster::Route::JOB_SLICE, hipHostMallocDefault));
     HIPCHK(hipMalloc((void**)&rt.d_jobs, 6 * jg_dense_cluster::Route::JOB_SLICE));
@@ -259,12 +255,21 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       if (e->seq < j.seq) return fail(JG_EDEVICE, "internal: routed round: the delivered step has no number");
     }
   }
-  {  // slices 0-3 in one copy
+  bool cleared = false;  // (the transport's tallies and bucket counters: zeroed with the round's mail, or by the first attempt's own launch)
+  if (vwords) {  // this round's mail cleared where it was written two rounds ago (a workgroup per chunk of the bitmaps) - and the tallies with it
+    hipLaunchKernelGGL(k_votes_clear, dim3((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK), dim3(JG_BLOCK), 0, L->stream, vcur, rt.d_count, (uint32_t)words, bk.hist,
+                       bk_clear);
+    HIPCHK(hipGetLastError());
+    cleared = true;
+  }
+  {  // slices 0-3 in one copy - by a kernel out of the pinned staging (k_copy_words: a copy engine's start-up was the round's largest gap)
     if (!jobs_a.empty()) std::memcpy(slice_h(0), jobs_a.data(), jobs_a.size() * sizeof(JgApplyJob));
     if (!jobs_v.empty()) std::memcpy(slice_h(0) + jobs_a.size() * sizeof(JgApplyJob), jobs_v.data(), jobs_v.size() * sizeof(JgApplyJob));
     if (!jobs_b.empty()) std::memcpy(slice_h(1), jobs_b.data(), jobs_b.size() * sizeof(JgApplyJob));
     if (!fjobs.empty()) std::memcpy(slice_h(2), fjobs.data(), fjobs.size() * sizeof(JgFollowerJob));
-    HIPCHK(hipMemcpyAsync(slice_d(0), slice_h(0), 4 * jg_dense_cluster::Route::JOB_SLICE, hipMemcpyHostToDevice, st));
+    const uint32_t n8 = (uint32_t)(4 * jg_dense_cluster::Route::JOB_SLICE / 8);
+    hipLaunchKernelGGL(k_copy_words, dim3((n8 + JG_BLOCK - 1) / JG_BLOCK), dim3(JG_BLOCK), 0, st, (uint64_t*)slice_d(0), (const uint64_t*)slice_h(0), n8);
+    HIPCHK(hipGetLastError());
   }
   // -- 1. (launches) what the transport delivered last round, then this round's injected rows
   if ((rc = apply_all(0, jobs_a, widest_a))) return rc;
@@ -286,9 +291,13 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   if (c->any) {  // (whoever owns a group reads `offered`: nothing to mask)
     if ((rc = cluster_launch_any(c))) return rc;
   } else {
-    hipLaunchKernelGGL(k_route_mask_appends, dim3((c->G + 255) / 256), dim3(256), 0, L->stream, c->G, (const uint32_t*)L->dev.flags,
-                       (const uint64_t*)c->offered, c->acks + (size_t)c->lead * c->G);
-    if ((rc = cluster_round_body(c, now_ms, true, false, slice_h(2), slice_d(2), &fjobs))) return rc;
+    // (ClientRequests only where the lead node - still - leads: its own slot's column holds the offers as they are, and the
+    // leader half does not look at a non-leader's - JgLeaderNode::mask_offers; until round 6 a launch of its own wrote a masked
+    // copy of the column every round)
+    L->cluster_mask_offers = true;
+    rc = cluster_round_body(c, now_ms, true, false, slice_h(2), slice_d(2), &fjobs);
+    L->cluster_mask_offers = false;
+    if (rc) return rc;
   }
   T1 = clk();
   // -- 3. the transport, on the lead node's stream behind everybody's round
@@ -311,37 +320,33 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     hipLaunchKernelGGL(k_route_scan_tiles, dim3(1), dim3(JG_BLOCK), 0, st, bk);
     hipLaunchKernelGGL(k_route_scatter, dim3(grid, n_seg), dim3(JG_BLOCK), 0, st, (const uint32_t*)d_cursor, seg_cap, (const uint64_t*)rt.key,
                        (const uint32_t*)rt.idx, bk, rt.key_alt, rt.idx_alt);
-    hipLaunchKernelGGL(k_route_sort_build, dim3(bk.n_buckets), dim3(JG_BLOCK), 0, st, bk, rt.key_alt, rt.idx_alt, (const jg_msg_row*)rt.row,
-                       rt.cols);
+    hipLaunchKernelGGL(k_route_sort_build, dim3((bk.n_buckets + JG_ROUTE_SORT_BUCKETS - 1) / JG_ROUTE_SORT_BUCKETS), dim3(JG_BLOCK), 0, st, bk, rt.key_alt, rt.idx_alt,
+                       (const jg_msg_row*)rt.row, rt.cols);
   };
   bool ordered = false;
   if (vwords) {  // the census of everything the round emitted (once: a repeated delivering pass finds it done)
-    if (!rjobs.empty())
-      hipLaunchKernelGGL(k_votes_census_rec_multi, dim3((widest_r + JG_BLOCK - 1) / JG_BLOCK, (uint32_t)rjobs.size()), dim3(JG_BLOCK), 0, st,
-                         (const JgRouteRecJob*)slice_d(3), vcur);
-    hipLaunchKernelGGL(k_votes_census_xq_multi, dim3(256, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteXqJob*)(slice_d(3) + rb), vcur);
+    hipLaunchKernelGGL(k_votes_census_multi, dim3(std::max<uint32_t>((widest_r + JG_BLOCK - 1) / JG_BLOCK, 64u), (uint32_t)(rjobs.size() + xjobs.size())), dim3(JG_BLOCK), 0, st,
+                       (const JgRouteRecJob*)slice_d(3), (uint32_t)rjobs.size(), (const JgRouteXqJob*)(slice_d(3) + rb), vcur);
     hipLaunchKernelGGL(k_votes_validate, dim3((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK), dim3(JG_BLOCK), 0, st, vcur, R - 1u);
     HIPCHK(hipGetLastError());
   }
   for (int attempt = 0;; attempt++) {  // (repeated once when the staging turns out too small: the pass modifies nothing)
-    hipLaunchKernelGGL(k_route_clear, dim3(64), dim3(JG_BLOCK), 0, st, rt.d_count, (uint32_t)words, bk.hist, bk_clear);
+    if (!cleared) hipLaunchKernelGGL(k_route_clear, dim3(64), dim3(JG_BLOCK), 0, st, rt.d_count, (uint32_t)words, bk.hist, bk_clear);
+    cleared = false;  // (a repeated attempt clears for itself)
     if (attempt) {  // (every attempt ends with a synchronisation - the counts - so the staging is free again)
       if ((rc = route_jobs())) return rc;
       HIPCHK(hipMemcpyAsync(slice_d(3), slice_h(3), rb + xb, hipMemcpyHostToDevice, st));
     }
-    if (vwords) {  // the delivering pass leaves the words' copies where they are; the answer words that must be rows after all
-      if (!rjobs.empty())
-        hipLaunchKernelGGL(k_route_rec_multi_words, dim3((widest_r + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS), (uint32_t)rjobs.size()),
-                           dim3(JG_BLOCK), 0, st, (const JgRouteRecJob*)slice_d(3), vcur);
-      hipLaunchKernelGGL(k_route_xq_multi_words, dim3(256, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteXqJob*)(slice_d(3) + rb), vcur);
-      hipLaunchKernelGGL(k_votes_expand_multi, dim3(std::min<uint32_t>((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK, 512u), (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st,
-                         (const JgRouteXqJob*)(slice_d(3) + rb), vcur);
-    } else {
-      if (!rjobs.empty())
-        hipLaunchKernelGGL(k_route_rec_multi, dim3((widest_r + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS), (uint32_t)rjobs.size()), dim3(JG_BLOCK), 0, st,
-                           (const JgRouteRecJob*)slice_d(3));
+    {  // the delivering pass: every sender's sparse steps, every sender's exceptional queue and (words) the answer words that must be rows after all, in ONE launch
+      const uint32_t rec_x = (widest_r + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS);
       // (256 workgroups per queue: a round's queue holds a few ten thousand rows, and every workgroup - busy or not - pays the tally)
-      hipLaunchKernelGGL(k_route_xq_multi, dim3(256, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteXqJob*)(slice_d(3) + rb));
+      const dim3 grid(std::max<uint32_t>(rec_x, 256u), (uint32_t)(rjobs.size() + xjobs.size() * (vwords ? 2 : 1)));
+      if (vwords)
+        hipLaunchKernelGGL(k_route_deliver_multi_words, grid, dim3(JG_BLOCK), 0, st, (const JgRouteRecJob*)slice_d(3), (uint32_t)rjobs.size(),
+                           (const JgRouteXqJob*)(slice_d(3) + rb), (uint32_t)xjobs.size(), vcur);
+      else
+        hipLaunchKernelGGL(k_route_deliver_multi, grid, dim3(JG_BLOCK), 0, st, (const JgRouteRecJob*)slice_d(3), (uint32_t)rjobs.size(),
+                           (const JgRouteXqJob*)(slice_d(3) + rb), (uint32_t)xjobs.size());
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(rt.h_count, rt.d_count, words * 4, hipMemcpyDeviceToHost, st));

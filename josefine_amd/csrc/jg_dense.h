@@ -393,7 +393,11 @@ __device__ __forceinline__ void jg_clock_read(const JgClock* c, uint32_t slot, u
 #define JG_AEC_INDIVIDUAL 0xfffffffffffffffeull  // JgLeaderNode::o_aec: "see the rows" (no JG_AE word: a range start key stays below JG_MAILBOX_NONE; not JG_NO_ACK: "nothing for anybody")
 struct JgLeaderNode {
   JgClock* clock;              // non-null: `now` and the step number come from here (slot clock_slot)
-  uint32_t clock_slot, pad_;
+  uint32_t clock_slot;
+  uint32_t mask_offers;        // 1: the own slot's append count is an OFFER, good only where this node leads the group (a routed
+                               //    round's ClientRequests: at a leaderless replica the reference queues them, follower.rs:258-270 -
+                               //    not a dense append); elsewhere it is not looked at.  0: asking a non-leader to append is
+                               //    JG_FAULT_ENGINE_DENSE_NONLEADER (jg_step_dense_acks)
   uint32_t ack_stride;         // 1, or 0: nothing came in (the `acks` argument points at an all-ones word)
   uint32_t packed;             // 1: `acks` holds jg_leader_inbox answer words (JG_ANSWER), not bare heads
   const uint64_t* hbr_commit;  // [R][G] (slow kernel only)
@@ -817,6 +821,12 @@ __device__ __forceinline__ void jg_dense_group(const JgDenseHot& h, const JgDev*
   const JgDev& d = *dp;  // (the ack-only kernel: loads from the device copy, general path only)
   // ---- everything else ---------------------------------------------------------------------------
   // dead groups, non-leaders and irregular chains are decided from the flag word in registers
+  // (cold: a non-leader's append count under mask_offers is nobody's request - what classify does with a non-leader that
+  // was asked nothing: no fault, no deferral, "nothing" in the outbox)
+  if (NODE && !ANY && nd.mask_offers && (f & JGF_ROLE_MASK) != JG_ROLE_LEADER) {
+    if (emit) jg_dense_outbox_none<R, UNIFORM>(h.G, nd, g, s);
+    return;
+  }
   int cls = jg_dense_classify(d, g, f, n_app, seq);
   // node tick: whatever is not served in lag space (a HeartbeatResponse without the commit, an
   // escaped lag field, an ack above the head) goes to k_dense_slow, which is always launched

@@ -114,6 +114,7 @@ __device__ __forceinline__ JgRouteSpot jg_route_reserve(const JgRouteTable& t, u
 // The workgroup's entries are one contiguous range of the staging: they are collected in LDS and leave in whole
 // lines, 8 bytes per lane and lanes side by side (written from the lanes that found them - a 40-byte row per lane,
 // five partial stores per line - the delivering pass put 104 MB on the bus for 34 MB of entries).
+#define JG_ROUTE_ITEMS 2  // slots per thread of the sparse steps' pass: a workgroup serves a tile of JG_BLOCK * JG_ROUTE_ITEMS
 template <uint32_t CAP>
 struct JgRouteStage {
   uint64_t key[CAP];
@@ -193,9 +194,9 @@ __device__ __forceinline__ void jg_route_note_kind(uint64_t& kd_lo, uint64_t& kd
 
 // The slots of one sparse step: every deliverable row goes to the staging (nothing is modified: the
 // pass can be repeated with a larger staging); rows that stay and FSM rows are counted.
-#define JG_ROUTE_ITEMS 2  // slots per thread: a workgroup serves a tile of JG_BLOCK * JG_ROUTE_ITEMS
+#define JG_ROUTE_REC_CAP (JG_BLOCK * JG_ROUTE_ITEMS)  // (one delivered row per slot is the usual yield: 24 KB of LDS)
 template <bool WORDS = false>
-__device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_t n, uint32_t per_row, uint32_t step,
+__device__ __forceinline__ void jg_route_rec_body(JgRouteStage<JG_ROUTE_REC_CAP>& st, const JgRouteTable& t, uint32_t n, uint32_t per_row, uint32_t step,
                                                   const uint32_t* __restrict__ msg_cnt, const jg_msg_row* __restrict__ msg,
                                                   const uint32_t* __restrict__ fsm_cnt, const JgVoteMail& vm = JgVoteMail{}) {
   if (blockIdx.x * (JG_BLOCK * JG_ROUTE_ITEMS) >= n) return;  // (a multi launch is as wide as its largest job)
@@ -222,8 +223,7 @@ __device__ __forceinline__ void jg_route_rec_body(const JgRouteTable& t, uint32_
       }
     }
   }
-  constexpr uint32_t CAP = JG_BLOCK * JG_ROUTE_ITEMS;  // (one delivered row per slot is the usual yield: 24 KB of LDS)
-  __shared__ JgRouteStage<CAP> st;
+  constexpr uint32_t CAP = JG_ROUTE_REC_CAP;
   const JgRouteSpot sp = jg_route_reserve(t, c);
   const bool staged = sp.whole && sp.tot <= CAP;  // (workgroup-uniform)
   uint32_t pos = sp.pos, at = sp.excl;
@@ -260,17 +260,8 @@ struct JgRouteRecJob {
   const jg_msg_row* msg;
   const uint32_t* fsm_cnt;
 };
-__global__ __launch_bounds__(JG_BLOCK) void k_route_rec_multi(const JgRouteRecJob* __restrict__ jobs) {
-  const JgRouteRecJob j = jobs[blockIdx.y];
-  jg_route_rec_body(j.t, j.n, j.per_row, j.step, j.msg_cnt, j.msg, j.fsm_cnt);
-}
-__global__ __launch_bounds__(JG_BLOCK) void k_route_rec_multi_words(const JgRouteRecJob* __restrict__ jobs, JgVoteMail vm) {
-  const JgRouteRecJob j = jobs[blockIdx.y];
-  jg_route_rec_body<true>(j.t, j.n, j.per_row, j.step, j.msg_cnt, j.msg, j.fsm_cnt, vm);
-}
 // the census of the same slots (jg_votes.h), before anything is delivered
-__global__ __launch_bounds__(JG_BLOCK) void k_votes_census_rec_multi(const JgRouteRecJob* __restrict__ jobs, JgVoteMail vm) {
-  const JgRouteRecJob& j = jobs[blockIdx.y];  // (a by-value copy went to scratch: 168 B per lane)
+__device__ __forceinline__ void jg_votes_census_rec_body(const JgRouteRecJob& j, const JgVoteMail& vm) {  // (the job through the reference: a by-value copy went to scratch, 168 B per lane)
   const uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x;
   if (i >= j.n) return;
   const uint32_t cnt = j.msg_cnt[i];
@@ -297,8 +288,9 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_rec_compact(JgRouteTable t, 
 // The exceptional-row queue of the dense steps.  COMPACT = false: deliver + count (nothing modified);
 // COMPACT = true: the rows that stay are appended to `keep` (the queue is unordered; its rows carry
 // their own step and emission index).
+#define JG_ROUTE_XQ_CAP (JG_BLOCK * 4)  // (a tile of JG_BLOCK queue entries yields up to JG_BLOCK * (R - 1) staged rows: a campaign's VoteRequest goes to every peer)
 template <bool COMPACT, bool WORDS = false>
-__device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const JgXqRec* __restrict__ xq,
+__device__ __forceinline__ void jg_route_xq_body(JgRouteStage<JG_ROUTE_XQ_CAP>* stp, const JgRouteTable& t, const JgXqRec* __restrict__ xq,
                                                  const uint32_t* __restrict__ xq_n, uint32_t xq_cap, uint32_t seq_base, uint32_t phases,
                                                  JgXqRec* __restrict__ keep, uint32_t* __restrict__ keep_n, const JgVoteMail& vm = JgVoteMail{}) {
   const uint32_t n = min(*xq_n, xq_cap);
@@ -327,9 +319,8 @@ __device__ __forceinline__ void jg_route_xq_body(const JgRouteTable& t, const Jg
       continue;
     }
     const uint32_t step = jg_route_phase(phases, q.seq - seq_base);
-    // (a tile of JG_BLOCK queue entries yields up to JG_BLOCK * (R - 1) staged rows: a campaign's VoteRequest goes to every peer)
-    constexpr uint32_t CAP = JG_BLOCK * 4;
-    __shared__ JgRouteStage<CAP> st;
+    constexpr uint32_t CAP = JG_ROUTE_XQ_CAP;
+    JgRouteStage<CAP>& st = *stp;  // (COMPACT: never touched - null)
     const JgRouteSpot sp = jg_route_reserve(t, __popc(mask));
     const bool staged = sp.whole && sp.tot <= CAP;  // (workgroup-uniform)
     uint32_t pos = sp.pos, at = sp.excl;
@@ -356,7 +347,7 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_xq(JgRouteTable t, const JgX
                                                        const uint32_t* __restrict__ xq_n, uint32_t xq_cap,
                                                        uint32_t seq_base, uint32_t phases, JgXqRec* __restrict__ keep,
                                                        uint32_t* __restrict__ keep_n) {
-  jg_route_xq_body<COMPACT>(t, xq, xq_n, xq_cap, seq_base, phases, keep, keep_n);
+  jg_route_xq_body<COMPACT>(nullptr, t, xq, xq_n, xq_cap, seq_base, phases, keep, keep_n);
 }
 struct JgRouteXqJob {  // the delivering pass over every sender's exceptional-row queue in one launch
   JgRouteTable t;
@@ -365,17 +356,8 @@ struct JgRouteXqJob {  // the delivering pass over every sender's exceptional-ro
   uint32_t xq_cap, seq_base;
   uint32_t phases, pad;  // the sender's steps of the round as phases (jg_route_phase)
 };
-__global__ __launch_bounds__(JG_BLOCK) void k_route_xq_multi(const JgRouteXqJob* __restrict__ jobs) {
-  const JgRouteXqJob j = jobs[blockIdx.y];
-  jg_route_xq_body<false>(j.t, j.xq, j.xq_n, j.xq_cap, j.seq_base, j.phases, nullptr, nullptr);
-}
-__global__ __launch_bounds__(JG_BLOCK) void k_route_xq_multi_words(const JgRouteXqJob* __restrict__ jobs, JgVoteMail vm) {
-  const JgRouteXqJob j = jobs[blockIdx.y];
-  jg_route_xq_body<false, true>(j.t, j.xq, j.xq_n, j.xq_cap, j.seq_base, j.phases, nullptr, nullptr, vm);
-}
 // the census of the same queues (jg_votes.h), before anything is delivered
-__global__ __launch_bounds__(JG_BLOCK) void k_votes_census_xq_multi(const JgRouteXqJob* __restrict__ jobs, JgVoteMail vm) {
-  const JgRouteXqJob& j = jobs[blockIdx.y];
+__device__ __forceinline__ void jg_votes_census_xq_body(const JgRouteXqJob& j, const JgVoteMail& vm) {
   const uint32_t n = min(*j.xq_n, j.xq_cap);
   for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < n; i += gridDim.x * JG_BLOCK) {
     const JgXqRec q = j.xq[i];
@@ -383,14 +365,20 @@ __global__ __launch_bounds__(JG_BLOCK) void k_votes_census_xq_multi(const JgRout
     jg_votes_census_row(vm, j.t.src, j.t.member_id[j.t.src], q.row, jg_route_phase(j.phases, q.seq - j.seq_base), q.k, jg_route_dests(q.row, j.t));
   }
 }
+// ONE launch for the census of everything the round emitted: blockIdx.y < n_rec - a sparse step's slots (gridDim.x covers the
+// widest), the rest - the senders' exceptional queues (their workgroups stride).  (Two launches until round 6: 17 + 7 us.)
+__global__ __launch_bounds__(JG_BLOCK) void k_votes_census_multi(const JgRouteRecJob* __restrict__ rjobs, uint32_t n_rec, const JgRouteXqJob* __restrict__ xjobs,
+                                                                 JgVoteMail vm) {
+  if (blockIdx.y < n_rec) jg_votes_census_rec_body(rjobs[blockIdx.y], vm);
+  else jg_votes_census_xq_body(xjobs[blockIdx.y - n_rec], vm);
+}
 #if JG_BLOCK % 64 == 0
 // the answer words whose addressee's partition takes rows after all: staged as the rows they stand for (blockIdx.y = the
 // sender; its table comes with its queue's job).  Rare - an answer word has to be rows only where its addressee's
 // partition has BOTH kinds of mail - so the pass runs over the bitmaps: a workgroup takes JG_VOTE_CHUNK words of
 // OR_d (wordmail[d] & rowmail[d]), a chunk without a bit costs nothing more (no reservation: the pass took 50 us of a
 // round that had nothing to expand), and the lanes take the set bits (JgBitChunk, jg_votes.h).
-__global__ __launch_bounds__(JG_BLOCK) void k_votes_expand_multi(const JgRouteXqJob* __restrict__ jobs, JgVoteMail vm) {
-  const JgRouteTable t = jobs[blockIdx.y].t;
+__device__ __forceinline__ void jg_votes_expand_body(const JgRouteTable& t, const JgVoteMail& vm) {
   __shared__ JgBitChunk s;
   uint64_t pd_lo = 0, pd_hi = 0, kd_lo = 0, kd_hi = 0;
   const uint32_t n_chunks = (vm.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK;
@@ -421,6 +409,40 @@ __global__ __launch_bounds__(JG_BLOCK) void k_votes_expand_multi(const JgRouteXq
   jg_route_tally(t, pd_lo, pd_hi, 0, JG_ROUTE_KEPT, 0, kd_lo, kd_hi);
 }
 #endif
+// ONE launch for the delivering pass (three until round 6: 29 + 16 + 14 us one behind the other, each a few dozen busy
+// workgroups): blockIdx.y < n_rec - a sparse step's slots (gridDim.x covers the widest job: a workgroup beyond its job's end
+// returns at once); < n_rec + n_xq - a sender's exceptional queue (strides); WORDS: the rest - a sender's answer words that
+// must be rows after all (strides over the bitmaps).  The passes only append to the staging and add to the tallies: any
+// order.  The two stagings share their LDS.
+union JgRouteStageAny {
+  JgRouteStage<JG_ROUTE_REC_CAP> rec;
+  JgRouteStage<JG_ROUTE_XQ_CAP> xq;
+};
+template <bool WORDS>
+__device__ __forceinline__ void jg_route_deliver_body(const JgRouteRecJob* __restrict__ rjobs, uint32_t n_rec, const JgRouteXqJob* __restrict__ xjobs, uint32_t n_xq,
+                                                      const JgVoteMail& vm) {
+  __shared__ JgRouteStageAny st;
+  if (blockIdx.y < n_rec) {
+    const JgRouteRecJob j = rjobs[blockIdx.y];
+    jg_route_rec_body<WORDS>(st.rec, j.t, j.n, j.per_row, j.step, j.msg_cnt, j.msg, j.fsm_cnt, vm);
+  } else if (blockIdx.y < n_rec + n_xq) {
+    const JgRouteXqJob j = xjobs[blockIdx.y - n_rec];
+    jg_route_xq_body<false, WORDS>(&st.xq, j.t, j.xq, j.xq_n, j.xq_cap, j.seq_base, j.phases, nullptr, nullptr, vm);
+  }
+#if JG_BLOCK % 64 == 0
+  else if (WORDS) {
+    const JgRouteTable t = xjobs[blockIdx.y - n_rec - n_xq].t;
+    jg_votes_expand_body(t, vm);
+  }
+#endif
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_route_deliver_multi(const JgRouteRecJob* __restrict__ rjobs, uint32_t n_rec, const JgRouteXqJob* __restrict__ xjobs, uint32_t n_xq) {
+  jg_route_deliver_body<false>(rjobs, n_rec, xjobs, n_xq, JgVoteMail{});
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_route_deliver_multi_words(const JgRouteRecJob* __restrict__ rjobs, uint32_t n_rec, const JgRouteXqJob* __restrict__ xjobs, uint32_t n_xq,
+                                                                         JgVoteMail vm) {
+  jg_route_deliver_body<true>(rjobs, n_rec, xjobs, n_xq, vm);
+}
 
 // sorted staging -> the command columns k_apply_rows consumes
 struct JgRouteCols {
@@ -554,11 +576,9 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_scatter(const uint32_t* __re
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(JG_BLOCK) void k_route_sort_build(JgRouteBuckets b, uint64_t* __restrict__ key, uint32_t* __restrict__ idx,
-                                                               const jg_msg_row* __restrict__ rows, JgRouteCols c) {
-  __shared__ uint64_t s_key[JG_ROUTE_SORT_CAP];
-  __shared__ uint32_t s_idx[JG_ROUTE_SORT_CAP];
-  const uint32_t lo = b.off(blockIdx.x), n = b.off(blockIdx.x + 1) - lo;
+__device__ __forceinline__ void jg_route_sort_bucket(const JgRouteBuckets& b, uint32_t bucket, uint64_t (&s_key)[JG_ROUTE_SORT_CAP], uint32_t (&s_idx)[JG_ROUTE_SORT_CAP],
+                                                     uint64_t* __restrict__ key, uint32_t* __restrict__ idx, const jg_msg_row* __restrict__ rows, const JgRouteCols& c) {
+  const uint32_t lo = b.off(bucket), n = b.off(bucket + 1) - lo;  // (workgroup-uniform)
   if (!n) return;
   if (n <= JG_BLOCK) {
     // the usual bucket (a tile of 256 groups holds ~64 rows of a round): every key's rank by counting the smaller
@@ -637,6 +657,20 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_sort_build(JgRouteBuckets b,
     c.term[p] = r.term, c.id[p] = r.id, c.aux[p] = r.aux;
   }
 }
+// A workgroup takes JG_ROUTE_SORT_BUCKETS consecutive buckets, one after the other: a round's rows sit in a few percent of the
+// R x G / 256 buckets (19.5 k at 1 M x 5), and a launch of one workgroup per bucket spent its 20 us dispatching empty ones.
+#define JG_ROUTE_SORT_BUCKETS 8u
+__global__ __launch_bounds__(JG_BLOCK) void k_route_sort_build(JgRouteBuckets b, uint64_t* __restrict__ key, uint32_t* __restrict__ idx,
+                                                               const jg_msg_row* __restrict__ rows, JgRouteCols c) {
+  __shared__ uint64_t s_key[JG_ROUTE_SORT_CAP];
+  __shared__ uint32_t s_idx[JG_ROUTE_SORT_CAP];
+  for (uint32_t k = 0; k < JG_ROUTE_SORT_BUCKETS; k++) {
+    const uint32_t bucket = blockIdx.x * JG_ROUTE_SORT_BUCKETS + k;
+    if (bucket >= b.n_buckets) return;
+    jg_route_sort_bucket(b, bucket, s_key, s_idx, key, idx, rows, c);
+    __syncthreads();  // (the LDS tile is the next bucket's)
+  }
+}
 
 // The same ordering for any list of (64-bit key, 32-bit value) pairs with UNIQUE keys (k_route_hist / _scan /
 // _scan_tiles / _scatter as above, then this instead of k_route_sort_build): one workgroup per bucket ranks its
@@ -675,20 +709,18 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_clear(uint32_t* __restrict__
     else b[i - na] = 0;
   }
 }
+// the round's job tables from the pinned host staging to their device copy, by a kernel: a hipMemcpyAsync of these 64 KB
+// took the copy engine 25-30 us to get going, with the stream idle behind it at the head of every round (rocprofv3
+// --kernel-trace: profiles/r06/routed_round_trace_before.txt); `n`: 8-byte words
+__global__ __launch_bounds__(JG_BLOCK) void k_copy_words(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint32_t n) {
+  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < n; i += gridDim.x * JG_BLOCK) dst[i] = src[i];
+}
 struct JgWordList {
   uint32_t* p[JG_MAX_REPLICAS];
   uint32_t n;
 };
 __global__ void k_route_clear_words(JgWordList w) {
   if (threadIdx.x < w.n) *w.p[threadIdx.x] = 0;
-}
-
-// ClientRequests are offered only where the lead node leads (at a leaderless replica the reference
-// queues them, follower.rs:258-270 — not expressible in the dense append column)
-__global__ void k_route_mask_appends(uint32_t G, const uint32_t* __restrict__ flags, const uint64_t* __restrict__ offered,
-                                     uint64_t* __restrict__ own_col) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < G) own_col[g] = (flags[g] & JGF_ROLE_MASK) == JG_ROLE_LEADER ? offered[g] : JG_ANSWER(0, JG_HB_NONE);  // (answer words)
 }
 
 // jg_dense_cluster_mailboxes: the common AppendEntries word of a group (JgLeaderNode::o_aec) into the rows of the block -

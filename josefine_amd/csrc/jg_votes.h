@@ -383,8 +383,14 @@ __global__ __launch_bounds__(JG_BLOCK) void k_votes_validate(JgVoteMail m, uint3
 // wordmail words says which partitions' control words are dirty (R x G / 8 bytes read instead of 8 x R x G bytes written
 // per round: 0.6 MB against 40 MB at 1 M x 5); then the bitmaps themselves (the thread that brought a word clears it: the
 // lanes work from the copy in LDS).
-__global__ __launch_bounds__(JG_BLOCK) void k_votes_clear(JgVoteMail m) {
+// (`a`, `b`: two more word ranges that go back to zero with the round's mail - the transport's tallies and its bucket
+// counters, k_route_clear's job: one launch less per round)
+__global__ __launch_bounds__(JG_BLOCK) void k_votes_clear(JgVoteMail m, uint32_t* __restrict__ a, uint32_t na, uint32_t* __restrict__ b, uint32_t nb) {
   __shared__ JgBitChunk s;
+  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < na + nb; i += gridDim.x * JG_BLOCK) {
+    if (i < na) a[i] = 0;
+    else b[i - na] = 0;
+  }
   const uint32_t n_chunks = (m.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK;
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const uint32_t w = c * JG_VOTE_CHUNK + threadIdx.x;

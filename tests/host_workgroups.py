@@ -436,21 +436,17 @@ VIS int hw_route(const WgRoute* rt, const WgSender* snd, const JgVoteMail* vm, u
   const JgVoteMail m = *vm;
   const uint32_t xgrid = 3;  // (the kernels stride: a few workgroups per queue are as good as 256 here)
   if ((rt->words & 1u) && !(rt->words & 2u)) {  // (the census once: a repeated delivering pass finds it done)
-    if (!rjobs.empty())
-      wg::launch(dim3((widest_r + JG_BLOCK - 1) / JG_BLOCK, (uint32_t)rjobs.size()), JG_BLOCK, [&] { k_votes_census_rec_multi(rjobs.data(), m); });
-    wg::launch(dim3(xgrid, (uint32_t)xjobs.size()), JG_BLOCK, [&] { k_votes_census_xq_multi(xjobs.data(), m); });
+    wg::launch(dim3(std::max<uint32_t>((widest_r + JG_BLOCK - 1) / JG_BLOCK, xgrid), (uint32_t)(rjobs.size() + xjobs.size())), JG_BLOCK,
+               [&] { k_votes_census_multi(rjobs.data(), (uint32_t)rjobs.size(), xjobs.data(), m); });
     wg::launch(dim3(2), JG_BLOCK, [&] { k_votes_validate(m, R - 1u); });
   }
   wg::launch(dim3(2), JG_BLOCK, [&] { k_route_clear(rt->count, (uint32_t)words, bk.hist, bk_clear); });
-  const dim3 rgrid((widest_r + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS), (uint32_t)rjobs.size());
-  if (rt->words & 1u) {
-    if (!rjobs.empty()) wg::launch(rgrid, JG_BLOCK, [&] { k_route_rec_multi_words(rjobs.data(), m); });
-    wg::launch(dim3(xgrid, (uint32_t)xjobs.size()), JG_BLOCK, [&] { k_route_xq_multi_words(xjobs.data(), m); });
-    wg::launch(dim3(std::min<uint32_t>((rt->G + JG_BLOCK - 1) / JG_BLOCK, 3u), (uint32_t)xjobs.size()), JG_BLOCK, [&] { k_votes_expand_multi(xjobs.data(), m); });
-  } else {
-    if (!rjobs.empty()) wg::launch(rgrid, JG_BLOCK, [&] { k_route_rec_multi(rjobs.data()); });
-    wg::launch(dim3(xgrid, (uint32_t)xjobs.size()), JG_BLOCK, [&] { k_route_xq_multi(xjobs.data()); });
-  }
+  // the delivering pass, ONE launch as round_routed_impl issues it: the sparse steps' slots, the queues and (words) the expansion by blockIdx.y
+  const uint32_t rec_x = (widest_r + JG_BLOCK * JG_ROUTE_ITEMS - 1) / (JG_BLOCK * JG_ROUTE_ITEMS);
+  const bool w = rt->words & 1u;
+  const dim3 dgrid(std::max<uint32_t>(rec_x, xgrid), (uint32_t)(rjobs.size() + xjobs.size() * (w ? 2 : 1)));
+  if (w) wg::launch(dgrid, JG_BLOCK, [&] { k_route_deliver_multi_words(rjobs.data(), (uint32_t)rjobs.size(), xjobs.data(), (uint32_t)xjobs.size(), m); });
+  else wg::launch(dgrid, JG_BLOCK, [&] { k_route_deliver_multi(rjobs.data(), (uint32_t)rjobs.size(), xjobs.data(), (uint32_t)xjobs.size()); });
   uint32_t total = 0, fullest = 0;
   for (uint32_t k = 0; k < rt->n_seg; k++) total += d_cursor[k], fullest = std::max(fullest, d_cursor[k]);
   if (fullest > rt->cap / rt->n_seg) return -2;  // (the host would grow the staging and repeat)
@@ -466,7 +462,7 @@ VIS int hw_route(const WgRoute* rt, const WgSender* snd, const JgVoteMail* vm, u
   wg::launch(dim3(n_tiles), JG_BLOCK, [&] { k_route_scan(bk); });
   wg::launch(dim3(1), JG_BLOCK, [&] { k_route_scan_tiles(bk); });
   wg::launch(dim3(grid, rt->n_seg), JG_BLOCK, [&] { k_route_scatter(d_cursor, seg_cap, rt->key, rt->idx, bk, rt->key_alt, rt->idx_alt); });
-  wg::launch(dim3(bk.n_buckets), JG_BLOCK, [&] { k_route_sort_build(bk, rt->key_alt, rt->idx_alt, rt->row, rt->cols); });
+  wg::launch(dim3((bk.n_buckets + JG_ROUTE_SORT_BUCKETS - 1) / JG_ROUTE_SORT_BUCKETS), JG_BLOCK, [&] { k_route_sort_build(bk, rt->key_alt, rt->idx_alt, rt->row, rt->cols); });
   return 0;
 }
 
@@ -508,7 +504,7 @@ VIS size_t hw_take_xq(Host* h, JgXqRec* out, size_t cap) {
 }
 VIS void hw_votes_clear(const JgVoteMail* m) {
   const JgVoteMail a = *m;
-  wg::launch(dim3(3), JG_BLOCK, [&] { k_votes_clear(a); });
+  wg::launch(dim3(3), JG_BLOCK, [&] { k_votes_clear(a, nullptr, 0, nullptr, 0); });
 }
 '''
 
