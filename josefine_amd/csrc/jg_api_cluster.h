@@ -67,6 +67,7 @@ struct jg_dense_cluster {
     void* vm_mem = nullptr;
     uint32_t vm_turn = 0;
     hipEvent_t ev_counts = nullptr;               // behind the delivering pass's counts on their way to the host
+
     uint32_t last_total = 0, last_fullest_seg = 0;  // the previous round's rows: what the ordering pass is sized for before the counts are in
   } rt;
 };

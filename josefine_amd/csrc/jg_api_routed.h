@@ -92,13 +92,13 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     const uint32_t tile = small_tiles(widest) ? JG_RUN_TILE_SMALL : JG_RUN_TILE;
     return std::min<uint32_t>(std::max<uint32_t>((widest + tile - 1) / tile, 1u), L->count_slots);
   };
-  auto apply_all = [&](int slice, std::vector<JgApplyJob>& jobs, uint32_t widest) -> int {
+  auto apply_all = [&](int slice, std::vector<JgApplyJob>& jobs, uint32_t widest, hipStream_t on) -> int {
     if (jobs.empty()) return JG_OK;
     if (slice == 0) {  // delivered rows: runs of 4-16 rows per group, a RUN per lane (jg_apply_runs_body)
       hipLaunchKernelGGL(small_tiles(widest) ? k_apply_runs_multi_small : k_apply_runs_multi, dim3(run_grid(widest), (uint32_t)jobs.size()),
-                         dim3(JG_BLOCK), 0, L->stream, (const JgApplyJob*)slice_d(slice));
+                         dim3(JG_BLOCK), 0, on, (const JgApplyJob*)slice_d(slice));
     } else {
-      hipLaunchKernelGGL(k_apply_rows_multi, dim3(grid_for(widest, L->count_slots), (uint32_t)jobs.size()), dim3(JG_BLOCK), 0, L->stream,
+      hipLaunchKernelGGL(k_apply_rows_multi, dim3(grid_for(widest, L->count_slots), (uint32_t)jobs.size()), dim3(JG_BLOCK), 0, on,
                          (const JgApplyJob*)slice_d(slice));
     }
     HIPCHK(hipGetLastError());
@@ -208,15 +208,15 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   bk.n_buckets = R << (rt.group_bits - tile_bits);
   const uint32_t n_tiles = (bk.n_buckets + JG_ROUTE_SCAN_TILE - 1) / JG_ROUTE_SCAN_TILE;
   {
-    const size_t bk_words = (size_t)n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets + n_tiles + 1;  // hist (whole tiles) | cur | tile
+    const size_t bk_words = (size_t)n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets + 1 + n_tiles + 1;  // hist (whole tiles) | cur | done | tile
     if (rt.bk_cap < bk_words) {
       if (rt.bk_hist) HIPCHK(hipFree(rt.bk_hist));
       rt.bk_cap = (uint32_t)bk_words;
       HIPCHK(hipMalloc((void**)&rt.bk_hist, bk_words * 4));
     }
-    bk.hist = rt.bk_hist, bk.cur = bk.hist + (size_t)n_tiles * JG_ROUTE_SCAN_TILE, bk.tile = bk.cur + bk.n_buckets;
+    bk.hist = rt.bk_hist, bk.cur = bk.hist + (size_t)n_tiles * JG_ROUTE_SCAN_TILE, bk.done = bk.cur + bk.n_buckets, bk.tile = bk.done + 1;
   }
-  const uint32_t bk_clear = n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets;  // counts and cursors
+  const uint32_t bk_clear = n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets + 1;  // counts, cursors and the scan's ticket
   // the delivering pass's jobs: every (sender, step) in one launch, every sender's exceptional-row queue in another
   std::vector<JgRouteRecJob> rjobs;
   std::vector<JgRouteXqJob> xjobs;
@@ -271,8 +271,11 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     hipLaunchKernelGGL(k_copy_words, dim3((n8 + JG_BLOCK - 1) / JG_BLOCK), dim3(JG_BLOCK), 0, st, (uint64_t*)slice_d(0), (const uint64_t*)slice_h(0), n8);
     HIPCHK(hipGetLastError());
   }
-  // -- 1. (launches) what the transport delivered last round, then this round's injected rows
-  if ((rc = apply_all(0, jobs_a, widest_a))) return rc;
+  // -- 1. (launches) what the transport delivered last round, then this round's injected rows.  (With the vote mail the
+  // delivered ROWS are other partitions' than the words', so their step could run BESIDE the receiving half on a stream of its
+  // own: tried in round 6 and removed - the two cross-queue dependencies cost 12-14 us more than the 34 us they hide,
+  // profiles/r06/ab_side_stream_sort_buckets.txt.)
+  if ((rc = apply_all(0, jobs_a, widest_a, L->stream))) return rc;
   if (!jobs_v.empty()) {  // (different nodes than jobs_a's: the two launches are independent of each other)
     hipLaunchKernelGGL(small_tiles(widest_v) ? k_apply_vote_runs_multi_small : k_apply_vote_runs_multi,
                        dim3(run_grid(widest_v), (uint32_t)jobs_v.size()), dim3(JG_BLOCK), 0, L->stream,
@@ -286,7 +289,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     hipLaunchKernelGGL(k_vote_half_multi, dim3(std::max(1u, std::min(n_chunks, slots)), R), dim3(JG_BLOCK), 0, L->stream, vjobs, vprev, vcur);
     HIPCHK(hipGetLastError());
   }
-  if ((rc = apply_all(1, jobs_b, widest_b))) return rc;
+  if ((rc = apply_all(1, jobs_b, widest_b, L->stream))) return rc;
   // -- 2. the dense round; ClientRequests only where the lead node (still) leads
   if (c->any) {  // (whoever owns a group reads `offered`: nothing to mask)
     if ((rc = cluster_launch_any(c))) return rc;
@@ -316,12 +319,15 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     const uint32_t seg_cap = rt.cap / n_seg;
     const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((std::min(fullest_seg, seg_cap) + JG_BLOCK - 1) / JG_BLOCK, 4096 / n_seg));
     hipLaunchKernelGGL(k_route_hist, dim3(grid, n_seg), dim3(JG_BLOCK), 0, st, (const uint32_t*)d_cursor, seg_cap, (const uint64_t*)rt.key, bk);
-    hipLaunchKernelGGL(k_route_scan, dim3(n_tiles), dim3(JG_BLOCK), 0, st, bk);
-    hipLaunchKernelGGL(k_route_scan_tiles, dim3(1), dim3(JG_BLOCK), 0, st, bk);
+    JgRouteXqDone xd{};  // (the queues the delivering pass delivered whole are emptied by the scan's last workgroup: no launch of their own)
+    xd.R = R, xd.route_words = ROUTE_WORDS, xd.n_seg = n_seg, xd.seg_cap = seg_cap, xd.count = rt.d_count, xd.cursor = d_cursor;
+    for (uint32_t s = 0; s < R; s++) xd.xq_n[s] = c->nodes[s]->dev.xq_n;
+    hipLaunchKernelGGL(k_route_scan_all, dim3(n_tiles), dim3(JG_BLOCK), 0, st, bk, xd);
     hipLaunchKernelGGL(k_route_scatter, dim3(grid, n_seg), dim3(JG_BLOCK), 0, st, (const uint32_t*)d_cursor, seg_cap, (const uint64_t*)rt.key,
                        (const uint32_t*)rt.idx, bk, rt.key_alt, rt.idx_alt);
-    hipLaunchKernelGGL(k_route_sort_build, dim3((bk.n_buckets + JG_ROUTE_SORT_BUCKETS - 1) / JG_ROUTE_SORT_BUCKETS), dim3(JG_BLOCK), 0, st, bk, rt.key_alt, rt.idx_alt,
-                       (const jg_msg_row*)rt.row, rt.cols);
+    const uint32_t per_wg = JG_ROUTE_SORT_BUCKETS;
+    hipLaunchKernelGGL(k_route_sort_build, dim3((bk.n_buckets + per_wg - 1) / per_wg), dim3(JG_BLOCK), 0, st, bk, rt.key_alt, rt.idx_alt,
+                       (const jg_msg_row*)rt.row, rt.cols, per_wg);
   };
   bool ordered = false;
   if (vwords) {  // the census of everything the round emitted (once: a repeated delivering pass finds it done)
@@ -410,7 +416,8 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       emptied.p[emptied.n++] = e->dev.xq_n;
     }
   }
-  if (emptied.n) hipLaunchKernelGGL(k_route_clear_words, dim3(1), dim3(64), 0, st, emptied);
+  // (a round that has rows to order has emptied them already: the last workgroup of its k_route_scan - JgRouteXqDone)
+  if (emptied.n && !ordered && !total) hipLaunchKernelGGL(k_route_clear_words, dim3(1), dim3(64), 0, st, emptied);
   // the staged rows in (destination, group, phase, emission index, sender) order -> the command columns of every
   // node's next round: bucket by (destination, group tile), sort every bucket in LDS (jg_route.h; round 2's library
   // radix sort took 240 us per 1.4 M rows)

@@ -475,6 +475,7 @@ struct JgRouteBuckets {
   uint32_t shift;   // key >> shift = bucket id
   uint32_t* hist;   // [n_buckets rounded up to the scan tile] counts, then (after the scan) offsets within the scan tile
   uint32_t* cur;    // [n_buckets] scatter cursors (zeroed with hist)
+  uint32_t* done;   // [1] scan tiles finished (zeroed with hist): the last workgroup of k_route_scan scans the tiles' totals
   uint32_t* tile;   // [n_tiles + 1] rows before each scan tile; entry n_tiles: all rows
   // first staging position of bucket i (i == n_buckets: the number of staged rows)
   __device__ __forceinline__ uint32_t off(uint32_t i) const {
@@ -523,9 +524,56 @@ __global__ __launch_bounds__(JG_BLOCK) void k_route_hist(const uint32_t* __restr
     __syncthreads();
   }
 }
-// exclusive scan of the bucket counts in two small launches: every workgroup scans its own tile of 1024 buckets
-// (one 16-byte access per thread; a single workgroup walking all 20 k buckets took 33-56 us), the tile totals
-// (a few dozen) are scanned by one wave's worth of a second launch
+// exclusive scan of the bucket counts: every workgroup scans its own tile of 1024 buckets (one 16-byte access per thread; a
+// single workgroup walking all 20 k buckets took 33-56 us), and the LAST workgroup to finish scans the tile totals (a few
+// dozen) - a launch of their own until round 6 (4.4 us of a round that is a chain of launches).  The same last workgroup
+// empties the exceptional queues the delivering pass - complete by now - has delivered whole (k_route_clear_words' job in the
+// rounds that have rows to order): a queue that kept nothing for the host, in a pass that does not have to be repeated (no
+// segment ran over, no emission index too wide: the host sees the same words and repeats it, with the queue intact).
+struct JgRouteXqDone {
+  uint32_t R, route_words, n_seg, seg_cap;
+  const uint32_t* count;   // [R][route_words] the senders' tallies (jg_route_tally)
+  const uint32_t* cursor;  // [n_seg]
+  uint32_t* xq_n[JG_MAX_REPLICAS];  // the senders' queue lengths (null: not this launch's business)
+};
+__global__ __launch_bounds__(JG_BLOCK) void k_route_scan_all(JgRouteBuckets b, JgRouteXqDone xd) {
+  static_assert(JG_ROUTE_SCAN_TILE == 4 * JG_BLOCK, "4 buckets per thread");
+  uint4* p = (uint4*)(b.hist + (size_t)blockIdx.x * JG_ROUTE_SCAN_TILE) + threadIdx.x;
+  const uint4 v = *p;  // (the array is padded to whole tiles and zeroed)
+  uint32_t tot;
+  const uint32_t ex = jg_block_exclusive_scan(v.x + v.y + v.z + v.w, &tot);
+  *p = uint4{ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z};
+  __shared__ uint32_t last_s;
+  if (threadIdx.x == 0) {
+    // (the total goes out and is read back through L2 atomics; the ticket's release / acquire orders it for the last workgroup)
+    (void)atomicExch(&b.tile[blockIdx.x], tot);
+    last_s = __hip_atomic_fetch_add(b.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  const uint32_t n_tiles = (b.n_buckets + JG_ROUTE_SCAN_TILE - 1u) / JG_ROUTE_SCAN_TILE;  // (= gridDim.x)
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base <= n_tiles; base += JG_BLOCK) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t t = i < n_tiles ? atomicAdd(&b.tile[i], 0u) : 0u;  // (an L2 read: what the other workgroups' exchanges left)
+    uint32_t tt;
+    const uint32_t e = carry_s + jg_block_exclusive_scan(t, &tt);
+    __syncthreads();
+    if (i <= n_tiles) b.tile[i] = e;
+    if (threadIdx.x == 0) carry_s += tt;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && xd.count) {
+    bool again = false;
+    for (uint32_t k = 0; k < xd.n_seg; k++) again = again || xd.cursor[k] > xd.seg_cap;
+    for (uint32_t s = 0; s < xd.R; s++) again = again || xd.count[(size_t)s * xd.route_words + xd.R + JG_ROUTE_OVERFLOW];
+    for (uint32_t s = 0; s < xd.R && !again; s++)
+      if (xd.xq_n[s] && !xd.count[(size_t)s * xd.route_words + xd.R + JG_ROUTE_KEPT_XQ]) *xd.xq_n[s] = 0;
+  }
+}
+// (the two-launch form: the fault records' and the node step's general-path ordering - off the routed round - keep it)
 __global__ __launch_bounds__(JG_BLOCK) void k_route_scan(JgRouteBuckets b) {
   static_assert(JG_ROUTE_SCAN_TILE == 4 * JG_BLOCK, "4 buckets per thread");
   uint4* p = (uint4*)(b.hist + (size_t)blockIdx.x * JG_ROUTE_SCAN_TILE) + threadIdx.x;
@@ -657,15 +705,17 @@ __device__ __forceinline__ void jg_route_sort_bucket(const JgRouteBuckets& b, ui
     c.term[p] = r.term, c.id[p] = r.id, c.aux[p] = r.aux;
   }
 }
-// A workgroup takes JG_ROUTE_SORT_BUCKETS consecutive buckets, one after the other: a round's rows sit in a few percent of the
-// R x G / 256 buckets (19.5 k at 1 M x 5), and a launch of one workgroup per bucket spent its 20 us dispatching empty ones.
-#define JG_ROUTE_SORT_BUCKETS 8u
+// A workgroup takes `per_wg` consecutive buckets, one after the other (a round's rows sit in a few percent of the
+// R x G / 256 buckets - 19.5 k at 1 M x 5 - and a launch of one workgroup per bucket spends most of its 20 us dispatching
+// empty ones; but a workgroup's buckets are served one BEHIND the other, each a chain of dependent loads: 8 per workgroup
+// took 27 us - profiles/r06/ab_sort_buckets.txt)
+#define JG_ROUTE_SORT_BUCKETS 2u
 __global__ __launch_bounds__(JG_BLOCK) void k_route_sort_build(JgRouteBuckets b, uint64_t* __restrict__ key, uint32_t* __restrict__ idx,
-                                                               const jg_msg_row* __restrict__ rows, JgRouteCols c) {
+                                                               const jg_msg_row* __restrict__ rows, JgRouteCols c, uint32_t per_wg) {
   __shared__ uint64_t s_key[JG_ROUTE_SORT_CAP];
   __shared__ uint32_t s_idx[JG_ROUTE_SORT_CAP];
-  for (uint32_t k = 0; k < JG_ROUTE_SORT_BUCKETS; k++) {
-    const uint32_t bucket = blockIdx.x * JG_ROUTE_SORT_BUCKETS + k;
+  for (uint32_t k = 0; k < per_wg; k++) {
+    const uint32_t bucket = blockIdx.x * per_wg + k;
     if (bucket >= b.n_buckets) return;
     jg_route_sort_bucket(b, bucket, s_key, s_idx, key, idx, rows, c);
     __syncthreads();  // (the LDS tile is the next bucket's)

@@ -51,6 +51,7 @@ template <class T, class U> static inline T atomicAnd(T* p, U v) { T o = *p; *p 
 template <class T, class U> static inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
 template <class T, class U> static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
 template <class T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+template <class T, class U> static inline T atomicExch(T* p, U v) { T o = *p; *p = (T)v; return o; }
 static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 static inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
 static inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
@@ -753,7 +754,7 @@ def _patched_sources():
     p = os.path.join(dst, "jg_route.h")
     text = open(p).read()
     line = '  static_assert(JG_ROUTE_SCAN_TILE == 4 * JG_BLOCK, "4 buckets per thread");'
-    assert text.count(line) == 1
+    assert text.count(line) == 2  # (k_route_scan_all and the two-launch form's k_route_scan)
     open(p, "w").write(text.replace(line, "  // (one-lane host build: " + line.strip() + ")"))
     return dst
 

@@ -289,6 +289,7 @@ template <class T, class U> static inline T atomicAnd(T* p, U v) { T o = *p; *p 
 template <class T, class U> static inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
 template <class T, class U> static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
 template <class T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+template <class T, class U> static inline T atomicExch(T* p, U v) { T o = *p; *p = (T)v; return o; }
 static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 static inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
 static inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
@@ -430,9 +431,9 @@ VIS int hw_route(const WgRoute* rt, const WgSender* snd, const JgVoteMail* vm, u
   const uint32_t tile_bits = std::min<uint32_t>(JG_ROUTE_TILE_BITS, rt->group_bits);
   bk.n_buckets = R << (rt->group_bits - tile_bits);
   const uint32_t n_tiles = (bk.n_buckets + JG_ROUTE_SCAN_TILE - 1) / JG_ROUTE_SCAN_TILE;
-  if ((size_t)n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets + n_tiles + 1 > rt->bk_words) return -1;
-  bk.hist = rt->bk, bk.cur = bk.hist + (size_t)n_tiles * JG_ROUTE_SCAN_TILE, bk.tile = bk.cur + bk.n_buckets;
-  const uint32_t bk_clear = n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets;
+  if ((size_t)n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets + 1 + n_tiles + 1 > rt->bk_words) return -1;
+  bk.hist = rt->bk, bk.cur = bk.hist + (size_t)n_tiles * JG_ROUTE_SCAN_TILE, bk.done = bk.cur + bk.n_buckets, bk.tile = bk.done + 1;
+  const uint32_t bk_clear = n_tiles * JG_ROUTE_SCAN_TILE + bk.n_buckets + 1;
   const JgVoteMail m = *vm;
   const uint32_t xgrid = 3;  // (the kernels stride: a few workgroups per queue are as good as 256 here)
   if ((rt->words & 1u) && !(rt->words & 2u)) {  // (the census once: a repeated delivering pass finds it done)
@@ -459,10 +460,9 @@ VIS int hw_route(const WgRoute* rt, const WgSender* snd, const JgVoteMail* vm, u
   const uint32_t seg_cap = rt->cap / rt->n_seg;
   const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((std::min(fullest, seg_cap) + JG_BLOCK - 1) / JG_BLOCK, 4096 / rt->n_seg));
   wg::launch(dim3(grid, rt->n_seg), JG_BLOCK, [&] { k_route_hist(d_cursor, seg_cap, rt->key, bk); });
-  wg::launch(dim3(n_tiles), JG_BLOCK, [&] { k_route_scan(bk); });
-  wg::launch(dim3(1), JG_BLOCK, [&] { k_route_scan_tiles(bk); });
+  wg::launch(dim3(n_tiles), JG_BLOCK, [&] { k_route_scan_all(bk, JgRouteXqDone{}); });  // (its last workgroup scans the tiles' totals; the queues are the harness's)
   wg::launch(dim3(grid, rt->n_seg), JG_BLOCK, [&] { k_route_scatter(d_cursor, seg_cap, rt->key, rt->idx, bk, rt->key_alt, rt->idx_alt); });
-  wg::launch(dim3((bk.n_buckets + JG_ROUTE_SORT_BUCKETS - 1) / JG_ROUTE_SORT_BUCKETS), JG_BLOCK, [&] { k_route_sort_build(bk, rt->key_alt, rt->idx_alt, rt->row, rt->cols); });
+  wg::launch(dim3((bk.n_buckets + 2) / 3), JG_BLOCK, [&] { k_route_sort_build(bk, rt->key_alt, rt->idx_alt, rt->row, rt->cols, 3); });
   return 0;
 }
 
