@@ -176,7 +176,12 @@ typedef struct jg_config {
 enum {
   /* keep the "commit" key out of the block keyspace, i.e. do NOT reproduce Q9
    * (SURVEY.md §7.3): unbounded ranges then simply end at the last block. */
-  JG_CFG_SEPARATE_COMMIT_KEY = 1u
+  JG_CFG_SEPARATE_COMMIT_KEY = 1u,
+  /* jg_step_node's row passes UNTILED: one thread per row scatters into the G-sized columns (three random 4-8-byte
+   * accesses per row and pass) instead of binning the rows by tile of 256 partitions and applying a tile's rows to its
+   * columns in LDS.  The results are the same bit for bit; the flat passes are the statement the tiled ones are held to
+   * (tests/test_node_step.py) and an A/B switch - nothing to set in production. */
+  JG_CFG_FLAT_ROW_PASSES = 2u
 };
 
 /* ---- SoA command batch (host memory), SURVEY.md §8(a) a18 -------------------- */

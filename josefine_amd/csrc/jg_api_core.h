@@ -350,6 +350,12 @@ struct jg_engine {
     size_t sp_cap = 0;
     uint32_t* bk_mem = nullptr;
     uint32_t bk_words = 0, bk_buckets = 0, bk_tile_bits = 0;
+    // the tiled row pass (jg_node.h, k_node_bin_* / k_node_tile): the chunks' counts per tile, the tiles' first rows, and the
+    // binned copies of a step's rows (grow-only; 38 bytes per row of room)
+    uint32_t *bin_cnt = nullptr, *bin_off = nullptr;
+    char* bin_mem = nullptr;
+    size_t bin_cap = 0;
+    uint32_t n_tiles = 0;
     uint32_t group_bits = 1;
     hipEvent_t ev_out = nullptr;
     hipEvent_t ev_cols = nullptr;      // behind the uploads of the handed-out columns: the pinned buffers are free again

@@ -185,6 +185,7 @@ void jg_engine_destroy(jg_engine* e) {
     if (p) (void)hipFree(p);
   if (e->fs_bk) (void)hipFree(e->fs_bk);
   if (e->node.sp_key) (void)hipFree(e->node.sp_key);
+  if (e->node.bin_mem) (void)hipFree(e->node.bin_mem);
   if (e->node.sp_idx) (void)hipFree(e->node.sp_idx);
   if (e->node.ev_out) (void)hipEventDestroy(e->node.ev_out);
   if (e->node.ev_cols) (void)hipEventDestroy(e->node.ev_cols);

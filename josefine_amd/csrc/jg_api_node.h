@@ -48,6 +48,11 @@ int node_ensure(jg_engine* e) {
   const uint32_t bk_tiles = (n.bk_buckets + JG_ROUTE_SCAN_TILE - 1) / JG_ROUTE_SCAN_TILE;
   n.bk_words = bk_tiles * JG_ROUTE_SCAN_TILE + n.bk_buckets + bk_tiles + 1;  // hist (whole tiles) | cur | tile
   A(n.bk_mem, n.bk_words);
+#if JG_BLOCK == 256
+  n.n_tiles = ((uint32_t)G + JGN_TILE - 1u) >> JGN_TILE_BITS;
+  A(n.bin_cnt, (size_t)JGN_BIN_WGS * (n.n_tiles + 1u));
+  A(n.bin_off, (size_t)n.n_tiles + 3u);
+#endif
 #undef A
   n.ready = true;
   return JG_OK;
@@ -105,8 +110,19 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     nd.cols_in_flight = true;
   }
   nd.col_mask = nd.col_hbc_mask = 0;  // (a hand-out covers one step)
-  hipLaunchKernelGGL(k_node_prefill, dim3(ggrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, e->uniform_self,
-                     halves & JG_NODE_LEADER_HALF, halves & JG_NODE_FOLLOWER_HALF, both_beats, col_mask);
+  // The row passes, TILED (jg_node.h): the rows binned by tile of 256 partitions, one workgroup per tile with the tile's
+  // columns in LDS - prefill, classification and scatter in one kernel, whole lines to and from HBM.  JG_NODE_FLAT=1 (an
+  // A/B and the tests' statement of it), a step without rows, or more tiles than the binning's LDS table holds: the flat
+  // passes (k_node_prefill + k_node_classify + k_node_route: three random accesses per row and pass).
+  static const bool flat_env = std::getenv("JG_NODE_FLAT") != nullptr;
+#if JG_BLOCK == 256
+  const bool tiled = n && !flat_env && !(e->cfg.flags & JG_CFG_FLAT_ROW_PASSES) && nd.n_tiles + 1u <= 16384u;
+#else
+  const bool tiled = false;
+#endif
+  if (!tiled)
+    hipLaunchKernelGGL(k_node_prefill, dim3(ggrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, e->uniform_self,
+                       halves & JG_NODE_LEADER_HALF, halves & JG_NODE_FOLLOWER_HALF, both_beats, col_mask);
   uint32_t n_sparse = 0;
   // the general path's sequence number is taken whether or not it runs: the shards of a multi-device engine must leave
   // one node step with the same numbers (the router merges their rows by step number first: jg_multi.h)
@@ -158,13 +174,64 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     for (uint32_t r = 0; r < JG_MAX_REPLICAS; r++) rows.ids[r] = r < R ? e->cfg.node_ids[r] : 0u;
     rows.blk_id = (const uint64_t*)(B + o_bid), rows.blk_next = (const uint64_t*)(B + o_bnext), rows.n_blocks = nb;
     const uint32_t rgrid = grid_for(n, 4096);
-    HIPCHK(hipMemsetAsync(nd.d_nsparse, 0, 8, e->stream));
-    hipLaunchKernelGGL(k_node_classify, dim3(rgrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rows, e->uniform_self,
-                       halves, both_beats, col_mask);
-    hipLaunchKernelGGL(k_node_route, dim3(rgrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rows, e->uniform_self,
-                       both_beats, nd.sp_key, nd.sp_idx, nd.d_nsparse);
+    HIPCHK(hipMemsetAsync(nd.d_nsparse, 0, 8, e->stream));  // (word 0: the general path's rows; word 1: the binning scan's ticket)
+#if JG_BLOCK == 256
+    if (tiled) {
+      if (nd.bin_cap < n) {
+        if (nd.bin_mem) HIPCHK(hipFree(nd.bin_mem));
+        nd.bin_cap = n + n / 2;
+        HIPCHK(hipMalloc((void**)&nd.bin_mem, nd.bin_cap * 41 + 64));
+      }
+      JgNodeBin bin{};
+      bin.n = (uint32_t)n, bin.n_tiles = nd.n_tiles;
+      bin.chunk = (uint32_t)(((n + JGN_BIN_WGS - 1) / JGN_BIN_WGS + JG_BLOCK - 1) / JG_BLOCK * JG_BLOCK);
+      bin.n_wg = (uint32_t)((n + bin.chunk - 1) / bin.chunk);
+      bin.cnt = nd.bin_cnt, bin.tile_off = nd.bin_off, bin.done = nd.d_nsparse + 1;
+      char* m = nd.bin_mem;  // widest first: the 16-byte records, then the optional columns the step has
+      const size_t cap = nd.bin_cap;
+      bin.rows = rows;
+      bin.rows.group = nullptr, bin.rows.kind = nullptr, bin.rows.id = nullptr;  // (in the records)
+      bin.rec = (JgNodeBinRec*)m, m += cap * 16;
+      bin.rows.term = has_term ? (const uint64_t*)m : nullptr, m += cap * 8;
+      bin.rows.aux = has_aux ? (const uint64_t*)m : nullptr, m += cap * 8;
+      bin.id_hi = lay.id32 ? nullptr : (uint32_t*)m, m += cap * 4;
+      bin.rows.from = has_from ? (const uint32_t*)m : nullptr, m += cap * 4;
+      bin.rows.flag = has_flag ? (const uint8_t*)m : nullptr;
+      const uint32_t nt1 = bin.n_tiles + 1u;
+      if (nt1 <= 4096u) hipLaunchKernelGGL((k_node_bin_count<4096>), dim3(bin.n_wg), dim3(JG_BLOCK), 0, e->stream, rows, bin, G);
+      else hipLaunchKernelGGL((k_node_bin_count<16384>), dim3(bin.n_wg), dim3(JG_BLOCK), 0, e->stream, rows, bin, G);
+      hipLaunchKernelGGL(k_node_bin_scan, dim3((nt1 + JG_BLOCK / JGN_BIN_SEGS - 1) / (JG_BLOCK / JGN_BIN_SEGS)), dim3(JG_BLOCK), 0, e->stream, bin);
+      if (nt1 <= 4096u) hipLaunchKernelGGL((k_node_bin_scatter<4096>), dim3(bin.n_wg), dim3(JG_BLOCK), 0, e->stream, e->dev, rows, bin);
+      else hipLaunchKernelGGL((k_node_bin_scatter<16384>), dim3(bin.n_wg), dim3(JG_BLOCK), 0, e->stream, e->dev, rows, bin);
+#define JG_LAUNCH_TILE(RR)                                                                                                                      \
+  if (halves & JG_NODE_FOLLOWER_HALF)                                                                                                            \
+    hipLaunchKernelGGL((k_node_tile<RR, true>), dim3(bin.n_tiles), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, bin, e->uniform_self, halves, \
+                       both_beats, col_mask, nd.sp_key, nd.sp_idx, nd.d_nsparse);                                                                \
+  else                                                                                                                                           \
+    hipLaunchKernelGGL((k_node_tile<RR, false>), dim3(bin.n_tiles), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, bin, e->uniform_self, halves, \
+                       both_beats, col_mask, nd.sp_key, nd.sp_idx, nd.d_nsparse)
+      switch (R) {
+        case 1: JG_LAUNCH_TILE(1); break;
+        case 2: JG_LAUNCH_TILE(2); break;
+        case 3: JG_LAUNCH_TILE(3); break;
+        case 4: JG_LAUNCH_TILE(4); break;
+        case 5: JG_LAUNCH_TILE(5); break;
+        case 6: JG_LAUNCH_TILE(6); break;
+        case 7: JG_LAUNCH_TILE(7); break;
+        default: JG_LAUNCH_TILE(8); break;
+      }
+#undef JG_LAUNCH_TILE
+      e->n_launch += 4;
+    } else
+#endif
+    {
+      hipLaunchKernelGGL(k_node_classify, dim3(rgrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rows, e->uniform_self,
+                         halves, both_beats, col_mask);
+      hipLaunchKernelGGL(k_node_route, dim3(rgrid), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rows, e->uniform_self,
+                         both_beats, nd.sp_key, nd.sp_idx, nd.d_nsparse);
+      e->n_launch += 3;
+    }
     HIPCHK(hipGetLastError());
-    e->n_launch += 3;
     HIPCHK(hipMemcpyAsync(nd.h_nsparse, nd.d_nsparse, 4, hipMemcpyDeviceToHost, e->stream));
     if (!async) {
       // the one synchronisation of a synchronous step: how many rows take the general path sizes that launch

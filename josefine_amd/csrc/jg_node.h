@@ -319,6 +319,371 @@ __global__ __launch_bounds__(JG_BLOCK) void k_node_route(JgDev d, JgNodeCols c, 
   }
 }
 
+// ---- the same two passes, TILED (round 6) ---------------------------------------------------------------------------
+// k_node_classify and k_node_route touch, per 9-byte row, the partition's class word, its arrival-index entry and its
+// answer word: three random 4-8-byte accesses into 40 MB columns per row and pass - 126-134 bytes of HBM traffic per row
+// (PMC, profiles/r05/event_loop_row_order_and_traffic.txt), 339 + 288 us for the 7 M shuffled rows of a 1 M x 5 tick, 78 %
+// of the event loop's kernel time.  Tiled: the rows are first BINNED by tile of JGN_TILE partitions (a counting pass, a
+// scan, a scattering pass - per workgroup an LDS table of cursors, no global atomic), then ONE workgroup per tile keeps the
+// tile's columns in LDS - the class words, the R answer words, the 2 R arrival indices, the follower half's inbox - applies
+// the tile's rows to them (classification, a barrier, the scatter: LDS atomics), and writes the columns back in whole
+// lines.  What k_node_prefill wrote is the tile's initial value: that launch is gone too.  Results are the flat passes',
+// bit for bit (the binning carries every row's ARRIVAL INDEX: nothing depends on the order of a tile's rows) - the flat
+// kernels stay as the statement of it (JG_NODE_FLAT=1; tests/test_node_step.py::test_tiled_row_pass_equals_the_flat_one).
+#if JG_BLOCK == 256  // (the kernels: 256-thread workgroups; the one-lane and one-wave host builds of the tests run the flat passes)
+#define JGN_TILE_BITS 8u
+#define JGN_TILE (1u << JGN_TILE_BITS)  // partitions per tile: one per thread of the tile's workgroup
+static_assert(JGN_TILE == JG_BLOCK, "a partition per thread");
+#define JGN_BIN_WGS 512u   // row chunks: workgroups of the counting and the scattering pass
+#define JGN_BIN_SEGS 8u    // the scan: a thread per (tile, segment of JGN_BIN_WGS / JGN_BIN_SEGS chunks)
+// A binned row: what every row has, as ONE 16-byte record - one store per row in the scattering pass, one load per row and
+// pass in the tile's kernel (as four columns the pass issued four scattered stores per row: 411 us per 7 M rows, more than
+// the flat passes it replaces - profiles/r06/tiled_row_pass.txt).  The optional columns (from, term, aux, flag, the upper
+// half of a 64-bit id) stay columns of their own, written only where the step has them: the compact bus has none.
+struct JgNodeBinRec {
+  uint32_t group, idx, id_lo, kind;  // kind: the row's kind byte as it came (JG_COL_PACKED_KIND: kind | sender slot << 4 | flag << 7)
+};
+struct JgNodeBin {
+  uint32_t n, n_tiles, n_wg, chunk;  // rows; tiles (bin n_tiles: rows whose group is out of range); chunks; rows per chunk
+  uint32_t* cnt;       // [n_wg][n_tiles + 1] rows of chunk w in tile t; after the scan: where chunk w's rows of tile t begin WITHIN the tile
+  uint32_t* tile_off;  // [n_tiles + 2] first row of tile t in the binned arrays (after the scan); before: the tiles' totals
+  uint32_t* done;      // the scan's ticket (zero before a step)
+  JgNodeBinRec* rec;   // [n] binned
+  uint32_t* id_hi;     // [n] (a 64-bit id column) or null
+  JgNodeRows rows;     // the binned copies of the optional columns the step has (from / term / aux / flag), the block side arrays and the formats' switches
+};
+template <uint32_t CAP>  // CAP >= n_tiles + 1: the LDS table
+__global__ __launch_bounds__(JG_BLOCK) void k_node_bin_count(JgNodeRows a, JgNodeBin b, uint32_t G) {
+  __shared__ uint32_t s_cnt[CAP];
+  const uint32_t nt1 = b.n_tiles + 1u;
+  for (uint32_t t = threadIdx.x; t < nt1; t += JG_BLOCK) s_cnt[t] = 0;
+  __syncthreads();
+  const uint32_t lo = blockIdx.x * b.chunk, hi = min(lo + b.chunk, a.n);  // (lo: a multiple of JG_BLOCK)
+  // four rows per thread and trip, one 16-byte load (a 4-byte load per trip left the loop waiting for one round trip to HBM
+  // per 256 rows: 30 us for a pass that reads 28 MB)
+  for (uint32_t i = lo + threadIdx.x * 4u; i < hi; i += JG_BLOCK * 4u) {
+    uint32_t g[4];
+    if (i + 4u <= hi) {
+      const uint4 v = *(const uint4*)(a.group + i);
+      g[0] = v.x, g[1] = v.y, g[2] = v.z, g[3] = v.w;
+    } else {
+      for (uint32_t k = 0; k < 4u; k++) g[k] = i + k < hi ? a.group[i + k] : 0xffffffffu;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++)
+      if (i + k < hi) atomicAdd(&s_cnt[g[k] < G ? g[k] >> JGN_TILE_BITS : b.n_tiles], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = b.cnt + (size_t)blockIdx.x * nt1;
+  for (uint32_t t = threadIdx.x; t < nt1; t += JG_BLOCK) out[t] = s_cnt[t];
+}
+// counts -> places: thread (tile, segment) sums its chunks' counts of the tile, the segments' sums are scanned in LDS, the
+// thread rewrites its chunks' counts as running offsets within the tile; the last workgroup to finish scans the tiles' totals
+__global__ __launch_bounds__(JG_BLOCK) void k_node_bin_scan(JgNodeBin b) {
+  constexpr uint32_t TL = JG_BLOCK / JGN_BIN_SEGS;  // tiles per workgroup: 32 neighbours = a 128-byte line per chunk
+  static_assert(JG_BLOCK % JGN_BIN_SEGS == 0 && JGN_BIN_WGS % JGN_BIN_SEGS == 0, "scan geometry");
+  __shared__ uint32_t s_part[JGN_BIN_SEGS][TL];
+  const uint32_t nt1 = b.n_tiles + 1u;
+  const uint32_t tl = threadIdx.x % TL, seg = threadIdx.x / TL;
+  const uint32_t t = blockIdx.x * TL + tl;
+  const uint32_t per = (b.n_wg + JGN_BIN_SEGS - 1u) / JGN_BIN_SEGS, w0 = min(seg * per, b.n_wg), w1 = min(w0 + per, b.n_wg);
+  // (eight loads in flight per thread: one at a time the two loops were 2 x 64 round trips one behind the other, 39 us)
+  constexpr uint32_t U = 8;
+  uint32_t sum = 0;
+  if (t < nt1)
+    for (uint32_t w = w0; w < w1; w += U) {
+      uint32_t v[U];
+#pragma unroll
+      for (uint32_t k = 0; k < U; k++) v[k] = w + k < w1 ? b.cnt[(size_t)(w + k) * nt1 + t] : 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < U; k++) sum += v[k];
+    }
+  s_part[seg][tl] = sum;
+  __syncthreads();
+  uint32_t pre = 0, tot = 0;
+  for (uint32_t q = 0; q < JGN_BIN_SEGS; q++) {
+    const uint32_t v = s_part[q][tl];
+    pre += q < seg ? v : 0u;
+    tot += v;
+  }
+  if (t < nt1) {
+    uint32_t run = pre;
+    for (uint32_t w = w0; w < w1; w += U) {
+      uint32_t v[U];
+#pragma unroll
+      for (uint32_t k = 0; k < U; k++) v[k] = w + k < w1 ? b.cnt[(size_t)(w + k) * nt1 + t] : 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < U; k++) {
+        if (w + k < w1) b.cnt[(size_t)(w + k) * nt1 + t] = run;
+        run += v[k];
+      }
+    }
+    if (seg == 0) (void)atomicExch(&b.tile_off[t], tot);
+  }
+  __shared__ uint32_t last_s;
+  __syncthreads();
+  if (threadIdx.x == 0) last_s = __hip_atomic_fetch_add(b.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+  __syncthreads();
+  if (!last_s) return;
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base <= nt1; base += JG_BLOCK) {  // exclusive scan of the nt1 totals; entry nt1: all rows
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nt1 ? atomicAdd(&b.tile_off[i], 0u) : 0u;
+    uint32_t tt;
+    const uint32_t e = carry_s + jg_block_exclusive_scan(v, &tt);
+    __syncthreads();
+    if (i <= nt1) b.tile_off[i] = e;
+    if (threadIdx.x == 0) carry_s += tt;
+    __syncthreads();
+  }
+}
+template <uint32_t CAP>
+__global__ __launch_bounds__(JG_BLOCK) void k_node_bin_scatter(JgDev d, JgNodeRows a, JgNodeBin b) {
+  __shared__ uint32_t s_cur[CAP];
+  const uint32_t nt1 = b.n_tiles + 1u;
+  const uint32_t* mine = b.cnt + (size_t)blockIdx.x * nt1;
+  for (uint32_t t = threadIdx.x; t < nt1; t += JG_BLOCK) s_cur[t] = b.tile_off[t] + mine[t];
+  __syncthreads();
+  const uint32_t lo = blockIdx.x * b.chunk, hi = min(lo + b.chunk, a.n);
+  const JgNodeRows& o = b.rows;
+  constexpr uint32_t U = 4;  // rows per thread and trip: their loads first, back to back
+  for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += JG_BLOCK * U) {
+    uint32_t g[U], kind[U], idl[U];
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++) {
+      const uint32_t i = i0 + k * JG_BLOCK;
+      const bool in = i < hi;
+      g[k] = in ? a.group[i] : 0xffffffffu;
+      kind[k] = in ? a.kind[i] : 0u;
+      idl[k] = in ? (a.id32 ? ((const uint32_t*)a.id)[i] : (uint32_t)a.id[i]) : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < U; k++) {
+      const uint32_t i = i0 + k * JG_BLOCK;
+      if (i >= hi) continue;
+      if (g[k] >= d.G) {  // (rows committed with JG_COL_UNCHECKED are validated on the device: not applied, JG_EINVAL)
+        *d.err = 7;
+        continue;
+      }
+      const uint32_t at = atomicAdd(&s_cur[g[k] >> JGN_TILE_BITS], 1u);
+      *(uint4*)&b.rec[at] = make_uint4(g[k], i, idl[k], kind[k]);
+      if (b.id_hi) b.id_hi[at] = (uint32_t)(a.id[i] >> 32);
+      if (a.from) ((uint32_t*)o.from)[at] = a.from[i];
+      if (a.term) ((uint64_t*)o.term)[at] = a.term[i];
+      if (a.aux) ((uint64_t*)o.aux)[at] = a.aux[i];
+      if (a.flag) ((uint8_t*)o.flag)[at] = a.flag[i];
+    }
+  }
+}
+// a binned row, decoded: what JgNodeRows' accessors say of row k of the binned arrays
+struct JgNodeBinRow {
+  uint32_t group, idx, kind, from, flag;
+  uint64_t id, term, aux;
+};
+__device__ __forceinline__ JgNodeBinRow jg_node_bin_row(const JgNodeBin& b, uint32_t k) {
+  const uint4 v = *(const uint4*)&b.rec[k];
+  const JgNodeRows& a = b.rows;
+  JgNodeBinRow r;
+  r.group = v.x, r.idx = v.y;
+  r.id = (uint64_t)v.z | (b.id_hi ? (uint64_t)b.id_hi[k] << 32 : 0ull);
+  const uint32_t kb = v.w;
+  r.kind = a.packed ? kb & 15u : kb;
+  if (a.packed) {
+    const uint32_t slot = (kb >> 4) & 7u;
+    uint32_t id = 0;  // (a select per slot, not an indexed read of a kernel argument: JgNodeRows::from_of)
+#pragma unroll
+    for (uint32_t q = 0; q < JG_MAX_REPLICAS; q++) id = slot == q ? a.ids[q] : id;
+    r.from = ((0xfcu >> (kb & 15u)) & 1u) ? id : 0u;
+    r.flag = (kb >> 7) & 1u;
+  } else {
+    r.from = a.from ? a.from[k] : 0u;
+    r.flag = a.flag ? a.flag[k] : 0u;
+  }
+  r.term = a.term ? a.term[k] : 0ull;
+  r.aux = a.aux ? a.aux[k] : 0ull;
+  return r;
+}
+// the tile's columns in LDS: sized by R (R = 5, both halves: 40 KB; the leader half alone: 24 KB)
+template <int R>
+struct JgNodeTile {
+  uint32_t cls[JGN_TILE], flags[JGN_TILE];
+  uint64_t answers[R][JGN_TILE];
+  uint32_t arr[2 * R][JGN_TILE];
+  uint64_t token[JGN_TILE];
+  uint64_t sparse[JGN_TILE / 64];
+};
+struct JgNodeTileF {  // ... and the follower half's inbox with its consistency columns (16 KB)
+  jg_leader_beat f_beat[JGN_TILE];
+  uint64_t f_ae[JGN_TILE];
+  uint32_t f_leader[JGN_TILE];
+  uint32_t fo[2][JGN_TILE];
+  uint64_t lt_max[JGN_TILE], lt_min[JGN_TILE];
+  uint32_t lf_max[JGN_TILE], lf_min[JGN_TILE];
+};
+template <int R, bool FOLLOWER>
+__global__ __launch_bounds__(JG_BLOCK) void k_node_tile(JgDev d, JgNodeCols c, JgNodeBin b, int us, uint32_t halves, uint32_t both_beats, uint32_t col_mask,
+                                                        uint64_t* __restrict__ sp_key, uint32_t* __restrict__ sp_idx, uint32_t* __restrict__ n_sparse) {
+  __shared__ JgNodeTile<R> T;
+  __shared__ JgNodeTileF F[1];  // (the leader-only instance never touches it: the compiler drops it)
+  const uint32_t G = d.G;
+  const uint32_t g0 = blockIdx.x << JGN_TILE_BITS, p = threadIdx.x, g = g0 + p;
+  const bool live = g < G;
+  const bool leader_half = halves & 1u, follower_half = FOLLOWER && (halves & 2u);
+  // -- the tile as k_node_prefill leaves a partition: nothing from anybody, the own slot's word = zero appends
+  const uint32_t f = live ? d.flags[g] : 0u;
+  const uint32_t self = us >= 0 ? (uint32_t)us : (f & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
+  T.cls[p] = 0, T.flags[p] = f;
+#pragma unroll
+  for (int r = 0; r < R; r++) T.answers[r][p] = (uint32_t)r == self ? JG_ANSWER(0, JG_HB_NONE) : JG_NO_ACK;
+#pragma unroll
+  for (int r = 0; r < 2 * R; r++) T.arr[r][p] = 0;
+  T.token[p] = 0;
+  if (FOLLOWER) {
+    F[0].fo[0][p] = F[0].fo[1][p] = 0;
+    F[0].f_beat[p] = jg_leader_beat{0, JG_NO_ACK}, F[0].f_ae[p] = JG_NO_ACK, F[0].f_leader[p] = 0;
+    F[0].lt_max[p] = 0, F[0].lt_min[p] = ~0ull, F[0].lf_max[p] = 0, F[0].lf_min[p] = ~0u;
+  }
+  if (p < JGN_TILE / 64) T.sparse[p] = 0;
+  __syncthreads();
+  const JgNodeRows& a = b.rows;
+  const uint32_t lo = b.tile_off[blockIdx.x], hi = b.tile_off[blockIdx.x + 1];
+  // -- k_node_classify over the tile's rows (any order: every row carries its arrival index)
+  for (uint32_t k = lo + p; k < hi; k += JG_BLOCK) {
+    const JgNodeBinRow row = jg_node_bin_row(b, k);
+    const uint32_t q = row.group - g0, kind = row.kind, i = row.idx;
+    if (kind >= JG_CMD__COUNT) {
+      *d.err = 7;
+      continue;
+    }
+    uint32_t bit = 0;
+    bool sparse = false;
+    const uint32_t fq = T.flags[q];
+    const uint32_t selfq = us >= 0 ? (uint32_t)us : (fq & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
+    switch (kind) {
+      case JG_CMD_APPEND_RESPONSE:
+      case JG_CMD_HEARTBEAT_RESPONSE: {
+        const int s = jg_node_slot_of(d, row.from);
+        if (s >= 0 && ((col_mask >> s) & 1u)) *d.err = 6;  // this sender's answers arrived as a column: rows AND a column in one tick
+        sparse = !leader_half || s < 0 || (uint32_t)s == selfq || (kind == JG_CMD_APPEND_RESPONSE && row.id >= JG_MAILBOX_NONE);
+        bit = s < 0 ? 0u : 1u << ((kind == JG_CMD_APPEND_RESPONSE ? JGN_ACK_SHIFT : JGN_HBR_SHIFT) + (uint32_t)s);
+        if (!sparse) T.arr[(kind == JG_CMD_APPEND_RESPONSE ? 0 : R) + s][q] = i + 1u;
+        break;
+      }
+      case JG_CMD_CLIENT_REQUEST:
+        sparse = !leader_half || (fq & JGF_ROLE_MASK) != JG_ROLE_LEADER;
+        bit = JGN_CR;
+        if (!sparse) T.arr[selfq][q] = i + 1u;
+        break;
+      case JG_CMD_HEARTBEAT:
+        sparse = !follower_half || row.id == JG_NO_ACK || row.from == 0 || (fq & JGF_ROLE_MASK) == JG_ROLE_LEADER;
+        bit = JGN_HB;
+        if (FOLLOWER) F[0].fo[0][q] = i + 1u;
+        break;
+      case JG_CMD_APPEND_ENTRIES: {
+        uint64_t from;
+        sparse = !follower_half || row.from == 0 || !jg_node_ae_run(a, row.id, row.aux, &from) || (fq & JGF_ROLE_MASK) == JG_ROLE_LEADER;
+        bit = JGN_AE;
+        if (FOLLOWER) F[0].fo[1][q] = i + 1u;
+        break;
+      }
+      default: sparse = true;
+    }
+    if (FOLLOWER && both_beats && (kind == JG_CMD_HEARTBEAT || kind == JG_CMD_APPEND_ENTRIES)) {
+      atomicMax((unsigned long long*)&F[0].lt_max[q], (unsigned long long)row.term);
+      atomicMin((unsigned long long*)&F[0].lt_min[q], (unsigned long long)row.term);
+      atomicMax(&F[0].lf_max[q], row.from);
+      atomicMin(&F[0].lf_min[q], row.from);
+    }
+    const uint32_t old = atomicOr(&T.cls[q], bit | (sparse ? JGN_SPARSE : 0u));
+    if ((old & bit) && !sparse) atomicOr(&T.cls[q], JGN_SPARSE);  // a second row for the same mailbox entry
+  }
+  __syncthreads();
+  // -- k_node_route
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t span = hi - lo, span_up = (span + 63u) & ~63u;  // (whole waves take every iteration together: the appends are wave-aggregated)
+  for (uint32_t j = p; j < span_up; j += JG_BLOCK) {
+    const uint32_t k = lo + j;
+    const bool in = j < span;
+    JgNodeBinRow row{};
+    if (in) row = jg_node_bin_row(b, k);
+    const uint32_t q = in ? row.group - g0 : 0u;
+    const bool valid = in && row.kind < JG_CMD__COUNT;
+    const uint32_t w = valid ? T.cls[q] : 0u;
+    bool sparse = valid && (w & JGN_SPARSE);
+    if (FOLLOWER && valid && !sparse && both_beats && (w & (JGN_HB | JGN_AE)) == (JGN_HB | JGN_AE))
+      sparse = F[0].lt_max[q] != F[0].lt_min[q] || F[0].lf_max[q] != F[0].lf_min[q] || F[0].fo[1][q] < F[0].fo[0][q];
+    const uint32_t i = row.idx;
+    const uint64_t m = __ballot(sparse);
+    if (m) {
+      uint32_t base = 0;
+      if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(n_sparse, (uint32_t)__popcll(m));
+      base = __shfl(base, __ffsll((long long)m) - 1, 64);
+      if (sparse) {
+        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        sp_key[at] = (uint64_t)(g0 + q) << 32 | i;
+        sp_idx[at] = i;
+        atomicOr((unsigned long long*)&T.sparse[q >> 6], 1ull << (q & 63u));
+      }
+    }
+    if (!valid || sparse) continue;
+    const uint32_t kind = row.kind;
+    const uint32_t fq = T.flags[q];
+    const uint32_t selfq = us >= 0 ? (uint32_t)us : (fq & JGF_SELF_MASK) >> JGF_SELF_SHIFT;
+    switch (kind) {
+      case JG_CMD_APPEND_RESPONSE: {
+        const int s = jg_node_slot_of(d, row.from);
+        atomicAnd((unsigned long long*)&T.answers[s][q], (unsigned long long)((row.id << 8) | 0xffull));
+        if ((w & JGN_CR) && i + 1u < T.arr[selfq][q])  // it arrived before the group's ClientRequest: it met the head before the append
+          atomicOr((unsigned long long*)&T.answers[selfq][q], 1ull << (JGN_PRE_SHIFT + (uint32_t)s));
+        break;
+      }
+      case JG_CMD_HEARTBEAT_RESPONSE: {
+        const int s = jg_node_slot_of(d, row.from);
+        const uint64_t has = row.flag ? 1 : 0;
+        atomicAnd((unsigned long long*)&T.answers[s][q], (unsigned long long)(~0xffull | has));
+        if (!has) c.hbr_commit[(size_t)s * G + g0 + q] = row.id;
+        break;
+      }
+      case JG_CMD_CLIENT_REQUEST:
+        atomicOr((unsigned long long*)&T.answers[selfq][q], 1ull << 8);
+        T.token[q] = row.id;
+        break;
+      case JG_CMD_HEARTBEAT:
+        if (FOLLOWER) F[0].f_beat[q] = jg_leader_beat{row.term, row.id}, F[0].f_leader[q] = row.from;
+        break;
+      default: {  // JG_CMD_APPEND_ENTRIES
+        uint64_t from = 0;
+        (void)jg_node_ae_run(a, row.id, row.aux, &from);
+        if (FOLLOWER) {
+          F[0].f_ae[q] = JG_AE(from, row.aux);
+          if (!(w & JGN_HB)) {  // (with a Heartbeat in the batch: the same term and sender, written by its row)
+            F[0].f_beat[q].term = row.term;
+            F[0].f_leader[q] = row.from;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // -- the columns go home, a line per wave and column
+  if (live) {
+    c.fsm_delta[g] = 0;
+    if (leader_half) {
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if ((uint32_t)r == self || !((col_mask >> r) & 1u)) c.answers[(size_t)r * G + g] = T.answers[r][p];
+#pragma unroll
+      for (int r = 0; r < 2 * R; r++) c.arr[(size_t)r * G + g] = T.arr[r][p];
+      c.token[g] = T.token[p];
+    }
+    if (follower_half) c.f_beat[g] = F[0].f_beat[p], c.f_ae[g] = F[0].f_ae[p], c.f_leader[g] = F[0].f_leader[p];
+  }
+  if (p < JGN_TILE / 64 && g0 + p * 64u < G) c.sparse_bits[(g0 >> 6) + p] = T.sparse[p];
+}
+#endif  // JG_BLOCK == 256
+
 // keep-flagged rows, already compacted (stream order) and sorted by group (stable): index list -> the
 // command columns k_apply_rows consumes
 struct JgNodeSorted {

@@ -293,6 +293,34 @@ def test_node_step_parity(R, flags, G):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R,flags,G", [(5, capi.CFG_SEPARATE_COMMIT_KEY, 70_001), (3, 0, 20_003), (2, 0, 257)])
+def test_tiled_row_pass_equals_the_flat_one(R, flags, G):
+    """jg_step_node's row passes TILED (the default since round 6: the rows binned by tile of 256 partitions, a tile's columns
+    in LDS - jg_node.h k_node_bin_* / k_node_tile) against the FLAT passes (JG_CFG_FLAT_ROW_PASSES: k_node_prefill +
+    k_node_classify + k_node_route, one thread per row scattering into the G-sized columns): the same traffic into two
+    engines - partitions in the hundreds of tiles, a ragged last tile, rows of every kind incl. the general path's - and
+    every outbox word, state column, drained row and counter equal after every tick; both are held to the oracle by the
+    other tests of this file (the tiled one by default)."""
+    T = 12
+    tiled, flat, rng = mixed_pair(BatchedRaft, lambda *a, **kw: BatchedRaft(*a, **{**kw, "flags": kw.get("flags", 0) | capi.CFG_FLAT_ROW_PASSES}), G, R, seed=5 + R, flags=flags,
+                                  election_timeout_ms=(700, 1500))
+    general = 0
+    for t in range(T):
+        now = 100 * (t + 1)
+        cols = node_traffic(rng, flat, token0=1000 * t)
+        outs = []
+        for e in (tiled, flat):
+            e.submit_columns(**cols)
+            outs.append(e.step_node(now))
+        compare_outboxes(outs[0], outs[1], f"tick {t}")
+        compare_snapshots(tiled, flat, f"tick {t}")
+        compare_drains(tiled, flat, f"tick {t}")
+        assert outs[0]["rows_general"] == outs[1]["rows_general"], t
+        general += outs[1]["rows_general"]
+    assert general > 0 and tiled.counters()["decisions"] == flat.counters()["decisions"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("leader,follower,tick", [(True, False, True), (False, True, True), (True, True, False)])
 def test_node_step_halves_and_no_tick(leader, follower, tick):
     G, R = 1500, 3
