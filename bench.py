@@ -1130,9 +1130,6 @@ def main():
     ap.add_argument("--groups", type=int, default=1_000_000, help="partitions per GPU")
     ap.add_argument("--replicas", type=int, default=5)
     ap.add_argument("--mode", type=int, default=0, help="0 steady-state (#3/#4), 1 ragged (#2)")
-    ap.add_argument("--graph", type=int, choices=[0, 1], default=1,
-                    help="the headline's K steps as K single-tick launches issued as ONE captured hipGraph (jg_dense_acks_graph_prepare outside the "
-                         "timed region, jg_dense_acks_graph_launch inside it); 0: K eager calls (the line carries both)")
     ap.add_argument("--ticks-per-launch", type=int, default=1,
                     help="T>1: temporal fusion (jg_step_dense_acks_device_n), state read/written once per T ticks")
     ap.add_argument("--failures", type=int, default=0,
@@ -1317,34 +1314,17 @@ def main():
         drained["applies"] += len(eng.drain_applies(copy=False))
         drained["faults"] += len(eng.drain_faults())
 
-    # The headline's K steps as K SINGLE-tick launches - the kernel and the bytes of jg_step_dense_acks_device, not the T-tick
-    # fusion - issued as ONE captured hipGraph (jg_dense_acks_graph_prepare, outside the timed region: milliseconds of host
-    # time in which nothing runs; jg_dense_acks_graph_launch inside it): a host that holds the ack blocks of K ticks pays
-    # one launch's latency for all of them.  --graph 0: K eager calls; both are on the line (`eager`).
-    use_graph = bool(args.graph) and T == 1 and not args.failures and args.mode == 0
-
-    def prepare_region():
-        if use_graph:
-            eng._check(api.dense_acks_graph_prepare(h, C.c_void_p(stream_buf.value + W * tick_bytes), K))
-
-    def issue_region():
-        if use_graph:
-            eng._check(api.dense_acks_graph_launch(h))
-            return K
-        return run_ticks(W, W + K)
-
     run_ticks(0, W)
     if fail_rows is not None:  # one more full drain cycle outside the timed region (pinned queues at their working size)
         eng.drain_flush()
         consume()
         eng._check(api.kernel_timing(h, 4))  # (every 4th dense launch: the event pair is not free in a tick of three small kernels)
-    prepare_region()
     barrier()
     c0 = eng.counters()
     barrier()
     t0 = time.perf_counter()
     eng._check(api.timer_start(h))
-    n_launches = issue_region()
+    n_launches = run_ticks(W, W + K)
     ev_ms = C.c_float(0)
     eng._check(api.timer_stop(h, C.byref(ev_ms)))  # HIP events on the engine's stream (synchronises it)
     torch.cuda.synchronize()
@@ -1359,7 +1339,6 @@ def main():
     # region is reported (`steps` stays K: one region; every region is listed in `timed_regions`).
     ticks_done = W + K
     regions = [(wall, ev_ms.value)]
-    eager_regions = []  # (use_graph: the same K steps as K eager calls, beside the graph's)
     if T == 1 and not args.failures and args.mode == 0:
         all_short = torch.tensor([1.0 if wall < 0.05 else 0.0], dtype=torch.float64, device=red_dev)
         if world > 1:
@@ -1368,20 +1347,6 @@ def main():
         for _ in range(n_more):
             for t in range(K):  # the next K ticks of the stream into the slots of W .. W+K-1
                 eng._check(api.synth_fill_acks_device(h, 0, ticks_done + t, sim, C.c_void_p(stream_buf.value + (W + t) * tick_bytes)))
-            prepare_region()
-            barrier()
-            tr0 = time.perf_counter()
-            eng._check(api.timer_start(h))
-            issue_region()
-            ev_r = C.c_float(0)
-            eng._check(api.timer_stop(h, C.byref(ev_r)))
-            torch.cuda.synchronize()
-            regions.append((time.perf_counter() - tr0, ev_r.value))
-            barrier()
-            ticks_done += K
-        for _ in range(5 if use_graph and n_more else 0):  # ... and as eager calls
-            for t in range(K):
-                eng._check(api.synth_fill_acks_device(h, 0, ticks_done + t, sim, C.c_void_p(stream_buf.value + (W + t) * tick_bytes)))
             barrier()
             tr0 = time.perf_counter()
             eng._check(api.timer_start(h))
@@ -1389,7 +1354,7 @@ def main():
             ev_r = C.c_float(0)
             eng._check(api.timer_stop(h, C.byref(ev_r)))
             torch.cuda.synchronize()
-            eager_regions.append((time.perf_counter() - tr0, ev_r.value))
+            regions.append((time.perf_counter() - tr0, ev_r.value))
             barrier()
             ticks_done += K
         if n_more:
@@ -1445,7 +1410,7 @@ def main():
                    "bytes_moved_per_group_step": 8 * R + 28 / TB,
                    "note": "same results bit for bit; state read/written once per launch"}
 
-    decisions = decisions / (len(regions) + len(eager_regions))  # (every region takes the same decisions: K steps of the same stream)
+    decisions = decisions / len(regions)  # (every region takes the same decisions: K steps of the same stream)
     per_rank = None
     if world > 1:
         td = torch.tensor([float(decisions)], dtype=torch.float64, device=red_dev)
@@ -1484,12 +1449,6 @@ def main():
                 "parallelism": f"{world} independent shard(s), no collective", **devices_config(args, world),
             },
             "group_steps_per_s": G * world * K / wall,
-            "issue": ("K single-tick launches (k_leader_tick_dense, one per tick: the kernel and the bytes of jg_step_dense_acks_device) as ONE captured hipGraph - "
-                      "jg_dense_acks_graph_prepare before the timed region, jg_dense_acks_graph_launch inside it" if use_graph else "K eager jg_step_dense_acks_device calls"),
-            "eager": ({"ms_per_step": sorted(r[0] for r in eager_regions)[(len(eager_regions) - 1) // 2] * 1e3 / K,
-                       "ms_per_step_events": sorted(r[1] for r in eager_regions)[(len(eager_regions) - 1) // 2] / K,
-                       "regions": len(eager_regions), "what": "the same K steps as K eager jg_step_dense_acks_device calls (round 5's headline), this rank"}
-                      if eager_regions else None),
             "timed_regions": {"n": len(regions_all), "reported": "median" if len(regions_all) > 1 else "the one region",
                               "ms_per_step_each": [r[0] * 1e3 / K for r in regions_all],
                               "ms_per_step_events_each": [r[1] / K for r in regions_all],

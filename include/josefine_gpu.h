@@ -389,16 +389,6 @@ int jg_step_dense_acks_device(jg_engine* e, const uint64_t* acks_dev);
  * acks_dev + t*R*G.  Identical in effect to n_ticks calls of jg_step_dense_acks_device;
  * the groups' state is read and written once per launch instead of once per tick. */
 int jg_step_dense_acks_device_n(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks);
-/* `n_ticks` consecutive dense ticks as n_ticks SINGLE-tick launches (the kernel and the bytes of jg_step_dense_acks_device -
- * not the T-tick fusion above) issued as ONE captured hipGraph: jg_dense_acks_graph_prepare records the launches - tick t
- * reads the block at acks_dev + t*R*G - and instantiates the graph (milliseconds of host time, nothing runs);
- * jg_dense_acks_graph_launch enqueues it on the engine's stream, ONCE (the launches carry their step numbers: prepare again for
- * the next n_ticks).  A host that already holds the ack blocks of n_ticks ticks pays one launch's host latency for all of them
- * (20 ticks at 1 M x 5: 12.5 -> 11.x us per tick by the wall clock).  Identical in effect to n_ticks calls of
- * jg_step_dense_acks_device.  Between prepare and launch no other step may be issued on the engine.  Single-device engines
- * (or a shard's own handle). */
-int jg_dense_acks_graph_prepare(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks);
-int jg_dense_acks_graph_launch(jg_engine* e);
 /* The same for every shard of a multi-device engine: acks_dev[d] is shard d's own [n_ticks][R][G_d]
  * block in the memory of its device (G_d = its n_groups).  One launch per shard, issued by the
  * shard's host thread on the shard's stream; returns when all are enqueued. */

@@ -237,8 +237,6 @@ class Api:
         "step_device_rows": (C.c_int, [_P, C.POINTER(CmdBatch), C.c_uint64]),
         "step_dense_acks_device": (C.c_int, [_P, _P]),
         "step_dense_acks_device_n": (C.c_int, [_P, _P, C.c_uint32]),
-        "dense_acks_graph_prepare": (C.c_int, [_P, _P, C.c_uint32]),
-        "dense_acks_graph_launch": (C.c_int, [_P]),
         "sync": (C.c_int, [_P]),
         "stream_wait": (C.c_int, [_P, _P]),
         "drain_prefetch": (C.c_int, [_P]),
@@ -306,6 +304,6 @@ HEADER_SYMBOLS = [
     "jg_step_dense_leader", "jg_step_dense_follower", "jg_chain_compact", "jg_chain_compact_resident", "jg_drain_compacted", "jg_sync", "jg_stream_wait",
     "jg_drain_messages", "jg_drain_applies", "jg_drain_faults", "jg_drain_messages_view", "jg_drain_applies_view", "jg_drain_prefetch", "jg_drain_flush", "jg_drain_wait", "jg_read_state", "jg_get_counters",
     "jg_device_alloc", "jg_device_free", "jg_device_upload", "jg_device_download",
-    "jg_dense_acks_graph_prepare", "jg_dense_acks_graph_launch", "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_dense_cluster_create", "jg_dense_cluster_destroy", "jg_dense_cluster_set_option", "jg_dense_cluster_set_appends", "jg_dense_cluster_withdraw_appends", "jg_dense_cluster_offer_appends", "jg_dense_cluster_rounds", "jg_dense_cluster_mailboxes", "jg_dense_cluster_round_routed", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",
+    "jg_timer_start", "jg_timer_stop", "jg_synth_fill_acks_device", "jg_calibrate_stream", "jg_dense_cluster_create", "jg_dense_cluster_destroy", "jg_dense_cluster_set_option", "jg_dense_cluster_set_appends", "jg_dense_cluster_withdraw_appends", "jg_dense_cluster_offer_appends", "jg_dense_cluster_rounds", "jg_dense_cluster_mailboxes", "jg_dense_cluster_round_routed", "jg_kernel_timing", "jg_kernel_timing_read", "jg_last_error", "jg_abi_version",
     "jg_step_node", "jg_node_outbox_view", "jg_submit_reserve", "jg_submit_commit", "jg_node_inbox_columns",
 ]

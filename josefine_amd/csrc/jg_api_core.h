@@ -326,10 +326,6 @@ struct jg_engine {
   // set while a jg_dense_cluster round is being captured into a hipGraph: the node kernels then
   // take logical time and step number from this device-resident clock instead of their arguments
   JgClock* replay_clock = nullptr;
-  // jg_dense_acks_graph_prepare / _launch: n single-tick launches captured as one graph, launched once
-  hipGraph_t dg_graph = nullptr;
-  hipGraphExec_t dg_exec = nullptr;
-  bool dg_ready = false;
   bool cluster_mask_offers = false;  // set by a routed round around its single-lead leader half (JgLeaderNode::mask_offers)
   uint64_t* cluster_aec = nullptr;  // set by a jg_dense_cluster around ITS dense halves: the cluster's common AppendEntries column (JgLeaderNode::o_aec)
   uint32_t replay_slot = 0;

@@ -184,8 +184,6 @@ void jg_engine_destroy(jg_engine* e) {
   for (char* p : e->up.buf)
     if (p) (void)hipFree(p);
   if (e->fs_bk) (void)hipFree(e->fs_bk);
-  if (e->dg_exec) (void)hipGraphExecDestroy(e->dg_exec);
-  if (e->dg_graph) (void)hipGraphDestroy(e->dg_graph);
   if (e->node.sp_key) (void)hipFree(e->node.sp_key);
   if (e->node.bin_mem) (void)hipFree(e->node.bin_mem);
   if (e->node.sp_idx) (void)hipFree(e->node.sp_idx);
@@ -548,40 +546,6 @@ int jg_step_dense_acks_device_n(jg_engine* e, const uint64_t* acks_dev, uint32_t
   if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
   HIPCHK(hipSetDevice(e->device));
   return dense_step(e, acks_dev, n_ticks);
-}
-
-int jg_dense_acks_graph_prepare(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks) {
-  if (!e || !acks_dev || !n_ticks) return fail(JG_EINVAL, "null argument");
-  if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
-  if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
-  if (e->kt_on) return fail(JG_EINVAL, "jg_dense_acks_graph_prepare: kernel timing brackets single launches (jg_kernel_timing(e, 0) first)");
-  HIPCHK(hipSetDevice(e->device));
-  {
-    const int rc = node_settle(e);  // (nothing may synchronise inside a capture)
-    if (rc) return rc;
-  }
-  if (e->dg_exec) (void)hipGraphExecDestroy(e->dg_exec), e->dg_exec = nullptr;
-  if (e->dg_graph) (void)hipGraphDestroy(e->dg_graph), e->dg_graph = nullptr;
-  e->dg_ready = false;
-  const size_t stride = (size_t)e->cfg.n_groups * e->cfg.n_replicas;
-  hipError_t he = hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed);
-  if (he != hipSuccess) return fail(JG_EDEVICE, std::string("hipGraph capture: ") + hipGetErrorString(he));
-  int rc = JG_OK;
-  for (uint32_t t = 0; t < n_ticks && !rc; t++) rc = dense_step(e, acks_dev + t * stride);  // (the host-side bookkeeping - step numbers, counters - is the eager calls')
-  he = hipStreamEndCapture(e->stream, &e->dg_graph);
-  if (rc) return rc;
-  if (he != hipSuccess) return fail(JG_EDEVICE, std::string("hipGraph capture: ") + hipGetErrorString(he));
-  HIPCHK(hipGraphInstantiate(&e->dg_exec, e->dg_graph, nullptr, nullptr, 0));
-  e->dg_ready = true;
-  return JG_OK;
-}
-int jg_dense_acks_graph_launch(jg_engine* e) {
-  if (!e) return fail(JG_EINVAL, "null argument");
-  if (!e->dg_ready) return fail(JG_EINVAL, "jg_dense_acks_graph_launch: nothing prepared (a prepared graph is launched once)");
-  HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipGraphLaunch(e->dg_exec, e->stream));
-  e->dg_ready = false;
-  return JG_OK;
 }
 
 int jg_step_dense_acks(jg_engine* e, const uint64_t* acks_host) {

@@ -398,22 +398,6 @@ class BatchedRaft:
         finally:
             self.api.device_free(self._h, buf)
 
-    def step_dense_acks_graph(self, acks: np.ndarray) -> None:
-        """T consecutive dense ticks from a host [T, R, G] array as T SINGLE-tick launches issued as one captured hipGraph
-        (jg_dense_acks_graph_prepare + jg_dense_acks_graph_launch): identical in effect to T calls of step_dense_acks."""
-        self._flush_pending()
-        a = np.ascontiguousarray(acks, dtype=np.uint64)
-        assert a.ndim == 3 and a.shape[1:] == (self.R, self.G), a.shape
-        buf = C.c_void_p()
-        self._check(self.api.device_alloc(self._h, a.nbytes, C.byref(buf)))
-        try:
-            self._check(self.api.device_upload(self._h, buf, a.ctypes.data, a.nbytes))
-            self._check(self.api.dense_acks_graph_prepare(self._h, buf, a.shape[0]))
-            self._check(self.api.dense_acks_graph_launch(self._h))
-            self._check(self.api.sync(self._h))
-        finally:
-            self.api.device_free(self._h, buf)
-
     # -- dense node tick (host-array convenience over the device-pointer ABI) ---------------
     def _is_device(self) -> bool:
         return hasattr(self.api, "device_alloc")

@@ -163,35 +163,6 @@ def test_dense_fused_ticks_parity(R, T):
     assert dev.counters()["dense_group_steps"] == G * t
 
 
-@pytest.mark.parametrize("R,T", [(3, 3), (5, 20), (1, 2)])
-def test_dense_acks_graph_equals_single_ticks(R, T):
-    """jg_dense_acks_graph_prepare / _launch: T single-tick launches issued as one captured hipGraph == T ticks on the oracle
-    (the ragged stream: drops, duplicates, 0-2 appends), state after every graph, a fault raised by a tick in the middle of a
-    graph with its step number, and a prepared graph launches once."""
-    from parity import synth_tick_host
-    from josefine_amd import EngineError
-    G = 5000
-    dev, ora = pair(G, R, seed=41 + R)
-    for e in (dev, ora):
-        elect_all(e)
-        e.drain_messages(), e.drain_applies()
-    sim = np.zeros((R, G), dtype=np.uint64)
-    t = 0
-    for launch in range(4):
-        block = np.stack([synth_tick_host(ora, 1, t + k, sim) for k in range(T)])
-        if launch == 2:  # an own-slot value outside its domain: a fault record in the middle of the graph's ticks
-            block[T // 2, int(ora.read("self_slot")[7]), 7] = np.uint64(capi.NO_ACK)
-        t += T
-        dev.step_dense_acks_graph(block)
-        for k in range(T):
-            ora.step_dense_acks(block[k])
-        compare_snapshots(dev, ora, f"graph R={R} T={T} launch {launch}", ["commit", "head", "match", "repl_state", "fault", "id_gen", "role"])
-        assert dev.drain_faults().tobytes() == ora.drain_faults().tobytes()
-    assert dev.counters()["decisions"] == ora.counters()["decisions"] and dev.counters()["dense_group_steps"] == G * t
-    with pytest.raises(EngineError, match="nothing prepared"):
-        dev._check(dev.api.dense_acks_graph_launch(dev._h))
-
-
 def _dense_edge_case_engines():
     """Groups 0: plain leader; 1: follower; 2: leader that will get forged acks; 3: leader whose
     chain is not in FAST form (restarted with commit 2: id_gen == head, Q8); 4: faulted leader."""
