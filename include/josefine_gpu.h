@@ -540,7 +540,10 @@ enum {
    * or JG_AEC_INDIVIDUAL: the words are in jg_node_outbox.ae (valid for exactly those partitions: they differ by addressee,
    * or the partition's rows took the general path in this step), which is
    * NULL - and is not downloaded: 8 bytes per partition instead of 8 (R - 1) - when no partition of the step needs it
-   * (jg_node_outbox_view fetches the rows when one does).  Single-device engines or shards. */
+   * (jg_node_outbox_view fetches the rows when one does).  Single-device engines or shards.
+   * WHICH partitions read JG_AEC_INDIVIDUAL is a matter of representation, not of results (the engine marks every
+   * partition whose rows took the general path; the oracle library reports the common word wherever the R - 1 words
+   * agree): compare aec / ae between backends only after expansion (BatchedRaft::expand_columns). */
   JG_NODE_COMMON_AE = 16u,
   /* A leader partition's fsm_tx rows of the step as one JG_FSM_LEADER_STEP row where the step appended a block and the
    * commit index is within 255 of it (24 bytes instead of 48 or 72; other partitions: the plain rows as before). */
@@ -637,7 +640,10 @@ int jg_dense_cluster_offer_appends(jg_dense_cluster* c, const uint32_t* groups_d
  * rounds are replayed as captured graphs (logical time and step numbers live in a device-resident clock that advances
  * itself), eight rounds to a graph where n_rounds allows; the results are those of n_rounds calls with one round each. */
 int jg_dense_cluster_rounds(jg_dense_cluster* c, uint64_t now_ms, uint64_t dt_ms, uint32_t n_rounds);
-/* The mailbox columns, for inspection: the leader's inbox / outbox as the structs above. */
+/* The mailbox columns, for inspection: the leader's inbox / outbox as the structs above.  out->ae is a SNAPSHOT of the
+ * last round's AppendEntries words, written out at this call (the cluster keeps ONE word per group where every follower's
+ * is the same: JgLeaderNode::o_aec) and valid until the next round; with JG_CLUSTER_ANY_LEADER the rows of a group nobody
+ * owns read JG_NO_ACK. */
 int jg_dense_cluster_mailboxes(jg_dense_cluster* c, jg_leader_inbox* in, jg_leader_outbox* out);
 
 /* One protocol round WITH a transport for everything outside the mailbox vocabulary — elections above

@@ -59,7 +59,10 @@ int jg_engine_create(const jg_config* cfg, jg_engine** out) {
   d.seed = cfg->seed;
   d.group_base = cfg->group_base;
   const char* env_grid = std::getenv("JG_DENSE_GRID");
-  uint32_t cap = env_grid ? (uint32_t)std::atoi(env_grid) : 8192u;  // measured best (profiles/README.md)
+  // (one workgroup per 256 groups, no grid-stride trip, up to 16.7 M groups: round 6's sweep - profiles/r06/headline_grid_sweep.txt -
+  // at 16 M x 5 172.1 us with the cap of 8192 the rounds before used, 159.9 us = 0.85 of peak in one pass; at 1 M every cap from 4096 up
+  // is the same launch, and a persistent grid of 256 CUs x 8 waves loses: 11.05 against 10.67 us)
+  uint32_t cap = env_grid ? (uint32_t)std::atoi(env_grid) : 65536u;
   if (cap < 1) cap = 1;
   e->dense_grid = grid_for(G, cap);
   e->count_slots = std::max<uint32_t>(e->dense_grid, 4096);
@@ -382,7 +385,7 @@ int jg_submit_commit(jg_engine* e, size_t n, size_t n_blocks, uint32_t optional_
     // no pass over the rows on the host (2.5 ms per 9 M rows): jg_step_node's classification checks group and kind on
     // the device; what the rows may hold is assumed (a Heartbeat; an AppendEntries if the aux column is there)
     seen = 2u | ((optional_columns & JG_COL_AUX) ? 1u : 0u);
-    e->p_unchecked = true;
+    if (n) e->p_unchecked = true;  // (an empty commit leaves nothing behind: a later jg_submit + jg_step finds no unchecked row)
   } else {
     int rc = validate_batch(e->cfg.n_groups, &b, &seen);
     if (rc) return rc;

@@ -248,6 +248,8 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     e->p_has_from = e->p_has_term = e->p_has_aux = e->p_has_flag = false;
     e->p_kinds_seen = 0;
     e->p_unchecked = e->p_packed = e->p_id32 = false;
+  } else {
+    e->p_unchecked = e->p_packed = e->p_id32 = false;  // (a step without rows: no format of a batch that is not there outlives it)
   }
   // the dense halves: every partition, the ones whose rows went the general way included (they are ticked here) -
   // except in an asynchronous step, whose halves leave those partitions to the catch-up pass (node_settle)

@@ -781,7 +781,11 @@ __global__ void k_aec_expand(uint32_t G, uint32_t R, uint32_t lead, const uint8_
   if (g >= G) return;
   const uint64_t c = aec[g];
   const uint32_t from = owner ? owner[g] : lead;
-  if (c == JG_AEC_INDIVIDUAL || from == JG_OWNER_NONE) return;
+  if (from == JG_OWNER_NONE) {  // (nobody owns the group this round: nobody's mail - not last round's words)
+    for (uint32_t r = 0; r < R; r++) ae[(size_t)r * G + g] = JG_NO_ACK;
+    return;
+  }
+  if (c == JG_AEC_INDIVIDUAL) return;
   for (uint32_t r = 0; r < R; r++)
     if (r != from) ae[(size_t)r * G + g] = c;
 }

@@ -50,6 +50,21 @@ def test_dense_ack_stream_parity(R, G, mode, ticks, slot_layout):
     assert int(dev.read("commit").max()) > 0
 
 
+@pytest.mark.parametrize("R", [3, 5])
+def test_survey_config_2_at_full_length(R):
+    """SURVEY.md 8(d) config #2 AS WRITTEN: G = 10^4, the ragged stream (0-2 appends, 5 % of the acks dropped, 5 % duplicated / stale,
+    follower heads advancing by U{0..MAX_INFLIGHT}), T = 1 000 ticks, commit / match / repl_state / fault (and head, id_gen, role, term,
+    every drained row) compared after EVERY tick - and R = 5 beside the survey's R = 3.  (test_dense_ack_stream_parity runs 200 ticks
+    of it in three own-slot layouts; the stream's rarer states - BEHIND escapes after 1 021 / 65 533 appends, the wide commit column - want
+    the full length.)"""
+    G, T = 10_000, 1000
+    dev, ora = pair(G, R, seed=0x6A6F7365 + 2)
+    for e in (dev, ora):
+        elect_all(e)
+    run_dense_ticks(dev, ora, mode=1, ticks=T, check_every=1)
+    assert int(dev.read("commit").min()) > T // 4 and dev.counters()["dense_group_steps"] == G * T
+
+
 @pytest.mark.parametrize("R", [1, 3, 5])
 def test_fuzz_command_stream_parity(R):
     """Random commands of every kind to every role, incl. the panic / Err paths."""
