@@ -232,6 +232,11 @@ class FailureRepairTrace:
         self.campaigning[self.campaigning == 1] = 2
         self.campaigning[recreated] = 1
         hit = synth_hash(self.seed, tick, gg, 7) % np.uint64(100) < np.uint64(self.percent)
+        if tick == 0:
+            # (no failure before the cluster's first round: a follower that has not yet heard from its leader has not voted
+            # - follower.rs:143,187 - and GRANTS; the designated candidate would simply be elected, at any R since the transport
+            # interleaves the voters' answers, and the partition would not be the trace's "leaderless until repaired")
+            hit[:] = False
         up = self.down_since < 0
         up[repaired] = False  # (not in the tick of its repair)
         failing = np.nonzero(hit & up)[0].astype(np.uint32)
