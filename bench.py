@@ -619,10 +619,15 @@ def cluster_failures_main(args, torch, dist, rank, world, dev_index, red_dev):
 
     def rounds(t0_, t1_, which):
         for t in range(t0_, t1_):
-            if withdraw[t] is not None:
-                lib.withdraw_appends(withdraw[t].ptr, withdraw[t].n)
-            if offer[t] is not None:
-                lib.offer_appends(offer[t].ptr, offer[t].n, 1)
+            # (the client's proposals: one per round for every partition, offered where replica 0 LEADS when the dense round begins -
+            # JgLeaderNode::mask_offers.  A failed partition has no leader there until it is re-created and its election is won, so
+            # nothing has to be withdrawn or offered again per round: rounds 5's two launches per round are gone.  --offer-lists 1
+            # issues them as before - jg_dense_cluster_withdraw_appends / _offer_appends, what tests/test_dense_node.py drives)
+            if args.offer_lists:
+                if withdraw[t] is not None:
+                    lib.withdraw_appends(withdraw[t].ptr, withdraw[t].n)
+                if offer[t] is not None:
+                    lib.offer_appends(offer[t].ptr, offer[t].n, 1)
             tr0 = time.perf_counter()
             st = lib.round_routed((t + 1) * 100, trace[t])
             if os.environ.get("JG_BENCH_TRACE_ROUNDS"):
@@ -1154,6 +1159,10 @@ def main():
     ap.add_argument("--recreate", action="store_true",
                     help="--cluster --any-leader --failures p: the failing group comes back on EMPTY stores (JG_CMD_RECREATE) - the campaign is won "
                          "through the transport, the winner appends, groups may fail again: a stationary trace with no synthetic vote")
+    ap.add_argument("--offer-lists", type=int, choices=[0, 1], default=0,
+                    help="--cluster --failures (single lead): 1 = the client's proposals withdrawn from a failed partition and offered again to a "
+                         "re-created one by two launches per round (jg_dense_cluster_withdraw_appends / _offer_appends: round 5); 0 = one proposal per "
+                         "partition and round throughout, taken only where replica 0 leads (the same appends: a failed partition has no leader there)")
     ap.add_argument("--repair-after", type=int, default=10,
                     help="--cluster --failures (single lead): rounds after which a failed partition is repaired (every replica restarts, "
                          "replica 0 is re-seated) - the stationary configs[4] trace; 0: never (the leaderless fraction grows)")

@@ -709,7 +709,7 @@ __device__ __forceinline__ void jg_route_sort_bucket(const JgRouteBuckets& b, ui
 // R x G / 256 buckets - 19.5 k at 1 M x 5 - and a launch of one workgroup per bucket spends most of its 20 us dispatching
 // empty ones; but a workgroup's buckets are served one BEHIND the other, each a chain of dependent loads: 8 per workgroup
 // took 27 us - profiles/r06/ab_sort_buckets.txt)
-#define JG_ROUTE_SORT_BUCKETS 2u
+#define JG_ROUTE_SORT_BUCKETS 1u
 __global__ __launch_bounds__(JG_BLOCK) void k_route_sort_build(JgRouteBuckets b, uint64_t* __restrict__ key, uint32_t* __restrict__ idx,
                                                                const jg_msg_row* __restrict__ rows, JgRouteCols c, uint32_t per_wg) {
   __shared__ uint64_t s_key[JG_ROUTE_SORT_CAP];

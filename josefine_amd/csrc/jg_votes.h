@@ -152,7 +152,8 @@ __device__ __forceinline__ bool jg_lane_same_state(const JgLane& a, const JgLane
 // request stretch holds the ords q_ord .. q_ord + q_n - 1, its answer stretch a_ord .. a_ord + a_n - 1.  The stretches'
 // cursors live in `st` - 2 x JG_MAX_REPLICAS words per lane, `stride` apart: LDS in the kernel (one word per lane and
 // stretch, lanes side by side: as register arrays they cost the kernel 45 VGPRs and a wave per SIMD, and a dynamic
-// index into registers is scratch), a local array on the host - as next ord | copies left << 12 | copies done << 20;
+// index into registers is scratch), a local array on the host - as next ord | copies left << 12 | copies done << 20
+// (| the two answer bits << 28), followed by the senders' answer terms;
 // the next copy is the minimum of (next ord, sender, kind) over the unfinished stretches.
 // What a copy emits goes where jg_emit_msg's mode 4 puts it: the VoteResponses to one requester, at consecutive emission
 // indices, into the lane's answer word, everything else (a second requester's answers, the Heartbeat of elect(),
@@ -164,7 +165,7 @@ __device__ __forceinline__ bool jg_lane_same_state(const JgLane& a, const JgLane
 // from the rest) that left the replica as it found it says what every further level does - nothing to the state, the same
 // emission, the same decisions - so the rest is accounted for without being run (a voter's 2nd ... R-1st refusal, a
 // leader's or a defeated candidate's 2nd ... R-1st round of ignored answers).
-#define JG_VOTE_ST_WORDS (2u * JG_MAX_REPLICAS)
+#define JG_VOTE_ST_WORDS (4u * JG_MAX_REPLICAS + 4u)  // per lane: 2 R stretch cursors, the R senders' answer terms (two words each), the first campaign's (term, head)
 __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32_t self, const JgVoteMail& in, const JgVoteMail& out, uint32_t need,
                                               uint64_t now, uint32_t seq, uint32_t step, uint32_t* st, uint32_t stride) {
   const uint32_t R = d.R;
@@ -195,14 +196,23 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
   L.cap_ack = 0, L.cap_hbc = 0;
   L.mp = L.mend = nullptr;
   L.fp = L.fend = nullptr;  // (an election's command queues nothing for the FSM: a row would raise L.overflow)
-  // the senders' stretches: st[2 s] the request's, st[2 s + 1] the answer's; zero where there is none
+  // the senders' stretches: st[2 s] the request's, st[2 s + 1] the answer's; zero where there is none.  Everything a sender
+  // said is loaded HERE, R independent 32-byte loads of one stretch of memory: the answers' terms go to the lane's LDS words,
+  // the first campaign's (term, head) stay in registers - a voter's one campaign, a candidate's R - 1 answer words then cost
+  // the loop below no further trip to memory (one dependent load per copy until round 6: 58 us of a round)
   uint32_t n_st = 0, n_ans = 0, ord0 = 0, cnt0 = 0;
   bool aligned = true;
+  uint32_t q1_s = ~0u;  // the first sender with a request word; its payload: four words behind the answer terms
+  uint32_t* const at_lo = st + (size_t)(2u * JG_MAX_REPLICAS) * stride;  // a_term of sender s: words [2 s], [2 s + 1]
+  uint32_t* const q1 = st + (size_t)(4u * JG_MAX_REPLICAS) * stride;
   for (uint32_t s = 0; s < R; s++) {
     uint32_t wq = 0, wa = 0;
     if (s != self) {
-      const uint64_t ctl = *(const uint64_t*)&in.rec[jg_vote_at(in, s, g)].q_ctl;  // (q_ctl | a_ctl << 32: one 8-byte load)
-      const uint32_t qc = (uint32_t)ctl, ac = (uint32_t)(ctl >> 32);
+      const uint4* rp = (const uint4*)&in.rec[jg_vote_at(in, s, g)];
+      const uint4 lo = rp[0], hi = rp[1];  // {q_term, q_head}, {a_term, q_ctl, a_ctl}
+      const uint32_t qc = hi.z, ac = hi.w;
+      at_lo[(2u * s) * stride] = hi.x, at_lo[(2u * s + 1u) * stride] = hi.y;
+      if ((qc & 0xffu) && q1_s == ~0u) q1_s = s, q1[0] = lo.x, q1[stride] = lo.y, q1[2u * stride] = lo.z, q1[3u * stride] = lo.w;
       const uint32_t q_n = qc & 0xffu, a_n = (ac & 0xffu) && ((ac >> 21) & 7u) == self ? (ac & 0xffu) : 0u;
       if (q_n) {  // (the copies' ords are consecutive - candidate.rs:24-44 is one loop - and q_ctl holds their sum)
         const uint32_t q_ord = ((qc >> 8) - q_n * (q_n - 1u) / 2u) / q_n;
@@ -213,7 +223,7 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
       }
       if (a_n) {
         const uint32_t a_ord = (ac >> 8) & ((1u << JG_VOTE_ORD_BITS) - 1u);
-        wa = a_ord | a_n << 12;
+        wa = a_ord | a_n << 12 | ((ac >> 19) & 3u) << 28;  // (the answer bits ride in the cursor word: first << 28 | rest << 29)
         aligned = aligned && (!n_st || (a_ord == ord0 && a_n == cnt0));
         if (!n_st) ord0 = a_ord, cnt0 = a_n;
         n_st++, n_ans++;
@@ -227,18 +237,30 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
     uint32_t best = ~0u;  // (ord of the stretch's next copy) << 4 | sender << 1 | answer
     for (uint32_t k = 0; k < 2u * R; k++) {
       const uint32_t w = st[k * stride];
-      if ((w >> 12) & 0xffu) best = min(best, (w & 0xfffu) << 4 | k);
+      if ((w >> 12) & 0xffu) best = min(best, (w & 0xfffu) << 4 | k);  // (bits 28-29: the answer bits, not part of the key)
     }
     if (best == ~0u) break;
     const uint32_t k = best & 15u, s = k >> 1;
     const bool do_ans = k & 1u;
-    const uint32_t w = st[k * stride], c = w >> 20;  // (c: this copy's index within its stretch)
+    const uint32_t w = st[k * stride], c = (w >> 20) & 0xffu;  // (c: this copy's index within its stretch)
     st[k * stride] = w + 1u - (1u << 12) + (1u << 20);
-    const JgVoteRec* rp = &in.rec[jg_vote_at(in, s, g)];  // (the lines the prologue loaded)
     JgCmd cmd;
-    cmd.from = d.node_ids[s];
-    if (do_ans) cmd.kind = JG_CMD_VOTE_RESPONSE, cmd.term = rp->a_term, cmd.id = 0, cmd.aux = 0, cmd.flag = (rp->a_ctl >> (c ? 20 : 19)) & 1u;
-    else cmd.kind = JG_CMD_VOTE_REQUEST, cmd.term = rp->q_term, cmd.id = rp->q_head, cmd.aux = cmd.term, cmd.flag = 0;
+    cmd.from = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < JG_MAX_REPLICAS; r++) cmd.from = s == r ? d.node_ids[r] : cmd.from;  // (a select per slot: an indexed read of the kernel's arguments is a load)
+    if (do_ans) {
+      cmd.kind = JG_CMD_VOTE_RESPONSE, cmd.term = (uint64_t)at_lo[(2u * s) * stride] | (uint64_t)at_lo[(2u * s + 1u) * stride] << 32;
+      cmd.id = 0, cmd.aux = 0, cmd.flag = (w >> (c ? 29 : 28)) & 1u;
+    } else {
+      cmd.kind = JG_CMD_VOTE_REQUEST, cmd.aux = 0, cmd.flag = 0;
+      if (s == q1_s) {
+        cmd.term = (uint64_t)q1[0] | (uint64_t)q1[stride] << 32, cmd.id = (uint64_t)q1[2u * stride] | (uint64_t)q1[3u * stride] << 32;
+      } else {  // (a second campaign for one partition in one round: its line is in L1)
+        const JgVoteRec* rp = &in.rec[jg_vote_at(in, s, g)];
+        cmd.term = rp->q_term, cmd.id = rp->q_head;
+      }
+      cmd.aux = cmd.term;
+    }
     jg_apply<JG_KINDS_VOTES>(d, L, cmd, nullptr, nullptr);
     if (!aligned || ++in_level != n_st) continue;
     // a whole level: copy `level` of every stretch
