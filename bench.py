@@ -1050,6 +1050,7 @@ def secondary_lines(args):
             "command": x["command"], "round_ms": x["line"]["ms_per_step"], "frac": x["line"]["roofline"]["frac"], "vote_words": x["line"]["vote_words"],
             "rows_routed_per_round": x["line"]["rows_routed_per_round"], "leaderless_fraction": x["line"]["leaderless_fraction"],
             "stationary": x["line"]["config"]["stationary"].split(":")[0].split(" ")[0], "round_ms_by_window": [w["ms_per_round"] for w in x["line"]["ms_per_round_by_leaderless_fraction"]],
+            "elections_won_through_the_transport": x["line"].get("elections_won_through_the_transport"), "synthetic_votes": x["line"].get("synthetic_votes"),
             "decisions_per_s": x["line"]["value"]}
     out["routed_round"] = routed(run("routed_round", ["--cluster", "--failures", "1", "--steps", "40", "--warmup", "10", "--vote-words", "1"]))
     out["routed_round_rows_only"] = routed(run("routed_round_rows_only", ["--cluster", "--failures", "1", "--steps", "40", "--warmup", "10", "--vote-words", "0"]))
@@ -1067,6 +1068,11 @@ def secondary_lines(args):
         "winners_appending_again_fraction_of_failed_groups": x["line"].get("winners_appending_again_fraction_of_failed_groups"),
         "elections_won_after_failures": x["line"]["elections_won_after_failures"], "leaderless_fraction": x["line"]["leaderless_fraction"],
         "rows_left_for_the_host": x["line"]["rows_left_for_the_host"], "decisions_per_s": x["line"]["value"]}
+    # (round 6: FIVE nodes elect their leaders through the device transport like three do - 1 M elections, 40 M routed rows in four rounds)
+    x = run("any_leader_x5", ["--cluster", "--any-leader", "--replicas", "5", "--steps", "60", "--warmup", "10"])
+    out["per_partition_leadership_five_nodes"] = x if "error" in x else {
+        "command": x["command"], "round_us": x["line"]["ms_per_step_events"] * 1e3, "frac": x["line"]["roofline"]["frac"],
+        "elections": x["line"]["elections"], "decisions_per_s": x["line"]["value"]}
     x = run("failures_tick", ["--failures", "1", "--steps", "160", "--warmup", "64"])  # (profiles/*/bench_failures_1pct.json's command)
     out["failures_tick"] = x if "error" in x else {
         "command": x["command"], "tick_ms": x["line"]["ms_per_step"], "dense_kernel_us": x["line"]["roofline"]["avg_launch_us"],

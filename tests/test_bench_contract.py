@@ -116,7 +116,11 @@ def test_default_line_carries_the_secondaries():
     d = run(["--groups", "100000", "--steps", "40", "--warmup", "5", "--no-cpu-baseline"], env={"JG_BENCH_SECONDARY": "1"})
     sec = d["secondary"]
     assert set(sec) == {"closed_loop", "routed_round", "routed_round_rows_only", "routed_round_no_repairs", "per_partition_leadership",
-                        "per_partition_leadership_failures", "failures_tick", "event_loop"}
+                        "per_partition_leadership_failures", "per_partition_leadership_five_nodes", "failures_tick", "event_loop"}
+    # round 6: no synthetic vote anywhere - configs[4]'s re-created partitions (R = 5) elect their leaders through the transport,
+    # and so do the five nodes of the per-partition-leadership cluster
+    assert sec["routed_round"]["elections_won_through_the_transport"] > 0 and sec["routed_round"]["synthetic_votes"] == 0
+    assert sec["per_partition_leadership_five_nodes"]["elections"]["won_through_the_transport"] is True
     ppf = sec["per_partition_leadership_failures"]  # re-created groups: every election won through the transport, the winners append
     assert ppf["rows_left_for_the_host"] == 0 and ppf["stationary"] == "yes" and ppf["winners_appending_again_fraction_of_failed_groups"] > 0.8
     assert ppf["elections_won_after_failures"] > 0
