@@ -794,8 +794,9 @@ def event_loop_main(args):
         queues unless told otherwise (GPU_MAX_HW_QUEUES), and streams that share one run one behind the other."""
         return os.environ.get("GPU_MAX_HW_QUEUES") or (str(2 * loops) if loops > 2 else None)
 
-    def run(mode, k, w, loops=1, polled=False, compact=False):
+    def run(mode, k, w, loops=1, polled=False, compact=False, in_flight=1):
         env = dict(os.environ)
+        env["JG_BENCH_IN_FLIGHT"] = str(in_flight)
         if env.get("JG_BENCH_POLLING_DEFAULTED"):  # (several loop threads waiting side by side: the runtime's default, interrupts)
             env.pop("HSA_ENABLE_INTERRUPT", None)
         if polled:  # (the A/B: the loop's thread spins on the completion signal instead of sleeping on an interrupt)
@@ -822,6 +823,11 @@ def event_loop_main(args):
     ptk = run("pipetasks", K, W, compact=True)
     ptck = run("pipetaskscolumns", K, W, compact=True)
     pk1 = run("pipe", K, W, compact=True)
+    # ... and with TWO ticks in flight (JG_NODE_KEEP): tick t + 1 begun before tick t's outputs are read
+    ptk2 = run("pipetasks", K, W, compact=True, in_flight=2)
+    ptck2 = run("pipetaskscolumns", K, W, compact=True, in_flight=2)
+    pt2 = run("pipetasks", K, W, in_flight=2)
+    ptk2_polled = run("pipetasks", K, W, compact=True, in_flight=2, polled=True)
     # ... and with the peers' traffic as the reference's BYTES (length-delimited serde_json frames, tcp.rs:139-170) through
     # host/formats.hpp's decoder in the connection tasks: a few ticks (the senders' encoding of every tick comes first)
     ptw = run("pipetaskswire", max(2, min(K, 4)), 2)
@@ -903,7 +909,21 @@ def event_loop_main(args):
                     "column_inbound_decisions_per_s": ptck["decisions_per_s"], "column_inbound_ms_per_tick": ptck["ms_per_tick"],
                     "column_inbound_pcie_bytes_per_decision": (ptck["pcie_h2d_bytes_per_tick"] + ptck["pcie_d2h_bytes_per_tick"]) * ptck["ticks"] / ptck["decisions"],
                     "one_thread_decisions_per_s": pk1["decisions_per_s"], "one_thread_ms_per_tick": pk1["ms_per_tick"],
-                    "rows_on_the_general_path": ptk["rows_general"] + ptck["rows_general"] + pk1["rows_general"]},
+                    "rows_on_the_general_path": ptk["rows_general"] + ptck["rows_general"] + pk1["rows_general"],
+                    "two_ticks_in_flight": {
+                        "what": "BatchedEventLoop::in_flight = 2 (JG_NODE_KEEP, ABI v9): tick t + 1 is begun - its rows on their way up, its kernels "
+                                "enqueued - BEFORE tick t's outbox is viewed; the view waits for tick t's outputs only, its fsm rows came home behind "
+                                "its own kernels (the copy sized from the tick before: no drain issued by the host, no count waited for).  Same rows, "
+                                "same sinks, same order (tests/test_node_step.py::test_node_step_two_in_flight_parity, the cluster of loops)",
+                        "decisions_per_s": ptk2["decisions_per_s"], "ms_per_tick": ptk2["ms_per_tick"],
+                        "ms_per_tick_parts": {"transport_decode_into_pinned_columns": ptk2["ms_fill"], "submit_commit": ptk2["ms_submit"],
+                                              "step_begin_and_previous_outputs": ptk2["ms_step_and_drain"]},
+                        "pcie_bytes_per_decision": (ptk2["pcie_h2d_bytes_per_tick"] + ptk2["pcie_d2h_bytes_per_tick"]) * ptk2["ticks"] / ptk2["decisions"],
+                        "pcie_GB_per_s_both_ways": (ptk2["pcie_h2d_bytes_per_tick"] + ptk2["pcie_d2h_bytes_per_tick"]) / (ptk2["ms_per_tick"] * 1e-3) / 1e9,
+                        "polled_decisions_per_s": ptk2_polled["decisions_per_s"],
+                        "column_inbound_decisions_per_s": ptck2["decisions_per_s"], "column_inbound_ms_per_tick": ptck2["ms_per_tick"],
+                        "plain_bus_decisions_per_s": pt2["decisions_per_s"], "plain_bus_ms_per_tick": pt2["ms_per_tick"],
+                        "rows_on_the_general_path": ptk2["rows_general"] + ptck2["rows_general"] + pt2["rows_general"]}},
                 "wire_decode": {
                     "what": "the same loop and tasks, but the peers' AppendResponses / HeartbeatResponses arrive as what a stock josefine peer sends - "
                             "LengthDelimitedCodec frames around serde_json(Message), one byte stream per connection (src/raft/tcp.rs:40-51,139-170) - "

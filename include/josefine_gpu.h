@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JG_ABI_VERSION 8u /* v8: jg_dense_cluster_round_routed delivers a partition's mail in the order (phase, emission index, sender) instead of
+#define JG_ABI_VERSION 9u /* v9: JG_NODE_KEEP (two node steps in flight: jg_node_outbox_view serves the oldest); v8: jg_dense_cluster_round_routed delivers a partition's mail in the order (phase, emission index, sender) instead of
                              (sender, step, emission index) - same entry points, same layouts, different (legal) network schedule; v5: jg_step_node = arrival-order Apply (fsm_tx: Apply / Notify / Apply per partition), JG_CLUSTER_ANY_LEADER,
                              jg_dense_cluster_withdraw_appends, JG_COL_UNCHECKED, JG_COL_UPLOAD_NOW; v6: jg_dense_cluster_set_option, jg_dense_cluster_offer_appends, JG_CMD_RECREATE;
                              v7: the node step's bus formats - JG_COL_PACKED_KIND, JG_COL_ID32, JG_NODE_COMMON_AE (jg_node_outbox.aec), JG_NODE_FSM_FUSED (JG_FSM_LEADER_STEP) */
@@ -547,7 +547,23 @@ enum {
   JG_NODE_COMMON_AE = 16u,
   /* A leader partition's fsm_tx rows of the step as one JG_FSM_LEADER_STEP row where the step appended a block and the
    * commit index is within 255 of it (24 bytes instead of 48 or 72; other partitions: the plain rows as before). */
-  JG_NODE_FSM_FUSED = 32u
+  JG_NODE_FSM_FUSED = 32u,
+  /* TWO STEPS IN FLIGHT (with JG_NODE_ASYNC; single-device engines or shards): the step keeps its outputs - the outbox
+   * columns and every fsm_tx / rpc_tx row and fault it produced - in a set of its own until its outbox has been VIEWED,
+   * and the next such step may be taken before that: while the device runs step t + 1 and its inputs travel up, step t's
+   * outputs travel home (server.rs:103-165's channels are asynchronous: what a tick pushed on fsm_tx / rpc_tx is
+   * consumed while the loop already takes the next messages).  With kept steps outstanding
+   *   - jg_node_outbox_view serves the OLDEST one: it waits for that step's outputs only (never for the newer step),
+   *     and makes exactly that step's rows - in the order a synchronous step would have queued them - what the next
+   *     jg_drain_applies[_view] / jg_drain_messages[_view] / jg_drain_faults deliver; the pointers of the view stay
+   *     valid until the second next kept step begins;
+   *   - at most TWO may be outstanding: a third jg_step_node is JG_EINVAL, and so is any other stepping call
+   *     (jg_step, a step without this flag, the dense entry points) - view the outboxes first;
+   *   - reads (jg_read_state, jg_sync, counters) see the engine after the newest step.
+   * The step's fsm rows come home behind its own kernels, the copy sized from the step before (no drain is issued by
+   * the host, nothing waits for a count); rows of the general path, exceptional rows and faults - none in the steady
+   * state - are collected when the outbox is viewed.  Same results, same rows, same order per step as without the flag. */
+  JG_NODE_KEEP = 64u
 };
 #define JG_AEC_INDIVIDUAL 0xfffffffffffffffeull /* jg_node_outbox.aec: "see the rows of ae" (no JG_AE word: a range start stays below JG_MAILBOX_NONE) */
 typedef struct jg_node_outbox { /* host pointers into the engine's pinned buffers; NULL: that half did not run */
@@ -579,7 +595,8 @@ int jg_node_inbox_columns(jg_engine* e, uint32_t slot, uint64_t** answer, uint64
  * (the number of general-path rows sizes that step's launch) - none at all with JG_NODE_ASYNC. */
 int jg_step_node(jg_engine* e, uint64_t now_ms, uint32_t flags);
 /* The mailbox columns the last jg_step_node produced: waits for them to land; the pointers stay valid
- * until the next jg_step_node.  On a multi-device engine the columns are the shards' concatenated. */
+ * until the next jg_step_node.  On a multi-device engine the columns are the shards' concatenated.
+ * (JG_NODE_KEEP: the OLDEST step whose outbox has not been viewed - see there.) */
 int jg_node_outbox_view(jg_engine* e, jg_node_outbox* out);
 
 /* ---- a closed loop of dense node ticks ------------------------------------------------------------

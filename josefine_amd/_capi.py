@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 CLUSTER_ANY_LEADER = 0xFFFFFFFF
 CLUSTER_OPT_VOTE_WORDS = 1
 MAX_REPLICAS = 8
@@ -49,7 +49,7 @@ FAULT_ENGINE_MAILBOX_RANGE = 133
 
 CFG_SEPARATE_COMMIT_KEY = 1
 CFG_FLAT_ROW_PASSES = 2  # jg_step_node's row passes untiled (the tiled ones' statement; an A/B)
-NODE_LEADER_HALF, NODE_FOLLOWER_HALF, NODE_TICK, NODE_ASYNC, NODE_COMMON_AE, NODE_FSM_FUSED = 1, 2, 4, 8, 16, 32
+NODE_LEADER_HALF, NODE_FOLLOWER_HALF, NODE_TICK, NODE_ASYNC, NODE_COMMON_AE, NODE_FSM_FUSED, NODE_KEEP = 1, 2, 4, 8, 16, 32, 64
 
 FSM_APPLY_LEADER, FSM_APPLY_FOLLOWER, FSM_NOTIFY, FSM_LEADER_STEP = 0, 1, 2, 3
 

@@ -330,19 +330,53 @@ struct jg_engine {
   uint64_t* cluster_aec = nullptr;  // set by a jg_dense_cluster around ITS dense halves: the cluster's common AppendEntries column (JgLeaderNode::o_aec)
   uint32_t replay_slot = 0;
   // jg_step_node: the inbox / outbox columns of the node step, their pinned host mirrors, rocPRIM scratch
-  struct NodeStep {
+  // JG_NODE_ASYNC: a step that returned without looking at its general-path row count (settled by node_settle)
+  struct NodePending {
+    bool on = false;
+    JgNodeRows rows{};
+    size_t n = 0, nb = 0, fsm_rec_seq = 0;
+    uint64_t now_ms = 0;
+    uint32_t flags = 0, col_mask = 0, seq_general = 0, seq_leader = 0, seq_follower = 0, seq_end = 0;
+  };
+  // What ONE node step leaves for the host.  A step owns a set until the next step begins - or, taken with JG_NODE_KEEP,
+  // until its outbox has been viewed: two such steps may be outstanding (the event loop's two ticks in flight), the newer
+  // one in NodeStep's own fields, the older one in NodeStep::spare (the sets change places when a step begins).
+  struct NodeOut {
+    jg_leader_beat* h_beat = nullptr;  // pinned mirrors of the outbox columns
+    uint64_t *h_ae = nullptr, *h_answer = nullptr, *h_hbc = nullptr, *h_aec = nullptr;
+    uint64_t* o_ae = nullptr;          // device: the AppendEntries words by addressee (JG_NODE_COMMON_AE fetches them when a partition needs them)
+    bool ae_rows_landed = false;       // JG_NODE_COMMON_AE: h_ae holds the step's rows (fetched when a partition needs them)
+    uint32_t* h_nsparse = nullptr;     // pinned: the step's copy of d_nsparse
+    hipEvent_t ev_out = nullptr;
+    NodePending pending;
+    jg_node_outbox last{};
+    uint32_t last_flags = 0;
+    // -- JG_NODE_KEEP ----------------------------------------------------------------------------------------------------
+    bool keep = false;                 // the step was taken with JG_NODE_KEEP
+    bool out = false;                  // ... and its outbox has not been viewed yet
+    int set = 0, arena = 0;            // the fault / exceptional-row queues and the arena its kernels used
+    hipEvent_t ev_early = nullptr;     // behind the copy of the general-path row count (the row passes are done)
+    uint32_t* h_status = nullptr;      // pinned [8]: the device status block behind the step's last kernel
+    uint64_t* h_total = nullptr;       // pinned: the fsm_tx rows of the step's dense halves ...
+    JgScanJob* h_job = nullptr;        // pinned: ... and the scan job that counts them
+    uint32_t* d_fsm_cnt = nullptr;     // the step's fsm regions (its arena's): counts, rows, tile sums, the compacted rows
+    jg_fsm_row *d_fsm = nullptr, *d_stage = nullptr;
+    uint64_t* d_bsum = nullptr;
+    PinnedQueue<jg_fsm_row> l_fsm;     // where the compacted rows land: the first `fsm_copied` came with the step's own copy
+    size_t fsm_copied = 0;
+    bool fsm_landed = false;           // l_fsm is to be handed to q_fsm by the next drain of that queue
+    uint64_t irr_gen = 0;
+    uint32_t seq_lo = 0, seq_hi = 0;   // the engine's step numbers before and after the step
+  };
+  struct NodeStep : NodeOut {
     bool ready = false;
     JgNodeCols cols{};
     jg_leader_beat* o_beat = nullptr;  // device outbox
-    uint64_t *o_ae = nullptr, *o_answer = nullptr, *o_hbc = nullptr;
+    uint64_t *o_answer = nullptr, *o_hbc = nullptr;
     uint64_t* o_aec = nullptr;         // JG_NODE_COMMON_AE: the common AppendEntries word (JgLeaderNode::o_aec), allocated at first use
-    jg_leader_beat* h_beat = nullptr;  // pinned mirrors
-    uint64_t *h_ae = nullptr, *h_answer = nullptr, *h_hbc = nullptr, *h_aec = nullptr;
-    bool ae_rows_landed = false;       // JG_NODE_COMMON_AE: h_ae holds the last step's rows (fetched when a partition needs them)
     uint64_t *h_in_answers = nullptr, *h_in_hbc = nullptr;  // pinned [R][G]: column inbound (jg_node_inbox_columns)
     uint32_t col_mask = 0, col_hbc_mask = 0;                // slots handed out for the next step / with their hb_commit column
     uint32_t* d_nsparse = nullptr;     // {general-path rows, -, partitions whose AppendEntries words differ by addressee (JG_NODE_COMMON_AE), -}
-    uint32_t* h_nsparse = nullptr;     // pinned
     // the general path's rows as (group << 32 | arrival index, arrival index) pairs, appended by k_node_route (grow-only),
     // and the bucket pass that orders them (jg_route.h: hist / scan / scatter + k_bucket_order)
     uint64_t* sp_key = nullptr;
@@ -357,19 +391,18 @@ struct jg_engine {
     size_t bin_cap = 0;
     uint32_t n_tiles = 0;
     uint32_t group_bits = 1;
-    hipEvent_t ev_out = nullptr;
     hipEvent_t ev_cols = nullptr;      // behind the uploads of the handed-out columns: the pinned buffers are free again
     bool cols_in_flight = false;
-    // JG_NODE_ASYNC: a step that returned without looking at its general-path row count (settled by node_settle)
-    struct Pending {
-      bool on = false;
-      JgNodeRows rows{};
-      size_t n = 0, nb = 0, fsm_rec_seq = 0;
-      uint64_t now_ms = 0;
-      uint32_t flags = 0, col_mask = 0, seq_general = 0, seq_leader = 0, seq_follower = 0, seq_end = 0;
-    } pending;
-    jg_node_outbox last{};
-    uint32_t last_flags = 0;
+    using Pending = NodePending;
+    // JG_NODE_KEEP: the other set (the OLDER outstanding step's while two are, a free one otherwise)
+    NodeOut spare;
+    bool spare_ready = false;
+    uint32_t kept_n = 0;               // kept steps whose outbox has not been viewed (0 .. 2)
+    bool in_step = false;              // node_step is running (its halves' own node_settle calls are not another caller's)
+    bool viewed_spare = false;         // the outbox viewed last is the spare set's
+    size_t fsm_guess = 0;              // fsm rows of the kept step finished last: what the next one's own copy takes along
+    NodeOut* fsm_visible = nullptr;    // the set whose l_fsm the next drain of the fsm queue hands over
+    NodeOut& own() { return *this; }
     // multi-device parent: the shards' columns concatenated
     std::vector<jg_leader_beat> cat_beat;
     std::vector<uint64_t> cat_ae, cat_answer, cat_hbc;
@@ -448,7 +481,17 @@ void launch_dense(jg_engine* e, const uint64_t* acks, uint32_t n_ticks, const Jg
 }
 
 int node_settle(jg_engine* e);  // (jg_step_node with JG_NODE_ASYNC: the step's general path, if it has one, runs when the step is settled)
+// JG_NODE_KEEP: while kept node steps are outstanding nothing else may step the engine - what it produced would have to be
+// delivered between two steps whose outputs are not due yet (the node step's own halves and its settling pass go through)
+inline int kept_refuse(const jg_engine* e) {
+  if (e->node.kept_n && !e->node.in_step) return fail(JG_EINVAL, "kept node steps are outstanding (JG_NODE_KEEP): jg_node_outbox_view first");
+  return JG_OK;
+}
 int dense_step(jg_engine* e, const uint64_t* acks_dev, uint32_t n_ticks = 1, const JgLeaderNode* nd = nullptr) {
+  {
+    const int rc = kept_refuse(e);
+    if (rc) return rc;
+  }
   if (!(nd && nd->sparse_mode == 2u)) {  // (not from inside node_settle's own catch-up pass)
     const int rc = node_settle(e);
     if (rc) return rc;

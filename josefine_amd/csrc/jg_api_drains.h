@@ -2,6 +2,7 @@
 // the device, optionally pipelined: jg_drain_prefetch), prepare_rows / the launch of a sparse step.  Part of josefine_gpu.hip's one translation unit.
 #pragma once
 namespace {
+int node_keep_handover(jg_engine* e);  // (jg_api_node.h)
 // ---- drains ------------------------------------------------------------------------------------
 // Finished steps' output rows and the device-side queues travel to the host queues in two
 // phases, both entirely on the device: A. one scan launch over the per-step tile sums (the host
@@ -302,6 +303,7 @@ int inflight_finish(jg_engine* e) {
 // `wait`: jg_drain_flush (block until the previous batch has landed); jg_drain_prefetch never
 // blocks: while a batch is still in transfer it starts nothing (the next call takes more steps)
 int drain_prefetch(jg_engine* e, bool wait) {
+  if (e->node.kept_n || e->node.keep) return fail(JG_EINVAL, "jg_drain_prefetch: the engine's node steps keep their outputs (JG_NODE_KEEP) - an engine overlaps its drains one way");
   HIPCHK(hipSetDevice(e->device));
   {
     const int rc = node_settle(e);
@@ -362,6 +364,18 @@ int collect(jg_engine* e, int release_mask) {
   static const bool trace = std::getenv("JG_TRACE_DRAIN") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
+  // JG_NODE_KEEP: what a viewed step left is in the queues already (its general-path rows, exceptional rows and faults) or
+  // in its landing buffer (the fsm rows of its dense halves: handed over here, a pointer swap when the consumer has taken
+  // everything before them); the device is not touched while kept steps are outstanding - their rows are not due yet
+  if (e->node.kept_n || e->node.fsm_landed || e->node.spare.fsm_landed) {
+    if (release_mask & 1) e->q_msgs.release_view();
+    if (release_mask & 2) {
+      e->q_fsm.release_view();
+      const int rc = node_keep_handover(e);
+      if (rc) return rc;
+    }
+    if (e->node.kept_n) return JG_OK;
+  }
   // (first: the batch in transfer lands BEHIND the rows a view may still cover; only then may
   // the queue be compacted)
   if (e->pipelined && !inflight_landed(e)) return JG_OK;  // nothing new yet; the queues are the drain thread's

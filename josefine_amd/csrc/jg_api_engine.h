@@ -191,6 +191,16 @@ void jg_engine_destroy(jg_engine* e) {
   if (e->node.bin_mem) (void)hipFree(e->node.bin_mem);
   if (e->node.sp_idx) (void)hipFree(e->node.sp_idx);
   if (e->node.ev_out) (void)hipEventDestroy(e->node.ev_out);
+  for (jg_engine::NodeOut* o : {&e->node.spare, &e->node.own()}) {  // (JG_NODE_KEEP)
+    if (o == &e->node.spare) {
+      for (void* p : {(void*)o->h_beat, (void*)o->h_ae, (void*)o->h_answer, (void*)o->h_hbc, (void*)o->h_nsparse, (void*)o->h_aec})
+        if (p) (void)hipHostFree(p);
+      if (o->ev_out) (void)hipEventDestroy(o->ev_out);
+    }
+    if (o->h_status) (void)hipHostFree(o->h_status);
+    if (o->ev_early) (void)hipEventDestroy(o->ev_early);
+    o->l_fsm.destroy();
+  }
   if (e->node.ev_cols) (void)hipEventDestroy(e->node.ev_cols);
   e->q_msgs.destroy();
   e->q_fsm.destroy();
@@ -425,8 +435,8 @@ int jg_step(jg_engine* e, uint64_t now_ms) {
   if (!e) return fail(JG_EINVAL, "null argument");
   if (e->router) return router_step(e, now_ms);
   {
-    const int rc = node_settle(e);
-    if (rc) return rc;
+    int rc = kept_refuse(e);
+    if (rc || (rc = node_settle(e))) return rc;
   }
   e->stepped = true;
   const size_t n = e->p_kind.size();
@@ -509,8 +519,8 @@ int jg_step_device_rows(jg_engine* e, const jg_cmd_batch* b, uint64_t now_ms) {
   if (e->router) return fail(JG_EINVAL, "device pointers are per shard: call this on a shard handle (jg_get_shard)");
   if (!e->p_kind.empty()) return fail(JG_EINVAL, "commands are queued: call jg_step first");
   {
-    const int rc = node_settle(e);
-    if (rc) return rc;
+    int rc = kept_refuse(e);
+    if (rc || (rc = node_settle(e))) return rc;
   }
   e->stepped = true;
   if (!b->n) return JG_OK;
@@ -595,6 +605,10 @@ namespace {
 // the two launches of a follower half; `fsm_*`: jg_step_node's fsm delta columns (or null)
 int follower_half(jg_engine* e, uint64_t now_ms, const jg_follower_inbox* in, const jg_follower_outbox* out, int tick,
                   uint32_t* fsm_delta, uint64_t* fsm_prev, const uint64_t* sparse_bits = nullptr, uint32_t sparse_mode = 0) {
+  {
+    const int rc = kept_refuse(e);
+    if (rc) return rc;
+  }
   if (sparse_mode != 2u) {  // (not from inside node_settle's own catch-up pass)
     const int rc = node_settle(e);
     if (rc) return rc;

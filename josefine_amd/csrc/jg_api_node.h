@@ -58,6 +58,45 @@ int node_ensure(jg_engine* e) {
   return JG_OK;
 }
 
+// JG_NODE_KEEP: what a set needs beyond node_ensure's - the spare set's own mirrors (`mirrors`), and for either set the
+// pinned words its status snapshot, fsm row count and scan job live in
+int node_keep_ensure(jg_engine* e, jg_engine::NodeOut& o, bool mirrors) {
+  const size_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
+  if (mirrors && !o.h_beat) {
+    HIPCHK(hipHostMalloc((void**)&o.h_beat, std::max<size_t>(G * sizeof(jg_leader_beat), 16), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&o.h_ae, std::max<size_t>(R * G * 8, 16), hipHostMallocDefault));
+    std::memset(o.h_ae, 0xff, std::max<size_t>(R * G * 8, 16));
+    HIPCHK(hipHostMalloc((void**)&o.h_answer, std::max<size_t>(G * 8, 16), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&o.h_hbc, std::max<size_t>(G * 8, 16), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&o.h_nsparse, 16, hipHostMallocDefault));
+    std::memset(o.h_nsparse, 0, 16);
+    HIPCHK(hipEventCreateWithFlags(&o.ev_out, hipEventDisableTiming));
+    int rc = dev_alloc(e, &o.o_ae, R * G);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(o.o_ae, 0xff, std::max<size_t>(R * G * 8, 16), e->stream));
+  }
+  if (!o.h_status) {
+    char* m = nullptr;
+    HIPCHK(hipHostMalloc((void**)&m, 64, hipHostMallocDefault));
+    std::memset(m, 0, 64);
+    o.h_status = (uint32_t*)m, o.h_total = (uint64_t*)(m + 32), o.h_job = (JgScanJob*)(m + 48);
+    HIPCHK(hipEventCreateWithFlags(&o.ev_early, hipEventDisableTiming));
+  }
+  return JG_OK;
+}
+// hands a viewed kept step's fsm rows to the queue jg_drain_applies reads (a pointer swap when the consumer has taken everything before them)
+int node_keep_handover(jg_engine* e) {
+  jg_engine::NodeStep& nd = e->node;
+  for (jg_engine::NodeOut* o : {&nd.spare, &nd.own()}) {
+    if (!o->fsm_landed) continue;
+    const int rc = handover(e->q_fsm, o->l_fsm, o->fsm_landed);
+    if (rc) return rc;
+  }
+  return JG_OK;
+}
+int node_keep_tail(jg_engine* e, uint32_t flags);
+int node_keep_finish(jg_engine* e, jg_engine::NodeOut& o);
+
 int node_dense_halves(jg_engine* e, uint64_t now_ms, uint32_t flags, uint32_t col_mask, uint32_t sparse_mode, uint64_t* bytes_down);
 int node_general(jg_engine* e, const JgNodeRows& rows, size_t n, size_t nb, uint32_t n_sparse, uint64_t now_ms);
 
@@ -66,12 +105,42 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   const uint32_t halves = flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF);
   // JG_NODE_ASYNC: no synchronisation inside the step - the general-path row count is looked at when the step is settled
   const bool async = (flags & JG_NODE_ASYNC) != 0;
+  const bool keep = (flags & JG_NODE_KEEP) != 0;
   HIPCHK(hipSetDevice(e->device));
   int rc = node_ensure(e);
   if (rc) return rc;
-  if ((rc = node_settle(e))) return rc;  // (an earlier asynchronous step)
+  if (keep && !async) return fail(JG_EINVAL, "jg_step_node: JG_NODE_KEEP goes with JG_NODE_ASYNC");
+  if (keep && (e->pipelined || e->inflight.phase)) return fail(JG_EINVAL, "jg_step_node: JG_NODE_KEEP or jg_drain_prefetch - an engine overlaps its drains one way");
+  if (nd.kept_n >= (keep ? 2u : 1u)) return fail(JG_EINVAL, "jg_step_node: kept steps are outstanding (JG_NODE_KEEP): jg_node_outbox_view first");
+  if ((rc = node_settle(e))) return rc;  // (an earlier asynchronous step; a kept one: only its row passes are waited for)
   if ((rc = ensure_xq(e))) return rc;
+  if (keep) {
+    // the sets change places: this step takes the one that is free (the spare: viewed, or never used), the step before -
+    // outstanding or not - keeps its own until the step after this one; with one outstanding the device-side queues and
+    // the arena change too (what that step's kernels appended and allocated is collected when its outbox is viewed)
+    if ((rc = node_keep_ensure(e, nd.spare, true)) || (rc = node_keep_ensure(e, nd.own(), false))) return rc;
+    if ((rc = node_keep_handover(e))) return rc;  // (rows nobody drained since their outbox was viewed: the set's landing buffer is about to be reused)
+    std::swap(nd.own(), nd.spare);
+    nd.viewed_spare = !nd.viewed_spare;
+    if (nd.kept_n) {
+      e->cur_set ^= 1, e->cur_arena ^= 1;
+      e->fault_floor[e->cur_set] = e->seq;
+      e->dev = dev_for_set(e, e->cur_set);
+      e->d_dev = e->d_dev2[e->cur_set];
+    }
+    nd.set = e->cur_set, nd.arena = e->cur_arena;
+    nd.d_fsm_cnt = nullptr, nd.d_fsm = nd.d_stage = nullptr, nd.d_bsum = nullptr;
+    nd.fsm_copied = 0, nd.l_fsm.n = 0;
+    nd.irr_gen = e->irr_gen, nd.seq_lo = e->seq;
+  }
+  nd.keep = keep;
+  if (!keep) nd.viewed_spare = false;  // (this step's set is the one a view shows)
   e->stepped = true;
+  struct InStep {
+    bool& f;
+    explicit InStep(bool& b) : f(b) { f = true; }
+    ~InStep() { f = false; }
+  } in_step(nd.in_step);
   jg_engine::NodeStep::Pending& pend = nd.pending;
   pend = jg_engine::NodeStep::Pending{};
   const uint32_t seq0 = e->seq;
@@ -233,6 +302,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(nd.h_nsparse, nd.d_nsparse, 4, hipMemcpyDeviceToHost, e->stream));
+    if (keep) HIPCHK(hipEventRecord(nd.ev_early, e->stream));  // (what the NEXT kept step waits for: the row passes, not the halves or the trip home)
     if (!async) {
       // the one synchronisation of a synchronous step: how many rows take the general path sizes that launch
       T1 = clk();
@@ -257,7 +327,9 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   e->seq = seq0 + 1;  // (the general path's number: taken above whether or not it runs)
   uint64_t bytes_down = 0;
   if ((rc = node_dense_halves(e, now_ms, flags, col_mask, async && n ? 1u : 0u, &bytes_down))) return rc;
-  {  // fsm_tx rows of the dense halves -> a step record of its own (per-group regions; compacted by the drains)
+  if (keep) {
+    if ((rc = node_keep_tail(e, flags))) return rc;
+  } else {  // fsm_tx rows of the dense halves -> a step record of its own (per-group regions; compacted by the drains)
     StepRec rec;
     rec.n = G;
     rec.seq = e->seq;
@@ -277,6 +349,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   }
   pend.seq_general = seq0 + 1, pend.seq_end = e->seq;
   HIPCHK(hipEventRecord(nd.ev_out, e->stream));
+  if (keep) nd.seq_hi = e->seq, nd.out = true, nd.kept_n++;
   if (trace)
     std::fprintf(stderr, "[jg node] %zu rows: uploads + classify + route issued in %.0f us, waited %.0f us (H2D %.1f MB), halves + fsm build + outbox copies issued in %.0f us\n",
                  n, T1 - T0, T2 - T1, bytes_up / 1e6, clk() - T2);
@@ -301,10 +374,8 @@ int node_dense_halves(jg_engine* e, uint64_t now_ms, uint32_t flags, uint32_t co
     ln.packed = 1;
     ln.ack_stride = 1;
     const bool common = tick && (flags & JG_NODE_COMMON_AE);
-    if (common && !nd.o_aec) {
-      if ((rc = dev_alloc(e, &nd.o_aec, (size_t)G))) return rc;
-      HIPCHK(hipHostMalloc((void**)&nd.h_aec, std::max<size_t>((size_t)G * 8, 16), hipHostMallocDefault));
-    }
+    if (common && !nd.o_aec && (rc = dev_alloc(e, &nd.o_aec, (size_t)G))) return rc;
+    if (common && !nd.h_aec) HIPCHK(hipHostMalloc((void**)&nd.h_aec, std::max<size_t>((size_t)G * 8, 16), hipHostMallocDefault));  // (per set: JG_NODE_KEEP)
     if (tick) ln.o_beat = nd.o_beat, ln.o_ae = nd.o_ae;
     if (common) ln.o_aec = nd.o_aec;
     ln.now = now_ms;
@@ -403,14 +474,23 @@ int node_general(jg_engine* e, const JgNodeRows& rows, size_t n, size_t nb, uint
 // halves come back for exactly the partitions they left alone - same results, same record order, one pass later.
 int node_settle(jg_engine* e) {
   jg_engine::NodeStep& nd = e->node;
+  if (nd.in_step) return JG_OK;  // (the halves of the step that is running)
   jg_engine::NodeStep::Pending& pd = nd.pending;
   if (!pd.on) return JG_OK;
   pd.on = false;
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  // (a kept step: its row passes are what the count depends on - the halves, the fsm rows and the trip home go on)
+  if (nd.keep) HIPCHK(hipEventSynchronize(nd.ev_early));
+  else HIPCHK(hipStreamSynchronize(e->stream));
   const uint32_t n_sparse = nd.h_nsparse[0];
   nd.last.rows_general = n_sparse;
   if (!n_sparse) return JG_OK;
+  if (nd.keep) HIPCHK(hipStreamSynchronize(e->stream));
+  struct InStep {
+    bool& f;
+    explicit InStep(bool& b) : f(b) { f = true; }
+    ~InStep() { f = false; }
+  } in_step(nd.in_step);
   int rc = JG_OK;
   const uint32_t seq_end = e->seq;
   e->seq = pd.seq_general;
@@ -425,8 +505,12 @@ int node_settle(jg_engine* e) {
   uint64_t bytes_down = 0;
   e->seq = pd.seq_general;  // (the halves number themselves from here exactly as in the first pass)
   if ((rc = node_dense_halves(e, pd.now_ms, pd.flags, pd.col_mask, 2u, &bytes_down))) return rc;
+  if (nd.keep) {  // the step's fsm rows once more, from the deltas the catch-up pass completed
+    if ((rc = node_keep_tail(e, pd.flags))) return rc;
+    HIPCHK(hipEventRecord(nd.ev_out, e->stream));
+  }
   for (StepRec& rec : e->recs)
-    if (rec.seq == pd.fsm_rec_seq && rec.fsm_per_row == JGN_FSM_ROWS && rec.msg_per_row == 0) {
+    if (!nd.keep && rec.seq == pd.fsm_rec_seq && rec.fsm_per_row == JGN_FSM_ROWS && rec.msg_per_row == 0) {
       const uint32_t n_tiles = (e->cfg.n_groups + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
       hipLaunchKernelGGL(k_node_fsm_build, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, rec.d_fsm, rec.d_fsm_cnt, rec.d_bsum_f,
                          (pd.flags & JG_NODE_FSM_FUSED) ? 1u : 0u);
@@ -437,13 +521,107 @@ int node_settle(jg_engine* e) {
   HIPCHK(hipStreamSynchronize(e->stream));
   return JG_OK;
 }
+
+// JG_NODE_KEEP: the fsm_tx rows of the step's dense halves, compacted and on their way home behind the step's own kernels -
+// what jg_drain_applies does for a step record (scan of the tile sums, gather, one copy), enqueued HERE, the copy sized
+// from the kept step finished last (the row count of a tick wobbles by a few percent at most; whatever is missing is
+// fetched when the outbox is viewed) - then the status block as the step leaves it.  No drain is issued by the host.
+int node_keep_tail(jg_engine* e, uint32_t flags) {
+  jg_engine::NodeStep& nd = e->node;
+  const uint32_t G = e->cfg.n_groups;
+  const uint32_t n_tiles = (G + JG_SCAN_TILE - 1) / JG_SCAN_TILE;
+  const size_t cap = (size_t)G * JGN_FSM_ROWS;
+  if (!nd.d_fsm) {
+    Arena& ar = e->arenas[nd.arena];
+    HIPCHK(ar.alloc((size_t)G * 4, (void**)&nd.d_fsm_cnt));
+    HIPCHK(ar.alloc(cap * sizeof(jg_fsm_row), (void**)&nd.d_fsm));
+    HIPCHK(ar.alloc((size_t)n_tiles * 8, (void**)&nd.d_bsum));
+    HIPCHK(ar.alloc(cap * sizeof(jg_fsm_row), (void**)&nd.d_stage));
+  }
+  hipLaunchKernelGGL(k_node_fsm_build, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, e->dev, nd.cols, nd.d_fsm, nd.d_fsm_cnt, nd.d_bsum,
+                     (flags & JG_NODE_FSM_FUSED) ? 1u : 0u);
+  nd.h_job[0] = JgScanJob{nd.d_bsum, n_tiles, 0};
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(JG_BLOCK), 0, e->stream, (const JgScanJob*)nd.h_job, nd.h_total);
+  hipLaunchKernelGGL(k_scan_gather<jg_fsm_row>, dim3(n_tiles), dim3(JG_BLOCK), 0, e->stream, nd.d_fsm_cnt, G, nd.d_bsum, (uint32_t)JGN_FSM_ROWS, nd.d_fsm,
+                     nd.d_stage);
+  HIPCHK(hipGetLastError());
+  e->n_launch += 3;
+  const size_t guess = std::min(cap, nd.fsm_guess ? nd.fsm_guess + nd.fsm_guess / 8 + 4096 : (size_t)0);
+  nd.l_fsm.n = 0;
+  if (guess) {
+    HIPCHK(nd.l_fsm.reserve(guess));
+    HIPCHK(hipMemcpyAsync(nd.l_fsm.p, nd.d_stage, guess * sizeof(jg_fsm_row), hipMemcpyDeviceToHost, e->stream));
+  }
+  nd.fsm_copied = guess;
+  HIPCHK(hipMemcpyAsync(nd.h_status, e->d_status, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  return JG_OK;
+}
+
+// JG_NODE_KEEP: the outbox of kept step `o` is being viewed - wait for ITS outputs (not for a newer step's), surface what
+// its status block says, collect what only a step outside the steady state leaves behind (general-path records,
+// exceptional rows, faults: the synchronous drain, over this step's queues and arena), and make its fsm rows the ones
+// the next drain of that queue delivers.
+int node_keep_finish(jg_engine* e, jg_engine::NodeOut& o) {
+  jg_engine::NodeStep& nd = e->node;
+  HIPCHK(hipSetDevice(e->device));
+  int rc = JG_OK;
+  if (&o == &nd.own() && (rc = node_settle(e))) return rc;  // (the newest step: nobody has looked at its row count yet)
+  HIPCHK(hipEventSynchronize(o.ev_out));
+  const uint32_t* st = o.h_status;
+  if ((rc = status_check(e, st))) return rc;
+  if (e->flag_check_pending && o.irr_gen == e->irr_gen) {  // (as a pipelined drain's snapshot: no step since could have left an irregular chain)
+    e->maybe_irregular = st[1] != 0;
+    e->flag_check_pending = false;
+  }
+  if (st[5]) e->maybe_irregular = true;
+  if (!e->slow_scheduled_ever && st[2]) return fail(JG_EDEVICE, "internal: irregular chain reached the fast-only dense path");
+  const uint32_t nf = st[o.set ? 6 : 3], nx = st[o.set ? 7 : 4];
+  if ((rc = node_keep_handover(e))) return rc;  // (the step before's rows, if nobody drained them: they come first)
+  // (records of THIS step and of what came before it: a newer kept step that somebody settled meanwhile - a read of the
+  // engine - keeps its own for its own view)
+  size_t nrec = 0;
+  while (nrec < e->recs.size() && e->recs[nrec].seq <= o.seq_hi) nrec++;
+  if (nrec || nf || nx) {
+    // outside the steady state: everything in flight first (the newer step's kernels too), then the synchronous drain
+    HIPCHK(hipStreamSynchronize(e->stream));
+    jg_engine::DrainBatch b;
+    b.set = o.set;
+    b.seq_hi = o.seq_hi;
+    b.nf = nf, b.nx = nx;
+    std::vector<StepRec> mine(e->recs.begin(), e->recs.begin() + nrec);
+    e->recs.erase(e->recs.begin(), e->recs.begin() + nrec);
+    if ((rc = drain_scan(e, mine, e->stream))) return rc;
+    if (nrec) HIPCHK(hipStreamSynchronize(e->stream));
+    if ((rc = drain_gather(e, b, mine, e->stream))) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if ((rc = drain_finish(e, b, mine, e->arenas[o.arena]))) return rc;
+    e->fault_floor[b.set] = b.seq_hi;
+  }
+  const size_t total = (size_t)*o.h_total;
+  if (total > o.fsm_copied) {  // (the copy behind the step was sized from the step before: the rest now)
+    o.l_fsm.n = o.fsm_copied;
+    HIPCHK(o.l_fsm.reserve(total));
+    HIPCHK(hipMemcpyAsync(o.l_fsm.p + o.fsm_copied, o.d_stage + o.fsm_copied, (total - o.fsm_copied) * sizeof(jg_fsm_row), hipMemcpyDeviceToHost,
+                          e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  o.l_fsm.n = total, o.fsm_landed = total != 0;
+  if (e->track_segs) seg_add(e->seg_f, o.seq_hi, total);
+  nd.fsm_guess = total;
+  // everything the step allocated has been read: its arena starts over (records, if it had any, were drained above)
+  e->arenas[o.arena].reset();
+  o.d_fsm_cnt = nullptr, o.d_fsm = o.d_stage = nullptr, o.d_bsum = nullptr;
+  o.out = false;
+  nd.kept_n--;
+  return JG_OK;
+}
 }  // namespace
 
 int jg_step_node(jg_engine* e, uint64_t now_ms, uint32_t flags) {
   if (!e) return fail(JG_EINVAL, "null argument");
-  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~63u))
-    return fail(JG_EINVAL, "jg_step_node: flags = JG_NODE_LEADER_HALF and / or JG_NODE_FOLLOWER_HALF [| JG_NODE_TICK] [| JG_NODE_ASYNC] [| JG_NODE_COMMON_AE] [| JG_NODE_FSM_FUSED]");
-  if (e->router && (flags & JG_NODE_COMMON_AE)) return fail(JG_EINVAL, "jg_step_node: JG_NODE_COMMON_AE is per shard (jg_get_shard)");
+  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~127u))
+    return fail(JG_EINVAL, "jg_step_node: flags = JG_NODE_LEADER_HALF and / or JG_NODE_FOLLOWER_HALF [| JG_NODE_TICK] [| JG_NODE_ASYNC] [| JG_NODE_COMMON_AE] [| JG_NODE_FSM_FUSED] [| JG_NODE_KEEP]");
+  if (e->router && (flags & (JG_NODE_COMMON_AE | JG_NODE_KEEP))) return fail(JG_EINVAL, "jg_step_node: JG_NODE_COMMON_AE and JG_NODE_KEEP are per shard (jg_get_shard)");
   if (e->router) return router_step_node(e, now_ms, flags);
   if (e->inflight.phase) return fail(JG_EINVAL, "a drain is in transfer: jg_drain_wait first");
   return node_step(e, now_ms, flags);
@@ -479,32 +657,41 @@ int jg_node_outbox_view(jg_engine* e, jg_node_outbox* out) {
   if (!e || !out) return fail(JG_EINVAL, "null argument");
   if (e->router) return router_node_outbox(e, out);
   jg_engine::NodeStep& nd = e->node;
-  if (!nd.ready || !nd.last_flags) return fail(JG_EINVAL, "no jg_step_node yet");
-  int rc = sync_and_check(e);  // (the columns have landed; device-side error flags surface here)
-  if (rc) return rc;
-  *out = nd.last;
-  if ((nd.last_flags & JG_NODE_LEADER_HALF) && (nd.last_flags & JG_NODE_TICK)) {
-    out->beat = nd.h_beat, out->ae = nd.h_ae;
-    if (nd.last_flags & JG_NODE_COMMON_AE) {
-      out->aec = nd.h_aec, out->ae = nullptr;
-      if (nd.h_nsparse[2]) {  // some partition's words differ by addressee: the rows are wanted after all
-        if (!nd.ae_rows_landed) {
+  if (!nd.ready || !(nd.last_flags | nd.spare.last_flags)) return fail(JG_EINVAL, "no jg_step_node yet");
+  // JG_NODE_KEEP: the OLDEST step whose outbox has not been viewed (two outstanding: the spare set's); none outstanding:
+  // the one viewed last, again
+  jg_engine::NodeOut& o = nd.kept_n == 2 || (nd.kept_n == 0 && nd.viewed_spare) ? nd.spare : nd.own();
+  int rc = JG_OK;
+  if (o.out) {
+    if ((rc = node_keep_finish(e, o))) return rc;  // (waits for THIS step's outputs only)
+    nd.viewed_spare = &o == &nd.spare;
+  } else if (!nd.kept_n) {
+    if ((rc = sync_and_check(e))) return rc;  // (the columns have landed; device-side error flags surface here)
+  }
+  *out = o.last;
+  if ((o.last_flags & JG_NODE_LEADER_HALF) && (o.last_flags & JG_NODE_TICK)) {
+    out->beat = o.h_beat, out->ae = o.h_ae;
+    if (o.last_flags & JG_NODE_COMMON_AE) {
+      out->aec = o.h_aec, out->ae = nullptr;
+      if (o.h_nsparse[2]) {  // some partition's words differ by addressee: the rows are wanted after all
+        if (!o.ae_rows_landed) {
           const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
           const uint32_t own = e->uniform_self >= 0 ? (uint32_t)e->uniform_self : R;
           HIPCHK(hipSetDevice(e->device));
-          if (own > 0) HIPCHK(hipMemcpyAsync(nd.h_ae, nd.o_ae, (size_t)std::min(own, R) * G * 8, hipMemcpyDeviceToHost, e->stream));
+          // (a kept step: its own copy of the rows - a newer step has written the other set's since)
+          if (own > 0) HIPCHK(hipMemcpyAsync(o.h_ae, o.o_ae, (size_t)std::min(own, R) * G * 8, hipMemcpyDeviceToHost, e->stream));
           if (own + 1 < R)
-            HIPCHK(hipMemcpyAsync(nd.h_ae + (size_t)(own + 1) * G, nd.o_ae + (size_t)(own + 1) * G, (size_t)(R - own - 1) * G * 8, hipMemcpyDeviceToHost,
+            HIPCHK(hipMemcpyAsync(o.h_ae + (size_t)(own + 1) * G, o.o_ae + (size_t)(own + 1) * G, (size_t)(R - own - 1) * G * 8, hipMemcpyDeviceToHost,
                                   e->stream));
           HIPCHK(hipStreamSynchronize(e->stream));
-          nd.last.bytes_d2h += (size_t)G * (size_t)(own < R ? R - 1 : R) * 8;
-          out->bytes_d2h = nd.last.bytes_d2h;
-          nd.ae_rows_landed = true;
+          o.last.bytes_d2h += (size_t)G * (size_t)(own < R ? R - 1 : R) * 8;
+          out->bytes_d2h = o.last.bytes_d2h;
+          o.ae_rows_landed = true;
         }
-        out->ae = nd.h_ae;
+        out->ae = o.h_ae;
       }
     }
   }
-  if (nd.last_flags & JG_NODE_FOLLOWER_HALF) out->answer = nd.h_answer, out->hb_commit = nd.h_hbc;
+  if (o.last_flags & JG_NODE_FOLLOWER_HALF) out->answer = o.h_answer, out->hb_commit = o.h_hbc;
   return JG_OK;
 }

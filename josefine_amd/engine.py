@@ -317,13 +317,25 @@ class BatchedRaft:
         row / PCIe byte counts.  common_ae (JG_NODE_COMMON_AE): "aec" [G] is the partition's AppendEntries word
         for every addressee, "ae" only comes down (else None) when some partition's words differ (AEC_INDIVIDUAL);
         fsm_fused (JG_NODE_FSM_FUSED): a leader's rows of a step as one FSM_LEADER_STEP row (`expand_fsm_rows`)."""
+        self.step_node_begin(now_ms, leader, follower, tick, async_, common_ae, fsm_fused)
+        if between is not None:  # (async_: what the caller does while the step runs - submits for the next one, say)
+            between()
+        return self.node_outbox()
+
+    def step_node_begin(self, now_ms: int = 0, leader: bool = True, follower: bool = True, tick: bool = True, async_: bool = False,
+                        common_ae: bool = False, fsm_fused: bool = False, keep: bool = False) -> None:
+        """jg_step_node alone (the outbox: `node_outbox`).  keep (JG_NODE_KEEP, with async_): the step keeps its outputs
+        until its outbox is viewed - a second such step may be begun before that; `node_outbox` then serves the OLDER
+        one and makes its rows the ones the next drains deliver."""
         self._flush_pending()
         flags = (capi.NODE_LEADER_HALF if leader else 0) | (capi.NODE_FOLLOWER_HALF if follower else 0) | \
                 (capi.NODE_TICK if tick else 0) | (capi.NODE_ASYNC if async_ else 0) | \
-                (capi.NODE_COMMON_AE if common_ae else 0) | (capi.NODE_FSM_FUSED if fsm_fused else 0)
+                (capi.NODE_COMMON_AE if common_ae else 0) | (capi.NODE_FSM_FUSED if fsm_fused else 0) | \
+                (capi.NODE_KEEP if keep else 0)
         self._check(self.api.step_node(self._h, int(now_ms), flags))
-        if between is not None:  # (async_: what the caller does while the step runs - submits for the next one, say)
-            between()
+
+    def node_outbox(self) -> dict:
+        """jg_node_outbox_view as host copies (see `step_node`)."""
         o = capi.NodeOutbox()
         self._check(self.api.node_outbox_view(self._h, C.byref(o)))
         G, R = self.G, self.R

@@ -166,7 +166,7 @@ struct LoopResult {
   bool ok = false;
   std::string error;
   uint64_t decisions = 0, rows_in = 0, general = 0, fsm_rows = 0, msg_rows = 0, up_bytes = 0, down_bytes = 0, sink = 0, wire_bytes = 0;
-  double wall_ms = 0, t_fill = 0, t_submit = 0, t_step = 0;
+  double wall_ms = 0, t_fill = 0, t_submit = 0, t_step = 0, t_sinks = 0, t_wait = 0;
   float k_us = 0;
   uint32_t k_n = 0;
 };
@@ -218,13 +218,27 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
     loop.halves = JG_NODE_LEADER_HALF;  // this node leads every partition
     loop.dense = mode != "general";
     loop.pipelined = pipe;
+    // JG_BENCH_IN_FLIGHT=2: two ticks in flight (BatchedEventLoop::in_flight, JG_NODE_KEEP) - tick t + 1 is begun before tick
+    // t's outputs are read; the same rows reach the same sinks in the same order, the device is never idle in between
+    if (const char* f = std::getenv("JG_BENCH_IN_FLIGHT")) loop.in_flight = pipe ? (uint32_t)std::max(1, std::atoi(f)) : 1u;
     if (compact) loop.bus = JG_NODE_COMMON_AE | JG_NODE_FSM_FUSED;
     uint64_t sink = 0, fsm_rows = 0, msg_rows = 0, col_bytes = 0, up_bytes = 0, general = 0;
-    raft.fsm_rows_tx = [&](const jg_fsm_row* r, size_t n) { sink += sum_split(r, n, sizeof(jg_fsm_row)), fsm_rows += n; };
-    raft.msg_rows_tx = [&](const jg_msg_row* r, size_t n) { sink += sum_split(r, n, sizeof(jg_msg_row)), msg_rows += n; };
+    double t_sinks = 0;  // (inside the sinks: the consumers' reading of what came home - the rest of a step's time is the engine's calls and their waits)
+    raft.fsm_rows_tx = [&](const jg_fsm_row* r, size_t n) {
+      const auto a = Clock::now();
+      sink += sum_split(r, n, sizeof(jg_fsm_row)), fsm_rows += n;
+      t_sinks += ms_since(a);
+    };
+    raft.msg_rows_tx = [&](const jg_msg_row* r, size_t n) {
+      const auto a = Clock::now();
+      sink += sum_split(r, n, sizeof(jg_msg_row)), msg_rows += n;
+      t_sinks += ms_since(a);
+    };
     raft.columns_tx = [&](const jg_node_outbox& o) {
+      const auto a = Clock::now();
       if (o.beat) sink += sum_split(o.beat, G, 16) + (o.aec ? sum_split(o.aec, G, 8) : 0) + (o.ae ? sum_split(o.ae, (size_t)R * G, 8) : 0);
       col_bytes += o.bytes_d2h, up_bytes += o.bytes_h2d, general += o.rows_general;
+      t_sinks += ms_since(a);
     };
     {  // this node wins every election the reference's way: Timeout, then granted votes until quorum
       RowQueue q;
@@ -361,7 +375,8 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
         loop.flush();
         if (jg_sync(raft.raw()) != JG_OK || jg_get_counters(raft.raw(), c0) != JG_OK) throw std::runtime_error("counters");
         sink = fsm_rows = msg_rows = col_bytes = up_bytes = general = rows_in = wire_bytes = 0;
-        t_fill = t_submit = t_step = 0;
+        t_fill = t_submit = t_step = t_sinks = 0;
+        raft.ms_waited_for_outputs = 0;
         t_begin = rv.arrive(), started = true;
       }
       const uint64_t now = 100ull * (t + 1);
@@ -389,13 +404,24 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
         t_step += ms_since(a);
         rows_in += G - n;  // (n is added below: count the rows actually submitted)
       } else if (mode == "inplace") {
+        static const bool tick_trace = std::getenv("JG_BENCH_TICK_TRACE") != nullptr;  // (one line per tick on stderr: where the loop's thread was)
+        const double w_before = raft.ms_waited_for_outputs, s_before = t_sinks;
+        const double at0 = t >= W ? std::chrono::duration<double, std::milli>(Clock::now() - t_begin).count() : 0;
+        const auto r0 = Clock::now();
         const jg_cmd_cols c = loop.tcp_rx_reserve(n);
+        const double ms_reserve = ms_since(r0);
         const size_t k = fill(t, c.kind, c.group, c.from, c.id, c.flag);
-        t_fill += ms_since(a), a = Clock::now();
+        const double ms_f = ms_since(a);
+        t_fill += ms_f, a = Clock::now();
         loop.tcp_rx_commit(k, 0, (packed ? (uint32_t)JG_COL_PACKED_KIND : (uint32_t)(JG_COL_FROM | JG_COL_FLAG)) | (id32 ? (uint32_t)JG_COL_ID32 : 0u) | unchecked);
-        t_submit += ms_since(a), a = Clock::now();
+        const double ms_c = ms_since(a);
+        t_submit += ms_c, a = Clock::now();
         loop.run_until(now);
-        t_step += ms_since(a);
+        const double ms_s = ms_since(a);
+        t_step += ms_s;
+        if (tick_trace && t >= W)
+          std::fprintf(stderr, "[tick %u] at %.3f ms: %zu rows, reserve %.3f, fill %.3f, commit %.3f, step %.3f (waiting for outputs %.3f, sinks %.3f)\n", t, at0, n, ms_reserve,
+                       ms_f, ms_c, ms_s, raft.ms_waited_for_outputs - w_before, t_sinks - s_before);
       } else {
         staged.kind.resize(n), staged.group.resize(n), staged.from.resize(n), staged.id.resize(n), staged.flag.resize(n);
         fill(t, staged.kind.data(), staged.group.data(), staged.from.data(), staged.id.data(), staged.flag.data());
@@ -427,7 +453,7 @@ static void run_loop(uint32_t G, uint32_t R, uint32_t T, uint32_t W, const std::
     out.decisions = c1[1] - c0[1];
     out.down_bytes = col_bytes + fsm_rows * sizeof(jg_fsm_row) + msg_rows * sizeof(jg_msg_row);
     out.rows_in = rows_in, out.general = general, out.fsm_rows = fsm_rows, out.msg_rows = msg_rows, out.up_bytes = up_bytes, out.sink = sink;
-    out.t_fill = t_fill, out.t_submit = t_submit, out.t_step = t_step;
+    out.t_fill = t_fill, out.t_submit = t_submit, out.t_step = t_step, out.t_sinks = t_sinks, out.t_wait = raft.ms_waited_for_outputs;
     out.wire_bytes = wire_bytes;
     out.ok = ok;
   } catch (const std::exception& e) {
@@ -493,16 +519,17 @@ int main(int argc, char** argv) {
     a.decisions += r.decisions, a.rows_in += r.rows_in, a.general += r.general, a.fsm_rows += r.fsm_rows, a.msg_rows += r.msg_rows;
     a.up_bytes += r.up_bytes, a.down_bytes += r.down_bytes, a.sink += r.sink, a.wire_bytes += r.wire_bytes;
     a.wall_ms = std::max(a.wall_ms, r.wall_ms);
-    a.t_fill += r.t_fill / L, a.t_submit += r.t_submit / L, a.t_step += r.t_step / L;  // (per loop: they run side by side)
+    a.t_fill += r.t_fill / L, a.t_submit += r.t_submit / L, a.t_step += r.t_step / L, a.t_sinks += r.t_sinks / L, a.t_wait += r.t_wait / L;  // (per loop: they run side by side)
     k_us += r.k_us / L, a.k_n += r.k_n;
   }
-  std::printf("{\"ok\": %s, \"mode\": \"%s\", \"bus\": \"%s\", \"G\": %u, \"R\": %u, \"loops\": %u, \"task_threads_beside_each_loop\": %u, \"ticks\": %u, \"warmup\": %u, \"decisions\": %llu, \"wall_ms\": %.3f, "
-              "\"decisions_per_s\": %.6g, \"ms_per_tick\": %.4f, \"ms_fill\": %.4f, \"ms_submit\": %.4f, \"ms_step_and_drain\": %.4f, "
+  const uint32_t in_flight = mode.rfind("pipe", 0) == 0 && std::getenv("JG_BENCH_IN_FLIGHT") ? (uint32_t)std::max(1, std::atoi(std::getenv("JG_BENCH_IN_FLIGHT"))) : 1u;
+  std::printf("{\"ok\": %s, \"mode\": \"%s\", \"ticks_in_flight\": %u, \"bus\": \"%s\", \"G\": %u, \"R\": %u, \"loops\": %u, \"task_threads_beside_each_loop\": %u, \"ticks\": %u, \"warmup\": %u, \"decisions\": %llu, \"wall_ms\": %.3f, "
+              "\"decisions_per_s\": %.6g, \"ms_per_tick\": %.4f, \"ms_fill\": %.4f, \"ms_submit\": %.4f, \"ms_step_and_drain\": %.4f, \"ms_in_the_sinks\": %.4f, \"ms_waiting_for_outputs\": %.4f, "
               "\"rows_in_per_tick\": %.1f, \"rows_general\": %llu, \"fsm_rows_per_tick\": %.1f, \"msg_rows_per_tick\": %.1f, "
               "\"pcie_h2d_bytes_per_tick\": %.1f, \"pcie_d2h_bytes_per_tick\": %.1f, \"leader_kernel_us\": %.3f, \"leader_kernel_launches\": %u, "
               "\"wire_bytes_decoded_per_tick\": %.1f, \"sink\": %llu}\n",
-              a.ok ? "true" : "false", mode.c_str(), compact ? "compact (packed kind byte, 32-bit ids, common AppendEntries word, fused fsm row)" : "plain", G, R, L, mode.rfind("pipetasks", 0) == 0 ? helpers : 0u, T, W, (unsigned long long)a.decisions, a.wall_ms, a.decisions / (a.wall_ms / 1e3),
-              a.wall_ms / T, a.t_fill / T, a.t_submit / T, a.t_step / T, (double)a.rows_in / T, (unsigned long long)a.general,
+              a.ok ? "true" : "false", mode.c_str(), in_flight, compact ? "compact (packed kind byte, 32-bit ids, common AppendEntries word, fused fsm row)" : "plain", G, R, L, mode.rfind("pipetasks", 0) == 0 ? helpers : 0u, T, W, (unsigned long long)a.decisions, a.wall_ms, a.decisions / (a.wall_ms / 1e3),
+              a.wall_ms / T, a.t_fill / T, a.t_submit / T, a.t_step / T, a.t_sinks / T, a.t_wait / T, (double)a.rows_in / T, (unsigned long long)a.general,
               (double)a.fsm_rows / T, (double)a.msg_rows / T, (double)a.up_bytes / T, (double)a.down_bytes / T, k_us, a.k_n,
               (double)a.wire_bytes / T, (unsigned long long)a.sink);
   return a.ok ? 0 : 1;

@@ -18,6 +18,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <chrono>
 #include <deque>
 #include <functional>
 #include <map>
@@ -206,20 +207,28 @@ class BatchedRaft {
   // device and classified (the engine's pinned input columns are free again) with the dense halves, the fsm build and the
   // downloads of the outputs still running; the caller decodes the NEXT tick's traffic meanwhile and calls finish() -
   // which waits for the outputs, feeds fsm_tx / rpc_tx / the column sink - right before the next begin().
-  void step_node_begin(uint64_t now_ms, uint32_t flags, bool async = false) {
+  // keep (JG_NODE_KEEP, with async): TWO steps in flight - begin() may be called again before the step before has been
+  // finished; finish() then serves the OLDER one (its outbox, its rows), while the device runs the newer.
+  void step_node_begin(uint64_t now_ms, uint32_t flags, bool async = false, bool keep = false) {
     flush_rows();
     // async: no synchronisation at all inside the call (JG_NODE_ASYNC) - the engine settles the step (its general path, if
     // it has one) when step_node_finish asks for the outbox
-    check(jg_step_node(e_, now_ms, flags | (async ? (uint32_t)JG_NODE_ASYNC : 0u)));
-    node_step_open_ = true;
+    check(jg_step_node(e_, now_ms, flags | (async ? (uint32_t)JG_NODE_ASYNC : 0u) | (keep ? (uint32_t)JG_NODE_KEEP : 0u)));
+    step_blocks_.emplace_back();
+    step_blocks_.back().swap(pending_blocks_);  // (the payloads of THIS step's AppendEntries rows: stored when it is finished)
   }
-  bool node_step_open() const { return node_step_open_; }
+  double ms_waited_for_outputs = 0;  // inside jg_node_outbox_view, summed over the steps finished so far (a loop's own accounting)
+  bool node_step_open() const { return !step_blocks_.empty(); }
+  size_t node_steps_open() const { return step_blocks_.size(); }
   void step_node_finish(const std::vector<NodeId>* answers_to = nullptr) {
-    if (!node_step_open_) return;
-    node_step_open_ = false;
+    if (step_blocks_.empty()) return;
     jg_node_outbox o{};
-    check(jg_node_outbox_view(e_, &o));
+    const auto w0 = std::chrono::steady_clock::now();
+    check(jg_node_outbox_view(e_, &o));  // (the oldest open step's)
+    ms_waited_for_outputs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
     last_outbox_ = o;
+    pending_blocks_.swap(step_blocks_.front());  // (nothing else is pending here: a plain step() is not taken between begin and finish)
+    step_blocks_.pop_front();
     after_step();
     if (columns_tx) columns_tx(o);
     else if (rpc_tx) expand_columns(o, answers_to);
@@ -480,7 +489,7 @@ class BatchedRaft {
   std::vector<uint32_t> group_, from_;
   std::vector<uint64_t> term_, id_, aux_, blk_id_, blk_next_;
   std::vector<std::pair<uint32_t, Block>> pending_blocks_;
-  bool node_step_open_ = false;
+  std::deque<std::vector<std::pair<uint32_t, Block>>> step_blocks_;  // one entry per node step begun and not finished (oldest first)
   std::set<uint32_t> extend_failed_;  // partitions whose process died in Chain::extend (until their restart)
   std::map<std::pair<uint32_t, uint64_t>, std::vector<uint8_t>> pending_reqs_;
 };
@@ -623,6 +632,14 @@ class BatchedEventLoop {
   // reference are asynchronous too (mod.rs:337-340) -, so that the transport decodes tick t + 1 into the engine's
   // pinned columns while the device runs tick t's kernels and sends its outputs home.
   bool pipelined = false;
+  // ... with TWO ticks in flight (2; needs pipelined): what step t pushed on fsm_tx / rpc_tx is delivered at the start of
+  // step t + 2 - step t + 1, begun a tick ago, keeps the device busy meanwhile (JG_NODE_KEEP: the engine keeps a step's
+  // outbox and rows in a set of its own until they have been viewed, and a view waits for ITS step only) - so that a tick's
+  // whole chain (rows up, kernels, columns and fsm rows down: ~3 ms at 1 M x 5) has two periods to complete and the loop's
+  // period is its slowest stage (the transport's decoding + the sinks, the bus one way, the bus the other way), not their
+  // sum.  The channels of the reference promise an order, not a latency (mod.rs:337-340): every channel carries the same
+  // rows in the same order per step, one step later than with 1.
+  uint32_t in_flight = 1;
   // the node step's compact bus formats (ABI v7): JG_NODE_COMMON_AE - the Tick's AppendEntries words come home as one
   // word per partition where the followers' agree - and / or JG_NODE_FSM_FUSED - a leader's fsm_tx rows of a step as one
   // row; both are expanded again by BatchedRaft before rpc_tx / fsm_tx see them (a column / row sink sees the compact form)
@@ -685,8 +702,7 @@ class BatchedEventLoop {
   }
   // pipelined: deliver what the last step pushed on fsm_tx / rpc_tx (run_until does it at the start of the next step)
   void flush() {
-    if (!raft_.node_step_open()) return;
-    raft_.step_node_finish(&answers_to_);
+    while (raft_.node_step_open()) finish_oldest();
     drain_local(last_at_);
   }
   size_t pending_requests() const { return requests_.size(); }
@@ -697,9 +713,20 @@ class BatchedEventLoop {
     // (pipelined: the previous step's outputs first - its pinned queues and outbox are about to be reused, the blocks
     // noted below belong to THIS step (BatchedRaft::after_step stores a step's blocks where its extend succeeded), and
     // its answers go to the senders of ITS Heartbeat / AppendEntries rows, not to this step's)
-    if (dense) flush();
+    const bool two = dense && pipelined && in_flight >= 2;
+    if (two) {
+      // two ticks in flight: what the step BEFORE LAST pushed on the channels is delivered now - its outputs have had this
+      // long to travel home - while the last step, begun a tick ago, keeps the device busy
+      while (raft_.node_steps_open() >= 2) finish_oldest();
+      if (!local_.empty()) flush();  // (Address::Local messages are applied by a step of their own: nothing may be in flight)
+    } else if (dense) {
+      flush();
+    }
+    // (who THIS step's answers go to: noted per step, applied when the step is finished - with two ticks in flight the
+    // step before is finished after this one has begun, and its answers go to the senders of ITS rows)
+    answers_of_step_.emplace_back();
     for (size_t i = 0; i < in_.size(); i++)
-      if (in_.kind[i] == JG_CMD_HEARTBEAT || in_.kind[i] == JG_CMD_APPEND_ENTRIES) answers_to_[in_.group[i]] = in_.from[i];
+      if (in_.kind[i] == JG_CMD_HEARTBEAT || in_.kind[i] == JG_CMD_APPEND_ENTRIES) answers_of_step_.back().push_back({in_.group[i], in_.from[i]});
     // payload-carrying rows (client proposals, blocks) go through submit() so that BatchedRaft's request /
     // block mirrors see them; everything else is one bulk jg_submit of the row queue
     for (auto& p : proposals_) raft_.note_proposal(p.group, p.id, std::move(p.data));
@@ -712,11 +739,12 @@ class BatchedEventLoop {
     if (dense) {
       if (!in_.empty()) raft_.submit_rows(in_.view());
       in_.clear();
+      raft_.step_node_begin(at, halves | bus | (tick ? (uint32_t)JG_NODE_TICK : 0u), pipelined, two);
       last_at_ = at;
-      raft_.step_node_begin(at, halves | bus | (tick ? (uint32_t)JG_NODE_TICK : 0u), pipelined);
       if (pipelined) return;
-      raft_.step_node_finish(&answers_to_);
+      finish_oldest();
     } else {
+      answers_of_step_.pop_back();
       if (tick)
         for (uint32_t g = 0; g < G_; g++) in_.push(g, JG_CMD_TICK);
       if (!in_.empty()) raft_.submit_rows(in_.view());
@@ -724,6 +752,13 @@ class BatchedEventLoop {
       raft_.step(at);
     }
     drain_local(at);
+  }
+  void finish_oldest() {
+    if (!answers_of_step_.empty()) {
+      for (const auto& u : answers_of_step_.front()) answers_to_[u.first] = u.second;
+      answers_of_step_.pop_front();
+    }
+    raft_.step_node_finish(&answers_to_);
   }
   // Address::Local messages (server.rs:143) are applied before anything new is accepted
   void drain_local(uint64_t at) {
@@ -788,6 +823,7 @@ class BatchedEventLoop {
   std::vector<Proposal> proposals_;                       // payloads of the ClientRequest rows in in_
   std::map<std::pair<uint32_t, uint64_t>, std::vector<uint8_t>> proxied_;
   std::vector<NodeId> answers_to_;                        // per partition: who its Heartbeat / AppendEntries came from
+  std::deque<std::vector<std::pair<uint32_t, NodeId>>> answers_of_step_;  // ... as noted by the steps begun and not finished
   std::deque<Message> local_;
   std::map<uint64_t, Response> requests_;
   std::map<std::pair<uint32_t, BlockId>, uint64_t> notifications_;

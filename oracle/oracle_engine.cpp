@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <deque>
 #include <thread>
 
 using namespace jo;
@@ -42,6 +43,19 @@ struct jo_engine {
   std::vector<jg_fsm_row> v_fsms;
   jg_node_outbox n_last{};
   uint32_t n_last_flags = 0;
+  // JG_NODE_KEEP: a kept step's outputs - its outbox columns and every row it queued - wait here until its outbox is
+  // viewed (jo_node_outbox_view serves the oldest); at most two
+  struct KeptStep {
+    std::vector<uint64_t> o_ae, o_answer, o_hbc, o_aec;
+    std::vector<jg_leader_beat> o_beat;
+    bool ae_individual = false;
+    jg_node_outbox last{};
+    uint32_t flags = 0;
+    std::vector<jg_msg_row> msgs;
+    std::vector<jg_fsm_row> fsms;
+    std::vector<jg_fault_row> faults;
+  };
+  std::deque<KeptStep> kept;
 };
 
 static thread_local std::string g_err;
@@ -676,7 +690,11 @@ int jo_synth_fill_acks(jo_engine* e, uint32_t mode, uint64_t tick, uint64_t* sim
 // the engine reports (which partitions count as rows_general, which messages leave as mailbox columns and
 // which as rows); every partition's rows are applied one command at a time in stream order either way.
 int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
-  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~63u)) return fail(JG_EINVAL, "jg_step_node: bad flags");  // (JG_NODE_ASYNC: a matter of when the engine looks at its own counts)
+  if (!(flags & (JG_NODE_LEADER_HALF | JG_NODE_FOLLOWER_HALF)) || (flags & ~127u)) return fail(JG_EINVAL, "jg_step_node: bad flags");  // (JG_NODE_ASYNC: a matter of when the engine looks at its own counts)
+  const bool keep = (flags & JG_NODE_KEEP) != 0;
+  if (keep && !(flags & JG_NODE_ASYNC)) return fail(JG_EINVAL, "jg_step_node: JG_NODE_KEEP goes with JG_NODE_ASYNC");
+  if (e->kept.size() >= (keep ? 2u : 1u)) return fail(JG_EINVAL, "jg_step_node: kept steps are outstanding (JG_NODE_KEEP): jg_node_outbox_view first");
+  const size_t keep_m0 = e->msgs.size(), keep_f0 = e->fsms.size(), keep_q0 = e->faults.size();
   e->stepped = true;
   const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
   const bool lead_half = flags & JG_NODE_LEADER_HALF, fol_half = flags & JG_NODE_FOLLOWER_HALF, tick = flags & JG_NODE_TICK;
@@ -909,6 +927,15 @@ int jo_step_node(jo_engine* e, uint64_t now_ms, uint32_t flags) {
   e->n_last = jg_node_outbox{};
   e->n_last.rows = n_rows, e->n_last.rows_general = n_general;
   e->n_last_flags = flags;
+  if (keep) {  // everything the step produced leaves the queues again: due when its outbox is viewed
+    e->kept.emplace_back();
+    jo_engine::KeptStep& k = e->kept.back();
+    k.o_ae.swap(e->n_o_ae), k.o_answer.swap(e->n_o_answer), k.o_hbc.swap(e->n_o_hbc), k.o_aec.swap(e->n_o_aec), k.o_beat.swap(e->n_o_beat);
+    k.ae_individual = e->n_ae_individual, k.last = e->n_last, k.flags = flags;
+    k.msgs.assign(e->msgs.begin() + keep_m0, e->msgs.end()), e->msgs.resize(keep_m0);
+    k.fsms.assign(e->fsms.begin() + keep_f0, e->fsms.end()), e->fsms.resize(keep_f0);
+    k.faults.assign(e->faults.begin() + keep_q0, e->faults.end()), e->faults.resize(keep_q0);
+  }
   return JG_OK;
 }
 
@@ -932,6 +959,15 @@ int jo_node_inbox_columns(jo_engine* e, uint32_t slot, uint64_t** answer, uint64
 
 int jo_node_outbox_view(jo_engine* e, jg_node_outbox* out) {
   if (!e->n_last_flags) return fail(JG_EINVAL, "no jg_step_node yet");
+  if (!e->kept.empty()) {  // JG_NODE_KEEP: the oldest kept step - its columns are the ones on view, its rows are due now
+    jo_engine::KeptStep& k = e->kept.front();
+    e->n_o_ae.swap(k.o_ae), e->n_o_answer.swap(k.o_answer), e->n_o_hbc.swap(k.o_hbc), e->n_o_aec.swap(k.o_aec), e->n_o_beat.swap(k.o_beat);
+    e->n_ae_individual = k.ae_individual, e->n_last = k.last, e->n_last_flags = k.flags;
+    e->msgs.insert(e->msgs.end(), k.msgs.begin(), k.msgs.end());
+    e->fsms.insert(e->fsms.end(), k.fsms.begin(), k.fsms.end());
+    e->faults.insert(e->faults.end(), k.faults.begin(), k.faults.end());
+    e->kept.pop_front();
+  }
   *out = e->n_last;
   if ((e->n_last_flags & JG_NODE_LEADER_HALF) && (e->n_last_flags & JG_NODE_TICK)) {
     out->beat = e->n_o_beat.data(), out->ae = e->n_o_ae.data();

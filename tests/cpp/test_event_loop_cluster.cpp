@@ -77,6 +77,9 @@ int main(int argc, char** argv) {
       loops.emplace_back(new BatchedEventLoop(*rafts[n], G));
       // JG_CLUSTER_PIPELINED=1: every loop overlaps with itself (a step's outputs are delivered at the start of the next)
       loops[n]->pipelined = std::getenv("JG_CLUSTER_PIPELINED") != nullptr;
+      // JG_CLUSTER_IN_FLIGHT=2 (with JG_CLUSTER_PIPELINED): two ticks in flight per loop (JG_NODE_KEEP) - a step's outputs
+      // are delivered at the start of the step after the next
+      if (const char* f = std::getenv("JG_CLUSTER_IN_FLIGHT")) loops[n]->in_flight = (uint32_t)std::atoi(f);
       // JG_CLUSTER_COMPACT=1: ABI v7's bus formats - the Tick's AppendEntries words as one word per partition where the
       // followers' agree, a leader's fsm_tx rows of a step as one row (the sinks below see the compact forms)
       if (std::getenv("JG_CLUSTER_COMPACT")) loops[n]->bus = JG_NODE_COMMON_AE | JG_NODE_FSM_FUSED;
@@ -257,7 +260,8 @@ int main(int argc, char** argv) {
     for (uint32_t n = 0; n < R; n++) fsm += n_fsm[n], msg += n_msg[n], cols += n_cols[n], general += n_general[n], rows += n_rows[n];
     bool ok = faults == 0;
     // (pipelined loops deliver a step's outputs at the start of the next: the round trip is two ticks longer)
-    const uint64_t lag = std::getenv("JG_CLUSTER_PIPELINED") ? 8 : 4;
+    const bool two_in_flight = std::getenv("JG_CLUSTER_PIPELINED") && std::getenv("JG_CLUSTER_IN_FLIGHT") && std::atoi(std::getenv("JG_CLUSTER_IN_FLIGHT")) >= 2;
+    const uint64_t lag = two_in_flight ? 16 : std::getenv("JG_CLUSTER_PIPELINED") ? 8 : 4;  // (two in flight: another tick each way)
     if (scripted) ok = ok && leaders == G && max_head == T && min_commit + lag >= T && general == 0;
     else ok = ok && leaders <= G;
     std::string by_node;

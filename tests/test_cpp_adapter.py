@@ -109,6 +109,13 @@ def test_event_loop_cluster_host_logic_on_oracle():
         for k in ("leaders", "faults", "proposals", "msg_rows", "column_messages", "rows_in", "rows_general", "decisions", "max_head", "leaders_by_node"):
             assert plain[k] == compact[k], (args, k, plain[k], compact[k])
         assert int(compact["fsm_rows"]) < int(plain["fsm_rows"])
+    # two ticks in flight (BatchedEventLoop::in_flight = 2 over the oracle's JG_NODE_KEEP): a step's outputs reach the
+    # channels a step later - the same protocol, the same ends
+    line = run_cluster(exe, 2000, 5, 50, "scripted", env={"JG_CLUSTER_PIPELINED": "1", "JG_CLUSTER_IN_FLIGHT": "2"})
+    assert "leaders=2000" in line and " rows_general=0 " in line and "max_head=50" in line
+    line = run_cluster(exe, 500, 3, 120, "elect", env={"JG_CLUSTER_PIPELINED": "1", "JG_CLUSTER_IN_FLIGHT": "2"})
+    assert "leaders=500" in line and "faults=0" in line
+    leadership_moved_and_stays_dense(line, 500)
     build_cluster_test(oracle=False)  # (links against the C ABI: compile check without a GPU)
 
 
@@ -143,13 +150,18 @@ def test_event_loop_cluster_equals_the_oracle_backed_loops(args):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("in_flight", [1, 2])
 @pytest.mark.parametrize("args", [(50_000, 5, 40, "scripted"), (3000, 3, 80, "elect")])
-def test_pipelined_event_loops_equal_the_oracle_backed_ones(args):
+def test_pipelined_event_loops_equal_the_oracle_backed_ones(args, in_flight):
     """BatchedEventLoop::pipelined (ONE loop that overlaps with itself: a step returns once its rows are on the device and
     classified, its outputs are delivered at the start of the next step) - the same cluster of loops, every rpc_tx / fsm_tx
     row and outbox word equal to the pipelined loops over the oracle library; and the run still does what the synchronous
-    one does (leaders elected, every partition committing)."""
-    env = {"JG_CLUSTER_PIPELINED": "1"}
+    one does (leaders elected, every partition committing).  in_flight = 2 (BatchedEventLoop::in_flight, JG_NODE_KEEP): TWO
+    ticks in flight - a step's outputs are delivered at the start of the step after the next; the elections of the `elect`
+    run put rows on the general path, exceptional rows and the late fetch of the AppendEntries rows through the kept steps."""
+    env = {"JG_CLUSTER_PIPELINED": "1", "JG_CLUSTER_IN_FLIGHT": str(in_flight)}
+    if in_flight == 2 and args[3] == "elect":
+        args = (args[0], args[1], 120, args[3])  # (every hop takes a tick longer: so do the elections)
     dev = run_cluster(build_cluster_test(oracle=False), *args, env=env)
     ora = run_cluster(build_cluster_test(oracle=True), *args, env=env)
     assert dev == ora, (dev, ora)
@@ -157,13 +169,16 @@ def test_pipelined_event_loops_equal_the_oracle_backed_ones(args):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("args,pipelined", [((50_000, 5, 40, "scripted"), False), ((3000, 3, 80, "elect"), False), ((3000, 3, 80, "elect"), True)])
+@pytest.mark.parametrize("args,pipelined", [((50_000, 5, 40, "scripted"), False), ((3000, 3, 80, "elect"), False), ((3000, 3, 80, "elect"), True),
+                                            ((3000, 3, 80, "elect"), 2), ((20_000, 5, 40, "scripted"), 2)])
 def test_compact_bus_event_loops_equal_the_oracle_backed_ones(args, pipelined):
     """ABI v7's bus formats through the loops (BatchedEventLoop::bus = JG_NODE_COMMON_AE | JG_NODE_FSM_FUSED): the Tick's
     AppendEntries words as one word per partition where the followers' agree, a leader's fsm_tx rows of a step as one row -
     every fsm row as it is, every outbox word it stands for and every rpc_tx row equal to the same loops over the oracle
     library, which restates the formats itself (oracle/oracle_engine.cpp)."""
-    env = {"JG_CLUSTER_COMPACT": "1", **({"JG_CLUSTER_PIPELINED": "1"} if pipelined else {})}
+    env = {"JG_CLUSTER_COMPACT": "1", **({"JG_CLUSTER_PIPELINED": "1"} if pipelined else {}), **({"JG_CLUSTER_IN_FLIGHT": "2"} if pipelined == 2 else {})}
+    if pipelined == 2 and args[3] == "elect":
+        args = (args[0], args[1], 120, args[3])  # (two ticks in flight: every hop takes a tick longer, so do the elections)
     dev = run_cluster(build_cluster_test(oracle=False), *args, env=env)
     ora = run_cluster(build_cluster_test(oracle=True), *args, env=env)
     assert dev == ora, (dev, ora)

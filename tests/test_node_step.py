@@ -15,7 +15,7 @@ Two links of one chain:
 import numpy as np
 import pytest
 
-from josefine_amd import BatchedRaft, capi
+from josefine_amd import BatchedRaft, EngineError, capi
 from node_step import (classify, columns_as_rows, compare_outboxes, elect_some, msgs_per_partition, node_traffic, plain_apply_equivalent,
                        rows_to_columns)
 from oracle_lib import oracle_engine
@@ -624,6 +624,69 @@ def test_node_step_async_parity(R, flags, G):
         general_ticks += b["rows_general"] > 0
     assert general_ticks > 5  # (the catch-up pass ran; steps without general rows: tests/cpp/test_event_loop_cluster.cpp, pipelined)
     assert dev.counters()["decisions"] == ora.counters()["decisions"]
+
+
+def _same_rows(a, b, what):
+    assert a.shape == b.shape and a.tobytes() == b.tobytes(), f"{what}: {len(a)} rows against {len(b)}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,flags,G,peek,bus", [(3, 0, 3000, False, False), (5, capi.CFG_SEPARATE_COMMIT_KEY, 3000, True, False),
+                                              (5, capi.CFG_SEPARATE_COMMIT_KEY, 2000, False, True), (1, 0, 200, False, False)])
+def test_node_step_two_in_flight_parity(R, flags, G, peek, bus):
+    """JG_NODE_KEEP: TWO steps in flight - tick t + 1 is begun before tick t's outbox has been viewed; the view then serves
+    the OLDER step (its columns, and exactly its fsm_tx / rpc_tx rows and faults through the drains that follow) while the
+    newer one runs.  Every outbox word and drained row of every tick equals the oracle's synchronous step of that tick,
+    general-path ticks (the row count is looked at when the next step begins), exceptional rows and faults included;
+    `peek`: the state columns are read while a step is outstanding (a read settles the newest step and consumes nothing).
+    `bus`: with ABI v7's compact formats (the common AppendEntries word's late fetch of the rows reads the step's own copy)."""
+    from josefine_amd import expand_fsm_rows
+    T = 40
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=77 + R, flags=flags, election_timeout_ms=(700, 1500))
+    own = int(ora.read("self_slot")[0])
+    kw = dict(common_ae=True, fsm_fused=True) if bus else {}
+    want = []  # per tick: the oracle's outbox and drains
+    general_ticks = fsm_rows = msg_rows = 0
+
+    def finish(t):
+        nonlocal fsm_rows, msg_rows
+        a = dev.node_outbox()
+        b, drains = want[t]
+        if bus:  # (WHICH partitions read AEC_INDIVIDUAL is a matter of representation: compare what the words stand for)
+            a = _expand_common_ae(a, own, R)
+        compare_outboxes(a, b, f"tick {t}")
+        for fn, rows in drains.items():
+            got = getattr(dev, fn)()
+            _same_rows(expand_fsm_rows(got) if bus and fn == "drain_applies" else got, rows, f"tick {t}: {fn}")
+        fsm_rows += len(drains["drain_applies"])
+        msg_rows += len(drains["drain_messages"])
+
+    for t in range(T):
+        now = 100 * (t + 1)
+        cols = node_traffic(rng, ora, token0=1000 * t, p_noise=0.03 if t % 3 else 0.0, p_reorder=0.08 if t % 3 else 0.0)
+        ora.submit_columns(**cols)
+        b = ora.step_node(now)  # (the plain formats: what the compact ones stand for)
+        want.append((b, {fn: getattr(ora, fn)() for fn in ("drain_messages", "drain_applies", "drain_faults")}))
+        general_ticks += b["rows_general"] > 0
+        dev.submit_columns(**cols)
+        dev.step_node_begin(now, async_=True, keep=True, **kw)
+        if peek and t % 4 == 1:
+            compare_snapshots(dev, ora, f"tick {t}, one step outstanding besides it")
+        if t:
+            finish(t - 1)
+        if t % 7 == 3:
+            with pytest.raises(EngineError, match="JG_NODE_KEEP"):
+                dev.step(now)  # nothing else steps the engine while kept steps are outstanding
+    finish(T - 1)
+    compare_snapshots(dev, ora, "after the last tick")
+    assert general_ticks > 5 and fsm_rows and msg_rows
+    assert dev.counters()["decisions"] == ora.counters()["decisions"]
+    # ... and the engine steps the plain way again afterwards
+    cols = node_traffic(rng, ora, token0=999_000)
+    ora.submit_columns(**cols), dev.submit_columns(**cols)
+    compare_outboxes(dev.step_node(100 * (T + 1)), ora.step_node(100 * (T + 1)), "a plain step afterwards")
+    compare_drains(dev, ora, "a plain step afterwards")
+    compare_snapshots(dev, ora, "a plain step afterwards")
 
 
 def _commit_in_place(dev, cols, extra_flags, lo=0, hi=None):
