@@ -1110,7 +1110,11 @@ def secondary_lines(args):
         "rows_on_the_general_path": x["line"]["event_loop"]["rows_on_the_general_path"],
         "pcie_bytes_per_decision": x["line"]["event_loop"]["pcie_bytes_per_decision"],
         "compact_bus_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["decisions_per_s"],
-        "compact_bus_pcie_bytes_per_decision": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["pcie_bytes_per_decision"]}
+        "compact_bus_pcie_bytes_per_decision": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["pcie_bytes_per_decision"],
+        # (round 6: two ticks in flight - JG_NODE_KEEP - on the same ONE loop)
+        "two_ticks_in_flight_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["two_ticks_in_flight"]["decisions_per_s"],
+        "two_ticks_in_flight_polled_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["two_ticks_in_flight"]["polled_decisions_per_s"],
+        "two_ticks_in_flight_column_inbound_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["two_ticks_in_flight"]["column_inbound_decisions_per_s"]}
     return out
 
 

@@ -344,7 +344,12 @@ struct jg_engine {
   struct NodeOut {
     jg_leader_beat* h_beat = nullptr;  // pinned mirrors of the outbox columns
     uint64_t *h_ae = nullptr, *h_answer = nullptr, *h_hbc = nullptr, *h_aec = nullptr;
-    uint64_t* o_ae = nullptr;          // device: the AppendEntries words by addressee (JG_NODE_COMMON_AE fetches them when a partition needs them)
+    // device outbox: a set has its own, so that a kept step's columns travel home (on a stream of their own) while the next
+    // step's kernels already write theirs
+    jg_leader_beat* o_beat = nullptr;
+    uint64_t *o_answer = nullptr, *o_hbc = nullptr;
+    uint64_t* o_aec = nullptr;         // JG_NODE_COMMON_AE: the common AppendEntries word (JgLeaderNode::o_aec), allocated at first use
+    uint64_t* o_ae = nullptr;          // the AppendEntries words by addressee (JG_NODE_COMMON_AE fetches them when a partition needs them)
     bool ae_rows_landed = false;       // JG_NODE_COMMON_AE: h_ae holds the step's rows (fetched when a partition needs them)
     uint32_t* h_nsparse = nullptr;     // pinned: the step's copy of d_nsparse
     hipEvent_t ev_out = nullptr;
@@ -356,6 +361,7 @@ struct jg_engine {
     bool out = false;                  // ... and its outbox has not been viewed yet
     int set = 0, arena = 0;            // the fault / exceptional-row queues and the arena its kernels used
     hipEvent_t ev_early = nullptr;     // behind the copy of the general-path row count (the row passes are done)
+    hipEvent_t ev_kernels = nullptr;   // behind the kernels whose output the down stream copies next
     uint32_t* h_status = nullptr;      // pinned [8]: the device status block behind the step's last kernel
     uint64_t* h_total = nullptr;       // pinned: the fsm_tx rows of the step's dense halves ...
     JgScanJob* h_job = nullptr;        // pinned: ... and the scan job that counts them
@@ -371,9 +377,6 @@ struct jg_engine {
   struct NodeStep : NodeOut {
     bool ready = false;
     JgNodeCols cols{};
-    jg_leader_beat* o_beat = nullptr;  // device outbox
-    uint64_t *o_answer = nullptr, *o_hbc = nullptr;
-    uint64_t* o_aec = nullptr;         // JG_NODE_COMMON_AE: the common AppendEntries word (JgLeaderNode::o_aec), allocated at first use
     uint64_t *h_in_answers = nullptr, *h_in_hbc = nullptr;  // pinned [R][G]: column inbound (jg_node_inbox_columns)
     uint32_t col_mask = 0, col_hbc_mask = 0;                // slots handed out for the next step / with their hb_commit column
     uint32_t* d_nsparse = nullptr;     // {general-path rows, -, partitions whose AppendEntries words differ by addressee (JG_NODE_COMMON_AE), -}
@@ -396,11 +399,14 @@ struct jg_engine {
     using Pending = NodePending;
     // JG_NODE_KEEP: the other set (the OLDER outstanding step's while two are, a free one otherwise)
     NodeOut spare;
-    bool spare_ready = false;
+    // ... and the stream a kept step's outputs travel home on (the outbox columns, the fsm rows, the status block): the step's
+    // kernels do not queue up behind the previous step's copies - a tick's kernels are 0.3 ms, its trip home 1 ms
+    hipStream_t down = nullptr;
     uint32_t kept_n = 0;               // kept steps whose outbox has not been viewed (0 .. 2)
     bool in_step = false;              // node_step is running (its halves' own node_settle calls are not another caller's)
     bool viewed_spare = false;         // the outbox viewed last is the spare set's
     size_t fsm_guess = 0;              // fsm rows of the kept step finished last: what the next one's own copy takes along
+    bool fsm_guess_known = false;
     NodeOut* fsm_visible = nullptr;    // the set whose l_fsm the next drain of the fsm queue hands over
     NodeOut& own() { return *this; }
     // multi-device parent: the shards' columns concatenated

@@ -191,6 +191,10 @@ void jg_engine_destroy(jg_engine* e) {
   if (e->node.bin_mem) (void)hipFree(e->node.bin_mem);
   if (e->node.sp_idx) (void)hipFree(e->node.sp_idx);
   if (e->node.ev_out) (void)hipEventDestroy(e->node.ev_out);
+  if (e->node.down) {
+    (void)hipStreamSynchronize(e->node.down);
+    (void)hipStreamDestroy(e->node.down);
+  }
   for (jg_engine::NodeOut* o : {&e->node.spare, &e->node.own()}) {  // (JG_NODE_KEEP)
     if (o == &e->node.spare) {
       for (void* p : {(void*)o->h_beat, (void*)o->h_ae, (void*)o->h_answer, (void*)o->h_hbc, (void*)o->h_nsparse, (void*)o->h_aec})
@@ -199,6 +203,7 @@ void jg_engine_destroy(jg_engine* e) {
     }
     if (o->h_status) (void)hipHostFree(o->h_status);
     if (o->ev_early) (void)hipEventDestroy(o->ev_early);
+    if (o->ev_kernels) (void)hipEventDestroy(o->ev_kernels);
     o->l_fsm.destroy();
   }
   if (e->node.ev_cols) (void)hipEventDestroy(e->node.ev_cols);

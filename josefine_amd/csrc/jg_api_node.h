@@ -72,7 +72,7 @@ int node_keep_ensure(jg_engine* e, jg_engine::NodeOut& o, bool mirrors) {
     std::memset(o.h_nsparse, 0, 16);
     HIPCHK(hipEventCreateWithFlags(&o.ev_out, hipEventDisableTiming));
     int rc = dev_alloc(e, &o.o_ae, R * G);
-    if (rc) return rc;
+    if (rc || (rc = dev_alloc(e, &o.o_beat, G)) || (rc = dev_alloc(e, &o.o_answer, G)) || (rc = dev_alloc(e, &o.o_hbc, G))) return rc;
     HIPCHK(hipMemsetAsync(o.o_ae, 0xff, std::max<size_t>(R * G * 8, 16), e->stream));
   }
   if (!o.h_status) {
@@ -81,7 +81,17 @@ int node_keep_ensure(jg_engine* e, jg_engine::NodeOut& o, bool mirrors) {
     std::memset(m, 0, 64);
     o.h_status = (uint32_t*)m, o.h_total = (uint64_t*)(m + 32), o.h_job = (JgScanJob*)(m + 48);
     HIPCHK(hipEventCreateWithFlags(&o.ev_early, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&o.ev_kernels, hipEventDisableTiming));
   }
+  if (!e->node.down) HIPCHK(hipStreamCreateWithFlags(&e->node.down, hipStreamNonBlocking));
+  // room up front for what a kept tick brings home and builds: pinning a 24 MB landing buffer or growing an arena by a
+  // 150 MB chunk takes milliseconds each, and the two sets and the queue they trade buffers with would pay them one after
+  // the other over the engine's first ticks (one fsm row per partition and step is the steady state's yield)
+  const size_t rows = G + G / 32 + 4096;
+  if (o.l_fsm.cap < rows) HIPCHK(o.l_fsm.reserve(rows));
+  if (e->q_fsm.cap < rows && !e->q_fsm.viewed) HIPCHK(e->q_fsm.reserve(rows));
+  const size_t build = (size_t)G * 4 + 2 * (size_t)G * JGN_FSM_ROWS * sizeof(jg_fsm_row) + ((G + JG_SCAN_TILE - 1) / JG_SCAN_TILE) * 8 + 4096;
+  for (Arena& ar : e->arenas) HIPCHK(ar.reserve(build));  // (an arena in use is left alone)
   return JG_OK;
 }
 // hands a viewed kept step's fsm rows to the queue jg_drain_applies reads (a pointer swap when the consumer has taken everything before them)
@@ -348,7 +358,7 @@ int node_step(jg_engine* e, uint64_t now_ms, uint32_t flags) {
     pend.fsm_rec_seq = rec.seq;
   }
   pend.seq_general = seq0 + 1, pend.seq_end = e->seq;
-  HIPCHK(hipEventRecord(nd.ev_out, e->stream));
+  HIPCHK(hipEventRecord(nd.ev_out, keep ? nd.down : e->stream));  // (a kept step: everything of it that travels home is on the down stream, behind its kernels)
   if (keep) nd.seq_hi = e->seq, nd.out = true, nd.kept_n++;
   if (trace)
     std::fprintf(stderr, "[jg node] %zu rows: uploads + classify + route issued in %.0f us, waited %.0f us (H2D %.1f MB), halves + fsm build + outbox copies issued in %.0f us\n",
@@ -368,6 +378,13 @@ int node_dense_halves(jg_engine* e, uint64_t now_ms, uint32_t flags, uint32_t co
   const bool tick = (flags & JG_NODE_TICK) != 0;
   const uint32_t G = e->cfg.n_groups, R = e->cfg.n_replicas;
   int rc = JG_OK;
+  // where the outbox columns travel home: a kept step's on the down stream, behind the kernels that wrote them
+  hipStream_t ds = nd.keep ? nd.down : e->stream;
+  auto behind_the_kernels = [&]() -> hipError_t {
+    if (!nd.keep) return hipSuccess;
+    hipError_t err = hipEventRecord(nd.ev_kernels, e->stream);
+    return err != hipSuccess ? err : hipStreamWaitEvent(nd.down, nd.ev_kernels, 0);
+  };
   if (halves & JG_NODE_LEADER_HALF) {
     JgLeaderNode ln{};
     ln.hbr_commit = nd.cols.hbr_commit;
@@ -390,20 +407,22 @@ int node_dense_halves(jg_engine* e, uint64_t now_ms, uint32_t flags, uint32_t co
       hipLaunchKernelGGL(k_node_count_individual, dim3(grid_for(G, 1024)), dim3(JG_BLOCK), 0, e->stream, (const uint64_t*)nd.o_aec, G, nd.d_nsparse + 2);
       HIPCHK(hipGetLastError());
       e->n_launch++;
-      HIPCHK(hipMemcpyAsync(nd.h_beat, nd.o_beat, (size_t)G * sizeof(jg_leader_beat), hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipMemcpyAsync(nd.h_aec, nd.o_aec, (size_t)G * 8, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipMemcpyAsync(nd.h_nsparse + 2, nd.d_nsparse + 2, 4, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(behind_the_kernels());
+      HIPCHK(hipMemcpyAsync(nd.h_beat, nd.o_beat, (size_t)G * sizeof(jg_leader_beat), hipMemcpyDeviceToHost, ds));
+      HIPCHK(hipMemcpyAsync(nd.h_aec, nd.o_aec, (size_t)G * 8, hipMemcpyDeviceToHost, ds));
       nd.ae_rows_landed = false;
       *bytes_down += (size_t)G * (sizeof(jg_leader_beat) + 8) + 4;
     } else if (tick) {
       nd.ae_rows_landed = true;
-      HIPCHK(hipMemcpyAsync(nd.h_beat, nd.o_beat, (size_t)G * sizeof(jg_leader_beat), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(behind_the_kernels());
+      HIPCHK(hipMemcpyAsync(nd.h_beat, nd.o_beat, (size_t)G * sizeof(jg_leader_beat), hipMemcpyDeviceToHost, ds));
       // (the own slot's row is JG_NO_ACK on both sides and stays there: not written, not downloaded)
       const uint32_t own = e->uniform_self >= 0 ? (uint32_t)e->uniform_self : R;
-      if (own > 0) HIPCHK(hipMemcpyAsync(nd.h_ae, nd.o_ae, (size_t)std::min(own, R) * G * 8, hipMemcpyDeviceToHost, e->stream));
+      if (own > 0) HIPCHK(hipMemcpyAsync(nd.h_ae, nd.o_ae, (size_t)std::min(own, R) * G * 8, hipMemcpyDeviceToHost, ds));
       if (own + 1 < R)
         HIPCHK(hipMemcpyAsync(nd.h_ae + (size_t)(own + 1) * G, nd.o_ae + (size_t)(own + 1) * G, (size_t)(R - own - 1) * G * 8, hipMemcpyDeviceToHost,
-                              e->stream));
+                              ds));
       *bytes_down += (size_t)G * (sizeof(jg_leader_beat) + (size_t)(own < R ? R - 1 : R) * 8);
     }
   }
@@ -414,8 +433,9 @@ int node_dense_halves(jg_engine* e, uint64_t now_ms, uint32_t flags, uint32_t co
     if ((rc = follower_half(e, now_ms, &fi, &fo, tick ? 1 : 0, nd.cols.fsm_delta, nd.cols.fsm_prev,
                             sparse_mode ? nd.cols.sparse_bits : nullptr, sparse_mode)))
       return rc;
-    HIPCHK(hipMemcpyAsync(nd.h_answer, nd.o_answer, (size_t)G * 8, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(nd.h_hbc, nd.o_hbc, (size_t)G * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(behind_the_kernels());
+    HIPCHK(hipMemcpyAsync(nd.h_answer, nd.o_answer, (size_t)G * 8, hipMemcpyDeviceToHost, ds));
+    HIPCHK(hipMemcpyAsync(nd.h_hbc, nd.o_hbc, (size_t)G * 8, hipMemcpyDeviceToHost, ds));
     *bytes_down += (size_t)G * 16;
   }
   return JG_OK;
@@ -507,7 +527,7 @@ int node_settle(jg_engine* e) {
   if ((rc = node_dense_halves(e, pd.now_ms, pd.flags, pd.col_mask, 2u, &bytes_down))) return rc;
   if (nd.keep) {  // the step's fsm rows once more, from the deltas the catch-up pass completed
     if ((rc = node_keep_tail(e, pd.flags))) return rc;
-    HIPCHK(hipEventRecord(nd.ev_out, e->stream));
+    HIPCHK(hipEventRecord(nd.ev_out, nd.down));
   }
   for (StepRec& rec : e->recs)
     if (!nd.keep && rec.seq == pd.fsm_rec_seq && rec.fsm_per_row == JGN_FSM_ROWS && rec.msg_per_row == 0) {
@@ -546,14 +566,18 @@ int node_keep_tail(jg_engine* e, uint32_t flags) {
                      nd.d_stage);
   HIPCHK(hipGetLastError());
   e->n_launch += 3;
-  const size_t guess = std::min(cap, nd.fsm_guess ? nd.fsm_guess + nd.fsm_guess / 8 + 4096 : (size_t)0);
+  const size_t last = nd.fsm_guess_known ? nd.fsm_guess : (size_t)G;  // (no kept step finished yet: a row per partition)
+  const size_t guess = std::min(cap, last + last / 32 + 4096);  // (3 % of room: every byte crosses the bus)
   nd.l_fsm.n = 0;
+  // (the status block is the step's own snapshot: taken on the step's stream, before a newer step's kernels touch it)
+  HIPCHK(hipMemcpyAsync(nd.h_status, e->d_status, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipEventRecord(nd.ev_kernels, e->stream));
+  HIPCHK(hipStreamWaitEvent(nd.down, nd.ev_kernels, 0));
   if (guess) {
     HIPCHK(nd.l_fsm.reserve(guess));
-    HIPCHK(hipMemcpyAsync(nd.l_fsm.p, nd.d_stage, guess * sizeof(jg_fsm_row), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(nd.l_fsm.p, nd.d_stage, guess * sizeof(jg_fsm_row), hipMemcpyDeviceToHost, nd.down));
   }
   nd.fsm_copied = guess;
-  HIPCHK(hipMemcpyAsync(nd.h_status, e->d_status, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
   return JG_OK;
 }
 
@@ -607,7 +631,7 @@ int node_keep_finish(jg_engine* e, jg_engine::NodeOut& o) {
   }
   o.l_fsm.n = total, o.fsm_landed = total != 0;
   if (e->track_segs) seg_add(e->seg_f, o.seq_hi, total);
-  nd.fsm_guess = total;
+  nd.fsm_guess = total, nd.fsm_guess_known = true;
   // everything the step allocated has been read: its arena starts over (records, if it had any, were drained above)
   e->arenas[o.arena].reset();
   o.d_fsm_cnt = nullptr, o.d_fsm = o.d_stage = nullptr, o.d_bsum = nullptr;

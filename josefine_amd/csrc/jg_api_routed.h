@@ -256,19 +256,21 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     }
   }
   bool cleared = false;  // (the transport's tallies and bucket counters: zeroed with the round's mail, or by the first attempt's own launch)
-  if (vwords) {  // this round's mail cleared where it was written two rounds ago (a workgroup per chunk of the bitmaps) - and the tallies with it
-    hipLaunchKernelGGL(k_votes_clear, dim3((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK), dim3(JG_BLOCK), 0, L->stream, vcur, rt.d_count, (uint32_t)words, bk.hist,
-                       bk_clear);
-    HIPCHK(hipGetLastError());
-    cleared = true;
-  }
-  {  // slices 0-3 in one copy - by a kernel out of the pinned staging (k_copy_words: a copy engine's start-up was the round's largest gap)
+  {  // slices 0-3 in one copy - by a kernel out of the pinned staging (a copy engine's start-up was the round's largest gap)
     if (!jobs_a.empty()) std::memcpy(slice_h(0), jobs_a.data(), jobs_a.size() * sizeof(JgApplyJob));
     if (!jobs_v.empty()) std::memcpy(slice_h(0) + jobs_a.size() * sizeof(JgApplyJob), jobs_v.data(), jobs_v.size() * sizeof(JgApplyJob));
     if (!jobs_b.empty()) std::memcpy(slice_h(1), jobs_b.data(), jobs_b.size() * sizeof(JgApplyJob));
     if (!fjobs.empty()) std::memcpy(slice_h(2), fjobs.data(), fjobs.size() * sizeof(JgFollowerJob));
     const uint32_t n8 = (uint32_t)(4 * jg_dense_cluster::Route::JOB_SLICE / 8);
-    hipLaunchKernelGGL(k_copy_words, dim3((n8 + JG_BLOCK - 1) / JG_BLOCK), dim3(JG_BLOCK), 0, st, (uint64_t*)slice_d(0), (const uint64_t*)slice_h(0), n8);
+    if (vwords) {
+      // ... the kernel that clears this round's mail where it was written two rounds ago (a workgroup per chunk of the bitmaps) -
+      // and the tallies with it (until round 6: three launches)
+      hipLaunchKernelGGL(k_votes_clear, dim3((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK), dim3(JG_BLOCK), 0, st, vcur, rt.d_count, (uint32_t)words, bk.hist,
+                         bk_clear, (uint64_t*)slice_d(0), (const uint64_t*)slice_h(0), n8);
+      cleared = true;
+    } else {
+      hipLaunchKernelGGL(k_copy_words, dim3((n8 + JG_BLOCK - 1) / JG_BLOCK), dim3(JG_BLOCK), 0, st, (uint64_t*)slice_d(0), (const uint64_t*)slice_h(0), n8);
+    }
     HIPCHK(hipGetLastError());
   }
   // -- 1. (launches) what the transport delivered last round, then this round's injected rows.  (With the vote mail the
@@ -332,8 +334,11 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   bool ordered = false;
   if (vwords) {  // the census of everything the round emitted (once: a repeated delivering pass finds it done)
     hipLaunchKernelGGL(k_votes_census_multi, dim3(std::max<uint32_t>((widest_r + JG_BLOCK - 1) / JG_BLOCK, 64u), (uint32_t)(rjobs.size() + xjobs.size())), dim3(JG_BLOCK), 0, st,
-                       (const JgRouteRecJob*)slice_d(3), (uint32_t)rjobs.size(), (const JgRouteXqJob*)(slice_d(3) + rb), vcur);
-    hipLaunchKernelGGL(k_votes_validate, dim3((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK), dim3(JG_BLOCK), 0, st, vcur, R - 1u);
+                       (const JgRouteRecJob*)slice_d(3), (uint32_t)rjobs.size(), (const JgRouteXqJob*)(slice_d(3) + rb), vcur, R - 1u);
+    // (the validation of the copies' counts - a launch of its own until round 6, k_votes_validate - rides on the census:
+    // JG_ROUTE_VALIDATE_PASS=1 runs it as well - it then finds nothing to add)
+    static const bool validate_pass = std::getenv("JG_ROUTE_VALIDATE_PASS") != nullptr;
+    if (validate_pass) hipLaunchKernelGGL(k_votes_validate, dim3((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK), dim3(JG_BLOCK), 0, st, vcur, R - 1u);
     HIPCHK(hipGetLastError());
   }
   for (int attempt = 0;; attempt++) {  // (repeated once when the staging turns out too small: the pass modifies nothing)
@@ -355,8 +360,11 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
                            (const JgRouteXqJob*)(slice_d(3) + rb), (uint32_t)xjobs.size());
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(rt.h_count, rt.d_count, words * 4, hipMemcpyDeviceToHost, st));
     ordered = false;
+    // (the counts' copy stays on the round's own stream: on a stream of its own - tried in round 6 - the event that orders it
+    // behind the delivering pass costs the round's stream as much as the copy did: 0.379-0.385 against 0.372-0.380 ms per round,
+    // profiles/r06/ab_counts_on_a_side_stream.txt)
+    HIPCHK(hipMemcpyAsync(rt.h_count, rt.d_count, words * 4, hipMemcpyDeviceToHost, st));
     if (optimistic) {
       HIPCHK(hipEventRecord(rt.ev_counts, st));
       launch_order(2 * rt.last_fullest_seg + JG_BLOCK);  // (a round's rows come in the numbers the last round's did; the kernels stride)

@@ -261,12 +261,12 @@ struct JgRouteRecJob {
   const uint32_t* fsm_cnt;
 };
 // the census of the same slots (jg_votes.h), before anything is delivered
-__device__ __forceinline__ void jg_votes_census_rec_body(const JgRouteRecJob& j, const JgVoteMail& vm) {  // (the job through the reference: a by-value copy went to scratch, 168 B per lane)
+__device__ __forceinline__ void jg_votes_census_rec_body(const JgRouteRecJob& j, const JgVoteMail& vm, uint32_t need = 0) {  // (the job through the reference: a by-value copy went to scratch, 168 B per lane)
   const uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x;
   if (i >= j.n) return;
   const uint32_t cnt = j.msg_cnt[i];
   const jg_msg_row* mine = j.msg + (size_t)i * j.per_row;
-  for (uint32_t k = 0; k < cnt; k++) jg_votes_census_row(vm, j.t.src, j.t.member_id[j.t.src], mine[k], j.step, k, jg_route_dests(mine[k], j.t));
+  for (uint32_t k = 0; k < cnt; k++) jg_votes_census_row(vm, j.t.src, j.t.member_id[j.t.src], mine[k], j.step, k, jg_route_dests(mine[k], j.t), need);
 }
 // second pass, only for a step that keeps rows for the host: the delivered rows leave their slots
 __global__ __launch_bounds__(JG_BLOCK) void k_route_rec_compact(JgRouteTable t, uint32_t n, uint32_t per_row,
@@ -357,20 +357,21 @@ struct JgRouteXqJob {  // the delivering pass over every sender's exceptional-ro
   uint32_t phases, pad;  // the sender's steps of the round as phases (jg_route_phase)
 };
 // the census of the same queues (jg_votes.h), before anything is delivered
-__device__ __forceinline__ void jg_votes_census_xq_body(const JgRouteXqJob& j, const JgVoteMail& vm) {
+__device__ __forceinline__ void jg_votes_census_xq_body(const JgRouteXqJob& j, const JgVoteMail& vm, uint32_t need = 0) {
   const uint32_t n = min(*j.xq_n, j.xq_cap);
   for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < n; i += gridDim.x * JG_BLOCK) {
     const JgXqRec q = j.xq[i];
     if (q.seq - j.seq_base - 1u >= 7u) continue;  // (not this round's mail)
-    jg_votes_census_row(vm, j.t.src, j.t.member_id[j.t.src], q.row, jg_route_phase(j.phases, q.seq - j.seq_base), q.k, jg_route_dests(q.row, j.t));
+    jg_votes_census_row(vm, j.t.src, j.t.member_id[j.t.src], q.row, jg_route_phase(j.phases, q.seq - j.seq_base), q.k, jg_route_dests(q.row, j.t), need);
   }
 }
 // ONE launch for the census of everything the round emitted: blockIdx.y < n_rec - a sparse step's slots (gridDim.x covers the
 // widest), the rest - the senders' exceptional queues (their workgroups stride).  (Two launches until round 6: 17 + 7 us.)
+// `need` = R - 1: the validation of the copies' counts rides along (jg_votes_census_row); 0: it is a pass of its own
 __global__ __launch_bounds__(JG_BLOCK) void k_votes_census_multi(const JgRouteRecJob* __restrict__ rjobs, uint32_t n_rec, const JgRouteXqJob* __restrict__ xjobs,
-                                                                 JgVoteMail vm) {
-  if (blockIdx.y < n_rec) jg_votes_census_rec_body(rjobs[blockIdx.y], vm);
-  else jg_votes_census_xq_body(xjobs[blockIdx.y - n_rec], vm);
+                                                                 JgVoteMail vm, uint32_t need = 0) {
+  if (blockIdx.y < n_rec) jg_votes_census_rec_body(rjobs[blockIdx.y], vm, need);
+  else jg_votes_census_xq_body(xjobs[blockIdx.y - n_rec], vm, need);
 }
 #if JG_BLOCK % 64 == 0
 // the answer words whose addressee's partition takes rows after all: staged as the rows they stand for (blockIdx.y = the

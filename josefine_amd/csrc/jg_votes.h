@@ -73,15 +73,20 @@ __device__ __forceinline__ bool jg_vote_row_is_request_copy(const jg_msg_row& r,
 }
 // the transport's census, once per emitted row of the round (sender slot `src`, the row's step of the round and its
 // emission index; `dests`: the members it is addressed to, jg_route_dests) - BEFORE anything is delivered
+// (`need` = R - 1 in the engine: a copy beyond a campaign's makes the partition's mail travel as rows for everybody HERE - what
+// k_votes_validate did in a launch of its own until round 6; a sender's copies are all broadcasts, so the copies beyond the
+// need-th name exactly the addressees the validation names.  FEWER copies than a campaign's cannot come without a row that
+// sets the same bits - a copy whose emission index does not fit the word is a row - and the receiving half says so loudly
+// if they ever do.  need = 0: no check here - the host tests validate in a pass of their own, jg_votes_validate_group.)
 __device__ __forceinline__ void jg_votes_census_row(const JgVoteMail& m, uint32_t src, uint32_t sender_id, const jg_msg_row& r, uint32_t step, uint32_t k,
-                                           uint32_t dests) {
+                                           uint32_t dests, uint32_t need = 0) {
   if (!dests) return;
   const uint32_t g = r.group;
   const uint64_t bit = 1ull << (g & 63u);
   if (jg_vote_row_is_request_copy(r, sender_id, k)) {
     const size_t i = jg_vote_at(m, src, g);
     const uint32_t old = atomicAdd(&m.rec[i].q_ctl, 1u | ((step & 7u) << 8 | k) << 8);
-    if ((old & 0xffu) >= 0x80u)  // (no campaign has that many copies, and the 8-bit count must not come round to R - 1 again: rows for everybody)
+    if ((old & 0xffu) >= 0x80u || (need && (old & 0xffu) >= need))  // (no campaign has that many copies, and the 8-bit count must not come round to R - 1 again: rows for everybody)
       for (uint32_t b = dests; b; b &= b - 1) atomicOr((unsigned long long*)&m.rowmail[(size_t)(__ffs(b) - 1) * m.words + (g >> 6)], (unsigned long long)bit);
     if ((old & 0xffu) == 0) {  // (every copy says the same; a second campaign's would not - and is not a word: the count)
       m.rec[i].q_term = r.term, m.rec[i].q_head = r.id;
@@ -214,6 +219,7 @@ __device__ inline uint32_t jg_vote_half_group(const JgDev& d, uint32_t g, uint32
       at_lo[(2u * s) * stride] = hi.x, at_lo[(2u * s + 1u) * stride] = hi.y;
       if ((qc & 0xffu) && q1_s == ~0u) q1_s = s, q1[0] = lo.x, q1[stride] = lo.y, q1[2u * stride] = lo.z, q1[3u * stride] = lo.w;
       const uint32_t q_n = qc & 0xffu, a_n = (ac & 0xffu) && ((ac >> 21) & 7u) == self ? (ac & 0xffu) : 0u;
+      if (q_n && !jg_vote_q_ok(qc, need)) *d.err = 1;  // (copies that are not a campaign's and no row bit: the census's rule - see jg_votes_census_row - does not hold)
       if (q_n) {  // (the copies' ords are consecutive - candidate.rs:24-44 is one loop - and q_ctl holds their sum)
         const uint32_t q_ord = ((qc >> 8) - q_n * (q_n - 1u) / 2u) / q_n;
         wq = (q_ord & 0xfffu) | q_n << 12;
@@ -406,9 +412,12 @@ __global__ __launch_bounds__(JG_BLOCK) void k_votes_validate(JgVoteMail m, uint3
 // per round: 0.6 MB against 40 MB at 1 M x 5); then the bitmaps themselves (the thread that brought a word clears it: the
 // lanes work from the copy in LDS).
 // (`a`, `b`: two more word ranges that go back to zero with the round's mail - the transport's tallies and its bucket
-// counters, k_route_clear's job: one launch less per round)
-__global__ __launch_bounds__(JG_BLOCK) void k_votes_clear(JgVoteMail m, uint32_t* __restrict__ a, uint32_t na, uint32_t* __restrict__ b, uint32_t nb) {
+// counters, k_route_clear's job: one launch less per round; `cp_*`: the round's job tables on their way from the host's pinned
+// staging to the device, k_copy_words' job: another one)
+__global__ __launch_bounds__(JG_BLOCK) void k_votes_clear(JgVoteMail m, uint32_t* __restrict__ a, uint32_t na, uint32_t* __restrict__ b, uint32_t nb,
+                                                          uint64_t* __restrict__ cp_dst = nullptr, const uint64_t* __restrict__ cp_src = nullptr, uint32_t cp_n = 0) {
   __shared__ JgBitChunk s;
+  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < cp_n; i += gridDim.x * JG_BLOCK) cp_dst[i] = cp_src[i];
   for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < na + nb; i += gridDim.x * JG_BLOCK) {
     if (i < na) a[i] = 0;
     else b[i - na] = 0;

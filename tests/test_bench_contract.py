@@ -230,6 +230,9 @@ def test_event_loop_line():
     assert cb["decisions_per_s"] > 0 and cb["rows_on_the_general_path"] == 0 and cb["fsm_rows_per_tick"] == 20000 == cb["fsm_rows_per_tick_plain"] / 2
     assert cb["pcie_bytes_per_decision"] <= 32 < cb["pcie_bytes_per_decision_plain"], cb
     assert cb["column_inbound_pcie_bytes_per_decision"] < cb["pcie_bytes_per_decision"]
+    two = cb["two_ticks_in_flight"]  # JG_NODE_KEEP (ABI v9): the same stream (the binary checks its closed form), the same bytes, two ticks in flight
+    assert two["decisions_per_s"] > 0 and two["polled_decisions_per_s"] > 0 and two["column_inbound_decisions_per_s"] > 0 and two["plain_bus_decisions_per_s"] > 0
+    assert two["rows_on_the_general_path"] == 0 and abs(two["pcie_bytes_per_decision"] - cb["pcie_bytes_per_decision"]) < 1.0, two
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["avg_launch_us"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] == "port"
