@@ -63,6 +63,7 @@ if [ "$part" = all ] || [ "$part" = stats ]; then
   stats routed_stationary_rows $B --cluster --failures 1 --steps 50 --warmup 10 --no-cpu-baseline --vote-words 0
   stats routed_no_repairs_words $B --cluster --failures 1 --steps 50 --warmup 10 --no-cpu-baseline --vote-words 1 --repair-after 0
   stats event_loop_1M_compact josefine_amd/host/bench_event_loop 1000000 5 20 5 pipetasks 0 1 4 compact
+  JG_BENCH_IN_FLIGHT=2 stats event_loop_1M_compact_two_in_flight josefine_amd/host/bench_event_loop 1000000 5 20 5 pipetasks 0 1 4 compact
   stats failures_1pct $B --failures 1 --steps 160 --warmup 64 --no-cpu-baseline
   head -4 $O/kernel_stats_1M.csv | cut -c1-160
 fi

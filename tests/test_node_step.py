@@ -689,6 +689,52 @@ def test_node_step_two_in_flight_parity(R, flags, G, peek, bus):
     compare_snapshots(dev, ora, "a plain step afterwards")
 
 
+@pytest.mark.gpu
+def test_node_step_keep_rules():
+    """JG_NODE_KEEP's rules at the boundary: it goes with JG_NODE_ASYNC; at most two kept steps are outstanding; nothing else
+    steps the engine meanwhile (a plain node step, jg_step, a drain prefetch); the drains deliver nothing that is not due; a
+    view without an outstanding step shows the last one again; reads go through."""
+    G, R = 300, 3
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=5, election_timeout_ms=(700, 1500))
+    with pytest.raises(EngineError, match="JG_NODE_ASYNC"):
+        dev.step_node_begin(100, keep=True)
+    outs = []
+    for t in range(2):
+        cols = node_traffic(rng, ora, token0=1000 * t)
+        ora.submit_columns(**cols), dev.submit_columns(**cols)
+        outs.append((ora.step_node(100 * (t + 1)), {fn: getattr(ora, fn)() for fn in ("drain_messages", "drain_applies", "drain_faults")}))
+        dev.step_node_begin(100 * (t + 1), async_=True, keep=True)
+        assert len(dev.drain_applies()) == 0 and len(dev.drain_messages()) == 0  # (nothing is due before its outbox has been viewed)
+    with pytest.raises(EngineError, match="outstanding"):
+        dev.step_node_begin(300, async_=True, keep=True)  # a third
+    with pytest.raises(EngineError, match="outstanding"):
+        dev.step_node_begin(300, async_=True)  # a step that would not keep its outputs
+    with pytest.raises(EngineError, match="JG_NODE_KEEP"):
+        dev.step(300)
+    with pytest.raises(EngineError, match="JG_NODE_KEEP"):
+        dev.drain_prefetch()
+    compare_snapshots(dev, ora, "two steps outstanding: a read sees the engine after the newest")
+    for t in range(2):
+        a = dev.node_outbox()
+        compare_outboxes(a, outs[t][0], f"view {t}")
+        again = dev.node_outbox() if t == 1 else None  # (nothing outstanding any more: the same outbox again)
+        if again is not None:
+            compare_outboxes(again, outs[t][0], "the last view again")
+        for fn, rows in outs[t][1].items():
+            _same_rows(getattr(dev, fn)(), rows, f"view {t}: {fn}")
+    # the views' rows handed over by VIEW drains as well (the queue's buffers change hands with the sets' landing buffers)
+    for t in range(2, 8):
+        cols = node_traffic(rng, ora, token0=1000 * t)
+        ora.submit_columns(**cols), dev.submit_columns(**cols)
+        want = (ora.step_node(100 * (t + 1)), ora.drain_applies())
+        ora.drain_messages(), ora.drain_faults()
+        dev.step_node_begin(100 * (t + 1), async_=True, keep=True)
+        compare_outboxes(dev.node_outbox(), want[0], f"tick {t}")
+        _same_rows(dev.drain_applies(), want[1], f"tick {t}: fsm rows")  # (the view form: josefine_amd.engine drains through jg_drain_applies_view)
+        dev.drain_messages(), dev.drain_faults()
+    compare_snapshots(dev, ora, "the end")
+
+
 def _commit_in_place(dev, cols, extra_flags, lo=0, hi=None):
     """rows [lo, hi) of `cols` written straight into the engine's pinned columns (jg_submit_reserve / jg_submit_commit)"""
     import ctypes as C
