@@ -642,7 +642,9 @@ def test_node_step_two_in_flight_parity(R, flags, G, peek, bus):
     `bus`: with ABI v7's compact formats (the common AppendEntries word's late fetch of the rows reads the step's own copy)."""
     from josefine_amd import expand_fsm_rows
     T = 40
-    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=77 + R, flags=flags, election_timeout_ms=(700, 1500))
+    import os
+    seed = 77 + R + int(os.environ.get("JG_SOAK_SEED", "0"))  # (profiles/micro/r06_two_in_flight_soak.sh: other seeds, on the device)
+    dev, ora, rng = mixed_pair(BatchedRaft, oracle_engine, G, R, seed=seed, flags=flags, election_timeout_ms=(700, 1500))
     own = int(ora.read("self_slot")[0])
     kw = dict(common_ae=True, fsm_fused=True) if bus else {}
     want = []  # per tick: the oracle's outbox and drains
