@@ -68,7 +68,49 @@ int main(int argc, char** argv) {
     std::vector<std::unique_ptr<BatchedEventLoop>> loops;
     std::vector<Fnv> hash(R);
     std::vector<uint64_t> n_fsm(R, 0), n_msg(R, 0), n_cols(R, 0), n_general(R, 0), n_rows(R, 0);
-    std::vector<RowQueue> wire(R);  // what the transport delivers to node n before its next step
+    // What the transport delivers to node n before its next step: every sender's stream in its own order - all a network promises
+    // (tcp.rs: one connection per peer pair) - the senders INTERLEAVED per partition: what every sender said first about a
+    // partition arrives before anybody's second row about it, the device transport's order (jg_route.h).  (Sender after sender,
+    // as until round 6, is a legal schedule too - under which an election of more than three nodes is never won: a candidate
+    // broadcasts its VoteRequest once per peer, candidate.rs:30-37, a voter grants the first copy and refuses the rest, and the
+    // later answer of a voter overwrites the earlier, election.rs:33-35.)
+    struct Wire {
+      std::vector<std::vector<jg_msg_row>> from;  // [sender]: its rows for this node, in the order it emitted them (AppendEntries: id = the run's start, aux = its length)
+      std::vector<uint32_t> nth;                  // scratch: rows seen per partition
+      void push(uint32_t src, uint32_t g, uint8_t kind, NodeId from_id, Term term, uint64_t id, uint64_t aux = 0, uint8_t flag = 0) {
+        jg_msg_row r{};
+        r.group = g, r.kind = kind, r.from = from_id, r.term = term, r.id = id, r.aux = aux, r.flag = flag;
+        from[src].push_back(r);
+      }
+      bool empty() const {
+        for (const auto& v : from)
+          if (!v.empty()) return false;
+        return true;
+      }
+      void clear() {
+        for (auto& v : from) v.clear();
+      }
+      void deliver(RowQueue& q, uint32_t G) {  // (emission index within the partition, sender): a stable order
+        struct Key {
+          uint32_t k, src, at;
+        };
+        std::vector<Key> order;
+        nth.assign(G, 0);
+        for (uint32_t s = 0; s < from.size(); s++) {
+          for (uint32_t i = 0; i < from[s].size(); i++) order.push_back({nth[from[s][i].group]++, s, i});
+          for (const jg_msg_row& r : from[s]) nth[r.group] = 0;
+        }
+        std::stable_sort(order.begin(), order.end(), [](const Key& a, const Key& b) { return a.k != b.k ? a.k < b.k : a.src < b.src; });
+        for (const Key& o : order) {
+          const jg_msg_row& r = from[o.src][o.at];
+          if (r.kind == JG_CMD_APPEND_ENTRIES) q.push_append_run(r.group, r.from, r.term, r.id, (uint32_t)r.aux);
+          else q.push(r.group, r.kind, r.from, r.term, r.id, r.aux, r.flag);
+        }
+      }
+    };
+    std::vector<Wire> wire(R);
+    for (Wire& w : wire) w.from.resize(R);
+    RowQueue wire_rows;
     std::vector<std::vector<NodeId>> answers_to(R, std::vector<NodeId>(G, 0));
     for (uint32_t n = 0; n < R; n++) {
       rafts.emplace_back(new BatchedRaft(G, ids, 0, 1000 + n, JG_CFG_SEPARATE_COMMIT_KEY));
@@ -99,8 +141,7 @@ int main(int argc, char** argv) {
           for (uint32_t dst = 0; dst < R; dst++) {
             if (dst == n) continue;
             if (!(r.to_kind == JG_TO_PEERS || (r.to_kind == JG_TO_PEER && r.to_id == ids[dst]))) continue;
-            if (r.kind == JG_CMD_APPEND_ENTRIES) wire[dst].push_append_run(r.group, r.from, r.term, r.id, (uint32_t)r.aux);
-            else wire[dst].push(r.group, r.kind, r.from, r.term, r.id, r.aux, r.flag);
+            wire[dst].push(n, r.group, r.kind, r.from, r.term, r.id, r.aux, r.flag);
             if (r.kind == JG_CMD_HEARTBEAT || r.kind == JG_CMD_APPEND_ENTRIES) answers_to[dst][r.group] = r.from;
           }
         }
@@ -125,8 +166,8 @@ int main(int argc, char** argv) {
             for (uint32_t q = 0; q < R; q++) {
               if (q == n) continue;
               const uint64_t w = ae_word(q, g);
-              if (hb) wire[q].push(g, JG_CMD_HEARTBEAT, ids[n], o.beat[g].term, o.beat[g].hb_commit), n_cols[n]++;
-              if (w != JG_NO_ACK) wire[q].push_append_run(g, ids[n], o.beat[g].term, w >> 8, (uint32_t)(w & 0xffu)), n_cols[n]++;
+              if (hb) wire[q].push(n, g, JG_CMD_HEARTBEAT, ids[n], o.beat[g].term, o.beat[g].hb_commit), n_cols[n]++;
+              if (w != JG_NO_ACK) wire[q].push(n, g, JG_CMD_APPEND_ENTRIES, ids[n], o.beat[g].term, w >> 8, w & 0xffu), n_cols[n]++;
               if (hb || w != JG_NO_ACK) answers_to[q][g] = ids[n];
             }
           }
@@ -140,9 +181,9 @@ int main(int argc, char** argv) {
             if (to == 0 || to > R) continue;
             if ((w & 0xffu) != JG_HB_NONE) {
               hash[n].u64(o.hb_commit[g]);
-              wire[to - 1].push(g, JG_CMD_HEARTBEAT_RESPONSE, ids[n], 0, o.hb_commit[g], 0, (uint8_t)(w & 0xffu)), n_cols[n]++;
+              wire[to - 1].push(n, g, JG_CMD_HEARTBEAT_RESPONSE, ids[n], 0, o.hb_commit[g], 0, (uint8_t)(w & 0xffu)), n_cols[n]++;
             }
-            if ((w >> 8) != JG_MAILBOX_NONE) wire[to - 1].push(g, JG_CMD_APPEND_RESPONSE, ids[n], 0, w >> 8, 0, 1), n_cols[n]++;
+            if ((w >> 8) != JG_MAILBOX_NONE) wire[to - 1].push(n, g, JG_CMD_APPEND_RESPONSE, ids[n], 0, w >> 8, 0, 1), n_cols[n]++;
           }
         }
       };
@@ -197,7 +238,11 @@ int main(int argc, char** argv) {
       now += BatchedEventLoop::TICK_MS;
       for (uint32_t n = 0; n < R; n++) {
         BatchedEventLoop& loop = *loops[n];
-        if (!wire[n].empty()) loop.tcp_rx_rows(wire[n].view());
+        if (!wire[n].empty()) {
+          wire_rows.clear();
+          wire[n].deliver(wire_rows, G);
+          loop.tcp_rx_rows(wire_rows.view());
+        }
         wire[n].clear();
         // client_rx: one request per partition this node leads
         if (scripted) {
