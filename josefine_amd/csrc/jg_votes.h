@@ -325,10 +325,12 @@ struct JgVoteHalfJobs {
 // PARTITION nearly every wave of the receiving half held one or two lanes with mail and waited for their dozen dependent
 // jg_apply calls with the other sixty idle (733 us per round on the MI355X, the chip latency-bound at 3 % lane
 // utilisation); with a lane per bitmap WORD the few waves there are walk their words' bits one after the other.  So: a
-// workgroup takes a CHUNK of the bitmap (JG_VOTE_CHUNK words = 2048 partitions; thread k < JG_VOTE_CHUNK brings word k),
+// workgroup takes a CHUNK of the bitmap (JG_VOTE_CHUNK words = 4096 partitions; thread k < JG_VOTE_CHUNK brings word k),
 // the words and their prefix popcounts go to LDS, and lane i takes the i-th set bit - whole waves at work, the rest of
 // the workgroup idle.
-#define JG_VOTE_CHUNK 32u
+#ifndef JG_VOTE_CHUNK
+#define JG_VOTE_CHUNK 64u  // (32 until round 6: the receiving half 52.9 -> 45.8 us per round; 16: 0.41 ms per round instead of 0.36; 128: as 64 - profiles/r06/ab_vote_chunk.txt)
+#endif
 static_assert(JG_BLOCK >= JG_VOTE_CHUNK, "a thread per word of the chunk");
 struct JgBitChunk {
   uint64_t w[JG_VOTE_CHUNK];
