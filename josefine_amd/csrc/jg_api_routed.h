@@ -277,19 +277,33 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   // delivered ROWS are other partitions' than the words', so their step could run BESIDE the receiving half on a stream of its
   // own: tried in round 6 and removed - the two cross-queue dependencies cost 12-14 us more than the 34 us they hide,
   // profiles/r06/ab_side_stream_sort_buckets.txt.)
-  if ((rc = apply_all(0, jobs_a, widest_a, L->stream))) return rc;
-  if (!jobs_v.empty()) {  // (different nodes than jobs_a's: the two launches are independent of each other)
-    hipLaunchKernelGGL(small_tiles(widest_v) ? k_apply_vote_runs_multi_small : k_apply_vote_runs_multi,
-                       dim3(run_grid(widest_v), (uint32_t)jobs_v.size()), dim3(JG_BLOCK), 0, L->stream,
-                       (const JgApplyJob*)slice_d(0) + jobs_a.size());
-    HIPCHK(hipGetLastError());
-  }
-  if (vwords) {  // (partitions other than the rows': a partition's mail of a round is words or rows, never both)
+  uint32_t vote_grid = 1;
+  if (vwords) {
     uint32_t slots = L->count_slots;
     for (jg_engine* e : c->nodes) slots = std::min(slots, e->count_slots);
     const uint32_t n_chunks = (vprev.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK;  // (a workgroup per chunk of the bitmap; its counter slot is blockIdx.x)
-    hipLaunchKernelGGL(k_vote_half_multi, dim3(std::max(1u, std::min(n_chunks, slots)), R), dim3(JG_BLOCK), 0, L->stream, vjobs, vprev, vcur);
+    vote_grid = std::max(1u, std::min(n_chunks, slots));
+  }
+  // (JG_ROUTE_SPLIT_HEAD=1: the receiving half and the delivered rows' step as launches of their own, one behind the other, as
+  // until the end of round 6 - the A/B)
+  static const bool split_head = std::getenv("JG_ROUTE_SPLIT_HEAD") != nullptr;
+  if (vwords && !split_head && !jobs_a.empty() && jobs_v.empty() && small_tiles(widest_a)) {
+    // the vote mail's receiving half and the delivered rows' step side by side in ONE launch (k_round_head_multi)
+    hipLaunchKernelGGL(k_round_head_multi, dim3(std::max(vote_grid, run_grid(widest_a)), R + (uint32_t)jobs_a.size()), dim3(JG_BLOCK), 0, L->stream, vjobs, R, vprev,
+                       vcur, (const JgApplyJob*)slice_d(0));
     HIPCHK(hipGetLastError());
+  } else {
+    if ((rc = apply_all(0, jobs_a, widest_a, L->stream))) return rc;
+    if (!jobs_v.empty()) {  // (different nodes than jobs_a's: the two launches are independent of each other)
+      hipLaunchKernelGGL(small_tiles(widest_v) ? k_apply_vote_runs_multi_small : k_apply_vote_runs_multi,
+                         dim3(run_grid(widest_v), (uint32_t)jobs_v.size()), dim3(JG_BLOCK), 0, L->stream,
+                         (const JgApplyJob*)slice_d(0) + jobs_a.size());
+      HIPCHK(hipGetLastError());
+    }
+    if (vwords) {  // (partitions other than the rows': a partition's mail of a round is words or rows, never both)
+      hipLaunchKernelGGL(k_vote_half_multi, dim3(vote_grid, R), dim3(JG_BLOCK), 0, L->stream, vjobs, vprev, vcur);
+      HIPCHK(hipGetLastError());
+    }
   }
   if ((rc = apply_all(1, jobs_b, widest_b, L->stream))) return rc;
   // -- 2. the dense round; ClientRequests only where the lead node (still) leads

@@ -364,8 +364,8 @@ __device__ __forceinline__ uint32_t jg_chunk_pick(const JgBitChunk& s, uint32_t 
 // (two of them run), a CANDIDATE the R - 1 answers of each of R - 1 voters - and a wave takes as long as its slowest
 // lane: the lanes that read answers go first (a second compaction in LDS), so that they share waves with each other.
 // (HBM: the bitmaps - G / 4 bytes per node - and, per partition with mail, the senders' control words and its columns.)
-__global__ __launch_bounds__(JG_BLOCK) void k_vote_half_multi(JgVoteHalfJobs jobs, JgVoteMail in, JgVoteMail out) {
-  const JgVoteHalfJob& j = jobs.j[blockIdx.y];
+__device__ __forceinline__ void jg_vote_half_body(const JgVoteHalfJobs& jobs, uint32_t node, const JgVoteMail& in, const JgVoteMail& out) {
+  const JgVoteHalfJob& j = jobs.j[node];
   __shared__ JgBitChunk s;
   __shared__ uint32_t s_g[JG_BLOCK];
   __shared__ uint32_t s_st[JG_VOTE_ST_WORDS][JG_BLOCK];  // the lanes' stretch cursors (jg_vote_half_group): 16 KB
@@ -394,6 +394,23 @@ __global__ __launch_bounds__(JG_BLOCK) void k_vote_half_multi(JgVoteHalfJobs job
     }
   }
   if (dec) (void)__hip_atomic_fetch_add(&j.d.blk_decisions[blockIdx.x], (uint64_t)dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(JG_BLOCK) void k_vote_half_multi(JgVoteHalfJobs jobs, JgVoteMail in, JgVoteMail out) { jg_vote_half_body(jobs, blockIdx.y, in, out); }
+// THE HEAD OF A ROUTED ROUND IN ONE LAUNCH: the receiving half on every node (blockIdx.y < n_vote) and, beside it, the step
+// that applies what the last round delivered as ROWS (the other values of blockIdx.y: a job each, jg_apply_runs_body's small
+// tiles) - other partitions than the words' (a partition's mail of a round is words or rows, never both), both under the
+// delivered step's number, both appending to queues that are unordered by design.  Each of them alone leaves most of the
+// chip idle - a few hundred workgroups of dependent loads, one wave per SIMD at work - and one behind the other they were
+// 46 + 34 us of a round; side by side on two streams (tried earlier in round 6) the two cross-queue dependencies cost more than
+// the overlap gained.  The receiving half's workgroups come first in dispatch order: they are the long ones.
+__global__ __launch_bounds__(JG_BLOCK) JG_GSM_OCC void k_round_head_multi(JgVoteHalfJobs vjobs, uint32_t n_vote, JgVoteMail in, JgVoteMail out,
+                                                                        const JgApplyJob* __restrict__ jobs) {
+  if (blockIdx.y < n_vote) {
+    jg_vote_half_body(vjobs, blockIdx.y, in, out);
+  } else {
+    const JgApplyJob& j = jobs[blockIdx.y - n_vote];
+    jg_apply_runs_body<JG_KINDS_ALL, JG_RUN_TILE_SMALL>(j.d, j.a);
+  }
 }
 // the validation (jg_votes_validate_group) of the partitions a wordmail bit names (any addressee's)
 __global__ __launch_bounds__(JG_BLOCK) void k_votes_validate(JgVoteMail m, uint32_t need) {

@@ -24,6 +24,7 @@ BUDGET = {
     "void k_leader_node_tick_any<5>": (80, 6),
     "k_cluster_claim": (32, 8),
     "k_vote_half_multi": (128, 4),                   # the vote mail's receiving half: no scratch (its jobs are kernel arguments)
+    "k_round_head_multi": (168, 3),                  # ... beside the delivered rows' step, one launch: the general state machine's registers, no scratch
     "k_votes_census_multi": (40, 8),                 # the census of a round's emissions, one launch
     "k_route_deliver_multi_words": (80, 3),          # the delivering pass, one launch (its LDS staging bounds the waves: 49 KB)
     "k_node_classify": (40, 7),                      # jg_step_node's row passes
