@@ -256,6 +256,7 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     }
   }
   bool cleared = false;  // (the transport's tallies and bucket counters: zeroed with the round's mail, or by the first attempt's own launch)
+  static const bool clear_early = std::getenv("JG_ROUTE_CLEAR_AT_HEAD") == nullptr;
   {  // slices 0-3 in one copy - by a kernel out of the pinned staging (a copy engine's start-up was the round's largest gap)
     if (!jobs_a.empty()) std::memcpy(slice_h(0), jobs_a.data(), jobs_a.size() * sizeof(JgApplyJob));
     if (!jobs_v.empty()) std::memcpy(slice_h(0) + jobs_a.size() * sizeof(JgApplyJob), jobs_v.data(), jobs_v.size() * sizeof(JgApplyJob));
@@ -265,8 +266,12 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
     if (vwords) {
       // ... the kernel that clears this round's mail where it was written two rounds ago (a workgroup per chunk of the bitmaps) -
       // and the tallies with it (until round 6: three launches)
-      hipLaunchKernelGGL(k_votes_clear, dim3((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK), dim3(JG_BLOCK), 0, st, vcur, rt.d_count, (uint32_t)words, bk.hist,
-                         bk_clear, (uint64_t*)slice_d(0), (const uint64_t*)slice_h(0), n8);
+      // (the mail itself - this round's to fill - was cleared beside the injected rows' step of the round before, where the
+      // receiving half had just read it: clear_early below; JG_ROUTE_CLEAR_AT_HEAD=1: here, as until the end of round 6)
+      JgVoteMail m = vcur;
+      if (clear_early) m.words = 0;
+      hipLaunchKernelGGL(k_votes_clear, dim3(clear_early ? 32u : (vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK), dim3(JG_BLOCK), 0, st, m, rt.d_count, (uint32_t)words,
+                         bk.hist, bk_clear, (uint64_t*)slice_d(0), (const uint64_t*)slice_h(0), n8);
       cleared = true;
     } else {
       hipLaunchKernelGGL(k_copy_words, dim3((n8 + JG_BLOCK - 1) / JG_BLOCK), dim3(JG_BLOCK), 0, st, (uint64_t*)slice_d(0), (const uint64_t*)slice_h(0), n8);
@@ -305,7 +310,16 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
       HIPCHK(hipGetLastError());
     }
   }
-  if ((rc = apply_all(1, jobs_b, widest_b, L->stream))) return rc;
+  if (vwords && clear_early) {
+    // the injected rows' step with the clearing of the mail the receiving half has just read beside it (the next round's to fill)
+    const uint32_t n_chunks = (vprev.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK;
+    const uint32_t gx = jobs_b.empty() ? n_chunks : std::max<uint32_t>(grid_for(widest_b, L->count_slots), std::min<uint32_t>(n_chunks, 64u));
+    hipLaunchKernelGGL(k_apply_rows_clear_multi, dim3(std::min<uint32_t>(gx, L->count_slots), (uint32_t)jobs_b.size() + 1u), dim3(JG_BLOCK), 0, L->stream,
+                       (const JgApplyJob*)slice_d(1), (uint32_t)jobs_b.size(), vprev);
+    HIPCHK(hipGetLastError());
+  } else if ((rc = apply_all(1, jobs_b, widest_b, L->stream))) {
+    return rc;
+  }
   // -- 2. the dense round; ClientRequests only where the lead node (still) leads
   if (c->any) {  // (whoever owns a group reads `offered`: nothing to mask)
     if ((rc = cluster_launch_any(c))) return rc;

@@ -402,13 +402,16 @@ __global__ __launch_bounds__(JG_BLOCK) void k_vote_half_multi(JgVoteHalfJobs job
 // delivered step's number, both appending to queues that are unordered by design.  Each of them alone leaves most of the
 // chip idle - a few hundred workgroups of dependent loads, one wave per SIMD at work - and one behind the other they were
 // 46 + 34 us of a round; side by side on two streams (tried earlier in round 6) the two cross-queue dependencies cost more than
-// the overlap gained.  The receiving half's workgroups come first in dispatch order: they are the long ones.
+// the overlap gained.
 __global__ __launch_bounds__(JG_BLOCK) JG_GSM_OCC void k_round_head_multi(JgVoteHalfJobs vjobs, uint32_t n_vote, JgVoteMail in, JgVoteMail out,
                                                                         const JgApplyJob* __restrict__ jobs) {
-  if (blockIdx.y < n_vote) {
-    jg_vote_half_body(vjobs, blockIdx.y, in, out);
+  // (dispatch order: blockIdx.y ascending.  The rows' workgroups go FIRST - there are few of them and each is long, a tile of
+  // runs walked lane by lane; the receiving half's many workgroups fill the chip around them)
+  const uint32_t n_rows = gridDim.y - n_vote;
+  if (blockIdx.y >= n_rows) {
+    jg_vote_half_body(vjobs, blockIdx.y - n_rows, in, out);
   } else {
-    const JgApplyJob& j = jobs[blockIdx.y - n_vote];
+    const JgApplyJob& j = jobs[blockIdx.y];
     jg_apply_runs_body<JG_KINDS_ALL, JG_RUN_TILE_SMALL>(j.d, j.a);
   }
 }
@@ -433,14 +436,8 @@ __global__ __launch_bounds__(JG_BLOCK) void k_votes_validate(JgVoteMail m, uint3
 // (`a`, `b`: two more word ranges that go back to zero with the round's mail - the transport's tallies and its bucket
 // counters, k_route_clear's job: one launch less per round; `cp_*`: the round's job tables on their way from the host's pinned
 // staging to the device, k_copy_words' job: another one)
-__global__ __launch_bounds__(JG_BLOCK) void k_votes_clear(JgVoteMail m, uint32_t* __restrict__ a, uint32_t na, uint32_t* __restrict__ b, uint32_t nb,
-                                                          uint64_t* __restrict__ cp_dst = nullptr, const uint64_t* __restrict__ cp_src = nullptr, uint32_t cp_n = 0) {
+__device__ __forceinline__ void jg_votes_clear_mail(const JgVoteMail& m) {
   __shared__ JgBitChunk s;
-  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < cp_n; i += gridDim.x * JG_BLOCK) cp_dst[i] = cp_src[i];
-  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < na + nb; i += gridDim.x * JG_BLOCK) {
-    if (i < na) a[i] = 0;
-    else b[i - na] = 0;
-  }
   const uint32_t n_chunks = (m.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK;
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const uint32_t w = c * JG_VOTE_CHUNK + threadIdx.x;
@@ -455,6 +452,28 @@ __global__ __launch_bounds__(JG_BLOCK) void k_votes_clear(JgVoteMail m, uint32_t
       const uint32_t g = c * JG_VOTE_CHUNK * 64u + jg_chunk_pick(s, i);
       for (uint32_t q = 0; q < m.R; q++) *(uint64_t*)&m.rec[jg_vote_at(m, q, g)].q_ctl = 0;  // (q_ctl | a_ctl: one 8-byte store)
     }
+  }
+}
+// (m.words = 0: no mail to clear - the round's mail was cleared beside the injected rows' step of the round before, k_apply_rows_clear_multi)
+__global__ __launch_bounds__(JG_BLOCK) void k_votes_clear(JgVoteMail m, uint32_t* __restrict__ a, uint32_t na, uint32_t* __restrict__ b, uint32_t nb,
+                                                          uint64_t* __restrict__ cp_dst = nullptr, const uint64_t* __restrict__ cp_src = nullptr, uint32_t cp_n = 0) {
+  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < cp_n; i += gridDim.x * JG_BLOCK) cp_dst[i] = cp_src[i];
+  for (uint32_t i = blockIdx.x * JG_BLOCK + threadIdx.x; i < na + nb; i += gridDim.x * JG_BLOCK) {
+    if (i < na) a[i] = 0;
+    else b[i - na] = 0;
+  }
+  jg_votes_clear_mail(m);
+}
+// The injected rows' step of a routed round (blockIdx.y < n_jobs: a node's batch each, jg_apply_rows_body) and, beside it, the
+// clearing of the mail the round's receiving half has just read - the NEXT round's to fill (the last value of blockIdx.y): the
+// step is a hundred workgroups of dependent loads, the clearing ten microseconds of a launch of its own at the head of every
+// round until the end of round 6.
+__global__ __launch_bounds__(JG_BLOCK) JG_GSM_OCC void k_apply_rows_clear_multi(const JgApplyJob* __restrict__ jobs, uint32_t n_jobs, JgVoteMail m) {
+  if (blockIdx.y < n_jobs) {
+    const JgApplyJob& j = jobs[blockIdx.y];
+    jg_apply_rows_body(j.d, j.a);
+  } else {
+    jg_votes_clear_mail(m);
   }
 }
 #endif
