@@ -361,6 +361,14 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   };
   bool ordered = false;
   if (vwords) {  // the census of everything the round emitted (once: a repeated delivering pass finds it done)
+    static const bool census_split = std::getenv("JG_CENSUS_SPLIT") != nullptr;  // (a measurement: the sparse steps' slots and the queues as launches of their own)
+    if (census_split) {
+      if (!rjobs.empty())
+        hipLaunchKernelGGL(k_votes_census_multi, dim3(std::max<uint32_t>((widest_r + JG_BLOCK - 1) / JG_BLOCK, 64u), (uint32_t)rjobs.size()), dim3(JG_BLOCK), 0, st,
+                           (const JgRouteRecJob*)slice_d(3), (uint32_t)rjobs.size(), (const JgRouteXqJob*)(slice_d(3) + rb), vcur, R - 1u);
+      hipLaunchKernelGGL(k_votes_census_multi, dim3(64u, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteRecJob*)slice_d(3), 0u,
+                         (const JgRouteXqJob*)(slice_d(3) + rb), vcur, R - 1u);
+    } else
     hipLaunchKernelGGL(k_votes_census_multi, dim3(std::max<uint32_t>((widest_r + JG_BLOCK - 1) / JG_BLOCK, 64u), (uint32_t)(rjobs.size() + xjobs.size())), dim3(JG_BLOCK), 0, st,
                        (const JgRouteRecJob*)slice_d(3), (uint32_t)rjobs.size(), (const JgRouteXqJob*)(slice_d(3) + rb), vcur, R - 1u);
     // (the validation of the copies' counts - a launch of its own until round 6, k_votes_validate - rides on the census:
