@@ -361,20 +361,10 @@ static int round_routed_impl(jg_dense_cluster* c, uint64_t now_ms, const jg_cmd_
   };
   bool ordered = false;
   if (vwords) {  // the census of everything the round emitted (once: a repeated delivering pass finds it done)
-    static const bool census_split = std::getenv("JG_CENSUS_SPLIT") != nullptr;  // (a measurement: the sparse steps' slots and the queues as launches of their own)
-    if (census_split) {
-      if (!rjobs.empty())
-        hipLaunchKernelGGL(k_votes_census_multi, dim3(std::max<uint32_t>((widest_r + JG_BLOCK - 1) / JG_BLOCK, 64u), (uint32_t)rjobs.size()), dim3(JG_BLOCK), 0, st,
-                           (const JgRouteRecJob*)slice_d(3), (uint32_t)rjobs.size(), (const JgRouteXqJob*)(slice_d(3) + rb), vcur, R - 1u);
-      hipLaunchKernelGGL(k_votes_census_multi, dim3(64u, (uint32_t)xjobs.size()), dim3(JG_BLOCK), 0, st, (const JgRouteRecJob*)slice_d(3), 0u,
-                         (const JgRouteXqJob*)(slice_d(3) + rb), vcur, R - 1u);
-    } else
     hipLaunchKernelGGL(k_votes_census_multi, dim3(std::max<uint32_t>((widest_r + JG_BLOCK - 1) / JG_BLOCK, 64u), (uint32_t)(rjobs.size() + xjobs.size())), dim3(JG_BLOCK), 0, st,
                        (const JgRouteRecJob*)slice_d(3), (uint32_t)rjobs.size(), (const JgRouteXqJob*)(slice_d(3) + rb), vcur, R - 1u);
     // (the validation of the copies' counts - a launch of its own until round 6, k_votes_validate - rides on the census:
-    // JG_ROUTE_VALIDATE_PASS=1 runs it as well - it then finds nothing to add)
-    static const bool validate_pass = std::getenv("JG_ROUTE_VALIDATE_PASS") != nullptr;
-    if (validate_pass) hipLaunchKernelGGL(k_votes_validate, dim3((vcur.words + JG_VOTE_CHUNK - 1) / JG_VOTE_CHUNK), dim3(JG_BLOCK), 0, st, vcur, R - 1u);
+    // profiles/r06/routed_round_15_launches_ab.txt)
     HIPCHK(hipGetLastError());
   }
   for (int attempt = 0;; attempt++) {  // (repeated once when the staging turns out too small: the pass modifies nothing)
