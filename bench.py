@@ -1179,8 +1179,9 @@ def main():
     ap.add_argument("--vote-words", type=int, choices=[0, 1], default=None,
                     help="--cluster with --failures: JG_CLUSTER_OPT_VOTE_WORDS - an election's traffic as mailbox words (csrc/jg_votes.h) instead of "
                          "rows.  Default: 1 for configs[4] as specified (single lead: campaigns that are refused recur at every election timeout - "
-                         "0.39 against 0.47 ms per round), 0 with --any-leader (R = 3, whole groups restart: every campaign is WON at once, the "
-                         "traffic is the winners' Heartbeats - rows - and the word passes buy nothing: 0.32 against 0.27 ms)")
+                         "0.39 against 0.47 ms per round), 0 with --any-leader at R = 3 (whole groups restart: every campaign is WON at once, the "
+                         "traffic is the winners' Heartbeats - rows - and the word passes buy nothing: 0.25 against 0.24 ms), 1 with --any-leader "
+                         "at R >= 5 (a campaign's 4 x 4 copies and their answers are most of a round's rows there: 0.378 against 0.415 ms)")
     ap.add_argument("--drain-applies", type=int, choices=[0, 1], default=1,
                     help="--cluster --failures: hand the rounds' FSM rows (the Apply ranges of repaired followers) to the host every round")
     ap.add_argument("--synthetic-votes", type=int, choices=[0, 1], default=0,
@@ -1225,7 +1226,7 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.vote_words is None:
-        args.vote_words = 0 if args.any_leader else 1
+        args.vote_words = (1 if args.replicas >= 5 else 0) if args.any_leader else 1
     if args.config == 3:
         args.groups, args.replicas = 1_250_000, 3
     elif args.config == 4:
