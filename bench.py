@@ -794,7 +794,7 @@ def event_loop_main(args):
         queues unless told otherwise (GPU_MAX_HW_QUEUES), and streams that share one run one behind the other."""
         return os.environ.get("GPU_MAX_HW_QUEUES") or (str(2 * loops) if loops > 2 else None)
 
-    def run(mode, k, w, loops=1, polled=False, compact=False, in_flight=1):
+    def run(mode, k, w, loops=1, polled=False, compact=False, in_flight=1, helpers=None):
         env = dict(os.environ)
         env["JG_BENCH_IN_FLIGHT"] = str(in_flight)
         if env.get("JG_BENCH_POLLING_DEFAULTED"):  # (several loop threads waiting side by side: the runtime's default, interrupts)
@@ -803,7 +803,7 @@ def event_loop_main(args):
             env["HSA_ENABLE_INTERRUPT"] = "0"
         if hw_queues(loops):
             env["GPU_MAX_HW_QUEUES"] = hw_queues(loops)
-        r = subprocess.run([exe, str(G), str(R), str(k), str(w), mode, "0", str(loops)] + ([str(R - 1), "compact"] if compact else []),
+        r = subprocess.run([exe, str(G), str(R), str(k), str(w), mode, "0", str(loops)] + ([str(helpers if helpers is not None else R - 1), "compact"] if compact else []),
                            capture_output=True, text=True, timeout=1200, env=env)
         if r.returncode != 0:
             raise SystemExit(f"bench_event_loop {mode} x {loops} failed: {r.stdout} {r.stderr}")
@@ -828,6 +828,8 @@ def event_loop_main(args):
     ptck2 = run("pipetaskscolumns", K, W, compact=True, in_flight=2)
     pt2 = run("pipetasks", K, W, in_flight=2)
     ptk2_polled = run("pipetasks", K, W, compact=True, in_flight=2, polled=True)
+    ptk2_8 = run("pipetasks", K, W, compact=True, in_flight=2, helpers=8)  # (the reference's runtime has a worker per core: eight task threads beside the loop's instead of R - 1)
+    ptk1_8 = run("pipetasks", K, W, compact=True, in_flight=1, helpers=8)
     # ... and with the peers' traffic as the reference's BYTES (length-delimited serde_json frames, tcp.rs:139-170) through
     # host/formats.hpp's decoder in the connection tasks: a few ticks (the senders' encoding of every tick comes first)
     ptw = run("pipetaskswire", max(2, min(K, 4)), 2)
@@ -921,6 +923,11 @@ def event_loop_main(args):
                         "pcie_bytes_per_decision": (ptk2["pcie_h2d_bytes_per_tick"] + ptk2["pcie_d2h_bytes_per_tick"]) * ptk2["ticks"] / ptk2["decisions"],
                         "pcie_GB_per_s_both_ways": (ptk2["pcie_h2d_bytes_per_tick"] + ptk2["pcie_d2h_bytes_per_tick"]) / (ptk2["ms_per_tick"] * 1e-3) / 1e9,
                         "polled_decisions_per_s": ptk2_polled["decisions_per_s"],
+                        "with_eight_task_threads": {"what": "the same loop with 8 task threads beside it instead of R - 1 = 4 (the transport's decoding and the sinks are "
+                                                            "what bounds it): two ticks in flight / one",
+                                                    "decisions_per_s": ptk2_8["decisions_per_s"], "ms_per_tick": ptk2_8["ms_per_tick"],
+                                                    "one_in_flight_decisions_per_s": ptk1_8["decisions_per_s"],
+                                                    "pcie_GB_per_s_both_ways": (ptk2_8["pcie_h2d_bytes_per_tick"] + ptk2_8["pcie_d2h_bytes_per_tick"]) / (ptk2_8["ms_per_tick"] * 1e-3) / 1e9},
                         "column_inbound_decisions_per_s": ptck2["decisions_per_s"], "column_inbound_ms_per_tick": ptck2["ms_per_tick"],
                         "plain_bus_decisions_per_s": pt2["decisions_per_s"], "plain_bus_ms_per_tick": pt2["ms_per_tick"],
                         "rows_on_the_general_path": ptk2["rows_general"] + ptck2["rows_general"] + pt2["rows_general"]}},
@@ -1114,7 +1121,8 @@ def secondary_lines(args):
         # (round 6: two ticks in flight - JG_NODE_KEEP - on the same ONE loop)
         "two_ticks_in_flight_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["two_ticks_in_flight"]["decisions_per_s"],
         "two_ticks_in_flight_polled_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["two_ticks_in_flight"]["polled_decisions_per_s"],
-        "two_ticks_in_flight_column_inbound_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["two_ticks_in_flight"]["column_inbound_decisions_per_s"]}
+        "two_ticks_in_flight_column_inbound_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["two_ticks_in_flight"]["column_inbound_decisions_per_s"],
+        "two_ticks_in_flight_eight_task_threads_decisions_per_s": x["line"]["event_loop"]["one_loop_with_transport_and_consumer_tasks"]["compact_bus"]["two_ticks_in_flight"]["with_eight_task_threads"]["decisions_per_s"]}
     return out
 
 

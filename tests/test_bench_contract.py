@@ -233,6 +233,7 @@ def test_event_loop_line():
     two = cb["two_ticks_in_flight"]  # JG_NODE_KEEP (ABI v9): the same stream (the binary checks its closed form), the same bytes, two ticks in flight
     assert two["decisions_per_s"] > 0 and two["polled_decisions_per_s"] > 0 and two["column_inbound_decisions_per_s"] > 0 and two["plain_bus_decisions_per_s"] > 0
     assert two["rows_on_the_general_path"] == 0 and abs(two["pcie_bytes_per_decision"] - cb["pcie_bytes_per_decision"]) < 1.0, two
+    assert two["with_eight_task_threads"]["decisions_per_s"] > 0 and two["with_eight_task_threads"]["one_in_flight_decisions_per_s"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["avg_launch_us"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] == "port"
